@@ -1,0 +1,245 @@
+"""CPU tests of the oracle itself: NumPy float64 (hand-derived gradients) vs torch-CPU float64
+autograd, known-answer tests, finite differences.  No GPU, no product code."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_ops as R
+from oracle import ref_torch as T
+
+torch.set_default_dtype(torch.float64)
+
+
+def t64(a, grad=False):
+    t = torch.tensor(np.asarray(a), dtype=torch.float64)
+    return t.requires_grad_(True) if grad else t
+
+
+@pytest.mark.parametrize("k,ci,co,h", [(3, 5, 4, 6), (1, 3, 7, 4), (3, 3, 2, 5), (4, 2, 3, 6)])
+def test_conv_numpy_vs_torch_and_loops(k, ci, co, h):
+    rng = np.random.default_rng(k * 100 + ci)
+    x = rng.normal(size=(2, h, h, ci))
+    w = rng.normal(size=(k, k, ci, co))
+    b = rng.normal(size=co)
+    dy = rng.normal(size=(2, h, h, co))
+    y = R.conv2d_same(x, w, b)
+    np.testing.assert_allclose(y, R.conv2d_direct_loops(x, w, b), atol=1e-12)
+    xt, wt, bt = t64(x, True), t64(w, True), t64(b, True)
+    yt = T.conv2d_same(xt, wt, bt)
+    np.testing.assert_allclose(y, yt.detach().numpy(), atol=1e-11)
+    yt.backward(t64(dy))
+    dx, dw, db = R.conv2d_same_grads(x, w, dy)
+    np.testing.assert_allclose(dx, xt.grad.numpy(), atol=1e-11)
+    np.testing.assert_allclose(dw, wt.grad.numpy(), atol=1e-11)
+    np.testing.assert_allclose(db, bt.grad.numpy(), atol=1e-11)
+
+
+def test_conv_delta_kernel_is_identity():
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(1, 5, 5, 3))
+    w = np.zeros((3, 3, 3, 3))
+    for c in range(3):
+        w[1, 1, c, c] = 1.
+    np.testing.assert_allclose(R.conv2d_same(x, w), x, atol=0)
+
+
+def test_conv_stride2_same_vs_torch():
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=(2, 8, 8, 3))
+    w = rng.normal(size=(4, 4, 3, 5))
+    y = R.conv2d_same(x, w, None, stride=2)
+    # TF SAME for k=4,s=2 on 8: pad 1 before, 1 after
+    xt = torch.nn.functional.pad(t64(x).permute(0, 3, 1, 2), (1, 1, 1, 1))
+    yt = torch.nn.functional.conv2d(xt, t64(w).permute(3, 2, 0, 1), stride=2).permute(0, 2, 3, 1)
+    np.testing.assert_allclose(y, yt.numpy(), atol=1e-11)
+
+
+@pytest.mark.parametrize("k", [3, 4, 5])
+def test_deconv_vs_torch_conv_transpose(k):
+    """Deconv2D (deconv2d.py:99-109): conv2d_transpose stride 2 SAME = autograd dgrad of the stride-2 conv."""
+    rng = np.random.default_rng(k)
+    x = rng.normal(size=(2, 4, 4, 3))            # [N,H,W,Cin]
+    f = rng.normal(size=(k, k, 5, 3))            # [k,k,Cout,Cin]
+    b = rng.normal(size=5)
+    y = R.deconv2d_same(x, f, b)
+    assert y.shape == (2, 8, 8, 5)
+    # independent: gradient of conv2d_same(stride 2) wrt its input, with upstream = x
+    inp = t64(np.zeros((2, 8, 8, 5)), True)
+    out = T_conv_stride(inp, t64(f), 2)
+    out.backward(t64(x))
+    np.testing.assert_allclose(y - b, inp.grad.numpy(), atol=1e-11)
+    # grads of the deconv itself by autograd through the same construction
+    dy = rng.normal(size=y.shape)
+    dx, df, db = R.deconv2d_same_grads(x, f, dy)
+    xt, ft = t64(x, True), t64(f, True)
+    inp = t64(np.zeros((2, 8, 8, 5)), True)
+    out = T_conv_stride(inp, ft, 2)
+    (yt,) = torch.autograd.grad(out, inp, xt, create_graph=True)
+    yt.backward(t64(dy))
+    np.testing.assert_allclose(dx, xt.grad.numpy(), atol=1e-11)
+    np.testing.assert_allclose(df, ft.grad.numpy(), atol=1e-11)
+    np.testing.assert_allclose(db, dy.sum(axis=(0, 1, 2)), atol=1e-11)
+
+
+def T_conv_stride(x, w, stride):
+    k = w.shape[0]
+    h = x.shape[1]
+    _, pt, pb = R.same_pads(h, k, stride)
+    xn = torch.nn.functional.pad(x.permute(0, 3, 1, 2), (pt, pb, pt, pb))
+    return torch.nn.functional.conv2d(xn, w.permute(3, 2, 0, 1), stride=stride).permute(0, 2, 3, 1)
+
+
+def test_upsample_is_depth_to_space_of_concat_and_pool_inverts_it():
+    rng = np.random.default_rng(2)
+    x = rng.normal(size=(2, 3, 4, 5))
+    up = R.upsample_nn2x(x)
+    for i in range(2):
+        for j in range(2):
+            np.testing.assert_array_equal(up[:, i::2, j::2, :], x)
+    np.testing.assert_allclose(R.meanpool2x2(up), x, atol=1e-15)
+    np.testing.assert_array_equal(up, T.upsample_nn2x(t64(x)).numpy())
+    dy = rng.normal(size=up.shape)
+    np.testing.assert_allclose(R.upsample_nn2x_grad(dy), 4 * R.meanpool2x2(dy), atol=1e-14)
+    np.testing.assert_allclose(R.meanpool2x2_grad(x), R.upsample_nn2x(x) / 4, atol=0)
+
+
+def test_1x1_conv_commutes_with_pool_and_upsample():
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(2, 4, 4, 6))
+    w = rng.normal(size=(1, 1, 6, 3))
+    b = rng.normal(size=3)
+    np.testing.assert_allclose(R.meanpool2x2(R.conv2d_same(x, w, b)), R.conv2d_same(R.meanpool2x2(x), w, b), atol=1e-12)
+    np.testing.assert_allclose(R.upsample_nn2x(R.conv2d_same(x, w, b)), R.conv2d_same(R.upsample_nn2x(x), w, b), atol=1e-12)
+
+
+@pytest.mark.parametrize("K,C", [(27, 8), (12, 1), (3, 16), (40, 40)])
+def test_sn_forward_backward_vs_autograd(K, C):
+    rng = np.random.default_rng(K + C)
+    W = rng.normal(size=(K, C))
+    u = T.trunc_normal(rng, (1, C)).astype(np.float64)
+    G = rng.normal(size=(K, C))
+    Wb, u1, sigma, v = R.sn_forward(W, u)
+    Wt = t64(W, True)
+    Wbt, u1t, sigt = T.spectral_normed_weight(Wt, t64(u))
+    np.testing.assert_allclose(Wb, Wbt.detach().numpy(), rtol=1e-12)
+    np.testing.assert_allclose(u1, u1t.detach().numpy(), rtol=1e-12)
+    np.testing.assert_allclose(sigma, float(sigt.detach()), rtol=1e-12)
+    Wbt.backward(t64(G))
+    dW = R.sn_backward(W, u, G)
+    np.testing.assert_allclose(dW, Wt.grad.numpy(), rtol=1e-9, atol=1e-12)
+    # the stop-gradient (Chainer-style) variant is a DIFFERENT gradient when u is not converged
+    dW_sg = G / sigma - (np.sum(G * W) / sigma ** 2) * np.outer(v.ravel(), u1.ravel())
+    if C > 1:
+        assert np.abs(dW_sg - dW).max() > 1e-4
+
+
+def test_sn_rank1_sigma_exact_and_converged_top_singular_value_is_one():
+    rng = np.random.default_rng(5)
+    p, q = rng.normal(size=(7, 1)), rng.normal(size=(1, 4))
+    W = p @ q
+    _, _, sigma, _ = R.sn_forward(W, rng.normal(size=(1, 4)))
+    np.testing.assert_allclose(sigma, np.linalg.norm(p) * np.linalg.norm(q), rtol=1e-12)
+    W = rng.normal(size=(9, 5))
+    u = rng.normal(size=(1, 5))
+    for _ in range(500):
+        _, u, sigma, _ = R.sn_forward(W, u)
+    Wb, _, _, _ = R.sn_forward(W, u)
+    np.testing.assert_allclose(np.linalg.svd(Wb, compute_uv=False)[0], 1., rtol=1e-9)
+
+
+def test_sn_conv_filter_reshape_is_rows_of_kh_kw_cin():
+    rng = np.random.default_rng(6)
+    W = rng.normal(size=(3, 3, 2, 4))
+    u = rng.normal(size=(1, 4))
+    Wb, _, sigma, _ = R.sn_forward(W, u)
+    Wb2, _, sigma2, _ = R.sn_forward(W.reshape(18, 4), u)
+    np.testing.assert_allclose(Wb.reshape(18, 4), Wb2)
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+def test_cbn_forward_backward_vs_autograd(groups):
+    rng = np.random.default_rng(7)
+    x = rng.normal(size=(4, 3, 3, 5)) * 2 + 1
+    labels = np.array([1, 0, 1, 2])
+    gamma = rng.normal(size=(3, 5))
+    beta = rng.normal(size=(3, 5))
+    dy = rng.normal(size=x.shape)
+    y, cache = R.cond_batchnorm_forward(x, labels, gamma, beta, groups)
+    xt, gt, bt = t64(x, True), t64(gamma, True), t64(beta, True)
+    yt = T.cond_batchnorm(xt, torch.tensor(labels), gt, bt, groups)
+    np.testing.assert_allclose(y, yt.detach().numpy(), atol=1e-12)
+    yt.backward(t64(dy))
+    dx, dg, db = R.cond_batchnorm_backward(dy, labels, gamma, cache, groups)
+    np.testing.assert_allclose(dx, xt.grad.numpy(), atol=1e-10)
+    np.testing.assert_allclose(dg, gt.grad.numpy(), atol=1e-10)
+    np.testing.assert_allclose(db, bt.grad.numpy(), atol=1e-10)
+
+
+def test_cbn_unit_gamma_gives_zero_mean_unit_var():
+    rng = np.random.default_rng(8)
+    x = rng.normal(size=(8, 4, 4, 3)) * 3 + 2
+    y, _ = R.cond_batchnorm_forward(x, np.zeros(8, int), np.ones((1, 3)), np.zeros((1, 3)))
+    np.testing.assert_allclose(y.mean(axis=(0, 1, 2)), 0, atol=1e-12)
+    np.testing.assert_allclose(y.var(axis=(0, 1, 2)), 1, atol=1e-4)   # eps=1e-5 bias
+
+
+def test_hinge_known_answers_and_grads():
+    loss, d = R.hinge_d_loss(np.array([1., 1., -1., -1.]), 2)
+    assert loss == 0. and not d.any()
+    loss, d = R.hinge_d_loss(np.array([0., 2., 0., -3.]), 2)
+    np.testing.assert_allclose(loss, 0.5 + 0.5)
+    np.testing.assert_allclose(d, [-0.5, 0, 0.5, 0])
+    loss, d = R.hinge_g_loss(np.array([1., 3.]))
+    np.testing.assert_allclose(loss, -2.)
+    np.testing.assert_allclose(d, [-0.5, -0.5])
+    lg = np.random.default_rng(9).normal(size=(5, 10))
+    lb = np.array([0, 3, 9, 3, 1])
+    loss, d = R.softmax_xent(lg, lb)
+    lt = t64(lg, True)
+    l2 = torch.nn.functional.cross_entropy(lt, torch.tensor(lb))
+    l2.backward()
+    np.testing.assert_allclose(loss, float(l2), rtol=1e-12)
+    np.testing.assert_allclose(d, lt.grad.numpy(), atol=1e-12)
+
+
+def test_adam_tf_first_step_known_answer():
+    """beta1=0: first step = lr*sqrt(0.1)*g/(sqrt(0.1 g^2)+eps)  (SURVEY 8c)."""
+    g = np.array([0.5, -2., 1e-3])
+    p, m, v = R.adam_tf_step(np.zeros(3), g, np.zeros(3), np.zeros(3), 1, 2e-4)
+    np.testing.assert_allclose(p, -2e-4 * np.sqrt(0.1) * g / (np.sqrt(0.1 * g * g) + 1e-8), rtol=1e-12)
+    assert R.lr_decay(0) == 1. and R.lr_decay(25000) == 0.75 and R.lr_decay(50000) == 0.5
+
+
+def test_param_counts_and_names():
+    P = T.init_sngan_params(0)
+    g = sum(v.size for k, v in P.items() if k.startswith('Generator/'))
+    d = sum(v.size for k, v in P.items() if k.startswith('Discriminator/') and not T.is_state(k))
+    assert g == 7875587 and d == 1701689
+    assert sum(1 for k in P if T.is_state(k)) == 12
+    assert 'Discriminator/D.Block.1.Conv1/filters/spectral_norm/u' in P
+    assert 'Generator/G.Block.1.N1/CondBatchNorm/scale' in P
+    assert 'Discriminator/Embedding.Label/embedding_map' in P
+
+
+def test_network_shapes_and_finite_difference_of_d_loss():
+    P = T.to_torch(T.init_sngan_params(1))
+    rng = np.random.default_rng(1)
+    z = t64(rng.normal(size=(4, 128)))
+    labels = torch.tensor([1, 5, 0, 9])
+    img = T.generator(P, z, labels, groups=2)
+    assert img.shape == (4, 3072) and float(img.abs().max()) <= 1.
+    real = torch.tensor(rng.integers(0, 256, (4, 3072)))
+    deq = t64(rng.uniform(0, 1 / 128, (4, 3072)))
+    loss, new_u, logits = T.d_loss_fn(P, real, labels, z, deq)
+    assert logits.shape == (8,) and len(new_u) == 12
+    name = 'Discriminator/D.Block.3.Conv1/Filters'
+    (g,) = torch.autograd.grad(loss, P[name])
+    idx = (1, 1, 3, 5)
+    eps = 1e-5
+    with torch.no_grad():
+        P[name][idx] += eps
+        lp = float(T.d_loss_fn(P, real, labels, z, deq)[0])
+        P[name][idx] -= 2 * eps
+        lm = float(T.d_loss_fn(P, real, labels, z, deq)[0])
+        P[name][idx] += eps
+    np.testing.assert_allclose((lp - lm) / (2 * eps), float(g[idx]), rtol=1e-4, atol=1e-9)
