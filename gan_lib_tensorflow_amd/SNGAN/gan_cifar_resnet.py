@@ -1,0 +1,293 @@
+"""SNGAN-ResNet CIFAR-10 -- drop-in for the model and train-step part of SNGAN/gan_cifar_resnet.py.
+
+`Generator(n_samples, labels, noise=None, reuse=False)` and
+`Discriminator(inputs, labels, update_collection=None, reuse=False)` keep the reference signatures
+(:237, :266) and variable names; `SNGANTrainer` is the loop body (:599-620) with the graph the script
+builds at import time (:317-526): 1 generator update on 2x64 fakes + N_CRITIC=5 critic updates on
+64 real + 64 fake, hinge loss, TF-Adam(beta1=0, beta2=0.9), LR decay.
+
+MI355X-first structure
+  * the reference's "two towers on one GPU" hack (:73-75) becomes a `groups` argument: one launch over
+    the whole batch, conditional-batch-norm statistics per tower -- identical arithmetic;
+  * the 12 spectral norms of the critic run as one batched launch group per critic forward;
+  * all trainable variables of a network live in one flat fp32 buffer: one memset zeroes the
+    gradients, one kernel applies Adam, one RCCL all-reduce exchanges gradients under data parallel;
+  * each update (G step, D step) is captured once into a hipGraph and replayed: ~250 kernel launches
+    per update cost one graph launch.  The RNG is counter-based with device-side state, so replays
+    draw fresh noise / labels / dequantisation.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import functional as Fn
+from .. import kernels as K
+from ..common import resnet_block as blocks
+from ..common.ops import embedding as _embedding
+from ..common.ops import linear as _linear
+from ..common.ops import conv2d as _conv2d
+from ..common.ops import sn as _sn
+from ..common.ops.sn import NO_OPS
+from ..store import ParamStore, get_default_store, set_default_store
+
+BATCH_SIZE = 64  # Critic batch size                                      (:38)
+GEN_BS_MULTIPLE = 2  # Generator batch size, as a multiple of BATCH_SIZE  (:39)
+ITERS = 100000
+DIM_G = 128
+DIM_D = 128
+NORMALIZATION_G = True
+NORMALIZATION_D = False
+OUTPUT_DIM = 3072
+LR = 0.0002
+DECAY = True
+N_CRITIC = 5
+CONDITIONAL = True
+ACGAN = False
+VOCAB_SIZE = 10
+EMBEDDING_DIM = 300
+LOSS_TYPE = 'HINGE'
+N_TOWERS = 2  # len(DEVICES) after the single-GPU hack (:73-75)
+
+nonlinearity = blocks.nonlinearity
+Normalize = blocks.Normalize
+ConvMeanPool = blocks.ConvMeanPool
+MeanPoolConv = blocks.MeanPoolConv
+UpsampleConv = blocks.UpsampleConv
+ResidualBlock = blocks.ResidualBlock
+OptimizedResBlockDisc1 = blocks.OptimizedResBlockDisc1
+
+
+def Generator(n_samples_, labels, noise=None, reuse=False, groups=1, rng_state=None):
+    """(:237-263)  noise [n,128] bf16 (drawn from the device RNG when None) -> [n, 3072] bf16, HWC order,
+    tanh range.  `groups` towers of n/groups samples have independent CBN statistics."""
+    store = get_default_store()
+    with store.variable_scope("Generator", reuse=reuse):
+        if noise is None:
+            if rng_state is None:
+                raise ValueError('Generator needs `noise` or an `rng_state` (kernels.new_rng_state)')
+            noise = K.rng_normal((n_samples_, 128), rng_state)                 # tf.random_normal (:240)
+        output = _linear.Linear(noise, 128, 4 * 4 * DIM_G * 8, 'G.Input')
+        output = output.reshape(-1, 4, 4, DIM_G * 8)
+        output = ResidualBlock(output, DIM_G * 8, DIM_G * 2, 3, 'G.Block.1', resample='up', labels=labels, biases=True, groups=groups)
+        output = ResidualBlock(output, DIM_G * 2, DIM_G * 2, 3, 'G.Block.2', resample='up', labels=labels, biases=True, groups=groups)
+        output = ResidualBlock(output, DIM_G * 2, DIM_G * 2, 3, 'G.Block.3', resample='up', labels=labels, biases=True, groups=groups)
+        output = Normalize('G.OutputNorm', output, labels, groups=groups, relu=True)    # + nonlinearity (:257-258)
+        output = _conv2d.Conv2D(output, DIM_G * 2, 3, 3, 1, 'G.Output', he_init=False, out_tanh=True)  # + tanh (:260-261)
+        return output.reshape(-1, OUTPUT_DIM)
+
+
+def Discriminator(inputs, labels, update_collection=None, reuse=False):
+    """(:266-313, ACGAN=False)  inputs [n,3072] bf16 (HWC order) -> (logits [n], None)."""
+    store = get_default_store()
+    with store.variable_scope("Discriminator", reuse=reuse):
+        prefix = store.full_name('')[:-1]
+        with _sn.precomputed(store, prefix, update_collection):       # one batched SN for all 12 weights
+            output = inputs.reshape(-1, 32, 32, 3)
+            output = OptimizedResBlockDisc1(output, spectral_normed=True, update_collection=update_collection, biases=True)
+            embedding_y = _embedding.embed_y(labels, VOCAB_SIZE, EMBEDDING_DIM)
+            embedding_y = _linear.Linear(embedding_y, EMBEDDING_DIM, DIM_D, 'D.Embedding_y', spectral_normed=True,
+                                         update_collection=update_collection, biases=True)
+            output = Fn.concat_tile(output, embedding_y)               # expand_dims x2 + tile + concat (:282-284)
+            output = ResidualBlock(output, DIM_D * 2, DIM_D, 3, 'D.Block.2', spectral_normed=True,
+                                   update_collection=update_collection, resample='down', labels=labels, biases=True)
+            output = ResidualBlock(output, DIM_D, DIM_D, 3, 'D.Block.3', spectral_normed=True,
+                                   update_collection=update_collection, resample=None, labels=labels, biases=True)
+            output = ResidualBlock(output, DIM_D, DIM_D, 3, 'D.Block.4', spectral_normed=True,
+                                   update_collection=update_collection, resample=None, labels=labels, biases=True)
+            output = Fn.relu_meanpool_hw(output)                       # nonlinearity + reduce_mean (:299-301)
+            output_wgan = _linear.Linear(output, DIM_D, 1, 'D.Output', spectral_normed=True,
+                                         update_collection=update_collection)
+            return output_wgan.reshape(-1), None
+
+
+def lr_decay(iteration):
+    """(:454-459)"""
+    if not DECAY:
+        return 1.
+    return max(0., 1. - iteration / 100000.) if iteration < 50000 else 0.5
+
+
+class AdamTF:
+    """tf.train.AdamOptimizer(beta1=0., beta2=0.9) over one flat buffer (:521-526)."""
+
+    def __init__(self, flat, iteration, lr=LR, beta1=0., beta2=0.9, eps=1e-8, grad_scale=1.0, decay=DECAY):
+        """All step state is device resident (hyper-parameters, step count t, the shared `iteration`
+        counter that drives the LR decay), so a captured update replays with no host traffic."""
+        self.flat, self.iteration = flat, iteration
+        dev = flat["params"].device
+        self.hp = torch.tensor([lr, beta1, beta2, eps, grad_scale, 1.0 if decay else 0.0, 0.0, 0.0],
+                               dtype=torch.float32, device=dev)
+        self.t = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def apply(self):
+        f = self.flat
+        K.adam_tf(f["params"], f["grads"], f["m"], f["v"], self.hp, self.t, self.iteration)
+
+
+class SNGANTrainer:
+    """One process = one GPU.  `world_size` > 1: each rank holds a full replica and its own
+    BATCH_SIZE-sample shard of the real data (weak scaling) or BATCH_SIZE/world_size (strong);
+    G and D gradients are summed with one RCCL all-reduce per update over the flat gradient buffer
+    and averaged inside the Adam kernel (grad_scale = 1/world_size; the reference averages its tower
+    losses, :436,:498)."""
+
+    def __init__(self, batch_size=BATCH_SIZE, device="cuda", seed=0, use_graphs=True, process_group=None, state=None):
+        self.device = torch.device(device)
+        self.batch = batch_size
+        self.store = set_default_store(ParamStore(self.device, seed=seed))
+        self.pg = process_group
+        self.world = 1
+        self.rank = 0
+        if process_group is not None:
+            import torch.distributed as dist
+            self.world, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
+        self.use_graphs = use_graphs
+        # data-side RNG differs per rank; parameter init (store seed) is identical on all ranks
+        self.rng_state = K.new_rng_state(1234567 + 7919 * self.rank + seed, self.device)
+        self.iteration = 0
+        self._build(state)
+        self._graphs = {}
+
+    # ---- graph construction (variables are created by name on the first call, :238,:267) ----------
+    def _build(self, state):
+        b = self.batch
+        with torch.no_grad():
+            labels = torch.zeros(b, dtype=torch.int32, device=self.device)
+            z = torch.zeros((b, 128), dtype=torch.bfloat16, device=self.device)
+            fake = Generator(b, labels, noise=z, groups=N_TOWERS)
+            Discriminator(fake, labels, update_collection=NO_OPS)
+        if state is not None:
+            self.store.load_state_dict(state)
+        self.g_flat = self.store.flatten('Generator')
+        self.d_flat = self.store.flatten('Discriminator')
+        self.iteration_dev = torch.zeros(1, dtype=torch.int64, device=self.device)   # `_iteration` feed (:320)
+        self.g_opt = AdamTF(self.g_flat, self.iteration_dev, grad_scale=1.0 / self.world)
+        self.d_opt = AdamTF(self.d_flat, self.iteration_dev, grad_scale=1.0 / self.world)
+        # static input buffers (graph replays read these addresses)
+        self.real_u8 = torch.zeros((b, OUTPUT_DIM), dtype=torch.uint8, device=self.device)
+        self.real_labels = torch.zeros(b, dtype=torch.int32, device=self.device)
+        self.d_loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.g_loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    # ---- the two updates, as plain eager code (captured into graphs by _run) -----------------------
+    def _d_forward_backward(self, real_pre=None, z=None):
+        """disc_cost and its gradients (:326-381): fakes from N_TOWERS generator towers conditioned on
+        the REAL labels, critic on concat(real, fake) with update_collection=None."""
+        b = self.batch
+        self.store.zero_grads('Discriminator')
+        with torch.no_grad():   # generator is not trained by disc_cost: no autograd graph through it
+            fake = Generator(b, self.real_labels, noise=z, groups=N_TOWERS, rng_state=self.rng_state)
+            real = K.preprocess_real(self.real_u8, self.rng_state).reshape(b, OUTPUT_DIM) if real_pre is None else real_pre
+            both = torch.cat([real, fake], 0)                          # plumbing: device memcpy
+            both_labels = torch.cat([self.real_labels, self.real_labels], 0)
+        logits, _ = Discriminator(both, both_labels, update_collection=None)
+        loss = Fn.hinge_d_loss(logits, b)
+        loss.backward()
+        self.d_loss.copy_(loss.detach())
+        return logits
+
+    def _g_forward_backward(self, z=None, fake_labels=None):
+        """gen_cost and its gradients (:464-498): N_TOWERS towers of GEN_BS_MULTIPLE*B/N_TOWERS samples,
+        critic with update_collection=NO_OPS (u read, never written)."""
+        n = GEN_BS_MULTIPLE * self.batch
+        self.store.zero_grads('Generator')
+        if fake_labels is None:
+            fake_labels = K.rng_labels(n, 10, self.rng_state)           # :467
+        fake = Generator(n, fake_labels, noise=z, groups=N_TOWERS, rng_state=self.rng_state)
+        d_params = self.store.params_with_name('Discriminator')
+        for p in d_params:      # gen_cost is differentiated w.r.t. gen_params only (:523)
+            p.requires_grad_(False)
+        try:
+            logits, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS)
+            loss = Fn.hinge_g_loss(logits)
+            loss.backward()
+        finally:
+            for p in d_params:
+                p.requires_grad_(True)
+        self.g_loss.copy_(loss.detach())
+        return logits
+
+    def _allreduce(self, flat):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(flat["grads"], op=dist.ReduceOp.SUM, group=self.pg)
+
+    def _run(self, key, fwd_bwd, opt, flat):
+        """fwd+bwd (graph) -> [RCCL all-reduce] -> Adam (graph)."""
+        if not self.use_graphs:
+            fwd_bwd()
+            self._allreduce(flat)
+            opt.apply()
+            return
+        if key not in self._graphs:
+            # the first call of each update runs eagerly on a side stream (this IS the step: allocator
+            # warm-up, lazy init), then the same code is captured (capture executes nothing)
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                fwd_bwd()
+                self._allreduce(flat)
+                opt.apply()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                fwd_bwd()
+                if self.world == 1:
+                    opt.apply()
+            g2 = None
+            if self.world > 1:
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2):
+                    opt.apply()
+            self._graphs[key] = (g1, g2)
+            return
+        g1, g2 = self._graphs[key]
+        g1.replay()
+        if g2 is not None:
+            self._allreduce(flat)
+            g2.replay()
+
+    # ---- public API ---------------------------------------------------------------------------------
+    def d_step(self, real_u8, labels):
+        """One critic update on a uint8 [B,3072] CHW-planar batch + int labels (the feed of :616-620)."""
+        self.real_u8.copy_(real_u8, non_blocking=True)
+        self.real_labels.copy_(labels, non_blocking=True)
+        self._run('d', self._d_forward_backward, self.d_opt, self.d_flat)
+        return self.d_loss
+
+    def g_step(self):
+        """One generator update (:602-603)."""
+        self._run('g', self._g_forward_backward, self.g_opt, self.g_flat)
+        return self.g_loss
+
+    def train_iteration(self, batches):
+        """One reference iteration (:599-620): G update (skipped at iteration 0), then N_CRITIC critic
+        updates, each on the next (uint8 images, labels) pair from `batches`."""
+        if self.iteration > 0:
+            self.g_step()
+        for _ in range(N_CRITIC):
+            data, labels = next(batches)
+            self.d_step(data, labels)
+        self.iteration += 1
+        K.counter_add(self.iteration_dev, 1)
+
+    @torch.no_grad()
+    def sample(self, n=100, labels=None, noise=None):
+        """Fixed-noise / IS sampling path (:530-555): one Generator call of n samples, batch statistics."""
+        if labels is None:
+            labels = K.rng_labels(n, 10, self.rng_state)
+        return Generator(n, labels, noise=noise, groups=1, rng_state=self.rng_state)
+
+
+def synthetic_batches(batch_size, device, seed=0):
+    """Synthetic CIFAR-10-shaped feed: uint8 [B,3072] uniform{0..255} in CHW-planar row layout and
+    int32 labels uniform{0..9} (common/data/cifar10.py:9-15 format), resident in HBM."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    pool = [(torch.randint(0, 256, (batch_size, OUTPUT_DIM), generator=g, dtype=torch.uint8).to(device),
+             torch.randint(0, 10, (batch_size,), generator=g, dtype=torch.int32).to(device)) for _ in range(8)]
+    i = 0
+    while True:
+        yield pool[i % len(pool)]
+        i += 1

@@ -1,0 +1,97 @@
+"""ctypes binding of libgank.so (include/gank.h).  There is NO fallback: if the HIP library is
+missing or a symbol is absent this module raises, and every compute entry point of the package
+goes through it."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgank.so")
+
+P, I, L, F = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+# flags (include/gank.h)
+IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X = 1, 2, 4, 8
+
+
+class SnDesc(C.Structure):
+    """gank_sn_desc"""
+    _fields_ = [(n, P) for n in ("W", "u_in", "u_out", "v", "W_bar", "scal", "a", "b", "bpart",
+                                 "dW_bar", "dW", "rowdot", "ga")] + \
+               [("K", I), ("C", I), ("row_offset", I), ("chunk_offset", I)]
+
+
+# name -> argument ctypes (all return int unless listed in _RET)
+PROTOTYPES = {
+    "gank_version": [],
+    "gank_last_error": [],
+    "gank_conv2d_prep_weights": [P, P, P, I, I, I, P],
+    "gank_conv2d_fprop": [P, P, P, P, P, P, I, I, I, I, I, I, I, F, P],
+    "gank_conv2d_dgrad": [P, P, P, P, P, I, I, I, I, I, I, I, F, P],
+    "gank_conv2d_wgrad": [P, P, P, I, I, I, I, I, I, I, F, P],
+    "gank_deconv2d_fprop": [P, P, P, P, I, I, I, I, I, I, P],
+    "gank_deconv2d_dgrad": [P, P, P, I, I, I, I, I, I, P],
+    "gank_deconv2d_wgrad": [P, P, P, I, I, I, I, I, I, P],
+    "gank_colsum_bf16": [P, P, L, I, F, P],
+    "gank_sn_power_iter_fwd": [C.POINTER(SnDesc), I, P],
+    "gank_sn_power_iter_bwd": [C.POINTER(SnDesc), I, P],
+    "gank_cbn_parts": [L],
+    "gank_cbn_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "gank_cbn_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "gank_pool2x2": [P, P, P, I, I, I, I, F, P],
+    "gank_unpool2x2_add": [P, P, P, I, I, I, I, F, P],
+    "gank_add_bf16": [P, P, P, L, P],
+    "gank_relu_fwd": [P, P, L, F, P],
+    "gank_relu_bwd": [P, P, P, L, F, P],
+    "gank_tanh_bwd": [P, P, P, L, P],
+    "gank_scale_f32": [P, P, P, L, P],
+    "gank_cast_f32_bf16": [P, P, L, P],
+    "gank_cast_bf16_f32": [P, P, L, P],
+    "gank_relu_meanpool_hw_fwd": [P, P, I, I, I, P],
+    "gank_relu_meanpool_hw_bwd": [P, P, P, I, I, I, P],
+    "gank_concat_tile_fwd": [P, P, P, I, I, I, I, P],
+    "gank_concat_tile_bwd": [P, P, P, I, I, I, I, P],
+    "gank_embedding_fwd": [P, P, P, I, I, I, P],
+    "gank_embedding_bwd": [P, P, P, I, I, I, P],
+    "gank_hinge_d_loss": [P, P, P, I, I, P],
+    "gank_hinge_g_loss": [P, P, P, I, P],
+    "gank_softmax_xent": [P, P, P, P, I, I, P],
+    "gank_adam_tf": [P, P, P, P, P, P, P, L, P],
+    "gank_counter_add": [P, C.c_int64, P],
+    "gank_preprocess_real": [P, P, P, I, P],
+    "gank_rng_normal_bf16": [P, L, P, P],
+    "gank_rng_labels": [P, L, I, P, P],
+    "gank_prof_enable": [I],
+    "gank_prof_reset": [],
+    "gank_prof_collect": [I, C.POINTER(C.c_double), C.POINTER(C.c_double)],
+    "gank_debug_tr_probe": [P, P],
+}
+_RET = {"gank_last_error": C.c_char_p}
+
+_lib = None
+
+
+def load():
+    """Load libgank.so and bind every symbol of include/gank.h.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run "
+            "`python -m gan_lib_tensorflow_amd.build` (needs hipcc). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"libgank.so does not export {name}; rebuild it") from e
+        fn.argtypes = args
+        fn.restype = _RET.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().gank_last_error()
+        raise RuntimeError(f"gank: {what}: {msg.decode() if msg else 'error'}")

@@ -1,0 +1,55 @@
+"""Build libgank.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
+
+    python -m gan_lib_tensorflow_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels with gpurun snapshots.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INC = os.path.join(os.path.dirname(HERE), "include")
+LIB = os.path.join(HERE, "libgank.so")
+SOURCES = ["api.hip", "conv_igemm.hip", "conv_wgrad.hip", "elementwise.hip", "sn.hip", "cbn.hip", "loss_opt.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(a, b):
+    return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(os.path.join(HERE, "_obj"), exist_ok=True)
+    hdrs = [os.path.join(CSRC, "gank_common.h"), os.path.join(INC, "gank.h")]
+    objs, procs = [], []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(HERE, "_obj", src.replace(".hip", ".o"))
+        objs.append(op)
+        if force or _newer(sp, op) or any(_newer(h, op) for h in hdrs):
+            cmd = ["hipcc", *FLAGS, "-I", INC, "-c", sp, "-o", op]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = False
+    for src, p in procs:
+        out = p.communicate()[0].decode()
+        if out.strip() and verbose:
+            print(out)
+        if p.returncode != 0:
+            print(out, file=sys.stderr)
+            failed = True
+    if failed:
+        raise RuntimeError("hipcc failed")
+    if force or procs or not os.path.exists(LIB):
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,107 @@
+"""Spectral normalisation -- drop-in for common/ops/sn.py of the reference.
+
+`spectral_normed_weight(W, u, num_iters=1, update_collection=None, with_sigma=False)` keeps the
+reference signature (sn.py:15).  One power-iteration step, sigma = v W u'^T, W/sigma, gradient
+THROUGH the iteration (sn.py:34-61 has no stop_gradient).  `u` write policy (sn.py:48-65):
+update_collection=None -> u is overwritten on every execution; NO_OPS -> never; any other value
+-> the pending update is appended to that collection (a list) as a callable.
+
+MI355X-first: `precomputed(...)` runs ONE batched launch group for all spectrally normalised
+weights of a network (12 in the SNGAN critic) instead of 12 x 3 dependent GEMVs.
+"""
+import contextlib
+import warnings
+
+import torch
+
+from ... import functional as Fn
+from ...store import get_default_store
+
+NO_OPS = 'NO_OPS'
+
+_active = []  # stack of {id(W): (W_bar, sigma)} dicts filled by `precomputed`
+
+
+def _apply_update(us, batch, update_collection):
+    if update_collection == NO_OPS:
+        return
+    new = batch.u_out_views()
+
+    def assign():
+        with torch.no_grad():
+            for u, un in zip(us, new):
+                u.view(-1).copy_(un)
+    if update_collection is None:
+        assign()                       # sn.py:55-56: u.assign(u_final) as a control dependency
+    else:
+        update_collection.append(assign)   # sn.py:64-65
+
+
+def spectral_normed_weight(W, u=None, num_iters=1, update_collection=None, with_sigma=False, reuse=False):
+    if num_iters != 1:
+        raise NotImplementedError('the hot path uses num_iters=1 (sn.py:15 default)')
+    for table in reversed(_active):
+        hit = table.get(id(W))
+        if hit is not None:
+            return hit if with_sigma else hit[0]
+    store = get_default_store()
+    with store.variable_scope('spectral_norm'):
+        if u is None:
+            c = W.shape[-1]
+            u = store.get_variable('u', [1, c], lambda rng: _trunc_normal(rng, (1, c)), trainable=False)
+    if update_collection is None:
+        warnings.warn('Setting update_collection to None will make u being updated every W execution. '
+                      'This maybe undesirable. Please consider using a update collection instead.')
+    # u is overwritten before backward runs -> the kernels read a snapshot
+    u_read = u.detach().clone() if update_collection != NO_OPS else u.detach()
+    (W_bar,), batch = Fn.spectral_norm_batch([W], [u_read])
+    _apply_update([u], batch, update_collection)
+    if with_sigma:
+        return W_bar, batch.sigma(0)
+    return W_bar
+
+
+def _trunc_normal(rng, size):
+    """tf.truncated_normal_initializer() (sn.py:32)."""
+    out = rng.normal(size=size)
+    bad = abs(out) > 2
+    while bad.any():
+        out[bad] = rng.normal(size=int(bad.sum()))
+        bad = abs(out) > 2
+    return out.astype('float32')
+
+
+def sn_pairs(store, prefix):
+    """[(W, u)] for every spectrally normalised variable under `prefix`, by the reference's names:
+    conv `X/filters/spectral_norm/u` <-> `X/Filters` (conv2d.py:142,170), linear
+    `X/spectral_norm/u` <-> `X/W` (linear.py:140,162-164)."""
+    pairs = []
+    for name in store.names(prefix):
+        if name.endswith('/filters/spectral_norm/u'):
+            pairs.append((store.vars[name[:-len('/filters/spectral_norm/u')] + '/Filters'], store.vars[name]))
+        elif name.endswith('/spectral_norm/u'):
+            pairs.append((store.vars[name[:-len('/spectral_norm/u')] + '/W'], store.vars[name]))
+    return pairs
+
+
+@contextlib.contextmanager
+def precomputed(store, prefix, update_collection=None):
+    """Normalise every SN weight under `prefix` in one batched call; inside the block
+    `spectral_normed_weight(W, ...)` returns the precomputed W_bar for those W."""
+    pairs = sn_pairs(store, prefix)
+    if not pairs:
+        yield None
+        return
+    Ws = [w for w, _ in pairs]
+    us = [u for _, u in pairs]
+    if update_collection != NO_OPS:
+        u_read = [u.detach().clone() for u in us]
+    else:
+        u_read = [u.detach() for u in us]
+    W_bars, batch = Fn.spectral_norm_batch(Ws, u_read)
+    _apply_update(us, batch, update_collection)
+    _active.append({id(w): (wb, batch.sigma(i)) for i, (w, wb) in enumerate(zip(Ws, W_bars))})
+    try:
+        yield batch
+    finally:
+        _active.pop()

@@ -1,0 +1,151 @@
+"""Block library -- drop-in for common/resnet_block.py:24-184 and the private copy inside
+SNGAN/gan_cifar_resnet.py:80-234 of the reference.
+
+Same functions, signatures and variable names.  What differs is underneath: every resampling /
+activation / shortcut-add around a convolution is folded into the MFMA conv kernel's gather or
+epilogue instead of being a TensorFlow op that materialises a tensor:
+  UpsampleConv  = conv with the nearest-neighbour 2x applied while staging the input patch
+                  (tf.concat x4 + tf.depth_to_space, gan_cifar_resnet.py:143-145, never materialised);
+  ConvMeanPool  = conv + 2x2 mean (the gradient of the pool is folded into dgrad/wgrad gathers);
+  pre-activation relu = relu on the conv operand (D) or fused into the CBN apply kernel (G);
+  shortcut + output   = residual add in the conv epilogue.
+"""
+import functools
+
+from .. import functional as Fn
+from ..store import get_default_store
+from .ops import conv2d as _conv2d
+from .ops import normalization as _normalization
+
+# reference globals (common/resnet_block.py:20-21; SNGAN/gan_cifar_resnet.py:43-44,51-52 overrides them)
+NORMALIZATION_G = True
+NORMALIZATION_D = False
+CONDITIONAL = True
+ACGAN = False
+DIM_D = 128
+
+
+def nonlinearity(x, activation_fn='relu', leakiness=0.2):
+    """gan_cifar_resnet.py:80-85"""
+    if activation_fn == 'relu':
+        return Fn.relu(x, 0.0)
+    if activation_fn == 'lrelu':
+        assert 0 < leakiness <= 1, "leakiness must be <= 1"
+        return Fn.relu(x, leakiness)
+
+
+def _normalize_kind(name, labels):
+    """Dispatch of Normalize (gan_cifar_resnet.py:88-109): 'cbn' | 'bn' | 'ln' | None."""
+    if not CONDITIONAL:
+        labels = None
+    if CONDITIONAL and ACGAN and ('D.' in name):
+        labels = None
+    if ('D.' in name) and NORMALIZATION_D:
+        return 'ln'
+    if ('G.' in name) and NORMALIZATION_G:
+        return 'cbn' if labels is not None else 'bn'
+    return None
+
+
+def Normalize(name, inputs, labels=None, groups=1, relu=False):
+    """Chooses between batchnorm, layernorm, their conditional variants, or nothing, depending on
+    `name` and the global flags (gan_cifar_resnet.py:88-109).  `relu=True` fuses the nonlinearity
+    that always follows (only honoured when a normalisation actually runs)."""
+    store = get_default_store()
+    with store.variable_scope(name):
+        kind = _normalize_kind(name, labels)
+        if kind == 'ln':
+            return _normalization.layer_norm(name, [1, 2, 3], inputs)
+        if kind == 'cbn':
+            return _normalization.cond_batchnorm(name, [0, 1, 2], inputs, labels=labels, n_labels=10,
+                                                 groups=groups, relu=relu)
+        if kind == 'bn':
+            return _normalization.batch_norm(inputs, fused=True)
+        return inputs
+
+
+def ConvMeanPool(inputs, output_dim, filter_size=3, stride=1, name=None,
+                 spectral_normed=False, update_collection=None, inputs_norm=False,
+                 he_init=True, biases=True, **fused):
+    """conv, then tf.add_n of the four stride-2 slices / 4 (gan_cifar_resnet.py:112-122)"""
+    return _conv2d.Conv2D(inputs, inputs.shape[-1], output_dim, filter_size, stride, name,
+                          spectral_normed=spectral_normed, update_collection=update_collection,
+                          he_init=he_init, biases=biases, pool_out=True, **fused)
+
+
+def MeanPoolConv(inputs, output_dim, filter_size=3, stride=1, name=None,
+                 spectral_normed=False, update_collection=None, inputs_norm=False,
+                 he_init=True, biases=True, **fused):
+    """2x2 mean, then conv (gan_cifar_resnet.py:125-137)"""
+    output = Fn.meanpool2x2(inputs)
+    return _conv2d.Conv2D(output, output.shape[-1], output_dim, filter_size, stride, name,
+                          spectral_normed=spectral_normed, update_collection=update_collection,
+                          he_init=he_init, biases=biases, **fused)
+
+
+def UpsampleConv(inputs, output_dim, filter_size=3, stride=1, name=None,
+                 spectral_normed=False, update_collection=None, inputs_norm=False,
+                 he_init=True, biases=True, **fused):
+    """nearest-neighbour 2x (concat x4 + depth_to_space), then conv (gan_cifar_resnet.py:140-153)"""
+    return _conv2d.Conv2D(inputs, inputs.shape[-1], output_dim, filter_size, stride, name,
+                          spectral_normed=spectral_normed, update_collection=update_collection,
+                          he_init=he_init, biases=biases, upsample=True, **fused)
+
+
+def ResidualBlock(inputs, input_dim, output_dim, filter_size, name,
+                  spectral_normed=False, update_collection=None, inputs_norm=False,
+                  resample=None, labels=None, biases=True, groups=1):
+    """resample: None, 'down', or 'up'  (gan_cifar_resnet.py:156-209)."""
+    if resample == 'down':
+        conv_1 = functools.partial(_conv2d.Conv2D, input_dim=input_dim, output_dim=input_dim)
+        conv_2 = functools.partial(ConvMeanPool, output_dim=output_dim)
+        conv_shortcut = ConvMeanPool
+    elif resample == 'up':
+        conv_1 = functools.partial(UpsampleConv, output_dim=output_dim)
+        conv_shortcut = UpsampleConv
+        conv_2 = functools.partial(_conv2d.Conv2D, input_dim=output_dim, output_dim=output_dim)
+    elif resample is None:
+        conv_shortcut = functools.partial(_conv2d.Conv2D, input_dim=input_dim)
+        conv_1 = functools.partial(_conv2d.Conv2D, input_dim=input_dim, output_dim=output_dim)
+        conv_2 = functools.partial(_conv2d.Conv2D, input_dim=output_dim, output_dim=output_dim)
+    else:
+        raise Exception('invalid resample value')
+
+    x_short, x_main = Fn.fork(inputs)
+    if output_dim == input_dim and resample is None:
+        shortcut = x_short  # Identity skip-connection
+    else:
+        shortcut = conv_shortcut(inputs=x_short, output_dim=output_dim, filter_size=1, name=name + '.Shortcut',
+                                 spectral_normed=spectral_normed, update_collection=update_collection,
+                                 he_init=False, biases=biases)
+
+    # Normalize + nonlinearity (:185-186): relu rides on the CBN apply kernel, or on conv_1's operand
+    norm1 = _normalize_kind(name + '.N1', labels) is not None
+    output = Normalize(name + '.N1', x_main, labels=labels, groups=groups, relu=True)
+    output = conv_1(inputs=output, filter_size=filter_size, name=name + '.Conv1',
+                    spectral_normed=spectral_normed, update_collection=update_collection,
+                    he_init=True, biases=biases, in_relu=not norm1)
+
+    norm2 = _normalize_kind(name + '.N2', labels) is not None
+    output = Normalize(name + '.N2', output, labels=labels, groups=groups, relu=True)
+    # shortcut + output (:209) rides on conv_2's epilogue
+    return conv_2(inputs=output, filter_size=filter_size, name=name + '.Conv2',
+                  spectral_normed=spectral_normed, update_collection=update_collection,
+                  he_init=True, biases=biases, in_relu=not norm2, residual=shortcut)
+
+
+def OptimizedResBlockDisc1(inputs, spectral_normed=False, update_collection=None, inputs_norm=False, biases=True):
+    """First critic block, no pre-activation on the image (gan_cifar_resnet.py:212-234)."""
+    conv_1 = functools.partial(_conv2d.Conv2D, input_dim=inputs.shape[-1], output_dim=DIM_D)
+    conv_2 = functools.partial(ConvMeanPool, output_dim=DIM_D)
+    conv_shortcut = MeanPoolConv
+    x_short, x_main = Fn.fork(inputs)
+    shortcut = conv_shortcut(inputs=x_short, output_dim=DIM_D, filter_size=1, name='D.Block.1.Shortcut',
+                             spectral_normed=spectral_normed, update_collection=update_collection,
+                             he_init=False, biases=biases)
+    output = conv_1(inputs=x_main, filter_size=3, name='D.Block.1.Conv1',
+                    spectral_normed=spectral_normed, update_collection=update_collection,
+                    he_init=True, biases=biases)
+    return conv_2(inputs=output, filter_size=3, name='D.Block.1.Conv2',
+                  spectral_normed=spectral_normed, update_collection=update_collection,
+                  he_init=True, biases=biases, in_relu=True, residual=shortcut)

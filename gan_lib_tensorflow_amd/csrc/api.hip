@@ -1,0 +1,66 @@
+// Error reporting, version, and the opt-in HIP-event profiler of libgank.
+#include "gank_common.h"
+#include <string.h>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+int gank_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return 1;
+}
+
+extern "C" const char* gank_last_error(void) { return g_err; }
+extern "C" int gank_version(void) { return GANK_VERSION; }
+
+// ---- profiler: one (start, stop) event pair per launch of a kernel family, recorded on the launch
+// stream.  Off by default; never active during graph capture (bench.py enables it for one eager pass).
+namespace {
+constexpr int kFamilies = 4;
+struct Rec { hipEvent_t a, b; double flops; };
+bool g_on = false;
+std::vector<Rec> g_recs[kFamilies];
+hipEvent_t g_open[kFamilies];
+}  // namespace
+
+void gank_prof_begin(int family, double flops, hipStream_t s) {
+  if (!g_on || family < 0 || family >= kFamilies) return;
+  Rec r;
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+  r.flops = flops;
+  hipEventRecord(r.a, s);
+  g_recs[family].push_back(r);
+}
+
+void gank_prof_end(int family, hipStream_t s) {
+  if (!g_on || family < 0 || family >= kFamilies || g_recs[family].empty()) return;
+  hipEventRecord(g_recs[family].back().b, s);
+}
+
+extern "C" int gank_prof_enable(int on) { g_on = on != 0; return 0; }
+
+extern "C" int gank_prof_reset(void) {
+  for (int f = 0; f < kFamilies; f++) {
+    for (auto& r : g_recs[f]) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    g_recs[f].clear();
+  }
+  return 0;
+}
+
+extern "C" int gank_prof_collect(int family, double* total_ms, double* total_flops) {
+  if (family < 0 || family >= kFamilies) return 0;
+  double ms = 0, fl = 0;
+  int n = 0;
+  for (auto& r : g_recs[family]) {
+    if (hipEventSynchronize(r.b) != hipSuccess) continue;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+    ms += t; fl += r.flops; n++;
+  }
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  return n;
+}

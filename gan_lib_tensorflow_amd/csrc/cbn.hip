@@ -1,0 +1,295 @@
+// Conditional batch norm (common/ops/normalization.py:27-59), forward and backward, HBM-bound.
+//   moments over (N/groups, H, W) per tower: two-pass like tf.nn.moments (mean, then mean of squared
+//   deviations; biased), eps = 1e-5; y = (x-mean)*invstd*gamma[label] + beta[label]; optional fused relu.
+// x is [N, HW, C] bf16 with C % 8 == 0: every lane moves 16 B; thread = (8-channel group, row lane).
+#include "gank_common.h"
+
+#define BN_EPS 1e-5f
+
+extern "C" int gank_cbn_parts(long rows_per_group) {
+  long p = (rows_per_group + 127) / 128;
+  if (p < 1) p = 1;
+  if (p > 128) p = 128;
+  return (int)p;
+}
+
+struct CbnGeom {
+  int N, HW, C, groups, parts, n_labels, relu;
+  long rows_per_group, rows_per_part;
+};
+
+// pass 1: ws_sum[g][p][c] = sum over the part's rows of x
+__global__ void cbn_sum_kernel(const bf16* __restrict__ x, float* __restrict__ ws, CbnGeom q) {
+  const int cg = q.C >> 3, RL = 256 / cg;
+  const int g = threadIdx.x % cg, rl = threadIdx.x / cg;
+  const int grp = blockIdx.x / q.parts, part = blockIdx.x % q.parts;
+  const long r0 = grp * q.rows_per_group + part * q.rows_per_part;
+  long r1 = r0 + q.rows_per_part;
+  const long rend = (grp + 1) * q.rows_per_group;
+  if (r1 > rend) r1 = rend;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rl < RL)
+    for (long r = r0 + rl; r < r1; r += RL) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + r * q.C + g * 8);
+#pragma unroll
+      for (int e = 0; e < 8; e++) acc[e] += bf2f(v[e]);
+    }
+  __shared__ float red[256 * 8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) red[threadIdx.x * 8 + e] = acc[e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < q.C; c += 256) {
+    float t = 0.f;
+    for (int l = 0; l < RL; l++) t += red[(l * cg + (c >> 3)) * 8 + (c & 7)];
+    ws[((long)grp * q.parts + part) * q.C + c] = t;
+  }
+}
+
+// pass 2: mean from pass-1 partials; ws_sq[g][p][c] = sum (x-mean)^2 ; part 0 also stores the mean
+__global__ void cbn_sqdev_kernel(const bf16* __restrict__ x, const float* __restrict__ ws_sum, float* __restrict__ ws_sq,
+                                 float* __restrict__ stats, CbnGeom q) {
+  const int cg = q.C >> 3, RL = 256 / cg;
+  const int g = threadIdx.x % cg, rl = threadIdx.x / cg;
+  const int grp = blockIdx.x / q.parts, part = blockIdx.x % q.parts;
+  __shared__ float smean[2048];
+  __shared__ float red[256 * 8];
+  for (int c = threadIdx.x; c < q.C; c += 256) {
+    float t = 0.f;
+    for (int p = 0; p < q.parts; p++) t += ws_sum[((long)grp * q.parts + p) * q.C + c];
+    const float m = t / (float)q.rows_per_group;
+    smean[c] = m;
+    if (part == 0) stats[((long)grp * 2 + 0) * q.C + c] = m;
+  }
+  __syncthreads();
+  const long r0 = grp * q.rows_per_group + part * q.rows_per_part;
+  long r1 = r0 + q.rows_per_part;
+  const long rend = (grp + 1) * q.rows_per_group;
+  if (r1 > rend) r1 = rend;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rl < RL) {
+    float mu[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) mu[e] = smean[g * 8 + e];
+    for (long r = r0 + rl; r < r1; r += RL) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + r * q.C + g * 8);
+#pragma unroll
+      for (int e = 0; e < 8; e++) { const float d = bf2f(v[e]) - mu[e]; acc[e] += d * d; }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; e++) red[threadIdx.x * 8 + e] = acc[e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < q.C; c += 256) {
+    float t = 0.f;
+    for (int l = 0; l < RL; l++) t += red[(l * cg + (c >> 3)) * 8 + (c & 7)];
+    ws_sq[((long)grp * q.parts + part) * q.C + c] = t;
+  }
+}
+
+// pass 3: invstd from pass-2 partials; normalise + gamma/beta gather (+relu)
+__global__ void cbn_apply_kernel(const bf16* __restrict__ x, const int* __restrict__ labels, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, bf16* __restrict__ y, const float* __restrict__ ws_sq,
+                                 float* __restrict__ stats, CbnGeom q) {
+  const int cg = q.C >> 3, RL = 256 / cg;
+  const int g = threadIdx.x % cg, rl = threadIdx.x / cg;
+  const int grp = blockIdx.x / q.parts, part = blockIdx.x % q.parts;
+  __shared__ float sinv[2048];
+  for (int c = threadIdx.x; c < q.C; c += 256) {
+    float t = 0.f;
+    for (int p = 0; p < q.parts; p++) t += ws_sq[((long)grp * q.parts + p) * q.C + c];
+    const float inv = 1.f / sqrtf(t / (float)q.rows_per_group + BN_EPS);
+    sinv[c] = inv;
+    if (part == 0) stats[((long)grp * 2 + 1) * q.C + c] = inv;
+  }
+  __syncthreads();
+  const long r0 = grp * q.rows_per_group + part * q.rows_per_part;
+  long r1 = r0 + q.rows_per_part;
+  const long rend = (grp + 1) * q.rows_per_group;
+  if (r1 > rend) r1 = rend;
+  if (rl >= RL) return;
+  float mu[8], iv[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) { mu[e] = stats[((long)grp * 2) * q.C + g * 8 + e]; iv[e] = sinv[g * 8 + e]; }
+  for (long r = r0 + rl; r < r1; r += RL) {
+    const int n = (int)(r / q.HW);
+    int lb = labels[n];
+    lb = lb < 0 ? 0 : (lb >= q.n_labels ? q.n_labels - 1 : lb);
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + (long)lb * q.C + g * 8);
+    const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + (long)lb * q.C + g * 8 + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + (long)lb * q.C + g * 8);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(beta + (long)lb * q.C + g * 8 + 4);
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + r * q.C + g * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const float ga = e < 4 ? g0[e] : g1[e - 4], be = e < 4 ? b0[e] : b1[e - 4];
+      float t = (bf2f(v[e]) - mu[e]) * iv[e] * ga + be;
+      if (q.relu) t = fmaxf(t, 0.f);
+      o[e] = f2bf(t);
+    }
+    *reinterpret_cast<bf16x8*>(y + r * q.C + g * 8) = o;
+  }
+}
+
+static int cbn_geom(CbnGeom& q, int N, int HW, int C, int groups, int n_labels, int relu) {
+  GANK_REQUIRE(N > 0 && HW > 0 && C > 0 && groups > 0 && n_labels > 0, "cbn: bad shape");
+  GANK_REQUIRE(N % groups == 0, "cbn: batch %d not divisible by %d towers", N, groups);
+  GANK_REQUIRE(C % 8 == 0 && C <= 2048 && 256 % (C / 8) == 0, "cbn: C=%d unsupported (need C%%8==0, (C/8) | 256)", C);
+  q.N = N; q.HW = HW; q.C = C; q.groups = groups; q.n_labels = n_labels; q.relu = relu;
+  q.rows_per_group = (long)(N / groups) * HW;
+  q.parts = gank_cbn_parts(q.rows_per_group);
+  q.rows_per_part = (q.rows_per_group + q.parts - 1) / q.parts;
+  return 0;
+}
+
+extern "C" int gank_cbn_fwd(const void* x, const int32_t* labels, const float* gamma, const float* beta, void* y,
+                            float* stats, float* ws, int N, int HW, int C, int groups, int n_labels, int relu, void* stream) {
+  GANK_REQUIRE(x && labels && gamma && beta && y && stats && ws, "cbn_fwd: null pointer");
+  CbnGeom q;
+  if (cbn_geom(q, N, HW, C, groups, n_labels, relu)) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  float* ws_sum = ws;
+  float* ws_sq = ws + (long)groups * q.parts * C;
+  const dim3 grid(groups * q.parts);
+  hipLaunchKernelGGL(cbn_sum_kernel, grid, dim3(256), 0, s, (const bf16*)x, ws_sum, q);
+  hipLaunchKernelGGL(cbn_sqdev_kernel, grid, dim3(256), 0, s, (const bf16*)x, ws_sum, ws_sq, stats, q);
+  hipLaunchKernelGGL(cbn_apply_kernel, grid, dim3(256), 0, s, (const bf16*)x, labels, gamma, beta, (bf16*)y, ws_sq, stats, q);
+  GANK_LAUNCH_OK("cbn_fwd");
+  return 0;
+}
+
+// ---- backward -------------------------------------------------------------------------------------
+// b1: per-sample sums S1[n][c] = sum_hw dym, S2[n][c] = sum_hw dym * xhat   (dym = dy masked by y>0)
+__global__ void cbn_bwd_sums_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, const bf16* __restrict__ y,
+                                    const float* __restrict__ stats, float* __restrict__ S, CbnGeom q, int hw_parts) {
+  const int cg = q.C >> 3, RL = 256 / cg;
+  const int g = threadIdx.x % cg, rl = threadIdx.x / cg;
+  const int n = blockIdx.x / hw_parts, hp = blockIdx.x % hw_parts;
+  const int grp = n / (q.N / q.groups);
+  const int per = (q.HW + hw_parts - 1) / hw_parts;
+  const int h0 = hp * per, h1 = min(q.HW, h0 + per);
+  float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rl < RL) {
+    float mu[8], iv[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      mu[e] = stats[((long)grp * 2) * q.C + g * 8 + e];
+      iv[e] = stats[((long)grp * 2 + 1) * q.C + g * 8 + e];
+    }
+    for (int r = h0 + rl; r < h1; r += RL) {
+      const long o = ((long)n * q.HW + r) * q.C + g * 8;
+      const bf16x8 d = *reinterpret_cast<const bf16x8*>(dy + o);
+      const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + o);
+      bf16x8 yv;
+      if (q.relu) yv = *reinterpret_cast<const bf16x8*>(y + o);
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        float dd = bf2f(d[e]);
+        if (q.relu && !(bf2f(yv[e]) > 0.f)) dd = 0.f;
+        a1[e] += dd;
+        a2[e] += dd * (bf2f(xv[e]) - mu[e]) * iv[e];
+      }
+    }
+  }
+  __shared__ float red[256 * 16];
+#pragma unroll
+  for (int e = 0; e < 8; e++) { red[threadIdx.x * 16 + e] = a1[e]; red[threadIdx.x * 16 + 8 + e] = a2[e]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < q.C; c += 256) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int l = 0; l < RL; l++) {
+      t1 += red[(l * cg + (c >> 3)) * 16 + (c & 7)];
+      t2 += red[(l * cg + (c >> 3)) * 16 + 8 + (c & 7)];
+    }
+    if (hw_parts == 1) {
+      S[((long)n * 2) * q.C + c] = t1;
+      S[((long)n * 2 + 1) * q.C + c] = t2;
+    } else {
+      atomicAdd(S + ((long)n * 2) * q.C + c, t1);
+      atomicAdd(S + ((long)n * 2 + 1) * q.C + c, t2);
+    }
+  }
+}
+
+// b2: thread per channel: table gradients (sequential over n: deterministic) and the per-tower means
+__global__ void cbn_bwd_tables_kernel(const float* __restrict__ S, const int* __restrict__ labels, const float* __restrict__ gamma,
+                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ M, CbnGeom q) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= q.C) return;
+  const int gs = q.N / q.groups;
+  for (int grp = 0; grp < q.groups; grp++) {
+    float m1 = 0.f, m2 = 0.f;
+    for (int i = 0; i < gs; i++) {
+      const int n = grp * gs + i;
+      int lb = labels[n];
+      lb = lb < 0 ? 0 : (lb >= q.n_labels ? q.n_labels - 1 : lb);
+      const float s1 = S[((long)n * 2) * q.C + c], s2 = S[((long)n * 2 + 1) * q.C + c];
+      const float ga = gamma[(long)lb * q.C + c];
+      dbeta[(long)lb * q.C + c] += s1;
+      dgamma[(long)lb * q.C + c] += s2;
+      m1 += ga * s1;
+      m2 += ga * s2;
+    }
+    M[((long)grp * 2) * q.C + c] = m1 / (float)q.rows_per_group;
+    M[((long)grp * 2 + 1) * q.C + c] = m2 / (float)q.rows_per_group;
+  }
+}
+
+// b3: dx = invstd * (g - mean(g) - xhat * mean(g xhat)),  g = dym * gamma[label]
+__global__ void cbn_bwd_apply_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, const bf16* __restrict__ y,
+                                     const int* __restrict__ labels, const float* __restrict__ gamma, const float* __restrict__ stats,
+                                     const float* __restrict__ M, bf16* __restrict__ dx, CbnGeom q, long total8) {
+  const int cg = q.C >> 3;
+  const int gs = q.N / q.groups;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % cg);
+    const long row = i / cg;
+    const int n = (int)(row / q.HW);
+    const int grp = n / gs;
+    int lb = labels[n];
+    lb = lb < 0 ? 0 : (lb >= q.n_labels ? q.n_labels - 1 : lb);
+    const bf16x8 d = reinterpret_cast<const bf16x8*>(dy)[i];
+    const bf16x8 xv = reinterpret_cast<const bf16x8*>(x)[i];
+    bf16x8 yv;
+    if (q.relu) yv = reinterpret_cast<const bf16x8*>(y)[i];
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int c = g * 8 + e;
+      const float mu = stats[((long)grp * 2) * q.C + c], iv = stats[((long)grp * 2 + 1) * q.C + c];
+      float dd = bf2f(d[e]);
+      if (q.relu && !(bf2f(yv[e]) > 0.f)) dd = 0.f;
+      const float gg = dd * gamma[(long)lb * q.C + c];
+      const float xh = (bf2f(xv[e]) - mu) * iv;
+      o[e] = f2bf(iv * (gg - M[((long)grp * 2) * q.C + c] - xh * M[((long)grp * 2 + 1) * q.C + c]));
+    }
+    reinterpret_cast<bf16x8*>(dx)[i] = o;
+  }
+}
+
+extern "C" int gank_cbn_bwd(const void* dy, const void* x, const void* y, const int32_t* labels, const float* gamma,
+                            const float* stats, void* dx, float* dgamma, float* dbeta, float* ws, int N, int HW, int C,
+                            int groups, int n_labels, int relu, void* stream) {
+  GANK_REQUIRE(dy && x && labels && gamma && stats && dx && dgamma && dbeta && ws, "cbn_bwd: null pointer");
+  GANK_REQUIRE(!relu || y, "cbn_bwd: relu backward needs y");
+  CbnGeom q;
+  if (cbn_geom(q, N, HW, C, groups, n_labels, relu)) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  float* S = ws;                       // [N][2][C]
+  float* M = ws + (long)N * 2 * C;     // [groups][2][C]
+  int hw_parts = HW / 64;
+  if (hw_parts < 1) hw_parts = 1;
+  if (hw_parts > 8) hw_parts = 8;
+  if (hw_parts > 1) {
+    hipError_t e = hipMemsetAsync(S, 0, sizeof(float) * (size_t)N * 2 * C, s);
+    if (e != hipSuccess) return gank_set_error("cbn_bwd: memset: %s", hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(cbn_bwd_sums_kernel, dim3(N * hw_parts), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (const bf16*)y, stats, S, q, hw_parts);
+  hipLaunchKernelGGL(cbn_bwd_tables_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, S, labels, gamma, dgamma, dbeta, M, q);
+  const long total8 = (long)N * HW * (C / 8);
+  long blocks = (total8 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(cbn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (const bf16*)y, labels, gamma, stats, M, (bf16*)dx, q, total8);
+  GANK_LAUNCH_OK("cbn_bwd");
+  return 0;
+}

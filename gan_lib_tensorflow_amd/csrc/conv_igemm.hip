@@ -1,0 +1,358 @@
+// Implicit-GEMM convolution on v_mfma_f32_32x32x16_bf16 (gfx950): fprop and dgrad.
+//
+// GEMM view:  Y[m, co] = sum_k  P[m, k] * Wt[co, k]      m = output pixel (n,oh,ow), k = (tap, ci)
+//   * MFMA "A" operand (32 rows)  = 32 output channels, fragment = 8 consecutive k of one channel
+//   * MFMA "B" operand (32 lanes) = 32 output pixels,   fragment = 8 consecutive k of one pixel
+//   so both fragments are one ds_read_b128 from [row][k] LDS tiles, and each lane ends up holding
+//   4 consecutive output channels of ONE pixel per accumulator quad -> 8-byte NHWC stores.
+//   * K-step = 64 (one tap x 64 input channels on the fast path); LDS rows are 64 bf16 + 8 pad
+//     = 144 B, which makes every ds_read_b128 lane group hit 16 distinct 4-bank slots.
+//   * global -> register -> LDS staging (not LDS-DMA): the staging pass is where zero padding,
+//     nearest-neighbour upsample, zero insertion, stride and the pre-activation relu are applied,
+//     so none of those tensors is ever materialised in HBM.
+// Replaces tf.nn.conv2d / Conv2DBackpropInput at common/ops/conv2d.py:180-187 and the
+// surrounding block-library glue (SNGAN/gan_cifar_resnet.py:112-153,186,198,209,261).
+#include "gank_common.h"
+
+#define IG_IN_ZEROINS2X 16
+#define IG_IN_STRIDE2 32
+
+struct IgemmArgs {
+  const bf16* x;
+  const bf16* w;
+  const float* bias;
+  const bf16* res;
+  const bf16* mask;
+  bf16* y;
+  int N, H, W;      // output spatial size
+  int Hin, Win;     // stored input spatial size
+  int Cin, Cout, CoutPad, Kpad;
+  int ks, pad, taps;
+  int M;            // N*H*W
+  int flags;
+  float scale;
+  int nsteps;       // Kpad / 64
+  int tiles_m, tiles_n;
+  int shw, sw;      // log2(H*W), log2(W) or -1
+};
+
+constexpr int LROW = 72;  // LDS row length in bf16 (64 + 8 pad) = 144 B
+
+template <int WM, int WN, int TM, int TN, bool PACKED>
+__global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int BM = WM * TM * 32;
+  constexpr int BN = WN * TN * 32;
+  constexpr int CP = BM * 8 / NT;  // 16-byte pixel chunks per thread per step
+  constexpr int CW = BN * 8 / NT;  // 16-byte weight chunks per thread per step
+  static_assert(CP >= 1 && CW >= 1, "tile too small for the thread count");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* sP = reinterpret_cast<bf16*>(smem);             // [2][BM][LROW]
+  bf16* sW = sP + 2 * BM * LROW;                        // [2][BN][LROW]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave % WM, wave_n = wave / WM;
+  const int r = lane & 31, h = lane >> 5;
+
+  const int nwg = a.tiles_m * a.tiles_n;
+  const int lid = xcd_remap(blockIdx.x, nwg);
+  const int tile_n = lid % a.tiles_n, tile_m = lid / a.tiles_n;
+
+  const int st = (a.flags & IG_IN_STRIDE2) ? 2 : 1;
+  const bool shr = (a.flags & (GANK_IN_UPSAMPLE2X | IG_IN_ZEROINS2X)) != 0;
+  const bool zins = (a.flags & IG_IN_ZEROINS2X) != 0;
+  const bool inrelu = (a.flags & GANK_IN_RELU) != 0;
+  const int LH = shr ? 2 * a.Hin : a.Hin, LW = shr ? 2 * a.Win : a.Win;
+
+  // per-thread pixel chunk descriptors (fixed for the whole K loop)
+  int p_base[CP], p_oh[CP], p_ow[CP];
+#pragma unroll
+  for (int j = 0; j < CP; j++) {
+    const int q = tid + NT * j;
+    const int m = tile_m * BM + (q >> 3);
+    if (m < a.M) {
+      int n, oh, ow;
+      pix_decomp(m, a.H, a.W, a.shw, a.sw, n, oh, ow);
+      p_base[j] = n * a.Hin * a.Win;
+      p_oh[j] = oh * st;
+      p_ow[j] = ow * st;
+    } else {
+      p_base[j] = 0;
+      p_oh[j] = -(1 << 20);
+      p_ow[j] = 0;
+    }
+  }
+
+  u32x4 rP[CP], rW[CW];
+
+  auto load_step = [&](int s) {
+    if constexpr (!PACKED) {
+      const int ck = a.Cin >> 6;
+      const int tap = s / ck;
+      const int c0 = (s - tap * ck) << 6;
+      const int dh = tap / a.ks - a.pad, dw = tap % a.ks - a.pad;
+#pragma unroll
+      for (int j = 0; j < CP; j++) {
+        const int cc = (tid + NT * j) & 7;
+        int ih = p_oh[j] + dh, iw = p_ow[j] + dw;
+        bool ok = (unsigned)ih < (unsigned)LH && (unsigned)iw < (unsigned)LW;
+        if (zins) ok = ok && (((ih | iw) & 1) == 0);
+        if (shr) { ih >>= 1; iw >>= 1; }
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (ok) {
+          const long off = ((long)(p_base[j] + ih * a.Win + iw)) * a.Cin + c0 + cc * 8;
+          v = *reinterpret_cast<const u32x4*>(a.x + off);
+          if (inrelu) v = relu_bf16x8(v);
+        }
+        rP[j] = v;
+      }
+    } else {
+      const int ktot = a.taps * a.Cin;
+#pragma unroll
+      for (int j = 0; j < CP; j++) {
+        const int cc = (tid + NT * j) & 7;
+        const int kb = s * 64 + cc * 8;
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const int k = kb + e;
+          float val = 0.f;
+          if (k < ktot) {
+            const int tap = k / a.Cin, ci = k - tap * a.Cin;
+            const int dh = tap / a.ks - a.pad, dw = tap % a.ks - a.pad;
+            int ih = p_oh[j] + dh, iw = p_ow[j] + dw;
+            bool ok = (unsigned)ih < (unsigned)LH && (unsigned)iw < (unsigned)LW;
+            if (zins) ok = ok && (((ih | iw) & 1) == 0);
+            if (shr) { ih >>= 1; iw >>= 1; }
+            if (ok) {
+              val = bf2f(a.x[((long)(p_base[j] + ih * a.Win + iw)) * a.Cin + ci]);
+              if (inrelu) val = fmaxf(val, 0.f);
+            }
+          }
+          v[e] = f2bf(val);
+        }
+        rP[j] = __builtin_bit_cast(u32x4, v);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < CW; j++) {
+      const int q = tid + NT * j;
+      const int co = tile_n * BN + (q >> 3);
+      rW[j] = *reinterpret_cast<const u32x4*>(a.w + (long)co * a.Kpad + s * 64 + (q & 7) * 8);
+    }
+  };
+
+  auto store_step = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < CP; j++) {
+      const int q = tid + NT * j;
+      *reinterpret_cast<u32x4*>(sP + (buf * BM + (q >> 3)) * LROW + (q & 7) * 8) = rP[j];
+    }
+#pragma unroll
+    for (int j = 0; j < CW; j++) {
+      const int q = tid + NT * j;
+      *reinterpret_cast<u32x4*>(sW + (buf * BN + (q >> 3)) * LROW + (q & 7) * 8) = rW[j];
+    }
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; i++)
+#pragma unroll
+    for (int j = 0; j < TM; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+  load_step(0);
+  store_step(0);
+  __syncthreads();
+
+  for (int s = 0; s < a.nsteps; s++) {
+    const int buf = s & 1;
+    if (s + 1 < a.nsteps) load_step(s + 1);
+    const bf16* pW = sW + (buf * BN + wave_n * TN * 32 + r) * LROW + h * 8;
+    const bf16* pP = sP + (buf * BM + wave_m * TM * 32 + r) * LROW + h * 8;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      bf16x8 fa[TN], fb[TM];
+#pragma unroll
+      for (int i = 0; i < TN; i++) fa[i] = *reinterpret_cast<const bf16x8*>(pW + i * 32 * LROW + kk * 16);
+#pragma unroll
+      for (int j = 0; j < TM; j++) fb[j] = *reinterpret_cast<const bf16x8*>(pP + j * 32 * LROW + kk * 16);
+#pragma unroll
+      for (int i = 0; i < TN; i++)
+#pragma unroll
+        for (int j = 0; j < TM; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (s + 1 < a.nsteps) store_step(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane holds, per accumulator quad g, channels co0+8g+4h .. +3 of pixel m
+  const bool vec = (a.Cout & 3) == 0;
+  const bool otanh = (a.flags & GANK_OUT_TANH) != 0;
+#pragma unroll
+  for (int j = 0; j < TM; j++) {
+    const int m = tile_m * BM + (wave_m * TM + j) * 32 + r;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int i = 0; i < TN; i++) {
+      const int co0 = tile_n * BN + (wave_n * TN + i) * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int co = co0 + 8 * g;
+        if (co >= a.Cout) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * g + e] * a.scale;
+        const long o = (long)m * a.Cout + co;
+        if (vec) {
+          if (a.bias) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] += b[e];
+          }
+          if (a.mask) {
+            const bf16x4 mk = *reinterpret_cast<const bf16x4*>(a.mask + o);
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = (bf2f(mk[e]) > 0.f) ? v[e] : 0.f;
+          }
+          if (a.res) {
+            const bf16x4 rs = *reinterpret_cast<const bf16x4*>(a.res + o);
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] += bf2f(rs[e]);
+          }
+          bf16x4 out;
+#pragma unroll
+          for (int e = 0; e < 4; e++) out[e] = f2bf(otanh ? tanhf(v[e]) : v[e]);
+          *reinterpret_cast<bf16x4*>(a.y + o) = out;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            if (co + e >= a.Cout) break;
+            float t = v[e];
+            if (a.bias) t += a.bias[co + e];
+            if (a.mask) t = (bf2f(a.mask[o + e]) > 0.f) ? t : 0.f;
+            if (a.res) t += bf2f(a.res[o + e]);
+            a.y[o + e] = f2bf(otanh ? tanhf(t) : t);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int TM, int TN, bool PACKED>
+static int launch_cfg(const IgemmArgs& a0, hipStream_t s) {
+  IgemmArgs a = a0;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  a.tiles_m = cdiv(a.M, BM);
+  a.tiles_n = a.CoutPad / BN;
+  const size_t lds = (size_t)2 * (BM + BN) * LROW * sizeof(bf16);
+  auto kern = conv_igemm_kernel<WM, WN, TM, TN, PACKED>;
+  static bool attr_set = false;  // benign race: idempotent
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return gank_set_error("conv_igemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(WM * WN * 64), lds, s, a);
+  GANK_LAUNCH_OK("conv_igemm");
+  return 0;
+}
+
+// x [N,Hin,Win,Cin] -> y [N,H,W,Cout];  w [CoutPad][Kpad] bf16
+int gank_igemm_dispatch(IgemmArgs a, hipStream_t s) {
+  GANK_REQUIRE(a.x && a.w && a.y, "conv_igemm: null pointer");
+  GANK_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Cin > 0 && a.Cout > 0, "conv_igemm: bad shape");
+  GANK_REQUIRE(a.ks >= 1 && a.ks <= 7, "conv_igemm: unsupported filter size %d", a.ks);
+  GANK_REQUIRE((long)a.N * a.Hin * a.Win * a.Cin < (1L << 31) && (long)a.N * a.H * a.W * a.Cout < (1L << 40), "conv_igemm: tensor too large");
+  a.taps = a.ks * a.ks;
+  a.CoutPad = roundup(a.Cout, 32);
+  a.Kpad = roundup(a.taps * a.Cin, 64);
+  a.nsteps = a.Kpad / 64;
+  a.M = a.N * a.H * a.W;
+  a.sw = log2_or_neg(a.W);
+  a.shw = log2_or_neg(a.H * a.W);
+  const bool packed = (a.Cin % 64) != 0;
+  const double flops = 2.0 * a.M * (double)a.Cout * a.taps * a.Cin;
+  gank_prof_begin(0, flops, s);
+  int rc;
+  const long tiles128 = (long)cdiv(a.M, 128) * (a.CoutPad / 128);
+  if (packed) {
+    if (a.CoutPad % 64 == 0) rc = launch_cfg<2, 2, 1, 1, true>(a, s);
+    else rc = launch_cfg<4, 1, 2, 1, true>(a, s);
+  } else if (a.CoutPad % 128 == 0 && tiles128 >= 192) {
+    rc = launch_cfg<2, 2, 2, 2, false>(a, s);
+  } else if (a.CoutPad % 64 == 0) {
+    rc = launch_cfg<2, 2, 1, 1, false>(a, s);
+  } else {
+    rc = launch_cfg<4, 1, 2, 1, false>(a, s);
+  }
+  gank_prof_end(0, s);
+  return rc;
+}
+
+extern "C" int gank_conv2d_fprop(const void* x, const void* wf, const float* bias, const void* residual,
+                                 const void* relu_ref, void* y, int N, int H, int W, int Cin, int Cout, int ksize,
+                                 int flags, float scale, void* stream) {
+  GANK_REQUIRE(ksize % 2 == 1, "conv2d_fprop: even filter sizes are not on this path (ksize=%d)", ksize);
+  GANK_REQUIRE(!(flags & GANK_IN_UPSAMPLE2X) || (H % 2 == 0 && W % 2 == 0), "conv2d_fprop: upsample needs even output size");
+  IgemmArgs a{};
+  a.x = (const bf16*)x; a.w = (const bf16*)wf; a.bias = bias; a.res = (const bf16*)residual;
+  a.mask = (const bf16*)relu_ref; a.y = (bf16*)y;
+  a.N = N; a.H = H; a.W = W;
+  const bool up = flags & GANK_IN_UPSAMPLE2X;
+  a.Hin = up ? H / 2 : H; a.Win = up ? W / 2 : W;
+  a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.pad = (ksize - 1) / 2;
+  a.flags = flags & (GANK_IN_UPSAMPLE2X | GANK_IN_RELU | GANK_OUT_TANH);
+  a.scale = scale;
+  return gank_igemm_dispatch(a, (hipStream_t)stream);
+}
+
+// dgrad of the stride-1 SAME conv = the same engine on dy with the flipped/transposed operand (wd)
+extern "C" int gank_conv2d_dgrad(const void* dy, const void* wd, const void* residual, const void* relu_ref, void* dx,
+                                 int N, int H, int W, int Cin, int Cout, int ksize, int flags, float scale, void* stream) {
+  GANK_REQUIRE(ksize % 2 == 1, "conv2d_dgrad: even filter sizes are not on this path (ksize=%d)", ksize);
+  IgemmArgs a{};
+  a.x = (const bf16*)dy; a.w = (const bf16*)wd; a.bias = nullptr; a.res = (const bf16*)residual;
+  a.mask = (const bf16*)relu_ref; a.y = (bf16*)dx;
+  a.N = N; a.H = H; a.W = W;
+  const bool up = flags & GANK_IN_UPSAMPLE2X;
+  a.Hin = up ? H / 2 : H; a.Win = up ? W / 2 : W;
+  a.Cin = Cout; a.Cout = Cin; a.ks = ksize; a.pad = (ksize - 1) / 2;
+  a.flags = flags & (GANK_IN_UPSAMPLE2X | GANK_IN_RELU);
+  a.scale = scale;
+  return gank_igemm_dispatch(a, (hipStream_t)stream);
+}
+
+// ---- Deconv2D (common/ops/deconv2d.py:99-114): conv2d_transpose, stride 2, SAME ---------------------
+// fprop = zero-insertion of x + stride-1 conv with the flipped filter (the dgrad operand layout of the
+// filter viewed as HWIO [k,k,Cout,Cin]); dgrad = the stride-2 SAME conv itself.
+static int deconv_pad_before(int ks) { int t = ks - 2; if (t < 0) t = 0; return t / 2; }
+
+extern "C" int gank_deconv2d_fprop(const void* x, const void* wz, const float* bias, void* y, int N, int H, int W,
+                                   int Cin, int Cout, int ksize, void* stream) {
+  IgemmArgs a{};
+  a.x = (const bf16*)x; a.w = (const bf16*)wz; a.bias = bias; a.y = (bf16*)y;
+  a.N = N; a.H = 2 * H; a.W = 2 * W; a.Hin = H; a.Win = W;
+  a.Cin = Cin; a.Cout = Cout; a.ks = ksize;
+  a.pad = ksize - 1 - deconv_pad_before(ksize);
+  a.flags = IG_IN_ZEROINS2X;
+  a.scale = 1.f;
+  return gank_igemm_dispatch(a, (hipStream_t)stream);
+}
+
+extern "C" int gank_deconv2d_dgrad(const void* dy, const void* wfz, void* dx, int N, int H, int W, int Cin, int Cout,
+                                   int ksize, void* stream) {
+  IgemmArgs a{};
+  a.x = (const bf16*)dy; a.w = (const bf16*)wfz; a.y = (bf16*)dx;
+  a.N = N; a.H = H; a.W = W; a.Hin = 2 * H; a.Win = 2 * W;
+  a.Cin = Cout; a.Cout = Cin; a.ks = ksize; a.pad = deconv_pad_before(ksize);
+  a.flags = IG_IN_STRIDE2;
+  a.scale = 1.f;
+  return gank_igemm_dispatch(a, (hipStream_t)stream);
+}

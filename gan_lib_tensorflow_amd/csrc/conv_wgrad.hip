@@ -1,0 +1,300 @@
+// Filter-gradient (wgrad) implicit GEMM on v_mfma_f32_32x32x16_bf16 (gfx950).
+//
+//   dW[tap][ci][co] += scale * sum_m  Xg[m, tap][ci] * dY[m][co]          m = output pixel
+// GEMM view per tap: rows = ci (MFMA A operand), cols = co (MFMA B operand, on the lanes),
+// reduction = pixels.  Both operands live in HBM as [pixel][channel] (NHWC) but the MFMA wants 8
+// consecutive *pixels* per lane, so tiles are staged [pixel][32 channels] (64-byte rows, which makes
+// every 32-lane half of a transposed read cover 256 contiguous bytes = all 64 banks once) and read
+// with ds_read_b64_tr_b16 -- the hardware transpose, no shuffles.
+// The reduction over N*H*W pixels is split over blocks; partial tiles are combined with fp32
+// atomics into dW (caller zeroes / accumulates).
+// Replaces Conv2DBackpropFilter for common/ops/conv2d.py:180-187; the gather fuses NN-upsample,
+// relu, the mean-pool gradient (dy stored at half size) and the stride-2 form used by Deconv2D.
+#include "gank_common.h"
+
+#define WG_X_ZEROINS2X 16  // (unused here; kept aligned with conv_igemm flags)
+#define WG_X_STRIDE2 32
+
+struct WgradArgs {
+  const bf16* x;
+  const bf16* dy;
+  float* dw;
+  int N, H, W;        // pixel grid the reduction runs over (conv output size)
+  int Hx, Wx;         // stored x spatial
+  int Hdy, Wdy;       // stored dy spatial
+  int Cin, Cout;
+  int ks, pad, taps;
+  int M;
+  int flags;
+  float scale;
+  int tiles_ci, tiles_co, splits, steps_per_split;
+  int shw, sw;
+};
+
+__device__ __forceinline__ s16x4 lds_tr_read(const bf16* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+
+// WA x WB waves; each wave TA x TB MFMA tiles of 32(ci) x 32(co); 64 pixels per step
+template <int WA, int WB, int TA, int TB>
+__global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int NT = WA * WB * 64;
+  constexpr int CiT = WA * TA * 32, CoT = WB * TB * 32;
+  constexpr int SUBA = CiT / 32, SUBB = CoT / 32;     // 32-channel sub-tiles, each [64 pixels][32 ch] = 4 KB
+  constexpr int CHA = 64 * CiT / 8, CHB = 64 * CoT / 8;  // 16-byte chunks per step
+  constexpr int CPA = (CHA + NT - 1) / NT, CPB = (CHB + NT - 1) / NT;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* sA = reinterpret_cast<bf16*>(smem);          // [2][SUBA][64][32]
+  bf16* sB = sA + 2 * SUBA * 2048;                   // [2][SUBB][64][32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_a = wave % WA, wave_b = wave / WA;
+
+  int bid = blockIdx.x;
+  const int split = bid % a.splits; bid /= a.splits;
+  const int tco = bid % a.tiles_co; bid /= a.tiles_co;
+  const int tci = bid % a.tiles_ci; bid /= a.tiles_ci;
+  const int tap = bid;
+  const int dh = tap / a.ks - a.pad, dw = tap % a.ks - a.pad;
+  const int ci0 = tci * CiT, co0 = tco * CoT;
+
+  const bool xup = (a.flags & GANK_IN_UPSAMPLE2X) != 0;
+  const bool xrelu = (a.flags & GANK_IN_RELU) != 0;
+  const bool dyup = (a.flags & GANK_DY_UPSAMPLE2X) != 0;
+  const int st = (a.flags & WG_X_STRIDE2) ? 2 : 1;
+  const int LH = xup ? 2 * a.Hx : a.Hx, LW = xup ? 2 * a.Wx : a.Wx;
+  const bool fastA = (a.Cin % 8) == 0, fastB = (a.Cout % 8) == 0;
+
+  const int step0 = split * a.steps_per_split;
+  int nsteps = (a.M + 63) / 64 - step0;
+  if (nsteps > a.steps_per_split) nsteps = a.steps_per_split;
+
+  u32x4 rA[CPA], rB[CPB];
+
+  auto load_step = [&](int s) {
+    const int mbase = (step0 + s) * 64;
+#pragma unroll
+    for (int j = 0; j < CPA; j++) {
+      const int q = tid + NT * j;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (CHA % NT == 0 || q < CHA) {
+        const int p = q / (CiT / 8), cc = q % (CiT / 8);
+        const int m = mbase + p;
+        const int c = ci0 + cc * 8;
+        if (m < a.M && c < a.Cin) {
+          int n, oh, ow;
+          pix_decomp(m, a.H, a.W, a.shw, a.sw, n, oh, ow);
+          int ih = oh * st + dh, iw = ow * st + dw;
+          const bool ok = (unsigned)ih < (unsigned)LH && (unsigned)iw < (unsigned)LW;
+          if (xup) { ih >>= 1; iw >>= 1; }
+          if (ok) {
+            const long off = ((long)(n * a.Hx + ih) * a.Wx + iw) * a.Cin + c;
+            if (fastA) {
+              v = *reinterpret_cast<const u32x4*>(a.x + off);
+            } else {
+              bf16x8 t;
+#pragma unroll
+              for (int e = 0; e < 8; e++) t[e] = (c + e < a.Cin) ? a.x[off + e] : f2bf(0.f);
+              v = __builtin_bit_cast(u32x4, t);
+            }
+            if (xrelu) v = relu_bf16x8(v);
+          }
+        }
+      }
+      rA[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < CPB; j++) {
+      const int q = tid + NT * j;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (CHB % NT == 0 || q < CHB) {
+        const int p = q / (CoT / 8), cc = q % (CoT / 8);
+        const int m = mbase + p;
+        const int c = co0 + cc * 8;
+        if (m < a.M && c < a.Cout) {
+          int n, oh, ow;
+          pix_decomp(m, a.H, a.W, a.shw, a.sw, n, oh, ow);
+          if (dyup) { oh >>= 1; ow >>= 1; }
+          const long off = ((long)(n * a.Hdy + oh) * a.Wdy + ow) * a.Cout + c;
+          if (fastB) {
+            v = *reinterpret_cast<const u32x4*>(a.dy + off);
+          } else {
+            bf16x8 t;
+#pragma unroll
+            for (int e = 0; e < 8; e++) t[e] = (c + e < a.Cout) ? a.dy[off + e] : f2bf(0.f);
+            v = __builtin_bit_cast(u32x4, t);
+          }
+        }
+      }
+      rB[j] = v;
+    }
+  };
+
+  auto store_step = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < CPA; j++) {
+      const int q = tid + NT * j;
+      if (CHA % NT == 0 || q < CHA) {
+        const int p = q / (CiT / 8), cc = q % (CiT / 8);
+        *reinterpret_cast<u32x4*>(sA + ((buf * SUBA + (cc >> 2)) * 64 + p) * 32 + (cc & 3) * 8) = rA[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < CPB; j++) {
+      const int q = tid + NT * j;
+      if (CHB % NT == 0 || q < CHB) {
+        const int p = q / (CoT / 8), cc = q % (CoT / 8);
+        *reinterpret_cast<u32x4*>(sB + ((buf * SUBB + (cc >> 2)) * 64 + p) * 32 + (cc & 3) * 8) = rB[j];
+      }
+    }
+  };
+
+  f32x16 acc[TA][TB];
+#pragma unroll
+  for (int i = 0; i < TA; i++)
+#pragma unroll
+    for (int j = 0; j < TB; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+  // transposed-read lane geometry: 16-lane group g=(lane>>4): channel half g&1, k half g>>1;
+  // lane i of the group supplies row (pixel) i>>2, channels 4*(i&3).. of the 4x16 block
+  const int g = lane >> 4, li = lane & 15;
+  const int tr_off = ((8 * (g >> 1) + (li >> 2)) * 32) + 16 * (g & 1) + 4 * (li & 3);  // in bf16 elements
+
+  if (nsteps > 0) {
+    load_step(0);
+    store_step(0);
+  }
+  __syncthreads();
+
+  for (int s = 0; s < nsteps; s++) {
+    const int buf = s & 1;
+    if (s + 1 < nsteps) load_step(s + 1);
+    const bf16* pA = sA + (buf * SUBA + wave_a * TA) * 2048 + tr_off;
+    const bf16* pB = sB + (buf * SUBB + wave_b * TB) * 2048 + tr_off;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      bf16x8 fa[TA], fb[TB];
+#pragma unroll
+      for (int i = 0; i < TA; i++) {
+        const s16x4 lo = lds_tr_read(pA + i * 2048 + kk * 16 * 32);
+        const s16x4 hi = lds_tr_read(pA + i * 2048 + kk * 16 * 32 + 4 * 32);
+        const s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        fa[i] = __builtin_bit_cast(bf16x8, t);
+      }
+#pragma unroll
+      for (int j = 0; j < TB; j++) {
+        const s16x4 lo = lds_tr_read(pB + j * 2048 + kk * 16 * 32);
+        const s16x4 hi = lds_tr_read(pB + j * 2048 + kk * 16 * 32 + 4 * 32);
+        const s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        fb[j] = __builtin_bit_cast(bf16x8, t);
+      }
+#pragma unroll
+      for (int i = 0; i < TA; i++)
+#pragma unroll
+        for (int j = 0; j < TB; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (s + 1 < nsteps) store_step(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (nsteps <= 0) return;
+  // D[i][j]: row i = ci (reg&3)+8*(reg>>2)+4*(lane>>5), col j = co = lane&31
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < TA; i++) {
+#pragma unroll
+    for (int j = 0; j < TB; j++) {
+      const int co = co0 + (wave_b * TB + j) * 32 + r;
+      if (co >= a.Cout) continue;
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int ci = ci0 + (wave_a * TA + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (ci < a.Cin) atomicAdd(a.dw + ((long)tap * a.Cin + ci) * a.Cout + co, acc[i][j][e] * a.scale);
+      }
+    }
+  }
+}
+
+template <int WA, int WB, int TA, int TB>
+static int launch_wgrad(WgradArgs a, hipStream_t s) {
+  constexpr int CiT = WA * TA * 32, CoT = WB * TB * 32;
+  a.tiles_ci = cdiv(a.Cin, CiT);
+  a.tiles_co = cdiv(a.Cout, CoT);
+  const int total_steps = cdiv(a.M, 64);
+  const long tiles = (long)a.taps * a.tiles_ci * a.tiles_co;
+  // enough blocks to fill 256 CUs ~3x, but at least 4 pixel steps per block
+  int splits = (int)((768 + tiles - 1) / tiles);
+  if (splits > total_steps / 4) splits = total_steps / 4;
+  if (splits < 1) splits = 1;
+  a.steps_per_split = cdiv(total_steps, splits);
+  a.splits = cdiv(total_steps, a.steps_per_split);
+  const size_t lds = (size_t)2 * (CiT / 32 + CoT / 32) * 2048 * sizeof(bf16);
+  auto kern = conv_wgrad_kernel<WA, WB, TA, TB>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return gank_set_error("conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  const long grid = tiles * a.splits;
+  GANK_REQUIRE(grid < (1L << 30), "conv_wgrad: grid too large");
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WA * WB * 64), lds, s, a);
+  GANK_LAUNCH_OK("conv_wgrad");
+  return 0;
+}
+
+int gank_wgrad_dispatch(WgradArgs a, hipStream_t s) {
+  GANK_REQUIRE(a.x && a.dy && a.dw, "conv_wgrad: null pointer");
+  GANK_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Cin > 0 && a.Cout > 0, "conv_wgrad: bad shape");
+  GANK_REQUIRE(a.ks >= 1 && a.ks <= 7, "conv_wgrad: unsupported filter size %d", a.ks);
+  a.taps = a.ks * a.ks;
+  a.M = a.N * a.H * a.W;
+  a.sw = log2_or_neg(a.W);
+  a.shw = log2_or_neg(a.H * a.W);
+  GANK_REQUIRE((long)a.N * a.H * a.W < (1L << 31), "conv_wgrad: too many pixels");
+  const double flops = 2.0 * a.M * (double)a.Cout * a.taps * a.Cin;
+  gank_prof_begin(1, flops, s);
+  int rc;
+  if (a.Cin >= 128 && a.Cout >= 128) rc = launch_wgrad<2, 2, 2, 2>(a, s);
+  else if (a.Cin <= 32) rc = launch_wgrad<1, 4, 1, 1>(a, s);     // 32 ci x 128 co (image-side layers)
+  else if (a.Cout <= 32) rc = launch_wgrad<4, 1, 1, 1>(a, s);    // 128 ci x 32 co (G.Output, D.Output)
+  else rc = launch_wgrad<2, 2, 1, 1>(a, s);                      // 64 x 64
+  gank_prof_end(1, s);
+  return rc;
+}
+
+extern "C" int gank_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int Cout,
+                                 int ksize, int flags, float scale, void* stream) {
+  GANK_REQUIRE(ksize % 2 == 1, "conv2d_wgrad: even filter sizes are not on this path (ksize=%d)", ksize);
+  WgradArgs a{};
+  a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.dw = dw;
+  a.N = N; a.H = H; a.W = W;
+  const bool xup = flags & GANK_IN_UPSAMPLE2X, dyup = flags & GANK_DY_UPSAMPLE2X;
+  GANK_REQUIRE(!(xup || dyup) || (H % 2 == 0 && W % 2 == 0), "conv2d_wgrad: 2x flags need even size");
+  a.Hx = xup ? H / 2 : H; a.Wx = xup ? W / 2 : W;
+  a.Hdy = dyup ? H / 2 : H; a.Wdy = dyup ? W / 2 : W;
+  a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.pad = (ksize - 1) / 2;
+  a.flags = flags & (GANK_IN_UPSAMPLE2X | GANK_IN_RELU | GANK_DY_UPSAMPLE2X);
+  a.scale = scale;
+  return gank_wgrad_dispatch(a, (hipStream_t)stream);
+}
+
+// Deconv2D filter gradient: dF[a,b,co,ci] = sum dy[n,2p+a-pt,2q+b-pl,co] * x[n,p,q,ci]
+// = this engine with the gathered operand := dy (stride 2) and the plain operand := x.
+extern "C" int gank_deconv2d_wgrad(const void* x, const void* dy, float* df, int N, int H, int W, int Cin, int Cout,
+                                   int ksize, void* stream) {
+  WgradArgs a{};
+  a.x = (const bf16*)dy; a.dy = (const bf16*)x; a.dw = df;
+  a.N = N; a.H = H; a.W = W;
+  a.Hx = 2 * H; a.Wx = 2 * W; a.Hdy = H; a.Wdy = W;
+  a.Cin = Cout; a.Cout = Cin; a.ks = ksize;
+  int t = ksize - 2; if (t < 0) t = 0;
+  a.pad = t / 2;
+  a.flags = WG_X_STRIDE2;
+  a.scale = 1.f;
+  return gank_wgrad_dispatch(a, (hipStream_t)stream);
+}

@@ -1,0 +1,446 @@
+// HBM-bound glue kernels of the block library: weight layout preparation, resampling, activations,
+// pooling, concat/tile, embedding, casts, column sums.  All bf16 traffic is 16 B per lane whenever the
+// channel count allows (C % 8 == 0); a scalar path covers the 3-channel image side and odd sizes.
+#include "gank_common.h"
+
+static inline dim3 grid1d(long n, int block = 256, int cap = 4096) {
+  long g = (n + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return dim3((unsigned)g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight preparation (see gank.h)
+// ------------------------------------------------------------------------------------------------
+// wf[co][k] = w[k][co]  (k = tap*Cin+ci), zero padded to [CoutPad][Kpad]: 32x32 LDS-tiled transpose
+__global__ void prep_wf_kernel(const float* __restrict__ w, bf16* __restrict__ wf, int K, int Cout, int CoutPad, int Kpad) {
+  __shared__ float t[32][33];
+  const int k0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int k = k0 + i, c = c0 + tx;
+    t[i][tx] = (k < K && c < Cout) ? w[(long)k * Cout + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, k = k0 + tx;
+    if (c < CoutPad && k < Kpad) wf[(long)c * Kpad + k] = f2bf(t[tx][i]);
+  }
+}
+
+// wd[ci][tap'*Cout+co] = w[taps-1-tap'][ci][co], zero padded to [CinPad][Kpad2]
+__global__ void prep_wd_kernel(const float* __restrict__ w, bf16* __restrict__ wd, int taps, int Cin, int Cout, int CinPad, int Kpad2) {
+  const long total = (long)CinPad * Kpad2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i / Kpad2), k = (int)(i - (long)ci * Kpad2);
+    float v = 0.f;
+    if (ci < Cin && k < taps * Cout) {
+      const int tp = k / Cout, co = k - tp * Cout;
+      v = w[((long)(taps - 1 - tp) * Cin + ci) * Cout + co];
+    }
+    wd[i] = f2bf(v);
+  }
+}
+
+extern "C" int gank_conv2d_prep_weights(const float* w, void* wf, void* wd, int ksize, int Cin, int Cout, void* stream) {
+  GANK_REQUIRE(w && (wf || wd), "prep_weights: null pointer");
+  GANK_REQUIRE(ksize >= 1 && Cin > 0 && Cout > 0, "prep_weights: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  const int taps = ksize * ksize;
+  if (wf) {
+    const int K = taps * Cin, Kpad = roundup(K, 64), CoutPad = roundup(Cout, 32);
+    hipLaunchKernelGGL(prep_wf_kernel, dim3(Kpad / 32, CoutPad / 32), dim3(256), 0, s, w, (bf16*)wf, K, Cout, CoutPad, Kpad);
+    GANK_LAUNCH_OK("prep_wf");
+  }
+  if (wd) {
+    const int Kpad2 = roundup(taps * Cout, 64), CinPad = roundup(Cin, 32);
+    hipLaunchKernelGGL(prep_wd_kernel, grid1d((long)CinPad * Kpad2), dim3(256), 0, s, w, (bf16*)wd, taps, Cin, Cout, CinPad, Kpad2);
+    GANK_LAUNCH_OK("prep_wd");
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sum  out[c] += scale * sum_r x[r][c]
+// ------------------------------------------------------------------------------------------------
+__global__ void colsum_vec_kernel(const bf16* __restrict__ x, float* __restrict__ out, long rows, int C, float scale, long rows_per_block) {
+  // thread -> (8-channel group, row lane); C/8 groups must divide into 256 threads
+  const int cg = C >> 3;
+  const int RL = 256 / cg;
+  const int g = threadIdx.x % cg, rl = threadIdx.x / cg;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long r0 = blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  if (rl < RL) {
+    for (long r = r0 + rl; r < r1; r += RL) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + r * C + g * 8);
+#pragma unroll
+      for (int e = 0; e < 8; e++) acc[e] += bf2f(v[e]);
+    }
+  }
+  __shared__ float red[256 * 8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) red[threadIdx.x * 8 + e] = acc[e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int gg = c >> 3, e = c & 7;
+    float t = 0.f;
+    for (int l = 0; l < RL; l++) t += red[(l * cg + gg) * 8 + e];
+    atomicAdd(out + c, t * scale);
+  }
+}
+
+template <int CMAX>
+__global__ void colsum_small_kernel(const bf16* __restrict__ x, float* __restrict__ out, long rows, int C, float scale) {
+  float acc[CMAX];
+#pragma unroll
+  for (int c = 0; c < CMAX; c++) acc[c] = 0.f;
+  for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x)
+#pragma unroll
+    for (int c = 0; c < CMAX; c++)
+      if (c < C) acc[c] += bf2f(x[r * C + c]);
+  __shared__ float red[16];
+#pragma unroll
+  for (int c = 0; c < CMAX; c++) {
+    if (c < C) {
+      const float t = block_sum(acc[c], red);
+      if (threadIdx.x == 0) atomicAdd(out + c, t * scale);
+    }
+  }
+}
+
+__global__ void colsum_generic_kernel(const bf16* __restrict__ x, float* __restrict__ out, long rows, int C, float scale) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float t = 0.f;
+  for (long r = 0; r < rows; r++) t += bf2f(x[r * C + c]);
+  out[c] += t * scale;
+}
+
+extern "C" int gank_colsum_bf16(const void* x, float* out, long rows, int C, float scale, void* stream) {
+  GANK_REQUIRE(x && out && rows > 0 && C > 0, "colsum: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (C % 8 == 0 && 256 % (C / 8) == 0) {
+    long blocks = (rows + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    const long rpb = (rows + blocks - 1) / blocks;
+    blocks = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(colsum_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16*)x, out, rows, C, scale, rpb);
+  } else if (C <= 8) {
+    hipLaunchKernelGGL(colsum_small_kernel<8>, grid1d(rows, 256, 512), dim3(256), 0, s, (const bf16*)x, out, rows, C, scale);
+  } else {
+    hipLaunchKernelGGL(colsum_generic_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, (const bf16*)x, out, rows, C, scale);
+  }
+  GANK_LAUNCH_OK("colsum");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2x2 pooling / unpooling
+// ------------------------------------------------------------------------------------------------
+template <int V>  // V = 8 (vector) or 1 (scalar)
+__global__ void pool2x2_kernel(const bf16* __restrict__ x, const bf16* __restrict__ res, bf16* __restrict__ y,
+                               int N, int Ho, int Wo, int C, float scale) {
+  const int cg = C / V;
+  const long total = (long)N * Ho * Wo * cg;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % cg);
+    long p = i / cg;
+    const int ow = (int)(p % Wo); p /= Wo;
+    const int oh = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    const long ib = (((long)n * 2 * Ho + 2 * oh) * 2 * Wo + 2 * ow) * C + g * V;
+    const long rs = (long)2 * Wo * C;
+    const long ob = (((long)n * Ho + oh) * Wo + ow) * C + g * V;
+    if constexpr (V == 8) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(x + ib);
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(x + ib + C);
+      const bf16x8 c = *reinterpret_cast<const bf16x8*>(x + ib + rs);
+      const bf16x8 d = *reinterpret_cast<const bf16x8*>(x + ib + rs + C);
+      bf16x8 r8;
+      if (res) r8 = *reinterpret_cast<const bf16x8*>(res + ob);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        float v = (bf2f(a[e]) + bf2f(c[e]) + bf2f(b[e]) + bf2f(d[e])) * scale;  // order of tf.add_n at :120-121
+        if (res) v += bf2f(r8[e]);
+        o[e] = f2bf(v);
+      }
+      *reinterpret_cast<bf16x8*>(y + ob) = o;
+    } else {
+      float v = (bf2f(x[ib]) + bf2f(x[ib + rs]) + bf2f(x[ib + C]) + bf2f(x[ib + rs + C])) * scale;
+      if (res) v += bf2f(res[ob]);
+      y[ob] = f2bf(v);
+    }
+  }
+}
+
+extern "C" int gank_pool2x2(const void* x, const void* residual, void* y, int N, int Hout, int Wout, int C, float scale, void* stream) {
+  GANK_REQUIRE(x && y && N > 0 && Hout > 0 && Wout > 0 && C > 0, "pool2x2: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (C % 8 == 0)
+    hipLaunchKernelGGL(pool2x2_kernel<8>, grid1d((long)N * Hout * Wout * (C / 8)), dim3(256), 0, s, (const bf16*)x, (const bf16*)residual, (bf16*)y, N, Hout, Wout, C, scale);
+  else
+    hipLaunchKernelGGL(pool2x2_kernel<1>, grid1d((long)N * Hout * Wout * C), dim3(256), 0, s, (const bf16*)x, (const bf16*)residual, (bf16*)y, N, Hout, Wout, C, scale);
+  GANK_LAUNCH_OK("pool2x2");
+  return 0;
+}
+
+template <int V>
+__global__ void unpool2x2_add_kernel(const bf16* __restrict__ g, const bf16* __restrict__ base, bf16* __restrict__ y,
+                                     int N, int Hi, int Wi, int C, float scale) {
+  const int cg = C / V;
+  const int Ho = 2 * Hi, Wo = 2 * Wi;
+  const long total = (long)N * Ho * Wo * cg;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int gi = (int)(i % cg);
+    long p = i / cg;
+    const int ow = (int)(p % Wo); p /= Wo;
+    const int oh = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    const long ob = i * V;
+    const long ib = (((long)n * Hi + (oh >> 1)) * Wi + (ow >> 1)) * C + gi * V;
+    if constexpr (V == 8) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(g + ib);
+      bf16x8 b;
+      if (base) b = *reinterpret_cast<const bf16x8*>(base + ob);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = f2bf(bf2f(a[e]) * scale + (base ? bf2f(b[e]) : 0.f));
+      *reinterpret_cast<bf16x8*>(y + ob) = o;
+    } else {
+      y[ob] = f2bf(bf2f(g[ib]) * scale + (base ? bf2f(base[ob]) : 0.f));
+    }
+  }
+}
+
+extern "C" int gank_unpool2x2_add(const void* g, const void* base, void* y, int N, int Hin, int Win, int C, float scale, void* stream) {
+  GANK_REQUIRE(g && y && N > 0 && Hin > 0 && Win > 0 && C > 0, "unpool2x2_add: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (C % 8 == 0)
+    hipLaunchKernelGGL(unpool2x2_add_kernel<8>, grid1d((long)N * Hin * Win * 4 * (C / 8)), dim3(256), 0, s, (const bf16*)g, (const bf16*)base, (bf16*)y, N, Hin, Win, C, scale);
+  else
+    hipLaunchKernelGGL(unpool2x2_add_kernel<1>, grid1d((long)N * Hin * Win * 4 * C), dim3(256), 0, s, (const bf16*)g, (const bf16*)base, (bf16*)y, N, Hin, Win, C, scale);
+  GANK_LAUNCH_OK("unpool2x2_add");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// flat elementwise: processed 8 bf16 per lane with a scalar tail
+// ------------------------------------------------------------------------------------------------
+enum { EW_ADD = 0, EW_RELU_FWD, EW_RELU_BWD, EW_TANH_BWD };
+
+template <int OP>
+__device__ __forceinline__ float ew_apply(float a, float b, float p) {
+  if constexpr (OP == EW_ADD) return a + b;
+  if constexpr (OP == EW_RELU_FWD) return fmaxf(a, p * a);                // tf.maximum(x, leak*x); leak=0 -> relu
+  if constexpr (OP == EW_RELU_BWD) return (b > 0.f) ? a : p * a;          // a=dy, b=x
+  if constexpr (OP == EW_TANH_BWD) return a * (1.f - b * b);              // a=dy, b=y
+  return 0.f;
+}
+
+template <int OP, bool BIN>
+__global__ void ew_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ y, long n, float p) {
+  const long nv = n >> 3;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    const bf16x8 va = reinterpret_cast<const bf16x8*>(a)[i];
+    bf16x8 vb;
+    if constexpr (BIN) vb = reinterpret_cast<const bf16x8*>(b)[i];
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = f2bf(ew_apply<OP>(bf2f(va[e]), BIN ? bf2f(vb[e]) : 0.f, p));
+    reinterpret_cast<bf16x8*>(y)[i] = o;
+  }
+  if (blockIdx.x == 0) {
+    for (long i = (nv << 3) + threadIdx.x; i < n; i += blockDim.x)
+      y[i] = f2bf(ew_apply<OP>(bf2f(a[i]), BIN ? bf2f(b[i]) : 0.f, p));
+  }
+}
+
+#define EW_ENTRY(NAME, OP, BIN, A, B, P)                                                                   \
+  GANK_REQUIRE(A && y && n > 0, NAME ": bad arguments");                                                   \
+  hipLaunchKernelGGL((ew_kernel<OP, BIN>), grid1d(n / 8 + 1), dim3(256), 0, (hipStream_t)stream, (const bf16*)A, (const bf16*)B, (bf16*)y, n, P); \
+  GANK_LAUNCH_OK(NAME);                                                                                    \
+  return 0;
+
+extern "C" int gank_add_bf16(const void* a, const void* b, void* y, long n, void* stream) { EW_ENTRY("add", EW_ADD, true, a, b, 0.f) }
+extern "C" int gank_relu_fwd(const void* x, void* y, long n, float leak, void* stream) { EW_ENTRY("relu_fwd", EW_RELU_FWD, false, x, x, leak) }
+extern "C" int gank_relu_bwd(const void* dy, const void* x, void* y, long n, float leak, void* stream) { EW_ENTRY("relu_bwd", EW_RELU_BWD, true, dy, x, leak) }
+extern "C" int gank_tanh_bwd(const void* dy, const void* yy, void* y, long n, void* stream) { EW_ENTRY("tanh_bwd", EW_TANH_BWD, true, dy, yy, 0.f) }
+
+__global__ void scale_f32_kernel(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ y, long n) {
+  const float k = s[0];
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = x[i] * k;
+}
+extern "C" int gank_scale_f32(const float* x, const float* sc, float* y, long n, void* stream) {
+  GANK_REQUIRE(x && sc && y && n > 0, "scale_f32: bad arguments");
+  hipLaunchKernelGGL(scale_f32_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, x, sc, y, n);
+  GANK_LAUNCH_OK("scale_f32");
+  return 0;
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = f2bf(x[i]);
+}
+__global__ void cast_bf16_f32_kernel(const bf16* __restrict__ x, float* __restrict__ y, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = bf2f(x[i]);
+}
+extern "C" int gank_cast_f32_bf16(const float* x, void* y, long n, void* stream) {
+  GANK_REQUIRE(x && y && n > 0, "cast_f32_bf16: bad arguments");
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, x, (bf16*)y, n);
+  GANK_LAUNCH_OK("cast_f32_bf16");
+  return 0;
+}
+extern "C" int gank_cast_bf16_f32(const void* x, float* y, long n, void* stream) {
+  GANK_REQUIRE(x && y && n > 0, "cast_bf16_f32: bad arguments");
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, y, n);
+  GANK_LAUNCH_OK("cast_bf16_f32");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// relu + global mean pool over H,W:  x [N,HW,C] -> y [N,C]          (gan_cifar_resnet.py:299-301)
+// one block per sample; threads = (C/8 channel groups) x (row lanes)
+// ------------------------------------------------------------------------------------------------
+__global__ void relu_meanpool_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int HW, int C) {
+  const int n = blockIdx.x;
+  const int cg = C >> 3, RL = 256 / cg;
+  const int g = threadIdx.x % cg, rl = threadIdx.x / cg;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rl < RL)
+    for (int r = rl; r < HW; r += RL) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + ((long)n * HW + r) * C + g * 8);
+#pragma unroll
+      for (int e = 0; e < 8; e++) acc[e] += fmaxf(bf2f(v[e]), 0.f);
+    }
+  __shared__ float red[256 * 8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) red[threadIdx.x * 8 + e] = acc[e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t = 0.f;
+    for (int l = 0; l < RL; l++) t += red[(l * cg + (c >> 3)) * 8 + (c & 7)];
+    y[(long)n * C + c] = f2bf(t / (float)HW);
+  }
+}
+
+__global__ void relu_meanpool_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, bf16* __restrict__ dx, long total8, int HW, int C) {
+  const int cg = C >> 3;
+  const float inv = 1.f / (float)HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % cg);
+    const long n = (i / cg) / HW;
+    const bf16x8 xv = reinterpret_cast<const bf16x8*>(x)[i];
+    const bf16x8 gv = *reinterpret_cast<const bf16x8*>(dy + n * C + g * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = f2bf(bf2f(xv[e]) > 0.f ? bf2f(gv[e]) * inv : 0.f);
+    reinterpret_cast<bf16x8*>(dx)[i] = o;
+  }
+}
+
+extern "C" int gank_relu_meanpool_hw_fwd(const void* x, void* y, int N, int HW, int C, void* stream) {
+  GANK_REQUIRE(x && y && N > 0 && HW > 0, "relu_meanpool_fwd: bad arguments");
+  GANK_REQUIRE(C % 8 == 0 && 256 % (C / 8) == 0, "relu_meanpool_fwd: C=%d unsupported (need C%%8==0 and (C/8) | 256)", C);
+  hipLaunchKernelGGL(relu_meanpool_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, HW, C);
+  GANK_LAUNCH_OK("relu_meanpool_fwd");
+  return 0;
+}
+extern "C" int gank_relu_meanpool_hw_bwd(const void* dy, const void* x, void* dx, int N, int HW, int C, void* stream) {
+  GANK_REQUIRE(dy && x && dx && N > 0 && HW > 0 && C % 8 == 0, "relu_meanpool_bwd: bad arguments");
+  const long total8 = (long)N * HW * (C / 8);
+  hipLaunchKernelGGL(relu_meanpool_bwd_kernel, grid1d(total8), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, (const bf16*)x, (bf16*)dx, total8, HW, C);
+  GANK_LAUNCH_OK("relu_meanpool_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// concat(a, tile(e)) on channels                                     (gan_cifar_resnet.py:282-284)
+// ------------------------------------------------------------------------------------------------
+__global__ void concat_tile_fwd_kernel(const bf16* __restrict__ a, const bf16* __restrict__ e, bf16* __restrict__ y, long total8, int HW, int C1, int C2) {
+  const int cg = (C1 + C2) >> 3, cg1 = C1 >> 3;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % cg);
+    const long p = i / cg;  // n*HW + hw
+    bf16x8 v;
+    if (g < cg1) v = *reinterpret_cast<const bf16x8*>(a + p * C1 + g * 8);
+    else v = *reinterpret_cast<const bf16x8*>(e + (p / HW) * C2 + (g - cg1) * 8);
+    reinterpret_cast<bf16x8*>(y)[i] = v;
+  }
+}
+
+// da = dy[..., :C1] ; de[n, c] = sum_hw dy[n, hw, C1 + c]   (block per sample)
+__global__ void concat_tile_bwd_kernel(const bf16* __restrict__ dy, bf16* __restrict__ da, bf16* __restrict__ de, int HW, int C1, int C2) {
+  const int n = blockIdx.x, C = C1 + C2;
+  const int cg1 = C1 >> 3;
+  for (int i = threadIdx.x; i < HW * cg1; i += 256) {
+    const int g = i % cg1, r = i / cg1;
+    *reinterpret_cast<bf16x8*>(da + ((long)n * HW + r) * C1 + g * 8) = *reinterpret_cast<const bf16x8*>(dy + ((long)n * HW + r) * C + g * 8);
+  }
+  const int cg2 = C2 >> 3, RL = 256 / cg2;
+  const int g = threadIdx.x % cg2, rl = threadIdx.x / cg2;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rl < RL)
+    for (int r = rl; r < HW; r += RL) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(dy + ((long)n * HW + r) * C + C1 + g * 8);
+#pragma unroll
+      for (int e = 0; e < 8; e++) acc[e] += bf2f(v[e]);
+    }
+  __shared__ float red[256 * 8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) red[threadIdx.x * 8 + e] = acc[e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C2; c += 256) {
+    float t = 0.f;
+    for (int l = 0; l < RL; l++) t += red[(l * cg2 + (c >> 3)) * 8 + (c & 7)];
+    de[(long)n * C2 + c] = f2bf(t);
+  }
+}
+
+extern "C" int gank_concat_tile_fwd(const void* a, const void* e, void* y, int N, int HW, int C1, int C2, void* stream) {
+  GANK_REQUIRE(a && e && y && N > 0 && HW > 0, "concat_tile_fwd: bad arguments");
+  GANK_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0, "concat_tile_fwd: channel counts must be multiples of 8");
+  const long total8 = (long)N * HW * ((C1 + C2) / 8);
+  hipLaunchKernelGGL(concat_tile_fwd_kernel, grid1d(total8), dim3(256), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)e, (bf16*)y, total8, HW, C1, C2);
+  GANK_LAUNCH_OK("concat_tile_fwd");
+  return 0;
+}
+extern "C" int gank_concat_tile_bwd(const void* dy, void* da, void* de, int N, int HW, int C1, int C2, void* stream) {
+  GANK_REQUIRE(dy && da && de && N > 0 && HW > 0, "concat_tile_bwd: bad arguments");
+  GANK_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && 256 % (C2 / 8) == 0, "concat_tile_bwd: unsupported channel counts %d,%d", C1, C2);
+  hipLaunchKernelGGL(concat_tile_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, (bf16*)da, (bf16*)de, HW, C1, C2);
+  GANK_LAUNCH_OK("concat_tile_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// embedding lookup / dense gradient                                 (common/ops/embedding.py:51)
+// ------------------------------------------------------------------------------------------------
+__global__ void embedding_fwd_kernel(const float* __restrict__ table, const int* __restrict__ idx, bf16* __restrict__ y, long total, int D, int vocab) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / D), d = (int)(i - (long)n * D);
+    const int r = idx[n];
+    y[i] = f2bf((r >= 0 && r < vocab) ? table[(long)r * D + d] : 0.f);
+  }
+}
+__global__ void embedding_bwd_kernel(const bf16* __restrict__ dy, const int* __restrict__ idx, float* __restrict__ dtable, long total, int D, int vocab) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / D), d = (int)(i - (long)n * D);
+    const int r = idx[n];
+    if (r >= 0 && r < vocab) atomicAdd(dtable + (long)r * D + d, bf2f(dy[i]));
+  }
+}
+extern "C" int gank_embedding_fwd(const float* table, const int32_t* idx, void* y, int N, int D, int vocab, void* stream) {
+  GANK_REQUIRE(table && idx && y && N > 0 && D > 0 && vocab > 0, "embedding_fwd: bad arguments");
+  hipLaunchKernelGGL(embedding_fwd_kernel, grid1d((long)N * D), dim3(256), 0, (hipStream_t)stream, table, idx, (bf16*)y, (long)N * D, D, vocab);
+  GANK_LAUNCH_OK("embedding_fwd");
+  return 0;
+}
+extern "C" int gank_embedding_bwd(const void* dy, const int32_t* idx, float* dtable, int N, int D, int vocab, void* stream) {
+  GANK_REQUIRE(dy && idx && dtable && N > 0 && D > 0 && vocab > 0, "embedding_bwd: bad arguments");
+  hipLaunchKernelGGL(embedding_bwd_kernel, grid1d((long)N * D), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, idx, dtable, (long)N * D, D, vocab);
+  GANK_LAUNCH_OK("embedding_bwd");
+  return 0;
+}

@@ -1,0 +1,94 @@
+// Shared device/host helpers for libgank (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/gank.h"
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+int gank_set_error(const char* fmt, ...);
+
+#define GANK_REQUIRE(cond, ...)                       \
+  do {                                                \
+    if (!(cond)) return gank_set_error(__VA_ARGS__);  \
+  } while (0)
+
+#define GANK_LAUNCH_OK(name)                                                               \
+  do {                                                                                     \
+    hipError_t e__ = hipGetLastError();                                                    \
+    if (e__ != hipSuccess) return gank_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline int roundup(int a, int b) { return (a + b - 1) / b * b; }
+static inline int log2_or_neg(int v) { int s = 0; while ((1 << s) < v) s++; return ((1 << s) == v) ? s : -1; }
+
+// profiling hooks (api.hip)
+void gank_prof_begin(int family, double flops, hipStream_t s);
+void gank_prof_end(int family, hipStream_t s);
+
+#ifdef __HIPCC__
+__device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
+__device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }
+
+// relu on 8 packed bf16: as signed 16-bit ints, negative floats are negative ints (v_pk_max_i16)
+__device__ __forceinline__ u32x4 relu_bf16x8(u32x4 v) {
+  s16x8 s = __builtin_bit_cast(s16x8, v);
+  s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  s = __builtin_elementwise_max(s, z);
+  return __builtin_bit_cast(u32x4, s);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); `red` is >= 16 floats of LDS
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; i++) t += red[i];
+  return t;
+}
+
+// m -> (n, oh, ow) over an [N,H,W] pixel grid; shifts when H*W and W are powers of two (sw/shw >= 0)
+__device__ __forceinline__ void pix_decomp(int m, int H, int W, int shw, int sw, int& n, int& oh, int& ow) {
+  if (shw >= 0 && sw >= 0) {
+    n = m >> shw;
+    const int rem = m & ((1 << shw) - 1);
+    oh = rem >> sw;
+    ow = rem & ((1 << sw) - 1);
+  } else {
+    const int hw = H * W;
+    n = m / hw;
+    const int rem = m - n * hw;
+    oh = rem / W;
+    ow = rem - oh * W;
+  }
+}
+
+// XCD-aware bijective block remap (8 XCDs; consecutive logical ids share an XCD's L2)
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+#endif

@@ -1,0 +1,270 @@
+// Losses, TF-style Adam, the input pipeline and the graph-safe counter-based RNG.
+#include "gank_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// hinge / softmax-xent losses: loss value + d loss / d logits in one single-block launch
+// ------------------------------------------------------------------------------------------------
+__global__ void hinge_d_kernel(const bf16* __restrict__ l, float* __restrict__ loss, bf16* __restrict__ dl, int n, int n_real) {
+  __shared__ float red[16];
+  const int n_fake = n - n_real;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float v = bf2f(l[i]);
+    if (i < n_real) {  // mean(relu(1 - real))   gan_cifar_resnet.py:379
+      const float t = 1.f - v;
+      acc += fmaxf(t, 0.f) / (float)n_real;
+      dl[i] = f2bf(t > 0.f ? -1.f / (float)n_real : 0.f);
+    } else {           // mean(relu(1 + fake))   gan_cifar_resnet.py:380
+      const float t = 1.f + v;
+      acc += fmaxf(t, 0.f) / (float)n_fake;
+      dl[i] = f2bf(t > 0.f ? 1.f / (float)n_fake : 0.f);
+    }
+  }
+  const float tot = block_sum(acc, red);
+  if (threadIdx.x == 0) loss[0] = tot;
+}
+
+__global__ void hinge_g_kernel(const bf16* __restrict__ l, float* __restrict__ loss, bf16* __restrict__ dl, int n) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    acc += bf2f(l[i]);
+    dl[i] = f2bf(-1.f / (float)n);
+  }
+  const float tot = block_sum(acc, red);
+  if (threadIdx.x == 0) loss[0] = -tot / (float)n;  // -mean(disc_fake)   gan_cifar_resnet.py:492
+}
+
+__global__ void softmax_xent_kernel(const bf16* __restrict__ lg, const int* __restrict__ labels, float* __restrict__ loss,
+                                    bf16* __restrict__ dl, int n, int classes) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float mx = -3.0e38f;
+    for (int c = 0; c < classes; c++) mx = fmaxf(mx, bf2f(lg[(long)i * classes + c]));
+    float se = 0.f;
+    for (int c = 0; c < classes; c++) se += expf(bf2f(lg[(long)i * classes + c]) - mx);
+    const float lse = logf(se);
+    const int lb = labels[i];
+    for (int c = 0; c < classes; c++) {
+      const float z = bf2f(lg[(long)i * classes + c]) - mx - lse;
+      if (c == lb) acc -= z / (float)n;
+      dl[(long)i * classes + c] = f2bf((expf(z) - (c == lb ? 1.f : 0.f)) / (float)n);
+    }
+  }
+  const float tot = block_sum(acc, red);
+  if (threadIdx.x == 0) loss[0] = tot;
+}
+
+extern "C" int gank_hinge_d_loss(const void* logits, float* loss, void* dlogits, int n, int n_real, void* stream) {
+  GANK_REQUIRE(logits && loss && dlogits && n > 0 && n_real > 0 && n_real < n, "hinge_d_loss: bad arguments");
+  hipLaunchKernelGGL(hinge_d_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, loss, (bf16*)dlogits, n, n_real);
+  GANK_LAUNCH_OK("hinge_d_loss");
+  return 0;
+}
+extern "C" int gank_hinge_g_loss(const void* logits, float* loss, void* dlogits, int n, void* stream) {
+  GANK_REQUIRE(logits && loss && dlogits && n > 0, "hinge_g_loss: bad arguments");
+  hipLaunchKernelGGL(hinge_g_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, loss, (bf16*)dlogits, n);
+  GANK_LAUNCH_OK("hinge_g_loss");
+  return 0;
+}
+extern "C" int gank_softmax_xent(const void* logits, const int32_t* labels, float* loss, void* dlogits, int n, int classes, void* stream) {
+  GANK_REQUIRE(logits && labels && loss && dlogits && n > 0 && classes > 0, "softmax_xent: bad arguments");
+  hipLaunchKernelGGL(softmax_xent_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, labels, loss, (bf16*)dlogits, n, classes);
+  GANK_LAUNCH_OK("softmax_xent");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tf.train.AdamOptimizer over a flat fp32 buffer   (gan_cifar_resnet.py:521-526), step state on device
+// hp = {lr, beta1, beta2, eps, grad_scale, decay_on};  t_state[0] = steps taken so far;
+// iteration[0] = training iteration fed as `_iteration` (:320, :454-459).
+//   decay = iteration < 50000 ? max(0, 1 - iteration/100000) : 0.5          (if decay_on)
+//   lr_t  = lr * decay * sqrt(1 - beta2^t) / (1 - beta1^t),  t = t_state[0] + 1
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr_t m / (sqrt(v) + eps)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float adam_lr_t(const float* hp, const long long* t_state, const long long* iteration) {
+  const double t = (double)(t_state[0] + 1);
+  double lr = hp[0];
+  if (hp[5] != 0.f && iteration) {
+    const double it = (double)iteration[0];
+    lr *= (it < 50000.0) ? fmax(0.0, 1.0 - it / 100000.0) : 0.5;
+  }
+  return (float)(lr * sqrt(1.0 - pow((double)hp[2], t)) / (1.0 - pow((double)hp[1], t)));
+}
+
+__global__ void adam_tf_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                               const float* __restrict__ hp, const long long* __restrict__ t_state,
+                               const long long* __restrict__ iteration, long n) {
+  __shared__ float s_lr;
+  if (threadIdx.x == 0) s_lr = adam_lr_t(hp, t_state, iteration);
+  __syncthreads();
+  const float lr_t = s_lr, b1 = hp[1], b2 = hp[2], eps = hp[3], gs = hp[4];
+  const long n4 = n >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
+    const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const float gr = gg[e] * gs;
+      mm[e] = b1 * mm[e] + (1.f - b1) * gr;
+      vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
+      pp[e] -= lr_t * mm[e] / (sqrtf(vv[e]) + eps);
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pp;
+    reinterpret_cast<f32x4*>(m)[i] = mm;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+  }
+  if (blockIdx.x == 0)
+    for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) {
+      const float gr = g[i] * gs;
+      const float mm = b1 * m[i] + (1.f - b1) * gr;
+      const float vv = b2 * v[i] + (1.f - b2) * gr * gr;
+      m[i] = mm; v[i] = vv;
+      p[i] -= lr_t * mm / (sqrtf(vv) + eps);
+    }
+}
+
+__global__ void counter_add_kernel(long long* c, long long inc) { c[0] += inc; }
+
+extern "C" int gank_adam_tf(float* p, const float* g, float* m, float* v, const float* hp, int64_t* t_state,
+                            const int64_t* iteration, long n, void* stream) {
+  GANK_REQUIRE(p && g && m && v && hp && t_state && n > 0, "adam_tf: bad arguments");
+  GANK_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_tf: buffers must be 16-byte aligned");
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(adam_tf_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, hp, (const long long*)t_state,
+                     (const long long*)iteration, n);
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, s, (long long*)t_state, 1LL);
+  GANK_LAUNCH_OK("adam_tf");
+  return 0;
+}
+
+extern "C" int gank_counter_add(int64_t* counter, int64_t inc, void* stream) {
+  GANK_REQUIRE(counter, "counter_add: null pointer");
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long*)counter, (long long)inc);
+  GANK_LAUNCH_OK("counter_add");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 counter-based RNG; state = {seed, offset} in device memory, advanced on the device
+// ------------------------------------------------------------------------------------------------
+struct u4 { unsigned x, y, z, w; };
+
+__device__ __forceinline__ u4 philox4x32_10(unsigned long long ctr, unsigned long long stream_off, unsigned long long seed) {
+  unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = (unsigned)stream_off, c3 = (unsigned)(stream_off >> 32);
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return {c0, c1, c2, c3};
+}
+__device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }  // [0,1)
+
+__global__ void rng_advance_kernel(unsigned long long* state, unsigned long long inc) { state[1] += inc; }
+
+__global__ void rng_normal_kernel(bf16* __restrict__ y, long n, const unsigned long long* __restrict__ state) {
+  const unsigned long long seed = state[0], off = state[1];
+  const long n4 = (n + 3) >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const u4 r = philox4x32_10((unsigned long long)i, off, seed);
+    const float u1 = 1.f - u01(r.x), u2 = u01(r.y), u3 = 1.f - u01(r.z), u4_ = u01(r.w);  // (0,1]
+    const float ra = sqrtf(-2.f * logf(u1)), rb = sqrtf(-2.f * logf(u3));
+    const float z[4] = {ra * cosf(6.2831853f * u2), ra * sinf(6.2831853f * u2), rb * cosf(6.2831853f * u4_), rb * sinf(6.2831853f * u4_)};
+    for (int e = 0; e < 4; e++)
+      if (i * 4 + e < n) y[i * 4 + e] = f2bf(z[e]);
+  }
+}
+
+__global__ void rng_labels_kernel(int* __restrict__ y, long n, int n_labels, const unsigned long long* __restrict__ state) {
+  const unsigned long long seed = state[0], off = state[1];
+  const long n4 = (n + 3) >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const u4 r = philox4x32_10((unsigned long long)i, off, seed);
+    const unsigned v[4] = {r.x, r.y, r.z, r.w};
+    for (int e = 0; e < 4; e++)
+      if (i * 4 + e < n) {  // tf.cast(tf.random_uniform([n]) * 10, tf.int32)   gan_cifar_resnet.py:467
+        int lb = (int)(u01(v[e]) * (float)n_labels);
+        y[i * 4 + e] = lb >= n_labels ? n_labels - 1 : lb;
+      }
+  }
+}
+
+// uint8 CHW-planar [B,3072] -> bf16 HWC [B,32,32,3]:  2*(x/256 - .5) + U[0,1/128)   (gan_cifar_resnet.py:334-337)
+__global__ void preprocess_kernel(const unsigned char* __restrict__ data, bf16* __restrict__ y, int B, const unsigned long long* __restrict__ state) {
+  const unsigned long long seed = state[0], off = state[1];
+  const long n = (long)B * 3072, n4 = n >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const u4 r = philox4x32_10((unsigned long long)i, off, seed);
+    const unsigned v[4] = {r.x, r.y, r.z, r.w};
+    for (int e = 0; e < 4; e++) {
+      const long o = i * 4 + e;            // output index in HWC order
+      const int b = (int)(o / 3072), rem = (int)(o - (long)b * 3072);
+      const int c = rem % 3, hw = rem / 3;
+      const float px = (float)data[(long)b * 3072 + c * 1024 + hw];
+      y[o] = f2bf(2.f * (px / 256.f - .5f) + u01(v[e]) * (1.f / 128.f));
+    }
+  }
+}
+
+static int rng_advance(unsigned long long* state, unsigned long long inc, hipStream_t s) {
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, s, state, inc);
+  GANK_LAUNCH_OK("rng_advance");
+  return 0;
+}
+
+static inline dim3 rgrid(long n4) {
+  long g = (n4 + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return dim3((unsigned)g);
+}
+
+extern "C" int gank_rng_normal_bf16(void* y, long n, uint64_t* rng_state, void* stream) {
+  GANK_REQUIRE(y && rng_state && n > 0, "rng_normal: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(rng_normal_kernel, rgrid((n + 3) / 4), dim3(256), 0, s, (bf16*)y, n, (const unsigned long long*)rng_state);
+  GANK_LAUNCH_OK("rng_normal");
+  return rng_advance((unsigned long long*)rng_state, 1, s);
+}
+extern "C" int gank_rng_labels(int32_t* y, long n, int n_labels, uint64_t* rng_state, void* stream) {
+  GANK_REQUIRE(y && rng_state && n > 0 && n_labels > 0, "rng_labels: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(rng_labels_kernel, rgrid((n + 3) / 4), dim3(256), 0, s, y, n, n_labels, (const unsigned long long*)rng_state);
+  GANK_LAUNCH_OK("rng_labels");
+  return rng_advance((unsigned long long*)rng_state, 1, s);
+}
+extern "C" int gank_preprocess_real(const uint8_t* data, void* y, uint64_t* rng_state, int B, void* stream) {
+  GANK_REQUIRE(data && y && rng_state && B > 0, "preprocess_real: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(preprocess_kernel, rgrid((long)B * 768), dim3(256), 0, s, data, (bf16*)y, B, (const unsigned long long*)rng_state);
+  GANK_LAUNCH_OK("preprocess_real");
+  return rng_advance((unsigned long long*)rng_state, 1, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// debug: dump what ds_read_b64_tr_b16 returns for LDS image lds[i] = i (16-bit), lane l reading at
+// byte address 8*l.  out[l*4+e] = element e delivered to lane l.
+// ------------------------------------------------------------------------------------------------
+__global__ void tr_probe_kernel(int* out) {
+  __shared__ __attribute__((aligned(16))) short img[1024];
+  for (int i = threadIdx.x; i < 1024; i += 64) img[i] = (short)i;
+  __syncthreads();
+  const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + threadIdx.x * 4));
+  for (int e = 0; e < 4; e++) out[threadIdx.x * 4 + e] = t[e];
+}
+extern "C" int gank_debug_tr_probe(int32_t* out, void* stream) {
+  GANK_REQUIRE(out, "tr_probe: null pointer");
+  hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out);
+  GANK_LAUNCH_OK("tr_probe");
+  return 0;
+}

@@ -1,0 +1,333 @@
+"""torch.autograd glue over the HIP kernels (kernels.py).  Autograd is plumbing here: it only
+orders the kernel launches of the backward pass.  Conventions:
+
+* activations and their gradients are bf16 NHWC; weights and weight gradients fp32;
+* a weight that carries `.main_grad` (ParamStore.flatten) gets its gradient ACCUMULATED there by the
+  wgrad kernel and autograd receives None for it -- no per-parameter gradient tensors, no packing
+  before the optimiser or the RCCL all-reduce;
+* fan-out of an activation goes through `fork`, whose backward is the gank add kernel, so no
+  framework elementwise kernel runs anywhere in the step.
+"""
+import torch
+from torch.autograd import Function
+
+from . import kernels as K
+
+BF16 = torch.bfloat16
+
+
+def _target(p):
+    mg = getattr(p, "main_grad", None)
+    if mg is not None:
+        return mg, True
+    return torch.zeros_like(p), False
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _Conv2d(Function):
+    """conv2d SAME stride 1 with fused NN-upsample / relu on the input and bias / mean-pool /
+    residual / tanh on the output (common/ops/conv2d.py:180-216; gan_cifar_resnet.py:112-153)."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, residual, upsample, in_relu, pool_out, out_tanh):
+        if W.dim() == 2:
+            k, cin, cout = 1, W.shape[0], W.shape[1]
+        else:
+            k, cin, cout = W.shape[0], W.shape[2], W.shape[3]
+        assert x.dim() == 4 and x.shape[3] == cin, (tuple(x.shape), tuple(W.shape))
+        assert not (pool_out and (out_tanh or upsample))
+        n, h, w, _ = x.shape
+        H, Wd = (2 * h, 2 * w) if upsample else (h, w)
+        wf, _ = K.prep_weights(W.detach().view(k, k, cin, cout), True, False)
+        flags = (K.IN_UPSAMPLE2X if upsample else 0) | (K.IN_RELU if in_relu else 0) | (K.OUT_TANH if out_tanh else 0)
+        b = bias.detach() if bias is not None else None
+        if pool_out:
+            yfull = K.conv2d_fprop(x, wf, b, (H, Wd), cout, k, flags)
+            y = K.pool2x2(yfull, 0.25, residual)
+        else:
+            y = K.conv2d_fprop(x, wf, b, (H, Wd), cout, k, flags, 1.0, residual)
+        ctx.save_for_backward(x, W, y if out_tanh else None)
+        ctx.cfg = (k, cin, cout, H, Wd, upsample, in_relu, pool_out, out_tanh, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, y = ctx.saved_tensors
+        k, cin, cout, H, Wd, upsample, in_relu, pool_out, out_tanh, bias = ctx.cfg
+        g = _c(dy)
+        if out_tanh:
+            g = K.tanh_bwd(g, y)
+        scale = 0.25 if pool_out else 1.0
+        dW = db = dx = None
+        if ctx.needs_input_grad[1]:
+            tgt, acc = _target(W)
+            wflags = (K.IN_UPSAMPLE2X if upsample else 0) | (K.IN_RELU if in_relu else 0) | (K.DY_UPSAMPLE2X if pool_out else 0)
+            K.conv2d_wgrad(x, g, tgt, (H, Wd), k, wflags, scale)
+            dW = None if acc else tgt
+        if bias is not None and ctx.needs_input_grad[2]:
+            tgt, acc = _target(bias)
+            K.colsum(g, tgt, 1.0)
+            db = None if acc else tgt
+        if ctx.needs_input_grad[0]:
+            _, wd = K.prep_weights(W.detach().view(k, k, cin, cout), False, True)
+            dflags = K.IN_UPSAMPLE2X if pool_out else 0
+            if upsample:
+                dxf = K.conv2d_dgrad(g, wd, (H, Wd), cin, k, dflags, scale)
+                dx = K.pool2x2(dxf, 1.0)                      # gradient of the NN-upsample: 2x2 sum
+                if in_relu:
+                    dx = K.relu_bwd(dx, x)
+            else:
+                dx = K.conv2d_dgrad(g, wd, (H, Wd), cin, k, dflags, scale, None, x if in_relu else None)
+        dres = g if ctx.needs_input_grad[3] else None
+        return dx, dW, db, dres, None, None, None, None
+
+
+def conv2d(x, W, bias=None, residual=None, upsample=False, in_relu=False, pool_out=False, out_tanh=False):
+    return _Conv2d.apply(x, W, bias, residual, upsample, in_relu, pool_out, out_tanh)
+
+
+def linear(x, W, bias=None):
+    """x [n, Cin] bf16, W fp32 [Cin, Cout]: the 1x1 case of the conv engine."""
+    n = x.shape[0]
+    return _Conv2d.apply(x.view(n, 1, 1, x.shape[1]), W, bias, None, False, False, False, False).view(n, W.shape[1])
+
+
+class _SpectralNorm(Function):
+    """Batched spectral_normed_weight (common/ops/sn.py:15-69); backward = full gradient."""
+
+    @staticmethod
+    def forward(ctx, batch, *Ws):
+        ctx.batch = batch
+        outs = batch.forward()
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        batch = ctx.batch
+        tgts, rets, gl = [], [], []
+        for W, g, wb in zip(batch.weights, gs, batch.W_bar):
+            tgt, acc = _target(W)
+            tgts.append(tgt)
+            rets.append(None if acc else tgt)
+            gl.append(_c(g) if g is not None else torch.zeros_like(wb))
+        batch.backward(gl, tgts)
+        return (None, *rets)
+
+
+def spectral_norm_batch(Ws, us):
+    """Ws: fp32 weights (Cout last); us: fp32 [.., C] vectors READ by this call (pass snapshots if the
+    stored u is overwritten before backward).  Returns (W_bars tuple, SnBatch)."""
+    batch = K.SnBatch(list(Ws), [u.detach() for u in us])
+    outs = _SpectralNorm.apply(batch, *Ws)
+    return outs, batch
+
+
+class _CondBatchNorm(Function):
+    @staticmethod
+    def forward(ctx, x, labels, gamma, beta, groups, relu):
+        y, stats = K.cbn_fwd(x, labels, gamma.detach(), beta.detach(), groups, relu)
+        ctx.save_for_backward(x, y, labels, gamma, beta, stats)
+        ctx.cfg = (groups, relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, labels, gamma, beta, stats = ctx.saved_tensors
+        groups, relu = ctx.cfg
+        tg, accg = _target(gamma)
+        tb, accb = _target(beta)
+        dx = K.cbn_bwd(_c(dy), x, y, labels, gamma.detach(), stats, tg, tb, groups, relu)
+        return dx, None, (None if accg else tg), (None if accb else tb), None, None
+
+
+def cond_batchnorm(x, labels, gamma, beta, groups=1, relu=False):
+    return _CondBatchNorm.apply(x, labels, gamma, beta, groups, relu)
+
+
+class _Fork(Function):
+    """Explicit activation fan-out: two aliases forward, one add kernel backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None:
+            return gb
+        if gb is None:
+            return ga
+        return K.add(_c(ga), _c(gb))
+
+
+def fork(x):
+    if not x.requires_grad:
+        return x, x
+    return _Fork.apply(x)
+
+
+class _Relu(Function):
+    @staticmethod
+    def forward(ctx, x, leak):
+        ctx.save_for_backward(x)
+        ctx.leak = leak
+        return K.relu_fwd(x, leak)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return K.relu_bwd(_c(dy), x, ctx.leak), None
+
+
+def relu(x, leak=0.0):
+    return _Relu.apply(x, leak)
+
+
+class _MeanPool(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return K.pool2x2(x, 0.25)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return K.unpool2x2_add(_c(dy), None, 0.25)
+
+
+def meanpool2x2(x):
+    return _MeanPool.apply(x)
+
+
+class _Upsample(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return K.unpool2x2_add(x, None, 1.0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return K.pool2x2(_c(dy), 1.0)
+
+
+def upsample_nn2x(x):
+    return _Upsample.apply(x)
+
+
+class _Add(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return K.add(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+class _ReluMeanPoolHW(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return K.relu_meanpool_hw_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return K.relu_meanpool_hw_bwd(_c(dy), x)
+
+
+def relu_meanpool_hw(x):
+    return _ReluMeanPoolHW.apply(x)
+
+
+class _ConcatTile(Function):
+    @staticmethod
+    def forward(ctx, a, e):
+        ctx.c1 = a.shape[3]
+        return K.concat_tile_fwd(a, e)
+
+    @staticmethod
+    def backward(ctx, dy):
+        da, de = K.concat_tile_bwd(_c(dy), ctx.c1)
+        return da, de
+
+
+def concat_tile(a, e):
+    return _ConcatTile.apply(a, e)
+
+
+class _Embedding(Function):
+    @staticmethod
+    def forward(ctx, table, idx):
+        ctx.save_for_backward(table, idx)
+        return K.embedding_fwd(table.detach(), idx)
+
+    @staticmethod
+    def backward(ctx, dy):
+        table, idx = ctx.saved_tensors
+        tgt, acc = _target(table)
+        K.embedding_bwd(_c(dy), idx, tgt)
+        return (None if acc else tgt), None
+
+
+def embedding(table, idx):
+    return _Embedding.apply(table, idx)
+
+
+class _Loss(Function):
+    """loss value (fp32[1]) with d loss / d logits computed in the same forward launch."""
+
+    @staticmethod
+    def forward(ctx, logits, kind, arg):
+        if kind == "hinge_d":
+            loss, dl = K.hinge_d_loss(logits, arg)
+        elif kind == "hinge_g":
+            loss, dl = K.hinge_g_loss(logits)
+        elif kind == "xent":
+            loss, dl = K.softmax_xent(logits, arg)
+        else:
+            raise NotImplementedError(kind)
+        ctx.save_for_backward(dl)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        # g is d(total)/d(loss), fp32[1]; the step always calls backward() on the loss itself (g == 1),
+        # so the saved gradient is returned as is.  Scaled losses go through `scale_loss`.
+        return dl, None, None
+
+
+def hinge_d_loss(logits, n_real):
+    return _Loss.apply(logits, "hinge_d", n_real)
+
+
+def hinge_g_loss(logits):
+    return _Loss.apply(logits, "hinge_g", None)
+
+
+def softmax_xent(logits, labels):
+    return _Loss.apply(logits, "xent", labels)
+
+
+class _Cast(Function):
+    @staticmethod
+    def forward(ctx, x, to_bf16):
+        ctx.to_bf16 = to_bf16
+        return K.to_bf16(x) if to_bf16 else K.to_f32(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (K.to_f32(_c(g)) if ctx.to_bf16 else K.to_bf16(_c(g))), None
+
+
+def to_bf16(x):
+    return x if x.dtype == BF16 else _Cast.apply(x, True)
+
+
+def to_f32(x):
+    return x if x.dtype == torch.float32 else _Cast.apply(x, False)

@@ -1,0 +1,374 @@
+"""Tensor-level wrappers over the C ABI (include/gank.h).  torch is used for device memory and
+streams only: every function checks its operands, then enqueues HIP kernels from libgank.so on the
+current torch stream.  Nothing here has a CPU path."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, SnDesc  # noqa: F401
+
+BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t, dtype=None, name="tensor"):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"gank: {name} must live on the GPU (no CPU path exists)")
+    if not t.is_contiguous():
+        raise RuntimeError(f"gank: {name} must be contiguous, got strides {t.stride()} for {tuple(t.shape)}")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"gank: {name} must be {dtype}, got {t.dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+def _roundup(a, b):
+    return (a + b - 1) // b * b
+
+
+def lib():
+    return _lib.load()
+
+
+# ------------------------------------------------------------------ conv
+def prep_weights(w, want_f=True, want_d=False):
+    """w fp32 [k,k,Cin,Cout] -> (wf bf16 [CoutPad,Kpad] | None, wd bf16 [CinPad,Kpad'] | None)"""
+    k, _, cin, cout = w.shape
+    taps = k * k
+    wf = torch.empty((_roundup(cout, 32), _roundup(taps * cin, 64)), dtype=BF16, device=w.device) if want_f else None
+    wd = torch.empty((_roundup(cin, 32), _roundup(taps * cout, 64)), dtype=BF16, device=w.device) if want_d else None
+    _lib.check(lib().gank_conv2d_prep_weights(_p(w, F32, "w"), _p(wf), _p(wd), k, cin, cout, _stream()), "prep_weights")
+    return wf, wd
+
+
+def conv2d_fprop(x, wf, bias, out_hw, cout, ksize, flags=0, scale=1.0, residual=None, relu_ref=None):
+    n, cin = x.shape[0], x.shape[3]
+    h, w = out_hw
+    y = torch.empty((n, h, w, cout), dtype=BF16, device=x.device)
+    _lib.check(lib().gank_conv2d_fprop(_p(x, BF16, "x"), _p(wf, BF16, "wf"), _p(bias, F32, "bias"),
+                                       _p(residual, BF16, "residual"), _p(relu_ref, BF16, "relu_ref"), _p(y),
+                                       n, h, w, cin, cout, ksize, flags, scale, _stream()), "conv2d_fprop")
+    return y
+
+
+def conv2d_dgrad(dy, wd, out_hw, cin, ksize, flags=0, scale=1.0, residual=None, relu_ref=None):
+    n, cout = dy.shape[0], dy.shape[3]
+    h, w = out_hw
+    dx = torch.empty((n, h, w, cin), dtype=BF16, device=dy.device)
+    _lib.check(lib().gank_conv2d_dgrad(_p(dy, BF16, "dy"), _p(wd, BF16, "wd"), _p(residual, BF16, "residual"),
+                                       _p(relu_ref, BF16, "relu_ref"), _p(dx), n, h, w, cin, cout, ksize, flags,
+                                       scale, _stream()), "conv2d_dgrad")
+    return dx
+
+
+def conv2d_wgrad(x, dy, dw, hw, ksize, flags=0, scale=1.0):
+    """ACCUMULATES into dw fp32 [k,k,Cin,Cout]."""
+    n, cin, cout = x.shape[0], x.shape[3], dy.shape[3]
+    assert dw.shape[-2] == cin and dw.shape[-1] == cout, (dw.shape, cin, cout)
+    _lib.check(lib().gank_conv2d_wgrad(_p(x, BF16, "x"), _p(dy, BF16, "dy"), _p(dw, F32, "dw"), n, hw[0], hw[1],
+                                       cin, cout, ksize, flags, scale, _stream()), "conv2d_wgrad")
+    return dw
+
+
+def deconv2d_fprop(x, wz, bias, cout, ksize):
+    n, h, w, cin = x.shape
+    y = torch.empty((n, 2 * h, 2 * w, cout), dtype=BF16, device=x.device)
+    _lib.check(lib().gank_deconv2d_fprop(_p(x, BF16, "x"), _p(wz, BF16), _p(bias, F32), _p(y), n, h, w, cin, cout, ksize,
+                                         _stream()), "deconv2d_fprop")
+    return y
+
+
+def deconv2d_dgrad(dy, wfz, cin, ksize):
+    n, h2, w2, cout = dy.shape
+    dx = torch.empty((n, h2 // 2, w2 // 2, cin), dtype=BF16, device=dy.device)
+    _lib.check(lib().gank_deconv2d_dgrad(_p(dy, BF16, "dy"), _p(wfz, BF16), _p(dx), n, h2 // 2, w2 // 2, cin, cout, ksize,
+                                         _stream()), "deconv2d_dgrad")
+    return dx
+
+
+def deconv2d_wgrad(x, dy, df, ksize):
+    n, h, w, cin = x.shape
+    cout = dy.shape[3]
+    _lib.check(lib().gank_deconv2d_wgrad(_p(x, BF16, "x"), _p(dy, BF16, "dy"), _p(df, F32), n, h, w, cin, cout, ksize,
+                                         _stream()), "deconv2d_wgrad")
+    return df
+
+
+def colsum(x2d, out, scale=1.0):
+    """out[c] += scale * sum_r x[r,c];  x bf16 [rows,C] (any leading dims flattened), out fp32 [C]"""
+    c = x2d.shape[-1]
+    rows = x2d.numel() // c
+    _lib.check(lib().gank_colsum_bf16(_p(x2d, BF16, "x"), _p(out, F32, "out"), rows, c, scale, _stream()), "colsum")
+    return out
+
+
+# ------------------------------------------------------------------ spectral norm
+class SnBatch:
+    """Workspaces + descriptor table for one batched spectral-norm call over several weights."""
+
+    def __init__(self, weights, us):
+        self.weights, self.us = list(weights), list(us)
+        dev = self.weights[0].device
+        self.n = len(self.weights)
+        self.KC = [(w.numel() // w.shape[-1], w.shape[-1]) for w in self.weights]
+        tot = lambda f: sum(f(k, c) for k, c in self.KC)  # noqa: E731
+        self.W_bar = [torch.empty_like(w) for w in self.weights]
+        self.u_out = torch.empty(tot(lambda k, c: c), dtype=F32, device=dev)
+        self.v = torch.empty(tot(lambda k, c: k), dtype=F32, device=dev)
+        self.a = torch.empty_like(self.v)
+        self.b = torch.empty_like(self.u_out)
+        self.scal = torch.zeros(self.n * 8, dtype=F32, device=dev)
+        self.bpart = torch.empty(tot(lambda k, c: ((k + 63) // 64) * c), dtype=F32, device=dev)
+        self.rowdot = torch.empty_like(self.v)
+        self.ga = torch.empty_like(self.v)
+        self.table = (SnDesc * self.n)()
+        ko = co = bo = 0
+        for i, (w, u, (k, c)) in enumerate(zip(self.weights, self.us, self.KC)):
+            d = self.table[i]
+            d.W, d.u_in = _p(w, F32, "W").value, _p(u, F32, "u").value
+            assert u.numel() == c, (u.shape, c)
+            d.u_out = self.u_out.data_ptr() + 4 * co
+            d.v = self.v.data_ptr() + 4 * ko
+            d.W_bar = self.W_bar[i].data_ptr()
+            d.scal = self.scal.data_ptr() + 32 * i
+            d.a = self.a.data_ptr() + 4 * ko
+            d.b = self.b.data_ptr() + 4 * co
+            d.bpart = self.bpart.data_ptr() + 4 * bo
+            d.rowdot = self.rowdot.data_ptr() + 4 * ko
+            d.ga = self.ga.data_ptr() + 4 * ko
+            d.K, d.C = k, c
+            ko, co, bo = ko + k, co + c, bo + ((k + 63) // 64) * c
+        self._co = co
+
+    def forward(self):
+        _lib.check(lib().gank_sn_power_iter_fwd(self.table, self.n, _stream()), "sn_power_iter_fwd")
+        return self.W_bar
+
+    def u_out_views(self):
+        out, o = [], 0
+        for _, c in self.KC:
+            out.append(self.u_out[o:o + c])
+            o += c
+        return out
+
+    def sigma(self, i):
+        return self.scal[8 * i]
+
+    def backward(self, dW_bars, dWs):
+        """dWs[i] += full SN gradient of dW_bars[i] (accumulating)."""
+        for i, (g, d) in enumerate(zip(dW_bars, dWs)):
+            self.table[i].dW_bar = _p(g, F32, "dW_bar").value
+            self.table[i].dW = _p(d, F32, "dW").value
+        _lib.check(lib().gank_sn_power_iter_bwd(self.table, self.n, _stream()), "sn_power_iter_bwd")
+
+
+# ------------------------------------------------------------------ conditional batch norm
+def cbn_fwd(x, labels, gamma, beta, groups=1, relu=False):
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    parts = lib().gank_cbn_parts((n // groups) * hw)
+    y = torch.empty_like(x)
+    stats = torch.empty((groups, 2, c), dtype=F32, device=x.device)
+    ws = torch.empty(groups * parts * 3 * c, dtype=F32, device=x.device)
+    _lib.check(lib().gank_cbn_fwd(_p(x, BF16, "x"), _p(labels, I32, "labels"), _p(gamma, F32, "gamma"), _p(beta, F32, "beta"),
+                                  _p(y), _p(stats), _p(ws), n, hw, c, groups, gamma.shape[0], int(relu), _stream()), "cbn_fwd")
+    return y, stats
+
+
+def cbn_bwd(dy, x, y, labels, gamma, stats, dgamma, dbeta, groups=1, relu=False):
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    dx = torch.empty_like(x)
+    ws = torch.empty(n * 2 * c + groups * 2 * c, dtype=F32, device=x.device)
+    _lib.check(lib().gank_cbn_bwd(_p(dy, BF16, "dy"), _p(x, BF16, "x"), _p(y, BF16, "y"), _p(labels, I32, "labels"),
+                                  _p(gamma, F32, "gamma"), _p(stats, F32), _p(dx), _p(dgamma, F32, "dgamma"),
+                                  _p(dbeta, F32, "dbeta"), _p(ws), n, hw, c, groups, gamma.shape[0], int(relu), _stream()),
+               "cbn_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------ glue
+def pool2x2(x, scale=0.25, residual=None):
+    n, h, w, c = x.shape
+    y = torch.empty((n, h // 2, w // 2, c), dtype=BF16, device=x.device)
+    _lib.check(lib().gank_pool2x2(_p(x, BF16, "x"), _p(residual, BF16, "residual"), _p(y), n, h // 2, w // 2, c, scale, _stream()), "pool2x2")
+    return y
+
+
+def unpool2x2_add(g, base=None, scale=0.25):
+    n, h, w, c = g.shape
+    y = torch.empty((n, 2 * h, 2 * w, c), dtype=BF16, device=g.device)
+    _lib.check(lib().gank_unpool2x2_add(_p(g, BF16, "g"), _p(base, BF16, "base"), _p(y), n, h, w, c, scale, _stream()), "unpool2x2_add")
+    return y
+
+
+def add(a, b):
+    y = torch.empty_like(a)
+    _lib.check(lib().gank_add_bf16(_p(a, BF16, "a"), _p(b, BF16, "b"), _p(y), a.numel(), _stream()), "add")
+    return y
+
+
+def relu_fwd(x, leak=0.0):
+    y = torch.empty_like(x)
+    _lib.check(lib().gank_relu_fwd(_p(x, BF16, "x"), _p(y), x.numel(), leak, _stream()), "relu_fwd")
+    return y
+
+
+def relu_bwd(dy, x, leak=0.0):
+    dx = torch.empty_like(x)
+    _lib.check(lib().gank_relu_bwd(_p(dy, BF16, "dy"), _p(x, BF16, "x"), _p(dx), x.numel(), leak, _stream()), "relu_bwd")
+    return dx
+
+
+def tanh_bwd(dy, y):
+    dx = torch.empty_like(y)
+    _lib.check(lib().gank_tanh_bwd(_p(dy, BF16, "dy"), _p(y, BF16, "y"), _p(dx), y.numel(), _stream()), "tanh_bwd")
+    return dx
+
+
+def scale_f32(x, s):
+    y = torch.empty_like(x)
+    _lib.check(lib().gank_scale_f32(_p(x, F32, "x"), _p(s, F32, "s"), _p(y), x.numel(), _stream()), "scale_f32")
+    return y
+
+
+def to_bf16(x):
+    y = torch.empty(x.shape, dtype=BF16, device=x.device)
+    _lib.check(lib().gank_cast_f32_bf16(_p(x, F32, "x"), _p(y), x.numel(), _stream()), "cast_f32_bf16")
+    return y
+
+
+def to_f32(x):
+    y = torch.empty(x.shape, dtype=F32, device=x.device)
+    _lib.check(lib().gank_cast_bf16_f32(_p(x, BF16, "x"), _p(y), x.numel(), _stream()), "cast_bf16_f32")
+    return y
+
+
+def relu_meanpool_hw_fwd(x):
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    y = torch.empty((n, c), dtype=BF16, device=x.device)
+    _lib.check(lib().gank_relu_meanpool_hw_fwd(_p(x, BF16, "x"), _p(y), n, hw, c, _stream()), "relu_meanpool_fwd")
+    return y
+
+
+def relu_meanpool_hw_bwd(dy, x):
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    dx = torch.empty_like(x)
+    _lib.check(lib().gank_relu_meanpool_hw_bwd(_p(dy, BF16, "dy"), _p(x, BF16, "x"), _p(dx), n, hw, c, _stream()), "relu_meanpool_bwd")
+    return dx
+
+
+def concat_tile_fwd(a, e):
+    n, h, w, c1 = a.shape
+    c2 = e.shape[1]
+    y = torch.empty((n, h, w, c1 + c2), dtype=BF16, device=a.device)
+    _lib.check(lib().gank_concat_tile_fwd(_p(a, BF16, "a"), _p(e, BF16, "e"), _p(y), n, h * w, c1, c2, _stream()), "concat_tile_fwd")
+    return y
+
+
+def concat_tile_bwd(dy, c1):
+    n, h, w, c = dy.shape
+    da = torch.empty((n, h, w, c1), dtype=BF16, device=dy.device)
+    de = torch.empty((n, c - c1), dtype=BF16, device=dy.device)
+    _lib.check(lib().gank_concat_tile_bwd(_p(dy, BF16, "dy"), _p(da), _p(de), n, h * w, c1, c - c1, _stream()), "concat_tile_bwd")
+    return da, de
+
+
+def embedding_fwd(table, idx):
+    n, (vocab, d) = idx.numel(), table.shape
+    y = torch.empty((n, d), dtype=BF16, device=table.device)
+    _lib.check(lib().gank_embedding_fwd(_p(table, F32, "table"), _p(idx, I32, "idx"), _p(y), n, d, vocab, _stream()), "embedding_fwd")
+    return y
+
+
+def embedding_bwd(dy, idx, dtable):
+    n, (vocab, d) = idx.numel(), dtable.shape
+    _lib.check(lib().gank_embedding_bwd(_p(dy, BF16, "dy"), _p(idx, I32, "idx"), _p(dtable, F32, "dtable"), n, d, vocab, _stream()), "embedding_bwd")
+    return dtable
+
+
+# ------------------------------------------------------------------ losses / optimiser / input
+def hinge_d_loss(logits, n_real):
+    loss = torch.empty(1, dtype=F32, device=logits.device)
+    dl = torch.empty_like(logits)
+    _lib.check(lib().gank_hinge_d_loss(_p(logits, BF16, "logits"), _p(loss), _p(dl), logits.numel(), n_real, _stream()), "hinge_d_loss")
+    return loss, dl
+
+
+def hinge_g_loss(logits):
+    loss = torch.empty(1, dtype=F32, device=logits.device)
+    dl = torch.empty_like(logits)
+    _lib.check(lib().gank_hinge_g_loss(_p(logits, BF16, "logits"), _p(loss), _p(dl), logits.numel(), _stream()), "hinge_g_loss")
+    return loss, dl
+
+
+def softmax_xent(logits, labels):
+    n, classes = logits.shape
+    loss = torch.empty(1, dtype=F32, device=logits.device)
+    dl = torch.empty_like(logits)
+    _lib.check(lib().gank_softmax_xent(_p(logits, BF16, "logits"), _p(labels, I32, "labels"), _p(loss), _p(dl), n, classes, _stream()), "softmax_xent")
+    return loss, dl
+
+
+def adam_tf(p, g, m, v, hp, t_state, iteration=None):
+    """hp fp32[8] = {lr, beta1, beta2, eps, grad_scale, decay_on}; t_state int64[1]; iteration int64[1] | None"""
+    _lib.check(lib().gank_adam_tf(_p(p, F32, "p"), _p(g, F32, "g"), _p(m, F32, "m"), _p(v, F32, "v"), _p(hp, F32, "hp"),
+                                  _p(t_state, torch.int64, "t_state"), _p(iteration, torch.int64, "iteration"),
+                                  p.numel(), _stream()), "adam_tf")
+
+
+def counter_add(counter, inc=1):
+    _lib.check(lib().gank_counter_add(_p(counter, torch.int64, "counter"), int(inc), _stream()), "counter_add")
+
+
+def new_rng_state(seed, device):
+    """{seed, offset} uint64[2] on the device (stored as int64 bits)."""
+    return torch.tensor([int(seed) & ((1 << 63) - 1), 0], dtype=torch.int64, device=device)
+
+
+def preprocess_real(data_u8, rng_state):
+    b = data_u8.shape[0]
+    assert data_u8.dtype == torch.uint8 and data_u8.shape[1] == 3072
+    y = torch.empty((b, 32, 32, 3), dtype=BF16, device=data_u8.device)
+    _lib.check(lib().gank_preprocess_real(_p(data_u8, torch.uint8, "data"), _p(y), _p(rng_state, torch.int64), b, _stream()), "preprocess_real")
+    return y
+
+
+def rng_normal(shape, rng_state):
+    y = torch.empty(shape, dtype=BF16, device=rng_state.device)
+    _lib.check(lib().gank_rng_normal_bf16(_p(y), y.numel(), _p(rng_state, torch.int64), _stream()), "rng_normal")
+    return y
+
+
+def rng_labels(n, n_labels, rng_state):
+    y = torch.empty(n, dtype=I32, device=rng_state.device)
+    _lib.check(lib().gank_rng_labels(_p(y), n, n_labels, _p(rng_state, torch.int64), _stream()), "rng_labels")
+    return y
+
+
+def tr_probe(device):
+    out = torch.empty(256, dtype=I32, device=device)
+    _lib.check(lib().gank_debug_tr_probe(_p(out), _stream()), "tr_probe")
+    return out
+
+
+# ------------------------------------------------------------------ profiler
+def prof_enable(on):
+    lib().gank_prof_enable(int(on))
+
+
+def prof_reset():
+    lib().gank_prof_reset()
+
+
+def prof_collect(family):
+    ms, fl = C.c_double(0), C.c_double(0)
+    n = lib().gank_prof_collect(family, C.byref(ms), C.byref(fl))
+    return n, ms.value, fl.value

@@ -1,0 +1,205 @@
+/*
+ * gank.h -- C ABI of libgank.so: the MI355X (gfx950 / CDNA4) kernels behind the SNGAN-ResNet
+ * CIFAR-10 training hot path of watsonyanghx/GAN_Lib_Tensorflow.
+ *
+ * The reference has no FFI: every FLOP runs inside TensorFlow-1.5 ops called from Python
+ * (SURVEY.md section 8b).  Each entry point below therefore cites the reference Python call site
+ * whose TensorFlow op(s) it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch); the caller allocates outputs
+ *     and workspaces; nothing here allocates, frees or synchronises (hipGraph-capturable);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it asynchronously;
+ *   - activations are bf16, NHWC; master weights, gradients of weights, statistics, losses and
+ *     optimiser state are fp32; conv filters are HWIO ([k,k,Cin,Cout]); linear weights [in,out];
+ *     labels are int32;
+ *   - return value 0 = launched, non-zero = argument/launch error, message in gank_last_error();
+ *   - thread-compatible: no global mutable state besides the per-thread error string and the
+ *     opt-in profiling event pool (gank_prof_*).
+ */
+#ifndef GANK_H
+#define GANK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GANK_VERSION 100
+
+/* conv flags */
+#define GANK_IN_UPSAMPLE2X 1   /* input is [N,H/2,W/2,C]; nearest-neighbour 2x on the fly            */
+#define GANK_IN_RELU 2         /* relu applied to the input operand while staging                     */
+#define GANK_OUT_TANH 4        /* tanh applied last in the epilogue                                   */
+#define GANK_DY_UPSAMPLE2X 8   /* wgrad only: dy is [N,H/2,W/2,Cout] (gradient of a 2x2 mean pool)    */
+
+int gank_version(void);
+const char* gank_last_error(void);
+
+/* ---- weight preparation: fp32 HWIO master/normalised filter -> bf16 MFMA operand layouts --------
+ * wf [CoutPad][Kpad]  : wf[co][tap*Cin+ci]        = w[tap][ci][co]                (fprop operand)
+ * wd [CinPad ][Kpad'] : wd[ci][tap'*Cout+co]      = w[taps-1-tap'][ci][co]        (dgrad operand)
+ * CoutPad = roundup(Cout,32), Kpad = roundup(taps*Cin,64); CinPad/Kpad' likewise.  Either output may
+ * be NULL.  Replaces the implicit filter transforms inside tf.nn.conv2d / its gradient ops
+ * (common/ops/conv2d.py:180-187). */
+int gank_conv2d_prep_weights(const float* w, void* wf, void* wd, int ksize, int Cin, int Cout, void* stream);
+
+/* ---- conv2d forward: y = epilogue(conv_SAME_stride1(in(x), w) * scale + bias) --------------------
+ * Replaces tf.nn.conv2d + tf.nn.bias_add (common/ops/conv2d.py:180-187,212-216), with the
+ * surrounding graph ops of the block library fused behind flags: NN-upsample of UpsampleConv
+ * (SNGAN/gan_cifar_resnet.py:143-145), pre-activation relu (:186,:198), shortcut add (:209),
+ * tanh (:261).  Epilogue order: v=acc*scale+bias; if relu_ref: v=(relu_ref>0)?v:0; if residual:
+ * v+=residual; if OUT_TANH: v=tanh(v).  x [N,Hin,Win,Cin] bf16, wf from gank_conv2d_prep_weights,
+ * y/residual/relu_ref [N,H,W,Cout] bf16 where (H,W) is the OUTPUT size. Implicit-GEMM on
+ * v_mfma_f32_32x32x16_bf16, fp32 accumulate. */
+int gank_conv2d_fprop(const void* x, const void* wf, const float* bias, const void* residual,
+                      const void* relu_ref, void* y, int N, int H, int W, int Cin, int Cout, int ksize,
+                      int flags, float scale, void* stream);
+
+/* ---- conv2d input gradient: dx = epilogue(conv_SAME(in(dy), flip(w)^T) * scale) ------------------
+ * Replaces the Conv2DBackpropInput op TensorFlow autodiff emits for conv2d.py:180-187.  Same engine
+ * as fprop with the roles of Cin/Cout swapped and the wd layout; flags/epilogue as above
+ * (relu_ref implements the relu backward mask of the preceding nonlinearity; residual the gradient
+ * fan-in of the shortcut).  dy [N,Hin,Win,Cout], dx [N,H,W,Cin]. */
+int gank_conv2d_dgrad(const void* dy, const void* wd, const void* residual, const void* relu_ref, void* dx,
+                      int N, int H, int W, int Cin, int Cout, int ksize, int flags, float scale, void* stream);
+
+/* ---- conv2d filter gradient: dw[tap][ci][co] += scale * sum_pixels in(x)[p+tap][ci] * dy[p][co] --
+ * Replaces Conv2DBackpropFilter for conv2d.py:180-187.  ACCUMULATES (fp32 atomics, split over pixel
+ * ranges) into dw [k,k,Cin,Cout] -- zero it first for a plain gradient.  (H,W) is the conv OUTPUT
+ * size; x is [N,H,W,Cin] (or half-size with IN_UPSAMPLE2X), dy [N,H,W,Cout] (or half-size with
+ * DY_UPSAMPLE2X). */
+int gank_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int Cout,
+                      int ksize, int flags, float scale, void* stream);
+
+/* ---- Deconv2D (common/ops/deconv2d.py:99-114): tf.nn.conv2d_transpose stride 2 SAME --------------
+ * x [N,H,W,Cin] -> y [N,2H,2W,Cout]; master filter F fp32 [k,k,Cout,Cin].  The op has no caller in
+ * the reference; it is provided at op level on the same two MFMA engines:
+ *   fprop = zero-insertion gather + stride-1 conv with the flipped filter; its operand wz is the `wd`
+ *           output of gank_conv2d_prep_weights(F, ksize, Cin:=Cout, Cout:=Cin)   (F viewed as HWIO);
+ *   dgrad = the stride-2 SAME conv; its operand wfz is the `wf` output of the same prep call;
+ *   wgrad accumulates into dF [k,k,Cout,Cin]. */
+int gank_deconv2d_fprop(const void* x, const void* wz, const float* bias, void* y, int N, int H, int W,
+                        int Cin, int Cout, int ksize, void* stream);
+int gank_deconv2d_dgrad(const void* dy, const void* wfz, void* dx, int N, int H, int W, int Cin, int Cout,
+                        int ksize, void* stream);
+int gank_deconv2d_wgrad(const void* x, const void* dy, float* df, int N, int H, int W, int Cin, int Cout,
+                        int ksize, void* stream);
+
+/* ---- column sum: out[c] += scale * sum_rows x[r][c]   (bias gradients; tf.nn.bias_add grad) ------ */
+int gank_colsum_bf16(const void* x, float* out, long rows, int C, float scale, void* stream);
+
+/* ---- spectral normalisation (common/ops/sn.py:15-69) ---------------------------------------------
+ * Batched over `count` weights described by a HOST array of gank_sn_desc (copied into the kernel
+ * arguments, 16 per launch group: no device table, capturable).  One power
+ * iteration from u_in: a=W u, v=a/(|a|+eps); b=W^T v, u'=b/(|b|+eps); sigma=v W u'^T; W_bar=W/sigma.
+ * fwd writes W_bar (fp32, same shape), v, u_out, and {sigma, |a|, |b|} to `scal`.  The caller copies
+ * u_out over u only under update_collection=None (sn.py:55-56); NO_OPS never writes u (sn.py:62-65).
+ * bwd is the FULL gradient through the iteration (no stop_gradient in sn.py:34-61) and ACCUMULATES
+ * into dW.  Workspaces: `a` [K], `bpart` [ceil(K/64)*C], `rowdot` [K], `ga` [K] per weight. */
+typedef struct gank_sn_desc {
+  const float* W;      /* [K,C] master weight                                   */
+  const float* u_in;   /* [C]                                                    */
+  float* u_out;        /* [C]                                                    */
+  float* v;            /* [K]                                                    */
+  float* W_bar;        /* [K,C]                                                  */
+  float* scal;         /* [8]: sigma, n=|a|, m=|b|, s, <G,W>, a.g_v, -, -        */
+  float* a;            /* [K]   workspace, kept for backward                     */
+  float* b;            /* [C]   kept for backward                                */
+  float* bpart;        /* [ceil(K/64)*C] workspace                               */
+  const float* dW_bar; /* [K,C] backward input                                   */
+  float* dW;           /* [K,C] backward output (accumulated)                    */
+  float* rowdot;       /* [K]   workspace                                        */
+  float* ga;           /* [K]   workspace                                        */
+  int K, C;
+  int row_offset;      /* filled by the library                                  */
+  int chunk_offset;    /* filled by the library                                  */
+} gank_sn_desc;
+int gank_sn_power_iter_fwd(const gank_sn_desc* table, int count, void* stream);
+int gank_sn_power_iter_bwd(const gank_sn_desc* table, int count, void* stream);
+
+/* ---- conditional batch norm (common/ops/normalization.py:27-59) ----------------------------------
+ * Batch moments over (N/groups, H, W) per tower (biased variance, eps 1e-5), per-sample gamma/beta
+ * rows gathered by label from [n_labels,C] tables.  `groups` towers of N/groups consecutive samples
+ * have independent statistics (one Generator() call per tower in the reference,
+ * SNGAN/gan_cifar_resnet.py:326-332,464-482).  relu!=0 fuses the following nonlinearity (:186).
+ * fwd: x,y bf16 [N,HW,C]; stats fp32 [groups][2][C] (mean, invstd); ws >= groups*parts*3*C floats
+ * with parts = gank_cbn_parts(N/groups*HW).  bwd: dy (gradient w.r.t. y; masked by y>0 when relu),
+ * writes dx and ACCUMULATES dgamma/dbeta [n_labels,C]; ws >= N*2*C + groups*2*C floats. */
+int gank_cbn_parts(long rows_per_group);
+int gank_cbn_fwd(const void* x, const int32_t* labels, const float* gamma, const float* beta, void* y,
+                 float* stats, float* ws, int N, int HW, int C, int groups, int n_labels, int relu, void* stream);
+int gank_cbn_bwd(const void* dy, const void* x, const void* y, const int32_t* labels, const float* gamma,
+                 const float* stats, void* dx, float* dgamma, float* dbeta, float* ws, int N, int HW, int C,
+                 int groups, int n_labels, int relu, void* stream);
+
+/* ---- resampling / elementwise glue of the block library ------------------------------------------
+ * pool2x2: y = scale * (sum of the 2x2 window) (+ residual)   -- tf.add_n(...)/4. at
+ *          gan_cifar_resnet.py:120-121,129-130 with scale=.25; scale=1 is the NN-upsample gradient.
+ * unpool2x2_add: y = base + scale * nn_upsample2x(g)            -- gradient of the mean pool. */
+int gank_pool2x2(const void* x, const void* residual, void* y, int N, int Hout, int Wout, int C, float scale, void* stream);
+int gank_unpool2x2_add(const void* g, const void* base, void* y, int N, int Hin, int Win, int C, float scale, void* stream);
+int gank_add_bf16(const void* a, const void* b, void* y, long n, void* stream);
+int gank_relu_fwd(const void* x, void* y, long n, float leak, void* stream);           /* gan_cifar_resnet.py:80-85 */
+int gank_relu_bwd(const void* dy, const void* x, void* dx, long n, float leak, void* stream);
+int gank_tanh_bwd(const void* dy, const void* y, void* dx, long n, void* stream);      /* tf.tanh grad, :261 */
+int gank_scale_f32(const float* x, const float* s, float* y, long n, void* stream);    /* y = x * s[0] */
+int gank_cast_f32_bf16(const float* x, void* y, long n, void* stream);
+int gank_cast_bf16_f32(const void* x, float* y, long n, void* stream);
+
+/* relu + tf.reduce_mean(axis=[1,2])  (gan_cifar_resnet.py:299-301): x [N,HW,C] -> y [N,C] */
+int gank_relu_meanpool_hw_fwd(const void* x, void* y, int N, int HW, int C, void* stream);
+int gank_relu_meanpool_hw_bwd(const void* dy, const void* x, void* dx, int N, int HW, int C, void* stream);
+
+/* expand_dims x2 + tf.tile + tf.concat(axis=3)  (gan_cifar_resnet.py:282-284):
+ * y[n,hw,:C1]=a[n,hw,:], y[n,hw,C1:]=e[n,:].  bwd: da = dy[..,:C1], de[n,:] = sum_hw dy[n,hw,C1:]. */
+int gank_concat_tile_fwd(const void* a, const void* e, void* y, int N, int HW, int C1, int C2, void* stream);
+int gank_concat_tile_bwd(const void* dy, void* da, void* de, int N, int HW, int C1, int C2, void* stream);
+
+/* tf.nn.embedding_lookup (common/ops/embedding.py:51) and its IndexedSlices gradient (dense, accumulated) */
+int gank_embedding_fwd(const float* table, const int32_t* idx, void* y, int N, int D, int vocab, void* stream);
+int gank_embedding_bwd(const void* dy, const int32_t* idx, float* dtable, int N, int D, int vocab, void* stream);
+
+/* ---- losses (loss value fp32[1] and d loss/d logits bf16 in one launch) --------------------------
+ * hinge_d: mean(relu(1-l[:n_real])) + mean(relu(1+l[n_real:]))   (gan_cifar_resnet.py:362-363,379-381)
+ * hinge_g: -mean(l)                                               (gan_cifar_resnet.py:492)
+ * softmax_xent: mean sparse softmax cross-entropy                 (gan_cifar_resnet.py:390-394) */
+int gank_hinge_d_loss(const void* logits, float* loss, void* dlogits, int n, int n_real, void* stream);
+int gank_hinge_g_loss(const void* logits, float* loss, void* dlogits, int n, void* stream);
+int gank_softmax_xent(const void* logits, const int32_t* labels, float* loss, void* dlogits, int n, int classes, void* stream);
+
+/* ---- tf.train.AdamOptimizer (gan_cifar_resnet.py:521-526), one launch over a flat buffer ---------
+ * All step state lives on the device so a captured update replays without host traffic:
+ * hp (float[8]) = {lr, beta1, beta2, eps, grad_scale, decay_on}; t_state[0] = updates applied so far
+ * (incremented by this call); iteration[0] = the `_iteration` feed (:320) driving the LR decay
+ * (:454-459), may be NULL.  lr_t = lr*decay*sqrt(1-b2^t)/(1-b1^t); g is multiplied by grad_scale
+ * first (1/world_size after a sum all-reduce).  gank_counter_add advances a device counter. */
+int gank_adam_tf(float* p, const float* g, float* m, float* v, const float* hp, int64_t* t_state,
+                 const int64_t* iteration, long n, void* stream);
+int gank_counter_add(int64_t* counter, int64_t inc, void* stream);
+
+/* ---- input pipeline (gan_cifar_resnet.py:334-337) and graph-safe RNG -----------------------------
+ * preprocess: uint8 CHW-planar rows [B,3072] -> bf16 HWC rows: 2*(x/256-.5) + U[0,1/128).
+ * RNG is counter based (Philox4x32-10): `state` (device, uint64[2] = {seed, offset}); each call
+ * consumes and advances the offset on the device, so a captured graph draws fresh numbers per replay
+ * (tf.random_normal :240, tf.random_uniform :335,:467). */
+int gank_preprocess_real(const uint8_t* data, void* y, uint64_t* rng_state, int B, void* stream);
+int gank_rng_normal_bf16(void* y, long n, uint64_t* rng_state, void* stream);
+int gank_rng_labels(int32_t* y, long n, int n_labels, uint64_t* rng_state, void* stream);
+
+/* ---- opt-in per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ------- */
+int gank_prof_enable(int on);
+int gank_prof_reset(void);
+/* fills up to `cap` records {launches, total_ms, total_flops} for kernel family `family`
+ * (0 = conv_fprop/dgrad igemm, 1 = conv_wgrad); synchronises.  Returns number of launches. */
+int gank_prof_collect(int family, double* total_ms, double* total_flops);
+
+/* debug: what ds_read_b64_tr_b16 delivers for a known LDS image (layout self-check) */
+int gank_debug_tr_probe(int32_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GANK_H */

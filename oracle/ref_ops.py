@@ -59,7 +59,7 @@ def conv2d_same_grads(x, w, dy, stride=1):
             sl = (slice(None), slice(i, i + (oh - 1) * stride + 1, stride),
                   slice(j, j + (ow - 1) * stride + 1, stride), slice(None))
             dxp[sl] += dy @ w[i, j].T
-            dw[i, j] = np.einsum('nhwc,nhwd->cd', xp[sl], dy)
+            dw[i, j] = xp[sl].reshape(-1, ci).T @ dy.reshape(-1, co)
     dx = dxp[:, pt:pt + h, pl:pl + wd, :]
     db = dy.sum(axis=(0, 1, 2))
     return dx, dw, db

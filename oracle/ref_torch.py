@@ -241,12 +241,13 @@ def preprocess_real(data_u8, deq_noise, dtype):
     return x.reshape(b, 3, 32, 32).permute(0, 2, 3, 1).reshape(b, 3072)
 
 
-def d_loss_fn(P, real_u8, labels, z, deq_noise, towers=2):
+def d_loss_fn(P, real_u8, labels, z, deq_noise, towers=2, real_pre=None):
     """One D-step loss (gan_cifar_resnet.py:326-381): fakes from `towers` Generator calls of
-    B/towers samples each, conditioned on the REAL labels; D on concat(real, fake)."""
+    B/towers samples each, conditioned on the REAL labels; D on concat(real, fake).
+    `real_pre` (already preprocessed [B,3072]) overrides real_u8/deq_noise when given."""
     dtype = z.dtype
     fake = generator(P, z, labels, groups=towers)
-    real = preprocess_real(real_u8, deq_noise, dtype)
+    real = preprocess_real(real_u8, deq_noise, dtype) if real_pre is None else real_pre
     logits, new_u = discriminator(P, torch.cat([real, fake], 0), torch.cat([labels, labels], 0))
     b = real.shape[0]
     loss = torch.relu(1. - logits[:b]).mean() + torch.relu(1. + logits[b:]).mean()
@@ -298,8 +299,8 @@ class Trainer:
         self.d_names = trainable_names(P, 'Discriminator')
         self.g_opt, self.d_opt = AdamTF(self.g_names), AdamTF(self.d_names)
 
-    def d_step(self, iteration, real_u8, labels, z, deq_noise):
-        loss, new_u, _ = d_loss_fn(self.P, real_u8, labels, z, deq_noise)
+    def d_step(self, iteration, real_u8, labels, z, deq_noise, real_pre=None):
+        loss, new_u, _ = d_loss_fn(self.P, real_u8, labels, z, deq_noise, real_pre=real_pre)
         grads = torch.autograd.grad(loss, [self.P[k] for k in self.d_names])
         with torch.no_grad():
             for k, u in new_u.items():          # update_collection=None: u <- u_final (sn.py:55-56)

@@ -1,0 +1,337 @@
+"""HIP kernels (through the C ABI) vs the float64 oracle, on a real MI355X.
+
+Tolerances (stated per the bf16 compute path; the reference arithmetic is fp32):
+  * inputs are drawn in fp32 and ROUNDED TO bf16 first, and the oracle gets the rounded values, so
+    the comparison isolates kernel arithmetic (fp32 accumulate) + one bf16 output rounding;
+  * bf16 outputs: max|hip-ref| <= 1e-2 * max|ref|  (bf16 has 2^-9 relative rounding; K up to 9216);
+  * fp32 outputs from bf16 operands (wgrad, bias grad, statistics): <= 2e-3 * max|ref|;
+  * pure fp32 kernels (spectral norm, Adam): <= 1e-5 relative.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+
+BF_TOL = 1e-2
+F32_FROM_BF_TOL = 2e-3
+
+
+@pytest.fixture(scope="module")
+def K():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from gan_lib_tensorflow_amd import kernels
+    kernels.lib()
+    return kernels
+
+
+def bf(a):
+    """fp32 ndarray -> (bf16-rounded float64 ndarray, bf16 cuda tensor)"""
+    t = torch.tensor(np.asarray(a, np.float32)).to(torch.bfloat16)
+    return t.to(torch.float64).numpy(), t.cuda().contiguous()
+
+
+def f32(a):
+    t = torch.tensor(np.asarray(a, np.float32))
+    return t.to(torch.float64).numpy(), t.cuda().contiguous()
+
+
+def relerr(got, ref):
+    got = got.detach().to(torch.float64).cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert np.isfinite(got).all(), "non-finite output"
+    return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+def test_tr_read_semantics(K):
+    """ds_read_b64_tr_b16: lane i of each 16-lane group receives column i of the 4x16 block."""
+    out = K.tr_probe("cuda").cpu().numpy().reshape(64, 4)
+    for lane in range(64):
+        g, i = lane // 16, lane % 16
+        np.testing.assert_array_equal(out[lane], [64 * g + 16 * q + i for q in range(4)])
+
+
+CONV_CASES = [
+    # n, h, cin, cout, k, flags-name
+    (2, 8, 64, 64, 3, ""),
+    (2, 8, 128, 128, 3, "relu"),
+    (3, 8, 64, 128, 1, ""),
+    (2, 4, 64, 64, 3, "up"),          # input 4x4 -> output 8x8
+    (2, 16, 256, 256, 3, ""),         # 128x128-tile config needs >=192 tiles: M=512 -> uses 64x64
+    (64, 16, 256, 256, 3, ""),        # M=16384 -> 128x128 tiles
+    (2, 8, 256, 3, 3, "tanh"),        # G.Output shape class (Cout=3, padded to 32)
+    (2, 8, 3, 128, 3, ""),            # D.Block.1.Conv1 class (Cin=3, packed K)
+    (2, 8, 3, 128, 1, ""),            # D.Block.1.Shortcut class
+    (5, 1, 300, 128, 1, ""),          # D.Embedding_y linear (K=300 packed)
+    (7, 1, 128, 1, 1, ""),            # D.Output linear
+    (3, 6, 64, 96, 3, ""),            # non power-of-two spatial size, Cout=96 (3 tiles of 32)
+]
+
+
+@pytest.mark.parametrize("n,h,cin,cout,k,mode", CONV_CASES)
+def test_conv_fprop(K, n, h, cin, cout, k, mode):
+    rng = np.random.default_rng(n * 1000 + cin + cout + k)
+    x, xt = bf(rng.normal(size=(n, h, h, cin)))
+    w, _ = bf(rng.normal(size=(k, k, cin, cout)) / np.sqrt(k * k * cin))
+    b, bt = f32(rng.normal(size=cout))
+    wt = torch.tensor(w, dtype=torch.float32).cuda()
+    wf, _ = K.prep_weights(wt, True, False)
+    flags = 0
+    xin = x
+    H = h
+    if "up" in mode:
+        flags |= K.IN_UPSAMPLE2X
+        xin = R.upsample_nn2x(x)
+        H = 2 * h
+    if "relu" in mode:
+        flags |= K.IN_RELU
+        xin = R.relu(xin)
+    if "tanh" in mode:
+        flags |= K.OUT_TANH
+    res, rest = bf(rng.normal(size=(n, H, H, cout)))
+    y = K.conv2d_fprop(xt, wf, bt, (H, H), cout, k, flags, 1.0, rest)
+    ref = R.conv2d_same(xin, w, b) + res
+    if "tanh" in mode:
+        ref = np.tanh(ref)
+    torch.cuda.synchronize()
+    assert relerr(y, ref) < BF_TOL
+
+
+@pytest.mark.parametrize("n,h,cin,cout,k,mode", [
+    (2, 8, 64, 64, 3, ""), (2, 8, 128, 256, 3, "mask"), (2, 8, 64, 128, 1, ""), (2, 8, 128, 128, 3, "pool"),
+    (2, 8, 256, 3, 3, ""),       # dgrad of G.Output: Cout=3 -> packed K
+    (2, 8, 3, 128, 3, ""),       # dgrad of D.Block.1.Conv1: output 3 channels
+    (4, 1, 300, 128, 1, ""), (4, 1, 128, 1, 1, ""),
+])
+def test_conv_dgrad(K, n, h, cin, cout, k, mode):
+    rng = np.random.default_rng(n * 77 + cin + cout + k)
+    x, xt = bf(rng.normal(size=(n, h, h, cin)))
+    w, _ = bf(rng.normal(size=(k, k, cin, cout)) / np.sqrt(k * k * cout))
+    wt = torch.tensor(w, dtype=torch.float32).cuda()
+    _, wd = K.prep_weights(wt, False, True)
+    if mode == "pool":   # conv followed by 2x2 mean: dy arrives at half size
+        dy, dyt = bf(rng.normal(size=(n, h // 2, h // 2, cout)))
+        dx = K.conv2d_dgrad(dyt, wd, (h, h), cin, k, K.IN_UPSAMPLE2X, 0.25)
+        ref, _, _ = R.conv2d_same_grads(x, w, R.meanpool2x2_grad(dy))
+    else:
+        dy, dyt = bf(rng.normal(size=(n, h, h, cout)))
+        dx = K.conv2d_dgrad(dyt, wd, (h, h), cin, k, 0, 1.0, None, xt if mode == "mask" else None)
+        ref, _, _ = R.conv2d_same_grads(x, w, dy)
+        if mode == "mask":
+            ref = ref * (x > 0)
+    torch.cuda.synchronize()
+    assert relerr(dx, ref) < BF_TOL
+
+
+@pytest.mark.parametrize("n,h,cin,cout,k,mode", [
+    (2, 8, 64, 64, 3, ""), (4, 8, 128, 128, 3, "relu"), (2, 8, 128, 256, 1, ""), (2, 4, 64, 64, 3, "up"),
+    (2, 8, 64, 128, 3, "pool"), (64, 16, 256, 256, 3, ""),
+    (2, 8, 3, 128, 3, ""), (2, 8, 3, 128, 1, ""), (2, 8, 256, 3, 3, ""),
+    (6, 1, 300, 128, 1, ""), (9, 1, 128, 1, 1, ""), (3, 6, 64, 96, 3, ""),
+])
+def test_conv_wgrad(K, n, h, cin, cout, k, mode):
+    rng = np.random.default_rng(n * 31 + cin + cout + k)
+    x, xt = bf(rng.normal(size=(n, h, h, cin)))
+    flags, scale, xin, H = 0, 1.0, x, h
+    if mode == "up":
+        flags, xin, H = K.IN_UPSAMPLE2X, R.upsample_nn2x(x), 2 * h
+    if mode == "relu":
+        flags, xin = K.IN_RELU, R.relu(x)
+    if mode == "pool":
+        dy, dyt = bf(rng.normal(size=(n, h // 2, h // 2, cout)))
+        flags, scale = K.DY_UPSAMPLE2X, 0.25
+        dyfull = R.meanpool2x2_grad(dy)
+    else:
+        dy, dyt = bf(rng.normal(size=(n, H, H, cout)))
+        dyfull = dy
+    dw = torch.zeros((k, k, cin, cout), dtype=torch.float32, device="cuda")
+    K.conv2d_wgrad(xt, dyt, dw, (H, H), k, flags, scale)
+    w0 = np.zeros((k, k, cin, cout))
+    _, ref, refb = R.conv2d_same_grads(xin, w0, dyfull)
+    torch.cuda.synchronize()
+    assert relerr(dw, ref) < F32_FROM_BF_TOL
+    K.conv2d_wgrad(xt, dyt, dw, (H, H), k, flags, scale)     # accumulates
+    torch.cuda.synchronize()
+    assert relerr(dw, 2 * ref) < F32_FROM_BF_TOL
+    db = torch.zeros(cout, dtype=torch.float32, device="cuda")
+    K.colsum(dyt, db, 1.0)
+    torch.cuda.synchronize()
+    assert relerr(db, dy.sum(axis=(0, 1, 2))) < F32_FROM_BF_TOL
+
+
+@pytest.mark.parametrize("k,cin,cout", [(4, 64, 64), (3, 64, 32), (5, 128, 64), (4, 3, 64)])
+def test_deconv2d(K, k, cin, cout):
+    rng = np.random.default_rng(k + cin)
+    n, h = 2, 4
+    x, xt = bf(rng.normal(size=(n, h, h, cin)))
+    f, _ = bf(rng.normal(size=(k, k, cout, cin)) / np.sqrt(k * k * cin))
+    b, bt = f32(rng.normal(size=cout))
+    ft = torch.tensor(f, dtype=torch.float32).cuda()
+    wfz, wz = K.prep_weights(ft, True, True)
+    y = K.deconv2d_fprop(xt, wz, bt, cout, k)
+    torch.cuda.synchronize()
+    assert relerr(y, R.deconv2d_same(x, f, b)) < BF_TOL
+    dy, dyt = bf(rng.normal(size=(n, 2 * h, 2 * h, cout)))
+    rdx, rdf, _ = R.deconv2d_same_grads(x, f, dy)
+    dx = K.deconv2d_dgrad(dyt, wfz, cin, k)
+    df = torch.zeros((k, k, cout, cin), dtype=torch.float32, device="cuda")
+    K.deconv2d_wgrad(xt, dyt, df, k)
+    torch.cuda.synchronize()
+    assert relerr(dx, rdx) < BF_TOL
+    assert relerr(df, rdf) < F32_FROM_BF_TOL
+
+
+def test_spectral_norm_batched_fwd_bwd(K):
+    rng = np.random.default_rng(5)
+    shapes = [(3, 128), (27, 128), (1152, 128), (300, 128), (2304, 256), (128, 1), (70, 33)]
+    Ws, us, Gs = [], [], []
+    for kk, c in shapes:
+        Ws.append(f32(rng.normal(size=(kk, c)) * 0.05))
+        us.append(f32(rng.normal(size=(1, c))))
+        Gs.append(f32(rng.normal(size=(kk, c))))
+    batch = K.SnBatch([w[1] for w in Ws], [u[1] for u in us])
+    Wbars = batch.forward()
+    dWs = [torch.zeros_like(w[1]) for w in Ws]
+    batch.backward([g[1] for g in Gs], dWs)
+    torch.cuda.synchronize()
+    for i, (w, u, g) in enumerate(zip(Ws, us, Gs)):
+        Wb, u1, sigma, v = R.sn_forward(w[0], u[0])
+        assert relerr(Wbars[i], Wb) < 1e-5
+        assert relerr(batch.u_out_views()[i], u1.ravel()) < 1e-5
+        assert abs(float(batch.sigma(i)) - sigma) / sigma < 1e-5
+        assert relerr(dWs[i], R.sn_backward(w[0], u[0], g[0])) < 2e-4
+
+
+@pytest.mark.parametrize("n,hw,c,groups,relu", [(8, 16, 1024, 2, True), (4, 64, 256, 1, True), (6, 256, 256, 2, False), (64, 1024, 256, 2, True)])
+def test_cond_batchnorm_fwd_bwd(K, n, hw, c, groups, relu):
+    rng = np.random.default_rng(n + hw)
+    side = int(round(hw ** 0.5))
+    x, xt = bf(rng.normal(size=(n, side, side, c)) * 1.5 + 0.3)
+    labels = rng.integers(0, 10, n)
+    lt = torch.tensor(labels, dtype=torch.int32).cuda()
+    gamma, gt = f32(1 + 0.3 * rng.normal(size=(10, c)))
+    beta, bt = f32(0.2 * rng.normal(size=(10, c)))
+    y, stats = K.cbn_fwd(xt, lt, gt, bt, groups, relu)
+    ry, cache = R.cond_batchnorm_forward(x, labels, gamma, beta, groups)
+    ref = R.relu(ry) if relu else ry
+    torch.cuda.synchronize()
+    assert relerr(y, ref) < BF_TOL
+    assert relerr(stats[:, 0, :], cache[2].reshape(groups, c)) < 1e-4
+    assert relerr(stats[:, 1, :], cache[1].reshape(groups, c)) < 1e-4
+    dy, dyt = bf(rng.normal(size=x.shape))
+    dg = torch.zeros_like(gt)
+    db = torch.zeros_like(bt)
+    dx = K.cbn_bwd(dyt, xt, y, lt, gt, stats, dg, db, groups, relu)
+    # the kernel masks by ITS bf16 y>0; use the same mask so the comparison is about the arithmetic
+    mask = (y.to(torch.float64).cpu().numpy() > 0) if relu else 1.0
+    rdx, rdg, rdb = R.cond_batchnorm_backward(dy * mask, labels, gamma, cache, groups)
+    torch.cuda.synchronize()
+    assert relerr(dx, rdx) < BF_TOL
+    assert relerr(dg, rdg) < F32_FROM_BF_TOL
+    assert relerr(db, rdb) < F32_FROM_BF_TOL
+
+
+def test_pool_unpool_add_relu_tanh(K):
+    rng = np.random.default_rng(11)
+    for c in (128, 3):
+        x, xt = bf(rng.normal(size=(3, 8, 8, c)))
+        r, rt = bf(rng.normal(size=(3, 4, 4, c)))
+        assert relerr(K.pool2x2(xt, 0.25, rt), R.meanpool2x2(x) + r) < BF_TOL
+        assert relerr(K.pool2x2(xt, 1.0), 4 * R.meanpool2x2(x)) < BF_TOL
+        assert relerr(K.unpool2x2_add(rt, xt, 0.25), x + R.meanpool2x2_grad(r)) < BF_TOL
+        assert relerr(K.unpool2x2_add(rt, None, 1.0), R.upsample_nn2x(r)) == 0.0
+    a, at = bf(rng.normal(size=1003))
+    b, bt = bf(rng.normal(size=1003))
+    assert relerr(K.add(at, bt), a + b) < BF_TOL
+    assert relerr(K.relu_fwd(at), R.relu(a)) == 0.0
+    assert relerr(K.relu_fwd(at, 0.2), R.lrelu(a)) < BF_TOL
+    assert relerr(K.relu_bwd(bt, at), b * (a > 0)) == 0.0
+    y = np.tanh(a)
+    yq, yt = bf(y)
+    assert relerr(K.tanh_bwd(bt, yt), b * (1 - yq * yq)) < BF_TOL
+    f, ft = f32(rng.normal(size=77))
+    assert relerr(K.to_f32(K.to_bf16(ft)), bf(f)[0]) == 0.0
+
+
+def test_relu_meanpool_concat_embedding(K):
+    rng = np.random.default_rng(12)
+    x, xt = bf(rng.normal(size=(5, 8, 8, 128)))
+    y = K.relu_meanpool_hw_fwd(xt)
+    assert relerr(y, R.relu_mean_hw(x)) < BF_TOL
+    dy, dyt = bf(rng.normal(size=(5, 128)))
+    assert relerr(K.relu_meanpool_hw_bwd(dyt, xt), (x > 0) * dy[:, None, None, :] / 64.) < BF_TOL
+    a, at = bf(rng.normal(size=(3, 4, 4, 128)))
+    e, et = bf(rng.normal(size=(3, 128)))
+    cat = K.concat_tile_fwd(at, et)
+    ref = np.concatenate([a, np.broadcast_to(e[:, None, None, :], (3, 4, 4, 128))], axis=3)
+    assert relerr(cat, ref) == 0.0
+    g, gt = bf(rng.normal(size=(3, 4, 4, 256)))
+    da, de = K.concat_tile_bwd(gt, 128)
+    assert relerr(da, g[..., :128]) == 0.0
+    assert relerr(de, g[..., 128:].sum(axis=(1, 2))) < BF_TOL
+    table, tt = f32(rng.uniform(-0.08, 0.08, size=(10, 300)))
+    idx = rng.integers(0, 10, 17)
+    it = torch.tensor(idx, dtype=torch.int32).cuda()
+    emb = K.embedding_fwd(tt, it)
+    assert relerr(emb, bf(table[idx])[0]) == 0.0
+    d, dt = bf(rng.normal(size=(17, 300)))
+    dtab = torch.zeros_like(tt)
+    K.embedding_bwd(dt, it, dtab)
+    assert relerr(dtab, R.embed_y_grad(idx, d, 10)) < 1e-5
+
+
+def test_losses(K):
+    rng = np.random.default_rng(13)
+    l, lt = bf(rng.normal(size=128) * 2)
+    loss, dl = K.hinge_d_loss(lt, 64)
+    rl, rd = R.hinge_d_loss(l, 64)
+    assert abs(float(loss) - rl) < 1e-5 and relerr(dl, rd) < BF_TOL
+    loss, dl = K.hinge_g_loss(lt)
+    rl, rd = R.hinge_g_loss(l)
+    assert abs(float(loss) - rl) < 1e-5 and relerr(dl, rd) < BF_TOL
+    lg, lgt = bf(rng.normal(size=(32, 10)) * 3)
+    lb = rng.integers(0, 10, 32)
+    loss, dl = K.softmax_xent(lgt, torch.tensor(lb, dtype=torch.int32).cuda())
+    rl, rd = R.softmax_xent(lg, lb)
+    assert abs(float(loss) - rl) < 1e-4 and relerr(dl, rd) < BF_TOL
+
+
+def test_adam_tf_and_lr_decay(K):
+    rng = np.random.default_rng(14)
+    n = 1003
+    p0, pt = f32(rng.normal(size=n))
+    pt = torch.cat([pt, torch.zeros(1, device="cuda")])[:n]   # keep 16-B alignment of a fresh buffer
+    m = torch.zeros(n, device="cuda")
+    v = torch.zeros(n, device="cuda")
+    hp = torch.tensor([2e-4, 0., 0.9, 1e-8, 0.5, 1.0, 0, 0], dtype=torch.float32, device="cuda")
+    t = torch.zeros(1, dtype=torch.int64, device="cuda")
+    it = torch.tensor([30000], dtype=torch.int64, device="cuda")
+    rp, rm, rv = p0.copy(), np.zeros(n), np.zeros(n)
+    for step in range(1, 4):
+        g, gt = f32(rng.normal(size=n))
+        K.adam_tf(pt, gt, m, v, hp, t, it)
+        rp, rm, rv = R.adam_tf_step(rp, 0.5 * g, rm, rv, step, 2e-4 * R.lr_decay(30000))
+    torch.cuda.synchronize()
+    assert int(t) == 3
+    assert relerr(pt, rp) < 1e-5 and relerr(v, rv) < 1e-5
+
+
+def test_preprocess_and_rng(K):
+    st = K.new_rng_state(42, "cuda")
+    data = torch.randint(0, 256, (16, 3072), dtype=torch.uint8)
+    y = K.preprocess_real(data.cuda(), st).to(torch.float64).cpu().numpy().reshape(16, 3072)
+    base = R.preprocess_real(data.numpy(), np.zeros((16, 3072)))
+    d = y - base
+    # dequantisation noise U[0,1/128) then bf16 rounding (|x|<=1 -> ulp <= 2^-8)
+    assert d.min() > -2 ** -8 and d.max() < 1 / 128 + 2 ** -8
+    assert int(st[1]) == 1
+    z = K.rng_normal((64, 128), st).to(torch.float64).cpu().numpy()
+    assert abs(z.mean()) < 0.05 and abs(z.std() - 1) < 0.05 and int(st[1]) == 2
+    z2 = K.rng_normal((64, 128), st).to(torch.float64).cpu().numpy()
+    assert np.abs(z - z2).max() > 0.1            # the offset advanced: fresh numbers
+    lb = K.rng_labels(4096, 10, st).cpu().numpy()
+    assert lb.min() == 0 and lb.max() == 9 and np.bincount(lb).min() > 300
