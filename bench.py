@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of the SNGAN-ResNet CIFAR-10 train iteration on N MI355X (BASELINE.json).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one reference iteration (SNGAN/gan_cifar_resnet.py:599-620): 1 generator update on 2x64
+fakes + N_CRITIC=5 critic updates on 64 real + 64 fake each, i.e. 320 real images per GPU.
+Weak scaling: every rank processes its own 64-image batches; G/D gradients are summed with one RCCL
+all-reduce per update.  Inputs are synthetic CIFAR-10-shaped uint8 batches already resident in HBM.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- dominant MFMA kernel family, algorithmic FLOPs / HIP-event time of its launches over one
+                  eagerly executed iteration (events recorded on the launch stream by libgank's profiler)
+  cpu_baseline -- the oracle's torch-CPU fp32 restatement of the same iteration, timed on this box's host
+                  cores on a bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+GFLOP_PER_REAL_IMAGE = 13.77   # 4406.0 GFLOP per iteration / 320 real images
+
+
+def cpu_baseline(budget_s=40.0):
+    """Oracle ("port") leg: torch-CPU fp32 restatement of the reference graph, 1 D update + 1 G update
+    timed on a bounded sample, extrapolated to the 5 D + 1 G iteration."""
+    import numpy as np
+    from oracle import ref_torch as T
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = T.to_torch(T.init_sngan_params(0), dtype=torch.float32)
+    tr = T.Trainer(P)
+    rng = np.random.default_rng(0)
+
+    def one(b):
+        z = torch.tensor(rng.normal(size=(b, 128)), dtype=torch.float32)
+        labels = torch.tensor(rng.integers(0, 10, b))
+        real = torch.tensor(rng.integers(0, 256, (b, 3072)))
+        deq = torch.tensor(rng.uniform(0, 1 / 128, (b, 3072)), dtype=torch.float32)
+        t0 = time.perf_counter()
+        tr.d_step(0, real, labels, z, deq)
+        t1 = time.perf_counter()
+        z2 = torch.tensor(rng.normal(size=(2 * b, 128)), dtype=torch.float32)
+        fl = torch.tensor(rng.integers(0, 10, 2 * b))
+        tr.g_step(0, z2, fl)
+        t2 = time.perf_counter()
+        return t1 - t0, t2 - t1
+
+    one(2)                                  # warm-up (thread pool, oneDNN primitives)
+    td, tg = one(8)
+    per_img = (td + tg) / 8
+    b = 64
+    while b > 8 and per_img * b > budget_s:
+        b //= 2
+    if b > 8:
+        td, tg = one(b)
+    t_iter = (5 * td + tg) * (64.0 / b)
+    return {"value": round(320.0 / t_iter, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"1 D update + 1 G update at batch {b} (torch-CPU fp32 restatement of the reference graph, "
+                      f"oracle/ref_torch.py), extrapolated to 5 D + 1 G at batch 64: D {td:.2f}s G {tg:.2f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+        pg = dist.group.WORLD
+
+    from gan_lib_tensorflow_amd import kernels as K
+    from gan_lib_tensorflow_amd.SNGAN import gan_cifar_resnet as S
+
+    tr = S.SNGANTrainer(batch_size=S.BATCH_SIZE, device=device, seed=0, use_graphs=not args.no_graphs, process_group=pg)
+    feed = S.synthetic_batches(S.BATCH_SIZE, device, seed=rank)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier(group=pg)
+        torch.cuda.synchronize()
+
+    warm = max(args.warmup, 2)    # iterations 0 and 1 run eagerly and capture the D and G graphs
+    for _ in range(warm):
+        tr.train_iteration(feed)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.train_iteration(feed)
+    torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0
+    barrier()
+    t = torch.tensor([t_local], dtype=torch.float64, device=device)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=pg)
+    elapsed = float(t)
+    finite = bool(torch.isfinite(tr.g_flat["params"]).all() and torch.isfinite(tr.d_flat["params"]).all())
+
+    # ---- roofline leg: one iteration executed eagerly with a HIP event pair around every MFMA conv launch
+    roofline = None
+    if rank == 0:
+        tr.use_graphs = False
+        tr.train_iteration(feed)          # untimed eager warm-up of the non-graph path
+        torch.cuda.synchronize()
+        K.prof_reset()
+        K.prof_enable(True)
+        tr.train_iteration(feed)
+        torch.cuda.synchronize()
+        K.prof_enable(False)
+        fam = {}
+        for f, name in ((0, "conv_igemm_kernel (fprop+dgrad)"), (1, "conv_wgrad_kernel")):
+            n, ms, fl = K.prof_collect(f)
+            fam[name] = (n, ms, fl)
+        K.prof_reset()
+        dom = max(fam, key=lambda k: fam[k][1])
+        n, ms, fl = fam[dom]
+        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches_per_iteration": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
+                    "avg_launch_gflop": round(fl / max(n, 1) / 1e9, 3),
+                    "families": {k: {"launches": v[0], "ms": round(v[1], 3),
+                                     "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else 0.0} for k, v in fam.items()}}
+        tr.use_graphs = not args.no_graphs
+
+    if rank == 0:
+        images = 320.0 * world * args.steps
+        value = images / elapsed
+        out = {
+            "metric": "images/sec (G+D step) SNGAN-ResNet CIFAR-10 bs=64", "value": round(value, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": warm, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "SNGAN ResNet CIFAR-10 32x32 bs=64 hinge: 1 G update (2x64 fakes) + 5 D updates (64 real + 64 fake) per step",
+                       "global_batch": 64 * world, "per_gpu_batch": 64, "parallelism": f"dp{world}",
+                       "graphs": not args.no_graphs, "finite": finite},
+            "whole_step_mfma_frac": round(value / world * GFLOP_PER_REAL_IMAGE * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier(group=pg)
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -174,6 +174,7 @@ class SNGANTrainer:
     def _d_forward_backward(self, real_pre=None, z=None):
         """disc_cost and its gradients (:326-381): fakes from N_TOWERS generator towers conditioned on
         the REAL labels, critic on concat(real, fake) with update_collection=None."""
+        set_default_store(self.store)
         b = self.batch
         self.store.zero_grads('Discriminator')
         with torch.no_grad():   # generator is not trained by disc_cost: no autograd graph through it
@@ -190,6 +191,7 @@ class SNGANTrainer:
     def _g_forward_backward(self, z=None, fake_labels=None):
         """gen_cost and its gradients (:464-498): N_TOWERS towers of GEN_BS_MULTIPLE*B/N_TOWERS samples,
         critic with update_collection=NO_OPS (u read, never written)."""
+        set_default_store(self.store)   # the store is the "default graph": several trainers may coexist
         n = GEN_BS_MULTIPLE * self.batch
         self.store.zero_grads('Generator')
         if fake_labels is None:
@@ -276,6 +278,7 @@ class SNGANTrainer:
     @torch.no_grad()
     def sample(self, n=100, labels=None, noise=None):
         """Fixed-noise / IS sampling path (:530-555): one Generator call of n samples, batch statistics."""
+        set_default_store(self.store)
         if labels is None:
             labels = K.rng_labels(n, 10, self.rng_state)
         return Generator(n, labels, noise=noise, groups=1, rng_state=self.rng_state)
