@@ -36,7 +36,8 @@ def cpu_baseline(budget_s=40.0):
     timed on a bounded sample, extrapolated to the 5 D + 1 G iteration."""
     import numpy as np
     from oracle import ref_torch as T
-    cores = os.cpu_count() or 1
+    # a one-GPU box owns a 16-core share of the host (more threads than that only oversubscribe)
+    cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     P = T.to_torch(T.init_sngan_params(0), dtype=torch.float32)
     tr = T.Trainer(P)

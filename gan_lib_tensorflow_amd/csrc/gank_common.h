@@ -28,7 +28,9 @@ int gank_set_error(const char* fmt, ...);
 #define GANK_LAUNCH_OK(name)                                                               \
   do {                                                                                     \
     hipError_t e__ = hipGetLastError();                                                    \
-    if (e__ != hipSuccess) return gank_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+    /* hipErrorNotReady is the sticky residue of the host's own hipEventQuery polling, not a launch error */ \
+    if (e__ != hipSuccess && e__ != hipErrorNotReady)                                      \
+      return gank_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));        \
   } while (0)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -304,9 +304,8 @@ def test_adam_tf_and_lr_decay(K):
     rng = np.random.default_rng(14)
     n = 1003
     p0, pt = f32(rng.normal(size=n))
-    pt = torch.cat([pt, torch.zeros(1, device="cuda")])[:n]   # keep 16-B alignment of a fresh buffer
-    m = torch.zeros(n, device="cuda")
-    v = torch.zeros(n, device="cuda")
+    m = torch.zeros(n, dtype=torch.float32, device="cuda")
+    v = torch.zeros(n, dtype=torch.float32, device="cuda")
     hp = torch.tensor([2e-4, 0., 0.9, 1e-8, 0.5, 1.0, 0, 0], dtype=torch.float32, device="cuda")
     t = torch.zeros(1, dtype=torch.int64, device="cuda")
     it = torch.tensor([30000], dtype=torch.int64, device="cuda")

@@ -149,8 +149,9 @@ def test_train_steps_eager_vs_graph_and_oracle_update(gpu):
     torch.cuda.synchronize()
     assert torch.equal(tr_e.rng_state, tr_g.rng_state)          # replay consumed the device RNG like eager
     a, b = tr_e.d_flat["params"], tr_g.d_flat["params"]
-    assert (a - b).abs().max().item() < 2e-6
-    assert abs(float(tr_e.d_loss) - float(tr_g.d_loss)) < 1e-5
+    # (a weight whose gradient is ~0 may take the other sign in its first Adam step: allow a few 2*lr flips)
+    assert ((a - b).abs() > 2e-6).float().mean().item() < 1e-4
+    assert abs(float(tr_e.d_loss) - float(tr_g.d_loss)) < 1e-4
     # then full iterations.  TF-Adam with beta1=0 moves a weight by ~lr*sign(g) on its first step, so an
     # atomics-order flip of a ~0 gradient is a 2*lr jump and bf16 rounding boundaries amplify it from
     # there (two EAGER runs diverge the same way): later steps are compared statistically.

@@ -7,7 +7,6 @@ import torch
 from oracle import ref_ops as R
 from oracle import ref_torch as T
 
-torch.set_default_dtype(torch.float64)
 
 
 def t64(a, grad=False):
