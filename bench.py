@@ -88,15 +88,10 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    pg = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
-        pg = dist.group.WORLD
-
     from gan_lib_tensorflow_amd import kernels as K
+    from gan_lib_tensorflow_amd import parallel
     from gan_lib_tensorflow_amd.SNGAN import gan_cifar_resnet as S
+    pg, rank, world = parallel.init_from_env(backend="nccl", device=device)   # RCCL over xGMI; None for 1 rank
 
     tr = S.SNGANTrainer(batch_size=S.BATCH_SIZE, device=device, seed=0, use_graphs=not args.no_graphs, process_group=pg)
     feed = S.synthetic_batches(S.BATCH_SIZE, device, seed=rank)

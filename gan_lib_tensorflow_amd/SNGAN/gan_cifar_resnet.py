@@ -23,6 +23,7 @@ import torch
 
 from .. import functional as Fn
 from .. import kernels as K
+from .. import parallel
 from ..common import resnet_block as blocks
 from ..common.ops import embedding as _embedding
 from ..common.ops import linear as _linear
@@ -144,7 +145,7 @@ class SNGANTrainer:
             self.world, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
         self.use_graphs = use_graphs
         # data-side RNG differs per rank; parameter init (store seed) is identical on all ranks
-        self.rng_state = K.new_rng_state(1234567 + 7919 * self.rank + seed, self.device)
+        self.rng_state = K.new_rng_state(parallel.data_seed(seed, self.rank), self.device)
         self.iteration = 0
         self._build(state)
         self._graphs = {}
@@ -212,8 +213,7 @@ class SNGANTrainer:
 
     def _allreduce(self, flat):
         if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(flat["grads"], op=dist.ReduceOp.SUM, group=self.pg)
+            parallel.allreduce_sum_(flat["grads"], self.pg)
 
     def _run(self, key, fwd_bwd, opt, flat):
         """fwd+bwd (graph) -> [RCCL all-reduce] -> Adam (graph)."""
@@ -233,17 +233,24 @@ class SNGANTrainer:
                 opt.apply()
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
-            g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                fwd_bwd()
-                if self.world == 1:
-                    opt.apply()
-            g2 = None
-            if self.world > 1:
-                g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2):
-                    opt.apply()
-            self._graphs[key] = (g1, g2)
+            try:
+                # thread_local: the RCCL watchdog thread polls events concurrently when world > 1
+                g1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                    fwd_bwd()
+                    if self.world == 1:
+                        opt.apply()
+                g2 = None
+                if self.world > 1:
+                    g2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+                        opt.apply()
+                self._graphs[key] = (g1, g2)
+            except Exception as e:  # noqa: BLE001 -- capture is an optimisation, never a correctness need
+                import sys
+                print(f"[gank] hipGraph capture of the {key!r} update failed ({e}); running eagerly", file=sys.stderr)
+                self.use_graphs = False
+                torch.cuda.synchronize()
             return
         g1, g2 = self._graphs[key]
         g1.replay()

@@ -27,7 +27,7 @@ PROTOTYPES = {
     "gank_conv2d_prep_weights": [P, P, P, I, I, I, P],
     "gank_conv2d_fprop": [P, P, P, P, P, P, I, I, I, I, I, I, I, F, P],
     "gank_conv2d_dgrad": [P, P, P, P, P, I, I, I, I, I, I, I, F, P],
-    "gank_conv2d_wgrad": [P, P, P, I, I, I, I, I, I, I, F, P],
+    "gank_conv2d_wgrad": [P, P, P, P, I, I, I, I, I, I, I, F, P],
     "gank_deconv2d_fprop": [P, P, P, P, I, I, I, I, I, I, P],
     "gank_deconv2d_dgrad": [P, P, P, I, I, I, I, I, I, P],
     "gank_deconv2d_wgrad": [P, P, P, I, I, I, I, I, I, P],

@@ -38,7 +38,9 @@ struct IgemmArgs {
 
 constexpr int LROW = 72;  // LDS row length in bf16 (64 + 8 pad) = 144 B
 
-template <int WM, int WN, int TM, int TN, bool PACKED>
+// PF = register prefetch slots: global loads for K-step s+PF-1 are in flight while step s is computed
+// (plain loads survive the per-step barrier; hipcc emits counted vmcnt waits for the oldest slot only).
+template <int WM, int WN, int TM, int TN, bool PACKED, int PF>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32;
@@ -85,9 +87,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
     }
   }
 
-  u32x4 rP[CP], rW[CW];
+  u32x4 rP[PF][CP], rW[PF][CW];
+  unsigned rOk[PF];   // per slot: bit j = pixel chunk j is inside the image (else it is zero padding)
 
-  auto load_step = [&](int s) {
+  // Loads are UNCONDITIONAL (out-of-image taps read a dummy in-bounds address and are zeroed when the
+  // slot is written to LDS): any branch around a load makes hipcc's vmcnt bookkeeping assume the worst
+  // path and drain the whole prefetch ring at every step.
+  auto load_step = [&](int s, u32x4 (&rP)[CP], u32x4 (&rW)[CW], unsigned& okm) {
+    okm = 0u;
     if constexpr (!PACKED) {
       const int ck = a.Cin >> 6;
       const int tap = s / ck;
@@ -100,15 +107,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
         bool ok = (unsigned)ih < (unsigned)LH && (unsigned)iw < (unsigned)LW;
         if (zins) ok = ok && (((ih | iw) & 1) == 0);
         if (shr) { ih >>= 1; iw >>= 1; }
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (ok) {
-          const long off = ((long)(p_base[j] + ih * a.Win + iw)) * a.Cin + c0 + cc * 8;
-          v = *reinterpret_cast<const u32x4*>(a.x + off);
-          if (inrelu) v = relu_bf16x8(v);
-        }
-        rP[j] = v;
+        const long off = ok ? ((long)(p_base[j] + ih * a.Win + iw)) * a.Cin + c0 + cc * 8 : 0L;
+        rP[j] = *reinterpret_cast<const u32x4*>(a.x + off);   // zero-fill and relu happen at LDS-store time
+        okm |= (ok ? 1u : 0u) << j;
       }
     } else {
+      okm = ~0u;
       const int ktot = a.taps * a.Cin;
 #pragma unroll
       for (int j = 0; j < CP; j++) {
@@ -144,11 +148,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
     }
   };
 
-  auto store_step = [&](int buf) {
+  auto store_step = [&](int buf, u32x4 (&rP)[CP], u32x4 (&rW)[CW], unsigned okm) {
 #pragma unroll
     for (int j = 0; j < CP; j++) {
       const int q = tid + NT * j;
-      *reinterpret_cast<u32x4*>(sP + (buf * BM + (q >> 3)) * LROW + (q & 7) * 8) = rP[j];
+      u32x4 v = rP[j];
+      if constexpr (!PACKED) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        v = ((okm >> j) & 1u) ? v : z;
+        if (inrelu) v = relu_bf16x8(v);
+      }
+      *reinterpret_cast<u32x4*>(sP + (buf * BM + (q >> 3)) * LROW + (q & 7) * 8) = v;
     }
 #pragma unroll
     for (int j = 0; j < CW; j++) {
@@ -165,30 +175,41 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
-  load_step(0);
-  store_step(0);
+  const int last = a.nsteps - 1;
+#pragma unroll
+  for (int d = 0; d < PF; d++) load_step(d < last ? d : last, rP[d], rW[d], rOk[d]);
+  store_step(0, rP[0], rW[0], rOk[0]);
   __syncthreads();
 
-  for (int s = 0; s < a.nsteps; s++) {
-    const int buf = s & 1;
-    if (s + 1 < a.nsteps) load_step(s + 1);
-    const bf16* pW = sW + (buf * BN + wave_n * TN * 32 + r) * LROW + h * 8;
-    const bf16* pP = sP + (buf * BM + wave_m * TM * 32 + r) * LROW + h * 8;
+  for (int s0 = 0; s0 < a.nsteps; s0 += PF) {
 #pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-      bf16x8 fa[TN], fb[TM];
+    for (int d = 0; d < PF; d++) {
+      const int s = s0 + d;
+      if (s >= a.nsteps) break;
+      const int buf = s & 1;
+      // slot d held step s (already in LDS): refill it with step s+PF (clamped: tail loads are redundant)
+      if constexpr (PF > 1) load_step(s + PF < last ? s + PF : last, rP[d], rW[d], rOk[d]);
+      const bf16* pW = sW + (buf * BN + wave_n * TN * 32 + r) * LROW + h * 8;
+      const bf16* pP = sP + (buf * BM + wave_m * TM * 32 + r) * LROW + h * 8;
 #pragma unroll
-      for (int i = 0; i < TN; i++) fa[i] = *reinterpret_cast<const bf16x8*>(pW + i * 32 * LROW + kk * 16);
+      for (int kk = 0; kk < 4; kk++) {
+        bf16x8 fa[TN], fb[TM];
 #pragma unroll
-      for (int j = 0; j < TM; j++) fb[j] = *reinterpret_cast<const bf16x8*>(pP + j * 32 * LROW + kk * 16);
+        for (int i = 0; i < TN; i++) fa[i] = *reinterpret_cast<const bf16x8*>(pW + i * 32 * LROW + kk * 16);
 #pragma unroll
-      for (int i = 0; i < TN; i++)
+        for (int j = 0; j < TM; j++) fb[j] = *reinterpret_cast<const bf16x8*>(pP + j * 32 * LROW + kk * 16);
 #pragma unroll
-        for (int j = 0; j < TM; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TN; i++)
+#pragma unroll
+          for (int j = 0; j < TM; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+      if (s + 1 < a.nsteps) {
+        if constexpr (PF == 1) load_step(s + 1, rP[0], rW[0], rOk[0]);
+        store_step(buf ^ 1, rP[(d + 1) % PF], rW[(d + 1) % PF], rOk[(d + 1) % PF]);
+      }
+      __syncthreads();
     }
-    if (s + 1 < a.nsteps) store_step(buf ^ 1);
-    __syncthreads();
   }
 
   // epilogue: lane holds, per accumulator quad g, channels co0+8g+4h .. +3 of pixel m
@@ -245,14 +266,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
   }
 }
 
-template <int WM, int WN, int TM, int TN, bool PACKED>
+template <int WM, int WN, int TM, int TN, bool PACKED, int PF>
 static int launch_cfg(const IgemmArgs& a0, hipStream_t s) {
   IgemmArgs a = a0;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   a.tiles_m = cdiv(a.M, BM);
   a.tiles_n = a.CoutPad / BN;
   const size_t lds = (size_t)2 * (BM + BN) * LROW * sizeof(bf16);
-  auto kern = conv_igemm_kernel<WM, WN, TM, TN, PACKED>;
+  auto kern = conv_igemm_kernel<WM, WN, TM, TN, PACKED, PF>;
   static bool attr_set = false;  // benign race: idempotent
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -283,14 +304,14 @@ int gank_igemm_dispatch(IgemmArgs a, hipStream_t s) {
   int rc;
   const long tiles128 = (long)cdiv(a.M, 128) * (a.CoutPad / 128);
   if (packed) {
-    if (a.CoutPad % 64 == 0) rc = launch_cfg<2, 2, 1, 1, true>(a, s);
-    else rc = launch_cfg<4, 1, 2, 1, true>(a, s);
+    if (a.CoutPad % 64 == 0) rc = launch_cfg<2, 2, 1, 1, true, 1>(a, s);
+    else rc = launch_cfg<4, 1, 2, 1, true, 1>(a, s);
   } else if (a.CoutPad % 128 == 0 && tiles128 >= 192) {
-    rc = launch_cfg<2, 2, 2, 2, false>(a, s);
+    rc = launch_cfg<2, 2, 2, 2, false, 3>(a, s);
   } else if (a.CoutPad % 64 == 0) {
-    rc = launch_cfg<2, 2, 1, 1, false>(a, s);
+    rc = launch_cfg<2, 2, 1, 1, false, 4>(a, s);
   } else {
-    rc = launch_cfg<4, 1, 2, 1, false>(a, s);
+    rc = launch_cfg<4, 1, 2, 1, false, 3>(a, s);
   }
   gank_prof_end(0, s);
   return rc;

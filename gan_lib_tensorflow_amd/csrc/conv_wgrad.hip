@@ -19,6 +19,7 @@ struct WgradArgs {
   const bf16* x;
   const bf16* dy;
   float* dw;
+  float* dbias;       // optional: dbias[co] += scale * sum_pixels dy[p][co] (fused bias gradient)
   int N, H, W;        // pixel grid the reduction runs over (conv output size)
   int Hx, Wx;         // stored x spatial
   int Hdy, Wdy;       // stored dy spatial
@@ -35,14 +36,19 @@ __device__ __forceinline__ s16x4 lds_tr_read(const bf16* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
 
-// WA x WB waves; each wave TA x TB MFMA tiles of 32(ci) x 32(co); 64 pixels per step
-template <int WA, int WB, int TA, int TB>
+// WA x WB waves; each wave TA x TB MFMA tiles of 32(ci) x 32(co); 64 pixels per step.
+// FAST (Cin%8==0 && Cout%8==0): 16-byte UNCONDITIONAL loads (out-of-range -> dummy address, zeroed at
+// LDS-store time) into a PF-deep register ring, so loads for step s+PF-1 are in flight during step s and
+// hipcc can emit counted vmcnt waits (a branch around a load would force a full drain every step).
+// !FAST: element-wise predicated gather for the narrow operands (3-channel image side, Cout=1/3, K=300).
+template <int WA, int WB, int TA, int TB, bool FAST, int PF>
 __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int NT = WA * WB * 64;
   constexpr int CiT = WA * TA * 32, CoT = WB * TB * 32;
   constexpr int SUBA = CiT / 32, SUBB = CoT / 32;     // 32-channel sub-tiles, each [64 pixels][32 ch] = 4 KB
   constexpr int CHA = 64 * CiT / 8, CHB = 64 * CoT / 8;  // 16-byte chunks per step
   constexpr int CPA = (CHA + NT - 1) / NT, CPB = (CHB + NT - 1) / NT;
+  static_assert(FAST || PF == 1, "the narrow path consumes its loads immediately");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16* sA = reinterpret_cast<bf16*>(smem);          // [2][SUBA][64][32]
@@ -64,16 +70,24 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_kernel(WgradArgs a) {
   const bool dyup = (a.flags & GANK_DY_UPSAMPLE2X) != 0;
   const int st = (a.flags & WG_X_STRIDE2) ? 2 : 1;
   const int LH = xup ? 2 * a.Hx : a.Hx, LW = xup ? 2 * a.Wx : a.Wx;
-  const bool fastA = (a.Cin % 8) == 0, fastB = (a.Cout % 8) == 0;
+  const bool do_bias = a.dbias != nullptr && tap == 0 && tci == 0;
 
   const int step0 = split * a.steps_per_split;
   int nsteps = (a.M + 63) / 64 - step0;
   if (nsteps > a.steps_per_split) nsteps = a.steps_per_split;
+  if (nsteps <= 0) return;   // uniform per block; cannot happen with the host's split computation
 
-  u32x4 rA[CPA], rB[CPB];
+  u32x4 rA[PF][CPA], rB[PF][CPB];
+  unsigned okA[PF], okB[PF];
+  float bsum[CPB][8];
+#pragma unroll
+  for (int j = 0; j < CPB; j++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) bsum[j][e] = 0.f;
 
-  auto load_step = [&](int s) {
+  auto load_step = [&](int s, u32x4 (&rA)[CPA], u32x4 (&rB)[CPB], unsigned& oka, unsigned& okb) {
     const int mbase = (step0 + s) * 64;
+    oka = 0u; okb = 0u;
 #pragma unroll
     for (int j = 0; j < CPA; j++) {
       const int q = tid + NT * j;
@@ -82,24 +96,22 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_kernel(WgradArgs a) {
         const int p = q / (CiT / 8), cc = q % (CiT / 8);
         const int m = mbase + p;
         const int c = ci0 + cc * 8;
-        if (m < a.M && c < a.Cin) {
-          int n, oh, ow;
-          pix_decomp(m, a.H, a.W, a.shw, a.sw, n, oh, ow);
-          int ih = oh * st + dh, iw = ow * st + dw;
-          const bool ok = (unsigned)ih < (unsigned)LH && (unsigned)iw < (unsigned)LW;
-          if (xup) { ih >>= 1; iw >>= 1; }
-          if (ok) {
-            const long off = ((long)(n * a.Hx + ih) * a.Wx + iw) * a.Cin + c;
-            if (fastA) {
-              v = *reinterpret_cast<const u32x4*>(a.x + off);
-            } else {
-              bf16x8 t;
+        int n, oh, ow;
+        pix_decomp(m, a.H, a.W, a.shw, a.sw, n, oh, ow);
+        int ih = oh * st + dh, iw = ow * st + dw;
+        const bool ok = m < a.M && c < a.Cin && (unsigned)ih < (unsigned)LH && (unsigned)iw < (unsigned)LW;
+        if (xup) { ih >>= 1; iw >>= 1; }
+        if constexpr (FAST) {
+          const long off = ok ? ((long)(n * a.Hx + ih) * a.Wx + iw) * a.Cin + c : 0L;
+          v = *reinterpret_cast<const u32x4*>(a.x + off);
+          oka |= (ok ? 1u : 0u) << j;
+        } else if (ok) {
+          const long off = ((long)(n * a.Hx + ih) * a.Wx + iw) * a.Cin + c;
+          bf16x8 t;
 #pragma unroll
-              for (int e = 0; e < 8; e++) t[e] = (c + e < a.Cin) ? a.x[off + e] : f2bf(0.f);
-              v = __builtin_bit_cast(u32x4, t);
-            }
-            if (xrelu) v = relu_bf16x8(v);
-          }
+          for (int e = 0; e < 8; e++) t[e] = (c + e < a.Cin) ? a.x[off + e] : f2bf(0.f);
+          v = __builtin_bit_cast(u32x4, t);
+          oka |= 1u << j;
         }
       }
       rA[j] = v;
@@ -112,32 +124,37 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_kernel(WgradArgs a) {
         const int p = q / (CoT / 8), cc = q % (CoT / 8);
         const int m = mbase + p;
         const int c = co0 + cc * 8;
-        if (m < a.M && c < a.Cout) {
-          int n, oh, ow;
-          pix_decomp(m, a.H, a.W, a.shw, a.sw, n, oh, ow);
-          if (dyup) { oh >>= 1; ow >>= 1; }
+        int n, oh, ow;
+        pix_decomp(m, a.H, a.W, a.shw, a.sw, n, oh, ow);
+        if (dyup) { oh >>= 1; ow >>= 1; }
+        const bool ok = m < a.M && c < a.Cout;
+        if constexpr (FAST) {
+          const long off = ok ? ((long)(n * a.Hdy + oh) * a.Wdy + ow) * a.Cout + c : 0L;
+          v = *reinterpret_cast<const u32x4*>(a.dy + off);
+          okb |= (ok ? 1u : 0u) << j;
+        } else if (ok) {
           const long off = ((long)(n * a.Hdy + oh) * a.Wdy + ow) * a.Cout + c;
-          if (fastB) {
-            v = *reinterpret_cast<const u32x4*>(a.dy + off);
-          } else {
-            bf16x8 t;
+          bf16x8 t;
 #pragma unroll
-            for (int e = 0; e < 8; e++) t[e] = (c + e < a.Cout) ? a.dy[off + e] : f2bf(0.f);
-            v = __builtin_bit_cast(u32x4, t);
-          }
+          for (int e = 0; e < 8; e++) t[e] = (c + e < a.Cout) ? a.dy[off + e] : f2bf(0.f);
+          v = __builtin_bit_cast(u32x4, t);
+          okb |= 1u << j;
         }
       }
       rB[j] = v;
     }
   };
 
-  auto store_step = [&](int buf) {
+  auto store_step = [&](int buf, u32x4 (&rA)[CPA], u32x4 (&rB)[CPB], unsigned oka, unsigned okb) {
+    const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int j = 0; j < CPA; j++) {
       const int q = tid + NT * j;
       if (CHA % NT == 0 || q < CHA) {
         const int p = q / (CiT / 8), cc = q % (CiT / 8);
-        *reinterpret_cast<u32x4*>(sA + ((buf * SUBA + (cc >> 2)) * 64 + p) * 32 + (cc & 3) * 8) = rA[j];
+        u32x4 v = ((oka >> j) & 1u) ? rA[j] : z;
+        if (xrelu) v = relu_bf16x8(v);
+        *reinterpret_cast<u32x4*>(sA + ((buf * SUBA + (cc >> 2)) * 64 + p) * 32 + (cc & 3) * 8) = v;
       }
     }
 #pragma unroll
@@ -145,7 +162,13 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_kernel(WgradArgs a) {
       const int q = tid + NT * j;
       if (CHB % NT == 0 || q < CHB) {
         const int p = q / (CoT / 8), cc = q % (CoT / 8);
-        *reinterpret_cast<u32x4*>(sB + ((buf * SUBB + (cc >> 2)) * 64 + p) * 32 + (cc & 3) * 8) = rB[j];
+        const u32x4 v = ((okb >> j) & 1u) ? rB[j] : z;
+        *reinterpret_cast<u32x4*>(sB + ((buf * SUBB + (cc >> 2)) * 64 + p) * 32 + (cc & 3) * 8) = v;
+        if (do_bias) {   // bias gradient = column sums of dy, fused into the pass that already streams dy
+          const bf16x8 t = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+          for (int e = 0; e < 8; e++) bsum[j][e] += bf2f(t[e]);
+        }
       }
     }
   };
@@ -163,45 +186,52 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_kernel(WgradArgs a) {
   const int g = lane >> 4, li = lane & 15;
   const int tr_off = ((8 * (g >> 1) + (li >> 2)) * 32) + 16 * (g & 1) + 4 * (li & 3);  // in bf16 elements
 
-  if (nsteps > 0) {
-    load_step(0);
-    store_step(0);
-  }
+  const int last = nsteps - 1;
+#pragma unroll
+  for (int d = 0; d < PF; d++) load_step(d < last ? d : last, rA[d], rB[d], okA[d], okB[d]);
+  store_step(0, rA[0], rB[0], okA[0], okB[0]);
   __syncthreads();
 
-  for (int s = 0; s < nsteps; s++) {
-    const int buf = s & 1;
-    if (s + 1 < nsteps) load_step(s + 1);
-    const bf16* pA = sA + (buf * SUBA + wave_a * TA) * 2048 + tr_off;
-    const bf16* pB = sB + (buf * SUBB + wave_b * TB) * 2048 + tr_off;
+  for (int s0 = 0; s0 < nsteps; s0 += PF) {
 #pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-      bf16x8 fa[TA], fb[TB];
+    for (int d = 0; d < PF; d++) {
+      const int s = s0 + d;
+      if (s >= nsteps) break;
+      const int buf = s & 1;
+      if constexpr (PF > 1) load_step(s + PF < last ? s + PF : last, rA[d], rB[d], okA[d], okB[d]);
+      const bf16* pA = sA + (buf * SUBA + wave_a * TA) * 2048 + tr_off;
+      const bf16* pB = sB + (buf * SUBB + wave_b * TB) * 2048 + tr_off;
 #pragma unroll
-      for (int i = 0; i < TA; i++) {
-        const s16x4 lo = lds_tr_read(pA + i * 2048 + kk * 16 * 32);
-        const s16x4 hi = lds_tr_read(pA + i * 2048 + kk * 16 * 32 + 4 * 32);
-        const s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        fa[i] = __builtin_bit_cast(bf16x8, t);
+      for (int kk = 0; kk < 4; kk++) {
+        bf16x8 fa[TA], fb[TB];
+#pragma unroll
+        for (int i = 0; i < TA; i++) {
+          const s16x4 lo = lds_tr_read(pA + i * 2048 + kk * 16 * 32);
+          const s16x4 hi = lds_tr_read(pA + i * 2048 + kk * 16 * 32 + 4 * 32);
+          const s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          fa[i] = __builtin_bit_cast(bf16x8, t);
+        }
+#pragma unroll
+        for (int j = 0; j < TB; j++) {
+          const s16x4 lo = lds_tr_read(pB + j * 2048 + kk * 16 * 32);
+          const s16x4 hi = lds_tr_read(pB + j * 2048 + kk * 16 * 32 + 4 * 32);
+          const s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          fb[j] = __builtin_bit_cast(bf16x8, t);
+        }
+#pragma unroll
+        for (int i = 0; i < TA; i++)
+#pragma unroll
+          for (int j = 0; j < TB; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
-#pragma unroll
-      for (int j = 0; j < TB; j++) {
-        const s16x4 lo = lds_tr_read(pB + j * 2048 + kk * 16 * 32);
-        const s16x4 hi = lds_tr_read(pB + j * 2048 + kk * 16 * 32 + 4 * 32);
-        const s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        fb[j] = __builtin_bit_cast(bf16x8, t);
+      if (s + 1 < nsteps) {
+        if constexpr (PF == 1) load_step(s + 1, rA[0], rB[0], okA[0], okB[0]);
+        store_step(buf ^ 1, rA[(d + 1) % PF], rB[(d + 1) % PF], okA[(d + 1) % PF], okB[(d + 1) % PF]);
       }
-#pragma unroll
-      for (int i = 0; i < TA; i++)
-#pragma unroll
-        for (int j = 0; j < TB; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      __syncthreads();
     }
-    if (s + 1 < nsteps) store_step(buf ^ 1);
-    __syncthreads();
   }
 
-  if (nsteps <= 0) return;
   // D[i][j]: row i = ci (reg&3)+8*(reg>>2)+4*(lane>>5), col j = co = lane&31
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -217,9 +247,21 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_kernel(WgradArgs a) {
       }
     }
   }
+  if (do_bias) {
+#pragma unroll
+    for (int j = 0; j < CPB; j++) {
+      const int q = tid + NT * j;
+      if (CHB % NT == 0 || q < CHB) {
+        const int c = co0 + (q % (CoT / 8)) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+          if (c + e < a.Cout) atomicAdd(a.dbias + c + e, bsum[j][e] * a.scale);
+      }
+    }
+  }
 }
 
-template <int WA, int WB, int TA, int TB>
+template <int WA, int WB, int TA, int TB, bool FAST, int PF>
 static int launch_wgrad(WgradArgs a, hipStream_t s) {
   constexpr int CiT = WA * TA * 32, CoT = WB * TB * 32;
   a.tiles_ci = cdiv(a.Cin, CiT);
@@ -233,7 +275,7 @@ static int launch_wgrad(WgradArgs a, hipStream_t s) {
   a.steps_per_split = cdiv(total_steps, splits);
   a.splits = cdiv(total_steps, a.steps_per_split);
   const size_t lds = (size_t)2 * (CiT / 32 + CoT / 32) * 2048 * sizeof(bf16);
-  auto kern = conv_wgrad_kernel<WA, WB, TA, TB>;
+  auto kern = conv_wgrad_kernel<WA, WB, TA, TB, FAST, PF>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -257,21 +299,29 @@ int gank_wgrad_dispatch(WgradArgs a, hipStream_t s) {
   a.shw = log2_or_neg(a.H * a.W);
   GANK_REQUIRE((long)a.N * a.H * a.W < (1L << 31), "conv_wgrad: too many pixels");
   const double flops = 2.0 * a.M * (double)a.Cout * a.taps * a.Cin;
+  const bool fast = (a.Cin % 8 == 0) && (a.Cout % 8 == 0);
   gank_prof_begin(1, flops, s);
   int rc;
-  if (a.Cin >= 128 && a.Cout >= 128) rc = launch_wgrad<2, 2, 2, 2>(a, s);
-  else if (a.Cin <= 32) rc = launch_wgrad<1, 4, 1, 1>(a, s);     // 32 ci x 128 co (image-side layers)
-  else if (a.Cout <= 32) rc = launch_wgrad<4, 1, 1, 1>(a, s);    // 128 ci x 32 co (G.Output, D.Output)
-  else rc = launch_wgrad<2, 2, 1, 1>(a, s);                      // 64 x 64
+  if (fast) {
+    if (a.Cin >= 128 && a.Cout >= 128) rc = launch_wgrad<2, 2, 2, 2, true, 3>(a, s);
+    else if (a.Cin <= 32) rc = launch_wgrad<1, 4, 1, 1, true, 3>(a, s);
+    else if (a.Cout <= 32) rc = launch_wgrad<4, 1, 1, 1, true, 3>(a, s);
+    else rc = launch_wgrad<2, 2, 1, 1, true, 3>(a, s);                    // 64 x 64
+  } else {
+    if (a.Cin >= 128 && a.Cout >= 128) rc = launch_wgrad<2, 2, 2, 2, false, 1>(a, s);
+    else if (a.Cin <= 32) rc = launch_wgrad<1, 4, 1, 1, false, 1>(a, s);  // 32 ci x 128 co (image-side layers)
+    else if (a.Cout <= 32) rc = launch_wgrad<4, 1, 1, 1, false, 1>(a, s); // 128 ci x 32 co (G.Output, D.Output)
+    else rc = launch_wgrad<2, 2, 1, 1, false, 1>(a, s);
+  }
   gank_prof_end(1, s);
   return rc;
 }
 
-extern "C" int gank_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int Cout,
-                                 int ksize, int flags, float scale, void* stream) {
+extern "C" int gank_conv2d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int Cin,
+                                 int Cout, int ksize, int flags, float scale, void* stream) {
   GANK_REQUIRE(ksize % 2 == 1, "conv2d_wgrad: even filter sizes are not on this path (ksize=%d)", ksize);
   WgradArgs a{};
-  a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.dw = dw;
+  a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.dw = dw; a.dbias = dbias;
   a.N = N; a.H = H; a.W = W;
   const bool xup = flags & GANK_IN_UPSAMPLE2X, dyup = flags & GANK_DY_UPSAMPLE2X;
   GANK_REQUIRE(!(xup || dyup) || (H % 2 == 0 && W % 2 == 0), "conv2d_wgrad: 2x flags need even size");

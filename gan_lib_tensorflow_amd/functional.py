@@ -62,15 +62,17 @@ class _Conv2d(Function):
             g = K.tanh_bwd(g, y)
         scale = 0.25 if pool_out else 1.0
         dW = db = dx = None
+        btgt = None
+        if bias is not None and ctx.needs_input_grad[2]:
+            btgt, bacc = _target(bias)
+            db = None if bacc else btgt
         if ctx.needs_input_grad[1]:
             tgt, acc = _target(W)
             wflags = (K.IN_UPSAMPLE2X if upsample else 0) | (K.IN_RELU if in_relu else 0) | (K.DY_UPSAMPLE2X if pool_out else 0)
-            K.conv2d_wgrad(x, g, tgt, (H, Wd), k, wflags, scale)
+            K.conv2d_wgrad(x, g, tgt, (H, Wd), k, wflags, scale, dbias=btgt)   # bias gradient rides on the dy stream
             dW = None if acc else tgt
-        if bias is not None and ctx.needs_input_grad[2]:
-            tgt, acc = _target(bias)
-            K.colsum(g, tgt, 1.0)
-            db = None if acc else tgt
+        elif btgt is not None:
+            K.colsum(g, btgt, 1.0)
         if ctx.needs_input_grad[0]:
             _, wd = K.prep_weights(W.detach().view(k, k, cin, cout), False, True)
             dflags = K.IN_UPSAMPLE2X if pool_out else 0

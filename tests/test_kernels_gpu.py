@@ -149,7 +149,10 @@ def test_conv_wgrad(K, n, h, cin, cout, k, mode):
         dy, dyt = bf(rng.normal(size=(n, H, H, cout)))
         dyfull = dy
     dw = torch.zeros((k, k, cin, cout), dtype=torch.float32, device="cuda")
-    K.conv2d_wgrad(xt, dyt, dw, (H, H), k, flags, scale)
+    dbf = torch.zeros(cout, dtype=torch.float32, device="cuda")
+    K.conv2d_wgrad(xt, dyt, dw, (H, H), k, flags, scale, dbias=dbf)      # fused bias gradient
+    torch.cuda.synchronize()
+    assert relerr(dbf, dy.sum(axis=(0, 1, 2))) < F32_FROM_BF_TOL
     w0 = np.zeros((k, k, cin, cout))
     _, ref, refb = R.conv2d_same_grads(xin, w0, dyfull)
     torch.cuda.synchronize()
