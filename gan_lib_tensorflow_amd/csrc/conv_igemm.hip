@@ -13,6 +13,8 @@
 // Replaces tf.nn.conv2d / Conv2DBackpropInput at common/ops/conv2d.py:180-187 and the
 // surrounding block-library glue (SNGAN/gan_cifar_resnet.py:112-153,186,198,209,261).
 #include "gank_common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 #define IG_IN_ZEROINS2X 16
 #define IG_IN_STRIDE2 32
@@ -38,9 +40,13 @@ struct IgemmArgs {
 
 constexpr int LROW = 72;  // LDS row length in bf16 (64 + 8 pad) = 144 B
 
-// PF = register prefetch slots: global loads for K-step s+PF-1 are in flight while step s is computed
-// (plain loads survive the per-step barrier; hipcc emits counted vmcnt waits for the oldest slot only).
-template <int WM, int WN, int TM, int TN, bool PACKED, int PF>
+// PF   = register prefetch slots: global loads for K-step s+PF-1 are in flight while step s is computed
+//        (plain loads survive the per-step barrier; hipcc emits counted vmcnt waits for the oldest slot).
+// MODE = compile-time gather mode (bit0: relu on the input operand, bit1: shifted index = NN-upsample or
+//        zero insertion).  The staging pass runs once per K-step per wave and competes with the MFMAs for
+//        issue slots, so its instruction count is what bounds this kernel: runtime flags cost selects,
+//        64-bit address arithmetic cost 3x the VALU work, tap decoding by division 100+ SALU per step.
+template <int WM, int WN, int TM, int TN, bool PACKED, int PF, int MODE>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32;
@@ -48,6 +54,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
   constexpr int CP = BM * 8 / NT;  // 16-byte pixel chunks per thread per step
   constexpr int CW = BN * 8 / NT;  // 16-byte weight chunks per thread per step
   static_assert(CP >= 1 && CW >= 1, "tile too small for the thread count");
+  static_assert(!PACKED || (PF == 1 && MODE == 0), "the packed path takes its flags at run time");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16* sP = reinterpret_cast<bf16*>(smem);             // [2][BM][LROW]
@@ -63,9 +70,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
   const int tile_n = lid % a.tiles_n, tile_m = lid / a.tiles_n;
 
   const int st = (a.flags & IG_IN_STRIDE2) ? 2 : 1;
-  const bool shr = (a.flags & (GANK_IN_UPSAMPLE2X | IG_IN_ZEROINS2X)) != 0;
+  const bool shr = PACKED ? (a.flags & (GANK_IN_UPSAMPLE2X | IG_IN_ZEROINS2X)) != 0 : (MODE & 2) != 0;
   const bool zins = (a.flags & IG_IN_ZEROINS2X) != 0;
-  const bool inrelu = (a.flags & GANK_IN_RELU) != 0;
+  const bool inrelu = PACKED ? (a.flags & GANK_IN_RELU) != 0 : (MODE & 1) != 0;
   const int LH = shr ? 2 * a.Hin : a.Hin, LW = shr ? 2 * a.Win : a.Win;
 
   // per-thread pixel chunk descriptors (fixed for the whole K loop)
@@ -88,36 +95,54 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
   }
 
   u32x4 rP[PF][CP], rW[PF][CW];
-  unsigned rOk[PF];   // per slot: bit j = pixel chunk j is inside the image (else it is zero padding)
 
-  // Loads are UNCONDITIONAL (out-of-image taps read a dummy in-bounds address and are zeroed when the
-  // slot is written to LDS): any branch around a load makes hipcc's vmcnt bookkeeping assume the worst
-  // path and drain the whole prefetch ring at every step.
-  auto load_step = [&](int s, u32x4 (&rP)[CP], u32x4 (&rW)[CW], unsigned& okm) {
-    okm = 0u;
+  // Fast path: buffer loads with 32-bit byte offsets.  Out-of-image taps get an out-of-range voffset,
+  // for which the hardware bounds check returns ZEROS: padding costs no branch, no select and no mask,
+  // and every load is unconditional (a branch around a load makes hipcc's vmcnt bookkeeping assume the
+  // worst path and drain the prefetch ring at every step).
+  constexpr int OOB = 0x7FFFFFF0;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16*>(a.x), 0, a.N * a.Hin * a.Win * a.Cin * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16*>(a.w), 0, a.CoutPad * a.Kpad * 2, 0x00020000);
+  int p_off[CP];   // byte offset of (n, oh*st, ow*st, cc*8) in x   (non-shifted-index modes)
+  int w_off[CW];   // byte offset of (co, cc*8) in w
+#pragma unroll
+  for (int j = 0; j < CP; j++)
+    p_off[j] = ((p_base[j] + p_oh[j] * a.Win + p_ow[j]) * a.Cin + ((tid + NT * j) & 7) * 8) * 2;
+#pragma unroll
+  for (int j = 0; j < CW; j++) {
+    const int q = tid + NT * j;
+    w_off[j] = ((tile_n * BN + (q >> 3)) * a.Kpad + (q & 7) * 8) * 2;
+  }
+
+  // K-step cursor, advanced incrementally (tap-major, then 64-channel chunk): no divisions in the loop.
+  // After the last step it stays put, so the PF-1 trailing refills of the ring re-load the last step.
+  const int last = a.nsteps - 1;
+  int cur = 0, cur_c0 = 0, cur_dh = -a.pad, cur_dw = -a.pad;
+
+  auto load_next = [&](u32x4 (&rP)[CP], u32x4 (&rW)[CW]) {
     if constexpr (!PACKED) {
-      const int ck = a.Cin >> 6;
-      const int tap = s / ck;
-      const int c0 = (s - tap * ck) << 6;
-      const int dh = tap / a.ks - a.pad, dw = tap % a.ks - a.pad;
+      const int delta = ((cur_dh * a.Win + cur_dw) * a.Cin + cur_c0) * 2;     // wave-uniform (SALU)
 #pragma unroll
       for (int j = 0; j < CP; j++) {
-        const int cc = (tid + NT * j) & 7;
-        int ih = p_oh[j] + dh, iw = p_ow[j] + dw;
+        const int ih = p_oh[j] + cur_dh, iw = p_ow[j] + cur_dw;
         bool ok = (unsigned)ih < (unsigned)LH && (unsigned)iw < (unsigned)LW;
-        if (zins) ok = ok && (((ih | iw) & 1) == 0);
-        if (shr) { ih >>= 1; iw >>= 1; }
-        const long off = ok ? ((long)(p_base[j] + ih * a.Win + iw)) * a.Cin + c0 + cc * 8 : 0L;
-        rP[j] = *reinterpret_cast<const u32x4*>(a.x + off);   // zero-fill and relu happen at LDS-store time
-        okm |= (ok ? 1u : 0u) << j;
+        int off;
+        if constexpr ((MODE & 2) != 0) {   // upsample / zero-insertion: the stored index is (ih>>1, iw>>1)
+          if (zins) ok = ok && (((ih | iw) & 1) == 0);
+          off = ((p_base[j] + (ih >> 1) * a.Win + (iw >> 1)) * a.Cin + cur_c0 + ((tid + NT * j) & 7) * 8) * 2;
+        } else {
+          off = p_off[j] + delta;
+        }
+        rP[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? off : OOB, 0, 0);
       }
     } else {
-      okm = ~0u;
       const int ktot = a.taps * a.Cin;
 #pragma unroll
       for (int j = 0; j < CP; j++) {
         const int cc = (tid + NT * j) & 7;
-        const int kb = s * 64 + cc * 8;
+        const int kb = cur * 64 + cc * 8;
         bf16x8 v;
 #pragma unroll
         for (int e = 0; e < 8; e++) {
@@ -141,23 +166,23 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
       }
     }
 #pragma unroll
-    for (int j = 0; j < CW; j++) {
-      const int q = tid + NT * j;
-      const int co = tile_n * BN + (q >> 3);
-      rW[j] = *reinterpret_cast<const u32x4*>(a.w + (long)co * a.Kpad + s * 64 + (q & 7) * 8);
+    for (int j = 0; j < CW; j++) rW[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off[j], cur * 128, 0);
+    if (cur < last) {
+      cur++;
+      cur_c0 += 64;
+      if (cur_c0 >= a.Cin) {
+        cur_c0 = 0;
+        if (++cur_dw > a.ks - 1 - a.pad) { cur_dw = -a.pad; cur_dh++; }
+      }
     }
   };
 
-  auto store_step = [&](int buf, u32x4 (&rP)[CP], u32x4 (&rW)[CW], unsigned okm) {
+  auto store_step = [&](int buf, u32x4 (&rP)[CP], u32x4 (&rW)[CW]) {
 #pragma unroll
     for (int j = 0; j < CP; j++) {
       const int q = tid + NT * j;
       u32x4 v = rP[j];
-      if constexpr (!PACKED) {
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        v = ((okm >> j) & 1u) ? v : z;
-        if (inrelu) v = relu_bf16x8(v);
-      }
+      if constexpr (!PACKED && (MODE & 1) != 0) v = relu_bf16x8(v);
       *reinterpret_cast<u32x4*>(sP + (buf * BM + (q >> 3)) * LROW + (q & 7) * 8) = v;
     }
 #pragma unroll
@@ -175,42 +200,49 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
-  const int last = a.nsteps - 1;
 #pragma unroll
-  for (int d = 0; d < PF; d++) load_step(d < last ? d : last, rP[d], rW[d], rOk[d]);
-  store_step(0, rP[0], rW[0], rOk[0]);
+  for (int d = 0; d < PF; d++) load_next(rP[d], rW[d]);     // steps 0 .. PF-1 (clamped)
+  store_step(0, rP[0], rW[0]);
   __syncthreads();
 
-  for (int s0 = 0; s0 < a.nsteps; s0 += PF) {
+  // one K-step on ring slot D (compile-time): refill the slot, MFMAs on LDS buffer s&1, stage step s+1
+  auto step = [&](int s, auto slot) {
+    constexpr int D = decltype(slot)::value;
+    const int buf = s & 1;
+    if constexpr (PF > 1) load_next(rP[D], rW[D]);     // slot D held step s (already in LDS): now step s+PF
+    const bf16* pW = sW + (buf * BN + wave_n * TN * 32 + r) * LROW + h * 8;
+    const bf16* pP = sP + (buf * BM + wave_m * TM * 32 + r) * LROW + h * 8;
 #pragma unroll
-    for (int d = 0; d < PF; d++) {
-      const int s = s0 + d;
-      if (s >= a.nsteps) break;
-      const int buf = s & 1;
-      // slot d held step s (already in LDS): refill it with step s+PF (clamped: tail loads are redundant)
-      if constexpr (PF > 1) load_step(s + PF < last ? s + PF : last, rP[d], rW[d], rOk[d]);
-      const bf16* pW = sW + (buf * BN + wave_n * TN * 32 + r) * LROW + h * 8;
-      const bf16* pP = sP + (buf * BM + wave_m * TM * 32 + r) * LROW + h * 8;
+    for (int kk = 0; kk < 4; kk++) {
+      bf16x8 fa[TN], fb[TM];
 #pragma unroll
-      for (int kk = 0; kk < 4; kk++) {
-        bf16x8 fa[TN], fb[TM];
+      for (int i = 0; i < TN; i++) fa[i] = *reinterpret_cast<const bf16x8*>(pW + i * 32 * LROW + kk * 16);
 #pragma unroll
-        for (int i = 0; i < TN; i++) fa[i] = *reinterpret_cast<const bf16x8*>(pW + i * 32 * LROW + kk * 16);
+      for (int j = 0; j < TM; j++) fb[j] = *reinterpret_cast<const bf16x8*>(pP + j * 32 * LROW + kk * 16);
 #pragma unroll
-        for (int j = 0; j < TM; j++) fb[j] = *reinterpret_cast<const bf16x8*>(pP + j * 32 * LROW + kk * 16);
+      for (int i = 0; i < TN; i++)
 #pragma unroll
-        for (int i = 0; i < TN; i++)
-#pragma unroll
-          for (int j = 0; j < TM; j++)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      }
-      if (s + 1 < a.nsteps) {
-        if constexpr (PF == 1) load_step(s + 1, rP[0], rW[0], rOk[0]);
-        store_step(buf ^ 1, rP[(d + 1) % PF], rW[(d + 1) % PF], rOk[(d + 1) % PF]);
-      }
-      __syncthreads();
+        for (int j = 0; j < TM; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
+    if (s + 1 < a.nsteps) {
+      if constexpr (PF == 1) load_next(rP[0], rW[0]);
+      store_step(buf ^ 1, rP[(D + 1) % PF], rW[(D + 1) % PF]);
+    }
+    __syncthreads();
+  };
+
+  // full ring revolutions (no exits inside the unrolled body), then the < PF leftover steps
+  int s0 = 0;
+  for (; s0 + PF <= a.nsteps; s0 += PF) {
+    if constexpr (PF >= 1) step(s0 + 0, std::integral_constant<int, 0>{});
+    if constexpr (PF >= 2) step(s0 + 1, std::integral_constant<int, 1 % PF>{});
+    if constexpr (PF >= 3) step(s0 + 2, std::integral_constant<int, 2 % PF>{});
+    if constexpr (PF >= 4) step(s0 + 3, std::integral_constant<int, 3 % PF>{});
   }
+  if constexpr (PF >= 2) { if (s0 + 0 < a.nsteps) step(s0 + 0, std::integral_constant<int, 0>{}); }
+  if constexpr (PF >= 3) { if (s0 + 1 < a.nsteps) step(s0 + 1, std::integral_constant<int, 1 % PF>{}); }
+  if constexpr (PF >= 4) { if (s0 + 2 < a.nsteps) step(s0 + 2, std::integral_constant<int, 2 % PF>{}); }
 
   // epilogue: lane holds, per accumulator quad g, channels co0+8g+4h .. +3 of pixel m
   const bool vec = (a.Cout & 3) == 0;
@@ -266,14 +298,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
   }
 }
 
-template <int WM, int WN, int TM, int TN, bool PACKED, int PF>
+template <int WM, int WN, int TM, int TN, bool PACKED, int PF, int MODE>
 static int launch_cfg(const IgemmArgs& a0, hipStream_t s) {
   IgemmArgs a = a0;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   a.tiles_m = cdiv(a.M, BM);
   a.tiles_n = a.CoutPad / BN;
   const size_t lds = (size_t)2 * (BM + BN) * LROW * sizeof(bf16);
-  auto kern = conv_igemm_kernel<WM, WN, TM, TN, PACKED, PF>;
+  auto kern = conv_igemm_kernel<WM, WN, TM, TN, PACKED, PF, MODE>;
   static bool attr_set = false;  // benign race: idempotent
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -285,12 +317,23 @@ static int launch_cfg(const IgemmArgs& a0, hipStream_t s) {
   return 0;
 }
 
+template <int WM, int WN, int TM, int TN, int PF>
+static int launch_mode(const IgemmArgs& a, hipStream_t s) {
+  const int mode = ((a.flags & GANK_IN_RELU) ? 1 : 0) | ((a.flags & (GANK_IN_UPSAMPLE2X | IG_IN_ZEROINS2X)) ? 2 : 0);
+  switch (mode) {
+    case 0: return launch_cfg<WM, WN, TM, TN, false, PF, 0>(a, s);
+    case 1: return launch_cfg<WM, WN, TM, TN, false, PF, 1>(a, s);
+    case 2: return launch_cfg<WM, WN, TM, TN, false, PF, 2>(a, s);
+    default: return launch_cfg<WM, WN, TM, TN, false, PF, 3>(a, s);
+  }
+}
+
 // x [N,Hin,Win,Cin] -> y [N,H,W,Cout];  w [CoutPad][Kpad] bf16
 int gank_igemm_dispatch(IgemmArgs a, hipStream_t s) {
   GANK_REQUIRE(a.x && a.w && a.y, "conv_igemm: null pointer");
   GANK_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Cin > 0 && a.Cout > 0, "conv_igemm: bad shape");
   GANK_REQUIRE(a.ks >= 1 && a.ks <= 7, "conv_igemm: unsupported filter size %d", a.ks);
-  GANK_REQUIRE((long)a.N * a.Hin * a.Win * a.Cin < (1L << 31) && (long)a.N * a.H * a.W * a.Cout < (1L << 40), "conv_igemm: tensor too large");
+  GANK_REQUIRE((long)a.N * a.Hin * a.Win * a.Cin < (1L << 30) && (long)a.N * a.H * a.W * a.Cout < (1L << 40), "conv_igemm: tensor too large (32-bit byte offsets)");
   a.taps = a.ks * a.ks;
   a.CoutPad = roundup(a.Cout, 32);
   a.Kpad = roundup(a.taps * a.Cin, 64);
@@ -303,15 +346,21 @@ int gank_igemm_dispatch(IgemmArgs a, hipStream_t s) {
   gank_prof_begin(0, flops, s);
   int rc;
   const long tiles128 = (long)cdiv(a.M, 128) * (a.CoutPad / 128);
+  static int pf_env = -1;   // experiment knob: GANK_IGEMM_PF=1|2|3 overrides the prefetch depth
+  if (pf_env < 0) { const char* e = getenv("GANK_IGEMM_PF"); pf_env = e ? atoi(e) : 0; }
   if (packed) {
-    if (a.CoutPad % 64 == 0) rc = launch_cfg<2, 2, 1, 1, true, 1>(a, s);
-    else rc = launch_cfg<4, 1, 2, 1, true, 1>(a, s);
+    if (a.CoutPad % 64 == 0) rc = launch_cfg<2, 2, 1, 1, true, 1, 0>(a, s);
+    else rc = launch_cfg<4, 1, 2, 1, true, 1, 0>(a, s);
   } else if (a.CoutPad % 128 == 0 && tiles128 >= 192) {
-    rc = launch_cfg<2, 2, 2, 2, false, 3>(a, s);
+    if (pf_env == 1) rc = launch_mode<2, 2, 2, 2, 1>(a, s);
+    else if (pf_env == 3) rc = launch_mode<2, 2, 2, 2, 3>(a, s);
+    else rc = launch_mode<2, 2, 2, 2, 2>(a, s);
   } else if (a.CoutPad % 64 == 0) {
-    rc = launch_cfg<2, 2, 1, 1, false, 4>(a, s);
+    if (pf_env == 1) rc = launch_mode<2, 2, 1, 1, 1>(a, s);
+    else if (pf_env == 3) rc = launch_mode<2, 2, 1, 1, 2>(a, s);
+    else rc = launch_mode<2, 2, 1, 1, 4>(a, s);
   } else {
-    rc = launch_cfg<4, 1, 2, 1, false, 3>(a, s);
+    rc = launch_mode<4, 1, 2, 1, 2>(a, s);
   }
   gank_prof_end(0, s);
   return rc;

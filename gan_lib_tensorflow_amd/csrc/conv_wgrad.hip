@@ -11,6 +11,7 @@
 // Replaces Conv2DBackpropFilter for common/ops/conv2d.py:180-187; the gather fuses NN-upsample,
 // relu, the mean-pool gradient (dy stored at half size) and the stride-2 form used by Deconv2D.
 #include "gank_common.h"
+#include <type_traits>
 
 #define WG_X_ZEROINS2X 16  // (unused here; kept aligned with conv_igemm flags)
 #define WG_X_STRIDE2 32
@@ -248,16 +249,290 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_kernel(WgradArgs a) {
     }
   }
   if (do_bias) {
+    // block-level reduction through LDS (the staging buffers are free now), then ONE atomic per channel:
+    // contended same-address float atomics serialise at the memory side
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);            // [NT][CPB*8]
+#pragma unroll
+    for (int j = 0; j < CPB; j++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) red[(tid * CPB + j) * 8 + e] = bsum[j][e];
+    __syncthreads();
+    for (int c = tid; c < CoT; c += NT) {
+      if (co0 + c >= a.Cout) continue;
+      const int cc = c >> 3, e = c & 7;
+      float t = 0.f;
+      // chunk (p, cc) lives in thread q % NT, slot q / NT with q = p * (CoT/8) + cc
+      for (int p = 0; p < 64; p++) {
+        const int q = p * (CoT / 8) + cc;
+        if (q < CHB) t += red[((q % NT) * CPB + q / NT) * 8 + e];
+      }
+      atomicAdd(a.dbias + co0 + c, t * a.scale);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Lean variant for the layers that carry the FLOPs: Cin%8==0, Cout%8==0, power-of-two H and W, stride 1,
+// M%64==0.  The general kernel above spends ~500 VALU instructions per 16 MFMAs on gather arithmetic
+// (rocprof: 20 VALU per MFMA, VALU-issue-bound at 186 TFLOP/s); here the staging pass is ~10 per 16-byte
+// chunk: 32-bit byte offsets into buffer loads (out-of-image -> out-of-range offset -> hardware returns
+// zeros), pixel coordinates by shift/mask, compile-time MODE (bit0 relu(x), bit1 x stored at half size,
+// bit2 dy stored at half size), PF-slot register ring with no exits inside the unrolled body.
+// Sub-tiles are 64 B apart mod 256 B so the ds_write_b128 of one pixel's 128 channels is conflict-free.
+// ------------------------------------------------------------------------------------------------------
+constexpr int SUBS = 2048 + 32;   // sub-tile stride in bf16 elements
+
+template <int WA, int WB, int TA, int TB, int PF, int MODE>
+__global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_lean_kernel(WgradArgs a) {
+  constexpr int NT = WA * WB * 64;
+  constexpr int CiT = WA * TA * 32, CoT = WB * TB * 32;
+  constexpr int SUBA = CiT / 32, SUBB = CoT / 32;
+  constexpr int CHA = 64 * CiT / 8, CHB = 64 * CoT / 8;
+  static_assert(CHA % NT == 0 && CHB % NT == 0, "tile/threads mismatch");
+  constexpr int CPA = CHA / NT, CPB = CHB / NT;
+  constexpr bool XRELU = (MODE & 1) != 0, XUP = (MODE & 2) != 0, DYUP = (MODE & 4) != 0;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* sA = reinterpret_cast<bf16*>(smem);          // [2][SUBA] sub-tiles of [64 pixels][32 ch]
+  bf16* sB = sA + 2 * SUBA * SUBS;                   // [2][SUBB]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_a = wave % WA, wave_b = wave / WA;
+
+  int bid = blockIdx.x;
+  const int split = bid % a.splits; bid /= a.splits;
+  const int tco = bid % a.tiles_co; bid /= a.tiles_co;
+  const int tci = bid % a.tiles_ci; bid /= a.tiles_ci;
+  const int tap = bid;
+  const int dh = tap / a.ks - a.pad, dw = tap % a.ks - a.pad;
+  const int ci0 = tci * CiT, co0 = tco * CoT;
+  const bool do_bias = a.dbias != nullptr && tap == 0 && tci == 0;
+
+  const int step0 = split * a.steps_per_split;
+  int nsteps = (a.M >> 6) - step0;
+  if (nsteps > a.steps_per_split) nsteps = a.steps_per_split;
+  if (nsteps <= 0) return;
+
+  constexpr int OOB = 0x7FFFFFF0;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16*>(a.x), 0, a.N * a.Hx * a.Wx * a.Cin * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16*>(a.dy), 0, a.N * a.Hdy * a.Wdy * a.Cout * 2, 0x00020000);
+  const int Wm = a.W - 1, Hm = a.H - 1, sw = a.sw, shw = a.shw;
+
+  // per-thread chunk constants: pixel-in-step p, channel byte offset (or OOB when the chunk is past C)
+  int a_p[CPA], a_c[CPA], b_p[CPB], b_c[CPB], a_lds[CPA], b_lds[CPB];
+#pragma unroll
+  for (int j = 0; j < CPA; j++) {
+    const int q = tid + NT * j, p = q / (CiT / 8), cc = q % (CiT / 8);
+    a_p[j] = p;
+    a_c[j] = (ci0 + cc * 8 < a.Cin) ? (ci0 + cc * 8) * 2 : OOB;
+    a_lds[j] = (cc >> 2) * SUBS + p * 32 + (cc & 3) * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < CPB; j++) {
+    const int q = tid + NT * j, p = q / (CoT / 8), cc = q % (CoT / 8);
+    b_p[j] = p;
+    b_c[j] = (co0 + cc * 8 < a.Cout) ? (co0 + cc * 8) * 2 : OOB;
+    b_lds[j] = (cc >> 2) * SUBS + p * 32 + (cc & 3) * 8;
+  }
+
+  u32x4 rA[PF][CPA], rB[PF][CPB];
+  float bsum[CPB][8];
+#pragma unroll
+  for (int j = 0; j < CPB; j++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) bsum[j][e] = 0.f;
+
+  const int last = nsteps - 1;
+  int cur = 0;   // step cursor; parks on the last step so trailing ring refills are harmless re-loads
+
+  auto load_next = [&](u32x4 (&rA)[CPA], u32x4 (&rB)[CPB]) {
+    const int mbase = (step0 + cur) << 6;
+#pragma unroll
+    for (int j = 0; j < CPA; j++) {
+      const int m = mbase + a_p[j];
+      const int ow = m & Wm, t = m >> sw, oh = t & Hm;
+      const int ih = oh + dh, iw = ow + dw;
+      const bool ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+      int off;
+      if constexpr (XUP) {
+        const int n = m >> shw;
+        off = ((n * a.Hx + (ih >> 1)) * a.Wx + (iw >> 1)) * a.Cin * 2 + a_c[j];
+      } else {
+        off = (m + dh * a.W + dw) * a.Cin * 2 + a_c[j];
+      }
+      rA[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? off : OOB, 0, 0);
+    }
 #pragma unroll
     for (int j = 0; j < CPB; j++) {
-      const int q = tid + NT * j;
-      if (CHB % NT == 0 || q < CHB) {
-        const int c = co0 + (q % (CoT / 8)) * 8;
+      const int m = mbase + b_p[j];
+      int off;
+      if constexpr (DYUP) {
+        const int ow = m & Wm, t = m >> sw, oh = t & Hm, n = m >> shw;
+        off = ((n * a.Hdy + (oh >> 1)) * a.Wdy + (ow >> 1)) * a.Cout * 2 + b_c[j];
+      } else {
+        off = m * a.Cout * 2 + b_c[j];
+      }
+      rB[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, off, 0, 0);   // b_c == OOB pushes it out of range
+    }
+    if (cur < last) cur++;
+  };
+
+  auto store_step = [&](int buf, u32x4 (&rA)[CPA], u32x4 (&rB)[CPB]) {
 #pragma unroll
-        for (int e = 0; e < 8; e++)
-          if (c + e < a.Cout) atomicAdd(a.dbias + c + e, bsum[j][e] * a.scale);
+    for (int j = 0; j < CPA; j++) {
+      u32x4 v = rA[j];
+      if constexpr (XRELU) v = relu_bf16x8(v);
+      *reinterpret_cast<u32x4*>(sA + buf * SUBA * SUBS + a_lds[j]) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < CPB; j++) {
+      *reinterpret_cast<u32x4*>(sB + buf * SUBB * SUBS + b_lds[j]) = rB[j];
+      if (do_bias) {
+        const bf16x8 t = __builtin_bit_cast(bf16x8, rB[j]);
+#pragma unroll
+        for (int e = 0; e < 8; e++) bsum[j][e] += bf2f(t[e]);
       }
     }
+  };
+
+  f32x16 acc[TA][TB];
+#pragma unroll
+  for (int i = 0; i < TA; i++)
+#pragma unroll
+    for (int j = 0; j < TB; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+  const int g = lane >> 4, li = lane & 15;
+  const int tr_off = ((8 * (g >> 1) + (li >> 2)) * 32) + 16 * (g & 1) + 4 * (li & 3);
+
+#pragma unroll
+  for (int d = 0; d < PF; d++) load_next(rA[d], rB[d]);
+  store_step(0, rA[0], rB[0]);
+  __syncthreads();
+
+  auto step = [&](int s, auto slot) {
+    constexpr int D = decltype(slot)::value;
+    const int buf = s & 1;
+    if constexpr (PF > 1) load_next(rA[D], rB[D]);
+    const bf16* pA = sA + (buf * SUBA + wave_a * TA) * SUBS + tr_off;
+    const bf16* pB = sB + (buf * SUBB + wave_b * TB) * SUBS + tr_off;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      bf16x8 fa[TA], fb[TB];
+#pragma unroll
+      for (int i = 0; i < TA; i++) {
+        const s16x4 lo = lds_tr_read(pA + i * SUBS + kk * 16 * 32);
+        const s16x4 hi = lds_tr_read(pA + i * SUBS + kk * 16 * 32 + 4 * 32);
+        const s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        fa[i] = __builtin_bit_cast(bf16x8, t);
+      }
+#pragma unroll
+      for (int j = 0; j < TB; j++) {
+        const s16x4 lo = lds_tr_read(pB + j * SUBS + kk * 16 * 32);
+        const s16x4 hi = lds_tr_read(pB + j * SUBS + kk * 16 * 32 + 4 * 32);
+        const s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        fb[j] = __builtin_bit_cast(bf16x8, t);
+      }
+#pragma unroll
+      for (int i = 0; i < TA; i++)
+#pragma unroll
+        for (int j = 0; j < TB; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (s + 1 < nsteps) {
+      if constexpr (PF == 1) load_next(rA[0], rB[0]);
+      store_step(buf ^ 1, rA[(D + 1) % PF], rB[(D + 1) % PF]);
+    }
+    __syncthreads();
+  };
+
+  int s0 = 0;
+  for (; s0 + PF <= nsteps; s0 += PF) {
+    if constexpr (PF >= 1) step(s0 + 0, std::integral_constant<int, 0>{});
+    if constexpr (PF >= 2) step(s0 + 1, std::integral_constant<int, 1 % PF>{});
+    if constexpr (PF >= 3) step(s0 + 2, std::integral_constant<int, 2 % PF>{});
+  }
+  if constexpr (PF >= 2) { if (s0 + 0 < nsteps) step(s0 + 0, std::integral_constant<int, 0>{}); }
+  if constexpr (PF >= 3) { if (s0 + 1 < nsteps) step(s0 + 1, std::integral_constant<int, 1 % PF>{}); }
+
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < TA; i++) {
+#pragma unroll
+    for (int j = 0; j < TB; j++) {
+      const int co = co0 + (wave_b * TB + j) * 32 + r;
+      if (co >= a.Cout) continue;
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int ci = ci0 + (wave_a * TA + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (ci < a.Cin) atomicAdd(a.dw + ((long)tap * a.Cin + ci) * a.Cout + co, acc[i][j][e] * a.scale);
+      }
+    }
+  }
+  if (do_bias) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);            // [NT][CPB*8]
+#pragma unroll
+    for (int j = 0; j < CPB; j++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) red[(tid * CPB + j) * 8 + e] = bsum[j][e];
+    __syncthreads();
+    for (int c = tid; c < CoT; c += NT) {
+      if (co0 + c >= a.Cout) continue;
+      const int cc = c >> 3, e = c & 7;
+      float t = 0.f;
+      for (int p = 0; p < 64; p++) {
+        const int q = p * (CoT / 8) + cc;
+        t += red[((q % NT) * CPB + q / NT) * 8 + e];
+      }
+      atomicAdd(a.dbias + co0 + c, t * a.scale);
+    }
+  }
+}
+
+template <int WA, int WB, int TA, int TB, int PF, int MODE>
+static int launch_wgrad_lean_mode(WgradArgs a, hipStream_t s) {
+  constexpr int CiT = WA * TA * 32, CoT = WB * TB * 32;
+  a.tiles_ci = cdiv(a.Cin, CiT);
+  a.tiles_co = cdiv(a.Cout, CoT);
+  const int total_steps = a.M / 64;
+  const long tiles = (long)a.taps * a.tiles_ci * a.tiles_co;
+  int splits = (int)((768 + tiles - 1) / tiles);
+  if (splits > total_steps / 4) splits = total_steps / 4;
+  if (splits < 1) splits = 1;
+  a.steps_per_split = cdiv(total_steps, splits);
+  a.splits = cdiv(total_steps, a.steps_per_split);
+  size_t lds = (size_t)2 * (CiT / 32 + CoT / 32) * SUBS * sizeof(bf16);
+  const size_t red = (size_t)WA * WB * 64 * (64 * CoT / 8 / (WA * WB * 64)) * 8 * sizeof(float);
+  if (red > lds) lds = red;
+  auto kern = conv_wgrad_lean_kernel<WA, WB, TA, TB, PF, MODE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return gank_set_error("conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  const long grid = tiles * a.splits;
+  GANK_REQUIRE(grid < (1L << 30), "conv_wgrad: grid too large");
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WA * WB * 64), lds, s, a);
+  GANK_LAUNCH_OK("conv_wgrad_lean");
+  return 0;
+}
+
+template <int WA, int WB, int TA, int TB, int PF>
+static int launch_wgrad_lean(const WgradArgs& a, hipStream_t s) {
+  const int mode = ((a.flags & GANK_IN_RELU) ? 1 : 0) | ((a.flags & GANK_IN_UPSAMPLE2X) ? 2 : 0) | ((a.flags & GANK_DY_UPSAMPLE2X) ? 4 : 0);
+  switch (mode) {
+    case 0: return launch_wgrad_lean_mode<WA, WB, TA, TB, PF, 0>(a, s);
+    case 1: return launch_wgrad_lean_mode<WA, WB, TA, TB, PF, 1>(a, s);
+    case 2: return launch_wgrad_lean_mode<WA, WB, TA, TB, PF, 2>(a, s);
+    case 4: return launch_wgrad_lean_mode<WA, WB, TA, TB, PF, 4>(a, s);
+    case 5: return launch_wgrad_lean_mode<WA, WB, TA, TB, PF, 5>(a, s);
+    default: return -1;   // combination not instantiated: caller falls back to the general kernel
   }
 }
 
@@ -301,8 +576,16 @@ int gank_wgrad_dispatch(WgradArgs a, hipStream_t s) {
   const double flops = 2.0 * a.M * (double)a.Cout * a.taps * a.Cin;
   const bool fast = (a.Cin % 8 == 0) && (a.Cout % 8 == 0);
   gank_prof_begin(1, flops, s);
-  int rc;
-  if (fast) {
+  int rc = -1;
+  const bool lean = fast && a.sw >= 0 && a.shw >= 0 && !(a.flags & WG_X_STRIDE2) && (a.M % 64 == 0) &&
+                    (long)a.N * a.Hx * a.Wx * a.Cin < (1L << 30) && (long)a.N * a.Hdy * a.Wdy * a.Cout < (1L << 30);
+  if (lean) {
+    if (a.Cin >= 128 && a.Cout >= 128) rc = launch_wgrad_lean<2, 2, 2, 2, 2>(a, s);
+    else if (a.Cin >= 64 && a.Cout >= 64) rc = launch_wgrad_lean<2, 2, 1, 1, 2>(a, s);
+  }
+  if (rc >= 0) {
+    // done by the lean kernel
+  } else if (fast) {
     if (a.Cin >= 128 && a.Cout >= 128) rc = launch_wgrad<2, 2, 2, 2, true, 3>(a, s);
     else if (a.Cin <= 32) rc = launch_wgrad<1, 4, 1, 1, true, 3>(a, s);
     else if (a.Cout <= 32) rc = launch_wgrad<4, 1, 1, 1, true, 3>(a, s);

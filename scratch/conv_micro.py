@@ -1,0 +1,29 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from gan_lib_tensorflow_amd import kernels as K
+which = sys.argv[1] if len(sys.argv) > 1 else "fprop"
+n, h, cin, cout, k = (int(v) for v in (sys.argv[2:7] if len(sys.argv) > 6 else (64, 32, 256, 256, 3)))
+reps = int(sys.argv[7]) if len(sys.argv) > 7 else 20
+x = torch.randn(n, h, h, cin, device="cuda").to(torch.bfloat16)
+w = (torch.randn(k, k, cin, cout, device="cuda") / (k * k * cin) ** 0.5)
+dy = torch.randn(n, h, h, cout, device="cuda").to(torch.bfloat16)
+wf, wd = K.prep_weights(w, True, True)
+dw = torch.zeros_like(w)
+torch.cuda.synchronize()
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+def run():
+    if which == "fprop":
+        K.conv2d_fprop(x, wf, None, (h, h), cout, k)
+    elif which == "dgrad":
+        K.conv2d_dgrad(dy, wd, (h, h), cin, k)
+    else:
+        K.conv2d_wgrad(x, dy, dw, (h, h), k)
+for _ in range(3): run()
+torch.cuda.synchronize()
+ev0.record()
+for _ in range(reps): run()
+ev1.record(); torch.cuda.synchronize()
+us = ev0.elapsed_time(ev1) * 1e3 / reps
+fl = 2.0 * n * h * h * cin * cout * k * k
+print(f"{which} n{n} h{h} {cin}->{cout} k{k}: {us:.1f} us  {fl/us/1e6:.0f} TFLOP/s")

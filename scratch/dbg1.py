@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from oracle import ref_torch as T
 from gan_lib_tensorflow_amd.SNGAN import gan_cifar_resnet as S
