@@ -536,6 +536,180 @@ static int launch_wgrad_lean(const WgradArgs& a, hipStream_t s) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Packed-narrow variant for the image-side layers (Cin=3: D.Block.1.Conv1/Shortcut) and the 3- or
+// 1-channel outputs (G.Output, D.Output).  The per-tap kernels above re-read the WIDE operand once per tap
+// (9 x 33 MB for D.Block.1.Conv1); here the narrow operand is im2col-packed on the fly into <= 32 columns
+// k = (tap, c) -- x[p+tap][ci] when PACK_X, dy[p-tap][co] otherwise -- so the wide operand streams through
+// ONCE and all taps come out of one MFMA pass.  4 waves, each a 32x32 tile along the wide channel axis.
+// ------------------------------------------------------------------------------------------------------
+template <bool PACK_X>
+__global__ __launch_bounds__(256) void conv_wgrad_packed_kernel(WgradArgs a) {
+  constexpr int NT = 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* sN = reinterpret_cast<bf16*>(smem);        // narrow operand [2][1 sub-tile]
+  bf16* sWd = sN + 2 * SUBS;                       // wide operand   [2][4 sub-tiles]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int split = blockIdx.x % a.splits, tw = blockIdx.x / a.splits;   // wide-channel tile
+  const int Cn = PACK_X ? a.Cin : a.Cout;          // narrow channels (<= 4)
+  const int Cw = PACK_X ? a.Cout : a.Cin;          // wide channels (% 8 == 0)
+  const bf16* pn = PACK_X ? a.x : a.dy;
+  const bf16* pw = PACK_X ? a.dy : a.x;
+  const int w0 = tw * 128;
+  const int kcols = a.taps * Cn;                   // <= 32
+  const int sgn = PACK_X ? 1 : -1;
+
+  const int step0 = split * a.steps_per_split;
+  int nsteps = (a.M + 63) / 64 - step0;
+  if (nsteps > a.steps_per_split) nsteps = a.steps_per_split;
+  if (nsteps <= 0) return;
+
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(pw), 0, a.M * Cw * 2, 0x00020000);
+  constexpr int OOB = 0x7FFFFFF0;
+  // narrow chunk of this thread: pixel np, columns ncc*8 .. +7 ; per-column tap offsets and channel
+  const int np = tid >> 2, ncc = tid & 3;
+  int k_dh[8], k_dw[8], k_c[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const int k = ncc * 8 + e;
+    const int tap = k / Cn;
+    k_c[e] = (k < kcols) ? k - tap * Cn : -1;
+    k_dh[e] = sgn * (tap / a.ks - a.pad);
+    k_dw[e] = sgn * (tap % a.ks - a.pad);
+  }
+  // wide chunks: 4 per thread
+  int w_p[4], w_c[4], w_lds[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int q = tid + NT * j, p = q >> 4, cc = q & 15;
+    w_p[j] = p;
+    w_c[j] = (w0 + cc * 8 < Cw) ? (w0 + cc * 8) * 2 : OOB;
+    w_lds[j] = (cc >> 2) * SUBS + p * 32 + (cc & 3) * 8;
+  }
+  const bool do_bias = PACK_X && a.dbias != nullptr && tw == 0;   // (!PACK_X: the host adds a column-sum launch)
+  float bw[4][8];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) bw[j][e] = 0.f;
+
+  u32x4 rN, rW[4];
+  auto load_step = [&](int s) {
+    const int mbase = (step0 + s) * 64;
+    {
+      const int m = mbase + np;
+      int n, oh, ow;
+      pix_decomp(m, a.H, a.W, a.shw, a.sw, n, oh, ow);
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const int ih = oh + k_dh[e], iw = ow + k_dw[e];
+        const bool ok = m < a.M && k_c[e] >= 0 && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+        v[e] = ok ? pn[((long)(n * a.H + ih) * a.W + iw) * Cn + k_c[e]] : f2bf(0.f);
+      }
+      rN = __builtin_bit_cast(u32x4, v);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int m = mbase + w_p[j];
+      rW[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, m < a.M ? m * Cw * 2 + w_c[j] : OOB, 0, 0);
+    }
+  };
+  auto store_step = [&](int buf) {
+    *reinterpret_cast<u32x4*>(sN + buf * SUBS + np * 32 + ncc * 8) = rN;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      *reinterpret_cast<u32x4*>(sWd + buf * 4 * SUBS + w_lds[j]) = rW[j];
+      if (PACK_X && do_bias) {      // bias gradient of the wide dy
+        const bf16x8 t = __builtin_bit_cast(bf16x8, rW[j]);
+#pragma unroll
+        for (int e = 0; e < 8; e++) bw[j][e] += bf2f(t[e]);
+      }
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; e++) acc[e] = 0.f;
+  const int g = lane >> 4, li = lane & 15;
+  const int tr_off = ((8 * (g >> 1) + (li >> 2)) * 32) + 16 * (g & 1) + 4 * (li & 3);
+
+  load_step(0);
+  store_step(0);
+  __syncthreads();
+  for (int s = 0; s < nsteps; s++) {
+    const int buf = s & 1;
+    if (s + 1 < nsteps) load_step(s + 1);
+    const bf16* pN = sN + buf * SUBS + tr_off;
+    const bf16* pW = sWd + (buf * 4 + wave) * SUBS + tr_off;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      const s16x4 nl = lds_tr_read(pN + kk * 16 * 32), nh = lds_tr_read(pN + kk * 16 * 32 + 4 * 32);
+      const s16x4 wl = lds_tr_read(pW + kk * 16 * 32), wh = lds_tr_read(pW + kk * 16 * 32 + 4 * 32);
+      const s16x8 tn = {nl[0], nl[1], nl[2], nl[3], nh[0], nh[1], nh[2], nh[3]};
+      const s16x8 tw8 = {wl[0], wl[1], wl[2], wl[3], wh[0], wh[1], wh[2], wh[3]};
+      const bf16x8 fn = __builtin_bit_cast(bf16x8, tn), fw = __builtin_bit_cast(bf16x8, tw8);
+      // rows (MFMA A) = ci side, cols (MFMA B, lanes) = co side
+      if constexpr (PACK_X) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fn, fw, acc, 0, 0, 0);
+      else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw, fn, acc, 0, 0, 0);
+    }
+    if (s + 1 < nsteps) store_step(buf ^ 1);
+    __syncthreads();
+  }
+
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int e = 0; e < 16; e++) {
+    const int row = (e & 3) + 8 * (e >> 2) + 4 * h;      // MFMA row index 0..31, col = r
+    if constexpr (PACK_X) {
+      const int k = row, co = w0 + wave * 32 + r;        // dw[(tap*Cin+ci)][co] == dw[k][co]
+      if (k < kcols && co < a.Cout) atomicAdd(a.dw + (long)k * a.Cout + co, acc[e] * a.scale);
+    } else {
+      const int ci = w0 + wave * 32 + row, k = r;        // k = tap*Cout + co
+      if (k < kcols && ci < a.Cin) {
+        const int tap = k / a.Cout, co = k - tap * a.Cout;
+        atomicAdd(a.dw + ((long)tap * a.Cin + ci) * a.Cout + co, acc[e] * a.scale);
+      }
+    }
+  }
+  if (PACK_X && do_bias) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);            // [256][32]
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) red[(tid * 4 + j) * 8 + e] = bw[j][e];
+    __syncthreads();
+    for (int c = tid; c < 128; c += NT) {
+      if (w0 + c >= a.Cout) continue;
+      const int cc = c >> 3, e = c & 7;
+      float t = 0.f;
+      for (int p = 0; p < 64; p++) {
+        const int q = p * 16 + cc;
+        t += red[((q % NT) * 4 + q / NT) * 8 + e];
+      }
+      atomicAdd(a.dbias + w0 + c, t * a.scale);
+    }
+  }
+}
+
+template <bool PACK_X>
+static int launch_wgrad_packed(WgradArgs a, hipStream_t s) {
+  const int Cw = PACK_X ? a.Cout : a.Cin;
+  const int tiles = cdiv(Cw, 128);
+  const int total_steps = cdiv(a.M, 64);
+  int splits = 256 / tiles;
+  if (splits > total_steps / 8) splits = total_steps / 8;
+  if (splits < 1) splits = 1;
+  a.steps_per_split = cdiv(total_steps, splits);
+  a.splits = cdiv(total_steps, a.steps_per_split);
+  const size_t lds = (size_t)2 * 5 * SUBS * sizeof(bf16);   // 41.6 KB (>= the 32 KB bias-reduction scratch)
+  auto kern = conv_wgrad_packed_kernel<PACK_X>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * a.splits)), dim3(256), lds, s, a);
+  GANK_LAUNCH_OK("conv_wgrad_packed");
+  return 0;
+}
+
 template <int WA, int WB, int TA, int TB, bool FAST, int PF>
 static int launch_wgrad(WgradArgs a, hipStream_t s) {
   constexpr int CiT = WA * TA * 32, CoT = WB * TB * 32;
@@ -583,8 +757,15 @@ int gank_wgrad_dispatch(WgradArgs a, hipStream_t s) {
     if (a.Cin >= 128 && a.Cout >= 128) rc = launch_wgrad_lean<2, 2, 2, 2, 2>(a, s);
     else if (a.Cin >= 64 && a.Cout >= 64) rc = launch_wgrad_lean<2, 2, 1, 1, 2>(a, s);
   }
+  // narrow operands: pack (tap, channel) into <= 32 MFMA columns so the wide operand streams once
+  const bool plain = (a.flags == 0) && (long)a.M * (a.Cin > a.Cout ? a.Cin : a.Cout) < (1L << 30);
+  if (rc < 0 && plain && a.Cin <= 4 && a.taps * a.Cin <= 32 && a.Cout % 8 == 0) rc = launch_wgrad_packed<true>(a, s);
+  if (rc < 0 && plain && a.Cout <= 4 && a.taps * a.Cout <= 32 && a.Cin % 8 == 0) {
+    rc = launch_wgrad_packed<false>(a, s);
+    if (rc == 0 && a.dbias) rc = gank_colsum_bf16(a.dy, a.dbias, a.M, a.Cout, a.scale, s);   // 3 columns: trivial
+  }
   if (rc >= 0) {
-    // done by the lean kernel
+    // done by a specialised kernel
   } else if (fast) {
     if (a.Cin >= 128 && a.Cout >= 128) rc = launch_wgrad<2, 2, 2, 2, true, 3>(a, s);
     else if (a.Cin <= 32) rc = launch_wgrad<1, 4, 1, 1, true, 3>(a, s);
