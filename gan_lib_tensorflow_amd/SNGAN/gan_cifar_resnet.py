@@ -149,6 +149,7 @@ class SNGANTrainer:
         self.iteration = 0
         self._build(state)
         self._graphs = {}
+        self._g_applier = type("_Apply", (), {"apply": staticmethod(self._g_apply)})()
 
     # ---- graph construction (variables are created by name on the first call, :238,:267) ----------
     def _build(self, state):
@@ -162,6 +163,12 @@ class SNGANTrainer:
             self.store.load_state_dict(state)
         self.g_flat = self.store.flatten('Generator')
         self.d_flat = self.store.flatten('Discriminator')
+        self.store.flatten_state('Discriminator')      # the 12 SN u vectors: one buffer
+        # bf16 MFMA operand copies of the generator weights: rebuilt by ONE launch after each G update
+        # (the generator runs 6 forwards per iteration on unchanged weights)
+        self._g_convs = [v for k, v in self.store.vars.items()
+                         if k.startswith('Generator/') and (k.endswith('/Filters') or k.endswith('/W'))]
+        self._refresh_g_prep()
         self.iteration_dev = torch.zeros(1, dtype=torch.int64, device=self.device)   # `_iteration` feed (:320)
         self.g_opt = AdamTF(self.g_flat, self.iteration_dev, grad_scale=1.0 / self.world)
         self.d_opt = AdamTF(self.d_flat, self.iteration_dev, grad_scale=1.0 / self.world)
@@ -170,6 +177,19 @@ class SNGANTrainer:
         self.real_labels = torch.zeros(b, dtype=torch.int32, device=self.device)
         self.d_loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.g_loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    def _refresh_g_prep(self):
+        K.prep_weights_batched(self._g_convs, want_d=True)
+
+    def load_state_dict(self, state, strict=True):
+        """Restore variables by name; cached operand copies and captured graphs are rebuilt."""
+        self.store.load_state_dict(state, strict)
+        self._refresh_g_prep()
+        self._graphs.clear()
+
+    def _g_apply(self):
+        self.g_opt.apply()
+        self._refresh_g_prep()
 
     # ---- the two updates, as plain eager code (captured into graphs by _run) -----------------------
     def _d_forward_backward(self, real_pre=None, z=None):
@@ -268,7 +288,7 @@ class SNGANTrainer:
 
     def g_step(self):
         """One generator update (:602-603)."""
-        self._run('g', self._g_forward_backward, self.g_opt, self.g_flat)
+        self._run('g', self._g_forward_backward, self._g_applier, self.g_flat)
         return self.g_loss
 
     def train_iteration(self, batches):

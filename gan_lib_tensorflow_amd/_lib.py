@@ -20,11 +20,17 @@ class SnDesc(C.Structure):
                [("K", I), ("C", I), ("row_offset", I), ("chunk_offset", I)]
 
 
+class PrepDesc(C.Structure):
+    """gank_prep_desc"""
+    _fields_ = [("w", P), ("wf", P), ("wd", P), ("ksize", I), ("Cin", I), ("Cout", I), ("_pad", I)]
+
+
 # name -> argument ctypes (all return int unless listed in _RET)
 PROTOTYPES = {
     "gank_version": [],
     "gank_last_error": [],
     "gank_conv2d_prep_weights": [P, P, P, I, I, I, P],
+    "gank_conv2d_prep_weights_batched": [C.POINTER(PrepDesc), I, P],
     "gank_conv2d_fprop": [P, P, P, P, P, P, I, I, I, I, I, I, I, F, P],
     "gank_conv2d_dgrad": [P, P, P, P, P, I, I, I, I, I, I, I, F, P],
     "gank_conv2d_wgrad": [P, P, P, P, I, I, I, I, I, I, I, F, P],

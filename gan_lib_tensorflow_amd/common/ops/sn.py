@@ -15,6 +15,7 @@ import warnings
 import torch
 
 from ... import functional as Fn
+from ... import kernels as K
 from ...store import get_default_store
 
 NO_OPS = 'NO_OPS'
@@ -84,22 +85,56 @@ def sn_pairs(store, prefix):
     return pairs
 
 
+def _flat_base(store, prefix, us):
+    """The flat state buffer if `us` are exactly its consecutive views (ParamStore.flatten_state)."""
+    f = store.flat.get(prefix + "#state")
+    if f is None:
+        return None
+    buf, o = f["buf"], 0
+    for u in us:
+        if u.data_ptr() != buf.data_ptr() + 4 * o:
+            return None
+        o += u.numel()
+    return buf if o == buf.numel() else None
+
+
 @contextlib.contextmanager
-def precomputed(store, prefix, update_collection=None):
-    """Normalise every SN weight under `prefix` in one batched call; inside the block
-    `spectral_normed_weight(W, ...)` returns the precomputed W_bar for those W."""
+def precomputed(store, prefix, update_collection=None, prepare=True):
+    """Normalise every SN weight under `prefix` in ONE batched launch group; inside the block
+    `spectral_normed_weight(W, ...)` returns the precomputed W_bar for those W.  Also (prepare=True)
+    builds the bf16 MFMA operand layouts of all W_bar in one launch and hands every W_bar a pre-zeroed
+    slice of one flat gradient buffer, so the backward pass needs no per-weight memsets."""
     pairs = sn_pairs(store, prefix)
     if not pairs:
         yield None
         return
     Ws = [w for w, _ in pairs]
     us = [u for _, u in pairs]
+    flat = _flat_base(store, prefix, us)
     if update_collection != NO_OPS:
-        u_read = [u.detach().clone() for u in us]
+        if flat is not None:                      # one snapshot copy instead of one per weight
+            snap, o, u_read = flat.clone(), 0, []
+            for u in us:
+                u_read.append(snap[o:o + u.numel()])
+                o += u.numel()
+        else:
+            u_read = [u.detach().clone() for u in us]
     else:
         u_read = [u.detach() for u in us]
     W_bars, batch = Fn.spectral_norm_batch(Ws, u_read)
-    _apply_update(us, batch, update_collection)
+    if update_collection is None and flat is not None:
+        with torch.no_grad():
+            flat.copy_(batch.u_out)               # u <- u_final for all weights: one copy (sn.py:55-56)
+    else:
+        _apply_update(us, batch, update_collection)
+    if prepare:
+        K.prep_weights_batched(list(W_bars), want_d=True)
+        if any(w.requires_grad for w in Ws):
+            gflat = torch.zeros(sum(w.numel() for w in W_bars), dtype=torch.float32, device=W_bars[0].device)
+            o = 0
+            for wb in W_bars:
+                wb._grad_buf = gflat[o:o + wb.numel()].view(wb.shape)
+                o += wb.numel()
     _active.append({id(w): (wb, batch.sigma(i)) for i, (w, wb) in enumerate(zip(Ws, W_bars))})
     try:
         yield batch

@@ -61,6 +61,82 @@ extern "C" int gank_conv2d_prep_weights(const float* w, void* wf, void* wd, int 
   return 0;
 }
 
+// ---- batched: every conv/linear weight of a network in ONE launch (the per-layer form costs 2 tiny
+// launches x ~5 us per layer per forward; a network has 11-12 weights).  Table by value in kernargs.
+#define PREP_MAX 16
+struct PrepTable {
+  gank_prep_desc d[PREP_MAX];
+  int first_block[PREP_MAX + 1];   // prefix sum of blocks per entry
+  int nwf[PREP_MAX];               // wf tiles of entry i (the rest of its blocks are wd work)
+  int count;
+};
+
+__global__ void prep_batch_kernel(PrepTable t) {
+  int e = 0;
+  for (int i = 1; i < t.count; i++)
+    if ((int)blockIdx.x >= t.first_block[i]) e = i;
+  const gank_prep_desc& d = t.d[e];
+  const int b = blockIdx.x - t.first_block[e];
+  const int taps = d.ksize * d.ksize;
+  if (b < t.nwf[e]) {
+    const int K = taps * d.Cin, Kpad = (K + 63) / 64 * 64, CoutPad = (d.Cout + 31) / 32 * 32;
+    __shared__ float tl[32][33];
+    const int ntk = Kpad / 32;
+    const int k0 = (b % ntk) * 32, c0 = (b / ntk) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+      const int k = k0 + i, c = c0 + tx;
+      tl[i][tx] = (k < K && c < d.Cout) ? d.w[(long)k * d.Cout + c] : 0.f;
+    }
+    __syncthreads();
+    bf16* wf = (bf16*)d.wf;
+    for (int i = ty; i < 32; i += 8) {
+      const int c = c0 + i, k = k0 + tx;
+      if (c < CoutPad && k < Kpad) wf[(long)c * Kpad + k] = f2bf(tl[tx][i]);
+    }
+  } else {
+    const int Kpad2 = (taps * d.Cout + 63) / 64 * 64, CinPad = (d.Cin + 31) / 32 * 32;
+    const long total = (long)CinPad * Kpad2;
+    bf16* wd = (bf16*)d.wd;
+    const long base = (long)(b - t.nwf[e]) * 2048;
+    for (int j = 0; j < 8; j++) {
+      const long i = base + j * 256 + threadIdx.x;
+      if (i >= total) break;
+      const int ci = (int)(i / Kpad2), k = (int)(i - (long)ci * Kpad2);
+      float v = 0.f;
+      if (ci < d.Cin && k < taps * d.Cout) {
+        const int tp = k / d.Cout, co = k - tp * d.Cout;
+        v = d.w[((long)(taps - 1 - tp) * d.Cin + ci) * d.Cout + co];
+      }
+      wd[i] = f2bf(v);
+    }
+  }
+}
+
+extern "C" int gank_conv2d_prep_weights_batched(const gank_prep_desc* table, int count, void* stream) {
+  GANK_REQUIRE(table && count > 0, "prep_weights_batched: empty table");
+  for (int base = 0; base < count; base += PREP_MAX) {
+    PrepTable t;
+    t.count = count - base < PREP_MAX ? count - base : PREP_MAX;
+    int blocks = 0;
+    for (int i = 0; i < t.count; i++) {
+      const gank_prep_desc& d = table[base + i];
+      GANK_REQUIRE(d.w && (d.wf || d.wd) && d.ksize >= 1 && d.Cin > 0 && d.Cout > 0, "prep_weights_batched: bad entry %d", base + i);
+      t.d[i] = d;
+      const int taps = d.ksize * d.ksize;
+      const int nwf = d.wf ? (roundup(taps * d.Cin, 64) / 32) * (roundup(d.Cout, 32) / 32) : 0;
+      const int nwd = d.wd ? cdiv((long)roundup(d.Cin, 32) * roundup(taps * d.Cout, 64), 2048) : 0;
+      t.first_block[i] = blocks;
+      t.nwf[i] = nwf;
+      blocks += nwf + nwd;
+    }
+    t.first_block[t.count] = blocks;
+    hipLaunchKernelGGL(prep_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t);
+    GANK_LAUNCH_OK("prep_weights_batched");
+  }
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // column sum  out[c] += scale * sum_r x[r][c]
 // ------------------------------------------------------------------------------------------------

@@ -17,10 +17,24 @@ BF16 = torch.bfloat16
 
 
 def _target(p):
+    """Where a weight gradient is written: (buffer, accumulated_in_place).  `main_grad` = view of the
+    network's flat gradient buffer (autograd gets None); `_grad_buf` = pre-zeroed view handed out by a
+    batched producer (spectral norm) and returned to autograd as the gradient; else a fresh zero tensor."""
     mg = getattr(p, "main_grad", None)
     if mg is not None:
         return mg, True
+    gb = getattr(p, "_grad_buf", None)
+    if gb is not None:
+        return gb, False
     return torch.zeros_like(p), False
+
+
+def _prepared(W, k, cin, cout, want_f, want_d):
+    """bf16 MFMA operand layouts of W: taken from `W._prep` when a batched preparation attached them."""
+    prep = getattr(W, "_prep", None)
+    if prep is not None and (not want_f or prep[0] is not None) and (not want_d or prep[1] is not None):
+        return prep
+    return K.prep_weights(W.detach().view(k, k, cin, cout), want_f, want_d)
 
 
 def _c(t):
@@ -41,7 +55,7 @@ class _Conv2d(Function):
         assert not (pool_out and (out_tanh or upsample))
         n, h, w, _ = x.shape
         H, Wd = (2 * h, 2 * w) if upsample else (h, w)
-        wf, _ = K.prep_weights(W.detach().view(k, k, cin, cout), True, False)
+        wf, _ = _prepared(W, k, cin, cout, True, False)
         flags = (K.IN_UPSAMPLE2X if upsample else 0) | (K.IN_RELU if in_relu else 0) | (K.OUT_TANH if out_tanh else 0)
         b = bias.detach() if bias is not None else None
         if pool_out:
@@ -74,7 +88,7 @@ class _Conv2d(Function):
         elif btgt is not None:
             K.colsum(g, btgt, 1.0)
         if ctx.needs_input_grad[0]:
-            _, wd = K.prep_weights(W.detach().view(k, k, cin, cout), False, True)
+            _, wd = _prepared(W, k, cin, cout, False, True)
             dflags = K.IN_UPSAMPLE2X if pool_out else 0
             if upsample:
                 dxf = K.conv2d_dgrad(g, wd, (H, Wd), cin, k, dflags, scale)

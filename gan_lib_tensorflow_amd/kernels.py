@@ -6,7 +6,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, SnDesc  # noqa: F401
+from ._lib import IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, SnDesc, PrepDesc  # noqa: F401
 
 BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
 
@@ -44,6 +44,33 @@ def prep_weights(w, want_f=True, want_d=False):
     wd = torch.empty((_roundup(cin, 32), _roundup(taps * cout, 64)), dtype=BF16, device=w.device) if want_d else None
     _lib.check(lib().gank_conv2d_prep_weights(_p(w, F32, "w"), _p(wf), _p(wd), k, cin, cout, _stream()), "prep_weights")
     return wf, wd
+
+
+def prep_weights_batched(ws, want_d=True):
+    """One launch for a list of fp32 weights ([k,k,Cin,Cout] or [Cin,Cout]); returns [(wf, wd)] and sets
+    `w._prep = (wf, wd)` on each tensor so the conv wrappers skip their own per-layer preparation."""
+    table = (PrepDesc * len(ws))()
+    outs = []
+    for i, w in enumerate(ws):
+        if w.dim() == 2:
+            k, cin, cout = 1, w.shape[0], w.shape[1]
+        else:
+            k, cin, cout = w.shape[0], w.shape[2], w.shape[3]
+        taps = k * k
+        old = getattr(w, "_prep", None)
+        if old is not None and old[0] is not None and (old[1] is not None or not want_d):
+            wf, wd = old      # persistent buffers are overwritten IN PLACE: captured graphs keep reading them
+        else:
+            wf = torch.empty((_roundup(cout, 32), _roundup(taps * cin, 64)), dtype=BF16, device=w.device)
+            wd = torch.empty((_roundup(cin, 32), _roundup(taps * cout, 64)), dtype=BF16, device=w.device) if want_d else None
+        d = table[i]
+        d.w, d.wf, d.wd = _p(w.detach(), F32, "w").value, wf.data_ptr(), (wd.data_ptr() if wd is not None else None)
+        d.ksize, d.Cin, d.Cout = k, cin, cout
+        outs.append((wf, wd))
+    _lib.check(lib().gank_conv2d_prep_weights_batched(table, len(ws), _stream()), "prep_weights_batched")
+    for w, o in zip(ws, outs):
+        w._prep = o
+    return outs
 
 
 def conv2d_fprop(x, wf, bias, out_hw, cout, ksize, flags=0, scale=1.0, residual=None, relu_ref=None):

@@ -59,7 +59,7 @@ class ParamStore:
             self.vars[full] = t
             self.trainable[full] = bool(trainable)
             for prefix in self.flat:
-                if full.startswith(prefix + "/") and trainable:
+                if full.startswith(prefix.split("#")[0] + "/") and (trainable or prefix.endswith("#state")):
                     raise RuntimeError(f"{full} created after flatten({prefix!r}); build the graph once before flattening")
         return t
 
@@ -92,6 +92,8 @@ class ParamStore:
                         raise ValueError(f"{k}: shape {v.shape} != {tuple(self.vars[k].shape)}")
                     continue
                 self.vars[k].copy_(torch.from_numpy(v).to(self.device))
+                if hasattr(self.vars[k], "_prep"):
+                    del self.vars[k]._prep          # cached MFMA operand copies are stale now
 
     # ---- flat buffers -------------------------------------------------------------------------
     def flatten(self, prefix):
@@ -116,6 +118,26 @@ class ParamStore:
         self.flat[prefix] = dict(params=params, grads=grads, names=names, offsets=offsets,
                                  m=torch.zeros_like(params), v=torch.zeros_like(params))
         return self.flat[prefix]
+
+    def flatten_state(self, prefix):
+        """Pack the NON-trainable variables under `prefix` (the spectral-norm `u` vectors) into one flat
+        buffer, in creation order, unpadded: snapshot and update of all of them are single copies."""
+        key = prefix + "#state"
+        if key in self.flat:
+            return self.flat[key]
+        names = self.names(prefix, trainable=False)
+        total = sum(self.vars[k].numel() for k in names)
+        buf = torch.zeros(total, dtype=torch.float32, device=self.device)
+        o = 0
+        with torch.no_grad():
+            for k in names:
+                v = self.vars[k]
+                n = v.numel()
+                buf[o:o + n].copy_(v.reshape(-1))
+                v.data = buf[o:o + n].view(v.shape)
+                o += n
+        self.flat[key] = dict(buf=buf, names=names)
+        return self.flat[key]
 
     def zero_grads(self, prefix):
         self.flat[prefix]["grads"].zero_()

@@ -45,6 +45,14 @@ const char* gank_last_error(void);
  * be NULL.  Replaces the implicit filter transforms inside tf.nn.conv2d / its gradient ops
  * (common/ops/conv2d.py:180-187). */
 int gank_conv2d_prep_weights(const float* w, void* wf, void* wd, int ksize, int Cin, int Cout, void* stream);
+/* the same for up to any number of weights in one launch per 16 (host table, copied into kernel arguments) */
+typedef struct gank_prep_desc {
+  const float* w; /* fp32 [k,k,Cin,Cout] */
+  void* wf;       /* bf16 [CoutPad][Kpad]  or NULL */
+  void* wd;       /* bf16 [CinPad][Kpad'] or NULL */
+  int ksize, Cin, Cout, _pad;
+} gank_prep_desc;
+int gank_conv2d_prep_weights_batched(const gank_prep_desc* table, int count, void* stream);
 
 /* ---- conv2d forward: y = epilogue(conv_SAME_stride1(in(x), w) * scale + bias) --------------------
  * Replaces tf.nn.conv2d + tf.nn.bias_add (common/ops/conv2d.py:180-187,212-216), with the
