@@ -1,15 +1,15 @@
 // Conditional batch norm (common/ops/normalization.py:27-59), forward and backward, HBM-bound.
-//   moments over (N/groups, H, W) per tower: two-pass like tf.nn.moments (mean, then mean of squared
-//   deviations; biased), eps = 1e-5; y = (x-mean)*invstd*gamma[label] + beta[label]; optional fused relu.
+//   moments over (N/groups, H, W) per tower, biased (tf.nn.moments): ONE pass of shifted sums per part
+//   + a deterministic Chan merge of the parts, eps = 1e-5; y = (x-mean)*invstd*gamma[label] + beta[label]; optional fused relu.
 // x is [N, HW, C] bf16 with C % 8 == 0: every lane moves 16 B; thread = (8-channel group, row lane).
 #include "gank_common.h"
 
 #define BN_EPS 1e-5f
 
 extern "C" int gank_cbn_parts(long rows_per_group) {
-  long p = (rows_per_group + 127) / 128;
+  long p = (rows_per_group + 255) / 256;
   if (p < 1) p = 1;
-  if (p > 128) p = 128;
+  if (p > 256) p = 256;
   return (int)p;
 }
 
@@ -18,90 +18,77 @@ struct CbnGeom {
   long rows_per_group, rows_per_part;
 };
 
-// pass 1: ws_sum[g][p][c] = sum over the part's rows of x
-__global__ void cbn_sum_kernel(const bf16* __restrict__ x, float* __restrict__ ws, CbnGeom q) {
-  const int cg = q.C >> 3, RL = 256 / cg;
+constexpr int CBN_NT = 1024;   // 16 waves per block: these kernels are latency-bound streams otherwise
+
+// pass 1 (ONE read of x): per part, shifted sums around the part's first row -> (mean_p, M2_p).
+// Shifting by a sample of the data keeps S2 - S1^2/n free of catastrophic cancellation in fp32.
+__global__ __launch_bounds__(CBN_NT) void cbn_stats_kernel(const bf16* __restrict__ x, float* __restrict__ ws, CbnGeom q) {
+  const int cg = q.C >> 3, RL = CBN_NT / cg;
   const int g = threadIdx.x % cg, rl = threadIdx.x / cg;
   const int grp = blockIdx.x / q.parts, part = blockIdx.x % q.parts;
   const long r0 = grp * q.rows_per_group + part * q.rows_per_part;
   long r1 = r0 + q.rows_per_part;
   const long rend = (grp + 1) * q.rows_per_group;
   if (r1 > rend) r1 = rend;
-  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, k[8];
+  {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + r0 * q.C + g * 8);
+#pragma unroll
+    for (int e = 0; e < 8; e++) k[e] = bf2f(v[e]);
+  }
   if (rl < RL)
     for (long r = r0 + rl; r < r1; r += RL) {
       const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + r * q.C + g * 8);
 #pragma unroll
-      for (int e = 0; e < 8; e++) acc[e] += bf2f(v[e]);
+      for (int e = 0; e < 8; e++) { const float d = bf2f(v[e]) - k[e]; s1[e] += d; s2[e] += d * d; }
     }
-  __shared__ float red[256 * 8];
+  __shared__ float red[CBN_NT * 16];
 #pragma unroll
-  for (int e = 0; e < 8; e++) red[threadIdx.x * 8 + e] = acc[e];
+  for (int e = 0; e < 8; e++) { red[threadIdx.x * 16 + e] = s1[e]; red[threadIdx.x * 16 + 8 + e] = s2[e]; }
   __syncthreads();
-  for (int c = threadIdx.x; c < q.C; c += 256) {
-    float t = 0.f;
-    for (int l = 0; l < RL; l++) t += red[(l * cg + (c >> 3)) * 8 + (c & 7)];
-    ws[((long)grp * q.parts + part) * q.C + c] = t;
+  const float n = (float)(r1 - r0);
+  for (int c = threadIdx.x; c < q.C; c += CBN_NT) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int l = 0; l < RL; l++) {
+      t1 += red[(l * cg + (c >> 3)) * 16 + (c & 7)];
+      t2 += red[(l * cg + (c >> 3)) * 16 + 8 + (c & 7)];
+    }
+    const float kk = bf2f(x[r0 * q.C + c]);
+    float* o = ws + (((long)grp * q.parts + part) * 2) * q.C;
+    o[c] = kk + t1 / n;                 // mean of the part
+    o[q.C + c] = t2 - t1 * t1 / n;      // sum of squared deviations from that mean
   }
 }
 
-// pass 2: mean from pass-1 partials; ws_sq[g][p][c] = sum (x-mean)^2 ; part 0 also stores the mean
-__global__ void cbn_sqdev_kernel(const bf16* __restrict__ x, const float* __restrict__ ws_sum, float* __restrict__ ws_sq,
-                                 float* __restrict__ stats, CbnGeom q) {
-  const int cg = q.C >> 3, RL = 256 / cg;
-  const int g = threadIdx.x % cg, rl = threadIdx.x / cg;
-  const int grp = blockIdx.x / q.parts, part = blockIdx.x % q.parts;
-  __shared__ float smean[2048];
-  __shared__ float red[256 * 8];
-  for (int c = threadIdx.x; c < q.C; c += 256) {
-    float t = 0.f;
-    for (int p = 0; p < q.parts; p++) t += ws_sum[((long)grp * q.parts + p) * q.C + c];
-    const float m = t / (float)q.rows_per_group;
-    smean[c] = m;
-    if (part == 0) stats[((long)grp * 2 + 0) * q.C + c] = m;
+// pass 2: merge the parts (Chan et al. pairwise update, sequential over parts: deterministic) -> mean, invstd
+__global__ void cbn_finalize_kernel(const float* __restrict__ ws, float* __restrict__ stats, CbnGeom q) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int grp = blockIdx.y;
+  if (c >= q.C) return;
+  float na = 0.f, mean = 0.f, m2 = 0.f;
+  for (int p = 0; p < q.parts; p++) {
+    long r0 = p * q.rows_per_part, r1 = r0 + q.rows_per_part;
+    if (r1 > q.rows_per_group) r1 = q.rows_per_group;
+    const float nb = (float)(r1 - r0);
+    if (nb <= 0.f) break;
+    const float* o = ws + (((long)grp * q.parts + p) * 2) * q.C;
+    const float mb = o[c], m2b = o[q.C + c];
+    const float d = mb - mean, nt = na + nb;
+    mean += d * nb / nt;
+    m2 += m2b + d * d * na * nb / nt;
+    na = nt;
   }
-  __syncthreads();
-  const long r0 = grp * q.rows_per_group + part * q.rows_per_part;
-  long r1 = r0 + q.rows_per_part;
-  const long rend = (grp + 1) * q.rows_per_group;
-  if (r1 > rend) r1 = rend;
-  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (rl < RL) {
-    float mu[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) mu[e] = smean[g * 8 + e];
-    for (long r = r0 + rl; r < r1; r += RL) {
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + r * q.C + g * 8);
-#pragma unroll
-      for (int e = 0; e < 8; e++) { const float d = bf2f(v[e]) - mu[e]; acc[e] += d * d; }
-    }
-  }
-#pragma unroll
-  for (int e = 0; e < 8; e++) red[threadIdx.x * 8 + e] = acc[e];
-  __syncthreads();
-  for (int c = threadIdx.x; c < q.C; c += 256) {
-    float t = 0.f;
-    for (int l = 0; l < RL; l++) t += red[(l * cg + (c >> 3)) * 8 + (c & 7)];
-    ws_sq[((long)grp * q.parts + part) * q.C + c] = t;
-  }
+  stats[((long)grp * 2 + 0) * q.C + c] = mean;
+  stats[((long)grp * 2 + 1) * q.C + c] = 1.f / sqrtf(m2 / na + BN_EPS);   // biased variance (tf.nn.moments)
 }
 
-// pass 3: invstd from pass-2 partials; normalise + gamma/beta gather (+relu)
-__global__ void cbn_apply_kernel(const bf16* __restrict__ x, const int* __restrict__ labels, const float* __restrict__ gamma,
-                                 const float* __restrict__ beta, bf16* __restrict__ y, const float* __restrict__ ws_sq,
-                                 float* __restrict__ stats, CbnGeom q) {
-  const int cg = q.C >> 3, RL = 256 / cg;
+// pass 3: normalise + gamma/beta gather (+relu)
+__global__ __launch_bounds__(CBN_NT) void cbn_apply_kernel(const bf16* __restrict__ x, const int* __restrict__ labels,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         bf16* __restrict__ y, const float* __restrict__ stats, CbnGeom q) {
+  const int cg = q.C >> 3, RL = CBN_NT / cg;
   const int g = threadIdx.x % cg, rl = threadIdx.x / cg;
   const int grp = blockIdx.x / q.parts, part = blockIdx.x % q.parts;
-  __shared__ float sinv[2048];
-  for (int c = threadIdx.x; c < q.C; c += 256) {
-    float t = 0.f;
-    for (int p = 0; p < q.parts; p++) t += ws_sq[((long)grp * q.parts + p) * q.C + c];
-    const float inv = 1.f / sqrtf(t / (float)q.rows_per_group + BN_EPS);
-    sinv[c] = inv;
-    if (part == 0) stats[((long)grp * 2 + 1) * q.C + c] = inv;
-  }
-  __syncthreads();
   const long r0 = grp * q.rows_per_group + part * q.rows_per_part;
   long r1 = r0 + q.rows_per_part;
   const long rend = (grp + 1) * q.rows_per_group;
@@ -109,7 +96,10 @@ __global__ void cbn_apply_kernel(const bf16* __restrict__ x, const int* __restri
   if (rl >= RL) return;
   float mu[8], iv[8];
 #pragma unroll
-  for (int e = 0; e < 8; e++) { mu[e] = stats[((long)grp * 2) * q.C + g * 8 + e]; iv[e] = sinv[g * 8 + e]; }
+  for (int e = 0; e < 8; e++) {
+    mu[e] = stats[((long)grp * 2) * q.C + g * 8 + e];
+    iv[e] = stats[((long)grp * 2 + 1) * q.C + g * 8 + e];
+  }
   for (long r = r0 + rl; r < r1; r += RL) {
     const int n = (int)(r / q.HW);
     int lb = labels[n];
@@ -139,6 +129,7 @@ static int cbn_geom(CbnGeom& q, int N, int HW, int C, int groups, int n_labels, 
   q.rows_per_group = (long)(N / groups) * HW;
   q.parts = gank_cbn_parts(q.rows_per_group);
   q.rows_per_part = (q.rows_per_group + q.parts - 1) / q.parts;
+  q.parts = (int)((q.rows_per_group + q.rows_per_part - 1) / q.rows_per_part);   // no empty parts
   return 0;
 }
 
@@ -148,12 +139,10 @@ extern "C" int gank_cbn_fwd(const void* x, const int32_t* labels, const float* g
   CbnGeom q;
   if (cbn_geom(q, N, HW, C, groups, n_labels, relu)) return 1;
   hipStream_t s = (hipStream_t)stream;
-  float* ws_sum = ws;
-  float* ws_sq = ws + (long)groups * q.parts * C;
   const dim3 grid(groups * q.parts);
-  hipLaunchKernelGGL(cbn_sum_kernel, grid, dim3(256), 0, s, (const bf16*)x, ws_sum, q);
-  hipLaunchKernelGGL(cbn_sqdev_kernel, grid, dim3(256), 0, s, (const bf16*)x, ws_sum, ws_sq, stats, q);
-  hipLaunchKernelGGL(cbn_apply_kernel, grid, dim3(256), 0, s, (const bf16*)x, labels, gamma, beta, (bf16*)y, ws_sq, stats, q);
+  hipLaunchKernelGGL(cbn_stats_kernel, grid, dim3(CBN_NT), 0, s, (const bf16*)x, ws, q);
+  hipLaunchKernelGGL(cbn_finalize_kernel, dim3(cdiv(C, 64), groups), dim3(64), 0, s, ws, stats, q);
+  hipLaunchKernelGGL(cbn_apply_kernel, grid, dim3(CBN_NT), 0, s, (const bf16*)x, labels, gamma, beta, (bf16*)y, stats, q);
   GANK_LAUNCH_OK("cbn_fwd");
   return 0;
 }
@@ -211,27 +200,40 @@ __global__ void cbn_bwd_sums_kernel(const bf16* __restrict__ dy, const bf16* __r
   }
 }
 
-// b2: thread per channel: table gradients (sequential over n: deterministic) and the per-tower means
+// b2: table gradients and per-tower means.  grid = (C/64, n_labels + 1): block row l < n_labels owns label l
+// (sequential over n: deterministic, no atomics, registers only); the last block row computes the means.
 __global__ void cbn_bwd_tables_kernel(const float* __restrict__ S, const int* __restrict__ labels, const float* __restrict__ gamma,
                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ M, CbnGeom q) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= q.C) return;
-  const int gs = q.N / q.groups;
-  for (int grp = 0; grp < q.groups; grp++) {
-    float m1 = 0.f, m2 = 0.f;
-    for (int i = 0; i < gs; i++) {
-      const int n = grp * gs + i;
+  const int l = blockIdx.y;
+  if (l < q.n_labels) {
+    float a1 = 0.f, a2 = 0.f;
+    for (int n = 0; n < q.N; n++) {
       int lb = labels[n];
       lb = lb < 0 ? 0 : (lb >= q.n_labels ? q.n_labels - 1 : lb);
-      const float s1 = S[((long)n * 2) * q.C + c], s2 = S[((long)n * 2 + 1) * q.C + c];
-      const float ga = gamma[(long)lb * q.C + c];
-      dbeta[(long)lb * q.C + c] += s1;
-      dgamma[(long)lb * q.C + c] += s2;
-      m1 += ga * s1;
-      m2 += ga * s2;
+      if (lb == l) {
+        a1 += S[((long)n * 2) * q.C + c];
+        a2 += S[((long)n * 2 + 1) * q.C + c];
+      }
     }
-    M[((long)grp * 2) * q.C + c] = m1 / (float)q.rows_per_group;
-    M[((long)grp * 2 + 1) * q.C + c] = m2 / (float)q.rows_per_group;
+    dbeta[(long)l * q.C + c] += a1;
+    dgamma[(long)l * q.C + c] += a2;
+  } else {
+    const int gs = q.N / q.groups;
+    for (int grp = 0; grp < q.groups; grp++) {
+      float m1 = 0.f, m2 = 0.f;
+      for (int i = 0; i < gs; i++) {
+        const int n = grp * gs + i;
+        int lb = labels[n];
+        lb = lb < 0 ? 0 : (lb >= q.n_labels ? q.n_labels - 1 : lb);
+        const float ga = gamma[(long)lb * q.C + c];
+        m1 += ga * S[((long)n * 2) * q.C + c];
+        m2 += ga * S[((long)n * 2 + 1) * q.C + c];
+      }
+      M[((long)grp * 2) * q.C + c] = m1 / (float)q.rows_per_group;
+      M[((long)grp * 2 + 1) * q.C + c] = m2 / (float)q.rows_per_group;
+    }
   }
 }
 
@@ -285,7 +287,7 @@ extern "C" int gank_cbn_bwd(const void* dy, const void* x, const void* y, const 
     if (e != hipSuccess) return gank_set_error("cbn_bwd: memset: %s", hipGetErrorString(e));
   }
   hipLaunchKernelGGL(cbn_bwd_sums_kernel, dim3(N * hw_parts), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (const bf16*)y, stats, S, q, hw_parts);
-  hipLaunchKernelGGL(cbn_bwd_tables_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, S, labels, gamma, dgamma, dbeta, M, q);
+  hipLaunchKernelGGL(cbn_bwd_tables_kernel, dim3(cdiv(C, 64), n_labels + 1), dim3(64), 0, s, S, labels, gamma, dgamma, dbeta, M, q);
   const long total8 = (long)N * HW * (C / 8);
   long blocks = (total8 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
