@@ -7,7 +7,7 @@
 #define BN_EPS 1e-5f
 
 extern "C" int gank_cbn_parts(long rows_per_group) {
-  long p = (rows_per_group + 255) / 256;
+  long p = (rows_per_group + 63) / 64;     // small tensors still get enough blocks to hide latency
   if (p < 1) p = 1;
   if (p > 256) p = 256;
   return (int)p;
@@ -60,26 +60,38 @@ __global__ __launch_bounds__(CBN_NT) void cbn_stats_kernel(const bf16* __restric
   }
 }
 
-// pass 2: merge the parts (Chan et al. pairwise update, sequential over parts: deterministic) -> mean, invstd
-__global__ void cbn_finalize_kernel(const float* __restrict__ ws, float* __restrict__ stats, CbnGeom q) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// pass 2: merge the parts (Chan et al. pairwise update; fixed merge order: deterministic) -> mean, invstd.
+// Block = 16 channels x 16 part-slices: each thread merges its strided slice, then slice 0 merges the 16
+// partial results through LDS (sequential depth parts/16 + 16 instead of parts).
+__device__ __forceinline__ void chan_merge(float& na, float& mean, float& m2, float nb, float mb, float m2b) {
+  if (nb <= 0.f) return;
+  const float d = mb - mean, nt = na + nb;
+  mean += d * nb / nt;
+  m2 += m2b + d * d * na * nb / nt;
+  na = nt;
+}
+
+__global__ __launch_bounds__(256) void cbn_finalize_kernel(const float* __restrict__ ws, float* __restrict__ stats, CbnGeom q) {
+  const int cl = threadIdx.x & 15, ps = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   const int grp = blockIdx.y;
-  if (c >= q.C) return;
+  __shared__ float sh[3][16][17];
   float na = 0.f, mean = 0.f, m2 = 0.f;
-  for (int p = 0; p < q.parts; p++) {
-    long r0 = p * q.rows_per_part, r1 = r0 + q.rows_per_part;
-    if (r1 > q.rows_per_group) r1 = q.rows_per_group;
-    const float nb = (float)(r1 - r0);
-    if (nb <= 0.f) break;
-    const float* o = ws + (((long)grp * q.parts + p) * 2) * q.C;
-    const float mb = o[c], m2b = o[q.C + c];
-    const float d = mb - mean, nt = na + nb;
-    mean += d * nb / nt;
-    m2 += m2b + d * d * na * nb / nt;
-    na = nt;
+  if (c < q.C) {
+    for (int p = ps; p < q.parts; p += 16) {
+      long r0 = (long)p * q.rows_per_part, r1 = r0 + q.rows_per_part;
+      if (r1 > q.rows_per_group) r1 = q.rows_per_group;
+      const float* o = ws + (((long)grp * q.parts + p) * 2) * q.C;
+      chan_merge(na, mean, m2, (float)(r1 - r0), o[c], o[q.C + c]);
+    }
   }
-  stats[((long)grp * 2 + 0) * q.C + c] = mean;
-  stats[((long)grp * 2 + 1) * q.C + c] = 1.f / sqrtf(m2 / na + BN_EPS);   // biased variance (tf.nn.moments)
+  sh[0][ps][cl] = na; sh[1][ps][cl] = mean; sh[2][ps][cl] = m2;
+  __syncthreads();
+  if (ps == 0 && c < q.C) {
+    for (int j = 1; j < 16; j++) chan_merge(na, mean, m2, sh[0][j][cl], sh[1][j][cl], sh[2][j][cl]);
+    stats[((long)grp * 2 + 0) * q.C + c] = mean;
+    stats[((long)grp * 2 + 1) * q.C + c] = 1.f / sqrtf(m2 / na + BN_EPS);   // biased variance (tf.nn.moments)
+  }
 }
 
 // pass 3: normalise + gamma/beta gather (+relu)
@@ -141,7 +153,7 @@ extern "C" int gank_cbn_fwd(const void* x, const int32_t* labels, const float* g
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(groups * q.parts);
   hipLaunchKernelGGL(cbn_stats_kernel, grid, dim3(CBN_NT), 0, s, (const bf16*)x, ws, q);
-  hipLaunchKernelGGL(cbn_finalize_kernel, dim3(cdiv(C, 64), groups), dim3(64), 0, s, ws, stats, q);
+  hipLaunchKernelGGL(cbn_finalize_kernel, dim3(cdiv(C, 16), groups), dim3(256), 0, s, ws, stats, q);
   hipLaunchKernelGGL(cbn_apply_kernel, grid, dim3(CBN_NT), 0, s, (const bf16*)x, labels, gamma, beta, (bf16*)y, stats, q);
   GANK_LAUNCH_OK("cbn_fwd");
   return 0;
@@ -209,13 +221,13 @@ __global__ void cbn_bwd_tables_kernel(const float* __restrict__ S, const int* __
   const int l = blockIdx.y;
   if (l < q.n_labels) {
     float a1 = 0.f, a2 = 0.f;
-    for (int n = 0; n < q.N; n++) {
+#pragma unroll 8
+    for (int n = 0; n < q.N; n++) {      // unconditional loads (pipelined), predicated adds
       int lb = labels[n];
       lb = lb < 0 ? 0 : (lb >= q.n_labels ? q.n_labels - 1 : lb);
-      if (lb == l) {
-        a1 += S[((long)n * 2) * q.C + c];
-        a2 += S[((long)n * 2 + 1) * q.C + c];
-      }
+      const float s1 = S[((long)n * 2) * q.C + c], s2 = S[((long)n * 2 + 1) * q.C + c];
+      a1 += (lb == l) ? s1 : 0.f;
+      a2 += (lb == l) ? s2 : 0.f;
     }
     dbeta[(long)l * q.C + c] += a1;
     dgamma[(long)l * q.C + c] += a2;
