@@ -33,7 +33,8 @@ PROTOTYPES = {
     "gank_conv2d_prep_weights_batched": [C.POINTER(PrepDesc), I, P],
     "gank_conv2d_fprop": [P, P, P, P, P, P, I, I, I, I, I, I, I, F, P],
     "gank_conv2d_dgrad": [P, P, P, P, P, I, I, I, I, I, I, I, F, P],
-    "gank_conv2d_wgrad": [P, P, P, P, I, I, I, I, I, I, I, F, P],
+    "gank_conv2d_wgrad_ws_elems": [I, I, I, I, I, I, I],
+    "gank_conv2d_wgrad": [P, P, P, P, P, L, I, I, I, I, I, I, I, F, P],
     "gank_deconv2d_fprop": [P, P, P, P, I, I, I, I, I, I, P],
     "gank_deconv2d_dgrad": [P, P, P, I, I, I, I, I, I, P],
     "gank_deconv2d_wgrad": [P, P, P, I, I, I, I, I, I, P],
@@ -71,7 +72,7 @@ PROTOTYPES = {
     "gank_prof_collect": [I, C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "gank_debug_tr_probe": [P, P],
 }
-_RET = {"gank_last_error": C.c_char_p}
+_RET = {"gank_last_error": C.c_char_p, "gank_conv2d_wgrad_ws_elems": C.c_long}
 
 _lib = None
 

@@ -209,7 +209,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
   auto step = [&](int s, auto slot) {
     constexpr int D = decltype(slot)::value;
     const int buf = s & 1;
-    if constexpr (PF > 1) load_next(rP[D], rW[D]);     // slot D held step s (already in LDS): now step s+PF
+    if constexpr (PF > 1) {
+      load_next(rP[D], rW[D]);     // slot D held step s (already in LDS): now step s+PF
+      // stage step s+1 BEFORE this step's MFMAs: its data was requested a full step ago, the other LDS
+      // buffer is free since the last barrier, and the write latency now hides behind the MFMAs instead
+      // of sitting between them and the barrier
+      if (s + 1 < a.nsteps) store_step(buf ^ 1, rP[(D + 1) % PF], rW[(D + 1) % PF]);
+    }
     const bf16* pW = sW + (buf * BN + wave_n * TN * 32 + r) * LROW + h * 8;
     const bf16* pP = sP + (buf * BM + wave_m * TM * 32 + r) * LROW + h * 8;
 #pragma unroll
@@ -225,9 +231,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
         for (int j = 0; j < TM; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    if (s + 1 < a.nsteps) {
-      if constexpr (PF == 1) load_next(rP[0], rW[0]);
-      store_step(buf ^ 1, rP[(D + 1) % PF], rW[(D + 1) % PF]);
+    if constexpr (PF == 1) {
+      if (s + 1 < a.nsteps) {
+        load_next(rP[0], rW[0]);
+        store_step(buf ^ 1, rP[0], rW[0]);
+      }
     }
     __syncthreads();
   };
@@ -351,12 +359,19 @@ int gank_igemm_dispatch(IgemmArgs a, hipStream_t s) {
   if (packed) {
     if (a.CoutPad % 64 == 0) rc = launch_cfg<2, 2, 1, 1, true, 1, 0>(a, s);
     else rc = launch_cfg<4, 1, 2, 1, true, 1, 0>(a, s);
-  } else if (a.CoutPad % 128 == 0 && tiles128 >= 192) {
+  } else if (a.CoutPad % 128 == 0 && tiles128 >= 192 && pf_env >= 20) {
+    if (pf_env == 20) rc = launch_mode<4, 2, 2, 2, 1>(a, s);          // 256 x 128, 8 waves
+    else if (pf_env == 21) rc = launch_mode<4, 2, 2, 2, 2>(a, s);
+    else if (pf_env == 22 && a.CoutPad % 256 == 0) rc = launch_mode<2, 4, 2, 2, 2>(a, s);   // 128 x 256
+    else if (pf_env == 23 && a.CoutPad % 256 == 0) rc = launch_mode<4, 2, 2, 4, 2>(a, s);   // 256 x 256, wave 64x128
+    else rc = launch_mode<4, 2, 2, 2, 2>(a, s);
+  } else if (a.CoutPad % 128 == 0 && tiles128 >= 192 && pf_env < 10) {
     if (pf_env == 1) rc = launch_mode<2, 2, 2, 2, 1>(a, s);
     else if (pf_env == 3) rc = launch_mode<2, 2, 2, 2, 3>(a, s);
     else rc = launch_mode<2, 2, 2, 2, 2>(a, s);
   } else if (a.CoutPad % 64 == 0) {
-    if (pf_env == 1) rc = launch_mode<2, 2, 1, 1, 1>(a, s);
+    if (pf_env == 1 || pf_env == 11) rc = launch_mode<2, 2, 1, 1, 1>(a, s);
+    else if (pf_env == 12) rc = launch_mode<2, 2, 1, 1, 2>(a, s);
     else if (pf_env == 3) rc = launch_mode<2, 2, 1, 1, 2>(a, s);
     else rc = launch_mode<2, 2, 1, 1, 4>(a, s);
   } else {

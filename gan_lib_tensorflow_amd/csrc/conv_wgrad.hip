@@ -12,6 +12,7 @@
 // relu, the mean-pool gradient (dy stored at half size) and the stride-2 form used by Deconv2D.
 #include "gank_common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 #define WG_X_ZEROINS2X 16  // (unused here; kept aligned with conv_igemm flags)
 #define WG_X_STRIDE2 32
@@ -21,6 +22,8 @@ struct WgradArgs {
   const bf16* dy;
   float* dw;
   float* dbias;       // optional: dbias[co] += scale * sum_pixels dy[p][co] (fused bias gradient)
+  float* ws;          // optional workspace for split partial slabs (all-taps kernel)
+  long ws_elems;
   int N, H, W;        // pixel grid the reduction runs over (conv output size)
   int Hx, Wx;         // stored x spatial
   int Hdy, Wdy;       // stored dy spatial
@@ -710,6 +713,268 @@ static int launch_wgrad_packed(WgradArgs a, hipStream_t s) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// All-taps variant for 3x3 / stride 1 / power-of-two images / Cin%64==0 / Cout%64==0 -- the layers that
+// carry the wgrad FLOPs.  One block owns a 64(ci) x 64(co) tile for ALL 9 taps: per step it stages ONE
+// 8x8 patch of dy and the 10x10 halo of x, then every tap's A fragments are transposed reads of the same
+// halo image at a shifted pixel offset (ds_read_b64_tr_b16 takes a per-lane row address, so a shifted
+// window is just address arithmetic).  Versus one block per tap: 3.5x less L2->LDS traffic, 4x fewer
+// ds_write, and 36 instead of 16 MFMAs per wave between barriers.  Partial tiles of the pixel splits go to
+// fp32 slabs with plain coalesced stores and are summed by a second tiny kernel (deterministic; the atomic
+// form would burst 9x more atomic bytes per block at the end of the kernel).
+// ------------------------------------------------------------------------------------------------------
+constexpr int XSUB = 100 * 32 + 32;   // halo sub-tile stride (bf16): 64 B off a 256 B multiple
+
+template <int MODE, int PF>
+__global__ __launch_bounds__(256) void conv_wgrad_taps_kernel(WgradArgs a) {
+  constexpr int NT = 256;
+  constexpr bool XRELU = (MODE & 1) != 0, XUP = (MODE & 2) != 0, DYUP = (MODE & 4) != 0;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* sX = reinterpret_cast<bf16*>(smem);        // [2][2 subs][100 pix][32 ch]
+  bf16* sD = sX + 2 * 2 * XSUB;                    // [2][2 subs][64 pix][32 ch]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_a = wave & 1, wave_b = wave >> 1;
+  int bid = blockIdx.x;
+  const int split = bid % a.splits; bid /= a.splits;
+  const int tco = bid % a.tiles_co, tci = bid / a.tiles_co;
+  const int ci0 = tci * 64, co0 = tco * 64;
+  const bool do_bias = a.dbias != nullptr && tci == 0;
+
+  const int step0 = split * a.steps_per_split;
+  int nsteps = (a.M >> 6) - step0;
+  if (nsteps > a.steps_per_split) nsteps = a.steps_per_split;
+  if (nsteps <= 0) return;
+
+  constexpr int OOB = 0x7FFFFFF0;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, a.N * a.Hx * a.Wx * a.Cin * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.dy), 0, a.N * a.Hdy * a.Wdy * a.Cout * 2, 0x00020000);
+  const int pw_shift = a.sw - 3, pi_shift = a.shw - 6;   // patches per row / per image (log2)
+
+  // per-thread chunk constants
+  int x_hy[4], x_hx[4], x_c[4], x_lds[4];
+  bool x_on[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int q = tid + NT * j;
+    x_on[j] = q < 800;
+    const int hp = x_on[j] ? q >> 3 : 0, cc = q & 7;
+    x_hy[j] = hp / 10 - 1;
+    x_hx[j] = hp % 10 - 1;
+    x_c[j] = x_on[j] ? (ci0 + cc * 8) * 2 : OOB;
+    x_lds[j] = (cc >> 2) * XSUB + hp * 32 + (cc & 3) * 8;
+  }
+  int d_y[2], d_x[2], d_c[2], d_lds[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int q = tid + NT * j, p = q >> 3, cc = q & 7;
+    d_y[j] = p >> 3; d_x[j] = p & 7;
+    d_c[j] = (co0 + cc * 8) * 2;
+    d_lds[j] = (cc >> 2) * SUBS + p * 32 + (cc & 3) * 8;
+  }
+
+  u32x4 rX[PF][4], rD[PF][2];
+  float bsum[2][8];
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) bsum[j][e] = 0.f;
+
+  const int last = nsteps - 1;
+  int cur = 0;
+  auto load_next = [&](u32x4 (&rX)[4], u32x4 (&rD)[2]) {
+    const int patch = step0 + cur;                       // wave-uniform (SALU)
+    const int n = patch >> pi_shift;
+    const int pin = patch & ((1 << pi_shift) - 1);
+    const int py0 = (pin >> pw_shift) << 3, px0 = (pin & ((1 << pw_shift) - 1)) << 3;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int iy = py0 + x_hy[j], ix = px0 + x_hx[j];
+      const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      int off;
+      if constexpr (XUP) off = ((n * a.Hx + (iy >> 1)) * a.Wx + (ix >> 1)) * a.Cin * 2 + x_c[j];
+      else off = ((n * a.H + iy) * a.W + ix) * a.Cin * 2 + x_c[j];
+      rX[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? off : OOB, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int oy = py0 + d_y[j], ox = px0 + d_x[j];
+      int off;
+      if constexpr (DYUP) off = ((n * a.Hdy + (oy >> 1)) * a.Wdy + (ox >> 1)) * a.Cout * 2 + d_c[j];
+      else off = ((n * a.H + oy) * a.W + ox) * a.Cout * 2 + d_c[j];
+      rD[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, off, 0, 0);
+    }
+    if (cur < last) cur++;
+  };
+  auto store_step = [&](int buf, u32x4 (&rX)[4], u32x4 (&rD)[2]) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (x_on[j]) {
+        u32x4 v = rX[j];
+        if constexpr (XRELU) v = relu_bf16x8(v);
+        *reinterpret_cast<u32x4*>(sX + buf * 2 * XSUB + x_lds[j]) = v;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      *reinterpret_cast<u32x4*>(sD + buf * 2 * SUBS + d_lds[j]) = rD[j];
+      if (do_bias) {
+        const bf16x8 t = __builtin_bit_cast(bf16x8, rD[j]);
+#pragma unroll
+        for (int e = 0; e < 8; e++) bsum[j][e] += bf2f(t[e]);
+      }
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; t++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+
+  const int g = lane >> 4, li = lane & 15;
+  // lane part of the transposed-read addresses: k half (g>>1) = patch row within the pair, (li>>2) = pixel
+  const int xl = ((g >> 1) * 10 + (li >> 2)) * 32 + 16 * (g & 1) + 4 * (li & 3);
+  const int dl = (8 * (g >> 1) + (li >> 2)) * 32 + 16 * (g & 1) + 4 * (li & 3);
+
+#pragma unroll
+  for (int d = 0; d < PF; d++) load_next(rX[d], rD[d]);
+  store_step(0, rX[0], rD[0]);
+  __syncthreads();
+
+  auto step = [&](int s, auto slot) {
+    constexpr int D = decltype(slot)::value;
+    const int buf = s & 1;
+    if constexpr (PF > 1) load_next(rX[D], rD[D]);
+    else if (s + 1 < nsteps) load_next(rX[0], rD[0]);
+    const bf16* pX = sX + (buf * 2 + wave_a) * XSUB + xl;
+    const bf16* pD = sD + (buf * 2 + wave_b) * SUBS + dl;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      const s16x4 bl = lds_tr_read(pD + kk * 16 * 32), bh = lds_tr_read(pD + kk * 16 * 32 + 4 * 32);
+      const s16x8 tb = {bl[0], bl[1], bl[2], bl[3], bh[0], bh[1], bh[2], bh[3]};
+      const bf16x8 fb = __builtin_bit_cast(bf16x8, tb);
+#pragma unroll
+      for (int t = 0; t < 9; t++) {
+        const int dh = t / 3 - 1, dw = t % 3 - 1;
+        const int o = ((2 * kk + 1 + dh) * 10 + 1 + dw) * 32;
+        const s16x4 al = lds_tr_read(pX + o), ah = lds_tr_read(pX + o + 4 * 32);
+        const s16x8 ta = {al[0], al[1], al[2], al[3], ah[0], ah[1], ah[2], ah[3]};
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ta), fb, acc[t], 0, 0, 0);
+      }
+    }
+    if (s + 1 < nsteps) store_step(buf ^ 1, rX[(D + 1) % PF], rD[(D + 1) % PF]);
+    __syncthreads();
+  };
+  int s0 = 0;
+  for (; s0 + PF <= nsteps; s0 += PF) {
+    step(s0 + 0, std::integral_constant<int, 0>{});
+    if constexpr (PF >= 2) step(s0 + 1, std::integral_constant<int, 1 % PF>{});
+  }
+  if constexpr (PF >= 2) { if (s0 < nsteps) step(s0, std::integral_constant<int, 0>{}); }
+
+  // partial tile -> slab [split][tap][Cin][Cout] (plain stores) or atomics straight into dw
+  const int r = lane & 31, h = lane >> 5;
+  const int co = co0 + wave_b * 32 + r;
+#pragma unroll
+  for (int t = 0; t < 9; t++) {
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const int ci = ci0 + wave_a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      const long o = ((long)t * a.Cin + ci) * a.Cout + co;
+      if (a.ws) a.ws[(long)split * 9 * a.Cin * a.Cout + o] = acc[t][e] * a.scale;
+      else atomicAdd(a.dw + o, acc[t][e] * a.scale);
+    }
+  }
+  if (do_bias) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);            // [256][16]
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) red[(tid * 2 + j) * 8 + e] = bsum[j][e];
+    __syncthreads();
+    if (tid < 64) {
+      const int cc = tid >> 3, e = tid & 7;
+      float tsum = 0.f;
+      for (int p = 0; p < 64; p++) {
+        const int q = p * 8 + cc;
+        tsum += red[((q % NT) * 2 + q / NT) * 8 + e];
+      }
+      atomicAdd(a.dbias + co0 + tid, tsum * a.scale);
+    }
+  }
+}
+
+// dw[i] += sum_split ws[split][i]
+__global__ void wgrad_reduce_slabs_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n4, int splits) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 t = reinterpret_cast<const f32x4*>(dw)[i];
+    for (int s = 0; s < splits; s++) {
+      const f32x4 v = reinterpret_cast<const f32x4*>(ws)[(long)s * n4 + i];
+      t[0] += v[0]; t[1] += v[1]; t[2] += v[2]; t[3] += v[3];
+    }
+    reinterpret_cast<f32x4*>(dw)[i] = t;
+  }
+}
+
+static bool wgrad_taps_ok(const WgradArgs& a) {
+  return a.ks == 3 && a.pad == 1 && !(a.flags & WG_X_STRIDE2) && a.sw >= 3 && a.shw >= 6 && a.H >= 8 && a.W >= 8 &&
+         a.M >= 16384 &&   // small reductions: the per-tap kernel's finer split fills the chip better
+        
+         a.Cin % 64 == 0 && a.Cout % 64 == 0 && (a.M % 64 == 0) &&
+         (long)a.N * a.Hx * a.Wx * a.Cin < (1L << 30) && (long)a.N * a.Hdy * a.Wdy * a.Cout < (1L << 30);
+}
+
+static void wgrad_taps_geometry(WgradArgs& a) {
+  a.tiles_ci = a.Cin / 64;
+  a.tiles_co = a.Cout / 64;
+  const int total_steps = a.M / 64;
+  const int tiles = a.tiles_ci * a.tiles_co;
+  int splits = (512 + tiles - 1) / tiles;
+  if (splits > total_steps / 4) splits = total_steps / 4;
+  if (splits < 1) splits = 1;
+  a.steps_per_split = cdiv(total_steps, splits);
+  a.splits = cdiv(total_steps, a.steps_per_split);
+}
+
+template <int MODE>
+static int launch_wgrad_taps_mode(WgradArgs a, hipStream_t s) {
+  wgrad_taps_geometry(a);
+  const long slab = 9L * a.Cin * a.Cout;
+  if (a.ws && a.ws_elems >= slab * a.splits && a.splits > 1) {
+    // slab mode
+  } else {
+    a.ws = nullptr;   // atomics
+  }
+  const size_t lds = (size_t)2 * 2 * (XSUB + SUBS) * sizeof(bf16);
+  static int tpf = -1;
+  if (tpf < 0) { const char* e = getenv("GANK_WGRAD_TAPS_PF"); tpf = e ? atoi(e) : 2; }
+  auto kern = tpf == 1 ? conv_wgrad_taps_kernel<MODE, 1> : conv_wgrad_taps_kernel<MODE, 2>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_ci * a.tiles_co * a.splits)), dim3(256), lds, s, a);
+  GANK_LAUNCH_OK("conv_wgrad_taps");
+  if (a.ws) {
+    const long n4 = slab / 4;
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a.ws, a.dw, n4, a.splits);
+    GANK_LAUNCH_OK("wgrad_reduce_slabs");
+  }
+  return 0;
+}
+
+static int launch_wgrad_taps(const WgradArgs& a, hipStream_t s) {
+  const int mode = ((a.flags & GANK_IN_RELU) ? 1 : 0) | ((a.flags & GANK_IN_UPSAMPLE2X) ? 2 : 0) | ((a.flags & GANK_DY_UPSAMPLE2X) ? 4 : 0);
+  switch (mode) {
+    case 0: return launch_wgrad_taps_mode<0>(a, s);
+    case 1: return launch_wgrad_taps_mode<1>(a, s);
+    case 2: return launch_wgrad_taps_mode<2>(a, s);
+    case 4: return launch_wgrad_taps_mode<4>(a, s);
+    case 5: return launch_wgrad_taps_mode<5>(a, s);
+    default: return -1;
+  }
+}
+
 template <int WA, int WB, int TA, int TB, bool FAST, int PF>
 static int launch_wgrad(WgradArgs a, hipStream_t s) {
   constexpr int CiT = WA * TA * 32, CoT = WB * TB * 32;
@@ -753,7 +1018,10 @@ int gank_wgrad_dispatch(WgradArgs a, hipStream_t s) {
   int rc = -1;
   const bool lean = fast && a.sw >= 0 && a.shw >= 0 && !(a.flags & WG_X_STRIDE2) && (a.M % 64 == 0) &&
                     (long)a.N * a.Hx * a.Wx * a.Cin < (1L << 30) && (long)a.N * a.Hdy * a.Wdy * a.Cout < (1L << 30);
-  if (lean) {
+  static int taps_env = -1;   // experiment knob: GANK_WGRAD_TAPS=0 disables the all-taps kernel
+  if (taps_env < 0) { const char* e = getenv("GANK_WGRAD_TAPS"); taps_env = e ? atoi(e) : 1; }
+  if (taps_env && wgrad_taps_ok(a)) rc = launch_wgrad_taps(a, s);
+  if (rc < 0 && lean) {
     if (a.Cin >= 128 && a.Cout >= 128) rc = launch_wgrad_lean<2, 2, 2, 2, 2>(a, s);
     else if (a.Cin >= 64 && a.Cout >= 64) rc = launch_wgrad_lean<2, 2, 1, 1, 2>(a, s);
   }
@@ -781,11 +1049,22 @@ int gank_wgrad_dispatch(WgradArgs a, hipStream_t s) {
   return rc;
 }
 
-extern "C" int gank_conv2d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int Cin,
-                                 int Cout, int ksize, int flags, float scale, void* stream) {
+extern "C" long gank_conv2d_wgrad_ws_elems(int N, int H, int W, int Cin, int Cout, int ksize, int flags) {
+  WgradArgs a{};
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.pad = (ksize - 1) / 2; a.flags = flags;
+  const bool xup = flags & GANK_IN_UPSAMPLE2X, dyup = flags & GANK_DY_UPSAMPLE2X;
+  a.Hx = xup ? H / 2 : H; a.Wx = xup ? W / 2 : W; a.Hdy = dyup ? H / 2 : H; a.Wdy = dyup ? W / 2 : W;
+  a.M = N * H * W; a.sw = log2_or_neg(W); a.shw = log2_or_neg(H * W);
+  if (!wgrad_taps_ok(a)) return 0;
+  wgrad_taps_geometry(a);
+  return a.splits > 1 ? 9L * Cin * Cout * a.splits : 0;
+}
+
+extern "C" int gank_conv2d_wgrad(const void* x, const void* dy, float* dw, float* dbias, float* ws, long ws_elems, int N,
+                                 int H, int W, int Cin, int Cout, int ksize, int flags, float scale, void* stream) {
   GANK_REQUIRE(ksize % 2 == 1, "conv2d_wgrad: even filter sizes are not on this path (ksize=%d)", ksize);
   WgradArgs a{};
-  a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.dw = dw; a.dbias = dbias;
+  a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.dw = dw; a.dbias = dbias; a.ws = ws; a.ws_elems = ws_elems;
   a.N = N; a.H = H; a.W = W;
   const bool xup = flags & GANK_IN_UPSAMPLE2X, dyup = flags & GANK_DY_UPSAMPLE2X;
   GANK_REQUIRE(!(xup || dyup) || (H % 2 == 0 && W % 2 == 0), "conv2d_wgrad: 2x flags need even size");

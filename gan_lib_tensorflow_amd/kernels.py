@@ -97,8 +97,11 @@ def conv2d_wgrad(x, dy, dw, hw, ksize, flags=0, scale=1.0, dbias=None):
     """ACCUMULATES into dw fp32 [k,k,Cin,Cout] (and the bias gradient into dbias fp32 [Cout] when given)."""
     n, cin, cout = x.shape[0], x.shape[3], dy.shape[3]
     assert dw.shape[-2] == cin and dw.shape[-1] == cout, (dw.shape, cin, cout)
-    _lib.check(lib().gank_conv2d_wgrad(_p(x, BF16, "x"), _p(dy, BF16, "dy"), _p(dw, F32, "dw"), _p(dbias, F32, "dbias"), n, hw[0], hw[1],
-                                       cin, cout, ksize, flags, scale, _stream()), "conv2d_wgrad")
+    ws_elems = lib().gank_conv2d_wgrad_ws_elems(n, hw[0], hw[1], cin, cout, ksize, flags)
+    ws = torch.empty(ws_elems, dtype=F32, device=x.device) if ws_elems > 0 else None
+    _lib.check(lib().gank_conv2d_wgrad(_p(x, BF16, "x"), _p(dy, BF16, "dy"), _p(dw, F32, "dw"), _p(dbias, F32, "dbias"),
+                                       _p(ws), ws_elems, n, hw[0], hw[1], cin, cout, ksize, flags, scale, _stream()),
+               "conv2d_wgrad")
     return dw
 
 

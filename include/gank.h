@@ -79,9 +79,12 @@ int gank_conv2d_dgrad(const void* dy, const void* wd, const void* residual, cons
  * ranges) into dw [k,k,Cin,Cout] -- zero it first for a plain gradient.  (H,W) is the conv OUTPUT
  * size; x is [N,H,W,Cin] (or half-size with IN_UPSAMPLE2X), dy [N,H,W,Cout] (or half-size with
  * DY_UPSAMPLE2X).  dbias (optional, [Cout]) += scale * column sums of dy: the tf.nn.bias_add gradient
- * (conv2d.py:216) fused into the pass that already streams dy. */
-int gank_conv2d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int Cin,
-                      int Cout, int ksize, int flags, float scale, void* stream);
+ * (conv2d.py:216) fused into the pass that already streams dy.
+ * ws (optional): fp32 scratch of gank_conv2d_wgrad_ws_elems(...) elements; when given, the split partial tiles
+ * are written as slabs and summed deterministically instead of with atomics. */
+long gank_conv2d_wgrad_ws_elems(int N, int H, int W, int Cin, int Cout, int ksize, int flags);
+int gank_conv2d_wgrad(const void* x, const void* dy, float* dw, float* dbias, float* ws, long ws_elems, int N, int H,
+                      int W, int Cin, int Cout, int ksize, int flags, float scale, void* stream);
 
 /* ---- Deconv2D (common/ops/deconv2d.py:99-114): tf.nn.conv2d_transpose stride 2 SAME --------------
  * x [N,H,W,Cin] -> y [N,2H,2W,Cout]; master filter F fp32 [k,k,Cout,Cin].  The op has no caller in
