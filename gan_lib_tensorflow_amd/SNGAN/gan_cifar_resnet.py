@@ -175,6 +175,11 @@ class SNGANTrainer:
         # static input buffers (graph replays read these addresses)
         self.real_u8 = torch.zeros((b, OUTPUT_DIM), dtype=torch.uint8, device=self.device)
         self.real_labels = torch.zeros(b, dtype=torch.int32, device=self.device)
+        # one iteration's worth of critic feeds and generator outputs (train_iteration)
+        self.real_all = torch.zeros((N_CRITIC, b, OUTPUT_DIM), dtype=torch.uint8, device=self.device)
+        self.labels_all = torch.zeros((N_CRITIC, b), dtype=torch.int32, device=self.device)
+        self.fake_all = torch.zeros((N_CRITIC, b, OUTPUT_DIM), dtype=torch.bfloat16, device=self.device)
+        self.fake_one = torch.zeros((b, OUTPUT_DIM), dtype=torch.bfloat16, device=self.device)
         self.d_loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.g_loss = torch.zeros(1, dtype=torch.float32, device=self.device)
 
@@ -192,14 +197,16 @@ class SNGANTrainer:
         self._refresh_g_prep()
 
     # ---- the two updates, as plain eager code (captured into graphs by _run) -----------------------
-    def _d_forward_backward(self, real_pre=None, z=None):
+    def _d_forward_backward(self, real_pre=None, z=None, fake=None):
         """disc_cost and its gradients (:326-381): fakes from N_TOWERS generator towers conditioned on
-        the REAL labels, critic on concat(real, fake) with update_collection=None."""
+        the REAL labels, critic on concat(real, fake) with update_collection=None.  `fake`: precomputed
+        generator output for this update (see _generate_for_critic)."""
         set_default_store(self.store)
         b = self.batch
         self.store.zero_grads('Discriminator')
         with torch.no_grad():   # generator is not trained by disc_cost: no autograd graph through it
-            fake = Generator(b, self.real_labels, noise=z, groups=N_TOWERS, rng_state=self.rng_state)
+            if fake is None:
+                fake = Generator(b, self.real_labels, noise=z, groups=N_TOWERS, rng_state=self.rng_state)
             real = K.preprocess_real(self.real_u8, self.rng_state).reshape(b, OUTPUT_DIM) if real_pre is None else real_pre
             both = torch.cat([real, fake], 0)                          # plumbing: device memcpy
             both_labels = torch.cat([self.real_labels, self.real_labels], 0)
@@ -208,6 +215,20 @@ class SNGANTrainer:
         loss.backward()
         self.d_loss.copy_(loss.detach())
         return logits
+
+    def _d_forward_backward_prefetched(self):
+        return self._d_forward_backward(fake=self.fake_one)
+
+    @torch.no_grad()
+    def _generate_for_critic(self):
+        """The generator is frozen during the N_CRITIC critic updates of an iteration (:599-620), so their
+        fakes are ONE generator pass over N_CRITIC*B samples: each update's N_TOWERS towers keep their own
+        conditional-batch-norm statistics (`groups`), each sample its own noise -- the same arithmetic as
+        N_CRITIC separate passes, in 5x fewer, 5x larger launches."""
+        set_default_store(self.store)
+        n = N_CRITIC * self.batch
+        fake = Generator(n, self.labels_all.reshape(-1), groups=N_CRITIC * N_TOWERS, rng_state=self.rng_state)
+        self.fake_all.copy_(fake.reshape(N_CRITIC, self.batch, OUTPUT_DIM))
 
     def _g_forward_backward(self, z=None, fake_labels=None):
         """gen_cost and its gradients (:464-498): N_TOWERS towers of GEN_BS_MULTIPLE*B/N_TOWERS samples,
@@ -278,6 +299,31 @@ class SNGANTrainer:
             self._allreduce(flat)
             g2.replay()
 
+    def _run_plain(self, key, fn):
+        """Capture-and-replay of a forward-only piece (no optimiser, no exchange)."""
+        if not self.use_graphs:
+            fn()
+            return
+        if key not in self._graphs:
+            st = torch.cuda.Stream()
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                fn()
+            torch.cuda.current_stream().wait_stream(st)
+            torch.cuda.synchronize()
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    fn()
+                self._graphs[key] = (g, None)
+            except Exception as e:  # noqa: BLE001
+                import sys
+                print(f"[gank] hipGraph capture of {key!r} failed ({e}); running eagerly", file=sys.stderr)
+                self.use_graphs = False
+                torch.cuda.synchronize()
+            return
+        self._graphs[key][0].replay()
+
     # ---- public API ---------------------------------------------------------------------------------
     def d_step(self, real_u8, labels):
         """One critic update on a uint8 [B,3072] CHW-planar batch + int labels (the feed of :616-620)."""
@@ -296,9 +342,16 @@ class SNGANTrainer:
         updates, each on the next (uint8 images, labels) pair from `batches`."""
         if self.iteration > 0:
             self.g_step()
-        for _ in range(N_CRITIC):
+        for i in range(N_CRITIC):
             data, labels = next(batches)
-            self.d_step(data, labels)
+            self.real_all[i].copy_(data, non_blocking=True)
+            self.labels_all[i].copy_(labels, non_blocking=True)
+        self._run_plain('gen5', self._generate_for_critic)
+        for i in range(N_CRITIC):
+            self.real_u8.copy_(self.real_all[i])
+            self.real_labels.copy_(self.labels_all[i])
+            self.fake_one.copy_(self.fake_all[i])
+            self._run('d_pre', self._d_forward_backward_prefetched, self.d_opt, self.d_flat)
         self.iteration += 1
         K.counter_add(self.iteration_dev, 1)
 
