@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgank.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("GANK_LIB_NAME", "libgank.so"))   # GANK_LIB_NAME: experiment builds
 
 P, I, L, F = C.c_void_p, C.c_int, C.c_long, C.c_float
 

@@ -11,9 +11,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(os.path.dirname(HERE), "include")
-LIB = os.path.join(HERE, "libgank.so")
+LIB = os.path.join(HERE, os.environ.get("GANK_LIB_NAME", "libgank.so"))   # experiment builds: GANK_LIB_NAME + GANK_EXTRA_FLAGS
 SOURCES = ["api.hip", "conv_igemm.hip", "conv_wgrad.hip", "elementwise.hip", "sn.hip", "cbn.hip", "loss_opt.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"] + \
+    os.environ.get("GANK_EXTRA_FLAGS", "").split()
 
 
 def _newer(a, b):
@@ -21,12 +22,13 @@ def _newer(a, b):
 
 
 def build(force=False, verbose=True):
-    os.makedirs(os.path.join(HERE, "_obj"), exist_ok=True)
+    objdir = "_obj" + ("_" + os.environ["GANK_LIB_NAME"] if "GANK_LIB_NAME" in os.environ else "")
+    os.makedirs(os.path.join(HERE, objdir), exist_ok=True)
     hdrs = [os.path.join(CSRC, "gank_common.h"), os.path.join(INC, "gank.h")]
     objs, procs = [], []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
-        op = os.path.join(HERE, "_obj", src.replace(".hip", ".o"))
+        op = os.path.join(HERE, objdir, src.replace(".hip", ".o"))
         objs.append(op)
         if force or _newer(sp, op) or any(_newer(h, op) for h in hdrs):
             cmd = ["hipcc", *FLAGS, "-I", INC, "-c", sp, "-o", op]

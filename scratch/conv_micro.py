@@ -7,6 +7,7 @@ n, h, cin, cout, k = (int(v) for v in (sys.argv[2:7] if len(sys.argv) > 6 else (
 reps = int(sys.argv[7]) if len(sys.argv) > 7 else 20
 x = torch.randn(n, h, h, cin, device="cuda").to(torch.bfloat16)
 w = (torch.randn(k, k, cin, cout, device="cuda") / (k * k * cin) ** 0.5)
+xh = torch.randn(n, h // 2, h // 2, cin, device="cuda").to(torch.bfloat16)
 dy = torch.randn(n, h, h, cout, device="cuda").to(torch.bfloat16)
 wf, wd = K.prep_weights(w, True, True)
 dw = torch.zeros_like(w)
@@ -15,6 +16,8 @@ ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=
 def run():
     if which == "fprop":
         K.conv2d_fprop(x, wf, None, (h, h), cout, k)
+    elif which == "fprop_up":
+        K.conv2d_fprop(xh, wf, None, (h, h), cout, k, K.IN_UPSAMPLE2X)
     elif which == "dgrad":
         K.conv2d_dgrad(dy, wd, (h, h), cin, k)
     else:
