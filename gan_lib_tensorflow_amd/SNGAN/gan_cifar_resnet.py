@@ -185,6 +185,9 @@ class SNGANTrainer:
 
     def _refresh_g_prep(self):
         K.prep_weights_batched(self._g_convs, want_d=True)
+        for k, v in self.store.vars.items():       # the three UpsampleConv 3x3 layers: phase operands
+            if k.startswith('Generator/') and k.endswith('.Conv1/Filters') and v.shape[0] == 3:
+                K.upconv3x3_prep(v)
 
     def load_state_dict(self, state, strict=True):
         """Restore variables by name; cached operand copies and captured graphs are rebuilt."""

@@ -35,6 +35,9 @@ PROTOTYPES = {
     "gank_conv2d_dgrad": [P, P, P, P, P, I, I, I, I, I, I, I, F, P],
     "gank_conv2d_wgrad_ws_elems": [I, I, I, I, I, I, I],
     "gank_conv2d_wgrad": [P, P, P, P, P, L, I, I, I, I, I, I, I, F, P],
+    "gank_upconv3x3_prep_weights": [P, P, P, I, I, P],
+    "gank_upconv3x3_fprop": [P, P, P, P, P, I, I, I, I, I, I, P],
+    "gank_upconv3x3_dgrad": [P, P, P, P, I, I, I, I, I, P],
     "gank_deconv2d_fprop": [P, P, P, P, I, I, I, I, I, I, P],
     "gank_deconv2d_dgrad": [P, P, P, I, I, I, I, I, I, P],
     "gank_deconv2d_wgrad": [P, P, P, I, I, I, I, I, I, P],

@@ -40,6 +40,7 @@ struct IgemmArgs {
   int tiles_m, tiles_n;
   int shw, sw;      // log2(H*W), log2(W) or -1
   int korder;       // bit0: tap-inner K order
+  int tiles_pp;     // phase mode: pixel tiles per phase
 };
 
 constexpr int LROW = 72;  // LDS row length in bf16 (64 + 8 pad) = 144 B
@@ -71,7 +72,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
 
   const int nwg = a.tiles_m * a.tiles_n;
   const int lid = xcd_remap(blockIdx.x, nwg);
-  const int tile_n = lid % a.tiles_n, tile_m = lid / a.tiles_n;
+  const int tile_n = lid % a.tiles_n;
+  int tile_m = lid / a.tiles_n;
+  // MODE bit 2: output-phase decomposition of a stride-2 transposed conv / NN-upsample+3x3 conv.  The grid
+  // holds 4 x tiles_pp pixel tiles; phase (a,b) = output parity.  Each phase is a 2x2-tap stride-1 conv over
+  // the LOW-RES input with its own weight matrix and pad (1-a, 1-b), written to the (2y+a, 2x+b) positions:
+  // 4 taps per output instead of 9 (or 16 with zero insertion).
+  constexpr bool PHASE = !PACKED && (MODE & 4) != 0;
+  int phase = 0;
+  if constexpr (PHASE) { phase = tile_m / a.tiles_pp; tile_m -= phase * a.tiles_pp; }
+  const int pad_h = PHASE ? 1 - (phase >> 1) : a.pad, pad_w = PHASE ? 1 - (phase & 1) : a.pad;
 
   const int st = (a.flags & IG_IN_STRIDE2) ? 2 : 1;
   const bool shr = PACKED ? (a.flags & (GANK_IN_UPSAMPLE2X | IG_IN_ZEROINS2X)) != 0 : (MODE & 2) != 0;
@@ -108,7 +118,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<bf16*>(a.x), 0, a.N * a.Hin * a.Win * a.Cin * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16*>(a.w), 0, a.CoutPad * a.Kpad * 2, 0x00020000);
+      const_cast<bf16*>(a.w), 0, a.CoutPad * a.Kpad * 2 * (PHASE ? 4 : 1), 0x00020000);
   int p_off[CP];   // byte offset of (n, oh*st, ow*st, cc*8) in x   (non-shifted-index modes)
   int w_off[CW];   // byte offset of (co, cc*8) in w
 #pragma unroll
@@ -117,13 +127,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
 #pragma unroll
   for (int j = 0; j < CW; j++) {
     const int q = tid + NT * j;
-    w_off[j] = ((tile_n * BN + (q >> 3)) * a.Kpad + (q & 7) * 8) * 2;
+    w_off[j] = (((PHASE ? phase * a.CoutPad : 0) + tile_n * BN + (q >> 3)) * a.Kpad + (q & 7) * 8) * 2;
   }
 
   // K-step cursor, advanced incrementally (tap-major, then 64-channel chunk): no divisions in the loop.
   // After the last step it stays put, so the PF-1 trailing refills of the ring re-load the last step.
   const int last = a.nsteps - 1;
-  int cur = 0, cur_c0 = 0, cur_tap = 0, cur_dh = -a.pad, cur_dw = -a.pad;
+  int cur = 0, cur_c0 = 0, cur_tap = 0, cur_dh = -pad_h, cur_dw = -pad_w;
   constexpr bool TAP_INNER = (GANK_KMODE & 1) != 0;   // compile-time experiment knob (build.py GANK_KMODE)
   constexpr int W_AUX = (GANK_KMODE >> 1) == 1 ? 2 : ((GANK_KMODE >> 1) == 2 ? 16 : 0);   // nt / sc1 / default
 
@@ -181,13 +191,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
         cur++;
         if constexpr (TAP_INNER) {  // K order: channel chunk outer, tap inner
           cur_tap++;
-          if (++cur_dw > a.ks - 1 - a.pad) { cur_dw = -a.pad; cur_dh++; }
-          if (cur_tap >= a.taps) { cur_tap = 0; cur_dh = -a.pad; cur_dw = -a.pad; cur_c0 += 64; }
+          if (++cur_dw > a.ks - 1 - pad_w) { cur_dw = -pad_w; cur_dh++; }
+          if (cur_tap >= a.taps) { cur_tap = 0; cur_dh = -pad_h; cur_dw = -pad_w; cur_c0 += 64; }
         } else {                    // K order: tap outer, channel chunk inner
           cur_c0 += 64;
           if (cur_c0 >= a.Cin) {
             cur_c0 = 0; cur_tap++;
-            if (++cur_dw > a.ks - 1 - a.pad) { cur_dw = -a.pad; cur_dh++; }
+            if (++cur_dw > a.ks - 1 - pad_w) { cur_dw = -pad_w; cur_dh++; }
           }
         }
       }
@@ -278,8 +288,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
   const bool otanh = (a.flags & GANK_OUT_TANH) != 0;
 #pragma unroll
   for (int j = 0; j < TM; j++) {
-    const int m = tile_m * BM + (wave_m * TM + j) * 32 + r;
+    int m = tile_m * BM + (wave_m * TM + j) * 32 + r;
     if (m >= a.M) continue;
+    if constexpr (PHASE) {      // low-res pixel (n,y,x) of this phase -> output pixel (n, 2y+a, 2x+b)
+      int n_, y_, x_;
+      pix_decomp(m, a.H, a.W, a.shw, a.sw, n_, y_, x_);
+      m = (n_ * 2 * a.H + 2 * y_ + (phase >> 1)) * 2 * a.W + 2 * x_ + (phase & 1);
+    }
 #pragma unroll
     for (int i = 0; i < TN; i++) {
       const int co0 = tile_n * BN + (wave_n * TN + i) * 32 + 4 * h;
@@ -552,6 +567,26 @@ static int launch_cfg(const IgemmArgs& a0, hipStream_t s) {
 }
 
 template <int WM, int WN, int TM, int TN, int PF>
+static int launch_phase(const IgemmArgs& a0, hipStream_t s) {
+  IgemmArgs a = a0;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  a.tiles_pp = cdiv(a.M, BM);
+  a.tiles_m = 4 * a.tiles_pp;
+  a.tiles_n = a.CoutPad / BN;
+  const size_t lds = (size_t)2 * (BM + BN) * LROW * sizeof(bf16);
+  auto kern = conv_igemm_kernel<WM, WN, TM, TN, false, PF, 4>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return gank_set_error("conv_igemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(WM * WN * 64), lds, s, a);
+  GANK_LAUNCH_OK("conv_igemm_phase");
+  return 0;
+}
+
+template <int WM, int WN, int TM, int TN, int PF>
 static int launch_mode(const IgemmArgs& a, hipStream_t s) {
   const int mode = ((a.flags & GANK_IN_RELU) ? 1 : 0) | ((a.flags & (GANK_IN_UPSAMPLE2X | IG_IN_ZEROINS2X)) ? 2 : 0);
   switch (mode) {
@@ -647,6 +682,46 @@ extern "C" int gank_conv2d_dgrad(const void* dy, const void* wd, const void* res
   a.Cin = Cout; a.Cout = Cin; a.ks = ksize; a.pad = (ksize - 1) / 2;
   a.flags = flags & (GANK_IN_UPSAMPLE2X | GANK_IN_RELU);
   a.scale = scale;
+  return gank_igemm_dispatch(a, (hipStream_t)stream);
+}
+
+
+// NN-upsample(2x) + 3x3 SAME conv == stride-2 transposed conv with a 4x4 kernel: computed as 4 output phases
+// of 2x2 taps over the low-res input (2.25x fewer MACs than 9 taps at high resolution).  wph comes from
+// gank_upconv3x3_prep_weights.  Epilogue as gank_conv2d_fprop (bias, residual at OUTPUT resolution, tanh).
+extern "C" int gank_upconv3x3_fprop(const void* x, const void* wph, const float* bias, const void* residual, void* y,
+                                    int N, int Hl, int Wl, int Cin, int Cout, int flags, void* stream) {
+  GANK_REQUIRE(Cin % 64 == 0, "upconv3x3_fprop: Cin must be a multiple of 64 (got %d)", Cin);
+  IgemmArgs a{};
+  a.x = (const bf16*)x; a.w = (const bf16*)wph; a.bias = bias; a.res = (const bf16*)residual; a.y = (bf16*)y;
+  a.N = N; a.H = Hl; a.W = Wl; a.Hin = Hl; a.Win = Wl;
+  a.Cin = Cin; a.Cout = Cout; a.ks = 2; a.pad = 0;
+  a.flags = flags & GANK_OUT_TANH;
+  a.scale = 1.f;
+  hipStream_t s = (hipStream_t)stream;
+  a.taps = 4; a.CoutPad = roundup(Cout, 32); a.Kpad = 4 * Cin; a.nsteps = a.Kpad / 64;
+  a.M = N * Hl * Wl; a.sw = log2_or_neg(Wl); a.shw = log2_or_neg(Hl * Wl);
+  GANK_REQUIRE((long)N * Hl * Wl * Cin < (1L << 30) && (long)a.M * 4 * Cout < (1L << 31), "upconv3x3_fprop: tensor too large");
+  gank_prof_begin(0, 2.0 * a.M * 4.0 * (double)Cout * 4 * Cin, s);
+  int rc;
+  const long tiles128 = 4L * cdiv(a.M, 128) * (a.CoutPad / 128);
+  if (a.CoutPad % 128 == 0 && tiles128 >= 192) rc = launch_phase<2, 2, 2, 2, 2>(a, s);
+  else if (a.CoutPad % 64 == 0) rc = launch_phase<2, 2, 1, 1, 4>(a, s);
+  else rc = launch_phase<4, 1, 2, 1, 2>(a, s);
+  gank_prof_end(0, s);
+  return rc;
+}
+
+// its input gradient: dx_low = stride-2 SAME conv (4x4 taps) of dy with the combined kernel (wd4 layout from
+// gank_upconv3x3_prep_weights): 16 taps per LOW-RES pixel = 4 per output pixel, and no 2x2 sum pass.
+extern "C" int gank_upconv3x3_dgrad(const void* dy, const void* wd4, const void* relu_ref, void* dx, int N, int Hl, int Wl,
+                                    int Cin, int Cout, void* stream) {
+  IgemmArgs a{};
+  a.x = (const bf16*)dy; a.w = (const bf16*)wd4; a.mask = (const bf16*)relu_ref; a.y = (bf16*)dx;
+  a.N = N; a.H = Hl; a.W = Wl; a.Hin = 2 * Hl; a.Win = 2 * Wl;
+  a.Cin = Cout; a.Cout = Cin; a.ks = 4; a.pad = 1;
+  a.flags = IG_IN_STRIDE2;
+  a.scale = 1.f;
   return gank_igemm_dispatch(a, (hipStream_t)stream);
 }
 

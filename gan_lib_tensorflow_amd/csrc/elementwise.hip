@@ -61,6 +61,66 @@ extern "C" int gank_conv2d_prep_weights(const float* w, void* wf, void* wd, int 
   return 0;
 }
 
+// ---- NN-upsample + 3x3 conv as a 4x4 stride-2 transposed conv: phase operand matrices and the
+// combined 4x4 kernel for the input gradient (see gank_upconv3x3_fprop / _dgrad).
+//   wph[p=(a,b)][co][(i*2+j)*Cin+ci] = sum_{dh in R(a,i)} sum_{dw in R(b,j)} w[dh][dw][ci][co]
+//       R(0,0)={0}  R(0,1)={1,2}  R(1,0)={0,1}  R(1,1)={2}
+//   wd4[ci][(u*4+v)*Cout+co]         = sum_{dh in S(u)} sum_{dw in S(v)} w[dh][dw][ci][co]
+//       S(0)={2}  S(1)={1,2}  S(2)={0,1}  S(3)={0}
+__device__ __forceinline__ void up_range_R(int a, int i, int& lo, int& hi) {
+  if (a == 0) { lo = i == 0 ? 0 : 1; hi = i == 0 ? 0 : 2; } else { lo = i == 0 ? 0 : 2; hi = i == 0 ? 1 : 2; }
+}
+__device__ __forceinline__ void up_range_S(int u, int& lo, int& hi) {
+  lo = u == 0 ? 2 : (u == 1 ? 1 : 0);
+  hi = u == 0 ? 2 : (u == 1 ? 2 : (u == 2 ? 1 : 0));
+}
+
+__global__ void prep_upconv_kernel(const float* __restrict__ w, bf16* __restrict__ wph, bf16* __restrict__ wd4,
+                                   int Cin, int Cout, int CoutPad, int CinPad, int Kpad4) {
+  const long nph = 4L * CoutPad * 4 * Cin;
+  const long nd4 = (long)CinPad * Kpad4;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < nph + nd4; idx += (long)gridDim.x * blockDim.x) {
+    if (idx < nph) {
+      const int k = (int)(idx % (4 * Cin));
+      long t = idx / (4 * Cin);
+      const int co = (int)(t % CoutPad), p = (int)(t / CoutPad);
+      const int tap = k / Cin, ci = k - tap * Cin;
+      float v = 0.f;
+      if (co < Cout) {
+        int h0, h1, w0, w1;
+        up_range_R(p >> 1, tap >> 1, h0, h1);
+        up_range_R(p & 1, tap & 1, w0, w1);
+        for (int dh = h0; dh <= h1; dh++)
+          for (int dw = w0; dw <= w1; dw++) v += w[((long)(dh * 3 + dw) * Cin + ci) * Cout + co];
+      }
+      wph[idx] = f2bf(v);
+    } else {
+      const long i2 = idx - nph;
+      const int ci = (int)(i2 / Kpad4), k = (int)(i2 - (long)ci * Kpad4);
+      float v = 0.f;
+      if (ci < Cin && k < 16 * Cout) {
+        const int tap = k / Cout, co = k - tap * Cout;
+        int h0, h1, w0, w1;
+        up_range_S(tap >> 2, h0, h1);
+        up_range_S(tap & 3, w0, w1);
+        for (int dh = h0; dh <= h1; dh++)
+          for (int dw = w0; dw <= w1; dw++) v += w[((long)(dh * 3 + dw) * Cin + ci) * Cout + co];
+      }
+      wd4[i2] = f2bf(v);
+    }
+  }
+}
+
+extern "C" int gank_upconv3x3_prep_weights(const float* w, void* wph, void* wd4, int Cin, int Cout, void* stream) {
+  GANK_REQUIRE(w && wph && wd4 && Cin > 0 && Cout > 0, "upconv3x3_prep_weights: bad arguments");
+  const int CoutPad = roundup(Cout, 32), CinPad = roundup(Cin, 32), Kpad4 = roundup(16 * Cout, 64);
+  const long total = 4L * CoutPad * 4 * Cin + (long)CinPad * Kpad4;
+  hipLaunchKernelGGL(prep_upconv_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, w, (bf16*)wph, (bf16*)wd4,
+                     Cin, Cout, CoutPad, CinPad, Kpad4);
+  GANK_LAUNCH_OK("prep_upconv");
+  return 0;
+}
+
 // ---- batched: every conv/linear weight of a network in ONE launch (the per-layer form costs 2 tiny
 // launches x ~5 us per layer per forward; a network has 11-12 weights).  Table by value in kernargs.
 #define PREP_MAX 16

@@ -14,6 +14,7 @@ from torch.autograd import Function
 from . import kernels as K
 
 BF16 = torch.bfloat16
+PHASE_UPCONV = True   # NN-upsample+3x3 conv as a phase-decomposed transposed conv (4 instead of 9 taps)
 
 
 def _target(p):
@@ -55,22 +56,28 @@ class _Conv2d(Function):
         assert not (pool_out and (out_tanh or upsample))
         n, h, w, _ = x.shape
         H, Wd = (2 * h, 2 * w) if upsample else (h, w)
-        wf, _ = _prepared(W, k, cin, cout, True, False)
         flags = (K.IN_UPSAMPLE2X if upsample else 0) | (K.IN_RELU if in_relu else 0) | (K.OUT_TANH if out_tanh else 0)
         b = bias.detach() if bias is not None else None
-        if pool_out:
+        # NN-upsample + 3x3: run as the 4 output phases of the equivalent 4x4 stride-2 transposed conv
+        phase = upsample and k == 3 and cin % 64 == 0 and not in_relu and PHASE_UPCONV
+        if phase:
+            wph, _ = getattr(W, "_prep_up", None) or K.upconv3x3_prep(W.detach().view(3, 3, cin, cout))
+            y = K.upconv3x3_fprop(x, wph, b, cout, K.OUT_TANH if out_tanh else 0, residual)
+        elif pool_out:
+            wf, _ = _prepared(W, k, cin, cout, True, False)
             yfull = K.conv2d_fprop(x, wf, b, (H, Wd), cout, k, flags)
             y = K.pool2x2(yfull, 0.25, residual)
         else:
+            wf, _ = _prepared(W, k, cin, cout, True, False)
             y = K.conv2d_fprop(x, wf, b, (H, Wd), cout, k, flags, 1.0, residual)
         ctx.save_for_backward(x, W, y if out_tanh else None)
-        ctx.cfg = (k, cin, cout, H, Wd, upsample, in_relu, pool_out, out_tanh, bias)
+        ctx.cfg = (k, cin, cout, H, Wd, upsample, in_relu, pool_out, out_tanh, bias, phase)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, W, y = ctx.saved_tensors
-        k, cin, cout, H, Wd, upsample, in_relu, pool_out, out_tanh, bias = ctx.cfg
+        k, cin, cout, H, Wd, upsample, in_relu, pool_out, out_tanh, bias, phase = ctx.cfg
         g = _c(dy)
         if out_tanh:
             g = K.tanh_bwd(g, y)
@@ -87,7 +94,10 @@ class _Conv2d(Function):
             dW = None if acc else tgt
         elif btgt is not None:
             K.colsum(g, btgt, 1.0)
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and phase:
+            prep = getattr(W, "_prep_up", None) or K.upconv3x3_prep(W.detach().view(3, 3, cin, cout))
+            dx = K.upconv3x3_dgrad(g, prep[1], cin)       # 4x4 stride-2 conv of dy: no hi-res dgrad, no 2x2 sum
+        elif ctx.needs_input_grad[0]:
             _, wd = _prepared(W, k, cin, cout, False, True)
             dflags = K.IN_UPSAMPLE2X if pool_out else 0
             if upsample:

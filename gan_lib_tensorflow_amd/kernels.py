@@ -105,6 +105,37 @@ def conv2d_wgrad(x, dy, dw, hw, ksize, flags=0, scale=1.0, dbias=None):
     return dw
 
 
+def upconv3x3_prep(w):
+    """w fp32 [3,3,Cin,Cout] -> (wph, wd4) for the phase-decomposed NN-upsample+3x3 conv; cached on the tensor
+    as `w._prep_up` and rewritten IN PLACE on later calls (captured graphs keep reading the same buffers)."""
+    _, _, cin, cout = w.shape
+    old = getattr(w, "_prep_up", None)
+    if old is not None:
+        wph, wd4 = old
+    else:
+        wph = torch.empty((4, _roundup(cout, 32), 4 * cin), dtype=BF16, device=w.device)
+        wd4 = torch.empty((_roundup(cin, 32), _roundup(16 * cout, 64)), dtype=BF16, device=w.device)
+    _lib.check(lib().gank_upconv3x3_prep_weights(_p(w.detach(), F32, "w"), _p(wph), _p(wd4), cin, cout, _stream()), "upconv3x3_prep")
+    w._prep_up = (wph, wd4)
+    return wph, wd4
+
+
+def upconv3x3_fprop(x, wph, bias, cout, flags=0, residual=None):
+    n, hl, wl, cin = x.shape
+    y = torch.empty((n, 2 * hl, 2 * wl, cout), dtype=BF16, device=x.device)
+    _lib.check(lib().gank_upconv3x3_fprop(_p(x, BF16, "x"), _p(wph, BF16), _p(bias, F32, "bias"), _p(residual, BF16, "residual"),
+                                          _p(y), n, hl, wl, cin, cout, flags, _stream()), "upconv3x3_fprop")
+    return y
+
+
+def upconv3x3_dgrad(dy, wd4, cin, relu_ref=None):
+    n, h2, w2, cout = dy.shape
+    dx = torch.empty((n, h2 // 2, w2 // 2, cin), dtype=BF16, device=dy.device)
+    _lib.check(lib().gank_upconv3x3_dgrad(_p(dy, BF16, "dy"), _p(wd4, BF16), _p(relu_ref, BF16, "relu_ref"), _p(dx),
+                                          n, h2 // 2, w2 // 2, cin, cout, _stream()), "upconv3x3_dgrad")
+    return dx
+
+
 def deconv2d_fprop(x, wz, bias, cout, ksize):
     n, h, w, cin = x.shape
     y = torch.empty((n, 2 * h, 2 * w, cout), dtype=BF16, device=x.device)

@@ -86,6 +86,19 @@ long gank_conv2d_wgrad_ws_elems(int N, int H, int W, int Cin, int Cout, int ksiz
 int gank_conv2d_wgrad(const void* x, const void* dy, float* dw, float* dbias, float* ws, long ws_elems, int N, int H,
                       int W, int Cin, int Cout, int ksize, int flags, float scale, void* stream);
 
+/* ---- UpsampleConv 3x3 (SNGAN/gan_cifar_resnet.py:140-153) as a stride-2 transposed conv -------------
+ * nearest-neighbour 2x followed by a 3x3 SAME conv equals a 4x4 stride-2 transposed conv whose taps are sums
+ * of the 3x3 taps.  fprop runs its 4 output phases (2x2 taps each over the LOW-RES input): 4 instead of 9
+ * MACs per output and weight; dgrad is the 4x4 stride-2 conv of dy.  Exact in real arithmetic; the summed
+ * taps are rounded to bf16 once.  prep: w fp32 [3,3,Cin,Cout] -> wph bf16 [4][roundup(Cout,32)][4*Cin] and
+ * wd4 bf16 [roundup(Cin,32)][roundup(16*Cout,64)].  x [N,Hl,Wl,Cin] -> y [N,2Hl,2Wl,Cout]; residual/relu_ref
+ * as in gank_conv2d_fprop/_dgrad.  (The filter gradient keeps gank_conv2d_wgrad with GANK_IN_UPSAMPLE2X.) */
+int gank_upconv3x3_prep_weights(const float* w, void* wph, void* wd4, int Cin, int Cout, void* stream);
+int gank_upconv3x3_fprop(const void* x, const void* wph, const float* bias, const void* residual, void* y,
+                         int N, int Hl, int Wl, int Cin, int Cout, int flags, void* stream);
+int gank_upconv3x3_dgrad(const void* dy, const void* wd4, const void* relu_ref, void* dx, int N, int Hl, int Wl,
+                         int Cin, int Cout, void* stream);
+
 /* ---- Deconv2D (common/ops/deconv2d.py:99-114): tf.nn.conv2d_transpose stride 2 SAME --------------
  * x [N,H,W,Cin] -> y [N,2H,2W,Cout]; master filter F fp32 [k,k,Cout,Cin].  The op has no caller in
  * the reference; it is provided at op level on the same two MFMA engines:

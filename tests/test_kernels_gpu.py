@@ -337,3 +337,25 @@ def test_preprocess_and_rng(K):
     assert np.abs(z - z2).max() > 0.1            # the offset advanced: fresh numbers
     lb = K.rng_labels(4096, 10, st).cpu().numpy()
     assert lb.min() == 0 and lb.max() == 9 and np.bincount(lb).min() > 300
+
+
+@pytest.mark.parametrize("n,hl,cin,cout", [(2, 4, 64, 64), (3, 8, 128, 256), (64, 16, 256, 256), (2, 8, 256, 32)])
+def test_upconv3x3_phase_decomposition(K, n, hl, cin, cout):
+    """NN-upsample + 3x3 SAME conv (gan_cifar_resnet.py:140-153) computed as the 4 output phases of the
+    equivalent 4x4 stride-2 transposed conv, and its input gradient as the 4x4 stride-2 conv of dy."""
+    rng = np.random.default_rng(n + hl + cin)
+    x, xt = bf(rng.normal(size=(n, hl, hl, cin)))
+    w, _ = bf(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin))
+    b, bt = f32(rng.normal(size=cout))
+    res, rest = bf(rng.normal(size=(n, 2 * hl, 2 * hl, cout)))
+    wt = torch.tensor(w, dtype=torch.float32).cuda()
+    wph, wd4 = K.upconv3x3_prep(wt)
+    y = K.upconv3x3_fprop(xt, wph, bt, cout, 0, rest)
+    ref = R.conv2d_same(R.upsample_nn2x(x), w, b) + res
+    torch.cuda.synchronize()
+    assert relerr(y, ref) < BF_TOL
+    dy, dyt = bf(rng.normal(size=(n, 2 * hl, 2 * hl, cout)))
+    dx = K.upconv3x3_dgrad(dyt, wd4, cin)
+    dx_hi, _, _ = R.conv2d_same_grads(R.upsample_nn2x(x), w, dy)
+    torch.cuda.synchronize()
+    assert relerr(dx, R.upsample_nn2x_grad(dx_hi)) < BF_TOL
