@@ -216,7 +216,7 @@ class SNGANTrainer:
         logits, _ = Discriminator(both, both_labels, update_collection=None)
         loss = Fn.hinge_d_loss(logits, b)
         loss.backward()
-        self.d_loss.copy_(loss.detach())
+        K.copy_(self.d_loss, loss.detach())
         return logits
 
     def _d_forward_backward_prefetched(self):
@@ -231,7 +231,7 @@ class SNGANTrainer:
         set_default_store(self.store)
         n = N_CRITIC * self.batch
         fake = Generator(n, self.labels_all.reshape(-1), groups=N_CRITIC * N_TOWERS, rng_state=self.rng_state)
-        self.fake_all.copy_(fake.reshape(N_CRITIC, self.batch, OUTPUT_DIM))
+        K.copy_(self.fake_all, fake)
 
     def _g_forward_backward(self, z=None, fake_labels=None):
         """gen_cost and its gradients (:464-498): N_TOWERS towers of GEN_BS_MULTIPLE*B/N_TOWERS samples,
@@ -252,7 +252,7 @@ class SNGANTrainer:
         finally:
             for p in d_params:
                 p.requires_grad_(True)
-        self.g_loss.copy_(loss.detach())
+        K.copy_(self.g_loss, loss.detach())
         return logits
 
     def _allreduce(self, flat):
@@ -351,9 +351,9 @@ class SNGANTrainer:
             self.labels_all[i].copy_(labels, non_blocking=True)
         self._run_plain('gen5', self._generate_for_critic)
         for i in range(N_CRITIC):
-            self.real_u8.copy_(self.real_all[i])
-            self.real_labels.copy_(self.labels_all[i])
-            self.fake_one.copy_(self.fake_all[i])
+            K.copy_(self.real_u8, self.real_all[i])
+            K.copy_(self.real_labels, self.labels_all[i])
+            K.copy_(self.fake_one, self.fake_all[i])
             self._run('d_pre', self._d_forward_backward_prefetched, self.d_opt, self.d_flat)
         self.iteration += 1
         K.counter_add(self.iteration_dev, 1)

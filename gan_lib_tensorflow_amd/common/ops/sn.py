@@ -31,7 +31,7 @@ def _apply_update(us, batch, update_collection):
     def assign():
         with torch.no_grad():
             for u, un in zip(us, new):
-                u.view(-1).copy_(un)
+                K.copy_(u.view(-1), un)
     if update_collection is None:
         assign()                       # sn.py:55-56: u.assign(u_final) as a control dependency
     else:
@@ -54,7 +54,7 @@ def spectral_normed_weight(W, u=None, num_iters=1, update_collection=None, with_
         warnings.warn('Setting update_collection to None will make u being updated every W execution. '
                       'This maybe undesirable. Please consider using a update collection instead.')
     # u is overwritten before backward runs -> the kernels read a snapshot
-    u_read = u.detach().clone() if update_collection != NO_OPS else u.detach()
+    u_read = K.clone(u.detach()) if update_collection != NO_OPS else u.detach()
     (W_bar,), batch = Fn.spectral_norm_batch([W], [u_read])
     _apply_update([u], batch, update_collection)
     if with_sigma:
@@ -113,18 +113,18 @@ def precomputed(store, prefix, update_collection=None, prepare=True):
     flat = _flat_base(store, prefix, us)
     if update_collection != NO_OPS:
         if flat is not None:                      # one snapshot copy instead of one per weight
-            snap, o, u_read = flat.clone(), 0, []
+            snap, o, u_read = K.clone(flat), 0, []
             for u in us:
                 u_read.append(snap[o:o + u.numel()])
                 o += u.numel()
         else:
-            u_read = [u.detach().clone() for u in us]
+            u_read = [K.clone(u.detach()) for u in us]
     else:
         u_read = [u.detach() for u in us]
     W_bars, batch = Fn.spectral_norm_batch(Ws, u_read)
     if update_collection is None and flat is not None:
         with torch.no_grad():
-            flat.copy_(batch.u_out)               # u <- u_final for all weights: one copy (sn.py:55-56)
+            K.copy_(flat, batch.u_out)            # u <- u_final for all weights: one copy (sn.py:55-56)
     else:
         _apply_update(us, batch, update_collection)
     if prepare:

@@ -212,6 +212,11 @@ __global__ void cbn_bwd_sums_kernel(const bf16* __restrict__ dy, const bf16* __r
   }
 }
 
+__global__ void cbn_zero_kernel(float* __restrict__ p, int n4) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) reinterpret_cast<f32x4*>(p)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 // b2: table gradients and per-tower means.  grid = (C/64, n_labels + 1): block row l < n_labels owns label l
 // (sequential over n: deterministic, no atomics, registers only); the last block row computes the means.
 __global__ void cbn_bwd_tables_kernel(const float* __restrict__ S, const int* __restrict__ labels, const float* __restrict__ gamma,
@@ -294,10 +299,9 @@ extern "C" int gank_cbn_bwd(const void* dy, const void* x, const void* y, const 
   int hw_parts = HW / 64;
   if (hw_parts < 1) hw_parts = 1;
   if (hw_parts > 8) hw_parts = 8;
-  if (hw_parts > 1) {
-    hipError_t e = hipMemsetAsync(S, 0, sizeof(float) * (size_t)N * 2 * C, s);
-    if (e != hipSuccess) return gank_set_error("cbn_bwd: memset: %s", hipGetErrorString(e));
-  }
+  // zeroed by a kernel, not hipMemsetAsync: inside a captured hipGraph the memset node was observed to race with
+  // its kernel neighbours (intermittent NaN generator gradients under graph replay, never in eager mode)
+  if (hw_parts > 1) hipLaunchKernelGGL(cbn_zero_kernel, dim3(cdiv(N * 2 * C / 4, 256)), dim3(256), 0, s, S, N * 2 * C / 4);
   hipLaunchKernelGGL(cbn_bwd_sums_kernel, dim3(N * hw_parts), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (const bf16*)y, stats, S, q, hw_parts);
   hipLaunchKernelGGL(cbn_bwd_tables_kernel, dim3(cdiv(C, 64), n_labels + 1), dim3(64), 0, s, S, labels, gamma, dgamma, dbeta, M, q);
   const long total8 = (long)N * HW * (C / 8);

@@ -417,6 +417,24 @@ extern "C" int gank_scale_f32(const float* x, const float* sc, float* y, long n,
   return 0;
 }
 
+// Device-to-device copy as a KERNEL.  Inside a captured hipGraph the memset/memcpy nodes that hipMemsetAsync /
+// hipMemcpyAsync turn into were observed to lose their ordering against neighbouring kernel nodes (gank_cbn_bwd
+// history), so everything the captured training step moves goes through kernels.
+__global__ void copy_bytes_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, long n16, long nbytes) {
+  const long stride = (long)gridDim.x * blockDim.x, t = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  for (long i = t; i < n16; i += stride) reinterpret_cast<u32x4*>(dst)[i] = reinterpret_cast<const u32x4*>(src)[i];
+  for (long i = n16 * 16 + t; i < nbytes; i += stride) dst[i] = src[i];
+}
+extern "C" int gank_copy_bytes(void* dst, const void* src, long nbytes, void* stream) {
+  GANK_REQUIRE(dst && src && nbytes > 0, "copy_bytes: bad arguments");
+  const bool al = (((uintptr_t)dst | (uintptr_t)src) & 15) == 0;
+  const long n16 = al ? nbytes / 16 : 0;
+  hipLaunchKernelGGL(copy_bytes_kernel, grid1d(al ? n16 + 15 : nbytes), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned char*)src, (unsigned char*)dst, n16, nbytes);
+  GANK_LAUNCH_OK("copy_bytes");
+  return 0;
+}
+
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, long n) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = f2bf(x[i]);
 }

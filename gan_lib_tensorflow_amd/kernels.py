@@ -292,6 +292,18 @@ def tanh_bwd(dy, y):
     return dx
 
 
+def copy_(dst, src):
+    """dst <- src (same dtype and element count, both contiguous) as a kernel launch, never a memcpy node."""
+    assert dst.dtype == src.dtype and dst.numel() == src.numel() and dst.is_contiguous() and src.is_contiguous(), \
+        (dst.dtype, src.dtype, tuple(dst.shape), tuple(src.shape))
+    _lib.check(lib().gank_copy_bytes(_p(dst, None, "dst"), _p(src, None, "src"), dst.numel() * dst.element_size(), _stream()), "copy_bytes")
+    return dst
+
+
+def clone(src):
+    return copy_(torch.empty_like(src), src)
+
+
 def scale_f32(x, s):
     y = torch.empty_like(x)
     _lib.check(lib().gank_scale_f32(_p(x, F32, "x"), _p(s, F32, "s"), _p(y), x.numel(), _stream()), "scale_f32")

@@ -171,6 +171,9 @@ int gank_relu_fwd(const void* x, void* y, long n, float leak, void* stream);    
 int gank_relu_bwd(const void* dy, const void* x, void* dx, long n, float leak, void* stream);
 int gank_tanh_bwd(const void* dy, const void* y, void* dx, long n, void* stream);      /* tf.tanh grad, :261 */
 int gank_scale_f32(const float* x, const float* s, float* y, long n, void* stream);    /* y = x * s[0] */
+/* dst[0:nbytes] = src[0:nbytes], device to device, as a kernel launch (the tf.assign / feed copies of the captured
+ * step: sn.py:55-56 u.assign, gan_cifar_resnet.py:616-620 feeds); 16-byte vectorised when both are 16-B aligned */
+int gank_copy_bytes(void* dst, const void* src, long nbytes, void* stream);
 int gank_cast_f32_bf16(const float* x, void* y, long n, void* stream);
 int gank_cast_bf16_f32(const void* x, float* y, long n, void* stream);
 

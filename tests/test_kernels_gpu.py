@@ -359,3 +359,17 @@ def test_upconv3x3_phase_decomposition(K, n, hl, cin, cout):
     dx_hi, _, _ = R.conv2d_same_grads(R.upsample_nn2x(x), w, dy)
     torch.cuda.synchronize()
     assert relerr(dx, R.upsample_nn2x_grad(dx_hi)) < BF_TOL
+
+
+def test_copy_bytes(K):
+    """Kernel-based device copy (the u.assign / feed copies of the captured step): bit-exact, any size/alignment."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for nbytes, so, do in ((1, 0, 0), (15, 0, 0), (16, 0, 0), (4099, 0, 0), (4099, 3, 0), (4099, 16, 5), (1 << 20, 0, 0), ((1 << 20) + 7, 16, 16)):
+        src = torch.randint(0, 256, (nbytes + 64,), generator=g, dtype=torch.uint8).cuda()
+        dst = torch.full((nbytes + 64,), 7, dtype=torch.uint8, device="cuda")
+        K.copy_(dst[do:do + nbytes], src[so:so + nbytes])
+        torch.cuda.synchronize()
+        assert torch.equal(dst[do:do + nbytes], src[so:so + nbytes])
+        assert bool((dst[:do] == 7).all()) and bool((dst[do + nbytes:] == 7).all())     # nothing outside the range
+    a = torch.randn(1000, generator=g).cuda()
+    assert torch.equal(K.clone(a), a)

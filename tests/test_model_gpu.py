@@ -208,3 +208,30 @@ def test_sampling_path(gpu):
     S, tr, _ = make_trainer(2, 4)
     img = tr.sample(100)
     assert img.shape == (100, 3072) and float(img.abs().max()) <= 1.0
+
+
+def test_graph_replay_stays_finite_with_poisoned_workspaces(gpu, monkeypatch):
+    """Every captured update must fully define what it reads: with every torch.empty buffer pre-filled with NaN,
+    several trainers replaying their hipGraphs keep finite parameters (regression: a hipMemsetAsync memset NODE
+    in the conditional-batch-norm backward lost its ordering under replay and let NaN workspaces through)."""
+    _empty, _empty_like = torch.empty, torch.empty_like
+
+    def empty(*a, **k):
+        t = _empty(*a, **k)
+        return t.fill_(float("nan")) if t.is_floating_point() else t
+
+    def empty_like(*a, **k):
+        t = _empty_like(*a, **k)
+        return t.fill_(float("nan")) if t.is_floating_point() else t
+    monkeypatch.setattr(torch, "empty", empty)
+    monkeypatch.setattr(torch, "empty_like", empty_like)
+    from gan_lib_tensorflow_amd.SNGAN import gan_cifar_resnet as S
+    for seed in range(3):
+        tr = S.SNGANTrainer(batch_size=64, device="cuda", seed=seed, use_graphs=True)
+        feed = S.synthetic_batches(64, tr.device, seed=seed)
+        for _ in range(6):
+            tr.train_iteration(feed)
+        torch.cuda.synchronize()
+        assert tr.use_graphs, "graph capture fell back to eager"
+        for flat in (tr.g_flat, tr.d_flat):
+            assert bool(torch.isfinite(flat["params"]).all()) and bool(torch.isfinite(flat["grads"]).all())
