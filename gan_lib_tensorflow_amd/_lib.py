@@ -38,6 +38,10 @@ PROTOTYPES = {
     "gank_upconv3x3_prep_weights": [P, P, P, I, I, P],
     "gank_upconv3x3_fprop": [P, P, P, P, P, I, I, I, I, I, I, P],
     "gank_upconv3x3_dgrad": [P, P, P, P, I, I, I, I, I, P],
+    "gank_convpool3x3_prep_weights": [P, P, P, I, I, P],
+    "gank_convpool3x3_fprop": [P, P, P, P, P, I, I, I, I, I, I, P],
+    "gank_convpool3x3_dgrad": [P, P, P, P, I, I, I, I, I, P],
+    "gank_convpool3x3_wgrad": [P, P, P, P, P, I, I, I, I, I, I, P],
     "gank_deconv2d_fprop": [P, P, P, P, I, I, I, I, I, I, P],
     "gank_deconv2d_dgrad": [P, P, P, I, I, I, I, I, I, P],
     "gank_deconv2d_wgrad": [P, P, P, I, I, I, I, I, I, P],

@@ -725,6 +725,45 @@ extern "C" int gank_upconv3x3_dgrad(const void* dy, const void* wd4, const void*
   return gank_igemm_dispatch(a, (hipStream_t)stream);
 }
 
+// ---- ConvMeanPool 3x3 (gan_cifar_resnet.py:112-123) as ONE 4x4 stride-2 conv ----------------------------
+// mean_pool(conv3x3(x)) has 16 taps per POOLED pixel = 4 per conv output instead of 9, and no full-resolution
+// intermediate.  Operands from gank_convpool3x3_prep_weights (the 1/4 is folded into them).
+extern "C" int gank_convpool3x3_fprop(const void* x, const void* wp4, const float* bias, const void* residual, void* y,
+                                      int N, int Hp, int Wp, int Cin, int Cout, int flags, void* stream) {
+  IgemmArgs a{};
+  a.x = (const bf16*)x; a.w = (const bf16*)wp4; a.bias = bias; a.res = (const bf16*)residual; a.y = (bf16*)y;
+  a.N = N; a.H = Hp; a.W = Wp; a.Hin = 2 * Hp; a.Win = 2 * Wp;
+  a.Cin = Cin; a.Cout = Cout; a.ks = 4; a.pad = 1;
+  a.flags = IG_IN_STRIDE2 | (flags & GANK_IN_RELU);
+  a.scale = 1.f;
+  return gank_igemm_dispatch(a, (hipStream_t)stream);
+}
+
+// its input gradient: the stride-2 transposed conv, as 4 output phases of 2x2 taps over dy (pooled resolution);
+// relu_ref (optional, [N,2Hp,2Wp,Cin]) masks the result with relu'(x) of the pre-activation input.
+extern "C" int gank_convpool3x3_dgrad(const void* dy, const void* wphd, const void* relu_ref, void* dx, int N, int Hp, int Wp,
+                                      int Cin, int Cout, void* stream) {
+  GANK_REQUIRE(Cout % 64 == 0, "convpool3x3_dgrad: Cout must be a multiple of 64 (got %d)", Cout);
+  IgemmArgs a{};
+  a.x = (const bf16*)dy; a.w = (const bf16*)wphd; a.mask = (const bf16*)relu_ref; a.y = (bf16*)dx;
+  a.N = N; a.H = Hp; a.W = Wp; a.Hin = Hp; a.Win = Wp;
+  a.Cin = Cout; a.Cout = Cin; a.ks = 2; a.pad = 0;
+  a.flags = 0;
+  a.scale = 1.f;
+  hipStream_t s = (hipStream_t)stream;
+  a.taps = 4; a.CoutPad = roundup(Cin, 32); a.Kpad = 4 * Cout; a.nsteps = a.Kpad / 64;
+  a.M = N * Hp * Wp; a.sw = log2_or_neg(Wp); a.shw = log2_or_neg(Hp * Wp);
+  GANK_REQUIRE((long)N * Hp * Wp * Cout < (1L << 30) && (long)a.M * 4 * Cin < (1L << 31), "convpool3x3_dgrad: tensor too large");
+  gank_prof_begin(0, 2.0 * a.M * 4.0 * (double)Cin * 4 * Cout, s);
+  int rc;
+  const long tiles128 = 4L * cdiv(a.M, 128) * (a.CoutPad / 128);
+  if (a.CoutPad % 128 == 0 && tiles128 >= 192) rc = launch_phase<2, 2, 2, 2, 2>(a, s);
+  else if (a.CoutPad % 64 == 0) rc = launch_phase<2, 2, 1, 1, 4>(a, s);
+  else rc = launch_phase<4, 1, 2, 1, 2>(a, s);
+  gank_prof_end(0, s);
+  return rc;
+}
+
 // ---- Deconv2D (common/ops/deconv2d.py:99-114): conv2d_transpose, stride 2, SAME ---------------------
 // fprop = zero-insertion of x + stride-1 conv with the flipped filter (the dgrad operand layout of the
 // filter viewed as HWIO [k,k,Cout,Cin]); dgrad = the stride-2 SAME conv itself.

@@ -295,6 +295,8 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_lean_kernel(WgradArgs 
   static_assert(CHA % NT == 0 && CHB % NT == 0, "tile/threads mismatch");
   constexpr int CPA = CHA / NT, CPB = CHB / NT;
   constexpr bool XRELU = (MODE & 1) != 0, XUP = (MODE & 2) != 0, DYUP = (MODE & 4) != 0;
+  constexpr bool XS2 = (MODE & 8) != 0;   // x is read at (2*oh+dh, 2*ow+dw): stride-2 conv (pooled ConvMeanPool form)
+  static_assert(!(XS2 && (XUP || DYUP)), "stride-2 x excludes the 2x flags");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16* sA = reinterpret_cast<bf16*>(smem);          // [2][SUBA] sub-tiles of [64 pixels][32 ch]
@@ -357,10 +359,14 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_lean_kernel(WgradArgs 
     for (int j = 0; j < CPA; j++) {
       const int m = mbase + a_p[j];
       const int ow = m & Wm, t = m >> sw, oh = t & Hm;
-      const int ih = oh + dh, iw = ow + dw;
-      const bool ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+      const int ih = XS2 ? 2 * oh + dh : oh + dh, iw = XS2 ? 2 * ow + dw : ow + dw;
+      const bool ok = XS2 ? ((unsigned)ih < (unsigned)a.Hx && (unsigned)iw < (unsigned)a.Wx)
+                          : ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W);
       int off;
-      if constexpr (XUP) {
+      if constexpr (XS2) {
+        const int n = m >> shw;
+        off = ((n * a.Hx + ih) * a.Wx + iw) * a.Cin * 2 + a_c[j];
+      } else if constexpr (XUP) {
         const int n = m >> shw;
         off = ((n * a.Hx + (ih >> 1)) * a.Wx + (iw >> 1)) * a.Cin * 2 + a_c[j];
       } else {
@@ -528,8 +534,11 @@ static int launch_wgrad_lean_mode(WgradArgs a, hipStream_t s) {
 
 template <int WA, int WB, int TA, int TB, int PF>
 static int launch_wgrad_lean(const WgradArgs& a, hipStream_t s) {
-  const int mode = ((a.flags & GANK_IN_RELU) ? 1 : 0) | ((a.flags & GANK_IN_UPSAMPLE2X) ? 2 : 0) | ((a.flags & GANK_DY_UPSAMPLE2X) ? 4 : 0);
+  const int mode = ((a.flags & GANK_IN_RELU) ? 1 : 0) | ((a.flags & GANK_IN_UPSAMPLE2X) ? 2 : 0) |
+                   ((a.flags & GANK_DY_UPSAMPLE2X) ? 4 : 0) | ((a.flags & WG_X_STRIDE2) ? 8 : 0);
   switch (mode) {
+    case 8: return launch_wgrad_lean_mode<WA, WB, TA, TB, PF, 8>(a, s);
+    case 9: return launch_wgrad_lean_mode<WA, WB, TA, TB, PF, 9>(a, s);
     case 0: return launch_wgrad_lean_mode<WA, WB, TA, TB, PF, 0>(a, s);
     case 1: return launch_wgrad_lean_mode<WA, WB, TA, TB, PF, 1>(a, s);
     case 2: return launch_wgrad_lean_mode<WA, WB, TA, TB, PF, 2>(a, s);
@@ -1016,7 +1025,7 @@ int gank_wgrad_dispatch(WgradArgs a, hipStream_t s) {
   const bool fast = (a.Cin % 8 == 0) && (a.Cout % 8 == 0);
   gank_prof_begin(1, flops, s);
   int rc = -1;
-  const bool lean = fast && a.sw >= 0 && a.shw >= 0 && !(a.flags & WG_X_STRIDE2) && (a.M % 64 == 0) &&
+  const bool lean = fast && a.sw >= 0 && a.shw >= 0 && (a.M % 64 == 0) &&
                     (long)a.N * a.Hx * a.Wx * a.Cin < (1L << 30) && (long)a.N * a.Hdy * a.Wdy * a.Cout < (1L << 30);
   static int taps_env = -1;   // experiment knob: GANK_WGRAD_TAPS=0 disables the all-taps kernel
   if (taps_env < 0) { const char* e = getenv("GANK_WGRAD_TAPS"); taps_env = e ? atoi(e) : 1; }
@@ -1074,6 +1083,50 @@ extern "C" int gank_conv2d_wgrad(const void* x, const void* dy, float* dw, float
   a.flags = flags & (GANK_IN_UPSAMPLE2X | GANK_IN_RELU | GANK_DY_UPSAMPLE2X);
   a.scale = scale;
   return gank_wgrad_dispatch(a, (hipStream_t)stream);
+}
+
+// ---- ConvMeanPool 3x3 filter gradient ------------------------------------------------------------------
+// dW3[i][j] = 1/4 sum_{s,t in {0,1}} dW4[i+s][j+t], where dW4 is the filter gradient of the equivalent 4x4
+// stride-2 conv over the POOLED pixel grid (16 taps x M/4 pixels instead of 9 taps x M).  ws16: fp32 scratch of
+// 16*Cin*Cout elements (zeroed here, by a kernel).
+__global__ void wgrad_zero_kernel(float* __restrict__ p, long n4) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i < n4) reinterpret_cast<f32x4*>(p)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+__global__ void wgrad_fold4x4_kernel(const float* __restrict__ w4, float* __restrict__ dw, long plane4) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;     // one float4 of the [Cin][Cout] plane
+  if (i >= plane4) return;
+  f32x4 t[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) t[k] = reinterpret_cast<const f32x4*>(w4)[k * plane4 + i];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      const f32x4 v = (t[a * 4 + b] + t[a * 4 + b + 1] + t[(a + 1) * 4 + b] + t[(a + 1) * 4 + b + 1]) * 0.25f;
+      reinterpret_cast<f32x4*>(dw)[(a * 3 + b) * plane4 + i] += v;
+    }
+}
+
+extern "C" int gank_convpool3x3_wgrad(const void* x, const void* dy, float* dw, float* dbias, float* ws16, int N, int Hp, int Wp,
+                                      int Cin, int Cout, int flags, void* stream) {
+  GANK_REQUIRE(x && dy && dw && ws16, "convpool3x3_wgrad: null pointer");
+  GANK_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "convpool3x3_wgrad: channels must be multiples of 4");
+  hipStream_t s = (hipStream_t)stream;
+  const long n4 = 16L * Cin * Cout / 4;
+  hipLaunchKernelGGL(wgrad_zero_kernel, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, s, ws16, n4);
+  WgradArgs a{};
+  a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.dw = ws16; a.dbias = dbias;
+  a.N = N; a.H = Hp; a.W = Wp;
+  a.Hx = 2 * Hp; a.Wx = 2 * Wp; a.Hdy = Hp; a.Wdy = Wp;
+  a.Cin = Cin; a.Cout = Cout; a.ks = 4; a.pad = 1;
+  a.flags = WG_X_STRIDE2 | (flags & GANK_IN_RELU);
+  a.scale = 1.f;
+  if (gank_wgrad_dispatch(a, s)) return 1;
+  const long plane4 = (long)Cin * Cout / 4;
+  hipLaunchKernelGGL(wgrad_fold4x4_kernel, dim3((unsigned)cdiv(plane4, 256)), dim3(256), 0, s, ws16, dw, plane4);
+  GANK_LAUNCH_OK("convpool3x3_wgrad");
+  return 0;
 }
 
 // Deconv2D filter gradient: dF[a,b,co,ci] = sum dy[n,2p+a-pt,2q+b-pl,co] * x[n,p,q,ci]

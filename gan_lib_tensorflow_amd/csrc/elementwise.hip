@@ -75,49 +75,88 @@ __device__ __forceinline__ void up_range_S(int u, int& lo, int& hi) {
   hi = u == 0 ? 2 : (u == 1 ? 2 : (u == 2 ? 1 : 0));
 }
 
-__global__ void prep_upconv_kernel(const float* __restrict__ w, bf16* __restrict__ wph, bf16* __restrict__ wd4,
-                                   int Cin, int Cout, int CoutPad, int CinPad, int Kpad4) {
-  const long nph = 4L * CoutPad * 4 * Cin;
-  const long nd4 = (long)CinPad * Kpad4;
+// One kernel builds both operands.  `ph` = phase matrix [4][CrP pad][4*CkP], `d4` = combined 4x4 matrix
+// [CrD pad][roundup(16*CkD,64)]; (sr, sk) are the strides of the row / inner channel in w's [ci][co] plane, so the
+// same code serves UpsampleConv (ph rows = co, d4 rows = ci) and ConvMeanPool (ph rows = ci, d4 rows = co, the
+// 3x3 taps flipped, everything scaled by 1/4 -- see gank_convpool3x3_prep_weights).
+struct PrepUpArgs {
+  const float* w;
+  bf16* ph;
+  bf16* d4;
+  int CrP, CkP, srP, skP, CrPpad;
+  int CrD, CkD, srD, skD, CrDpad, Kpad4;
+  int flip, plane;     // plane = Cin*Cout (stride of one 3x3 tap)
+  float scale;
+};
+
+__global__ void prep_upconv_kernel(PrepUpArgs q) {
+  const long nph = 4L * q.CrPpad * 4 * q.CkP;
+  const long nd4 = (long)q.CrDpad * q.Kpad4;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < nph + nd4; idx += (long)gridDim.x * blockDim.x) {
     if (idx < nph) {
-      const int k = (int)(idx % (4 * Cin));
-      long t = idx / (4 * Cin);
-      const int co = (int)(t % CoutPad), p = (int)(t / CoutPad);
-      const int tap = k / Cin, ci = k - tap * Cin;
+      const int k = (int)(idx % (4 * q.CkP));
+      long t = idx / (4 * q.CkP);
+      const int r = (int)(t % q.CrPpad), p = (int)(t / q.CrPpad);
+      const int tap = k / q.CkP, c = k - tap * q.CkP;
       float v = 0.f;
-      if (co < Cout) {
+      if (r < q.CrP) {
         int h0, h1, w0, w1;
         up_range_R(p >> 1, tap >> 1, h0, h1);
         up_range_R(p & 1, tap & 1, w0, w1);
         for (int dh = h0; dh <= h1; dh++)
-          for (int dw = w0; dw <= w1; dw++) v += w[((long)(dh * 3 + dw) * Cin + ci) * Cout + co];
+          for (int dw = w0; dw <= w1; dw++) {
+            const int t3 = q.flip ? (2 - dh) * 3 + (2 - dw) : dh * 3 + dw;
+            v += q.w[(long)t3 * q.plane + (long)r * q.srP + (long)c * q.skP];
+          }
       }
-      wph[idx] = f2bf(v);
+      q.ph[idx] = f2bf(v * q.scale);
     } else {
       const long i2 = idx - nph;
-      const int ci = (int)(i2 / Kpad4), k = (int)(i2 - (long)ci * Kpad4);
+      const int r = (int)(i2 / q.Kpad4), k = (int)(i2 - (long)r * q.Kpad4);
       float v = 0.f;
-      if (ci < Cin && k < 16 * Cout) {
-        const int tap = k / Cout, co = k - tap * Cout;
+      if (r < q.CrD && k < 16 * q.CkD) {
+        const int tap = k / q.CkD, c = k - tap * q.CkD;
         int h0, h1, w0, w1;
         up_range_S(tap >> 2, h0, h1);
         up_range_S(tap & 3, w0, w1);
         for (int dh = h0; dh <= h1; dh++)
-          for (int dw = w0; dw <= w1; dw++) v += w[((long)(dh * 3 + dw) * Cin + ci) * Cout + co];
+          for (int dw = w0; dw <= w1; dw++) {
+            const int t3 = q.flip ? (2 - dh) * 3 + (2 - dw) : dh * 3 + dw;
+            v += q.w[(long)t3 * q.plane + (long)r * q.srD + (long)c * q.skD];
+          }
       }
-      wd4[i2] = f2bf(v);
+      q.d4[i2] = f2bf(v * q.scale);
     }
   }
 }
 
 extern "C" int gank_upconv3x3_prep_weights(const float* w, void* wph, void* wd4, int Cin, int Cout, void* stream) {
   GANK_REQUIRE(w && wph && wd4 && Cin > 0 && Cout > 0, "upconv3x3_prep_weights: bad arguments");
-  const int CoutPad = roundup(Cout, 32), CinPad = roundup(Cin, 32), Kpad4 = roundup(16 * Cout, 64);
-  const long total = 4L * CoutPad * 4 * Cin + (long)CinPad * Kpad4;
-  hipLaunchKernelGGL(prep_upconv_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, w, (bf16*)wph, (bf16*)wd4,
-                     Cin, Cout, CoutPad, CinPad, Kpad4);
+  PrepUpArgs q{};
+  q.w = w; q.ph = (bf16*)wph; q.d4 = (bf16*)wd4;
+  q.CrP = Cout; q.CkP = Cin; q.srP = 1; q.skP = Cout; q.CrPpad = roundup(Cout, 32);
+  q.CrD = Cin; q.CkD = Cout; q.srD = Cout; q.skD = 1; q.CrDpad = roundup(Cin, 32); q.Kpad4 = roundup(16 * Cout, 64);
+  q.flip = 0; q.plane = Cin * Cout; q.scale = 1.f;
+  const long total = 4L * q.CrPpad * 4 * q.CkP + (long)q.CrDpad * q.Kpad4;
+  hipLaunchKernelGGL(prep_upconv_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, q);
   GANK_LAUNCH_OK("prep_upconv");
+  return 0;
+}
+
+// ConvMeanPool 3x3 (gan_cifar_resnet.py:112-123): mean_pool2x2(conv3x3_SAME(x)) == 4x4 stride-2 conv (pad 1) with
+//   W4[a][b] = 1/4 sum_{i in I(a)} sum_{j in I(b)} W3[i][j],   I(0)={0} I(1)={0,1} I(2)={1,2} I(3)={2}
+// wp4 [roundup(Cout,32)][roundup(16*Cin,64)] is its fprop operand; wphd [4][roundup(Cin,32)][4*Cout] holds the 4
+// output phases of the transposed conv that is its input gradient (2x2 taps of dy per high-res pixel).
+extern "C" int gank_convpool3x3_prep_weights(const float* w, void* wp4, void* wphd, int Cin, int Cout, void* stream) {
+  GANK_REQUIRE(w && wp4 && wphd && Cin > 0 && Cout > 0, "convpool3x3_prep_weights: bad arguments");
+  PrepUpArgs q{};
+  q.w = w; q.ph = (bf16*)wphd; q.d4 = (bf16*)wp4;
+  q.CrP = Cin; q.CkP = Cout; q.srP = Cout; q.skP = 1; q.CrPpad = roundup(Cin, 32);
+  q.CrD = Cout; q.CkD = Cin; q.srD = 1; q.skD = Cout; q.CrDpad = roundup(Cout, 32); q.Kpad4 = roundup(16 * Cin, 64);
+  q.flip = 1; q.plane = Cin * Cout; q.scale = 0.25f;
+  const long total = 4L * q.CrPpad * 4 * q.CkP + (long)q.CrDpad * q.Kpad4;
+  hipLaunchKernelGGL(prep_upconv_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, q);
+  GANK_LAUNCH_OK("prep_convpool");
   return 0;
 }
 

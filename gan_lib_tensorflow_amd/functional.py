@@ -14,6 +14,7 @@ from torch.autograd import Function
 from . import kernels as K
 
 BF16 = torch.bfloat16
+POOL_CONV4 = True     # 3x3 conv + 2x2 mean pool as one 4x4 stride-2 conv (4 instead of 9 taps per conv output)
 PHASE_UPCONV = True   # NN-upsample+3x3 conv as a phase-decomposed transposed conv (4 instead of 9 taps)
 
 
@@ -60,9 +61,14 @@ class _Conv2d(Function):
         b = bias.detach() if bias is not None else None
         # NN-upsample + 3x3: run as the 4 output phases of the equivalent 4x4 stride-2 transposed conv
         phase = upsample and k == 3 and cin % 64 == 0 and not in_relu and PHASE_UPCONV
+        # 3x3 conv + 2x2 mean pool: run as ONE 4x4 stride-2 conv (16 taps per pooled pixel = 4 per conv output)
+        pool4 = pool_out and k == 3 and cin % 64 == 0 and cout % 64 == 0 and POOL_CONV4
         if phase:
             wph, _ = getattr(W, "_prep_up", None) or K.upconv3x3_prep(W.detach().view(3, 3, cin, cout))
             y = K.upconv3x3_fprop(x, wph, b, cout, K.OUT_TANH if out_tanh else 0, residual)
+        elif pool4:
+            wp4, _ = getattr(W, "_prep_pool", None) or K.convpool3x3_prep(W.detach().view(3, 3, cin, cout))
+            y = K.convpool3x3_fprop(x, wp4, b, cout, K.IN_RELU if in_relu else 0, residual)
         elif pool_out:
             wf, _ = _prepared(W, k, cin, cout, True, False)
             yfull = K.conv2d_fprop(x, wf, b, (H, Wd), cout, k, flags)
@@ -71,13 +77,13 @@ class _Conv2d(Function):
             wf, _ = _prepared(W, k, cin, cout, True, False)
             y = K.conv2d_fprop(x, wf, b, (H, Wd), cout, k, flags, 1.0, residual)
         ctx.save_for_backward(x, W, y if out_tanh else None)
-        ctx.cfg = (k, cin, cout, H, Wd, upsample, in_relu, pool_out, out_tanh, bias, phase)
+        ctx.cfg = (k, cin, cout, H, Wd, upsample, in_relu, pool_out, out_tanh, bias, phase, pool4)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, W, y = ctx.saved_tensors
-        k, cin, cout, H, Wd, upsample, in_relu, pool_out, out_tanh, bias, phase = ctx.cfg
+        k, cin, cout, H, Wd, upsample, in_relu, pool_out, out_tanh, bias, phase, pool4 = ctx.cfg
         g = _c(dy)
         if out_tanh:
             g = K.tanh_bwd(g, y)
@@ -87,7 +93,11 @@ class _Conv2d(Function):
         if bias is not None and ctx.needs_input_grad[2]:
             btgt, bacc = _target(bias)
             db = None if bacc else btgt
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and pool4:
+            tgt, acc = _target(W)
+            K.convpool3x3_wgrad(x, g, tgt.view(3, 3, cin, cout), K.IN_RELU if in_relu else 0, dbias=btgt)
+            dW = None if acc else tgt
+        elif ctx.needs_input_grad[1]:
             tgt, acc = _target(W)
             wflags = (K.IN_UPSAMPLE2X if upsample else 0) | (K.IN_RELU if in_relu else 0) | (K.DY_UPSAMPLE2X if pool_out else 0)
             K.conv2d_wgrad(x, g, tgt, (H, Wd), k, wflags, scale, dbias=btgt)   # bias gradient rides on the dy stream
@@ -97,6 +107,9 @@ class _Conv2d(Function):
         if ctx.needs_input_grad[0] and phase:
             prep = getattr(W, "_prep_up", None) or K.upconv3x3_prep(W.detach().view(3, 3, cin, cout))
             dx = K.upconv3x3_dgrad(g, prep[1], cin)       # 4x4 stride-2 conv of dy: no hi-res dgrad, no 2x2 sum
+        elif ctx.needs_input_grad[0] and pool4:
+            prep = getattr(W, "_prep_pool", None) or K.convpool3x3_prep(W.detach().view(3, 3, cin, cout))
+            dx = K.convpool3x3_dgrad(g, prep[1], cin, x if in_relu else None)
         elif ctx.needs_input_grad[0]:
             _, wd = _prepared(W, k, cin, cout, False, True)
             dflags = K.IN_UPSAMPLE2X if pool_out else 0

@@ -136,6 +136,48 @@ def upconv3x3_dgrad(dy, wd4, cin, relu_ref=None):
     return dx
 
 
+def convpool3x3_prep(w):
+    """w fp32 [3,3,Cin,Cout] -> (wp4, wphd): operands of ConvMeanPool 3x3 run as one 4x4 stride-2 conv; cached on the
+    tensor as `w._prep_pool` and rewritten IN PLACE on later calls."""
+    _, _, cin, cout = w.shape
+    old = getattr(w, "_prep_pool", None)
+    if old is not None:
+        wp4, wphd = old
+    else:
+        wp4 = torch.empty((_roundup(cout, 32), _roundup(16 * cin, 64)), dtype=BF16, device=w.device)
+        wphd = torch.empty((4, _roundup(cin, 32), 4 * cout), dtype=BF16, device=w.device)
+    _lib.check(lib().gank_convpool3x3_prep_weights(_p(w.detach(), F32, "w"), _p(wp4), _p(wphd), cin, cout, _stream()), "convpool3x3_prep")
+    w._prep_pool = (wp4, wphd)
+    return wp4, wphd
+
+
+def convpool3x3_fprop(x, wp4, bias, cout, flags=0, residual=None):
+    n, h, w, cin = x.shape
+    y = torch.empty((n, h // 2, w // 2, cout), dtype=BF16, device=x.device)
+    _lib.check(lib().gank_convpool3x3_fprop(_p(x, BF16, "x"), _p(wp4, BF16), _p(bias, F32, "bias"), _p(residual, BF16, "residual"),
+                                            _p(y), n, h // 2, w // 2, cin, cout, flags, _stream()), "convpool3x3_fprop")
+    return y
+
+
+def convpool3x3_dgrad(dy, wphd, cin, relu_ref=None):
+    n, hp, wp, cout = dy.shape
+    dx = torch.empty((n, 2 * hp, 2 * wp, cin), dtype=BF16, device=dy.device)
+    _lib.check(lib().gank_convpool3x3_dgrad(_p(dy, BF16, "dy"), _p(wphd, BF16), _p(relu_ref, BF16, "relu_ref"), _p(dx),
+                                            n, hp, wp, cin, cout, _stream()), "convpool3x3_dgrad")
+    return dx
+
+
+def convpool3x3_wgrad(x, dy, dw, flags=0, dbias=None):
+    """ACCUMULATES the ConvMeanPool 3x3 filter gradient into dw fp32 [3,3,Cin,Cout] (and dbias)."""
+    n, hp, wp, cout = dy.shape
+    cin = x.shape[3]
+    assert x.shape[1] == 2 * hp and x.shape[2] == 2 * wp and dw.numel() == 9 * cin * cout, (x.shape, dy.shape, dw.shape)
+    ws16 = torch.empty(16 * cin * cout, dtype=F32, device=x.device)
+    _lib.check(lib().gank_convpool3x3_wgrad(_p(x, BF16, "x"), _p(dy, BF16, "dy"), _p(dw, F32, "dw"), _p(dbias, F32, "dbias"),
+                                            _p(ws16), n, hp, wp, cin, cout, flags, _stream()), "convpool3x3_wgrad")
+    return dw
+
+
 def deconv2d_fprop(x, wz, bias, cout, ksize):
     n, h, w, cin = x.shape
     y = torch.empty((n, 2 * h, 2 * w, cout), dtype=BF16, device=x.device)

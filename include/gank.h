@@ -99,6 +99,26 @@ int gank_upconv3x3_fprop(const void* x, const void* wph, const float* bias, cons
 int gank_upconv3x3_dgrad(const void* dy, const void* wd4, const void* relu_ref, void* dx, int N, int Hl, int Wl,
                          int Cin, int Cout, void* stream);
 
+/* ---- ConvMeanPool 3x3 (SNGAN/gan_cifar_resnet.py:112-123; common/resnet_block.py:53-65) as a 4x4 stride-2 conv ---
+ * mean_pool2x2(conv3x3_SAME(x) + b) == conv4x4_stride2_pad1(x, W4) + b with
+ *   W4[a][b] = 1/4 sum_{i in I(a), j in I(b)} W3[i][j],  I(0)={0} I(1)={0,1} I(2)={1,2} I(3)={2}:
+ * 16 taps per POOLED pixel (= 4 per conv output instead of 9) and no full-resolution intermediate.  Exact in real
+ * arithmetic; the summed taps are rounded to bf16 once.
+ *   prep : w fp32 [3,3,Cin,Cout] -> wp4 bf16 [roundup(Cout,32)][roundup(16*Cin,64)]   (fprop operand)
+ *                                   wphd bf16 [4][roundup(Cin,32)][4*Cout]             (dgrad operand, 4 phases)
+ *   fprop: x [N,2Hp,2Wp,Cin] -> y [N,Hp,Wp,Cout]; flags: GANK_IN_RELU; bias/residual (pooled resolution) optional
+ *   dgrad: dy [N,Hp,Wp,Cout] -> dx [N,2Hp,2Wp,Cin] (stride-2 transposed conv as 4 phases of 2x2 taps);
+ *          relu_ref (optional, like dx) masks the result with relu_ref > 0.  Needs Cout % 64 == 0.
+ *   wgrad: dw fp32 [3,3,Cin,Cout] += fold(dW4), dbias (optional) += column sums of dy; ws16 = fp32 scratch of
+ *          16*Cin*Cout elements; flags: GANK_IN_RELU (relu applied to x while staging). */
+int gank_convpool3x3_prep_weights(const float* w, void* wp4, void* wphd, int Cin, int Cout, void* stream);
+int gank_convpool3x3_fprop(const void* x, const void* wp4, const float* bias, const void* residual, void* y,
+                           int N, int Hp, int Wp, int Cin, int Cout, int flags, void* stream);
+int gank_convpool3x3_dgrad(const void* dy, const void* wphd, const void* relu_ref, void* dx, int N, int Hp, int Wp,
+                           int Cin, int Cout, void* stream);
+int gank_convpool3x3_wgrad(const void* x, const void* dy, float* dw, float* dbias, float* ws16, int N, int Hp, int Wp,
+                           int Cin, int Cout, int flags, void* stream);
+
 /* ---- Deconv2D (common/ops/deconv2d.py:99-114): tf.nn.conv2d_transpose stride 2 SAME --------------
  * x [N,H,W,Cin] -> y [N,2H,2W,Cout]; master filter F fp32 [k,k,Cout,Cin].  The op has no caller in
  * the reference; it is provided at op level on the same two MFMA engines:

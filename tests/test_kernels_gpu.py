@@ -373,3 +373,36 @@ def test_copy_bytes(K):
         assert bool((dst[:do] == 7).all()) and bool((dst[do + nbytes:] == 7).all())     # nothing outside the range
     a = torch.randn(1000, generator=g).cuda()
     assert torch.equal(K.clone(a), a)
+
+
+@pytest.mark.parametrize("n,hp,cin,cout,relu", [(2, 4, 64, 64, False), (3, 8, 128, 128, True), (128, 16, 128, 128, True),
+                                                (16, 8, 256, 128, True), (2, 4, 128, 64, False)])
+def test_convpool3x3_as_stride2_conv(K, n, hp, cin, cout, relu):
+    """ConvMeanPool 3x3 (gan_cifar_resnet.py:112-123): mean_pool(conv3x3(relu?(x)) + b) + residual run as ONE 4x4
+    stride-2 conv; its input gradient as the 4-phase transposed conv, its filter gradient folded from 16 taps."""
+    rng = np.random.default_rng(n * 7 + hp + cin)
+    x, xt = bf(rng.normal(size=(n, 2 * hp, 2 * hp, cin)))
+    w, _ = bf(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin))
+    b, bt = f32(rng.normal(size=cout))
+    res, rest = bf(rng.normal(size=(n, hp, hp, cout)))
+    wt = torch.tensor(w, dtype=torch.float32).cuda()
+    wp4, wphd = K.convpool3x3_prep(wt)
+    xin = R.relu(x) if relu else x
+    y = K.convpool3x3_fprop(xt, wp4, bt, cout, K.IN_RELU if relu else 0, rest)
+    ref = R.meanpool2x2(R.conv2d_same(xin, w, b)) + res
+    torch.cuda.synchronize()
+    assert relerr(y, ref) < BF_TOL
+    dy, dyt = bf(rng.normal(size=(n, hp, hp, cout)))
+    dx_ref, dw_ref, db_ref = R.conv2d_same_grads(xin, w, R.meanpool2x2_grad(dy))
+    if relu:
+        dx_ref = dx_ref * (x > 0)
+    dx = K.convpool3x3_dgrad(dyt, wphd, cin, xt if relu else None)
+    torch.cuda.synchronize()
+    assert relerr(dx, dx_ref) < BF_TOL
+    dw = torch.zeros((3, 3, cin, cout), dtype=torch.float32, device="cuda")
+    dw += 1.0                                  # accumulates on top of existing content
+    db = torch.zeros(cout, dtype=torch.float32, device="cuda")
+    K.convpool3x3_wgrad(xt, dyt, dw, K.IN_RELU if relu else 0, dbias=db)
+    torch.cuda.synchronize()
+    assert relerr(dw - 1.0, dw_ref) < F32_FROM_BF_TOL
+    assert relerr(db, dy.sum((0, 1, 2))) < F32_FROM_BF_TOL
