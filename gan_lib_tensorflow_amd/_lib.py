@@ -58,6 +58,8 @@ PROTOTYPES = {
     "gank_relu_bwd": [P, P, P, L, F, P],
     "gank_tanh_bwd": [P, P, P, L, P],
     "gank_scale_f32": [P, P, P, L, P],
+    "gank_linear_fwd": [P, P, P, P, I, I, I, P],
+    "gank_linear_bwd": [P, P, P, P, P, P, I, I, I, P],
     "gank_copy_bytes": [P, P, L, P],
     "gank_cast_f32_bf16": [P, P, L, P],
     "gank_cast_bf16_f32": [P, P, L, P],

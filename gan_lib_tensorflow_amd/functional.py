@@ -128,9 +128,41 @@ def conv2d(x, W, bias=None, residual=None, upsample=False, in_relu=False, pool_o
     return _Conv2d.apply(x, W, bias, residual, upsample, in_relu, pool_out, out_tanh)
 
 
+class _LinearSmall(Function):
+    """Latency-sized dense layer straight on the fp32 weight (no MFMA operand preparation)."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias):
+        ctx.save_for_backward(x, W)
+        ctx.bias = bias
+        return K.linear_fwd(x, W.detach(), bias.detach() if bias is not None else None)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        bias = ctx.bias
+        g = _c(dy)
+        dW = db = None
+        wt = bt = None
+        if ctx.needs_input_grad[1]:
+            wt, acc = _target(W)
+            dW = None if acc else wt
+        if bias is not None and ctx.needs_input_grad[2]:
+            bt, bacc = _target(bias)
+            db = None if bacc else bt
+        dx = K.linear_bwd(g, x, W.detach(), ctx.needs_input_grad[0], wt, bt)
+        return dx, dW, db
+
+
+SMALL_LINEAR_MACS = 1 << 24   # below this many multiply-adds a dense layer is a launch-latency problem
+
+
 def linear(x, W, bias=None):
-    """x [n, Cin] bf16, W fp32 [Cin, Cout]: the 1x1 case of the conv engine."""
+    """x [n, Cin] bf16, W fp32 [Cin, Cout]: small layers on dedicated kernels, large ones as the 1x1 case of the
+    conv engine."""
     n = x.shape[0]
+    if n * W.shape[0] * W.shape[1] <= SMALL_LINEAR_MACS:
+        return _LinearSmall.apply(_c(x), W, bias)
     return _Conv2d.apply(x.view(n, 1, 1, x.shape[1]), W, bias, None, False, False, False, False).view(n, W.shape[1])
 
 

@@ -202,6 +202,26 @@ def deconv2d_wgrad(x, dy, df, ksize):
     return df
 
 
+def linear_fwd(x, w, bias=None):
+    """y = x w + bias on the fp32 master weight (small layers): x bf16 [M,K], w fp32 [K,C] -> y bf16 [M,C]"""
+    m, k = x.shape
+    c = w.shape[1]
+    assert w.shape[0] == k, (x.shape, w.shape)
+    y = torch.empty((m, c), dtype=BF16, device=x.device)
+    _lib.check(lib().gank_linear_fwd(_p(x, BF16, "x"), _p(w, F32, "w"), _p(bias, F32, "bias"), _p(y), m, k, c, _stream()), "linear_fwd")
+    return y
+
+
+def linear_bwd(dy, x, w, want_dx=True, dw=None, dbias=None):
+    """dx = dy w^T (returned when want_dx); dw += x^T dy; dbias += colsum(dy)"""
+    m, c = dy.shape
+    k = w.shape[0] if w is not None else (x.shape[1] if x is not None else 1)
+    dx = torch.empty((m, k), dtype=BF16, device=dy.device) if want_dx else None
+    _lib.check(lib().gank_linear_bwd(_p(dy, BF16, "dy"), _p(x, BF16, "x"), _p(w, F32, "w"), _p(dx), _p(dw, F32, "dw"),
+                                     _p(dbias, F32, "dbias"), m, k, c, _stream()), "linear_bwd")
+    return dx
+
+
 def colsum(x2d, out, scale=1.0):
     """out[c] += scale * sum_r x[r,c];  x bf16 [rows,C] (any leading dims flattened), out fp32 [C]"""
     c = x2d.shape[-1]

@@ -197,6 +197,15 @@ int gank_copy_bytes(void* dst, const void* src, long nbytes, void* stream);
 int gank_cast_f32_bf16(const float* x, void* y, long n, void* stream);
 int gank_cast_bf16_f32(const void* x, float* y, long n, void* stream);
 
+/* ---- small dense layers (common/ops/linear.py:161-180: tf.matmul + tf.nn.bias_add) on the fp32 master weights ----
+ * y[M,C] = x[M,K] w[K,C] + bias;  x, y, dy, dx bf16; w, dw, dbias fp32, no operand preparation.  For the critic's
+ * D.Embedding_y (300->128) and D.Output (128->1) (gan_cifar_resnet.py:296-304), which are launch-latency problems;
+ * large layers (G.Input 128->16384) use gank_conv2d_* with ksize 1.  bwd: dx (optional) = dy w^T; dw (optional)
+ * += x^T dy; dbias (optional) += column sums of dy. */
+int gank_linear_fwd(const void* x, const float* w, const float* bias, void* y, int M, int K, int C, void* stream);
+int gank_linear_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, float* dbias, int M, int K, int C,
+                    void* stream);
+
 /* relu + tf.reduce_mean(axis=[1,2])  (gan_cifar_resnet.py:299-301): x [N,HW,C] -> y [N,C] */
 int gank_relu_meanpool_hw_fwd(const void* x, void* y, int N, int HW, int C, void* stream);
 int gank_relu_meanpool_hw_bwd(const void* dy, const void* x, void* dx, int N, int HW, int C, void* stream);

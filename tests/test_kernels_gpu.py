@@ -406,3 +406,28 @@ def test_convpool3x3_as_stride2_conv(K, n, hp, cin, cout, relu):
     torch.cuda.synchronize()
     assert relerr(dw - 1.0, dw_ref) < F32_FROM_BF_TOL
     assert relerr(db, dy.sum((0, 1, 2))) < F32_FROM_BF_TOL
+
+
+@pytest.mark.parametrize("m,k,c", [(128, 300, 128), (128, 128, 1), (5, 7, 3), (64, 128, 10), (33, 65, 130)])
+def test_linear_small(K, m, k, c):
+    """tf.matmul + bias_add on the fp32 weight (linear.py:161-180) and its three gradients."""
+    rng = np.random.default_rng(m + k + c)
+    x, xt = bf(rng.normal(size=(m, k)))
+    w, wt = f32(rng.normal(size=(k, c)) / np.sqrt(k))
+    b, bt = f32(rng.normal(size=c))
+    y = K.linear_fwd(xt, wt, bt)
+    torch.cuda.synchronize()
+    assert relerr(y, R.linear(x, w, b)) < BF_TOL
+    dy, dyt = bf(rng.normal(size=(m, c)))
+    dw = torch.full((k, c), 0.5, dtype=torch.float32, device="cuda")
+    db = torch.full((c,), -1.0, dtype=torch.float32, device="cuda")
+    dx = K.linear_bwd(dyt, xt, wt, True, dw, db)
+    dx_ref, dw_ref = R.linear_grads(x, w, dy)[:2]
+    torch.cuda.synchronize()
+    assert relerr(dx, dx_ref) < BF_TOL
+    assert relerr(dw - 0.5, dw_ref) < 1e-5
+    assert relerr(db + 1.0, dy.sum(0)) < 1e-5
+    db2 = torch.zeros(c, dtype=torch.float32, device="cuda")
+    assert K.linear_bwd(dyt, None, None, False, None, db2) is None        # bias gradient alone
+    torch.cuda.synchronize()
+    assert relerr(db2, dy.sum(0)) < 1e-5
