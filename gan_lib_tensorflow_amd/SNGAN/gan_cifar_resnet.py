@@ -78,12 +78,27 @@ def Generator(n_samples_, labels, noise=None, reuse=False, groups=1, rng_state=N
         return output.reshape(-1, OUTPUT_DIM)
 
 
+def _d_prep_kind(name, W):
+    """MFMA operand layout per critic weight (kernels.prep_weights_batched): the two ConvMeanPool 3x3 layers run as
+    4x4 stride-2 convs, the two small dense layers read their fp32 weight directly."""
+    if W.dim() == 2 and W.numel() <= 65536:
+        return None
+    if Fn.POOL_CONV4 and name.endswith(('D.Block.1.Conv2/Filters', 'D.Block.2.Conv2/Filters')):
+        return 2
+    return 0
+
+
+def _g_prep_kind(name, W):
+    """the three UpsampleConv 3x3 layers run phase-decomposed"""
+    return 1 if (Fn.PHASE_UPCONV and name.endswith('.Conv1/Filters') and W.dim() == 4 and W.shape[0] == 3) else 0
+
+
 def Discriminator(inputs, labels, update_collection=None, reuse=False):
     """(:266-313, ACGAN=False)  inputs [n,3072] bf16 (HWC order) -> (logits [n], None)."""
     store = get_default_store()
     with store.variable_scope("Discriminator", reuse=reuse):
         prefix = store.full_name('')[:-1]
-        with _sn.precomputed(store, prefix, update_collection):       # one batched SN for all 12 weights
+        with _sn.precomputed(store, prefix, update_collection, prep_kind=_d_prep_kind):   # one batched SN for all 12 weights
             output = inputs.reshape(-1, 32, 32, 3)
             output = OptimizedResBlockDisc1(output, spectral_normed=True, update_collection=update_collection, biases=True)
             embedding_y = _embedding.embed_y(labels, VOCAB_SIZE, EMBEDDING_DIM)
@@ -166,7 +181,7 @@ class SNGANTrainer:
         self.store.flatten_state('Discriminator')      # the 12 SN u vectors: one buffer
         # bf16 MFMA operand copies of the generator weights: rebuilt by ONE launch after each G update
         # (the generator runs 6 forwards per iteration on unchanged weights)
-        self._g_convs = [v for k, v in self.store.vars.items()
+        self._g_convs = [(k, v) for k, v in self.store.vars.items()
                          if k.startswith('Generator/') and (k.endswith('/Filters') or k.endswith('/W'))]
         self._refresh_g_prep()
         self.iteration_dev = torch.zeros(1, dtype=torch.int64, device=self.device)   # `_iteration` feed (:320)
@@ -184,10 +199,7 @@ class SNGANTrainer:
         self.g_loss = torch.zeros(1, dtype=torch.float32, device=self.device)
 
     def _refresh_g_prep(self):
-        K.prep_weights_batched(self._g_convs, want_d=True)
-        for k, v in self.store.vars.items():       # the three UpsampleConv 3x3 layers: phase operands
-            if k.startswith('Generator/') and k.endswith('.Conv1/Filters') and v.shape[0] == 3:
-                K.upconv3x3_prep(v)
+        K.prep_weights_batched([v for _, v in self._g_convs], want_d=True, kinds=[_g_prep_kind(k, v) for k, v in self._g_convs])
 
     def load_state_dict(self, state, strict=True):
         """Restore variables by name; cached operand copies and captured graphs are rebuilt."""

@@ -22,7 +22,7 @@ class SnDesc(C.Structure):
 
 class PrepDesc(C.Structure):
     """gank_prep_desc"""
-    _fields_ = [("w", P), ("wf", P), ("wd", P), ("ksize", I), ("Cin", I), ("Cout", I), ("_pad", I)]
+    _fields_ = [("w", P), ("wf", P), ("wd", P), ("ksize", I), ("Cin", I), ("Cout", I), ("kind", I)]
 
 
 # name -> argument ctypes (all return int unless listed in _RET)

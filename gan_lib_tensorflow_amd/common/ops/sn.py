@@ -72,16 +72,19 @@ def _trunc_normal(rng, size):
     return out.astype('float32')
 
 
-def sn_pairs(store, prefix):
+def sn_pairs(store, prefix, with_names=False):
     """[(W, u)] for every spectrally normalised variable under `prefix`, by the reference's names:
     conv `X/filters/spectral_norm/u` <-> `X/Filters` (conv2d.py:142,170), linear
     `X/spectral_norm/u` <-> `X/W` (linear.py:140,162-164)."""
     pairs = []
     for name in store.names(prefix):
         if name.endswith('/filters/spectral_norm/u'):
-            pairs.append((store.vars[name[:-len('/filters/spectral_norm/u')] + '/Filters'], store.vars[name]))
+            wname = name[:-len('/filters/spectral_norm/u')] + '/Filters'
         elif name.endswith('/spectral_norm/u'):
-            pairs.append((store.vars[name[:-len('/spectral_norm/u')] + '/W'], store.vars[name]))
+            wname = name[:-len('/spectral_norm/u')] + '/W'
+        else:
+            continue
+        pairs.append((store.vars[wname], store.vars[name], wname) if with_names else (store.vars[wname], store.vars[name]))
     return pairs
 
 
@@ -99,17 +102,18 @@ def _flat_base(store, prefix, us):
 
 
 @contextlib.contextmanager
-def precomputed(store, prefix, update_collection=None, prepare=True):
+def precomputed(store, prefix, update_collection=None, prepare=True, prep_kind=None):
     """Normalise every SN weight under `prefix` in ONE batched launch group; inside the block
     `spectral_normed_weight(W, ...)` returns the precomputed W_bar for those W.  Also (prepare=True)
     builds the bf16 MFMA operand layouts of all W_bar in one launch and hands every W_bar a pre-zeroed
-    slice of one flat gradient buffer, so the backward pass needs no per-weight memsets."""
-    pairs = sn_pairs(store, prefix)
+    slice of one flat gradient buffer, so the backward pass needs no per-weight memsets.
+    `prep_kind(variable_name, W)` -> 0 | 1 | 2 | None chooses the operand layout per weight (kernels.prep_weights_batched)."""
+    pairs = sn_pairs(store, prefix, with_names=True)
     if not pairs:
         yield None
         return
-    Ws = [w for w, _ in pairs]
-    us = [u for _, u in pairs]
+    Ws = [w for w, _, _ in pairs]
+    us = [u for _, u, _ in pairs]
     flat = _flat_base(store, prefix, us)
     if update_collection != NO_OPS:
         if flat is not None:                      # one snapshot copy instead of one per weight
@@ -128,7 +132,8 @@ def precomputed(store, prefix, update_collection=None, prepare=True):
     else:
         _apply_update(us, batch, update_collection)
     if prepare:
-        K.prep_weights_batched(list(W_bars), want_d=True)
+        kinds = [prep_kind(nm, w) for w, _, nm in pairs] if prep_kind is not None else None
+        K.prep_weights_batched(list(W_bars), want_d=True, kinds=kinds)
         if any(w.requires_grad for w in Ws):
             gflat = torch.zeros(sum(w.numel() for w in W_bars), dtype=torch.float32, device=W_bars[0].device)
             o = 0

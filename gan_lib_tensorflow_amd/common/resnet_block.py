@@ -24,6 +24,11 @@ CONDITIONAL = True
 ACGAN = False
 DIM_D = 128
 
+# A 1x1 convolution commutes with 2x2 mean pooling and with nearest-neighbour upsampling (both act per pixel /
+# per channel): the shortcut convolutions run at the LOW resolution, 4x fewer MACs (exact in real
+# arithmetic; bf16 rounding of the intermediate moves from before to after the resampling).
+COMMUTE_1X1 = True
+
 
 def nonlinearity(x, activation_fn='relu', leakiness=0.2):
     """gan_cifar_resnet.py:80-85"""
@@ -68,6 +73,9 @@ def ConvMeanPool(inputs, output_dim, filter_size=3, stride=1, name=None,
                  spectral_normed=False, update_collection=None, inputs_norm=False,
                  he_init=True, biases=True, **fused):
     """conv, then tf.add_n of the four stride-2 slices / 4 (gan_cifar_resnet.py:112-122)"""
+    if filter_size == 1 and COMMUTE_1X1 and not fused:      # mean_pool(conv1x1(x) + b) == conv1x1(mean_pool(x)) + b
+        return MeanPoolConv(inputs, output_dim, filter_size, stride, name, spectral_normed=spectral_normed,
+                            update_collection=update_collection, he_init=he_init, biases=biases, **fused)
     return _conv2d.Conv2D(inputs, inputs.shape[-1], output_dim, filter_size, stride, name,
                           spectral_normed=spectral_normed, update_collection=update_collection,
                           he_init=he_init, biases=biases, pool_out=True, **fused)
@@ -87,6 +95,11 @@ def UpsampleConv(inputs, output_dim, filter_size=3, stride=1, name=None,
                  spectral_normed=False, update_collection=None, inputs_norm=False,
                  he_init=True, biases=True, **fused):
     """nearest-neighbour 2x (concat x4 + depth_to_space), then conv (gan_cifar_resnet.py:140-153)"""
+    if filter_size == 1 and COMMUTE_1X1 and not fused:      # conv1x1(upsample(x)) + b == upsample(conv1x1(x) + b)
+        low = _conv2d.Conv2D(inputs, inputs.shape[-1], output_dim, filter_size, stride, name,
+                             spectral_normed=spectral_normed, update_collection=update_collection,
+                             he_init=he_init, biases=biases)
+        return Fn.upsample_nn2x(low)
     return _conv2d.Conv2D(inputs, inputs.shape[-1], output_dim, filter_size, stride, name,
                           spectral_normed=spectral_normed, update_collection=update_collection,
                           he_init=he_init, biases=biases, upsample=True, **fused)

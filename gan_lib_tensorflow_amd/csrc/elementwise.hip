@@ -89,56 +89,73 @@ struct PrepUpArgs {
   float scale;
 };
 
-__global__ void prep_upconv_kernel(PrepUpArgs q) {
+__device__ __forceinline__ void prep_up_element(const PrepUpArgs& q, long idx) {
   const long nph = 4L * q.CrPpad * 4 * q.CkP;
-  const long nd4 = (long)q.CrDpad * q.Kpad4;
-  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < nph + nd4; idx += (long)gridDim.x * blockDim.x) {
-    if (idx < nph) {
-      const int k = (int)(idx % (4 * q.CkP));
-      long t = idx / (4 * q.CkP);
-      const int r = (int)(t % q.CrPpad), p = (int)(t / q.CrPpad);
-      const int tap = k / q.CkP, c = k - tap * q.CkP;
-      float v = 0.f;
-      if (r < q.CrP) {
-        int h0, h1, w0, w1;
-        up_range_R(p >> 1, tap >> 1, h0, h1);
-        up_range_R(p & 1, tap & 1, w0, w1);
-        for (int dh = h0; dh <= h1; dh++)
-          for (int dw = w0; dw <= w1; dw++) {
-            const int t3 = q.flip ? (2 - dh) * 3 + (2 - dw) : dh * 3 + dw;
-            v += q.w[(long)t3 * q.plane + (long)r * q.srP + (long)c * q.skP];
-          }
-      }
-      q.ph[idx] = f2bf(v * q.scale);
-    } else {
-      const long i2 = idx - nph;
-      const int r = (int)(i2 / q.Kpad4), k = (int)(i2 - (long)r * q.Kpad4);
-      float v = 0.f;
-      if (r < q.CrD && k < 16 * q.CkD) {
-        const int tap = k / q.CkD, c = k - tap * q.CkD;
-        int h0, h1, w0, w1;
-        up_range_S(tap >> 2, h0, h1);
-        up_range_S(tap & 3, w0, w1);
-        for (int dh = h0; dh <= h1; dh++)
-          for (int dw = w0; dw <= w1; dw++) {
-            const int t3 = q.flip ? (2 - dh) * 3 + (2 - dw) : dh * 3 + dw;
-            v += q.w[(long)t3 * q.plane + (long)r * q.srD + (long)c * q.skD];
-          }
-      }
-      q.d4[i2] = f2bf(v * q.scale);
+  if (idx < nph) {
+    const int k = (int)(idx % (4 * q.CkP));
+    long t = idx / (4 * q.CkP);
+    const int r = (int)(t % q.CrPpad), p = (int)(t / q.CrPpad);
+    const int tap = k / q.CkP, c = k - tap * q.CkP;
+    float v = 0.f;
+    if (r < q.CrP) {
+      int h0, h1, w0, w1;
+      up_range_R(p >> 1, tap >> 1, h0, h1);
+      up_range_R(p & 1, tap & 1, w0, w1);
+      for (int dh = h0; dh <= h1; dh++)
+        for (int dw = w0; dw <= w1; dw++) {
+          const int t3 = q.flip ? (2 - dh) * 3 + (2 - dw) : dh * 3 + dw;
+          v += q.w[(long)t3 * q.plane + (long)r * q.srP + (long)c * q.skP];
+        }
     }
+    q.ph[idx] = f2bf(v * q.scale);
+  } else {
+    const long i2 = idx - nph;
+    const int r = (int)(i2 / q.Kpad4), k = (int)(i2 - (long)r * q.Kpad4);
+    float v = 0.f;
+    if (r < q.CrD && k < 16 * q.CkD) {
+      const int tap = k / q.CkD, c = k - tap * q.CkD;
+      int h0, h1, w0, w1;
+      up_range_S(tap >> 2, h0, h1);
+      up_range_S(tap & 3, w0, w1);
+      for (int dh = h0; dh <= h1; dh++)
+        for (int dw = w0; dw <= w1; dw++) {
+          const int t3 = q.flip ? (2 - dh) * 3 + (2 - dw) : dh * 3 + dw;
+          v += q.w[(long)t3 * q.plane + (long)r * q.srD + (long)c * q.skD];
+        }
+    }
+    q.d4[i2] = f2bf(v * q.scale);
   }
+}
+__host__ __device__ inline long prep_up_total(const PrepUpArgs& q) { return 4L * q.CrPpad * 4 * q.CkP + (long)q.CrDpad * q.Kpad4; }
+
+__global__ void prep_upconv_kernel(PrepUpArgs q) {
+  const long total = prep_up_total(q);
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) prep_up_element(q, idx);
+}
+
+// kind 1 = UpsampleConv 3x3 (ph rows = co, d4 rows = ci); kind 2 = ConvMeanPool 3x3 (ph rows = ci, d4 rows = co, flipped, x 1/4)
+__host__ __device__ inline PrepUpArgs prep_up_args(int kind, const float* w, void* ph, void* d4, int Cin, int Cout) {
+  PrepUpArgs q{};
+  q.w = w; q.ph = (bf16*)ph; q.d4 = (bf16*)d4; q.plane = Cin * Cout;
+  if (kind == 1) {
+    q.CrP = Cout; q.CkP = Cin; q.srP = 1; q.skP = Cout;
+    q.CrD = Cin; q.CkD = Cout; q.srD = Cout; q.skD = 1;
+    q.flip = 0; q.scale = 1.f;
+  } else {
+    q.CrP = Cin; q.CkP = Cout; q.srP = Cout; q.skP = 1;
+    q.CrD = Cout; q.CkD = Cin; q.srD = 1; q.skD = Cout;
+    q.flip = 1; q.scale = 0.25f;
+  }
+  q.CrPpad = (q.CrP + 31) / 32 * 32;
+  q.CrDpad = (q.CrD + 31) / 32 * 32;
+  q.Kpad4 = (16 * q.CkD + 63) / 64 * 64;
+  return q;
 }
 
 extern "C" int gank_upconv3x3_prep_weights(const float* w, void* wph, void* wd4, int Cin, int Cout, void* stream) {
   GANK_REQUIRE(w && wph && wd4 && Cin > 0 && Cout > 0, "upconv3x3_prep_weights: bad arguments");
-  PrepUpArgs q{};
-  q.w = w; q.ph = (bf16*)wph; q.d4 = (bf16*)wd4;
-  q.CrP = Cout; q.CkP = Cin; q.srP = 1; q.skP = Cout; q.CrPpad = roundup(Cout, 32);
-  q.CrD = Cin; q.CkD = Cout; q.srD = Cout; q.skD = 1; q.CrDpad = roundup(Cin, 32); q.Kpad4 = roundup(16 * Cout, 64);
-  q.flip = 0; q.plane = Cin * Cout; q.scale = 1.f;
-  const long total = 4L * q.CrPpad * 4 * q.CkP + (long)q.CrDpad * q.Kpad4;
-  hipLaunchKernelGGL(prep_upconv_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, q);
+  const PrepUpArgs q = prep_up_args(1, w, wph, wd4, Cin, Cout);
+  hipLaunchKernelGGL(prep_upconv_kernel, grid1d(prep_up_total(q)), dim3(256), 0, (hipStream_t)stream, q);
   GANK_LAUNCH_OK("prep_upconv");
   return 0;
 }
@@ -149,13 +166,8 @@ extern "C" int gank_upconv3x3_prep_weights(const float* w, void* wph, void* wd4,
 // output phases of the transposed conv that is its input gradient (2x2 taps of dy per high-res pixel).
 extern "C" int gank_convpool3x3_prep_weights(const float* w, void* wp4, void* wphd, int Cin, int Cout, void* stream) {
   GANK_REQUIRE(w && wp4 && wphd && Cin > 0 && Cout > 0, "convpool3x3_prep_weights: bad arguments");
-  PrepUpArgs q{};
-  q.w = w; q.ph = (bf16*)wphd; q.d4 = (bf16*)wp4;
-  q.CrP = Cin; q.CkP = Cout; q.srP = Cout; q.skP = 1; q.CrPpad = roundup(Cin, 32);
-  q.CrD = Cout; q.CkD = Cin; q.srD = 1; q.skD = Cout; q.CrDpad = roundup(Cout, 32); q.Kpad4 = roundup(16 * Cin, 64);
-  q.flip = 1; q.plane = Cin * Cout; q.scale = 0.25f;
-  const long total = 4L * q.CrPpad * 4 * q.CkP + (long)q.CrDpad * q.Kpad4;
-  hipLaunchKernelGGL(prep_upconv_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, q);
+  const PrepUpArgs q = prep_up_args(2, w, wphd, wp4, Cin, Cout);
+  hipLaunchKernelGGL(prep_upconv_kernel, grid1d(prep_up_total(q)), dim3(256), 0, (hipStream_t)stream, q);
   GANK_LAUNCH_OK("prep_convpool");
   return 0;
 }
@@ -165,6 +177,7 @@ extern "C" int gank_convpool3x3_prep_weights(const float* w, void* wp4, void* wp
 #define PREP_MAX 16
 struct PrepTable {
   gank_prep_desc d[PREP_MAX];
+  PrepUpArgs up[PREP_MAX];         // kinds 1/2: operand geometry, filled on the host
   int first_block[PREP_MAX + 1];   // prefix sum of blocks per entry
   int nwf[PREP_MAX];               // wf tiles of entry i (the rest of its blocks are wd work)
   int count;
@@ -177,7 +190,14 @@ __global__ void prep_batch_kernel(PrepTable t) {
   const gank_prep_desc& d = t.d[e];
   const int b = blockIdx.x - t.first_block[e];
   const int taps = d.ksize * d.ksize;
-  if (b < t.nwf[e]) {
+  if (d.kind != 0) {       // UpsampleConv / ConvMeanPool 3x3 operands
+    const PrepUpArgs& q = t.up[e];
+    const long total = prep_up_total(q), base = (long)b * 2048;
+    for (int j = 0; j < 8; j++) {
+      const long i = base + j * 256 + threadIdx.x;
+      if (i < total) prep_up_element(q, i);
+    }
+  } else if (b < t.nwf[e]) {
     const int K = taps * d.Cin, Kpad = (K + 63) / 64 * 64, CoutPad = (d.Cout + 31) / 32 * 32;
     __shared__ float tl[32][33];
     const int ntk = Kpad / 32;
@@ -215,16 +235,23 @@ __global__ void prep_batch_kernel(PrepTable t) {
 extern "C" int gank_conv2d_prep_weights_batched(const gank_prep_desc* table, int count, void* stream) {
   GANK_REQUIRE(table && count > 0, "prep_weights_batched: empty table");
   for (int base = 0; base < count; base += PREP_MAX) {
-    PrepTable t;
+    PrepTable t{};
     t.count = count - base < PREP_MAX ? count - base : PREP_MAX;
     int blocks = 0;
     for (int i = 0; i < t.count; i++) {
       const gank_prep_desc& d = table[base + i];
       GANK_REQUIRE(d.w && (d.wf || d.wd) && d.ksize >= 1 && d.Cin > 0 && d.Cout > 0, "prep_weights_batched: bad entry %d", base + i);
+      GANK_REQUIRE(d.kind == 0 || ((d.kind == 1 || d.kind == 2) && d.ksize == 3 && d.wf && d.wd),
+                   "prep_weights_batched: entry %d: kind %d needs ksize 3 and both outputs", base + i, d.kind);
       t.d[i] = d;
       const int taps = d.ksize * d.ksize;
-      const int nwf = d.wf ? (roundup(taps * d.Cin, 64) / 32) * (roundup(d.Cout, 32) / 32) : 0;
-      const int nwd = d.wd ? cdiv((long)roundup(d.Cin, 32) * roundup(taps * d.Cout, 64), 2048) : 0;
+      int nwf = d.wf ? (roundup(taps * d.Cin, 64) / 32) * (roundup(d.Cout, 32) / 32) : 0;
+      int nwd = d.wd ? cdiv((long)roundup(d.Cin, 32) * roundup(taps * d.Cout, 64), 2048) : 0;
+      if (d.kind != 0) {
+        t.up[i] = d.kind == 1 ? prep_up_args(1, d.w, d.wf, d.wd, d.Cin, d.Cout) : prep_up_args(2, d.w, d.wd, d.wf, d.Cin, d.Cout);
+        nwf = 0;
+        nwd = (int)cdiv(prep_up_total(t.up[i]), 2048);
+      }
       t.first_block[i] = blocks;
       t.nwf[i] = nwf;
       blocks += nwf + nwd;

@@ -46,30 +46,48 @@ def prep_weights(w, want_f=True, want_d=False):
     return wf, wd
 
 
-def prep_weights_batched(ws, want_d=True):
-    """One launch for a list of fp32 weights ([k,k,Cin,Cout] or [Cin,Cout]); returns [(wf, wd)] and sets
-    `w._prep = (wf, wd)` on each tensor so the conv wrappers skip their own per-layer preparation."""
-    table = (PrepDesc * len(ws))()
+def prep_weights_batched(ws, want_d=True, kinds=None):
+    """One launch for a list of fp32 weights ([k,k,Cin,Cout] or [Cin,Cout]).  kinds[i]: 0 = plain conv/linear ->
+    `w._prep = (wf, wd)`; 1 = UpsampleConv 3x3 -> `w._prep_up = (wph, wd4)`; 2 = ConvMeanPool 3x3 ->
+    `w._prep_pool = (wp4, wphd)`; None = skip (the layer prepares nothing).  The conv wrappers pick the attributes up
+    and skip their own per-layer preparation.  Buffers persist on the tensor and are rewritten IN PLACE on later
+    calls: captured graphs keep reading the same addresses."""
+    kinds = list(kinds) if kinds is not None else [0] * len(ws)
+    todo = [(w, kd) for w, kd in zip(ws, kinds) if kd is not None]
+    table = (PrepDesc * len(todo))()
     outs = []
-    for i, w in enumerate(ws):
+    for i, (w, kind) in enumerate(todo):
         if w.dim() == 2:
             k, cin, cout = 1, w.shape[0], w.shape[1]
         else:
             k, cin, cout = w.shape[0], w.shape[2], w.shape[3]
         taps = k * k
-        old = getattr(w, "_prep", None)
-        if old is not None and old[0] is not None and (old[1] is not None or not want_d):
-            wf, wd = old      # persistent buffers are overwritten IN PLACE: captured graphs keep reading them
+        dev = w.device
+        if kind == 0:
+            old = getattr(w, "_prep", None)
+            if old is not None and old[0] is not None and (old[1] is not None or not want_d):
+                wf, wd = old
+            else:
+                wf = torch.empty((_roundup(cout, 32), _roundup(taps * cin, 64)), dtype=BF16, device=dev)
+                wd = torch.empty((_roundup(cin, 32), _roundup(taps * cout, 64)), dtype=BF16, device=dev) if want_d else None
+        elif kind == 1:
+            assert k == 3
+            wf, wd = getattr(w, "_prep_up", None) or (torch.empty((4, _roundup(cout, 32), 4 * cin), dtype=BF16, device=dev),
+                                                     torch.empty((_roundup(cin, 32), _roundup(16 * cout, 64)), dtype=BF16, device=dev))
+        elif kind == 2:
+            assert k == 3
+            wf, wd = getattr(w, "_prep_pool", None) or (torch.empty((_roundup(cout, 32), _roundup(16 * cin, 64)), dtype=BF16, device=dev),
+                                                       torch.empty((4, _roundup(cin, 32), 4 * cout), dtype=BF16, device=dev))
         else:
-            wf = torch.empty((_roundup(cout, 32), _roundup(taps * cin, 64)), dtype=BF16, device=w.device)
-            wd = torch.empty((_roundup(cin, 32), _roundup(taps * cout, 64)), dtype=BF16, device=w.device) if want_d else None
+            raise ValueError(f"unknown preparation kind {kind}")
         d = table[i]
         d.w, d.wf, d.wd = _p(w.detach(), F32, "w").value, wf.data_ptr(), (wd.data_ptr() if wd is not None else None)
-        d.ksize, d.Cin, d.Cout = k, cin, cout
+        d.ksize, d.Cin, d.Cout, d.kind = k, cin, cout, kind
         outs.append((wf, wd))
-    _lib.check(lib().gank_conv2d_prep_weights_batched(table, len(ws), _stream()), "prep_weights_batched")
-    for w, o in zip(ws, outs):
-        w._prep = o
+    if todo:
+        _lib.check(lib().gank_conv2d_prep_weights_batched(table, len(todo), _stream()), "prep_weights_batched")
+    for (w, kind), o in zip(todo, outs):
+        setattr(w, ("_prep", "_prep_up", "_prep_pool")[kind], o)
     return outs
 
 

@@ -48,9 +48,11 @@ int gank_conv2d_prep_weights(const float* w, void* wf, void* wd, int ksize, int 
 /* the same for up to any number of weights in one launch per 16 (host table, copied into kernel arguments) */
 typedef struct gank_prep_desc {
   const float* w; /* fp32 [k,k,Cin,Cout] */
-  void* wf;       /* bf16 [CoutPad][Kpad]  or NULL */
-  void* wd;       /* bf16 [CinPad][Kpad'] or NULL */
-  int ksize, Cin, Cout, _pad;
+  void* wf;       /* kind 0: bf16 [CoutPad][Kpad] or NULL;  kind 1: wph;  kind 2: wp4   (the fprop operand) */
+  void* wd;       /* kind 0: bf16 [CinPad][Kpad'] or NULL;  kind 1: wd4;  kind 2: wphd  (the dgrad operand) */
+  int ksize, Cin, Cout;
+  int kind;       /* 0 plain conv/linear; 1 UpsampleConv 3x3 (gank_upconv3x3_prep_weights layouts);
+                     2 ConvMeanPool 3x3 (gank_convpool3x3_prep_weights layouts) */
 } gank_prep_desc;
 int gank_conv2d_prep_weights_batched(const gank_prep_desc* table, int count, void* stream);
 

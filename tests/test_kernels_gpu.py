@@ -431,3 +431,28 @@ def test_linear_small(K, m, k, c):
     assert K.linear_bwd(dyt, None, None, False, None, db2) is None        # bias gradient alone
     torch.cuda.synchronize()
     assert relerr(db2, dy.sum(0)) < 1e-5
+
+
+def test_batched_prep_kinds_match_standalone(K):
+    """One batched launch builds plain, UpsampleConv (kind 1) and ConvMeanPool (kind 2) operands: bit-identical to
+    the per-layer entry points, buffers reused in place on the second call."""
+    g = torch.Generator(device="cpu").manual_seed(11)
+    ws = [torch.randn(s, generator=g).cuda() for s in ((3, 3, 64, 128), (3, 3, 128, 64), (3, 3, 64, 64), (128, 96), (1, 1, 64, 32))]
+    kinds = [1, 2, 0, 0, None]
+    K.prep_weights_batched(ws, want_d=True, kinds=kinds)
+    torch.cuda.synchronize()
+    assert not hasattr(ws[4], "_prep")
+    ref_up = K.upconv3x3_prep(ws[0].clone())
+    ref_pool = K.convpool3x3_prep(ws[1].clone())
+    ref_plain = K.prep_weights(ws[2], True, True)
+    ref_lin = K.prep_weights(ws[3].view(1, 1, 128, 96), True, True)
+    torch.cuda.synchronize()
+    for got, ref in ((ws[0]._prep_up, ref_up), (ws[1]._prep_pool, ref_pool), (ws[2]._prep, ref_plain), (ws[3]._prep, ref_lin)):
+        for a, b in zip(got, ref):
+            assert a.shape == b.shape and torch.equal(a.view(torch.int16), b.view(torch.int16))
+    ptrs = [t.data_ptr() for t in ws[0]._prep_up + ws[1]._prep_pool + ws[2]._prep]
+    ws[0].mul_(2.0)
+    K.prep_weights_batched(ws, want_d=True, kinds=kinds)
+    torch.cuda.synchronize()
+    assert ptrs == [t.data_ptr() for t in ws[0]._prep_up + ws[1]._prep_pool + ws[2]._prep]
+    assert torch.equal(ws[0]._prep_up[0].float(), ref_up[0].float() * 2)
