@@ -464,9 +464,11 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_lean_kernel(WgradArgs 
     if constexpr (PF >= 1) step(s0 + 0, std::integral_constant<int, 0>{});
     if constexpr (PF >= 2) step(s0 + 1, std::integral_constant<int, 1 % PF>{});
     if constexpr (PF >= 3) step(s0 + 2, std::integral_constant<int, 2 % PF>{});
+    if constexpr (PF >= 4) step(s0 + 3, std::integral_constant<int, 3 % PF>{});
   }
   if constexpr (PF >= 2) { if (s0 + 0 < nsteps) step(s0 + 0, std::integral_constant<int, 0>{}); }
   if constexpr (PF >= 3) { if (s0 + 1 < nsteps) step(s0 + 1, std::integral_constant<int, 1 % PF>{}); }
+  if constexpr (PF >= 4) { if (s0 + 2 < nsteps) step(s0 + 2, std::integral_constant<int, 2 % PF>{}); }
 
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -510,8 +512,11 @@ static int launch_wgrad_lean_mode(WgradArgs a, hipStream_t s) {
   a.tiles_co = cdiv(a.Cout, CoT);
   const int total_steps = a.M / 64;
   const long tiles = (long)a.taps * a.tiles_ci * a.tiles_co;
-  int splits = (int)((768 + tiles - 1) / tiles);
-  if (splits > total_steps / 4) splits = total_steps / 4;
+  static int target_env = -1, minsteps_env = -1;   // experiment knobs
+  if (target_env < 0) { const char* e = getenv("GANK_WGRAD_SPLIT_TARGET"); target_env = e ? atoi(e) : 256; }
+  if (minsteps_env < 0) { const char* e = getenv("GANK_WGRAD_MIN_STEPS"); minsteps_env = e ? atoi(e) : 8; }
+  int splits = (int)((target_env + tiles - 1) / tiles);
+  if (splits > total_steps / minsteps_env) splits = total_steps / minsteps_env;
   if (splits < 1) splits = 1;
   a.steps_per_split = cdiv(total_steps, splits);
   a.splits = cdiv(total_steps, a.steps_per_split);
@@ -1030,8 +1035,12 @@ int gank_wgrad_dispatch(WgradArgs a, hipStream_t s) {
   static int taps_env = -1;   // experiment knob: GANK_WGRAD_TAPS=0 disables the all-taps kernel
   if (taps_env < 0) { const char* e = getenv("GANK_WGRAD_TAPS"); taps_env = e ? atoi(e) : 1; }
   if (taps_env && wgrad_taps_ok(a)) rc = launch_wgrad_taps(a, s);
+  static int lpf_env = -1;   // experiment knob: prefetch depth of the lean kernel
+  if (lpf_env < 0) { const char* e = getenv("GANK_WGRAD_LEAN_PF"); lpf_env = e ? atoi(e) : 2; }
   if (rc < 0 && lean) {
-    if (a.Cin >= 128 && a.Cout >= 128) rc = launch_wgrad_lean<2, 2, 2, 2, 2>(a, s);
+    if (a.Cin >= 128 && a.Cout >= 128 && lpf_env == 4) rc = launch_wgrad_lean<2, 2, 2, 2, 4>(a, s);
+    else if (a.Cin >= 128 && a.Cout >= 128 && lpf_env == 3) rc = launch_wgrad_lean<2, 2, 2, 2, 3>(a, s);
+    else if (a.Cin >= 128 && a.Cout >= 128) rc = launch_wgrad_lean<2, 2, 2, 2, 2>(a, s);
     else if (a.Cin >= 64 && a.Cout >= 64) rc = launch_wgrad_lean<2, 2, 1, 1, 2>(a, s);
   }
   // narrow operands: pack (tap, channel) into <= 32 MFMA columns so the wide operand streams once

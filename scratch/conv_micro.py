@@ -9,6 +9,7 @@ x = torch.randn(n, h, h, cin, device="cuda").to(torch.bfloat16)
 w = (torch.randn(k, k, cin, cout, device="cuda") / (k * k * cin) ** 0.5)
 xh = torch.randn(n, h // 2, h // 2, cin, device="cuda").to(torch.bfloat16)
 dy = torch.randn(n, h, h, cout, device="cuda").to(torch.bfloat16)
+dyp = torch.randn(n, h // 2, h // 2, cout, device="cuda").to(torch.bfloat16)
 wf, wd = K.prep_weights(w, True, True)
 dw = torch.zeros_like(w)
 torch.cuda.synchronize()
@@ -20,6 +21,10 @@ def run():
         K.conv2d_fprop(xh, wf, None, (h, h), cout, k, K.IN_UPSAMPLE2X)
     elif which == "dgrad":
         K.conv2d_dgrad(dy, wd, (h, h), cin, k)
+    elif which == "cpwgrad":      # ConvMeanPool 3x3 filter gradient: x [n,h,h,cin], dy pooled [n,h/2,h/2,cout]
+        K.convpool3x3_wgrad(x, dyp, dw, K.IN_RELU)
+    elif which == "wgrad_relu":
+        K.conv2d_wgrad(x, dy, dw, (h, h), k, K.IN_RELU)
     else:
         K.conv2d_wgrad(x, dy, dw, (h, h), k)
 for _ in range(3): run()
