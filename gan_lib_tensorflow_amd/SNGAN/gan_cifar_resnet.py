@@ -85,12 +85,19 @@ def _d_prep_kind(name, W):
         return None
     if Fn.POOL_CONV4 and name.endswith(('D.Block.1.Conv2/Filters', 'D.Block.2.Conv2/Filters')):
         return 2
+    if Fn.FRAG_PATCH and name.endswith('D.Block.2.Conv1/Filters'):      # plain 3x3 256->256 at 16x16
+        return 3
     return 0
 
 
 def _g_prep_kind(name, W):
-    """the three UpsampleConv 3x3 layers run phase-decomposed"""
-    return 1 if (Fn.PHASE_UPCONV and name.endswith('.Conv1/Filters') and W.dim() == 4 and W.shape[0] == 3) else 0
+    """the three UpsampleConv 3x3 layers run phase-decomposed; the plain 3x3 convs at 16x16 / 32x32 get the
+    fragment-major operand copy of the register-weight patch kernel"""
+    if Fn.PHASE_UPCONV and name.endswith('.Conv1/Filters') and W.dim() == 4 and W.shape[0] == 3:
+        return 1
+    if Fn.FRAG_PATCH and name.endswith(('G.Block.2.Conv2/Filters', 'G.Block.3.Conv2/Filters')):
+        return 3
+    return 0
 
 
 def Discriminator(inputs, labels, update_collection=None, reuse=False):

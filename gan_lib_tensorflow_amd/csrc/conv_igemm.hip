@@ -21,6 +21,7 @@
 #endif
 #define IG_IN_ZEROINS2X 16
 #define IG_IN_STRIDE2 32
+#define IG_W_FRAG 64          // the operand buffer carries the fragment-major copy (public GANK_W_FRAG)
 
 struct IgemmArgs {
   const bf16* x;
@@ -353,13 +354,19 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
 // per MFMA.  Weights stream exactly as in the generic kernel (2-slot register ring, double-buffered LDS).
 // ------------------------------------------------------------------------------------------------------
 constexpr int PHALO = 180;   // 10 x 18 halo pixels
+// Halo image row pitch (bf16 elements).  A B-fragment ds_read_b128 covers 16 pixels of one halo row (lanes 0-15)
+// and 16 of the next (lanes 16-31); its 16-lane groups {0-3,12-15,20-27}, ... mix both rows, and with the natural
+// pitch of 18 x 144 B = 2592 B (= 32 mod 256) two lanes of every group share a bank: SQ_LDS_BANK_CONFLICT showed 4
+// extra cycles on every B read (8 instead of 4).  A pitch that is a multiple of 256 B keeps the 144-B pixel stride's
+// conflict-free slot permutation across the row change.
+constexpr int HROWP = 1408;  // 2816 B = 11 x 256 B  (>= 18 * LROW = 1296)
 
 template <int MODE>   // bit0: relu on the input operand
 __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
   constexpr int NT = 256, BN = 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16* sP = reinterpret_cast<bf16*>(smem);             // [PHALO][LROW]  (single buffer)
-  bf16* sW = sP + PHALO * LROW;                         // [2][BN][LROW]
+  bf16* sP = reinterpret_cast<bf16*>(smem);             // [10][HROWP]  (single buffer; pixel stride LROW inside a row)
+  bf16* sW = sP + 10 * HROWP;                           // [2][BN][LROW]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_m = wave & 1, wave_n = wave >> 1;      // 2 x 2 waves, each 64 pixels x 64 couts
@@ -385,7 +392,7 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
     const int iy = py0 - 1 + hp / 18, ix = px0 - 1 + hp % 18;
     const bool ok = q < PHALO * 8 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
     h_off[j] = ok ? (((n * a.H + iy) * a.W + ix) * a.Cin + cc * 8) * 2 : OOB;
-    h_lds[j] = (q < PHALO * 8) ? hp * LROW + cc * 8 : -1;
+    h_lds[j] = (q < PHALO * 8) ? (hp / 18) * HROWP + (hp % 18) * LROW + cc * 8 : -1;
   }
   int w_off[4];
 #pragma unroll
@@ -441,7 +448,7 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
   // B-fragment base of this lane inside the halo image: pixel (wave_m*4 + 2j + (r>>4), r&15), centre tap
   int pb[2];
 #pragma unroll
-  for (int j = 0; j < 2; j++) pb[j] = ((wave_m * 4 + 2 * j + (r >> 4) + 1) * 18 + (r & 15) + 1) * LROW + h * 8;
+  for (int j = 0; j < 2; j++) pb[j] = (wave_m * 4 + 2 * j + (r >> 4) + 1) * HROWP + ((r & 15) + 1) * LROW + h * 8;
   const int ab = (wave_n * 64 + r) * LROW + h * 8;
 
   load_halo(0);
@@ -458,7 +465,7 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
     for (int tap = 0; tap < 9; tap++, s++) {
       const int buf = s & 1;
       if (s < last) load_w();                        // weights of step s+1
-      const int toff = (dh * 18 + dw) * LROW;
+      const int toff = dh * HROWP + dw * LROW;
       const bf16* pW = sW + buf * BN * LROW + ab;
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) {
@@ -529,12 +536,215 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Second-generation patch kernel for plain 3x3 / stride 1 / SAME convolutions with H % 16 == 0, W % 16 == 0,
+// Cin % 64 == 0, Cout % 128 == 0 and a fragment-major weight copy (prep kind 3).
+// The PMC picture of conv_igemm_patch_kernel (profiles/, round 1): MFMA pipe 32 % busy, LDS 34 % busy -- neither
+// saturated; the waves sit at the per-tap barrier (one every 16 MFMAs per wave) and in LDS latency behind it.
+// Here one block owns a 16x16 output patch x 128 couts and each wave a 128-pixel x 64-cout tile (4 x 2 MFMA tiles):
+//   * weights never touch LDS: every wave loads its A fragments straight from L2 into a 3-step register ring (one
+//     coalesced 1 KB request per fragment); no weight ds_writes, no weight ds_reads, and no barrier per tap;
+//   * the 18x18 halo of the next 64-channel chunk is staged piecewise (1/9 per tap-step) into the OTHER LDS buffer,
+//     so there is ONE barrier per 9 tap-steps = 288 MFMAs per wave;
+//   * LDS traffic is the B operand only: 4 fragment reads per 8 MFMAs (0.5 KB per MFMA, was 1 KB + weight writes).
+// One block per CU (93 KB LDS), one wave per SIMD: latency is hidden inside the wave by the register ring and by
+// hipcc hoisting the next kk's ds_reads above the current MFMAs (8 independent accumulator tiles).
+// ------------------------------------------------------------------------------------------------------
+constexpr int P2HALO = 18 * 18;   // halo pixels of a 16x16 patch
+
+template <int MODE>   // bit0: relu on the input operand
+__global__ __launch_bounds__(256) void conv_igemm_patch2_kernel(IgemmArgs a) {
+  constexpr int NT = 256, BN = 128, PFW = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* sP = reinterpret_cast<bf16*>(smem);             // [2][18][HROWP]  (pixel stride LROW inside a halo row)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave & 1, wave_n = wave >> 1;      // 2 x 2 waves, each 128 pixels (8 patch rows) x 64 couts
+  const int r = lane & 31, h = lane >> 5;
+
+  const int nwg = a.tiles_m * a.tiles_n;
+  const int lid = xcd_remap(blockIdx.x, nwg);
+  const int tile_n = lid % a.tiles_n, tile_m = lid / a.tiles_n;
+  const int pw = a.W >> 4, ph = a.H >> 4;
+  const int n = tile_m / (pw * ph), pr = tile_m - n * pw * ph;
+  const int py0 = (pr / pw) << 4, px0 = (pr % pw) << 4;
+
+  constexpr int OOB = 0x7FFFFFF0;
+  const int nsteps = a.nsteps;                          // 9 * Cin / 64
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, a.N * a.H * a.W * a.Cin * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w) + (long)a.CoutPad * a.Kpad, 0,
+                                                                        a.CoutPad * a.Kpad * 2, 0x00020000);
+
+  // ---- halo pieces: 2592 16-byte chunks per 64-channel slab, 288 per tap-step (thread: chunk tid, and 256+tid < 288)
+  auto halo_off = [&](int q, int& lds) -> int {         // q in [0, 2592): byte offset in x of chunk q (or OOB), LDS element offset
+    const int hp = q >> 3, cc = q & 7;
+    const int hy = hp / 18, hx = hp - hy * 18;
+    const int iy = py0 - 1 + hy, ix = px0 - 1 + hx;
+    lds = hy * HROWP + hx * LROW + cc * 8;
+    const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    return ok ? (((n * a.H + iy) * a.W + ix) * a.Cin + cc * 8) * 2 : OOB;
+  };
+  u32x4 rH[2];
+  int hl[2];
+  auto load_piece = [&](int piece, int c) {              // piece 0..8 of the slab of chunk c
+    const int q0 = piece * 288 + tid;
+    int off = halo_off(q0, hl[0]);
+    rH[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off == OOB ? OOB : off + c * 128, 0, 0);
+    if (tid < 32) {
+      off = halo_off(q0 + 256, hl[1]);
+      rH[1] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off == OOB ? OOB : off + c * 128, 0, 0);
+    }
+  };
+  auto store_piece = [&](int buf) {
+    u32x4 v = rH[0];
+    if constexpr ((MODE & 1) != 0) v = relu_bf16x8(v);
+    *reinterpret_cast<u32x4*>(sP + buf * 18 * HROWP + hl[0]) = v;
+    if (tid < 32) {
+      u32x4 v1 = rH[1];
+      if constexpr ((MODE & 1) != 0) v1 = relu_bf16x8(v1);
+      *reinterpret_cast<u32x4*>(sP + buf * 18 * HROWP + hl[1]) = v1;
+    }
+  };
+
+  // ---- weight fragments: [32-cout tile][K-step][kk][lane][8] (prep kind 3); this wave's two tiles, 4 kk each
+  const int T0 = tile_n * (BN / 32) + wave_n * 2;
+  const int wv0 = lane * 16;                              // + kk * 1024 (folded into the instruction offset)
+  const int wv1 = wv0 + nsteps * 4096;                    // second cout tile
+  u32x4 rW[PFW][2][4];
+  auto load_w = [&](u32x4 (&dst)[2][4], int step) {
+    // wave-uniform by construction (wave index, tile index): tell the compiler, or every load becomes a waterfall loop
+    const int so = __builtin_amdgcn_readfirstlane((T0 * nsteps + (step < nsteps ? step : nsteps - 1)) * 4096);
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      dst[0][kk] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wv0 + kk * 1024, so, 0);
+      dst[1][kk] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wv1 + kk * 1024, so, 0);
+    }
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+  // B-fragment base of this lane in the halo image: pixel (wave_m*8 + 2j + (r>>4), r&15), centre tap
+  int pb[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) pb[j] = (wave_m * 8 + 2 * j + (r >> 4) + 1) * HROWP + ((r & 15) + 1) * LROW + h * 8;
+
+  // prologue: slab 0 into buffer 0, the first PFW weight steps into the ring
+#pragma unroll 1
+  for (int p = 0; p < 9; p++) { load_piece(p, 0); store_piece(0); }
+#pragma unroll
+  for (int d = 0; d < PFW; d++) load_w(rW[d], d);
+  __syncthreads();
+
+  const int nchunks = a.Cin >> 6;
+#pragma unroll 1
+  for (int c = 0; c < nchunks; c++) {
+    const int cur = c & 1;
+    const bool more = c + 1 < nchunks;
+    const bf16* sH = sP + cur * 18 * HROWP;
+    // 36 stages (tap, kk) per slab; the B fragments of stage t+1 are requested before the MFMAs of stage t
+    bf16x8 fb[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) fb[0][j] = *reinterpret_cast<const bf16x8*>(sH + pb[j] - HROWP - LROW);
+#pragma unroll
+    for (int t = 0; t < 36; t++) {
+      const int tap = t >> 2, kk = t & 3;
+      if (kk == 0 && more) load_piece(tap, c + 1);       // lands while this tap's MFMAs run
+      if (t + 1 < 36) {
+        const int tn = (t + 1) >> 2, kn = (t + 1) & 3;
+        const int toff = (tn / 3 - 1) * HROWP + (tn % 3 - 1) * LROW + kn * 16;
+#pragma unroll
+        for (int j = 0; j < 4; j++) fb[(t + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(sH + pb[j] + toff);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const bf16x8 fa = __builtin_bit_cast(bf16x8, rW[tap % PFW][i][kk]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[t & 1][j], acc[i][j], 0, 0, 0);
+      }
+      if (kk == 3) {
+        load_w(rW[tap % PFW], c * 9 + tap + PFW);        // this slot is consumed: refill it PFW steps ahead
+        if (more) store_piece(cur ^ 1);
+      }
+    }
+    __syncthreads();     // next slab complete, everyone is done reading this one
+  }
+
+  // epilogue (same order as the other kernels): lane holds channels co0+8g+4h..+3 of one pixel per quad
+  const bool otanh = (a.flags & GANK_OUT_TANH) != 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int py = wave_m * 8 + 2 * j + (r >> 4), px = r & 15;
+    const long m = ((long)(n * a.H + py0 + py)) * a.W + px0 + px;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int co0 = tile_n * BN + (wave_n * 2 + i) * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int co = co0 + 8 * g;
+        if (co >= a.Cout) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * g + e] * a.scale;
+        const long o = m * a.Cout + co;
+        if (a.bias) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += b[e];
+        }
+        if (a.mask) {
+          const bf16x4 mk = *reinterpret_cast<const bf16x4*>(a.mask + o);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = (bf2f(mk[e]) > 0.f) ? v[e] : 0.f;
+        }
+        if (a.res) {
+          const bf16x4 rs = *reinterpret_cast<const bf16x4*>(a.res + o);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += bf2f(rs[e]);
+        }
+        bf16x4 out;
+        if (otanh) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) out[e] = f2bf(tanhf(v[e]));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; e++) out[e] = f2bf(v[e]);
+        }
+        *reinterpret_cast<bf16x4*>(a.y + o) = out;
+      }
+    }
+  }
+}
+
+template <int MODE>
+static int launch_patch2(const IgemmArgs& a0, hipStream_t s) {
+  IgemmArgs a = a0;
+  a.tiles_m = a.N * (a.H / 16) * (a.W / 16);
+  a.tiles_n = a.CoutPad / 128;
+  const size_t lds = (size_t)2 * 18 * HROWP * sizeof(bf16);
+  auto kern = conv_igemm_patch2_kernel<MODE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return gank_set_error("conv_igemm_patch2: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+  GANK_LAUNCH_OK("conv_igemm_patch2");
+  return 0;
+}
+
 template <int MODE>
 static int launch_patch(const IgemmArgs& a0, hipStream_t s) {
   IgemmArgs a = a0;
   a.tiles_m = a.N * (a.H / 8) * (a.W / 16);
   a.tiles_n = a.CoutPad / 128;
-  const size_t lds = (size_t)(PHALO + 2 * 128) * LROW * sizeof(bf16);
+  const size_t lds = ((size_t)10 * HROWP + (size_t)2 * 128 * LROW) * sizeof(bf16);
   auto kern = conv_igemm_patch_kernel<MODE>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -625,7 +835,13 @@ int gank_igemm_dispatch(IgemmArgs a, hipStream_t s) {
   const bool patch_ok = patch_env && !packed && a.ks == 3 && a.pad == 1 && (a.Cout % 4) == 0 &&
                         !(a.flags & (GANK_IN_UPSAMPLE2X | IG_IN_ZEROINS2X | IG_IN_STRIDE2)) &&
                         a.W % 16 == 0 && a.H % 8 == 0 && a.CoutPad % 128 == 0 && a.Hin == a.H && a.Win == a.W;
-  if (patch_ok) {
+  static int patch2_env = -1;  // experiment knob: GANK_IGEMM_PATCH2=0 disables the register-weight patch kernel
+  if (patch2_env < 0) { const char* e = getenv("GANK_IGEMM_PATCH2"); patch2_env = e ? atoi(e) : 1; }
+  const bool patch2_ok = patch_ok && patch2_env && (a.flags & IG_W_FRAG) && a.W % 16 == 0 && a.H % 16 == 0 && a.Cout % 128 == 0 &&
+                         a.Kpad == a.taps * a.Cin && (long)a.CoutPad * a.Kpad * 2 < (1L << 30);
+  if (patch2_ok) {
+    rc = (a.flags & GANK_IN_RELU) ? launch_patch2<1>(a, s) : launch_patch2<0>(a, s);
+  } else if (patch_ok) {
     rc = (a.flags & GANK_IN_RELU) ? launch_patch<1>(a, s) : launch_patch<0>(a, s);
   } else if (packed) {
     if (a.CoutPad % 64 == 0) rc = launch_cfg<2, 2, 1, 1, true, 1, 0>(a, s);
@@ -664,7 +880,7 @@ extern "C" int gank_conv2d_fprop(const void* x, const void* wf, const float* bia
   const bool up = flags & GANK_IN_UPSAMPLE2X;
   a.Hin = up ? H / 2 : H; a.Win = up ? W / 2 : W;
   a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.pad = (ksize - 1) / 2;
-  a.flags = flags & (GANK_IN_UPSAMPLE2X | GANK_IN_RELU | GANK_OUT_TANH);
+  a.flags = (flags & (GANK_IN_UPSAMPLE2X | GANK_IN_RELU | GANK_OUT_TANH)) | ((flags & GANK_W_FRAG) ? IG_W_FRAG : 0);
   a.scale = scale;
   return gank_igemm_dispatch(a, (hipStream_t)stream);
 }
@@ -680,7 +896,7 @@ extern "C" int gank_conv2d_dgrad(const void* dy, const void* wd, const void* res
   const bool up = flags & GANK_IN_UPSAMPLE2X;
   a.Hin = up ? H / 2 : H; a.Win = up ? W / 2 : W;
   a.Cin = Cout; a.Cout = Cin; a.ks = ksize; a.pad = (ksize - 1) / 2;
-  a.flags = flags & (GANK_IN_UPSAMPLE2X | GANK_IN_RELU);
+  a.flags = (flags & (GANK_IN_UPSAMPLE2X | GANK_IN_RELU)) | ((flags & GANK_W_FRAG) ? IG_W_FRAG : 0);
   a.scale = scale;
   return gank_igemm_dispatch(a, (hipStream_t)stream);
 }

@@ -183,6 +183,18 @@ struct PrepTable {
   int count;
 };
 
+// Fragment-major operand copy (kind 3): the 16 bytes lane l of a wave feeds to v_mfma_f32_32x32x16_bf16 as its A
+// operand are contiguous, fragments ordered [32-row tile][K-step = 64-channel chunk outer, tap inner][kk][lane], so a
+// wave loads one fragment as ONE coalesced 1 KB request straight into registers (conv_igemm_patch2_kernel).
+// row: output row of the operand matrix, k = tap*C + c its column (C = channels per tap, C % 64 == 0).
+__device__ __forceinline__ long frag_index(int row, int k, int C, int taps, int nsteps) {
+  const int tap = k / C, ch = k - tap * C;
+  const int chunk = ch >> 6, w64 = ch & 63;
+  const int kk = w64 >> 4, hh = (w64 >> 3) & 1, j = w64 & 7;
+  const int kstep = chunk * taps + tap;
+  return ((((long)(row >> 5) * nsteps + kstep) * 4 + kk) * 64 + hh * 32 + (row & 31)) * 8 + j;
+}
+
 __global__ void prep_batch_kernel(PrepTable t) {
   int e = 0;
   for (int i = 1; i < t.count; i++)
@@ -190,7 +202,7 @@ __global__ void prep_batch_kernel(PrepTable t) {
   const gank_prep_desc& d = t.d[e];
   const int b = blockIdx.x - t.first_block[e];
   const int taps = d.ksize * d.ksize;
-  if (d.kind != 0) {       // UpsampleConv / ConvMeanPool 3x3 operands
+  if (d.kind == 1 || d.kind == 2) {       // UpsampleConv / ConvMeanPool 3x3 operands
     const PrepUpArgs& q = t.up[e];
     const long total = prep_up_total(q), base = (long)b * 2048;
     for (int j = 0; j < 8; j++) {
@@ -211,7 +223,11 @@ __global__ void prep_batch_kernel(PrepTable t) {
     bf16* wf = (bf16*)d.wf;
     for (int i = ty; i < 32; i += 8) {
       const int c = c0 + i, k = k0 + tx;
-      if (c < CoutPad && k < Kpad) wf[(long)c * Kpad + k] = f2bf(tl[tx][i]);
+      if (c < CoutPad && k < Kpad) {
+        const bf16 v = f2bf(tl[tx][i]);
+        wf[(long)c * Kpad + k] = v;
+        if (d.kind == 3) wf[(long)CoutPad * Kpad + frag_index(c, k, d.Cin, taps, Kpad / 64)] = v;   // fragment-major copy
+      }
     }
   } else {
     const int Kpad2 = (taps * d.Cout + 63) / 64 * 64, CinPad = (d.Cin + 31) / 32 * 32;
@@ -228,6 +244,7 @@ __global__ void prep_batch_kernel(PrepTable t) {
         v = d.w[((long)(taps - 1 - tp) * d.Cin + ci) * d.Cout + co];
       }
       wd[i] = f2bf(v);
+      if (d.kind == 3) wd[total + frag_index(ci, k, d.Cout, taps, Kpad2 / 64)] = f2bf(v);
     }
   }
 }
@@ -241,13 +258,14 @@ extern "C" int gank_conv2d_prep_weights_batched(const gank_prep_desc* table, int
     for (int i = 0; i < t.count; i++) {
       const gank_prep_desc& d = table[base + i];
       GANK_REQUIRE(d.w && (d.wf || d.wd) && d.ksize >= 1 && d.Cin > 0 && d.Cout > 0, "prep_weights_batched: bad entry %d", base + i);
-      GANK_REQUIRE(d.kind == 0 || ((d.kind == 1 || d.kind == 2) && d.ksize == 3 && d.wf && d.wd),
-                   "prep_weights_batched: entry %d: kind %d needs ksize 3 and both outputs", base + i, d.kind);
+      GANK_REQUIRE(d.kind == 0 || ((d.kind == 1 || d.kind == 2) && d.ksize == 3 && d.wf && d.wd) ||
+                   (d.kind == 3 && d.Cin % 64 == 0 && d.Cout % 64 == 0),
+                   "prep_weights_batched: entry %d: kind %d needs ksize 3 and both outputs (1, 2) / channels %% 64 == 0 (3)", base + i, d.kind);
       t.d[i] = d;
       const int taps = d.ksize * d.ksize;
       int nwf = d.wf ? (roundup(taps * d.Cin, 64) / 32) * (roundup(d.Cout, 32) / 32) : 0;
       int nwd = d.wd ? cdiv((long)roundup(d.Cin, 32) * roundup(taps * d.Cout, 64), 2048) : 0;
-      if (d.kind != 0) {
+      if (d.kind == 1 || d.kind == 2) {
         t.up[i] = d.kind == 1 ? prep_up_args(1, d.w, d.wf, d.wd, d.Cin, d.Cout) : prep_up_args(2, d.w, d.wd, d.wf, d.Cin, d.Cout);
         nwf = 0;
         nwd = (int)cdiv(prep_up_total(t.up[i]), 2048);

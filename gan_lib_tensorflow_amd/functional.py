@@ -14,6 +14,10 @@ from torch.autograd import Function
 from . import kernels as K
 
 BF16 = torch.bfloat16
+# register-weight patch kernel (prep kind 3, GANK_W_FRAG) for the plain 3x3 convs at 16x16 / 32x32: measured equal to
+# the LDS-weight patch kernel within 2 % either way (both sit at ~75 % of what a bare MFMA loop reaches on this
+# chip under DVFS), so the simpler operand layout stays the default
+FRAG_PATCH = False
 POOL_CONV4 = True     # 3x3 conv + 2x2 mean pool as one 4x4 stride-2 conv (4 instead of 9 taps per conv output)
 PHASE_UPCONV = True   # NN-upsample+3x3 conv as a phase-decomposed transposed conv (4 instead of 9 taps)
 

@@ -6,7 +6,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, SnDesc, PrepDesc  # noqa: F401
+from ._lib import IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, W_FRAG, SnDesc, PrepDesc  # noqa: F401
 
 BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
 
@@ -49,7 +49,8 @@ def prep_weights(w, want_f=True, want_d=False):
 def prep_weights_batched(ws, want_d=True, kinds=None):
     """One launch for a list of fp32 weights ([k,k,Cin,Cout] or [Cin,Cout]).  kinds[i]: 0 = plain conv/linear ->
     `w._prep = (wf, wd)`; 1 = UpsampleConv 3x3 -> `w._prep_up = (wph, wd4)`; 2 = ConvMeanPool 3x3 ->
-    `w._prep_pool = (wp4, wphd)`; None = skip (the layer prepares nothing).  The conv wrappers pick the attributes up
+    `w._prep_pool = (wp4, wphd)`; 3 = plain + fragment-major copies for the register-weight patch kernel (the conv
+    wrappers pass GANK_W_FRAG when they see them); None = skip (the layer prepares nothing).  The conv wrappers pick the attributes up
     and skip their own per-layer preparation.  Buffers persist on the tensor and are rewritten IN PLACE on later
     calls: captured graphs keep reading the same addresses."""
     kinds = list(kinds) if kinds is not None else [0] * len(ws)
@@ -63,13 +64,19 @@ def prep_weights_batched(ws, want_d=True, kinds=None):
             k, cin, cout = w.shape[0], w.shape[2], w.shape[3]
         taps = k * k
         dev = w.device
-        if kind == 0:
+        if kind == 0 or kind == 3:
+            # kind 3: every operand is followed by its MFMA-fragment-major copy (buffers of twice the size, `_frag`)
             old = getattr(w, "_prep", None)
-            if old is not None and old[0] is not None and (old[1] is not None or not want_d):
+            if (old is not None and old[0] is not None and (old[1] is not None or not want_d)
+                    and bool(getattr(old[0], "_frag", False)) == (kind == 3)):
                 wf, wd = old
             else:
-                wf = torch.empty((_roundup(cout, 32), _roundup(taps * cin, 64)), dtype=BF16, device=dev)
-                wd = torch.empty((_roundup(cin, 32), _roundup(taps * cout, 64)), dtype=BF16, device=dev) if want_d else None
+                lead = (2,) if kind == 3 else ()
+                wf = torch.empty(lead + (_roundup(cout, 32), _roundup(taps * cin, 64)), dtype=BF16, device=dev)
+                wd = torch.empty(lead + (_roundup(cin, 32), _roundup(taps * cout, 64)), dtype=BF16, device=dev) if want_d else None
+                wf._frag = kind == 3
+                if wd is not None:
+                    wd._frag = kind == 3
         elif kind == 1:
             assert k == 3
             wf, wd = getattr(w, "_prep_up", None) or (torch.empty((4, _roundup(cout, 32), 4 * cin), dtype=BF16, device=dev),
@@ -87,7 +94,7 @@ def prep_weights_batched(ws, want_d=True, kinds=None):
     if todo:
         _lib.check(lib().gank_conv2d_prep_weights_batched(table, len(todo), _stream()), "prep_weights_batched")
     for (w, kind), o in zip(todo, outs):
-        setattr(w, ("_prep", "_prep_up", "_prep_pool")[kind], o)
+        setattr(w, ("_prep", "_prep_up", "_prep_pool", "_prep")[kind], o)
     return outs
 
 
@@ -95,6 +102,8 @@ def conv2d_fprop(x, wf, bias, out_hw, cout, ksize, flags=0, scale=1.0, residual=
     n, cin = x.shape[0], x.shape[3]
     h, w = out_hw
     y = torch.empty((n, h, w, cout), dtype=BF16, device=x.device)
+    if getattr(wf, "_frag", False):
+        flags |= W_FRAG
     _lib.check(lib().gank_conv2d_fprop(_p(x, BF16, "x"), _p(wf, BF16, "wf"), _p(bias, F32, "bias"),
                                        _p(residual, BF16, "residual"), _p(relu_ref, BF16, "relu_ref"), _p(y),
                                        n, h, w, cin, cout, ksize, flags, scale, _stream()), "conv2d_fprop")
@@ -105,6 +114,8 @@ def conv2d_dgrad(dy, wd, out_hw, cin, ksize, flags=0, scale=1.0, residual=None, 
     n, cout = dy.shape[0], dy.shape[3]
     h, w = out_hw
     dx = torch.empty((n, h, w, cin), dtype=BF16, device=dy.device)
+    if getattr(wd, "_frag", False):
+        flags |= W_FRAG
     _lib.check(lib().gank_conv2d_dgrad(_p(dy, BF16, "dy"), _p(wd, BF16, "wd"), _p(residual, BF16, "residual"),
                                        _p(relu_ref, BF16, "relu_ref"), _p(dx), n, h, w, cin, cout, ksize, flags,
                                        scale, _stream()), "conv2d_dgrad")

@@ -34,6 +34,7 @@ extern "C" {
 #define GANK_IN_RELU 2         /* relu applied to the input operand while staging                     */
 #define GANK_OUT_TANH 4        /* tanh applied last in the epilogue                                   */
 #define GANK_DY_UPSAMPLE2X 8   /* wgrad only: dy is [N,H/2,W/2,Cout] (gradient of a 2x2 mean pool)    */
+#define GANK_W_FRAG 32         /* fprop/dgrad: the operand buffer carries the fragment-major copy (prep kind 3) */
 
 int gank_version(void);
 const char* gank_last_error(void);
@@ -52,7 +53,9 @@ typedef struct gank_prep_desc {
   void* wd;       /* kind 0: bf16 [CinPad][Kpad'] or NULL;  kind 1: wd4;  kind 2: wphd  (the dgrad operand) */
   int ksize, Cin, Cout;
   int kind;       /* 0 plain conv/linear; 1 UpsampleConv 3x3 (gank_upconv3x3_prep_weights layouts);
-                     2 ConvMeanPool 3x3 (gank_convpool3x3_prep_weights layouts) */
+                     2 ConvMeanPool 3x3 (gank_convpool3x3_prep_weights layouts);
+                     3 plain + a second, MFMA-fragment-major copy right after each row-major operand (buffers of
+                       twice the size; Cin % 64 == 0 and Cout % 64 == 0): pass GANK_W_FRAG to fprop / dgrad */
 } gank_prep_desc;
 int gank_conv2d_prep_weights_batched(const gank_prep_desc* table, int count, void* stream);
 

@@ -11,6 +11,8 @@ xh = torch.randn(n, h // 2, h // 2, cin, device="cuda").to(torch.bfloat16)
 dy = torch.randn(n, h, h, cout, device="cuda").to(torch.bfloat16)
 dyp = torch.randn(n, h // 2, h // 2, cout, device="cuda").to(torch.bfloat16)
 wf, wd = K.prep_weights(w, True, True)
+if os.environ.get("MICRO_FRAG", "0") == "1":
+    (wf, wd), = K.prep_weights_batched([w], want_d=True, kinds=[3])
 dw = torch.zeros_like(w)
 torch.cuda.synchronize()
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
