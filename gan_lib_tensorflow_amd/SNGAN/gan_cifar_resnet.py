@@ -16,6 +16,8 @@ MI355X-first structure
     per update cost one graph launch.  The RNG is counter-based with device-side state, so replays
     draw fresh noise / labels / dequantisation.
 """
+import contextlib
+import gc
 import math
 
 import numpy as np
@@ -146,6 +148,21 @@ class AdamTF:
     def apply(self):
         f = self.flat
         K.adam_tf(f["params"], f["grads"], f["m"], f["v"], self.hp, self.t, self.iteration)
+
+
+@contextlib.contextmanager
+def _capture(graph):
+    """hipGraph capture with the Python garbage collector paused: a cyclic-GC pass in the middle of a capture can
+    destroy an older trainer's CUDAGraph / return its pool memory while the stream is capturing, which aborts the
+    process (torch only collects once, on entry)."""
+    was = gc.isenabled()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        gc.disable()
+        try:
+            yield
+        finally:
+            if was:
+                gc.enable()
 
 
 class SNGANTrainer:
@@ -299,14 +316,14 @@ class SNGANTrainer:
             try:
                 # thread_local: the RCCL watchdog thread polls events concurrently when world > 1
                 g1 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                with _capture(g1):
                     fwd_bwd()
                     if self.world == 1:
                         opt.apply()
                 g2 = None
                 if self.world > 1:
                     g2 = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+                    with _capture(g2):
                         opt.apply()
                 self._graphs[key] = (g1, g2)
             except Exception as e:  # noqa: BLE001 -- capture is an optimisation, never a correctness need
@@ -335,7 +352,7 @@ class SNGANTrainer:
             torch.cuda.synchronize()
             try:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                with _capture(g):
                     fn()
                 self._graphs[key] = (g, None)
             except Exception as e:  # noqa: BLE001

@@ -361,15 +361,21 @@ constexpr int PHALO = 180;   // 10 x 18 halo pixels
 // conflict-free slot permutation across the row change.
 constexpr int HROWP = 1408;  // 2816 B = 11 x 256 B  (>= 18 * LROW = 1296)
 
-template <int MODE>   // bit0: relu on the input operand
+// BN = 128: 2 x 2 waves of 64 pixels x 64 couts.  BN = 32: 4 x 1 waves of 32 pixels x 32 couts, for the 3-channel
+// output conv of the generator (G.Output 256 -> 3, padded to one 32-row MFMA tile): the generic 256x32 kernel
+// re-fetched the 256-channel pixel operand per tap; here it is staged once per chunk like any other 3x3 conv.
+template <int MODE, int BN>   // MODE bit0: relu on the input operand
 __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
-  constexpr int NT = 256, BN = 128;
+  constexpr int NT = 256;
+  constexpr int WN = BN == 128 ? 2 : 1, WM = 4 / WN, TN = BN / (32 * WN), TM = 4 / WM;   // wave tile TM x TN MFMA tiles
+  constexpr int CW = BN * 8 / NT;                       // weight chunks per thread per step
+  static_assert(BN == 128 || BN == 32, "cout tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16* sP = reinterpret_cast<bf16*>(smem);             // [10][HROWP]  (single buffer; pixel stride LROW inside a row)
   bf16* sW = sP + 10 * HROWP;                           // [2][BN][LROW]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wave_m = wave & 1, wave_n = wave >> 1;      // 2 x 2 waves, each 64 pixels x 64 couts
+  const int wave_m = wave % WM, wave_n = wave / WM;
   const int r = lane & 31, h = lane >> 5;
 
   const int nwg = a.tiles_m * a.tiles_n;
@@ -394,21 +400,21 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
     h_off[j] = ok ? (((n * a.H + iy) * a.W + ix) * a.Cin + cc * 8) * 2 : OOB;
     h_lds[j] = (q < PHALO * 8) ? (hp / 18) * HROWP + (hp % 18) * LROW + cc * 8 : -1;
   }
-  int w_off[4];
+  int w_off[CW];
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
+  for (int j = 0; j < CW; j++) {
     const int q = tid + NT * j;
     w_off[j] = ((tile_n * BN + (q >> 3)) * a.Kpad + (q & 7) * 8) * 2;
   }
 
-  u32x4 rH[6], rW[4];
+  u32x4 rH[6], rW[CW];
   const int nchunks = a.Cin >> 6;
   const int last = nchunks * 9 - 1;
   int wcur = 0, wtap = 0, wc0 = 0;      // weight cursor (chunk outer, tap inner): k offset = tap*Cin + c0
   auto load_w = [&]() {
     const int wk = (wtap * a.Cin + wc0) * 2;
 #pragma unroll
-    for (int j = 0; j < 4; j++) rW[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off[j], wk, 0);
+    for (int j = 0; j < CW; j++) rW[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off[j], wk, 0);
     if (wcur < last) {
       wcur++;
       if (++wtap == 9) { wtap = 0; wc0 += 64; }
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
   };
   auto store_w = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < CW; j++) {
       const int q = tid + NT * j;
       *reinterpret_cast<u32x4*>(sW + (buf * BN + (q >> 3)) * LROW + (q & 7) * 8) = rW[j];
     }
@@ -437,19 +443,19 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TN][TM];
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < TN; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < TM; j++)
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
   // B-fragment base of this lane inside the halo image: pixel (wave_m*4 + 2j + (r>>4), r&15), centre tap
-  int pb[2];
+  int pb[TM];
 #pragma unroll
-  for (int j = 0; j < 2; j++) pb[j] = (wave_m * 4 + 2 * j + (r >> 4) + 1) * HROWP + ((r & 15) + 1) * LROW + h * 8;
-  const int ab = (wave_n * 64 + r) * LROW + h * 8;
+  for (int j = 0; j < TM; j++) pb[j] = (wave_m * 2 * TM + 2 * j + (r >> 4) + 1) * HROWP + ((r & 15) + 1) * LROW + h * 8;
+  const int ab = (wave_n * TN * 32 + r) * LROW + h * 8;
 
   load_halo(0);
   load_w();                 // step 0
@@ -469,15 +475,15 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
       const bf16* pW = sW + buf * BN * LROW + ab;
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) {
-        bf16x8 fa[2], fb[2];
+        bf16x8 fa[TN], fb[TM];
 #pragma unroll
-        for (int i = 0; i < 2; i++) fa[i] = *reinterpret_cast<const bf16x8*>(pW + i * 32 * LROW + kk * 16);
+        for (int i = 0; i < TN; i++) fa[i] = *reinterpret_cast<const bf16x8*>(pW + i * 32 * LROW + kk * 16);
 #pragma unroll
-        for (int j = 0; j < 2; j++) fb[j] = *reinterpret_cast<const bf16x8*>(sP + pb[j] + toff + kk * 16);
+        for (int j = 0; j < TM; j++) fb[j] = *reinterpret_cast<const bf16x8*>(sP + pb[j] + toff + kk * 16);
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < TN; i++)
 #pragma unroll
-          for (int j = 0; j < 2; j++)
+          for (int j = 0; j < TM; j++)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
       if (s < last) store_w(buf ^ 1);
@@ -492,13 +498,14 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
 
   // epilogue (same order as the generic kernel): lane holds channels co0+8g+4h..+3 of one pixel per quad
   const bool otanh = (a.flags & GANK_OUT_TANH) != 0;
+  const bool vec = (a.Cout & 3) == 0;
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
-    const int py = wave_m * 4 + 2 * j + (r >> 4), px = r & 15;
+  for (int j = 0; j < TM; j++) {
+    const int py = wave_m * 2 * TM + 2 * j + (r >> 4), px = r & 15;
     const long m = ((long)(n * a.H + py0 + py)) * a.W + px0 + px;
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-      const int co0 = tile_n * BN + (wave_n * 2 + i) * 32 + 4 * h;
+    for (int i = 0; i < TN; i++) {
+      const int co0 = tile_n * BN + (wave_n * TN + i) * 32 + 4 * h;
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         const int co = co0 + 8 * g;
@@ -507,6 +514,18 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * g + e] * a.scale;
         const long o = m * a.Cout + co;
+        if (!vec) {          // narrow outputs (Cout = 3): element-wise tail
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            if (co + e >= a.Cout) break;
+            float t = v[e];
+            if (a.bias) t += a.bias[co + e];
+            if (a.mask) t = (bf2f(a.mask[o + e]) > 0.f) ? t : 0.f;
+            if (a.res) t += bf2f(a.res[o + e]);
+            a.y[o + e] = f2bf(otanh ? tanhf(t) : t);
+          }
+          continue;
+        }
         if (a.bias) {
           const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + co);
 #pragma unroll
@@ -739,13 +758,136 @@ static int launch_patch2(const IgemmArgs& a0, hipStream_t s) {
   return 0;
 }
 
-template <int MODE>
+// ------------------------------------------------------------------------------------------------------
+// Narrow-input convolutions: Cin <= 4 with taps*Cin <= 32 -- the image side of the critic (D.Block.1.Conv1 3->128
+// 3x3, D.Block.1.Shortcut 3->128 1x1, gan_cifar_resnet.py:212-234) and the input gradient of G.Output (3 <- 256).
+// The whole reduction is ONE 32-deep MFMA K-step, so there is nothing to pipeline and nothing to share: no LDS,
+// no barriers.  A wave owns 32 pixels x 128 couts; each lane gathers its own 16 im2col values (2-byte loads from a
+// tensor that lives in L1/L2: 6 KB per image) and reads its weight fragments straight from the row-major operand.
+// The kernel is bound by writing the output (33.5 MB for D.Block.1.Conv1 at N=128); the K-packed generic path spent
+// 45-55 us per call in per-element index arithmetic for it, this one a few microseconds above the write time.
+// ------------------------------------------------------------------------------------------------------
+template <int KS, int CIN>
+__global__ __launch_bounds__(256) void conv_narrow_in_kernel(IgemmArgs a) {
+  constexpr int TAPS = KS * KS, KTOT = TAPS * CIN, PAD = (KS - 1) / 2;
+  static_assert(KTOT <= 32, "one 32-deep K-step");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int tile_n = blockIdx.x % a.tiles_n, tile_m = blockIdx.x / a.tiles_n;
+  const int m = tile_m * 128 + wave * 32 + r;
+  const bool inrelu = (a.flags & GANK_IN_RELU) != 0;
+
+  int n = 0, oh = 0, ow = 0;
+  if (m < a.M) pix_decomp(m, a.H, a.W, a.shw, a.sw, n, oh, ow);
+  // B fragments: k = kk*16 + 8h + j  ->  (tap, c) = (k / CIN, k % CIN)
+  bf16x8 fb[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; kk++) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int k = kk * 16 + 8 * h + j;            // h is runtime: (tap, c) need real arithmetic, CIN / KS are constants
+      const int tap = k / CIN, c = k - tap * CIN;
+      const int ih = oh + tap / KS - PAD, iw = ow + tap % KS - PAD;
+      const bool ok = m < a.M && k < KTOT && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+      bf16 v = f2bf(0.f);
+      if (ok) v = a.x[((long)(n * a.H + ih) * a.W + iw) * CIN + c];
+      if (inrelu && bf2f(v) < 0.f) v = f2bf(0.f);
+      fb[kk][j] = v;
+    }
+  }
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[i][e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const bf16* wr = a.w + (long)(tile_n * 128 + i * 32 + r) * a.Kpad + h * 8;     // rows < CoutPad (CoutPad % 128 == 0)
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      const bf16x8 fa = *reinterpret_cast<const bf16x8*>(wr + kk * 16);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[kk], acc[i], 0, 0, 0);
+    }
+  }
+  // Epilogue.  The accumulator layout (lane = pixel, registers = channels) would store 8 bytes per lane into 64
+  // different rows per instruction; this kernel is bound by its output write, so the wave's 32 x 128 tile is turned
+  // through LDS and leaves as whole 256-byte channel rows (64 lanes x 16 B = 4 pixels per store instruction).
+  __shared__ __attribute__((aligned(16))) bf16 sO[4][32][136];      // 272-B rows: conflict-free 8-B writes / 16-B reads
+  const bool otanh = (a.flags & GANK_OUT_TANH) != 0;
+  const bool fast = (a.Cout - tile_n * 128) >= 128 && !a.mask && !a.res;   // full 128-channel tile, bias/tanh only
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int co0 = tile_n * 128 + i * 32 + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const int co = co0 + 8 * g;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) v[e] = acc[i][4 * g + e] * a.scale;
+      if (fast) {
+        if (a.bias) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += b[e];
+        }
+        bf16x4 out;
+#pragma unroll
+        for (int e = 0; e < 4; e++) out[e] = f2bf(otanh ? tanhf(v[e]) : v[e]);
+        *reinterpret_cast<bf16x4*>(&sO[wave][r][i * 32 + 8 * g + 4 * h]) = out;
+      } else if (m < a.M && co < a.Cout) {
+        const long o = (long)m * a.Cout + co;
+        if (a.bias) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += b[e];
+        }
+        if (a.mask) {
+          const bf16x4 mk = *reinterpret_cast<const bf16x4*>(a.mask + o);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = (bf2f(mk[e]) > 0.f) ? v[e] : 0.f;
+        }
+        if (a.res) {
+          const bf16x4 rs = *reinterpret_cast<const bf16x4*>(a.res + o);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += bf2f(rs[e]);
+        }
+        bf16x4 out;
+#pragma unroll
+        for (int e = 0; e < 4; e++) out[e] = f2bf(otanh ? tanhf(v[e]) : v[e]);
+        *reinterpret_cast<bf16x4*>(a.y + o) = out;
+      }
+    }
+  }
+  if (fast) {                       // block-uniform
+    __syncthreads();
+    const int m0 = tile_m * 128 + wave * 32;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int idx = it * 64 + lane, row = idx >> 4, c16 = idx & 15;
+      if (m0 + row < a.M)
+        *reinterpret_cast<u32x4*>(a.y + (long)(m0 + row) * a.Cout + tile_n * 128 + c16 * 8) =
+            *reinterpret_cast<const u32x4*>(&sO[wave][row][c16 * 8]);
+    }
+  }
+}
+
+template <int KS, int CIN>
+static int launch_narrow_in(const IgemmArgs& a0, hipStream_t s) {
+  IgemmArgs a = a0;
+  a.tiles_m = cdiv(a.M, 128);
+  a.tiles_n = a.CoutPad / 128;
+  hipLaunchKernelGGL((conv_narrow_in_kernel<KS, CIN>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
+  GANK_LAUNCH_OK("conv_narrow_in");
+  return 0;
+}
+
+template <int MODE, int BN>
 static int launch_patch(const IgemmArgs& a0, hipStream_t s) {
   IgemmArgs a = a0;
   a.tiles_m = a.N * (a.H / 8) * (a.W / 16);
-  a.tiles_n = a.CoutPad / 128;
-  const size_t lds = ((size_t)10 * HROWP + (size_t)2 * 128 * LROW) * sizeof(bf16);
-  auto kern = conv_igemm_patch_kernel<MODE>;
+  a.tiles_n = a.CoutPad / BN;
+  const size_t lds = ((size_t)10 * HROWP + (size_t)2 * BN * LROW) * sizeof(bf16);
+  auto kern = conv_igemm_patch_kernel<MODE, BN>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -832,17 +974,25 @@ int gank_igemm_dispatch(IgemmArgs a, hipStream_t s) {
   if (pf_env < 0) { const char* e = getenv("GANK_IGEMM_PF"); pf_env = e ? atoi(e) : 0; }
   static int patch_env = -1;   // experiment knob: GANK_IGEMM_PATCH=0 disables the LDS-patch kernel
   if (patch_env < 0) { const char* e = getenv("GANK_IGEMM_PATCH"); patch_env = e ? atoi(e) : 1; }
-  const bool patch_ok = patch_env && !packed && a.ks == 3 && a.pad == 1 && (a.Cout % 4) == 0 &&
-                        !(a.flags & (GANK_IN_UPSAMPLE2X | IG_IN_ZEROINS2X | IG_IN_STRIDE2)) &&
-                        a.W % 16 == 0 && a.H % 8 == 0 && a.CoutPad % 128 == 0 && a.Hin == a.H && a.Win == a.W;
+  const bool patch_geom = patch_env && !packed && a.ks == 3 && a.pad == 1 &&
+                          !(a.flags & (GANK_IN_UPSAMPLE2X | IG_IN_ZEROINS2X | IG_IN_STRIDE2)) &&
+                          a.W % 16 == 0 && a.H % 8 == 0 && a.Hin == a.H && a.Win == a.W;
+  const bool patch_ok = patch_geom && (a.Cout % 4) == 0 && a.CoutPad % 128 == 0;
+  const bool patch32_ok = patch_geom && a.CoutPad == 32;
   static int patch2_env = -1;  // experiment knob: GANK_IGEMM_PATCH2=0 disables the register-weight patch kernel
   if (patch2_env < 0) { const char* e = getenv("GANK_IGEMM_PATCH2"); patch2_env = e ? atoi(e) : 1; }
   const bool patch2_ok = patch_ok && patch2_env && (a.flags & IG_W_FRAG) && a.W % 16 == 0 && a.H % 16 == 0 && a.Cout % 128 == 0 &&
                          a.Kpad == a.taps * a.Cin && (long)a.CoutPad * a.Kpad * 2 < (1L << 30);
-  if (patch2_ok) {
+  const bool narrow_ok = a.Cin == 3 && (a.ks == 1 || a.ks == 3) && a.pad == (a.ks - 1) / 2 && a.CoutPad % 128 == 0 && a.Cout % 4 == 0 &&
+                         !(a.flags & (GANK_IN_UPSAMPLE2X | IG_IN_ZEROINS2X | IG_IN_STRIDE2)) && a.Hin == a.H && a.Win == a.W;
+  if (narrow_ok) {
+    rc = a.ks == 3 ? launch_narrow_in<3, 3>(a, s) : launch_narrow_in<1, 3>(a, s);
+  } else if (patch2_ok) {
     rc = (a.flags & GANK_IN_RELU) ? launch_patch2<1>(a, s) : launch_patch2<0>(a, s);
   } else if (patch_ok) {
-    rc = (a.flags & GANK_IN_RELU) ? launch_patch<1>(a, s) : launch_patch<0>(a, s);
+    rc = (a.flags & GANK_IN_RELU) ? launch_patch<1, 128>(a, s) : launch_patch<0, 128>(a, s);
+  } else if (patch32_ok) {
+    rc = (a.flags & GANK_IN_RELU) ? launch_patch<1, 32>(a, s) : launch_patch<0, 32>(a, s);
   } else if (packed) {
     if (a.CoutPad % 64 == 0) rc = launch_cfg<2, 2, 1, 1, true, 1, 0>(a, s);
     else rc = launch_cfg<4, 1, 2, 1, true, 1, 0>(a, s);

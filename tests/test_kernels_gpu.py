@@ -69,6 +69,11 @@ CONV_CASES = [
     (5, 1, 300, 128, 1, ""),          # D.Embedding_y linear (K=300 packed)
     (7, 1, 128, 1, 1, ""),            # D.Output linear
     (3, 6, 64, 96, 3, ""),            # non power-of-two spatial size, Cout=96 (3 tiles of 32)
+    (2, 16, 256, 3, 3, "tanh"),       # G.Output through the 32-cout patch kernel (W % 16 == 0)
+    (3, 32, 64, 3, 3, "relu"),
+    (4, 32, 3, 128, 3, ""),           # narrow-input kernel at the real D.Block.1.Conv1 geometry
+    (4, 16, 3, 256, 1, ""),           # narrow-input 1x1
+    (1, 5, 3, 128, 3, "relu"),        # narrow-input, ragged pixel count (25 pixels)
 ]
 
 
@@ -103,7 +108,8 @@ def test_conv_fprop(K, n, h, cin, cout, k, mode):
 
 @pytest.mark.parametrize("n,h,cin,cout,k,mode", [
     (2, 8, 64, 64, 3, ""), (2, 8, 128, 256, 3, "mask"), (2, 8, 64, 128, 1, ""), (2, 8, 128, 128, 3, "pool"),
-    (2, 8, 256, 3, 3, ""),       # dgrad of G.Output: Cout=3 -> packed K
+    (2, 8, 256, 3, 3, ""),       # dgrad of G.Output: Cout=3 -> narrow-input kernel with 256 output rows
+    (3, 32, 128, 3, 3, "mask"),
     (2, 8, 3, 128, 3, ""),       # dgrad of D.Block.1.Conv1: output 3 channels
     (4, 1, 300, 128, 1, ""), (4, 1, 128, 1, 1, ""),
 ])

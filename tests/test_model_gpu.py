@@ -3,6 +3,7 @@ the C ABI) vs the torch-CPU float64 oracle on identical parameters and inputs, p
 golden vectors.  Tolerances are for the bf16 compute path against a float64 restatement of the
 fp32 reference: images (tanh range) |d| <= 0.03; logits |d| <= 0.06*max(1,|ref|); gradients
 max|d| <= 6e-2 * max|ref| per tensor."""
+import gc
 import os
 
 import numpy as np
@@ -236,3 +237,6 @@ def test_graph_replay_stays_finite_with_poisoned_workspaces(gpu, monkeypatch):
         assert tr.use_graphs, "graph capture fell back to eager"
         for flat in (tr.g_flat, tr.d_flat):
             assert bool(torch.isfinite(flat["params"]).all()) and bool(torch.isfinite(flat["grads"]).all())
+        del tr, feed
+        gc.collect()
+        torch.cuda.synchronize()
