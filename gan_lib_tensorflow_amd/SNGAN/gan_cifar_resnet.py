@@ -80,6 +80,9 @@ def Generator(n_samples_, labels, noise=None, reuse=False, groups=1, rng_state=N
         return output.reshape(-1, OUTPUT_DIM)
 
 
+SIDE_STREAM_WGRAD = False    # filter gradients on a second HIP stream: measured 6 % SLOWER per iteration (the branches contend for L2 and CUs), kept for experiments
+
+
 def _d_prep_kind(name, W):
     """MFMA operand layout per critic weight (kernels.prep_weights_batched): the two ConvMeanPool 3x3 layers run as
     4x4 stride-2 convs, the two small dense layers read their fp32 weight directly."""
@@ -183,6 +186,8 @@ class SNGANTrainer:
             import torch.distributed as dist
             self.world, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
         self.use_graphs = use_graphs
+        self.side_stream = SIDE_STREAM_WGRAD
+        self._side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         # data-side RNG differs per rank; parameter init (store seed) is identical on all ranks
         self.rng_state = K.new_rng_state(parallel.data_seed(seed, self.rank), self.device)
         self.iteration = 0
@@ -251,7 +256,7 @@ class SNGANTrainer:
             both_labels = torch.cat([self.real_labels, self.real_labels], 0)
         logits, _ = Discriminator(both, both_labels, update_collection=None)
         loss = Fn.hinge_d_loss(logits, b)
-        loss.backward()
+        self._backward(loss)
         K.copy_(self.d_loss, loss.detach())
         return logits
 
@@ -284,12 +289,21 @@ class SNGANTrainer:
         try:
             logits, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS)
             loss = Fn.hinge_g_loss(logits)
-            loss.backward()
+            self._backward(loss)
         finally:
             for p in d_params:
                 p.requires_grad_(True)
         K.copy_(self.g_loss, loss.detach())
         return logits
+
+    def _backward(self, loss):
+        """loss.backward() with the filter gradients on the side stream, joined before anything reads them."""
+        Fn.set_wgrad_stream(self._side if self.side_stream else None)
+        try:
+            loss.backward()
+            Fn.join_wgrad()
+        finally:
+            Fn.set_wgrad_stream(None)
 
     def _allreduce(self, flat):
         if self.world > 1:

@@ -42,6 +42,31 @@ void gank_prof_end(int family, hipStream_t s) {
 
 extern "C" int gank_prof_enable(int on) { g_on = on != 0; return 0; }
 
+// What an event pair costs by itself: n launches of an empty kernel, each between its own pair, average ms per pair.
+// bench.py reports it next to the family times (an event pair reads a few microseconds longer than the kernel's own
+// begin-to-end time that rocprofv3 reports).
+__global__ void prof_empty_kernel() {}
+extern "C" double gank_prof_calibrate(int n, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n <= 0) return 0.0;
+  std::vector<Rec> recs(n);
+  for (auto& r : recs) {
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1.0;
+    hipEventRecord(r.a, s);
+    hipLaunchKernelGGL(prof_empty_kernel, dim3(1), dim3(64), 0, s);
+    hipEventRecord(r.b, s);
+  }
+  double ms = 0;
+  for (auto& r : recs) {
+    float t = 0.f;
+    hipEventSynchronize(r.b);
+    hipEventElapsedTime(&t, r.a, r.b);
+    ms += t;
+    hipEventDestroy(r.a); hipEventDestroy(r.b);
+  }
+  return ms / n;
+}
+
 extern "C" int gank_prof_reset(void) {
   for (int f = 0; f < kFamilies; f++) {
     for (auto& r : g_recs[f]) { hipEventDestroy(r.a); hipEventDestroy(r.b); }

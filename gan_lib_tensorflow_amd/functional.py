@@ -22,6 +22,38 @@ POOL_CONV4 = True     # 3x3 conv + 2x2 mean pool as one 4x4 stride-2 conv (4 ins
 PHASE_UPCONV = True   # NN-upsample+3x3 conv as a phase-decomposed transposed conv (4 instead of 9 taps)
 
 
+class _Side:
+    """Filter gradients on a second HIP stream.  A filter gradient only feeds the optimiser (or the batched spectral
+    norm backward), never the next layer's backward, so it can overlap the input-gradient chain: small layers
+    leave most CUs idle (one workgroup per CU at best) and their wgrad kernels fill them.  Under hipGraph capture
+    the fork/join becomes parallel branches of the graph.  Operands are kept alive until the join: the caching
+    allocator could otherwise hand their memory to a later main-stream kernel while the side stream still reads it."""
+    stream = None
+    keep = []
+
+
+def set_wgrad_stream(stream):
+    _Side.stream = stream
+
+
+def _on_side(fn, *operands):
+    st = _Side.stream
+    if st is None:
+        fn()
+        return
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        fn()
+    _Side.keep.append(operands)
+
+
+def join_wgrad():
+    """Main stream waits for every filter gradient issued so far (before the optimiser / the SN backward)."""
+    if _Side.stream is not None and _Side.keep:
+        torch.cuda.current_stream().wait_stream(_Side.stream)
+        _Side.keep.clear()
+
+
 def _target(p):
     """Where a weight gradient is written: (buffer, accumulated_in_place).  `main_grad` = view of the
     network's flat gradient buffer (autograd gets None); `_grad_buf` = pre-zeroed view handed out by a
@@ -99,12 +131,13 @@ class _Conv2d(Function):
             db = None if bacc else btgt
         if ctx.needs_input_grad[1] and pool4:
             tgt, acc = _target(W)
-            K.convpool3x3_wgrad(x, g, tgt.view(3, 3, cin, cout), K.IN_RELU if in_relu else 0, dbias=btgt)
+            _on_side(lambda: K.convpool3x3_wgrad(x, g, tgt.view(3, 3, cin, cout), K.IN_RELU if in_relu else 0, dbias=btgt), x, g)
             dW = None if acc else tgt
         elif ctx.needs_input_grad[1]:
             tgt, acc = _target(W)
             wflags = (K.IN_UPSAMPLE2X if upsample else 0) | (K.IN_RELU if in_relu else 0) | (K.DY_UPSAMPLE2X if pool_out else 0)
-            K.conv2d_wgrad(x, g, tgt, (H, Wd), k, wflags, scale, dbias=btgt)   # bias gradient rides on the dy stream
+            # bias gradient rides on the dy stream
+            _on_side(lambda: K.conv2d_wgrad(x, g, tgt, (H, Wd), k, wflags, scale, dbias=btgt), x, g)
             dW = None if acc else tgt
         elif btgt is not None:
             K.colsum(g, btgt, 1.0)
@@ -181,6 +214,7 @@ class _SpectralNorm(Function):
 
     @staticmethod
     def backward(ctx, *gs):
+        join_wgrad()          # the dW_bar buffers are written by the filter-gradient stream
         batch = ctx.batch
         tgts, rets, gl = [], [], []
         for W, g, wb in zip(batch.weights, gs, batch.W_bar):

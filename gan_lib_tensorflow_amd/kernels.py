@@ -536,3 +536,8 @@ def prof_collect(family):
     ms, fl = C.c_double(0), C.c_double(0)
     n = lib().gank_prof_collect(family, C.byref(ms), C.byref(fl))
     return n, ms.value, fl.value
+
+
+def prof_calibrate(n=200):
+    """average ms an event pair around an empty kernel reads (the fixed cost inside every profiler record)"""
+    return float(lib().gank_prof_calibrate(int(n), _stream()))

@@ -257,6 +257,8 @@ int gank_prof_reset(void);
 /* fills up to `cap` records {launches, total_ms, total_flops} for kernel family `family`
  * (0 = conv_fprop/dgrad igemm, 1 = conv_wgrad); synchronises.  Returns number of launches. */
 int gank_prof_collect(int family, double* total_ms, double* total_flops);
+/* average milliseconds an event pair around an EMPTY kernel reads (n launches): the fixed cost inside every record */
+double gank_prof_calibrate(int n, void* stream);
 
 /* debug: what ds_read_b64_tr_b16 delivers for a known LDS image (layout self-check) */
 int gank_debug_tr_probe(int32_t* out, void* stream);
