@@ -206,7 +206,7 @@ class SNGANTrainer:
         if state is not None:
             self.store.load_state_dict(state)
         self.g_flat = self.store.flatten('Generator')
-        self.d_flat = self.store.flatten('Discriminator')
+        self.d_flat = self.store.flatten('Discriminator', scratch_tail=True)
         self.store.flatten_state('Discriminator')      # the 12 SN u vectors: one buffer
         # bf16 MFMA operand copies of the generator weights: rebuilt by ONE launch after each G update
         # (the generator runs 6 forwards per iteration on unchanged weights)
@@ -223,7 +223,11 @@ class SNGANTrainer:
         self.real_all = torch.zeros((N_CRITIC, b, OUTPUT_DIM), dtype=torch.uint8, device=self.device)
         self.labels_all = torch.zeros((N_CRITIC, b), dtype=torch.int32, device=self.device)
         self.fake_all = torch.zeros((N_CRITIC, b, OUTPUT_DIM), dtype=torch.bfloat16, device=self.device)
-        self.fake_one = torch.zeros((b, OUTPUT_DIM), dtype=torch.bfloat16, device=self.device)
+        # the critic's input of one update, laid out by ONE launch from slot `feed_slot` of the ring above
+        self.both = torch.zeros((2 * b, OUTPUT_DIM), dtype=torch.bfloat16, device=self.device)
+        self.both_labels = torch.zeros(2 * b, dtype=torch.int32, device=self.device)
+        self.feed_slot = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.feed_done = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.d_loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.g_loss = torch.zeros(1, dtype=torch.float32, device=self.device)
 
@@ -254,14 +258,25 @@ class SNGANTrainer:
             real = K.preprocess_real(self.real_u8, self.rng_state).reshape(b, OUTPUT_DIM) if real_pre is None else real_pre
             both = torch.cat([real, fake], 0)                          # plumbing: device memcpy
             both_labels = torch.cat([self.real_labels, self.real_labels], 0)
-        logits, _ = Discriminator(both, both_labels, update_collection=None)
+        with _sn.grad_scratch(self.d_flat["scratch"]):        # zeroed by zero_grads above
+            logits, _ = Discriminator(both, both_labels, update_collection=None)
         loss = Fn.hinge_d_loss(logits, b)
         self._backward(loss)
         K.copy_(self.d_loss, loss.detach())
         return logits
 
     def _d_forward_backward_prefetched(self):
-        return self._d_forward_backward(fake=self.fake_one)
+        """Critic update number `feed_slot` of the iteration: inputs come from the feed ring by one launch."""
+        set_default_store(self.store)
+        self.store.zero_grads('Discriminator')
+        K.critic_feed(self.real_all, self.labels_all, self.fake_all, self.both, self.both_labels, self.feed_slot,
+                      self.rng_state, self.feed_done)
+        with _sn.grad_scratch(self.d_flat["scratch"]):        # zeroed by zero_grads above
+            logits, _ = Discriminator(self.both, self.both_labels, update_collection=None)
+        loss = Fn.hinge_d_loss(logits, self.batch)
+        self._backward(loss)
+        K.copy_(self.d_loss, loss.detach())
+        return logits
 
     @torch.no_grad()
     def _generate_for_critic(self):
@@ -400,10 +415,7 @@ class SNGANTrainer:
             self.real_all[i].copy_(data, non_blocking=True)
             self.labels_all[i].copy_(labels, non_blocking=True)
         self._run_plain('gen5', self._generate_for_critic)
-        for i in range(N_CRITIC):
-            K.copy_(self.real_u8, self.real_all[i])
-            K.copy_(self.real_labels, self.labels_all[i])
-            K.copy_(self.fake_one, self.fake_all[i])
+        for i in range(N_CRITIC):      # slot i of the feed ring: the device-side slot counter walks 0..N_CRITIC-1
             self._run('d_pre', self._d_forward_backward_prefetched, self.d_opt, self.d_flat)
         self.iteration += 1
         K.counter_add(self.iteration_dev, 1)

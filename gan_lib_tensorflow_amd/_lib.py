@@ -16,7 +16,7 @@ IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, W_FRAG = 1, 2, 4, 8, 32
 class SnDesc(C.Structure):
     """gank_sn_desc"""
     _fields_ = [(n, P) for n in ("W", "u_in", "u_out", "v", "W_bar", "scal", "a", "b", "bpart",
-                                 "dW_bar", "dW", "rowdot", "ga")] + \
+                                 "dW_bar", "dW", "rowdot", "ga", "u_snap")] + \
                [("K", I), ("C", I), ("row_offset", I), ("chunk_offset", I)]
 
 
@@ -81,6 +81,7 @@ PROTOTYPES = {
     "gank_prof_reset": [],
     "gank_prof_collect": [I, C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "gank_prof_calibrate": [I, P],
+    "gank_critic_feed": [P, P, P, P, P, P, P, P, I, I, P],
     "gank_debug_tr_probe": [P, P],
 }
 _RET = {"gank_last_error": C.c_char_p, "gank_conv2d_wgrad_ws_elems": C.c_long, "gank_prof_calibrate": C.c_double}

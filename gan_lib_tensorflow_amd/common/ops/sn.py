@@ -21,6 +21,18 @@ from ...store import get_default_store
 NO_OPS = 'NO_OPS'
 
 _active = []  # stack of {id(W): (W_bar, sigma)} dicts filled by `precomputed`
+_grad_scratch = [None]   # a pre-ZEROED fp32 buffer the next `precomputed` may carve its dW_bar slices from
+
+
+@contextlib.contextmanager
+def grad_scratch(buf):
+    """`buf` (zeroed by the caller for this backward pass, e.g. the scratch half of ParamStore.flatten's gradient
+    buffer) replaces the per-step torch.zeros of the normalised weights' gradient slices."""
+    _grad_scratch[0] = buf
+    try:
+        yield
+    finally:
+        _grad_scratch[0] = None
 
 
 def _apply_update(us, batch, update_collection):
@@ -115,27 +127,32 @@ def precomputed(store, prefix, update_collection=None, prepare=True, prep_kind=N
     Ws = [w for w, _, _ in pairs]
     us = [u for _, u, _ in pairs]
     flat = _flat_base(store, prefix, us)
-    if update_collection != NO_OPS:
-        if flat is not None:                      # one snapshot copy instead of one per weight
-            snap, o, u_read = K.clone(flat), 0, []
-            for u in us:
-                u_read.append(snap[o:o + u.numel()])
-                o += u.numel()
+    if update_collection is None:
+        # u <- u_final on every execution (sn.py:55-56): the kernels keep the u they read for the backward pass and
+        # write u_final over u themselves -- no snapshot copy, no copy-back
+        W_bars, batch = Fn.spectral_norm_batch(Ws, [u.detach() for u in us], snapshot=True, inplace=True)
+    else:
+        if update_collection != NO_OPS:
+            if flat is not None:                      # one snapshot copy instead of one per weight
+                snap, o, u_read = K.clone(flat), 0, []
+                for u in us:
+                    u_read.append(snap[o:o + u.numel()])
+                    o += u.numel()
+            else:
+                u_read = [K.clone(u.detach()) for u in us]
         else:
-            u_read = [K.clone(u.detach()) for u in us]
-    else:
-        u_read = [u.detach() for u in us]
-    W_bars, batch = Fn.spectral_norm_batch(Ws, u_read)
-    if update_collection is None and flat is not None:
-        with torch.no_grad():
-            K.copy_(flat, batch.u_out)            # u <- u_final for all weights: one copy (sn.py:55-56)
-    else:
+            u_read = [u.detach() for u in us]
+        W_bars, batch = Fn.spectral_norm_batch(Ws, u_read)
         _apply_update(us, batch, update_collection)
     if prepare:
         kinds = [prep_kind(nm, w) for w, _, nm in pairs] if prep_kind is not None else None
         K.prep_weights_batched(list(W_bars), want_d=True, kinds=kinds)
         if any(w.requires_grad for w in Ws):
-            gflat = torch.zeros(sum(w.numel() for w in W_bars), dtype=torch.float32, device=W_bars[0].device)
+            need = sum(w.numel() for w in W_bars)
+            gflat = _grad_scratch[0]
+            _grad_scratch[0] = None                      # one use per zeroing
+            if gflat is None or gflat.numel() < need:
+                gflat = torch.zeros(need, dtype=torch.float32, device=W_bars[0].device)
             o = 0
             for wb in W_bars:
                 wb._grad_buf = gflat[o:o + wb.numel()].view(wb.shape)

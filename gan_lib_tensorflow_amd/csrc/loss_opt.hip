@@ -251,6 +251,63 @@ extern "C" int gank_preprocess_real(const uint8_t* data, void* y, uint64_t* rng_
   return rng_advance((unsigned long long*)rng_state, 1, s);
 }
 
+// ---- the critic's feed for one update, in ONE launch (gan_cifar_resnet.py:334-338,361,616-620) ---------------
+// both[0:B] = 2*(real/256 - .5) + U[0,1/128) for slot *slot of the iteration's real batches (CHW rows -> HWC),
+// both[B:2B] = the generator output kept for that slot, labels2 = the slot's labels twice; then the slot counter
+// and the RNG offset advance.  Replaces 3 staging copies, the preprocess launch, its RNG advance and two concats.
+// The counters are advanced by the LAST workgroup to finish (every workgroup has read them by then).
+__global__ void critic_feed_kernel(const unsigned char* __restrict__ real_all, const int* __restrict__ labels_all,
+                                   const bf16* __restrict__ fake_all, bf16* __restrict__ both, int* __restrict__ labels2,
+                                   int* __restrict__ slot, unsigned long long* __restrict__ state, unsigned* __restrict__ done,
+                                   int B, int n_slots) {
+  const unsigned long long seed = state[0], off = state[1];
+  const int sl = slot[0];
+  const unsigned char* data = real_all + (long)sl * B * 3072;
+  const long n = (long)B * 3072, n4 = n >> 2;
+  const long stride = (long)gridDim.x * blockDim.x, t = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  for (long i = t; i < n4; i += stride) {                       // identical arithmetic to preprocess_kernel
+    const u4 r = philox4x32_10((unsigned long long)i, off, seed);
+    const unsigned v[4] = {r.x, r.y, r.z, r.w};
+    for (int e = 0; e < 4; e++) {
+      const long o = i * 4 + e;
+      const int b = (int)(o / 3072), rem = (int)(o - (long)b * 3072);
+      const int c = rem % 3, hw = rem / 3;
+      const float px = (float)data[(long)b * 3072 + c * 1024 + hw];
+      both[o] = f2bf(2.f * (px / 256.f - .5f) + u01(v[e]) * (1.f / 128.f));
+    }
+  }
+  const u32x4* fs = reinterpret_cast<const u32x4*>(fake_all + (long)sl * n);
+  u32x4* fd = reinterpret_cast<u32x4*>(both + n);
+  for (long i = t; i < n / 8; i += stride) fd[i] = fs[i];
+  for (long i = t; i < B; i += stride) {
+    const int lb = labels_all[(long)sl * B + i];
+    labels2[i] = lb;
+    labels2[B + i] = lb;
+  }
+  // no fence: the counters only have to be READ by every workgroup before the last one rewrites them, and each
+  // workgroup's loads of them are consumed (addresses of everything above) before it reaches its atomic
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned prev = atomicAdd(done, 1u);
+    if (prev == gridDim.x - 1) {
+      done[0] = 0u;
+      slot[0] = sl + 1 < n_slots ? sl + 1 : 0;
+      state[1] = off + 1;
+    }
+  }
+}
+
+extern "C" int gank_critic_feed(const uint8_t* real_all, const int32_t* labels_all, const void* fake_all, void* both,
+                                int32_t* labels2, int32_t* slot, uint64_t* rng_state, uint32_t* done_counter, int B, int n_slots,
+                                void* stream) {
+  GANK_REQUIRE(real_all && labels_all && fake_all && both && labels2 && slot && rng_state && done_counter && B > 0 && n_slots > 0,
+               "critic_feed: bad arguments");
+  hipLaunchKernelGGL(critic_feed_kernel, rgrid((long)B * 768), dim3(256), 0, (hipStream_t)stream, real_all, labels_all,
+                     (const bf16*)fake_all, (bf16*)both, labels2, slot, (unsigned long long*)rng_state, done_counter, B, n_slots);
+  GANK_LAUNCH_OK("critic_feed");
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // debug: dump what ds_read_b64_tr_b16 returns for LDS image lds[i] = i (16-bit), lane l reading at
 // byte address 8*l.  out[l*4+e] = element e delivered to lane l.

@@ -46,6 +46,8 @@ __global__ void sn_rowdot_u_kernel(SnTable t, int total_rows) {
   for (int c = lane; c < d.C; c += 64) s += d.W[(long)k * d.C + c] * d.u_in[c];
   s = wave_sum(s);
   if (lane == 0) d.a[k] = s;
+  if (k == 0 && d.u_snap)       // the weight's first row also keeps u_in for the backward pass
+    for (int c = lane; c < d.C; c += 64) d.u_snap[c] = d.u_in[c];
 }
 
 // k2: n = |a|; v = a/(n+eps) for this chunk's rows; bpart[chunk][c] = sum_{k in chunk} W[k,c] v[k]
@@ -156,9 +158,10 @@ __global__ void sn_bwd_apply_kernel(SnTable t, int total_rows) {
   const float sigma = d.scal[0], s = d.scal[3];
   const float coef = d.scal[4] / (sigma * sigma);
   const float sv = s * d.v[k], gak = d.ga[k];
+  const float* uin = d.u_snap ? d.u_snap : d.u_in;
   for (int c = threadIdx.x & 63; c < d.C; c += 64) {
     const long i = (long)k * d.C + c;
-    d.dW[i] += d.dW_bar[i] / sigma - coef * (sv * d.b[c] + gak * d.u_in[c]);
+    d.dW[i] += d.dW_bar[i] / sigma - coef * (sv * d.b[c] + gak * uin[c]);
   }
 }
 

@@ -226,10 +226,11 @@ class _SpectralNorm(Function):
         return (None, *rets)
 
 
-def spectral_norm_batch(Ws, us):
+def spectral_norm_batch(Ws, us, snapshot=False, inplace=False):
     """Ws: fp32 weights (Cout last); us: fp32 [.., C] vectors READ by this call (pass snapshots if the
-    stored u is overwritten before backward).  Returns (W_bars tuple, SnBatch)."""
-    batch = K.SnBatch(list(Ws), [u.detach() for u in us])
+    stored u is overwritten before backward, or let the kernels keep one: snapshot=True; inplace=True writes
+    u_final straight over `us`).  Returns (W_bars tuple, SnBatch)."""
+    batch = K.SnBatch(list(Ws), [u.detach() for u in us], snapshot, inplace)
     outs = _SpectralNorm.apply(batch, *Ws)
     return outs, batch
 

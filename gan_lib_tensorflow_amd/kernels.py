@@ -263,7 +263,9 @@ def colsum(x2d, out, scale=1.0):
 class SnBatch:
     """Workspaces + descriptor table for one batched spectral-norm call over several weights."""
 
-    def __init__(self, weights, us):
+    def __init__(self, weights, us, snapshot=False, inplace=False):
+        """snapshot: the kernels keep their own copy of u for the backward pass; inplace: u_final is written straight
+        over `us` (needs snapshot when a backward pass follows): u.assign(u_final) without clone/copy launches."""
         self.weights, self.us = list(weights), list(us)
         dev = self.weights[0].device
         self.n = len(self.weights)
@@ -278,13 +280,16 @@ class SnBatch:
         self.bpart = torch.empty(tot(lambda k, c: ((k + 63) // 64) * c), dtype=F32, device=dev)
         self.rowdot = torch.empty_like(self.v)
         self.ga = torch.empty_like(self.v)
+        self.u_snap = torch.empty_like(self.u_out) if snapshot else None
+        self.inplace = inplace
         self.table = (SnDesc * self.n)()
         ko = co = bo = 0
         for i, (w, u, (k, c)) in enumerate(zip(self.weights, self.us, self.KC)):
             d = self.table[i]
             d.W, d.u_in = _p(w, F32, "W").value, _p(u, F32, "u").value
             assert u.numel() == c, (u.shape, c)
-            d.u_out = self.u_out.data_ptr() + 4 * co
+            d.u_out = d.u_in if inplace else self.u_out.data_ptr() + 4 * co
+            d.u_snap = self.u_snap.data_ptr() + 4 * co if snapshot else None
             d.v = self.v.data_ptr() + 4 * ko
             d.W_bar = self.W_bar[i].data_ptr()
             d.scal = self.scal.data_ptr() + 32 * i
@@ -515,6 +520,15 @@ def rng_labels(n, n_labels, rng_state):
     y = torch.empty(n, dtype=I32, device=rng_state.device)
     _lib.check(lib().gank_rng_labels(_p(y), n, n_labels, _p(rng_state, torch.int64), _stream()), "rng_labels")
     return y
+
+
+def critic_feed(real_all, labels_all, fake_all, both, labels2, slot, rng_state, done):
+    """both/labels2 <- slot `slot[0]` of the feed ring (preprocessed reals, kept fakes, labels twice); advances slot and RNG"""
+    n_slots, b = labels_all.shape
+    assert both.shape[0] == 2 * b and labels2.numel() == 2 * b and real_all.shape[0] == n_slots and fake_all.shape[0] == n_slots
+    _lib.check(lib().gank_critic_feed(_p(real_all, torch.uint8, "real_all"), _p(labels_all, I32, "labels_all"), _p(fake_all, BF16, "fake_all"),
+                                      _p(both, BF16, "both"), _p(labels2, I32, "labels2"), _p(slot, I32, "slot"),
+                                      _p(rng_state, torch.int64, "rng_state"), _p(done, I32, "done"), b, n_slots, _stream()), "critic_feed")
 
 
 def tr_probe(device):

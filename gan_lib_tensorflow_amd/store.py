@@ -96,9 +96,11 @@ class ParamStore:
                     del self.vars[k]._prep          # cached MFMA operand copies are stale now
 
     # ---- flat buffers -------------------------------------------------------------------------
-    def flatten(self, prefix):
+    def flatten(self, prefix, scratch_tail=False):
         """Move every trainable variable under `prefix` into one flat fp32 buffer; give each a
-        `.main_grad` view into one flat gradient buffer.  Idempotent."""
+        `.main_grad` view into one flat gradient buffer.  Idempotent.  scratch_tail: the gradient buffer gets a
+        second half (`scratch`) that zero_grads() clears in the same fill -- room for the gradients of derived
+        weights (spectrally normalised copies), which would otherwise need their own fill per step."""
         if prefix in self.flat:
             return self.flat[prefix]
         names = self.names(prefix, trainable=True)
@@ -107,7 +109,8 @@ class ParamStore:
             offsets[k] = total
             total += (self.vars[k].numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         params = torch.zeros(total, dtype=torch.float32, device=self.device)
-        grads = torch.zeros(total, dtype=torch.float32, device=self.device)
+        grads_all = torch.zeros(2 * total if scratch_tail else total, dtype=torch.float32, device=self.device)
+        grads = grads_all[:total]
         with torch.no_grad():
             for k in names:
                 v = self.vars[k]
@@ -115,7 +118,8 @@ class ParamStore:
                 params[o:o + n].copy_(v.reshape(-1))
                 v.data = params[o:o + n].view(v.shape)
                 v.main_grad = grads[o:o + n].view(v.shape)
-        self.flat[prefix] = dict(params=params, grads=grads, names=names, offsets=offsets,
+        self.flat[prefix] = dict(params=params, grads=grads, names=names, offsets=offsets, grads_all=grads_all,
+                                 scratch=grads_all[total:] if scratch_tail else None,
                                  m=torch.zeros_like(params), v=torch.zeros_like(params))
         return self.flat[prefix]
 
@@ -140,7 +144,7 @@ class ParamStore:
         return self.flat[key]
 
     def zero_grads(self, prefix):
-        self.flat[prefix]["grads"].zero_()
+        self.flat[prefix]["grads_all"].zero_()
 
 
 _default_store = None

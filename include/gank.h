@@ -163,6 +163,8 @@ typedef struct gank_sn_desc {
   float* dW;           /* [K,C] backward output (accumulated)                    */
   float* rowdot;       /* [K]   workspace                                        */
   float* ga;           /* [K]   workspace                                        */
+  float* u_snap;       /* [C] or NULL: fwd also copies u_in here and bwd reads it instead of u_in, so that
+                          u_out may alias u_in (u.assign(u_final) of sn.py:55-56 without a snapshot/copy-back pair) */
   int K, C;
   int row_offset;      /* filled by the library                                  */
   int chunk_offset;    /* filled by the library                                  */
@@ -248,6 +250,15 @@ int gank_counter_add(int64_t* counter, int64_t inc, void* stream);
  * consumes and advances the offset on the device, so a captured graph draws fresh numbers per replay
  * (tf.random_normal :240, tf.random_uniform :335,:467). */
 int gank_preprocess_real(const uint8_t* data, void* y, uint64_t* rng_state, int B, void* stream);
+/* One launch that lays out a critic update's inputs from slot *slot of the iteration's feed ring (the per-update
+ * feed of gan_cifar_resnet.py:616-620 + :334-338 + the concat of :361): both [2B,3072] bf16 = {preprocessed
+ * real_all[slot] (same arithmetic and random numbers as gank_preprocess_real), fake_all[slot]}, labels2 [2B] =
+ * labels_all[slot] twice; then *slot = (*slot + 1) % n_slots and the RNG offset advances by one.  real_all
+ * uint8 [n_slots,B,3072], labels_all int32 [n_slots,B], fake_all bf16 [n_slots,B,3072]; done_counter: one zeroed
+ * uint32 of scratch that the call leaves zero. */
+int gank_critic_feed(const uint8_t* real_all, const int32_t* labels_all, const void* fake_all, void* both,
+                     int32_t* labels2, int32_t* slot, uint64_t* rng_state, uint32_t* done_counter, int B, int n_slots,
+                     void* stream);
 int gank_rng_normal_bf16(void* y, long n, uint64_t* rng_state, void* stream);
 int gank_rng_labels(int32_t* y, long n, int n_labels, uint64_t* rng_state, void* stream);
 

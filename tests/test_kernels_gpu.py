@@ -496,3 +496,26 @@ def test_conv3x3_register_weight_patch_kernel(K, n, h, cin, cout, mode):
     dref, _, _ = R.conv2d_same_grads(x, w, dy)
     torch.cuda.synchronize()
     assert relerr(dx, dref * (x > 0)) < BF_TOL
+
+
+def test_critic_feed_matches_separate_launches(K):
+    """gank_critic_feed == gank_preprocess_real + the staging copies + the concat, bit for bit, and walks the ring."""
+    g = torch.Generator(device="cpu").manual_seed(3)
+    b, slots = 8, 3
+    real_all = torch.randint(0, 256, (slots, b, 3072), generator=g, dtype=torch.uint8).cuda()
+    labels_all = torch.randint(0, 10, (slots, b), generator=g, dtype=torch.int32).cuda()
+    fake_all = torch.randn((slots, b, 3072), generator=g).to(torch.bfloat16).cuda()
+    both = torch.zeros((2 * b, 3072), dtype=torch.bfloat16, device="cuda")
+    labels2 = torch.zeros(2 * b, dtype=torch.int32, device="cuda")
+    slot = torch.zeros(1, dtype=torch.int32, device="cuda")
+    done = torch.zeros(1, dtype=torch.int32, device="cuda")
+    rng_a, rng_b = K.new_rng_state(99, "cuda"), K.new_rng_state(99, "cuda")
+    for step in range(slots + 1):
+        i = step % slots
+        K.critic_feed(real_all, labels_all, fake_all, both, labels2, slot, rng_a, done)
+        ref_real = K.preprocess_real(real_all[i], rng_b).reshape(b, 3072)
+        torch.cuda.synchronize()
+        assert torch.equal(both[:b].view(torch.int16), ref_real.view(torch.int16))
+        assert torch.equal(both[b:].view(torch.int16), fake_all[i].view(torch.int16))
+        assert torch.equal(labels2[:b], labels_all[i]) and torch.equal(labels2[b:], labels_all[i])
+        assert int(slot) == (i + 1) % slots and int(done) == 0 and torch.equal(rng_a, rng_b)
