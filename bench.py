@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo for rehearsals)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -94,12 +95,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if local_rank >= torch.cuda.device_count():     # rehearsal of the N > 1 path on fewer GPUs than ranks (gloo only)
+        assert args.backend != "nccl", "RCCL needs one GPU per rank"
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     from gan_lib_tensorflow_amd import kernels as K
     from gan_lib_tensorflow_amd import parallel
     from gan_lib_tensorflow_amd.SNGAN import gan_cifar_resnet as S
-    pg, rank, world = parallel.init_from_env(backend="nccl", device=device)   # RCCL over xGMI; None for 1 rank
+    pg, rank, world = parallel.init_from_env(backend=args.backend, device=device)   # nccl = RCCL over xGMI; None for 1 rank
 
     tr = S.SNGANTrainer(batch_size=S.BATCH_SIZE, device=device, seed=0, use_graphs=not args.no_graphs, process_group=pg)
     feed = S.synthetic_batches(S.BATCH_SIZE, device, seed=rank)
@@ -127,28 +131,42 @@ def main():
     elapsed = float(t)
     finite = bool(torch.isfinite(tr.g_flat["params"]).all() and torch.isfinite(tr.d_flat["params"]).all())
 
-    # ---- roofline leg: one iteration executed eagerly with a HIP event pair around every MFMA conv launch
+    # ---- roofline leg: one iteration executed eagerly with a HIP event pair around every MFMA conv launch.
+    # EVERY rank runs the two eager iterations (they contain the gradient all-reduces: a rank that skipped them
+    # would leave the others waiting in the collective); only rank 0 records and reports.
     roofline = None
+    tr.use_graphs = False
+    tr.train_iteration(feed)          # untimed eager warm-up of the non-graph path
+    torch.cuda.synchronize()
     if rank == 0:
-        tr.use_graphs = False
-        tr.train_iteration(feed)          # untimed eager warm-up of the non-graph path
-        torch.cuda.synchronize()
         K.prof_reset()
         K.prof_enable(True)
-        tr.train_iteration(feed)
-        torch.cuda.synchronize()
+    tr.train_iteration(feed)
+    torch.cuda.synchronize()
+    if rank == 0:
         K.prof_enable(False)
         fam = {}
+        alg_bytes = {}
         for f, name in ((0, "conv_igemm_kernel (fprop+dgrad)"), (1, "conv_wgrad_kernel")):
             n, ms, fl = K.prof_collect(f)
             fam[name] = (n, ms, fl)
+            alg_bytes[name] = K.prof_bytes(f)
         K.prof_reset()
         pair_us = 1e3 * K.prof_calibrate(200)      # what an event pair around an EMPTY kernel reads
         dom = max(fam, key=lambda k: fam[k][1])
         n, ms, fl = fam[dom]
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # HBM traffic per launch of this family: rocprofv3 PMC passes cannot run inside this process; the committed
+        # measurement of scratch/pmc_bench_traffic.sh over this same workload is reported when present
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if dom.startswith("conv_igemm") and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            traffic, traffic_src = round(tj["bytes_per_launch"]), "profiles/r01_traffic.json (" + tj["method"] + ")"
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": round(alg_bytes[dom] / max(n, 1)),
                     "launches_per_iteration": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
                     # an event pair reads the kernel plus a fixed few microseconds (measured on an empty kernel,
                     # whose own run time is part of it): rocprofv3's kernel-only durations are shorter by about that

@@ -81,10 +81,11 @@ PROTOTYPES = {
     "gank_prof_reset": [],
     "gank_prof_collect": [I, C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "gank_prof_calibrate": [I, P],
+    "gank_prof_bytes": [I],
     "gank_critic_feed": [P, P, P, P, P, P, P, P, I, I, P],
     "gank_debug_tr_probe": [P, P],
 }
-_RET = {"gank_last_error": C.c_char_p, "gank_conv2d_wgrad_ws_elems": C.c_long, "gank_prof_calibrate": C.c_double}
+_RET = {"gank_last_error": C.c_char_p, "gank_conv2d_wgrad_ws_elems": C.c_long, "gank_prof_calibrate": C.c_double, "gank_prof_bytes": C.c_double}
 
 _lib = None
 

@@ -20,17 +20,18 @@ extern "C" int gank_version(void) { return GANK_VERSION; }
 // stream.  Off by default; never active during graph capture (bench.py enables it for one eager pass).
 namespace {
 constexpr int kFamilies = 4;
-struct Rec { hipEvent_t a, b; double flops; };
+struct Rec { hipEvent_t a, b; double flops, bytes; };
 bool g_on = false;
 std::vector<Rec> g_recs[kFamilies];
 hipEvent_t g_open[kFamilies];
 }  // namespace
 
-void gank_prof_begin(int family, double flops, hipStream_t s) {
+void gank_prof_begin(int family, double flops, hipStream_t s, double bytes) {
   if (!g_on || family < 0 || family >= kFamilies) return;
   Rec r;
   if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
   r.flops = flops;
+  r.bytes = bytes;
   hipEventRecord(r.a, s);
   g_recs[family].push_back(r);
 }
@@ -51,6 +52,7 @@ extern "C" double gank_prof_calibrate(int n, void* stream) {
   if (n <= 0) return 0.0;
   std::vector<Rec> recs(n);
   for (auto& r : recs) {
+    r.flops = r.bytes = 0;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1.0;
     hipEventRecord(r.a, s);
     hipLaunchKernelGGL(prof_empty_kernel, dim3(1), dim3(64), 0, s);
@@ -73,6 +75,13 @@ extern "C" int gank_prof_reset(void) {
     g_recs[f].clear();
   }
   return 0;
+}
+
+extern "C" double gank_prof_bytes(int family) {
+  double b = 0;
+  if (family >= 0 && family < kFamilies)
+    for (auto& r : g_recs[family]) b += r.bytes;
+  return b;
 }
 
 extern "C" int gank_prof_collect(int family, double* total_ms, double* total_flops) {

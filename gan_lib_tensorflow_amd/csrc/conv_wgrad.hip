@@ -932,10 +932,14 @@ __global__ void wgrad_reduce_slabs_kernel(const float* __restrict__ ws, float* _
   }
 }
 
+static int wgrad_taps_min_m() {
+  static int v = -1;   // experiment knob
+  if (v < 0) { const char* e = getenv("GANK_WGRAD_TAPS_MINM"); v = e ? atoi(e) : 16384; }
+  return v;
+}
 static bool wgrad_taps_ok(const WgradArgs& a) {
   return a.ks == 3 && a.pad == 1 && !(a.flags & WG_X_STRIDE2) && a.sw >= 3 && a.shw >= 6 && a.H >= 8 && a.W >= 8 &&
-         a.M >= 16384 &&   // small reductions: the per-tap kernel's finer split fills the chip better
-        
+         a.M >= wgrad_taps_min_m() &&   // small reductions: the per-tap kernel's finer split fills the chip better
          a.Cin % 64 == 0 && a.Cout % 64 == 0 && (a.M % 64 == 0) &&
          (long)a.N * a.Hx * a.Wx * a.Cin < (1L << 30) && (long)a.N * a.Hdy * a.Wdy * a.Cout < (1L << 30);
 }

@@ -38,7 +38,7 @@ static inline int roundup(int a, int b) { return (a + b - 1) / b * b; }
 static inline int log2_or_neg(int v) { int s = 0; while ((1 << s) < v) s++; return ((1 << s) == v) ? s : -1; }
 
 // profiling hooks (api.hip)
-void gank_prof_begin(int family, double flops, hipStream_t s);
+void gank_prof_begin(int family, double flops, hipStream_t s, double bytes = 0.0);   // bytes: algorithmic operand + result bytes
 void gank_prof_end(int family, hipStream_t s);
 
 #ifdef __HIPCC__

@@ -552,6 +552,10 @@ def prof_collect(family):
     return n, ms.value, fl.value
 
 
+def prof_bytes(family):
+    return float(lib().gank_prof_bytes(int(family)))
+
+
 def prof_calibrate(n=200):
     """average ms an event pair around an empty kernel reads (the fixed cost inside every profiler record)"""
     return float(lib().gank_prof_calibrate(int(n), _stream()))

@@ -268,6 +268,8 @@ int gank_prof_reset(void);
 /* fills up to `cap` records {launches, total_ms, total_flops} for kernel family `family`
  * (0 = conv_fprop/dgrad igemm, 1 = conv_wgrad); synchronises.  Returns number of launches. */
 int gank_prof_collect(int family, double* total_ms, double* total_flops);
+/* sum of the algorithmic bytes (operands read once + result written once) of the recorded launches of `family` */
+double gank_prof_bytes(int family);
 /* average milliseconds an event pair around an EMPTY kernel reads (n launches): the fixed cost inside every record */
 double gank_prof_calibrate(int n, void* stream);
 
