@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling (the reference's semantics, gan_cifar_resnet.py:324,330): the global batch of 64 is split over the ranks")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo for rehearsals)")
     args = ap.parse_args()
 
@@ -105,8 +107,10 @@ def main():
     from gan_lib_tensorflow_amd.SNGAN import gan_cifar_resnet as S
     pg, rank, world = parallel.init_from_env(backend=args.backend, device=device)   # nccl = RCCL over xGMI; None for 1 rank
 
-    tr = S.SNGANTrainer(batch_size=S.BATCH_SIZE, device=device, seed=0, use_graphs=not args.no_graphs, process_group=pg)
-    feed = S.synthetic_batches(S.BATCH_SIZE, device, seed=rank)
+    per_gpu = S.BATCH_SIZE // world if args.strong else S.BATCH_SIZE
+    assert per_gpu >= 2 and per_gpu * world == (S.BATCH_SIZE if args.strong else S.BATCH_SIZE * world), "batch 64 must split evenly"
+    tr = S.SNGANTrainer(batch_size=per_gpu, device=device, seed=0, use_graphs=not args.no_graphs, process_group=pg)
+    feed = S.synthetic_batches(per_gpu, device, seed=rank)
 
     def barrier():
         if world > 1:
@@ -178,19 +182,19 @@ def main():
         tr.use_graphs = not args.no_graphs
 
     if rank == 0:
-        images = 320.0 * world * args.steps
+        images = 5.0 * per_gpu * world * args.steps
         value = images / elapsed
         out = {
             "metric": "images/sec (G+D step) SNGAN-ResNet CIFAR-10 bs=64", "value": round(value, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": warm, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "SNGAN ResNet CIFAR-10 32x32 bs=64 hinge: 1 G update (2x64 fakes) + 5 D updates (64 real + 64 fake) per step",
-                       "global_batch": 64 * world, "per_gpu_batch": 64, "parallelism": f"dp{world}",
+                       "global_batch": per_gpu * world, "per_gpu_batch": per_gpu, "parallelism": f"dp{world}",
                        "graphs": not args.no_graphs, "finite": finite},
             # reference algorithm (9-tap upsample convs, SURVEY 8d: 13.77 GFLOP per real image) and the algorithm as run
             # (UpsampleConv 3x3 as a 4-tap-per-output transposed conv; conv FLOPs counted by the kernels themselves)
             "whole_step_mfma_frac": round(value / world * GFLOP_PER_REAL_IMAGE * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
-            "whole_step_mfma_frac_as_run": (round(roofline["conv_gflop_per_iteration_as_run"] * 1e9 * (value / world / 320.0)
+            "whole_step_mfma_frac_as_run": (round(roofline["conv_gflop_per_iteration_as_run"] * 1e9 * (value / world / (5.0 * per_gpu))
                                                   / (PEAK_BF16_TFLOPS * 1e12), 4) if roofline else None),
             "roofline": roofline,
         }
