@@ -74,8 +74,9 @@ CONV_CASES = [
     (4, 32, 3, 128, 3, ""),           # narrow-input kernel at the real D.Block.1.Conv1 geometry
     (4, 16, 3, 256, 1, ""),           # narrow-input 1x1
     (1, 5, 3, 128, 3, "relu"),        # narrow-input, ragged pixel count (25 pixels)
-    (3, 8, 256, 128, 1, ""),          # 128-channel-step kernel, 1x1
-    (1, 5, 128, 192, 3, "relu"),      # 128-channel-step kernel, ragged pixel count, Cout = 3 tiles of 64
+    (256, 16, 64, 128, 3, "relu"),    # >= 256 blocks of 16x16 patches: the 8-wave patch kernel
+    (3, 8, 256, 128, 1, ""),          # 1x1, Cin = 256
+    (1, 5, 128, 192, 3, "relu"),      # ragged pixel count, Cout = 3 tiles of 64
 ]
 
 
