@@ -1,5 +1,5 @@
 """Counterpart of the reference's `common` package (imported there as `lib`), hot path only."""
-from . import ops  # noqa: F401
+from . import misc, ops  # noqa: F401
 from ..store import ParamStore, get_default_store, set_default_store  # noqa: F401
 
 

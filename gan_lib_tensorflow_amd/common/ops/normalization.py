@@ -21,8 +21,47 @@ def cond_batchnorm(name, axes, inputs, is_training=None, stats_iter=None, update
         return Fn.cond_batchnorm(inputs, labels, scale_m, offset_m, groups, relu)
 
 
-def batch_norm(inputs, decay=0.9, epsilon=1e-5, is_training=True, fused=True):
-    raise NotImplementedError('unconditional batch_norm (normalization.py:8-24) is config 3 (ACGAN), not built yet')
+_zero_labels = {}
+
+
+def batch_norm(inputs, decay=0.9, epsilon=1e-5, is_training=True, fused=True, groups=1, relu=False):
+    """tf.contrib.layers.batch_norm(center, scale, updates_collections=None, zero_debias_moving_mean=True, fused,
+    scope='BatchNorm')  (normalization.py:8-24): train-mode batch normalisation over (N,H,W) with in-place
+    moving-statistic updates.  Variables `BatchNorm/{beta,gamma,moving_mean,moving_variance}` and the zero-debias
+    helpers `BatchNorm/moving_mean/{biased,local_step}`.  Runs on the conditional-batch-norm kernels with a
+    one-row gamma/beta table; the moving statistics (state only: every call site of the reference trains) are
+    updated per tower like the reference's per-tower update ops:
+        moving_variance <- decay*mv + (1-decay) * var * n/(n-1)      (fused batch norm reports the unbiased variance)
+        biased <- decay*biased + (1-decay)*mean; local_step += 1; moving_mean <- biased / (1 - decay**local_step)"""
+    if not is_training:
+        raise NotImplementedError('the reference only ever calls batch_norm with is_training=True (normalization.py:8)')
+    if abs(epsilon - 1e-5) > 1e-12:
+        raise NotImplementedError('the batch-norm kernels are built with epsilon = 1e-5 (the reference default)')
+    import torch
+    store = get_default_store()
+    n, c = inputs.shape[0], inputs.shape[-1]
+    with store.variable_scope('BatchNorm'):
+        beta = store.get_variable('beta', [1, c], np.zeros((1, c), 'float32'))
+        gamma = store.get_variable('gamma', [1, c], np.ones((1, c), 'float32'))
+        mm = store.get_variable('moving_mean', [c], np.zeros(c, 'float32'), trainable=False)
+        mv = store.get_variable('moving_variance', [c], np.ones(c, 'float32'), trainable=False)
+        with store.variable_scope('moving_mean'):
+            biased = store.get_variable('biased', [c], np.zeros(c, 'float32'), trainable=False)
+            step = store.get_variable('local_step', [1], np.zeros(1, 'float32'), trainable=False)
+    key = (n, str(inputs.device))
+    if key not in _zero_labels:
+        _zero_labels[key] = torch.zeros(n, dtype=torch.int32, device=inputs.device)
+    y, stats = Fn.batchnorm_with_stats(inputs, _zero_labels[key], gamma, beta, groups, relu)
+    with torch.no_grad():
+        cnt = inputs.numel() // c // groups
+        for g in range(groups):
+            mean, invstd = stats[g, 0], stats[g, 1]
+            var = (1.0 / (invstd * invstd) - 1e-5) * (cnt / max(cnt - 1, 1))
+            mv.mul_(decay).add_(var, alpha=1.0 - decay)
+            biased.mul_(decay).add_(mean, alpha=1.0 - decay)
+            step.add_(1.0)
+            mm.copy_(biased / (1.0 - torch.pow(torch.full_like(step, decay), step)))
+    return y
 
 
 def layer_norm(name, norm_axes, inputs):

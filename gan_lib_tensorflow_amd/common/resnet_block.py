@@ -65,7 +65,7 @@ def Normalize(name, inputs, labels=None, groups=1, relu=False):
             return _normalization.cond_batchnorm(name, [0, 1, 2], inputs, labels=labels, n_labels=10,
                                                  groups=groups, relu=relu)
         if kind == 'bn':
-            return _normalization.batch_norm(inputs, fused=True)
+            return _normalization.batch_norm(inputs, fused=True, groups=groups, relu=relu)
         return inputs
 
 

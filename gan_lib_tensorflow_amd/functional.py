@@ -257,6 +257,31 @@ def cond_batchnorm(x, labels, gamma, beta, groups=1, relu=False):
     return _CondBatchNorm.apply(x, labels, gamma, beta, groups, relu)
 
 
+class _BatchNormStats(Function):
+    """cond_batchnorm with the batch statistics as a second, non-differentiable output ([groups, 2, C]: mean, invstd)."""
+
+    @staticmethod
+    def forward(ctx, x, labels, gamma, beta, groups, relu):
+        y, stats = K.cbn_fwd(x, labels, gamma.detach(), beta.detach(), groups, relu)
+        ctx.save_for_backward(x, y, labels, gamma, beta, stats)
+        ctx.cfg = (groups, relu)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        x, y, labels, gamma, beta, stats = ctx.saved_tensors
+        groups, relu = ctx.cfg
+        tg, accg = _target(gamma)
+        tb, accb = _target(beta)
+        dx = K.cbn_bwd(_c(dy), x, y, labels, gamma.detach(), stats, tg, tb, groups, relu)
+        return dx, None, (None if accg else tg), (None if accb else tb), None, None
+
+
+def batchnorm_with_stats(x, labels, gamma, beta, groups=1, relu=False):
+    return _BatchNormStats.apply(x, labels, gamma, beta, groups, relu)
+
+
 class _Fork(Function):
     """Explicit activation fan-out: two aliases forward, one add kernel backward."""
 

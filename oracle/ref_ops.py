@@ -260,6 +260,29 @@ def cond_batchnorm_backward(dy, labels, gamma, cache, groups=1):
 # --------------------------------------------------------------------------------------
 # linear / embedding / pooling / losses / optimiser
 # --------------------------------------------------------------------------------------
+def batch_norm_train(x, gamma, beta, moving, decay=0.9, eps=BN_EPS):
+    """tf.contrib.layers.batch_norm(center, scale, is_training=True, fused=True, updates_collections=None,
+    zero_debias_moving_mean=True)   (common/ops/normalization.py:8-24), one tower.
+    Output: batch moments over (N,H,W), biased variance.  State (`moving` = dict moving_mean, moving_variance, biased,
+    local_step; TF 1.5 moving_averages.assign_moving_average / _zero_debias):
+        moving_variance <- mv - (1-decay)(mv - var_unbiased)     (fused batch norm reports the Bessel-corrected variance)
+        biased <- biased - (1-decay)(biased - mean); local_step += 1; moving_mean <- biased / (1 - decay**local_step)
+    Returns (y, cache for cond_batchnorm_backward, new_moving)."""
+    x = np.asarray(x, F64)
+    c = x.shape[-1]
+    labels = np.zeros(x.shape[0], np.int64)
+    y, cache = cond_batchnorm_forward(x, labels, np.asarray(gamma, F64).reshape(1, c), np.asarray(beta, F64).reshape(1, c), 1, eps)
+    cnt = x.size // c
+    mean = x.reshape(-1, c).mean(0)
+    var_unbiased = x.reshape(-1, c).var(0) * cnt / max(cnt - 1, 1)
+    new = dict(moving)
+    new['moving_variance'] = moving['moving_variance'] - (1 - decay) * (moving['moving_variance'] - var_unbiased)
+    new['biased'] = moving['biased'] - (1 - decay) * (moving['biased'] - mean)
+    new['local_step'] = moving['local_step'] + 1
+    new['moving_mean'] = new['biased'] / (1 - decay ** new['local_step'])
+    return y, cache, new
+
+
 def linear(x, W, b=None):
     """tf.matmul + bias_add   (common/ops/linear.py:161-180)"""
     y = np.asarray(x, F64) @ np.asarray(W, F64)

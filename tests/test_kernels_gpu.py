@@ -522,3 +522,59 @@ def test_critic_feed_matches_separate_launches(K):
         assert torch.equal(both[b:].view(torch.int16), fake_all[i].view(torch.int16))
         assert torch.equal(labels2[:b], labels_all[i]) and torch.equal(labels2[b:], labels_all[i])
         assert int(slot) == (i + 1) % slots and int(done) == 0 and torch.equal(rng_a, rng_b)
+
+
+def test_batch_norm_op_and_get_loss(K):
+    """a4' / a15 of the scope table: tf.contrib batch_norm in train mode (normalization.py:8-24) with its moving
+    statistics, and common/misc.py get_loss('HINGE'), through the reference-shaped ops."""
+    from gan_lib_tensorflow_amd.store import ParamStore, set_default_store
+    from gan_lib_tensorflow_amd.common.ops import normalization as Nm
+    from gan_lib_tensorflow_amd.common import misc
+    rng = np.random.default_rng(12)
+    n, hw, c = 6, 4, 64
+    store = set_default_store(ParamStore("cuda", seed=0))
+    moving = dict(moving_mean=np.zeros(c), moving_variance=np.ones(c), biased=np.zeros(c), local_step=0.0)
+    gamma = rng.normal(size=c).astype(np.float32) + 1.0
+    beta = rng.normal(size=c).astype(np.float32)
+    for step in range(2):
+        x, xt = bf(rng.normal(size=(n, hw, hw, c)) * 2.0 + 0.5)
+        xt.requires_grad_(True)
+        with store.variable_scope("D.BN", reuse=step > 0):
+            if step == 0:
+                y = Nm.batch_norm(xt)                      # creates the variables
+                with torch.no_grad():
+                    store.vars["D.BN/BatchNorm/gamma"].copy_(torch.tensor(gamma).view(1, c))
+                    store.vars["D.BN/BatchNorm/beta"].copy_(torch.tensor(beta).view(1, c))
+                    for k in ("moving_mean", "moving_variance", "moving_mean/biased", "moving_mean/local_step"):
+                        v = store.vars["D.BN/BatchNorm/" + k]
+                        v.copy_(torch.ones_like(v) if k == "moving_variance" else torch.zeros_like(v))
+            y = Nm.batch_norm(xt)
+        ref, cache, moving = R.batch_norm_train(x, gamma, beta, moving)
+        dy, dyt = bf(rng.normal(size=ref.shape))
+        for k in ("gamma", "beta"):
+            store.vars["D.BN/BatchNorm/" + k].grad = None
+        y.backward(dyt)
+        dx_ref, dg_ref, db_ref = R.cond_batchnorm_backward(dy, np.zeros(n, np.int64), gamma.reshape(1, c).astype(np.float64), cache, 1)
+        torch.cuda.synchronize()
+        assert relerr(y, ref) < BF_TOL
+        assert relerr(xt.grad, dx_ref) < 2 * BF_TOL
+        assert relerr(store.vars["D.BN/BatchNorm/gamma"].grad, dg_ref) < F32_FROM_BF_TOL
+        assert relerr(store.vars["D.BN/BatchNorm/beta"].grad, db_ref) < F32_FROM_BF_TOL
+        assert relerr(store.vars["D.BN/BatchNorm/moving_mean"], moving["moving_mean"]) < 1e-4
+        assert relerr(store.vars["D.BN/BatchNorm/moving_variance"], moving["moving_variance"]) < 1e-3
+        assert float(store.vars["D.BN/BatchNorm/moving_mean/local_step"]) == step + 1
+    with pytest.raises(NotImplementedError):
+        Nm.batch_norm(xt, is_training=False)
+    real, realt = bf(rng.normal(size=7))
+    fake, faket = bf(rng.normal(size=5))
+    realt.requires_grad_(True)
+    faket.requires_grad_(True)
+    d_loss, g_loss = misc.get_loss(realt, faket, 'HINGE')
+    lref, dref = R.hinge_d_loss(np.concatenate([real, fake]), 7)
+    gref, _ = R.hinge_g_loss(fake)
+    d_loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(d_loss) - lref) < 1e-5 and abs(float(g_loss) - gref) < 1e-5
+    assert relerr(realt.grad, dref[:7]) < BF_TOL and relerr(faket.grad, dref[7:]) < BF_TOL
+    with pytest.raises(NotImplementedError):
+        misc.get_loss(realt, faket, 'WGAN-GP')

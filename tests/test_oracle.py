@@ -242,3 +242,18 @@ def test_network_shapes_and_finite_difference_of_d_loss():
         lm = float(T.d_loss_fn(P, real, labels, z, deq)[0])
         P[name][idx] += eps
     np.testing.assert_allclose((lp - lm) / (2 * eps), float(g[idx]), rtol=1e-4, atol=1e-9)
+
+
+def test_batch_norm_train_known_answers():
+    """normalization.py:8-24 restated: unit-variance output, and the zero-debiased moving mean of a constant batch
+    mean IS that mean after any number of steps (that is what zero_debias_moving_mean buys)."""
+    rng = np.random.default_rng(0)
+    c = 5
+    moving = dict(moving_mean=np.zeros(c), moving_variance=np.ones(c), biased=np.zeros(c), local_step=0.0)
+    x = rng.normal(size=(6, 4, 4, c)) * 3.0 + 2.0
+    for step in range(1, 4):
+        y, _, moving = R.batch_norm_train(x, np.ones(c), np.zeros(c), moving)
+        assert np.allclose(y.reshape(-1, c).mean(0), 0, atol=1e-12) and np.allclose(y.reshape(-1, c).var(0), 1, atol=1e-4)
+        assert np.allclose(moving['moving_mean'], x.reshape(-1, c).mean(0), rtol=1e-12)
+        vu = x.reshape(-1, c).var(0) * 96 / 95
+        assert np.allclose(moving['moving_variance'], 1 + (1 - 0.9 ** step) * (vu - 1), rtol=1e-12)
