@@ -155,22 +155,27 @@ def main():
             n, ms, fl = K.prof_collect(f)
             fam[name] = (n, ms, fl)
             alg_bytes[name] = K.prof_bytes(f)
+        # the dominant KERNEL (one symbol, as rocprofv3 lists it) over both conv families, by total time
+        kernels = [(nm, n_, ms_, fl_, by_, fname) for f, fname in ((0, "conv_igemm_kernel (fprop+dgrad)"), (1, "conv_wgrad_kernel"))
+                   for nm, n_, ms_, fl_, by_ in K.prof_kernels(f)]
         K.prof_reset()
         pair_us = 1e3 * K.prof_calibrate(200)      # what an event pair around an EMPTY kernel reads
-        dom = max(fam, key=lambda k: fam[k][1])
-        n, ms, fl = fam[dom]
+        kernels.sort(key=lambda t: -t[2])
+        dom, n, ms, fl, by, dom_family = kernels[0]
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        # HBM traffic per launch of this family: rocprofv3 PMC passes cannot run inside this process; the committed
-        # measurement of scratch/pmc_bench_traffic.sh over this same workload is reported when present
+        # HBM traffic per launch: rocprofv3 PMC passes cannot run inside this process; the committed measurement of
+        # scratch/pmc_bench_traffic.sh over this same workload is reported when it covers the dominant kernel
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if dom.startswith("conv_igemm") and os.path.exists(tpath):
+        if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            traffic, traffic_src = round(tj["bytes_per_launch"]), "profiles/r01_traffic.json (" + tj["method"] + ")"
+            per = tj.get("per_kernel", {}).get(dom)
+            if per is not None:
+                traffic, traffic_src = round(per["bytes_per_launch"]), "profiles/r01_traffic.json (" + tj["method"] + ")"
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": round(alg_bytes[dom] / max(n, 1)),
+                    "algorithmic_bytes_per_launch": round(by / max(n, 1)),
                     "launches_per_iteration": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
                     # an event pair reads the kernel plus a fixed few microseconds (measured on an empty kernel,
                     # whose own run time is part of it): rocprofv3's kernel-only durations are shorter by about that
@@ -178,7 +183,9 @@ def main():
                     "avg_launch_gflop": round(fl / max(n, 1) / 1e9, 3),
                     "conv_gflop_per_iteration_as_run": round(sum(v[2] for v in fam.values()) / 1e9, 1),
                     "families": {k: {"launches": v[0], "ms": round(v[1], 3),
-                                     "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else 0.0} for k, v in fam.items()}}
+                                     "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else 0.0} for k, v in fam.items()},
+                    "kernels": [{"kernel": t[0], "launches": t[1], "ms": round(t[2], 3),
+                                 "tflops": round(t[3] / (t[2] * 1e-3) / 1e12, 1) if t[2] > 0 else 0.0} for t in kernels[:8]]}
         tr.use_graphs = not args.no_graphs
 
     if rank == 0:

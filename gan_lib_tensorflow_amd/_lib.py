@@ -82,6 +82,7 @@ PROTOTYPES = {
     "gank_prof_collect": [I, C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "gank_prof_calibrate": [I, P],
     "gank_prof_bytes": [I],
+    "gank_prof_kernel_stats": [I, I, C.c_char_p, I, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "gank_critic_feed": [P, P, P, P, P, P, P, P, I, I, P],
     "gank_debug_tr_probe": [P, P],
 }

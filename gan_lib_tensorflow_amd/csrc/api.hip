@@ -1,6 +1,9 @@
 // Error reporting, version, and the opt-in HIP-event profiler of libgank.
 #include "gank_common.h"
 #include <string.h>
+#include <algorithm>
+#include <map>
+#include <string>
 #include <vector>
 
 static thread_local char g_err[512] = "";
@@ -20,7 +23,7 @@ extern "C" int gank_version(void) { return GANK_VERSION; }
 // stream.  Off by default; never active during graph capture (bench.py enables it for one eager pass).
 namespace {
 constexpr int kFamilies = 4;
-struct Rec { hipEvent_t a, b; double flops, bytes; };
+struct Rec { hipEvent_t a, b; double flops, bytes; const char* tag; };
 bool g_on = false;
 std::vector<Rec> g_recs[kFamilies];
 hipEvent_t g_open[kFamilies];
@@ -32,8 +35,14 @@ void gank_prof_begin(int family, double flops, hipStream_t s, double bytes) {
   if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
   r.flops = flops;
   r.bytes = bytes;
+  r.tag = "";
   hipEventRecord(r.a, s);
   g_recs[family].push_back(r);
+}
+
+void gank_prof_tag(int family, const char* kernel_name) {
+  if (!g_on || family < 0 || family >= kFamilies || g_recs[family].empty()) return;
+  g_recs[family].back().tag = kernel_name;
 }
 
 void gank_prof_end(int family, hipStream_t s) {
@@ -52,7 +61,7 @@ extern "C" double gank_prof_calibrate(int n, void* stream) {
   if (n <= 0) return 0.0;
   std::vector<Rec> recs(n);
   for (auto& r : recs) {
-    r.flops = r.bytes = 0;
+    r.flops = r.bytes = 0; r.tag = "";
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1.0;
     hipEventRecord(r.a, s);
     hipLaunchKernelGGL(prof_empty_kernel, dim3(1), dim3(64), 0, s);
@@ -75,6 +84,30 @@ extern "C" int gank_prof_reset(void) {
     g_recs[f].clear();
   }
   return 0;
+}
+
+// per-kernel breakdown of a family: entry `index` (sorted by total time, longest first) -> its symbol name as the
+// launcher recorded it, launches, total ms, FLOPs and algorithmic bytes.  Returns 0 when index is past the end.
+extern "C" int gank_prof_kernel_stats(int family, int index, char* name, int name_cap, int* launches, double* total_ms,
+                                      double* total_flops, double* total_bytes) {
+  if (family < 0 || family >= kFamilies || index < 0) return 0;
+  struct Agg { int n = 0; double ms = 0, fl = 0, by = 0; };
+  std::map<std::string, Agg> m;
+  for (auto& r : g_recs[family]) {
+    float t = 0.f;
+    if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+    Agg& a = m[r.tag ? r.tag : ""];
+    a.n++; a.ms += t; a.fl += r.flops; a.by += r.bytes;
+  }
+  std::vector<std::pair<std::string, Agg>> v(m.begin(), m.end());
+  std::sort(v.begin(), v.end(), [](const auto& x, const auto& y) { return x.second.ms > y.second.ms; });
+  if (index >= (int)v.size()) return 0;
+  if (name && name_cap > 0) { strncpy(name, v[index].first.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  if (launches) *launches = v[index].second.n;
+  if (total_ms) *total_ms = v[index].second.ms;
+  if (total_flops) *total_flops = v[index].second.fl;
+  if (total_bytes) *total_bytes = v[index].second.by;
+  return 1;
 }
 
 extern "C" double gank_prof_bytes(int family) {

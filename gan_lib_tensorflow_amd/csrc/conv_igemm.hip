@@ -753,6 +753,9 @@ static int launch_patch2(const IgemmArgs& a0, hipStream_t s) {
     if (e != hipSuccess) return gank_set_error("conv_igemm_patch2: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
+  static char tag[64];
+  if (!tag[0]) snprintf(tag, sizeof(tag), "conv_igemm_patch2_kernel<%d>", MODE);
+  gank_prof_tag(0, tag);
   hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
   GANK_LAUNCH_OK("conv_igemm_patch2");
   return 0;
@@ -876,6 +879,9 @@ static int launch_narrow_in(const IgemmArgs& a0, hipStream_t s) {
   IgemmArgs a = a0;
   a.tiles_m = cdiv(a.M, 128);
   a.tiles_n = a.CoutPad / 128;
+  static char tag[64];
+  if (!tag[0]) snprintf(tag, sizeof(tag), "conv_narrow_in_kernel<%d, %d>", KS, CIN);
+  gank_prof_tag(0, tag);
   hipLaunchKernelGGL((conv_narrow_in_kernel<KS, CIN>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
   GANK_LAUNCH_OK("conv_narrow_in");
   return 0;
@@ -894,6 +900,9 @@ static int launch_patch(const IgemmArgs& a0, hipStream_t s) {
     if (e != hipSuccess) return gank_set_error("conv_igemm_patch: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
+  static char tag[64];
+  if (!tag[0]) snprintf(tag, sizeof(tag), "conv_igemm_patch_kernel<%d, %d>", MODE, BN);
+  gank_prof_tag(0, tag);
   hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
   GANK_LAUNCH_OK("conv_igemm_patch");
   return 0;
@@ -913,6 +922,9 @@ static int launch_cfg(const IgemmArgs& a0, hipStream_t s) {
     if (e != hipSuccess) return gank_set_error("conv_igemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
+  static char tag[96];
+  if (!tag[0]) snprintf(tag, sizeof(tag), "conv_igemm_kernel<%d, %d, %d, %d, %s, %d, %d>", WM, WN, TM, TN, PACKED ? "true" : "false", PF, MODE);
+  gank_prof_tag(0, tag);
   hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(WM * WN * 64), lds, s, a);
   GANK_LAUNCH_OK("conv_igemm");
   return 0;
@@ -933,6 +945,9 @@ static int launch_phase(const IgemmArgs& a0, hipStream_t s) {
     if (e != hipSuccess) return gank_set_error("conv_igemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
+  static char tag[96];
+  if (!tag[0]) snprintf(tag, sizeof(tag), "conv_igemm_kernel<%d, %d, %d, %d, false, %d, 4>", WM, WN, TM, TN, PF);
+  gank_prof_tag(0, tag);
   hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(WM * WN * 64), lds, s, a);
   GANK_LAUNCH_OK("conv_igemm_phase");
   return 0;

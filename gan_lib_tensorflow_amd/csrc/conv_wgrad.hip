@@ -532,6 +532,9 @@ static int launch_wgrad_lean_mode(WgradArgs a, hipStream_t s) {
   }
   const long grid = tiles * a.splits;
   GANK_REQUIRE(grid < (1L << 30), "conv_wgrad: grid too large");
+  static char tag[96];
+  if (!tag[0]) snprintf(tag, sizeof(tag), "conv_wgrad_lean_kernel<%d, %d, %d, %d, %d, %d>", WA, WB, TA, TB, PF, MODE);
+  gank_prof_tag(1, tag);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WA * WB * 64), lds, s, a);
   GANK_LAUNCH_OK("conv_wgrad_lean");
   return 0;
@@ -722,6 +725,7 @@ static int launch_wgrad_packed(WgradArgs a, hipStream_t s) {
   a.splits = cdiv(total_steps, a.steps_per_split);
   const size_t lds = (size_t)2 * 5 * SUBS * sizeof(bf16);   // 41.6 KB (>= the 32 KB bias-reduction scratch)
   auto kern = conv_wgrad_packed_kernel<PACK_X>;
+  gank_prof_tag(1, PACK_X ? "conv_wgrad_packed_kernel<true>" : "conv_wgrad_packed_kernel<false>");
   hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * a.splits)), dim3(256), lds, s, a);
   GANK_LAUNCH_OK("conv_wgrad_packed");
   return 0;
@@ -969,6 +973,9 @@ static int launch_wgrad_taps_mode(WgradArgs a, hipStream_t s) {
   static int tpf = -1;
   if (tpf < 0) { const char* e = getenv("GANK_WGRAD_TAPS_PF"); tpf = e ? atoi(e) : 2; }
   auto kern = tpf == 1 ? conv_wgrad_taps_kernel<MODE, 1> : conv_wgrad_taps_kernel<MODE, 2>;
+  static char tag[64];
+  if (!tag[0]) snprintf(tag, sizeof(tag), "conv_wgrad_taps_kernel<%d, 2> + wgrad_reduce_slabs_kernel", MODE);
+  gank_prof_tag(1, tag);
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_ci * a.tiles_co * a.splits)), dim3(256), lds, s, a);
   GANK_LAUNCH_OK("conv_wgrad_taps");
   if (a.ws) {
@@ -1016,6 +1023,9 @@ static int launch_wgrad(WgradArgs a, hipStream_t s) {
   }
   const long grid = tiles * a.splits;
   GANK_REQUIRE(grid < (1L << 30), "conv_wgrad: grid too large");
+  static char tag[96];
+  if (!tag[0]) snprintf(tag, sizeof(tag), "conv_wgrad_kernel<%d, %d, %d, %d, %s, %d>", WA, WB, TA, TB, FAST ? "true" : "false", PF);
+  gank_prof_tag(1, tag);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WA * WB * 64), lds, s, a);
   GANK_LAUNCH_OK("conv_wgrad");
   return 0;
@@ -1032,7 +1042,7 @@ int gank_wgrad_dispatch(WgradArgs a, hipStream_t s) {
   GANK_REQUIRE((long)a.N * a.H * a.W < (1L << 31), "conv_wgrad: too many pixels");
   const double flops = 2.0 * a.M * (double)a.Cout * a.taps * a.Cin;
   const bool fast = (a.Cin % 8 == 0) && (a.Cout % 8 == 0);
-  gank_prof_begin(1, flops, s);
+  gank_prof_begin(1, flops, s, 2.0 * ((double)a.N * a.Hx * a.Wx * a.Cin + (double)a.N * a.Hdy * a.Wdy * a.Cout) + 4.0 * a.taps * a.Cin * a.Cout);
   int rc = -1;
   const bool lean = fast && a.sw >= 0 && a.shw >= 0 && (a.M % 64 == 0) &&
                     (long)a.N * a.Hx * a.Wx * a.Cin < (1L << 30) && (long)a.N * a.Hdy * a.Wdy * a.Cout < (1L << 30);

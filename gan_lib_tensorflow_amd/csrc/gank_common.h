@@ -40,6 +40,7 @@ static inline int log2_or_neg(int v) { int s = 0; while ((1 << s) < v) s++; retu
 // profiling hooks (api.hip)
 void gank_prof_begin(int family, double flops, hipStream_t s, double bytes = 0.0);   // bytes: algorithmic operand + result bytes
 void gank_prof_end(int family, hipStream_t s);
+void gank_prof_tag(int family, const char* kernel_name);   // names the kernel of the open record (static string)
 
 #ifdef __HIPCC__
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }

@@ -552,6 +552,18 @@ def prof_collect(family):
     return n, ms.value, fl.value
 
 
+def prof_kernels(family):
+    """[(kernel symbol, launches, total_ms, flops, algorithmic_bytes)] of a family, longest total time first"""
+    out, i = [], 0
+    while True:
+        name = C.create_string_buffer(128)
+        n, ms, fl, by = C.c_int(0), C.c_double(0), C.c_double(0), C.c_double(0)
+        if not lib().gank_prof_kernel_stats(family, i, name, 128, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)):
+            return out
+        out.append((name.value.decode(), n.value, ms.value, fl.value, by.value))
+        i += 1
+
+
 def prof_bytes(family):
     return float(lib().gank_prof_bytes(int(family)))
 

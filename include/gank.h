@@ -268,6 +268,10 @@ int gank_prof_reset(void);
 /* fills up to `cap` records {launches, total_ms, total_flops} for kernel family `family`
  * (0 = conv_fprop/dgrad igemm, 1 = conv_wgrad); synchronises.  Returns number of launches. */
 int gank_prof_collect(int family, double* total_ms, double* total_flops);
+/* per-kernel breakdown of a family: entry `index` (longest total time first) -> kernel symbol name (as rocprofv3
+ * prints it, without the argument list), launches, total ms, FLOPs, algorithmic bytes; returns 0 past the end */
+int gank_prof_kernel_stats(int family, int index, char* name, int name_cap, int* launches, double* total_ms,
+                           double* total_flops, double* total_bytes);
 /* sum of the algorithmic bytes (operands read once + result written once) of the recorded launches of `family` */
 double gank_prof_bytes(int family);
 /* average milliseconds an event pair around an EMPTY kernel reads (n launches): the fixed cost inside every record */

@@ -8,20 +8,27 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 280 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_b_$c -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 2 > /dev/null 2>&1 < /dev/null || { echo "pass $c failed"; exit 1; }
 done
 python3 - "$out" <<'PY'
-import csv, glob, sys, json, collections
-res = {}
-fam = lambda n: ('conv_igemm' in n or 'conv_narrow' in n)
+import csv, glob, sys, json, collections, re
+def sym(n):      # rocprofv3 prints "void name<...>(ArgTypes)": keep name<...> as libgank's launchers record it
+    n = re.sub(r"^void ", "", n)
+    return re.sub(r"\((IgemmArgs|WgradArgs)\)$", "", n)
+per = collections.defaultdict(lambda: {"FETCH_SIZE": [], "WRITE_SIZE": []})
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f'/tmp/pmc_b_{c}/**/*counter_collection.csv', recursive=True)[0]
-    vals = [float(r['Counter_Value']) for r in csv.DictReader(open(f)) if r['Counter_Name'] == c and fam(r['Kernel_Name'])]
-    res[c] = {"launches": len(vals), "avg_kb_per_launch": sum(vals) / max(len(vals), 1)}
-fetch = 2.0 * 1024.0 * res["FETCH_SIZE"]["avg_kb_per_launch"]      # gfx950: FETCH_SIZE tallies 128-B requests at 64 B
-write = 1024.0 * res["WRITE_SIZE"]["avg_kb_per_launch"]
-res["bytes_per_launch"] = fetch + write
-res["fetch_bytes_per_launch_corrected"] = fetch
-res["write_bytes_per_launch"] = write
-res["kernel_family"] = "conv_igemm_* + conv_narrow_in (fprop + dgrad), all launches of bench.py --steps 3 --warmup 2"
+    for r in csv.DictReader(open(f)):
+        if r['Counter_Name'] == c and ('conv_' in r['Kernel_Name']) and 'prep' not in r['Kernel_Name']:
+            per[sym(r['Kernel_Name'])][c].append(float(r['Counter_Value']))
+res = {"per_kernel": {}}
+for k, d in per.items():
+    if not d["FETCH_SIZE"] or not d["WRITE_SIZE"]:
+        continue
+    fetch = 2.0 * 1024.0 * sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"])     # gfx950: FETCH_SIZE tallies 128-B requests at 64 B
+    write = 1024.0 * sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
+    res["per_kernel"][k] = {"launches": len(d["FETCH_SIZE"]), "fetch_bytes_per_launch_corrected": fetch,
+                            "write_bytes_per_launch": write, "bytes_per_launch": fetch + write}
+res["workload"] = "every conv kernel launch of bench.py --no-cpu-baseline --steps 3 --warmup 2"
 res["method"] = "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; KB -> bytes; FETCH_SIZE x2 (gfx950)"
 json.dump(res, open(sys.argv[1], "w"), indent=1)
-print(json.dumps(res))
+for k, v in sorted(res["per_kernel"].items(), key=lambda kv: -kv[1]["bytes_per_launch"] * kv[1]["launches"])[:8]:
+    print(k, v)
 PY
