@@ -219,37 +219,54 @@ __global__ void cbn_zero_kernel(float* __restrict__ p, int n4) {
 
 // b2: table gradients and per-tower means.  grid = (C/64, n_labels + 1): block row l < n_labels owns label l
 // (sequential over n: deterministic, no atomics, registers only); the last block row computes the means.
-__global__ void cbn_bwd_tables_kernel(const float* __restrict__ S, const int* __restrict__ labels, const float* __restrict__ gamma,
-                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ M, CbnGeom q) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= q.C) return;
+__global__ __launch_bounds__(256) void cbn_bwd_tables_kernel(const float* __restrict__ S, const int* __restrict__ labels,
+                                                            const float* __restrict__ gamma, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ M, CbnGeom q) {
+  // 64 channels x 4 waves: wave w takes the samples n = w (mod 4) -- the sample loop was the whole run time of the
+  // 64-thread version (N dependent load pairs in a row); the 4 partial sums meet in LDS, in a fixed order
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int cc = c < q.C ? c : q.C - 1;
   const int l = blockIdx.y;
+  __shared__ float red[4][2][64];
   if (l < q.n_labels) {
     float a1 = 0.f, a2 = 0.f;
 #pragma unroll 8
-    for (int n = 0; n < q.N; n++) {      // unconditional loads (pipelined), predicated adds
+    for (int n = wv; n < q.N; n += 4) {      // unconditional loads (pipelined), predicated adds
       int lb = labels[n];
       lb = lb < 0 ? 0 : (lb >= q.n_labels ? q.n_labels - 1 : lb);
-      const float s1 = S[((long)n * 2) * q.C + c], s2 = S[((long)n * 2 + 1) * q.C + c];
+      const float s1 = S[((long)n * 2) * q.C + cc], s2 = S[((long)n * 2 + 1) * q.C + cc];
       a1 += (lb == l) ? s1 : 0.f;
       a2 += (lb == l) ? s2 : 0.f;
     }
-    dbeta[(long)l * q.C + c] += a1;
-    dgamma[(long)l * q.C + c] += a2;
+    red[wv][0][lane] = a1;
+    red[wv][1][lane] = a2;
+    __syncthreads();
+    if (wv == 0 && c < q.C) {
+      dbeta[(long)l * q.C + c] += red[0][0][lane] + red[1][0][lane] + red[2][0][lane] + red[3][0][lane];
+      dgamma[(long)l * q.C + c] += red[0][1][lane] + red[1][1][lane] + red[2][1][lane] + red[3][1][lane];
+    }
   } else {
     const int gs = q.N / q.groups;
     for (int grp = 0; grp < q.groups; grp++) {
       float m1 = 0.f, m2 = 0.f;
-      for (int i = 0; i < gs; i++) {
+#pragma unroll 4
+      for (int i = wv; i < gs; i += 4) {
         const int n = grp * gs + i;
         int lb = labels[n];
         lb = lb < 0 ? 0 : (lb >= q.n_labels ? q.n_labels - 1 : lb);
-        const float ga = gamma[(long)lb * q.C + c];
-        m1 += ga * S[((long)n * 2) * q.C + c];
-        m2 += ga * S[((long)n * 2 + 1) * q.C + c];
+        const float ga = gamma[(long)lb * q.C + cc];
+        m1 += ga * S[((long)n * 2) * q.C + cc];
+        m2 += ga * S[((long)n * 2 + 1) * q.C + cc];
       }
-      M[((long)grp * 2) * q.C + c] = m1 / (float)q.rows_per_group;
-      M[((long)grp * 2 + 1) * q.C + c] = m2 / (float)q.rows_per_group;
+      __syncthreads();                       // the previous group's sums have been read
+      red[wv][0][lane] = m1;
+      red[wv][1][lane] = m2;
+      __syncthreads();
+      if (wv == 0 && c < q.C) {
+        M[((long)grp * 2) * q.C + c] = (red[0][0][lane] + red[1][0][lane] + red[2][0][lane] + red[3][0][lane]) / (float)q.rows_per_group;
+        M[((long)grp * 2 + 1) * q.C + c] = (red[0][1][lane] + red[1][1][lane] + red[2][1][lane] + red[3][1][lane]) / (float)q.rows_per_group;
+      }
     }
   }
 }
@@ -303,7 +320,7 @@ extern "C" int gank_cbn_bwd(const void* dy, const void* x, const void* y, const 
   // its kernel neighbours (intermittent NaN generator gradients under graph replay, never in eager mode)
   if (hw_parts > 1) hipLaunchKernelGGL(cbn_zero_kernel, dim3(cdiv(N * 2 * C / 4, 256)), dim3(256), 0, s, S, N * 2 * C / 4);
   hipLaunchKernelGGL(cbn_bwd_sums_kernel, dim3(N * hw_parts), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (const bf16*)y, stats, S, q, hw_parts);
-  hipLaunchKernelGGL(cbn_bwd_tables_kernel, dim3(cdiv(C, 64), n_labels + 1), dim3(64), 0, s, S, labels, gamma, dgamma, dbeta, M, q);
+  hipLaunchKernelGGL(cbn_bwd_tables_kernel, dim3(cdiv(C, 64), n_labels + 1), dim3(256), 0, s, S, labels, gamma, dgamma, dbeta, M, q);
   const long total8 = (long)N * HW * (C / 8);
   long blocks = (total8 + 255) / 256;
   if (blocks > 4096) blocks = 4096;

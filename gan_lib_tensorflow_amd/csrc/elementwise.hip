@@ -609,15 +609,17 @@ __global__ void concat_tile_fwd_kernel(const bf16* __restrict__ a, const bf16* _
   }
 }
 
-// da = dy[..., :C1] ; de[n, c] = sum_hw dy[n, hw, C1 + c]   (block per sample)
-__global__ void concat_tile_bwd_kernel(const bf16* __restrict__ dy, bf16* __restrict__ da, bf16* __restrict__ de, int HW, int C1, int C2) {
+// da = dy[..., :C1] ; de[n, c] = sum_hw dy[n, hw, C1 + c]   (block of 1024 threads per sample)
+__global__ __launch_bounds__(1024) void concat_tile_bwd_kernel(const bf16* __restrict__ dy, bf16* __restrict__ da, bf16* __restrict__ de,
+                                                              int HW, int C1, int C2) {
+  constexpr int NT = 1024;
   const int n = blockIdx.x, C = C1 + C2;
   const int cg1 = C1 >> 3;
-  for (int i = threadIdx.x; i < HW * cg1; i += 256) {
+  for (int i = threadIdx.x; i < HW * cg1; i += NT) {
     const int g = i % cg1, r = i / cg1;
     *reinterpret_cast<bf16x8*>(da + ((long)n * HW + r) * C1 + g * 8) = *reinterpret_cast<const bf16x8*>(dy + ((long)n * HW + r) * C + g * 8);
   }
-  const int cg2 = C2 >> 3, RL = 256 / cg2;
+  const int cg2 = C2 >> 3, RL = NT / cg2;
   const int g = threadIdx.x % cg2, rl = threadIdx.x / cg2;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (rl < RL)
@@ -626,11 +628,11 @@ __global__ void concat_tile_bwd_kernel(const bf16* __restrict__ dy, bf16* __rest
 #pragma unroll
       for (int e = 0; e < 8; e++) acc[e] += bf2f(v[e]);
     }
-  __shared__ float red[256 * 8];
+  __shared__ float red[NT * 8];
 #pragma unroll
   for (int e = 0; e < 8; e++) red[threadIdx.x * 8 + e] = acc[e];
   __syncthreads();
-  for (int c = threadIdx.x; c < C2; c += 256) {
+  for (int c = threadIdx.x; c < C2; c += NT) {
     float t = 0.f;
     for (int l = 0; l < RL; l++) t += red[(l * cg2 + (c >> 3)) * 8 + (c & 7)];
     de[(long)n * C2 + c] = f2bf(t);
@@ -647,8 +649,8 @@ extern "C" int gank_concat_tile_fwd(const void* a, const void* e, void* y, int N
 }
 extern "C" int gank_concat_tile_bwd(const void* dy, void* da, void* de, int N, int HW, int C1, int C2, void* stream) {
   GANK_REQUIRE(dy && da && de && N > 0 && HW > 0, "concat_tile_bwd: bad arguments");
-  GANK_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && 256 % (C2 / 8) == 0, "concat_tile_bwd: unsupported channel counts %d,%d", C1, C2);
-  hipLaunchKernelGGL(concat_tile_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, (bf16*)da, (bf16*)de, HW, C1, C2);
+  GANK_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && 1024 % (C2 / 8) == 0, "concat_tile_bwd: unsupported channel counts %d,%d", C1, C2);
+  hipLaunchKernelGGL(concat_tile_bwd_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, (const bf16*)dy, (bf16*)da, (bf16*)de, HW, C1, C2);
   GANK_LAUNCH_OK("concat_tile_bwd");
   return 0;
 }
