@@ -240,3 +240,35 @@ def test_graph_replay_stays_finite_with_poisoned_workspaces(gpu, monkeypatch):
         del tr, feed
         gc.collect()
         torch.cuda.synchronize()
+
+
+def test_unconditional_generator_uses_batch_norm(gpu):
+    """CONDITIONAL=False routes Normalize to batch_norm (gan_cifar_resnet.py:92-106): with freshly initialised
+    tables (scale 1, offset 0) the conditional and the unconditional generator are the same function, and the
+    unconditional one owns BatchNorm variables with moving statistics instead of CondBatchNorm tables."""
+    from gan_lib_tensorflow_amd.SNGAN import gan_cifar_resnet as S
+    from gan_lib_tensorflow_amd.common import resnet_block as blocks
+    from gan_lib_tensorflow_amd.store import ParamStore, set_default_store
+    g = torch.Generator().manual_seed(4)
+    z = torch.randn(8, 128, generator=g).to(torch.bfloat16).cuda()
+    labels = torch.randint(0, 10, (8,), generator=g, dtype=torch.int32).cuda()
+    imgs = {}
+    for cond in (True, False):
+        blocks.CONDITIONAL = cond
+        try:
+            store = set_default_store(ParamStore("cuda", seed=7))
+            z_in = z.clone().requires_grad_(not cond)
+            img = S.Generator(8, labels, noise=z_in, groups=2)
+            imgs[cond] = img.detach().clone()
+            names = list(store.vars)
+            if cond:
+                assert any(k.endswith('CondBatchNorm/scale') for k in names) and not any('BatchNorm/gamma' in k for k in names)
+            else:
+                assert any(k.endswith('G.Block.1.N1/BatchNorm/gamma') for k in names) and not any('CondBatchNorm' in k for k in names)
+                img.float().sum().backward()                      # gradients flow through the batch-norm path
+                gm = store.vars['Generator/G.OutputNorm/BatchNorm/gamma']
+                assert gm.grad is not None and bool(torch.isfinite(gm.grad).all()) and float(gm.grad.abs().sum()) > 0
+                assert float(store.vars['Generator/G.OutputNorm/BatchNorm/moving_mean/local_step']) == 2.0    # two towers
+        finally:
+            blocks.CONDITIONAL = True
+    assert torch.equal(imgs[True], imgs[False])
