@@ -28,6 +28,8 @@ DIM_D = 128
 # per channel): the shortcut convolutions run at the LOW resolution, 4x fewer MACs (exact in real
 # arithmetic; bf16 rounding of the intermediate moves from before to after the resampling).
 COMMUTE_1X1 = True
+# the commuted 'up' shortcut stays at half resolution and is added, upsampled on the fly, in conv_2's epilogue
+FUSE_SHORTCUT_UPSAMPLE = True
 
 
 def nonlinearity(x, activation_fn='relu', leakiness=0.2):
@@ -99,6 +101,9 @@ def UpsampleConv(inputs, output_dim, filter_size=3, stride=1, name=None,
         low = _conv2d.Conv2D(inputs, inputs.shape[-1], output_dim, filter_size, stride, name,
                              spectral_normed=spectral_normed, update_collection=update_collection,
                              he_init=he_init, biases=biases)
+        if FUSE_SHORTCUT_UPSAMPLE:
+            low._up2x = True      # consumed as `residual=`: the next conv's epilogue adds it upsampled (no materialisation)
+            return low
         return Fn.upsample_nn2x(low)
     return _conv2d.Conv2D(inputs, inputs.shape[-1], output_dim, filter_size, stride, name,
                           spectral_normed=spectral_normed, update_collection=update_collection,

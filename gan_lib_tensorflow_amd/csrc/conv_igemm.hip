@@ -22,6 +22,7 @@
 #define IG_IN_ZEROINS2X 16
 #define IG_IN_STRIDE2 32
 #define IG_W_FRAG 64          // the operand buffer carries the fragment-major copy (public GANK_W_FRAG)
+#define IG_RES_UP2X 128       // residual is [N,H/2,W/2,Cout]: read at (oh>>1, ow>>1) (public GANK_RES_UPSAMPLE2X)
 
 struct IgemmArgs {
   const bf16* x;
@@ -296,6 +297,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
       pix_decomp(m, a.H, a.W, a.shw, a.sw, n_, y_, x_);
       m = (n_ * 2 * a.H + 2 * y_ + (phase >> 1)) * 2 * a.W + 2 * x_ + (phase & 1);
     }
+    long mr = m;                 // residual pixel: the output pixel, or its low-resolution parent
+    if (!PHASE && (a.flags & IG_RES_UP2X)) {
+      int n_, y_, x_;
+      pix_decomp(m, a.H, a.W, a.shw, a.sw, n_, y_, x_);
+      mr = ((long)(n_ * (a.H >> 1) + (y_ >> 1))) * (a.W >> 1) + (x_ >> 1);
+    }
 #pragma unroll
     for (int i = 0; i < TN; i++) {
       const int co0 = tile_n * BN + (wave_n * TN + i) * 32 + 4 * h;
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
             for (int e = 0; e < 4; e++) v[e] = (bf2f(mk[e]) > 0.f) ? v[e] : 0.f;
           }
           if (a.res) {
-            const bf16x4 rs = *reinterpret_cast<const bf16x4*>(a.res + o);
+            const bf16x4 rs = *reinterpret_cast<const bf16x4*>(a.res + mr * a.Cout + co);
 #pragma unroll
             for (int e = 0; e < 4; e++) v[e] += bf2f(rs[e]);
           }
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
             float t = v[e];
             if (a.bias) t += a.bias[co + e];
             if (a.mask) t = (bf2f(a.mask[o + e]) > 0.f) ? t : 0.f;
-            if (a.res) t += bf2f(a.res[o + e]);
+            if (a.res) t += bf2f(a.res[mr * a.Cout + co + e]);
             a.y[o + e] = f2bf(otanh ? tanhf(t) : t);
           }
         }
@@ -503,6 +510,7 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
   for (int j = 0; j < TM; j++) {
     const int py = wave_m * 2 * TM + 2 * j + (r >> 4), px = r & 15;
     const long m = ((long)(n * a.H + py0 + py)) * a.W + px0 + px;
+    const long mr = (a.flags & IG_RES_UP2X) ? ((long)(n * (a.H >> 1) + ((py0 + py) >> 1))) * (a.W >> 1) + ((px0 + px) >> 1) : m;
 #pragma unroll
     for (int i = 0; i < TN; i++) {
       const int co0 = tile_n * BN + (wave_n * TN + i) * 32 + 4 * h;
@@ -521,7 +529,7 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
             float t = v[e];
             if (a.bias) t += a.bias[co + e];
             if (a.mask) t = (bf2f(a.mask[o + e]) > 0.f) ? t : 0.f;
-            if (a.res) t += bf2f(a.res[o + e]);
+            if (a.res) t += bf2f(a.res[mr * a.Cout + co + e]);
             a.y[o + e] = f2bf(otanh ? tanhf(t) : t);
           }
           continue;
@@ -537,7 +545,7 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
           for (int e = 0; e < 4; e++) v[e] = (bf2f(mk[e]) > 0.f) ? v[e] : 0.f;
         }
         if (a.res) {
-          const bf16x4 rs = *reinterpret_cast<const bf16x4*>(a.res + o);
+          const bf16x4 rs = *reinterpret_cast<const bf16x4*>(a.res + mr * a.Cout + co);
 #pragma unroll
           for (int e = 0; e < 4; e++) v[e] += bf2f(rs[e]);
         }
@@ -997,9 +1005,9 @@ int gank_igemm_dispatch(IgemmArgs a, hipStream_t s) {
   const bool patch32_ok = patch_geom && a.CoutPad == 32;
   static int patch2_env = -1;  // experiment knob: GANK_IGEMM_PATCH2=0 disables the register-weight patch kernel
   if (patch2_env < 0) { const char* e = getenv("GANK_IGEMM_PATCH2"); patch2_env = e ? atoi(e) : 1; }
-  const bool patch2_ok = patch_ok && patch2_env && (a.flags & IG_W_FRAG) && a.W % 16 == 0 && a.H % 16 == 0 && a.Cout % 128 == 0 &&
+  const bool patch2_ok = patch_ok && patch2_env && !(a.flags & IG_RES_UP2X) && (a.flags & IG_W_FRAG) && a.W % 16 == 0 && a.H % 16 == 0 && a.Cout % 128 == 0 &&
                          a.Kpad == a.taps * a.Cin && (long)a.CoutPad * a.Kpad * 2 < (1L << 30);
-  const bool narrow_ok = a.Cin == 3 && (a.ks == 1 || a.ks == 3) && a.pad == (a.ks - 1) / 2 && a.CoutPad % 128 == 0 && a.Cout % 4 == 0 &&
+  const bool narrow_ok = !(a.flags & IG_RES_UP2X) && a.Cin == 3 && (a.ks == 1 || a.ks == 3) && a.pad == (a.ks - 1) / 2 && a.CoutPad % 128 == 0 && a.Cout % 4 == 0 &&
                          !(a.flags & (GANK_IN_UPSAMPLE2X | IG_IN_ZEROINS2X | IG_IN_STRIDE2)) && a.Hin == a.H && a.Win == a.W;
   if (narrow_ok) {
     rc = a.ks == 3 ? launch_narrow_in<3, 3>(a, s) : launch_narrow_in<1, 3>(a, s);
@@ -1046,7 +1054,9 @@ extern "C" int gank_conv2d_fprop(const void* x, const void* wf, const float* bia
   const bool up = flags & GANK_IN_UPSAMPLE2X;
   a.Hin = up ? H / 2 : H; a.Win = up ? W / 2 : W;
   a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.pad = (ksize - 1) / 2;
-  a.flags = (flags & (GANK_IN_UPSAMPLE2X | GANK_IN_RELU | GANK_OUT_TANH)) | ((flags & GANK_W_FRAG) ? IG_W_FRAG : 0);
+  a.flags = (flags & (GANK_IN_UPSAMPLE2X | GANK_IN_RELU | GANK_OUT_TANH)) | ((flags & GANK_W_FRAG) ? IG_W_FRAG : 0) |
+            ((flags & GANK_RES_UPSAMPLE2X) ? IG_RES_UP2X : 0);
+  GANK_REQUIRE(!(flags & GANK_RES_UPSAMPLE2X) || (residual && H % 2 == 0 && W % 2 == 0), "conv2d_fprop: RES_UPSAMPLE2X needs a residual and even output size");
   a.scale = scale;
   return gank_igemm_dispatch(a, (hipStream_t)stream);
 }

@@ -95,10 +95,17 @@ class _Conv2d(Function):
         H, Wd = (2 * h, 2 * w) if upsample else (h, w)
         flags = (K.IN_UPSAMPLE2X if upsample else 0) | (K.IN_RELU if in_relu else 0) | (K.OUT_TANH if out_tanh else 0)
         b = bias.detach() if bias is not None else None
+        # a shortcut computed at half resolution (1x1 conv commuted with the upsample): the epilogue adds it
+        # nearest-neighbour upsampled; paths without that epilogue get it materialised
+        res_up = residual is not None and getattr(residual, "_up2x", False)
+        ctx.res_up_orig = res_up
         # NN-upsample + 3x3: run as the 4 output phases of the equivalent 4x4 stride-2 transposed conv
         phase = upsample and k == 3 and cin % 64 == 0 and not in_relu and PHASE_UPCONV
         # 3x3 conv + 2x2 mean pool: run as ONE 4x4 stride-2 conv (16 taps per pooled pixel = 4 per conv output)
         pool4 = pool_out and k == 3 and cin % 64 == 0 and cout % 64 == 0 and POOL_CONV4
+        if res_up and (phase or pool_out):
+            residual = K.unpool2x2_add(residual, None, 1.0)
+            res_up = False
         if phase:
             wph, _ = getattr(W, "_prep_up", None) or K.upconv3x3_prep(W.detach().view(3, 3, cin, cout))
             y = K.upconv3x3_fprop(x, wph, b, cout, K.OUT_TANH if out_tanh else 0, residual)
@@ -111,7 +118,8 @@ class _Conv2d(Function):
             y = K.pool2x2(yfull, 0.25, residual)
         else:
             wf, _ = _prepared(W, k, cin, cout, True, False)
-            y = K.conv2d_fprop(x, wf, b, (H, Wd), cout, k, flags, 1.0, residual)
+            y = K.conv2d_fprop(x, wf, b, (H, Wd), cout, k, flags | (K.RES_UPSAMPLE2X if res_up else 0), 1.0, residual)
+        ctx.res_up = res_up
         ctx.save_for_backward(x, W, y if out_tanh else None)
         ctx.cfg = (k, cin, cout, H, Wd, upsample, in_relu, pool_out, out_tanh, bias, phase, pool4)
         return y
@@ -157,7 +165,10 @@ class _Conv2d(Function):
                     dx = K.relu_bwd(dx, x)
             else:
                 dx = K.conv2d_dgrad(g, wd, (H, Wd), cin, k, dflags, scale, None, x if in_relu else None)
-        dres = g if ctx.needs_input_grad[3] else None
+        dres = None
+        if ctx.needs_input_grad[3]:
+            # gradient of the (upsampled) shortcut add: dy itself, or its 2x2 sums for a half-resolution shortcut
+            dres = K.pool2x2(g, 1.0) if (ctx.res_up or getattr(ctx, "res_up_orig", False)) else g
         return dx, dW, db, dres, None, None, None, None
 
 

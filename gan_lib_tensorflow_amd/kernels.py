@@ -6,7 +6,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, W_FRAG, SnDesc, PrepDesc  # noqa: F401
+from ._lib import IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, W_FRAG, RES_UPSAMPLE2X, SnDesc, PrepDesc  # noqa: F401
 
 BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
 

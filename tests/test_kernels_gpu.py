@@ -578,3 +578,19 @@ def test_batch_norm_op_and_get_loss(K):
     assert relerr(realt.grad, dref[:7]) < BF_TOL and relerr(faket.grad, dref[7:]) < BF_TOL
     with pytest.raises(NotImplementedError):
         misc.get_loss(realt, faket, 'WGAN-GP')
+
+
+@pytest.mark.parametrize("n,h,cin,cout,k", [(3, 8, 64, 128, 3), (2, 16, 128, 128, 3), (2, 32, 64, 256, 3), (2, 8, 64, 64, 1), (1, 6, 64, 96, 3)])
+def test_conv_fprop_upsampled_residual(K, n, h, cin, cout, k):
+    """GANK_RES_UPSAMPLE2X: the shortcut of an 'up' block (gan_cifar_resnet.py:179-182,209) stays at half resolution
+    and is added nearest-neighbour upsampled in the epilogue (generic and patch kernels)."""
+    rng = np.random.default_rng(n + h + cin + cout + k)
+    x, xt = bf(rng.normal(size=(n, h, h, cin)))
+    w, _ = bf(rng.normal(size=(k, k, cin, cout)) / np.sqrt(k * k * cin))
+    b, bt = f32(rng.normal(size=cout))
+    res, rest = bf(rng.normal(size=(n, h // 2, h // 2, cout)))
+    wf, _ = K.prep_weights(torch.tensor(w, dtype=torch.float32).cuda(), True, False)
+    y = K.conv2d_fprop(xt, wf, bt, (h, h), cout, k, K.RES_UPSAMPLE2X, 1.0, rest)
+    ref = R.conv2d_same(x, w, b) + R.upsample_nn2x(res)
+    torch.cuda.synchronize()
+    assert relerr(y, ref) < BF_TOL
