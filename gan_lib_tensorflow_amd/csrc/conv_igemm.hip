@@ -371,9 +371,15 @@ constexpr int HROWP = 1408;  // 2816 B = 11 x 256 B  (>= 18 * LROW = 1296)
 // BN = 128: 2 x 2 waves of 64 pixels x 64 couts.  BN = 32: 4 x 1 waves of 32 pixels x 32 couts, for the 3-channel
 // output conv of the generator (G.Output 256 -> 3, padded to one 32-row MFMA tile): the generic 256x32 kernel
 // re-fetched the 256-channel pixel operand per tap; here it is staged once per chunk like any other 3x3 conv.
+// MODE bit 2 (PHASE): one output phase (a, b) of a stride-2 transposed conv -- UpsampleConv 3x3 fprop, ConvMeanPool
+// input gradient -- over an 8x16 LOW-RES patch: 2x2 taps at offsets (i - (1-a), j - (1-b)) out of the same halo,
+// weights of phase p at w + p*CoutPad*Kpad (Kpad = 4*Cin), results written to (2y+a, 2x+b).  The per-tap gather of
+// the generic phase kernel fetched 16 KB of pixels per 16 KB of weights per step; the halo makes it 23 KB per 4 steps.
 template <int MODE, int BN>   // MODE bit0: relu on the input operand
 __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
   constexpr int NT = 256;
+  constexpr bool PHASE = (MODE & 4) != 0;
+  constexpr int NTAPS = PHASE ? 4 : 9, KS = PHASE ? 2 : 3;
   constexpr int WN = BN == 128 ? 2 : 1, WM = 4 / WN, TN = BN / (32 * WN), TM = 4 / WM;   // wave tile TM x TN MFMA tiles
   constexpr int CW = BN * 8 / NT;                       // weight chunks per thread per step
   static_assert(BN == 128 || BN == 32, "cout tile");
@@ -387,14 +393,19 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
 
   const int nwg = a.tiles_m * a.tiles_n;
   const int lid = xcd_remap(blockIdx.x, nwg);
-  const int tile_n = lid % a.tiles_n, tile_m = lid / a.tiles_n;
+  const int tile_n = lid % a.tiles_n;
+  int tile_m = lid / a.tiles_n;
+  int phase = 0;
+  if constexpr (PHASE) { phase = tile_m / a.tiles_pp; tile_m -= phase * a.tiles_pp; }
+  const int pad_h = PHASE ? 1 - (phase >> 1) : 1, pad_w = PHASE ? 1 - (phase & 1) : 1;
   const int pw = a.W >> 4, ph = a.H >> 3;               // patches per row / column
   const int n = tile_m / (pw * ph), pr = tile_m - n * pw * ph;
   const int py0 = (pr / pw) << 3, px0 = (pr % pw) << 4;
 
   constexpr int OOB = 0x7FFFFFF0;
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, a.N * a.H * a.W * a.Cin * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w), 0, a.CoutPad * a.Kpad * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w) + (PHASE ? (long)phase * a.CoutPad * a.Kpad : 0L), 0,
+                                                                        a.CoutPad * a.Kpad * 2, 0x00020000);
 
   // halo chunks of this thread: 1440 16-byte chunks over 256 threads = 6 slots (the last one partial)
   int h_off[6], h_lds[6];
@@ -416,7 +427,7 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
 
   u32x4 rH[6], rW[CW];
   const int nchunks = a.Cin >> 6;
-  const int last = nchunks * 9 - 1;
+  const int last = nchunks * NTAPS - 1;
   int wcur = 0, wtap = 0, wc0 = 0;      // weight cursor (chunk outer, tap inner): k offset = tap*Cin + c0
   auto load_w = [&]() {
     const int wk = (wtap * a.Cin + wc0) * 2;
@@ -424,7 +435,7 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
     for (int j = 0; j < CW; j++) rW[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off[j], wk, 0);
     if (wcur < last) {
       wcur++;
-      if (++wtap == 9) { wtap = 0; wc0 += 64; }
+      if (++wtap == NTAPS) { wtap = 0; wc0 += 64; }
     }
   };
   auto store_w = [&](int buf) {
@@ -473,9 +484,9 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
   int s = 0;
   for (int c = 0; c < nchunks; c++) {
     if (c + 1 < nchunks) load_halo(c + 1);           // in flight during the 9 tap-steps of this chunk
-    int dh = -1, dw = -1;
+    int dh = -pad_h, dw = -pad_w;
 #pragma unroll 1
-    for (int tap = 0; tap < 9; tap++, s++) {
+    for (int tap = 0; tap < NTAPS; tap++, s++) {
       const int buf = s & 1;
       if (s < last) load_w();                        // weights of step s+1
       const int toff = dh * HROWP + dw * LROW;
@@ -495,7 +506,7 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
       }
       if (s < last) store_w(buf ^ 1);
       __syncthreads();
-      if (++dw > 1) { dw = -1; dh++; }
+      if (++dw > KS - 1 - pad_w) { dw = -pad_w; dh++; }
     }
     if (c + 1 < nchunks) {                           // every wave is past its last read of the patch (barrier)
       store_halo();
@@ -509,8 +520,9 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
 #pragma unroll
   for (int j = 0; j < TM; j++) {
     const int py = wave_m * 2 * TM + 2 * j + (r >> 4), px = r & 15;
-    const long m = ((long)(n * a.H + py0 + py)) * a.W + px0 + px;
-    const long mr = (a.flags & IG_RES_UP2X) ? ((long)(n * (a.H >> 1) + ((py0 + py) >> 1))) * (a.W >> 1) + ((px0 + px) >> 1) : m;
+    const long m = PHASE ? ((long)(n * 2 * a.H + 2 * (py0 + py) + (phase >> 1))) * (2 * a.W) + 2 * (px0 + px) + (phase & 1)
+                         : ((long)(n * a.H + py0 + py)) * a.W + px0 + px;
+    const long mr = (!PHASE && (a.flags & IG_RES_UP2X)) ? ((long)(n * (a.H >> 1) + ((py0 + py) >> 1))) * (a.W >> 1) + ((px0 + px) >> 1) : m;
 #pragma unroll
     for (int i = 0; i < TN; i++) {
       const int co0 = tile_n * BN + (wave_n * TN + i) * 32 + 4 * h;
@@ -746,6 +758,33 @@ __global__ __launch_bounds__(256) void conv_igemm_patch2_kernel(IgemmArgs a) {
       }
     }
   }
+}
+
+template <int MODE>    // MODE has bit 2 set
+static int launch_patch_phase(const IgemmArgs& a0, hipStream_t s) {
+  IgemmArgs a = a0;
+  a.tiles_pp = a.N * (a.H / 8) * (a.W / 16);
+  a.tiles_m = 4 * a.tiles_pp;
+  a.tiles_n = a.CoutPad / 128;
+  const size_t lds = ((size_t)10 * HROWP + (size_t)2 * 128 * LROW) * sizeof(bf16);
+  auto kern = conv_igemm_patch_kernel<MODE, 128>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return gank_set_error("conv_igemm_patch: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  static char tag[64];
+  if (!tag[0]) snprintf(tag, sizeof(tag), "conv_igemm_patch_kernel<%d, 128>", MODE);
+  gank_prof_tag(0, tag);
+  hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+  GANK_LAUNCH_OK("conv_igemm_patch_phase");
+  return 0;
+}
+static bool patch_phase_ok(const IgemmArgs& a) {   // a.H, a.W = low-res grid; a.Cin % 64 == 0 is checked by the callers
+  static int env = -1;   // GANK_IGEMM_PATCH_PHASE=0 keeps the per-tap phase kernel
+  if (env < 0) { const char* e = getenv("GANK_IGEMM_PATCH_PHASE"); env = e ? atoi(e) : 1; }
+  return env && a.W % 16 == 0 && a.H % 8 == 0 && a.CoutPad % 128 == 0 && a.Cout % 4 == 0 && a.Cin % 64 == 0;
 }
 
 template <int MODE>
@@ -1097,7 +1136,8 @@ extern "C" int gank_upconv3x3_fprop(const void* x, const void* wph, const float*
   gank_prof_begin(0, 2.0 * a.M * 4.0 * (double)Cout * 4 * Cin, s, 2.0 * ((double)a.M * Cin + 16.0 * Cin * Cout + 4.0 * a.M * Cout));
   int rc;
   const long tiles128 = 4L * cdiv(a.M, 128) * (a.CoutPad / 128);
-  if (a.CoutPad % 128 == 0 && tiles128 >= 192) rc = launch_phase<2, 2, 2, 2, 2>(a, s);
+  if (patch_phase_ok(a)) rc = launch_patch_phase<4>(a, s);
+  else if (a.CoutPad % 128 == 0 && tiles128 >= 192) rc = launch_phase<2, 2, 2, 2, 2>(a, s);
   else if (a.CoutPad % 64 == 0) rc = launch_phase<2, 2, 1, 1, 4>(a, s);
   else rc = launch_phase<4, 1, 2, 1, 2>(a, s);
   gank_prof_end(0, s);
@@ -1149,7 +1189,8 @@ extern "C" int gank_convpool3x3_dgrad(const void* dy, const void* wphd, const vo
   gank_prof_begin(0, 2.0 * a.M * 4.0 * (double)Cin * 4 * Cout, s, 2.0 * ((double)a.M * Cout + 16.0 * Cin * Cout + 4.0 * a.M * Cin));
   int rc;
   const long tiles128 = 4L * cdiv(a.M, 128) * (a.CoutPad / 128);
-  if (a.CoutPad % 128 == 0 && tiles128 >= 192) rc = launch_phase<2, 2, 2, 2, 2>(a, s);
+  if (patch_phase_ok(a)) rc = launch_patch_phase<4>(a, s);
+  else if (a.CoutPad % 128 == 0 && tiles128 >= 192) rc = launch_phase<2, 2, 2, 2, 2>(a, s);
   else if (a.CoutPad % 64 == 0) rc = launch_phase<2, 2, 1, 1, 4>(a, s);
   else rc = launch_phase<4, 1, 2, 1, 2>(a, s);
   gank_prof_end(0, s);
