@@ -80,6 +80,7 @@ def Generator(n_samples_, labels, noise=None, reuse=False, groups=1, rng_state=N
         return output.reshape(-1, OUTPUT_DIM)
 
 
+BATCH_SMALL_WGRADS = True    # same-shape small filter gradients of an update are issued in one launch
 SIDE_STREAM_WGRAD = False    # filter gradients on a second HIP stream: measured 6 % SLOWER per iteration (the branches contend for L2 and CUs), kept for experiments
 
 
@@ -314,10 +315,12 @@ class SNGANTrainer:
     def _backward(self, loss):
         """loss.backward() with the filter gradients on the side stream, joined before anything reads them."""
         Fn.set_wgrad_stream(self._side if self.side_stream else None)
+        Fn.BATCH_SMALL_WGRADS = BATCH_SMALL_WGRADS
         try:
             loss.backward()
             Fn.join_wgrad()
         finally:
+            Fn.BATCH_SMALL_WGRADS = False
             Fn.set_wgrad_stream(None)
 
     def _allreduce(self, flat):

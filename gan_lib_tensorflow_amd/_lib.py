@@ -20,6 +20,11 @@ class SnDesc(C.Structure):
                [("K", I), ("C", I), ("row_offset", I), ("chunk_offset", I)]
 
 
+class WgradItem(C.Structure):
+    """gank_wgrad_item"""
+    _fields_ = [("x", P), ("dy", P), ("dw", P), ("dbias", P)]
+
+
 class PrepDesc(C.Structure):
     """gank_prep_desc"""
     _fields_ = [("w", P), ("wf", P), ("wd", P), ("ksize", I), ("Cin", I), ("Cout", I), ("kind", I)]
@@ -33,6 +38,7 @@ PROTOTYPES = {
     "gank_conv2d_prep_weights_batched": [C.POINTER(PrepDesc), I, P],
     "gank_conv2d_fprop": [P, P, P, P, P, P, I, I, I, I, I, I, I, F, P],
     "gank_conv2d_dgrad": [P, P, P, P, P, I, I, I, I, I, I, I, F, P],
+    "gank_conv2d_wgrad_batched": [C.POINTER(WgradItem), I, I, I, I, I, I, I, I, F, P],
     "gank_conv2d_wgrad_ws_elems": [I, I, I, I, I, I, I],
     "gank_conv2d_wgrad": [P, P, P, P, P, L, I, I, I, I, I, I, I, F, P],
     "gank_upconv3x3_prep_weights": [P, P, P, I, I, P],

@@ -34,6 +34,12 @@ struct WgradArgs {
   float scale;
   int tiles_ci, tiles_co, splits, steps_per_split;
   int shw, sw;
+  // batched launch of up to 4 same-shape layers (gank_conv2d_wgrad_batched): blockIdx.y picks the operand set
+  int nbatch;
+  const bf16* xs[4];
+  const bf16* dys[4];
+  float* dws[4];
+  float* dbs[4];
 };
 
 __device__ __forceinline__ s16x4 lds_tr_read(const bf16* p) {
@@ -304,6 +310,20 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_lean_kernel(WgradArgs 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_a = wave % WA, wave_b = wave / WA;
+  // operand set of this block: the single layer, or layer blockIdx.y of a same-shape batch.  Static indices only: a
+  // dynamically indexed (or modified) by-value argument struct is spilled to scratch and every field read pays for it
+  // (measured: every instantiation of this kernel ran 2x slower).
+  const bf16* X = a.x;
+  const bf16* DY = a.dy;
+  float* DW = a.dw;
+  float* DB = a.dbias;
+  if (a.nbatch > 0) {
+    const int bi = blockIdx.y;
+    X = bi == 0 ? a.xs[0] : (bi == 1 ? a.xs[1] : (bi == 2 ? a.xs[2] : a.xs[3]));
+    DY = bi == 0 ? a.dys[0] : (bi == 1 ? a.dys[1] : (bi == 2 ? a.dys[2] : a.dys[3]));
+    DW = bi == 0 ? a.dws[0] : (bi == 1 ? a.dws[1] : (bi == 2 ? a.dws[2] : a.dws[3]));
+    DB = bi == 0 ? a.dbs[0] : (bi == 1 ? a.dbs[1] : (bi == 2 ? a.dbs[2] : a.dbs[3]));
+  }
 
   int bid = blockIdx.x;
   const int split = bid % a.splits; bid /= a.splits;
@@ -312,7 +332,7 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_lean_kernel(WgradArgs 
   const int tap = bid;
   const int dh = tap / a.ks - a.pad, dw = tap % a.ks - a.pad;
   const int ci0 = tci * CiT, co0 = tco * CoT;
-  const bool do_bias = a.dbias != nullptr && tap == 0 && tci == 0;
+  const bool do_bias = DB != nullptr && tap == 0 && tci == 0;
 
   const int step0 = split * a.steps_per_split;
   int nsteps = (a.M >> 6) - step0;
@@ -321,9 +341,9 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_lean_kernel(WgradArgs 
 
   constexpr int OOB = 0x7FFFFFF0;
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16*>(a.x), 0, a.N * a.Hx * a.Wx * a.Cin * 2, 0x00020000);
+      const_cast<bf16*>(X), 0, a.N * a.Hx * a.Wx * a.Cin * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16*>(a.dy), 0, a.N * a.Hdy * a.Wdy * a.Cout * 2, 0x00020000);
+      const_cast<bf16*>(DY), 0, a.N * a.Hdy * a.Wdy * a.Cout * 2, 0x00020000);
   const int Wm = a.W - 1, Hm = a.H - 1, sw = a.sw, shw = a.shw;
 
   // per-thread chunk constants: pixel-in-step p, channel byte offset (or OOB when the chunk is past C)
@@ -480,7 +500,7 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_lean_kernel(WgradArgs 
 #pragma unroll
       for (int e = 0; e < 16; e++) {
         const int ci = ci0 + (wave_a * TA + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (ci < a.Cin) atomicAdd(a.dw + ((long)tap * a.Cin + ci) * a.Cout + co, acc[i][j][e] * a.scale);
+        if (ci < a.Cin) atomicAdd(DW + ((long)tap * a.Cin + ci) * a.Cout + co, acc[i][j][e] * a.scale);
       }
     }
   }
@@ -500,7 +520,7 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_lean_kernel(WgradArgs 
         const int q = p * (CoT / 8) + cc;
         t += red[((q % NT) * CPB + q / NT) * 8 + e];
       }
-      atomicAdd(a.dbias + co0 + c, t * a.scale);
+      atomicAdd(DB + co0 + c, t * a.scale);
     }
   }
 }
@@ -535,7 +555,7 @@ static int launch_wgrad_lean_mode(WgradArgs a, hipStream_t s) {
   static char tag[96];
   if (!tag[0]) snprintf(tag, sizeof(tag), "conv_wgrad_lean_kernel<%d, %d, %d, %d, %d, %d>", WA, WB, TA, TB, PF, MODE);
   gank_prof_tag(1, tag);
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WA * WB * 64), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid, a.nbatch > 0 ? a.nbatch : 1), dim3(WA * WB * 64), lds, s, a);
   GANK_LAUNCH_OK("conv_wgrad_lean");
   return 0;
 }
@@ -1149,6 +1169,43 @@ extern "C" int gank_convpool3x3_wgrad(const void* x, const void* dy, float* dw, 
   const long plane4 = (long)Cin * Cout / 4;
   hipLaunchKernelGGL(wgrad_fold4x4_kernel, dim3((unsigned)cdiv(plane4, 256)), dim3(256), 0, s, ws16, dw, plane4);
   GANK_LAUNCH_OK("convpool3x3_wgrad");
+  return 0;
+}
+
+// Same-shape layers in one launch.  The critic's 8x8x128 residual blocks (D.Block.3/4, four 3x3 128->128 convs) have
+// filter gradients of 2.4 GFLOP each that fill 144 workgroups for a few microseconds; issued together (grid.y = layer)
+// they overlap each other's latency instead of queueing behind one another.
+extern "C" int gank_conv2d_wgrad_batched(const gank_wgrad_item* items, int count, int N, int H, int W, int Cin, int Cout,
+                                         int ksize, int flags, float scale, void* stream) {
+  GANK_REQUIRE(items && count > 0, "conv2d_wgrad_batched: empty list");
+  GANK_REQUIRE(ksize % 2 == 1, "conv2d_wgrad_batched: even filter sizes are not on this path (ksize=%d)", ksize);
+  hipStream_t s = (hipStream_t)stream;
+  WgradArgs a{};
+  a.N = N; a.H = H; a.W = W; a.Hx = H; a.Wx = W; a.Hdy = H; a.Wdy = W;
+  a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.pad = (ksize - 1) / 2; a.taps = ksize * ksize;
+  a.flags = flags & GANK_IN_RELU;
+  a.scale = scale;
+  a.M = N * H * W; a.sw = log2_or_neg(W); a.shw = log2_or_neg(H * W);
+  const bool batchable = (flags & ~GANK_IN_RELU) == 0 && Cin % 8 == 0 && Cout % 8 == 0 && Cin >= 128 && Cout >= 128 && a.sw >= 0 &&
+                         a.shw >= 0 && a.M % 64 == 0 && !wgrad_taps_ok(a) && (long)a.M * (Cin > Cout ? Cin : Cout) < (1L << 30);
+  int i = 0;
+  while (batchable && count - i >= 2) {
+    const int nb = count - i < 4 ? count - i : 4;
+    for (int j = 0; j < nb; j++) {
+      GANK_REQUIRE(items[i + j].x && items[i + j].dy && items[i + j].dw, "conv2d_wgrad_batched: null pointer in item %d", i + j);
+      a.xs[j] = (const bf16*)items[i + j].x; a.dys[j] = (const bf16*)items[i + j].dy;
+      a.dws[j] = items[i + j].dw; a.dbs[j] = items[i + j].dbias;
+    }
+    a.nbatch = nb;
+    a.x = a.xs[0]; a.dy = a.dys[0]; a.dw = a.dws[0]; a.dbias = a.dbs[0];
+    gank_prof_begin(1, 2.0 * nb * a.M * (double)Cout * a.taps * Cin, s, nb * (2.0 * a.M * ((double)Cin + Cout) + 4.0 * a.taps * Cin * Cout));
+    const int rc = launch_wgrad_lean<2, 2, 2, 2, 2>(a, s);
+    gank_prof_end(1, s);
+    if (rc) return rc > 0 ? rc : gank_set_error("conv2d_wgrad_batched: mode not instantiated");
+    i += nb;
+  }
+  for (; i < count; i++)
+    if (gank_conv2d_wgrad(items[i].x, items[i].dy, items[i].dw, items[i].dbias, nullptr, 0, N, H, W, Cin, Cout, ksize, flags, scale, stream)) return 1;
   return 0;
 }
 

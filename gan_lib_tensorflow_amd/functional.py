@@ -47,8 +47,28 @@ def _on_side(fn, *operands):
     _Side.keep.append(operands)
 
 
+# Small same-shape filter gradients are not launched where autograd reaches them but collected and issued together
+# (gank_conv2d_wgrad_batched): the critic's four 8x8x128 convs fill 144 workgroups each for a few microseconds; one
+# launch of all four overlaps their latencies.  Flushed before anything reads the gradients (join_wgrad).
+BATCH_SMALL_WGRADS = False     # switched on by a caller that guarantees a join_wgrad() after backward (SNGANTrainer._backward)
+_deferred = {}
+
+
+def _defer_wgrad(x, g, tgt, btgt, hw, k, flags):
+    _deferred.setdefault((tuple(x.shape), tuple(g.shape), hw, k, flags), []).append((x, g, tgt, btgt))
+
+
+def flush_wgrads():
+    for (_, _, hw, k, flags), items in _deferred.items():
+        K.conv2d_wgrad_batched(items, hw, k, flags, 1.0)
+    _deferred.clear()
+
+
 def join_wgrad():
-    """Main stream waits for every filter gradient issued so far (before the optimiser / the SN backward)."""
+    """Every filter gradient issued or deferred so far is complete / in stream order (before the optimiser and the
+    SN backward)."""
+    if _deferred:
+        flush_wgrads()
     if _Side.stream is not None and _Side.keep:
         torch.cuda.current_stream().wait_stream(_Side.stream)
         _Side.keep.clear()
@@ -144,8 +164,13 @@ class _Conv2d(Function):
         elif ctx.needs_input_grad[1]:
             tgt, acc = _target(W)
             wflags = (K.IN_UPSAMPLE2X if upsample else 0) | (K.IN_RELU if in_relu else 0) | (K.DY_UPSAMPLE2X if pool_out else 0)
-            # bias gradient rides on the dy stream
-            _on_side(lambda: K.conv2d_wgrad(x, g, tgt, (H, Wd), k, wflags, scale, dbias=btgt), x, g)
+            small = (BATCH_SMALL_WGRADS and not upsample and not pool_out and k == 3 and cin % 128 == 0 and cout % 128 == 0
+                     and x.shape[0] * H * Wd <= 8192 and _Side.stream is None)
+            if small:
+                _defer_wgrad(x, g, tgt, btgt, (H, Wd), k, wflags)
+            else:
+                # bias gradient rides on the dy stream
+                _on_side(lambda: K.conv2d_wgrad(x, g, tgt, (H, Wd), k, wflags, scale, dbias=btgt), x, g)
             dW = None if acc else tgt
         elif btgt is not None:
             K.colsum(g, btgt, 1.0)

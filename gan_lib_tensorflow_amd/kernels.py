@@ -6,7 +6,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, W_FRAG, RES_UPSAMPLE2X, SnDesc, PrepDesc  # noqa: F401
+from ._lib import IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, W_FRAG, RES_UPSAMPLE2X, SnDesc, PrepDesc, WgradItem  # noqa: F401
 
 BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
 
@@ -132,6 +132,20 @@ def conv2d_wgrad(x, dy, dw, hw, ksize, flags=0, scale=1.0, dbias=None):
                                        _p(ws), ws_elems, n, hw[0], hw[1], cin, cout, ksize, flags, scale, _stream()),
                "conv2d_wgrad")
     return dw
+
+
+def conv2d_wgrad_batched(items, hw, ksize, flags=0, scale=1.0):
+    """items: [(x, dy, dw, dbias | None)] of identical geometry; ACCUMULATES every dw (and dbias) in as few launches
+    as possible."""
+    x0, dy0 = items[0][0], items[0][1]
+    n, cin, cout = x0.shape[0], x0.shape[3], dy0.shape[3]
+    table = (WgradItem * len(items))()
+    for t, (x, dy, dw, db) in zip(table, items):
+        assert x.shape == x0.shape and dy.shape == dy0.shape and dw.numel() == ksize * ksize * cin * cout
+        t.x, t.dy, t.dw = _p(x, BF16, "x").value, _p(dy, BF16, "dy").value, _p(dw, F32, "dw").value
+        t.dbias = _p(db, F32, "dbias").value if db is not None else None
+    _lib.check(lib().gank_conv2d_wgrad_batched(table, len(items), n, hw[0], hw[1], cin, cout, ksize, flags, scale, _stream()),
+               "conv2d_wgrad_batched")
 
 
 def upconv3x3_prep(w):

@@ -94,6 +94,17 @@ long gank_conv2d_wgrad_ws_elems(int N, int H, int W, int Cin, int Cout, int ksiz
 int gank_conv2d_wgrad(const void* x, const void* dy, float* dw, float* dbias, float* ws, long ws_elems, int N, int H,
                       int W, int Cin, int Cout, int ksize, int flags, float scale, void* stream);
 
+/* `count` filter gradients of identical geometry (N,H,W,Cin,Cout,ksize; flags: GANK_IN_RELU only) in as few launches
+ * as possible (up to 4 layers per launch); same arithmetic as `count` calls of gank_conv2d_wgrad without workspace. */
+typedef struct gank_wgrad_item {
+  const void* x;   /* bf16 [N,H,W,Cin]  */
+  const void* dy;  /* bf16 [N,H,W,Cout] */
+  float* dw;       /* fp32 [k,k,Cin,Cout], accumulated */
+  float* dbias;    /* fp32 [Cout] or NULL, accumulated  */
+} gank_wgrad_item;
+int gank_conv2d_wgrad_batched(const gank_wgrad_item* items, int count, int N, int H, int W, int Cin, int Cout,
+                              int ksize, int flags, float scale, void* stream);
+
 /* ---- UpsampleConv 3x3 (SNGAN/gan_cifar_resnet.py:140-153) as a stride-2 transposed conv -------------
  * nearest-neighbour 2x followed by a 3x3 SAME conv equals a 4x4 stride-2 transposed conv whose taps are sums
  * of the 3x3 taps.  fprop runs its 4 output phases (2x2 taps each over the LOW-RES input): 4 instead of 9

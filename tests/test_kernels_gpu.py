@@ -594,3 +594,24 @@ def test_conv_fprop_upsampled_residual(K, n, h, cin, cout, k):
     ref = R.conv2d_same(x, w, b) + R.upsample_nn2x(res)
     torch.cuda.synchronize()
     assert relerr(y, ref) < BF_TOL
+
+
+def test_conv_wgrad_batched_equals_separate(K):
+    """Four same-shape 3x3 filter gradients (the critic's 8x8x128 blocks) in one launch == four separate launches."""
+    rng = np.random.default_rng(8)
+    n, h, c = 16, 8, 128
+    items, refs = [], []
+    for i in range(5):                      # 4 in one launch + 1 through the single-layer path
+        x, xt = bf(rng.normal(size=(n, h, h, c)))
+        dy, dyt = bf(rng.normal(size=(n, h, h, c)))
+        dw = torch.full((3, 3, c, c), float(i), dtype=torch.float32, device="cuda")
+        db = torch.zeros(c, dtype=torch.float32, device="cuda") if i % 2 == 0 else None
+        items.append((xt, dyt, dw, db))
+        _, dw_ref, db_ref = R.conv2d_same_grads(R.relu(x), np.zeros((3, 3, c, c)), dy)
+        refs.append((dw_ref, db_ref))
+    K.conv2d_wgrad_batched(items, (h, h), 3, K.IN_RELU, 1.0)
+    torch.cuda.synchronize()
+    for i, ((_, _, dw, db), (dw_ref, db_ref)) in enumerate(zip(items, refs)):
+        assert relerr(dw - float(i), dw_ref) < F32_FROM_BF_TOL
+        if db is not None:
+            assert relerr(db, db_ref) < F32_FROM_BF_TOL
