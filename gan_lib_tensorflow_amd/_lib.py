@@ -56,6 +56,11 @@ PROTOTYPES = {
     "gank_sn_power_iter_bwd": [C.POINTER(SnDesc), I, P],
     "gank_cbn_parts": [L],
     "gank_cbn_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "gank_cbn_fwd_eps": [P, P, P, P, P, P, P, I, I, I, I, I, I, F, P],
+    "gank_layer_norm_fwd": [P, P, P, P, P, I, I, I, F, P],
+    "gank_layer_norm_bwd": [P, P, P, P, P, P, P, I, I, I, P],
+    "gank_pixel_norm_fwd": [P, P, L, I, F, P],
+    "gank_pixel_norm_bwd": [P, P, P, L, I, F, P],
     "gank_cbn_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     "gank_pool2x2": [P, P, P, I, I, I, I, F, P],
     "gank_unpool2x2_add": [P, P, P, I, I, I, I, F, P],

@@ -65,12 +65,33 @@ def batch_norm(inputs, decay=0.9, epsilon=1e-5, is_training=True, fused=True, gr
 
 
 def layer_norm(name, norm_axes, inputs):
-    raise NotImplementedError('layer_norm (normalization.py:62-102) is only reached with NORMALIZATION_D=True')
+    """tf.contrib.layers.layer_norm(center, scale, begin_norm_axis=1, begin_params_axis=-1, scope=name)
+    (normalization.py:62-102): moments over every non-batch axis per sample (variance epsilon 1e-12, TF's constant),
+    `gamma` / `beta` over the last axis, created under scope `name`."""
+    store = get_default_store()
+    c = inputs.shape[-1]
+    with store.variable_scope(name):
+        beta = store.get_variable('beta', [c], np.zeros(c, 'float32'))
+        gamma = store.get_variable('gamma', [c], np.ones(c, 'float32'))
+    return Fn.layer_norm(inputs, gamma, beta, 1e-12)
 
 
 def instance_norm(inputs, epsilon=1e-06):
-    raise NotImplementedError('instance_norm (normalization.py:105-122) belongs to Pix2Pix (config 5)')
+    """tf.contrib.layers.instance_norm(center, scale, data_format='NHWC')  (normalization.py:105-122): moments over
+    (H,W) per sample and channel -- the conditional-batch-norm kernels with one tower per sample and a one-row table."""
+    import torch
+    store = get_default_store()
+    n, c = inputs.shape[0], inputs.shape[-1]
+    with store.variable_scope('InstanceNorm'):
+        beta = store.get_variable('beta', [1, c], np.zeros((1, c), 'float32'))
+        gamma = store.get_variable('gamma', [1, c], np.ones((1, c), 'float32'))
+    key = (n, str(inputs.device))
+    if key not in _zero_labels:
+        _zero_labels[key] = torch.zeros(n, dtype=torch.int32, device=inputs.device)
+    y, _ = Fn.batchnorm_with_stats(inputs, _zero_labels[key], gamma, beta, groups=n, relu=False, eps=epsilon)
+    return y
 
 
 def pixel_norm(inputs, eps=1e-8):
-    raise NotImplementedError('pixel_norm (normalization.py:125-140) belongs to PGGAN (config 4)')
+    """From PGGAN (normalization.py:125-140): inputs * rsqrt(mean(inputs**2, axis=3) + eps)."""
+    return Fn.pixel_norm(inputs, eps)

@@ -16,6 +16,7 @@ extern "C" int gank_cbn_parts(long rows_per_group) {
 struct CbnGeom {
   int N, HW, C, groups, parts, n_labels, relu;
   long rows_per_group, rows_per_part;
+  float eps;
 };
 
 constexpr int CBN_NT = 1024;   // 16 waves per block: these kernels are latency-bound streams otherwise
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void cbn_finalize_kernel(const float* __restri
   if (ps == 0 && c < q.C) {
     for (int j = 1; j < 16; j++) chan_merge(na, mean, m2, sh[0][j][cl], sh[1][j][cl], sh[2][j][cl]);
     stats[((long)grp * 2 + 0) * q.C + c] = mean;
-    stats[((long)grp * 2 + 1) * q.C + c] = 1.f / sqrtf(m2 / na + BN_EPS);   // biased variance (tf.nn.moments)
+    stats[((long)grp * 2 + 1) * q.C + c] = 1.f / sqrtf(m2 / na + q.eps);   // biased variance (tf.nn.moments)
   }
 }
 
@@ -145,11 +146,13 @@ static int cbn_geom(CbnGeom& q, int N, int HW, int C, int groups, int n_labels, 
   return 0;
 }
 
-extern "C" int gank_cbn_fwd(const void* x, const int32_t* labels, const float* gamma, const float* beta, void* y,
-                            float* stats, float* ws, int N, int HW, int C, int groups, int n_labels, int relu, void* stream) {
+extern "C" int gank_cbn_fwd_eps(const void* x, const int32_t* labels, const float* gamma, const float* beta, void* y,
+                            float* stats, float* ws, int N, int HW, int C, int groups, int n_labels, int relu, float eps, void* stream) {
   GANK_REQUIRE(x && labels && gamma && beta && y && stats && ws, "cbn_fwd: null pointer");
   CbnGeom q;
   if (cbn_geom(q, N, HW, C, groups, n_labels, relu)) return 1;
+  GANK_REQUIRE(eps > 0.f, "cbn_fwd: eps must be positive");
+  q.eps = eps;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(groups * q.parts);
   hipLaunchKernelGGL(cbn_stats_kernel, grid, dim3(CBN_NT), 0, s, (const bf16*)x, ws, q);
@@ -157,6 +160,11 @@ extern "C" int gank_cbn_fwd(const void* x, const int32_t* labels, const float* g
   hipLaunchKernelGGL(cbn_apply_kernel, grid, dim3(CBN_NT), 0, s, (const bf16*)x, labels, gamma, beta, (bf16*)y, stats, q);
   GANK_LAUNCH_OK("cbn_fwd");
   return 0;
+}
+
+extern "C" int gank_cbn_fwd(const void* x, const int32_t* labels, const float* gamma, const float* beta, void* y,
+                            float* stats, float* ws, int N, int HW, int C, int groups, int n_labels, int relu, void* stream) {
+  return gank_cbn_fwd_eps(x, labels, gamma, beta, y, stats, ws, N, HW, C, groups, n_labels, relu, BN_EPS, stream);
 }
 
 // ---- backward -------------------------------------------------------------------------------------

@@ -297,8 +297,8 @@ class _BatchNormStats(Function):
     """cond_batchnorm with the batch statistics as a second, non-differentiable output ([groups, 2, C]: mean, invstd)."""
 
     @staticmethod
-    def forward(ctx, x, labels, gamma, beta, groups, relu):
-        y, stats = K.cbn_fwd(x, labels, gamma.detach(), beta.detach(), groups, relu)
+    def forward(ctx, x, labels, gamma, beta, groups, relu, eps=1e-5):
+        y, stats = K.cbn_fwd(x, labels, gamma.detach(), beta.detach(), groups, relu, eps)
         ctx.save_for_backward(x, y, labels, gamma, beta, stats)
         ctx.cfg = (groups, relu)
         ctx.mark_non_differentiable(stats)
@@ -311,11 +311,48 @@ class _BatchNormStats(Function):
         tg, accg = _target(gamma)
         tb, accb = _target(beta)
         dx = K.cbn_bwd(_c(dy), x, y, labels, gamma.detach(), stats, tg, tb, groups, relu)
-        return dx, None, (None if accg else tg), (None if accb else tb), None, None
+        return dx, None, (None if accg else tg), (None if accb else tb), None, None, None
 
 
-def batchnorm_with_stats(x, labels, gamma, beta, groups=1, relu=False):
-    return _BatchNormStats.apply(x, labels, gamma, beta, groups, relu)
+def batchnorm_with_stats(x, labels, gamma, beta, groups=1, relu=False, eps=1e-5):
+    return _BatchNormStats.apply(x, labels, gamma, beta, groups, relu, eps)
+
+
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        y, stats = K.layer_norm_fwd(x, gamma.detach(), beta.detach(), eps)
+        ctx.save_for_backward(x, gamma, beta, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stats = ctx.saved_tensors
+        tg, accg = _target(gamma)
+        tb, accb = _target(beta)
+        dx = K.layer_norm_bwd(_c(dy), x, gamma.detach(), stats, tg, tb)
+        return dx, (None if accg else tg), (None if accb else tb), None
+
+
+def layer_norm(x, gamma, beta, eps=1e-12):
+    return _LayerNorm.apply(x, gamma, beta, eps)
+
+
+class _PixelNorm(Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        ctx.save_for_backward(x)
+        ctx.eps = eps
+        return K.pixel_norm_fwd(x, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return K.pixel_norm_bwd(_c(dy), x, ctx.eps), None
+
+
+def pixel_norm(x, eps=1e-8):
+    return _PixelNorm.apply(x, eps)
 
 
 class _Fork(Function):

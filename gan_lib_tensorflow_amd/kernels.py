@@ -339,16 +339,51 @@ class SnBatch:
 
 
 # ------------------------------------------------------------------ conditional batch norm
-def cbn_fwd(x, labels, gamma, beta, groups=1, relu=False):
+def cbn_fwd(x, labels, gamma, beta, groups=1, relu=False, eps=1e-5):
     n, c = x.shape[0], x.shape[-1]
     hw = x.numel() // (n * c)
     parts = lib().gank_cbn_parts((n // groups) * hw)
     y = torch.empty_like(x)
     stats = torch.empty((groups, 2, c), dtype=F32, device=x.device)
     ws = torch.empty(groups * parts * 3 * c, dtype=F32, device=x.device)
-    _lib.check(lib().gank_cbn_fwd(_p(x, BF16, "x"), _p(labels, I32, "labels"), _p(gamma, F32, "gamma"), _p(beta, F32, "beta"),
-                                  _p(y), _p(stats), _p(ws), n, hw, c, groups, gamma.shape[0], int(relu), _stream()), "cbn_fwd")
+    _lib.check(lib().gank_cbn_fwd_eps(_p(x, BF16, "x"), _p(labels, I32, "labels"), _p(gamma, F32, "gamma"), _p(beta, F32, "beta"),
+                                      _p(y), _p(stats), _p(ws), n, hw, c, groups, gamma.shape[0], int(relu), float(eps), _stream()),
+               "cbn_fwd")
     return y, stats
+
+
+def layer_norm_fwd(x, gamma, beta, eps=1e-12):
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    y = torch.empty_like(x)
+    stats = torch.empty((n, 2), dtype=F32, device=x.device)
+    _lib.check(lib().gank_layer_norm_fwd(_p(x, BF16, "x"), _p(gamma, F32, "gamma"), _p(beta, F32, "beta"), _p(y), _p(stats),
+                                         n, hw, c, float(eps), _stream()), "layer_norm_fwd")
+    return y, stats
+
+
+def layer_norm_bwd(dy, x, gamma, stats, dgamma, dbeta):
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    dx = torch.empty_like(x)
+    _lib.check(lib().gank_layer_norm_bwd(_p(dy, BF16, "dy"), _p(x, BF16, "x"), _p(gamma, F32, "gamma"), _p(stats, F32, "stats"), _p(dx),
+                                         _p(dgamma, F32, "dgamma"), _p(dbeta, F32, "dbeta"), n, hw, c, _stream()), "layer_norm_bwd")
+    return dx
+
+
+def pixel_norm_fwd(x, eps=1e-8):
+    c = x.shape[-1]
+    y = torch.empty_like(x)
+    _lib.check(lib().gank_pixel_norm_fwd(_p(x, BF16, "x"), _p(y), x.numel() // c, c, float(eps), _stream()), "pixel_norm_fwd")
+    return y
+
+
+def pixel_norm_bwd(dy, x, eps=1e-8):
+    c = x.shape[-1]
+    dx = torch.empty_like(x)
+    _lib.check(lib().gank_pixel_norm_bwd(_p(dy, BF16, "dy"), _p(x, BF16, "x"), _p(dx), x.numel() // c, c, float(eps), _stream()),
+               "pixel_norm_bwd")
+    return dx
 
 
 def cbn_bwd(dy, x, y, labels, gamma, stats, dgamma, dbeta, groups=1, relu=False):

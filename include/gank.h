@@ -197,6 +197,10 @@ int gank_sn_power_iter_bwd(const gank_sn_desc* table, int count, void* stream);
 int gank_cbn_parts(long rows_per_group);
 int gank_cbn_fwd(const void* x, const int32_t* labels, const float* gamma, const float* beta, void* y,
                  float* stats, float* ws, int N, int HW, int C, int groups, int n_labels, int relu, void* stream);
+/* the same with the variance epsilon as an argument: instance_norm (normalization.py:105-122, epsilon 1e-6) is this
+ * kernel set with groups = N (one tower per sample) and a one-row gamma/beta table */
+int gank_cbn_fwd_eps(const void* x, const int32_t* labels, const float* gamma, const float* beta, void* y,
+                     float* stats, float* ws, int N, int HW, int C, int groups, int n_labels, int relu, float eps, void* stream);
 int gank_cbn_bwd(const void* dy, const void* x, const void* y, const int32_t* labels, const float* gamma,
                  const float* stats, void* dx, float* dgamma, float* dbeta, float* ws, int N, int HW, int C,
                  int groups, int n_labels, int relu, void* stream);
@@ -205,6 +209,17 @@ int gank_cbn_bwd(const void* dy, const void* x, const void* y, const int32_t* la
  * pool2x2: y = scale * (sum of the 2x2 window) (+ residual)   -- tf.add_n(...)/4. at
  *          gan_cifar_resnet.py:120-121,129-130 with scale=.25; scale=1 is the NN-upsample gradient.
  * unpool2x2_add: y = base + scale * nn_upsample2x(g)            -- gradient of the mean pool. */
+/* ---- layer_norm (normalization.py:62-102; tf.contrib.layers.layer_norm, begin_norm_axis=1, begin_params_axis=-1):
+ * moments over (H,W,C) per sample (biased variance, eps as given: TF uses 1e-12), gamma/beta fp32 [C].
+ * x,y,dy,dx bf16 [N,HW,C]; stats fp32 [N][2] (mean, invstd) from fwd; bwd ACCUMULATES dgamma/dbeta. C % 8 == 0. */
+int gank_layer_norm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int N, int HW, int C,
+                        float eps, void* stream);
+int gank_layer_norm_bwd(const void* dy, const void* x, const float* gamma, const float* stats, void* dx, float* dgamma,
+                        float* dbeta, int N, int HW, int C, void* stream);
+/* ---- pixel_norm (normalization.py:125-140): y = x * rsqrt(mean_c(x^2) + eps) per pixel; bwd recomputes the scale */
+int gank_pixel_norm_fwd(const void* x, void* y, long pixels, int C, float eps, void* stream);
+int gank_pixel_norm_bwd(const void* dy, const void* x, void* dx, long pixels, int C, float eps, void* stream);
+
 int gank_pool2x2(const void* x, const void* residual, void* y, int N, int Hout, int Wout, int C, float scale, void* stream);
 int gank_unpool2x2_add(const void* g, const void* base, void* y, int N, int Hin, int Win, int C, float scale, void* stream);
 int gank_add_bf16(const void* a, const void* b, void* y, long n, void* stream);

@@ -283,6 +283,49 @@ def batch_norm_train(x, gamma, beta, moving, decay=0.9, eps=BN_EPS):
     return y, cache, new
 
 
+def layer_norm_forward(x, gamma, beta, eps=1e-12):
+    """tf.contrib.layers.layer_norm, begin_norm_axis=1, begin_params_axis=-1 (common/ops/normalization.py:62-102):
+    moments over all non-batch axes per sample (biased variance, variance_epsilon 1e-12), gamma/beta over the last axis."""
+    x = np.asarray(x, F64)
+    ax = tuple(range(1, x.ndim))
+    mean = x.mean(axis=ax, keepdims=True)
+    var = ((x - mean) ** 2).mean(axis=ax, keepdims=True)
+    invstd = 1. / np.sqrt(var + eps)
+    xhat = (x - mean) * invstd
+    return xhat * np.asarray(gamma, F64) + np.asarray(beta, F64), (xhat, invstd)
+
+
+def layer_norm_backward(dy, gamma, cache):
+    xhat, invstd = cache
+    dy = np.asarray(dy, F64)
+    ax = tuple(range(1, dy.ndim))
+    red = tuple(range(dy.ndim - 1))
+    g = dy * np.asarray(gamma, F64)
+    dx = invstd * (g - g.mean(axis=ax, keepdims=True) - xhat * (g * xhat).mean(axis=ax, keepdims=True))
+    return dx, (dy * xhat).sum(axis=red), dy.sum(axis=red)
+
+
+def instance_norm_forward(x, gamma, beta, eps=1e-6):
+    """tf.contrib.layers.instance_norm, NHWC (normalization.py:105-122): moments over (H,W) per sample and channel =
+    conditional batch norm with one tower per sample and a one-row table."""
+    x = np.asarray(x, F64)
+    c = x.shape[-1]
+    return cond_batchnorm_forward(x, np.zeros(x.shape[0], np.int64), np.asarray(gamma, F64).reshape(1, c),
+                                  np.asarray(beta, F64).reshape(1, c), groups=x.shape[0], eps=eps)
+
+
+def pixel_norm_forward(x, eps=1e-8):
+    """normalization.py:125-140: x * rsqrt(mean(x*x, axis=3) + eps)"""
+    x = np.asarray(x, F64)
+    return x / np.sqrt((x * x).mean(axis=-1, keepdims=True) + eps)
+
+
+def pixel_norm_backward(dy, x, eps=1e-8):
+    x, dy = np.asarray(x, F64), np.asarray(dy, F64)
+    a = 1. / np.sqrt((x * x).mean(axis=-1, keepdims=True) + eps)
+    return a * dy - x * a ** 3 * (dy * x).mean(axis=-1, keepdims=True)
+
+
 def linear(x, W, b=None):
     """tf.matmul + bias_add   (common/ops/linear.py:161-180)"""
     y = np.asarray(x, F64) @ np.asarray(W, F64)

@@ -615,3 +615,50 @@ def test_conv_wgrad_batched_equals_separate(K):
         assert relerr(dw - float(i), dw_ref) < F32_FROM_BF_TOL
         if db is not None:
             assert relerr(db, db_ref) < F32_FROM_BF_TOL
+
+
+@pytest.mark.parametrize("n,hw,c", [(3, 4, 64), (5, 16, 128), (2, 32, 256)])
+def test_layer_instance_pixel_norm_ops(K, n, hw, c):
+    """layer_norm / instance_norm / pixel_norm of common/ops/normalization.py:62-140 through the reference-shaped ops."""
+    from gan_lib_tensorflow_amd.store import ParamStore, set_default_store
+    from gan_lib_tensorflow_amd.common.ops import normalization as Nm
+    rng = np.random.default_rng(n + hw + c)
+    store = set_default_store(ParamStore("cuda", seed=0))
+    x, xt0 = bf(rng.normal(size=(n, hw, hw, c)) * 1.5 + 0.4)
+    dy, dyt = bf(rng.normal(size=x.shape))
+    gamma = (rng.normal(size=c) + 1.0).astype(np.float32)
+    beta = rng.normal(size=c).astype(np.float32)
+
+    def run(op, scope, gname, bname, shape):
+        xt = xt0.clone().requires_grad_(True)
+        with store.variable_scope(scope):
+            op(xt)                                            # creates gamma / beta
+        with torch.no_grad():
+            store.vars[gname].copy_(torch.tensor(gamma).view(shape))
+            store.vars[bname].copy_(torch.tensor(beta).view(shape))
+        store.vars[gname].grad = store.vars[bname].grad = None
+        with store.variable_scope(scope):
+            y = op(xt)
+        y.backward(dyt)
+        torch.cuda.synchronize()
+        return y, xt.grad, store.vars[gname].grad, store.vars[bname].grad
+
+    # layer norm
+    y, dx, dg, db = run(lambda t: Nm.layer_norm('D.Block.2.N1', [1, 2, 3], t), 'Discriminator', 'Discriminator/D.Block.2.N1/gamma',
+                        'Discriminator/D.Block.2.N1/beta', (c,))
+    ref, cache = R.layer_norm_forward(x, gamma, beta)
+    dx_ref, dg_ref, db_ref = R.layer_norm_backward(dy, gamma, cache)
+    assert relerr(y, ref) < BF_TOL and relerr(dx, dx_ref) < 2 * BF_TOL
+    assert relerr(dg, dg_ref) < F32_FROM_BF_TOL and relerr(db, db_ref) < F32_FROM_BF_TOL
+    # instance norm
+    y, dx, dg, db = run(lambda t: Nm.instance_norm(t), 'G.IN', 'G.IN/InstanceNorm/gamma', 'G.IN/InstanceNorm/beta', (1, c))
+    ref, cache = R.instance_norm_forward(x, gamma, beta)
+    dx_ref, dg_ref, db_ref = R.cond_batchnorm_backward(dy, np.zeros(n, np.int64), gamma.reshape(1, c).astype(np.float64), cache, n)
+    assert relerr(y, ref) < BF_TOL and relerr(dx, dx_ref) < 2 * BF_TOL
+    assert relerr(dg, dg_ref) < F32_FROM_BF_TOL and relerr(db, db_ref) < F32_FROM_BF_TOL
+    # pixel norm
+    xt = xt0.clone().requires_grad_(True)
+    y = Nm.pixel_norm(xt)
+    y.backward(dyt)
+    torch.cuda.synchronize()
+    assert relerr(y, R.pixel_norm_forward(x)) < BF_TOL and relerr(xt.grad, R.pixel_norm_backward(dy, x)) < BF_TOL

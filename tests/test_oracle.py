@@ -257,3 +257,35 @@ def test_batch_norm_train_known_answers():
         assert np.allclose(moving['moving_mean'], x.reshape(-1, c).mean(0), rtol=1e-12)
         vu = x.reshape(-1, c).var(0) * 96 / 95
         assert np.allclose(moving['moving_variance'], 1 + (1 - 0.9 ** step) * (vu - 1), rtol=1e-12)
+
+
+def test_layer_instance_pixel_norm_gradients_match_autograd():
+    """hand-derived backward passes of the three remaining normalisations (normalization.py:62-140) vs torch autograd"""
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(3, 4, 5, 8)) * 1.7 + 0.3
+    dy = rng.normal(size=x.shape)
+    gamma, beta = rng.normal(size=8) + 1.0, rng.normal(size=8)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    gt = torch.tensor(gamma, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(beta, dtype=torch.float64, requires_grad=True)
+    # layer norm
+    y, cache = R.layer_norm_forward(x, gamma, beta)
+    mu = xt.mean(dim=(1, 2, 3), keepdim=True)
+    var = ((xt - mu) ** 2).mean(dim=(1, 2, 3), keepdim=True)
+    yt = (xt - mu) / torch.sqrt(var + 1e-12) * gt + bt
+    assert np.allclose(y, yt.detach().numpy(), atol=1e-12)
+    gx, gg, gb = torch.autograd.grad(yt, [xt, gt, bt], torch.tensor(dy))
+    dx, dg, db = R.layer_norm_backward(dy, gamma, cache)
+    assert np.allclose(dx, gx.numpy(), atol=1e-10) and np.allclose(dg, gg.numpy(), atol=1e-10) and np.allclose(db, gb.numpy(), atol=1e-10)
+    # instance norm: per (sample, channel) statistics over (H, W)
+    y, _ = R.instance_norm_forward(x, gamma, beta)
+    mu = xt.mean(dim=(1, 2), keepdim=True)
+    var = ((xt - mu) ** 2).mean(dim=(1, 2), keepdim=True)
+    assert np.allclose(y, ((xt - mu) / torch.sqrt(var + 1e-6) * gt + bt).detach().numpy(), atol=1e-12)
+    # pixel norm
+    y = R.pixel_norm_forward(x)
+    yt = xt * torch.rsqrt((xt * xt).mean(dim=3, keepdim=True) + 1e-8)
+    assert np.allclose(y, yt.detach().numpy(), atol=1e-12)
+    (gx,) = torch.autograd.grad(yt, [xt], torch.tensor(dy))
+    assert np.allclose(R.pixel_norm_backward(dy, x), gx.numpy(), atol=1e-10)
+    assert np.allclose((R.pixel_norm_forward(x) ** 2).mean(-1), 1.0, atol=1e-6)      # unit mean square per pixel
