@@ -662,3 +662,44 @@ def test_layer_instance_pixel_norm_ops(K, n, hw, c):
     y.backward(dyt)
     torch.cuda.synchronize()
     assert relerr(y, R.pixel_norm_forward(x)) < BF_TOL and relerr(xt.grad, R.pixel_norm_backward(dy, x)) < BF_TOL
+
+
+def _rand_conv_cases(seed, count):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(count):
+        k = int(rng.choice([1, 3]))
+        cin = int(rng.choice([3, 8, 64, 96, 128, 256]))
+        cout = int(rng.choice([3, 8, 32, 64, 128, 192]))
+        h = int(rng.choice([1, 2, 3, 5, 8, 16]))
+        w = int(rng.choice([1, 2, 4, 6, 8, 16, 32]))
+        n = int(rng.integers(1, 5))
+        cases.append((n, h, w, cin, cout, k, bool(rng.integers(0, 2))))
+    return cases
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,k,relu", _rand_conv_cases(2024, 24) + [(2, 8, 16, 64, 128, 3, True), (1, 16, 32, 128, 128, 3, False),
+                                                                               (3, 8, 32, 64, 3, 3, False), (2, 4, 16, 3, 128, 3, False)])
+def test_conv_random_and_non_square_shapes(K, n, h, w, cin, cout, k, relu):
+    """Seeded random geometry sweep, including non-square images (H != W) that no reference layer uses but the ABI
+    accepts: fprop (+bias), dgrad and wgrad (+bias gradient) of the same layer against the oracle."""
+    rng = np.random.default_rng(n * 131 + h * 17 + w * 5 + cin + cout + k)
+    x, xt = bf(rng.normal(size=(n, h, w, cin)))
+    wgt, _ = bf(rng.normal(size=(k, k, cin, cout)) / np.sqrt(k * k * cin))
+    b, bt = f32(rng.normal(size=cout))
+    dy, dyt = bf(rng.normal(size=(n, h, w, cout)))
+    wt = torch.tensor(wgt, dtype=torch.float32).cuda()
+    wf, wd = K.prep_weights(wt, True, True)
+    flags = K.IN_RELU if relu else 0
+    xin = R.relu(x) if relu else x
+    y = K.conv2d_fprop(xt, wf, bt, (h, w), cout, k, flags)
+    dx = K.conv2d_dgrad(dyt, wd, (h, w), cin, k)
+    dw = torch.zeros((k, k, cin, cout), dtype=torch.float32, device="cuda")
+    db = torch.zeros(cout, dtype=torch.float32, device="cuda")
+    K.conv2d_wgrad(xt, dyt, dw, (h, w), k, flags, 1.0, dbias=db)
+    dx_ref, dw_ref, db_ref = R.conv2d_same_grads(xin, wgt, dy)
+    torch.cuda.synchronize()
+    assert relerr(y, R.conv2d_same(xin, wgt, b)) < BF_TOL
+    assert relerr(dx, dx_ref) < BF_TOL                        # gradient w.r.t. the (relu'd) conv operand
+    assert relerr(dw, dw_ref) < F32_FROM_BF_TOL
+    assert relerr(db, db_ref) < F32_FROM_BF_TOL
