@@ -71,7 +71,16 @@ __global__ void sn_colpart_kernel(SnTable t) {
   __syncthreads();
   for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
     float s = 0.f;
-    for (int k = 0; k < kn; k++) s += d.W[(long)(k0 + k) * d.C + c] * vs[k];
+    // 64 rows in batches of 16 independent loads (rows past kn re-read the last row against vs = 0): a plain loop with
+    // a run-time bound issued one load per L2 round trip
+#pragma unroll
+    for (int kb = 0; kb < 64; kb += 16) {
+      float w[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) w[u] = d.W[(long)(k0 + min(kb + u, kn - 1)) * d.C + c];
+#pragma unroll
+      for (int u = 0; u < 16; u++) s += w[u] * vs[kb + u];
+    }
     d.bpart[(long)ch * d.C + c] = s;
   }
 }
@@ -84,7 +93,13 @@ __global__ void sn_finalize_kernel(SnTable t) {
   float ss = 0.f;
   for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
     float s = 0.f;
-    for (int j = 0; j < nch; j++) s += d.bpart[(long)j * d.C + c];
+    for (int jb = 0; jb < nch; jb += 8) {            // batches of 8 independent loads
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) t[u] = d.bpart[(long)min(jb + u, nch - 1) * d.C + c];
+#pragma unroll
+      for (int u = 0; u < 8; u++) s += (jb + u < nch) ? t[u] : 0.f;
+    }
     d.b[c] = s;
     ss += s * s;
   }
