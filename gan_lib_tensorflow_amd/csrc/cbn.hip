@@ -79,11 +79,24 @@ __global__ __launch_bounds__(256) void cbn_finalize_kernel(const float* __restri
   __shared__ float sh[3][16][17];
   float na = 0.f, mean = 0.f, m2 = 0.f;
   if (c < q.C) {
-    for (int p = ps; p < q.parts; p += 16) {
-      long r0 = (long)p * q.rows_per_part, r1 = r0 + q.rows_per_part;
-      if (r1 > q.rows_per_group) r1 = q.rows_per_group;
-      const float* o = ws + (((long)grp * q.parts + p) * 2) * q.C;
-      chan_merge(na, mean, m2, (float)(r1 - r0), o[c], o[q.C + c]);
+    for (int pb = ps; pb < q.parts; pb += 64) {          // 4 parts per batch: their loads are issued together
+      float pm[4], pv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int p = min(pb + 16 * u, q.parts - 1);
+        const float* o = ws + (((long)grp * q.parts + p) * 2) * q.C;
+        pm[u] = o[c];
+        pv[u] = o[q.C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int p = pb + 16 * u;
+        if (p < q.parts) {
+          long r0 = (long)p * q.rows_per_part, r1 = r0 + q.rows_per_part;
+          if (r1 > q.rows_per_group) r1 = q.rows_per_group;
+          chan_merge(na, mean, m2, (float)(r1 - r0), pm[u], pv[u]);
+        }
+      }
     }
   }
   sh[0][ps][cl] = na; sh[1][ps][cl] = mean; sh[2][ps][cl] = m2;

@@ -948,9 +948,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_taps_kernel(WgradArgs a) {
 __global__ void wgrad_reduce_slabs_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n4, int splits) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     f32x4 t = reinterpret_cast<const f32x4*>(dw)[i];
-    for (int s = 0; s < splits; s++) {
-      const f32x4 v = reinterpret_cast<const f32x4*>(ws)[(long)s * n4 + i];
-      t[0] += v[0]; t[1] += v[1]; t[2] += v[2]; t[3] += v[3];
+    for (int sb = 0; sb < splits; sb += 8) {          // 8 independent slab loads per batch, summed in slab order
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = reinterpret_cast<const f32x4*>(ws)[(long)min(sb + u, splits - 1) * n4 + i];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (sb + u < splits) { t[0] += v[u][0]; t[1] += v[u][1]; t[2] += v[u][2]; t[3] += v[u][3]; }
     }
     reinterpret_cast<f32x4*>(dw)[i] = t;
   }
@@ -973,7 +977,9 @@ static void wgrad_taps_geometry(WgradArgs& a) {
   a.tiles_co = a.Cout / 64;
   const int total_steps = a.M / 64;
   const int tiles = a.tiles_ci * a.tiles_co;
-  int splits = (512 + tiles - 1) / tiles;
+  static int target = -1;   // experiment knob
+  if (target < 0) { const char* e = getenv("GANK_WGRAD_TAPS_TARGET"); target = e ? atoi(e) : 256; }   // one workgroup per CU: 384 leaves a half-empty second round, 512 doubles the slab traffic
+  int splits = (target + tiles - 1) / tiles;
   if (splits > total_steps / 4) splits = total_steps / 4;
   if (splits < 1) splits = 1;
   a.steps_per_split = cdiv(total_steps, splits);
