@@ -128,9 +128,62 @@ __device__ __forceinline__ void prep_up_element(const PrepUpArgs& q, long idx) {
 }
 __host__ __device__ inline long prep_up_total(const PrepUpArgs& q) { return 4L * q.CrPpad * 4 * q.CkP + (long)q.CrDpad * q.Kpad4; }
 
-__global__ void prep_upconv_kernel(PrepUpArgs q) {
-  const long total = prep_up_total(q);
-  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) prep_up_element(q, idx);
+// The operand whose inner index runs along w's SLOW channel axis (sr == 1: the phase matrix of UpsampleConv, the
+// 4x4 matrix of ConvMeanPool) read element-wise is a stride-Cout gather (the 16.8 M-element generator preparation took
+// 91 us).  Here one block turns a 32 x 32 (row, inner) tile of one (phase, tap) / tap slice through LDS: coalesced reads
+// along the rows, coalesced writes along the inner index.  Needs Ck % 32 == 0 and no K padding.
+__host__ __device__ inline int prep_up_tiles(const PrepUpArgs& q, bool ph) {
+  return ph ? 16 * (q.CrPpad / 32) * (q.CkP / 32) : 16 * (q.CrDpad / 32) * (q.CkD / 32);
+}
+__device__ __forceinline__ void prep_up_tile(const PrepUpArgs& q, bool ph, int tile, float (*tl)[33]) {
+  const int Cr = ph ? q.CrP : q.CrD, Ck = ph ? q.CkP : q.CkD, CrPad = ph ? q.CrPpad : q.CrDpad, sk = ph ? q.skP : q.skD;
+  const int tk = Ck / 32, tr = CrPad / 32;
+  const int c0 = (tile % tk) * 32, r0 = ((tile / tk) % tr) * 32, slice = tile / (tk * tr);      // slice 0..15
+  int h0, h1, w0, w1;
+  if (ph) { up_range_R((slice >> 2) >> 1, (slice & 3) >> 1, h0, h1); up_range_R((slice >> 2) & 1, slice & 1, w0, w1); }
+  else { up_range_S(slice >> 2, h0, h1); up_range_S(slice & 3, w0, w1); }
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    float v = 0.f;
+    if (r < Cr)
+      for (int dh = h0; dh <= h1; dh++)
+        for (int dw = w0; dw <= w1; dw++) {
+          const int t3 = q.flip ? (2 - dh) * 3 + (2 - dw) : dh * 3 + dw;
+          v += q.w[(long)t3 * q.plane + r + (long)c * sk];
+        }
+    tl[i][tx] = v * q.scale;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    if (ph) q.ph[((long)((slice >> 2) * CrPad + r) * 4 + (slice & 3)) * Ck + c] = f2bf(tl[tx][i]);
+    else q.d4[(long)r * q.Kpad4 + (long)slice * Ck + c] = f2bf(tl[tx][i]);
+  }
+}
+
+// standalone form: `ntiles` leading blocks take the transposed tiles of matrix `ph_tiled`, the rest go element-wise over [lo, hi)
+__global__ __launch_bounds__(256) void prep_upconv_kernel(PrepUpArgs q, int ntiles, int ph_tiled, long lo, long hi) {
+  __shared__ float tt[32][33];
+  if ((int)blockIdx.x < ntiles) { prep_up_tile(q, ph_tiled != 0, blockIdx.x, tt); return; }
+  const long base = lo + (long)(blockIdx.x - ntiles) * 2048;
+  for (int j = 0; j < 8; j++) {
+    const long i = base + j * 256 + threadIdx.x;
+    if (i < hi) prep_up_element(q, i);
+  }
+}
+// block split shared by the standalone and the batched launchers
+struct PrepUpSplit { int ntiles, nelem; long lo, hi; };
+static inline PrepUpSplit prep_up_split(const PrepUpArgs& q, int kind) {
+  const bool ph = kind == 1;          // which matrix has the strided source: kind 1 the phase matrix, kind 2 the 4x4 one
+  const bool tiled = ph ? (q.srP == 1 && q.CkP % 32 == 0) : (q.srD == 1 && q.CkD % 32 == 0 && q.Kpad4 == 16 * q.CkD);
+  const long nph = 4L * q.CrPpad * 4 * q.CkP, total = prep_up_total(q);
+  PrepUpSplit s;
+  s.ntiles = tiled ? prep_up_tiles(q, ph) : 0;
+  s.lo = tiled && ph ? nph : 0;
+  s.hi = tiled && !ph ? nph : total;
+  s.nelem = (int)cdiv(s.hi - s.lo, 2048);
+  return s;
 }
 
 // kind 1 = UpsampleConv 3x3 (ph rows = co, d4 rows = ci); kind 2 = ConvMeanPool 3x3 (ph rows = ci, d4 rows = co, flipped, x 1/4)
@@ -155,7 +208,8 @@ __host__ __device__ inline PrepUpArgs prep_up_args(int kind, const float* w, voi
 extern "C" int gank_upconv3x3_prep_weights(const float* w, void* wph, void* wd4, int Cin, int Cout, void* stream) {
   GANK_REQUIRE(w && wph && wd4 && Cin > 0 && Cout > 0, "upconv3x3_prep_weights: bad arguments");
   const PrepUpArgs q = prep_up_args(1, w, wph, wd4, Cin, Cout);
-  hipLaunchKernelGGL(prep_upconv_kernel, grid1d(prep_up_total(q)), dim3(256), 0, (hipStream_t)stream, q);
+  const PrepUpSplit sp = prep_up_split(q, 1);
+  hipLaunchKernelGGL(prep_upconv_kernel, dim3(sp.ntiles + sp.nelem), dim3(256), 0, (hipStream_t)stream, q, sp.ntiles, 1, sp.lo, sp.hi);
   GANK_LAUNCH_OK("prep_upconv");
   return 0;
 }
@@ -167,7 +221,8 @@ extern "C" int gank_upconv3x3_prep_weights(const float* w, void* wph, void* wd4,
 extern "C" int gank_convpool3x3_prep_weights(const float* w, void* wp4, void* wphd, int Cin, int Cout, void* stream) {
   GANK_REQUIRE(w && wp4 && wphd && Cin > 0 && Cout > 0, "convpool3x3_prep_weights: bad arguments");
   const PrepUpArgs q = prep_up_args(2, w, wphd, wp4, Cin, Cout);
-  hipLaunchKernelGGL(prep_upconv_kernel, grid1d(prep_up_total(q)), dim3(256), 0, (hipStream_t)stream, q);
+  const PrepUpSplit sp = prep_up_split(q, 2);
+  hipLaunchKernelGGL(prep_upconv_kernel, dim3(sp.ntiles + sp.nelem), dim3(256), 0, (hipStream_t)stream, q, sp.ntiles, 0, sp.lo, sp.hi);
   GANK_LAUNCH_OK("prep_convpool");
   return 0;
 }
@@ -204,10 +259,18 @@ __global__ void prep_batch_kernel(PrepTable t) {
   const int taps = d.ksize * d.ksize;
   if (d.kind == 1 || d.kind == 2) {       // UpsampleConv / ConvMeanPool 3x3 operands
     const PrepUpArgs& q = t.up[e];
-    const long total = prep_up_total(q), base = (long)b * 2048;
-    for (int j = 0; j < 8; j++) {
-      const long i = base + j * 256 + threadIdx.x;
-      if (i < total) prep_up_element(q, i);
+    __shared__ float tt[32][33];
+    const long nph = 4L * q.CrPpad * 4 * q.CkP, total = prep_up_total(q);
+    if (b < t.nwf[e]) {                   // transposed tiles of the strided-source matrix (nwf = their count, or 0)
+      prep_up_tile(q, d.kind == 1, b, tt);
+    } else {                              // the other matrix (or both when the tile path does not apply), element-wise
+      long lo = 0, hi = total;
+      if (t.nwf[e] > 0) { if (d.kind == 1) lo = nph; else hi = nph; }
+      const long base = lo + (long)(b - t.nwf[e]) * 2048;
+      for (int j = 0; j < 8; j++) {
+        const long i = base + j * 256 + threadIdx.x;
+        if (i < hi) prep_up_element(q, i);
+      }
     }
   } else if (b < t.nwf[e]) {
     const int K = taps * d.Cin, Kpad = (K + 63) / 64 * 64, CoutPad = (d.Cout + 31) / 32 * 32;
@@ -267,8 +330,9 @@ extern "C" int gank_conv2d_prep_weights_batched(const gank_prep_desc* table, int
       int nwd = d.wd ? cdiv((long)roundup(d.Cin, 32) * roundup(taps * d.Cout, 64), 2048) : 0;
       if (d.kind == 1 || d.kind == 2) {
         t.up[i] = d.kind == 1 ? prep_up_args(1, d.w, d.wf, d.wd, d.Cin, d.Cout) : prep_up_args(2, d.w, d.wd, d.wf, d.Cin, d.Cout);
-        nwf = 0;
-        nwd = (int)cdiv(prep_up_total(t.up[i]), 2048);
+        const PrepUpSplit sp = prep_up_split(t.up[i], d.kind);
+        nwf = sp.ntiles;
+        nwd = sp.nelem;
       }
       t.first_block[i] = blocks;
       t.nwf[i] = nwf;
