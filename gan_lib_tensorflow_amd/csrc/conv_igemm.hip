@@ -937,6 +937,235 @@ static int launch_narrow_in(const IgemmArgs& a0, hipStream_t s) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Two-group ("ping-pong") patch kernel for plain 3x3 / stride 1 / SAME convolutions with W % 32 == 0, H % 8 == 0,
+// Cin % 32 == 0, Cout % 256 == 0.  Every kernel above keeps ~0.9 PFLOP/s: a 128-wide tile, 2-3 blocks per CU, one
+// __syncthreads (with its vmcnt(0) drain) per K-step.  This one follows the structure that gets past that on a GEMM:
+//   * one 512-thread block per CU owns an 8 x 32 pixel patch x 256 couts; wave (wm, wn) = 128 pixels (4 patch rows)
+//     x 64 couts = 4 x 2 MFMA tiles, 128 accumulator registers, 12 fragment reads per 16 MFMAs;
+//   * a phase is one K-step of 32 channels of one tap: {12 ds_read_b128, 2-3 LDS-DMA issues, counted vmcnt, s_barrier,
+//     16 MFMAs, s_barrier}.  The two wave groups (wm = 0 / 1, one wave of each per SIMD) run ONE barrier apart, so a
+//     SIMD's matrix pipe always has the other group's MFMA cluster while this group reads and stages;
+//   * both operands arrive by LDS-DMA (buffer_load ... lds, 16 B per lane, no VGPRs, OOB lanes deliver the zero
+//     padding): weights into a ring of 5 slots (16 KB = 256 couts x 32 k, issued 3 phases ahead), the 10 x 34 halo of
+//     the next 32-channel chunk into the other of two halo images during taps 1-3 of the current chunk.  Nothing in
+//     the loop waits for vmcnt(0): the wait before a phase's first barrier leaves the loads of the last two phases in
+//     flight, and a slot / image is rewritten two phases after its last read;
+//   * LDS images are lane-linear per DMA (1 KB = 16 pixels or couts x 64 B); the 16-byte chunk inside a 64-B row is
+//     XOR-swizzled with (row >> 2) & 3 on the SOURCE address and on the read, which makes every 16-lane ds_read_b128
+//     group hit 16 distinct slots of the 256-B bank row (a pixel tile is one patch row, so its lanes are distinct mod 16).
+// ------------------------------------------------------------------------------------------------------
+constexpr int PP_HALO_PX = 10 * 34;
+constexpr int PP_HROW = 34 * 64;                   // bytes per halo row
+constexpr int PP_HALO_BYTES = 24576;               // 340 px x 64 B = 21760, rounded up to 3 DMA rounds of 512 x 16 B
+constexpr int PP_WSLOT_BYTES = 16384;              // 256 couts x 32 k x 2 B = 2 DMA rounds
+constexpr int PP_NSLOT = 5;
+constexpr int PP_WRING = 2 * PP_HALO_BYTES;
+constexpr int PP_LDS_BYTES = PP_WRING + PP_NSLOT * PP_WSLOT_BYTES;   // 128 KB
+
+template <int N>
+__device__ __forceinline__ void pp_wait_vmcnt() {
+  static_assert(N >= 0 && N <= 8, "vmcnt");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  static_assert(N == 0 || N == 2 || N == 4 || N == 5 || N == 6, "vmcnt value not instantiated");
+}
+
+template <int MODE>   // bit0: relu on the input operand
+__global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int r = lane & 31, h = lane >> 5;
+
+  const int nwg = a.tiles_m * a.tiles_n;
+  const int lid = xcd_remap(blockIdx.x, nwg);
+  const int tile_n = lid % a.tiles_n, tile_m = lid / a.tiles_n;
+  const int pw = a.W >> 5, ph = a.H >> 3;
+  const int n = tile_m / (pw * ph), pr = tile_m - n * pw * ph;
+  const int py0 = (pr / pw) << 3, px0 = (pr % pw) << 5;
+
+  constexpr unsigned OOB = 0x7FFFFFF0u;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, a.N * a.H * a.W * a.Cin * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w), 0, a.CoutPad * a.Kpad * 2, 0x00020000);
+
+  // DMA source offsets.  Halo: 16-byte piece q of the image = pixel q>>2 (row-major 10 x 34), slot q&3 holding channel
+  // chunk (q&3) ^ ((hx>>2)&3).  Weights: piece q of a slot = cout q>>2, slot q&3 holding k chunk (q&3) ^ ((co>>2)&3).
+  unsigned h_off[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const int q = (j * 8 + wave) * 64 + lane;
+    const int hp = q >> 2, hy = hp / 34, hx = hp - hy * 34;
+    const int iy = py0 - 1 + hy, ix = px0 - 1 + hx;
+    const bool ok = hp < PP_HALO_PX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    h_off[j] = ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin + (((q & 3) ^ ((hx >> 2) & 3)) << 3)) * 2) : OOB;
+  }
+  int w_off[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int q = (j * 8 + wave) * 64 + lane;
+    const int co = q >> 2;
+    w_off[j] = ((tile_n * 256 + co) * a.Kpad + (((q & 3) ^ ((co >> 2) & 3)) << 3)) * 2;
+  }
+  // fragment read offsets of this lane (bytes): weights row r of the wave's cout range, pixels column r+1+dw of patch row wm*4
+  int a_lane[2], b_lane[3][2];
+#pragma unroll
+  for (int kk = 0; kk < 2; kk++) {
+    a_lane[kk] = PP_WRING + (wn * 64 + r) * 64 + (((kk * 2 + h) ^ ((r >> 2) & 3)) << 4);
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      const int hx = r + d;          // = r + 1 + dw
+      b_lane[d][kk] = wm * 4 * PP_HROW + hx * 64 + (((kk * 2 + h) ^ ((hx >> 2) & 3)) << 4);
+    }
+  }
+
+  const int nch = a.Cin >> 5;
+  auto issue_w = [&](int slot_bytes, int c, int tap) {      // K-step (chunk c, tap) -> ring slot
+    const int koff = (tap * a.Cin + c * 32) * 2;
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_t)(smem + PP_WRING + slot_bytes + (j * 8 + wave) * 1024), 16, w_off[j], koff, 0, 0);
+  };
+  auto issue_h = [&](int buf, int c, int j) {               // DMA round j of chunk c's halo -> image buf
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_t)(smem + buf * PP_HALO_BYTES + (j * 8 + wave) * 1024), 16, (int)(h_off[j] + (unsigned)c * 64u), 0, 0, 0);
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+  // prologue: halo of chunk 0, weights of K-steps 0, 1, 2 (issue order matters: the counted waits rely on it)
+  issue_h(0, 0, 0); issue_h(0, 0, 1); issue_h(0, 0, 2);
+  issue_w(0, 0, 0);
+  issue_w(PP_WSLOT_BYTES, 0, 1);
+  issue_w(2 * PP_WSLOT_BYTES, 0, 2);
+  pp_wait_vmcnt<4>();
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0 from here on
+
+  int rslot = 0, wslot = 3 * PP_WSLOT_BYTES;
+  for (int c = 0; c < nch; c++) {
+    const int hb = (c & 1) * PP_HALO_BYTES;
+    const int cn = (c + 1 < nch) ? c + 1 : nch - 1;
+    auto phase = [&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      constexpr int dh1 = t / 3, dw1 = t % 3;          // dh + 1, dw + 1
+      bf16x8 fa[2][2], fb[4][2];
+#pragma unroll
+      for (int kk = 0; kk < 2; kk++) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) fa[i][kk] = *reinterpret_cast<const bf16x8*>(smem + rslot + i * 2048 + a_lane[kk]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) fb[j][kk] = *reinterpret_cast<const bf16x8*>(smem + hb + (j + dh1) * PP_HROW + b_lane[dw1][kk]);
+      }
+      // stage K-step p+3 (clamped to the last one: a spare write into a slot nobody reads again)
+      {
+        constexpr int t3 = (t + 3) % 9;
+        int c3 = c + (t + 3) / 9, tt = t3;
+        if (c3 >= nch) { c3 = nch - 1; tt = 8; }
+        issue_w(wslot, c3, tt);
+      }
+      if constexpr (t >= 1 && t <= 3) issue_h((c + 1) & 1, cn, t - 1);
+      constexpr int NV = 4 + ((t >= 1 && t <= 3) ? 1 : 0) + ((t >= 2 && t <= 4) ? 1 : 0);   // loads of this and the previous phase
+      pp_wait_vmcnt<NV>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr ((MODE & 1) != 0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int kk = 0; kk < 2; kk++) fb[j][kk] = __builtin_bit_cast(bf16x8, relu_bf16x8(__builtin_bit_cast(u32x4, fb[j][kk])));
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+      rslot += PP_WSLOT_BYTES; if (rslot == PP_NSLOT * PP_WSLOT_BYTES) rslot = 0;
+      wslot += PP_WSLOT_BYTES; if (wslot == PP_NSLOT * PP_WSLOT_BYTES) wslot = 0;
+    };
+    phase(std::integral_constant<int, 0>{}); phase(std::integral_constant<int, 1>{}); phase(std::integral_constant<int, 2>{});
+    phase(std::integral_constant<int, 3>{}); phase(std::integral_constant<int, 4>{}); phase(std::integral_constant<int, 5>{});
+    phase(std::integral_constant<int, 6>{}); phase(std::integral_constant<int, 7>{}); phase(std::integral_constant<int, 8>{});
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();          // same barrier count for both groups
+  pp_wait_vmcnt<0>();                                 // the clamped spare DMAs must land before the LDS is released
+
+  // epilogue (same order as the other kernels): lane holds channels co0+8g+4h..+3 of one pixel per quad
+  const bool otanh = (a.flags & GANK_OUT_TANH) != 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int py = py0 + wm * 4 + j, px = px0 + r;
+    const long m = ((long)(n * a.H + py)) * a.W + px;
+    const long mr = (a.flags & IG_RES_UP2X) ? ((long)(n * (a.H >> 1) + (py >> 1))) * (a.W >> 1) + (px >> 1) : m;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int co0 = tile_n * 256 + (wn * 2 + i) * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int co = co0 + 8 * g;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * g + e] * a.scale;
+        const long o = m * a.Cout + co;
+        if (a.bias) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += b[e];
+        }
+        if (a.mask) {
+          const bf16x4 mk = *reinterpret_cast<const bf16x4*>(a.mask + o);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = (bf2f(mk[e]) > 0.f) ? v[e] : 0.f;
+        }
+        if (a.res) {
+          const bf16x4 rs = *reinterpret_cast<const bf16x4*>(a.res + mr * a.Cout + co);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += bf2f(rs[e]);
+        }
+        bf16x4 out;
+#pragma unroll
+        for (int e = 0; e < 4; e++) out[e] = f2bf(otanh ? tanhf(v[e]) : v[e]);
+        *reinterpret_cast<bf16x4*>(a.y + o) = out;
+      }
+    }
+  }
+}
+
+template <int MODE>
+static int launch_pp(const IgemmArgs& a0, hipStream_t s) {
+  IgemmArgs a = a0;
+  a.tiles_m = a.N * (a.H / 8) * (a.W / 32);
+  a.tiles_n = a.Cout / 256;
+  auto kern = conv_igemm_pp_kernel<MODE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+    if (e != hipSuccess) return gank_set_error("conv_igemm_pp: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  static char tag[64];
+  if (!tag[0]) snprintf(tag, sizeof(tag), "conv_igemm_pp_kernel<%d>", MODE);
+  gank_prof_tag(0, tag);
+  hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(512), PP_LDS_BYTES, s, a);
+  GANK_LAUNCH_OK("conv_igemm_pp");
+  return 0;
+}
+
 template <int MODE, int BN>
 static int launch_patch(const IgemmArgs& a0, hipStream_t s) {
   IgemmArgs a = a0;
@@ -1051,8 +1280,13 @@ int gank_igemm_dispatch(IgemmArgs a, hipStream_t s) {
                          a.Kpad == a.taps * a.Cin && (long)a.CoutPad * a.Kpad * 2 < (1L << 30);
   const bool narrow_ok = !(a.flags & IG_RES_UP2X) && a.Cin == 3 && (a.ks == 1 || a.ks == 3) && a.pad == (a.ks - 1) / 2 && a.CoutPad % 128 == 0 && a.Cout % 4 == 0 &&
                          !(a.flags & (GANK_IN_UPSAMPLE2X | IG_IN_ZEROINS2X | IG_IN_STRIDE2)) && a.Hin == a.H && a.Win == a.W;
+  static int pp_env = -1;      // experiment knob: GANK_IGEMM_PP=1 enables the two-group LDS-DMA kernel
+  if (pp_env < 0) { const char* e = getenv("GANK_IGEMM_PP"); pp_env = e ? atoi(e) : 0; }
+  const bool pp_ok = pp_env && patch_geom && a.W % 32 == 0 && a.Cout % 256 == 0 && a.Kpad == a.taps * a.Cin;
   if (narrow_ok) {
     rc = a.ks == 3 ? launch_narrow_in<3, 3>(a, s) : launch_narrow_in<1, 3>(a, s);
+  } else if (pp_ok) {
+    rc = (a.flags & GANK_IN_RELU) ? launch_pp<1>(a, s) : launch_pp<0>(a, s);
   } else if (patch2_ok) {
     rc = (a.flags & GANK_IN_RELU) ? launch_patch2<1>(a, s) : launch_patch2<0>(a, s);
   } else if (patch_ok) {
