@@ -938,71 +938,96 @@ static int launch_narrow_in(const IgemmArgs& a0, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Two-group ("ping-pong") patch kernel for plain 3x3 / stride 1 / SAME convolutions with W % 32 == 0, H % 8 == 0,
-// Cin % 32 == 0, Cout % 256 == 0.  Every kernel above keeps ~0.9 PFLOP/s: a 128-wide tile, 2-3 blocks per CU, one
-// __syncthreads (with its vmcnt(0) drain) per K-step.  This one follows the structure that gets past that on a GEMM:
-//   * one 512-thread block per CU owns an 8 x 32 pixel patch x 256 couts; wave (wm, wn) = 128 pixels (4 patch rows)
-//     x 64 couts = 4 x 2 MFMA tiles, 128 accumulator registers, 12 fragment reads per 16 MFMAs;
-//   * a phase is one K-step of 32 channels of one tap: {12 ds_read_b128, 2-3 LDS-DMA issues, counted vmcnt, s_barrier,
-//     16 MFMAs, s_barrier}.  The two wave groups (wm = 0 / 1, one wave of each per SIMD) run ONE barrier apart, so a
-//     SIMD's matrix pipe always has the other group's MFMA cluster while this group reads and stages;
-//   * both operands arrive by LDS-DMA (buffer_load ... lds, 16 B per lane, no VGPRs, OOB lanes deliver the zero
-//     padding): weights into a ring of 5 slots (16 KB = 256 couts x 32 k, issued 3 phases ahead), the 10 x 34 halo of
-//     the next 32-channel chunk into the other of two halo images during taps 1-3 of the current chunk.  Nothing in
-//     the loop waits for vmcnt(0): the wait before a phase's first barrier leaves the loads of the last two phases in
-//     flight, and a slot / image is rewritten two phases after its last read;
+// Two-group ("ping-pong") patch kernel for 3x3 / stride 1 / SAME convolutions and for the four output phases of the
+// stride-2 transposed convolutions (UpsampleConv 3x3 fprop, ConvMeanPool 3x3 input gradient), Cin % 32 == 0,
+// Cout % 256 == 0, on 8 x 32 (PW = 32) or 16 x 16 (PW = 16) pixel patches.
+// Every kernel above sits at ~0.9 PFLOP/s: a 128-wide tile, 2-3 blocks per CU, one __syncthreads (with its vmcnt(0)
+// drain) per K-step.  This one has the structure that gets past that on a GEMM:
+//   * one 512-thread block per CU owns 256 pixels x 256 couts; wave (wm, wn) = 128 pixels x 64 couts = 4 x 2 MFMA
+//     tiles, 128 accumulator registers, 12 fragment reads (ds_read_b128) per 16 MFMAs;
+//   * a phase is one K-step of 32 channels of one tap: {12 fragment reads R, LDS-DMA issues, counted vmcnt, 16 MFMAs M}
+//     with ONE s_barrier, which group 0 (waves 0-3) takes between R and M and group 1 (waves 4-7: the other wave of
+//     each SIMD) at the top of the phase.  After barrier p group 0 therefore runs {M_p, R_p+1} while group 1 runs
+//     {R_p, M_p}: each SIMD's matrix pipe has one group's MFMAs beside the other group's reads and staging;
+//   * both operands arrive by LDS-DMA (buffer_load ... lds, 16 B per lane, no VGPRs; out-of-range lanes deliver the
+//     zero padding).  Weights: a ring of 6 slots (16 KB = 256 couts x 32 k), every wave issues its 2 pieces of K-step
+//     p+4 in phase p.  Pixels: the halo of the next 32-channel chunk goes into the other of two halo images, issued by
+//     group 1 only, in the first two phases of the current chunk and AHEAD of those phases' weight pieces.
+//     Nothing in the loop waits for vmcnt(0): a phase's wait leaves the weight pieces of that phase and the one before
+//     in flight.  What makes this safe (q = a K-step, interval j = between barriers j and j+1; group 0 reads R_q in
+//     interval q-1, group 1 in interval q): a piece of step q is retired by group 0's wait in phase q-1 and group 1's
+//     in phase q-2, both ahead of barrier q-1; a slot is rewritten in phase q+2 at the earliest, two barriers after its
+//     last read; the halo image of chunk c+1 is rewritten after barrier (first phase of chunk c), one barrier after
+//     group 1's last read of it, and is retired by group 1's wait in the chunk's last-but-one phase (hence "ahead of
+//     the weight pieces": vmcnt retires in issue order);
 //   * LDS images are lane-linear per DMA (1 KB = 16 pixels or couts x 64 B); the 16-byte chunk inside a 64-B row is
-//     XOR-swizzled with (row >> 2) & 3 on the SOURCE address and on the read, which makes every 16-lane ds_read_b128
-//     group hit 16 distinct slots of the 256-B bank row (a pixel tile is one patch row, so its lanes are distinct mod 16).
+//     XOR-swizzled with (row >> 2) & 3 on the SOURCE address and on the read: conflict-free ds_read_b128 groups for
+//     the weights and for one-row pixel tiles (PW = 32; SQ_LDS_BANK_CONFLICT = 0), a residual 2-way conflict on 2 of
+//     16 lanes for the two-row tiles of PW = 16;
+//   * the epilogue widens its stores with v_permlane32_swap (8 consecutive channels = 16 B per lane): with one block
+//     per CU nothing else overlaps them.
+// Measured (256 -> 256, 32 x 32, n = 128, random data): 1.10-1.14 PFLOP/s against 0.81-0.86 for conv_igemm_patch_kernel.
+// The matrix pipe is then 61-67 % busy at the clock the chip holds under this load (1.5-1.8 GHz; MFMAs alone: 2.3).
 // ------------------------------------------------------------------------------------------------------
-constexpr int PP_HALO_PX = 10 * 34;
-constexpr int PP_HROW = 34 * 64;                   // bytes per halo row
-constexpr int PP_HALO_BYTES = 24576;               // 340 px x 64 B = 21760, rounded up to 3 DMA rounds of 512 x 16 B
-constexpr int PP_WSLOT_BYTES = 16384;              // 256 couts x 32 k x 2 B = 2 DMA rounds
-constexpr int PP_NSLOT = 5;
+constexpr int PP_HALO_BYTES = 24576;               // 10 x 34 (or 18 x 18) px x 64 B <= 24 DMA pieces of 1 KB
+constexpr int PP_WSLOT_BYTES = 16384;              // 256 couts x 32 k x 2 B = 16 pieces
+constexpr int PP_NSLOT = 6, PP_PD = 4;             // ring slots, prefetch distance in K-steps
 constexpr int PP_WRING = 2 * PP_HALO_BYTES;
-constexpr int PP_LDS_BYTES = PP_WRING + PP_NSLOT * PP_WSLOT_BYTES;   // 128 KB
+constexpr int PP_LDS_BYTES = PP_WRING + PP_NSLOT * PP_WSLOT_BYTES;   // 144 KB
 
 template <int N>
 __device__ __forceinline__ void pp_wait_vmcnt() {
-  static_assert(N >= 0 && N <= 8, "vmcnt");
+  static_assert(N == 0 || N == 4 || N == 6 || N == 7, "vmcnt value not instantiated");
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
   if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  static_assert(N == 0 || N == 2 || N == 4 || N == 5 || N == 6, "vmcnt value not instantiated");
+  if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
 }
 
-template <int MODE>   // bit0: relu on the input operand
+template <int MODE, int PW>   // MODE bit0: relu on the input operand; bit2: one output phase of a stride-2 transposed conv
 __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
+  constexpr bool PHASE = (MODE & 4) != 0;
+  constexpr int NT = PHASE ? 4 : 9;                  // taps (K-steps) per 32-channel chunk
+  constexpr int PHH = 256 / PW;                      // patch rows
+  constexpr int HW_ = PW + 2, HROW = HW_ * 64;       // halo width (pixels), halo row pitch (bytes)
+  constexpr int HPX = (PHH + 2) * HW_;               // halo pixels
+  constexpr int RS = 32 / PW;                        // patch rows per 32-pixel MFMA tile
+  static_assert(PW == 32 || PW == 16, "patch width");
+  static_assert(HPX * 64 <= PP_HALO_BYTES, "halo image");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_t;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int r = lane & 31, h = lane >> 5;
+  const int prow = RS == 1 ? 0 : (r >> 4), pcol = RS == 1 ? r : (r & 15);   // this lane's pixel inside a tile
 
   const int nwg = a.tiles_m * a.tiles_n;
   const int lid = xcd_remap(blockIdx.x, nwg);
-  const int tile_n = lid % a.tiles_n, tile_m = lid / a.tiles_n;
-  const int pw = a.W >> 5, ph = a.H >> 3;
+  const int tile_n = lid % a.tiles_n;
+  int tile_m = lid / a.tiles_n;
+  int phase = 0;
+  if constexpr (PHASE) { phase = tile_m / a.tiles_pp; tile_m -= phase * a.tiles_pp; }
+  const int pad_h = PHASE ? 1 - (phase >> 1) : 1, pad_w = PHASE ? 1 - (phase & 1) : 1;
+  const int pw = a.W / PW, ph = a.H / PHH;
   const int n = tile_m / (pw * ph), pr = tile_m - n * pw * ph;
-  const int py0 = (pr / pw) << 3, px0 = (pr % pw) << 5;
+  const int py0 = (pr / pw) * PHH, px0 = (pr % pw) * PW;
 
   constexpr unsigned OOB = 0x7FFFFFF0u;
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, a.N * a.H * a.W * a.Cin * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w), 0, a.CoutPad * a.Kpad * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w) + (PHASE ? (long)phase * a.CoutPad * a.Kpad : 0L), 0,
+                                                                        a.CoutPad * a.Kpad * 2, 0x00020000);
 
-  // DMA source offsets.  Halo: 16-byte piece q of the image = pixel q>>2 (row-major 10 x 34), slot q&3 holding channel
-  // chunk (q&3) ^ ((hx>>2)&3).  Weights: piece q of a slot = cout q>>2, slot q&3 holding k chunk (q&3) ^ ((co>>2)&3).
-  unsigned h_off[3];
+  // DMA source offsets.  Halo (group 1 only, 6 pieces per wave): 16-byte unit q of the image = pixel q>>2 (row-major
+  // (PHH+2) x (PW+2), origin (py0-1, px0-1)), slot q&3 holding channel chunk (q&3) ^ ((hx>>2)&3).  Weights: unit q of a
+  // slot = cout q>>2, slot q&3 holding k chunk (q&3) ^ ((co>>2)&3).
+  unsigned h_off[6];
 #pragma unroll
-  for (int j = 0; j < 3; j++) {
-    const int q = (j * 8 + wave) * 64 + lane;
-    const int hp = q >> 2, hy = hp / 34, hx = hp - hy * 34;
+  for (int j = 0; j < 6; j++) {
+    const int q = (j * 4 + wn) * 64 + lane;
+    const int hp = q >> 2, hy = hp / HW_, hx = hp - hy * HW_;
     const int iy = py0 - 1 + hy, ix = px0 - 1 + hx;
-    const bool ok = hp < PP_HALO_PX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    const bool ok = hp < HPX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
     h_off[j] = ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin + (((q & 3) ^ ((hx >> 2) & 3)) << 3)) * 2) : OOB;
   }
   int w_off[2];
@@ -1012,15 +1037,18 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
     const int co = q >> 2;
     w_off[j] = ((tile_n * 256 + co) * a.Kpad + (((q & 3) ^ ((co >> 2) & 3)) << 3)) * 2;
   }
-  // fragment read offsets of this lane (bytes): weights row r of the wave's cout range, pixels column r+1+dw of patch row wm*4
-  int a_lane[2], b_lane[3][2];
+  // fragment read offsets of this lane (bytes): weights row r of the wave's cout range; pixels: halo column pcol + d of
+  // the wave's first patch row (+ the tap's row offset as an immediate), d = the tap's column offset 0..2
+  constexpr int ND = PHASE ? 2 : 3;
+  int a_lane[2], b_lane[ND][2];
 #pragma unroll
   for (int kk = 0; kk < 2; kk++) {
     a_lane[kk] = PP_WRING + (wn * 64 + r) * 64 + (((kk * 2 + h) ^ ((r >> 2) & 3)) << 4);
 #pragma unroll
-    for (int d = 0; d < 3; d++) {
-      const int hx = r + d;          // = r + 1 + dw
-      b_lane[d][kk] = wm * 4 * PP_HROW + hx * 64 + (((kk * 2 + h) ^ ((hx >> 2) & 3)) << 4);
+    for (int d = 0; d < ND; d++) {
+      const int hx = pcol + d + (PHASE ? 1 - pad_w : 0);
+      const int hy = wm * (PHH / 2) + prow + (PHASE ? 1 - pad_h : 0);
+      b_lane[d][kk] = hy * HROW + hx * 64 + (((kk * 2 + h) ^ ((hx >> 2) & 3)) << 4);
     }
   }
 
@@ -1031,8 +1059,10 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
     for (int j = 0; j < 2; j++)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_t)(smem + PP_WRING + slot_bytes + (j * 8 + wave) * 1024), 16, w_off[j], koff, 0, 0);
   };
-  auto issue_h = [&](int buf, int c, int j) {               // DMA round j of chunk c's halo -> image buf
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_t)(smem + buf * PP_HALO_BYTES + (j * 8 + wave) * 1024), 16, (int)(h_off[j] + (unsigned)c * 64u), 0, 0, 0);
+  auto issue_h = [&](int buf, int c, int j0) {              // pieces j0..j0+2 of chunk c's halo -> image buf (group 1)
+#pragma unroll
+    for (int j = j0; j < j0 + 3; j++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_t)(smem + buf * PP_HALO_BYTES + (j * 4 + wn) * 1024), 16, (int)(h_off[j] + (unsigned)c * 64u), 0, 0, 0);
   };
 
   f32x16 acc[2][4];
@@ -1043,41 +1073,47 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
-  // prologue: halo of chunk 0, weights of K-steps 0, 1, 2 (issue order matters: the counted waits rely on it)
-  issue_h(0, 0, 0); issue_h(0, 0, 1); issue_h(0, 0, 2);
-  issue_w(0, 0, 0);
-  issue_w(PP_WSLOT_BYTES, 0, 1);
-  issue_w(2 * PP_WSLOT_BYTES, 0, 2);
-  pp_wait_vmcnt<4>();
+  // prologue: halo of chunk 0, weights of K-steps 0..3 (issue order matters: the counted waits rely on it)
+  if (wm == 1) { issue_h(0, 0, 0); issue_h(0, 0, 3); }
+  {
+    int c = 0, t = 0;
+#pragma unroll
+    for (int q = 0; q < PP_PD; q++) {
+      issue_w(q * PP_WSLOT_BYTES, c, t);
+      if (++t == NT) { t = 0; c++; }
+      if (c >= nch) { c = nch - 1; t = NT - 1; }
+    }
+  }
+  pp_wait_vmcnt<6>();                                  // step 0 and the halo have landed; steps 1-3 stay in flight
   __builtin_amdgcn_s_barrier();
-  if (wm == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0 from here on
 
-  int rslot = 0, wslot = 3 * PP_WSLOT_BYTES;
+  int rslot = 0, wslot = PP_PD * PP_WSLOT_BYTES;
   for (int c = 0; c < nch; c++) {
     const int hb = (c & 1) * PP_HALO_BYTES;
     const int cn = (c + 1 < nch) ? c + 1 : nch - 1;
-    auto phase = [&](auto tc) {
+    auto phase_step = [&](auto tc) {
       constexpr int t = decltype(tc)::value;
-      constexpr int dh1 = t / 3, dw1 = t % 3;          // dh + 1, dw + 1
+      constexpr int dh1 = PHASE ? t / 2 : t / 3, dw1 = PHASE ? t % 2 : t % 3;
+      if (wm == 1) __builtin_amdgcn_s_barrier();
       bf16x8 fa[2][2], fb[4][2];
 #pragma unroll
       for (int kk = 0; kk < 2; kk++) {
 #pragma unroll
         for (int i = 0; i < 2; i++) fa[i][kk] = *reinterpret_cast<const bf16x8*>(smem + rslot + i * 2048 + a_lane[kk]);
 #pragma unroll
-        for (int j = 0; j < 4; j++) fb[j][kk] = *reinterpret_cast<const bf16x8*>(smem + hb + (j + dh1) * PP_HROW + b_lane[dw1][kk]);
+        for (int j = 0; j < 4; j++) fb[j][kk] = *reinterpret_cast<const bf16x8*>(smem + hb + (j * RS + dh1) * HROW + b_lane[dw1][kk]);
       }
-      // stage K-step p+3 (clamped to the last one: a spare write into a slot nobody reads again)
-      {
-        constexpr int t3 = (t + 3) % 9;
-        int c3 = c + (t + 3) / 9, tt = t3;
-        if (c3 >= nch) { c3 = nch - 1; tt = 8; }
-        issue_w(wslot, c3, tt);
+      // group 1: half of the next chunk's halo, ahead of the weight pieces (clamped past the end: a spare image)
+      if constexpr (t < 2) { if (wm == 1) issue_h((c + 1) & 1, cn, 3 * t); }
+      {                                                // K-step p + 4 (clamped to the last one: a spare write into a dead slot)
+        constexpr int t4 = (t + PP_PD) % NT;
+        int c4 = c + (t + PP_PD) / NT, tt = t4;
+        if (c4 >= nch) { c4 = nch - 1; tt = NT - 1; }
+        issue_w(wslot, c4, tt);
       }
-      if constexpr (t >= 1 && t <= 3) issue_h((c + 1) & 1, cn, t - 1);
-      constexpr int NV = 4 + ((t >= 1 && t <= 3) ? 1 : 0) + ((t >= 2 && t <= 4) ? 1 : 0);   // loads of this and the previous phase
-      pp_wait_vmcnt<NV>();
-      __builtin_amdgcn_s_barrier();
+      if constexpr (t < 2) { if (wm == 1) pp_wait_vmcnt<7>(); else pp_wait_vmcnt<4>(); }
+      else pp_wait_vmcnt<4>();
+      if (wm == 0) __builtin_amdgcn_s_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if constexpr ((MODE & 1) != 0) {
 #pragma unroll
@@ -1085,7 +1121,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
 #pragma unroll
           for (int kk = 0; kk < 2; kk++) fb[j][kk] = __builtin_bit_cast(bf16x8, relu_bf16x8(__builtin_bit_cast(u32x4, fb[j][kk])));
       }
-      __builtin_amdgcn_s_setprio(1);
+      __builtin_amdgcn_sched_barrier(0);               // keeps the MFMA cluster behind the barrier (hipcc hoists it otherwise)
 #pragma unroll
       for (int kk = 0; kk < 2; kk++)
 #pragma unroll
@@ -1093,65 +1129,78 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
 #pragma unroll
           for (int j = 0; j < 4; j++)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
       rslot += PP_WSLOT_BYTES; if (rslot == PP_NSLOT * PP_WSLOT_BYTES) rslot = 0;
       wslot += PP_WSLOT_BYTES; if (wslot == PP_NSLOT * PP_WSLOT_BYTES) wslot = 0;
     };
-    phase(std::integral_constant<int, 0>{}); phase(std::integral_constant<int, 1>{}); phase(std::integral_constant<int, 2>{});
-    phase(std::integral_constant<int, 3>{}); phase(std::integral_constant<int, 4>{}); phase(std::integral_constant<int, 5>{});
-    phase(std::integral_constant<int, 6>{}); phase(std::integral_constant<int, 7>{}); phase(std::integral_constant<int, 8>{});
+    phase_step(std::integral_constant<int, 0>{}); phase_step(std::integral_constant<int, 1>{});
+    phase_step(std::integral_constant<int, 2>{}); phase_step(std::integral_constant<int, 3>{});
+    if constexpr (!PHASE) {
+      phase_step(std::integral_constant<int, 4>{}); phase_step(std::integral_constant<int, 5>{}); phase_step(std::integral_constant<int, 6>{});
+      phase_step(std::integral_constant<int, 7>{}); phase_step(std::integral_constant<int, 8>{});
+    }
   }
-  if (wm == 0) __builtin_amdgcn_s_barrier();          // same barrier count for both groups
   pp_wait_vmcnt<0>();                                 // the clamped spare DMAs must land before the LDS is released
 
-  // epilogue (same order as the other kernels): lane holds channels co0+8g+4h..+3 of one pixel per quad
+  // epilogue.  An accumulator quad g of lane (r, h) is channels 8g+4h..+3 of pixel r: 8-byte pieces.  v_permlane32_swap
+  // trades quad 2q+1 of the h = 0 half-wave for quad 2q of the h = 1 half-wave, after which every lane owns 8
+  // CONSECUTIVE channels (16q + 8h ..) and writes, and reads mask / residual, 16 bytes at a time.
   const bool otanh = (a.flags & GANK_OUT_TANH) != 0;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    const int py = py0 + wm * 4 + j, px = px0 + r;
-    const long m = ((long)(n * a.H + py)) * a.W + px;
-    const long mr = (a.flags & IG_RES_UP2X) ? ((long)(n * (a.H >> 1) + (py >> 1))) * (a.W >> 1) + (px >> 1) : m;
+    const int py = py0 + wm * (PHH / 2) + j * RS + prow, px = px0 + pcol;
+    const long m = PHASE ? ((long)(n * 2 * a.H + 2 * py + (phase >> 1))) * (2 * a.W) + 2 * px + (phase & 1) : ((long)(n * a.H + py)) * a.W + px;
+    const long mr = (!PHASE && (a.flags & IG_RES_UP2X)) ? ((long)(n * (a.H >> 1) + (py >> 1))) * (a.W >> 1) + (px >> 1) : m;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      const int co0 = tile_n * 256 + (wn * 2 + i) * 32 + 4 * h;
 #pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const int co = co0 + 8 * g;
-        float v[4];
+      for (int q = 0; q < 2; q++) {
+        float v[8];
 #pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * g + e] * a.scale;
+        for (int e = 0; e < 4; e++) {
+          // inline asm, not __builtin_amdgcn_permlane32_swap: hipcc (ROCm 7.2) dropped the builtin's second result here
+          // (the +4 half came out as a copy of the first).  s_nop 1 = the 2 wait states a VALU write needs before the swap reads it.
+          float lo = acc[i][j][8 * q + e] * a.scale, hi = acc[i][j][8 * q + 4 + e] * a.scale;
+          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+          v[e] = lo;
+          v[4 + e] = hi;
+        }
+        const int co = tile_n * 256 + (wn * 2 + i) * 32 + 16 * q + 8 * h;
         const long o = m * a.Cout + co;
         if (a.bias) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + co);
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + co), b1 = *reinterpret_cast<const f32x4*>(a.bias + co + 4);
 #pragma unroll
-          for (int e = 0; e < 4; e++) v[e] += b[e];
+          for (int e = 0; e < 4; e++) { v[e] += b0[e]; v[4 + e] += b1[e]; }
         }
         if (a.mask) {
-          const bf16x4 mk = *reinterpret_cast<const bf16x4*>(a.mask + o);
+          const bf16x8 mk = *reinterpret_cast<const bf16x8*>(a.mask + o);
 #pragma unroll
-          for (int e = 0; e < 4; e++) v[e] = (bf2f(mk[e]) > 0.f) ? v[e] : 0.f;
+          for (int e = 0; e < 8; e++) v[e] = (bf2f(mk[e]) > 0.f) ? v[e] : 0.f;
         }
         if (a.res) {
-          const bf16x4 rs = *reinterpret_cast<const bf16x4*>(a.res + mr * a.Cout + co);
+          const bf16x8 rs = *reinterpret_cast<const bf16x8*>(a.res + mr * a.Cout + co);
 #pragma unroll
-          for (int e = 0; e < 4; e++) v[e] += bf2f(rs[e]);
+          for (int e = 0; e < 8; e++) v[e] += bf2f(rs[e]);
         }
-        bf16x4 out;
+        bf16x8 out;
 #pragma unroll
-        for (int e = 0; e < 4; e++) out[e] = f2bf(otanh ? tanhf(v[e]) : v[e]);
-        *reinterpret_cast<bf16x4*>(a.y + o) = out;
+        for (int e = 0; e < 8; e++) out[e] = f2bf(otanh ? tanhf(v[e]) : v[e]);
+        *reinterpret_cast<bf16x8*>(a.y + o) = out;
       }
     }
   }
 }
 
-template <int MODE>
+template <int MODE, int PW>
 static int launch_pp(const IgemmArgs& a0, hipStream_t s) {
   IgemmArgs a = a0;
-  a.tiles_m = a.N * (a.H / 8) * (a.W / 32);
+  constexpr bool PHASE = (MODE & 4) != 0;
+  const int tiles = a.N * (a.H / (256 / PW)) * (a.W / PW);
+  a.tiles_pp = tiles;
+  a.tiles_m = PHASE ? 4 * tiles : tiles;
   a.tiles_n = a.Cout / 256;
-  auto kern = conv_igemm_pp_kernel<MODE>;
+  if (PHASE) { a.Kpad = 4 * a.Cin; a.Hin = a.H; a.Win = a.W; }
+  auto kern = conv_igemm_pp_kernel<MODE, PW>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
@@ -1159,11 +1208,32 @@ static int launch_pp(const IgemmArgs& a0, hipStream_t s) {
     attr_set = true;
   }
   static char tag[64];
-  if (!tag[0]) snprintf(tag, sizeof(tag), "conv_igemm_pp_kernel<%d>", MODE);
+  if (!tag[0]) snprintf(tag, sizeof(tag), "conv_igemm_pp_kernel<%d, %d>", MODE, PW);
   gank_prof_tag(0, tag);
   hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(512), PP_LDS_BYTES, s, a);
   GANK_LAUNCH_OK("conv_igemm_pp");
   return 0;
+}
+// geometry both PP forms need (H, W = the grid the patches tile: the output for a plain conv, the low-res grid in phase mode)
+static int pp_patch_width(int H, int W) { return (W % 32 == 0 && H % 8 == 0) ? 32 : (W % 16 == 0 && H % 16 == 0) ? 16 : 0; }
+static int pp_env() {          // GANK_IGEMM_PP: 0 off, 1 32-wide patches of plain convs only, 2 (default) every form
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("GANK_IGEMM_PP"); v = e ? atoi(e) : 2; }
+  return v;
+}
+// One 512-thread block per CU: below ~a full round of blocks the 128-wide kernels (2-3 blocks per CU) fill the chip better
+// (16 x 16 images, n = 128: 128 blocks, 49.6 us against 43.9).
+static bool pp_enough_blocks(const IgemmArgs& a, int phases) {
+  const int pw = pp_patch_width(a.H, a.W);
+  return pw != 0 && (long)phases * a.N * (a.H / (256 / pw)) * (a.W / pw) * (a.Cout / 256) >= 224;
+}
+static bool pp_phase_ok(const IgemmArgs& a) {   // a.H, a.W = low-res grid
+  return pp_env() >= 2 && a.Cout % 256 == 0 && a.Cin % 32 == 0 && pp_enough_blocks(a, 4);
+}
+static int launch_pp_phase(const IgemmArgs& a, hipStream_t s) {
+  const bool relu = (a.flags & GANK_IN_RELU) != 0;
+  if (pp_patch_width(a.H, a.W) == 32) return relu ? launch_pp<5, 32>(a, s) : launch_pp<4, 32>(a, s);
+  return relu ? launch_pp<5, 16>(a, s) : launch_pp<4, 16>(a, s);
 }
 
 template <int MODE, int BN>
@@ -1280,13 +1350,14 @@ int gank_igemm_dispatch(IgemmArgs a, hipStream_t s) {
                          a.Kpad == a.taps * a.Cin && (long)a.CoutPad * a.Kpad * 2 < (1L << 30);
   const bool narrow_ok = !(a.flags & IG_RES_UP2X) && a.Cin == 3 && (a.ks == 1 || a.ks == 3) && a.pad == (a.ks - 1) / 2 && a.CoutPad % 128 == 0 && a.Cout % 4 == 0 &&
                          !(a.flags & (GANK_IN_UPSAMPLE2X | IG_IN_ZEROINS2X | IG_IN_STRIDE2)) && a.Hin == a.H && a.Win == a.W;
-  static int pp_env = -1;      // experiment knob: GANK_IGEMM_PP=1 enables the two-group LDS-DMA kernel
-  if (pp_env < 0) { const char* e = getenv("GANK_IGEMM_PP"); pp_env = e ? atoi(e) : 0; }
-  const bool pp_ok = pp_env && patch_geom && a.W % 32 == 0 && a.Cout % 256 == 0 && a.Kpad == a.taps * a.Cin;
+  const bool pp_ok = pp_env() && patch_geom && a.Cout % 256 == 0 && a.Kpad == a.taps * a.Cin && pp_enough_blocks(a, 1) &&
+                     (pp_env() >= 2 || pp_patch_width(a.H, a.W) == 32);
   if (narrow_ok) {
     rc = a.ks == 3 ? launch_narrow_in<3, 3>(a, s) : launch_narrow_in<1, 3>(a, s);
   } else if (pp_ok) {
-    rc = (a.flags & GANK_IN_RELU) ? launch_pp<1>(a, s) : launch_pp<0>(a, s);
+    const bool relu = (a.flags & GANK_IN_RELU) != 0;
+    if (pp_patch_width(a.H, a.W) == 32) rc = relu ? launch_pp<1, 32>(a, s) : launch_pp<0, 32>(a, s);
+    else rc = relu ? launch_pp<1, 16>(a, s) : launch_pp<0, 16>(a, s);
   } else if (patch2_ok) {
     rc = (a.flags & GANK_IN_RELU) ? launch_patch2<1>(a, s) : launch_patch2<0>(a, s);
   } else if (patch_ok) {
@@ -1373,7 +1444,8 @@ extern "C" int gank_upconv3x3_fprop(const void* x, const void* wph, const float*
   gank_prof_begin(0, 2.0 * a.M * 4.0 * (double)Cout * 4 * Cin, s, 2.0 * ((double)a.M * Cin + 16.0 * Cin * Cout + 4.0 * a.M * Cout));
   int rc;
   const long tiles128 = 4L * cdiv(a.M, 128) * (a.CoutPad / 128);
-  if (patch_phase_ok(a)) rc = launch_patch_phase<4>(a, s);
+  if (pp_phase_ok(a)) rc = launch_pp_phase(a, s);
+  else if (patch_phase_ok(a)) rc = launch_patch_phase<4>(a, s);
   else if (a.CoutPad % 128 == 0 && tiles128 >= 192) rc = launch_phase<2, 2, 2, 2, 2>(a, s);
   else if (a.CoutPad % 64 == 0) rc = launch_phase<2, 2, 1, 1, 4>(a, s);
   else rc = launch_phase<4, 1, 2, 1, 2>(a, s);
@@ -1426,7 +1498,8 @@ extern "C" int gank_convpool3x3_dgrad(const void* dy, const void* wphd, const vo
   gank_prof_begin(0, 2.0 * a.M * 4.0 * (double)Cin * 4 * Cout, s, 2.0 * ((double)a.M * Cout + 16.0 * Cin * Cout + 4.0 * a.M * Cin));
   int rc;
   const long tiles128 = 4L * cdiv(a.M, 128) * (a.CoutPad / 128);
-  if (patch_phase_ok(a)) rc = launch_patch_phase<4>(a, s);
+  if (pp_phase_ok(a)) rc = launch_pp_phase(a, s);
+  else if (patch_phase_ok(a)) rc = launch_patch_phase<4>(a, s);
   else if (a.CoutPad % 128 == 0 && tiles128 >= 192) rc = launch_phase<2, 2, 2, 2, 2>(a, s);
   else if (a.CoutPad % 64 == 0) rc = launch_phase<2, 2, 1, 1, 4>(a, s);
   else rc = launch_phase<4, 1, 2, 1, 2>(a, s);

@@ -13,12 +13,15 @@ dyp = torch.randn(n, h // 2, h // 2, cout, device="cuda").to(torch.bfloat16)
 wf, wd = K.prep_weights(w, True, True)
 if os.environ.get("MICRO_FRAG", "0") == "1":
     (wf, wd), = K.prep_weights_batched([w], want_d=True, kinds=[3])
+wup = K.upconv3x3_prep(w) if k == 3 and cin % 64 == 0 else None
 dw = torch.zeros_like(w)
 torch.cuda.synchronize()
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 def run():
     if which == "fprop":
         K.conv2d_fprop(x, wf, None, (h, h), cout, k)
+    elif which == "upfprop":      # phase-decomposed UpsampleConv 3x3: x low-res [n,h/2,h/2,cin] -> [n,h,h,cout]
+        K.upconv3x3_fprop(xh, wup[0], None, cout)
     elif which == "fprop_up":
         K.conv2d_fprop(xh, wf, None, (h, h), cout, k, K.IN_UPSAMPLE2X)
     elif which == "dgrad":
