@@ -703,3 +703,85 @@ def test_conv_random_and_non_square_shapes(K, n, h, w, cin, cout, k, relu):
     assert relerr(dx, dx_ref) < BF_TOL                        # gradient w.r.t. the (relu'd) conv operand
     assert relerr(dw, dw_ref) < F32_FROM_BF_TOL
     assert relerr(db, db_ref) < F32_FROM_BF_TOL
+
+
+# ---- two-group LDS-DMA patch kernel (conv_igemm_pp_kernel): taken only when a full round of 512-thread blocks exists, so
+# these cases are sized to >= 224 blocks of 256 pixels x 256 couts.
+@pytest.mark.parametrize("n,h,w_,cin,cout,opts", [
+    (56, 32, 32, 64, 256, "bias,res"),              # 8 x 32 patches (one-row pixel tiles)
+    (28, 32, 64, 64, 256, "relu,bias"),             # two patches per image row
+    (56, 32, 32, 128, 256, "tanh,scale"),           # 4 chunks of 32 channels
+    (224, 16, 16, 64, 256, "relu,res_up"),          # 16 x 16 patches (two-row pixel tiles), residual stored at half size
+    (112, 16, 16, 64, 512, ""),                     # two cout tiles
+])
+def test_conv3x3_two_group_kernel_fprop(K, n, h, w_, cin, cout, opts):
+    rng = np.random.default_rng(n + h + cin + cout)
+    x, xt = bf(rng.normal(size=(n, h, w_, cin)))
+    w, _ = bf(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin))
+    wt = torch.tensor(w, dtype=torch.float32).cuda()
+    wf, _ = K.prep_weights(wt, True, False)
+    b, bt = f32(rng.normal(size=cout)) if "bias" in opts else (0.0, None)
+    flags = (K.IN_RELU if "relu" in opts else 0) | (K.OUT_TANH if "tanh" in opts else 0)
+    scale = 0.5 if "scale" in opts else 1.0
+    res, rest = None, None
+    if "res_up" in opts:
+        res, rest = bf(rng.normal(size=(n, h // 2, w_ // 2, cout)))
+        flags |= K.RES_UPSAMPLE2X
+    elif "res" in opts:
+        res, rest = bf(rng.normal(size=(n, h, w_, cout)))
+    K.prof_reset()
+    K.prof_enable(True)
+    y = K.conv2d_fprop(xt, wf, bt, (h, w_), cout, 3, flags, scale, rest)
+    K.prof_enable(False)
+    K.prof_collect(0)
+    ran = [k[0] for k in K.prof_kernels(0)]
+    K.prof_reset()
+    assert any("conv_igemm_pp_kernel" in k for k in ran), ran      # the case really exercises the two-group kernel
+    ref = R.conv2d_same(R.relu(x) if "relu" in opts else x, w, np.zeros(cout)) * scale + b
+    if res is not None:
+        ref = ref + (R.upsample_nn2x(res) if "res_up" in opts else res)
+    if "tanh" in opts:
+        ref = np.tanh(ref)
+    torch.cuda.synchronize()
+    assert relerr(y, ref) < BF_TOL
+
+
+@pytest.mark.parametrize("n,h,cin,cout,mask", [(56, 32, 256, 64, True), (224, 16, 256, 64, False)])
+def test_conv3x3_two_group_kernel_dgrad(K, n, h, cin, cout, mask):
+    """Input gradient of a 3x3 conv = the same kernel over dy with the flipped filter; relu mask in its epilogue."""
+    rng = np.random.default_rng(n + h + cin)
+    x, xt = bf(rng.normal(size=(n, h, h, cin)))
+    w, _ = bf(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cout))
+    wt = torch.tensor(w, dtype=torch.float32).cuda()
+    _, wd = K.prep_weights(wt, False, True)
+    dy, dyt = bf(rng.normal(size=(n, h, h, cout)))
+    dx = K.conv2d_dgrad(dyt, wd, (h, h), cin, 3, 0, 1.0, None, xt if mask else None)
+    ref, _, _ = R.conv2d_same_grads(x, w, dy)
+    if mask:
+        ref = ref * (x > 0)
+    torch.cuda.synchronize()
+    assert relerr(dx, ref) < BF_TOL
+
+
+@pytest.mark.parametrize("n,hl,wl,cin,cout", [(56, 16, 16, 64, 256), (28, 8, 32, 64, 256), (28, 16, 16, 128, 512)])
+def test_two_group_kernel_phase_form(K, n, hl, wl, cin, cout):
+    """The four output phases of the stride-2 transposed convs on the two-group kernel: UpsampleConv 3x3 fprop over a
+    low-res grid, and the ConvMeanPool 3x3 input gradient (relu mask in the epilogue)."""
+    rng = np.random.default_rng(n + hl + cin)
+    x, xt = bf(rng.normal(size=(n, hl, wl, cin)))
+    w, _ = bf(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin))
+    b, bt = f32(rng.normal(size=cout))
+    res, rest = bf(rng.normal(size=(n, 2 * hl, 2 * wl, cout)))
+    wph, _ = K.upconv3x3_prep(torch.tensor(w, dtype=torch.float32).cuda())
+    y = K.upconv3x3_fprop(xt, wph, bt, cout, 0, rest)
+    torch.cuda.synchronize()
+    assert relerr(y, R.conv2d_same(R.upsample_nn2x(x), w, b) + res) < BF_TOL
+    # ConvMeanPool with cin2 = cout (a multiple of 256) input channels: dy [n,hl,wl,cin] -> dx [n,2hl,2wl,cout]
+    x2, x2t = bf(rng.normal(size=(n, 2 * hl, 2 * wl, cout)))
+    w2, _ = bf(rng.normal(size=(3, 3, cout, cin)) / np.sqrt(9 * cin))
+    _, wphd = K.convpool3x3_prep(torch.tensor(w2, dtype=torch.float32).cuda())
+    dy, dyt = bf(rng.normal(size=(n, hl, wl, cin)))
+    dx = K.convpool3x3_dgrad(dyt, wphd, cout, x2t)
+    dx_ref, _, _ = R.conv2d_same_grads(R.relu(x2), w2, R.meanpool2x2_grad(dy))
+    torch.cuda.synchronize()
+    assert relerr(dx, dx_ref * (x2 > 0)) < BF_TOL
