@@ -531,7 +531,7 @@ static int launch_wgrad_lean_mode(WgradArgs a, hipStream_t s) {
   a.tiles_ci = cdiv(a.Cin, CiT);
   a.tiles_co = cdiv(a.Cout, CoT);
   const int total_steps = a.M / 64;
-  const long tiles = (long)a.taps * a.tiles_ci * a.tiles_co;
+  const long tiles = (long)a.taps * a.tiles_ci * a.tiles_co * (a.nbatch > 0 ? a.nbatch : 1);   // grid.y layers fill the chip too
   static int target_env = -1, minsteps_env = -1;   // experiment knobs
   if (target_env < 0) { const char* e = getenv("GANK_WGRAD_SPLIT_TARGET"); target_env = e ? atoi(e) : 256; }
   if (minsteps_env < 0) { const char* e = getenv("GANK_WGRAD_MIN_STEPS"); minsteps_env = e ? atoi(e) : 8; }
@@ -550,7 +550,7 @@ static int launch_wgrad_lean_mode(WgradArgs a, hipStream_t s) {
     if (e != hipSuccess) return gank_set_error("conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  const long grid = tiles * a.splits;
+  const long grid = tiles / (a.nbatch > 0 ? a.nbatch : 1) * a.splits;
   GANK_REQUIRE(grid < (1L << 30), "conv_wgrad: grid too large");
   static char tag[96];
   if (!tag[0]) snprintf(tag, sizeof(tag), "conv_wgrad_lean_kernel<%d, %d, %d, %d, %d, %d>", WA, WB, TA, TB, PF, MODE);
