@@ -229,6 +229,7 @@ class SNGANTrainer:
         self.both_labels = torch.zeros(2 * b, dtype=torch.int32, device=self.device)
         self.feed_slot = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.feed_done = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._seed = {}
         self.d_loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.g_loss = torch.zeros(1, dtype=torch.float32, device=self.device)
 
@@ -317,7 +318,11 @@ class SNGANTrainer:
         Fn.set_wgrad_stream(self._side if self.side_stream else None)
         Fn.BATCH_SMALL_WGRADS = BATCH_SMALL_WGRADS
         try:
-            loss.backward()
+            # the gradient seed is a persistent tensor: loss.backward() alone launches a ones_like fill per update
+            seed = self._seed.get(loss.shape)
+            if seed is None:
+                seed = self._seed[loss.shape] = torch.ones_like(loss)
+            loss.backward(gradient=seed)
             Fn.join_wgrad()
         finally:
             Fn.BATCH_SMALL_WGRADS = False

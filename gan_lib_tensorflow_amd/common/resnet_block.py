@@ -30,6 +30,7 @@ DIM_D = 128
 COMMUTE_1X1 = True
 # the commuted 'up' shortcut stays at half resolution and is added, upsampled on the fly, in conv_2's epilogue
 FUSE_SHORTCUT_UPSAMPLE = True
+FUSE_IDENTITY_SHORTCUT_GRAD = True   # identity shortcut: its gradient is added by conv_1's input-gradient kernel
 
 
 def nonlinearity(x, activation_fn='relu', leakiness=0.2):
@@ -132,6 +133,10 @@ def ResidualBlock(inputs, input_dim, output_dim, filter_size, name,
     x_short, x_main = Fn.fork(inputs)
     if output_dim == input_dim and resample is None:
         shortcut = x_short  # Identity skip-connection
+        if FUSE_IDENTITY_SHORTCUT_GRAD and _normalize_kind(name + '.N1', labels) is None and x_short is not x_main:
+            link = Fn.ShortcutLink()          # dy of the block rides on conv_1's input-gradient epilogue
+            x_short._grad_link = link
+            x_main._add_link = link
     else:
         shortcut = conv_shortcut(inputs=x_short, output_dim=output_dim, filter_size=1, name=name + '.Shortcut',
                                  spectral_normed=spectral_normed, update_collection=update_collection,

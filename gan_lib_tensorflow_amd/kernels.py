@@ -290,7 +290,7 @@ class SnBatch:
         self.v = torch.empty(tot(lambda k, c: k), dtype=F32, device=dev)
         self.a = torch.empty_like(self.v)
         self.b = torch.empty_like(self.u_out)
-        self.scal = torch.zeros(self.n * 8, dtype=F32, device=dev)
+        self.scal = torch.empty(self.n * 8, dtype=F32, device=dev)     # every entry is plainly written before it is read
         self.bpart = torch.empty(tot(lambda k, c: ((k + 63) // 64) * c), dtype=F32, device=dev)
         self.rowdot = torch.empty_like(self.v)
         self.ga = torch.empty_like(self.v)
