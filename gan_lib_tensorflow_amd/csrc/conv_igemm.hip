@@ -1084,7 +1084,10 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
       if (c >= nch) { c = nch - 1; t = NT - 1; }
     }
   }
-  pp_wait_vmcnt<6>();                                  // step 0 and the halo have landed; steps 1-3 stay in flight
+  // Steps 0 AND 1 (and the halo) must have landed here: group 0 reads step 1 right after barrier 0, and group 1's first
+  // in-loop wait comes after that barrier ("group 1's wait in phase q-2" is this one for q = 1).  Steps 2-3 stay in flight.
+  // (A vmcnt(6) here passed every parity test and failed the run-to-run identity screen in 1-30 % of the launches.)
+  pp_wait_vmcnt<4>();
   __builtin_amdgcn_s_barrier();
 
   int rslot = 0, wslot = PP_PD * PP_WSLOT_BYTES;

@@ -785,3 +785,31 @@ def test_two_group_kernel_phase_form(K, n, hl, wl, cin, cout):
     dx_ref, _, _ = R.conv2d_same_grads(R.relu(x2), w2, R.meanpool2x2_grad(dy))
     torch.cuda.synchronize()
     assert relerr(dx, dx_ref * (x2 > 0)) < BF_TOL
+
+
+@pytest.mark.parametrize("form,n,h,w_,cin,cout", [("plain", 320, 32, 32, 64, 512), ("plain", 320, 16, 16, 256, 256), ("phase", 128, 16, 16, 256, 256)])
+def test_two_group_kernel_race_screen(K, form, n, h, w_, cin, cout):
+    """The two-group kernel has no atomics: every repetition over the same operands must be BIT-identical to the first.
+    A staged LDS buffer read before its DMA landed shows up as a differing tile (a prologue wait that left K-step 1 in
+    flight passed every parity test above and failed this screen in 1-30 % of the launches).  A second stream streams
+    HBM beside the kernel to perturb DMA latency."""
+    g = torch.Generator(device="cpu").manual_seed(n + cin)
+    x = torch.randn((n, h, w_, cin), generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn((3, 3, cin, cout), generator=g) / (9 * cin) ** 0.5).cuda()
+    if form == "plain":
+        wf, _ = K.prep_weights(w, True, False)
+        run = lambda: K.conv2d_fprop(x, wf, None, (h, w_), cout, 3)     # noqa: E731
+    else:
+        wph, _ = K.upconv3x3_prep(w)
+        run = lambda: K.upconv3x3_fprop(x, wph, None, cout)              # noqa: E731
+    side, junk = torch.cuda.Stream(), torch.randn(32 << 20, device="cuda")
+    ref = run().clone()
+    torch.cuda.synchronize()
+    differing = 0
+    for rep in range(120):
+        if rep % 3 == 0:
+            with torch.cuda.stream(side):
+                junk.mul_(1.0001)
+        differing += 0 if torch.equal(run(), ref) else 1
+    torch.cuda.synchronize()
+    assert differing == 0
