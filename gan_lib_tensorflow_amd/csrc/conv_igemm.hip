@@ -7,9 +7,11 @@
 //   4 consecutive output channels of ONE pixel per accumulator quad -> 8-byte NHWC stores.
 //   * K-step = 64 (one tap x 64 input channels on the fast path); LDS rows are 64 bf16 + 8 pad
 //     = 144 B, which makes every ds_read_b128 lane group hit 16 distinct 4-bank slots.
-//   * global -> register -> LDS staging (not LDS-DMA): the staging pass is where zero padding,
+//   * generic and LDS-patch kernels: global -> register -> LDS staging: the staging pass is where zero padding,
 //     nearest-neighbour upsample, zero insertion, stride and the pre-activation relu are applied,
-//     so none of those tensors is ever materialised in HBM.
+//     so none of those tensors is ever materialised in HBM;
+//   * two-group kernel (conv_igemm_pp_kernel, the large 256-channel layers): both operands by LDS-DMA
+//     (buffer_load ... lds), 64-B swizzled rows, one block per CU -- its own header below.
 // Replaces tf.nn.conv2d / Conv2DBackpropInput at common/ops/conv2d.py:180-187 and the
 // surrounding block-library glue (SNGAN/gan_cifar_resnet.py:112-153,186,198,209,261).
 #include "gank_common.h"
