@@ -81,3 +81,38 @@ def test_synthetic_feed_shapes():
     it = S.synthetic_batches(4, "cpu", seed=0)
     d, l = next(it)
     assert d.shape == (4, 3072) and d.dtype == torch.uint8 and l.dtype == torch.int32 and int(l.max()) <= 9
+
+
+def test_sampling_quantisation_and_inception_score_statistics():
+    """Host side of the sampling / IS harness (gan_cifar_resnet.py:536-551, inception_score.py:59-90): known answers."""
+    from gan_lib_tensorflow_amd.common.inception.inception_score import quantize_samples, preds2score, get_inception_score
+    x = np.array([-1.0, -0.5, 0.0, 0.999, 1.0], np.float32)
+    np.testing.assert_array_equal(quantize_samples(x), [0, 63, 127, 254, 255])                 # (x+1)*127.5, truncated
+    np.testing.assert_array_equal(quantize_samples(x, for_score=True), [0, 63, 127, 255, 255])  # (x+1)*127.995
+    # every sample predicts the marginal: KL = 0 -> score 1, std 0
+    uni = np.full((100, 10), 0.1)
+    m, s = preds2score(uni, 10)
+    assert abs(m - 1.0) < 1e-12 and s < 1e-12
+    # confident and evenly spread over K classes inside every split: score -> K
+    K_, eps = 5, 1e-9
+    p = np.full((100, K_), eps)
+    p[np.arange(100), np.arange(100) % K_] = 1.0 - (K_ - 1) * eps
+    m, s = preds2score(p, 10)
+    assert abs(m - K_) < 1e-5 and s < 1e-9
+    # against an independent entropy formulation: exp(H(marginal) - mean H(p(y|x)))
+    rng = np.random.default_rng(0)
+    q = rng.dirichlet(np.ones(7), size=60)
+    H = lambda r: -(r * np.log(r)).sum(-1)            # noqa: E731
+    want = [np.exp(H(q[i * 20:(i + 1) * 20].mean(0)) - H(q[i * 20:(i + 1) * 20]).mean()) for i in range(3)]
+    m, s = preds2score(q, 3)
+    assert abs(m - np.mean(want)) < 1e-12 and abs(s - np.std(want)) < 1e-12
+    # the classifier is a parameter (no Inception weights here): pixel-valued input is mapped to [-1,1], whole batches only
+    seen = []
+    def clf(b):
+        seen.append((b.min(), b.max(), b.shape))
+        return np.tile(np.arange(1008, dtype=np.float64) * 0.0, (b.shape[0], 1))
+    imgs = rng.integers(0, 256, (130, 4, 4, 3))
+    m, s = get_inception_score(imgs, splits=2, classifier=clf, batch_size=64)
+    assert len(seen) == 2 and all(lo >= -1 and hi <= 1 and sh == (64, 4, 4, 3) for lo, hi, sh in seen) and abs(m - 1.0) < 1e-12
+    with pytest.raises(NotImplementedError):
+        get_inception_score(imgs)

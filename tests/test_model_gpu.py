@@ -215,6 +215,25 @@ def test_sampling_path(gpu):
     assert img.shape == (100, 3072) and float(img.abs().max()) <= 1.0
 
 
+def test_fixed_noise_samples_batch_100_vs_oracle(gpu):
+    """The sample grid of gan_cifar_resnet.py:530-538: Generator(100, [0..9]*10, noise=fixed_noise) -- a batch that is
+    neither a power of two nor a multiple of 64 through every kernel, conditional-batch-norm statistics over the 100
+    samples -- against the float64 oracle, and its host-side quantisation."""
+    from gan_lib_tensorflow_amd.common.inception.inception_score import quantize_samples
+    S, tr, state = make_trainer(11, 4)
+    rng = np.random.default_rng(100)
+    z = bf16r(rng.normal(size=(100, 128)))
+    labels = torch.tensor([0, 1, 2, 3, 4, 5, 6, 7, 8, 9] * 10, dtype=torch.int32)
+    img = tr.sample(100, labels=labels.cuda(), noise=z.cuda())
+    ref = T.generator(T.to_torch(state), z.to(torch.float64), labels.long(), groups=1).detach()
+    diff = (img.to(torch.float64).cpu() - ref).abs()
+    # same bounds as the 4-sample golden case above: bf16 storage between 20 layers, fp32 statistics
+    assert diff.max().item() < 0.08 and diff.mean().item() < 0.008, (diff.max().item(), diff.mean().item())
+    q, qr = quantize_samples(img.float().cpu().numpy()), quantize_samples(ref.numpy())
+    assert q.dtype == np.int32 and q.min() >= 0 and q.max() <= 255
+    assert np.abs(q - qr).mean() < 1.0                      # under one grey level on average
+
+
 def test_graph_replay_stays_finite_with_poisoned_workspaces(gpu, monkeypatch):
     """Every captured update must fully define what it reads: with every torch.empty buffer pre-filled with NaN,
     several trainers replaying their hipGraphs keep finite parameters (regression: a hipMemsetAsync memset NODE
