@@ -111,6 +111,10 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run "
             "`python -m gan_lib_tensorflow_amd.build` (needs hipcc). There is no CPU fallback.")
+    # libgank.so must bind to the HIP runtime that torch ships (torch/lib/libamdhip64.so), not to a second copy from
+    # /opt/rocm: with two runtimes in one process the second one sees no device ("no ROCm-capable device is detected" on
+    # the first launch).  Importing torch first makes its runtime the one the loader reuses for our DT_NEEDED entry.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, args in PROTOTYPES.items():
         try:
