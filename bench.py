@@ -31,13 +31,29 @@ PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.m
 GFLOP_PER_REAL_IMAGE = 13.77   # 4406.0 GFLOP per iteration / 320 real images
 
 
+def host_cores():
+    """Physical cores this process may run on: the box's share of the host (scheduler affinity / cgroup), not the
+    machine's total; hyper-thread siblings count once."""
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = os.cpu_count() or 1
+    try:
+        import psutil
+        phys, logical = psutil.cpu_count(logical=False) or allowed, psutil.cpu_count(logical=True) or allowed
+        if logical > phys:                      # SMT: the affinity mask counts logical CPUs
+            allowed = max(1, allowed * phys // logical)
+    except Exception:  # noqa: BLE001
+        pass
+    return max(1, allowed)
+
+
 def cpu_baseline(budget_s=40.0):
     """Oracle ("port") leg: torch-CPU fp32 restatement of the reference graph; the timed sample is one whole
     iteration (5 D updates + 1 G update), at batch 64 when that fits budget_s, else at a smaller batch scaled up."""
     import numpy as np
     from oracle import ref_torch as T
-    # a one-GPU box owns a 16-core share of the host (more threads than that only oversubscribe)
-    cores = min(16, os.cpu_count() or 1)
+    cores = host_cores()
     torch.set_num_threads(cores)
     P = T.to_torch(T.init_sngan_params(0), dtype=torch.float32)
     tr = T.Trainer(P)
@@ -82,8 +98,8 @@ def cpu_baseline(budget_s=40.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)     # ~1 s timed: long enough for clocks to settle
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--strong", action="store_true",
@@ -95,8 +111,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+                         " (one rank per GPU)")
     if local_rank >= torch.cuda.device_count():     # rehearsal of the N > 1 path on fewer GPUs than ranks (gloo only)
         assert args.backend != "nccl", "RCCL needs one GPU per rank"
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
@@ -121,13 +137,25 @@ def main():
     warm = max(args.warmup, 2)    # iterations 0 and 1 run eagerly and capture the D and G graphs
     for _ in range(warm):
         tr.train_iteration(feed)
+    if not args.no_graphs and not tr.use_graphs:
+        # capture fell back to eager execution during warm-up: a line that says "graphs" must not describe eager runs
+        print("[bench] hipGraph capture failed during warm-up; refusing to report an eager run as a graph run "
+              "(use --no-graphs to measure eager execution)", file=sys.stderr, flush=True)
+        sys.exit(3)
     barrier()
+    # per-step HIP events on the launch stream (graph replays and eager kernels both go to torch's current stream)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    ev[0].record()
+    for i in range(args.steps):
         tr.train_iteration(feed)
+        ev[i + 1].record()
     torch.cuda.synchronize()
     t_local = time.perf_counter() - t0
     barrier()
+    step_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2]
+    graphs_used = bool(tr.use_graphs)
     t = torch.tensor([t_local], dtype=torch.float64, device=device)
     if world > 1:
         import torch.distributed as dist
@@ -169,12 +197,13 @@ def main():
         # HBM traffic per launch: rocprofv3 PMC passes cannot run inside this process; the committed measurement of
         # scratch/pmc_bench_traffic.sh over this same workload is reported when it covers the dominant kernel
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath):
+        import glob
+        for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):   # latest round first
             tj = json.load(open(tpath))
             per = tj.get("per_kernel", {}).get(dom)
             if per is not None:
-                traffic, traffic_src = round(per["bytes_per_launch"]), "profiles/r01_traffic.json (" + tj["method"] + ")"
+                traffic, traffic_src = round(per["bytes_per_launch"]), f"profiles/{os.path.basename(tpath)} (" + tj["method"] + ")"
+                break
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
@@ -189,18 +218,21 @@ def main():
                                      "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else 0.0} for k, v in fam.items()},
                     "kernels": [{"kernel": t[0], "launches": t[1], "ms": round(t[2], 3),
                                  "tflops": round(t[3] / (t[2] * 1e-3) / 1e12, 1) if t[2] > 0 else 0.0} for t in kernels[:8]]}
-        tr.use_graphs = not args.no_graphs
+    tr.use_graphs = graphs_used            # every rank (the eager roofline pass above switched it off)
 
     if rank == 0:
         images = 5.0 * per_gpu * world * args.steps
         value = images / elapsed
         out = {
+            # images = real images through the critic: 5 critic batches of 64 per step (and per GPU)
             "metric": "images/sec (G+D step) SNGAN-ResNet CIFAR-10 bs=64", "value": round(value, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": warm, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "median_ms_per_step_hip_events": round(median_ms, 3), "min_ms_per_step_hip_events": round(step_ms[0], 3),
             "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "SNGAN ResNet CIFAR-10 32x32 bs=64 hinge: 1 G update (2x64 fakes) + 5 D updates (64 real + 64 fake) per step",
                        "global_batch": per_gpu * world, "per_gpu_batch": per_gpu, "parallelism": f"dp{world}",
-                       "graphs": not args.no_graphs, "finite": finite},
+                       "images_per_step": "5 critic batches x 64 real images per GPU",
+                       "graphs": graphs_used, "finite": finite},
             # reference algorithm (9-tap upsample convs, SURVEY 8d: 13.77 GFLOP per real image) and the algorithm as run
             # (UpsampleConv 3x3 as a 4-tap-per-output transposed conv; conv FLOPs counted by the kernels themselves)
             "whole_step_mfma_frac": round(value / world * GFLOP_PER_REAL_IMAGE * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),

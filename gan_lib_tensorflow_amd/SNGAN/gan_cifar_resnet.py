@@ -236,9 +236,48 @@ class SNGANTrainer:
     def _refresh_g_prep(self):
         K.prep_weights_batched([v for _, v in self._g_convs], want_d=True, kinds=[_g_prep_kind(k, v) for k, v in self._g_convs])
 
+    # ---- checkpoint (tf.train.Saver of the reference, :585-590: variables, Adam slots, beta powers) ------------
+    def state_dict(self):
+        """Everything a resumed run needs to continue the SAME trajectory: the named variables (TF names), the Adam
+        slots as `<var>/Adam` (m) and `<var>/Adam_1` (v) -- the names tf.train.AdamOptimizer gives them --, the two
+        optimisers' step counts (TF stores them as beta1_power / beta2_power; `<net>/adam_t` here, from which the
+        powers follow), the iteration counter that drives the LR decay (:454-459), and the device RNG state."""
+        sd = self.store.state_dict()
+        for net, flat, opt in (('Generator', self.g_flat, self.g_opt), ('Discriminator', self.d_flat, self.d_opt)):
+            m, v = flat['m'].detach().cpu().numpy(), flat['v'].detach().cpu().numpy()
+            for k in flat['names']:
+                o, n = flat['offsets'][k], self.store.vars[k].numel()
+                shape = tuple(self.store.vars[k].shape)
+                sd[k + '/Adam'] = m[o:o + n].reshape(shape).copy()
+                sd[k + '/Adam_1'] = v[o:o + n].reshape(shape).copy()
+            sd[net + '/adam_t'] = np.asarray(int(opt.t.item()), dtype=np.int64)
+        sd['_iteration'] = np.asarray(int(self.iteration), dtype=np.int64)
+        sd['_rng_state'] = self.rng_state.detach().cpu().numpy().copy()
+        return sd
+
     def load_state_dict(self, state, strict=True):
-        """Restore variables by name; cached operand copies and captured graphs are rebuilt."""
+        """Restore variables by name; optimiser slots / step counts / iteration / RNG state are restored when the
+        checkpoint carries them and RESET otherwise (a weights-only checkpoint restarts Adam's bias correction, as a
+        fresh tf.train.AdamOptimizer would).  Cached operand copies and captured graphs are rebuilt."""
+        state = dict(state)
+        extra = {k: state.pop(k) for k in list(state) if k.endswith(('/Adam', '/Adam_1', '/adam_t')) or k in ('_iteration', '_rng_state')}
         self.store.load_state_dict(state, strict)
+        with torch.no_grad():
+            for net, flat, opt in (('Generator', self.g_flat, self.g_opt), ('Discriminator', self.d_flat, self.d_opt)):
+                flat['m'].zero_()
+                flat['v'].zero_()
+                for k in flat['names']:
+                    o, n = flat['offsets'][k], self.store.vars[k].numel()
+                    for suffix, buf in (('/Adam', flat['m']), ('/Adam_1', flat['v'])):
+                        val = extra.get(k + suffix)
+                        if val is not None:
+                            buf[o:o + n].copy_(torch.from_numpy(np.asarray(val, np.float32).reshape(-1)).to(self.device))
+                opt.t.fill_(int(extra.get(net + '/adam_t', 0)))
+            self.iteration = int(extra.get('_iteration', 0))
+            self.iteration_dev.fill_(self.iteration)
+            if '_rng_state' in extra:
+                self.rng_state.copy_(torch.from_numpy(np.asarray(extra['_rng_state'], np.int64)).to(self.device))
+            self.feed_slot.zero_()
         self._refresh_g_prep()
         self._graphs.clear()
 
@@ -315,16 +354,15 @@ class SNGANTrainer:
 
     def _backward(self, loss):
         """loss.backward() with the filter gradients on the side stream, joined before anything reads them."""
+        Fn.reset_deferred()
         Fn.set_wgrad_stream(self._side if self.side_stream else None)
         Fn.BATCH_SMALL_WGRADS = BATCH_SMALL_WGRADS
         try:
             # the gradient seed is a persistent tensor: loss.backward() alone launches a ones_like fill per update
-            seed = self._seed.get(loss.shape)
-            if seed is None:
-                seed = self._seed[loss.shape] = torch.ones_like(loss)
-            loss.backward(gradient=seed)
+            loss.backward(gradient=Fn.unit_seed(loss))
             Fn.join_wgrad()
         finally:
+            Fn.reset_deferred()      # empty after a clean join; after an exception: nothing stale survives
             Fn.BATCH_SMALL_WGRADS = False
             Fn.set_wgrad_stream(None)
 

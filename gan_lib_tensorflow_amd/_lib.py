@@ -80,9 +80,10 @@ PROTOTYPES = {
     "gank_concat_tile_bwd": [P, P, P, I, I, I, I, P],
     "gank_embedding_fwd": [P, P, P, I, I, I, P],
     "gank_embedding_bwd": [P, P, P, I, I, I, P],
-    "gank_hinge_d_loss": [P, P, P, I, I, P],
-    "gank_hinge_g_loss": [P, P, P, I, P],
-    "gank_softmax_xent": [P, P, P, P, I, I, P],
+    "gank_hinge_d_loss": [P, P, P, P, I, I, P],
+    "gank_hinge_g_loss": [P, P, P, P, I, P],
+    "gank_softmax_xent": [P, P, P, P, P, I, I, P],
+    "gank_loss_grad_scale": [P, P, P, L, P],
     "gank_adam_tf": [P, P, P, P, P, P, P, L, P],
     "gank_counter_add": [P, C.c_int64, P],
     "gank_preprocess_real": [P, P, P, I, P],

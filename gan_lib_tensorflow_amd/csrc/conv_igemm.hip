@@ -770,15 +770,9 @@ static int launch_patch_phase(const IgemmArgs& a0, hipStream_t s) {
   a.tiles_n = a.CoutPad / 128;
   const size_t lds = ((size_t)10 * HROWP + (size_t)2 * 128 * LROW) * sizeof(bf16);
   auto kern = conv_igemm_patch_kernel<MODE, 128>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return gank_set_error("conv_igemm_patch: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
-  static char tag[64];
-  if (!tag[0]) snprintf(tag, sizeof(tag), "conv_igemm_patch_kernel<%d, 128>", MODE);
-  gank_prof_tag(0, tag);
+  GANK_MAX_DYNAMIC_LDS(kern, (int)lds, "conv_igemm_patch");
+  static const std::string tag = gank_format("conv_igemm_patch_kernel<%d, 128>", MODE);     // magic static: built once, thread-safe
+  gank_prof_tag(0, tag.c_str());
   hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
   GANK_LAUNCH_OK("conv_igemm_patch_phase");
   return 0;
@@ -796,15 +790,9 @@ static int launch_patch2(const IgemmArgs& a0, hipStream_t s) {
   a.tiles_n = a.CoutPad / 128;
   const size_t lds = (size_t)2 * 18 * HROWP * sizeof(bf16);
   auto kern = conv_igemm_patch2_kernel<MODE>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return gank_set_error("conv_igemm_patch2: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
-  static char tag[64];
-  if (!tag[0]) snprintf(tag, sizeof(tag), "conv_igemm_patch2_kernel<%d>", MODE);
-  gank_prof_tag(0, tag);
+  GANK_MAX_DYNAMIC_LDS(kern, (int)lds, "conv_igemm_patch2");
+  static const std::string tag = gank_format("conv_igemm_patch2_kernel<%d>", MODE);     // magic static: built once, thread-safe
+  gank_prof_tag(0, tag.c_str());
   hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
   GANK_LAUNCH_OK("conv_igemm_patch2");
   return 0;
@@ -931,9 +919,8 @@ static int launch_narrow_in(const IgemmArgs& a0, hipStream_t s) {
   IgemmArgs a = a0;
   a.tiles_m = cdiv(a.M, 128);
   a.tiles_n = a.CoutPad / 128;
-  static char tag[64];
-  if (!tag[0]) snprintf(tag, sizeof(tag), "conv_narrow_in_kernel<%d, %d>", KS, CIN);
-  gank_prof_tag(0, tag);
+  static const std::string tag = gank_format("conv_narrow_in_kernel<%d, %d>", KS, CIN);     // magic static: built once, thread-safe
+  gank_prof_tag(0, tag.c_str());
   hipLaunchKernelGGL((conv_narrow_in_kernel<KS, CIN>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
   GANK_LAUNCH_OK("conv_narrow_in");
   return 0;
@@ -1206,15 +1193,9 @@ static int launch_pp(const IgemmArgs& a0, hipStream_t s) {
   a.tiles_n = a.Cout / 256;
   if (PHASE) { a.Kpad = 4 * a.Cin; a.Hin = a.H; a.Win = a.W; }
   auto kern = conv_igemm_pp_kernel<MODE, PW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-    if (e != hipSuccess) return gank_set_error("conv_igemm_pp: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
-  static char tag[64];
-  if (!tag[0]) snprintf(tag, sizeof(tag), "conv_igemm_pp_kernel<%d, %d>", MODE, PW);
-  gank_prof_tag(0, tag);
+  GANK_MAX_DYNAMIC_LDS(kern, PP_LDS_BYTES, "conv_igemm_pp");
+  static const std::string tag = gank_format("conv_igemm_pp_kernel<%d, %d>", MODE, PW);     // magic static: built once, thread-safe
+  gank_prof_tag(0, tag.c_str());
   hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(512), PP_LDS_BYTES, s, a);
   GANK_LAUNCH_OK("conv_igemm_pp");
   return 0;
@@ -1248,15 +1229,9 @@ static int launch_patch(const IgemmArgs& a0, hipStream_t s) {
   a.tiles_n = a.CoutPad / BN;
   const size_t lds = ((size_t)10 * HROWP + (size_t)2 * BN * LROW) * sizeof(bf16);
   auto kern = conv_igemm_patch_kernel<MODE, BN>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return gank_set_error("conv_igemm_patch: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
-  static char tag[64];
-  if (!tag[0]) snprintf(tag, sizeof(tag), "conv_igemm_patch_kernel<%d, %d>", MODE, BN);
-  gank_prof_tag(0, tag);
+  GANK_MAX_DYNAMIC_LDS(kern, (int)lds, "conv_igemm_patch");
+  static const std::string tag = gank_format("conv_igemm_patch_kernel<%d, %d>", MODE, BN);     // magic static: built once, thread-safe
+  gank_prof_tag(0, tag.c_str());
   hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
   GANK_LAUNCH_OK("conv_igemm_patch");
   return 0;
@@ -1270,15 +1245,9 @@ static int launch_cfg(const IgemmArgs& a0, hipStream_t s) {
   a.tiles_n = a.CoutPad / BN;
   const size_t lds = (size_t)2 * (BM + BN) * LROW * sizeof(bf16);
   auto kern = conv_igemm_kernel<WM, WN, TM, TN, PACKED, PF, MODE>;
-  static bool attr_set = false;  // benign race: idempotent
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return gank_set_error("conv_igemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
-  static char tag[96];
-  if (!tag[0]) snprintf(tag, sizeof(tag), "conv_igemm_kernel<%d, %d, %d, %d, %s, %d, %d>", WM, WN, TM, TN, PACKED ? "true" : "false", PF, MODE);
-  gank_prof_tag(0, tag);
+  GANK_MAX_DYNAMIC_LDS(kern, (int)lds, "conv_igemm");
+  static const std::string tag = gank_format("conv_igemm_kernel<%d, %d, %d, %d, %s, %d, %d>", WM, WN, TM, TN, PACKED ? "true" : "false", PF, MODE);     // magic static: built once, thread-safe
+  gank_prof_tag(0, tag.c_str());
   hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(WM * WN * 64), lds, s, a);
   GANK_LAUNCH_OK("conv_igemm");
   return 0;
@@ -1293,15 +1262,9 @@ static int launch_phase(const IgemmArgs& a0, hipStream_t s) {
   a.tiles_n = a.CoutPad / BN;
   const size_t lds = (size_t)2 * (BM + BN) * LROW * sizeof(bf16);
   auto kern = conv_igemm_kernel<WM, WN, TM, TN, false, PF, 4>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return gank_set_error("conv_igemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
-  static char tag[96];
-  if (!tag[0]) snprintf(tag, sizeof(tag), "conv_igemm_kernel<%d, %d, %d, %d, false, %d, 4>", WM, WN, TM, TN, PF);
-  gank_prof_tag(0, tag);
+  GANK_MAX_DYNAMIC_LDS(kern, (int)lds, "conv_igemm");
+  static const std::string tag = gank_format("conv_igemm_kernel<%d, %d, %d, %d, false, %d, 4>", WM, WN, TM, TN, PF);     // magic static: built once, thread-safe
+  gank_prof_tag(0, tag.c_str());
   hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(WM * WN * 64), lds, s, a);
   GANK_LAUNCH_OK("conv_igemm_phase");
   return 0;

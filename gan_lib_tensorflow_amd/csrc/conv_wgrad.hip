@@ -544,17 +544,11 @@ static int launch_wgrad_lean_mode(WgradArgs a, hipStream_t s) {
   const size_t red = (size_t)WA * WB * 64 * (64 * CoT / 8 / (WA * WB * 64)) * 8 * sizeof(float);
   if (red > lds) lds = red;
   auto kern = conv_wgrad_lean_kernel<WA, WB, TA, TB, PF, MODE>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return gank_set_error("conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  GANK_MAX_DYNAMIC_LDS(kern, (int)lds, "conv_wgrad");
   const long grid = tiles / (a.nbatch > 0 ? a.nbatch : 1) * a.splits;
   GANK_REQUIRE(grid < (1L << 30), "conv_wgrad: grid too large");
-  static char tag[96];
-  if (!tag[0]) snprintf(tag, sizeof(tag), "conv_wgrad_lean_kernel<%d, %d, %d, %d, %d, %d>", WA, WB, TA, TB, PF, MODE);
-  gank_prof_tag(1, tag);
+  static const std::string tag = gank_format("conv_wgrad_lean_kernel<%d, %d, %d, %d, %d, %d>", WA, WB, TA, TB, PF, MODE);     // magic static: built once, thread-safe
+  gank_prof_tag(1, tag.c_str());
   hipLaunchKernelGGL(kern, dim3((unsigned)grid, a.nbatch > 0 ? a.nbatch : 1), dim3(WA * WB * 64), lds, s, a);
   GANK_LAUNCH_OK("conv_wgrad_lean");
   return 0;
@@ -999,9 +993,8 @@ static int launch_wgrad_taps_mode(WgradArgs a, hipStream_t s) {
   static int tpf = -1;
   if (tpf < 0) { const char* e = getenv("GANK_WGRAD_TAPS_PF"); tpf = e ? atoi(e) : 2; }
   auto kern = tpf == 1 ? conv_wgrad_taps_kernel<MODE, 1> : conv_wgrad_taps_kernel<MODE, 2>;
-  static char tag[64];
-  if (!tag[0]) snprintf(tag, sizeof(tag), "conv_wgrad_taps_kernel<%d, 2> + wgrad_reduce_slabs_kernel", MODE);
-  gank_prof_tag(1, tag);
+  static const std::string tag = gank_format("conv_wgrad_taps_kernel<%d, 2> + wgrad_reduce_slabs_kernel", MODE);     // magic static: built once, thread-safe
+  gank_prof_tag(1, tag.c_str());
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_ci * a.tiles_co * a.splits)), dim3(256), lds, s, a);
   GANK_LAUNCH_OK("conv_wgrad_taps");
   if (a.ws) {
@@ -1041,17 +1034,11 @@ static int launch_wgrad(WgradArgs a, hipStream_t s) {
   a.splits = cdiv(total_steps, a.steps_per_split);
   const size_t lds = (size_t)2 * (CiT / 32 + CoT / 32) * 2048 * sizeof(bf16);
   auto kern = conv_wgrad_kernel<WA, WB, TA, TB, FAST, PF>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return gank_set_error("conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  GANK_MAX_DYNAMIC_LDS(kern, (int)lds, "conv_wgrad");
   const long grid = tiles * a.splits;
   GANK_REQUIRE(grid < (1L << 30), "conv_wgrad: grid too large");
-  static char tag[96];
-  if (!tag[0]) snprintf(tag, sizeof(tag), "conv_wgrad_kernel<%d, %d, %d, %d, %s, %d>", WA, WB, TA, TB, FAST ? "true" : "false", PF);
-  gank_prof_tag(1, tag);
+  static const std::string tag = gank_format("conv_wgrad_kernel<%d, %d, %d, %d, %s, %d>", WA, WB, TA, TB, FAST ? "true" : "false", PF);     // magic static: built once, thread-safe
+  gank_prof_tag(1, tag.c_str());
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WA * WB * 64), lds, s, a);
   GANK_LAUNCH_OK("conv_wgrad");
   return 0;

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
+#include <string>
 
 #include "../../include/gank.h"
 
@@ -32,6 +34,32 @@ int gank_set_error(const char* fmt, ...);
     if (e__ != hipSuccess && e__ != hipErrorNotReady)                                      \
       return gank_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));        \
   } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): the attribute is per device, so a
+// process that drives a second GPU must set it there too (a process-wide flag left the 144 KB kernels unlaunchable
+// on every device but the first).
+#define GANK_MAX_DYNAMIC_LDS(kern, bytes, name)                                                               \
+  do {                                                                                                        \
+    static std::atomic<unsigned long long> done__{0};          /* bit d = set on device d (d < 64) */         \
+    int dev__ = 0;                                                                                            \
+    (void)hipGetDevice(&dev__);                                                                               \
+    const unsigned long long bit__ = 1ull << (dev__ & 63);                                                    \
+    if (!(done__.load(std::memory_order_relaxed) & bit__)) {                                                  \
+      hipError_t e__ = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes));         \
+      if (e__ != hipSuccess) return gank_set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e__)); \
+      done__.fetch_or(bit__, std::memory_order_relaxed);                                                      \
+    }                                                                                                         \
+  } while (0)
+
+static inline std::string gank_format(const char* fmt, ...) {
+  char buf[160];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  return std::string(buf);
+}
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline int roundup(int a, int b) { return (a + b - 1) / b * b; }

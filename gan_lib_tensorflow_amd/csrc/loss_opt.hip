@@ -4,39 +4,46 @@
 // ------------------------------------------------------------------------------------------------
 // hinge / softmax-xent losses: loss value + d loss / d logits in one single-block launch
 // ------------------------------------------------------------------------------------------------
-__global__ void hinge_d_kernel(const bf16* __restrict__ l, float* __restrict__ loss, bf16* __restrict__ dl, int n, int n_real) {
+// Every loss kernel writes d loss / d logits twice: bf16 (`dl`, what the backward pass of the layer below consumes when
+// the loss itself is differentiated, upstream gradient 1) and fp32 (`dl32`, optional: the exact values, scaled by the
+// upstream gradient and rounded ONCE by gank_loss_grad_scale when the loss enters a weighted sum).
+__global__ void hinge_d_kernel(const bf16* __restrict__ l, float* __restrict__ loss, bf16* __restrict__ dl, float* __restrict__ dl32, int n, int n_real) {
   __shared__ float red[16];
   const int n_fake = n - n_real;
   float acc = 0.f;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const float v = bf2f(l[i]);
+    float d;
     if (i < n_real) {  // mean(relu(1 - real))   gan_cifar_resnet.py:379
       const float t = 1.f - v;
       acc += fmaxf(t, 0.f) / (float)n_real;
-      dl[i] = f2bf(t > 0.f ? -1.f / (float)n_real : 0.f);
+      d = t > 0.f ? -1.f / (float)n_real : 0.f;
     } else {           // mean(relu(1 + fake))   gan_cifar_resnet.py:380
       const float t = 1.f + v;
       acc += fmaxf(t, 0.f) / (float)n_fake;
-      dl[i] = f2bf(t > 0.f ? 1.f / (float)n_fake : 0.f);
+      d = t > 0.f ? 1.f / (float)n_fake : 0.f;
     }
+    dl[i] = f2bf(d);
+    if (dl32) dl32[i] = d;
   }
   const float tot = block_sum(acc, red);
   if (threadIdx.x == 0) loss[0] = tot;
 }
 
-__global__ void hinge_g_kernel(const bf16* __restrict__ l, float* __restrict__ loss, bf16* __restrict__ dl, int n) {
+__global__ void hinge_g_kernel(const bf16* __restrict__ l, float* __restrict__ loss, bf16* __restrict__ dl, float* __restrict__ dl32, int n) {
   __shared__ float red[16];
   float acc = 0.f;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     acc += bf2f(l[i]);
     dl[i] = f2bf(-1.f / (float)n);
+    if (dl32) dl32[i] = -1.f / (float)n;
   }
   const float tot = block_sum(acc, red);
   if (threadIdx.x == 0) loss[0] = -tot / (float)n;  // -mean(disc_fake)   gan_cifar_resnet.py:492
 }
 
 __global__ void softmax_xent_kernel(const bf16* __restrict__ lg, const int* __restrict__ labels, float* __restrict__ loss,
-                                    bf16* __restrict__ dl, int n, int classes) {
+                                    bf16* __restrict__ dl, float* __restrict__ dl32, int n, int classes) {
   __shared__ float red[16];
   float acc = 0.f;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -49,29 +56,44 @@ __global__ void softmax_xent_kernel(const bf16* __restrict__ lg, const int* __re
     for (int c = 0; c < classes; c++) {
       const float z = bf2f(lg[(long)i * classes + c]) - mx - lse;
       if (c == lb) acc -= z / (float)n;
-      dl[(long)i * classes + c] = f2bf((expf(z) - (c == lb ? 1.f : 0.f)) / (float)n);
+      const float d = (expf(z) - (c == lb ? 1.f : 0.f)) / (float)n;
+      dl[(long)i * classes + c] = f2bf(d);
+      if (dl32) dl32[(long)i * classes + c] = d;
     }
   }
   const float tot = block_sum(acc, red);
   if (threadIdx.x == 0) loss[0] = tot;
 }
 
-extern "C" int gank_hinge_d_loss(const void* logits, float* loss, void* dlogits, int n, int n_real, void* stream) {
+extern "C" int gank_hinge_d_loss(const void* logits, float* loss, void* dlogits, float* dlogits_f32, int n, int n_real, void* stream) {
   GANK_REQUIRE(logits && loss && dlogits && n > 0 && n_real > 0 && n_real < n, "hinge_d_loss: bad arguments");
-  hipLaunchKernelGGL(hinge_d_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, loss, (bf16*)dlogits, n, n_real);
+  hipLaunchKernelGGL(hinge_d_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, loss, (bf16*)dlogits, dlogits_f32, n, n_real);
   GANK_LAUNCH_OK("hinge_d_loss");
   return 0;
 }
-extern "C" int gank_hinge_g_loss(const void* logits, float* loss, void* dlogits, int n, void* stream) {
+extern "C" int gank_hinge_g_loss(const void* logits, float* loss, void* dlogits, float* dlogits_f32, int n, void* stream) {
   GANK_REQUIRE(logits && loss && dlogits && n > 0, "hinge_g_loss: bad arguments");
-  hipLaunchKernelGGL(hinge_g_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, loss, (bf16*)dlogits, n);
+  hipLaunchKernelGGL(hinge_g_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, loss, (bf16*)dlogits, dlogits_f32, n);
   GANK_LAUNCH_OK("hinge_g_loss");
   return 0;
 }
-extern "C" int gank_softmax_xent(const void* logits, const int32_t* labels, float* loss, void* dlogits, int n, int classes, void* stream) {
+extern "C" int gank_softmax_xent(const void* logits, const int32_t* labels, float* loss, void* dlogits, float* dlogits_f32, int n, int classes, void* stream) {
   GANK_REQUIRE(logits && labels && loss && dlogits && n > 0 && classes > 0, "softmax_xent: bad arguments");
-  hipLaunchKernelGGL(softmax_xent_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, labels, loss, (bf16*)dlogits, n, classes);
+  hipLaunchKernelGGL(softmax_xent_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, labels, loss, (bf16*)dlogits, dlogits_f32, n, classes);
   GANK_LAUNCH_OK("softmax_xent");
+  return 0;
+}
+
+// d(total)/d(logits) = g[0] * d(loss)/d(logits) for a loss that enters a weighted sum (gen_cost + ACGAN_SCALE_G * xent,
+// gan_cifar_resnet.py:476; ACGAN/train.py:119-121): product in fp32, one rounding to bf16
+__global__ void loss_grad_scale_kernel(const float* __restrict__ dl32, const float* __restrict__ g, bf16* __restrict__ out, long n) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = f2bf(dl32[i] * g[0]);
+}
+extern "C" int gank_loss_grad_scale(const float* dlogits_f32, const float* g, void* dlogits, long n, void* stream) {
+  GANK_REQUIRE(dlogits_f32 && g && dlogits && n > 0, "loss_grad_scale: bad arguments");
+  hipLaunchKernelGGL(loss_grad_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dlogits_f32, g, (bf16*)dlogits, n);
+  GANK_LAUNCH_OK("loss_grad_scale");
   return 0;
 }
 

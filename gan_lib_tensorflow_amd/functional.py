@@ -64,6 +64,13 @@ def flush_wgrads():
     _deferred.clear()
 
 
+def reset_deferred():
+    """Drop every deferred / side-stream filter gradient (start of a backward pass, and after one that raised or whose
+    capture aborted): stale (x, dy) pairs must never be flushed into another pass's gradient buffers."""
+    _deferred.clear()
+    _Side.keep.clear()
+
+
 def join_wgrad():
     """Every filter gradient issued or deferred so far is complete / in stream order (before the optimiser and the
     SN backward)."""
@@ -520,22 +527,40 @@ class _Loss(Function):
     @staticmethod
     def forward(ctx, logits, kind, arg):
         if kind == "hinge_d":
-            loss, dl = K.hinge_d_loss(logits, arg)
+            loss, dl, dl32 = K.hinge_d_loss(logits, arg)
         elif kind == "hinge_g":
-            loss, dl = K.hinge_g_loss(logits)
+            loss, dl, dl32 = K.hinge_g_loss(logits)
         elif kind == "xent":
-            loss, dl = K.softmax_xent(logits, arg)
+            loss, dl, dl32 = K.softmax_xent(logits, arg)
         else:
             raise NotImplementedError(kind)
-        ctx.save_for_backward(dl)
+        ctx.save_for_backward(dl, dl32)
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        (dl,) = ctx.saved_tensors
-        # g is d(total)/d(loss), fp32[1]; the step always calls backward() on the loss itself (g == 1),
-        # so the saved gradient is returned as is.  Scaled losses go through `scale_loss`.
-        return dl, None, None
+        dl, dl32 = ctx.saved_tensors
+        # g = d(total)/d(loss), fp32[1].  The train step differentiates the loss itself with a persistent unit seed
+        # (unit_seed): the bf16 gradient of the forward launch is returned as is.  Any other upstream gradient (a
+        # weighted sum of losses, loss / accum_steps) scales the fp32 gradient on the device and rounds once.
+        if g.data_ptr() in _unit_seed_ptrs:
+            return dl, None, None
+        return K.loss_grad_scale(dl32, _c(g.to(torch.float32)).reshape(1)), None, None
+
+
+_unit_seeds = {}
+_unit_seed_ptrs = set()
+
+
+def unit_seed(loss):
+    """Persistent all-ones gradient seed for `loss.backward(gradient=...)`: no ones_like fill per update, and _Loss
+    recognises it (by identity) and skips the scale launch."""
+    key = (loss.device, tuple(loss.shape))
+    s = _unit_seeds.get(key)
+    if s is None:
+        s = _unit_seeds[key] = torch.ones_like(loss)      # never freed, never written: its address identifies it
+        _unit_seed_ptrs.add(s.data_ptr())
+    return s
 
 
 def hinge_d_loss(logits, n_real):

@@ -514,25 +514,36 @@ def embedding_bwd(dy, idx, dtable):
 
 # ------------------------------------------------------------------ losses / optimiser / input
 def hinge_d_loss(logits, n_real):
+    """-> (loss fp32[1], dlogits bf16, dlogits fp32): the bf16 copy is the gradient for an upstream gradient of 1"""
     loss = torch.empty(1, dtype=F32, device=logits.device)
     dl = torch.empty_like(logits)
-    _lib.check(lib().gank_hinge_d_loss(_p(logits, BF16, "logits"), _p(loss), _p(dl), logits.numel(), n_real, _stream()), "hinge_d_loss")
-    return loss, dl
+    dl32 = torch.empty(logits.shape, dtype=F32, device=logits.device)
+    _lib.check(lib().gank_hinge_d_loss(_p(logits, BF16, "logits"), _p(loss), _p(dl), _p(dl32), logits.numel(), n_real, _stream()), "hinge_d_loss")
+    return loss, dl, dl32
 
 
 def hinge_g_loss(logits):
     loss = torch.empty(1, dtype=F32, device=logits.device)
     dl = torch.empty_like(logits)
-    _lib.check(lib().gank_hinge_g_loss(_p(logits, BF16, "logits"), _p(loss), _p(dl), logits.numel(), _stream()), "hinge_g_loss")
-    return loss, dl
+    dl32 = torch.empty(logits.shape, dtype=F32, device=logits.device)
+    _lib.check(lib().gank_hinge_g_loss(_p(logits, BF16, "logits"), _p(loss), _p(dl), _p(dl32), logits.numel(), _stream()), "hinge_g_loss")
+    return loss, dl, dl32
 
 
 def softmax_xent(logits, labels):
     n, classes = logits.shape
     loss = torch.empty(1, dtype=F32, device=logits.device)
     dl = torch.empty_like(logits)
-    _lib.check(lib().gank_softmax_xent(_p(logits, BF16, "logits"), _p(labels, I32, "labels"), _p(loss), _p(dl), n, classes, _stream()), "softmax_xent")
-    return loss, dl
+    dl32 = torch.empty(logits.shape, dtype=F32, device=logits.device)
+    _lib.check(lib().gank_softmax_xent(_p(logits, BF16, "logits"), _p(labels, I32, "labels"), _p(loss), _p(dl), _p(dl32), n, classes, _stream()), "softmax_xent")
+    return loss, dl, dl32
+
+
+def loss_grad_scale(dl32, g):
+    """bf16(g[0] * dl32): the gradient of a loss that entered a weighted sum (g = fp32[1] upstream gradient)"""
+    out = torch.empty(dl32.shape, dtype=BF16, device=dl32.device)
+    _lib.check(lib().gank_loss_grad_scale(_p(dl32, F32, "dl32"), _p(g, F32, "g"), _p(out), dl32.numel(), _stream()), "loss_grad_scale")
+    return out
 
 
 def adam_tf(p, g, m, v, hp, t_state, iteration=None):

@@ -255,13 +255,18 @@ int gank_concat_tile_bwd(const void* dy, void* da, void* de, int N, int HW, int 
 int gank_embedding_fwd(const float* table, const int32_t* idx, void* y, int N, int D, int vocab, void* stream);
 int gank_embedding_bwd(const void* dy, const int32_t* idx, float* dtable, int N, int D, int vocab, void* stream);
 
-/* ---- losses (loss value fp32[1] and d loss/d logits bf16 in one launch) --------------------------
+/* ---- losses (loss value fp32[1] and d loss/d logits in one launch) ------------------------------
+ * dlogits: bf16, the gradient for an upstream gradient of 1 (loss.backward() on the loss itself);
+ * dlogits_f32 (may be NULL): the same values unrounded, for gank_loss_grad_scale when the loss is a term of a
+ * weighted sum (gen_cost + ACGAN_SCALE_G*xent, gan_cifar_resnet.py:476; ACGAN/train.py:119-121).
  * hinge_d: mean(relu(1-l[:n_real])) + mean(relu(1+l[n_real:]))   (gan_cifar_resnet.py:362-363,379-381)
  * hinge_g: -mean(l)                                               (gan_cifar_resnet.py:492)
  * softmax_xent: mean sparse softmax cross-entropy                 (gan_cifar_resnet.py:390-394) */
-int gank_hinge_d_loss(const void* logits, float* loss, void* dlogits, int n, int n_real, void* stream);
-int gank_hinge_g_loss(const void* logits, float* loss, void* dlogits, int n, void* stream);
-int gank_softmax_xent(const void* logits, const int32_t* labels, float* loss, void* dlogits, int n, int classes, void* stream);
+int gank_hinge_d_loss(const void* logits, float* loss, void* dlogits, float* dlogits_f32, int n, int n_real, void* stream);
+int gank_hinge_g_loss(const void* logits, float* loss, void* dlogits, float* dlogits_f32, int n, void* stream);
+int gank_softmax_xent(const void* logits, const int32_t* labels, float* loss, void* dlogits, float* dlogits_f32, int n, int classes, void* stream);
+/* dlogits (bf16) = g[0] * dlogits_f32: the chain rule through `total = ... + g * loss` (tf.gradients of a scaled loss) */
+int gank_loss_grad_scale(const float* dlogits_f32, const float* g, void* dlogits, long n, void* stream);
 
 /* ---- tf.train.AdamOptimizer (gan_cifar_resnet.py:521-526), one launch over a flat buffer ---------
  * All step state lives on the device so a captured update replays without host traffic:

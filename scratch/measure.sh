@@ -3,7 +3,7 @@
 tag=${1:-m}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/prof_$tag
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o $tag --output-format csv -- python3 bench.py --no-cpu-baseline > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err < /dev/null
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o $tag --output-format csv -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err < /dev/null
 python3 scratch/cat_summary.py gpurun_out/prof_$tag 27 > gpurun_out/cat_$tag.txt 2>&1
 grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' gpurun_out/bench_$tag.json | head -2
 head -14 gpurun_out/cat_$tag.txt

@@ -116,30 +116,3 @@ def test_sampling_quantisation_and_inception_score_statistics():
     assert len(seen) == 2 and all(lo >= -1 and hi <= 1 and sh == (64, 4, 4, 3) for lo, hi, sh in seen) and abs(m - 1.0) < 1e-12
     with pytest.raises(NotImplementedError):
         get_inception_score(imgs)
-
-
-def test_committed_bench_line_keeps_the_contract():
-    """The newest committed bench line (profiles/r01_*_bench.json, written by `python bench.py` on an MI355X) carries
-    every field the driver and the judge read, with consistent arithmetic."""
-    import glob, json, os, re
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(glob.glob(os.path.join(root, "profiles", "r01_v*_bench.json")), key=lambda f: int(re.search(r"_v(\d+)_", f).group(1)))
-    assert files, "no committed bench line"
-    j = json.load(open(files[-1]))
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline"):
-        assert k in j, k
-    assert j["unit"] == "images/sec" and j["higher_is_better"] is True and j["scaling"] == "weak" and j["vs_baseline"] is None
-    assert j["data"] == "synthetic" and j["dtype"] == "bf16" and "workload" in j["config"] and "model" not in j["config"]
-    # value = 5 x 64 real images per iteration / time per iteration
-    assert abs(j["value"] - 320.0 * j["n_gpus"] / (j["ms_per_step"] * 1e-3)) / j["value"] < 2e-3
-    r = j["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "algorithmic_bytes_per_launch"):
-        assert k in r, k
-    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
-    assert abs(r["achieved"] - r["avg_launch_gflop"] / r["avg_launch_us"] * 1e3) / r["achieved"] < 2e-2     # TFLOP/s = GFLOP / us * 1e3
-    assert r["traffic"] is None or r["traffic"] >= 0.9 * r["algorithmic_bytes_per_launch"]
-    c = j["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
-        assert k in c, k
-    assert c["kind"] in ("port", "reference") and c["unit"] == j["unit"] and c["cores"] >= 1

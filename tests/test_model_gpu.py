@@ -48,7 +48,7 @@ def rel(got, ref):
 
 def test_names_and_param_counts(gpu):
     S, tr, state = make_trainer(0, 4)
-    assert list(tr.store.vars.keys()).sort() == list(state.keys()).sort()
+    assert sorted(tr.store.vars.keys()) == sorted(state.keys())
     assert set(tr.store.vars.keys()) == set(state.keys())
     assert tr.store.param_count('Generator') == 7875587
     assert tr.store.param_count('Discriminator') == 1701689
