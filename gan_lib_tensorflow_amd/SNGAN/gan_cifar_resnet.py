@@ -93,6 +93,8 @@ def _d_prep_kind(name, W):
         return 2
     if Fn.FRAG_PATCH and name.endswith('D.Block.2.Conv1/Filters'):      # plain 3x3 256->256 at 16x16
         return 3
+    if blocks.FUSE_RES8 and W.dim() == 4 and tuple(W.shape) == (3, 3, 128, 128) and ('D.Block.3.' in name or 'D.Block.4.' in name):
+        return 4                                                          # fused 8x8 residual blocks: "rfrag" operands
     return 0
 
 
@@ -120,11 +122,16 @@ def Discriminator(inputs, labels, update_collection=None, reuse=False):
             output = Fn.concat_tile(output, embedding_y)               # expand_dims x2 + tile + concat (:282-284)
             output = ResidualBlock(output, DIM_D * 2, DIM_D, 3, 'D.Block.2', spectral_normed=True,
                                    update_collection=update_collection, resample='down', labels=labels, biases=True)
-            output = ResidualBlock(output, DIM_D, DIM_D, 3, 'D.Block.3', spectral_normed=True,
-                                   update_collection=update_collection, resample=None, labels=labels, biases=True)
-            output = ResidualBlock(output, DIM_D, DIM_D, 3, 'D.Block.4', spectral_normed=True,
-                                   update_collection=update_collection, resample=None, labels=labels, biases=True)
-            output = Fn.relu_meanpool_hw(output)                       # nonlinearity + reduce_mean (:299-301)
+            if blocks.res_chain8_eligible(output, DIM_D, ['D.Block.3', 'D.Block.4'], labels):
+                # D.Block.3, D.Block.4 and nonlinearity + reduce_mean (:291-301) as ONE launch: an 8x8x128 sample stays in LDS
+                output = blocks.ResidualBlockChain8(output, DIM_D, ['D.Block.3', 'D.Block.4'], spectral_normed=True,
+                                                    update_collection=update_collection, biases=True, pool=True)
+            else:
+                output = ResidualBlock(output, DIM_D, DIM_D, 3, 'D.Block.3', spectral_normed=True,
+                                       update_collection=update_collection, resample=None, labels=labels, biases=True)
+                output = ResidualBlock(output, DIM_D, DIM_D, 3, 'D.Block.4', spectral_normed=True,
+                                       update_collection=update_collection, resample=None, labels=labels, biases=True)
+                output = Fn.relu_meanpool_hw(output)                       # nonlinearity + reduce_mean (:299-301)
             output_wgan = _linear.Linear(output, DIM_D, 1, 'D.Output', spectral_normed=True,
                                          update_collection=update_collection)
             return output_wgan.reshape(-1), None

@@ -33,13 +33,12 @@ def unset_weights_stdev():
     _weights_stdev = None
 
 
-def Conv2D(inputs, input_dim, output_dim, filter_size=3, stride=1, name='Conv2D',
-           conv_type='conv2d', channel_multiplier=0, padding='SAME',
-           spectral_normed=False, update_collection=None, inputs_norm=False, he_init=True,
-           mask_type=None, weightnorm=None, biases=True, gain=1.,
-           residual=None, upsample=False, in_relu=False, pool_out=False, out_tanh=False):
-    """inputs: bf16 tensor [batch, height, width, in_channels] on the GPU.
-    Returns [batch, out_height, out_width, output_dim]."""
+def conv2d_variables(input_dim, output_dim, filter_size=3, stride=1, name='Conv2D', conv_type='conv2d', padding='SAME',
+                     spectral_normed=False, update_collection=None, inputs_norm=False, he_init=True,
+                     mask_type=None, weightnorm=None, biases=True, gain=1.):
+    """The variable half of Conv2D (conv2d.py:59-176): creates / fetches `<name>/Filters` (spectrally normalised when
+    asked) and `<name>/Biases` under the current scope and returns (filters, biases | None).  Shared by Conv2D and by
+    fused multi-convolution kernels, so both paths own identical variables."""
     store = get_default_store()
     with store.variable_scope(name):
         if conv_type != 'conv2d':
@@ -72,6 +71,18 @@ def Conv2D(inputs, input_dim, output_dim, filter_size=3, stride=1, name='Conv2D'
         _biases = None
         if biases:
             _biases = store.get_variable('Biases', [output_dim], np.zeros(output_dim, 'float32'))
+        return filters, _biases
 
-        return Fn.conv2d(inputs, filters, _biases, residual=residual, upsample=upsample, in_relu=in_relu,
-                         pool_out=pool_out, out_tanh=out_tanh)
+
+def Conv2D(inputs, input_dim, output_dim, filter_size=3, stride=1, name='Conv2D',
+           conv_type='conv2d', channel_multiplier=0, padding='SAME',
+           spectral_normed=False, update_collection=None, inputs_norm=False, he_init=True,
+           mask_type=None, weightnorm=None, biases=True, gain=1.,
+           residual=None, upsample=False, in_relu=False, pool_out=False, out_tanh=False):
+    """inputs: bf16 tensor [batch, height, width, in_channels] on the GPU.
+    Returns [batch, out_height, out_width, output_dim]."""
+    filters, _biases = conv2d_variables(input_dim, output_dim, filter_size, stride, name, conv_type, padding,
+                                        spectral_normed, update_collection, inputs_norm, he_init, mask_type, weightnorm,
+                                        biases, gain)
+    return Fn.conv2d(inputs, filters, _biases, residual=residual, upsample=upsample, in_relu=in_relu,
+                     pool_out=pool_out, out_tanh=out_tanh)

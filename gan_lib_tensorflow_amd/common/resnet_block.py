@@ -157,6 +157,34 @@ def ResidualBlock(inputs, input_dim, output_dim, filter_size, name,
                   he_init=True, biases=biases, in_relu=not norm2, residual=shortcut)
 
 
+FUSE_RES8 = True     # consecutive identity-shortcut 8x8x128 blocks without normalisation: one fused launch each way
+
+
+def res_chain8_eligible(inputs, input_dim, names, labels=None):
+    """The fused kernels (conv_resident.hip) cover blocks of 128 -> 128 channels on 8x8 images with no normalisation."""
+    return (FUSE_RES8 and len(names) in (1, 2) and inputs.dim() == 4 and tuple(inputs.shape[1:]) == (8, 8, 128) and input_dim == 128
+            and all(_normalize_kind(nm + '.N1', labels) is None and _normalize_kind(nm + '.N2', labels) is None for nm in names))
+
+
+def ResidualBlockChain8(inputs, dim, names, spectral_normed=False, update_collection=None, biases=True, pool=False):
+    """`ResidualBlock(..., resample=None)` for each name in `names`, in sequence, on 8x8 images with dim == 128 and no
+    normalisation (gan_cifar_resnet.py:291-297), as one fused kernel; pool=True appends the `nonlinearity` +
+    `reduce_mean(axis=[1, 2])` that follows the last critic block (:299-301).  Owns exactly the variables the
+    per-block path creates (`<name>.Conv1/Filters`, ...)."""
+    params = []
+    for nm in names:
+        w1, b1 = _conv2d.conv2d_variables(dim, dim, 3, 1, nm + '.Conv1', spectral_normed=spectral_normed,
+                                          update_collection=update_collection, he_init=True, biases=biases)
+        w2, b2 = _conv2d.conv2d_variables(dim, dim, 3, 1, nm + '.Conv2', spectral_normed=spectral_normed,
+                                          update_collection=update_collection, he_init=True, biases=biases)
+        for w in (w1, w2):
+            if getattr(w, '_prep_res', None) is None:       # not prepared by a batched pass (sn.precomputed): do it here
+                from .. import kernels as _K
+                _K.prep_weights_batched([w], want_d=True, kinds=[4])
+        params.append((w1, b1, w2, b2))
+    return Fn.res_chain8(inputs, params, pool=pool)
+
+
 def OptimizedResBlockDisc1(inputs, spectral_normed=False, update_collection=None, inputs_norm=False, biases=True):
     """First critic block, no pre-activation on the image (gan_cifar_resnet.py:212-234)."""
     conv_1 = functools.partial(_conv2d.Conv2D, input_dim=inputs.shape[-1], output_dim=DIM_D)

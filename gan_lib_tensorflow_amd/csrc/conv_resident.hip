@@ -1,0 +1,289 @@
+// "Resident" convolutions for the critic's small layers (gfx950): the whole input of a workgroup -- every channel of
+// its pixels plus the halo -- sits in LDS for the whole kernel, the weights stream from L2 straight into registers in
+// MFMA-fragment order, and there is NO barrier inside a convolution.
+//
+// Why: the critic works on 128 samples per update.  Its 8x8x128 residual blocks (D.Block.3 / D.Block.4,
+// SNGAN/gan_cifar_resnet.py:156-209 with resample=None) are 2.4 GFLOP per conv; as four implicit-GEMM launches per
+// block pair they ran 10-13 us each (one 4-wave workgroup per CU, a barrier and a dependent global->LDS round trip
+// per 64-deep K-step, 0.08 of the MFMA peak, 2.5x the algorithmic HBM bytes).  An 8x8x128 sample is 16 KB, so one
+// workgroup per sample keeps  relu -> conv1 -> relu -> conv2 -> + shortcut  of BOTH blocks (and the final
+// relu + spatial mean) on chip: the activations make one trip to HBM per tensor the backward pass needs, the 24
+// launches per critic pass become 2 (forward chain, backward chain).
+//
+// Layout: LDS image = 10 x 10 halo pixels, pixel pitch 272 B (128 channels + 16 B), row pitch 2944 B; with these
+// pitches the 16-lane groups of a ds_read_b128 B-fragment read (32 lanes = 4 image rows x 8 columns, one tap) fall on
+// 16 distinct 16-byte bank slots.  The border stays zero (SAME padding); images hold RAW values and the relu is
+// applied to the fragment after the read (v_pk_max_i16), so the shortcut operand and the tensors saved for the
+// backward pass come from the same image.  Weight operand ("rfrag", prep kind 4): [32-row tile][tap][k/16][lane][8]
+// bf16, one coalesced 1 KB request per MFMA A-fragment, a register ring of 8 requests in flight per wave.
+// Wave (ct, pt) of the 8: output channels 32*ct .. +31 of the pixels of image rows 4*pt .. +3.
+#include "gank_common.h"
+
+namespace {
+constexpr int RB_C = 128;                    // channels
+constexpr int RB_PPB = RB_C * 2 + 16;        // pixel pitch (bytes): 17 sixteen-byte units
+constexpr int RB_RPB = 2944;                 // halo row pitch (bytes): 184 units = 8 mod 16
+constexpr int RB_IMG = 10 * RB_RPB;          // one halo image
+constexpr int RB_STEPS = 9 * (RB_C / 16);    // MFMA K-steps per conv (tap-major)
+constexpr int RB_WBYTES = RB_C * 9 * RB_C * 2;
+constexpr int RB_LDS = 2 * RB_IMG;
+
+struct ResFwdArgs {
+  const bf16* x;          // [N,8,8,C] chain input
+  const bf16* w[4];       // rfrag fprop operands: block0.conv1, block0.conv2, block1.conv1, block1.conv2
+  const float* bias[4];   // may be null
+  bf16* h1[2];            // conv1 output (bias added, before the relu) per block; null = not kept
+  bf16* y[2];             // block outputs; null = not kept
+  bf16* pooled;           // optional [N,C]: mean over the 64 pixels of relu(y_last)   (gan_cifar_resnet.py:299-301)
+  int N, nblocks;
+};
+
+struct ResBwdArgs {
+  const bf16* dy;         // [N,8,8,C] gradient of the chain output, or null with dpool
+  const bf16* dpool;      // optional [N,C]: gradient of `pooled`; dy = dpool/64 * [y_last > 0]
+  const bf16* ylast;      // y of the last block (with dpool)
+  bf16* dy_out;           // optional: where the dy built from dpool is kept (operand of the last conv2's filter gradient)
+  const bf16* wd[4];      // rfrag dgrad operands in the order applied: last block conv2, conv1, then the block before
+  const bf16* h1[2];      // relu masks, same order
+  const bf16* xin[2];     // block inputs (mask of the pre-activation relu), same order
+  bf16* g1[2];            // out: gradient of conv1's output (dy operand of conv1's filter gradient); null = not kept
+  bf16* dx[2];            // out: gradient of the block input; null = not kept (the last one is the chain's result)
+  int N, nblocks;
+};
+
+template <bool RELU>
+__device__ __forceinline__ void res_conv3x3(f32x16& acc, const char* smem, int b_base, const __amdgpu_buffer_rsrc_t rw, int lane16, int wbase) {
+  constexpr int PF = 8;
+  u32x4 ring[PF];
+#pragma unroll
+  for (int s = 0; s < PF; s++) ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, wbase + s * 1024, 0);
+#pragma unroll
+  for (int s = 0; s < RB_STEPS; s++) {
+    const int tap = s >> 3, kk = s & 7;
+    const bf16x8 fa = __builtin_bit_cast(bf16x8, ring[s % PF]);
+    if (s + PF < RB_STEPS) ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, wbase + (s + PF) * 1024, 0);
+    u32x4 bv = *reinterpret_cast<const u32x4*>(smem + b_base + (tap / 3) * RB_RPB + (tap % 3) * RB_PPB + kk * 32);
+    if constexpr (RELU) bv = relu_bf16x8(bv);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+  }
+}
+
+// interior of an image <-> [64 pixels][C] in HBM, 16 bytes per lane, whole 256-byte pixel rows
+__device__ __forceinline__ void res_store_image(const char* img, bf16* dst, int tid) {
+#pragma unroll
+  for (int it = 0; it < 2; it++) {
+    const int q = tid + it * 512, px = q >> 4, c16 = q & 15;
+    *reinterpret_cast<u32x4*>(dst + px * RB_C + c16 * 8) =
+        *reinterpret_cast<const u32x4*>(img + ((px >> 3) + 1) * RB_RPB + ((px & 7) + 1) * RB_PPB + c16 * 16);
+  }
+}
+__device__ __forceinline__ void res_load_image(char* img, const bf16* src, int tid) {
+#pragma unroll
+  for (int it = 0; it < 2; it++) {
+    const int q = tid + it * 512, px = q >> 4, c16 = q & 15;
+    *reinterpret_cast<u32x4*>(img + ((px >> 3) + 1) * RB_RPB + ((px & 7) + 1) * RB_PPB + c16 * 16) =
+        *reinterpret_cast<const u32x4*>(src + px * RB_C + c16 * 8);
+  }
+}
+}  // namespace
+
+__global__ __launch_bounds__(512) void res8_chain_fwd_kernel(ResFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = wave & 3, pt = wave >> 2;
+  const int r = lane & 31, h = lane >> 5;
+  const long n = blockIdx.x;
+  const int row = 4 * pt + (r >> 3), col = r & 7;
+  const int b_base = row * RB_RPB + col * RB_PPB + h * 16;                        // tap (0,0), kk 0 of this lane's pixel
+  const int own = (row + 1) * RB_RPB + (col + 1) * RB_PPB + ct * 64 + h * 8;      // this lane's 4 channels of quad g: + 16 g
+  const int wbase = ct * RB_STEPS * 1024;
+
+  for (int i = tid; i < RB_LDS / 16; i += 512) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+  res_load_image(smem, a.x + n * 64 * RB_C, tid);
+  __syncthreads();
+
+#pragma unroll 1
+  for (int b = 0; b < a.nblocks; b++) {
+    // static indexing of the by-value argument arrays (a dynamic index spills the struct to scratch)
+    const bf16* w1 = b == 0 ? a.w[0] : a.w[2];
+    const bf16* w2 = b == 0 ? a.w[1] : a.w[3];
+    const float* bias1 = b == 0 ? a.bias[0] : a.bias[2];
+    const float* bias2 = b == 0 ? a.bias[1] : a.bias[3];
+    bf16* h1 = b == 0 ? a.h1[0] : a.h1[1];
+    bf16* y = b == 0 ? a.y[0] : a.y[1];
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(w1), 0, RB_WBYTES, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(w2), 0, RB_WBYTES, 0x00020000);
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.f;
+    res_conv3x3<true>(acc, smem, b_base, r1, lane * 16, wbase);                   // conv_1(relu(x))      (:186-190)
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+      if (bias1) bb = *reinterpret_cast<const f32x4*>(bias1 + ct * 32 + 8 * g + 4 * h);
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; e++) o[e] = f2bf(acc[4 * g + e] + bb[e]);
+      *reinterpret_cast<bf16x4*>(smem + RB_IMG + own + 16 * g) = o;
+    }
+    __syncthreads();                                                              // image B = h1 complete
+    if (h1) res_store_image(smem + RB_IMG, h1 + n * 64 * RB_C, tid);
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.f;
+    res_conv3x3<true>(acc, smem + RB_IMG, b_base, r2, lane * 16, wbase);          // conv_2(relu(h1))     (:198-207)
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+      if (bias2) bb = *reinterpret_cast<const f32x4*>(bias2 + ct * 32 + 8 * g + 4 * h);
+      const bf16x4 xs = *reinterpret_cast<const bf16x4*>(smem + own + 16 * g);    // shortcut + output   (:209)
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; e++) o[e] = f2bf(acc[4 * g + e] + bb[e] + bf2f(xs[e]));
+      *reinterpret_cast<bf16x4*>(smem + own + 16 * g) = o;                        // own elements only: no other wave reads or writes them here
+    }
+    __syncthreads();                                                              // image A = y complete
+    if (y) res_store_image(smem, y + n * 64 * RB_C, tid);
+  }
+  if (a.pooled && tid < RB_C) {                                                   // relu + mean over the 8 x 8 pixels (:299-301)
+    float s = 0.f;
+    for (int px = 0; px < 64; px++)
+      s += fmaxf(bf2f(*reinterpret_cast<const bf16*>(smem + ((px >> 3) + 1) * RB_RPB + ((px & 7) + 1) * RB_PPB + tid * 2)), 0.f);
+    a.pooled[n * RB_C + tid] = f2bf(s * (1.f / 64.f));
+  }
+}
+
+__global__ __launch_bounds__(512) void res8_chain_bwd_kernel(ResBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = wave & 3, pt = wave >> 2;
+  const int r = lane & 31, h = lane >> 5;
+  const long n = blockIdx.x;
+  const int row = 4 * pt + (r >> 3), col = r & 7;
+  const int b_base = row * RB_RPB + col * RB_PPB + h * 16;
+  const int own = (row + 1) * RB_RPB + (col + 1) * RB_PPB + ct * 64 + h * 8;
+  const long own_g = (n * 64 + row * 8 + col) * RB_C + ct * 32 + 4 * h;           // the same elements in HBM: + 8 g
+  const int wbase = ct * RB_STEPS * 1024;
+
+  for (int i = tid; i < RB_LDS / 16; i += 512) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+  if (a.dpool) {                                     // gradient of relu + spatial mean: dpool / 64 where y_last > 0
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      const int q = tid + it * 512, px = q >> 4, c16 = q & 15;
+      const bf16x8 yv = *reinterpret_cast<const bf16x8*>(a.ylast + (n * 64 + px) * RB_C + c16 * 8);
+      const bf16x8 dp = *reinterpret_cast<const bf16x8*>(a.dpool + n * RB_C + c16 * 8);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = f2bf(bf2f(yv[e]) > 0.f ? bf2f(dp[e]) * (1.f / 64.f) : 0.f);
+      *reinterpret_cast<bf16x8*>(smem + ((px >> 3) + 1) * RB_RPB + ((px & 7) + 1) * RB_PPB + c16 * 16) = o;
+      if (a.dy_out) *reinterpret_cast<bf16x8*>(a.dy_out + (n * 64 + px) * RB_C + c16 * 8) = o;
+    }
+  } else {
+    res_load_image(smem, a.dy + n * 64 * RB_C, tid);
+  }
+  __syncthreads();
+
+#pragma unroll 1
+  for (int b = 0; b < a.nblocks; b++) {
+    const bf16* wd2 = b == 0 ? a.wd[0] : a.wd[2];
+    const bf16* wd1 = b == 0 ? a.wd[1] : a.wd[3];
+    const bf16* h1 = b == 0 ? a.h1[0] : a.h1[1];
+    const bf16* xin = b == 0 ? a.xin[0] : a.xin[1];
+    bf16* g1 = b == 0 ? a.g1[0] : a.g1[1];
+    bf16* dx = b == 0 ? a.dx[0] : a.dx[1];
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(wd2), 0, RB_WBYTES, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(wd1), 0, RB_WBYTES, 0x00020000);
+
+    bf16x4 m[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) m[g] = *reinterpret_cast<const bf16x4*>(h1 + own_g + 8 * g);     // in flight during the conv
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.f;
+    res_conv3x3<false>(acc, smem, b_base, r2, lane * 16, wbase);                  // input gradient of conv_2
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; e++) o[e] = f2bf(bf2f(m[g][e]) > 0.f ? acc[4 * g + e] : 0.f);       // relu'(h1)
+      *reinterpret_cast<bf16x4*>(smem + RB_IMG + own + 16 * g) = o;
+    }
+    __syncthreads();                                                              // image B = g1 complete
+    if (g1) res_store_image(smem + RB_IMG, g1 + n * 64 * RB_C, tid);
+#pragma unroll
+    for (int g = 0; g < 4; g++) m[g] = *reinterpret_cast<const bf16x4*>(xin + own_g + 8 * g);
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.f;
+    res_conv3x3<false>(acc, smem + RB_IMG, b_base, r1, lane * 16, wbase);         // input gradient of conv_1
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const bf16x4 ds = *reinterpret_cast<const bf16x4*>(smem + own + 16 * g);    // + dy along the identity shortcut
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; e++) o[e] = f2bf((bf2f(m[g][e]) > 0.f ? acc[4 * g + e] : 0.f) + bf2f(ds[e]));
+      *reinterpret_cast<bf16x4*>(smem + own + 16 * g) = o;
+    }
+    __syncthreads();                                                              // image A = dx complete
+    if (dx) res_store_image(smem, dx + n * 64 * RB_C, tid);
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+extern "C" int gank_res8_chain_fwd(const void* x, const void* const* w_rfrag, const float* const* bias, void* const* h1,
+                                   void* const* y, void* pooled, int N, int C, int nblocks, void* stream) {
+  GANK_REQUIRE(x && w_rfrag && bias && h1 && y && N > 0, "res8_chain_fwd: null pointer");
+  GANK_REQUIRE(C == RB_C, "res8_chain_fwd: built for %d channels (got %d)", RB_C, C);
+  GANK_REQUIRE(nblocks == 1 || nblocks == 2, "res8_chain_fwd: 1 or 2 blocks per launch (got %d)", nblocks);
+  ResFwdArgs a{};
+  a.x = (const bf16*)x; a.pooled = (bf16*)pooled; a.N = N; a.nblocks = nblocks;
+  for (int i = 0; i < 2 * nblocks; i++) {
+    GANK_REQUIRE(w_rfrag[i], "res8_chain_fwd: null weight operand %d", i);
+    a.w[i] = (const bf16*)w_rfrag[i];
+    a.bias[i] = bias[i];
+  }
+  for (int b = 0; b < nblocks; b++) { a.h1[b] = (bf16*)h1[b]; a.y[b] = (bf16*)y[b]; }
+  GANK_REQUIRE(a.y[nblocks - 1] || a.pooled, "res8_chain_fwd: no output requested");
+  hipStream_t s = (hipStream_t)stream;
+  GANK_MAX_DYNAMIC_LDS(res8_chain_fwd_kernel, RB_LDS, "res8_chain_fwd");
+  // algorithmic bytes: x, every weight once, every tensor written once
+  gank_prof_begin(0, 2.0 * nblocks * 2.0 * N * 64.0 * RB_C * 9.0 * RB_C, s,
+                  2.0 * N * 64.0 * RB_C * (1 + 2 * nblocks) + 2.0 * nblocks * RB_WBYTES);
+  gank_prof_tag(0, "res8_chain_fwd_kernel");
+  hipLaunchKernelGGL(res8_chain_fwd_kernel, dim3(N), dim3(512), RB_LDS, s, a);
+  gank_prof_end(0, s);
+  GANK_LAUNCH_OK("res8_chain_fwd");
+  return 0;
+}
+
+extern "C" int gank_res8_chain_bwd(const void* dy, const void* dpool, const void* ylast, void* dy_out, const void* const* wd_rfrag,
+                                   const void* const* h1, const void* const* xin, void* const* g1, void* const* dx, int N, int C,
+                                   int nblocks, void* stream) {
+  GANK_REQUIRE((dy || (dpool && ylast)) && wd_rfrag && h1 && xin && g1 && dx && N > 0, "res8_chain_bwd: null pointer");
+  GANK_REQUIRE(C == RB_C, "res8_chain_bwd: built for %d channels (got %d)", RB_C, C);
+  GANK_REQUIRE(nblocks == 1 || nblocks == 2, "res8_chain_bwd: 1 or 2 blocks per launch (got %d)", nblocks);
+  ResBwdArgs a{};
+  a.dy = (const bf16*)dy; a.dpool = dy ? nullptr : (const bf16*)dpool; a.ylast = (const bf16*)ylast; a.dy_out = (bf16*)dy_out;
+  a.N = N; a.nblocks = nblocks;
+  for (int i = 0; i < 2 * nblocks; i++) {
+    GANK_REQUIRE(wd_rfrag[i], "res8_chain_bwd: null weight operand %d", i);
+    a.wd[i] = (const bf16*)wd_rfrag[i];
+  }
+  for (int b = 0; b < nblocks; b++) {
+    GANK_REQUIRE(h1[b] && xin[b], "res8_chain_bwd: null mask tensor of block %d", b);
+    a.h1[b] = (const bf16*)h1[b]; a.xin[b] = (const bf16*)xin[b]; a.g1[b] = (bf16*)g1[b]; a.dx[b] = (bf16*)dx[b];
+  }
+  GANK_REQUIRE(a.dx[nblocks - 1], "res8_chain_bwd: the chain's input gradient has no destination");
+  hipStream_t s = (hipStream_t)stream;
+  GANK_MAX_DYNAMIC_LDS(res8_chain_bwd_kernel, RB_LDS, "res8_chain_bwd");
+  gank_prof_begin(0, 2.0 * nblocks * 2.0 * N * 64.0 * RB_C * 9.0 * RB_C, s,
+                  2.0 * N * 64.0 * RB_C * (1 + 4 * nblocks) + 2.0 * nblocks * RB_WBYTES);
+  gank_prof_tag(0, "res8_chain_bwd_kernel");
+  hipLaunchKernelGGL(res8_chain_bwd_kernel, dim3(N), dim3(512), RB_LDS, s, a);
+  gank_prof_end(0, s);
+  GANK_LAUNCH_OK("res8_chain_bwd");
+  return 0;
+}

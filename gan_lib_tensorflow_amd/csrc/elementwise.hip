@@ -272,6 +272,30 @@ __global__ void prep_batch_kernel(PrepTable t) {
         if (i < hi) prep_up_element(q, i);
       }
     }
+  } else if (d.kind == 4) {
+    // "rfrag" operands of the resident kernels (conv_resident.hip): [32-row tile][tap][k/16][lane = h*32 + r][8], one
+    // 16-byte chunk (8 consecutive k of one row) per thread.  wf rows = co, k = ci; wd rows = ci, k = co, taps flipped.
+    const bool isf = b < t.nwf[e];
+    const int rows = isf ? d.Cout : d.Cin, kc = isf ? d.Cin : d.Cout;
+    const long nchunk = (long)(rows / 32) * taps * (kc / 16) * 64;
+    bf16* dst = (bf16*)(isf ? d.wf : d.wd);
+    const long base = (long)(isf ? b : b - t.nwf[e]) * 256;
+    const long q = base + threadIdx.x;
+    if (q < nchunk) {
+      const int lane = (int)(q & 63);
+      long u = q >> 6;
+      const int kk = (int)(u % (kc / 16)); u /= (kc / 16);
+      const int tap = (int)(u % taps);
+      const int rt = (int)(u / taps);
+      const int row = rt * 32 + (lane & 31), k0 = kk * 16 + (lane >> 5) * 8;
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int k = k0 + j;
+        o[j] = f2bf(isf ? d.w[((long)tap * d.Cin + k) * d.Cout + row] : d.w[((long)(taps - 1 - tap) * d.Cin + row) * d.Cout + k]);
+      }
+      *reinterpret_cast<bf16x8*>(dst + q * 8) = o;
+    }
   } else if (b < t.nwf[e]) {
     const int K = taps * d.Cin, Kpad = (K + 63) / 64 * 64, CoutPad = (d.Cout + 31) / 32 * 32;
     __shared__ float tl[32][33];
@@ -322,8 +346,8 @@ extern "C" int gank_conv2d_prep_weights_batched(const gank_prep_desc* table, int
       const gank_prep_desc& d = table[base + i];
       GANK_REQUIRE(d.w && (d.wf || d.wd) && d.ksize >= 1 && d.Cin > 0 && d.Cout > 0, "prep_weights_batched: bad entry %d", base + i);
       GANK_REQUIRE(d.kind == 0 || ((d.kind == 1 || d.kind == 2) && d.ksize == 3 && d.wf && d.wd) ||
-                   (d.kind == 3 && d.Cin % 64 == 0 && d.Cout % 64 == 0),
-                   "prep_weights_batched: entry %d: kind %d needs ksize 3 and both outputs (1, 2) / channels %% 64 == 0 (3)", base + i, d.kind);
+                   (d.kind == 3 && d.Cin % 64 == 0 && d.Cout % 64 == 0) || (d.kind == 4 && d.Cin % 32 == 0 && d.Cout % 32 == 0),
+                   "prep_weights_batched: entry %d: kind %d needs ksize 3 and both outputs (1, 2) / channels %% 64 == 0 (3) / %% 32 == 0 (4)", base + i, d.kind);
       t.d[i] = d;
       const int taps = d.ksize * d.ksize;
       int nwf = d.wf ? (roundup(taps * d.Cin, 64) / 32) * (roundup(d.Cout, 32) / 32) : 0;
@@ -333,6 +357,10 @@ extern "C" int gank_conv2d_prep_weights_batched(const gank_prep_desc* table, int
         const PrepUpSplit sp = prep_up_split(t.up[i], d.kind);
         nwf = sp.ntiles;
         nwd = sp.nelem;
+      }
+      if (d.kind == 4) {          // one 16-byte chunk per thread
+        nwf = d.wf ? cdiv((long)d.Cout * taps * d.Cin / 8, 256) : 0;
+        nwd = d.wd ? cdiv((long)d.Cin * taps * d.Cout / 8, 256) : 0;
       }
       t.first_block[i] = blocks;
       t.nwf[i] = nwf;

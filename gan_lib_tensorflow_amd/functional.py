@@ -235,6 +235,62 @@ def conv2d(x, W, bias=None, residual=None, upsample=False, in_relu=False, pool_o
     return _Conv2d.apply(x, W, bias, residual, upsample, in_relu, pool_out, out_tanh)
 
 
+class _ResChain8(Function):
+    """Up to two identity-shortcut residual blocks on 8x8x128 images in one launch each way (conv_resident.hip):
+    y = x + conv_2(relu(conv_1(relu(x)) + b1)) + b2 per block (gan_cifar_resnet.py:176-209 with resample=None and no
+    normalisation), optionally followed by relu + spatial mean (:299-301).  params = (W1, b1, W2, b2) per block; every W
+    carries `_prep_res` (prep kind 4)."""
+
+    @staticmethod
+    def forward(ctx, x, pool, *params):
+        nb = len(params) // 4
+        Ws = [params[4 * b + 2 * j] for b in range(nb) for j in range(2)]
+        bs = [params[4 * b + 2 * j + 1] for b in range(nb) for j in range(2)]
+        keep = any(ctx.needs_input_grad)
+        out, h1s, ys = K.res8_chain_fwd(x, [w._prep_res[0] for w in Ws], [b.detach() if b is not None else None for b in bs], keep, pool)
+        ctx.cfg = (nb, pool, Ws, bs)
+        ctx.kept = (x, h1s, ys) if keep else None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        nb, pool, Ws, bs = ctx.cfg
+        x, h1s, ys = ctx.kept
+        need_w = [ctx.needs_input_grad[2 + 4 * b + 2 * j] for b in range(nb) for j in range(2)]
+        need_b = [bs[i] is not None and ctx.needs_input_grad[2 + 2 * i + 1] for i in range(2 * nb)]
+        train = any(need_w) or any(need_b)
+        xins = [x] + ys[:-1]
+        g = _c(g)
+        dx, g1s, dys = K.res8_chain_bwd(None if pool else g, g if pool else None, ys[-1] if pool else None,
+                                        [w._prep_res[1] for w in Ws], h1s, xins, keep=train)
+        grads = [None] * (4 * nb)
+        if train:
+            for b in range(nb):
+                for j, (xop, gop) in enumerate(((xins[b], g1s[b]), (h1s[b], dys[b]))):      # conv_1: (relu(x), g1); conv_2: (relu(h1), dy)
+                    i = 2 * b + j
+                    W, bias = Ws[i], bs[i]
+                    btgt = None
+                    if need_b[i]:
+                        btgt, bacc = _target(bias)
+                        grads[4 * b + 2 * j + 1] = None if bacc else btgt
+                    if need_w[i]:
+                        tgt, acc = _target(W)
+                        grads[4 * b + 2 * j] = None if acc else tgt
+                        if BATCH_SMALL_WGRADS and _Side.stream is None:
+                            _defer_wgrad(xop, gop, tgt, btgt, (8, 8), 3, K.IN_RELU)
+                        else:
+                            _on_side(lambda xop=xop, gop=gop, tgt=tgt, btgt=btgt: K.conv2d_wgrad(xop, gop, tgt, (8, 8), 3, K.IN_RELU, 1.0, dbias=btgt), xop, gop)
+                    elif btgt is not None:
+                        K.colsum(gop, btgt, 1.0)
+        return (dx if ctx.needs_input_grad[0] else None, None, *grads)
+
+
+def res_chain8(x, blocks_params, pool=False):
+    """blocks_params: [(W1, b1, W2, b2), ...] (1 or 2 blocks)"""
+    flat = [t for bp in blocks_params for t in bp]
+    return _ResChain8.apply(x, pool, *flat)
+
+
 class _LinearSmall(Function):
     """Latency-sized dense layer straight on the fp32 weight (no MFMA operand preparation)."""
 

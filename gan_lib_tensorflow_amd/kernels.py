@@ -50,7 +50,8 @@ def prep_weights_batched(ws, want_d=True, kinds=None):
     """One launch for a list of fp32 weights ([k,k,Cin,Cout] or [Cin,Cout]).  kinds[i]: 0 = plain conv/linear ->
     `w._prep = (wf, wd)`; 1 = UpsampleConv 3x3 -> `w._prep_up = (wph, wd4)`; 2 = ConvMeanPool 3x3 ->
     `w._prep_pool = (wp4, wphd)`; 3 = plain + fragment-major copies for the register-weight patch kernel (the conv
-    wrappers pass GANK_W_FRAG when they see them); None = skip (the layer prepares nothing).  The conv wrappers pick the attributes up
+    wrappers pass GANK_W_FRAG when they see them); 4 = "rfrag" operands of the resident kernels -> `w._prep_res = (rf, rd)`;
+    None = skip (the layer prepares nothing).  The conv wrappers pick the attributes up
     and skip their own per-layer preparation.  Buffers persist on the tensor and are rewritten IN PLACE on later
     calls: captured graphs keep reading the same addresses."""
     kinds = list(kinds) if kinds is not None else [0] * len(ws)
@@ -85,6 +86,10 @@ def prep_weights_batched(ws, want_d=True, kinds=None):
             assert k == 3
             wf, wd = getattr(w, "_prep_pool", None) or (torch.empty((_roundup(cout, 32), _roundup(16 * cin, 64)), dtype=BF16, device=dev),
                                                        torch.empty((4, _roundup(cin, 32), 4 * cout), dtype=BF16, device=dev))
+        elif kind == 4:
+            assert k == 3 and cin % 32 == 0 and cout % 32 == 0
+            wf, wd = getattr(w, "_prep_res", None) or (torch.empty(taps * cin * cout, dtype=BF16, device=dev),
+                                                      torch.empty(taps * cin * cout, dtype=BF16, device=dev) if want_d else None)
         else:
             raise ValueError(f"unknown preparation kind {kind}")
         d = table[i]
@@ -94,7 +99,7 @@ def prep_weights_batched(ws, want_d=True, kinds=None):
     if todo:
         _lib.check(lib().gank_conv2d_prep_weights_batched(table, len(todo), _stream()), "prep_weights_batched")
     for (w, kind), o in zip(todo, outs):
-        setattr(w, ("_prep", "_prep_up", "_prep_pool", "_prep")[kind], o)
+        setattr(w, ("_prep", "_prep_up", "_prep_pool", "_prep", "_prep_res")[kind], o)
     return outs
 
 
@@ -219,6 +224,59 @@ def convpool3x3_wgrad(x, dy, dw, flags=0, dbias=None):
     _lib.check(lib().gank_convpool3x3_wgrad(_p(x, BF16, "x"), _p(dy, BF16, "dy"), _p(dw, F32, "dw"), _p(dbias, F32, "dbias"),
                                             _p(ws16), n, hp, wp, cin, cout, flags, _stream()), "convpool3x3_wgrad")
     return dw
+
+
+def _ptr_array(ts):
+    arr = (C.c_void_p * len(ts))()
+    for i, t in enumerate(ts):
+        arr[i] = t.data_ptr() if t is not None else None
+    return arr
+
+
+def res8_chain_fwd(x, w_rfrag, biases, keep=True, pool=False):
+    """Fused identity-shortcut residual blocks on 8x8 images (gank_res8_chain_fwd).  x bf16 [N,8,8,128]; w_rfrag: the
+    2*nblocks kind-4 `rf` operands (conv_1, conv_2 per block); biases: fp32 [128] or None each.
+    -> (out, h1s, ys): out = pooled [N,128] when pool else the last block's output; h1s / ys = per-block tensors kept for
+    the backward pass (empty lists when keep=False and they are not the result)."""
+    n, hh, ww, c = x.shape
+    assert hh == 8 and ww == 8 and len(w_rfrag) in (2, 4) and len(biases) == len(w_rfrag), (x.shape, len(w_rfrag))
+    nb = len(w_rfrag) // 2
+    for w in w_rfrag:
+        _p(w, BF16, "w_rfrag")
+    for b in biases:
+        _p(b, F32, "bias")
+    h1s = [torch.empty_like(x) for _ in range(nb)] if keep else [None] * nb
+    ys = [torch.empty_like(x) if (keep or (b == nb - 1 and not pool)) else None for b in range(nb)]
+    pooled = torch.empty((n, c), dtype=BF16, device=x.device) if pool else None
+    _lib.check(lib().gank_res8_chain_fwd(_p(x, BF16, "x"), _ptr_array(w_rfrag), _ptr_array(biases), _ptr_array(h1s), _ptr_array(ys),
+                                         _p(pooled), n, c, nb, _stream()), "res8_chain_fwd")
+    return (pooled if pool else ys[-1]), h1s, ys
+
+
+def res8_chain_bwd(dy, dpool, ylast, wd_rfrag, h1s, xins, keep=True):
+    """Backward chain (gank_res8_chain_bwd); lists are in FORWARD order (reversed here).  dy [N,8,8,128] or None with
+    dpool [N,128] + ylast.  -> (dx, g1s, dys): dx = gradient of the chain input; g1s[b] = gradient of block b's conv_1
+    output, dys[b] = gradient of block b's output (forward order; None entries when keep=False)."""
+    nb = len(h1s)
+    assert len(wd_rfrag) == 2 * nb and len(xins) == nb and (dy is not None or (dpool is not None and ylast is not None))
+    ref = xins[0]
+    n, c = ref.shape[0], ref.shape[3]
+    for w in wd_rfrag:
+        _p(w, BF16, "wd_rfrag")
+    for t in list(h1s) + list(xins):
+        _p(t, BF16, "mask tensor")
+    g1s = [torch.empty_like(ref) if keep else None for _ in range(nb)]
+    dxs = [torch.empty_like(ref) if (keep or b == 0) else None for b in range(nb)]       # dxs[b] = gradient of block b's input
+    dy_out = torch.empty_like(ref) if (dy is None and keep) else None
+    wd_rev, h1_rev, x_rev, g1_rev, dx_rev = [], [], [], [], []
+    for b in reversed(range(nb)):
+        wd_rev += [wd_rfrag[2 * b + 1], wd_rfrag[2 * b]]       # conv_2's operand first
+        h1_rev.append(h1s[b]); x_rev.append(xins[b]); g1_rev.append(g1s[b]); dx_rev.append(dxs[b])
+    _lib.check(lib().gank_res8_chain_bwd(_p(dy, BF16, "dy"), _p(dpool, BF16, "dpool"), _p(ylast, BF16, "ylast"), _p(dy_out),
+                                         _ptr_array(wd_rev), _ptr_array(h1_rev), _ptr_array(x_rev), _ptr_array(g1_rev), _ptr_array(dx_rev),
+                                         n, c, nb, _stream()), "res8_chain_bwd")
+    dys = [dxs[b + 1] if b + 1 < nb else (dy if dy is not None else dy_out) for b in range(nb)]
+    return dxs[0], g1s, dys
 
 
 def deconv2d_fprop(x, wz, bias, cout, ksize):

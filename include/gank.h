@@ -58,7 +58,10 @@ typedef struct gank_prep_desc {
   int kind;       /* 0 plain conv/linear; 1 UpsampleConv 3x3 (gank_upconv3x3_prep_weights layouts);
                      2 ConvMeanPool 3x3 (gank_convpool3x3_prep_weights layouts);
                      3 plain + a second, MFMA-fragment-major copy right after each row-major operand (buffers of
-                       twice the size; Cin % 64 == 0 and Cout % 64 == 0): pass GANK_W_FRAG to fprop / dgrad */
+                       twice the size; Cin % 64 == 0 and Cout % 64 == 0): pass GANK_W_FRAG to fprop / dgrad;
+                     4 "rfrag" operands of the resident kernels (gank_res8_chain_*): bf16 [rows/32][taps][k/16][64 lanes][8],
+                       lane = 32*h + r holding k = 16*kk + 8*h .. +7 of row 32*tile + r; wf: rows = co, k = ci;
+                       wd: rows = ci, k = co, taps flipped.  Cin % 32 == 0 and Cout % 32 == 0; taps*Cin*Cout elements each */
 } gank_prep_desc;
 int gank_conv2d_prep_weights_batched(const gank_prep_desc* table, int count, void* stream);
 
@@ -104,6 +107,25 @@ typedef struct gank_wgrad_item {
 } gank_wgrad_item;
 int gank_conv2d_wgrad_batched(const gank_wgrad_item* items, int count, int N, int H, int W, int Cin, int Cout,
                               int ksize, int flags, float scale, void* stream);
+
+/* ---- identity-shortcut residual blocks on 8x8 images, fused (SNGAN/gan_cifar_resnet.py:156-209, resample=None,
+ * no normalisation: the critic's D.Block.3 / D.Block.4, :291-297) ---------------------------------------------------
+ * One workgroup per sample keeps  y = x + conv_2(relu(conv_1(relu(x)) + b1)) + b2  of up to two consecutive blocks on
+ * chip (and, optionally, the relu + spatial mean that follows the last block, :299-301).  C must be 128.
+ *   fwd: x [N,8,8,C]; w_rfrag[2*nblocks]: prep kind 4 `wf` operands (conv_1, conv_2 per block); bias[2*nblocks] (entries
+ *        may be NULL); h1[b] (optional) <- conv_1 output of block b before its relu, y[b] (optional) <- block output,
+ *        both [N,8,8,C]: what the backward pass needs; pooled (optional) [N,C].
+ *   bwd: dy [N,8,8,C] gradient of the last block's output -- or dy = NULL and dpool [N,C] + ylast: the gradient of
+ *        `pooled`, expanded on the fly (kept in dy_out when given: the last conv_2's filter gradient reads it).
+ *        wd_rfrag / h1 / xin / g1 / dx are listed in the order the backward pass visits them: LAST block first;
+ *        wd_rfrag[2*i], [2*i+1] = kind 4 `wd` operands of conv_2, conv_1 of that block; xin = the block's input.
+ *        g1[i] (optional) <- gradient of conv_1's output, dx[i] (optional except the last) <- gradient of the block input.
+ *        Filter gradients: gank_conv2d_wgrad(_batched) on (relu(xin), g1) and (relu(h1), dy of the block). */
+int gank_res8_chain_fwd(const void* x, const void* const* w_rfrag, const float* const* bias, void* const* h1,
+                        void* const* y, void* pooled, int N, int C, int nblocks, void* stream);
+int gank_res8_chain_bwd(const void* dy, const void* dpool, const void* ylast, void* dy_out, const void* const* wd_rfrag,
+                        const void* const* h1, const void* const* xin, void* const* g1, void* const* dx, int N, int C,
+                        int nblocks, void* stream);
 
 /* ---- UpsampleConv 3x3 (SNGAN/gan_cifar_resnet.py:140-153) as a stride-2 transposed conv -------------
  * nearest-neighbour 2x followed by a 3x3 SAME conv equals a 4x4 stride-2 transposed conv whose taps are sums

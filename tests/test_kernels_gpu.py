@@ -843,3 +843,50 @@ def test_two_group_kernel_race_screen(K, form, n, h, w_, cin, cout):
         differing += 0 if torch.equal(run(), ref) else 1
     torch.cuda.synchronize()
     assert differing == 0
+
+
+@pytest.mark.parametrize("n,nb,pool", [(3, 2, True), (5, 1, False), (2, 2, False), (128, 2, True), (1, 1, True)])
+def test_res8_chain_fused_residual_blocks(K, n, nb, pool):
+    """conv_resident.hip: nb identity-shortcut residual blocks on 8x8x128 images (+ relu + spatial mean) in one launch each
+    way, against torch-CPU float64 autograd of gan_cifar_resnet.py:176-209,299-301 on the same bf16-rounded operands.  The
+    HIP path rounds h1 and every block output to bf16 between the convolutions (the oracle does not): outputs and input
+    gradients <= 1.5e-2 of the maximum, filter / bias gradients (fp32 from bf16 operands through up to 4 convs) <= 1e-2."""
+    from oracle import ref_torch as T
+    from gan_lib_tensorflow_amd import functional as Fn
+    rng = np.random.default_rng(800 + n + 10 * nb + pool)
+    x, xt = bf(rng.normal(size=(n, 8, 8, 128)))
+    params_t, params_r = [], []
+    for b in range(nb):
+        blk_t, blk_r = [], []
+        for j in range(2):
+            w, _ = bf(rng.normal(size=(3, 3, 128, 128)) / np.sqrt(9 * 128) * 1.4)
+            bias, biast = f32(rng.normal(size=128) * 0.1)
+            wt = torch.tensor(w, dtype=torch.float32).cuda().requires_grad_(True)
+            biast.requires_grad_(True)
+            blk_t += [wt, biast]
+            blk_r += [torch.tensor(w, requires_grad=True), torch.tensor(bias, requires_grad=True)]
+        params_t.append(tuple(blk_t))
+        params_r.append(blk_r)
+    K.prep_weights_batched([p[i] for p in params_t for i in (0, 2)], want_d=True, kinds=[4] * (2 * nb))
+    xt.requires_grad_(True)
+    out = Fn.res_chain8(xt, params_t, pool=pool)
+    g, gt = bf(rng.normal(size=tuple(out.shape)))
+    out.backward(gt)
+    torch.cuda.synchronize()
+    xr = torch.tensor(x, requires_grad=True)
+    cur = xr
+    for w1, b1, w2, b2 in params_r:
+        h = T.conv2d_same(torch.relu(cur), w1, b1)
+        cur = cur + T.conv2d_same(torch.relu(h), w2, b2)
+    ref = torch.relu(cur).mean(dim=(1, 2)) if pool else cur
+    ref.backward(torch.tensor(g))
+    assert relerr(out, ref.detach().numpy()) < 1.5e-2
+    assert relerr(xt.grad, xr.grad.numpy()) < 1.5e-2
+    for b in range(nb):
+        for i in range(4):
+            e = relerr(params_t[b][i].grad, params_r[b][i].grad.numpy())
+            assert e < 1e-2, (b, i, e)
+    # inference form (nothing requires a gradient): same output, nothing kept
+    with torch.no_grad():
+        out2 = Fn.res_chain8(xt.detach(), [tuple(t.detach() if hasattr(t, "detach") else t for t in p) for p in params_t], pool=pool)
+    assert torch.equal(out2, out.detach())
