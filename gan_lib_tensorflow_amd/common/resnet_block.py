@@ -177,10 +177,6 @@ def ResidualBlockChain8(inputs, dim, names, spectral_normed=False, update_collec
                                           update_collection=update_collection, he_init=True, biases=biases)
         w2, b2 = _conv2d.conv2d_variables(dim, dim, 3, 1, nm + '.Conv2', spectral_normed=spectral_normed,
                                           update_collection=update_collection, he_init=True, biases=biases)
-        for w in (w1, w2):
-            if getattr(w, '_prep_res', None) is None:       # not prepared by a batched pass (sn.precomputed): do it here
-                from .. import kernels as _K
-                _K.prep_weights_batched([w], want_d=True, kinds=[4])
         params.append((w1, b1, w2, b2))
     return Fn.res_chain8(inputs, params, pool=pool)
 

@@ -288,6 +288,9 @@ class _ResChain8(Function):
 def res_chain8(x, blocks_params, pool=False):
     """blocks_params: [(W1, b1, W2, b2), ...] (1 or 2 blocks)"""
     flat = [t for bp in blocks_params for t in bp]
+    todo = [w for w in flat[0::2] if getattr(w, "_prep_res", None) is None]
+    if todo:                                         # not prepared by a batched pass (sn.precomputed)
+        K.prep_weights_batched(todo, want_d=True, kinds=[4] * len(todo))
     return _ResChain8.apply(x, pool, *flat)
 
 

@@ -163,6 +163,34 @@ def cond_batchnorm(x, labels, scale, offset, groups=1):
     return xhat * scale[labels][:, None, None, :] + offset[labels][:, None, None, :]
 
 
+# ------------------------------------------------------------------ storage emulation (test instrument)
+# The product path keeps every activation and activation gradient in bf16 between kernels.  STORE, when set, is applied
+# to every tensor that path materialises (conv / linear outputs, normalised+activated tensors, block outputs), so a test
+# can measure what bf16 STORAGE alone does to losses and gradients, independently of any kernel: see
+# tests/test_oracle.py::test_bf16_storage_sensitivity_of_generator_gradients.  None (the default) = exact arithmetic.
+STORE = None
+
+
+class _RoundBoth(torch.autograd.Function):
+    """value and gradient both rounded to bf16 (what a bf16 tensor in HBM does to the forward and backward streams)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def bf16_storage(x):
+    return _RoundBoth.apply(x)
+
+
+def _st(x):
+    return x if STORE is None else STORE(x)
+
+
 # ------------------------------------------------------------------ model
 class _Ctx:
     """Mimics the reference's variable scopes: fetches variables by name, records new SN u."""
@@ -177,7 +205,7 @@ class _Ctx:
             key = f'{self.scope}/{name}/filters/spectral_norm/u'
             W, u_new, _ = spectral_normed_weight(W, self.P[key])
             self.new_u[key] = u_new.detach()
-        return conv2d_same(x, W, self.P[f'{self.scope}/{name}/Biases'])
+        return conv2d_same(x, W, self.P[f'{self.scope}/{name}/Biases'])          # stored by the caller (after the fused epilogue)
 
     def linear(self, x, name, sn=False):
         W = self.P[f'{self.scope}/{name}/W']
@@ -195,17 +223,17 @@ class _Ctx:
 def generator(P, noise, labels, groups=1):
     """gan_cifar_resnet.py:237-263.  noise [n,128] -> [n,3072] (HWC order, tanh range)."""
     c = _Ctx(P, 'Generator', False)
-    out = c.linear(noise, 'G.Input').reshape(-1, 4, 4, DIM_G * 8)
+    out = _st(c.linear(noise, 'G.Input')).reshape(-1, 4, 4, DIM_G * 8)
     for i in (1, 2, 3):
         name = f'G.Block.{i}'
-        shortcut = c.conv(upsample_nn2x(out), name + '.Shortcut')          # :179-182 -> :140-151
-        h = torch.relu(c.cbn(out, name + '.N1', labels, groups))
-        h = c.conv(upsample_nn2x(h), name + '.Conv1')                      # :192-195
-        h = torch.relu(c.cbn(h, name + '.N2', labels, groups))
+        shortcut = _st(c.conv(upsample_nn2x(out), name + '.Shortcut'))     # :179-182 -> :140-151
+        h = _st(torch.relu(c.cbn(out, name + '.N1', labels, groups)))
+        h = _st(c.conv(upsample_nn2x(h), name + '.Conv1'))                 # :192-195
+        h = _st(torch.relu(c.cbn(h, name + '.N2', labels, groups)))
         h = c.conv(h, name + '.Conv2')
-        out = shortcut + h
-    out = torch.relu(c.cbn(out, 'G.OutputNorm', labels, groups))
-    out = torch.tanh(c.conv(out, 'G.Output'))
+        out = _st(shortcut + h)
+    out = _st(torch.relu(c.cbn(out, 'G.OutputNorm', labels, groups)))
+    out = _st(torch.tanh(c.conv(out, 'G.Output')))
     return out.reshape(-1, 3072)
 
 
@@ -213,24 +241,24 @@ def discriminator(P, x, labels):
     """gan_cifar_resnet.py:266-313 (ACGAN=False).  Returns logits [n] and {u name: new u}."""
     c = _Ctx(P, 'Discriminator', True)
     x = x.reshape(-1, 32, 32, 3)
-    shortcut = c.conv(meanpool2x2(x), 'D.Block.1.Shortcut', sn=True)      # :218-221 -> :125-135
-    h = c.conv(x, 'D.Block.1.Conv1', sn=True)
+    shortcut = _st(c.conv(meanpool2x2(x), 'D.Block.1.Shortcut', sn=True))  # :218-221 -> :125-135
+    h = _st(c.conv(x, 'D.Block.1.Conv1', sn=True))
     h = meanpool2x2(c.conv(torch.relu(h), 'D.Block.1.Conv2', sn=True))
-    out = shortcut + h
-    emb = c.linear(P['Discriminator/Embedding.Label/embedding_map'][labels], 'D.Embedding_y', sn=True)
+    out = _st(shortcut + h)
+    emb = _st(c.linear(P['Discriminator/Embedding.Label/embedding_map'][labels], 'D.Embedding_y', sn=True))
     emb = emb[:, None, None, :].expand(-1, out.shape[1], out.shape[2], -1)
     out = torch.cat([out, emb], dim=3)                                      # :282-284
     # D.Block.2, resample='down'
-    shortcut = meanpool2x2(c.conv(out, 'D.Block.2.Shortcut', sn=True))     # ConvMeanPool :112-122
-    h = c.conv(torch.relu(out), 'D.Block.2.Conv1', sn=True)
+    shortcut = _st(meanpool2x2(c.conv(out, 'D.Block.2.Shortcut', sn=True)))    # ConvMeanPool :112-122
+    h = _st(c.conv(torch.relu(out), 'D.Block.2.Conv1', sn=True))
     h = meanpool2x2(c.conv(torch.relu(h), 'D.Block.2.Conv2', sn=True))
-    out = shortcut + h
+    out = _st(shortcut + h)
     for i in (3, 4):                                                        # identity shortcut :176-177
-        h = c.conv(torch.relu(out), f'D.Block.{i}.Conv1', sn=True)
+        h = _st(c.conv(torch.relu(out), f'D.Block.{i}.Conv1', sn=True))
         h = c.conv(torch.relu(h), f'D.Block.{i}.Conv2', sn=True)
-        out = out + h
-    out = torch.relu(out).mean(dim=(1, 2))                                  # :299-301
-    logits = c.linear(out, 'D.Output', sn=True).reshape(-1)
+        out = _st(out + h)
+    out = _st(torch.relu(out).mean(dim=(1, 2)))                             # :299-301
+    logits = _st(c.linear(out, 'D.Output', sn=True)).reshape(-1)
     return logits, c.new_u
 
 

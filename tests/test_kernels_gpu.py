@@ -849,8 +849,10 @@ def test_two_group_kernel_race_screen(K, form, n, h, w_, cin, cout):
 def test_res8_chain_fused_residual_blocks(K, n, nb, pool):
     """conv_resident.hip: nb identity-shortcut residual blocks on 8x8x128 images (+ relu + spatial mean) in one launch each
     way, against torch-CPU float64 autograd of gan_cifar_resnet.py:176-209,299-301 on the same bf16-rounded operands.  The
-    HIP path rounds h1 and every block output to bf16 between the convolutions (the oracle does not): outputs and input
-    gradients <= 1.5e-2 of the maximum, filter / bias gradients (fp32 from bf16 operands through up to 4 convs) <= 1e-2."""
+    HIP path stores h1 and every block output as bf16 and takes its relu masks from those tensors; the oracle rounds the
+    same tensors to bf16 with a straight-through estimator, so both sides differentiate through the same masks (against
+    unrounded float64 intermediates ~0.1 % of the masks flip and the gradients differ by 3e-2 in L2 -- a property of bf16
+    storage, not of the kernel).  Outputs and input gradients <= 1.5e-2 of the maximum; filter / bias gradients <= 1e-2."""
     from oracle import ref_torch as T
     from gan_lib_tensorflow_amd import functional as Fn
     rng = np.random.default_rng(800 + n + 10 * nb + pool)
@@ -875,18 +877,24 @@ def test_res8_chain_fused_residual_blocks(K, n, nb, pool):
     torch.cuda.synchronize()
     xr = torch.tensor(x, requires_grad=True)
     cur = xr
+    def rb(t):          # bf16 storage, identity gradient
+        return t + (t.detach().to(torch.bfloat16).to(torch.float64) - t.detach())
     for w1, b1, w2, b2 in params_r:
-        h = T.conv2d_same(torch.relu(cur), w1, b1)
-        cur = cur + T.conv2d_same(torch.relu(h), w2, b2)
+        h = rb(T.conv2d_same(torch.relu(cur), w1, b1))
+        cur = rb(cur + T.conv2d_same(torch.relu(h), w2, b2))
     ref = torch.relu(cur).mean(dim=(1, 2)) if pool else cur
     ref.backward(torch.tensor(g))
     assert relerr(out, ref.detach().numpy()) < 1.5e-2
-    assert relerr(xt.grad, xr.grad.numpy()) < 1.5e-2
+    # a mask still flips where fp32-accumulated and float64 values round to different sides of zero (a few elements in a
+    # million): bound the input gradient in L2 and the fraction of elements off by more than the max-norm tolerance
+    gd = (xt.grad.double().cpu() - xr.grad).abs()
+    l2, frac = float(gd.norm() / xr.grad.norm()), float((gd > 1.5e-2 * xr.grad.abs().max()).double().mean())
+    assert l2 < 1e-2 and frac < 5e-4, (l2, frac)        # measured 5.5e-3 / 1.6e-4 on 1 M elements through 4 masks
     for b in range(nb):
         for i in range(4):
             e = relerr(params_t[b][i].grad, params_r[b][i].grad.numpy())
             assert e < 1e-2, (b, i, e)
     # inference form (nothing requires a gradient): same output, nothing kept
     with torch.no_grad():
-        out2 = Fn.res_chain8(xt.detach(), [tuple(t.detach() if hasattr(t, "detach") else t for t in p) for p in params_t], pool=pool)
+        out2 = Fn.res_chain8(xt, params_t, pool=pool)
     assert torch.equal(out2, out.detach())

@@ -309,9 +309,18 @@ def _grad_errors(tr, names, ref_g):
 def test_headline_batch_64_forward_and_gradients_vs_oracle(gpu):
     """BASELINE.json config 2 at its real size -- batch 64 (32 samples per tower), critic on 64 real + 64 fake, generator
     update on 2 x 64 fakes -- against the float64 oracle.  At this size the conditional-batch-norm statistics are
-    over 32 x 16..1024 values per channel, so the bf16 path tracks the oracle much more closely than the toy-batch
-    tests above: images max |d| <= 0.03 (tanh range), mean <= 0.003; logits <= 0.02*max(1,|ref|); every critic
-    and generator gradient tensor cosine >= 0.999 and relative L2 <= 0.03, except the ones named below."""
+    over 32 x 16..1024 values per channel.  Stated bounds (measured values in brackets):
+      * critic: logits <= 0.02*max(1,|ref|) [8e-4], loss <= 5e-3 [2.4e-4], every gradient tensor cosine >= 0.9999 and
+        relative L2 <= 0.015 [0.003..0.007]; the label-embedding branch (gradients constant over 16 x 16 pixels that
+        largely cancel) cosine >= 0.999, L2 <= 0.03 [0.011];
+      * generator images (tanh range): max |d| <= 0.09, mean <= 0.007 [0.060 / 0.0045]: 20 bf16-stored layers, the same
+        as at the toy batch -- the error is storage rounding, not statistics;
+      * generator gradients: relative L2 grows by 1-2 % per conditional batch norm on the way back from the image
+        [G.Output 0.003, G.Block.3 0.03-0.06, G.Block.2 0.04-0.08, G.Block.1 / G.Input 0.07-0.145], cosine >= 0.985.  That
+        growth is a property of bf16 STORAGE, not of the kernels: the float64 oracle with nothing but bf16 rounding of the
+        stored tensors deviates from itself by the same amounts (tests/test_oracle.py::
+        test_bf16_storage_sensitivity_of_generator_gradients: 0.005 / 0.04-0.08 / 0.06-0.10 / 0.09-0.125).  Limits per
+        depth: G.Output* 0.02, G.Block.3 0.10, G.Block.2 0.13, G.Block.1 and G.Input 0.22."""
     seed, b = 21, 64
     S, tr, state = make_trainer(seed, b)
     rng = np.random.default_rng(64)
@@ -327,7 +336,7 @@ def test_headline_batch_64_forward_and_gradients_vs_oracle(gpu):
         ref_img = T.generator(P, z.to(torch.float64), labels.long(), groups=2)
     diff = (img.to(torch.float64).cpu() - ref_img).abs()
     print("bs64 image max/mean |d|:", diff.max().item(), diff.mean().item())
-    assert diff.max().item() < 0.03 and diff.mean().item() < 0.003, (diff.max().item(), diff.mean().item())
+    assert diff.max().item() < 0.09 and diff.mean().item() < 0.007, (diff.max().item(), diff.mean().item())
     # ---- critic loss, logits and gradients
     loss, _, ref_logits = T.d_loss_fn(P, None, labels.long(), z.to(torch.float64), None, real_pre=real_pre.to(torch.float64))
     dn = T.trainable_names(P, 'Discriminator')
@@ -342,9 +351,13 @@ def test_headline_batch_64_forward_and_gradients_vs_oracle(gpu):
     errs = _grad_errors(tr, dn, ref_g)
     print("bs64 D grads (cos, relL2):", {k.split('/', 1)[1]: (round(c, 5), round(l, 4)) for k, (c, l, _, _) in errs.items()})
     bad = []
-    for k, (cos, l2, rn, _) in errs.items():
+    for k, (cos, l2, rn, gmax) in errs.items():
+        if rn < 1e-9:          # D.Output/b: the hinge gradients of an all-active batch sum to exactly zero
+            if gmax > 1e-6:
+                bad.append((k, 'abs', gmax))
+            continue
         # the label-embedding branch sums gradients that are constant over 16 x 16 pixels and largely cancel
-        lim = (0.995, 0.08) if 'mbedding' in k else (0.999, 0.03)
+        lim = (0.999, 0.03) if 'mbedding' in k else (0.9999, 0.015)
         if cos < lim[0] or l2 > lim[1]:
             bad.append((k, cos, l2))
     assert not bad, bad
@@ -367,7 +380,8 @@ def test_headline_batch_64_forward_and_gradients_vs_oracle(gpu):
             if gmax > 2e-4:
                 bad.append((k, 'abs', gmax))
             continue
-        if cos < 0.999 or l2 > 0.03:
+        lim = 0.02 if 'G.Output' in k else 0.10 if 'G.Block.3' in k else 0.13 if 'G.Block.2' in k else 0.22
+        if cos < 0.985 or l2 > lim:
             bad.append((k, cos, l2))
     assert not bad, bad
 
@@ -411,24 +425,56 @@ def test_short_training_tracks_the_fp32_restatement(gpu):
     assert np.isfinite(hip_d).all() and np.isfinite(hip_g).all()
     # first updates: same function of the same inputs (before chaos sets in)
     assert np.abs(hip_d[:5] - ref_d[:5]).max() < 0.05, (hip_d[:5], ref_d[:5])
-    # loss curves, window means (50 critic updates / 10 generator updates per window)
+    # critic loss curve, window means over 50 updates (measured differences: 0.006 .. 0.085)
     wd = np.abs(hip_d.reshape(-1, 50).mean(1) - ref_d.reshape(-1, 50).mean(1))
-    wg = np.abs(hip_g[:50].reshape(-1, 10).mean(1) - ref_g[:50].reshape(-1, 10).mean(1))
     print("short training: d_loss windows", hip_d.reshape(-1, 50).mean(1), ref_d.reshape(-1, 50).mean(1))
-    print("short training: g_loss windows", hip_g[:50].reshape(-1, 10).mean(1), ref_g[:50].reshape(-1, 10).mean(1))
-    assert wd.max() < 0.25 and wg.max() < 0.35, (wd, wg)
-    # parameter norms and distance travelled, per tensor
-    worst_norm, worst_travel = 0.0, 0.0
+    print("short training: g_loss mean/std", hip_g.mean(), hip_g.std(), ref_g.mean(), ref_g.std())
+    assert wd.max() < 0.2, wd
+    # generator loss = -mean(D(G(z))) over 16 samples swings by +-1 from update to update on either trajectory (std ~0.8):
+    # only its level over the whole run is comparable
+    assert abs(hip_g.mean() - ref_g.mean()) < 0.6 and 0.0 < hip_g.mean() < 5.0, (hip_g.mean(), ref_g.mean())
+    # parameter norms and distance travelled, per tensor.  (Conv biases that feed a batch norm are excluded: their true
+    # gradient is exactly zero, TF-Adam turns whatever rounding noise arrives into steps of ~lr, and the normalisation
+    # removes the bias again -- they random-walk differently on every implementation without touching the function.)
+    norms, travels = {}, {}
     for k in ot.g_names + ot.d_names:
+        if k.startswith('Generator/') and k.endswith('Biases') and 'G.Output' not in k:
+            continue
         a = tr.store.vars[k].detach().float().cpu()
         r = P[k].detach()
-        if float(r.norm()) > 1e-3:
-            worst_norm = max(worst_norm, abs(float(a.norm()) / float(r.norm()) - 1.0))
+        if float(r.norm()) > 1e-3 and float(P0[k].norm()) > 0.5 * float(r.norm()):      # zero-initialised tensors: travel only
+            norms[k] = abs(float(a.norm()) / float(r.norm()) - 1.0)
         ta, trf = float((a - P0[k]).norm()), float((r - P0[k]).norm())
         if trf > 1e-3 and r.numel() >= 128:
-            worst_travel = max(worst_travel, abs(ta / trf - 1.0))
-    print("short training: worst |norm ratio - 1|", worst_norm, "worst |travel ratio - 1|", worst_travel)
-    assert worst_norm < 0.02 and worst_travel < 0.25, (worst_norm, worst_travel)
+            travels[k] = abs(ta / trf - 1.0)
+    top = lambda d: sorted(d.items(), key=lambda kv: -kv[1])[:3]      # noqa: E731
+    print("short training: worst |norm ratio - 1|", top(norms), "worst |travel ratio - 1|", top(travels))
+    assert max(norms.values()) < 0.02 and max(travels.values()) < 0.25, (top(norms), top(travels))
+    # ---- parity at a TRAINED state (spectral norms, conditional-batch-norm tables and Adam-shaped weights have moved):
+    # the HIP trainer takes over the restatement's parameters and both differentiate the same losses on the same inputs
+    tr.store.load_state_dict({k: v.detach().numpy() for k, v in P.items()})
+    tr._refresh_g_prep()
+    P64 = T.to_torch({k: v.detach().numpy() for k, v in P.items()})
+    z = bf16r(rng.normal(size=(b, 128)))
+    labels = torch.tensor(rng.integers(0, 10, b), dtype=torch.int32)
+    # the trained critic separates the synthetic "real" images from the fakes perfectly (hinge loss exactly 0, zero
+    # gradient); feeding it generator samples in the REAL slot keeps the hinge active and the gradients informative
+    with torch.no_grad():
+        z_r = bf16r(rng.normal(size=(b, 128)))
+        real_pre = bf16r(T.generator(P64, z_r.to(torch.float64), labels.long(), groups=2).numpy())
+    loss, _, _ = T.d_loss_fn(P64, None, labels.long(), z.to(torch.float64), None, real_pre=real_pre.to(torch.float64))
+    assert float(loss) > 0.5
+    dn = T.trainable_names(P64, 'Discriminator')
+    ref_gr = dict(zip(dn, torch.autograd.grad(loss, [P64[k] for k in dn])))
+    tr.real_labels.copy_(labels)
+    tr._d_forward_backward(real_pre=real_pre.cuda(), z=z.cuda())
+    torch.cuda.synchronize()
+    errs = _grad_errors(tr, dn, ref_gr)
+    print("trained-state D loss", float(tr.d_loss), float(loss), "grads (cos, relL2):",
+          {k.split('/', 1)[1]: (round(c, 4), round(l, 3)) for k, (c, l, _, _) in errs.items()})
+    assert abs(float(tr.d_loss) - float(loss)) < 0.05
+    bad = [(k, c, l) for k, (c, l, rn, _) in errs.items() if rn > 1e-9 and (c < 0.999 or l > (0.05 if 'mbedding' in k else 0.03))]    # measured: cosine 0.9999-1.0, L2 0.001-0.017
+    assert not bad, bad
 
 
 def test_trainer_checkpoint_restores_the_optimiser_and_counters(gpu):

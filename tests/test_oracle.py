@@ -289,3 +289,38 @@ def test_layer_instance_pixel_norm_gradients_match_autograd():
     (gx,) = torch.autograd.grad(yt, [xt], torch.tensor(dy))
     assert np.allclose(R.pixel_norm_backward(dy, x), gx.numpy(), atol=1e-10)
     assert np.allclose((R.pixel_norm_forward(x) ** 2).mean(-1), 1.0, atol=1e-6)      # unit mean square per pixel
+
+
+def test_bf16_storage_sensitivity_of_generator_gradients():
+    """What bf16 STORAGE of activations and activation gradients alone does to the generator's gradients, with exact
+    (float64) arithmetic everywhere else: the float64 oracle against itself with every tensor the product path
+    materialises rounded to bf16 (ref_torch.STORE).  The deviation grows by 1-2 % (relative L2) per conditional batch
+    norm on the way back from the image -- relu masks taken right after a normalisation flip for ~0.1 % of the
+    elements, each flip costs the element's whole gradient -- and reaches ~0.1 at G.Input.  This is the floor for ANY
+    bf16 implementation of this path (BASELINE.json config 2 is bf16); tests/test_model_gpu.py bounds the HIP path's
+    per-tensor gradient errors at the headline batch against it."""
+    import torch
+    from oracle import ref_torch as T
+    torch.set_num_threads(8)
+    b = 8
+    state = T.init_sngan_params(21)
+    rng = np.random.default_rng(64)
+    z2 = torch.tensor(rng.normal(size=(2 * b, 128))).to(torch.bfloat16).to(torch.float64)
+    fl = torch.tensor(rng.integers(0, 10, 2 * b))
+
+    def grads(store):
+        T.STORE = store
+        try:
+            P = T.to_torch(state)
+            loss, _ = T.g_loss_fn(P, z2, fl)
+            gn = [k for k in T.trainable_names(P, 'Generator') if not (k.endswith('Biases') and 'G.Output' not in k)]
+            return loss.item(), dict(zip(gn, torch.autograd.grad(loss, [P[k] for k in gn])))
+        finally:
+            T.STORE = None
+    l0, g0 = grads(None)
+    l1, g1 = grads(T.bf16_storage)
+    assert abs(l0 - l1) < 5e-3
+    err = {k: float((g1[k] - g0[k]).norm() / g0[k].norm()) for k in g0}
+    assert err['Generator/G.Output/Filters'] < 0.02, err['Generator/G.Output/Filters']
+    assert 0.02 < err['Generator/G.Input/W'] < 0.4, err['Generator/G.Input/W']            # measured 0.12 at batch 16, 0.125-0.15 at 64
+    assert err['Generator/G.Input/W'] > 3 * err['Generator/G.Output/Filters']          # it accumulates with depth
