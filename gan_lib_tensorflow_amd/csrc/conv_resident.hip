@@ -16,8 +16,9 @@
 // applied to the fragment after the read (v_pk_max_i16), so the shortcut operand and the tensors saved for the
 // backward pass come from the same image.  Weight operand ("rfrag", prep kind 4): [32-row tile][tap][k/16][lane][8]
 // bf16, one coalesced 1 KB request per MFMA A-fragment, a register ring of 8 requests in flight per wave.
-// Wave (ct, pt) of the 8: output channels 32*ct .. +31 of the pixels of image rows 4*pt .. +3.
+// Wave ct of the 4: output channels 32*ct .. +31 of all 64 pixels (two MFMA tiles: image rows 0-3, 4-7).
 #include "gank_common.h"
+#include <stdlib.h>
 
 namespace {
 constexpr int RB_C = 128;                    // channels
@@ -51,57 +52,86 @@ struct ResBwdArgs {
   int N, nblocks;
 };
 
-template <bool RELU>
-__device__ __forceinline__ void res_conv3x3(f32x16& acc, const char* smem, int b_base, const __amdgpu_buffer_rsrc_t rw, int lane16, int wbase) {
-  constexpr int PF = 8;
-  u32x4 ring[PF];
+// TPW = 32-pixel MFMA tiles per wave (1: 8 waves per sample, 2: 4 waves, every weight fragment feeds two MFMAs);
+// PF = weight fragments in flight per wave.  A wave consumes one 1 KB fragment per TPW x 32 MFMA cycles and an L2 hit
+// takes 500+ cycles under load, so PF x TPW x 32 must cover that: 8 in flight left the matrix pipe waiting.
+// The weight stream never stops: the ring is filled once (res_ring_fill) and the last PF steps of a conv already
+// request the first PF fragments of the NEXT conv (`rn`), so the L2 round trip of a conv's first fragments hides behind
+// the previous conv's tail, its epilogue and the barrier instead of opening every conv with an idle matrix pipe.
+template <int PF>
+__device__ __forceinline__ void res_ring_fill(u32x4 (&ring)[PF], const __amdgpu_buffer_rsrc_t rw, int lane16, int wbase) {
 #pragma unroll
   for (int s = 0; s < PF; s++) ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, wbase + s * 1024, 0);
+}
+template <bool RELU, int TPW, int PF>
+__device__ __forceinline__ void res_conv3x3(f32x16 (&acc)[TPW], u32x4 (&ring)[PF], const char* smem, int b_base, const __amdgpu_buffer_rsrc_t rw,
+                                            const __amdgpu_buffer_rsrc_t rn, bool has_next, int lane16, int wbase) {
+  static_assert(RB_STEPS % PF == 0, "the ring position must be the same at the start of every conv");
+  constexpr int PB = 2;                              // pixel fragments are read PB steps ahead of their MFMAs
+  u32x4 bq[PB + 1][TPW];
+  auto read_b = [&](int s, u32x4 (&dst)[TPW]) {
+    const int tap = s >> 3, kk = s & 7;
+#pragma unroll
+    for (int t = 0; t < TPW; t++)
+      dst[t] = *reinterpret_cast<const u32x4*>(smem + b_base + (4 * t + tap / 3) * RB_RPB + (tap % 3) * RB_PPB + kk * 32);
+  };
+#pragma unroll
+  for (int s = 0; s < PB; s++) read_b(s, bq[s]);
 #pragma unroll
   for (int s = 0; s < RB_STEPS; s++) {
-    const int tap = s >> 3, kk = s & 7;
+    if (s + PB < RB_STEPS) read_b(s + PB, bq[(s + PB) % (PB + 1)]);
     const bf16x8 fa = __builtin_bit_cast(bf16x8, ring[s % PF]);
     if (s + PF < RB_STEPS) ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, wbase + (s + PF) * 1024, 0);
-    u32x4 bv = *reinterpret_cast<const u32x4*>(smem + b_base + (tap / 3) * RB_RPB + (tap % 3) * RB_PPB + kk * 32);
-    if constexpr (RELU) bv = relu_bf16x8(bv);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+    else if (has_next) ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rn, lane16, wbase + (s + PF - RB_STEPS) * 1024, 0);
+#pragma unroll
+    for (int t = 0; t < TPW; t++) {
+      u32x4 bv = bq[s % (PB + 1)][t];
+      if constexpr (RELU) bv = relu_bf16x8(bv);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, bv), acc[t], 0, 0, 0);
+    }
   }
 }
 
 // interior of an image <-> [64 pixels][C] in HBM, 16 bytes per lane, whole 256-byte pixel rows
+template <int NT>
 __device__ __forceinline__ void res_store_image(const char* img, bf16* dst, int tid) {
 #pragma unroll
-  for (int it = 0; it < 2; it++) {
-    const int q = tid + it * 512, px = q >> 4, c16 = q & 15;
+  for (int it = 0; it < 1024 / NT; it++) {
+    const int q = tid + it * NT, px = q >> 4, c16 = q & 15;
     *reinterpret_cast<u32x4*>(dst + px * RB_C + c16 * 8) =
         *reinterpret_cast<const u32x4*>(img + ((px >> 3) + 1) * RB_RPB + ((px & 7) + 1) * RB_PPB + c16 * 16);
   }
 }
+template <int NT>
 __device__ __forceinline__ void res_load_image(char* img, const bf16* src, int tid) {
 #pragma unroll
-  for (int it = 0; it < 2; it++) {
-    const int q = tid + it * 512, px = q >> 4, c16 = q & 15;
+  for (int it = 0; it < 1024 / NT; it++) {
+    const int q = tid + it * NT, px = q >> 4, c16 = q & 15;
     *reinterpret_cast<u32x4*>(img + ((px >> 3) + 1) * RB_RPB + ((px & 7) + 1) * RB_PPB + c16 * 16) =
         *reinterpret_cast<const u32x4*>(src + px * RB_C + c16 * 8);
   }
 }
 }  // namespace
 
-__global__ __launch_bounds__(512) void res8_chain_fwd_kernel(ResFwdArgs a) {
+template <int TPW, int PF>
+__global__ __launch_bounds__(512 / TPW) void res8_chain_fwd_kernel(ResFwdArgs a) {
+  constexpr int NT = 512 / TPW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ct = wave & 3, pt = wave >> 2;
+  const int ct = wave & 3;                                                        // 32 output channels per wave
   const int r = lane & 31, h = lane >> 5;
   const long n = blockIdx.x;
-  const int row = 4 * pt + (r >> 3), col = r & 7;
+  const int row = 4 * (wave >> 2) + (r >> 3), col = r & 7;                        // pixel of this wave's first tile; tile t = 4 t rows below
   const int b_base = row * RB_RPB + col * RB_PPB + h * 16;                        // tap (0,0), kk 0 of this lane's pixel
-  const int own = (row + 1) * RB_RPB + (col + 1) * RB_PPB + ct * 64 + h * 8;      // this lane's 4 channels of quad g: + 16 g
+  const int own = (row + 1) * RB_RPB + (col + 1) * RB_PPB + ct * 64 + h * 8;      // this lane's 4 channels of quad g: + 16 g (+ 4 rows for tile 1)
   const int wbase = ct * RB_STEPS * 1024;
 
-  for (int i = tid; i < RB_LDS / 16; i += 512) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+  u32x4 ring[PF];
+  res_ring_fill<PF>(ring, __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w[0]), 0, RB_WBYTES, 0x00020000), lane * 16, wbase);
+  for (int i = tid; i < RB_LDS / 16; i += NT) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
   __syncthreads();
-  res_load_image(smem, a.x + n * 64 * RB_C, tid);
+  res_load_image<NT>(smem, a.x + n * 64 * RB_C, tid);
   __syncthreads();
 
 #pragma unroll 1
@@ -115,37 +145,47 @@ __global__ __launch_bounds__(512) void res8_chain_fwd_kernel(ResFwdArgs a) {
     bf16* y = b == 0 ? a.y[0] : a.y[1];
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(w1), 0, RB_WBYTES, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(w2), 0, RB_WBYTES, 0x00020000);
+    const bool more = b + 1 < a.nblocks;             // a.w[2] is the next block's conv_1 (a valid pointer is needed only then)
+    const __amdgpu_buffer_rsrc_t r3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(more ? a.w[2] : w2), 0, RB_WBYTES, 0x00020000);
 
-    f32x16 acc;
+    f32x16 acc[TPW];
 #pragma unroll
-    for (int e = 0; e < 16; e++) acc[e] = 0.f;
-    res_conv3x3<true>(acc, smem, b_base, r1, lane * 16, wbase);                   // conv_1(relu(x))      (:186-190)
+    for (int t = 0; t < TPW; t++)
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-      f32x4 bb = {0.f, 0.f, 0.f, 0.f};
-      if (bias1) bb = *reinterpret_cast<const f32x4*>(bias1 + ct * 32 + 8 * g + 4 * h);
-      bf16x4 o;
+      for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+    res_conv3x3<true, TPW, PF>(acc, ring, smem, b_base, r1, r2, true, lane * 16, wbase);                   // conv_1(relu(x))      (:186-190)
 #pragma unroll
-      for (int e = 0; e < 4; e++) o[e] = f2bf(acc[4 * g + e] + bb[e]);
-      *reinterpret_cast<bf16x4*>(smem + RB_IMG + own + 16 * g) = o;
-    }
+    for (int t = 0; t < TPW; t++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+        if (bias1) bb = *reinterpret_cast<const f32x4*>(bias1 + ct * 32 + 8 * g + 4 * h);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] = f2bf(acc[t][4 * g + e] + bb[e]);
+        *reinterpret_cast<bf16x4*>(smem + RB_IMG + own + 4 * t * RB_RPB + 16 * g) = o;
+      }
     __syncthreads();                                                              // image B = h1 complete
-    if (h1) res_store_image(smem + RB_IMG, h1 + n * 64 * RB_C, tid);
+    if (h1) res_store_image<NT>(smem + RB_IMG, h1 + n * 64 * RB_C, tid);
 #pragma unroll
-    for (int e = 0; e < 16; e++) acc[e] = 0.f;
-    res_conv3x3<true>(acc, smem + RB_IMG, b_base, r2, lane * 16, wbase);          // conv_2(relu(h1))     (:198-207)
+    for (int t = 0; t < TPW; t++)
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-      f32x4 bb = {0.f, 0.f, 0.f, 0.f};
-      if (bias2) bb = *reinterpret_cast<const f32x4*>(bias2 + ct * 32 + 8 * g + 4 * h);
-      const bf16x4 xs = *reinterpret_cast<const bf16x4*>(smem + own + 16 * g);    // shortcut + output   (:209)
-      bf16x4 o;
+      for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+    res_conv3x3<true, TPW, PF>(acc, ring, smem + RB_IMG, b_base, r2, r3, more, lane * 16, wbase);          // conv_2(relu(h1))     (:198-207)
 #pragma unroll
-      for (int e = 0; e < 4; e++) o[e] = f2bf(acc[4 * g + e] + bb[e] + bf2f(xs[e]));
-      *reinterpret_cast<bf16x4*>(smem + own + 16 * g) = o;                        // own elements only: no other wave reads or writes them here
-    }
+    for (int t = 0; t < TPW; t++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+        if (bias2) bb = *reinterpret_cast<const f32x4*>(bias2 + ct * 32 + 8 * g + 4 * h);
+        const bf16x4 xs = *reinterpret_cast<const bf16x4*>(smem + own + 4 * t * RB_RPB + 16 * g);    // shortcut + output   (:209)
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] = f2bf(acc[t][4 * g + e] + bb[e] + bf2f(xs[e]));
+        *reinterpret_cast<bf16x4*>(smem + own + 4 * t * RB_RPB + 16 * g) = o;     // own elements only: no other wave reads or writes them here
+      }
     __syncthreads();                                                              // image A = y complete
-    if (y) res_store_image(smem, y + n * 64 * RB_C, tid);
+    if (y) res_store_image<NT>(smem, y + n * 64 * RB_C, tid);
   }
   if (a.pooled && tid < RB_C) {                                                   // relu + mean over the 8 x 8 pixels (:299-301)
     float s = 0.f;
@@ -155,25 +195,29 @@ __global__ __launch_bounds__(512) void res8_chain_fwd_kernel(ResFwdArgs a) {
   }
 }
 
-__global__ __launch_bounds__(512) void res8_chain_bwd_kernel(ResBwdArgs a) {
+template <int TPW, int PF>
+__global__ __launch_bounds__(512 / TPW) void res8_chain_bwd_kernel(ResBwdArgs a) {
+  constexpr int NT = 512 / TPW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ct = wave & 3, pt = wave >> 2;
+  const int ct = wave & 3;
   const int r = lane & 31, h = lane >> 5;
   const long n = blockIdx.x;
-  const int row = 4 * pt + (r >> 3), col = r & 7;
+  const int row = 4 * (wave >> 2) + (r >> 3), col = r & 7;
   const int b_base = row * RB_RPB + col * RB_PPB + h * 16;
   const int own = (row + 1) * RB_RPB + (col + 1) * RB_PPB + ct * 64 + h * 8;
-  const long own_g = (n * 64 + row * 8 + col) * RB_C + ct * 32 + 4 * h;           // the same elements in HBM: + 8 g
+  const long own_g = (n * 64 + row * 8 + col) * RB_C + ct * 32 + 4 * h;           // the same elements in HBM: + 8 g (+ 32 pixels for tile 1)
   const int wbase = ct * RB_STEPS * 1024;
 
-  for (int i = tid; i < RB_LDS / 16; i += 512) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+  u32x4 ring[PF];
+  res_ring_fill<PF>(ring, __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.wd[0]), 0, RB_WBYTES, 0x00020000), lane * 16, wbase);
+  for (int i = tid; i < RB_LDS / 16; i += NT) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
   __syncthreads();
   if (a.dpool) {                                     // gradient of relu + spatial mean: dpool / 64 where y_last > 0
 #pragma unroll
-    for (int it = 0; it < 2; it++) {
-      const int q = tid + it * 512, px = q >> 4, c16 = q & 15;
+    for (int it = 0; it < 1024 / NT; it++) {
+      const int q = tid + it * NT, px = q >> 4, c16 = q & 15;
       const bf16x8 yv = *reinterpret_cast<const bf16x8*>(a.ylast + (n * 64 + px) * RB_C + c16 * 8);
       const bf16x8 dp = *reinterpret_cast<const bf16x8*>(a.dpool + n * RB_C + c16 * 8);
       bf16x8 o;
@@ -183,7 +227,7 @@ __global__ __launch_bounds__(512) void res8_chain_bwd_kernel(ResBwdArgs a) {
       if (a.dy_out) *reinterpret_cast<bf16x8*>(a.dy_out + (n * 64 + px) * RB_C + c16 * 8) = o;
     }
   } else {
-    res_load_image(smem, a.dy + n * 64 * RB_C, tid);
+    res_load_image<NT>(smem, a.dy + n * 64 * RB_C, tid);
   }
   __syncthreads();
 
@@ -197,42 +241,83 @@ __global__ __launch_bounds__(512) void res8_chain_bwd_kernel(ResBwdArgs a) {
     bf16* dx = b == 0 ? a.dx[0] : a.dx[1];
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(wd2), 0, RB_WBYTES, 0x00020000);
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(wd1), 0, RB_WBYTES, 0x00020000);
+    const bool more = b + 1 < a.nblocks;
+    const __amdgpu_buffer_rsrc_t r3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(more ? a.wd[2] : wd1), 0, RB_WBYTES, 0x00020000);
 
-    bf16x4 m[4];
+    bf16x4 m[TPW][4];
 #pragma unroll
-    for (int g = 0; g < 4; g++) m[g] = *reinterpret_cast<const bf16x4*>(h1 + own_g + 8 * g);     // in flight during the conv
-    f32x16 acc;
+    for (int t = 0; t < TPW; t++)
 #pragma unroll
-    for (int e = 0; e < 16; e++) acc[e] = 0.f;
-    res_conv3x3<false>(acc, smem, b_base, r2, lane * 16, wbase);                  // input gradient of conv_2
+      for (int g = 0; g < 4; g++) m[t][g] = *reinterpret_cast<const bf16x4*>(h1 + own_g + t * 32 * RB_C + 8 * g);     // in flight during the conv
+    f32x16 acc[TPW];
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-      bf16x4 o;
+    for (int t = 0; t < TPW; t++)
 #pragma unroll
-      for (int e = 0; e < 4; e++) o[e] = f2bf(bf2f(m[g][e]) > 0.f ? acc[4 * g + e] : 0.f);       // relu'(h1)
-      *reinterpret_cast<bf16x4*>(smem + RB_IMG + own + 16 * g) = o;
-    }
+      for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+    res_conv3x3<false, TPW, PF>(acc, ring, smem, b_base, r2, r1, true, lane * 16, wbase);                  // input gradient of conv_2
+#pragma unroll
+    for (int t = 0; t < TPW; t++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] = f2bf(bf2f(m[t][g][e]) > 0.f ? acc[t][4 * g + e] : 0.f);       // relu'(h1)
+        *reinterpret_cast<bf16x4*>(smem + RB_IMG + own + 4 * t * RB_RPB + 16 * g) = o;
+      }
     __syncthreads();                                                              // image B = g1 complete
-    if (g1) res_store_image(smem + RB_IMG, g1 + n * 64 * RB_C, tid);
+    if (g1) res_store_image<NT>(smem + RB_IMG, g1 + n * 64 * RB_C, tid);
 #pragma unroll
-    for (int g = 0; g < 4; g++) m[g] = *reinterpret_cast<const bf16x4*>(xin + own_g + 8 * g);
+    for (int t = 0; t < TPW; t++)
 #pragma unroll
-    for (int e = 0; e < 16; e++) acc[e] = 0.f;
-    res_conv3x3<false>(acc, smem + RB_IMG, b_base, r1, lane * 16, wbase);         // input gradient of conv_1
+      for (int g = 0; g < 4; g++) m[t][g] = *reinterpret_cast<const bf16x4*>(xin + own_g + t * 32 * RB_C + 8 * g);
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-      const bf16x4 ds = *reinterpret_cast<const bf16x4*>(smem + own + 16 * g);    // + dy along the identity shortcut
-      bf16x4 o;
+    for (int t = 0; t < TPW; t++)
 #pragma unroll
-      for (int e = 0; e < 4; e++) o[e] = f2bf((bf2f(m[g][e]) > 0.f ? acc[4 * g + e] : 0.f) + bf2f(ds[e]));
-      *reinterpret_cast<bf16x4*>(smem + own + 16 * g) = o;
-    }
+      for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+    res_conv3x3<false, TPW, PF>(acc, ring, smem + RB_IMG, b_base, r1, r3, more, lane * 16, wbase);         // input gradient of conv_1
+#pragma unroll
+    for (int t = 0; t < TPW; t++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const bf16x4 ds = *reinterpret_cast<const bf16x4*>(smem + own + 4 * t * RB_RPB + 16 * g);    // + dy along the identity shortcut
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] = f2bf((bf2f(m[t][g][e]) > 0.f ? acc[t][4 * g + e] : 0.f) + bf2f(ds[e]));
+        *reinterpret_cast<bf16x4*>(smem + own + 4 * t * RB_RPB + 16 * g) = o;
+      }
     __syncthreads();                                                              // image A = dx complete
-    if (dx) res_store_image(smem, dx + n * 64 * RB_C, tid);
+    if (dx) res_store_image<NT>(smem, dx + n * 64 * RB_C, tid);
   }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
+static int res8_cfg() {          // experiment knob GANK_RES8_CFG = 10*TPW + {1: 8, 2: 12, 3: 24 fragments in flight}: 12 = 8 waves, 12 in flight (default)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("GANK_RES8_CFG"); v = e ? atoi(e) : 12; }
+  return v;
+}
+template <int TPW, int PF>
+static int res8_launch_fwd(const ResFwdArgs& a, hipStream_t s) {
+  GANK_MAX_DYNAMIC_LDS((res8_chain_fwd_kernel<TPW, PF>), RB_LDS, "res8_chain_fwd");
+  hipLaunchKernelGGL((res8_chain_fwd_kernel<TPW, PF>), dim3(a.N), dim3(512 / TPW), RB_LDS, s, a);
+  return 0;
+}
+template <int TPW, int PF>
+static int res8_launch_bwd(const ResBwdArgs& a, hipStream_t s) {
+  GANK_MAX_DYNAMIC_LDS((res8_chain_bwd_kernel<TPW, PF>), RB_LDS, "res8_chain_bwd");
+  hipLaunchKernelGGL((res8_chain_bwd_kernel<TPW, PF>), dim3(a.N), dim3(512 / TPW), RB_LDS, s, a);
+  return 0;
+}
+#define RES8_DISPATCH(fn, a, s)                                      \
+  switch (res8_cfg()) {                                              \
+    case 11: rc = fn<1, 8>(a, s); break;                             \
+    case 13: rc = fn<1, 24>(a, s); break;                            \
+    case 21: rc = fn<2, 8>(a, s); break;                             \
+    case 22: rc = fn<2, 12>(a, s); break;                            \
+    case 23: rc = fn<2, 24>(a, s); break;                            \
+    default: rc = fn<1, 12>(a, s); break;                            \
+  }
+
 extern "C" int gank_res8_chain_fwd(const void* x, const void* const* w_rfrag, const float* const* bias, void* const* h1,
                                    void* const* y, void* pooled, int N, int C, int nblocks, void* stream) {
   GANK_REQUIRE(x && w_rfrag && bias && h1 && y && N > 0, "res8_chain_fwd: null pointer");
@@ -248,13 +333,14 @@ extern "C" int gank_res8_chain_fwd(const void* x, const void* const* w_rfrag, co
   for (int b = 0; b < nblocks; b++) { a.h1[b] = (bf16*)h1[b]; a.y[b] = (bf16*)y[b]; }
   GANK_REQUIRE(a.y[nblocks - 1] || a.pooled, "res8_chain_fwd: no output requested");
   hipStream_t s = (hipStream_t)stream;
-  GANK_MAX_DYNAMIC_LDS(res8_chain_fwd_kernel, RB_LDS, "res8_chain_fwd");
   // algorithmic bytes: x, every weight once, every tensor written once
   gank_prof_begin(0, 2.0 * nblocks * 2.0 * N * 64.0 * RB_C * 9.0 * RB_C, s,
                   2.0 * N * 64.0 * RB_C * (1 + 2 * nblocks) + 2.0 * nblocks * RB_WBYTES);
   gank_prof_tag(0, "res8_chain_fwd_kernel");
-  hipLaunchKernelGGL(res8_chain_fwd_kernel, dim3(N), dim3(512), RB_LDS, s, a);
+  int rc = 0;
+  RES8_DISPATCH(res8_launch_fwd, a, s);
   gank_prof_end(0, s);
+  if (rc) return rc;
   GANK_LAUNCH_OK("res8_chain_fwd");
   return 0;
 }
@@ -278,12 +364,13 @@ extern "C" int gank_res8_chain_bwd(const void* dy, const void* dpool, const void
   }
   GANK_REQUIRE(a.dx[nblocks - 1], "res8_chain_bwd: the chain's input gradient has no destination");
   hipStream_t s = (hipStream_t)stream;
-  GANK_MAX_DYNAMIC_LDS(res8_chain_bwd_kernel, RB_LDS, "res8_chain_bwd");
   gank_prof_begin(0, 2.0 * nblocks * 2.0 * N * 64.0 * RB_C * 9.0 * RB_C, s,
                   2.0 * N * 64.0 * RB_C * (1 + 4 * nblocks) + 2.0 * nblocks * RB_WBYTES);
   gank_prof_tag(0, "res8_chain_bwd_kernel");
-  hipLaunchKernelGGL(res8_chain_bwd_kernel, dim3(N), dim3(512), RB_LDS, s, a);
+  int rc = 0;
+  RES8_DISPATCH(res8_launch_bwd, a, s);
   gank_prof_end(0, s);
+  if (rc) return rc;
   GANK_LAUNCH_OK("res8_chain_bwd");
   return 0;
 }
