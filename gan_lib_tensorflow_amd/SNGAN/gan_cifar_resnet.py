@@ -90,6 +90,8 @@ def _d_prep_kind(name, W):
     if W.dim() == 2 and W.numel() <= 65536:
         return None
     if Fn.POOL_CONV4 and name.endswith(('D.Block.1.Conv2/Filters', 'D.Block.2.Conv2/Filters')):
+        if Fn.CPOOL_RESIDENT and W.dim() == 4 and W.shape[3] == 128 and W.shape[2] % 128 == 0:
+            return 5           # resident ConvMeanPool kernels (geometry of both critic layers: pooled 16x16 and 8x8)
         return 2
     if Fn.FRAG_PATCH and name.endswith('D.Block.2.Conv1/Filters'):      # plain 3x3 256->256 at 16x16
         return 3

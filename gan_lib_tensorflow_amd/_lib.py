@@ -50,6 +50,8 @@ PROTOTYPES = {
     "gank_convpool3x3_wgrad": [P, P, P, P, P, I, I, I, I, I, I, P],
     "gank_res8_chain_fwd": [P, P, P, P, P, P, I, I, I, P],
     "gank_res8_chain_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "gank_cpool_res_fprop": [P, P, P, P, P, I, I, I, I, I, I, P],
+    "gank_cpool_res_dgrad": [P, P, P, P, I, I, I, I, I, P],
     "gank_deconv2d_fprop": [P, P, P, P, I, I, I, I, I, I, P],
     "gank_deconv2d_dgrad": [P, P, P, I, I, I, I, I, I, P],
     "gank_deconv2d_wgrad": [P, P, P, I, I, I, I, I, I, P],

@@ -374,3 +374,318 @@ extern "C" int gank_res8_chain_bwd(const void* dy, const void* dpool, const void
   GANK_LAUNCH_OK("res8_chain_bwd");
   return 0;
 }
+
+// ==================================================================================================================
+// ConvMeanPool 3x3 (gan_cifar_resnet.py:112-123) on resident images: fprop = 4x4 stride-2 conv, dgrad = its transposed
+// conv as 4 output phases of 2x2 taps (same algebra as gank_convpool3x3_*; operands: prep kind 5).
+//
+// The implicit-GEMM forms gathered every tap from HBM/L2 again: 16 taps x 33.5 MB for D.Block.1.Conv2 at n = 128
+// (51.7 us, 0.33 PFLOP/s; 89.8 MB of HBM traffic for 42 MB of operands).  Here a workgroup owns a patch of POOLED pixels
+// (8 x 16 or 8 x 8), stages the input region it needs ONCE per 64-channel chunk -- as four parity planes
+// plane[(r & 1, c & 1)][r >> 1][c >> 1], so a stride-2 tap becomes a unit-stride read of one plane -- and runs all 16
+// taps of the chunk out of LDS with no barrier in between; weights stream from L2 in fragment order (one 1 KB request
+// per A fragment, ring of 12 in flight).  Wave (ct, pg): 32 output channels x TPW 32-pixel tiles.
+// Pitches: pixel 144 B (64 ch + 16 B = 9 sixteen-byte units, odd => consecutive pixels take distinct bank slots), plane
+// row pitch = 0 mod 256 B for 16-wide tiles (2 rows x 16 columns) and 128 mod 256 B for 8-wide tiles (4 rows x 8
+// columns): every 16-lane group of a ds_read_b128 then covers 16 distinct slots.
+// ==================================================================================================================
+namespace {
+constexpr int CP_PP = 144;                           // pixel pitch (bytes) of a 64-channel chunk image
+
+template <int PW> struct CpGeom {
+  static constexpr int PHH = 8;                      // pooled patch rows
+  static constexpr int PLW = PW + 1, PLH = PHH + 1;  // plane size (pixels)
+  static constexpr int RP = PW == 16 ? 2560 : 1408;  // plane row pitch: 17*144 = 2448 -> 2560 (0 mod 256); 9*144 = 1296 -> 1408 (128 mod 256)
+  static constexpr int PLANE = PLH * RP;
+  static constexpr int IMG = 4 * PLANE;              // 92160 / 50688 bytes
+  static constexpr int TROWS = 32 / PW;              // patch rows per 32-pixel tile
+};
+
+struct CpFwdArgs {
+  const bf16* x;          // [N, 2Hp, 2Wp, Cin]
+  const bf16* w;          // rfrag: [Cout/32][Cin/64][16 taps][4 kk][64][8]
+  const float* bias;      // optional [Cout]
+  const bf16* res;        // optional residual at pooled resolution [N,Hp,Wp,Cout]
+  bf16* y;                // [N,Hp,Wp,Cout]
+  int N, Hp, Wp, Cin, Cout, relu;
+};
+
+struct CpBwdArgs {
+  const bf16* dy;         // [N,Hp,Wp,Cout]
+  const bf16* w;          // rfrag: [4 phases][Cin/32][Cout/64][4 taps][4 kk][64][8]
+  const bf16* mask;       // optional relu reference [N,2Hp,2Wp,Cin]
+  bf16* dx;               // [N,2Hp,2Wp,Cin]
+  int N, Hp, Wp, Cin, Cout;
+};
+}  // namespace
+
+// fprop: 8 waves = (Cout tile ct = wave & 3) x (pixel group pg = wave >> 2); a workgroup covers 128 output channels
+template <int PW, int TPW, int PF>
+__global__ __launch_bounds__(512) void cpool_res_fprop_kernel(CpFwdArgs a) {
+  using G = CpGeom<PW>;
+  static_assert(2 * TPW * G::TROWS == G::PHH, "8 waves = 4 channel tiles x 2 pixel groups must tile the patch");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = wave & 3, pg = wave >> 2;
+  const int r = lane & 31, h = lane >> 5;
+  const int pw_n = a.Wp / PW, ph_n = a.Hp / G::PHH, cgroups = a.Cout >> 7;
+  int bid = blockIdx.x;
+  const int cg = bid % cgroups; bid /= cgroups;
+  const int n = bid / (pw_n * ph_n), pr = bid - n * pw_n * ph_n;
+  const int py0 = (pr / pw_n) * G::PHH, px0 = (pr % pw_n) * PW;          // pooled patch origin
+  const int nchunks = a.Cin >> 6;
+  const int H2 = 2 * a.Hp, W2 = 2 * a.Wp;
+
+  // this lane's pixel inside a tile, and its B-fragment base inside plane (0,0): (row, col) + h*16 bytes
+  const int trow = PW == 16 ? (r >> 4) : (r >> 3), tcol = PW == 16 ? (r & 15) : (r & 7);
+  const int b_base = (pg * TPW * G::TROWS + trow) * G::RP + tcol * CP_PP + h * 16;
+
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w), 0, a.Cout * 16 * a.Cin * 2, 0x00020000);
+  const int wbase = (cg * 4 + ct) * nchunks * 64 * 1024;                  // 64 steps (16 taps x 4 kk) of 1 KB per chunk
+  const int nsteps = nchunks * 64;
+  u32x4 ring[PF];
+#pragma unroll
+  for (int s = 0; s < PF; s++) ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, wbase + (s < nsteps ? s : nsteps - 1) * 1024, 0);
+
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; t++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+
+  // staging: the (2*PHH + 2) x (2*PW + 2) input pixels of the patch, 8 sixteen-byte pieces (64 channels) per pixel
+  constexpr int HR = 2 * G::PHH + 2, HC = 2 * PW + 2, NPIECE = HR * HC * 8;
+  constexpr int NLD = (NPIECE + 511) / 512;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, a.N * H2 * W2 * a.Cin * 2, 0x00020000);
+  constexpr int OOB = 0x7FFFFFF0;
+
+  int step = 0;
+#pragma unroll 1
+  for (int c = 0; c < nchunks; c++) {
+    if (c > 0) __syncthreads();                                           // every wave is done reading the previous chunk's image
+#pragma unroll
+    for (int j = 0; j < NLD; j++) {
+      const int q = tid + j * 512;
+      if (NPIECE % 512 == 0 || q < NPIECE) {
+        const int hp = q >> 3, c16 = q & 7;
+        const int hr = hp / HC, hc = hp - hr * HC;                        // halo row / column: input pixel (2*py0 - 1 + hr, 2*px0 - 1 + hc)
+        const int iy = 2 * py0 - 1 + hr, ix = 2 * px0 - 1 + hc;
+        const bool ok = (unsigned)iy < (unsigned)H2 && (unsigned)ix < (unsigned)W2;
+        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (((n * H2 + iy) * W2 + ix) * a.Cin + c * 64 + c16 * 8) * 2 : OOB, 0, 0);
+        if (a.relu) v = relu_bf16x8(v);
+        *reinterpret_cast<u32x4*>(smem + ((hr & 1) * 2 + (hc & 1)) * G::PLANE + (hr >> 1) * G::RP + (hc >> 1) * CP_PP + c16 * 16) = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 64; s++, step++) {
+      const int tap = s >> 2, kk = s & 3, ta = tap >> 2, tb = tap & 3;
+      const bf16x8 fa = __builtin_bit_cast(bf16x8, ring[s % PF]);
+      static_assert(64 % PF == 0, "ring position is chunk-invariant");
+      {
+        const int nx = step + PF;
+        ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, wbase + (nx < nsteps ? nx : nsteps - 1) * 1024, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < TPW; t++) {
+        const bf16x8 fb = *reinterpret_cast<const bf16x8*>(smem + b_base + ((ta & 1) * 2 + (tb & 1)) * G::PLANE +
+                                                             (t * G::TROWS + (ta >> 1)) * G::RP + (tb >> 1) * CP_PP + kk * 32);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
+      }
+    }
+  }
+
+  // epilogue: lane holds channels co0 + 8g + 4h .. +3 of one pooled pixel per quad g
+#pragma unroll
+  for (int t = 0; t < TPW; t++) {
+    const int py = py0 + (pg * TPW + t) * G::TROWS + trow, px = px0 + tcol;
+    const long m = ((long)n * a.Hp + py) * a.Wp + px;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const int co = cg * 128 + ct * 32 + 8 * g + 4 * h;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) v[e] = acc[t][4 * g + e];
+      if (a.bias) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] += bb[e];
+      }
+      if (a.res) {
+        const bf16x4 rs = *reinterpret_cast<const bf16x4*>(a.res + m * a.Cout + co);
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] += bf2f(rs[e]);
+      }
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; e++) o[e] = f2bf(v[e]);
+      *reinterpret_cast<bf16x4*>(a.y + m * a.Cout + co) = o;
+    }
+  }
+}
+
+// dgrad: dx[n, 2y+pa, 2x+pb, ci] = sum_{i,j in {0,1}} sum_co dy[n, y+i-(1-pa), x+j-(1-pb), co] * Wph[pa,pb][ci][(i,j),co].
+// The dy patch (+1 halo) with Cout = 128 channels stays in LDS for all four phases (pixel pitch 272 B); a workgroup covers
+// 128 of the Cin "output" channels; wave (ct, pg) as above.
+namespace {
+template <int PW> struct CdGeom {
+  static constexpr int PHH = 8;
+  static constexpr int PP = 272;                                   // 128 channels + 16 B = 17 units
+  static constexpr int RP = PW == 16 ? 5120 : 2944;                // 18*272 = 4896 -> 5120 (0 mod 256); 10*272 = 2720 -> 2944 (128 mod 256)
+  static constexpr int IMG = (PHH + 2) * RP;                       // 51200 / 29440
+  static constexpr int TROWS = 32 / PW;
+};
+}  // namespace
+
+template <int PW, int TPW, int PF>
+__global__ __launch_bounds__(512) void cpool_res_dgrad_kernel(CpBwdArgs a) {
+  using G = CdGeom<PW>;
+  static_assert(2 * TPW * G::TROWS == G::PHH, "8 waves = 4 channel tiles x 2 pixel groups must tile the patch");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = wave & 3, pg = wave >> 2;
+  const int r = lane & 31, h = lane >> 5;
+  const int pw_n = a.Wp / PW, ph_n = a.Hp / G::PHH, cgroups = a.Cin >> 7;
+  int bid = blockIdx.x;
+  const int cg = bid % cgroups; bid /= cgroups;
+  const int n = bid / (pw_n * ph_n), pr = bid - n * pw_n * ph_n;
+  const int py0 = (pr / pw_n) * G::PHH, px0 = (pr % pw_n) * PW;
+  const int trow = PW == 16 ? (r >> 4) : (r >> 3), tcol = PW == 16 ? (r & 15) : (r & 7);
+  const int b_base = (pg * TPW * G::TROWS + trow) * G::RP + tcol * G::PP + h * 16;      // halo pixel (row, col): dy pixel (py0-1+row, px0-1+col)
+
+  // operand: [phase][Cin/32][4 taps][Cout/16 kk][64][8]; Cout == 128 -> 32 steps of 1 KB per (phase, tile)
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w), 0, 4 * a.Cin * 4 * a.Cout * 2, 0x00020000);
+  const int tiles = a.Cin >> 5, tile = cg * 4 + ct;
+  auto wofs = [&](int phase, int s) { return ((phase * tiles + tile) * 32 + s) * 1024; };
+  u32x4 ring[PF];
+  static_assert(32 % PF == 0, "ring position is phase-invariant");
+#pragma unroll
+  for (int s = 0; s < PF; s++) ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, wofs(0, s), 0);
+
+  // stage the dy halo: (PHH + 2) x (PW + 2) pixels x 16 pieces
+  constexpr int HR = G::PHH + 2, HC = PW + 2, NPIECE = HR * HC * 16;
+  constexpr int NLD = (NPIECE + 511) / 512;
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.dy), 0, a.N * a.Hp * a.Wp * a.Cout * 2, 0x00020000);
+  constexpr int OOB = 0x7FFFFFF0;
+#pragma unroll
+  for (int j = 0; j < NLD; j++) {
+    const int q = tid + j * 512;
+    if (NPIECE % 512 == 0 || q < NPIECE) {
+      const int hp = q >> 4, c16 = q & 15;
+      const int hr = hp / HC, hc = hp - hr * HC;
+      const int iy = py0 - 1 + hr, ix = px0 - 1 + hc;
+      const bool ok = (unsigned)iy < (unsigned)a.Hp && (unsigned)ix < (unsigned)a.Wp;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ry, ok ? (((n * a.Hp + iy) * a.Wp + ix) * a.Cout + c16 * 8) * 2 : OOB, 0, 0);
+      *reinterpret_cast<u32x4*>(smem + hr * G::RP + hc * G::PP + c16 * 16) = v;
+    }
+  }
+  __syncthreads();
+
+  const int H2 = 2 * a.Hp, W2 = 2 * a.Wp;
+#pragma unroll 1
+  for (int phase = 0; phase < 4; phase++) {
+    const int pa = phase >> 1, pb = phase & 1;
+    const int poff = pa * G::RP + pb * G::PP;                  // tap (i, j) reads halo pixel (y + i + pa, x + j + pb)
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; t++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; s++) {
+      const int tap = s >> 3, kk = s & 7, ti = tap >> 1, tj = tap & 1;
+      const bf16x8 fa = __builtin_bit_cast(bf16x8, ring[s % PF]);
+      {
+        const int nx = s + PF;
+        const int np = nx < 32 ? phase : (phase < 3 ? phase + 1 : 3), ns = nx < 32 ? nx : (phase < 3 ? nx - 32 : 31);
+        ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, wofs(np, ns), 0);
+      }
+#pragma unroll
+      for (int t = 0; t < TPW; t++) {
+        const bf16x8 fb = *reinterpret_cast<const bf16x8*>(smem + b_base + poff + (t * G::TROWS + ti) * G::RP + tj * G::PP + kk * 32);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; t++) {
+      const int y = py0 + (pg * TPW + t) * G::TROWS + trow, x = px0 + tcol;
+      const long m = ((long)n * H2 + 2 * y + pa) * W2 + 2 * x + pb;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int ci = cg * 128 + ct * 32 + 8 * g + 4 * h;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = acc[t][4 * g + e];
+        if (a.mask) {
+          const bf16x4 mk = *reinterpret_cast<const bf16x4*>(a.mask + m * a.Cin + ci);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = bf2f(mk[e]) > 0.f ? v[e] : 0.f;
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] = f2bf(v[e]);
+        *reinterpret_cast<bf16x4*>(a.dx + m * a.Cin + ci) = o;
+      }
+    }
+  }
+}
+
+static bool cpool_res_geom_ok(int Hp, int Wp) { return Hp % 8 == 0 && (Wp % 16 == 0 || Wp == 8); }
+
+extern "C" int gank_cpool_res_fprop(const void* x, const void* w_rfrag, const float* bias, const void* residual, void* y, int N, int Hp,
+                                    int Wp, int Cin, int Cout, int flags, void* stream) {
+  GANK_REQUIRE(x && w_rfrag && y && N > 0, "cpool_res_fprop: null pointer");
+  GANK_REQUIRE(Cin % 64 == 0 && Cout % 128 == 0 && cpool_res_geom_ok(Hp, Wp),
+               "cpool_res_fprop: needs Cin %% 64 == 0, Cout %% 128 == 0, Hp %% 8 == 0 and Wp %% 16 == 0 or Wp == 8 (got %d, %d, %dx%d)", Cin, Cout, Hp, Wp);
+  GANK_REQUIRE((long)N * 4 * Hp * Wp * Cin < (1L << 30) && (long)Cout * 16 * Cin * 2 < (1L << 31), "cpool_res_fprop: tensor too large (32-bit byte offsets)");
+  CpFwdArgs a{};
+  a.x = (const bf16*)x; a.w = (const bf16*)w_rfrag; a.bias = bias; a.res = (const bf16*)residual; a.y = (bf16*)y;
+  a.N = N; a.Hp = Hp; a.Wp = Wp; a.Cin = Cin; a.Cout = Cout; a.relu = (flags & GANK_IN_RELU) ? 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  const double M = (double)N * Hp * Wp;
+  gank_prof_begin(0, 2.0 * M * Cout * 16.0 * Cin, s, 2.0 * (4.0 * M * Cin + 16.0 * Cin * Cout + M * Cout));
+  if (Wp % 16 == 0) {
+    const int grid = N * (Hp / 8) * (Wp / 16) * (Cout / 128);
+    GANK_MAX_DYNAMIC_LDS((cpool_res_fprop_kernel<16, 2, 8>), CpGeom<16>::IMG, "cpool_res_fprop");
+    gank_prof_tag(0, "cpool_res_fprop_kernel<16, 2, 8>");
+    hipLaunchKernelGGL((cpool_res_fprop_kernel<16, 2, 8>), dim3(grid), dim3(512), CpGeom<16>::IMG, s, a);
+  } else {
+    const int grid = N * (Hp / 8) * (Cout / 128);
+    GANK_MAX_DYNAMIC_LDS((cpool_res_fprop_kernel<8, 1, 8>), CpGeom<8>::IMG, "cpool_res_fprop");
+    gank_prof_tag(0, "cpool_res_fprop_kernel<8, 1, 8>");
+    hipLaunchKernelGGL((cpool_res_fprop_kernel<8, 1, 8>), dim3(grid), dim3(512), CpGeom<8>::IMG, s, a);
+  }
+  gank_prof_end(0, s);
+  GANK_LAUNCH_OK("cpool_res_fprop");
+  return 0;
+}
+
+extern "C" int gank_cpool_res_dgrad(const void* dy, const void* w_rfrag, const void* relu_ref, void* dx, int N, int Hp, int Wp, int Cin,
+                                    int Cout, void* stream) {
+  GANK_REQUIRE(dy && w_rfrag && dx && N > 0, "cpool_res_dgrad: null pointer");
+  GANK_REQUIRE(Cout == 128 && Cin % 128 == 0 && cpool_res_geom_ok(Hp, Wp),
+               "cpool_res_dgrad: needs Cout == 128, Cin %% 128 == 0, Hp %% 8 == 0 and Wp %% 16 == 0 or Wp == 8 (got %d, %d, %dx%d)", Cout, Cin, Hp, Wp);
+  GANK_REQUIRE((long)N * 4 * Hp * Wp * Cin < (1L << 30), "cpool_res_dgrad: tensor too large (32-bit byte offsets)");
+  CpBwdArgs a{};
+  a.dy = (const bf16*)dy; a.w = (const bf16*)w_rfrag; a.mask = (const bf16*)relu_ref; a.dx = (bf16*)dx;
+  a.N = N; a.Hp = Hp; a.Wp = Wp; a.Cin = Cin; a.Cout = Cout;
+  hipStream_t s = (hipStream_t)stream;
+  const double M = (double)N * Hp * Wp;
+  gank_prof_begin(0, 2.0 * M * 4.0 * Cin * 4.0 * Cout, s, 2.0 * (M * Cout + 16.0 * Cin * Cout + 4.0 * M * Cin));
+  if (Wp % 16 == 0) {
+    const int grid = N * (Hp / 8) * (Wp / 16) * (Cin / 128);
+    GANK_MAX_DYNAMIC_LDS((cpool_res_dgrad_kernel<16, 2, 8>), CdGeom<16>::IMG, "cpool_res_dgrad");
+    gank_prof_tag(0, "cpool_res_dgrad_kernel<16, 2, 8>");
+    hipLaunchKernelGGL((cpool_res_dgrad_kernel<16, 2, 8>), dim3(grid), dim3(512), CdGeom<16>::IMG, s, a);
+  } else {
+    const int grid = N * (Hp / 8) * (Cin / 128);
+    GANK_MAX_DYNAMIC_LDS((cpool_res_dgrad_kernel<8, 1, 8>), CdGeom<8>::IMG, "cpool_res_dgrad");
+    gank_prof_tag(0, "cpool_res_dgrad_kernel<8, 1, 8>");
+    hipLaunchKernelGGL((cpool_res_dgrad_kernel<8, 1, 8>), dim3(grid), dim3(512), CdGeom<8>::IMG, s, a);
+  }
+  gank_prof_end(0, s);
+  GANK_LAUNCH_OK("cpool_res_dgrad");
+  return 0;
+}

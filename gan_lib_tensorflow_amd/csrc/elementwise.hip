@@ -296,6 +296,55 @@ __global__ void prep_batch_kernel(PrepTable t) {
       }
       *reinterpret_cast<bf16x8*>(dst + q * 8) = o;
     }
+  } else if (d.kind == 5) {
+    // ConvMeanPool 3x3 operands of the resident kernels (conv_resident.hip), one 16-byte chunk per thread:
+    //   wf [Cout/32][Cin/64][16 taps][4 kk][64 lanes][8]   = W4[tap][ci][co]        (the 4x4 stride-2 kernel, x 1/4)
+    //   wd [4 phases][Cin/32][4 taps][Cout/16 kk][64][8]   = Wph[phase][ci][tap,co]  (its transposed conv by output phase)
+    // same tap algebra as kind 2 (gank_convpool3x3_prep_weights).
+    const bool isf = b < t.nwf[e];
+    const long q = (long)(isf ? b : b - t.nwf[e]) * 256 + threadIdx.x;
+    const long nchunk = 2L * d.Cin * d.Cout;                 // 16 * Cin * Cout / 8 sixteen-byte chunks, both operands
+    if (q < nchunk) {
+      const int lane = (int)(q & 63), r = lane & 31, hh = lane >> 5;
+      long u = q >> 6;
+      bf16x8 o;
+      if (isf) {
+        const int kk = (int)(u & 3); u >>= 2;
+        const int tap = (int)(u & 15); u >>= 4;
+        const int nch = d.Cin >> 6;
+        const int chunk = (int)(u % nch), co = (int)(u / nch) * 32 + r;
+        int h0, h1, w0, w1;
+        up_range_S(tap >> 2, h0, h1);
+        up_range_S(tap & 3, w0, w1);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int ci = chunk * 64 + kk * 16 + hh * 8 + j;
+          float v = 0.f;
+          for (int dh = h0; dh <= h1; dh++)
+            for (int dw = w0; dw <= w1; dw++) v += d.w[((long)((2 - dh) * 3 + (2 - dw)) * d.Cin + ci) * d.Cout + co];
+          o[j] = f2bf(0.25f * v);
+        }
+        *reinterpret_cast<bf16x8*>((bf16*)d.wf + q * 8) = o;
+      } else {
+        const int nkk = d.Cout >> 4;
+        const int kk = (int)(u % nkk); u /= nkk;
+        const int tap = (int)(u & 3); u >>= 2;
+        const int tiles = d.Cin >> 5;
+        const int ci = (int)(u % tiles) * 32 + r, phase = (int)(u / tiles);
+        int h0, h1, w0, w1;
+        up_range_R(phase >> 1, tap >> 1, h0, h1);
+        up_range_R(phase & 1, tap & 1, w0, w1);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int co = kk * 16 + hh * 8 + j;
+          float v = 0.f;
+          for (int dh = h0; dh <= h1; dh++)
+            for (int dw = w0; dw <= w1; dw++) v += d.w[((long)((2 - dh) * 3 + (2 - dw)) * d.Cin + ci) * d.Cout + co];
+          o[j] = f2bf(0.25f * v);
+        }
+        *reinterpret_cast<bf16x8*>((bf16*)d.wd + q * 8) = o;
+      }
+    }
   } else if (b < t.nwf[e]) {
     const int K = taps * d.Cin, Kpad = (K + 63) / 64 * 64, CoutPad = (d.Cout + 31) / 32 * 32;
     __shared__ float tl[32][33];
@@ -346,8 +395,9 @@ extern "C" int gank_conv2d_prep_weights_batched(const gank_prep_desc* table, int
       const gank_prep_desc& d = table[base + i];
       GANK_REQUIRE(d.w && (d.wf || d.wd) && d.ksize >= 1 && d.Cin > 0 && d.Cout > 0, "prep_weights_batched: bad entry %d", base + i);
       GANK_REQUIRE(d.kind == 0 || ((d.kind == 1 || d.kind == 2) && d.ksize == 3 && d.wf && d.wd) ||
-                   (d.kind == 3 && d.Cin % 64 == 0 && d.Cout % 64 == 0) || (d.kind == 4 && d.Cin % 32 == 0 && d.Cout % 32 == 0),
-                   "prep_weights_batched: entry %d: kind %d needs ksize 3 and both outputs (1, 2) / channels %% 64 == 0 (3) / %% 32 == 0 (4)", base + i, d.kind);
+                   (d.kind == 3 && d.Cin % 64 == 0 && d.Cout % 64 == 0) || (d.kind == 4 && d.Cin % 32 == 0 && d.Cout % 32 == 0) ||
+                   (d.kind == 5 && d.ksize == 3 && d.wf && d.wd && d.Cin % 64 == 0 && d.Cout % 32 == 0),
+                   "prep_weights_batched: entry %d: kind %d needs ksize 3 and both outputs (1, 2, 5) / channels %% 64 == 0 (3) / %% 32 == 0 (4) / Cin %% 64 == 0 (5)", base + i, d.kind);
       t.d[i] = d;
       const int taps = d.ksize * d.ksize;
       int nwf = d.wf ? (roundup(taps * d.Cin, 64) / 32) * (roundup(d.Cout, 32) / 32) : 0;
@@ -358,6 +408,7 @@ extern "C" int gank_conv2d_prep_weights_batched(const gank_prep_desc* table, int
         nwf = sp.ntiles;
         nwd = sp.nelem;
       }
+      if (d.kind == 5) nwf = nwd = cdiv(2L * d.Cin * d.Cout, 256);
       if (d.kind == 4) {          // one 16-byte chunk per thread
         nwf = d.wf ? cdiv((long)d.Cout * taps * d.Cin / 8, 256) : 0;
         nwd = d.wd ? cdiv((long)d.Cin * taps * d.Cout / 8, 256) : 0;

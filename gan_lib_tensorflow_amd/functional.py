@@ -19,6 +19,7 @@ BF16 = torch.bfloat16
 # chip under DVFS), so the simpler operand layout stays the default
 FRAG_PATCH = False
 POOL_CONV4 = True     # 3x3 conv + 2x2 mean pool as one 4x4 stride-2 conv (4 instead of 9 taps per conv output)
+CPOOL_RESIDENT = True   # ... on the LDS-resident kernels where they apply (prep kind 5; kernels.cpool_res_ok)
 PHASE_UPCONV = True   # NN-upsample+3x3 conv as a phase-decomposed transposed conv (4 instead of 9 taps)
 
 
@@ -148,6 +149,8 @@ class _Conv2d(Function):
         if phase:
             wph, _ = getattr(W, "_prep_up", None) or K.upconv3x3_prep(W.detach().view(3, 3, cin, cout))
             y = K.upconv3x3_fprop(x, wph, b, cout, K.OUT_TANH if out_tanh else 0, residual)
+        elif pool4 and getattr(W, "_prep_cpres", None) is not None:       # resident form (conv_resident.hip)
+            y = K.cpool_res_fprop(x, W._prep_cpres[0], b, cout, K.IN_RELU if in_relu else 0, residual)
         elif pool4:
             wp4, _ = getattr(W, "_prep_pool", None) or K.convpool3x3_prep(W.detach().view(3, 3, cin, cout))
             y = K.convpool3x3_fprop(x, wp4, b, cout, K.IN_RELU if in_relu else 0, residual)
@@ -206,6 +209,8 @@ class _Conv2d(Function):
         if ctx.needs_input_grad[0] and phase:
             prep = getattr(W, "_prep_up", None) or K.upconv3x3_prep(W.detach().view(3, 3, cin, cout))
             dx = K.upconv3x3_dgrad(g, prep[1], cin)       # 4x4 stride-2 conv of dy: no hi-res dgrad, no 2x2 sum
+        elif ctx.needs_input_grad[0] and pool4 and getattr(W, "_prep_cpres", None) is not None:
+            dx = K.cpool_res_dgrad(g, W._prep_cpres[1], cin, x if in_relu else None)
         elif ctx.needs_input_grad[0] and pool4:
             prep = getattr(W, "_prep_pool", None) or K.convpool3x3_prep(W.detach().view(3, 3, cin, cout))
             dx = K.convpool3x3_dgrad(g, prep[1], cin, x if in_relu else None)

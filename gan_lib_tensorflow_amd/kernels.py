@@ -51,6 +51,7 @@ def prep_weights_batched(ws, want_d=True, kinds=None):
     `w._prep = (wf, wd)`; 1 = UpsampleConv 3x3 -> `w._prep_up = (wph, wd4)`; 2 = ConvMeanPool 3x3 ->
     `w._prep_pool = (wp4, wphd)`; 3 = plain + fragment-major copies for the register-weight patch kernel (the conv
     wrappers pass GANK_W_FRAG when they see them); 4 = "rfrag" operands of the resident kernels -> `w._prep_res = (rf, rd)`;
+    5 = ConvMeanPool 3x3 operands of the resident kernels -> `w._prep_cpres = (rf, rd)`;
     None = skip (the layer prepares nothing).  The conv wrappers pick the attributes up
     and skip their own per-layer preparation.  Buffers persist on the tensor and are rewritten IN PLACE on later
     calls: captured graphs keep reading the same addresses."""
@@ -90,6 +91,10 @@ def prep_weights_batched(ws, want_d=True, kinds=None):
             assert k == 3 and cin % 32 == 0 and cout % 32 == 0
             wf, wd = getattr(w, "_prep_res", None) or (torch.empty(taps * cin * cout, dtype=BF16, device=dev),
                                                       torch.empty(taps * cin * cout, dtype=BF16, device=dev) if want_d else None)
+        elif kind == 5:
+            assert k == 3 and cin % 64 == 0 and cout % 32 == 0
+            wf, wd = getattr(w, "_prep_cpres", None) or (torch.empty(16 * cin * cout, dtype=BF16, device=dev),
+                                                        torch.empty(16 * cin * cout, dtype=BF16, device=dev))
         else:
             raise ValueError(f"unknown preparation kind {kind}")
         d = table[i]
@@ -99,7 +104,7 @@ def prep_weights_batched(ws, want_d=True, kinds=None):
     if todo:
         _lib.check(lib().gank_conv2d_prep_weights_batched(table, len(todo), _stream()), "prep_weights_batched")
     for (w, kind), o in zip(todo, outs):
-        setattr(w, ("_prep", "_prep_up", "_prep_pool", "_prep", "_prep_res")[kind], o)
+        setattr(w, ("_prep", "_prep_up", "_prep_pool", "_prep", "_prep_res", "_prep_cpres")[kind], o)
     return outs
 
 
@@ -212,6 +217,27 @@ def convpool3x3_dgrad(dy, wphd, cin, relu_ref=None):
     dx = torch.empty((n, 2 * hp, 2 * wp, cin), dtype=BF16, device=dy.device)
     _lib.check(lib().gank_convpool3x3_dgrad(_p(dy, BF16, "dy"), _p(wphd, BF16), _p(relu_ref, BF16, "relu_ref"), _p(dx),
                                             n, hp, wp, cin, cout, _stream()), "convpool3x3_dgrad")
+    return dx
+
+
+def cpool_res_ok(n, hp, wp, cin, cout):
+    """shapes the resident ConvMeanPool kernels cover (fprop and dgrad)"""
+    return cout == 128 and cin % 128 == 0 and hp % 8 == 0 and (wp % 16 == 0 or wp == 8) and n * 4 * hp * wp * cin < (1 << 30)
+
+
+def cpool_res_fprop(x, rf, bias, cout, flags=0, residual=None):
+    n, h, w, cin = x.shape
+    y = torch.empty((n, h // 2, w // 2, cout), dtype=BF16, device=x.device)
+    _lib.check(lib().gank_cpool_res_fprop(_p(x, BF16, "x"), _p(rf, BF16, "rf"), _p(bias, F32, "bias"), _p(residual, BF16, "residual"),
+                                          _p(y), n, h // 2, w // 2, cin, cout, flags, _stream()), "cpool_res_fprop")
+    return y
+
+
+def cpool_res_dgrad(dy, rd, cin, relu_ref=None):
+    n, hp, wp, cout = dy.shape
+    dx = torch.empty((n, 2 * hp, 2 * wp, cin), dtype=BF16, device=dy.device)
+    _lib.check(lib().gank_cpool_res_dgrad(_p(dy, BF16, "dy"), _p(rd, BF16, "rd"), _p(relu_ref, BF16, "relu_ref"), _p(dx),
+                                          n, hp, wp, cin, cout, _stream()), "cpool_res_dgrad")
     return dx
 
 

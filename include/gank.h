@@ -61,7 +61,10 @@ typedef struct gank_prep_desc {
                        twice the size; Cin % 64 == 0 and Cout % 64 == 0): pass GANK_W_FRAG to fprop / dgrad;
                      4 "rfrag" operands of the resident kernels (gank_res8_chain_*): bf16 [rows/32][taps][k/16][64 lanes][8],
                        lane = 32*h + r holding k = 16*kk + 8*h .. +7 of row 32*tile + r; wf: rows = co, k = ci;
-                       wd: rows = ci, k = co, taps flipped.  Cin % 32 == 0 and Cout % 32 == 0; taps*Cin*Cout elements each */
+                       wd: rows = ci, k = co, taps flipped.  Cin % 32 == 0 and Cout % 32 == 0; taps*Cin*Cout elements each;
+                     5 ConvMeanPool 3x3 operands of the resident kernels (gank_cpool_res_*), 16*Cin*Cout elements each, same
+                       tap algebra as kind 2: wf bf16 [Cout/32][Cin/64][16 taps][4][64 lanes][8] (the 4x4 stride-2 kernel),
+                       wd bf16 [4 phases][Cin/32][4 taps][Cout/16][64][8] (its transposed conv).  Cin % 64 == 0, Cout % 32 == 0 */
 } gank_prep_desc;
 int gank_conv2d_prep_weights_batched(const gank_prep_desc* table, int count, void* stream);
 
@@ -126,6 +129,18 @@ int gank_res8_chain_fwd(const void* x, const void* const* w_rfrag, const float* 
 int gank_res8_chain_bwd(const void* dy, const void* dpool, const void* ylast, void* dy_out, const void* const* wd_rfrag,
                         const void* const* h1, const void* const* xin, void* const* g1, void* const* dx, int N, int C,
                         int nblocks, void* stream);
+
+/* ---- ConvMeanPool 3x3 on LDS-resident images (same arithmetic as gank_convpool3x3_fprop / _dgrad; operands: prep kind 5)
+ * A workgroup owns an 8x16 (or 8x8) patch of POOLED pixels and 128 output channels, stages its input region once per
+ * 64-channel chunk as four parity planes (stride-2 taps become unit-stride LDS reads) and streams the weights from L2 in
+ * MFMA-fragment order: no per-tap re-gather of the input (16 taps x 33.5 MB for D.Block.1.Conv2), no barrier per K-step.
+ *   fprop: x [N,2Hp,2Wp,Cin] -> y [N,Hp,Wp,Cout]; Cin % 64 == 0, Cout % 128 == 0, Hp % 8 == 0, Wp % 16 == 0 or Wp == 8;
+ *          flags: GANK_IN_RELU; bias / residual (pooled resolution) optional
+ *   dgrad: dy [N,Hp,Wp,Cout] -> dx [N,2Hp,2Wp,Cin]; Cout == 128, Cin % 128 == 0; relu_ref optional (masks with relu_ref > 0) */
+int gank_cpool_res_fprop(const void* x, const void* w_rfrag, const float* bias, const void* residual, void* y, int N, int Hp,
+                         int Wp, int Cin, int Cout, int flags, void* stream);
+int gank_cpool_res_dgrad(const void* dy, const void* w_rfrag, const void* relu_ref, void* dx, int N, int Hp, int Wp, int Cin,
+                         int Cout, void* stream);
 
 /* ---- UpsampleConv 3x3 (SNGAN/gan_cifar_resnet.py:140-153) as a stride-2 transposed conv -------------
  * nearest-neighbour 2x followed by a 3x3 SAME conv equals a 4x4 stride-2 transposed conv whose taps are sums

@@ -898,3 +898,40 @@ def test_res8_chain_fused_residual_blocks(K, n, nb, pool):
     with torch.no_grad():
         out2 = Fn.res_chain8(xt, params_t, pool=pool)
     assert torch.equal(out2, out.detach())
+
+
+@pytest.mark.parametrize("n,hp,wp,cin,relu", [(3, 16, 16, 128, True), (2, 8, 8, 256, True), (2, 8, 16, 128, False), (5, 8, 8, 128, False),
+                                              (2, 16, 32, 256, True)])
+def test_convpool3x3_resident_kernels(K, n, hp, wp, cin, relu):
+    """conv_resident.hip: ConvMeanPool 3x3 forward (4x4 stride-2 conv out of parity-plane LDS images) and input gradient
+    (4 phases out of one resident dy patch), prep kind 5 -- against the un-reduced oracle composition
+    mean_pool(conv3x3(relu?(x)) + b) + residual and its gradient, and bit-for-bit against nothing: the implicit-GEMM form
+    (gank_convpool3x3_*) sums the same bf16 products in a different order."""
+    cout = 128
+    rng = np.random.default_rng(n * 11 + hp + wp + cin)
+    x, xt = bf(rng.normal(size=(n, 2 * hp, 2 * wp, cin)))
+    w, _ = bf(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin))
+    b, bt = f32(rng.normal(size=cout))
+    res, rest = bf(rng.normal(size=(n, hp, wp, cout)))
+    wt = torch.tensor(w, dtype=torch.float32).cuda()
+    assert K.cpool_res_ok(n, hp, wp, cin, cout)
+    (rf, rd), = K.prep_weights_batched([wt], want_d=True, kinds=[5])
+    xin = R.relu(x) if relu else x
+    y = K.cpool_res_fprop(xt, rf, bt, cout, K.IN_RELU if relu else 0, rest)
+    ref = R.meanpool2x2(R.conv2d_same(xin, w, b)) + res
+    torch.cuda.synchronize()
+    assert relerr(y, ref) < BF_TOL
+    y2 = K.cpool_res_fprop(xt, rf, None, cout, K.IN_RELU if relu else 0, None)          # no bias, no residual
+    assert relerr(y2, R.meanpool2x2(R.conv2d_same(xin, w))) < BF_TOL
+    dy, dyt = bf(rng.normal(size=(n, hp, wp, cout)))
+    dx_ref, _, _ = R.conv2d_same_grads(xin, w, R.meanpool2x2_grad(dy))
+    if relu:
+        dx_ref = dx_ref * (x > 0)
+    dx = K.cpool_res_dgrad(dyt, rd, cin, xt if relu else None)
+    torch.cuda.synchronize()
+    assert relerr(dx, dx_ref) < BF_TOL
+    # the resident and the implicit-GEMM forms agree to bf16 rounding of the same operands
+    wp4, wphd = K.convpool3x3_prep(wt)
+    y_ig = K.convpool3x3_fprop(xt, wp4, bt, cout, K.IN_RELU if relu else 0, rest)
+    dx_ig = K.convpool3x3_dgrad(dyt, wphd, cin, xt if relu else None)
+    assert relerr(y, y_ig.double().cpu().numpy()) < 1e-2 and relerr(dx, dx_ig.double().cpu().numpy()) < 1e-2
