@@ -80,6 +80,14 @@ def Generator(n_samples_, labels, noise=None, reuse=False, groups=1, rng_state=N
         return output.reshape(-1, OUTPUT_DIM)
 
 
+# The critic's kernels are small (128 samples: a few hundred workgroups, bound by latency and per-CU L2 bandwidth) and
+# leave most of the chip idle; the generator pass that produces the fakes of critic updates 2..N_CRITIC is independent
+# of critic update 1, so it CAN run beside it on a second HIP stream (one fork and one join inside the captured graph).
+# Measured (round 2, interleaved A/B in one gpurun call, 100 iterations each): 7.93-7.99 ms per iteration with the overlap
+# against 7.67 without -- the generator's one-workgroup-per-CU kernels push the critic's kernels off the CUs instead of
+# filling their gaps, and the split pass (64 + 256 samples) is less efficient than one pass over 320.  Kept as a knob
+# (GANK_OVERLAP_GEN=1), off by default.
+OVERLAP_GEN_WITH_CRITIC = False
 BATCH_SMALL_WGRADS = True    # same-shape small filter gradients of an update are issued in one launch
 SIDE_STREAM_WGRAD = False    # filter gradients on a second HIP stream: measured 6 % SLOWER per iteration (the branches contend for L2 and CUs), kept for experiments
 
@@ -200,6 +208,12 @@ class SNGANTrainer:
         self._side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         # data-side RNG differs per rank; parameter init (store seed) is identical on all ranks
         self.rng_state = K.new_rng_state(parallel.data_seed(seed, self.rank), self.device)
+        # the generator pass that runs BESIDE a critic update draws from its own stream of random numbers (two kernels
+        # advancing one {seed, offset} pair concurrently would race)
+        self.rng_state_gen = K.new_rng_state(parallel.data_seed(seed, self.rank) + 104729, self.device)
+        import os
+        self.overlap_gen = (OVERLAP_GEN_WITH_CRITIC if os.environ.get("GANK_OVERLAP_GEN") is None else os.environ["GANK_OVERLAP_GEN"] == "1") \
+            and self.device.type == "cuda"
         self.iteration = 0
         self._build(state)
         self._graphs = {}
@@ -262,6 +276,7 @@ class SNGANTrainer:
             sd[net + '/adam_t'] = np.asarray(int(opt.t.item()), dtype=np.int64)
         sd['_iteration'] = np.asarray(int(self.iteration), dtype=np.int64)
         sd['_rng_state'] = self.rng_state.detach().cpu().numpy().copy()
+        sd['_rng_state_gen'] = self.rng_state_gen.detach().cpu().numpy().copy()
         return sd
 
     def load_state_dict(self, state, strict=True):
@@ -269,7 +284,7 @@ class SNGANTrainer:
         checkpoint carries them and RESET otherwise (a weights-only checkpoint restarts Adam's bias correction, as a
         fresh tf.train.AdamOptimizer would).  Cached operand copies and captured graphs are rebuilt."""
         state = dict(state)
-        extra = {k: state.pop(k) for k in list(state) if k.endswith(('/Adam', '/Adam_1', '/adam_t')) or k in ('_iteration', '_rng_state')}
+        extra = {k: state.pop(k) for k in list(state) if k.endswith(('/Adam', '/Adam_1', '/adam_t')) or k in ('_iteration', '_rng_state', '_rng_state_gen')}
         self.store.load_state_dict(state, strict)
         with torch.no_grad():
             for net, flat, opt in (('Generator', self.g_flat, self.g_opt), ('Discriminator', self.d_flat, self.d_opt)):
@@ -286,6 +301,8 @@ class SNGANTrainer:
             self.iteration_dev.fill_(self.iteration)
             if '_rng_state' in extra:
                 self.rng_state.copy_(torch.from_numpy(np.asarray(extra['_rng_state'], np.int64)).to(self.device))
+            if '_rng_state_gen' in extra:
+                self.rng_state_gen.copy_(torch.from_numpy(np.asarray(extra['_rng_state_gen'], np.int64)).to(self.device))
             self.feed_slot.zero_()
         self._refresh_g_prep()
         self._graphs.clear()
@@ -327,6 +344,24 @@ class SNGANTrainer:
         self._backward(loss)
         K.copy_(self.d_loss, loss.detach())
         return logits
+
+    @torch.no_grad()
+    def _generate_slots(self, lo, hi, rng_state):
+        """fakes of critic updates lo..hi-1 of this iteration (one generator pass, towers of B/N_TOWERS samples)"""
+        set_default_store(self.store)
+        n = (hi - lo) * self.batch
+        fake = Generator(n, self.labels_all[lo:hi].reshape(-1), groups=(hi - lo) * N_TOWERS, rng_state=rng_state)
+        K.copy_(self.fake_all[lo:hi], fake)
+
+    def _d_first_with_generator_beside(self):
+        """Critic update 1 of the iteration with the generator pass for updates 2..N_CRITIC on the side stream."""
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            self._generate_slots(1, N_CRITIC, self.rng_state_gen)
+        out = self._d_forward_backward_prefetched()
+        main.wait_stream(self._side)
+        return out
 
     @torch.no_grad()
     def _generate_for_critic(self):
@@ -469,9 +504,15 @@ class SNGANTrainer:
             data, labels = next(batches)
             self.real_all[i].copy_(data, non_blocking=True)
             self.labels_all[i].copy_(labels, non_blocking=True)
-        self._run_plain('gen5', self._generate_for_critic)
-        for i in range(N_CRITIC):      # slot i of the feed ring: the device-side slot counter walks 0..N_CRITIC-1
-            self._run('d_pre', self._d_forward_backward_prefetched, self.d_opt, self.d_flat)
+        if self.overlap_gen and N_CRITIC > 1:
+            self._run_plain('gen1', lambda: self._generate_slots(0, 1, self.rng_state_gen))
+            self._run('d_first', self._d_first_with_generator_beside, self.d_opt, self.d_flat)
+            for i in range(1, N_CRITIC):
+                self._run('d_pre', self._d_forward_backward_prefetched, self.d_opt, self.d_flat)
+        else:
+            self._run_plain('gen5', self._generate_for_critic)
+            for i in range(N_CRITIC):      # slot i of the feed ring: the device-side slot counter walks 0..N_CRITIC-1
+                self._run('d_pre', self._d_forward_backward_prefetched, self.d_opt, self.d_flat)
         self.iteration += 1
         K.counter_add(self.iteration_dev, 1)
 

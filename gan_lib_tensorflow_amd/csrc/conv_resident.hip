@@ -79,16 +79,21 @@ __device__ __forceinline__ void res_conv3x3(f32x16 (&acc)[TPW], u32x4 (&ring)[PF
   for (int s = 0; s < PB; s++) read_b(s, bq[s]);
 #pragma unroll
   for (int s = 0; s < RB_STEPS; s++) {
+    // sched_barrier: hipcc otherwise sinks the LDS reads to just in front of their MFMAs (lgkmcnt(0) before every pair,
+    // the whole LDS latency exposed) and lets only ~5 weight requests stay in flight
     if (s + PB < RB_STEPS) read_b(s + PB, bq[(s + PB) % (PB + 1)]);
     const bf16x8 fa = __builtin_bit_cast(bf16x8, ring[s % PF]);
-    if (s + PF < RB_STEPS) ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, wbase + (s + PF) * 1024, 0);
-    else if (has_next) ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rn, lane16, wbase + (s + PF - RB_STEPS) * 1024, 0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < TPW; t++) {
       u32x4 bv = bq[s % (PB + 1)][t];
       if constexpr (RELU) bv = relu_bf16x8(bv);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, bv), acc[t], 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + PF < RB_STEPS) ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, wbase + (s + PF) * 1024, 0);
+    else if (has_next) ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rn, lane16, wbase + (s + PF - RB_STEPS) * 1024, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -478,21 +483,31 @@ __global__ __launch_bounds__(512) void cpool_res_fprop_kernel(CpFwdArgs a) {
       }
     }
     __syncthreads();
+    static_assert(64 % PF == 0, "ring position is chunk-invariant");
+    constexpr int PB = 2;                                                   // pixel fragments are read PB steps ahead of their MFMAs
+    bf16x8 bq[PB + 1][TPW];
+    auto read_b = [&](int s, bf16x8 (&dst)[TPW]) {
+      const int tap = s >> 2, kk = s & 3, ta = tap >> 2, tb = tap & 3;
+#pragma unroll
+      for (int t = 0; t < TPW; t++)
+        dst[t] = *reinterpret_cast<const bf16x8*>(smem + b_base + ((ta & 1) * 2 + (tb & 1)) * G::PLANE +
+                                                   (t * G::TROWS + (ta >> 1)) * G::RP + (tb >> 1) * CP_PP + kk * 32);
+    };
+#pragma unroll
+    for (int s = 0; s < PB; s++) read_b(s, bq[s]);
 #pragma unroll
     for (int s = 0; s < 64; s++, step++) {
-      const int tap = s >> 2, kk = s & 3, ta = tap >> 2, tb = tap & 3;
+      if (s + PB < 64) read_b(s + PB, bq[(s + PB) % (PB + 1)]);
       const bf16x8 fa = __builtin_bit_cast(bf16x8, ring[s % PF]);
-      static_assert(64 % PF == 0, "ring position is chunk-invariant");
+      __builtin_amdgcn_sched_barrier(0);                                    // see res_conv3x3: keeps reads early and the ring deep
+#pragma unroll
+      for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, bq[s % (PB + 1)][t], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
       {
         const int nx = step + PF;
         ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, wbase + (nx < nsteps ? nx : nsteps - 1) * 1024, 0);
       }
-#pragma unroll
-      for (int t = 0; t < TPW; t++) {
-        const bf16x8 fb = *reinterpret_cast<const bf16x8*>(smem + b_base + ((ta & 1) * 2 + (tb & 1)) * G::PLANE +
-                                                             (t * G::TROWS + (ta >> 1)) * G::RP + (tb >> 1) * CP_PP + kk * 32);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
-      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
@@ -593,20 +608,41 @@ __global__ __launch_bounds__(512) void cpool_res_dgrad_kernel(CpBwdArgs a) {
     for (int t = 0; t < TPW; t++)
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+    // relu masks of this phase's outputs: requested now, consumed after the K loop
+    bf16x4 mk[TPW][4];
+    if (a.mask) {
+#pragma unroll
+      for (int t = 0; t < TPW; t++) {
+        const int y = py0 + (pg * TPW + t) * G::TROWS + trow, x = px0 + tcol;
+        const long m = ((long)n * H2 + 2 * y + pa) * W2 + 2 * x + pb;
+#pragma unroll
+        for (int g = 0; g < 4; g++) mk[t][g] = *reinterpret_cast<const bf16x4*>(a.mask + m * a.Cin + cg * 128 + ct * 32 + 8 * g + 4 * h);
+      }
+    }
+    constexpr int PB = 2;
+    bf16x8 bq[PB + 1][TPW];
+    auto read_b = [&](int s, bf16x8 (&dst)[TPW]) {
+      const int tap = s >> 3, kk = s & 7, ti = tap >> 1, tj = tap & 1;
+#pragma unroll
+      for (int t = 0; t < TPW; t++)
+        dst[t] = *reinterpret_cast<const bf16x8*>(smem + b_base + poff + (t * G::TROWS + ti) * G::RP + tj * G::PP + kk * 32);
+    };
+#pragma unroll
+    for (int s = 0; s < PB; s++) read_b(s, bq[s]);
 #pragma unroll
     for (int s = 0; s < 32; s++) {
-      const int tap = s >> 3, kk = s & 7, ti = tap >> 1, tj = tap & 1;
+      if (s + PB < 32) read_b(s + PB, bq[(s + PB) % (PB + 1)]);
       const bf16x8 fa = __builtin_bit_cast(bf16x8, ring[s % PF]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, bq[s % (PB + 1)][t], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
       {
         const int nx = s + PF;
         const int np = nx < 32 ? phase : (phase < 3 ? phase + 1 : 3), ns = nx < 32 ? nx : (phase < 3 ? nx - 32 : 31);
         ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, wofs(np, ns), 0);
       }
-#pragma unroll
-      for (int t = 0; t < TPW; t++) {
-        const bf16x8 fb = *reinterpret_cast<const bf16x8*>(smem + b_base + poff + (t * G::TROWS + ti) * G::RP + tj * G::PP + kk * 32);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
-      }
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int t = 0; t < TPW; t++) {
@@ -619,9 +655,8 @@ __global__ __launch_bounds__(512) void cpool_res_dgrad_kernel(CpBwdArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; e++) v[e] = acc[t][4 * g + e];
         if (a.mask) {
-          const bf16x4 mk = *reinterpret_cast<const bf16x4*>(a.mask + m * a.Cin + ci);
 #pragma unroll
-          for (int e = 0; e < 4; e++) v[e] = bf2f(mk[e]) > 0.f ? v[e] : 0.f;
+          for (int e = 0; e < 4; e++) v[e] = bf2f(mk[t][g][e]) > 0.f ? v[e] : 0.f;
         }
         bf16x4 o;
 #pragma unroll

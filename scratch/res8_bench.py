@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from gan_lib_tensorflow_amd import kernels as K
-n = 128
+n = int(os.environ.get('RES8_N', '128'))
 x = torch.randn(n, 8, 8, 128, device="cuda").to(torch.bfloat16)
 ws = [(torch.randn(3, 3, 128, 128, device="cuda") / 34.) for _ in range(4)]
 K.prep_weights_batched(ws, want_d=True, kinds=[4] * 4)
@@ -19,4 +19,4 @@ def timeit(f, reps=300):
     for _ in range(reps): f()
     e1.record(); torch.cuda.synchronize()
     return 1e3 * e0.elapsed_time(e1) / reps
-print("cfg", os.environ.get("GANK_RES8_CFG", "default"), "fwd %.1f us  bwd(train) %.1f us  bwd(dx only) %.1f us" % (timeit(fwd), timeit(lambda: bwd(True)), timeit(lambda: bwd(False))))
+print("N", n, "cfg", os.environ.get("GANK_RES8_CFG", "default"), "fwd %.1f us  bwd(train) %.1f us  bwd(dx only) %.1f us" % (timeit(fwd), timeit(lambda: bwd(True)), timeit(lambda: bwd(False))))
