@@ -116,6 +116,15 @@ def main():
     if local_rank >= torch.cuda.device_count():     # rehearsal of the N > 1 path on fewer GPUs than ranks (gloo only)
         assert args.backend != "nccl", "RCCL needs one GPU per rank"
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    rccl_log = None
+    if world > 1 and args.backend == "nccl":
+        # which algorithm / protocol / channel count RCCL picks over the xGMI mesh is part of the result: log the
+        # communicator setup (not every collective) and summarise it in the JSON line
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        rccl_log = os.path.join(ROOT, "gpurun_out", f"rccl_n{world}_rank{rank}.log")
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,TUNING")
+        os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     from gan_lib_tensorflow_amd import kernels as K
@@ -240,6 +249,18 @@ def main():
                                                   / (PEAK_BF16_TFLOPS * 1e12), 4) if roofline else None),
             "roofline": roofline,
         }
+        if rccl_log and os.path.exists(rccl_log):
+            import re
+            txt = open(rccl_log, errors="replace").read()
+            out["config"]["rccl"] = {
+                "log": os.path.relpath(rccl_log, ROOT),
+                "version": (re.findall(r"(?:RCCL|NCCL) version ([^\s]+)", txt) or [None])[0],
+                "channels": sorted(set(re.findall(r"(\d+) coll channels", txt))),
+                "rings_or_trees": sorted(set(re.findall(r"\b(Ring|Tree|CollNet|NVLS|PAT)\b", txt))),
+                "xgmi_or_p2p_lines": len(re.findall(r"via P2P|XGMI|xGMI", txt)),
+                "gradient_exchange": "generator: 4 fp32 buckets (G.OutputNorm+G.Output, G.Block.3, G.Block.2, G.Input+G.Block.1) all-reduced "
+                                     "on a communication stream beside the segmented backward pass; critic: one fp32 all-reduce of 6.8 MB per update",
+            }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         else:

@@ -73,8 +73,11 @@ def Generator(n_samples_, labels, noise=None, reuse=False, groups=1, rng_state=N
         output = _linear.Linear(noise, 128, 4 * 4 * DIM_G * 8, 'G.Input')
         output = output.reshape(-1, 4, 4, DIM_G * 8)
         output = ResidualBlock(output, DIM_G * 8, DIM_G * 2, 3, 'G.Block.1', resample='up', labels=labels, biases=True, groups=groups)
+        output = Fn.boundary(output, 'G.Block.1')      # gradient-bucket boundaries of the data-parallel backward pass
         output = ResidualBlock(output, DIM_G * 2, DIM_G * 2, 3, 'G.Block.2', resample='up', labels=labels, biases=True, groups=groups)
+        output = Fn.boundary(output, 'G.Block.2')
         output = ResidualBlock(output, DIM_G * 2, DIM_G * 2, 3, 'G.Block.3', resample='up', labels=labels, biases=True, groups=groups)
+        output = Fn.boundary(output, 'G.Block.3')
         output = Normalize('G.OutputNorm', output, labels, groups=groups, relu=True)    # + nonlinearity (:257-258)
         output = _conv2d.Conv2D(output, DIM_G * 2, 3, 3, 1, 'G.Output', he_init=False, out_tanh=True)  # + tanh (:260-261)
         return output.reshape(-1, OUTPUT_DIM)
@@ -88,6 +91,10 @@ def Generator(n_samples_, labels, noise=None, reuse=False, groups=1, rng_state=N
 # filling their gaps, and the split pass (64 + 256 samples) is less efficient than one pass over 320.  Kept as a knob
 # (GANK_OVERLAP_GEN=1), off by default.
 OVERLAP_GEN_WITH_CRITIC = False
+# Data parallel: the generator's gradient buffer (31.5 MB fp32) leaves in these buckets, last layers first, each as soon
+# as the backward pass has passed the block boundary below it (parallel.GradBuckets).  Forward / creation order.
+G_BUCKETS = (('G.Input/', 'G.Block.1.'), ('G.Block.2.',), ('G.Block.3.',), ('G.OutputNorm/', 'G.Output/'))
+BUCKETED_G_ALLREDUCE = True
 BATCH_SMALL_WGRADS = True    # same-shape small filter gradients of an update are issued in one launch
 SIDE_STREAM_WGRAD = False    # filter gradients on a second HIP stream: measured 6 % SLOWER per iteration (the branches contend for L2 and CUs), kept for experiments
 
@@ -204,6 +211,10 @@ class SNGANTrainer:
             import torch.distributed as dist
             self.world, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
         self.use_graphs = use_graphs
+        self._g_buckets = None
+        # world > 1: the generator's gradients leave in buckets beside the backward pass; `bucketed` forces that path for a
+        # single rank too (tests: same arithmetic as the one-piece update)
+        self.bucketed = BUCKETED_G_ALLREDUCE and process_group is not None
         self.side_stream = SIDE_STREAM_WGRAD
         self._side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         # data-side RNG differs per rank; parameter init (store seed) is identical on all ranks
@@ -410,6 +421,111 @@ class SNGANTrainer:
             Fn.BATCH_SMALL_WGRADS = False
             Fn.set_wgrad_stream(None)
 
+    # ---- data parallel generator update: segmented backward, bucketed all-reduce beside it ---------------------------
+    def _g_phases(self):
+        """The generator update as a list of phases [forward, backward segment 0 .. 3, optimiser] and, per phase, the
+        bucket whose all-reduce may start when that phase has been enqueued (None: nothing).  Segment k runs the backward
+        pass from the boundary above bucket k down to the boundary below it."""
+        st = {}
+        nb = len(G_BUCKETS)
+
+        def forward():
+            set_default_store(self.store)
+            n = GEN_BS_MULTIPLE * self.batch
+            self.store.zero_grads('Generator')
+            fake_labels = K.rng_labels(n, 10, self.rng_state)
+            with Fn.record_boundaries() as marks:
+                fake = Generator(n, fake_labels, groups=N_TOWERS, rng_state=self.rng_state)
+            d_params = self.store.params_with_name('Discriminator')
+            for p in d_params:
+                p.requires_grad_(False)
+            try:
+                logits, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS)
+                loss = Fn.hinge_g_loss(logits)
+            finally:
+                for p in d_params:
+                    p.requires_grad_(True)
+            K.copy_(self.g_loss, loss.detach())
+            cuts = [t for tag, t in marks if tag in ('G.Block.1', 'G.Block.2', 'G.Block.3')]
+            assert len(cuts) == nb - 1, [tag for tag, _ in marks]
+            st['top'], st['gtop'], st['cuts'] = loss, Fn.unit_seed(loss), cuts
+
+        def segment(k):          # k = nb-1 (next to the loss) .. 0 (the network input side)
+            def run():
+                names = [nm for nm in self.g_flat['names'] if any(sub in nm for sub in G_BUCKETS[k])]
+                params = [self.store.vars[nm] for nm in names]
+                below = st['cuts'][k - 1] if k > 0 else None
+                inputs = ([below] if below is not None else []) + params
+                Fn.reset_deferred()
+                Fn.BATCH_SMALL_WGRADS = BATCH_SMALL_WGRADS
+                try:
+                    grads = torch.autograd.grad([st['top']], inputs, [st['gtop']], allow_unused=True)
+                    Fn.join_wgrad()
+                finally:
+                    Fn.reset_deferred()
+                    Fn.BATCH_SMALL_WGRADS = False
+                if below is not None:
+                    st['top'], st['gtop'] = below, grads[0]
+                else:
+                    st.clear()
+            return run
+
+        phases = [forward] + [segment(k) for k in reversed(range(nb))] + [self._g_apply]
+        after = [None] + list(reversed(range(nb))) + [None]
+        return phases, after
+
+    def _g_step_bucketed(self):
+        if self._g_buckets is None:
+            self._g_buckets = parallel.GradBuckets(self.g_flat['grads'], parallel.bucket_ranges(self.g_flat, G_BUCKETS), self.pg)
+        gb = self._g_buckets
+        phases, after = self._g_phases()
+        last = len(phases) - 1
+
+        def between(i):
+            if after[i] is not None:
+                gb.launch(after[i])
+            if i == last - 1:
+                gb.join()              # the optimiser phase reads every bucket
+
+        if not self.use_graphs:
+            for i, ph in enumerate(phases):
+                ph()
+                between(i)
+            return
+        if 'g_seg' not in self._graphs:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):          # eager first execution (this IS the update), exactly as _run does
+                for i, ph in enumerate(phases):
+                    ph()
+                    between(i)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            try:
+                pool = torch.cuda.graph_pool_handle()
+                graphs = []
+                for ph in phases:               # one graph per phase, one memory pool: later phases read what earlier ones made
+                    g = torch.cuda.CUDAGraph()
+                    was = gc.isenabled()
+                    with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                        gc.disable()
+                        try:
+                            ph()
+                        finally:
+                            if was:
+                                gc.enable()
+                    graphs.append(g)
+                self._graphs['g_seg'] = graphs
+            except Exception as e:  # noqa: BLE001
+                import sys
+                print(f"[gank] hipGraph capture of the bucketed generator update failed ({e}); running eagerly", file=sys.stderr)
+                self.use_graphs = False
+                torch.cuda.synchronize()
+            return
+        for i, g in enumerate(self._graphs['g_seg']):
+            g.replay()
+            between(i)
+
     def _allreduce(self, flat):
         if self.world > 1:
             parallel.allreduce_sum_(flat["grads"], self.pg)
@@ -492,7 +608,10 @@ class SNGANTrainer:
 
     def g_step(self):
         """One generator update (:602-603)."""
-        self._run('g', self._g_forward_backward, self._g_applier, self.g_flat)
+        if self.bucketed:
+            self._g_step_bucketed()
+        else:
+            self._run('g', self._g_forward_backward, self._g_applier, self.g_flat)
         return self.g_loss
 
     def train_iteration(self, batches):

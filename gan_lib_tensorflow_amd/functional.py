@@ -23,6 +23,31 @@ CPOOL_RESIDENT = True   # ... on the LDS-resident kernels where they apply (prep
 PHASE_UPCONV = True   # NN-upsample+3x3 conv as a phase-decomposed transposed conv (4 instead of 9 taps)
 
 
+# Boundaries of the backward pass (data parallel: the gradient buckets of parallel.GradBuckets end here).  A network
+# marks the output of each block with `boundary(x, tag)`; when a recorder is active the tensors are collected, so the
+# caller can run the backward pass in segments (torch.autograd.grad from one boundary to the previous one) and start the
+# all-reduce of a finished bucket while the next segment runs.
+_boundary_log = None
+
+
+def boundary(x, tag):
+    if _boundary_log is not None and x.requires_grad:
+        _boundary_log.append((tag, x))
+    return x
+
+
+class record_boundaries:
+    def __enter__(self):
+        global _boundary_log
+        self._prev, _boundary_log = _boundary_log, []
+        return _boundary_log
+
+    def __exit__(self, *exc):
+        global _boundary_log
+        _boundary_log = self._prev
+        return False
+
+
 class _Side:
     """Filter gradients on a second HIP stream.  A filter gradient only feeds the optimiser (or the batched spectral
     norm backward), never the next layer's backward, so it can overlap the input-gradient chain: small layers

@@ -42,3 +42,57 @@ def data_seed(base_seed, rank):
     """Parameter init uses `base_seed` on every rank (identical replicas without a broadcast);
     the data-side RNG (z, fake labels, dequantisation) must differ per rank."""
     return 1234567 + 7919 * int(rank) + int(base_seed)
+
+
+def bucket_ranges(flat, groups):
+    """Contiguous [start, end) element ranges of a ParamStore.flatten() buffer, one per group of variable-name
+    substrings (forward / creation order).  Every trainable variable of the buffer must fall in exactly one group and the
+    members of a group must be adjacent in the buffer -- the layout flatten() produces for a network built block by block."""
+    names, offsets = flat["names"], flat["offsets"]
+    total = flat["params"].numel()
+    ends = [offsets[names[i + 1]] if i + 1 < len(names) else total for i in range(len(names))]
+    owner = []
+    for k in names:
+        hit = [gi for gi, subs in enumerate(groups) if any(sub in k for sub in subs)]
+        if len(hit) != 1:
+            raise ValueError(f"{k} belongs to {len(hit)} gradient buckets")
+        owner.append(hit[0])
+    ranges = []
+    for gi in range(len(groups)):
+        idx = [i for i, o in enumerate(owner) if o == gi]
+        if not idx or idx != list(range(idx[0], idx[-1] + 1)):
+            raise ValueError(f"bucket {gi} ({groups[gi]}) is empty or not contiguous in the flat buffer")
+        ranges.append((offsets[names[idx[0]]], ends[idx[-1]]))
+    if sorted(ranges) != ranges or ranges[0][0] != 0 or ranges[-1][1] != total or any(a[1] != b[0] for a, b in zip(ranges, ranges[1:])):
+        raise ValueError(f"buckets do not tile the buffer: {ranges} of {total}")
+    return ranges
+
+
+class GradBuckets:
+    """The flat gradient buffer of a network cut into contiguous buckets that are all-reduced one by one, each as soon as
+    the backward pass has produced its last gradient, on a communication stream of their own: the collective of bucket k
+    (RCCL over xGMI; SUM, the 1/world factor is applied by the optimiser) runs beside the backward kernels of bucket k+1.
+    The reference sums its tower gradients in one tf.add_n at the end of the graph (SNGAN/gan_cifar_resnet.py:523-526);
+    bucketing changes the schedule, not the arithmetic: every element is summed over the same ranks exactly once."""
+
+    def __init__(self, flat_grads, ranges, group):
+        self.group = group
+        self.buckets = [flat_grads[a:b] for a, b in ranges]
+        self.cuda = flat_grads.is_cuda
+        self.comm = torch.cuda.Stream(device=flat_grads.device) if self.cuda else None
+
+    def launch(self, k):
+        """all-reduce bucket k; call right after the last kernel that writes it was enqueued on the current stream"""
+        if self.group is None:
+            return
+        if self.cuda:
+            self.comm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm):
+                dist.all_reduce(self.buckets[k], op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            dist.all_reduce(self.buckets[k], op=dist.ReduceOp.SUM, group=self.group)
+
+    def join(self):
+        """the compute stream waits for every launched collective (before the optimiser reads the gradients)"""
+        if self.cuda and self.group is not None:
+            torch.cuda.current_stream().wait_stream(self.comm)

@@ -92,3 +92,83 @@ def test_single_rank_is_a_noop():
     t = torch.ones(5)
     assert parallel.allreduce_sum_(t, None) is t
     assert parallel.init_from_env() == (None, 0, 1) or os.environ.get("WORLD_SIZE", "1") != "1"
+
+
+# ---- bucketed exchange of the generator's gradients ---------------------------------------------------------------
+def _g_inputs(rank):
+    rng = np.random.default_rng(300 + rank)
+    return torch.tensor(rng.normal(size=(2 * B, 128))), torch.tensor(rng.integers(0, 10, 2 * B))
+
+
+def _bucket_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    pg, r, w = parallel.init_from_env(backend="gloo")
+    torch.set_num_threads(2)
+    from gan_lib_tensorflow_amd.SNGAN.gan_cifar_resnet import G_BUCKETS
+    state = T.init_sngan_params(0)
+    P = T.to_torch(state)
+    z, fl = _g_inputs(rank)
+    loss, _ = T.g_loss_fn(P, z, fl, towers=1)
+    names = T.trainable_names(P, 'Generator')
+    grads = torch.autograd.grad(loss, [P[k] for k in names])
+    store = ParamStore("cpu")
+    for k in names:
+        store.get_variable(k, None, state[k])
+    flat = store.flatten('Generator')
+    with torch.no_grad():
+        for k, g in zip(names, grads):
+            store.vars[k].main_grad.copy_(g.to(torch.float32))
+    ranges = parallel.bucket_ranges(flat, G_BUCKETS)
+    gb = parallel.GradBuckets(flat["grads"], ranges, pg)
+    before = flat["grads"].clone()
+    seen = []
+    for k in reversed(range(len(ranges))):       # the order the backward pass finishes them: output side first
+        gb.launch(k)
+        # buckets not launched yet still hold the LOCAL gradients: nothing outside bucket k was touched
+        for j, (a, b_) in enumerate(ranges):
+            if j < k:
+                assert torch.equal(flat["grads"][a:b_], before[a:b_]), (k, j)
+        seen.append(k)
+    gb.join()
+    if rank == 0:
+        out.put(({k: (store.vars[k].main_grad / world).numpy().copy() for k in names}, ranges, flat["params"].numel()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_generator_allreduce_equals_gradient_of_mean_loss_per_bucket():
+    """parallel.bucket_ranges tiles the generator's flat gradient buffer block by block (SNGAN G_BUCKETS) and
+    parallel.GradBuckets all-reduces the buckets one at a time, output side first; after the last one every bucket holds
+    the gradient of the mean of the two ranks' losses (the reference averages its tower losses, gan_cifar_resnet.py:498)."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, ranges, total = out.get(timeout=600)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    assert len(ranges) == 4 and ranges[0][0] == 0 and ranges[-1][1] == total and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    sizes = [b - a for a, b in ranges]
+    assert sizes[0] > sizes[1] and sizes[3] < 20000          # G.Input + G.Block.1 is the big one; G.OutputNorm + G.Output is tiny
+    P = T.to_torch(T.init_sngan_params(0))
+    loss = sum(T.g_loss_fn(P, *_g_inputs(r), towers=1)[0] for r in range(2)) / 2
+    names = T.trainable_names(P, 'Generator')
+    ref = torch.autograd.grad(loss, [P[k] for k in names])
+    for k, g in zip(names, ref):
+        np.testing.assert_allclose(got[k], g.numpy(), rtol=2e-5, atol=1e-9, err_msg=k)
+
+
+def test_bucket_ranges_rejects_bad_groupings():
+    store = ParamStore("cpu")
+    for k in ("Net/A/w", "Net/B/w", "Net/A/b"):
+        store.get_variable(k, None, np.zeros(5, np.float32))
+    flat = store.flatten("Net")
+    import pytest
+    with pytest.raises(ValueError, match="not contiguous"):
+        parallel.bucket_ranges(flat, (("A/",), ("B/",)))          # A's variables are not adjacent
+    with pytest.raises(ValueError, match="belongs to 0"):
+        parallel.bucket_ranges(flat, (("A/",),))
+    assert parallel.bucket_ranges(flat, (("Net/",),)) == [(0, flat["params"].numel())]
