@@ -88,6 +88,13 @@ PROTOTYPES = {
     "gank_hinge_g_loss": [P, P, P, P, I, P],
     "gank_softmax_xent": [P, P, P, P, P, I, I, P],
     "gank_loss_grad_scale": [P, P, P, L, P],
+    "gank_bn_bwd_bwd": [P, P, P, P, P, P, P, P, P, L, I, P],
+    "gank_bn_moving_update": [P, P, P, P, P, I, I, L, F, F, P],
+    "gank_gp_loss": [P, P, P, P, I, L, F, P],
+    "gank_lerp_rows": [P, P, P, P, I, L, P],
+    "gank_sum_hw": [P, P, I, I, I, F, P],
+    "gank_bcast_hw": [P, P, I, I, I, F, P],
+    "gank_rng_uniform_f32": [P, L, P, P],
     "gank_adam_tf": [P, P, P, P, P, P, P, L, P],
     "gank_counter_add": [P, C.c_int64, P],
     "gank_preprocess_real": [P, P, P, I, P],

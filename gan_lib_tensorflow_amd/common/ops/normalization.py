@@ -52,15 +52,8 @@ def batch_norm(inputs, decay=0.9, epsilon=1e-5, is_training=True, fused=True, gr
     if key not in _zero_labels:
         _zero_labels[key] = torch.zeros(n, dtype=torch.int32, device=inputs.device)
     y, stats = Fn.batchnorm_with_stats(inputs, _zero_labels[key], gamma, beta, groups, relu)
-    with torch.no_grad():
-        cnt = inputs.numel() // c // groups
-        for g in range(groups):
-            mean, invstd = stats[g, 0], stats[g, 1]
-            var = (1.0 / (invstd * invstd) - 1e-5) * (cnt / max(cnt - 1, 1))
-            mv.mul_(decay).add_(var, alpha=1.0 - decay)
-            biased.mul_(decay).add_(mean, alpha=1.0 - decay)
-            step.add_(1.0)
-            mm.copy_(biased / (1.0 - torch.pow(torch.full_like(step, decay), step)))
+    from ... import kernels as K
+    K.bn_moving_update(stats, mm, mv, biased, step, inputs.numel() // c // groups, decay)     # one launch, towers in order
     return y
 
 

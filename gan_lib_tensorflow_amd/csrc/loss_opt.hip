@@ -258,6 +258,23 @@ extern "C" int gank_rng_normal_bf16(void* y, long n, uint64_t* rng_state, void* 
   GANK_LAUNCH_OK("rng_normal");
   return rng_advance((unsigned long long*)rng_state, 1, s);
 }
+__global__ void rng_uniform_kernel(float* __restrict__ y, long n, const unsigned long long* __restrict__ state) {
+  const unsigned long long seed = state[0], off = state[1];
+  const long n4 = (n + 3) >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const u4 r = philox4x32_10((unsigned long long)i, off, seed);
+    const unsigned v[4] = {r.x, r.y, r.z, r.w};
+    for (int e = 0; e < 4; e++)
+      if (i * 4 + e < n) y[i * 4 + e] = u01(v[e]);      // tf.random_uniform(minval=0, maxval=1)   ACGAN/train.py:99
+  }
+}
+extern "C" int gank_rng_uniform_f32(float* y, long n, uint64_t* rng_state, void* stream) {
+  GANK_REQUIRE(y && rng_state && n > 0, "rng_uniform: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(rng_uniform_kernel, rgrid((n + 3) / 4), dim3(256), 0, s, y, n, (const unsigned long long*)rng_state);
+  GANK_LAUNCH_OK("rng_uniform");
+  return rng_advance((unsigned long long*)rng_state, 1, s);
+}
 extern "C" int gank_rng_labels(int32_t* y, long n, int n_labels, uint64_t* rng_state, void* stream) {
   GANK_REQUIRE(y && rng_state && n > 0 && n_labels > 0, "rng_labels: bad arguments");
   hipStream_t s = (hipStream_t)stream;

@@ -1,0 +1,352 @@
+"""Twice-differentiable operators: the critic of the ACGAN configuration under the WGAN-GP term.
+
+ACGAN/train.py:99-107 differentiates the critic's INPUT gradient with respect to the critic's weights
+(`tf.gradients(D(interpolates), [interpolates])` inside the loss).  TensorFlow gets the second-order graph from its op
+registry; here every operator of that critic (ACGAN/model.py:49-90) is a `torch.autograd.Function` whose backward is
+written in terms of OTHER Functions of this module, so autograd can differentiate the backward pass again:
+
+    conv   : ConvF (fprop)  <->  ConvD (input gradient)  <->  ConvW (filter gradient)     -- closed under differentiation,
+             all three on the same MFMA kernels as the first-order path (gank_conv2d_fprop / _dgrad / _wgrad);
+    dense  : LinF / LinD / LinW the same way on gank_linear_fwd / _bwd;
+    lrelu  : LRelu -> LReluB (mask multiply; linear in dy, zero second derivative in x);
+    pooling: Pool2 <-> Unpool2, SumHW <-> BcastHW (linear, mutually adjoint);
+    batch norm (train mode): BNF -> BNB -> gank_bn_bwd_bwd (its second derivative is a kernel of its own).
+
+Weight gradients are RETURNED (autograd accumulates them into `p.grad`, which the trainer points at the flat gradient
+buffer): a filter receives first- and second-order contributions in one backward pass.  Activations bf16 NHWC, weights fp32.
+"""
+import torch
+from torch.autograd import Function
+
+from . import kernels as K
+
+BF16 = torch.bfloat16
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _geom(W):
+    if W.dim() == 2:
+        return 1, W.shape[0], W.shape[1]
+    return W.shape[0], W.shape[2], W.shape[3]
+
+
+def _wf(W):
+    k, cin, cout = _geom(W)
+    return K.prep_weights(_c(W.detach().to(torch.float32)).view(k, k, cin, cout), True, False)[0]
+
+
+def _wd(W):
+    k, cin, cout = _geom(W)
+    return K.prep_weights(_c(W.detach().to(torch.float32)).view(k, k, cin, cout), False, True)[1]
+
+
+class ConvF(Function):
+    """y = conv2d_SAME(x, W) + b   (conv2d.py:180-187,212-216)"""
+
+    @staticmethod
+    def forward(ctx, x, W, bias):
+        k, cin, cout = _geom(W)
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = bias is not None
+        n, h, w, _ = x.shape
+        return K.conv2d_fprop(_c(x), _wf(W), bias.detach() if bias is not None else None, (h, w), cout, k)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = _c(dy)
+        dx = ConvD.apply(dy, W) if ctx.needs_input_grad[0] else None
+        dW = ConvW.apply(x, dy, W.shape) if ctx.needs_input_grad[1] else None
+        db = ColSum.apply(dy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dW, db
+
+
+class ConvD(Function):
+    """dx = conv2d_SAME(dy, flip(W)^T): the adjoint of ConvF in x (Conv2DBackpropInput)"""
+
+    @staticmethod
+    def forward(ctx, dy, W):
+        k, cin, cout = _geom(W)
+        ctx.save_for_backward(dy, W)
+        n, h, w, _ = dy.shape
+        return K.conv2d_dgrad(_c(dy), _wd(W), (h, w), cin, k)
+
+    @staticmethod
+    def backward(ctx, g):
+        dy, W = ctx.saved_tensors
+        g = _c(g)
+        d_dy = ConvF.apply(g, W, None) if ctx.needs_input_grad[0] else None
+        dW = ConvW.apply(g, dy, W.shape) if ctx.needs_input_grad[1] else None
+        return d_dy, dW
+
+
+class ConvW(Function):
+    """dW[tap, ci, co] = sum_pixels x[p + tap, ci] * dy[p, co]   (Conv2DBackpropFilter), fp32"""
+
+    @staticmethod
+    def forward(ctx, x, dy, wshape):
+        ctx.save_for_backward(x, dy)
+        ctx.wshape = tuple(wshape)
+        k = 1 if len(wshape) == 2 else wshape[0]
+        cin, cout = wshape[-2], wshape[-1]
+        dw = torch.zeros((k, k, cin, cout), dtype=torch.float32, device=x.device)
+        n, h, w, _ = x.shape
+        K.conv2d_wgrad(_c(x), _c(dy), dw, (h, w), k)
+        return dw.view(ctx.wshape)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, dy = ctx.saved_tensors
+        g = _c(g).view(ctx.wshape)
+        dx = ConvD.apply(dy, g) if ctx.needs_input_grad[0] else None
+        d_dy = ConvF.apply(x, g, None) if ctx.needs_input_grad[1] else None
+        return dx, d_dy, None
+
+
+class ColSum(Function):
+    """bias gradient: sum over pixels (tf.nn.bias_add gradient)"""
+
+    @staticmethod
+    def forward(ctx, dy):
+        out = torch.zeros(dy.shape[-1], dtype=torch.float32, device=dy.device)
+        return K.colsum(_c(dy), out, 1.0)
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError("second derivative through a bias gradient: the gradient penalty only uses the input gradient")
+
+
+class LinF(Function):
+    """y = x W + b on the fp32 weight (linear.py:161-180)"""
+
+    @staticmethod
+    def forward(ctx, x, W, bias):
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = bias is not None
+        return K.linear_fwd(_c(x), _c(W.detach().to(torch.float32)), bias.detach() if bias is not None else None)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = _c(dy)
+        dx = LinD.apply(dy, W) if ctx.needs_input_grad[0] else None
+        dW = LinW.apply(x, dy) if ctx.needs_input_grad[1] else None
+        db = ColSum.apply(dy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dW, db
+
+
+class LinD(Function):
+    """dx = dy W^T"""
+
+    @staticmethod
+    def forward(ctx, dy, W):
+        ctx.save_for_backward(dy, W)
+        return K.linear_bwd(_c(dy), None, _c(W.detach().to(torch.float32)), True)
+
+    @staticmethod
+    def backward(ctx, g):
+        dy, W = ctx.saved_tensors
+        g = _c(g)
+        d_dy = LinF.apply(g, W, None) if ctx.needs_input_grad[0] else None
+        dW = LinW.apply(g, dy) if ctx.needs_input_grad[1] else None
+        return d_dy, dW
+
+
+class LinW(Function):
+    """dW = x^T dy, fp32 [K, C]"""
+
+    @staticmethod
+    def forward(ctx, x, dy):
+        ctx.save_for_backward(x, dy)
+        dw = torch.zeros((x.shape[1], dy.shape[1]), dtype=torch.float32, device=x.device)
+        K.linear_bwd(_c(dy), _c(x), None, False, dw, None)
+        return dw
+
+    @staticmethod
+    def backward(ctx, g):
+        x, dy = ctx.saved_tensors
+        dx = LinD.apply(dy, g) if ctx.needs_input_grad[0] else None
+        d_dy = LinF.apply(x, g, None) if ctx.needs_input_grad[1] else None
+        return dx, d_dy
+
+
+class LRelu(Function):
+    """tf.maximum(x, leak * x)   (resnet_block.py:24-29); leak = 0 is relu"""
+
+    @staticmethod
+    def forward(ctx, x, leak):
+        ctx.save_for_backward(x)
+        ctx.leak = leak
+        return K.relu_fwd(_c(x), leak)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return LReluB.apply(dy, x, ctx.leak), None
+
+
+class LReluB(Function):
+    """dx = dy * (x > 0 ? 1 : leak): linear in dy, piecewise constant in x"""
+
+    @staticmethod
+    def forward(ctx, dy, x, leak):
+        ctx.save_for_backward(x)
+        ctx.leak = leak
+        return K.relu_bwd(_c(dy), x, leak)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return LReluB.apply(g, x, ctx.leak), None, None
+
+
+class Pool2(Function):
+    """y = scale * (sum of each 2x2 block): the reference's add_n of four strided slices / 4 (resnet_block.py:62-64)"""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return K.pool2x2(_c(x), scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return Unpool2.apply(dy, ctx.scale), None
+
+
+class Unpool2(Function):
+    @staticmethod
+    def forward(ctx, g, scale):
+        ctx.scale = scale
+        return K.unpool2x2_add(_c(g), None, scale)
+
+    @staticmethod
+    def backward(ctx, g2):
+        return Pool2.apply(g2, ctx.scale), None
+
+
+class SumHW(Function):
+    """y[n, c] = scale * sum over (h, w): tf.reduce_mean(axis=[1, 2]) with scale = 1 / (H W)   (model.py:72)"""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.hw, ctx.scale = (x.shape[1], x.shape[2]), scale
+        return K.sum_hw(_c(x), scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return BcastHW.apply(dy, ctx.hw, ctx.scale), None
+
+
+class BcastHW(Function):
+    @staticmethod
+    def forward(ctx, g, hw, scale):
+        ctx.scale = scale
+        return K.bcast_hw(_c(g), hw, scale)
+
+    @staticmethod
+    def backward(ctx, g2):
+        return SumHW.apply(g2, ctx.scale), None, None
+
+
+_zero_labels = {}
+
+
+def _zl(x):
+    key = (x.shape[0], str(x.device))
+    if key not in _zero_labels:
+        _zero_labels[key] = torch.zeros(x.shape[0], dtype=torch.int32, device=x.device)
+    return _zero_labels[key]
+
+
+class BNF(Function):
+    """train-mode batch norm over (N, H, W): y = gamma (x - mean) * invstd + beta; second output = [mean, invstd] ([2, C], not
+    differentiable: feeds the moving-statistics update)"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        x = _c(x)
+        y, stats = K.cbn_fwd(x, _zl(x), gamma.detach().view(1, -1), beta.detach().view(1, -1), 1, False)
+        stats = stats.view(2, -1)
+        ctx.save_for_backward(x, gamma, stats)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _ds):
+        x, gamma, stats = ctx.saved_tensors
+        dx, dgamma, dbeta = BNB.apply(dy, x, gamma, stats)
+        return dx, dgamma, dbeta
+
+
+class BNB(Function):
+    """first backward of BNF: (dx, dgamma, dbeta)"""
+
+    @staticmethod
+    def forward(ctx, dy, x, gamma, stats):
+        dy = _c(dy)
+        c = x.shape[-1]
+        dgamma = torch.zeros((1, c), dtype=torch.float32, device=x.device)
+        dbeta = torch.zeros((1, c), dtype=torch.float32, device=x.device)
+        dx = K.cbn_bwd(dy, x, x, _zl(x), gamma.detach().view(1, -1), stats.view(1, 2, c), dgamma, dbeta, 1, False)
+        ctx.save_for_backward(dy, x, gamma, stats)
+        ctx.set_materialize_grads(False)
+        return dx, dgamma.view(gamma.shape), dbeta.view(gamma.shape)
+
+    @staticmethod
+    def backward(ctx, g_dx, g_dgamma, g_dbeta):
+        dy, x, gamma, stats = ctx.saved_tensors
+        if g_dgamma is not None or g_dbeta is not None:
+            raise NotImplementedError("second derivative through dgamma / dbeta: the gradient penalty only uses the input gradient")
+        if g_dx is None:
+            return None, None, None, None
+        gG = torch.zeros(gamma.numel(), dtype=torch.float32, device=x.device)
+        gI, ggO = K.bn_bwd_bwd(_c(g_dx), dy, x, _c(gamma.detach().view(-1)), _c(stats.view(-1)), gG)
+        return ggO, gI, gG.view(gamma.shape), None
+
+
+class GPLoss(Function):
+    """lambda * mean_n (||g_n||_2 - 1)^2 with the reference's sqrt(sum + 1e-10)   (ACGAN/train.py:104-106)"""
+
+    @staticmethod
+    def forward(ctx, grad, lam):
+        loss, dg = K.gp_loss(_c(grad), lam)
+        ctx.save_for_backward(dg)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dg32,) = ctx.saved_tensors
+        return K.loss_grad_scale(dg32, _c(g.to(torch.float32)).reshape(1)), None       # fp32 product, one rounding to bf16
+
+
+# ---- functional forms -------------------------------------------------------------------------------------------
+def conv2d(x, W, bias=None):
+    return ConvF.apply(x, W, bias)
+
+
+def linear(x, W, bias=None):
+    return LinF.apply(x, W, bias)
+
+
+def lrelu(x, leak=0.2):
+    return LRelu.apply(x, leak)
+
+
+def meanpool2x2(x):
+    return Pool2.apply(x, 0.25)
+
+
+def mean_hw(x):
+    return SumHW.apply(x, 1.0 / (x.shape[1] * x.shape[2]))
+
+
+def batch_norm_train(x, gamma, beta):
+    """-> (y, stats [2, C])"""
+    return BNF.apply(x, gamma, beta)
+
+
+def gradient_penalty(grad, lam=10.0):
+    return GPLoss.apply(grad, lam)

@@ -666,6 +666,64 @@ def rng_labels(n, n_labels, rng_state):
     return y
 
 
+# ------------------------------------------------------------------ ACGAN configuration
+def bn_bwd_bwd(ggI, dy, x, gamma, stats, gG=None):
+    """second-order train-mode batch norm (gank_bn_bwd_bwd) -> (gI, ggO); gG (fp32 [C]) accumulated when given"""
+    c = x.shape[-1]
+    rows = x.numel() // c
+    gI, ggO = torch.empty_like(x), torch.empty_like(x)
+    ws = torch.empty(5 * c, dtype=F32, device=x.device)
+    _lib.check(lib().gank_bn_bwd_bwd(_p(ggI, BF16, "ggI"), _p(dy, BF16, "dy"), _p(x, BF16, "x"), _p(gamma, F32, "gamma"), _p(stats, F32, "stats"),
+                                     _p(gI), _p(ggO), _p(gG, F32, "gG"), _p(ws), rows, c, _stream()), "bn_bwd_bwd")
+    return gI, ggO
+
+
+def bn_moving_update(stats, mm, mv, biased, step, count, decay=0.9, eps=1e-5):
+    groups, _, c = stats.shape
+    _lib.check(lib().gank_bn_moving_update(_p(stats, F32, "stats"), _p(mm, F32, "moving_mean"), _p(mv, F32, "moving_variance"), _p(biased, F32, "biased"),
+                                           _p(step, F32, "local_step"), c, groups, int(count), float(decay), float(eps), _stream()), "bn_moving_update")
+
+
+def gp_loss(grad, lam=10.0):
+    """grad bf16 [N, ...] -> (loss fp32[1], d loss / d grad fp32)"""
+    n = grad.shape[0]
+    d = grad.numel() // n
+    loss = torch.empty(1, dtype=F32, device=grad.device)
+    dg = torch.empty(grad.shape, dtype=F32, device=grad.device)
+    ws = torch.empty(n, dtype=F32, device=grad.device)
+    _lib.check(lib().gank_gp_loss(_p(grad, BF16, "grad"), _p(loss), _p(dg), _p(ws), n, d, float(lam), _stream()), "gp_loss")
+    return loss, dg
+
+
+def lerp_rows(real, fake, alpha):
+    n = real.shape[0]
+    out = torch.empty_like(real)
+    _lib.check(lib().gank_lerp_rows(_p(real, BF16, "real"), _p(fake, BF16, "fake"), _p(alpha, F32, "alpha"), _p(out), n, real.numel() // n, _stream()), "lerp_rows")
+    return out
+
+
+def sum_hw(x, scale):
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    y = torch.empty((n, c), dtype=BF16, device=x.device)
+    _lib.check(lib().gank_sum_hw(_p(x, BF16, "x"), _p(y), n, hw, c, float(scale), _stream()), "sum_hw")
+    return y
+
+
+def bcast_hw(g, hw_shape, scale):
+    n, c = g.shape
+    h, w = hw_shape
+    y = torch.empty((n, h, w, c), dtype=BF16, device=g.device)
+    _lib.check(lib().gank_bcast_hw(_p(g, BF16, "g"), _p(y), n, h * w, c, float(scale), _stream()), "bcast_hw")
+    return y
+
+
+def rng_uniform(n, rng_state):
+    y = torch.empty(n, dtype=F32, device=rng_state.device)
+    _lib.check(lib().gank_rng_uniform_f32(_p(y), n, _p(rng_state, torch.int64), _stream()), "rng_uniform")
+    return y
+
+
 def critic_feed(real_all, labels_all, fake_all, both, labels2, slot, rng_state, done):
     """both/labels2 <- slot `slot[0]` of the feed ring (preprocessed reals, kept fakes, labels twice); advances slot and RNG"""
     n_slots, b = labels_all.shape

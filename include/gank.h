@@ -305,6 +305,30 @@ int gank_softmax_xent(const void* logits, const int32_t* labels, float* loss, vo
 /* dlogits (bf16) = g[0] * dlogits_f32: the chain rule through `total = ... + g * loss` (tf.gradients of a scaled loss) */
 int gank_loss_grad_scale(const float* dlogits_f32, const float* g, void* dlogits, long n, void* stream);
 
+/* ---- ACGAN configuration (ACGAN/train.py:89-121; ACGAN/model.py:49-90) ---------------------------------------------
+ * The WGAN-GP term (train.py:99-107) differentiates the critic's INPUT gradient with respect to the critic's weights.
+ * Conv / dense / pooling / leaky-relu second derivatives compose from the first-order entry points above (the host layer
+ * makes fprop / dgrad / wgrad mutually differentiable); train-mode batch norm needs its own second-order kernel:
+ *   gank_bn_bwd_bwd: given ggI = dL/d(dx) of the first backward pass dx = BN'(dy; x, gamma, mean, invstd) over `rows` =
+ *   N*H*W rows of C channels (stats = [mean[C], invstd[C]] as gank_cbn_fwd leaves them for one tower, gamma [C]):
+ *   gI <- dL/dx, ggO <- dL/d(dy) (bf16 [rows,C]), gG (fp32 [C], may be NULL) += dL/dgamma; ws: fp32 scratch of 5*C.
+ *   gank_bn_moving_update: tf.contrib.layers.batch_norm's moving statistics (decay, zero-debiased mean; normalization.py:
+ *   10-22) for `groups` towers in one launch; stats [groups][2][C], count = rows per tower (for the unbiased variance).
+ *   gank_gp_loss: loss <- lambda * mean_n (sqrt(sum_d g[n,d]^2 + 1e-10) - 1)^2, dgrad <- its derivative (fp32 [N,D]: scaled by
+ *   the upstream gradient and rounded once by gank_loss_grad_scale); ws fp32 [N].
+ *   gank_lerp_rows: out[n,:] = real[n,:] + alpha[n] * (fake[n,:] - real[n,:]).
+ *   gank_sum_hw / gank_bcast_hw: y[n,c] = scale * sum_hw x[n,hw,c] (tf.reduce_mean(axis=[1,2]), model.py:72) and its adjoint.
+ *   gank_rng_uniform_f32: U[0,1) from the device RNG state (advances it). */
+int gank_bn_bwd_bwd(const void* ggI, const void* dy, const void* x, const float* gamma, const float* stats, void* gI, void* ggO,
+                    float* gG, float* ws, long rows, int C, void* stream);
+int gank_bn_moving_update(const float* stats, float* moving_mean, float* moving_var, float* biased, float* local_step, int C,
+                          int groups, long count, float decay, float eps, void* stream);
+int gank_gp_loss(const void* grad, float* loss, void* dgrad, float* ws, int N, long D, float lambda, void* stream);
+int gank_lerp_rows(const void* real, const void* fake, const float* alpha, void* out, int N, long D, void* stream);
+int gank_sum_hw(const void* x, void* y, int N, int HW, int C, float scale, void* stream);
+int gank_bcast_hw(const void* g, void* y, int N, int HW, int C, float scale, void* stream);
+int gank_rng_uniform_f32(float* y, long n, uint64_t* rng_state, void* stream);
+
 /* ---- tf.train.AdamOptimizer (gan_cifar_resnet.py:521-526), one launch over a flat buffer ---------
  * All step state lives on the device so a captured update replays without host traffic:
  * hp (float[8]) = {lr, beta1, beta2, eps, grad_scale, decay_on}; t_state[0] = updates applied so far

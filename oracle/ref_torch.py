@@ -101,8 +101,8 @@ def init_sngan_params(seed=0):
 
 
 def is_state(name):
-    """Non-trainable variables (the SN `u` vectors, sn.py:32 trainable=False)."""
-    return name.endswith('spectral_norm/u')
+    """Non-trainable variables: the SN `u` vectors (sn.py:32 trainable=False) and batch-norm moving statistics."""
+    return name.endswith(('spectral_norm/u', '/moving_mean', '/moving_variance', '/moving_mean/biased', '/moving_mean/local_step'))
 
 
 def to_torch(P, dtype=torch.float64, requires_grad=True):
@@ -341,3 +341,131 @@ class Trainer:
         grads = torch.autograd.grad(loss, [self.P[k] for k in self.g_names])
         self.g_opt.step(self.P, grads, self.lr * lr_decay(iteration))
         return float(loss)
+
+
+# ================================================================== ACGAN configuration (BASELINE.json config 3)
+def init_acgan_params(seed=0, z_dim=128):
+    """All variables of ACGAN.get_generator / get_discriminator (ACGAN/model.py:21-90), scopes g_net / d_net."""
+    rng = np.random.default_rng(seed)
+    P = OrderedDict()
+
+    def conv(scope, name, k, cin, cout, he_init=True):
+        P[f'{scope}/{name}/Filters'] = conv_init(rng, k, cin, cout, he_init)
+        P[f'{scope}/{name}/Biases'] = np.zeros(cout, 'float32')
+
+    def lin(scope, name, cin, cout):
+        P[f'{scope}/{name}/W'] = linear_init(rng, cin, cout)
+        P[f'{scope}/{name}/b'] = np.zeros(cout, 'float32')
+
+    def cbn(scope, name, c):
+        P[f'{scope}/{name}/CondBatchNorm/offset'] = np.zeros((N_LABELS, c), 'float32')
+        P[f'{scope}/{name}/CondBatchNorm/scale'] = np.ones((N_LABELS, c), 'float32')
+
+    def bn(scope, name, c):
+        P[f'{scope}/{name}/BatchNorm/beta'] = np.zeros((1, c), 'float32')
+        P[f'{scope}/{name}/BatchNorm/gamma'] = np.ones((1, c), 'float32')
+        P[f'{scope}/{name}/BatchNorm/moving_mean'] = np.zeros(c, 'float32')
+        P[f'{scope}/{name}/BatchNorm/moving_variance'] = np.ones(c, 'float32')
+        P[f'{scope}/{name}/BatchNorm/moving_mean/biased'] = np.zeros(c, 'float32')
+        P[f'{scope}/{name}/BatchNorm/moving_mean/local_step'] = np.zeros(1, 'float32')
+
+    g = 'g_net'
+    lin(g, 'G.Input', z_dim, 4 * 4 * 1024)
+    for i, (ci, co) in enumerate([(1024, 256), (256, 256), (256, 256)], 1):
+        conv(g, f'G.{i}.Shortcut', 1, ci, co, he_init=False)
+        cbn(g, f'G.{i}.N1', ci)
+        conv(g, f'G.{i}.Conv1', 3, ci, co)
+        cbn(g, f'G.{i}.N2', co)
+        conv(g, f'G.{i}.Conv2', 3, co, co)
+    bn(g, 'G.OutputN', 256)
+    conv(g, 'G.Output', 3, 256, 3, he_init=False)
+    d = 'd_net'
+    conv(d, 'D.DownBlock.1.Shortcut', 1, 3, 128, he_init=False)
+    conv(d, 'D.DownBlock.1.Conv1', 3, 3, 128)
+    conv(d, 'D.DownBlock.1.Conv2', 3, 128, 128)
+    for name, down in (('D.DownBlock.2', True), ('D.NoneBlock.3', False), ('D.NoneBlock.4', False)):
+        if down:
+            conv(d, name + '.Shortcut', 1, 128, 128, he_init=False)
+        bn(d, name + '.N1', 128)
+        conv(d, name + '.Conv1', 3, 128, 128)
+        bn(d, name + '.N2', 128)
+        conv(d, name + '.Conv2', 3, 128, 128)
+    lin(d, 'D.Output', 128, 1)
+    lin(d, 'D.ACGANOutput', 128, 10)
+    return P
+
+
+def batch_norm_train(x, gamma, beta, eps=BN_EPS):
+    """tf.contrib.layers.batch_norm(is_training=True): biased batch variance over (N, H, W)  (normalization.py:8-24)"""
+    mean = x.mean(dim=(0, 1, 2), keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=(0, 1, 2), keepdim=True)
+    return (x - mean) * torch.rsqrt(var + eps) * gamma.reshape(1, 1, 1, -1) + beta.reshape(1, 1, 1, -1)
+
+
+def lrelu(x, leak=0.2):
+    return torch.maximum(x, leak * x)
+
+
+def acgan_generator(P, z, labels):
+    """ACGAN/model.py:31-47 -> [N, 32, 32, 3]"""
+    c = _Ctx(P, 'g_net', False)
+    out = _st(c.linear(z, 'G.Input')).reshape(-1, 4, 4, 1024)
+    for i in (1, 2, 3):
+        name = f'G.{i}'
+        shortcut = _st(c.conv(upsample_nn2x(out), name + '.Shortcut'))
+        h = _st(torch.relu(c.cbn(out, name + '.N1', labels, 1)))
+        h = _st(c.conv(upsample_nn2x(h), name + '.Conv1'))
+        h = _st(torch.relu(c.cbn(h, name + '.N2', labels, 1)))
+        out = _st(shortcut + c.conv(h, name + '.Conv2'))
+    out = _st(torch.relu(batch_norm_train(out, P['g_net/G.OutputN/BatchNorm/gamma'], P['g_net/G.OutputN/BatchNorm/beta'])))
+    return _st(torch.tanh(c.conv(out, 'G.Output')))
+
+
+def acgan_discriminator(P, x):
+    """ACGAN/model.py:59-88: x [N, 32, 32, 3] -> (logits [N], class logits [N, 10]); batch norm uses batch statistics"""
+    c = _Ctx(P, 'd_net', False)
+
+    def bn(h, name):
+        return batch_norm_train(h, P[f'd_net/{name}/BatchNorm/gamma'], P[f'd_net/{name}/BatchNorm/beta'])
+    shortcut = _st(c.conv(meanpool2x2(x), 'D.DownBlock.1.Shortcut'))
+    h = _st(c.conv(x, 'D.DownBlock.1.Conv1'))
+    h = _st(lrelu(h))
+    h = _st(meanpool2x2(_st(c.conv(h, 'D.DownBlock.1.Conv2'))))
+    out = _st(shortcut + h)
+    for name, down in (('D.DownBlock.2', True), ('D.NoneBlock.3', False), ('D.NoneBlock.4', False)):
+        sc = _st(meanpool2x2(_st(c.conv(out, name + '.Shortcut')))) if down else out
+        h = _st(lrelu(_st(bn(out, name + '.N1'))))
+        h = _st(c.conv(h, name + '.Conv1'))
+        h = _st(lrelu(_st(bn(h, name + '.N2'))))
+        h = _st(c.conv(h, name + '.Conv2'))
+        if down:
+            h = _st(meanpool2x2(h))
+        out = _st(sc + h)
+    out = _st(_st(lrelu(out)).mean(dim=(1, 2)))
+    return _st(c.linear(out, 'D.Output')).reshape(-1), _st(c.linear(out, 'D.ACGANOutput'))
+
+
+def acgan_d_loss(P, real, real_labels, z, fake_labels, alpha):
+    """ACGAN/train.py:89-115: hinge + 10 * gradient penalty + class cross-entropy on the real batch.
+    real [N,32,32,3] (preprocessed), alpha [N].  Returns (total, parts dict)."""
+    with torch.no_grad():
+        x_fake = acgan_generator(P, z, fake_labels)
+    disc_real, ac_real = acgan_discriminator(P, real)
+    disc_fake, _ = acgan_discriminator(P, x_fake)
+    d_gan = torch.relu(1. - disc_real).mean() + torch.relu(1. + disc_fake).mean()
+    interp = (real + alpha.reshape(-1, 1, 1, 1) * (x_fake - real)).detach().requires_grad_(True)
+    d_int, _ = acgan_discriminator(P, interp)
+    (grads,) = torch.autograd.grad(d_int.sum(), interp, create_graph=True)
+    slopes = torch.sqrt((grads ** 2).sum(dim=(1, 2, 3)) + 1e-10)
+    gp = 10. * ((slopes - 1.) ** 2).mean()
+    d_ac = F.cross_entropy(ac_real, real_labels.long())
+    return d_gan + gp + d_ac, dict(d_gan=d_gan, gp=gp, d_ac=d_ac, disc_real=disc_real, disc_fake=disc_fake, grads=grads, x_fake=x_fake)
+
+
+def acgan_g_loss(P, z, fake_labels, acgan_scale_G=0.1):
+    """ACGAN/train.py:117-121"""
+    x_fake = acgan_generator(P, z, fake_labels)
+    disc_fake, ac_fake = acgan_discriminator(P, x_fake)
+    g_gan = -disc_fake.mean()
+    g_ac = F.cross_entropy(ac_fake, fake_labels.long())
+    return g_gan + acgan_scale_G * g_ac, dict(g_gan=g_gan, g_ac=g_ac)

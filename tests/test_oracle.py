@@ -324,3 +324,31 @@ def test_bf16_storage_sensitivity_of_generator_gradients():
     assert err['Generator/G.Output/Filters'] < 0.02, err['Generator/G.Output/Filters']
     assert 0.02 < err['Generator/G.Input/W'] < 0.4, err['Generator/G.Input/W']            # measured 0.12 at batch 16, 0.125-0.15 at 64
     assert err['Generator/G.Input/W'] > 3 * err['Generator/G.Output/Filters']          # it accumulates with depth
+
+
+def test_acgan_restatement_known_answers():
+    """ACGAN additions of the oracle (BASELINE config 3): train-mode batch norm equals torch's own functional form; the
+    gradient-penalty expression has the closed form 10 (||w|| - 1)^2 for a linear critic; variable names and counts of
+    ACGAN/model.py:21-90 (no spectral norm: no `u` vectors; batch-norm moving statistics are state, not parameters)."""
+    import torch
+    import torch.nn.functional as tF
+    from oracle import ref_torch as T
+    rng = np.random.default_rng(0)
+    x = torch.tensor(rng.normal(size=(5, 4, 4, 6)))
+    g, b = torch.tensor(rng.normal(size=6)), torch.tensor(rng.normal(size=6))
+    ref = tF.batch_norm(x.permute(0, 3, 1, 2), None, None, g, b, training=True, eps=1e-5).permute(0, 2, 3, 1)
+    assert float((T.batch_norm_train(x, g, b) - ref).abs().max()) < 1e-12
+    w = torch.tensor(rng.normal(size=(4 * 4 * 6,)))
+    xi = x.clone().requires_grad_(True)
+    (gr,) = torch.autograd.grad((xi.reshape(5, -1) @ w).sum(), xi, create_graph=True)
+    slopes = torch.sqrt((gr ** 2).sum(dim=(1, 2, 3)) + 1e-10)
+    assert abs(float(10. * ((slopes - 1.) ** 2).mean()) - 10. * (float(w.norm()) - 1.) ** 2) < 1e-9
+    P = T.init_acgan_params(0)
+    assert not any(k.endswith('spectral_norm/u') for k in P)
+    gcount = sum(v.size for k, v in P.items() if k.startswith('g_net/') and not T.is_state(k))
+    dcount = sum(v.size for k, v in P.items() if k.startswith('d_net/') and not T.is_state(k))
+    # generator: SNGAN's 7 875 587 with G.OutputNorm's 10 x 256 x 2 table replaced by one gamma/beta pair
+    assert gcount == 7875587 - 2 * 10 * 256 + 2 * 256
+    conv = lambda k, ci, co: k * k * ci * co + co      # noqa: E731
+    assert dcount == conv(1, 3, 128) + conv(3, 3, 128) + conv(3, 128, 128) + conv(1, 128, 128) + 6 * conv(3, 128, 128) + 6 * 2 * 128 + 129 + 1290
+    assert T.is_state('d_net/D.NoneBlock.3.N1/BatchNorm/moving_mean/local_step') and not T.is_state('d_net/D.NoneBlock.3.N1/BatchNorm/gamma')
