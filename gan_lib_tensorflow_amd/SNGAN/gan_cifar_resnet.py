@@ -149,6 +149,13 @@ def Discriminator(inputs, labels, update_collection=None, reuse=False):
                 output = ResidualBlock(output, DIM_D, DIM_D, 3, 'D.Block.4', spectral_normed=True,
                                        update_collection=update_collection, resample=None, labels=labels, biases=True)
                 output = Fn.relu_meanpool_hw(output)                       # nonlinearity + reduce_mean (:299-301)
+            if CONDITIONAL and ACGAN:            # two heads read the pooled features (:302-311)
+                out_a, out_b = Fn.fork(output)
+                output_wgan = _linear.Linear(out_a, DIM_D, 1, 'D.Output', spectral_normed=True,
+                                             update_collection=update_collection)
+                output_acgan = _linear.Linear(out_b, DIM_D, 10, 'D.ACGANOutput', spectral_normed=True,
+                                              update_collection=update_collection, biases=True)
+                return output_wgan.reshape(-1), output_acgan
             output_wgan = _linear.Linear(output, DIM_D, 1, 'D.Output', spectral_normed=True,
                                          update_collection=update_collection)
             return output_wgan.reshape(-1), None

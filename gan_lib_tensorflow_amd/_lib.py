@@ -86,6 +86,7 @@ PROTOTYPES = {
     "gank_embedding_bwd": [P, P, P, I, I, I, P],
     "gank_hinge_d_loss": [P, P, P, P, I, I, P],
     "gank_hinge_g_loss": [P, P, P, P, I, P],
+    "gank_wgan_d_loss": [P, P, P, P, I, I, P],
     "gank_softmax_xent": [P, P, P, P, P, I, I, P],
     "gank_loss_grad_scale": [P, P, P, L, P],
     "gank_bn_bwd_bwd": [P, P, P, P, P, P, P, P, P, L, I, P],

@@ -65,6 +65,28 @@ __global__ void softmax_xent_kernel(const bf16* __restrict__ lg, const int* __re
   if (threadIdx.x == 0) loss[0] = tot;
 }
 
+// WGAN critic loss  -mean(real) + mean(fake)   (misc.py:328-331; the 'WGAN-GP' branch, :337-352, is the same pair: its
+// penalty term is added by the caller -- gank_gp_loss).  Generator side: gank_hinge_g_loss (-mean(fake), :335,:352).
+__global__ void wgan_d_kernel(const bf16* __restrict__ l, float* __restrict__ loss, bf16* __restrict__ dl, float* __restrict__ dl32, int n, int n_real) {
+  __shared__ float red[16];
+  const int n_fake = n - n_real;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float v = bf2f(l[i]);
+    const float d = i < n_real ? -1.f / (float)n_real : 1.f / (float)n_fake;
+    acc += v * d;
+    dl[i] = f2bf(d);
+    if (dl32) dl32[i] = d;
+  }
+  const float tot = block_sum(acc, red);
+  if (threadIdx.x == 0) loss[0] = tot;
+}
+extern "C" int gank_wgan_d_loss(const void* logits, float* loss, void* dlogits, float* dlogits_f32, int n, int n_real, void* stream) {
+  GANK_REQUIRE(logits && loss && dlogits && n > 0 && n_real > 0 && n_real < n, "wgan_d_loss: bad arguments");
+  hipLaunchKernelGGL(wgan_d_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, loss, (bf16*)dlogits, dlogits_f32, n, n_real);
+  GANK_LAUNCH_OK("wgan_d_loss");
+  return 0;
+}
 extern "C" int gank_hinge_d_loss(const void* logits, float* loss, void* dlogits, float* dlogits_f32, int n, int n_real, void* stream) {
   GANK_REQUIRE(logits && loss && dlogits && n > 0 && n_real > 0 && n_real < n, "hinge_d_loss: bad arguments");
   hipLaunchKernelGGL(hinge_d_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, loss, (bf16*)dlogits, dlogits_f32, n, n_real);

@@ -617,6 +617,8 @@ class _Loss(Function):
     def forward(ctx, logits, kind, arg):
         if kind == "hinge_d":
             loss, dl, dl32 = K.hinge_d_loss(logits, arg)
+        elif kind == "wgan_d":
+            loss, dl, dl32 = K.wgan_d_loss(logits, arg)
         elif kind == "hinge_g":
             loss, dl, dl32 = K.hinge_g_loss(logits)
         elif kind == "xent":
@@ -658,6 +660,10 @@ def hinge_d_loss(logits, n_real):
 
 def hinge_g_loss(logits):
     return _Loss.apply(logits, "hinge_g", None)
+
+
+def wgan_d_loss(logits, n_real):
+    return _Loss.apply(logits, "wgan_d", n_real)
 
 
 def softmax_xent(logits, labels):

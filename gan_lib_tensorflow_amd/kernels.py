@@ -606,6 +606,14 @@ def hinge_d_loss(logits, n_real):
     return loss, dl, dl32
 
 
+def wgan_d_loss(logits, n_real):
+    loss = torch.empty(1, dtype=F32, device=logits.device)
+    dl = torch.empty_like(logits)
+    dl32 = torch.empty(logits.shape, dtype=F32, device=logits.device)
+    _lib.check(lib().gank_wgan_d_loss(_p(logits, BF16, "logits"), _p(loss), _p(dl), _p(dl32), logits.numel(), n_real, _stream()), "wgan_d_loss")
+    return loss, dl, dl32
+
+
 def hinge_g_loss(logits):
     loss = torch.empty(1, dtype=F32, device=logits.device)
     dl = torch.empty_like(logits)

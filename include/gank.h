@@ -301,6 +301,8 @@ int gank_embedding_bwd(const void* dy, const int32_t* idx, float* dtable, int N,
  * softmax_xent: mean sparse softmax cross-entropy                 (gan_cifar_resnet.py:390-394) */
 int gank_hinge_d_loss(const void* logits, float* loss, void* dlogits, float* dlogits_f32, int n, int n_real, void* stream);
 int gank_hinge_g_loss(const void* logits, float* loss, void* dlogits, float* dlogits_f32, int n, void* stream);
+/* wgan_d: -mean(l[:n_real]) + mean(l[n_real:])  (common/misc.py:328-331 'WGAN', :337-352 'WGAN-GP' before its penalty) */
+int gank_wgan_d_loss(const void* logits, float* loss, void* dlogits, float* dlogits_f32, int n, int n_real, void* stream);
 int gank_softmax_xent(const void* logits, const int32_t* labels, float* loss, void* dlogits, float* dlogits_f32, int n, int classes, void* stream);
 /* dlogits (bf16) = g[0] * dlogits_f32: the chain rule through `total = ... + g * loss` (tf.gradients of a scaled loss) */
 int gank_loss_grad_scale(const float* dlogits_f32, const float* g, void* dlogits, long n, void* stream);

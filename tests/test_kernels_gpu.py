@@ -606,8 +606,24 @@ def test_batch_norm_op_and_get_loss(K):
     torch.cuda.synchronize()
     assert abs(float(d_loss) - lref) < 1e-5 and abs(float(g_loss) - gref) < 1e-5
     assert relerr(realt.grad, dref[:7]) < BF_TOL and relerr(faket.grad, dref[7:]) < BF_TOL
+    # 'WGAN' / 'WGAN-GP' (misc.py:328-352): -mean(real) + mean(fake); -mean(fake)
+    realt.grad = faket.grad = None
+    d_loss, g_loss = misc.get_loss(realt, faket, 'WGAN-GP')
+    d_loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(d_loss) - (-real.mean() + fake.mean())) < 1e-5 and abs(float(g_loss) + fake.mean()) < 1e-5
+    assert relerr(realt.grad, np.full(7, -1 / 7)) < BF_TOL and relerr(faket.grad, np.full(5, 1 / 5)) < BF_TOL
     with pytest.raises(NotImplementedError):
-        misc.get_loss(realt, faket, 'WGAN-GP')
+        misc.get_loss(realt, faket, 'LSGAN')
+    # the penalty the reference pastes at the call site (misc.py:341-349): value and derivative
+    gsrc, gt = bf(rng.normal(size=(6, 4, 4, 3)))
+    gt.requires_grad_(True)
+    gp = misc.gradient_penalty(gt, 10.0)
+    gp.backward()
+    gr = torch.tensor(gsrc, requires_grad=True)
+    ref = 10. * ((torch.sqrt((gr ** 2).sum(dim=(1, 2, 3)) + 1e-10) - 1.) ** 2).mean()
+    ref.backward()
+    assert abs(float(gp) - float(ref)) < 1e-3 * float(ref) and relerr(gt.grad, gr.grad.numpy()) < BF_TOL
 
 
 @pytest.mark.parametrize("n,h,cin,cout,k", [(3, 8, 64, 128, 3), (2, 16, 128, 128, 3), (2, 32, 64, 256, 3), (2, 8, 64, 64, 1), (1, 6, 64, 96, 3)])

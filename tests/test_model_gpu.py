@@ -566,3 +566,28 @@ def test_bucketed_generator_update_through_rccl_matches_the_one_piece_update(gpu
             assert abs(got[2] - ref[2]) < 0.5
     finally:
         dist.destroy_process_group()
+
+
+def test_sngan_critic_acgan_head(gpu):
+    """CONDITIONAL and ACGAN (gan_cifar_resnet.py:302-311): the critic grows a second, spectrally normalised 10-way head
+    `D.ACGANOutput` on the pooled features; both heads receive gradients."""
+    from gan_lib_tensorflow_amd.SNGAN import gan_cifar_resnet as S
+    from gan_lib_tensorflow_amd import functional as Fn
+    from gan_lib_tensorflow_amd.store import ParamStore, set_default_store
+    S.ACGAN = True
+    try:
+        store = set_default_store(ParamStore("cuda", seed=3))
+        g = torch.Generator().manual_seed(1)
+        x = (torch.rand(6, 3072, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+        labels = torch.randint(0, 10, (6,), generator=g, dtype=torch.int32).cuda()
+        logits, ac = S.Discriminator(x, labels, update_collection=S.NO_OPS)
+        assert logits.shape == (6,) and ac.shape == (6, 10)
+        for k in ('Discriminator/D.ACGANOutput/W', 'Discriminator/D.ACGANOutput/b', 'Discriminator/D.ACGANOutput/spectral_norm/u'):
+            assert k in store.vars, k
+        total = Fn.hinge_g_loss(logits) + 0.1 * Fn.softmax_xent(ac, labels)        # gen_cost + ACGAN_SCALE_G * acgan cost (:476)
+        total.backward()
+        for k in ('Discriminator/D.ACGANOutput/W', 'Discriminator/D.Output/W', 'Discriminator/D.Block.3.Conv1/Filters'):
+            gr = store.vars[k].grad
+            assert gr is not None and bool(torch.isfinite(gr).all()) and float(gr.abs().sum()) > 0, k
+    finally:
+        S.ACGAN = False
