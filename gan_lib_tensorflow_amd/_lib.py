@@ -52,6 +52,7 @@ PROTOTYPES = {
     "gank_res8_chain_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, P],
     "gank_cpool_res_fprop": [P, P, P, P, P, I, I, I, I, I, I, P],
     "gank_cpool_res_dgrad": [P, P, P, P, I, I, I, I, I, P],
+    "gank_deconv2d_prep_phases": [P, P, I, I, I, P],
     "gank_deconv2d_fprop": [P, P, P, P, I, I, I, I, I, I, P],
     "gank_deconv2d_dgrad": [P, P, P, I, I, I, I, I, I, P],
     "gank_deconv2d_wgrad": [P, P, P, I, I, I, I, I, I, P],

@@ -1,8 +1,9 @@
 """Transposed convolution -- drop-in for common/ops/deconv2d.py of the reference.
 
 tf.nn.conv2d_transpose, stride 2, SAME, filter [k,k,Cout,Cin], output 2H x 2W (deconv2d.py:99-114).
-The op has no caller in the reference; it is provided at op level on the MFMA engines
-(zero-insertion gather for fprop, stride-2 gather for dgrad/wgrad)."""
+The op has no caller in the reference; it is provided at op level on the MFMA engines: fprop by output phase (four
+2x2-tap convolutions over the low-resolution input, 4 MACs per output) for filter sizes 3 and 4 with in_channels % 64 == 0,
+the zero-insertion gather otherwise (k = 5: three taps per axis in the odd phases); stride-2 gather for dgrad / wgrad."""
 import numpy as np
 import torch
 from torch.autograd import Function
@@ -13,14 +14,20 @@ from ...store import get_default_store
 
 _default_weightnorm = False
 _weights_stdev = None
+PHASE_FORM = True    # fprop by output phase where it applies (no MACs on inserted zeros)
 
 
 class _Deconv2d(Function):
     @staticmethod
     def forward(ctx, x, F, bias):
         k, _, cout, cin = F.shape
-        wfz, wz = K.prep_weights(F.detach(), True, True)     # F viewed as HWIO (I=Cout, O=Cin)
-        y = K.deconv2d_fprop(x, wz, bias.detach() if bias is not None else None, cout, k)
+        b = bias.detach() if bias is not None else None
+        if PHASE_FORM and k in (3, 4) and cin % 64 == 0:
+            wfz, _ = K.prep_weights(F.detach(), True, False)  # the dgrad operand: F viewed as HWIO (I=Cout, O=Cin)
+            y = K.upconv3x3_fprop(x, K.deconv2d_prep_phases(F.detach()), b, cout)
+        else:
+            wfz, wz = K.prep_weights(F.detach(), True, True)
+            y = K.deconv2d_fprop(x, wz, b, cout, k)
         ctx.save_for_backward(x, F, wfz)
         ctx.bias = bias
         return y

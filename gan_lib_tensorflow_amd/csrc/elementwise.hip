@@ -227,6 +227,38 @@ extern "C" int gank_convpool3x3_prep_weights(const float* w, void* wp4, void* wp
   return 0;
 }
 
+// ---- Deconv2D (tf.nn.conv2d_transpose, stride 2, SAME; common/ops/deconv2d.py:99-109) by output phase --------------
+// out[n, 2y+a, 2x+b, co] = sum_{i,j in {0,1}} sum_ci x[n, y+i-(1-a), x+j-(1-b), ci] * f[ta][tb][co][ci],
+//   ta = 2 - a - 2i + pb, tb = 2 - b - 2j + pb, pb = (k-2)/2 (TensorFlow's SAME pad-before of the stride-2 conv whose
+//   gradient this op is); taps outside [0, k) are zero.  Exact for k = 3 (one or two taps per phase and axis) and k = 4
+//   (two): the zero-insertion form spends k*k MACs per output on 3/4 zeros, this one 4.  (k = 5 needs three taps per axis
+//   in the odd phases and stays on the zero-insertion form.)  wph layout = gank_upconv3x3_prep_weights': [4][CoutPad][4*Cin].
+__global__ void deconv_phase_prep_kernel(const float* __restrict__ f, bf16* __restrict__ wph, int k, int Cin, int Cout, int CoutPad) {
+  const long total = 4L * CoutPad * 4 * Cin;
+  const int pb = (k - 2) / 2;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(idx % Cin);
+    long t = idx / Cin;
+    const int tap = (int)(t & 3); t >>= 2;
+    const int co = (int)(t % CoutPad), p = (int)(t / CoutPad);
+    const int ta = 2 - (p >> 1) - 2 * (tap >> 1) + pb, tb = 2 - (p & 1) - 2 * (tap & 1) + pb;
+    float v = 0.f;
+    if (co < Cout && ta >= 0 && ta < k && tb >= 0 && tb < k) v = f[(((long)ta * k + tb) * Cout + co) * Cin + ci];
+    wph[idx] = f2bf(v);
+  }
+}
+extern "C" int gank_deconv2d_prep_phases(const float* f, void* wph, int ksize, int Cin, int Cout, void* stream) {
+  GANK_REQUIRE(f && wph && Cin > 0 && Cout > 0, "deconv2d_prep_phases: bad arguments");
+  GANK_REQUIRE(ksize == 3 || ksize == 4, "deconv2d_prep_phases: 2x2 taps per phase cover filter sizes 3 and 4 (got %d)", ksize);
+  const int CoutPad = roundup(Cout, 32);
+  const long total = 4L * CoutPad * 4 * Cin;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(deconv_phase_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, f, (bf16*)wph, ksize, Cin, Cout, CoutPad);
+  GANK_LAUNCH_OK("deconv2d_prep_phases");
+  return 0;
+}
+
 // ---- batched: every conv/linear weight of a network in ONE launch (the per-layer form costs 2 tiny
 // launches x ~5 us per layer per forward; a network has 11-12 weights).  Table by value in kernargs.
 #define PREP_MAX 16

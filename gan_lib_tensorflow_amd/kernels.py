@@ -305,6 +305,14 @@ def res8_chain_bwd(dy, dpool, ylast, wd_rfrag, h1s, xins, keep=True):
     return dxs[0], g1s, dys
 
 
+def deconv2d_prep_phases(f):
+    """f fp32 [k,k,Cout,Cin], k in (3, 4) -> wph bf16 [4][roundup(Cout,32)][4*Cin] for upconv3x3_fprop"""
+    k, _, cout, cin = f.shape
+    wph = torch.empty((4, _roundup(cout, 32), 4 * cin), dtype=BF16, device=f.device)
+    _lib.check(lib().gank_deconv2d_prep_phases(_p(f, F32, "f"), _p(wph), k, cin, cout, _stream()), "deconv2d_prep_phases")
+    return wph
+
+
 def deconv2d_fprop(x, wz, bias, cout, ksize):
     n, h, w, cin = x.shape
     y = torch.empty((n, 2 * h, 2 * w, cout), dtype=BF16, device=x.device)

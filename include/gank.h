@@ -182,6 +182,10 @@ int gank_convpool3x3_wgrad(const void* x, const void* dy, float* dw, float* dbia
  *           output of gank_conv2d_prep_weights(F, ksize, Cin:=Cout, Cout:=Cin)   (F viewed as HWIO);
  *   dgrad = the stride-2 SAME conv; its operand wfz is the `wf` output of the same prep call;
  *   wgrad accumulates into dF [k,k,Cout,Cin]. */
+/* fprop by output phase for ksize 3 and 4 (4 MACs per output instead of k*k on inserted zeros): build wph
+ * [4][roundup(Cout,32)][4*Cin] from the filter f fp32 [k,k,Cout,Cin] and run gank_upconv3x3_fprop(x, wph, bias, NULL, y, ...)
+ * -- the same four 2x2-tap phases over the low-resolution input; needs Cin % 64 == 0. */
+int gank_deconv2d_prep_phases(const float* f, void* wph, int ksize, int Cin, int Cout, void* stream);
 int gank_deconv2d_fprop(const void* x, const void* wz, const float* bias, void* y, int N, int H, int W,
                         int Cin, int Cout, int ksize, void* stream);
 int gank_deconv2d_dgrad(const void* dy, const void* wfz, void* dx, int N, int H, int W, int Cin, int Cout,

@@ -197,6 +197,42 @@ def test_deconv2d(K, k, cin, cout):
     assert relerr(df, rdf) < F32_FROM_BF_TOL
 
 
+@pytest.mark.parametrize("n,h,k,cin,cout", [(2, 4, 3, 64, 64), (2, 4, 4, 64, 96), (3, 8, 4, 128, 3), (64, 16, 4, 256, 256), (64, 16, 3, 256, 256), (2, 6, 3, 64, 32)])
+def test_deconv2d_phase_form(K, n, h, k, cin, cout):
+    """Deconv2D fprop by output phase (k = 3, 4): four 2x2-tap convolutions over the low-resolution input instead of a
+    k x k conv over the zero-inserted one, against the oracle's conv2d_transpose and against the zero-insertion path;
+    including a realistic shape (n = 64, 16 -> 32, 256 channels: the generator-block size of the SNGAN path) and the
+    reference-shaped op end to end (values + the three gradients through autograd)."""
+    rng = np.random.default_rng(k * 100 + cin + n)
+    x, xt = bf(rng.normal(size=(n, h, h, cin)))
+    f, _ = bf(rng.normal(size=(k, k, cout, cin)) / np.sqrt(k * k * cin / 4))
+    b, bt = f32(rng.normal(size=cout))
+    ft = torch.tensor(f, dtype=torch.float32).cuda()
+    y = K.upconv3x3_fprop(xt, K.deconv2d_prep_phases(ft), bt, cout)
+    torch.cuda.synchronize()
+    big = n * h * h * cin > 1 << 20
+    if not big:
+        assert relerr(y, R.deconv2d_same(x, f, b)) < BF_TOL
+    _, wz = K.prep_weights(ft, False, True)
+    y0 = K.deconv2d_fprop(xt, wz, bt, cout, k)                          # zero-insertion form: same products, other order
+    assert relerr(y, y0.double().cpu().numpy()) < (2e-2 if big else 1e-2)
+    if not big:
+        from gan_lib_tensorflow_amd.common.ops import deconv2d as D
+        from gan_lib_tensorflow_amd.store import ParamStore, set_default_store
+        store = set_default_store(ParamStore("cuda", seed=1))
+        xt2 = xt.clone().requires_grad_(True)
+        out = D.Deconv2D(xt2, cin, cout, k, name='T')
+        with torch.no_grad():
+            store.vars['T/Filters'].copy_(ft)
+            store.vars['T/Biases'].copy_(bt)
+        out = D.Deconv2D(xt2, cin, cout, k, name='T')
+        dy, dyt = bf(rng.normal(size=(n, 2 * h, 2 * h, cout)))
+        out.backward(dyt)
+        rdx, rdf, rdb = R.deconv2d_same_grads(x, f, dy)
+        assert relerr(out, R.deconv2d_same(x, f, b)) < BF_TOL and relerr(xt2.grad, rdx) < BF_TOL
+        assert relerr(store.vars['T/Filters'].grad, rdf) < F32_FROM_BF_TOL and relerr(store.vars['T/Biases'].grad, rdb) < F32_FROM_BF_TOL
+
+
 def test_spectral_norm_batched_fwd_bwd(K):
     rng = np.random.default_rng(5)
     shapes = [(3, 128), (27, 128), (1152, 128), (300, 128), (2304, 256), (128, 1), (70, 33)]
