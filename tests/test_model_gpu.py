@@ -591,3 +591,27 @@ def test_sngan_critic_acgan_head(gpu):
             assert gr is not None and bool(torch.isfinite(gr).all()) and float(gr.abs().sum()) > 0, k
     finally:
         S.ACGAN = False
+
+
+def test_tf_saver_checkpoint_round_trip_through_the_trainer(gpu, tmp_path):
+    """SNGANTrainer.state_dict() -> the tensors tf.train.Saver holds (TF variable names, <var>/Adam slots, beta powers)
+    -> V2 checkpoint files -> optimistic_restore into a differently initialised trainer: same weights, Adam moments
+    and step counts (gan_cifar_resnet.py:585-590; common/misc.py:275-307)."""
+    from gan_lib_tensorflow_amd.common import tf_checkpoint as C
+    S, tr, _ = make_trainer(51, 8)
+    feed = S.synthetic_batches(8, "cuda", seed=4)
+    for _ in range(2):
+        tr.train_iteration(feed)
+    torch.cuda.synchronize()
+    prefix = str(tmp_path / "model.ckpt-1")
+    C.write_checkpoint(prefix, C.checkpoint_from_trainer_state(tr.state_dict()))
+    names = {n for n, _, _ in C.list_variables(prefix)}
+    assert {'Generator/G.Block.1.Conv1/Filters', 'Generator/G.Block.1.Conv1/Filters/Adam_1', 'Discriminator/D.Output/spectral_norm/u',
+            'beta2_power', 'beta2_power_1'} <= names and not any(n.startswith('_') for n in names)
+    tr2 = S.SNGANTrainer(batch_size=8, seed=7, use_graphs=False)
+    restored = C.optimistic_restore(tr2, prefix)
+    assert len(restored) == len(tr.store.vars)
+    for k in tr.store.vars:
+        assert torch.equal(tr.store.vars[k], tr2.store.vars[k]), k
+    assert torch.equal(tr.g_flat['m'], tr2.g_flat['m']) and torch.equal(tr.d_flat['v'], tr2.d_flat['v'])
+    assert int(tr2.d_opt.t) == int(tr.d_opt.t) == 10 and int(tr2.g_opt.t) == int(tr.g_opt.t) == 1
