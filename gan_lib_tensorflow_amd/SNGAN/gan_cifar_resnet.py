@@ -72,11 +72,11 @@ def Generator(n_samples_, labels, noise=None, reuse=False, groups=1, rng_state=N
             noise = K.rng_normal((n_samples_, 128), rng_state)                 # tf.random_normal (:240)
         output = _linear.Linear(noise, 128, 4 * 4 * DIM_G * 8, 'G.Input')
         output = output.reshape(-1, 4, 4, DIM_G * 8)
-        output = ResidualBlock(output, DIM_G * 8, DIM_G * 2, 3, 'G.Block.1', resample='up', labels=labels, biases=True, groups=groups)
+        output = ResidualBlock(output, DIM_G * 8, DIM_G * 2, 3, 'G.Block.1', resample='up', labels=labels, biases=True, groups=groups, out_stats=groups)
         output = Fn.boundary(output, 'G.Block.1')      # gradient-bucket boundaries of the data-parallel backward pass
-        output = ResidualBlock(output, DIM_G * 2, DIM_G * 2, 3, 'G.Block.2', resample='up', labels=labels, biases=True, groups=groups)
+        output = ResidualBlock(output, DIM_G * 2, DIM_G * 2, 3, 'G.Block.2', resample='up', labels=labels, biases=True, groups=groups, out_stats=groups)
         output = Fn.boundary(output, 'G.Block.2')
-        output = ResidualBlock(output, DIM_G * 2, DIM_G * 2, 3, 'G.Block.3', resample='up', labels=labels, biases=True, groups=groups)
+        output = ResidualBlock(output, DIM_G * 2, DIM_G * 2, 3, 'G.Block.3', resample='up', labels=labels, biases=True, groups=groups, out_stats=groups)
         output = Fn.boundary(output, 'G.Block.3')
         output = Normalize('G.OutputNorm', output, labels, groups=groups, relu=True)    # + nonlinearity (:257-258)
         output = _conv2d.Conv2D(output, DIM_G * 2, 3, 3, 1, 'G.Output', he_init=False, out_tanh=True)  # + tanh (:260-261)

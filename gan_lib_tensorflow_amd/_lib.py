@@ -11,6 +11,7 @@ P, I, L, F = C.c_void_p, C.c_int, C.c_long, C.c_float
 
 # flags (include/gank.h)
 IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, W_FRAG, RES_UPSAMPLE2X = 1, 2, 4, 8, 32, 64
+STAT_SLOTS = 16   # GANK_STAT_SLOTS
 
 
 class SnDesc(C.Structure):
@@ -37,12 +38,14 @@ PROTOTYPES = {
     "gank_conv2d_prep_weights": [P, P, P, I, I, I, P],
     "gank_conv2d_prep_weights_batched": [C.POINTER(PrepDesc), I, P],
     "gank_conv2d_fprop": [P, P, P, P, P, P, I, I, I, I, I, I, I, F, P],
+    "gank_conv2d_fprop_stats": [P, P, P, P, P, P, I, I, I, I, I, I, I, F, P, I, P, P],
     "gank_conv2d_dgrad": [P, P, P, P, P, I, I, I, I, I, I, I, F, P],
     "gank_conv2d_wgrad_batched": [C.POINTER(WgradItem), I, I, I, I, I, I, I, I, F, P],
     "gank_conv2d_wgrad_ws_elems": [I, I, I, I, I, I, I],
     "gank_conv2d_wgrad": [P, P, P, P, P, L, I, I, I, I, I, I, I, F, P],
     "gank_upconv3x3_prep_weights": [P, P, P, I, I, P],
     "gank_upconv3x3_fprop": [P, P, P, P, P, I, I, I, I, I, I, P],
+    "gank_upconv3x3_fprop_stats": [P, P, P, P, P, I, I, I, I, I, I, P, I, P, P],
     "gank_upconv3x3_dgrad": [P, P, P, P, I, I, I, I, I, P],
     "gank_convpool3x3_prep_weights": [P, P, P, I, I, P],
     "gank_convpool3x3_fprop": [P, P, P, P, P, I, I, I, I, I, I, P],
@@ -61,6 +64,7 @@ PROTOTYPES = {
     "gank_sn_power_iter_bwd": [C.POINTER(SnDesc), I, P],
     "gank_cbn_parts": [L],
     "gank_cbn_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "gank_cbn_fwd_from_sums": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P],
     "gank_cbn_fwd_eps": [P, P, P, P, P, P, P, I, I, I, I, I, I, F, P],
     "gank_layer_norm_fwd": [P, P, P, P, P, I, I, I, F, P],
     "gank_layer_norm_bwd": [P, P, P, P, P, P, P, I, I, I, P],

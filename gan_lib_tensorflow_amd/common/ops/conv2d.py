@@ -78,11 +78,12 @@ def Conv2D(inputs, input_dim, output_dim, filter_size=3, stride=1, name='Conv2D'
            conv_type='conv2d', channel_multiplier=0, padding='SAME',
            spectral_normed=False, update_collection=None, inputs_norm=False, he_init=True,
            mask_type=None, weightnorm=None, biases=True, gain=1.,
-           residual=None, upsample=False, in_relu=False, pool_out=False, out_tanh=False):
+           residual=None, upsample=False, in_relu=False, pool_out=False, out_tanh=False, stats_groups=0):
     """inputs: bf16 tensor [batch, height, width, in_channels] on the GPU.
-    Returns [batch, out_height, out_width, output_dim]."""
+    Returns [batch, out_height, out_width, output_dim].  stats_groups: the result feeds a batch norm over that many
+    towers (functional.conv2d)."""
     filters, _biases = conv2d_variables(input_dim, output_dim, filter_size, stride, name, conv_type, padding,
                                         spectral_normed, update_collection, inputs_norm, he_init, mask_type, weightnorm,
                                         biases, gain)
     return Fn.conv2d(inputs, filters, _biases, residual=residual, upsample=upsample, in_relu=in_relu,
-                     pool_out=pool_out, out_tanh=out_tanh)
+                     pool_out=pool_out, out_tanh=out_tanh, stats_groups=stats_groups)

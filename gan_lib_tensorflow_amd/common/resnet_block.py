@@ -113,8 +113,9 @@ def UpsampleConv(inputs, output_dim, filter_size=3, stride=1, name=None,
 
 def ResidualBlock(inputs, input_dim, output_dim, filter_size, name,
                   spectral_normed=False, update_collection=None, inputs_norm=False,
-                  resample=None, labels=None, biases=True, groups=1):
-    """resample: None, 'down', or 'up'  (gan_cifar_resnet.py:156-209)."""
+                  resample=None, labels=None, biases=True, groups=1, out_stats=0):
+    """resample: None, 'down', or 'up'  (gan_cifar_resnet.py:156-209).  out_stats: the block's output feeds a batch norm
+    over that many towers (its statistics then come out of conv_2's epilogue where the kernel can produce them)."""
     if resample == 'down':
         conv_1 = functools.partial(_conv2d.Conv2D, input_dim=input_dim, output_dim=input_dim)
         conv_2 = functools.partial(ConvMeanPool, output_dim=output_dim)
@@ -144,17 +145,17 @@ def ResidualBlock(inputs, input_dim, output_dim, filter_size, name,
 
     # Normalize + nonlinearity (:185-186): relu rides on the CBN apply kernel, or on conv_1's operand
     norm1 = _normalize_kind(name + '.N1', labels) is not None
+    norm2 = _normalize_kind(name + '.N2', labels) is not None
     output = Normalize(name + '.N1', x_main, labels=labels, groups=groups, relu=True)
     output = conv_1(inputs=output, filter_size=filter_size, name=name + '.Conv1',
                     spectral_normed=spectral_normed, update_collection=update_collection,
-                    he_init=True, biases=biases, in_relu=not norm1)
+                    he_init=True, biases=biases, in_relu=not norm1, stats_groups=groups if norm2 else 0)
 
-    norm2 = _normalize_kind(name + '.N2', labels) is not None
     output = Normalize(name + '.N2', output, labels=labels, groups=groups, relu=True)
     # shortcut + output (:209) rides on conv_2's epilogue
     return conv_2(inputs=output, filter_size=filter_size, name=name + '.Conv2',
                   spectral_normed=spectral_normed, update_collection=update_collection,
-                  he_init=True, biases=biases, in_relu=not norm2, residual=shortcut)
+                  he_init=True, biases=biases, in_relu=not norm2, residual=shortcut, stats_groups=out_stats)
 
 
 FUSE_RES8 = True     # consecutive identity-shortcut 8x8x128 blocks without normalisation: one fused launch each way

@@ -147,6 +147,65 @@ __global__ __launch_bounds__(CBN_NT) void cbn_apply_kernel(const bf16* __restric
   }
 }
 
+// apply pass fed by statistics the PRODUCING conv accumulated in its epilogue (gank_conv2d_fprop_stats): every block
+// turns the shifted sums of its 8 channels into (mean, invstd) itself -- no statistics pass over x, no finalize launch.
+// sums [groups][GANK_STAT_SLOTS][2][C] = partial sums / sums of squares of (x - shift[c]) per tower; shift (the conv bias) may be null.
+__global__ __launch_bounds__(CBN_NT) void cbn_apply_sums_kernel(const bf16* __restrict__ x, const int* __restrict__ labels,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              bf16* __restrict__ y, float* __restrict__ stats, const float* __restrict__ sums,
+                                                              const float* __restrict__ shift, CbnGeom q) {
+  const int cg = q.C >> 3, RL = CBN_NT / cg;
+  const int g = threadIdx.x % cg, rl = threadIdx.x / cg;
+  const int grp = blockIdx.x / q.parts, part = blockIdx.x % q.parts;
+  const long r0 = grp * q.rows_per_group + part * q.rows_per_part;
+  long r1 = r0 + q.rows_per_part;
+  const long rend = (grp + 1) * q.rows_per_group;
+  if (r1 > rend) r1 = rend;
+  // one thread per channel adds the partial copies and leaves (mean, invstd) in LDS for the block
+  __shared__ float s_mu[2048], s_iv[2048];
+  const float M = (float)q.rows_per_group;
+  for (int c = threadIdx.x; c < q.C; c += CBN_NT) {
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < GANK_STAT_SLOTS; sl++) {
+      t1 += sums[(((long)grp * GANK_STAT_SLOTS + sl) * 2) * q.C + c];
+      t2 += sums[(((long)grp * GANK_STAT_SLOTS + sl) * 2 + 1) * q.C + c];
+    }
+    const float m1 = t1 / M, m2 = t2 / M;
+    const float mean = m1 + (shift ? shift[c] : 0.f), is = 1.f / sqrtf(fmaxf(m2 - m1 * m1, 0.f) + q.eps);   // biased variance (tf.nn.moments)
+    s_mu[c] = mean;
+    s_iv[c] = is;
+    if (part == 0) {                                                 // what the backward pass reads
+      stats[((long)grp * 2) * q.C + c] = mean;
+      stats[((long)grp * 2 + 1) * q.C + c] = is;
+    }
+  }
+  __syncthreads();
+  if (rl >= RL) return;
+  float mu[8], iv[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) { mu[e] = s_mu[g * 8 + e]; iv[e] = s_iv[g * 8 + e]; }
+  for (long r = r0 + rl; r < r1; r += RL) {
+    const int n = (int)(r / q.HW);
+    int lb = labels[n];
+    lb = lb < 0 ? 0 : (lb >= q.n_labels ? q.n_labels - 1 : lb);
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + (long)lb * q.C + g * 8);
+    const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + (long)lb * q.C + g * 8 + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + (long)lb * q.C + g * 8);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(beta + (long)lb * q.C + g * 8 + 4);
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + r * q.C + g * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const float ga = e < 4 ? g0[e] : g1[e - 4], be = e < 4 ? b0[e] : b1[e - 4];
+      float t = (bf2f(v[e]) - mu[e]) * iv[e] * ga + be;
+      if (q.relu) t = fmaxf(t, 0.f);
+      o[e] = f2bf(t);
+    }
+    *reinterpret_cast<bf16x8*>(y + r * q.C + g * 8) = o;
+  }
+}
+
 static int cbn_geom(CbnGeom& q, int N, int HW, int C, int groups, int n_labels, int relu) {
   GANK_REQUIRE(N > 0 && HW > 0 && C > 0 && groups > 0 && n_labels > 0, "cbn: bad shape");
   GANK_REQUIRE(N % groups == 0, "cbn: batch %d not divisible by %d towers", N, groups);
@@ -172,6 +231,20 @@ extern "C" int gank_cbn_fwd_eps(const void* x, const int32_t* labels, const floa
   hipLaunchKernelGGL(cbn_finalize_kernel, dim3(cdiv(C, 16), groups), dim3(256), 0, s, ws, stats, q);
   hipLaunchKernelGGL(cbn_apply_kernel, grid, dim3(CBN_NT), 0, s, (const bf16*)x, labels, gamma, beta, (bf16*)y, stats, q);
   GANK_LAUNCH_OK("cbn_fwd");
+  return 0;
+}
+
+extern "C" int gank_cbn_fwd_from_sums(const void* x, const int32_t* labels, const float* gamma, const float* beta, void* y, float* stats,
+                                      const float* sums, const float* shift, int N, int HW, int C, int groups, int n_labels, int relu,
+                                      float eps, void* stream) {
+  GANK_REQUIRE(x && labels && gamma && beta && y && stats && sums, "cbn_fwd_from_sums: null pointer");
+  CbnGeom q;
+  if (cbn_geom(q, N, HW, C, groups, n_labels, relu)) return 1;
+  GANK_REQUIRE(eps > 0.f, "cbn_fwd_from_sums: eps must be positive");
+  q.eps = eps;
+  hipLaunchKernelGGL(cbn_apply_sums_kernel, dim3(groups * q.parts), dim3(CBN_NT), 0, (hipStream_t)stream, (const bf16*)x, labels, gamma, beta,
+                     (bf16*)y, stats, sums, shift, q);
+  GANK_LAUNCH_OK("cbn_fwd_from_sums");
   return 0;
 }
 

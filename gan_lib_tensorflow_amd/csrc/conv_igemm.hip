@@ -45,6 +45,10 @@ struct IgemmArgs {
   int shw, sw;      // log2(H*W), log2(W) or -1
   int korder;       // bit0: tap-inner K order
   int tiles_pp;     // phase mode: pixel tiles per phase
+  // conditional-batch-norm statistics of the OUTPUT, accumulated by the epilogue (two-group kernel only):
+  // stat_sums [groups][2][Cout] += (sum, sum of squares) of (y - bias) over the samples of each tower; null = off
+  float* stat_sums;
+  int stat_n_per_group;
 };
 
 constexpr int LROW = 72;  // LDS row length in bf16 (64 + 8 pad) = 144 B
@@ -964,6 +968,19 @@ constexpr int PP_NSLOT = 6, PP_PD = 4;             // ring slots, prefetch dista
 constexpr int PP_WRING = 2 * PP_HALO_BYTES;
 constexpr int PP_LDS_BYTES = PP_WRING + PP_NSLOT * PP_WSLOT_BYTES;   // 144 KB
 
+template <int CTRL>
+__device__ __forceinline__ float pp_dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+// all 16 lanes of a DPP row end up with the row's sum: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ float pp_row_sum(float v) {
+  v = pp_dpp_add<0xB1>(v);
+  v = pp_dpp_add<0x4E>(v);
+  v = pp_dpp_add<0x141>(v);
+  v = pp_dpp_add<0x140>(v);
+  return v;
+}
+
 template <int N>
 __device__ __forceinline__ void pp_wait_vmcnt() {
   static_assert(N == 0 || N == 4 || N == 6 || N == 7, "vmcnt value not instantiated");
@@ -973,7 +990,7 @@ __device__ __forceinline__ void pp_wait_vmcnt() {
   if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
 }
 
-template <int MODE, int PW>   // MODE bit0: relu on the input operand; bit2: one output phase of a stride-2 transposed conv
+template <int MODE, int PW, bool STATS = false>   // MODE bit0: relu on the input operand; bit2: one output phase of a stride-2 transposed conv
 __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
   constexpr bool PHASE = (MODE & 4) != 0;
   constexpr int NT = PHASE ? 4 : 9;                  // taps (K-steps) per 32-channel chunk
@@ -1138,15 +1155,32 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
   // trades quad 2q+1 of the h = 0 half-wave for quad 2q of the h = 1 half-wave, after which every lane owns 8
   // CONSECUTIVE channels (16q + 8h ..) and writes, and reads mask / residual, 16 bytes at a time.
   const bool otanh = (a.flags & GANK_OUT_TANH) != 0;
+  // Loop order (i, q) outside, the 4 pixels of the lane inside: with STATS the epilogue also accumulates the batch-norm
+  // statistics of what it writes (normalization.py:47: tf.nn.moments of the NEXT layer's input) and needs only 16 live
+  // sums at a time (all 64 at once pushed the kernel past its register budget).  Sums are of (y - bias): the mean of a
+  // conv output is mostly its bias, and E[x^2] - E[x]^2 in fp32 wants a small mean.  A wave reduces its 32 pixels by
+  // shuffles; lanes r = 0 add to one of GANK_STAT_SLOTS copies of the tower's sums (blocks of a tower spread over the
+  // copies: same-address float atomics serialise at the memory side).
+  float keep1 = 0.f, keep2 = 0.f;
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int py = py0 + wm * (PHH / 2) + j * RS + prow, px = px0 + pcol;
-    const long m = PHASE ? ((long)(n * 2 * a.H + 2 * py + (phase >> 1))) * (2 * a.W) + 2 * px + (phase & 1) : ((long)(n * a.H + py)) * a.W + px;
-    const long mr = (!PHASE && (a.flags & IG_RES_UP2X)) ? ((long)(n * (a.H >> 1) + (py >> 1))) * (a.W >> 1) + (px >> 1) : m;
+  for (int i = 0; i < 2; i++) {
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int q = 0; q < 2; q++) {
+      const int co = tile_n * 256 + (wn * 2 + i) * 32 + 16 * q + 8 * h;
+      float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (a.bias) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + co), b1 = *reinterpret_cast<const f32x4*>(a.bias + co + 4);
 #pragma unroll
-      for (int q = 0; q < 2; q++) {
+        for (int e = 0; e < 4; e++) { bb[e] = b0[e]; bb[4 + e] = b1[e]; }
+      }
+      float st1[8], st2[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) { st1[e] = 0.f; st2[e] = 0.f; }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int py = py0 + wm * (PHH / 2) + j * RS + prow, px = px0 + pcol;
+        const long m = PHASE ? ((long)(n * 2 * a.H + 2 * py + (phase >> 1))) * (2 * a.W) + 2 * px + (phase & 1) : ((long)(n * a.H + py)) * a.W + px;
+        const long mr = (!PHASE && (a.flags & IG_RES_UP2X)) ? ((long)(n * (a.H >> 1) + (py >> 1))) * (a.W >> 1) + (px >> 1) : m;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
@@ -1157,13 +1191,9 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
           v[e] = lo;
           v[4 + e] = hi;
         }
-        const int co = tile_n * 256 + (wn * 2 + i) * 32 + 16 * q + 8 * h;
         const long o = m * a.Cout + co;
-        if (a.bias) {
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + co), b1 = *reinterpret_cast<const f32x4*>(a.bias + co + 4);
 #pragma unroll
-          for (int e = 0; e < 4; e++) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-        }
+        for (int e = 0; e < 8; e++) v[e] += bb[e];
         if (a.mask) {
           const bf16x8 mk = *reinterpret_cast<const bf16x8*>(a.mask + o);
 #pragma unroll
@@ -1174,26 +1204,62 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
 #pragma unroll
           for (int e = 0; e < 8; e++) v[e] += bf2f(rs[e]);
         }
+        if constexpr (STATS) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) { const float d = v[e] - bb[e]; st1[e] += d; st2[e] += d * d; }
+        }
         bf16x8 out;
 #pragma unroll
         for (int e = 0; e < 8; e++) out[e] = f2bf(otanh ? tanhf(v[e]) : v[e]);
         *reinterpret_cast<bf16x8*>(a.y + o) = out;
       }
+      if constexpr (STATS) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          // sum over the 32 lanes of a half-wave: 16-lane rows by DPP (VALU operand swizzles: lane^1, lane^2, half-row
+          // mirror, row mirror), the two rows by one LDS-crossbar shuffle (5 shuffles per value made this epilogue LDS-bound)
+          float s1 = pp_row_sum(st1[e]), s2 = pp_row_sum(st2[e]);
+          s1 += __shfl_xor(s1, 16, 64);
+          s2 += __shfl_xor(s2, 16, 64);
+          // every lane of the half-wave now holds the sums of channel (i, q, e): lane r = (2i + q) * 8 + e keeps them
+          const bool mine = r == (2 * i + q) * 8 + e;
+          keep1 = mine ? s1 : keep1;
+          keep2 = mine ? s2 : keep2;
+        }
+      }
     }
   }
+  if constexpr (STATS) {
+    // ONE full-width atomic per statistic and wave (an atomic instruction costs the memory pipe the same with 2 lanes as
+    // with 64: 512 two-lane atomics per block made this epilogue slower than the statistics pass it replaces)
+    float* dst = a.stat_sums + ((long)(n / a.stat_n_per_group) * GANK_STAT_SLOTS + (blockIdx.x % GANK_STAT_SLOTS)) * 2 * a.Cout;
+    const int ci = r >> 4, cq = (r >> 3) & 1, ce = r & 7;
+    const int co = tile_n * 256 + (wn * 2 + ci) * 32 + 16 * cq + 8 * h + ce;
+    atomicAdd(dst + co, keep1);
+    atomicAdd(dst + a.Cout + co, keep2);
+  }
+}
+
+static thread_local int tl_stats_done = 0;     // did the kernel chosen by the last dispatch accumulate a.stat_sums?
+__global__ void ig_zero_kernel(float* __restrict__ p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0.f;
 }
 
 template <int MODE, int PW>
 static int launch_pp(const IgemmArgs& a0, hipStream_t s) {
   IgemmArgs a = a0;
+  if (a.stat_sums) tl_stats_done = 1;
+  const bool stats = a.stat_sums != nullptr;
   constexpr bool PHASE = (MODE & 4) != 0;
   const int tiles = a.N * (a.H / (256 / PW)) * (a.W / PW);
   a.tiles_pp = tiles;
   a.tiles_m = PHASE ? 4 * tiles : tiles;
   a.tiles_n = a.Cout / 256;
   if (PHASE) { a.Kpad = 4 * a.Cin; a.Hin = a.H; a.Win = a.W; }
-  auto kern = conv_igemm_pp_kernel<MODE, PW>;
-  GANK_MAX_DYNAMIC_LDS(kern, PP_LDS_BYTES, "conv_igemm_pp");
+  auto kern = stats ? conv_igemm_pp_kernel<MODE, PW, true> : conv_igemm_pp_kernel<MODE, PW, false>;
+  if (stats) { GANK_MAX_DYNAMIC_LDS((conv_igemm_pp_kernel<MODE, PW, true>), PP_LDS_BYTES, "conv_igemm_pp"); }
+  else { GANK_MAX_DYNAMIC_LDS((conv_igemm_pp_kernel<MODE, PW, false>), PP_LDS_BYTES, "conv_igemm_pp"); }
   static const std::string tag = gank_format("conv_igemm_pp_kernel<%d, %d>", MODE, PW);     // magic static: built once, thread-safe
   gank_prof_tag(0, tag.c_str());
   hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(512), PP_LDS_BYTES, s, a);
@@ -1357,9 +1423,20 @@ int gank_igemm_dispatch(IgemmArgs a, hipStream_t s) {
   return rc;
 }
 
-extern "C" int gank_conv2d_fprop(const void* x, const void* wf, const float* bias, const void* residual,
-                                 const void* relu_ref, void* y, int N, int H, int W, int Cin, int Cout, int ksize,
-                                 int flags, float scale, void* stream) {
+static int stats_setup(IgemmArgs& a, float* stat_sums, int groups, int N, int Cout, hipStream_t s) {
+  tl_stats_done = 0;
+  if (!stat_sums) return 0;
+  GANK_REQUIRE(groups > 0 && N % groups == 0, "conv statistics: batch %d not divisible by %d towers", N, groups);
+  a.stat_sums = stat_sums;
+  a.stat_n_per_group = N / groups;
+  const int n = groups * GANK_STAT_SLOTS * 2 * Cout;
+  hipLaunchKernelGGL(ig_zero_kernel, dim3((n + 255) / 256), dim3(256), 0, s, stat_sums, n);
+  return 0;
+}
+
+static int conv2d_fprop_impl(const void* x, const void* wf, const float* bias, const void* residual,
+                             const void* relu_ref, void* y, int N, int H, int W, int Cin, int Cout, int ksize,
+                             int flags, float scale, float* stat_sums, int groups, void* stream) {
   GANK_REQUIRE(ksize % 2 == 1, "conv2d_fprop: even filter sizes are not on this path (ksize=%d)", ksize);
   GANK_REQUIRE(!(flags & GANK_IN_UPSAMPLE2X) || (H % 2 == 0 && W % 2 == 0), "conv2d_fprop: upsample needs even output size");
   IgemmArgs a{};
@@ -1373,7 +1450,22 @@ extern "C" int gank_conv2d_fprop(const void* x, const void* wf, const float* bia
             ((flags & GANK_RES_UPSAMPLE2X) ? IG_RES_UP2X : 0);
   GANK_REQUIRE(!(flags & GANK_RES_UPSAMPLE2X) || (residual && H % 2 == 0 && W % 2 == 0), "conv2d_fprop: RES_UPSAMPLE2X needs a residual and even output size");
   a.scale = scale;
+  if (stats_setup(a, stat_sums, groups, N, Cout, (hipStream_t)stream)) return 1;
   return gank_igemm_dispatch(a, (hipStream_t)stream);
+}
+
+extern "C" int gank_conv2d_fprop(const void* x, const void* wf, const float* bias, const void* residual,
+                                 const void* relu_ref, void* y, int N, int H, int W, int Cin, int Cout, int ksize,
+                                 int flags, float scale, void* stream) {
+  return conv2d_fprop_impl(x, wf, bias, residual, relu_ref, y, N, H, W, Cin, Cout, ksize, flags, scale, nullptr, 0, stream);
+}
+extern "C" int gank_conv2d_fprop_stats(const void* x, const void* wf, const float* bias, const void* residual,
+                                       const void* relu_ref, void* y, int N, int H, int W, int Cin, int Cout, int ksize,
+                                       int flags, float scale, float* stat_sums, int groups, int* produced, void* stream) {
+  GANK_REQUIRE(stat_sums && produced, "conv2d_fprop_stats: null statistics pointers");
+  const int rc = conv2d_fprop_impl(x, wf, bias, residual, relu_ref, y, N, H, W, Cin, Cout, ksize, flags, scale, stat_sums, groups, stream);
+  *produced = tl_stats_done;
+  return rc;
 }
 
 // dgrad of the stride-1 SAME conv = the same engine on dy with the flipped/transposed operand (wd)
@@ -1396,8 +1488,8 @@ extern "C" int gank_conv2d_dgrad(const void* dy, const void* wd, const void* res
 // NN-upsample(2x) + 3x3 SAME conv == stride-2 transposed conv with a 4x4 kernel: computed as 4 output phases
 // of 2x2 taps over the low-res input (2.25x fewer MACs than 9 taps at high resolution).  wph comes from
 // gank_upconv3x3_prep_weights.  Epilogue as gank_conv2d_fprop (bias, residual at OUTPUT resolution, tanh).
-extern "C" int gank_upconv3x3_fprop(const void* x, const void* wph, const float* bias, const void* residual, void* y,
-                                    int N, int Hl, int Wl, int Cin, int Cout, int flags, void* stream) {
+static int upconv3x3_fprop_impl(const void* x, const void* wph, const float* bias, const void* residual, void* y,
+                                int N, int Hl, int Wl, int Cin, int Cout, int flags, float* stat_sums, int groups, void* stream) {
   GANK_REQUIRE(Cin % 64 == 0, "upconv3x3_fprop: Cin must be a multiple of 64 (got %d)", Cin);
   IgemmArgs a{};
   a.x = (const bf16*)x; a.w = (const bf16*)wph; a.bias = bias; a.res = (const bf16*)residual; a.y = (bf16*)y;
@@ -1409,6 +1501,7 @@ extern "C" int gank_upconv3x3_fprop(const void* x, const void* wph, const float*
   a.taps = 4; a.CoutPad = roundup(Cout, 32); a.Kpad = 4 * Cin; a.nsteps = a.Kpad / 64;
   a.M = N * Hl * Wl; a.sw = log2_or_neg(Wl); a.shw = log2_or_neg(Hl * Wl);
   GANK_REQUIRE((long)N * Hl * Wl * Cin < (1L << 30) && (long)a.M * 4 * Cout < (1L << 31), "upconv3x3_fprop: tensor too large");
+  if (stats_setup(a, stat_sums, groups, N, Cout, s)) return 1;
   gank_prof_begin(0, 2.0 * a.M * 4.0 * (double)Cout * 4 * Cin, s, 2.0 * ((double)a.M * Cin + 16.0 * Cin * Cout + 4.0 * a.M * Cout));
   int rc;
   const long tiles128 = 4L * cdiv(a.M, 128) * (a.CoutPad / 128);
@@ -1418,6 +1511,19 @@ extern "C" int gank_upconv3x3_fprop(const void* x, const void* wph, const float*
   else if (a.CoutPad % 64 == 0) rc = launch_phase<2, 2, 1, 1, 4>(a, s);
   else rc = launch_phase<4, 1, 2, 1, 2>(a, s);
   gank_prof_end(0, s);
+  return rc;
+}
+
+extern "C" int gank_upconv3x3_fprop(const void* x, const void* wph, const float* bias, const void* residual, void* y,
+                                    int N, int Hl, int Wl, int Cin, int Cout, int flags, void* stream) {
+  return upconv3x3_fprop_impl(x, wph, bias, residual, y, N, Hl, Wl, Cin, Cout, flags, nullptr, 0, stream);
+}
+extern "C" int gank_upconv3x3_fprop_stats(const void* x, const void* wph, const float* bias, const void* residual, void* y,
+                                          int N, int Hl, int Wl, int Cin, int Cout, int flags, float* stat_sums, int groups, int* produced,
+                                          void* stream) {
+  GANK_REQUIRE(stat_sums && produced, "upconv3x3_fprop_stats: null statistics pointers");
+  const int rc = upconv3x3_fprop_impl(x, wph, bias, residual, y, N, Hl, Wl, Cin, Cout, flags, stat_sums, groups, stream);
+  *produced = tl_stats_done;
   return rc;
 }
 

@@ -149,7 +149,8 @@ class _Conv2d(Function):
     residual / tanh on the output (common/ops/conv2d.py:180-216; gan_cifar_resnet.py:112-153)."""
 
     @staticmethod
-    def forward(ctx, x, W, bias, residual, upsample, in_relu, pool_out, out_tanh):
+    def forward(ctx, x, W, bias, residual, upsample, in_relu, pool_out, out_tanh, stats_groups=0):
+        _Conv2d.last_stats = None
         if W.dim() == 2:
             k, cin, cout = 1, W.shape[0], W.shape[1]
         else:
@@ -173,7 +174,10 @@ class _Conv2d(Function):
             res_up = False
         if phase:
             wph, _ = getattr(W, "_prep_up", None) or K.upconv3x3_prep(W.detach().view(3, 3, cin, cout))
-            y = K.upconv3x3_fprop(x, wph, b, cout, K.OUT_TANH if out_tanh else 0, residual)
+            if stats_groups and not out_tanh:
+                y, _Conv2d.last_stats = K.upconv3x3_fprop(x, wph, b, cout, 0, residual, stats_groups)
+            else:
+                y = K.upconv3x3_fprop(x, wph, b, cout, K.OUT_TANH if out_tanh else 0, residual)
         elif pool4 and getattr(W, "_prep_cpres", None) is not None:       # resident form (conv_resident.hip)
             y = K.cpool_res_fprop(x, W._prep_cpres[0], b, cout, K.IN_RELU if in_relu else 0, residual)
         elif pool4:
@@ -185,7 +189,11 @@ class _Conv2d(Function):
             y = K.pool2x2(yfull, 0.25, residual)
         else:
             wf, _ = _prepared(W, k, cin, cout, True, False)
-            y = K.conv2d_fprop(x, wf, b, (H, Wd), cout, k, flags | (K.RES_UPSAMPLE2X if res_up else 0), 1.0, residual)
+            if stats_groups and not out_tanh:
+                y, _Conv2d.last_stats = K.conv2d_fprop(x, wf, b, (H, Wd), cout, k, flags | (K.RES_UPSAMPLE2X if res_up else 0), 1.0, residual,
+                                                       stats_groups=stats_groups)
+            else:
+                y = K.conv2d_fprop(x, wf, b, (H, Wd), cout, k, flags | (K.RES_UPSAMPLE2X if res_up else 0), 1.0, residual)
         ctx.res_up = res_up
         # identity-shortcut fusion (ShortcutLink): conv_1 arms the link when it will produce a plain input gradient;
         # conv_2 (called after it) then parks dy for it instead of returning it along the shortcut
@@ -258,11 +266,21 @@ class _Conv2d(Function):
         elif ctx.needs_input_grad[3]:
             # gradient of the (upsampled) shortcut add: dy itself, or its 2x2 sums for a half-resolution shortcut
             dres = K.pool2x2(g, 1.0) if (ctx.res_up or getattr(ctx, "res_up_orig", False)) else g
-        return dx, dW, db, dres, None, None, None, None
+        return dx, dW, db, dres, None, None, None, None, None
 
 
-def conv2d(x, W, bias=None, residual=None, upsample=False, in_relu=False, pool_out=False, out_tanh=False):
-    return _Conv2d.apply(x, W, bias, residual, upsample, in_relu, pool_out, out_tanh)
+import os as _os
+CONV_EPILOGUE_STATS = _os.environ.get("GANK_EPILOGUE_STATS", "1") == "1"     # batch-norm statistics of a conv's output from its own epilogue (two-group kernel), where asked for
+
+
+def conv2d(x, W, bias=None, residual=None, upsample=False, in_relu=False, pool_out=False, out_tanh=False, stats_groups=0):
+    """stats_groups > 0: the output feeds a (conditional) batch norm over that many towers; when the kernel that runs can
+    accumulate its statistics, they ride along on the result (`y._cbn_stats`) and cond_batchnorm skips its statistics pass."""
+    y = _Conv2d.apply(x, W, bias, residual, upsample, in_relu, pool_out, out_tanh, stats_groups if CONV_EPILOGUE_STATS else 0)
+    if stats_groups and _Conv2d.last_stats is not None:
+        y._cbn_stats = _Conv2d.last_stats
+        _Conv2d.last_stats = None
+    return y
 
 
 class _ResChain8(Function):
@@ -397,7 +415,11 @@ def spectral_norm_batch(Ws, us, snapshot=False, inplace=False):
 class _CondBatchNorm(Function):
     @staticmethod
     def forward(ctx, x, labels, gamma, beta, groups, relu):
-        y, stats = K.cbn_fwd(x, labels, gamma.detach(), beta.detach(), groups, relu)
+        cs = getattr(x, "_cbn_stats", None)
+        if cs is not None and cs.groups == groups and cs.sums.shape[-1] == x.shape[-1]:
+            y, stats = K.cbn_fwd_from_sums(x, labels, gamma.detach(), beta.detach(), cs, relu)      # statistics came with x
+        else:
+            y, stats = K.cbn_fwd(x, labels, gamma.detach(), beta.detach(), groups, relu)
         ctx.save_for_backward(x, y, labels, gamma, beta, stats)
         ctx.cfg = (groups, relu)
         return y
@@ -498,7 +520,11 @@ class _Fork(Function):
 def fork(x):
     if not x.requires_grad:
         return x, x
-    return _Fork.apply(x)
+    a, b = _Fork.apply(x)
+    cs = getattr(x, "_cbn_stats", None)
+    if cs is not None:                       # statistics that came with x (conv epilogue) belong to both aliases
+        a._cbn_stats = b._cbn_stats = cs
+    return a, b
 
 
 class _Relu(Function):

@@ -108,12 +108,30 @@ def prep_weights_batched(ws, want_d=True, kinds=None):
     return outs
 
 
-def conv2d_fprop(x, wf, bias, out_hw, cout, ksize, flags=0, scale=1.0, residual=None, relu_ref=None):
+class ConvStats:
+    """Batch-norm statistics a conv epilogue accumulated for the layer that consumes its output (gank_conv2d_fprop_stats):
+    sums [groups][STAT_SLOTS][2][C]: partial sums of (y - shift) and its square per tower; `shift` = the conv's bias (or None)."""
+    __slots__ = ("sums", "shift", "groups")
+
+    def __init__(self, sums, shift, groups):
+        self.sums, self.shift, self.groups = sums, shift, groups
+
+
+def conv2d_fprop(x, wf, bias, out_hw, cout, ksize, flags=0, scale=1.0, residual=None, relu_ref=None, stats_groups=0):
+    """stats_groups > 0: also returns a ConvStats (or None when the kernel that ran does not produce them) -> (y, stats)"""
     n, cin = x.shape[0], x.shape[3]
     h, w = out_hw
     y = torch.empty((n, h, w, cout), dtype=BF16, device=x.device)
     if getattr(wf, "_frag", False):
         flags |= W_FRAG
+    if stats_groups:
+        sums = torch.empty((stats_groups, _lib.STAT_SLOTS, 2, cout), dtype=F32, device=x.device)
+        produced = C.c_int(0)
+        _lib.check(lib().gank_conv2d_fprop_stats(_p(x, BF16, "x"), _p(wf, BF16, "wf"), _p(bias, F32, "bias"),
+                                                 _p(residual, BF16, "residual"), _p(relu_ref, BF16, "relu_ref"), _p(y),
+                                                 n, h, w, cin, cout, ksize, flags, scale, _p(sums), stats_groups, C.byref(produced),
+                                                 _stream()), "conv2d_fprop_stats")
+        return y, (ConvStats(sums, bias, stats_groups) if produced.value else None)
     _lib.check(lib().gank_conv2d_fprop(_p(x, BF16, "x"), _p(wf, BF16, "wf"), _p(bias, F32, "bias"),
                                        _p(residual, BF16, "residual"), _p(relu_ref, BF16, "relu_ref"), _p(y),
                                        n, h, w, cin, cout, ksize, flags, scale, _stream()), "conv2d_fprop")
@@ -173,9 +191,16 @@ def upconv3x3_prep(w):
     return wph, wd4
 
 
-def upconv3x3_fprop(x, wph, bias, cout, flags=0, residual=None):
+def upconv3x3_fprop(x, wph, bias, cout, flags=0, residual=None, stats_groups=0):
     n, hl, wl, cin = x.shape
     y = torch.empty((n, 2 * hl, 2 * wl, cout), dtype=BF16, device=x.device)
+    if stats_groups:
+        sums = torch.empty((stats_groups, _lib.STAT_SLOTS, 2, cout), dtype=F32, device=x.device)
+        produced = C.c_int(0)
+        _lib.check(lib().gank_upconv3x3_fprop_stats(_p(x, BF16, "x"), _p(wph, BF16), _p(bias, F32, "bias"), _p(residual, BF16, "residual"),
+                                                    _p(y), n, hl, wl, cin, cout, flags, _p(sums), stats_groups, C.byref(produced), _stream()),
+                   "upconv3x3_fprop_stats")
+        return y, (ConvStats(sums, bias, stats_groups) if produced.value else None)
     _lib.check(lib().gank_upconv3x3_fprop(_p(x, BF16, "x"), _p(wph, BF16), _p(bias, F32, "bias"), _p(residual, BF16, "residual"),
                                           _p(y), n, hl, wl, cin, cout, flags, _stream()), "upconv3x3_fprop")
     return y
@@ -441,6 +466,18 @@ def cbn_fwd(x, labels, gamma, beta, groups=1, relu=False, eps=1e-5):
     _lib.check(lib().gank_cbn_fwd_eps(_p(x, BF16, "x"), _p(labels, I32, "labels"), _p(gamma, F32, "gamma"), _p(beta, F32, "beta"),
                                       _p(y), _p(stats), _p(ws), n, hw, c, groups, gamma.shape[0], int(relu), float(eps), _stream()),
                "cbn_fwd")
+    return y, stats
+
+
+def cbn_fwd_from_sums(x, labels, gamma, beta, cs, relu=False, eps=1e-5):
+    """conditional batch norm forward on statistics a conv epilogue produced (ConvStats): one launch"""
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    y = torch.empty_like(x)
+    stats = torch.empty((cs.groups, 2, c), dtype=F32, device=x.device)
+    _lib.check(lib().gank_cbn_fwd_from_sums(_p(x, BF16, "x"), _p(labels, I32, "labels"), _p(gamma, F32, "gamma"), _p(beta, F32, "beta"),
+                                            _p(y), _p(stats), _p(cs.sums, F32, "sums"), _p(cs.shift, F32, "shift"), n, hw, c, cs.groups,
+                                            gamma.shape[0], int(relu), float(eps), _stream()), "cbn_fwd_from_sums")
     return y, stats
 
 

@@ -35,6 +35,7 @@ extern "C" {
 #define GANK_OUT_TANH 4        /* tanh applied last in the epilogue                                   */
 #define GANK_DY_UPSAMPLE2X 8   /* wgrad only: dy is [N,H/2,W/2,Cout] (gradient of a 2x2 mean pool)    */
 #define GANK_W_FRAG 32         /* fprop/dgrad: the operand buffer carries the fragment-major copy (prep kind 3) */
+#define GANK_STAT_SLOTS 16     /* copies of each tower's statistics sums the conv epilogues spread their atomics over */
 #define GANK_RES_UPSAMPLE2X 64 /* fprop: residual is [N,H/2,W/2,Cout] and is added nearest-neighbour upsampled: the
                                   shortcut of an 'up' residual block (gan_cifar_resnet.py:179-182,209) without
                                   materialising the upsampled tensor */
@@ -79,6 +80,15 @@ int gank_conv2d_prep_weights_batched(const gank_prep_desc* table, int count, voi
 int gank_conv2d_fprop(const void* x, const void* wf, const float* bias, const void* residual,
                       const void* relu_ref, void* y, int N, int H, int W, int Cin, int Cout, int ksize,
                       int flags, float scale, void* stream);
+
+/* The same with the conditional-batch-norm statistics of y accumulated by the epilogue (normalization.py:47: the
+ * tf.nn.moments of the layer that consumes y): stat_sums [groups][GANK_STAT_SLOTS][2][Cout] fp32 <- per tower (N/groups
+ * consecutive samples) the sum and the sum of squares of (y - bias), spread over GANK_STAT_SLOTS partial copies (add them up).  Only the two-group LDS-DMA kernel does it: *produced = 1 if the
+ * sums were written (feed them to gank_cbn_fwd_from_sums), 0 if another kernel ran (use gank_cbn_fwd).  The buffer is
+ * zeroed here.  gank_upconv3x3_fprop_stats: likewise for the phase-decomposed UpsampleConv. */
+int gank_conv2d_fprop_stats(const void* x, const void* wf, const float* bias, const void* residual,
+                            const void* relu_ref, void* y, int N, int H, int W, int Cin, int Cout, int ksize,
+                            int flags, float scale, float* stat_sums, int groups, int* produced, void* stream);
 
 /* ---- conv2d input gradient: dx = epilogue(conv_SAME(in(dy), flip(w)^T) * scale) ------------------
  * Replaces the Conv2DBackpropInput op TensorFlow autodiff emits for conv2d.py:180-187.  Same engine
@@ -152,6 +162,9 @@ int gank_cpool_res_dgrad(const void* dy, const void* w_rfrag, const void* relu_r
 int gank_upconv3x3_prep_weights(const float* w, void* wph, void* wd4, int Cin, int Cout, void* stream);
 int gank_upconv3x3_fprop(const void* x, const void* wph, const float* bias, const void* residual, void* y,
                          int N, int Hl, int Wl, int Cin, int Cout, int flags, void* stream);
+int gank_upconv3x3_fprop_stats(const void* x, const void* wph, const float* bias, const void* residual, void* y,
+                               int N, int Hl, int Wl, int Cin, int Cout, int flags, float* stat_sums, int groups, int* produced,
+                               void* stream);
 int gank_upconv3x3_dgrad(const void* dy, const void* wd4, const void* relu_ref, void* dx, int N, int Hl, int Wl,
                          int Cin, int Cout, void* stream);
 
@@ -242,6 +255,12 @@ int gank_cbn_fwd(const void* x, const int32_t* labels, const float* gamma, const
  * kernel set with groups = N (one tower per sample) and a one-row gamma/beta table */
 int gank_cbn_fwd_eps(const void* x, const int32_t* labels, const float* gamma, const float* beta, void* y,
                      float* stats, float* ws, int N, int HW, int C, int groups, int n_labels, int relu, float eps, void* stream);
+/* forward with the statistics taken from the producing conv's epilogue (gank_conv2d_fprop_stats): sums [groups][GANK_STAT_SLOTS][2][C]
+ * of (x - shift[c]) and its square per tower (partial copies, added here), shift = that conv's bias or NULL.  ONE launch (no statistics pass, no merge);
+ * writes stats [groups][2][C] (mean, invstd) for gank_cbn_bwd. */
+int gank_cbn_fwd_from_sums(const void* x, const int32_t* labels, const float* gamma, const float* beta, void* y, float* stats,
+                           const float* sums, const float* shift, int N, int HW, int C, int groups, int n_labels, int relu,
+                           float eps, void* stream);
 int gank_cbn_bwd(const void* dy, const void* x, const void* y, const int32_t* labels, const float* gamma,
                  const float* stats, void* dx, float* dgamma, float* dbeta, float* ws, int N, int HW, int C,
                  int groups, int n_labels, int relu, void* stream);
