@@ -101,6 +101,15 @@ PROTOTYPES = {
     "gank_sum_hw": [P, P, I, I, I, F, P],
     "gank_bcast_hw": [P, P, I, I, I, F, P],
     "gank_rng_uniform_f32": [P, L, P, P],
+    "gank_axpby_bf16": [P, P, F, F, P, L, P],
+    "gank_minibatch_std_fwd": [P, P, P, I, I, I, P],
+    "gank_minibatch_std_bwd": [P, P, P, P, I, I, I, P],
+    "gank_resize_bilinear": [P, P, I, I, I, I, I, I, P],
+    "gank_concat_channels": [P, P, P, L, I, I, P],
+    "gank_split_channels": [P, P, P, L, I, I, P],
+    "gank_l1_loss": [P, P, P, P, P, L, P],
+    "gank_dropout_fwd": [P, P, P, L, F, P, P],
+    "gank_dropout_bwd": [P, P, P, L, F, P],
     "gank_adam_tf": [P, P, P, P, P, P, P, L, P],
     "gank_counter_add": [P, C.c_int64, P],
     "gank_preprocess_real": [P, P, P, I, P],

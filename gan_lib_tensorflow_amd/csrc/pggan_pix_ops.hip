@@ -1,0 +1,232 @@
+// Small HBM / latency bound operators of the PGGAN (BASELINE.json config 4) and Pix2Pix (config 5) paths:
+//   axpby           y = alpha*a + beta*b                      fade-in blend (PGGAN/model_nvidia.py:116,206), scaling
+//   minibatch_std   (PGGAN/model_nvidia.py:20-29)             forward and backward
+//   resize_bilinear tf.image.resize_images (PGGAN/train.py:88-92; Pix2Pix/train.py) legacy semantics (no half-pixel offset)
+//   concat_c        tf.concat(axis=3) of two NHWC tensors      U-Net skip connections (Pix2Pix/networks.py:470-520) + split
+//   dropout         tf.nn.dropout(keep_prob) from the device RNG (networks.py:480-500), mask kept for the backward pass
+//   abs_diff_mean   mean |a - b| and its gradient              L1 loss (Pix2Pix/train.py:510-512)
+#include "gank_common.h"
+
+static inline dim3 g1(long n, long cap = 4096) {
+  long b = (n + 255) / 256;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return dim3((unsigned)b);
+}
+
+__global__ void axpby_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, float alpha, float beta, bf16* __restrict__ y, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = f2bf(alpha * bf2f(a[i]) + (b ? beta * bf2f(b[i]) : 0.f));
+}
+extern "C" int gank_axpby_bf16(const void* a, const void* b, float alpha, float beta, void* y, long n, void* stream) {
+  GANK_REQUIRE(a && y && n > 0, "axpby: bad arguments");
+  hipLaunchKernelGGL(axpby_kernel, g1(n), dim3(256), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b, alpha, beta, (bf16*)y, n);
+  GANK_LAUNCH_OK("axpby");
+  return 0;
+}
+
+// ---- minibatch_std: y = concat(x, s), s = mean over (h,w,c) of sqrt(var_batch(x) + 1e-8) --------------------------------
+// ws: fp32 [R + 1] (R = HW*C): per-position sqrt(v + eps), then the scalar at ws[R]
+__global__ void mbstd_pos_kernel(const bf16* __restrict__ x, float* __restrict__ ws, int B, long R) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= R) return;
+  float m = 0.f;
+  for (int b = 0; b < B; b++) m += bf2f(x[b * R + i]);
+  m /= (float)B;
+  float v = 0.f;
+  for (int b = 0; b < B; b++) { const float d = bf2f(x[b * R + i]) - m; v += d * d; }
+  ws[i] = sqrtf(v / (float)B + 1e-8f);
+}
+__global__ __launch_bounds__(256) void mbstd_mean_kernel(float* __restrict__ ws, long R) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (long i = threadIdx.x; i < R; i += blockDim.x) acc += ws[i];
+  const float tot = block_sum(acc, red);
+  if (threadIdx.x == 0) ws[R] = tot / (float)R;
+}
+__global__ void mbstd_concat_kernel(const bf16* __restrict__ x, const float* __restrict__ ws, bf16* __restrict__ y, long pixels, int C, long R) {
+  const long total = pixels * (C + 1);
+  const bf16 s = f2bf(ws[R]);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long p = i / (C + 1);
+    const int c = (int)(i - p * (C + 1));
+    y[i] = c < C ? x[p * C + c] : s;
+  }
+}
+extern "C" int gank_minibatch_std_fwd(const void* x, void* y, float* ws, int B, int HW, int C, void* stream) {
+  GANK_REQUIRE(x && y && ws && B > 0 && HW > 0 && C > 0, "minibatch_std_fwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const long R = (long)HW * C;
+  hipLaunchKernelGGL(mbstd_pos_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, (const bf16*)x, ws, B, R);
+  hipLaunchKernelGGL(mbstd_mean_kernel, dim3(1), dim3(256), 0, s, ws, R);
+  hipLaunchKernelGGL(mbstd_concat_kernel, g1((long)B * HW * (C + 1)), dim3(256), 0, s, (const bf16*)x, ws, (bf16*)y, (long)B * HW, C, R);
+  GANK_LAUNCH_OK("minibatch_std_fwd");
+  return 0;
+}
+// dx[b,i] = dy[b,i(:C)] + ds/(R*B) * (x[b,i] - m_i) / sqrt(v_i + eps),   ds = sum over (b,hw) of dy[b,hw,C]
+__global__ __launch_bounds__(256) void mbstd_ds_kernel(const bf16* __restrict__ dy, float* __restrict__ ws, long pixels, int C, long R) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (long p = threadIdx.x; p < pixels; p += blockDim.x) acc += bf2f(dy[p * (C + 1) + C]);
+  const float tot = block_sum(acc, red);
+  if (threadIdx.x == 0) ws[R + 1] = tot;
+}
+__global__ void mbstd_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, const float* __restrict__ ws, bf16* __restrict__ dx,
+                                 int B, int HW, int C, long R) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= R) return;
+  float m = 0.f;
+  for (int b = 0; b < B; b++) m += bf2f(x[b * R + i]);
+  m /= (float)B;
+  const float k = ws[R + 1] / ((float)R * (float)B) / ws[i];
+  const long hw = i / C;
+  const int c = (int)(i - hw * C);
+  for (int b = 0; b < B; b++)
+    dx[b * R + i] = f2bf(bf2f(dy[((long)b * HW + hw) * (C + 1) + c]) + k * (bf2f(x[b * R + i]) - m));
+}
+extern "C" int gank_minibatch_std_bwd(const void* dy, const void* x, float* ws, void* dx, int B, int HW, int C, void* stream) {
+  GANK_REQUIRE(dy && x && ws && dx && B > 0 && HW > 0 && C > 0, "minibatch_std_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const long R = (long)HW * C;
+  hipLaunchKernelGGL(mbstd_ds_kernel, dim3(1), dim3(256), 0, s, (const bf16*)dy, ws, (long)B * HW, C, R);
+  hipLaunchKernelGGL(mbstd_bwd_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, ws, (bf16*)dx, B, HW, C, R);
+  GANK_LAUNCH_OK("minibatch_std_bwd");
+  return 0;
+}
+
+// ---- tf.image.resize_images(method=BILINEAR, align_corners=False), TF1 legacy sampling: src = dst * (in / out) --------
+__global__ void resize_bilinear_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int N, int Hi, int Wi, int Ho, int Wo, int C) {
+  const long total = (long)N * Ho * Wo * C;
+  const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const float fy = oy * sy, fx = ox * sx;
+    const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+    const int y1 = y0 + 1 < Hi ? y0 + 1 : Hi - 1, x1 = x0 + 1 < Wi ? x0 + 1 : Wi - 1;
+    const float wy = fy - y0, wx = fx - x0;
+    const bf16* base = x + (long)n * Hi * Wi * C + c;
+    const float v00 = bf2f(base[((long)y0 * Wi + x0) * C]), v01 = bf2f(base[((long)y0 * Wi + x1) * C]);
+    const float v10 = bf2f(base[((long)y1 * Wi + x0) * C]), v11 = bf2f(base[((long)y1 * Wi + x1) * C]);
+    const float top = v00 + (v01 - v00) * wx, bot = v10 + (v11 - v10) * wx;
+    y[i] = f2bf(top + (bot - top) * wy);
+  }
+}
+extern "C" int gank_resize_bilinear(const void* x, void* y, int N, int Hi, int Wi, int Ho, int Wo, int C, void* stream) {
+  GANK_REQUIRE(x && y && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "resize_bilinear: bad arguments");
+  hipLaunchKernelGGL(resize_bilinear_kernel, g1((long)N * Ho * Wo * C), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, N, Hi, Wi, Ho, Wo, C);
+  GANK_LAUNCH_OK("resize_bilinear");
+  return 0;
+}
+
+// ---- channel concat / split of NHWC tensors --------------------------------------------------------------------------
+__global__ void concat_c_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ y, long pixels, int Ca, int Cb) {
+  const int C = Ca + Cb;
+  const long total = pixels * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long p = i / C;
+    const int c = (int)(i - p * C);
+    y[i] = c < Ca ? a[p * Ca + c] : b[p * Cb + (c - Ca)];
+  }
+}
+__global__ void split_c_kernel(const bf16* __restrict__ y, bf16* __restrict__ a, bf16* __restrict__ b, long pixels, int Ca, int Cb) {
+  const int C = Ca + Cb;
+  const long total = pixels * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long p = i / C;
+    const int c = (int)(i - p * C);
+    if (c < Ca) { if (a) a[p * Ca + c] = y[i]; }
+    else if (b) b[p * Cb + (c - Ca)] = y[i];
+  }
+}
+extern "C" int gank_concat_channels(const void* a, const void* b, void* y, long pixels, int Ca, int Cb, void* stream) {
+  GANK_REQUIRE(a && b && y && pixels > 0 && Ca > 0 && Cb > 0, "concat_channels: bad arguments");
+  hipLaunchKernelGGL(concat_c_kernel, g1(pixels * (Ca + Cb)), dim3(256), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b, (bf16*)y, pixels, Ca, Cb);
+  GANK_LAUNCH_OK("concat_channels");
+  return 0;
+}
+extern "C" int gank_split_channels(const void* y, void* a, void* b, long pixels, int Ca, int Cb, void* stream) {
+  GANK_REQUIRE(y && (a || b) && pixels > 0 && Ca > 0 && Cb > 0, "split_channels: bad arguments");
+  hipLaunchKernelGGL(split_c_kernel, g1(pixels * (Ca + Cb)), dim3(256), 0, (hipStream_t)stream, (const bf16*)y, (bf16*)a, (bf16*)b, pixels, Ca, Cb);
+  GANK_LAUNCH_OK("split_channels");
+  return 0;
+}
+
+// ---- L1 loss: mean |a - b|, gradient wrt a ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l1_part_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, float* __restrict__ part, float* __restrict__ dl32, long n) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  const float inv = 1.f / (float)n;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float d = bf2f(a[i]) - bf2f(b[i]);
+    acc += fabsf(d);
+    dl32[i] = d > 0.f ? inv : (d < 0.f ? -inv : 0.f);
+  }
+  const float tot = block_sum(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot * inv;
+}
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ part, float* __restrict__ out, int n) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) acc += part[i];
+  const float tot = block_sum(acc, red);
+  if (threadIdx.x == 0) out[0] = tot;
+}
+extern "C" int gank_l1_loss(const void* a, const void* b, float* loss, float* dl32, float* ws, long n, void* stream) {
+  GANK_REQUIRE(a && b && loss && dl32 && ws && n > 0, "l1_loss: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid = g1(n, 1024);
+  hipLaunchKernelGGL(l1_part_kernel, grid, dim3(256), 0, s, (const bf16*)a, (const bf16*)b, ws, dl32, n);
+  hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(256), 0, s, ws, loss, (int)grid.x);
+  GANK_LAUNCH_OK("l1_loss");
+  return 0;
+}
+
+// ---- dropout: y = x * mask / keep, mask ~ Bernoulli(keep) from Philox (same generator as loss_opt.hip) ---------------------
+__device__ __forceinline__ unsigned philox_word(unsigned long long ctr, unsigned long long off, unsigned long long seed) {
+  unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = (unsigned)off, c3 = (unsigned)(off >> 32);
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return c0;
+}
+__global__ void dropout_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, unsigned char* __restrict__ mask, long n, float keep,
+                               const unsigned long long* __restrict__ state) {
+  const unsigned long long seed = state[0], off = state[1];
+  const float inv = 1.f / keep;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float u = (float)(philox_word((unsigned long long)i, off, seed) >> 8) * (1.0f / 16777216.0f);
+    const unsigned char m = u < keep ? 1 : 0;
+    mask[i] = m;
+    y[i] = f2bf(m ? bf2f(x[i]) * inv : 0.f);
+  }
+}
+__global__ void dropout_advance_kernel(unsigned long long* state) { state[1] += 1; }
+__global__ void dropout_bwd_kernel(const bf16* __restrict__ dy, const unsigned char* __restrict__ mask, bf16* __restrict__ dx, long n, float keep) {
+  const float inv = 1.f / keep;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dx[i] = f2bf(mask[i] ? bf2f(dy[i]) * inv : 0.f);
+}
+extern "C" int gank_dropout_fwd(const void* x, void* y, uint8_t* mask, long n, float keep, uint64_t* rng_state, void* stream) {
+  GANK_REQUIRE(x && y && mask && rng_state && n > 0 && keep > 0.f && keep <= 1.f, "dropout_fwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(dropout_kernel, g1(n), dim3(256), 0, s, (const bf16*)x, (bf16*)y, mask, n, keep, (const unsigned long long*)rng_state);
+  hipLaunchKernelGGL(dropout_advance_kernel, dim3(1), dim3(1), 0, s, (unsigned long long*)rng_state);
+  GANK_LAUNCH_OK("dropout_fwd");
+  return 0;
+}
+extern "C" int gank_dropout_bwd(const void* dy, const uint8_t* mask, void* dx, long n, float keep, void* stream) {
+  GANK_REQUIRE(dy && mask && dx && n > 0 && keep > 0.f, "dropout_bwd: bad arguments");
+  hipLaunchKernelGGL(dropout_bwd_kernel, g1(n), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, mask, (bf16*)dx, n, keep);
+  GANK_LAUNCH_OK("dropout_bwd");
+  return 0;
+}

@@ -713,3 +713,95 @@ def to_bf16(x):
 
 def to_f32(x):
     return x if x.dtype == torch.float32 else _Cast.apply(x, False)
+
+
+# ---------------------------------------------------------------- PGGAN / Pix2Pix operators
+class _Blend(Function):
+    """(1 - alpha) * a + alpha * b: the fade-in of a new resolution (PGGAN/model_nvidia.py:116,206); alpha is a Python float
+    (a placeholder fed per step in the reference, train.py:81)"""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        ctx.alpha = float(alpha)
+        return K.axpby(a, b, 1.0 - ctx.alpha, ctx.alpha)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        return (K.axpby(g, None, 1.0 - ctx.alpha) if ctx.needs_input_grad[0] else None,
+                K.axpby(g, None, ctx.alpha) if ctx.needs_input_grad[1] else None, None)
+
+
+def blend(a, b, alpha):
+    return _Blend.apply(a, b, alpha)
+
+
+class _MinibatchStd(Function):
+    @staticmethod
+    def forward(ctx, x):
+        y, ws = K.minibatch_std_fwd(x)
+        ctx.save_for_backward(x, ws)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, ws = ctx.saved_tensors
+        return K.minibatch_std_bwd(_c(dy), x, ws)
+
+
+def minibatch_std(x):
+    """PGGAN/model_nvidia.py:20-29"""
+    return _MinibatchStd.apply(_c(x))
+
+
+class _ConcatC(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.ca = a.shape[-1]
+        return K.concat_channels(_c(a), _c(b))
+
+    @staticmethod
+    def backward(ctx, g):
+        return K.split_channels(_c(g), ctx.ca)
+
+
+def concat_channels(a, b):
+    """tf.concat([a, b], axis=3)"""
+    return _ConcatC.apply(a, b)
+
+
+class _Dropout(Function):
+    @staticmethod
+    def forward(ctx, x, keep, rng_state):
+        y, mask = K.dropout_fwd(_c(x), keep, rng_state)
+        ctx.save_for_backward(mask)
+        ctx.keep = keep
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return K.dropout_bwd(_c(g), mask, ctx.keep), None, None
+
+
+def dropout(x, keep_prob, rng_state):
+    """tf.nn.dropout(x, keep_prob)"""
+    return _Dropout.apply(x, keep_prob, rng_state)
+
+
+class _L1(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        loss, dl32 = K.l1_loss(_c(a), _c(b))
+        ctx.save_for_backward(dl32)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl32,) = ctx.saved_tensors
+        return K.loss_grad_scale(dl32, _c(g.to(torch.float32)).reshape(1)), None
+
+
+def l1_loss(a, b):
+    """tf.reduce_mean(tf.abs(a - b)); differentiable in a (the target b is data)"""
+    return _L1.apply(a, b)

@@ -777,6 +777,76 @@ def rng_uniform(n, rng_state):
     return y
 
 
+# ------------------------------------------------------------------ PGGAN / Pix2Pix operators
+def axpby(a, b, alpha, beta=0.0):
+    """alpha * a + beta * b (b may be None), bf16"""
+    y = torch.empty_like(a)
+    _lib.check(lib().gank_axpby_bf16(_p(a, BF16, "a"), _p(b, BF16, "b"), float(alpha), float(beta), _p(y), a.numel(), _stream()), "axpby")
+    return y
+
+
+def minibatch_std_fwd(x):
+    b, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (b * c)
+    y = torch.empty(tuple(x.shape[:-1]) + (c + 1,), dtype=BF16, device=x.device)
+    ws = torch.empty(hw * c + 2, dtype=F32, device=x.device)
+    _lib.check(lib().gank_minibatch_std_fwd(_p(x, BF16, "x"), _p(y), _p(ws), b, hw, c, _stream()), "minibatch_std_fwd")
+    return y, ws
+
+
+def minibatch_std_bwd(dy, x, ws):
+    b, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (b * c)
+    dx = torch.empty_like(x)
+    _lib.check(lib().gank_minibatch_std_bwd(_p(dy, BF16, "dy"), _p(x, BF16, "x"), _p(ws, F32, "ws"), _p(dx), b, hw, c, _stream()), "minibatch_std_bwd")
+    return dx
+
+
+def resize_bilinear(x, out_hw):
+    n, hi, wi, c = x.shape
+    y = torch.empty((n, out_hw[0], out_hw[1], c), dtype=BF16, device=x.device)
+    _lib.check(lib().gank_resize_bilinear(_p(x, BF16, "x"), _p(y), n, hi, wi, out_hw[0], out_hw[1], c, _stream()), "resize_bilinear")
+    return y
+
+
+def concat_channels(a, b):
+    ca, cb = a.shape[-1], b.shape[-1]
+    assert a.shape[:-1] == b.shape[:-1], (a.shape, b.shape)
+    y = torch.empty(tuple(a.shape[:-1]) + (ca + cb,), dtype=BF16, device=a.device)
+    _lib.check(lib().gank_concat_channels(_p(a, BF16, "a"), _p(b, BF16, "b"), _p(y), a.numel() // ca, ca, cb, _stream()), "concat_channels")
+    return y
+
+
+def split_channels(y, ca):
+    c = y.shape[-1]
+    a = torch.empty(tuple(y.shape[:-1]) + (ca,), dtype=BF16, device=y.device)
+    b = torch.empty(tuple(y.shape[:-1]) + (c - ca,), dtype=BF16, device=y.device)
+    _lib.check(lib().gank_split_channels(_p(y, BF16, "y"), _p(a), _p(b), y.numel() // c, ca, c - ca, _stream()), "split_channels")
+    return a, b
+
+
+def l1_loss(a, b):
+    """-> (mean |a - b| fp32[1], d/da fp32)"""
+    loss = torch.empty(1, dtype=F32, device=a.device)
+    dl32 = torch.empty(a.shape, dtype=F32, device=a.device)
+    ws = torch.empty(1024, dtype=F32, device=a.device)
+    _lib.check(lib().gank_l1_loss(_p(a, BF16, "a"), _p(b, BF16, "b"), _p(loss), _p(dl32), _p(ws), a.numel(), _stream()), "l1_loss")
+    return loss, dl32
+
+
+def dropout_fwd(x, keep, rng_state):
+    y = torch.empty_like(x)
+    mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    _lib.check(lib().gank_dropout_fwd(_p(x, BF16, "x"), _p(y), _p(mask), x.numel(), float(keep), _p(rng_state, torch.int64), _stream()), "dropout_fwd")
+    return y, mask
+
+
+def dropout_bwd(dy, mask, keep):
+    dx = torch.empty_like(dy)
+    _lib.check(lib().gank_dropout_bwd(_p(dy, BF16, "dy"), _p(mask, torch.uint8, "mask"), _p(dx), dy.numel(), float(keep), _stream()), "dropout_bwd")
+    return dx
+
+
 def critic_feed(real_all, labels_all, fake_all, both, labels2, slot, rng_state, done):
     """both/labels2 <- slot `slot[0]` of the feed ring (preprocessed reals, kept fakes, labels twice); advances slot and RNG"""
     n_slots, b = labels_all.shape

@@ -354,6 +354,24 @@ int gank_sum_hw(const void* x, void* y, int N, int HW, int C, float scale, void*
 int gank_bcast_hw(const void* g, void* y, int N, int HW, int C, float scale, void* stream);
 int gank_rng_uniform_f32(float* y, long n, uint64_t* rng_state, void* stream);
 
+/* ---- small operators of the PGGAN (config 4) and Pix2Pix (config 5) paths --------------------------------------------
+ * axpby: y = alpha*a + beta*b (b may be NULL): the fade-in blend (1-alpha)*toRGB2 + alpha*toRGB1 (PGGAN/model_nvidia.py:116,206).
+ * minibatch_std (model_nvidia.py:20-29): y [B,HW,C+1] = concat(x, mean_{hwc} sqrt(var_batch(x)+1e-8)); ws fp32 [HW*C + 2] is
+ *   kept from fwd to bwd; bwd: dx from dy [B,HW,C+1].
+ * resize_bilinear: tf.image.resize_images (BILINEAR, align_corners=False; PGGAN/train.py:88-92).
+ * concat_channels / split_channels: tf.concat(axis=3) of two NHWC tensors and its gradient (Pix2Pix/networks.py U-Net skips).
+ * l1_loss: mean |a-b| (Pix2Pix/train.py:510-512); dl32 fp32 = d loss / d a (gank_loss_grad_scale rounds it once); ws fp32 [1024].
+ * dropout: tf.nn.dropout(x, keep) with a byte mask from the device RNG (networks.py decoder), and its gradient. */
+int gank_axpby_bf16(const void* a, const void* b, float alpha, float beta, void* y, long n, void* stream);
+int gank_minibatch_std_fwd(const void* x, void* y, float* ws, int B, int HW, int C, void* stream);
+int gank_minibatch_std_bwd(const void* dy, const void* x, float* ws, void* dx, int B, int HW, int C, void* stream);
+int gank_resize_bilinear(const void* x, void* y, int N, int Hi, int Wi, int Ho, int Wo, int C, void* stream);
+int gank_concat_channels(const void* a, const void* b, void* y, long pixels, int Ca, int Cb, void* stream);
+int gank_split_channels(const void* y, void* a, void* b, long pixels, int Ca, int Cb, void* stream);
+int gank_l1_loss(const void* a, const void* b, float* loss, float* dl32, float* ws, long n, void* stream);
+int gank_dropout_fwd(const void* x, void* y, uint8_t* mask, long n, float keep, uint64_t* rng_state, void* stream);
+int gank_dropout_bwd(const void* dy, const uint8_t* mask, void* dx, long n, float keep, void* stream);
+
 /* ---- tf.train.AdamOptimizer (gan_cifar_resnet.py:521-526), one launch over a flat buffer ---------
  * All step state lives on the device so a captured update replays without host traffic:
  * hp (float[8]) = {lr, beta1, beta2, eps, grad_scale, decay_on}; t_state[0] = updates applied so far
