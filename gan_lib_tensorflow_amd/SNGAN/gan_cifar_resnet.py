@@ -181,8 +181,11 @@ class AdamTF:
         self.t = torch.zeros(1, dtype=torch.int64, device=dev)
 
     def apply(self):
+        """One launch: the update, the step count, and the gradient buffer (with its scratch half) cleared for the next
+        backward pass -- `flat['clean']` tells the trainer that no fill is needed."""
         f = self.flat
-        K.adam_tf(f["params"], f["grads"], f["m"], f["v"], self.hp, self.t, self.iteration)
+        K.adam_tf(f["params"], f["grads_all"], f["m"], f["v"], self.hp, self.t, self.iteration, zero_grads=True)
+        f["clean"] = True
 
 
 @contextlib.contextmanager
@@ -329,6 +332,20 @@ class SNGANTrainer:
         self.g_opt.apply()
         self._refresh_g_prep()
 
+    def _begin_grads(self, flat):
+        """Gradients accumulate into the flat buffer, which must be zero when a backward pass starts.  The optimiser launch
+        leaves it zero (AdamTF.apply); only a pass that follows another pass without an update in between -- tests and
+        tools calling the *_forward_backward pieces directly -- needs the fill."""
+        if not flat.get("clean", False):
+            flat["grads_all"].zero_()
+        flat["clean"] = False
+
+    def _ensure_clean(self, flat):
+        """before replaying a captured update (its graph contains no fill)"""
+        if not flat.get("clean", False):
+            flat["grads_all"].zero_()
+            flat["clean"] = True
+
     # ---- the two updates, as plain eager code (captured into graphs by _run) -----------------------
     def _d_forward_backward(self, real_pre=None, z=None, fake=None):
         """disc_cost and its gradients (:326-381): fakes from N_TOWERS generator towers conditioned on
@@ -336,7 +353,7 @@ class SNGANTrainer:
         generator output for this update (see _generate_for_critic)."""
         set_default_store(self.store)
         b = self.batch
-        self.store.zero_grads('Discriminator')
+        self._begin_grads(self.d_flat)
         with torch.no_grad():   # generator is not trained by disc_cost: no autograd graph through it
             if fake is None:
                 fake = Generator(b, self.real_labels, noise=z, groups=N_TOWERS, rng_state=self.rng_state)
@@ -345,22 +362,20 @@ class SNGANTrainer:
             both_labels = torch.cat([self.real_labels, self.real_labels], 0)
         with _sn.grad_scratch(self.d_flat["scratch"]):        # zeroed by zero_grads above
             logits, _ = Discriminator(both, both_labels, update_collection=None)
-        loss = Fn.hinge_d_loss(logits, b)
+        loss = Fn.hinge_d_loss(logits, b, out=self.d_loss)
         self._backward(loss)
-        K.copy_(self.d_loss, loss.detach())
         return logits
 
     def _d_forward_backward_prefetched(self):
         """Critic update number `feed_slot` of the iteration: inputs come from the feed ring by one launch."""
         set_default_store(self.store)
-        self.store.zero_grads('Discriminator')
+        self._begin_grads(self.d_flat)
         K.critic_feed(self.real_all, self.labels_all, self.fake_all, self.both, self.both_labels, self.feed_slot,
                       self.rng_state, self.feed_done)
         with _sn.grad_scratch(self.d_flat["scratch"]):        # zeroed by zero_grads above
             logits, _ = Discriminator(self.both, self.both_labels, update_collection=None)
-        loss = Fn.hinge_d_loss(logits, self.batch)
+        loss = Fn.hinge_d_loss(logits, self.batch, out=self.d_loss)
         self._backward(loss)
-        K.copy_(self.d_loss, loss.detach())
         return logits
 
     @torch.no_grad()
@@ -397,7 +412,7 @@ class SNGANTrainer:
         critic with update_collection=NO_OPS (u read, never written)."""
         set_default_store(self.store)   # the store is the "default graph": several trainers may coexist
         n = GEN_BS_MULTIPLE * self.batch
-        self.store.zero_grads('Generator')
+        self._begin_grads(self.g_flat)
         if fake_labels is None:
             fake_labels = K.rng_labels(n, 10, self.rng_state)           # :467
         fake = Generator(n, fake_labels, noise=z, groups=N_TOWERS, rng_state=self.rng_state)
@@ -406,12 +421,11 @@ class SNGANTrainer:
             p.requires_grad_(False)
         try:
             logits, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS)
-            loss = Fn.hinge_g_loss(logits)
+            loss = Fn.hinge_g_loss(logits, out=self.g_loss)
             self._backward(loss)
         finally:
             for p in d_params:
                 p.requires_grad_(True)
-        K.copy_(self.g_loss, loss.detach())
         return logits
 
     def _backward(self, loss):
@@ -439,7 +453,7 @@ class SNGANTrainer:
         def forward():
             set_default_store(self.store)
             n = GEN_BS_MULTIPLE * self.batch
-            self.store.zero_grads('Generator')
+            self._begin_grads(self.g_flat)
             fake_labels = K.rng_labels(n, 10, self.rng_state)
             with Fn.record_boundaries() as marks:
                 fake = Generator(n, fake_labels, groups=N_TOWERS, rng_state=self.rng_state)
@@ -448,11 +462,10 @@ class SNGANTrainer:
                 p.requires_grad_(False)
             try:
                 logits, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS)
-                loss = Fn.hinge_g_loss(logits)
+                loss = Fn.hinge_g_loss(logits, out=self.g_loss)
             finally:
                 for p in d_params:
                     p.requires_grad_(True)
-            K.copy_(self.g_loss, loss.detach())
             cuts = [t for tag, t in marks if tag in ('G.Block.1', 'G.Block.2', 'G.Block.3')]
             assert len(cuts) == nb - 1, [tag for tag, _ in marks]
             st['top'], st['gtop'], st['cuts'] = loss, Fn.unit_seed(loss), cuts
@@ -529,9 +542,11 @@ class SNGANTrainer:
                 self.use_graphs = False
                 torch.cuda.synchronize()
             return
+        self._ensure_clean(self.g_flat)
         for i, g in enumerate(self._graphs['g_seg']):
             g.replay()
             between(i)
+        self.g_flat["clean"] = True
 
     def _allreduce(self, flat):
         if self.world > 1:
@@ -575,6 +590,7 @@ class SNGANTrainer:
                 torch.cuda.synchronize()
             return
         g1, g2 = self._graphs[key]
+        self._ensure_clean(flat)
         g1.replay()
         if g2 is not None:
             self._allreduce(flat)
@@ -626,10 +642,15 @@ class SNGANTrainer:
         updates, each on the next (uint8 images, labels) pair from `batches`."""
         if self.iteration > 0:
             self.g_step()
-        for i in range(N_CRITIC):
-            data, labels = next(batches)
-            self.real_all[i].copy_(data, non_blocking=True)
-            self.labels_all[i].copy_(labels, non_blocking=True)
+        feed = [next(batches) for _ in range(N_CRITIC)]
+        if all(d.is_cuda and l.is_cuda for d, l in feed):
+            # device-resident batches: the ten slot copies are two multi-tensor launches
+            torch._foreach_copy_(list(self.real_all.unbind(0)), [d.view(self.batch, OUTPUT_DIM) for d, _ in feed])
+            torch._foreach_copy_(list(self.labels_all.unbind(0)), [l for _, l in feed])
+        else:
+            for i, (data, labels) in enumerate(feed):
+                self.real_all[i].copy_(data, non_blocking=True)
+                self.labels_all[i].copy_(labels, non_blocking=True)
         if self.overlap_gen and N_CRITIC > 1:
             self._run_plain('gen1', lambda: self._generate_slots(0, 1, self.rng_state_gen))
             self._run('d_first', self._d_first_with_generator_beside, self.d_opt, self.d_flat)

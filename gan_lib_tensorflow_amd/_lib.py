@@ -50,7 +50,8 @@ PROTOTYPES = {
     "gank_convpool3x3_prep_weights": [P, P, P, I, I, P],
     "gank_convpool3x3_fprop": [P, P, P, P, P, I, I, I, I, I, I, P],
     "gank_convpool3x3_dgrad": [P, P, P, P, I, I, I, I, I, P],
-    "gank_convpool3x3_wgrad": [P, P, P, P, P, I, I, I, I, I, I, P],
+    "gank_convpool3x3_wgrad": [P, P, P, P, P, L, I, I, I, I, I, I, P],
+    "gank_convpool3x3_wgrad_ws_elems": [I, I, I, I, I],
     "gank_res8_chain_fwd": [P, P, P, P, P, P, I, I, I, P],
     "gank_res8_chain_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, P],
     "gank_cpool_res_fprop": [P, P, P, P, P, I, I, I, I, I, I, P],
@@ -110,7 +111,7 @@ PROTOTYPES = {
     "gank_l1_loss": [P, P, P, P, P, L, P],
     "gank_dropout_fwd": [P, P, P, L, F, P, P],
     "gank_dropout_bwd": [P, P, P, L, F, P],
-    "gank_adam_tf": [P, P, P, P, P, P, P, L, P],
+    "gank_adam_tf": [P, P, P, P, P, P, P, L, L, P],
     "gank_counter_add": [P, C.c_int64, P],
     "gank_preprocess_real": [P, P, P, I, P],
     "gank_rng_normal_bf16": [P, L, P, P],
@@ -124,7 +125,7 @@ PROTOTYPES = {
     "gank_critic_feed": [P, P, P, P, P, P, P, P, I, I, P],
     "gank_debug_tr_probe": [P, P],
 }
-_RET = {"gank_last_error": C.c_char_p, "gank_conv2d_wgrad_ws_elems": C.c_long, "gank_prof_calibrate": C.c_double, "gank_prof_bytes": C.c_double}
+_RET = {"gank_last_error": C.c_char_p, "gank_conv2d_wgrad_ws_elems": C.c_long, "gank_convpool3x3_wgrad_ws_elems": C.c_long, "gank_prof_calibrate": C.c_double, "gank_prof_bytes": C.c_double}
 
 _lib = None
 

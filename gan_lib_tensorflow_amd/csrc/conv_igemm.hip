@@ -48,7 +48,7 @@ struct IgemmArgs {
   // conditional-batch-norm statistics of the OUTPUT, accumulated by the epilogue (two-group kernel only):
   // stat_sums [groups][2][Cout] += (sum, sum of squares) of (y - bias) over the samples of each tower; null = off
   float* stat_sums;
-  int stat_n_per_group;
+  int stat_n_per_group, stat_groups;
 };
 
 constexpr int LROW = 72;  // LDS row length in bf16 (64 + 8 pad) = 144 B
@@ -1246,11 +1246,12 @@ __global__ void ig_zero_kernel(float* __restrict__ p, int n) {
   if (i < n) p[i] = 0.f;
 }
 
+static void stats_zero(const IgemmArgs& a, hipStream_t s);
 template <int MODE, int PW>
 static int launch_pp(const IgemmArgs& a0, hipStream_t s) {
   IgemmArgs a = a0;
-  if (a.stat_sums) tl_stats_done = 1;
   const bool stats = a.stat_sums != nullptr;
+  if (stats) { tl_stats_done = 1; stats_zero(a, s); }
   constexpr bool PHASE = (MODE & 4) != 0;
   const int tiles = a.N * (a.H / (256 / PW)) * (a.W / PW);
   a.tiles_pp = tiles;
@@ -1429,9 +1430,13 @@ static int stats_setup(IgemmArgs& a, float* stat_sums, int groups, int N, int Co
   GANK_REQUIRE(groups > 0 && N % groups == 0, "conv statistics: batch %d not divisible by %d towers", N, groups);
   a.stat_sums = stat_sums;
   a.stat_n_per_group = N / groups;
-  const int n = groups * GANK_STAT_SLOTS * 2 * Cout;
-  hipLaunchKernelGGL(ig_zero_kernel, dim3((n + 255) / 256), dim3(256), 0, s, stat_sums, n);
+  a.stat_groups = groups;
   return 0;
+}
+// the sums are cleared by the launcher of a kernel that accumulates them (a kernel that does not never pays for the fill)
+static void stats_zero(const IgemmArgs& a, hipStream_t s) {
+  const int n = a.stat_groups * GANK_STAT_SLOTS * 2 * a.Cout;
+  hipLaunchKernelGGL(ig_zero_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a.stat_sums, n);
 }
 
 static int conv2d_fprop_impl(const void* x, const void* wf, const float* bias, const void* residual,

@@ -1144,11 +1144,278 @@ __global__ void wgrad_fold4x4_kernel(const float* __restrict__ w4, float* __rest
     }
 }
 
-extern "C" int gank_convpool3x3_wgrad(const void* x, const void* dy, float* dw, float* dbias, float* ws16, int N, int Hp, int Wp,
+// ------------------------------------------------------------------------------------------------------
+// ConvMeanPool 3x3 filter gradient, filter-row form.  The 16-tap stride-2 gradient through the per-tap kernel above
+// re-reads x and dy from L2 once per tap and lands at ~0.2-0.4 PFLOP/s with a zero fill in front and a fold behind it.
+// Here one block owns a 64(ci) x 64(co) tile for the FOUR taps of one filter row a over a range of 8x8 patches of the
+// pooled grid: per patch it stages dy (64 pixels) and the 8 x-rows 2*py + a - 1 that this filter row touches (18
+// columns), and the four taps b read their A fragments from that image at shifted columns.  The image is stored with
+// the columns DE-INTERLEAVED by parity ([row][parity][9]), so a tap's stride-2 pixel walk is a unit-stride walk inside
+// one parity plane and the transposed reads stay conflict-free (interleaved, pixels 0 and 2 of a 16-lane group would
+// share banks).  Partial tiles go to slabs [split][16 taps][Cin][Cout]; ONE kernel then sums the splits, folds 4x4 -> 3x3
+// (dW3[i][j] = 1/4 sum_{s,t} dW4[i+s][j+t]) and accumulates into dw: two launches instead of fill + 16-tap kernel + fold,
+// 4 instead of 16 operand passes through L2.
+// ------------------------------------------------------------------------------------------------------
+constexpr int CPR_PIX = 8 * 18;
+constexpr int CPR_XSUB = CPR_PIX * 32 + 32;   // sub-tile stride (bf16): 64 B off a 256 B multiple
+
+template <int MODE, int PF>
+__global__ __launch_bounds__(256) void conv_wgrad_cpool_rows_kernel(WgradArgs a) {
+  constexpr int NT = 256;
+  constexpr bool XRELU = (MODE & 1) != 0;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* sX = reinterpret_cast<bf16*>(smem);        // [2][2 subs][144 pix][32 ch]
+  bf16* sD = sX + 2 * 2 * CPR_XSUB;                // [2][2 subs][64 pix][32 ch]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_a = wave & 1, wave_b = wave >> 1;
+  int bid = blockIdx.x;
+  const int split = bid % a.splits; bid /= a.splits;
+  const int tco = bid % a.tiles_co; bid /= a.tiles_co;
+  const int tci = bid % a.tiles_ci;
+  const int frow = bid / a.tiles_ci;               // filter row a of the 4x4 kernel
+  const int ci0 = tci * 64, co0 = tco * 64;
+  const bool do_bias = a.dbias != nullptr && tci == 0 && frow == 0;
+
+  const int step0 = split * a.steps_per_split;
+  int nsteps = (a.M >> 6) - step0;
+  if (nsteps > a.steps_per_split) nsteps = a.steps_per_split;
+  if (nsteps <= 0) return;
+
+  constexpr int OOB = 0x7FFFFFF0;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, a.N * a.Hx * a.Wx * a.Cin * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.dy), 0, a.N * a.H * a.W * a.Cout * 2, 0x00020000);
+  const int pw_shift = a.sw - 3, pi_shift = a.shw - 6;   // patches per row / per image of the pooled grid (log2)
+
+  // x chunks: 144 halo pixels x 8 chunks of 8 channels = 1152 = 4.5 per thread
+  int x_hy[5], x_hx[5], x_c[5], x_lds[5];
+  bool x_on[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    const int q = tid + NT * j;
+    x_on[j] = q < CPR_PIX * 8;
+    const int hp = x_on[j] ? q >> 3 : 0, cc = q & 7;
+    const int hyi = hp / 18, hx = hp % 18;
+    x_hy[j] = 2 * hyi + frow - 1;
+    x_hx[j] = hx - 1;
+    x_c[j] = x_on[j] ? (ci0 + cc * 8) * 2 : OOB;
+    x_lds[j] = (cc >> 2) * CPR_XSUB + (hyi * 18 + (hx & 1) * 9 + (hx >> 1)) * 32 + (cc & 3) * 8;
+  }
+  int d_y[2], d_x[2], d_c[2], d_lds[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int q = tid + NT * j, p = q >> 3, cc = q & 7;
+    d_y[j] = p >> 3; d_x[j] = p & 7;
+    d_c[j] = (co0 + cc * 8) * 2;
+    d_lds[j] = (cc >> 2) * SUBS + p * 32 + (cc & 3) * 8;
+  }
+
+  u32x4 rX[PF][5], rD[PF][2];
+  float bsum[2][8];
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) bsum[j][e] = 0.f;
+
+  const int last = nsteps - 1;
+  int cur = 0;
+  auto load_next = [&](u32x4 (&rX)[5], u32x4 (&rD)[2]) {
+    const int patch = step0 + cur;                       // wave-uniform
+    const int n = patch >> pi_shift;
+    const int pin = patch & ((1 << pi_shift) - 1);
+    const int py0 = (pin >> pw_shift) << 3, px0 = (pin & ((1 << pw_shift) - 1)) << 3;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      const int iy = 2 * py0 + x_hy[j], ix = 2 * px0 + x_hx[j];
+      const bool ok = (unsigned)iy < (unsigned)a.Hx && (unsigned)ix < (unsigned)a.Wx;
+      const int off = ((n * a.Hx + iy) * a.Wx + ix) * a.Cin * 2 + x_c[j];
+      rX[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? off : OOB, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int off = ((n * a.H + py0 + d_y[j]) * a.W + px0 + d_x[j]) * a.Cout * 2 + d_c[j];
+      rD[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, off, 0, 0);
+    }
+    if (cur < last) cur++;
+  };
+  auto store_step = [&](int buf, u32x4 (&rX)[5], u32x4 (&rD)[2]) {
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      if (x_on[j]) {
+        u32x4 v = rX[j];
+        if constexpr (XRELU) v = relu_bf16x8(v);
+        *reinterpret_cast<u32x4*>(sX + buf * 2 * CPR_XSUB + x_lds[j]) = v;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      *reinterpret_cast<u32x4*>(sD + buf * 2 * SUBS + d_lds[j]) = rD[j];
+      if (do_bias) {
+        const bf16x8 t = __builtin_bit_cast(bf16x8, rD[j]);
+#pragma unroll
+        for (int e = 0; e < 8; e++) bsum[j][e] += bf2f(t[e]);
+      }
+    }
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+
+  const int g = lane >> 4, li = lane & 15;
+  // lane part of the transposed-read addresses: k half (g>>1) = pooled row within the pair, (li>>2) = pooled column
+  const int xl = ((g >> 1) * 18 + (li >> 2)) * 32 + 16 * (g & 1) + 4 * (li & 3);
+  const int dl = (8 * (g >> 1) + (li >> 2)) * 32 + 16 * (g & 1) + 4 * (li & 3);
+
+#pragma unroll
+  for (int d = 0; d < PF; d++) load_next(rX[d], rD[d]);
+  store_step(0, rX[0], rD[0]);
+  __syncthreads();
+
+  auto step = [&](int s, auto slot) {
+    constexpr int D = decltype(slot)::value;
+    const int buf = s & 1;
+    if constexpr (PF > 1) load_next(rX[D], rD[D]);
+    else if (s + 1 < nsteps) load_next(rX[0], rD[0]);
+    const bf16* pX = sX + (buf * 2 + wave_a) * CPR_XSUB + xl;
+    const bf16* pD = sD + (buf * 2 + wave_b) * SUBS + dl;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      const s16x4 bl = lds_tr_read(pD + kk * 16 * 32), bh = lds_tr_read(pD + kk * 16 * 32 + 4 * 32);
+      const s16x8 tb = {bl[0], bl[1], bl[2], bl[3], bh[0], bh[1], bh[2], bh[3]};
+      const bf16x8 fb = __builtin_bit_cast(bf16x8, tb);
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int o = (2 * kk * 18 + (t & 1) * 9 + (t >> 1)) * 32;
+        const s16x4 al = lds_tr_read(pX + o), ah = lds_tr_read(pX + o + 4 * 32);
+        const s16x8 ta = {al[0], al[1], al[2], al[3], ah[0], ah[1], ah[2], ah[3]};
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ta), fb, acc[t], 0, 0, 0);
+      }
+    }
+    if (s + 1 < nsteps) store_step(buf ^ 1, rX[(D + 1) % PF], rD[(D + 1) % PF]);
+    __syncthreads();
+  };
+  int s0 = 0;
+  for (; s0 + PF <= nsteps; s0 += PF) {
+    step(s0 + 0, std::integral_constant<int, 0>{});
+    if constexpr (PF >= 2) step(s0 + 1, std::integral_constant<int, 1 % PF>{});
+  }
+  if constexpr (PF >= 2) { if (s0 < nsteps) step(s0, std::integral_constant<int, 0>{}); }
+
+  // partial tile -> slab [split][frow*4 + t][Cin][Cout]
+  const int r = lane & 31, h = lane >> 5;
+  const int co = co0 + wave_b * 32 + r;
+  const long plane = (long)a.Cin * a.Cout;
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    float* dst = a.ws + ((long)split * 16 + frow * 4 + t) * plane;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const int ci = ci0 + wave_a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      dst[(long)ci * a.Cout + co] = acc[t][e];
+    }
+  }
+  if (do_bias) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);            // [256][16]
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) red[(tid * 2 + j) * 8 + e] = bsum[j][e];
+    __syncthreads();
+    if (tid < 64) {
+      const int cc = tid >> 3, e = tid & 7;
+      float tsum = 0.f;
+      for (int p = 0; p < 64; p++) {
+        const int q = p * 8 + cc;
+        tsum += red[((q % NT) * 2 + q / NT) * 8 + e];
+      }
+      atomicAdd(a.dbias + co0 + tid, tsum);
+    }
+  }
+}
+
+// dw[i][j] += 1/4 sum_{s,t in {0,1}} sum_split slab[split][(i+s)*4 + j+t]      (one thread per (3x3 tap, float4 of the plane))
+__global__ void wgrad_cpool_fold_slabs_kernel(const float* __restrict__ ws, float* __restrict__ dw, long plane4, int splits) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= plane4) return;
+  const int tap = blockIdx.y, ti = tap / 3, tj = tap % 3;
+  f32x4 t = {0.f, 0.f, 0.f, 0.f};
+  for (int sp = 0; sp < splits; sp += 2) {          // 8 independent loads per batch (2 splits x 4 source taps), fixed order
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int s2 = min(sp + (u >> 2), splits - 1);
+      const int src = (ti + ((u >> 1) & 1)) * 4 + tj + (u & 1);
+      v[u] = reinterpret_cast<const f32x4*>(ws)[((long)s2 * 16 + src) * plane4 + i];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (sp + (u >> 2) < splits) { t[0] += v[u][0]; t[1] += v[u][1]; t[2] += v[u][2]; t[3] += v[u][3]; }
+  }
+  f32x4 o = reinterpret_cast<f32x4*>(dw)[(long)tap * plane4 + i];
+  o[0] += 0.25f * t[0]; o[1] += 0.25f * t[1]; o[2] += 0.25f * t[2]; o[3] += 0.25f * t[3];
+  reinterpret_cast<f32x4*>(dw)[(long)tap * plane4 + i] = o;
+}
+
+static bool wgrad_cpool_rows_ok(int N, int Hp, int Wp, int Cin, int Cout) {
+  static int env = -1;   // experiment knob: GANK_CPOOL_ROWS=0 falls back to the 16-tap per-tap kernel
+  if (env < 0) { const char* e = getenv("GANK_CPOOL_ROWS"); env = e ? atoi(e) : 1; }
+  return env && Hp >= 8 && Wp >= 8 && log2_or_neg(Hp) >= 0 && log2_or_neg(Wp) >= 0 && Cin % 64 == 0 && Cout % 64 == 0 &&
+         (long)N * 4 * Hp * Wp * Cin < (1L << 30) && (long)N * Hp * Wp * Cout < (1L << 30);
+}
+static void wgrad_cpool_rows_geometry(WgradArgs& a) {
+  a.tiles_ci = a.Cin / 64;
+  a.tiles_co = a.Cout / 64;
+  const int total_steps = a.M / 64;
+  const int tiles = a.tiles_ci * a.tiles_co * 4;
+  static int target = -1;   // experiment knob
+  if (target < 0) { const char* e = getenv("GANK_CPOOL_ROWS_TARGET"); target = e ? atoi(e) : 256; }
+  int splits = (target + tiles - 1) / tiles;
+  if (splits > total_steps / 4) splits = total_steps / 4;
+  if (splits < 1) splits = 1;
+  a.steps_per_split = cdiv(total_steps, splits);
+  a.splits = cdiv(total_steps, a.steps_per_split);
+}
+
+extern "C" long gank_convpool3x3_wgrad_ws_elems(int N, int Hp, int Wp, int Cin, int Cout) {
+  if (!wgrad_cpool_rows_ok(N, Hp, Wp, Cin, Cout)) return 16L * Cin * Cout;
+  WgradArgs a{};
+  a.Cin = Cin; a.Cout = Cout; a.M = N * Hp * Wp;
+  wgrad_cpool_rows_geometry(a);
+  return 16L * Cin * Cout * a.splits;
+}
+
+extern "C" int gank_convpool3x3_wgrad(const void* x, const void* dy, float* dw, float* dbias, float* ws16, long ws_elems, int N, int Hp, int Wp,
                                       int Cin, int Cout, int flags, void* stream) {
   GANK_REQUIRE(x && dy && dw && ws16, "convpool3x3_wgrad: null pointer");
   GANK_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "convpool3x3_wgrad: channels must be multiples of 4");
   hipStream_t s = (hipStream_t)stream;
+  if (wgrad_cpool_rows_ok(N, Hp, Wp, Cin, Cout)) {
+    WgradArgs a{};
+    a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.dw = dw; a.dbias = dbias; a.ws = ws16;
+    a.N = N; a.H = Hp; a.W = Wp; a.Hx = 2 * Hp; a.Wx = 2 * Wp; a.Hdy = Hp; a.Wdy = Wp;
+    a.Cin = Cin; a.Cout = Cout; a.M = N * Hp * Wp;
+    a.sw = log2_or_neg(Wp); a.shw = log2_or_neg(Hp * Wp);
+    wgrad_cpool_rows_geometry(a);
+    GANK_REQUIRE(ws_elems >= 16L * Cin * Cout * a.splits, "convpool3x3_wgrad: workspace of %ld floats, need %ld (gank_convpool3x3_wgrad_ws_elems)",
+                 ws_elems, 16L * Cin * Cout * a.splits);
+    gank_prof_begin(1, 2.0 * a.M * 16.0 * Cin * Cout, s, 2.0 * ((double)N * 4 * Hp * Wp * Cin + (double)a.M * Cout) + 36.0 * Cin * Cout);
+    gank_prof_tag(1, "conv_wgrad_cpool_rows_kernel + wgrad_cpool_fold_slabs_kernel");
+    const size_t lds = (size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16);
+    auto kern = (flags & GANK_IN_RELU) ? conv_wgrad_cpool_rows_kernel<1, 2> : conv_wgrad_cpool_rows_kernel<0, 2>;
+    if (flags & GANK_IN_RELU) { GANK_MAX_DYNAMIC_LDS((conv_wgrad_cpool_rows_kernel<1, 2>), (int)lds, "conv_wgrad_cpool_rows"); }
+    else { GANK_MAX_DYNAMIC_LDS((conv_wgrad_cpool_rows_kernel<0, 2>), (int)lds, "conv_wgrad_cpool_rows"); }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(4 * a.tiles_ci * a.tiles_co * a.splits)), dim3(256), lds, s, a);
+    const long plane4 = (long)Cin * Cout / 4;
+    hipLaunchKernelGGL(wgrad_cpool_fold_slabs_kernel, dim3((unsigned)cdiv(plane4, 256), 9), dim3(256), 0, s, ws16, dw, plane4, a.splits);
+    gank_prof_end(1, s);
+    GANK_LAUNCH_OK("convpool3x3_wgrad");
+    return 0;
+  }
+  GANK_REQUIRE(ws_elems >= 16L * Cin * Cout, "convpool3x3_wgrad: workspace of %ld floats, need %ld", ws_elems, 16L * Cin * Cout);
   const long n4 = 16L * Cin * Cout / 4;
   hipLaunchKernelGGL(wgrad_zero_kernel, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, s, ws16, n4);
   WgradArgs a{};

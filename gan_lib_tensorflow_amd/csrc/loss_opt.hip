@@ -137,14 +137,27 @@ __device__ __forceinline__ float adam_lr_t(const float* hp, const long long* t_s
   return (float)(lr * sqrt(1.0 - pow((double)hp[2], t)) / (1.0 - pow((double)hp[1], t)));
 }
 
-__global__ void adam_tf_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                               const float* __restrict__ hp, const long long* __restrict__ t_state,
-                               const long long* __restrict__ iteration, long n) {
+// One launch per update: the step count advances and (zero_n > 0) the gradient buffer is cleared here too.  Every block
+// derives lr_t from t_state[0] BEFORE it takes a ticket (the value goes through LDS, so the load has completed); the block that
+// draws the last ticket therefore knows every block has read the count, advances it and resets the ticket (hp[6], as an integer).
+// zero_n floats of g (>= n: the critic's buffer carries the spectral-norm scratch half behind the gradients) are cleared after
+// they have been consumed, so the next backward pass accumulates into zeros without a fill launch of its own.
+__global__ void adam_tf_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                               float* __restrict__ hp, long long* __restrict__ t_state,
+                               const long long* __restrict__ iteration, long n, long zero_n) {
   __shared__ float s_lr;
   if (threadIdx.x == 0) s_lr = adam_lr_t(hp, t_state, iteration);
   __syncthreads();
   const float lr_t = s_lr, b1 = hp[1], b2 = hp[2], eps = hp[3], gs = hp[4];
+  if (threadIdx.x == 0) {
+    unsigned* ticket = reinterpret_cast<unsigned*>(hp + 6);
+    if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+      *ticket = 0u;
+      t_state[0] += 1;
+    }
+  }
   const long n4 = n >> 2;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
     const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
@@ -159,6 +172,7 @@ __global__ void adam_tf_kernel(float* __restrict__ p, const float* __restrict__ 
     reinterpret_cast<f32x4*>(p)[i] = pp;
     reinterpret_cast<f32x4*>(m)[i] = mm;
     reinterpret_cast<f32x4*>(v)[i] = vv;
+    if (zero_n > 0) reinterpret_cast<f32x4*>(g)[i] = z4;
   }
   if (blockIdx.x == 0)
     for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) {
@@ -167,22 +181,26 @@ __global__ void adam_tf_kernel(float* __restrict__ p, const float* __restrict__ 
       const float vv = b2 * v[i] + (1.f - b2) * gr * gr;
       m[i] = mm; v[i] = vv;
       p[i] -= lr_t * mm / (sqrtf(vv) + eps);
+      if (zero_n > 0) g[i] = 0.f;
     }
+  // the tail behind the gradients (n is a multiple of 4 whenever zero_n > n: checked by the host)
+  for (long i = n4 + blockIdx.x * (long)blockDim.x + threadIdx.x; i < (zero_n >> 2); i += (long)gridDim.x * blockDim.x)
+    reinterpret_cast<f32x4*>(g)[i] = z4;
 }
 
 __global__ void counter_add_kernel(long long* c, long long inc) { c[0] += inc; }
 
-extern "C" int gank_adam_tf(float* p, const float* g, float* m, float* v, const float* hp, int64_t* t_state,
-                            const int64_t* iteration, long n, void* stream) {
+extern "C" int gank_adam_tf(float* p, float* g, float* m, float* v, float* hp, int64_t* t_state,
+                            const int64_t* iteration, long n, long zero_n, void* stream) {
   GANK_REQUIRE(p && g && m && v && hp && t_state && n > 0, "adam_tf: bad arguments");
   GANK_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_tf: buffers must be 16-byte aligned");
+  GANK_REQUIRE(zero_n == 0 || zero_n == n || (zero_n > n && n % 4 == 0 && zero_n % 4 == 0), "adam_tf: zero_n must be 0, n, or a multiple of 4 beyond an n that is one");
   long blocks = (n / 4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(adam_tf_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, hp, (const long long*)t_state,
-                     (const long long*)iteration, n);
-  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, s, (long long*)t_state, 1LL);
+  hipLaunchKernelGGL(adam_tf_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, hp, (long long*)t_state,
+                     (const long long*)iteration, n, zero_n);
   GANK_LAUNCH_OK("adam_tf");
   return 0;
 }

@@ -640,19 +640,22 @@ class _Loss(Function):
     """loss value (fp32[1]) with d loss / d logits computed in the same forward launch."""
 
     @staticmethod
-    def forward(ctx, logits, kind, arg):
+    def forward(ctx, logits, kind, arg, out=None):
+        # out: a _Box around a persistent fp32[1] buffer the value is written to (autograd must not see that tensor as an
+        # input); the result is a fresh alias of it
+        buf = out.t if out is not None else None
         if kind == "hinge_d":
-            loss, dl, dl32 = K.hinge_d_loss(logits, arg)
+            loss, dl, dl32 = K.hinge_d_loss(logits, arg, buf)
         elif kind == "wgan_d":
-            loss, dl, dl32 = K.wgan_d_loss(logits, arg)
+            loss, dl, dl32 = K.wgan_d_loss(logits, arg, buf)
         elif kind == "hinge_g":
-            loss, dl, dl32 = K.hinge_g_loss(logits)
+            loss, dl, dl32 = K.hinge_g_loss(logits, buf)
         elif kind == "xent":
             loss, dl, dl32 = K.softmax_xent(logits, arg)
         else:
             raise NotImplementedError(kind)
         ctx.save_for_backward(dl, dl32)
-        return loss
+        return loss.detach() if buf is not None else loss
 
     @staticmethod
     def backward(ctx, g):
@@ -661,8 +664,8 @@ class _Loss(Function):
         # (unit_seed): the bf16 gradient of the forward launch is returned as is.  Any other upstream gradient (a
         # weighted sum of losses, loss / accum_steps) scales the fp32 gradient on the device and rounds once.
         if g.data_ptr() in _unit_seed_ptrs:
-            return dl, None, None
-        return K.loss_grad_scale(dl32, _c(g.to(torch.float32)).reshape(1)), None, None
+            return dl, None, None, None
+        return K.loss_grad_scale(dl32, _c(g.to(torch.float32)).reshape(1)), None, None, None
 
 
 _unit_seeds = {}
@@ -680,16 +683,24 @@ def unit_seed(loss):
     return s
 
 
-def hinge_d_loss(logits, n_real):
-    return _Loss.apply(logits, "hinge_d", n_real)
+class _Box:
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
 
 
-def hinge_g_loss(logits):
-    return _Loss.apply(logits, "hinge_g", None)
+def hinge_d_loss(logits, n_real, out=None):
+    """out: persistent fp32[1] buffer that also receives the loss value (no copy launch for the reported loss)"""
+    return _Loss.apply(logits, "hinge_d", n_real, _Box(out) if out is not None else None)
 
 
-def wgan_d_loss(logits, n_real):
-    return _Loss.apply(logits, "wgan_d", n_real)
+def hinge_g_loss(logits, out=None):
+    return _Loss.apply(logits, "hinge_g", None, _Box(out) if out is not None else None)
+
+
+def wgan_d_loss(logits, n_real, out=None):
+    return _Loss.apply(logits, "wgan_d", n_real, _Box(out) if out is not None else None)
 
 
 def softmax_xent(logits, labels):

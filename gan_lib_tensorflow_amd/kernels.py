@@ -271,9 +271,10 @@ def convpool3x3_wgrad(x, dy, dw, flags=0, dbias=None):
     n, hp, wp, cout = dy.shape
     cin = x.shape[3]
     assert x.shape[1] == 2 * hp and x.shape[2] == 2 * wp and dw.numel() == 9 * cin * cout, (x.shape, dy.shape, dw.shape)
-    ws16 = torch.empty(16 * cin * cout, dtype=F32, device=x.device)
+    ws_elems = lib().gank_convpool3x3_wgrad_ws_elems(n, hp, wp, cin, cout)
+    ws16 = torch.empty(ws_elems, dtype=F32, device=x.device)
     _lib.check(lib().gank_convpool3x3_wgrad(_p(x, BF16, "x"), _p(dy, BF16, "dy"), _p(dw, F32, "dw"), _p(dbias, F32, "dbias"),
-                                            _p(ws16), n, hp, wp, cin, cout, flags, _stream()), "convpool3x3_wgrad")
+                                            _p(ws16), ws_elems, n, hp, wp, cin, cout, flags, _stream()), "convpool3x3_wgrad")
     return dw
 
 
@@ -642,25 +643,26 @@ def embedding_bwd(dy, idx, dtable):
 
 
 # ------------------------------------------------------------------ losses / optimiser / input
-def hinge_d_loss(logits, n_real):
-    """-> (loss fp32[1], dlogits bf16, dlogits fp32): the bf16 copy is the gradient for an upstream gradient of 1"""
-    loss = torch.empty(1, dtype=F32, device=logits.device)
+def hinge_d_loss(logits, n_real, loss=None):
+    """-> (loss fp32[1], dlogits bf16, dlogits fp32): the bf16 copy is the gradient for an upstream gradient of 1.
+    `loss`: a persistent fp32[1] buffer to write the value into (the trainers' reported loss: no copy launch)"""
+    loss = torch.empty(1, dtype=F32, device=logits.device) if loss is None else loss
     dl = torch.empty_like(logits)
     dl32 = torch.empty(logits.shape, dtype=F32, device=logits.device)
     _lib.check(lib().gank_hinge_d_loss(_p(logits, BF16, "logits"), _p(loss), _p(dl), _p(dl32), logits.numel(), n_real, _stream()), "hinge_d_loss")
     return loss, dl, dl32
 
 
-def wgan_d_loss(logits, n_real):
-    loss = torch.empty(1, dtype=F32, device=logits.device)
+def wgan_d_loss(logits, n_real, loss=None):
+    loss = torch.empty(1, dtype=F32, device=logits.device) if loss is None else loss
     dl = torch.empty_like(logits)
     dl32 = torch.empty(logits.shape, dtype=F32, device=logits.device)
     _lib.check(lib().gank_wgan_d_loss(_p(logits, BF16, "logits"), _p(loss), _p(dl), _p(dl32), logits.numel(), n_real, _stream()), "wgan_d_loss")
     return loss, dl, dl32
 
 
-def hinge_g_loss(logits):
-    loss = torch.empty(1, dtype=F32, device=logits.device)
+def hinge_g_loss(logits, loss=None):
+    loss = torch.empty(1, dtype=F32, device=logits.device) if loss is None else loss
     dl = torch.empty_like(logits)
     dl32 = torch.empty(logits.shape, dtype=F32, device=logits.device)
     _lib.check(lib().gank_hinge_g_loss(_p(logits, BF16, "logits"), _p(loss), _p(dl), _p(dl32), logits.numel(), _stream()), "hinge_g_loss")
@@ -683,11 +685,13 @@ def loss_grad_scale(dl32, g):
     return out
 
 
-def adam_tf(p, g, m, v, hp, t_state, iteration=None):
-    """hp fp32[8] = {lr, beta1, beta2, eps, grad_scale, decay_on}; t_state int64[1]; iteration int64[1] | None"""
+def adam_tf(p, g, m, v, hp, t_state, iteration=None, zero_grads=False):
+    """hp fp32[8] = {lr, beta1, beta2, eps, grad_scale, decay_on, 0, 0}; t_state int64[1]; iteration int64[1] | None.
+    zero_grads: clear g (ALL of it: it may be longer than p, e.g. a scratch half behind the gradients) in the same launch."""
+    assert g.numel() >= p.numel() and hp.numel() >= 8
     _lib.check(lib().gank_adam_tf(_p(p, F32, "p"), _p(g, F32, "g"), _p(m, F32, "m"), _p(v, F32, "v"), _p(hp, F32, "hp"),
                                   _p(t_state, torch.int64, "t_state"), _p(iteration, torch.int64, "iteration"),
-                                  p.numel(), _stream()), "adam_tf")
+                                  p.numel(), g.numel() if zero_grads else 0, _stream()), "adam_tf")
 
 
 def counter_add(counter, inc=1):

@@ -179,13 +179,15 @@ int gank_upconv3x3_dgrad(const void* dy, const void* wd4, const void* relu_ref, 
  *   dgrad: dy [N,Hp,Wp,Cout] -> dx [N,2Hp,2Wp,Cin] (stride-2 transposed conv as 4 phases of 2x2 taps);
  *          relu_ref (optional, like dx) masks the result with relu_ref > 0.  Needs Cout % 64 == 0.
  *   wgrad: dw fp32 [3,3,Cin,Cout] += fold(dW4), dbias (optional) += column sums of dy; ws16 = fp32 scratch of
- *          16*Cin*Cout elements; flags: GANK_IN_RELU (relu applied to x while staging). */
+ *          ws_elems >= gank_convpool3x3_wgrad_ws_elems(...) elements (the partial tiles of the pixel splits);
+ *          flags: GANK_IN_RELU (relu applied to x while staging). */
 int gank_convpool3x3_prep_weights(const float* w, void* wp4, void* wphd, int Cin, int Cout, void* stream);
 int gank_convpool3x3_fprop(const void* x, const void* wp4, const float* bias, const void* residual, void* y,
                            int N, int Hp, int Wp, int Cin, int Cout, int flags, void* stream);
 int gank_convpool3x3_dgrad(const void* dy, const void* wphd, const void* relu_ref, void* dx, int N, int Hp, int Wp,
                            int Cin, int Cout, void* stream);
-int gank_convpool3x3_wgrad(const void* x, const void* dy, float* dw, float* dbias, float* ws16, int N, int Hp, int Wp,
+long gank_convpool3x3_wgrad_ws_elems(int N, int Hp, int Wp, int Cin, int Cout);
+int gank_convpool3x3_wgrad(const void* x, const void* dy, float* dw, float* dbias, float* ws16, long ws_elems, int N, int Hp, int Wp,
                            int Cin, int Cout, int flags, void* stream);
 
 /* ---- Deconv2D (common/ops/deconv2d.py:99-114): tf.nn.conv2d_transpose stride 2 SAME --------------
@@ -374,12 +376,13 @@ int gank_dropout_bwd(const void* dy, const uint8_t* mask, void* dx, long n, floa
 
 /* ---- tf.train.AdamOptimizer (gan_cifar_resnet.py:521-526), one launch over a flat buffer ---------
  * All step state lives on the device so a captured update replays without host traffic:
- * hp (float[8]) = {lr, beta1, beta2, eps, grad_scale, decay_on}; t_state[0] = updates applied so far
- * (incremented by this call); iteration[0] = the `_iteration` feed (:320) driving the LR decay
- * (:454-459), may be NULL.  lr_t = lr*decay*sqrt(1-b2^t)/(1-b1^t); g is multiplied by grad_scale
- * first (1/world_size after a sum all-reduce).  gank_counter_add advances a device counter. */
-int gank_adam_tf(float* p, const float* g, float* m, float* v, const float* hp, int64_t* t_state,
-                 const int64_t* iteration, long n, void* stream);
+ * hp (float[8]) = {lr, beta1, beta2, eps, grad_scale, decay_on, <ticket word, keep 0>, -}; t_state[0] = updates applied
+ * so far (incremented by this call, inside the same launch); iteration[0] = the `_iteration` feed (:320) driving the LR
+ * decay (:454-459), may be NULL.  lr_t = lr*decay*sqrt(1-b2^t)/(1-b1^t); g is multiplied by grad_scale first (1/world_size
+ * after a sum all-reduce).  zero_n > 0: the first zero_n floats of g (>= n: a scratch tail may follow the gradients) are
+ * cleared once consumed, so the next backward pass needs no fill launch.  gank_counter_add advances a device counter. */
+int gank_adam_tf(float* p, float* g, float* m, float* v, float* hp, int64_t* t_state,
+                 const int64_t* iteration, long n, long zero_n, void* stream);
 int gank_counter_add(int64_t* counter, int64_t inc, void* stream);
 
 /* ---- input pipeline (gan_cifar_resnet.py:334-337) and graph-safe RNG -----------------------------

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scratch/measure.sh <tag>   -- bench under rocprofv3 kernel trace, category summary per iteration
+# usage: scratch/measure.sh <tag>   -- bench under rocprofv3 kernel trace, category summary per iteration, kernel sequence of one iteration
 tag=${1:-m}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/prof_$tag
@@ -7,4 +7,5 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o $t
 python3 scratch/cat_summary.py gpurun_out/prof_$tag 27 > gpurun_out/cat_$tag.txt 2>&1
 grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' gpurun_out/bench_$tag.json | head -2
 head -14 gpurun_out/cat_$tag.txt
+python3 scratch/seq_dump.py gpurun_out/prof_$tag 1000 > gpurun_out/seq_$tag.txt 2>&1
 rm -f gpurun_out/prof_$tag/*kernel_trace.csv

@@ -395,6 +395,15 @@ def test_adam_tf_and_lr_decay(K):
     torch.cuda.synchronize()
     assert int(t) == 3
     assert relerr(pt, rp) < 1e-5 and relerr(v, rv) < 1e-5
+    assert int(hp.view(torch.int32)[6]) == 0                       # the ticket word is back at zero after every launch
+    # zero_grads: the whole gradient buffer (it may carry a scratch tail behind the gradients) is cleared by the same launch
+    n2 = 4096
+    p2 = torch.zeros(n2, dtype=torch.float32, device="cuda")
+    g2 = torch.ones(2 * n2, dtype=torch.float32, device="cuda")
+    m2, v2 = torch.zeros_like(p2), torch.zeros_like(p2)
+    K.adam_tf(p2, g2, m2, v2, hp, t, it, zero_grads=True)
+    torch.cuda.synchronize()
+    assert int(t) == 4 and float(g2.abs().max()) == 0.0 and float(p2.abs().min()) > 0.0
 
 
 def test_preprocess_and_rng(K):
