@@ -961,7 +961,7 @@ static int wgrad_taps_min_m() {
 }
 static bool wgrad_taps_ok(const WgradArgs& a) {
   return a.ks == 3 && a.pad == 1 && !(a.flags & WG_X_STRIDE2) && a.sw >= 3 && a.shw >= 6 && a.H >= 8 && a.W >= 8 &&
-         a.M >= wgrad_taps_min_m() &&   // small reductions: the per-tap kernel's finer split fills the chip better
+         (a.M >= wgrad_taps_min_m() || (a.M >= 8192 && (a.Cin / 64) * (a.Cout / 64) >= 64)) &&   // small reductions go to the filter-row kernel unless the channel tiles alone fill the chip
          a.Cin % 64 == 0 && a.Cout % 64 == 0 && (a.M % 64 == 0) &&
          (long)a.N * a.Hx * a.Wx * a.Cin < (1L << 30) && (long)a.N * a.Hdy * a.Wdy * a.Cout < (1L << 30);
 }
@@ -1019,6 +1019,250 @@ static int launch_wgrad_taps(const WgradArgs& a, hipStream_t s) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// ConvMeanPool 3x3 filter gradient, filter-row form.  The 16-tap stride-2 gradient through the per-tap kernel above
+// re-reads x and dy from L2 once per tap and lands at ~0.2-0.4 PFLOP/s with a zero fill in front and a fold behind it.
+// Here one block owns a 64(ci) x 64(co) tile for the FOUR taps of one filter row a over a range of 8x8 patches of the
+// pooled grid: per patch it stages dy (64 pixels) and the 8 x-rows 2*py + a - 1 that this filter row touches (18
+// columns), and the four taps b read their A fragments from that image at shifted columns.  The image is stored with
+// the columns DE-INTERLEAVED by parity ([row][parity][9]), so a tap's stride-2 pixel walk is a unit-stride walk inside
+// one parity plane and the transposed reads stay conflict-free (interleaved, pixels 0 and 2 of a 16-lane group would
+// share banks).  Partial tiles go to slabs [split][16 taps][Cin][Cout]; ONE kernel then sums the splits, folds 4x4 -> 3x3
+// (dW3[i][j] = 1/4 sum_{s,t} dW4[i+s][j+t]) and accumulates into dw: two launches instead of fill + 16-tap kernel + fold,
+// 4 instead of 16 operand passes through L2.
+// ------------------------------------------------------------------------------------------------------
+constexpr int CPR_XSUB = 8 * 18 * 32 + 32;   // sub-tile stride (bf16) of the widest image: 64 B off a 256 B multiple
+
+// S2 = true: the ConvMeanPool form above (4 taps per filter row, x read at stride 2, slabs).
+// S2 = false: the same structure for a plain 3x3 stride-1 filter gradient (3 taps per filter row, 8 x 10 halo pixels per
+// patch) -- for layers too small for the all-taps kernel (its 9-tap partial tiles, one per pixel split, cost more slab
+// traffic than the layer has FLOPs); partial tiles are added to dw with fp32 atomics (a third of the all-taps volume per
+// block) or written to slabs when a workspace is given.  grid.y = layer of a same-shape batch (nbatch > 0).
+template <int MODE, int PF, bool S2>
+__global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs a) {
+  constexpr int NT = 256;
+  constexpr bool XRELU = (MODE & 1) != 0;
+  constexpr int COLS = S2 ? 18 : 10, NTAP = S2 ? 4 : 3, ST = S2 ? 2 : 1;
+  constexpr int XCHUNKS = 8 * COLS * 8, NXC = (XCHUNKS + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* sX = reinterpret_cast<bf16*>(smem);        // [2][2 subs][8 * COLS pix][32 ch]
+  bf16* sD = sX + 2 * 2 * CPR_XSUB;                // [2][2 subs][64 pix][32 ch]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_a = wave & 1, wave_b = wave >> 1;
+  const bf16* X = a.x;
+  const bf16* DY = a.dy;
+  float* DW = a.dw;
+  float* DB = a.dbias;
+  if (a.nbatch > 0) {      // static indices only (a dynamically indexed by-value struct is spilled to scratch)
+    const int bi = blockIdx.y;
+    X = bi == 0 ? a.xs[0] : (bi == 1 ? a.xs[1] : (bi == 2 ? a.xs[2] : a.xs[3]));
+    DY = bi == 0 ? a.dys[0] : (bi == 1 ? a.dys[1] : (bi == 2 ? a.dys[2] : a.dys[3]));
+    DW = bi == 0 ? a.dws[0] : (bi == 1 ? a.dws[1] : (bi == 2 ? a.dws[2] : a.dws[3]));
+    DB = bi == 0 ? a.dbs[0] : (bi == 1 ? a.dbs[1] : (bi == 2 ? a.dbs[2] : a.dbs[3]));
+  }
+  int bid = blockIdx.x;
+  const int split = bid % a.splits; bid /= a.splits;
+  const int tco = bid % a.tiles_co; bid /= a.tiles_co;
+  const int tci = bid % a.tiles_ci;
+  const int frow = bid / a.tiles_ci;               // filter row
+  const int ci0 = tci * 64, co0 = tco * 64;
+  const bool do_bias = DB != nullptr && tci == 0 && frow == 0;
+
+  const int step0 = split * a.steps_per_split;
+  int nsteps = (a.M >> 6) - step0;
+  if (nsteps > a.steps_per_split) nsteps = a.steps_per_split;
+  if (nsteps <= 0) return;
+
+  constexpr int OOB = 0x7FFFFFF0;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(X), 0, a.N * a.Hx * a.Wx * a.Cin * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(DY), 0, a.N * a.H * a.W * a.Cout * 2, 0x00020000);
+  const int pw_shift = a.sw - 3, pi_shift = a.shw - 6;   // patches per row / per image of the dy grid (log2)
+
+  int x_hy[NXC], x_hx[NXC], x_c[NXC], x_lds[NXC];
+  bool x_on[NXC];
+#pragma unroll
+  for (int j = 0; j < NXC; j++) {
+    const int q = tid + NT * j;
+    x_on[j] = q < XCHUNKS;
+    const int hp = x_on[j] ? q >> 3 : 0, cc = q & 7;
+    const int hyi = hp / COLS, hx = hp % COLS;
+    x_hy[j] = ST * hyi + frow - 1;
+    x_hx[j] = hx - 1;
+    x_c[j] = x_on[j] ? (ci0 + cc * 8) * 2 : OOB;
+    const int slot = S2 ? hyi * COLS + (hx & 1) * (COLS / 2) + (hx >> 1) : hyi * COLS + hx;
+    x_lds[j] = (cc >> 2) * CPR_XSUB + slot * 32 + (cc & 3) * 8;
+  }
+  int d_y[2], d_x[2], d_c[2], d_lds[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int q = tid + NT * j, p = q >> 3, cc = q & 7;
+    d_y[j] = p >> 3; d_x[j] = p & 7;
+    d_c[j] = (co0 + cc * 8) * 2;
+    d_lds[j] = (cc >> 2) * SUBS + p * 32 + (cc & 3) * 8;
+  }
+
+  u32x4 rX[PF][NXC], rD[PF][2];
+  float bsum[2][8];
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) bsum[j][e] = 0.f;
+
+  const int last = nsteps - 1;
+  int cur = 0;
+  auto load_next = [&](u32x4 (&rX)[NXC], u32x4 (&rD)[2]) {
+    const int patch = step0 + cur;                       // wave-uniform
+    const int n = patch >> pi_shift;
+    const int pin = patch & ((1 << pi_shift) - 1);
+    const int py0 = (pin >> pw_shift) << 3, px0 = (pin & ((1 << pw_shift) - 1)) << 3;
+#pragma unroll
+    for (int j = 0; j < NXC; j++) {
+      const int iy = ST * py0 + x_hy[j], ix = ST * px0 + x_hx[j];
+      const bool ok = (unsigned)iy < (unsigned)a.Hx && (unsigned)ix < (unsigned)a.Wx;
+      const int off = ((n * a.Hx + iy) * a.Wx + ix) * a.Cin * 2 + x_c[j];
+      rX[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? off : OOB, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int off = ((n * a.H + py0 + d_y[j]) * a.W + px0 + d_x[j]) * a.Cout * 2 + d_c[j];
+      rD[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, off, 0, 0);
+    }
+    if (cur < last) cur++;
+  };
+  auto store_step = [&](int buf, u32x4 (&rX)[NXC], u32x4 (&rD)[2]) {
+#pragma unroll
+    for (int j = 0; j < NXC; j++) {
+      if (x_on[j]) {
+        u32x4 v = rX[j];
+        if constexpr (XRELU) v = relu_bf16x8(v);
+        *reinterpret_cast<u32x4*>(sX + buf * 2 * CPR_XSUB + x_lds[j]) = v;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      *reinterpret_cast<u32x4*>(sD + buf * 2 * SUBS + d_lds[j]) = rD[j];
+      if (do_bias) {
+        const bf16x8 t = __builtin_bit_cast(bf16x8, rD[j]);
+#pragma unroll
+        for (int e = 0; e < 8; e++) bsum[j][e] += bf2f(t[e]);
+      }
+    }
+  };
+
+  f32x16 acc[NTAP];
+#pragma unroll
+  for (int t = 0; t < NTAP; t++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+
+  const int g = lane >> 4, li = lane & 15;
+  // lane part of the transposed-read addresses: k half (g>>1) = dy row within the pair, (li>>2) = dy column
+  const int xl = ((g >> 1) * COLS + (li >> 2)) * 32 + 16 * (g & 1) + 4 * (li & 3);
+  const int dl = (8 * (g >> 1) + (li >> 2)) * 32 + 16 * (g & 1) + 4 * (li & 3);
+
+#pragma unroll
+  for (int d = 0; d < PF; d++) load_next(rX[d], rD[d]);
+  store_step(0, rX[0], rD[0]);
+  __syncthreads();
+
+  auto step = [&](int s, auto slot) {
+    constexpr int D = decltype(slot)::value;
+    const int buf = s & 1;
+    if constexpr (PF > 1) load_next(rX[D], rD[D]);
+    else if (s + 1 < nsteps) load_next(rX[0], rD[0]);
+    const bf16* pX = sX + (buf * 2 + wave_a) * CPR_XSUB + xl;
+    const bf16* pD = sD + (buf * 2 + wave_b) * SUBS + dl;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      const s16x4 bl = lds_tr_read(pD + kk * 16 * 32), bh = lds_tr_read(pD + kk * 16 * 32 + 4 * 32);
+      const s16x8 tb = {bl[0], bl[1], bl[2], bl[3], bh[0], bh[1], bh[2], bh[3]};
+      const bf16x8 fb = __builtin_bit_cast(bf16x8, tb);
+#pragma unroll
+      for (int t = 0; t < NTAP; t++) {
+        const int o = S2 ? (2 * kk * COLS + (t & 1) * (COLS / 2) + (t >> 1)) * 32 : (2 * kk * COLS + t) * 32;
+        const s16x4 al = lds_tr_read(pX + o), ah = lds_tr_read(pX + o + 4 * 32);
+        const s16x8 ta = {al[0], al[1], al[2], al[3], ah[0], ah[1], ah[2], ah[3]};
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ta), fb, acc[t], 0, 0, 0);
+      }
+    }
+    if (s + 1 < nsteps) store_step(buf ^ 1, rX[(D + 1) % PF], rD[(D + 1) % PF]);
+    __syncthreads();
+  };
+  int s0 = 0;
+  for (; s0 + PF <= nsteps; s0 += PF) {
+    step(s0 + 0, std::integral_constant<int, 0>{});
+    if constexpr (PF >= 2) step(s0 + 1, std::integral_constant<int, 1 % PF>{});
+  }
+  if constexpr (PF >= 2) { if (s0 < nsteps) step(s0, std::integral_constant<int, 0>{}); }
+
+  // partial tile -> slab [split][frow*NTAP + t][Cin][Cout], or atomics into dw
+  const int r = lane & 31, h = lane >> 5;
+  const int co = co0 + wave_b * 32 + r;
+  const long plane = (long)a.Cin * a.Cout;
+#pragma unroll
+  for (int t = 0; t < NTAP; t++) {
+    float* dst = a.ws ? a.ws + ((long)split * NTAP * NTAP + frow * NTAP + t) * plane : DW + (long)(frow * NTAP + t) * plane;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const int ci = ci0 + wave_a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (a.ws) dst[(long)ci * a.Cout + co] = acc[t][e];
+      else atomicAdd(dst + (long)ci * a.Cout + co, acc[t][e] * a.scale);
+    }
+  }
+  if (do_bias) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);            // [256][16]
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) red[(tid * 2 + j) * 8 + e] = bsum[j][e];
+    __syncthreads();
+    if (tid < 64) {
+      const int cc = tid >> 3, e = tid & 7;
+      float tsum = 0.f;
+      for (int p = 0; p < 64; p++) {
+        const int q = p * 8 + cc;
+        tsum += red[((q % NT) * 2 + q / NT) * 8 + e];
+      }
+      atomicAdd(DB + co0 + tid, tsum * a.scale);
+    }
+  }
+}
+
+// filter-row kernel for plain 3x3 stride-1 layers below the all-taps kernel's size (single layer or a same-shape batch)
+static bool wgrad_rows_ok(const WgradArgs& a) {
+  static int env = -1;   // experiment knob: GANK_WGRAD_ROWS=0 keeps these layers on the per-tap kernel
+  if (env < 0) { const char* e = getenv("GANK_WGRAD_ROWS"); env = e ? atoi(e) : 1; }
+  return env && a.ks == 3 && a.pad == 1 && (a.flags & ~GANK_IN_RELU) == 0 && a.sw >= 3 && a.shw >= 6 && a.H >= 8 && a.W >= 8 &&
+         a.Hx == a.H && a.Wx == a.W && a.Hdy == a.H && a.Wdy == a.W && a.Cin % 64 == 0 && a.Cout % 64 == 0 && a.M % 64 == 0 &&
+         (long)a.N * a.H * a.W * a.Cin < (1L << 30) && (long)a.N * a.H * a.W * a.Cout < (1L << 30);
+}
+static int launch_wgrad_rows(WgradArgs a, hipStream_t s) {
+  const int nb = a.nbatch > 0 ? a.nbatch : 1;
+  a.tiles_ci = a.Cin / 64;
+  a.tiles_co = a.Cout / 64;
+  const int total_steps = a.M / 64;
+  const int tiles = a.tiles_ci * a.tiles_co * 3 * nb;
+  static int target = -1;   // experiment knob
+  if (target < 0) { const char* e = getenv("GANK_WGRAD_ROWS_TARGET"); target = e ? atoi(e) : 256; }
+  int splits = (target + tiles - 1) / tiles;
+  if (splits > total_steps / 4) splits = total_steps / 4;
+  if (splits < 1) splits = 1;
+  a.steps_per_split = cdiv(total_steps, splits);
+  a.splits = cdiv(total_steps, a.steps_per_split);
+  a.ws = nullptr;          // partial tiles by fp32 atomics
+  const size_t lds = (size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16);
+  const bool relu = (a.flags & GANK_IN_RELU) != 0;
+  auto kern = relu ? conv_wgrad_rows_kernel<1, 2, false> : conv_wgrad_rows_kernel<0, 2, false>;
+  if (relu) { GANK_MAX_DYNAMIC_LDS((conv_wgrad_rows_kernel<1, 2, false>), (int)lds, "conv_wgrad_rows"); }
+  else { GANK_MAX_DYNAMIC_LDS((conv_wgrad_rows_kernel<0, 2, false>), (int)lds, "conv_wgrad_rows"); }
+  gank_prof_tag(1, relu ? "conv_wgrad_rows_kernel<1, 2, false>" : "conv_wgrad_rows_kernel<0, 2, false>");
+  hipLaunchKernelGGL(kern, dim3((unsigned)(3 * a.tiles_ci * a.tiles_co * a.splits), nb), dim3(256), lds, s, a);
+  GANK_LAUNCH_OK("conv_wgrad_rows");
+  return 0;
+}
+
 template <int WA, int WB, int TA, int TB, bool FAST, int PF>
 static int launch_wgrad(WgradArgs a, hipStream_t s) {
   constexpr int CiT = WA * TA * 32, CoT = WB * TB * 32;
@@ -1062,6 +1306,7 @@ int gank_wgrad_dispatch(WgradArgs a, hipStream_t s) {
   static int taps_env = -1;   // experiment knob: GANK_WGRAD_TAPS=0 disables the all-taps kernel
   if (taps_env < 0) { const char* e = getenv("GANK_WGRAD_TAPS"); taps_env = e ? atoi(e) : 1; }
   if (taps_env && wgrad_taps_ok(a)) rc = launch_wgrad_taps(a, s);
+  if (rc < 0 && wgrad_rows_ok(a)) rc = launch_wgrad_rows(a, s);
   static int lpf_env = -1;   // experiment knob: prefetch depth of the lean kernel
   if (lpf_env < 0) { const char* e = getenv("GANK_WGRAD_LEAN_PF"); lpf_env = e ? atoi(e) : 2; }
   if (rc < 0 && lean) {
@@ -1144,199 +1389,6 @@ __global__ void wgrad_fold4x4_kernel(const float* __restrict__ w4, float* __rest
     }
 }
 
-// ------------------------------------------------------------------------------------------------------
-// ConvMeanPool 3x3 filter gradient, filter-row form.  The 16-tap stride-2 gradient through the per-tap kernel above
-// re-reads x and dy from L2 once per tap and lands at ~0.2-0.4 PFLOP/s with a zero fill in front and a fold behind it.
-// Here one block owns a 64(ci) x 64(co) tile for the FOUR taps of one filter row a over a range of 8x8 patches of the
-// pooled grid: per patch it stages dy (64 pixels) and the 8 x-rows 2*py + a - 1 that this filter row touches (18
-// columns), and the four taps b read their A fragments from that image at shifted columns.  The image is stored with
-// the columns DE-INTERLEAVED by parity ([row][parity][9]), so a tap's stride-2 pixel walk is a unit-stride walk inside
-// one parity plane and the transposed reads stay conflict-free (interleaved, pixels 0 and 2 of a 16-lane group would
-// share banks).  Partial tiles go to slabs [split][16 taps][Cin][Cout]; ONE kernel then sums the splits, folds 4x4 -> 3x3
-// (dW3[i][j] = 1/4 sum_{s,t} dW4[i+s][j+t]) and accumulates into dw: two launches instead of fill + 16-tap kernel + fold,
-// 4 instead of 16 operand passes through L2.
-// ------------------------------------------------------------------------------------------------------
-constexpr int CPR_PIX = 8 * 18;
-constexpr int CPR_XSUB = CPR_PIX * 32 + 32;   // sub-tile stride (bf16): 64 B off a 256 B multiple
-
-template <int MODE, int PF>
-__global__ __launch_bounds__(256) void conv_wgrad_cpool_rows_kernel(WgradArgs a) {
-  constexpr int NT = 256;
-  constexpr bool XRELU = (MODE & 1) != 0;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16* sX = reinterpret_cast<bf16*>(smem);        // [2][2 subs][144 pix][32 ch]
-  bf16* sD = sX + 2 * 2 * CPR_XSUB;                // [2][2 subs][64 pix][32 ch]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wave_a = wave & 1, wave_b = wave >> 1;
-  int bid = blockIdx.x;
-  const int split = bid % a.splits; bid /= a.splits;
-  const int tco = bid % a.tiles_co; bid /= a.tiles_co;
-  const int tci = bid % a.tiles_ci;
-  const int frow = bid / a.tiles_ci;               // filter row a of the 4x4 kernel
-  const int ci0 = tci * 64, co0 = tco * 64;
-  const bool do_bias = a.dbias != nullptr && tci == 0 && frow == 0;
-
-  const int step0 = split * a.steps_per_split;
-  int nsteps = (a.M >> 6) - step0;
-  if (nsteps > a.steps_per_split) nsteps = a.steps_per_split;
-  if (nsteps <= 0) return;
-
-  constexpr int OOB = 0x7FFFFFF0;
-  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, a.N * a.Hx * a.Wx * a.Cin * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.dy), 0, a.N * a.H * a.W * a.Cout * 2, 0x00020000);
-  const int pw_shift = a.sw - 3, pi_shift = a.shw - 6;   // patches per row / per image of the pooled grid (log2)
-
-  // x chunks: 144 halo pixels x 8 chunks of 8 channels = 1152 = 4.5 per thread
-  int x_hy[5], x_hx[5], x_c[5], x_lds[5];
-  bool x_on[5];
-#pragma unroll
-  for (int j = 0; j < 5; j++) {
-    const int q = tid + NT * j;
-    x_on[j] = q < CPR_PIX * 8;
-    const int hp = x_on[j] ? q >> 3 : 0, cc = q & 7;
-    const int hyi = hp / 18, hx = hp % 18;
-    x_hy[j] = 2 * hyi + frow - 1;
-    x_hx[j] = hx - 1;
-    x_c[j] = x_on[j] ? (ci0 + cc * 8) * 2 : OOB;
-    x_lds[j] = (cc >> 2) * CPR_XSUB + (hyi * 18 + (hx & 1) * 9 + (hx >> 1)) * 32 + (cc & 3) * 8;
-  }
-  int d_y[2], d_x[2], d_c[2], d_lds[2];
-#pragma unroll
-  for (int j = 0; j < 2; j++) {
-    const int q = tid + NT * j, p = q >> 3, cc = q & 7;
-    d_y[j] = p >> 3; d_x[j] = p & 7;
-    d_c[j] = (co0 + cc * 8) * 2;
-    d_lds[j] = (cc >> 2) * SUBS + p * 32 + (cc & 3) * 8;
-  }
-
-  u32x4 rX[PF][5], rD[PF][2];
-  float bsum[2][8];
-#pragma unroll
-  for (int j = 0; j < 2; j++)
-#pragma unroll
-    for (int e = 0; e < 8; e++) bsum[j][e] = 0.f;
-
-  const int last = nsteps - 1;
-  int cur = 0;
-  auto load_next = [&](u32x4 (&rX)[5], u32x4 (&rD)[2]) {
-    const int patch = step0 + cur;                       // wave-uniform
-    const int n = patch >> pi_shift;
-    const int pin = patch & ((1 << pi_shift) - 1);
-    const int py0 = (pin >> pw_shift) << 3, px0 = (pin & ((1 << pw_shift) - 1)) << 3;
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-      const int iy = 2 * py0 + x_hy[j], ix = 2 * px0 + x_hx[j];
-      const bool ok = (unsigned)iy < (unsigned)a.Hx && (unsigned)ix < (unsigned)a.Wx;
-      const int off = ((n * a.Hx + iy) * a.Wx + ix) * a.Cin * 2 + x_c[j];
-      rX[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? off : OOB, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int off = ((n * a.H + py0 + d_y[j]) * a.W + px0 + d_x[j]) * a.Cout * 2 + d_c[j];
-      rD[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, off, 0, 0);
-    }
-    if (cur < last) cur++;
-  };
-  auto store_step = [&](int buf, u32x4 (&rX)[5], u32x4 (&rD)[2]) {
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-      if (x_on[j]) {
-        u32x4 v = rX[j];
-        if constexpr (XRELU) v = relu_bf16x8(v);
-        *reinterpret_cast<u32x4*>(sX + buf * 2 * CPR_XSUB + x_lds[j]) = v;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      *reinterpret_cast<u32x4*>(sD + buf * 2 * SUBS + d_lds[j]) = rD[j];
-      if (do_bias) {
-        const bf16x8 t = __builtin_bit_cast(bf16x8, rD[j]);
-#pragma unroll
-        for (int e = 0; e < 8; e++) bsum[j][e] += bf2f(t[e]);
-      }
-    }
-  };
-
-  f32x16 acc[4];
-#pragma unroll
-  for (int t = 0; t < 4; t++)
-#pragma unroll
-    for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
-
-  const int g = lane >> 4, li = lane & 15;
-  // lane part of the transposed-read addresses: k half (g>>1) = pooled row within the pair, (li>>2) = pooled column
-  const int xl = ((g >> 1) * 18 + (li >> 2)) * 32 + 16 * (g & 1) + 4 * (li & 3);
-  const int dl = (8 * (g >> 1) + (li >> 2)) * 32 + 16 * (g & 1) + 4 * (li & 3);
-
-#pragma unroll
-  for (int d = 0; d < PF; d++) load_next(rX[d], rD[d]);
-  store_step(0, rX[0], rD[0]);
-  __syncthreads();
-
-  auto step = [&](int s, auto slot) {
-    constexpr int D = decltype(slot)::value;
-    const int buf = s & 1;
-    if constexpr (PF > 1) load_next(rX[D], rD[D]);
-    else if (s + 1 < nsteps) load_next(rX[0], rD[0]);
-    const bf16* pX = sX + (buf * 2 + wave_a) * CPR_XSUB + xl;
-    const bf16* pD = sD + (buf * 2 + wave_b) * SUBS + dl;
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-      const s16x4 bl = lds_tr_read(pD + kk * 16 * 32), bh = lds_tr_read(pD + kk * 16 * 32 + 4 * 32);
-      const s16x8 tb = {bl[0], bl[1], bl[2], bl[3], bh[0], bh[1], bh[2], bh[3]};
-      const bf16x8 fb = __builtin_bit_cast(bf16x8, tb);
-#pragma unroll
-      for (int t = 0; t < 4; t++) {
-        const int o = (2 * kk * 18 + (t & 1) * 9 + (t >> 1)) * 32;
-        const s16x4 al = lds_tr_read(pX + o), ah = lds_tr_read(pX + o + 4 * 32);
-        const s16x8 ta = {al[0], al[1], al[2], al[3], ah[0], ah[1], ah[2], ah[3]};
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ta), fb, acc[t], 0, 0, 0);
-      }
-    }
-    if (s + 1 < nsteps) store_step(buf ^ 1, rX[(D + 1) % PF], rD[(D + 1) % PF]);
-    __syncthreads();
-  };
-  int s0 = 0;
-  for (; s0 + PF <= nsteps; s0 += PF) {
-    step(s0 + 0, std::integral_constant<int, 0>{});
-    if constexpr (PF >= 2) step(s0 + 1, std::integral_constant<int, 1 % PF>{});
-  }
-  if constexpr (PF >= 2) { if (s0 < nsteps) step(s0, std::integral_constant<int, 0>{}); }
-
-  // partial tile -> slab [split][frow*4 + t][Cin][Cout]
-  const int r = lane & 31, h = lane >> 5;
-  const int co = co0 + wave_b * 32 + r;
-  const long plane = (long)a.Cin * a.Cout;
-#pragma unroll
-  for (int t = 0; t < 4; t++) {
-    float* dst = a.ws + ((long)split * 16 + frow * 4 + t) * plane;
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-      const int ci = ci0 + wave_a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-      dst[(long)ci * a.Cout + co] = acc[t][e];
-    }
-  }
-  if (do_bias) {
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);            // [256][16]
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int e = 0; e < 8; e++) red[(tid * 2 + j) * 8 + e] = bsum[j][e];
-    __syncthreads();
-    if (tid < 64) {
-      const int cc = tid >> 3, e = tid & 7;
-      float tsum = 0.f;
-      for (int p = 0; p < 64; p++) {
-        const int q = p * 8 + cc;
-        tsum += red[((q % NT) * 2 + q / NT) * 8 + e];
-      }
-      atomicAdd(a.dbias + co0 + tid, tsum);
-    }
-  }
-}
-
 // dw[i][j] += 1/4 sum_{s,t in {0,1}} sum_split slab[split][(i+s)*4 + j+t]      (one thread per (3x3 tap, float4 of the plane))
 __global__ void wgrad_cpool_fold_slabs_kernel(const float* __restrict__ ws, float* __restrict__ dw, long plane4, int splits) {
   const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -1403,11 +1455,12 @@ extern "C" int gank_convpool3x3_wgrad(const void* x, const void* dy, float* dw, 
     GANK_REQUIRE(ws_elems >= 16L * Cin * Cout * a.splits, "convpool3x3_wgrad: workspace of %ld floats, need %ld (gank_convpool3x3_wgrad_ws_elems)",
                  ws_elems, 16L * Cin * Cout * a.splits);
     gank_prof_begin(1, 2.0 * a.M * 16.0 * Cin * Cout, s, 2.0 * ((double)N * 4 * Hp * Wp * Cin + (double)a.M * Cout) + 36.0 * Cin * Cout);
-    gank_prof_tag(1, "conv_wgrad_cpool_rows_kernel + wgrad_cpool_fold_slabs_kernel");
+    gank_prof_tag(1, "conv_wgrad_rows_kernel<1, 2, true> + wgrad_cpool_fold_slabs_kernel");
     const size_t lds = (size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16);
-    auto kern = (flags & GANK_IN_RELU) ? conv_wgrad_cpool_rows_kernel<1, 2> : conv_wgrad_cpool_rows_kernel<0, 2>;
-    if (flags & GANK_IN_RELU) { GANK_MAX_DYNAMIC_LDS((conv_wgrad_cpool_rows_kernel<1, 2>), (int)lds, "conv_wgrad_cpool_rows"); }
-    else { GANK_MAX_DYNAMIC_LDS((conv_wgrad_cpool_rows_kernel<0, 2>), (int)lds, "conv_wgrad_cpool_rows"); }
+    a.scale = 1.f;
+    auto kern = (flags & GANK_IN_RELU) ? conv_wgrad_rows_kernel<1, 2, true> : conv_wgrad_rows_kernel<0, 2, true>;
+    if (flags & GANK_IN_RELU) { GANK_MAX_DYNAMIC_LDS((conv_wgrad_rows_kernel<1, 2, true>), (int)lds, "conv_wgrad_rows"); }
+    else { GANK_MAX_DYNAMIC_LDS((conv_wgrad_rows_kernel<0, 2, true>), (int)lds, "conv_wgrad_rows"); }
     hipLaunchKernelGGL(kern, dim3((unsigned)(4 * a.tiles_ci * a.tiles_co * a.splits)), dim3(256), lds, s, a);
     const long plane4 = (long)Cin * Cout / 4;
     hipLaunchKernelGGL(wgrad_cpool_fold_slabs_kernel, dim3((unsigned)cdiv(plane4, 256), 9), dim3(256), 0, s, ws16, dw, plane4, a.splits);
@@ -1448,8 +1501,9 @@ extern "C" int gank_conv2d_wgrad_batched(const gank_wgrad_item* items, int count
   a.M = N * H * W; a.sw = log2_or_neg(W); a.shw = log2_or_neg(H * W);
   const bool batchable = (flags & ~GANK_IN_RELU) == 0 && Cin % 8 == 0 && Cout % 8 == 0 && Cin >= 128 && Cout >= 128 && a.sw >= 0 &&
                          a.shw >= 0 && a.M % 64 == 0 && !wgrad_taps_ok(a) && (long)a.M * (Cin > Cout ? Cin : Cout) < (1L << 30);
+  const bool rows = batchable && wgrad_rows_ok(a);
   int i = 0;
-  while (batchable && count - i >= 2) {
+  while (batchable && count - i >= (rows ? 1 : 2)) {
     const int nb = count - i < 4 ? count - i : 4;
     for (int j = 0; j < nb; j++) {
       GANK_REQUIRE(items[i + j].x && items[i + j].dy && items[i + j].dw, "conv2d_wgrad_batched: null pointer in item %d", i + j);
@@ -1459,7 +1513,7 @@ extern "C" int gank_conv2d_wgrad_batched(const gank_wgrad_item* items, int count
     a.nbatch = nb;
     a.x = a.xs[0]; a.dy = a.dys[0]; a.dw = a.dws[0]; a.dbias = a.dbs[0];
     gank_prof_begin(1, 2.0 * nb * a.M * (double)Cout * a.taps * Cin, s, nb * (2.0 * a.M * ((double)Cin + Cout) + 4.0 * a.taps * Cin * Cout));
-    const int rc = launch_wgrad_lean<2, 2, 2, 2, 2>(a, s);
+    const int rc = rows ? launch_wgrad_rows(a, s) : launch_wgrad_lean<2, 2, 2, 2, 2>(a, s);
     gank_prof_end(1, s);
     if (rc) return rc > 0 ? rc : gank_set_error("conv2d_wgrad_batched: mode not instantiated");
     i += nb;

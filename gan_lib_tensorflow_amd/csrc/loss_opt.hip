@@ -196,7 +196,7 @@ extern "C" int gank_adam_tf(float* p, float* g, float* m, float* v, float* hp, i
   GANK_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_tf: buffers must be 16-byte aligned");
   GANK_REQUIRE(zero_n == 0 || zero_n == n || (zero_n > n && n % 4 == 0 && zero_n % 4 == 0), "adam_tf: zero_n must be 0, n, or a multiple of 4 beyond an n that is one");
   long blocks = (n / 4 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 512) blocks = 512;      // two per CU: every block draws a ticket from ONE address, and same-address atomics serialise (1662 blocks: +16 us)
   if (blocks < 1) blocks = 1;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(adam_tf_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, hp, (long long*)t_state,

@@ -708,6 +708,27 @@ def test_conv_wgrad_batched_equals_separate(K):
             assert relerr(db, db_ref) < F32_FROM_BF_TOL
 
 
+@pytest.mark.parametrize("n,h,w_,cin,cout,relu", [(3, 8, 16, 64, 128, True), (5, 16, 8, 128, 64, False), (24, 8, 8, 256, 256, True)])
+def test_conv_wgrad_filter_row_kernel(K, n, h, w_, cin, cout, relu):
+    """Plain 3x3 filter gradients below the all-taps kernel's size run on the filter-row kernel (one block = the three taps of
+    one filter row of a 64x64 channel tile; several 8x8 patches per image, non-square grids, pixel splits with atomics)."""
+    rng = np.random.default_rng(n + h + w_ + cin)
+    x, xt = bf(rng.normal(size=(n, h, w_, cin)))
+    dy, dyt = bf(rng.normal(size=(n, h, w_, cout)))
+    dw = torch.full((3, 3, cin, cout), 2.0, dtype=torch.float32, device="cuda")
+    db = torch.zeros(cout, dtype=torch.float32, device="cuda")
+    K.prof_enable(True)
+    K.prof_reset()
+    K.conv2d_wgrad(xt, dyt, dw, (h, w_), 3, K.IN_RELU if relu else 0, 1.0, dbias=db)
+    torch.cuda.synchronize()
+    ran = [k[0] for k in K.prof_kernels(1)]
+    K.prof_enable(False)
+    assert any("conv_wgrad_rows_kernel" in k for k in ran), ran
+    _, ref, refb = R.conv2d_same_grads(R.relu(x) if relu else x, np.zeros((3, 3, cin, cout)), dy)
+    assert relerr(dw - 2.0, ref) < F32_FROM_BF_TOL
+    assert relerr(db, refb) < F32_FROM_BF_TOL
+
+
 @pytest.mark.parametrize("n,hw,c", [(3, 4, 64), (5, 16, 128), (2, 32, 256)])
 def test_layer_instance_pixel_norm_ops(K, n, hw, c):
     """layer_norm / instance_norm / pixel_norm of common/ops/normalization.py:62-140 through the reference-shaped ops."""
