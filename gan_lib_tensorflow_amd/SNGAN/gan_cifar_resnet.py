@@ -65,7 +65,10 @@ def Generator(n_samples_, labels, noise=None, reuse=False, groups=1, rng_state=N
     """(:237-263)  noise [n,128] bf16 (drawn from the device RNG when None) -> [n, 3072] bf16, HWC order,
     tanh range.  `groups` towers of n/groups samples have independent CBN statistics."""
     store = get_default_store()
-    with store.variable_scope("Generator", reuse=reuse):
+    # the statistics sums of the six convs that feed a conditional batch norm: one fill for the whole pass
+    arena = K.stats_arena(6 * groups * 16 * 2 * DIM_G * 2 + 512, labels.device) if (NORMALIZATION_G and Fn.CONV_EPILOGUE_STATS and labels.is_cuda) \
+        else contextlib.nullcontext()
+    with store.variable_scope("Generator", reuse=reuse), arena:
         if noise is None:
             if rng_state is None:
                 raise ValueError('Generator needs `noise` or an `rng_state` (kernels.new_rng_state)')

@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, os.environ.get("GANK_LIB_NAME", "libgank.so"))   
 P, I, L, F = C.c_void_p, C.c_int, C.c_long, C.c_float
 
 # flags (include/gank.h)
-IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, W_FRAG, RES_UPSAMPLE2X = 1, 2, 4, 8, 32, 64
+IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, W_FRAG, RES_UPSAMPLE2X, STATS_PREZEROED = 1, 2, 4, 8, 32, 64, 256
 STAT_SLOTS = 16   # GANK_STAT_SLOTS
 
 

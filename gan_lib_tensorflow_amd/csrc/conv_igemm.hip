@@ -48,10 +48,23 @@ struct IgemmArgs {
   // conditional-batch-norm statistics of the OUTPUT, accumulated by the epilogue (two-group kernel only):
   // stat_sums [groups][2][Cout] += (sum, sum of squares) of (y - bias) over the samples of each tower; null = off
   float* stat_sums;
-  int stat_n_per_group, stat_groups;
+  int stat_n_per_group, stat_groups, stat_prezeroed;
 };
 
 constexpr int LROW = 72;  // LDS row length in bf16 (64 + 8 pad) = 144 B
+
+template <int CTRL>
+__device__ __forceinline__ float pp_dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+// all 16 lanes of a DPP row end up with the row's sum: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ float pp_row_sum(float v) {
+  v = pp_dpp_add<0xB1>(v);
+  v = pp_dpp_add<0x4E>(v);
+  v = pp_dpp_add<0x141>(v);
+  v = pp_dpp_add<0x140>(v);
+  return v;
+}
 
 // PF   = register prefetch slots: global loads for K-step s+PF-1 are in flight while step s is computed
 //        (plain loads survive the per-step barrier; hipcc emits counted vmcnt waits for the oldest slot).
@@ -59,8 +72,9 @@ constexpr int LROW = 72;  // LDS row length in bf16 (64 + 8 pad) = 144 B
 //        zero insertion).  The staging pass runs once per K-step per wave and competes with the MFMAs for
 //        issue slots, so its instruction count is what bounds this kernel: runtime flags cost selects,
 //        64-bit address arithmetic cost 3x the VALU work, tap decoding by division 100+ SALU per step.
-template <int WM, int WN, int TM, int TN, bool PACKED, int PF, int MODE>
+template <int WM, int WN, int TM, int TN, bool PACKED, int PF, int MODE, bool STATS = false>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
+  static_assert(!STATS || (!PACKED && TN * 16 <= 32), "statistics epilogue: plain operands, at most 32 channels per half-wave");
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
@@ -294,6 +308,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
   // epilogue: lane holds, per accumulator quad g, channels co0+8g+4h .. +3 of pixel m
   const bool vec = (a.Cout & 3) == 0;
   const bool otanh = (a.flags & GANK_OUT_TANH) != 0;
+  // STATS (host guarantees: full tiles, every tile inside one tower, Cout % BN == 0): per-lane sums of (y - bias) and
+  // its square per channel, reduced over the wave's pixels after the stores -- the batch-norm statistics of the layer
+  // that consumes y (normalization.py:47), as in the two-group kernel's epilogue
+  float st1[STATS ? TN * 16 : 1], st2[STATS ? TN * 16 : 1];
+  if constexpr (STATS) {
+#pragma unroll
+    for (int q = 0; q < TN * 16; q++) { st1[q] = 0.f; st2[q] = 0.f; }
+  }
 #pragma unroll
   for (int j = 0; j < TM; j++) {
     int m = tile_m * BM + (wave_m * TM + j) * 32 + r;
@@ -321,8 +343,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
         for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * g + e] * a.scale;
         const long o = (long)m * a.Cout + co;
         if (vec) {
+          f32x4 b = {0.f, 0.f, 0.f, 0.f};
           if (a.bias) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + co);
+            b = *reinterpret_cast<const f32x4*>(a.bias + co);
 #pragma unroll
             for (int e = 0; e < 4; e++) v[e] += b[e];
           }
@@ -335,6 +358,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
             const bf16x4 rs = *reinterpret_cast<const bf16x4*>(a.res + mr * a.Cout + co);
 #pragma unroll
             for (int e = 0; e < 4; e++) v[e] += bf2f(rs[e]);
+          }
+          if constexpr (STATS) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const float d = v[e] - b[e]; st1[i * 16 + g * 4 + e] += d; st2[i * 16 + g * 4 + e] += d * d; }
           }
           bf16x4 out;
 #pragma unroll
@@ -352,6 +379,26 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
           }
         }
       }
+    }
+  }
+  if constexpr (STATS) {
+    float keep1 = 0.f, keep2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < TN * 16; q++) {
+      // sum over the 32 lanes of the half-wave (its 32 pixels): DPP inside the 16-lane rows, one shuffle across them
+      float s1 = pp_row_sum(st1[q]), s2 = pp_row_sum(st2[q]);
+      s1 += __shfl_xor(s1, 16, 64);
+      s2 += __shfl_xor(s2, 16, 64);
+      keep1 = r == q ? s1 : keep1;
+      keep2 = r == q ? s2 : keep2;
+    }
+    if (r < TN * 16) {          // lane (r, h) holds channel (i, g, e) = (r >> 4, (r >> 2) & 3, r & 3) of its half
+      const int m0 = tile_m * BM;                      // the tile's first pixel (phase mode: low-resolution pixel index)
+      const int n0 = a.shw >= 0 ? (m0 >> a.shw) : m0 / (a.H * a.W);
+      float* dst = a.stat_sums + ((long)(n0 / a.stat_n_per_group) * GANK_STAT_SLOTS + (blockIdx.x % GANK_STAT_SLOTS)) * 2 * a.Cout;
+      const int co = tile_n * BN + (wave_n * TN + (r >> 4)) * 32 + 8 * ((r >> 2) & 3) + 4 * h + (r & 3);
+      atomicAdd(dst + co, keep1);
+      atomicAdd(dst + a.Cout + co, keep2);
     }
   }
 }
@@ -968,19 +1015,6 @@ constexpr int PP_NSLOT = 6, PP_PD = 4;             // ring slots, prefetch dista
 constexpr int PP_WRING = 2 * PP_HALO_BYTES;
 constexpr int PP_LDS_BYTES = PP_WRING + PP_NSLOT * PP_WSLOT_BYTES;   // 144 KB
 
-template <int CTRL>
-__device__ __forceinline__ float pp_dpp_add(float v) {
-  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
-}
-// all 16 lanes of a DPP row end up with the row's sum: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
-__device__ __forceinline__ float pp_row_sum(float v) {
-  v = pp_dpp_add<0xB1>(v);
-  v = pp_dpp_add<0x4E>(v);
-  v = pp_dpp_add<0x141>(v);
-  v = pp_dpp_add<0x140>(v);
-  return v;
-}
-
 template <int N>
 __device__ __forceinline__ void pp_wait_vmcnt() {
   static_assert(N == 0 || N == 4 || N == 6 || N == 7, "vmcnt value not instantiated");
@@ -1247,6 +1281,14 @@ __global__ void ig_zero_kernel(float* __restrict__ p, int n) {
 }
 
 static void stats_zero(const IgemmArgs& a, hipStream_t s);
+// generic kernel with the statistics epilogue: every pixel tile full and inside one tower, every channel tile full
+// (a.M, a.H, a.W: the grid the tiles walk -- the low-resolution grid in phase mode)
+static bool igemm_stats_ok(const IgemmArgs& a, int BM, int BN) {
+  static int env = -1;   // experiment knob: GANK_IGEMM_STATS=0 leaves the statistics to the batch-norm kernels
+  if (env < 0) { const char* e = getenv("GANK_IGEMM_STATS"); env = e ? atoi(e) : 1; }
+  return env && a.stat_sums != nullptr && !(a.flags & GANK_OUT_TANH) && a.M % BM == 0 && a.Cout % BN == 0 &&
+         ((long)a.stat_n_per_group * a.H * a.W) % BM == 0;
+}
 template <int MODE, int PW>
 static int launch_pp(const IgemmArgs& a0, hipStream_t s) {
   IgemmArgs a = a0;
@@ -1311,10 +1353,21 @@ static int launch_cfg(const IgemmArgs& a0, hipStream_t s) {
   a.tiles_m = cdiv(a.M, BM);
   a.tiles_n = a.CoutPad / BN;
   const size_t lds = (size_t)2 * (BM + BN) * LROW * sizeof(bf16);
-  auto kern = conv_igemm_kernel<WM, WN, TM, TN, PACKED, PF, MODE>;
-  GANK_MAX_DYNAMIC_LDS(kern, (int)lds, "conv_igemm");
   static const std::string tag = gank_format("conv_igemm_kernel<%d, %d, %d, %d, %s, %d, %d>", WM, WN, TM, TN, PACKED ? "true" : "false", PF, MODE);     // magic static: built once, thread-safe
   gank_prof_tag(0, tag.c_str());
+  if constexpr (!PACKED && MODE == 0 && TN * 16 <= 32) {
+    if (igemm_stats_ok(a, BM, BN)) {      // the layer that consumes y is a batch norm: its statistics ride on this epilogue
+      auto kern = conv_igemm_kernel<WM, WN, TM, TN, PACKED, PF, MODE, true>;
+      GANK_MAX_DYNAMIC_LDS(kern, (int)lds, "conv_igemm");
+      tl_stats_done = 1;
+      stats_zero(a, s);
+      hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(WM * WN * 64), lds, s, a);
+      GANK_LAUNCH_OK("conv_igemm");
+      return 0;
+    }
+  }
+  auto kern = conv_igemm_kernel<WM, WN, TM, TN, PACKED, PF, MODE>;
+  GANK_MAX_DYNAMIC_LDS(kern, (int)lds, "conv_igemm");
   hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(WM * WN * 64), lds, s, a);
   GANK_LAUNCH_OK("conv_igemm");
   return 0;
@@ -1328,10 +1381,21 @@ static int launch_phase(const IgemmArgs& a0, hipStream_t s) {
   a.tiles_m = 4 * a.tiles_pp;
   a.tiles_n = a.CoutPad / BN;
   const size_t lds = (size_t)2 * (BM + BN) * LROW * sizeof(bf16);
-  auto kern = conv_igemm_kernel<WM, WN, TM, TN, false, PF, 4>;
-  GANK_MAX_DYNAMIC_LDS(kern, (int)lds, "conv_igemm");
   static const std::string tag = gank_format("conv_igemm_kernel<%d, %d, %d, %d, false, %d, 4>", WM, WN, TM, TN, PF);     // magic static: built once, thread-safe
   gank_prof_tag(0, tag.c_str());
+  if constexpr (TN * 16 <= 32) {
+    if (igemm_stats_ok(a, BM, BN)) {
+      auto kern = conv_igemm_kernel<WM, WN, TM, TN, false, PF, 4, true>;
+      GANK_MAX_DYNAMIC_LDS(kern, (int)lds, "conv_igemm");
+      tl_stats_done = 1;
+      stats_zero(a, s);
+      hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(WM * WN * 64), lds, s, a);
+      GANK_LAUNCH_OK("conv_igemm_phase");
+      return 0;
+    }
+  }
+  auto kern = conv_igemm_kernel<WM, WN, TM, TN, false, PF, 4>;
+  GANK_MAX_DYNAMIC_LDS(kern, (int)lds, "conv_igemm");
   hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(WM * WN * 64), lds, s, a);
   GANK_LAUNCH_OK("conv_igemm_phase");
   return 0;
@@ -1424,9 +1488,10 @@ int gank_igemm_dispatch(IgemmArgs a, hipStream_t s) {
   return rc;
 }
 
-static int stats_setup(IgemmArgs& a, float* stat_sums, int groups, int N, int Cout, hipStream_t s) {
+static int stats_setup(IgemmArgs& a, float* stat_sums, int groups, int N, int Cout, hipStream_t s, int flags) {
   tl_stats_done = 0;
   if (!stat_sums) return 0;
+  a.stat_prezeroed = (flags & GANK_STATS_PREZEROED) != 0;
   GANK_REQUIRE(groups > 0 && N % groups == 0, "conv statistics: batch %d not divisible by %d towers", N, groups);
   a.stat_sums = stat_sums;
   a.stat_n_per_group = N / groups;
@@ -1435,6 +1500,7 @@ static int stats_setup(IgemmArgs& a, float* stat_sums, int groups, int N, int Co
 }
 // the sums are cleared by the launcher of a kernel that accumulates them (a kernel that does not never pays for the fill)
 static void stats_zero(const IgemmArgs& a, hipStream_t s) {
+  if (a.stat_prezeroed) return;          // GANK_STATS_PREZEROED: the caller cleared the sums (one fill for a whole pass)
   const int n = a.stat_groups * GANK_STAT_SLOTS * 2 * a.Cout;
   hipLaunchKernelGGL(ig_zero_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a.stat_sums, n);
 }
@@ -1455,7 +1521,7 @@ static int conv2d_fprop_impl(const void* x, const void* wf, const float* bias, c
             ((flags & GANK_RES_UPSAMPLE2X) ? IG_RES_UP2X : 0);
   GANK_REQUIRE(!(flags & GANK_RES_UPSAMPLE2X) || (residual && H % 2 == 0 && W % 2 == 0), "conv2d_fprop: RES_UPSAMPLE2X needs a residual and even output size");
   a.scale = scale;
-  if (stats_setup(a, stat_sums, groups, N, Cout, (hipStream_t)stream)) return 1;
+  if (stats_setup(a, stat_sums, groups, N, Cout, (hipStream_t)stream, flags)) return 1;
   return gank_igemm_dispatch(a, (hipStream_t)stream);
 }
 
@@ -1506,7 +1572,7 @@ static int upconv3x3_fprop_impl(const void* x, const void* wph, const float* bia
   a.taps = 4; a.CoutPad = roundup(Cout, 32); a.Kpad = 4 * Cin; a.nsteps = a.Kpad / 64;
   a.M = N * Hl * Wl; a.sw = log2_or_neg(Wl); a.shw = log2_or_neg(Hl * Wl);
   GANK_REQUIRE((long)N * Hl * Wl * Cin < (1L << 30) && (long)a.M * 4 * Cout < (1L << 31), "upconv3x3_fprop: tensor too large");
-  if (stats_setup(a, stat_sums, groups, N, Cout, s)) return 1;
+  if (stats_setup(a, stat_sums, groups, N, Cout, s, flags)) return 1;
   gank_prof_begin(0, 2.0 * a.M * 4.0 * (double)Cout * 4 * Cin, s, 2.0 * ((double)a.M * Cin + 16.0 * Cin * Cout + 4.0 * a.M * Cout));
   int rc;
   const long tiles128 = 4L * cdiv(a.M, 128) * (a.CoutPad / 128);

@@ -1193,8 +1193,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs a) {
   for (; s0 + PF <= nsteps; s0 += PF) {
     step(s0 + 0, std::integral_constant<int, 0>{});
     if constexpr (PF >= 2) step(s0 + 1, std::integral_constant<int, 1 % PF>{});
+    if constexpr (PF >= 3) step(s0 + 2, std::integral_constant<int, 2 % PF>{});
+    if constexpr (PF >= 4) step(s0 + 3, std::integral_constant<int, 3 % PF>{});
   }
-  if constexpr (PF >= 2) { if (s0 < nsteps) step(s0, std::integral_constant<int, 0>{}); }
+  if constexpr (PF >= 2) { if (s0 + 0 < nsteps) step(s0 + 0, std::integral_constant<int, 0>{}); }
+  if constexpr (PF >= 3) { if (s0 + 1 < nsteps) step(s0 + 1, std::integral_constant<int, 1 % PF>{}); }
+  if constexpr (PF >= 4) { if (s0 + 2 < nsteps) step(s0 + 2, std::integral_constant<int, 2 % PF>{}); }
 
   // partial tile -> slab [split][frow*NTAP + t][Cin][Cout], or atomics into dw
   const int r = lane & 31, h = lane >> 5;
@@ -1254,9 +1258,11 @@ static int launch_wgrad_rows(WgradArgs a, hipStream_t s) {
   a.ws = nullptr;          // partial tiles by fp32 atomics
   const size_t lds = (size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16);
   const bool relu = (a.flags & GANK_IN_RELU) != 0;
-  auto kern = relu ? conv_wgrad_rows_kernel<1, 2, false> : conv_wgrad_rows_kernel<0, 2, false>;
-  if (relu) { GANK_MAX_DYNAMIC_LDS((conv_wgrad_rows_kernel<1, 2, false>), (int)lds, "conv_wgrad_rows"); }
-  else { GANK_MAX_DYNAMIC_LDS((conv_wgrad_rows_kernel<0, 2, false>), (int)lds, "conv_wgrad_rows"); }
+  static int pf = -1;       // experiment knob: register prefetch depth
+  if (pf < 0) { const char* e = getenv("GANK_WGRAD_ROWS_PF"); pf = e ? atoi(e) : 2; }
+  auto kern = relu ? (pf == 4 ? conv_wgrad_rows_kernel<1, 4, false> : pf == 3 ? conv_wgrad_rows_kernel<1, 3, false> : conv_wgrad_rows_kernel<1, 2, false>)
+                   : (pf == 4 ? conv_wgrad_rows_kernel<0, 4, false> : pf == 3 ? conv_wgrad_rows_kernel<0, 3, false> : conv_wgrad_rows_kernel<0, 2, false>);
+  static_assert((size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16) <= 65536, "below the default dynamic-LDS limit: no attribute call");
   gank_prof_tag(1, relu ? "conv_wgrad_rows_kernel<1, 2, false>" : "conv_wgrad_rows_kernel<0, 2, false>");
   hipLaunchKernelGGL(kern, dim3((unsigned)(3 * a.tiles_ci * a.tiles_co * a.splits), nb), dim3(256), lds, s, a);
   GANK_LAUNCH_OK("conv_wgrad_rows");
@@ -1458,9 +1464,11 @@ extern "C" int gank_convpool3x3_wgrad(const void* x, const void* dy, float* dw, 
     gank_prof_tag(1, "conv_wgrad_rows_kernel<1, 2, true> + wgrad_cpool_fold_slabs_kernel");
     const size_t lds = (size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16);
     a.scale = 1.f;
-    auto kern = (flags & GANK_IN_RELU) ? conv_wgrad_rows_kernel<1, 2, true> : conv_wgrad_rows_kernel<0, 2, true>;
-    if (flags & GANK_IN_RELU) { GANK_MAX_DYNAMIC_LDS((conv_wgrad_rows_kernel<1, 2, true>), (int)lds, "conv_wgrad_rows"); }
-    else { GANK_MAX_DYNAMIC_LDS((conv_wgrad_rows_kernel<0, 2, true>), (int)lds, "conv_wgrad_rows"); }
+    static int pf = -1;       // experiment knob: register prefetch depth
+    if (pf < 0) { const char* e = getenv("GANK_CPOOL_ROWS_PF"); pf = e ? atoi(e) : 2; }
+    auto kern = (flags & GANK_IN_RELU) ? (pf == 3 ? conv_wgrad_rows_kernel<1, 3, true> : conv_wgrad_rows_kernel<1, 2, true>)
+                                       : (pf == 3 ? conv_wgrad_rows_kernel<0, 3, true> : conv_wgrad_rows_kernel<0, 2, true>);
+    static_assert((size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16) <= 65536, "below the default dynamic-LDS limit: no attribute call");
     hipLaunchKernelGGL(kern, dim3((unsigned)(4 * a.tiles_ci * a.tiles_co * a.splits)), dim3(256), lds, s, a);
     const long plane4 = (long)Cin * Cout / 4;
     hipLaunchKernelGGL(wgrad_cpool_fold_slabs_kernel, dim3((unsigned)cdiv(plane4, 256), 9), dim3(256), 0, s, ws16, dw, plane4, a.splits);

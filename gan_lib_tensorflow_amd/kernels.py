@@ -6,7 +6,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, W_FRAG, RES_UPSAMPLE2X, SnDesc, PrepDesc, WgradItem  # noqa: F401
+from ._lib import IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, W_FRAG, RES_UPSAMPLE2X, STATS_PREZEROED, SnDesc, PrepDesc, WgradItem  # noqa: F401
 
 BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
 
@@ -108,6 +108,38 @@ def prep_weights_batched(ws, want_d=True, kinds=None):
     return outs
 
 
+class stats_arena:
+    """One zero fill for the statistics sums of every conv of a pass: inside the context, conv2d_fprop / upconv3x3_fprop
+    take their `sums` buffers from one pre-cleared allocation (GANK_STATS_PREZEROED) instead of each launching a fill.
+    `floats`: capacity; a request that does not fit falls back to its own buffer and fill."""
+    current = None
+
+    def __init__(self, floats, device):
+        self.buf = torch.zeros(int(floats), dtype=F32, device=device)
+        self.used = 0
+
+    def __enter__(self):
+        self.prev, stats_arena.current = stats_arena.current, self
+        return self
+
+    def __exit__(self, *exc):
+        stats_arena.current = self.prev
+        return False
+
+    @staticmethod
+    def take(shape, device):
+        """-> (buffer, prezeroed)"""
+        n = 1
+        for d in shape:
+            n *= d
+        ar = stats_arena.current
+        if ar is not None and ar.buf.device == device and ar.used + n <= ar.buf.numel():
+            out = ar.buf[ar.used:ar.used + n].view(shape)
+            ar.used += (n + 63) // 64 * 64
+            return out, True
+        return torch.empty(shape, dtype=F32, device=device), False
+
+
 class ConvStats:
     """Batch-norm statistics a conv epilogue accumulated for the layer that consumes its output (gank_conv2d_fprop_stats):
     sums [groups][STAT_SLOTS][2][C]: partial sums of (y - shift) and its square per tower; `shift` = the conv's bias (or None)."""
@@ -125,11 +157,11 @@ def conv2d_fprop(x, wf, bias, out_hw, cout, ksize, flags=0, scale=1.0, residual=
     if getattr(wf, "_frag", False):
         flags |= W_FRAG
     if stats_groups:
-        sums = torch.empty((stats_groups, _lib.STAT_SLOTS, 2, cout), dtype=F32, device=x.device)
+        sums, pre = stats_arena.take((stats_groups, _lib.STAT_SLOTS, 2, cout), x.device)
         produced = C.c_int(0)
         _lib.check(lib().gank_conv2d_fprop_stats(_p(x, BF16, "x"), _p(wf, BF16, "wf"), _p(bias, F32, "bias"),
                                                  _p(residual, BF16, "residual"), _p(relu_ref, BF16, "relu_ref"), _p(y),
-                                                 n, h, w, cin, cout, ksize, flags, scale, _p(sums), stats_groups, C.byref(produced),
+                                                 n, h, w, cin, cout, ksize, flags | (STATS_PREZEROED if pre else 0), scale, _p(sums), stats_groups, C.byref(produced),
                                                  _stream()), "conv2d_fprop_stats")
         return y, (ConvStats(sums, bias, stats_groups) if produced.value else None)
     _lib.check(lib().gank_conv2d_fprop(_p(x, BF16, "x"), _p(wf, BF16, "wf"), _p(bias, F32, "bias"),
@@ -195,10 +227,10 @@ def upconv3x3_fprop(x, wph, bias, cout, flags=0, residual=None, stats_groups=0):
     n, hl, wl, cin = x.shape
     y = torch.empty((n, 2 * hl, 2 * wl, cout), dtype=BF16, device=x.device)
     if stats_groups:
-        sums = torch.empty((stats_groups, _lib.STAT_SLOTS, 2, cout), dtype=F32, device=x.device)
+        sums, pre = stats_arena.take((stats_groups, _lib.STAT_SLOTS, 2, cout), x.device)
         produced = C.c_int(0)
         _lib.check(lib().gank_upconv3x3_fprop_stats(_p(x, BF16, "x"), _p(wph, BF16), _p(bias, F32, "bias"), _p(residual, BF16, "residual"),
-                                                    _p(y), n, hl, wl, cin, cout, flags, _p(sums), stats_groups, C.byref(produced), _stream()),
+                                                    _p(y), n, hl, wl, cin, cout, flags | (STATS_PREZEROED if pre else 0), _p(sums), stats_groups, C.byref(produced), _stream()),
                    "upconv3x3_fprop_stats")
         return y, (ConvStats(sums, bias, stats_groups) if produced.value else None)
     _lib.check(lib().gank_upconv3x3_fprop(_p(x, BF16, "x"), _p(wph, BF16), _p(bias, F32, "bias"), _p(residual, BF16, "residual"),

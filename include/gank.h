@@ -36,6 +36,7 @@ extern "C" {
 #define GANK_DY_UPSAMPLE2X 8   /* wgrad only: dy is [N,H/2,W/2,Cout] (gradient of a 2x2 mean pool)    */
 #define GANK_W_FRAG 32         /* fprop/dgrad: the operand buffer carries the fragment-major copy (prep kind 3) */
 #define GANK_STAT_SLOTS 16     /* copies of each tower's statistics sums the conv epilogues spread their atomics over */
+#define GANK_STATS_PREZEROED 256 /* *_fprop_stats: stat_sums was cleared by the caller (one fill for all layers of a pass) */
 #define GANK_RES_UPSAMPLE2X 64 /* fprop: residual is [N,H/2,W/2,Cout] and is added nearest-neighbour upsampled: the
                                   shortcut of an 'up' residual block (gan_cifar_resnet.py:179-182,209) without
                                   materialising the upsampled tensor */

@@ -1019,12 +1019,13 @@ def test_convpool3x3_resident_kernels(K, n, hp, wp, cin, relu):
     assert relerr(y, y_ig.double().cpu().numpy()) < 1e-2 and relerr(dx, dx_ig.double().cpu().numpy()) < 1e-2
 
 
-@pytest.mark.parametrize("form,n,h,groups", [("plain", 64, 32, 4), ("up", 64, 16, 2), ("plain", 8, 8, 2)])
+@pytest.mark.parametrize("form,n,h,groups", [("plain", 64, 32, 4), ("up", 64, 16, 2), ("plain", 8, 8, 2), ("up", 8, 4, 2), ("plain", 128, 8, 2),
+                                             ("up", 128, 8, 2), ("plain", 320, 8, 10), ("up", 320, 4, 10)])
 def test_conv_epilogue_statistics_feed_cond_batchnorm(K, form, n, h, groups):
     """gank_conv2d_fprop_stats / gank_upconv3x3_fprop_stats + gank_cbn_fwd_from_sums: the batch-norm statistics of a conv
-    output from the conv's own epilogue (two-group kernel: `produced` = 1) equal the moments of the stored tensor, and the
-    conditional batch norm fed by them equals the three-pass one (mean / invstd <= 1e-3 relative: the epilogue sums the
-    fp32 values before their bf16 rounding); small shapes run another kernel and report produced = 0."""
+    output from the conv's own epilogue (the two-group kernel at the large shapes, the generic implicit-GEMM kernel at the
+    small ones and in its phase form) equal the moments of the stored tensor, and the conditional batch norm fed by them
+    equals the three-pass one (mean / invstd <= 1e-3 relative: the epilogue sums the fp32 values before their bf16 rounding)."""
     rng = np.random.default_rng(n + h + groups)
     cin = cout = 256
     x, xt = bf(rng.normal(size=(n, h, h, cin)))
@@ -1042,21 +1043,19 @@ def test_conv_epilogue_statistics_feed_cond_batchnorm(K, form, n, h, groups):
         y0 = K.upconv3x3_fprop(xt, wph, bt, cout)
     torch.cuda.synchronize()
     assert torch.equal(y, y0)                                       # the statistics do not touch the output
-    if n * h * h < 224 * 256 // (4 if form == "up" else 1):
-        assert cs is None                                           # fewer than a round of blocks: not the two-group kernel
-        return
     assert cs is not None and cs.groups == groups
     yd = y.double().cpu().numpy().reshape(groups, -1, cout)
     M = yd.shape[1]
     tot = cs.sums.double().sum(dim=1).cpu().numpy()               # add the partial copies
     mean = tot[:, 0] / M + b
     var = tot[:, 1] / M - (tot[:, 0] / M) ** 2
-    assert np.abs(mean - yd.mean(1)).max() < 1e-3 * np.abs(yd).max() and np.abs(var / yd.var(1) - 1).max() < 2e-3
+    # (few samples per tower: the bf16 rounding of the stored tensor no longer averages out of its variance)
+    assert np.abs(mean - yd.mean(1)).max() < 1e-3 * np.abs(yd).max() and np.abs(var / yd.var(1) - 1).max() < (2e-3 if M >= 16384 else 8e-3)
     labels = torch.tensor(rng.integers(0, 10, n), dtype=torch.int32).cuda()
     gamma = torch.tensor(rng.normal(size=(10, cout)) * 0.2 + 1, dtype=torch.float32).cuda()
     beta = torch.tensor(rng.normal(size=(10, cout)) * 0.2, dtype=torch.float32).cuda()
     z1, s1 = K.cbn_fwd_from_sums(y, labels, gamma, beta, cs, relu=True)
     z0, s0 = K.cbn_fwd(y, labels, gamma, beta, groups, True)
     torch.cuda.synchronize()
-    assert relerr(s1[:, 0], s0[:, 0].double().cpu().numpy()) < 1e-3 and relerr(s1[:, 1], s0[:, 1].double().cpu().numpy()) < 2e-3
+    assert relerr(s1[:, 0], s0[:, 0].double().cpu().numpy()) < 1e-3 and relerr(s1[:, 1], s0[:, 1].double().cpu().numpy()) < (2e-3 if M >= 16384 else 4e-3)
     assert relerr(z1, z0.double().cpu().numpy()) < BF_TOL

@@ -152,6 +152,11 @@ def test_d_and_g_gradients_vs_oracle(gpu):
 def test_train_steps_eager_vs_graph_and_oracle_update(gpu):
     """Same seeds, same feed: hipGraph replay must reproduce the eager steps (bit-for-bit except the
     fp32 atomics of wgrad), and one D update must move the parameters like the oracle's TF-Adam."""
+    from gan_lib_tensorflow_amd import functional as Fn
+    # the batch-norm statistics of this part come from the deterministic three-pass kernels: sums accumulated by conv
+    # epilogues (fp32 atomics, arrival order) make the FAKES differ in their last bf16 bit from run to run, and this
+    # comparison isolates what graph replay itself changes
+    stats_were, Fn.CONV_EPILOGUE_STATS = Fn.CONV_EPILOGUE_STATS, False
     S, tr_e, state = make_trainer(11, 8, use_graphs=False)
     feed_e = S.synthetic_batches(8, "cuda", seed=1)
     _, tr_g, _ = make_trainer(11, 8, use_graphs=True)
@@ -169,6 +174,9 @@ def test_train_steps_eager_vs_graph_and_oracle_update(gpu):
     d = (a - b).abs()
     assert (d > 2e-5).float().mean().item() < 5e-3 and d.mean().item() < 2e-6, ((d > 2e-5).float().mean().item(), d.mean().item())
     assert abs(float(tr_e.d_loss) - float(tr_g.d_loss)) < 1e-4
+    Fn.CONV_EPILOGUE_STATS = stats_were
+    tr_e._graphs.clear()
+    tr_g._graphs.clear()
     # then full iterations.  TF-Adam with beta1=0 moves a weight by ~lr*sign(g) on its first step, so an
     # atomics-order flip of a ~0 gradient is a 2*lr jump and bf16 rounding boundaries amplify it from
     # there (two EAGER runs diverge the same way): later steps are compared statistically.
@@ -275,8 +283,13 @@ def test_unconditional_generator_uses_batch_norm(gpu):
     z = torch.randn(8, 128, generator=g).to(torch.bfloat16).cuda()
     labels = torch.randint(0, 10, (8,), generator=g, dtype=torch.int32).cuda()
     imgs = {}
+    from gan_lib_tensorflow_amd import functional as Fn
+    stats_were = Fn.CONV_EPILOGUE_STATS
     for cond in (True, False):
         blocks.CONDITIONAL = cond
+        # both paths on the three-pass statistics kernels: the bit-for-bit comparison below is about the routing, and
+        # statistics accumulated by conv epilogues (conditional path only) round differently in their last bit
+        Fn.CONV_EPILOGUE_STATS = False
         try:
             store = set_default_store(ParamStore("cuda", seed=7))
             z_in = z.clone().requires_grad_(not cond)
@@ -293,6 +306,7 @@ def test_unconditional_generator_uses_batch_norm(gpu):
                 assert float(store.vars['Generator/G.OutputNorm/BatchNorm/moving_mean/local_step']) == 2.0    # two towers
         finally:
             blocks.CONDITIONAL = True
+            Fn.CONV_EPILOGUE_STATS = stats_were
     assert torch.equal(imgs[True], imgs[False])
 
 
@@ -524,6 +538,12 @@ def test_bucketed_generator_update_through_rccl_matches_the_one_piece_update(gpu
     s.close()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # the segmented backward pass produces the gradient buffer of the one-piece pass (same kernels, same order per tensor)
+    # (batch-norm statistics from the three-pass kernels here: sums accumulated by conv epilogues arrive in a different
+    # order on every run, and the generator gradient -- ill-conditioned under bf16, see test_d_and_g_gradients_vs_oracle --
+    # then differs by 2-5 % between two runs of the SAME pass (scratch/g_repro.py), which would hide a segmentation error;
+    # kept off for the trajectory comparison below as well, whose bounds were set on atomics-order noise of the backward pass alone)
+    from gan_lib_tensorflow_amd import functional as Fn
+    stats_were, Fn.CONV_EPILOGUE_STATS = Fn.CONV_EPILOGUE_STATS, False
     tr = S.SNGANTrainer(batch_size=8, seed=17, use_graphs=False)
     rng0 = tr.rng_state.clone()
     tr._g_forward_backward()
@@ -568,6 +588,7 @@ def test_bucketed_generator_update_through_rccl_matches_the_one_piece_update(gpu
                 assert torch.isfinite(a).all() and d.max().item() < 40 * 2e-4 and d.mean().item() < 2e-4, (name, d.max().item(), d.mean().item())
             assert abs(got[2] - ref[2]) < 0.5
     finally:
+        Fn.CONV_EPILOGUE_STATS = stats_were
         dist.destroy_process_group()
 
 
