@@ -620,7 +620,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_packed_kernel(WgradArgs a) {
     w_c[j] = (w0 + cc * 8 < Cw) ? (w0 + cc * 8) * 2 : OOB;
     w_lds[j] = (cc >> 2) * SUBS + p * 32 + (cc & 3) * 8;
   }
-  const bool do_bias = PACK_X && a.dbias != nullptr && tw == 0;   // (!PACK_X: the host adds a column-sum launch)
+  const bool do_bias = PACK_X && a.dbias != nullptr;   // every wide-channel tile sums its own 128 columns of dy (!PACK_X: the host adds a column-sum launch)
   float bw[4][8];
 #pragma unroll
   for (int j = 0; j < 4; j++)

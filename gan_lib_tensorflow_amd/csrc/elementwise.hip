@@ -524,7 +524,8 @@ extern "C" int gank_colsum_bf16(const void* x, float* out, long rows, int C, flo
     blocks = (rows + rpb - 1) / rpb;
     hipLaunchKernelGGL(colsum_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16*)x, out, rows, C, scale, rpb);
   } else if (C <= 8) {
-    hipLaunchKernelGGL(colsum_small_kernel<8>, grid1d(rows, 256, 512), dim3(256), 0, s, (const bf16*)x, out, rows, C, scale);
+    // 64 blocks: every block ends in C same-address atomics, which serialise (512 blocks: 15 of the kernel's 22 us)
+    hipLaunchKernelGGL(colsum_small_kernel<8>, grid1d(rows, 256, 64), dim3(256), 0, s, (const bf16*)x, out, rows, C, scale);
   } else {
     hipLaunchKernelGGL(colsum_generic_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, (const bf16*)x, out, rows, C, scale);
   }

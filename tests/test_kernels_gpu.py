@@ -141,6 +141,7 @@ def test_conv_dgrad(K, n, h, cin, cout, k, mode):
     (2, 8, 64, 128, 3, "pool"), (64, 16, 256, 256, 3, ""),
     (2, 8, 3, 128, 3, ""), (2, 8, 3, 128, 1, ""), (2, 8, 256, 3, 3, ""),
     (6, 1, 300, 128, 1, ""), (9, 1, 128, 1, 1, ""), (3, 6, 64, 96, 3, ""),
+    (2, 8, 3, 512, 1, ""), (2, 8, 3, 256, 3, ""),            # narrow input, several 128-channel tiles (PGGAN fromRGB): every tile owns its bias columns
 ])
 def test_conv_wgrad(K, n, h, cin, cout, k, mode):
     rng = np.random.default_rng(n * 31 + cin + cout + k)

@@ -352,3 +352,29 @@ def test_acgan_restatement_known_answers():
     conv = lambda k, ci, co: k * k * ci * co + co      # noqa: E731
     assert dcount == conv(1, 3, 128) + conv(3, 3, 128) + conv(3, 128, 128) + conv(1, 128, 128) + 6 * conv(3, 128, 128) + 6 * 2 * 128 + 129 + 1290
     assert T.is_state('d_net/D.NoneBlock.3.N1/BatchNorm/moving_mean/local_step') and not T.is_state('d_net/D.NoneBlock.3.N1/BatchNorm/gamma')
+
+
+def test_pggan_oracle_pieces():
+    """oracle/ref_pggan.py: the minibatch-std statistic against plain NumPy, the TF-1.5 bilinear resize on known values, and
+    shapes / variable names of the restated networks at three stages of the progression."""
+    from oracle import ref_pggan as G
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(5, 4, 4, 7))
+    assert np.allclose(G.minibatch_std(torch.tensor(x)).numpy(), G.minibatch_std_numpy(x))
+    assert np.allclose(G.minibatch_std_numpy(np.ones((3, 2, 2, 4)))[..., -1], 1e-4)            # zero variance: sqrt(1e-8)
+    r = G.resize_bilinear(np.arange(16.).reshape(1, 4, 4, 1), (8, 8))[0, :, :, 0]
+    assert r[0, 1] == 0.5 and r[1, 0] == 2.0 and r[2, 2] == 5.0 and r[7, 7] == 15.0
+    assert np.array_equal(G.resize_bilinear(np.arange(64.).reshape(1, 8, 8, 1), (4, 4))[0, :, :, 0], np.arange(64.).reshape(8, 8)[::2, ::2])
+    y = torch.tensor(rng.normal(size=(2, 3, 3, 6)))
+    assert torch.allclose((G.pixel_norm(y) ** 2).mean(dim=3), torch.ones(2, 3, 3, dtype=torch.float64), atol=1e-6)
+    assert [G.get_dim(i) for i in range(7)] == [512, 512, 512, 256, 128, 64, 32]
+    for bc, trans in ((0, False), (1, True), (2, False)):
+        P = T.to_torch(G.init_params(1, bc, trans, z_dim=32))
+        z = torch.tensor(rng.normal(size=(3, 32)))
+        img = G.generator(P, z, 0.25, bc, trans)
+        assert img.shape == (3, 4 * 2 ** bc, 4 * 2 ** bc, 3)
+        lg, nu = G.discriminator(P, img, 0.25, bc, trans, update_u=True)
+        assert lg.shape == (3,) and len(nu) == sum(1 for k in P if k.endswith('spectral_norm/u'))
+        if trans:      # alpha = 0: only the skip path (toRGB2 of the upsampled features); alpha = 1: only the new block
+            a0, a1 = G.generator(P, z, 0.0, bc, trans), G.generator(P, z, 1.0, bc, trans)
+            assert torch.allclose(img, 0.75 * a0 + 0.25 * a1, atol=1e-9)
