@@ -52,6 +52,9 @@ PROTOTYPES = {
     "gank_convpool3x3_dgrad": [P, P, P, P, I, I, I, I, I, P],
     "gank_convpool3x3_wgrad": [P, P, P, P, P, L, I, I, I, I, I, I, P],
     "gank_convpool3x3_wgrad_ws_elems": [I, I, I, I, I],
+    "gank_conv2d_general_fprop": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
+    "gank_conv2d_general_dgrad": [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
+    "gank_conv2d_general_wgrad": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     "gank_res8_chain_fwd": [P, P, P, P, P, P, I, I, I, P],
     "gank_res8_chain_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, P],
     "gank_cpool_res_fprop": [P, P, P, P, P, I, I, I, I, I, I, P],

@@ -1556,6 +1556,41 @@ extern "C" int gank_conv2d_dgrad(const void* dy, const void* wd, const void* res
 }
 
 
+// ---- general convolution: any filter size <= 7 (even sizes too), stride 1 or 2, explicit leading pad, input and output
+// sizes given separately -- TF SAME with an even filter (pad_before = (k-1)/2 ... the surplus goes after), explicit tf.pad +
+// VALID, and the 1x1 -> 1x1 bottom of a U-Net are all the same gather with out-of-image taps read as zeros.  Runs on the
+// generic implicit-GEMM kernel (Pix2Pix/networks.py:366-470: 4x4 stride-2 encoders, 4x4 stride-1 decoders on NN-upsampled
+// inputs, the PatchGAN critic's padded VALID convs).  flags: GANK_IN_RELU, GANK_IN_UPSAMPLE2X (stride 1; Hin, Win are the
+// STORED input sizes), GANK_OUT_TANH.
+extern "C" int gank_conv2d_general_fprop(const void* x, const void* wf, const float* bias, void* y, int N, int Hin, int Win,
+                                         int Hout, int Wout, int Cin, int Cout, int ksize, int stride, int pad, int flags, void* stream) {
+  GANK_REQUIRE(stride == 1 || stride == 2, "conv2d_general_fprop: stride %d (1 or 2)", stride);
+  GANK_REQUIRE(pad >= 0 && pad < ksize, "conv2d_general_fprop: pad %d outside [0, ksize)", pad);
+  GANK_REQUIRE(!((flags & GANK_IN_UPSAMPLE2X) && stride == 2), "conv2d_general_fprop: upsampled input with stride 2");
+  GANK_REQUIRE(Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "conv2d_general_fprop: bad sizes");
+  IgemmArgs a{};
+  a.x = (const bf16*)x; a.w = (const bf16*)wf; a.bias = bias; a.y = (bf16*)y;
+  a.N = N; a.H = Hout; a.W = Wout; a.Hin = Hin; a.Win = Win;
+  a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.pad = pad;
+  a.flags = (flags & (GANK_IN_UPSAMPLE2X | GANK_IN_RELU | GANK_OUT_TANH)) | (stride == 2 ? IG_IN_STRIDE2 : 0);
+  a.scale = 1.f;
+  return gank_igemm_dispatch(a, (hipStream_t)stream);
+}
+// input gradient of the stride-1 form: the same engine on dy with the flipped operand (wd of gank_conv2d_prep_weights) and
+// the complementary pad.  dx [N,Hx,Wx,Cin] (for an upsampled-input conv: the gradient at the UPSAMPLED size -- the caller
+// sums 2x2), relu_ref (optional, like dx) masks the result.  The stride-2 input gradient is the transposed conv:
+// gank_deconv2d_prep_phases + gank_upconv3x3_fprop on the same filter memory.
+extern "C" int gank_conv2d_general_dgrad(const void* dy, const void* wd, const void* relu_ref, void* dx, int N, int Hx, int Wx,
+                                         int Hdy, int Wdy, int Cin, int Cout, int ksize, int pad, void* stream) {
+  GANK_REQUIRE(pad >= 0 && pad < ksize, "conv2d_general_dgrad: pad %d outside [0, ksize)", pad);
+  IgemmArgs a{};
+  a.x = (const bf16*)dy; a.w = (const bf16*)wd; a.mask = (const bf16*)relu_ref; a.y = (bf16*)dx;
+  a.N = N; a.H = Hx; a.W = Wx; a.Hin = Hdy; a.Win = Wdy;
+  a.Cin = Cout; a.Cout = Cin; a.ks = ksize; a.pad = ksize - 1 - pad;
+  a.scale = 1.f;
+  return gank_igemm_dispatch(a, (hipStream_t)stream);
+}
+
 // NN-upsample(2x) + 3x3 SAME conv == stride-2 transposed conv with a 4x4 kernel: computed as 4 output phases
 // of 2x2 taps over the low-res input (2.25x fewer MACs than 9 taps at high resolution).  wph comes from
 // gank_upconv3x3_prep_weights.  Epilogue as gank_conv2d_fprop (bias, residual at OUTPUT resolution, tanh).

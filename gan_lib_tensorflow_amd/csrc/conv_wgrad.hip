@@ -1307,7 +1307,9 @@ int gank_wgrad_dispatch(WgradArgs a, hipStream_t s) {
   const bool fast = (a.Cin % 8 == 0) && (a.Cout % 8 == 0);
   gank_prof_begin(1, flops, s, 2.0 * ((double)a.N * a.Hx * a.Wx * a.Cin + (double)a.N * a.Hdy * a.Wdy * a.Cout) + 4.0 * a.taps * a.Cin * a.Cout);
   int rc = -1;
-  const bool lean = fast && a.sw >= 0 && a.shw >= 0 && (a.M % 64 == 0) &&
+  const bool same_grid = (a.flags & (WG_X_STRIDE2 | GANK_IN_UPSAMPLE2X)) || (a.Hx == a.H && a.Wx == a.W);    // the lean kernel's plain gather assumes x on dy's grid
+  const bool dy_grid = (a.flags & GANK_DY_UPSAMPLE2X) || (a.Hdy == a.H && a.Wdy == a.W);
+  const bool lean = fast && same_grid && dy_grid && a.sw >= 0 && a.shw >= 0 && (a.M % 64 == 0) &&
                     (long)a.N * a.Hx * a.Wx * a.Cin < (1L << 30) && (long)a.N * a.Hdy * a.Wdy * a.Cout < (1L << 30);
   static int taps_env = -1;   // experiment knob: GANK_WGRAD_TAPS=0 disables the all-taps kernel
   if (taps_env < 0) { const char* e = getenv("GANK_WGRAD_TAPS"); taps_env = e ? atoi(e) : 1; }
@@ -1322,7 +1324,8 @@ int gank_wgrad_dispatch(WgradArgs a, hipStream_t s) {
     else if (a.Cin >= 64 && a.Cout >= 64) rc = launch_wgrad_lean<2, 2, 1, 1, 2>(a, s);
   }
   // narrow operands: pack (tap, channel) into <= 32 MFMA columns so the wide operand streams once
-  const bool plain = (a.flags == 0) && (long)a.M * (a.Cin > a.Cout ? a.Cin : a.Cout) < (1L << 30);
+  const bool plain = (a.flags == 0) && a.Hx == a.H && a.Wx == a.W && a.Hdy == a.H && a.Wdy == a.W &&      // the packed kernels walk x and dy on one grid
+                     (long)a.M * (a.Cin > a.Cout ? a.Cin : a.Cout) < (1L << 30);
   if (rc < 0 && plain && a.Cin <= 4 && a.taps * a.Cin <= 32 && a.Cout % 8 == 0) rc = launch_wgrad_packed<true>(a, s);
   if (rc < 0 && plain && a.Cout <= 4 && a.taps * a.Cout <= 32 && a.Cin % 8 == 0) {
     rc = launch_wgrad_packed<false>(a, s);
@@ -1369,6 +1372,22 @@ extern "C" int gank_conv2d_wgrad(const void* x, const void* dy, float* dw, float
   a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.pad = (ksize - 1) / 2;
   a.flags = flags & (GANK_IN_UPSAMPLE2X | GANK_IN_RELU | GANK_DY_UPSAMPLE2X);
   a.scale = scale;
+  return gank_wgrad_dispatch(a, (hipStream_t)stream);
+}
+
+// filter gradient of the general convolution (gank_conv2d_general_fprop): x [N,Hx,Wx,Cin] as stored, dy [N,Hdy,Wdy,Cout];
+// flags GANK_IN_RELU, GANK_IN_UPSAMPLE2X; ACCUMULATES into dw fp32 [k,k,Cin,Cout] (and dbias)
+extern "C" int gank_conv2d_general_wgrad(const void* x, const void* dy, float* dw, float* dbias, int N, int Hx, int Wx, int Hdy, int Wdy,
+                                         int Cin, int Cout, int ksize, int stride, int pad, int flags, void* stream) {
+  GANK_REQUIRE(stride == 1 || stride == 2, "conv2d_general_wgrad: stride %d (1 or 2)", stride);
+  GANK_REQUIRE(pad >= 0 && pad < ksize, "conv2d_general_wgrad: pad %d outside [0, ksize)", pad);
+  GANK_REQUIRE(!((flags & GANK_IN_UPSAMPLE2X) && stride == 2), "conv2d_general_wgrad: upsampled input with stride 2");
+  WgradArgs a{};
+  a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.dw = dw; a.dbias = dbias;
+  a.N = N; a.H = Hdy; a.W = Wdy; a.Hx = Hx; a.Wx = Wx; a.Hdy = Hdy; a.Wdy = Wdy;
+  a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.pad = pad;
+  a.flags = (flags & (GANK_IN_UPSAMPLE2X | GANK_IN_RELU)) | (stride == 2 ? WG_X_STRIDE2 : 0);
+  a.scale = 1.f;
   return gank_wgrad_dispatch(a, (hipStream_t)stream);
 }
 

@@ -269,6 +269,66 @@ class _Conv2d(Function):
         return dx, dW, db, dres, None, None, None, None, None
 
 
+class _ConvGeneral(Function):
+    """Convolution with any filter size (even ones too), stride 1 or 2 and an explicit leading pad -- the 4x4 convs of the
+    Pix2Pix U-Net and PatchGAN critic (Pix2Pix/networks.py:366-536).  `pad` rows / columns of zeros in front; the output
+    size says how far the window runs past the other edge (TF SAME and tf.pad + VALID are both this)."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, stride, pad, out_hw, upsample, in_relu, out_tanh):
+        k, cin, cout = W.shape[0], W.shape[2], W.shape[3]
+        assert x.dim() == 4 and x.shape[3] == cin, (tuple(x.shape), tuple(W.shape))
+        wf, _ = _prepared(W, k, cin, cout, True, False)
+        flags = (K.IN_UPSAMPLE2X if upsample else 0) | (K.IN_RELU if in_relu else 0) | (K.OUT_TANH if out_tanh else 0)
+        y = K.conv2d_general_fprop(x, wf, bias.detach() if bias is not None else None, out_hw, cout, k, stride, pad, flags)
+        ctx.save_for_backward(x, W, y if out_tanh else None)
+        ctx.cfg = (k, cin, cout, stride, pad, upsample, in_relu, out_tanh, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, y = ctx.saved_tensors
+        k, cin, cout, stride, pad, upsample, in_relu, out_tanh, bias = ctx.cfg
+        g = _c(dy)
+        if out_tanh:
+            g = K.tanh_bwd(g, y)
+        dW = db = dx = None
+        btgt = None
+        if bias is not None and ctx.needs_input_grad[2]:
+            btgt, bacc = _target(bias)
+            db = None if bacc else btgt
+        if ctx.needs_input_grad[1]:
+            tgt, acc = _target(W)
+            K.conv2d_general_wgrad(x, g, tgt, k, stride, pad, (K.IN_UPSAMPLE2X if upsample else 0) | (K.IN_RELU if in_relu else 0), dbias=btgt)
+            dW = None if acc else tgt
+        elif btgt is not None:
+            K.colsum(g, btgt, 1.0)
+        if ctx.needs_input_grad[0]:
+            n, h, w, _ = x.shape
+            if stride == 1:
+                _, wd = _prepared(W, k, cin, cout, False, True)
+                if upsample:
+                    dx = K.pool2x2(K.conv2d_general_dgrad(g, wd, (2 * h, 2 * w), cin, k, pad), 1.0)       # gradient of the NN-upsample: 2x2 sum
+                    if in_relu:
+                        dx = K.relu_bwd(dx, x)
+                else:
+                    dx = K.conv2d_general_dgrad(g, wd, (h, w), cin, k, pad, x if in_relu else None)
+            else:
+                # transposed conv by output phase: the filter memory [k,k,Cin,Cout] IS the transposed conv's filter [k,k,Cout',Cin']
+                if not (k in (3, 4) and cout % 64 == 0 and pad == (max(k - 2, 0)) // 2):
+                    raise NotImplementedError(f"stride-2 input gradient needs a 3x3 / 4x4 filter, its SAME pad and Cout % 64 == 0 (k={k}, pad={pad}, Cout={cout})")
+                dx = K.upconv3x3_fprop(g, K.deconv2d_prep_phases(W.detach().view(k, k, cin, cout)), None, cin)
+                if dx.shape[1] != h or dx.shape[2] != w:
+                    dx = dx[:, :h, :w, :].contiguous()            # an odd input size (the 1x1 bottom of a U-Net)
+                if in_relu:
+                    dx = K.relu_bwd(dx, x)
+        return dx, dW, db, None, None, None, None, None, None
+
+
+def conv2d_general(x, W, bias=None, stride=1, pad=0, out_hw=None, upsample=False, in_relu=False, out_tanh=False):
+    return _ConvGeneral.apply(x, W, bias, int(stride), int(pad), (int(out_hw[0]), int(out_hw[1])), upsample, in_relu, out_tanh)
+
+
 import os as _os
 CONV_EPILOGUE_STATS = _os.environ.get("GANK_EPILOGUE_STATS", "1") == "1"     # batch-norm statistics of a conv's output from its own epilogue (two-group kernel), where asked for
 

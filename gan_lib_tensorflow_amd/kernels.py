@@ -208,6 +208,34 @@ def conv2d_wgrad_batched(items, hw, ksize, flags=0, scale=1.0):
                "conv2d_wgrad_batched")
 
 
+def conv2d_general_fprop(x, wf, bias, out_hw, cout, ksize, stride, pad, flags=0):
+    """any filter size / stride 1|2 / leading pad (gank_conv2d_general_fprop); x as stored [N,Hin,Win,Cin]"""
+    n, hin, win, cin = x.shape
+    y = torch.empty((n, out_hw[0], out_hw[1], cout), dtype=BF16, device=x.device)
+    _lib.check(lib().gank_conv2d_general_fprop(_p(x, BF16, "x"), _p(wf, BF16, "wf"), _p(bias, F32, "bias"), _p(y), n, hin, win,
+                                               out_hw[0], out_hw[1], cin, cout, ksize, stride, pad, flags, _stream()), "conv2d_general_fprop")
+    return y
+
+
+def conv2d_general_dgrad(dy, wd, x_hw, cin, ksize, pad, relu_ref=None):
+    """stride-1 input gradient at size x_hw (the gathered size: 2x the stored one for an upsampled-input conv)"""
+    n, hdy, wdy, cout = dy.shape
+    dx = torch.empty((n, x_hw[0], x_hw[1], cin), dtype=BF16, device=dy.device)
+    _lib.check(lib().gank_conv2d_general_dgrad(_p(dy, BF16, "dy"), _p(wd, BF16, "wd"), _p(relu_ref, BF16, "relu_ref"), _p(dx), n, x_hw[0], x_hw[1],
+                                               hdy, wdy, cin, cout, ksize, pad, _stream()), "conv2d_general_dgrad")
+    return dx
+
+
+def conv2d_general_wgrad(x, dy, dw, ksize, stride, pad, flags=0, dbias=None):
+    """ACCUMULATES into dw fp32 [k,k,Cin,Cout] (and dbias)"""
+    n, hx, wx, cin = x.shape
+    _, hdy, wdy, cout = dy.shape
+    assert dw.numel() == ksize * ksize * cin * cout
+    _lib.check(lib().gank_conv2d_general_wgrad(_p(x, BF16, "x"), _p(dy, BF16, "dy"), _p(dw, F32, "dw"), _p(dbias, F32, "dbias"), n, hx, wx, hdy, wdy,
+                                               cin, cout, ksize, stride, pad, flags, _stream()), "conv2d_general_wgrad")
+    return dw
+
+
 def upconv3x3_prep(w):
     """w fp32 [3,3,Cin,Cout] -> (wph, wd4) for the phase-decomposed NN-upsample+3x3 conv; cached on the tensor
     as `w._prep_up` and rewritten IN PLACE on later calls (captured graphs keep reading the same buffers)."""

@@ -191,6 +191,21 @@ long gank_convpool3x3_wgrad_ws_elems(int N, int Hp, int Wp, int Cin, int Cout);
 int gank_convpool3x3_wgrad(const void* x, const void* dy, float* dw, float* dbias, float* ws16, long ws_elems, int N, int Hp, int Wp,
                            int Cin, int Cout, int flags, void* stream);
 
+/* ---- general convolution (Pix2Pix/networks.py:366-536: 4x4 stride-2 SAME encoders, 4x4 stride-1 SAME decoders on
+ * NN-upsampled inputs, tf.pad + VALID 4x4 convs of the PatchGAN critic) -----------------------------------------------
+ * Any ksize <= 7, stride 1 | 2, `pad` = rows/columns of zeros in FRONT (TF SAME: (total pad)/2 rounded down; tf.pad 1 +
+ * VALID: 1); taps past the stored image read zeros, so the trailing pad is implied by the output size.  x [N,Hin,Win,Cin]
+ * as stored, y [N,Hout,Wout,Cout]; wf / wd from gank_conv2d_prep_weights(w [k,k,Cin,Cout]).  flags: GANK_IN_RELU,
+ * GANK_IN_UPSAMPLE2X (stride 1 only), GANK_OUT_TANH (fprop).  dgrad covers stride 1 (dx at the gathered -- upsampled --
+ * size; relu_ref optional mask); the stride-2 input gradient is the transposed conv: gank_deconv2d_prep_phases on the same
+ * filter memory ([k,k,Cin,Cout] read as [k,k,Cout',Cin']) + gank_upconv3x3_fprop.  wgrad ACCUMULATES. */
+int gank_conv2d_general_fprop(const void* x, const void* wf, const float* bias, void* y, int N, int Hin, int Win,
+                              int Hout, int Wout, int Cin, int Cout, int ksize, int stride, int pad, int flags, void* stream);
+int gank_conv2d_general_dgrad(const void* dy, const void* wd, const void* relu_ref, void* dx, int N, int Hx, int Wx,
+                              int Hdy, int Wdy, int Cin, int Cout, int ksize, int pad, void* stream);
+int gank_conv2d_general_wgrad(const void* x, const void* dy, float* dw, float* dbias, int N, int Hx, int Wx, int Hdy, int Wdy,
+                              int Cin, int Cout, int ksize, int stride, int pad, int flags, void* stream);
+
 /* ---- Deconv2D (common/ops/deconv2d.py:99-114): tf.nn.conv2d_transpose stride 2 SAME --------------
  * x [N,H,W,Cin] -> y [N,2H,2W,Cout]; master filter F fp32 [k,k,Cout,Cin].  The op has no caller in
  * the reference; it is provided at op level on the same two MFMA engines:

@@ -378,3 +378,27 @@ def test_pggan_oracle_pieces():
         if trans:      # alpha = 0: only the skip path (toRGB2 of the upsampled features); alpha = 1: only the new block
             a0, a1 = G.generator(P, z, 0.0, bc, trans), G.generator(P, z, 1.0, bc, trans)
             assert torch.allclose(img, 0.75 * a0 + 0.25 * a1, atol=1e-9)
+
+
+def test_pix2pix_oracle_pieces():
+    """oracle/ref_pix2pix.py: tf.nn.conv2d semantics for even filters (SAME puts the surplus pad behind, tf.pad + VALID, the
+    1x1 -> 1x1 stride-2 bottom) against plain loops, instance norm moments, and the variable list of the U-Net / PatchGAN."""
+    from oracle import ref_pix2pix as X
+    rng = np.random.default_rng(0)
+    w = rng.normal(size=(4, 4, 3, 2))
+    for h, stride, padding, pad_in, pad, out in ((5, 2, 'SAME', 0, 1, 3), (6, 2, 'SAME', 0, 1, 3), (1, 2, 'SAME', 0, 1, 1), (5, 1, 'SAME', 0, 1, 5),
+                                                 (5, 1, 'VALID', 1, 1, 4), (6, 2, 'VALID', 1, 1, 3)):
+        x = rng.normal(size=(2, h, h, 3))
+        y = X.conv2d_tf(torch.tensor(x), torch.tensor(w), None, stride, padding, pad_in).numpy()
+        assert y.shape == (2, out, out, 2), (h, stride, padding, y.shape)
+        assert np.allclose(y, X.conv2d_numpy(x, w, None, stride, pad, (out, out)))
+    x = torch.tensor(rng.normal(size=(3, 4, 4, 5)) * 2 + 1)
+    y = X.instance_norm(x, torch.ones(1, 5, dtype=torch.float64), torch.zeros(1, 5, dtype=torch.float64))
+    assert torch.allclose(y.mean(dim=(1, 2)), torch.zeros(3, 5, dtype=torch.float64), atol=1e-9)
+    assert torch.allclose((y ** 2).mean(dim=(1, 2)), torch.ones(3, 5, dtype=torch.float64), atol=1e-4)
+    one = X.instance_norm(x[:, :1, :1], torch.ones(1, 5, dtype=torch.float64), torch.full((1, 5), 0.3, dtype=torch.float64))
+    assert torch.allclose(one, torch.full_like(one, 0.3))                    # a 1x1 map normalises to its offset (the U-Net's bottom)
+    P = X.init_params(0, ngf=8, ndf=8)
+    assert sum(1 for k in P if k.endswith('/Filters')) == 9 + 9 + 6 and sum(1 for k in P if k.endswith('spectral_norm/u')) == 6
+    assert P['g_net/decoder_8/Conv2D/Filters'].shape == (4, 4, 128, 64) and P['g_net/decoder_1/Conv2D/Filters'].shape == (4, 4, 16, 3)
+    assert P['d_net/layer_1/Conv2D/Filters'].shape == (4, 4, 6, 8) and P['d_net/layer_6/Conv2D/Filters'].shape == (4, 4, 64, 1)
