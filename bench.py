@@ -45,6 +45,21 @@ def host_cores():
             allowed = max(1, allowed * phys // logical)
     except Exception:  # noqa: BLE001
         pass
+    # the container's CPU bandwidth quota (cgroup v2 cpu.max / v1 cfs quota): a GPU box shows all 256 logical CPUs of its host
+    # in the affinity mask but may run 16 of them at a time -- 128 threads on that share ran the baseline 4x slower than 16
+    try:
+        quota = None
+        if os.path.exists("/sys/fs/cgroup/cpu.max"):
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            quota = None if q == "max" else float(q) / float(per)
+        elif os.path.exists("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = None if q <= 0 else q / per
+        if quota is not None:
+            allowed = min(allowed, max(1, int(quota)))
+    except Exception:  # noqa: BLE001
+        pass
     return max(1, allowed)
 
 

@@ -128,8 +128,14 @@ def _g_prep_kind(name, W):
     return 0
 
 
-def Discriminator(inputs, labels, update_collection=None, reuse=False):
-    """(:266-313, ACGAN=False)  inputs [n,3072] bf16 (HWC order) -> (logits [n], None)."""
+import os as _os
+FUSED_HEAD = _os.environ.get("GANK_FUSED_HEAD", "1") == "1"      # D.Output + hinge loss (+ the layer's three gradients) as one launch where the train step asks for it
+
+
+def Discriminator(inputs, labels, update_collection=None, reuse=False, loss_head=None):
+    """(:266-313, ACGAN=False)  inputs [n,3072] bf16 (HWC order) -> (logits [n], None).
+    loss_head: a callable (features [n, DIM_D], W_bar [DIM_D, 1], b [1]) -> loss that replaces the last dense layer AND the
+    loss on its logits (functional.hinge_d_head / hinge_g_head): the call then returns (loss, None)."""
     store = get_default_store()
     with store.variable_scope("Discriminator", reuse=reuse):
         prefix = store.full_name('')[:-1]
@@ -159,6 +165,9 @@ def Discriminator(inputs, labels, update_collection=None, reuse=False):
                 output_acgan = _linear.Linear(out_b, DIM_D, 10, 'D.ACGANOutput', spectral_normed=True,
                                               update_collection=update_collection, biases=True)
                 return output_wgan.reshape(-1), output_acgan
+            if loss_head is not None:
+                w_out, b_out = _linear.linear_variables(DIM_D, 1, 'D.Output', spectral_normed=True, update_collection=update_collection)
+                return loss_head(output, w_out, b_out), None
             output_wgan = _linear.Linear(output, DIM_D, 1, 'D.Output', spectral_normed=True,
                                          update_collection=update_collection)
             return output_wgan.reshape(-1), None
@@ -364,8 +373,13 @@ class SNGANTrainer:
             both = torch.cat([real, fake], 0)                          # plumbing: device memcpy
             both_labels = torch.cat([self.real_labels, self.real_labels], 0)
         with _sn.grad_scratch(self.d_flat["scratch"]):        # zeroed by zero_grads above
-            logits, _ = Discriminator(both, both_labels, update_collection=None)
-        loss = Fn.hinge_d_loss(logits, b, out=self.d_loss)
+            if FUSED_HEAD:
+                loss, _ = Discriminator(both, both_labels, update_collection=None,
+                                        loss_head=lambda f, w, bb: Fn.hinge_d_head(f, w, bb, b, out=self.d_loss))
+                logits = loss.logits
+            else:
+                logits, _ = Discriminator(both, both_labels, update_collection=None)
+                loss = Fn.hinge_d_loss(logits, b, out=self.d_loss)
         self._backward(loss)
         return logits
 
@@ -376,8 +390,13 @@ class SNGANTrainer:
         K.critic_feed(self.real_all, self.labels_all, self.fake_all, self.both, self.both_labels, self.feed_slot,
                       self.rng_state, self.feed_done)
         with _sn.grad_scratch(self.d_flat["scratch"]):        # zeroed by zero_grads above
-            logits, _ = Discriminator(self.both, self.both_labels, update_collection=None)
-        loss = Fn.hinge_d_loss(logits, self.batch, out=self.d_loss)
+            if FUSED_HEAD:
+                loss, _ = Discriminator(self.both, self.both_labels, update_collection=None,
+                                        loss_head=lambda f, w, b: Fn.hinge_d_head(f, w, b, self.batch, out=self.d_loss))
+                logits = loss.logits
+            else:
+                logits, _ = Discriminator(self.both, self.both_labels, update_collection=None)
+                loss = Fn.hinge_d_loss(logits, self.batch, out=self.d_loss)
         self._backward(loss)
         return logits
 
@@ -423,8 +442,13 @@ class SNGANTrainer:
         for p in d_params:      # gen_cost is differentiated w.r.t. gen_params only (:523)
             p.requires_grad_(False)
         try:
-            logits, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS)
-            loss = Fn.hinge_g_loss(logits, out=self.g_loss)
+            if FUSED_HEAD:
+                loss, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS,
+                                        loss_head=lambda f, w, b: Fn.hinge_g_head(f, w, b, out=self.g_loss))
+                logits = loss.logits
+            else:
+                logits, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS)
+                loss = Fn.hinge_g_loss(logits, out=self.g_loss)
             self._backward(loss)
         finally:
             for p in d_params:
@@ -464,8 +488,12 @@ class SNGANTrainer:
             for p in d_params:
                 p.requires_grad_(False)
             try:
-                logits, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS)
-                loss = Fn.hinge_g_loss(logits, out=self.g_loss)
+                if FUSED_HEAD:
+                    loss, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS,
+                                            loss_head=lambda f, w, b: Fn.hinge_g_head(f, w, b, out=self.g_loss))
+                else:
+                    logits, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS)
+                    loss = Fn.hinge_g_loss(logits, out=self.g_loss)
             finally:
                 for p in d_params:
                     p.requires_grad_(True)

@@ -93,6 +93,7 @@ PROTOTYPES = {
     "gank_concat_tile_bwd": [P, P, P, I, I, I, I, P],
     "gank_embedding_fwd": [P, P, P, I, I, I, P],
     "gank_embedding_bwd": [P, P, P, I, I, I, P],
+    "gank_critic_head_hinge": [P, P, P, P, P, P, P, P, I, I, I, I, P],
     "gank_hinge_d_loss": [P, P, P, P, I, I, P],
     "gank_hinge_g_loss": [P, P, P, P, I, P],
     "gank_wgan_d_loss": [P, P, P, P, I, I, P],

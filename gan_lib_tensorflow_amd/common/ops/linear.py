@@ -34,10 +34,10 @@ def unset_weights_stdev():
     _weights_stdev = None
 
 
-def Linear(inputs, input_dim, output_dim, name,
-           spectral_normed=False, update_collection=None, reuse=False, inputs_norm=False,
-           biases=True, initialization=None, weightnorm=None, gain=1.):
-    """initialization: None, `lecun`, 'glorot', `he`, 'glorot_he', `("uniform", range)`"""
+def linear_variables(input_dim, output_dim, name, spectral_normed=False, update_collection=None, inputs_norm=False,
+                     biases=True, initialization=None, weightnorm=None, gain=1.):
+    """The variable half of Linear (linear.py:45-177): creates / fetches `<name>/W` (spectrally normalised when asked) and
+    `<name>/b`; returns (weight, biases | None).  Shared by Linear and by fused heads, so both own identical variables."""
     store = get_default_store()
     with store.variable_scope(name):
         if inputs_norm or (weightnorm if weightnorm is not None else _default_weightnorm):
@@ -74,7 +74,15 @@ def Linear(inputs, input_dim, output_dim, name,
         _biases = None
         if biases:
             _biases = store.get_variable('b', [output_dim], np.zeros(output_dim, 'float32'))
+        return weight, _biases
 
-        lead = inputs.shape[:-1]
-        result = Fn.linear(inputs.reshape(-1, input_dim), weight, _biases)
-        return result.reshape(*lead, output_dim)
+
+def Linear(inputs, input_dim, output_dim, name,
+           spectral_normed=False, update_collection=None, reuse=False, inputs_norm=False,
+           biases=True, initialization=None, weightnorm=None, gain=1.):
+    """initialization: None, `lecun`, 'glorot', `he`, 'glorot_he', `("uniform", range)`"""
+    weight, _biases = linear_variables(input_dim, output_dim, name, spectral_normed, update_collection, inputs_norm, biases,
+                                       initialization, weightnorm, gain)
+    lead = inputs.shape[:-1]
+    result = Fn.linear(inputs.reshape(-1, input_dim), weight, _biases)
+    return result.reshape(*lead, output_dim)

@@ -106,6 +106,84 @@ extern "C" int gank_softmax_xent(const void* logits, const int32_t* labels, floa
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Critic head in ONE launch: logits = x w + b (D.Output, gan_cifar_resnet.py:303-304), the hinge loss of them (:379-381 /
+// :492) and everything the backward pass needs from this layer -- d loss / d x, and (w_grad / b_grad given) the weight and
+// bias gradients ACCUMULATED.  Unfused this is four latency-sized launches (linear fwd, loss, linear bwd data, linear bwd
+// weight) in every critic pass.  The arithmetic is that of the unfused path: the logit is rounded to bf16 before the loss
+// reads it, d loss / d logit is rounded to bf16 before the two products.  One block of 1024 threads; M * K is a few
+// thousand multiply-adds.  mode 0: hinge_d (first n_real rows are real), mode 1: hinge_g.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void critic_head_hinge_kernel(const bf16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                                bf16* __restrict__ logits, float* __restrict__ loss, bf16* __restrict__ dx,
+                                                                float* __restrict__ w_grad, float* __restrict__ b_grad, int M, int K, int n_real, int mode) {
+  extern __shared__ float sm[];          // dl[M] | w[K] | red[32]
+  float* s_dl = sm;
+  float* s_w = sm + M;
+  float* red = s_w + K;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+  for (int k = tid; k < K; k += blockDim.x) s_w[k] = w[k];
+  __syncthreads();
+  const float bias = b ? b[0] : 0.f;
+  const int n_fake = M - n_real;
+  float acc = 0.f;
+  for (int m = wv; m < M; m += nw) {                 // one wave per row
+    float t = 0.f;
+    for (int k = lane; k < K; k += 64) t += bf2f(x[(long)m * K + k]) * s_w[k];
+    t = wave_sum(t);
+    if (lane == 0) {
+      const bf16 lg = f2bf(t + bias);
+      logits[m] = lg;
+      const float v = bf2f(lg);
+      float d, l;
+      if (mode == 1) { l = -v / (float)M; d = -1.f / (float)M; }
+      else if (m < n_real) { const float u = 1.f - v; l = fmaxf(u, 0.f) / (float)n_real; d = u > 0.f ? -1.f / (float)n_real : 0.f; }
+      else { const float u = 1.f + v; l = fmaxf(u, 0.f) / (float)n_fake; d = u > 0.f ? 1.f / (float)n_fake : 0.f; }
+      s_dl[m] = bf2f(f2bf(d));
+      acc += l;
+    }
+  }
+  if (lane != 0) acc = 0.f;
+  __syncthreads();
+  // block sum of the per-row loss terms (lanes 0 of every wave hold them)
+  acc = wave_sum(acc);
+  if (lane == 0) red[wv] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int i = 0; i < nw; i++) t += red[i];
+    loss[0] = t;
+  }
+  // d loss / d x = dl[m] * w[k]
+  if (dx)
+    for (long i = tid; i < (long)M * K; i += blockDim.x) {
+      const int m = (int)(i / K), k = (int)(i - (long)m * K);
+      dx[i] = f2bf(s_dl[m] * s_w[k]);
+    }
+  // w_grad[k] += sum_m x[m][k] dl[m]  (thread per k, rows in order: deterministic);  b_grad += sum_m dl[m]
+  if (w_grad)
+    for (int k = tid; k < K; k += blockDim.x) {
+      float t = 0.f;
+      for (int m = 0; m < M; m++) t += bf2f(x[(long)m * K + k]) * s_dl[m];
+      w_grad[k] += t;
+    }
+  if (b_grad && tid == 0) {
+    float t = 0.f;
+    for (int m = 0; m < M; m++) t += s_dl[m];
+    b_grad[0] += t;
+  }
+}
+extern "C" int gank_critic_head_hinge(const void* x, const float* w, const float* b, void* logits, float* loss, void* dx, float* w_grad,
+                                      float* b_grad, int M, int K, int n_real, int mode, void* stream) {
+  GANK_REQUIRE(x && w && logits && loss && M > 0 && K > 0 && (mode == 0 || mode == 1), "critic_head_hinge: bad arguments");
+  GANK_REQUIRE(mode == 1 || (n_real > 0 && n_real < M), "critic_head_hinge: n_real must split the batch");
+  GANK_REQUIRE((size_t)(M + K + 32) * sizeof(float) <= 60000, "critic_head_hinge: M + K too large for one block");
+  hipLaunchKernelGGL(critic_head_hinge_kernel, dim3(1), dim3(1024), (size_t)(M + K + 32) * sizeof(float), (hipStream_t)stream, (const bf16*)x, w, b,
+                     (bf16*)logits, loss, (bf16*)dx, w_grad, b_grad, M, K, n_real, mode);
+  GANK_LAUNCH_OK("critic_head_hinge");
+  return 0;
+}
+
 // d(total)/d(logits) = g[0] * d(loss)/d(logits) for a loss that enters a weighted sum (gen_cost + ACGAN_SCALE_G * xent,
 // gan_cifar_resnet.py:476; ACGAN/train.py:119-121): product in fp32, one rounding to bf16
 __global__ void loss_grad_scale_kernel(const float* __restrict__ dl32, const float* __restrict__ g, bf16* __restrict__ out, long n) {

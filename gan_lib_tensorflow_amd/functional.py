@@ -743,6 +743,51 @@ def unit_seed(loss):
     return s
 
 
+class _HingeHead(Function):
+    """D.Output (a dense layer to one logit) + hinge loss in one launch (kernels.critic_head_hinge).  The weight and bias
+    gradients are accumulated into their targets by the forward launch (a backward pass always follows in the train step);
+    the loss must be differentiated directly (unit upstream gradient) -- a weighted sum goes through linear + hinge_*_loss."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, n_real, mode, out):
+        need_w = ctx.needs_input_grad[1]
+        need_b = bias is not None and ctx.needs_input_grad[2]
+        wt = bt = None
+        ctx.ret = [None, None]
+        if need_w:
+            wt, acc = _target(W)
+            ctx.ret[0] = None if acc else wt
+        if need_b:
+            bt, bacc = _target(bias)
+            ctx.ret[1] = None if bacc else bt
+        buf = out.t if out is not None else None
+        loss, logits, dx = K.critic_head_hinge(_c(x), W.detach().reshape(-1), bias.detach() if bias is not None else None, n_real, mode,
+                                               ctx.needs_input_grad[0], wt.view(-1) if wt is not None else None, bt, buf)
+        ctx.dx = dx
+        _HingeHead.last_logits = logits
+        return loss.detach() if buf is not None else loss
+
+    @staticmethod
+    def backward(ctx, g):
+        if g.data_ptr() not in _unit_seed_ptrs:
+            raise NotImplementedError("the fused critic head differentiates the loss itself (loss.backward(gradient=unit_seed(loss))); "
+                                      "use linear + hinge_*_loss for a weighted sum of losses")
+        return ctx.dx, ctx.ret[0], ctx.ret[1], None, None, None
+
+
+def hinge_d_head(x, W, bias, n_real, out=None):
+    """hinge_d_loss(linear(x, W, bias), n_real) in one launch; the logits ride along as `loss.logits` (bf16 [M], detached)"""
+    loss = _HingeHead.apply(x, W, bias, int(n_real), 0, _Box(out) if out is not None else None)
+    loss.logits, _HingeHead.last_logits = _HingeHead.last_logits, None
+    return loss
+
+
+def hinge_g_head(x, W, bias, out=None):
+    loss = _HingeHead.apply(x, W, bias, 0, 1, _Box(out) if out is not None else None)
+    loss.logits, _HingeHead.last_logits = _HingeHead.last_logits, None
+    return loss
+
+
 class _Box:
     __slots__ = ("t",)
 

@@ -729,6 +729,19 @@ def hinge_g_loss(logits, loss=None):
     return loss, dl, dl32
 
 
+def critic_head_hinge(x, w, b, n_real, mode, want_dx=True, w_grad=None, b_grad=None, loss=None):
+    """fused D.Output + hinge loss (gank_critic_head_hinge) -> (loss fp32[1], logits bf16 [M], dx bf16 [M,K] | None);
+    w_grad / b_grad are ACCUMULATED when given"""
+    m, k = x.shape
+    assert w.numel() == k and (b is None or b.numel() == 1)
+    loss = torch.empty(1, dtype=F32, device=x.device) if loss is None else loss
+    logits = torch.empty(m, dtype=BF16, device=x.device)
+    dx = torch.empty((m, k), dtype=BF16, device=x.device) if want_dx else None
+    _lib.check(lib().gank_critic_head_hinge(_p(x, BF16, "x"), _p(w, F32, "w"), _p(b, F32, "b"), _p(logits), _p(loss), _p(dx), _p(w_grad, F32, "w_grad"),
+                                            _p(b_grad, F32, "b_grad"), m, k, int(n_real), int(mode), _stream()), "critic_head_hinge")
+    return loss, logits, dx
+
+
 def softmax_xent(logits, labels):
     n, classes = logits.shape
     loss = torch.empty(1, dtype=F32, device=logits.device)

@@ -340,6 +340,12 @@ int gank_embedding_bwd(const void* dy, const int32_t* idx, float* dtable, int N,
  * hinge_d: mean(relu(1-l[:n_real])) + mean(relu(1+l[n_real:]))   (gan_cifar_resnet.py:362-363,379-381)
  * hinge_g: -mean(l)                                               (gan_cifar_resnet.py:492)
  * softmax_xent: mean sparse softmax cross-entropy                 (gan_cifar_resnet.py:390-394) */
+/* critic head in one launch: logits [M] = x [M,K] w [K] + b[0] (D.Output, gan_cifar_resnet.py:303-304), their hinge loss
+ * (mode 0: hinge_d with the first n_real rows real, :379-381; mode 1: hinge_g, :492), dx [M,K] = d loss / d x (NULL: skip),
+ * and the layer's weight / bias gradients ACCUMULATED into w_grad [K] / b_grad [1] (NULL: skip).  Same arithmetic as
+ * gank_linear_fwd + gank_hinge_*_loss + gank_linear_bwd (bf16 logits, bf16 d loss / d logits). */
+int gank_critic_head_hinge(const void* x, const float* w, const float* b, void* logits, float* loss, void* dx, float* w_grad,
+                           float* b_grad, int M, int K, int n_real, int mode, void* stream);
 int gank_hinge_d_loss(const void* logits, float* loss, void* dlogits, float* dlogits_f32, int n, int n_real, void* stream);
 int gank_hinge_g_loss(const void* logits, float* loss, void* dlogits, float* dlogits_f32, int n, void* stream);
 /* wgan_d: -mean(l[:n_real]) + mean(l[n_real:])  (common/misc.py:328-331 'WGAN', :337-352 'WGAN-GP' before its penalty) */

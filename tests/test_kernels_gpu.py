@@ -379,6 +379,44 @@ def test_scaled_and_summed_losses_scale_their_gradients(K):
     assert relerr(lt.grad, rdd) < BF_TOL
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_fused_critic_head_equals_linear_plus_hinge(K, mode):
+    """gank_critic_head_hinge: D.Output + hinge loss + the layer's three gradients in one launch == linear_fwd, hinge_*_loss,
+    linear_bwd one after the other (bit-for-bit for the logits, the loss and d loss / d x; weight gradient to fp32 summation
+    order), and matches the oracle."""
+    rng = np.random.default_rng(21 + mode)
+    m, k, n_real = 128, 128, 64
+    x, xt = bf(rng.normal(size=(m, k)))
+    w, wt = f32(rng.normal(size=(k, 1)) * 0.2)
+    b, bt = f32(rng.normal(size=1))
+    gw = torch.full((k,), 0.5, dtype=torch.float32, device="cuda")          # accumulates on top of existing content
+    gb = torch.full((1,), 0.25, dtype=torch.float32, device="cuda")
+    loss, logits, dx = K.critic_head_hinge(xt, wt.view(-1), bt, n_real, mode, True, gw, gb)
+    y = K.linear_fwd(xt, wt, bt)
+    l0, dl, _ = K.hinge_d_loss(y.view(-1), n_real) if mode == 0 else K.hinge_g_loss(y.view(-1))
+    gw0 = torch.zeros((k, 1), dtype=torch.float32, device="cuda")
+    gb0 = torch.zeros(1, dtype=torch.float32, device="cuda")
+    dx0 = K.linear_bwd(dl.view(m, 1), xt, wt, True, gw0, gb0)
+    torch.cuda.synchronize()
+    assert torch.equal(logits, y.view(-1)) and torch.equal(dx, dx0)
+    assert abs(float(loss) - float(l0)) < 1e-6
+    assert relerr(gw - 0.5, gw0.view(-1).double().cpu().numpy()) < 1e-5 and abs(float(gb) - 0.25 - float(gb0)) < 1e-6
+    lg = x @ w[:, 0] + b[0]
+    rl, rd = R.hinge_d_loss(lg, n_real) if mode == 0 else R.hinge_g_loss(lg)
+    assert abs(float(loss) - rl) < 2e-2 * max(1.0, abs(rl))
+    # through autograd, with and without the weight gradients
+    from gan_lib_tensorflow_amd import functional as Fn
+    xg = xt.clone().requires_grad_(True)
+    wg, bg = wt.clone().requires_grad_(True), bt.clone().requires_grad_(True)
+    out = Fn.hinge_d_head(xg, wg, bg, n_real) if mode == 0 else Fn.hinge_g_head(xg, wg, bg)
+    out.backward(gradient=Fn.unit_seed(out))
+    torch.cuda.synchronize()
+    assert torch.equal(out.logits, logits) and torch.equal(xg.grad, dx0)
+    assert relerr(wg.grad, gw0.double().cpu().numpy()) < 1e-5 and relerr(bg.grad, gb0.double().cpu().numpy()) < 1e-5
+    with pytest.raises(NotImplementedError):
+        (0.5 * (Fn.hinge_g_head(xg, wg, bg))).backward()                      # a weighted loss goes through the unfused operators
+
+
 def test_adam_tf_and_lr_decay(K):
     rng = np.random.default_rng(14)
     n = 1003
