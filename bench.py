@@ -63,6 +63,20 @@ def host_cores():
     return max(1, allowed)
 
 
+def traffic_per_launch(tj, tag):
+    """HBM bytes per launch of a launcher tag from a pmc_bench_traffic.sh table.  A tag may name a kernel plus its follow-up
+    launch ("a + b": the parts add) and leaves out trailing template arguments the launcher chooses at run time (the
+    statistics epilogue: `<0, 32>` covers rocprofv3's `<0, 32, true>` and `<0, 32, false>`, weighted by launches)."""
+    per, total = tj.get("per_kernel", {}), 0.0
+    for part in tag.split(" + "):
+        hits = [v for k, v in per.items() if k == part or (part.endswith(">") and k.startswith(part[:-1] + ", ") and k.count(",") == part.count(",") + 1)]
+        if not hits:
+            return None
+        n = sum(v["launches"] for v in hits)
+        total += sum(v["bytes_per_launch"] * v["launches"] for v in hits) / max(n, 1)
+    return total
+
+
 def cpu_baseline(budget_s=40.0):
     """Oracle ("port") leg: torch-CPU fp32 restatement of the reference graph; the timed sample is one whole
     iteration (5 D updates + 1 G update), at batch 64 when that fits budget_s, else at a smaller batch scaled up."""
@@ -220,13 +234,13 @@ def main():
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         # HBM traffic per launch: rocprofv3 PMC passes cannot run inside this process; the committed measurement of
         # scratch/pmc_bench_traffic.sh over this same workload is reported when it covers the dominant kernel
-        traffic, traffic_src = None, None
+        traffic, traffic_src, tj = None, None, None
         import glob
         for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):   # latest round first
             tj = json.load(open(tpath))
-            per = tj.get("per_kernel", {}).get(dom)
-            if per is not None:
-                traffic, traffic_src = round(per["bytes_per_launch"]), f"profiles/{os.path.basename(tpath)} (" + tj["method"] + ")"
+            traffic = traffic_per_launch(tj, dom)
+            if traffic is not None:
+                traffic_src = f"profiles/{os.path.basename(tpath)} (" + tj["method"] + ")"
                 break
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
@@ -241,7 +255,11 @@ def main():
                     "families": {k: {"launches": v[0], "ms": round(v[1], 3),
                                      "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else 0.0} for k, v in fam.items()},
                     "kernels": [{"kernel": t[0], "launches": t[1], "ms": round(t[2], 3),
-                                 "tflops": round(t[3] / (t[2] * 1e-3) / 1e12, 1) if t[2] > 0 else 0.0} for t in kernels[:8]]}
+                                 "tflops": round(t[3] / (t[2] * 1e-3) / 1e12, 1) if t[2] > 0 else 0.0} for t in kernels[:8]],
+                    # every conv kernel of the iteration: measured HBM bytes per launch (the committed PMC passes) over its
+                    # algorithmic bytes (operands read once + result written once, summed by the launchers)
+                    "traffic_ratio": {t[0]: round(tr_b / (t[4] / max(t[1], 1)), 2) for t in kernels
+                                      for tr_b in [traffic_per_launch(tj, t[0]) if tj else None] if tr_b and t[4] > 0}}
     tr.use_graphs = graphs_used            # every rank (the eager roofline pass above switched it off)
 
     if rank == 0:
