@@ -19,6 +19,7 @@ from .. import functional as Fn
 from .. import functional2 as F2
 from .. import kernels as K
 from .. import parallel
+from ..graphs import GraphRunner
 from ..store import ParamStore, set_default_store
 from .model import ACGAN
 
@@ -31,7 +32,7 @@ def polynomial_decay(step, lr0=0.0004, decay_steps=50000, lr_end=0.0002):
 
 class ACGANTrainer:
     def __init__(self, batch_size=64, z_dim=128, acgan_scale_G=0.1, n_dis=5, max_iter=100000, device="cuda", seed=0,
-                 process_group=None, state=None):
+                 process_group=None, state=None, use_graphs=True):
         self.device = torch.device(device)
         self.batch, self.z_dim, self.scale_g, self.n_dis, self.max_iter = batch_size, z_dim, acgan_scale_G, n_dis, max_iter
         self.store = set_default_store(ParamStore(self.device, seed=seed))
@@ -61,19 +62,33 @@ class ACGANTrainer:
         self.g_opt = self._adam(self.g_flat)
         self.d_opt = self._adam(self.d_flat)
         self.losses = {}
+        # the two updates as captured hipGraphs (gan_lib_tensorflow_amd/graphs.py): static input buffers, the learning rate
+        # written into the optimiser's device-side hyper-parameters outside the captured region
+        self.graphs = GraphRunner(use_graphs)
+        self.real_u8 = torch.zeros((batch_size, 3072), dtype=torch.uint8, device=self.device)
+        self.real_labels = torch.zeros(batch_size, dtype=torch.int32, device=self.device)
 
     def _adam(self, flat):
         dev = self.device
         return dict(hp=torch.tensor([0.0004, 0.0, 0.9, 1e-8, 1.0 / self.world, 0.0, 0.0, 0.0], dtype=torch.float32, device=dev),
                     t=torch.zeros(1, dtype=torch.int64, device=dev), flat=flat)
 
+    def _set_lr(self, opt):
+        opt['hp'][0:1].fill_(polynomial_decay(self.global_step, decay_steps=self.max_iter // 2))
+
     def _apply(self, opt):
-        lr = polynomial_decay(self.global_step, decay_steps=self.max_iter // 2)
-        opt['hp'][0:1].fill_(lr)
         f = opt['flat']
-        if self.world > 1:
-            parallel.allreduce_sum_(f['grads'], self.pg)
         K.adam_tf(f['params'], f['grads'], f['m'], f['v'], opt['hp'], opt['t'], None)
+
+    def _update(self, key, fwd_bwd, opt):
+        """fwd_bwd (graph) -> [RCCL all-reduce] -> Adam (graph): one graph when there is nothing to exchange"""
+        self._set_lr(opt)
+        if self.world == 1:
+            self.graphs.run(key, lambda: (fwd_bwd(), self._apply(opt)))
+        else:
+            self.graphs.run(key, fwd_bwd)
+            parallel.allreduce_sum_(opt['flat']['grads'], self.pg)
+            self.graphs.run(key + '/adam', lambda: self._apply(opt))
 
     # ---- the two losses (eager; explicit inputs override the device RNG for parity tests) -----------------------------
     def d_loss(self, real, real_labels, z=None, fake_labels=None, alpha=None):
@@ -123,22 +138,30 @@ class ACGANTrainer:
         return total
 
     # ---- updates --------------------------------------------------------------------------------------------------
-    def d_step(self, real_u8, labels):
-        """one critic update on a uint8 [B, 3072] CHW-planar batch + int labels (train.py:199-204)"""
-        real = K.preprocess_real(real_u8, self.rng_state)              # [B, 32, 32, 3] bf16   (train.py:80-83)
+    def _d_fwd_bwd(self):
+        real = K.preprocess_real(self.real_u8, self.rng_state)         # [B, 32, 32, 3] bf16   (train.py:80-83)
         self.d_flat['grads'].zero_()
-        loss = self.d_loss(real, labels)
+        loss = self.d_loss(real, self.real_labels)
         loss.backward()
-        self._apply(self.d_opt)
-        return loss.detach()
+        self.losses['d_loss'] = loss.detach()
 
-    def g_step(self):
+    def _g_fwd_bwd(self):
         self.store.zero_grads('g_net')
         loss = self.g_loss()
         loss.backward()
-        self._apply(self.g_opt)
+        self.losses['g_loss'] = loss.detach()
+
+    def d_step(self, real_u8, labels):
+        """one critic update on a uint8 [B, 3072] CHW-planar batch + int labels (train.py:199-204)"""
+        self.real_u8.copy_(real_u8, non_blocking=True)
+        self.real_labels.copy_(labels, non_blocking=True)
+        self._update('d', self._d_fwd_bwd, self.d_opt)
+        return self.losses['d_loss']
+
+    def g_step(self):
+        self._update('g', self._g_fwd_bwd, self.g_opt)
         self.global_step += 1            # minimize(..., global_step=global_step) on the generator's optimiser (train.py:146)
-        return loss.detach()
+        return self.losses['g_loss']
 
     def train_iteration(self, batches, step=None):
         step = self.global_step_counter if step is None else step

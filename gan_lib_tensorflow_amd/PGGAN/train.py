@@ -16,6 +16,7 @@ import torch
 from .. import functional as Fn
 from .. import kernels as K
 from .. import parallel
+from ..graphs import GraphRunner
 from ..store import ParamStore, set_default_store
 from .model_nvidia import PGGAN
 
@@ -29,7 +30,7 @@ def default_args(**over):
 
 
 class PGGANTrainer:
-    def __init__(self, args, device="cuda", seed=0, process_group=None, state=None):
+    def __init__(self, args, device="cuda", seed=0, process_group=None, state=None, use_graphs=True):
         assert args.image_size == 4 * 2 ** args.block_count, "image_size must be 4 * 2**block_count (train.py:52-54)"
         self.args = args
         self.device = torch.device(device)
@@ -55,6 +56,10 @@ class PGGANTrainer:
         self.g_opt = self._adam(self.g_flat)
         self.d_opt = self._adam(self.d_flat)
         self.losses = {}
+        # the two updates as captured hipGraphs: static input rows, the fade-in weight in device memory (written before a replay)
+        self.graphs = GraphRunner(use_graphs)
+        self.real_u8 = torch.zeros((args.batch_size, args.image_dim), dtype=torch.uint8, device=self.device)
+        self.alpha_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
 
     def _adam(self, flat):
         dev = self.device
@@ -63,9 +68,16 @@ class PGGANTrainer:
 
     def _apply(self, opt):
         f = opt['flat']
-        if self.world > 1:
-            parallel.allreduce_sum_(f['grads'], self.pg)
         K.adam_tf(f['params'], f['grads'], f['m'], f['v'], opt['hp'], opt['t'], None, zero_grads=True)
+
+    def _update(self, key, fwd_bwd, opt):
+        """fwd_bwd (graph) -> [RCCL all-reduce] -> Adam (graph): one graph when there is nothing to exchange"""
+        if self.world == 1:
+            self.graphs.run(key, lambda: (fwd_bwd(), self._apply(opt)))
+        else:
+            self.graphs.run(key, fwd_bwd)
+            parallel.allreduce_sum_(opt['flat']['grads'], self.pg)
+            self.graphs.run(key + '/adam', lambda: self._apply(opt))
 
     def alpha(self, step=None):
         return float(self.step if step is None else step) / float(self.args.max_iter)        # feed_dict alpha (:186)
@@ -119,18 +131,25 @@ class PGGANTrainer:
         finally:
             Fn.reset_deferred()
 
-    def d_step(self, real_u8, alpha=None):
-        loss = self.d_loss(self.real_images(real_u8), alpha=alpha)
+    def _d_fwd_bwd(self):
+        loss = self.d_loss(self.real_images(self.real_u8), alpha=self.alpha_dev)
         self._backward(loss)
-        self._apply(self.d_opt)
         self.losses['d_loss'] = loss.detach()
+
+    def _g_fwd_bwd(self):
+        loss = self.g_loss(alpha=self.alpha_dev)
+        self._backward(loss)
+        self.losses['g_loss'] = loss.detach()
+
+    def d_step(self, real_u8, alpha=None):
+        self.real_u8.copy_(real_u8, non_blocking=True)
+        self.alpha_dev.fill_(self.alpha() if alpha is None else float(alpha))
+        self._update('d', self._d_fwd_bwd, self.d_opt)
         return self.losses['d_loss']
 
     def g_step(self, alpha=None):
-        loss = self.g_loss(alpha=alpha)
-        self._backward(loss)
-        self._apply(self.g_opt)
-        self.losses['g_loss'] = loss.detach()
+        self.alpha_dev.fill_(self.alpha() if alpha is None else float(alpha))
+        self._update('g', self._g_fwd_bwd, self.g_opt)
         return self.losses['g_loss']
 
     def train_iteration(self, batches):

@@ -16,6 +16,7 @@ import torch
 from .. import functional as Fn
 from .. import kernels as K
 from .. import parallel
+from ..graphs import GraphRunner
 from ..store import ParamStore, set_default_store
 from .model import Pix2Pix
 
@@ -35,7 +36,7 @@ def polynomial_decay(step, lr0, decay_steps, lr_end):
 
 
 class Pix2PixTrainer:
-    def __init__(self, args, device="cuda", seed=0, process_group=None, state=None, in_channels=3, out_channels=3):
+    def __init__(self, args, device="cuda", seed=0, process_group=None, state=None, in_channels=3, out_channels=3, use_graphs=True):
         if args.loss_type != 'HINGE':
             raise NotImplementedError('loss_type HINGE (the reference default, train.py:38)')
         self.args = args
@@ -64,6 +65,10 @@ class Pix2PixTrainer:
         self.g_opt = self._adam(self.g_flat)
         self.d_opt = self._adam(self.d_flat)
         self.losses = {}
+        # the two updates as captured hipGraphs: static input / target buffers, the learning rate written outside the capture
+        self.graphs = GraphRunner(use_graphs)
+        self.inputs = torch.zeros((args.batch_size, args.crop_size, args.crop_size, in_channels), dtype=torch.bfloat16, device=self.device)
+        self.targets = torch.zeros((args.batch_size, args.crop_size, args.crop_size, out_channels), dtype=torch.bfloat16, device=self.device)
 
     def _generator(self, inputs, reuse=True):
         a = self.args
@@ -83,12 +88,19 @@ class Pix2PixTrainer:
                     t=torch.zeros(1, dtype=torch.int64, device=dev), flat=flat)
 
     def _apply(self, opt):
+        f = opt['flat']
+        K.adam_tf(f['params'], f['grads'], f['m'], f['v'], opt['hp'], opt['t'], None, zero_grads=True)
+
+    def _update(self, key, fwd_bwd, opt):
+        """fwd_bwd (graph) -> [RCCL all-reduce] -> Adam (graph): one graph when there is nothing to exchange"""
         a = self.args
         opt['hp'][0:1].fill_(polynomial_decay(self.global_step, a.initial_lr, a.max_steps, a.end_lr))
-        f = opt['flat']
-        if self.world > 1:
-            parallel.allreduce_sum_(f['grads'], self.pg)
-        K.adam_tf(f['params'], f['grads'], f['m'], f['v'], opt['hp'], opt['t'], None, zero_grads=True)
+        if self.world == 1:
+            self.graphs.run(key, lambda: (fwd_bwd(), self._apply(opt)))
+        else:
+            self.graphs.run(key, fwd_bwd)
+            parallel.allreduce_sum_(opt['flat']['grads'], self.pg)
+            self.graphs.run(key + '/adam', lambda: self._apply(opt))
 
     # ---- losses ---------------------------------------------------------------------------------------------------
     def d_loss(self, inputs, targets):
@@ -129,19 +141,32 @@ class Pix2PixTrainer:
         finally:
             Fn.reset_deferred()
 
-    def d_step(self, inputs, targets):
-        loss = self.d_loss(inputs, targets)
+    def _d_fwd_bwd(self):
+        loss = self.d_loss(self.inputs, self.targets)
         self._backward(loss)
-        self._apply(self.d_opt)
         self.losses['discrim_loss'] = loss.detach()
+
+    def _g_fwd_bwd(self):
+        loss = self.g_loss(self.inputs, self.targets)
+        self._backward(loss)
+        self.losses['gen_loss'] = loss.detach()
+
+    def _feed(self, inputs, targets):
+        if inputs.data_ptr() != self.inputs.data_ptr():
+            self.inputs.copy_(inputs, non_blocking=True)
+        if targets.data_ptr() != self.targets.data_ptr():
+            self.targets.copy_(targets, non_blocking=True)
+
+    def d_step(self, inputs, targets):
+        self._feed(inputs, targets)
+        self._update('d', self._d_fwd_bwd, self.d_opt)
         return self.losses['discrim_loss']
 
     def g_step(self, inputs, targets):
-        loss = self.g_loss(inputs, targets)
-        self._backward(loss)
-        self._apply(self.g_opt)
+        self._feed(inputs, targets)
+        self._update('g', self._g_fwd_bwd, self.g_opt)
         self.global_step += 1            # apply_gradients(..., global_step=global_step) on the generator's optimiser (:554)
-        return loss.detach()
+        return self.losses['gen_loss']
 
     def train_step(self, inputs, targets):
         """train.py:704-730: n_dis critic updates, then the generator update, on one batch of pairs"""

@@ -107,6 +107,7 @@ PROTOTYPES = {
     "gank_bcast_hw": [P, P, I, I, I, F, P],
     "gank_rng_uniform_f32": [P, L, P, P],
     "gank_axpby_bf16": [P, P, F, F, P, L, P],
+    "gank_blend_dev": [P, P, P, P, L, I, P],
     "gank_minibatch_std_fwd": [P, P, P, I, I, I, P],
     "gank_minibatch_std_bwd": [P, P, P, P, I, I, I, P],
     "gank_resize_bilinear": [P, P, I, I, I, I, I, I, P],

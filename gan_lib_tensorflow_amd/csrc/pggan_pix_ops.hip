@@ -25,6 +25,21 @@ extern "C" int gank_axpby_bf16(const void* a, const void* b, float alpha, float 
   return 0;
 }
 
+// the same with the weight read from device memory (a captured train step replays with the fade-in weight of the day):
+// mode 0: y = (1 - alpha) a + alpha b;  mode 1: y = (1 - alpha) a;  mode 2: y = alpha a      (the two gradients of mode 0)
+__global__ void blend_dev_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, const float* __restrict__ alpha, bf16* __restrict__ y, long n, int mode) {
+  const float al = alpha[0];
+  const float wa = mode == 2 ? al : 1.f - al, wb = mode == 0 ? al : 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = f2bf(wa * bf2f(a[i]) + (mode == 0 ? wb * bf2f(b[i]) : 0.f));
+}
+extern "C" int gank_blend_dev(const void* a, const void* b, const float* alpha, void* y, long n, int mode, void* stream) {
+  GANK_REQUIRE(a && alpha && y && n > 0 && mode >= 0 && mode <= 2 && (mode != 0 || b), "blend_dev: bad arguments");
+  hipLaunchKernelGGL(blend_dev_kernel, g1(n), dim3(256), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b, alpha, (bf16*)y, n, mode);
+  GANK_LAUNCH_OK("blend_dev");
+  return 0;
+}
+
 // ---- minibatch_std: y = concat(x, s), s = mean over (h,w,c) of sqrt(var_batch(x) + 1e-8) --------------------------------
 // ws: fp32 [R + 1] (R = HW*C): per-position sqrt(v + eps), then the scalar at ws[R]
 __global__ void mbstd_pos_kernel(const bf16* __restrict__ x, float* __restrict__ ws, int B, long R) {

@@ -834,16 +834,22 @@ def to_f32(x):
 # ---------------------------------------------------------------- PGGAN / Pix2Pix operators
 class _Blend(Function):
     """(1 - alpha) * a + alpha * b: the fade-in of a new resolution (PGGAN/model_nvidia.py:116,206); alpha is a Python float
-    (a placeholder fed per step in the reference, train.py:81)"""
+    or an fp32[1] device tensor (a placeholder fed per step in the reference, train.py:81)"""
 
     @staticmethod
     def forward(ctx, a, b, alpha):
+        if torch.is_tensor(alpha):          # fp32[1] on the device: read by the kernels (a captured step replays with today's value)
+            ctx.alpha = alpha
+            return K.blend_dev(_c(a), _c(b), alpha, 0)
         ctx.alpha = float(alpha)
         return K.axpby(a, b, 1.0 - ctx.alpha, ctx.alpha)
 
     @staticmethod
     def backward(ctx, g):
         g = _c(g)
+        if torch.is_tensor(ctx.alpha):
+            return (K.blend_dev(g, None, ctx.alpha, 1) if ctx.needs_input_grad[0] else None,
+                    K.blend_dev(g, None, ctx.alpha, 2) if ctx.needs_input_grad[1] else None, None)
         return (K.axpby(g, None, 1.0 - ctx.alpha) if ctx.needs_input_grad[0] else None,
                 K.axpby(g, None, ctx.alpha) if ctx.needs_input_grad[1] else None, None)
 

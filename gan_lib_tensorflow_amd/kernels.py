@@ -862,6 +862,13 @@ def axpby(a, b, alpha, beta=0.0):
     return y
 
 
+def blend_dev(a, b, alpha, mode=0):
+    """fade-in blend with the weight `alpha` (fp32[1]) in device memory: mode 0 (1-alpha) a + alpha b; 1 (1-alpha) a; 2 alpha a"""
+    y = torch.empty_like(a)
+    _lib.check(lib().gank_blend_dev(_p(a, BF16, "a"), _p(b, BF16, "b"), _p(alpha, F32, "alpha"), _p(y), a.numel(), int(mode), _stream()), "blend_dev")
+    return y
+
+
 def minibatch_std_fwd(x):
     b, c = x.shape[0], x.shape[-1]
     hw = x.numel() // (b * c)

@@ -387,6 +387,8 @@ int gank_rng_uniform_f32(float* y, long n, uint64_t* rng_state, void* stream);
  * l1_loss: mean |a-b| (Pix2Pix/train.py:510-512); dl32 fp32 = d loss / d a (gank_loss_grad_scale rounds it once); ws fp32 [1024].
  * dropout: tf.nn.dropout(x, keep) with a byte mask from the device RNG (networks.py decoder), and its gradient. */
 int gank_axpby_bf16(const void* a, const void* b, float alpha, float beta, void* y, long n, void* stream);
+/* fade-in blend with the weight in device memory (graph replay): mode 0: y = (1-alpha[0]) a + alpha[0] b; 1: (1-alpha[0]) a; 2: alpha[0] a */
+int gank_blend_dev(const void* a, const void* b, const float* alpha, void* y, long n, int mode, void* stream);
 int gank_minibatch_std_fwd(const void* x, void* y, float* ws, int B, int HW, int C, void* stream);
 int gank_minibatch_std_bwd(const void* dy, const void* x, float* ws, void* dx, int B, int HW, int C, void* stream);
 int gank_resize_bilinear(const void* x, void* y, int N, int Hi, int Wi, int Ho, int Wo, int C, void* stream);
