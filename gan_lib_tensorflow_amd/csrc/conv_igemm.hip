@@ -49,7 +49,14 @@ struct IgemmArgs {
   // stat_sums [groups][2][Cout] += (sum, sum of squares) of (y - bias) over the samples of each tower; null = off
   float* stat_sums;
   int stat_n_per_group, stat_groups, stat_prezeroed;
+  int phase_inner;  // phase mode: block -> (tile, phase) with the phase fastest (default) or slowest
 };
+
+static int phase_inner_env() {
+  static int v = -1;   // experiment knob: GANK_PHASE_INNER=0 restores the phase-slowest block order
+  if (v < 0) { const char* e = getenv("GANK_PHASE_INNER"); v = e ? atoi(e) : 1; }
+  return v;
+}
 
 constexpr int LROW = 72;  // LDS row length in bf16 (64 + 8 pad) = 144 B
 
@@ -102,7 +109,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
   // 4 taps per output instead of 9 (or 16 with zero insertion).
   constexpr bool PHASE = !PACKED && (MODE & 4) != 0;
   int phase = 0;
-  if constexpr (PHASE) { phase = tile_m / a.tiles_pp; tile_m -= phase * a.tiles_pp; }
+  if constexpr (PHASE) {
+    // phase fastest: the four phases of a pixel tile get consecutive logical ids = the same XCD, back to back -- they read the
+    // same input tile from that L2 and their interleaved output pixels (each phase writes every other pixel of a row) meet
+    // in it before they reach HBM.  Phase-slowest put them on four different XCDs: 1.7x the algorithmic write bytes.
+    if (a.phase_inner) { phase = tile_m & 3; tile_m >>= 2; }
+    else { phase = tile_m / a.tiles_pp; tile_m -= phase * a.tiles_pp; }
+  }
   const int pad_h = PHASE ? 1 - (phase >> 1) : a.pad, pad_w = PHASE ? 1 - (phase & 1) : a.pad;
 
   const int st = (a.flags & IG_IN_STRIDE2) ? 2 : 1;
@@ -449,7 +462,13 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
   const int tile_n = lid % a.tiles_n;
   int tile_m = lid / a.tiles_n;
   int phase = 0;
-  if constexpr (PHASE) { phase = tile_m / a.tiles_pp; tile_m -= phase * a.tiles_pp; }
+  if constexpr (PHASE) {
+    // phase fastest: the four phases of a pixel tile get consecutive logical ids = the same XCD, back to back -- they read the
+    // same input tile from that L2 and their interleaved output pixels (each phase writes every other pixel of a row) meet
+    // in it before they reach HBM.  Phase-slowest put them on four different XCDs: 1.7x the algorithmic write bytes.
+    if (a.phase_inner) { phase = tile_m & 3; tile_m >>= 2; }
+    else { phase = tile_m / a.tiles_pp; tile_m -= phase * a.tiles_pp; }
+  }
   const int pad_h = PHASE ? 1 - (phase >> 1) : 1, pad_w = PHASE ? 1 - (phase & 1) : 1;
   const int pw = a.W >> 4, ph = a.H >> 3;               // patches per row / column
   const int n = tile_m / (pw * ph), pr = tile_m - n * pw * ph;
@@ -817,6 +836,7 @@ template <int MODE>    // MODE has bit 2 set
 static int launch_patch_phase(const IgemmArgs& a0, hipStream_t s) {
   IgemmArgs a = a0;
   a.tiles_pp = a.N * (a.H / 8) * (a.W / 16);
+  a.phase_inner = phase_inner_env();
   a.tiles_m = 4 * a.tiles_pp;
   a.tiles_n = a.CoutPad / 128;
   const size_t lds = ((size_t)10 * HROWP + (size_t)2 * 128 * LROW) * sizeof(bf16);
@@ -1047,7 +1067,13 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
   const int tile_n = lid % a.tiles_n;
   int tile_m = lid / a.tiles_n;
   int phase = 0;
-  if constexpr (PHASE) { phase = tile_m / a.tiles_pp; tile_m -= phase * a.tiles_pp; }
+  if constexpr (PHASE) {
+    // phase fastest: the four phases of a pixel tile get consecutive logical ids = the same XCD, back to back -- they read the
+    // same input tile from that L2 and their interleaved output pixels (each phase writes every other pixel of a row) meet
+    // in it before they reach HBM.  Phase-slowest put them on four different XCDs: 1.7x the algorithmic write bytes.
+    if (a.phase_inner) { phase = tile_m & 3; tile_m >>= 2; }
+    else { phase = tile_m / a.tiles_pp; tile_m -= phase * a.tiles_pp; }
+  }
   const int pad_h = PHASE ? 1 - (phase >> 1) : 1, pad_w = PHASE ? 1 - (phase & 1) : 1;
   const int pw = a.W / PW, ph = a.H / PHH;
   const int n = tile_m / (pw * ph), pr = tile_m - n * pw * ph;
@@ -1281,6 +1307,12 @@ __global__ void ig_zero_kernel(float* __restrict__ p, int n) {
 }
 
 static void stats_zero(const IgemmArgs& a, hipStream_t s);
+// 128x128 tiles from this many tiles on; fewer run as 64x64 (4x the workgroups: the grid rounds better on 256 CUs)
+static int t128_min() {
+  static int v = -1;   // experiment knob
+  if (v < 0) { const char* e = getenv("GANK_IGEMM_T128_MIN"); v = e ? atoi(e) : 192; }
+  return v;
+}
 // generic kernel with the statistics epilogue: every pixel tile full and inside one tower, every channel tile full
 // (a.M, a.H, a.W: the grid the tiles walk -- the low-resolution grid in phase mode)
 static bool igemm_stats_ok(const IgemmArgs& a, int BM, int BN) {
@@ -1297,6 +1329,7 @@ static int launch_pp(const IgemmArgs& a0, hipStream_t s) {
   constexpr bool PHASE = (MODE & 4) != 0;
   const int tiles = a.N * (a.H / (256 / PW)) * (a.W / PW);
   a.tiles_pp = tiles;
+  a.phase_inner = phase_inner_env();
   a.tiles_m = PHASE ? 4 * tiles : tiles;
   a.tiles_n = a.Cout / 256;
   if (PHASE) { a.Kpad = 4 * a.Cin; a.Hin = a.H; a.Win = a.W; }
@@ -1378,6 +1411,7 @@ static int launch_phase(const IgemmArgs& a0, hipStream_t s) {
   IgemmArgs a = a0;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   a.tiles_pp = cdiv(a.M, BM);
+  a.phase_inner = phase_inner_env();
   a.tiles_m = 4 * a.tiles_pp;
   a.tiles_n = a.CoutPad / BN;
   const size_t lds = (size_t)2 * (BM + BN) * LROW * sizeof(bf16);
@@ -1466,13 +1500,13 @@ int gank_igemm_dispatch(IgemmArgs a, hipStream_t s) {
   } else if (packed) {
     if (a.CoutPad % 64 == 0) rc = launch_cfg<2, 2, 1, 1, true, 1, 0>(a, s);
     else rc = launch_cfg<4, 1, 2, 1, true, 1, 0>(a, s);
-  } else if (a.CoutPad % 128 == 0 && tiles128 >= 192 && pf_env >= 20) {
+  } else if (a.CoutPad % 128 == 0 && tiles128 >= t128_min() && pf_env >= 20) {
     if (pf_env == 20) rc = launch_mode<4, 2, 2, 2, 1>(a, s);          // 256 x 128, 8 waves
     else if (pf_env == 21) rc = launch_mode<4, 2, 2, 2, 2>(a, s);
     else if (pf_env == 22 && a.CoutPad % 256 == 0) rc = launch_mode<2, 4, 2, 2, 2>(a, s);   // 128 x 256
     else if (pf_env == 23 && a.CoutPad % 256 == 0) rc = launch_mode<4, 2, 2, 4, 2>(a, s);   // 256 x 256, wave 64x128
     else rc = launch_mode<4, 2, 2, 2, 2>(a, s);
-  } else if (a.CoutPad % 128 == 0 && tiles128 >= 192 && pf_env < 10) {
+  } else if (a.CoutPad % 128 == 0 && tiles128 >= t128_min() && pf_env < 10) {
     if (pf_env == 1) rc = launch_mode<2, 2, 2, 2, 1>(a, s);
     else if (pf_env == 3) rc = launch_mode<2, 2, 2, 2, 3>(a, s);
     else rc = launch_mode<2, 2, 2, 2, 2>(a, s);
@@ -1613,7 +1647,7 @@ static int upconv3x3_fprop_impl(const void* x, const void* wph, const float* bia
   const long tiles128 = 4L * cdiv(a.M, 128) * (a.CoutPad / 128);
   if (pp_phase_ok(a)) rc = launch_pp_phase(a, s);
   else if (patch_phase_ok(a)) rc = launch_patch_phase<4>(a, s);
-  else if (a.CoutPad % 128 == 0 && tiles128 >= 192) rc = launch_phase<2, 2, 2, 2, 2>(a, s);
+  else if (a.CoutPad % 128 == 0 && tiles128 >= t128_min()) rc = launch_phase<2, 2, 2, 2, 2>(a, s);
   else if (a.CoutPad % 64 == 0) rc = launch_phase<2, 2, 1, 1, 4>(a, s);
   else rc = launch_phase<4, 1, 2, 1, 2>(a, s);
   gank_prof_end(0, s);
@@ -1680,7 +1714,7 @@ extern "C" int gank_convpool3x3_dgrad(const void* dy, const void* wphd, const vo
   const long tiles128 = 4L * cdiv(a.M, 128) * (a.CoutPad / 128);
   if (pp_phase_ok(a)) rc = launch_pp_phase(a, s);
   else if (patch_phase_ok(a)) rc = launch_patch_phase<4>(a, s);
-  else if (a.CoutPad % 128 == 0 && tiles128 >= 192) rc = launch_phase<2, 2, 2, 2, 2>(a, s);
+  else if (a.CoutPad % 128 == 0 && tiles128 >= t128_min()) rc = launch_phase<2, 2, 2, 2, 2>(a, s);
   else if (a.CoutPad % 64 == 0) rc = launch_phase<2, 2, 1, 1, 4>(a, s);
   else rc = launch_phase<4, 1, 2, 1, 2>(a, s);
   gank_prof_end(0, s);
