@@ -260,6 +260,12 @@ def main():
                     # algorithmic bytes (operands read once + result written once, summed by the launchers)
                     "traffic_ratio": {t[0]: round(tr_b / (t[4] / max(t[1], 1)), 2) for t in kernels
                                       for tr_b in [traffic_per_launch(tj, t[0]) if tj else None] if tr_b and t[4] > 0}}
+        # the same over ALL conv launches of the iteration: a kernel's PMC bytes include dirty lines of its predecessors that
+        # the L2 / Infinity Cache evict while it runs, so only the sum is attribution-free
+        cov = [(traffic_per_launch(tj, t[0]) if tj else None, t) for t in kernels]
+        cov = [(b, t) for b, t in cov if b and t[4] > 0]
+        if cov:
+            roofline["traffic_ratio_all_conv_kernels"] = round(sum(b * t[1] for b, t in cov) / sum(t[4] for _, t in cov), 3)
     tr.use_graphs = graphs_used            # every rank (the eager roofline pass above switched it off)
 
     if rank == 0:

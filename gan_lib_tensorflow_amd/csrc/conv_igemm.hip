@@ -1462,7 +1462,9 @@ int gank_igemm_dispatch(IgemmArgs a, hipStream_t s) {
   const bool packed = (a.Cin % 64) != 0;
   const double flops = 2.0 * a.M * (double)a.Cout * a.taps * a.Cin;
   // algorithmic bytes: every input pixel-channel and weight read once, every output written once
-  gank_prof_begin(0, flops, s, 2.0 * ((double)a.N * a.Hin * a.Win * a.Cin + (double)a.taps * a.Cin * a.Cout + (double)a.M * a.Cout));
+  // (+ the epilogue's operands: the residual -- a quarter of it when it is added upsampled -- and the relu mask)
+  gank_prof_begin(0, flops, s, 2.0 * ((double)a.N * a.Hin * a.Win * a.Cin + (double)a.taps * a.Cin * a.Cout + (double)a.M * a.Cout +
+                                      (a.res ? (double)a.M * a.Cout / ((a.flags & IG_RES_UP2X) ? 4.0 : 1.0) : 0.0) + (a.mask ? (double)a.M * a.Cout : 0.0)));
   int rc;
   const long tiles128 = (long)cdiv(a.M, 128) * (a.CoutPad / 128);
   static int ko_env = -1;
@@ -1642,7 +1644,7 @@ static int upconv3x3_fprop_impl(const void* x, const void* wph, const float* bia
   a.M = N * Hl * Wl; a.sw = log2_or_neg(Wl); a.shw = log2_or_neg(Hl * Wl);
   GANK_REQUIRE((long)N * Hl * Wl * Cin < (1L << 30) && (long)a.M * 4 * Cout < (1L << 31), "upconv3x3_fprop: tensor too large");
   if (stats_setup(a, stat_sums, groups, N, Cout, s, flags)) return 1;
-  gank_prof_begin(0, 2.0 * a.M * 4.0 * (double)Cout * 4 * Cin, s, 2.0 * ((double)a.M * Cin + 16.0 * Cin * Cout + 4.0 * a.M * Cout));
+  gank_prof_begin(0, 2.0 * a.M * 4.0 * (double)Cout * 4 * Cin, s, 2.0 * ((double)a.M * Cin + 16.0 * Cin * Cout + 4.0 * a.M * Cout + (residual ? 4.0 * a.M * Cout : 0.0)));
   int rc;
   const long tiles128 = 4L * cdiv(a.M, 128) * (a.CoutPad / 128);
   if (pp_phase_ok(a)) rc = launch_pp_phase(a, s);
@@ -1709,7 +1711,7 @@ extern "C" int gank_convpool3x3_dgrad(const void* dy, const void* wphd, const vo
   a.taps = 4; a.CoutPad = roundup(Cin, 32); a.Kpad = 4 * Cout; a.nsteps = a.Kpad / 64;
   a.M = N * Hp * Wp; a.sw = log2_or_neg(Wp); a.shw = log2_or_neg(Hp * Wp);
   GANK_REQUIRE((long)N * Hp * Wp * Cout < (1L << 30) && (long)a.M * 4 * Cin < (1L << 31), "convpool3x3_dgrad: tensor too large");
-  gank_prof_begin(0, 2.0 * a.M * 4.0 * (double)Cin * 4 * Cout, s, 2.0 * ((double)a.M * Cout + 16.0 * Cin * Cout + 4.0 * a.M * Cin));
+  gank_prof_begin(0, 2.0 * a.M * 4.0 * (double)Cin * 4 * Cout, s, 2.0 * ((double)a.M * Cout + 16.0 * Cin * Cout + 4.0 * a.M * Cin + (relu_ref ? 4.0 * a.M * Cin : 0.0)));
   int rc;
   const long tiles128 = 4L * cdiv(a.M, 128) * (a.CoutPad / 128);
   if (pp_phase_ok(a)) rc = launch_pp_phase(a, s);

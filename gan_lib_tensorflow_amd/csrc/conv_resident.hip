@@ -680,7 +680,7 @@ extern "C" int gank_cpool_res_fprop(const void* x, const void* w_rfrag, const fl
   a.N = N; a.Hp = Hp; a.Wp = Wp; a.Cin = Cin; a.Cout = Cout; a.relu = (flags & GANK_IN_RELU) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   const double M = (double)N * Hp * Wp;
-  gank_prof_begin(0, 2.0 * M * Cout * 16.0 * Cin, s, 2.0 * (4.0 * M * Cin + 16.0 * Cin * Cout + M * Cout));
+  gank_prof_begin(0, 2.0 * M * Cout * 16.0 * Cin, s, 2.0 * (4.0 * M * Cin + 16.0 * Cin * Cout + M * Cout + (residual ? M * Cout : 0.0)));
   if (Wp % 16 == 0) {
     const int grid = N * (Hp / 8) * (Wp / 16) * (Cout / 128);
     GANK_MAX_DYNAMIC_LDS((cpool_res_fprop_kernel<16, 2, 8>), CpGeom<16>::IMG, "cpool_res_fprop");
@@ -708,7 +708,7 @@ extern "C" int gank_cpool_res_dgrad(const void* dy, const void* w_rfrag, const v
   a.N = N; a.Hp = Hp; a.Wp = Wp; a.Cin = Cin; a.Cout = Cout;
   hipStream_t s = (hipStream_t)stream;
   const double M = (double)N * Hp * Wp;
-  gank_prof_begin(0, 2.0 * M * 4.0 * Cin * 4.0 * Cout, s, 2.0 * (M * Cout + 16.0 * Cin * Cout + 4.0 * M * Cin));
+  gank_prof_begin(0, 2.0 * M * 4.0 * Cin * 4.0 * Cout, s, 2.0 * (M * Cout + 16.0 * Cin * Cout + 4.0 * M * Cin + (relu_ref ? 4.0 * M * Cin : 0.0)));
   if (Wp % 16 == 0) {
     const int grid = N * (Hp / 8) * (Wp / 16) * (Cin / 128);
     GANK_MAX_DYNAMIC_LDS((cpool_res_dgrad_kernel<16, 2, 8>), CdGeom<16>::IMG, "cpool_res_dgrad");
