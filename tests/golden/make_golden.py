@@ -72,7 +72,39 @@ def network():
                         grad_D_Output_W=grads[2].numpy())
 
 
+def configs45():
+    """PGGAN (oracle/ref_pggan.py) and Pix2Pix (oracle/ref_pix2pix.py) restatements at small sizes: inputs and small outputs"""
+    from oracle import ref_pggan as G
+    from oracle import ref_pix2pix as X
+    rng = np.random.default_rng(45)
+    out = {}
+    # PGGAN, 8x8 with the new block fading in (block_count 1, trans)
+    P = T.to_torch(G.init_params(5, 1, True, z_dim=32))
+    z = bf16_round(rng.normal(size=(3, 32)))
+    img = G.generator(P, torch.tensor(z), 0.3, 1, True)
+    lg, new_u = G.discriminator(P, img.detach(), 0.3, 1, True, update_u=True)
+    dl, _ = G.d_loss(P, img.detach() * 0.5, torch.tensor(z), 0.3, 1, True)
+    out.update(pg_z=z, pg_img=img.detach().numpy(), pg_logits=lg.detach().numpy(), pg_d_loss=float(dl),
+               pg_u=new_u['d_net/D.Conv/filters/spectral_norm/u'].numpy(), pg_mbstd=G.minibatch_std_numpy(z.reshape(3, 2, 2, 8)),
+               pg_resize=G.resize_bilinear(z.reshape(1, 4, 8, 3), (8, 16)))
+    # Pix2Pix: the general convolution and instance norm, and the PatchGAN critic on 64x64 (ndf 8)
+    x = bf16_round(rng.normal(size=(2, 6, 6, 5)))
+    w = bf16_round(rng.normal(size=(4, 4, 5, 3)) / 9.)
+    out.update(px_x=x, px_w=w,
+               px_s2_same=X.conv2d_tf(torch.tensor(x), torch.tensor(w), None, 2, 'SAME').numpy(),
+               px_s1_same=X.conv2d_tf(torch.tensor(x), torch.tensor(w), None, 1, 'SAME').numpy(),
+               px_s1_valid=X.conv2d_tf(torch.tensor(x), torch.tensor(w), None, 1, 'VALID', 1).numpy(),
+               px_inorm=X.instance_norm(torch.tensor(x), torch.ones(1, 5, dtype=torch.float64) * 1.5, torch.ones(1, 5, dtype=torch.float64) * 0.1).numpy())
+    Pd = T.to_torch(X.init_params(9, ngf=8, ndf=8))
+    a = bf16_round(rng.uniform(-1, 1, size=(2, 64, 64, 3)))
+    b = bf16_round(rng.uniform(-1, 1, size=(2, 64, 64, 3)))
+    pr, _ = X.discriminator(Pd, torch.tensor(a), torch.tensor(b))
+    out.update(px_a=a, px_b=b, px_patch=pr.detach().numpy())
+    np.savez_compressed(os.path.join(OUT, "configs45.npz"), **out)
+
+
 if __name__ == "__main__":
     ops()
     network()
+    configs45()
     print("golden vectors written to", OUT)
