@@ -255,8 +255,12 @@ extern "C" int gank_cbn_fwd(const void* x, const int32_t* labels, const float* g
 
 // ---- backward -------------------------------------------------------------------------------------
 // b1: per-sample sums S1[n][c] = sum_hw dym, S2[n][c] = sum_hw dym * xhat   (dym = dy masked by y>0)
+// The relu mask is y > 0.  With `beta` given it is RECOMPUTED from x -- (x - mean) * invstd * gamma + beta, the forward pass's
+// own expression in the forward pass's order -- instead of read: one of the three tensor reads of this pass (and one of the
+// four accesses of the apply pass) less.
 __global__ void cbn_bwd_sums_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, const bf16* __restrict__ y,
-                                    const float* __restrict__ stats, float* __restrict__ S, CbnGeom q, int hw_parts) {
+                                    const float* __restrict__ stats, float* __restrict__ S, CbnGeom q, int hw_parts,
+                                    const int* __restrict__ labels, const float* __restrict__ gamma, const float* __restrict__ beta) {
   const int cg = q.C >> 3, RL = 256 / cg;
   const int g = threadIdx.x % cg, rl = threadIdx.x / cg;
   const int n = blockIdx.x / hw_parts, hp = blockIdx.x % hw_parts;
@@ -271,16 +275,26 @@ __global__ void cbn_bwd_sums_kernel(const bf16* __restrict__ dy, const bf16* __r
       mu[e] = stats[((long)grp * 2) * q.C + g * 8 + e];
       iv[e] = stats[((long)grp * 2 + 1) * q.C + g * 8 + e];
     }
+    float ga[8], be[8];
+    if (q.relu && beta) {
+      int lb = labels[n];
+      lb = lb < 0 ? 0 : (lb >= q.n_labels ? q.n_labels - 1 : lb);
+#pragma unroll
+      for (int e = 0; e < 8; e++) { ga[e] = gamma[(long)lb * q.C + g * 8 + e]; be[e] = beta[(long)lb * q.C + g * 8 + e]; }
+    }
     for (int r = h0 + rl; r < h1; r += RL) {
       const long o = ((long)n * q.HW + r) * q.C + g * 8;
       const bf16x8 d = *reinterpret_cast<const bf16x8*>(dy + o);
       const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + o);
       bf16x8 yv;
-      if (q.relu) yv = *reinterpret_cast<const bf16x8*>(y + o);
+      if (q.relu && !beta) yv = *reinterpret_cast<const bf16x8*>(y + o);
 #pragma unroll
       for (int e = 0; e < 8; e++) {
         float dd = bf2f(d[e]);
-        if (q.relu && !(bf2f(yv[e]) > 0.f)) dd = 0.f;
+        if (q.relu) {
+          const bool on = beta ? ((bf2f(xv[e]) - mu[e]) * iv[e] * ga[e] + be[e] > 0.f) : (bf2f(yv[e]) > 0.f);
+          if (!on) dd = 0.f;
+        }
         a1[e] += dd;
         a2[e] += dd * (bf2f(xv[e]) - mu[e]) * iv[e];
       }
@@ -368,7 +382,7 @@ __global__ __launch_bounds__(256) void cbn_bwd_tables_kernel(const float* __rest
 // b3: dx = invstd * (g - mean(g) - xhat * mean(g xhat)),  g = dym * gamma[label]
 __global__ void cbn_bwd_apply_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, const bf16* __restrict__ y,
                                      const int* __restrict__ labels, const float* __restrict__ gamma, const float* __restrict__ stats,
-                                     const float* __restrict__ M, bf16* __restrict__ dx, CbnGeom q, long total8) {
+                                     const float* __restrict__ M, bf16* __restrict__ dx, CbnGeom q, long total8, const float* __restrict__ beta) {
   const int cg = q.C >> 3;
   const int gs = q.N / q.groups;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
@@ -381,27 +395,45 @@ __global__ void cbn_bwd_apply_kernel(const bf16* __restrict__ dy, const bf16* __
     const bf16x8 d = reinterpret_cast<const bf16x8*>(dy)[i];
     const bf16x8 xv = reinterpret_cast<const bf16x8*>(x)[i];
     bf16x8 yv;
-    if (q.relu) yv = reinterpret_cast<const bf16x8*>(y)[i];
+    if (q.relu && !beta) yv = reinterpret_cast<const bf16x8*>(y)[i];
+    // the 8 channels' parameters as 16-byte loads (40 scalar loads per 16 bytes of data made this pass instruction-bound:
+    // its tensors mostly sit in the Infinity Cache when it runs)
+    const float* sp = stats + ((long)grp * 2) * q.C + g * 8;
+    const float* mp = M + ((long)grp * 2) * q.C + g * 8;
+    const float* gp = gamma + (long)lb * q.C + g * 8;
+    const f32x4 mu0 = *reinterpret_cast<const f32x4*>(sp), mu1 = *reinterpret_cast<const f32x4*>(sp + 4);
+    const f32x4 iv0 = *reinterpret_cast<const f32x4*>(sp + q.C), iv1 = *reinterpret_cast<const f32x4*>(sp + q.C + 4);
+    const f32x4 ma0 = *reinterpret_cast<const f32x4*>(mp), ma1 = *reinterpret_cast<const f32x4*>(mp + 4);
+    const f32x4 mb0 = *reinterpret_cast<const f32x4*>(mp + q.C), mb1 = *reinterpret_cast<const f32x4*>(mp + q.C + 4);
+    const f32x4 ga0 = *reinterpret_cast<const f32x4*>(gp), ga1 = *reinterpret_cast<const f32x4*>(gp + 4);
+    f32x4 be0 = {0.f, 0.f, 0.f, 0.f}, be1 = be0;
+    if (q.relu && beta) {
+      be0 = *reinterpret_cast<const f32x4*>(beta + (long)lb * q.C + g * 8);
+      be1 = *reinterpret_cast<const f32x4*>(beta + (long)lb * q.C + g * 8 + 4);
+    }
     bf16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-      const int c = g * 8 + e;
-      const float mu = stats[((long)grp * 2) * q.C + c], iv = stats[((long)grp * 2 + 1) * q.C + c];
+      const float mu = e < 4 ? mu0[e] : mu1[e - 4], iv = e < 4 ? iv0[e] : iv1[e - 4];
+      const float ga = e < 4 ? ga0[e] : ga1[e - 4];
       float dd = bf2f(d[e]);
-      if (q.relu && !(bf2f(yv[e]) > 0.f)) dd = 0.f;
-      const float gg = dd * gamma[(long)lb * q.C + c];
+      if (q.relu) {
+        const bool on = beta ? ((bf2f(xv[e]) - mu) * iv * ga + (e < 4 ? be0[e] : be1[e - 4]) > 0.f) : (bf2f(yv[e]) > 0.f);
+        if (!on) dd = 0.f;
+      }
+      const float gg = dd * ga;
       const float xh = (bf2f(xv[e]) - mu) * iv;
-      o[e] = f2bf(iv * (gg - M[((long)grp * 2) * q.C + c] - xh * M[((long)grp * 2 + 1) * q.C + c]));
+      o[e] = f2bf(iv * (gg - (e < 4 ? ma0[e] : ma1[e - 4]) - xh * (e < 4 ? mb0[e] : mb1[e - 4])));
     }
     reinterpret_cast<bf16x8*>(dx)[i] = o;
   }
 }
 
-extern "C" int gank_cbn_bwd(const void* dy, const void* x, const void* y, const int32_t* labels, const float* gamma,
-                            const float* stats, void* dx, float* dgamma, float* dbeta, float* ws, int N, int HW, int C,
-                            int groups, int n_labels, int relu, void* stream) {
+static int cbn_bwd_impl(const void* dy, const void* x, const void* y, const float* beta, const int32_t* labels, const float* gamma,
+                        const float* stats, void* dx, float* dgamma, float* dbeta, float* ws, int N, int HW, int C,
+                        int groups, int n_labels, int relu, void* stream) {
   GANK_REQUIRE(dy && x && labels && gamma && stats && dx && dgamma && dbeta && ws, "cbn_bwd: null pointer");
-  GANK_REQUIRE(!relu || y, "cbn_bwd: relu backward needs y");
+  GANK_REQUIRE(!relu || y || beta, "cbn_bwd: relu backward needs y or beta");
   CbnGeom q;
   if (cbn_geom(q, N, HW, C, groups, n_labels, relu)) return 1;
   hipStream_t s = (hipStream_t)stream;
@@ -413,12 +445,25 @@ extern "C" int gank_cbn_bwd(const void* dy, const void* x, const void* y, const 
   // zeroed by a kernel, not hipMemsetAsync: inside a captured hipGraph the memset node was observed to race with
   // its kernel neighbours (intermittent NaN generator gradients under graph replay, never in eager mode)
   if (hw_parts > 1) hipLaunchKernelGGL(cbn_zero_kernel, dim3(cdiv(N * 2 * C / 4, 256)), dim3(256), 0, s, S, N * 2 * C / 4);
-  hipLaunchKernelGGL(cbn_bwd_sums_kernel, dim3(N * hw_parts), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (const bf16*)y, stats, S, q, hw_parts);
+  hipLaunchKernelGGL(cbn_bwd_sums_kernel, dim3(N * hw_parts), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (const bf16*)y, stats, S, q, hw_parts, labels, gamma, beta);
   hipLaunchKernelGGL(cbn_bwd_tables_kernel, dim3(cdiv(C, 64), n_labels + 1), dim3(256), 0, s, S, labels, gamma, dgamma, dbeta, M, q);
   const long total8 = (long)N * HW * (C / 8);
   long blocks = (total8 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(cbn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (const bf16*)y, labels, gamma, stats, M, (bf16*)dx, q, total8);
+  hipLaunchKernelGGL(cbn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (const bf16*)y, labels, gamma, stats, M, (bf16*)dx, q, total8, beta);
   GANK_LAUNCH_OK("cbn_bwd");
   return 0;
+}
+
+extern "C" int gank_cbn_bwd(const void* dy, const void* x, const void* y, const int32_t* labels, const float* gamma,
+                            const float* stats, void* dx, float* dgamma, float* dbeta, float* ws, int N, int HW, int C,
+                            int groups, int n_labels, int relu, void* stream) {
+  return cbn_bwd_impl(dy, x, y, nullptr, labels, gamma, stats, dx, dgamma, dbeta, ws, N, HW, C, groups, n_labels, relu, stream);
+}
+// the same with the relu mask recomputed from x, gamma and beta (what the forward pass computed, bit for bit) instead of read from y
+extern "C" int gank_cbn_bwd_remask(const void* dy, const void* x, const float* beta, const int32_t* labels, const float* gamma,
+                                   const float* stats, void* dx, float* dgamma, float* dbeta, float* ws, int N, int HW, int C,
+                                   int groups, int n_labels, int relu, void* stream) {
+  GANK_REQUIRE(!relu || beta, "cbn_bwd_remask: relu backward needs beta");
+  return cbn_bwd_impl(dy, x, nullptr, beta, labels, gamma, stats, dx, dgamma, dbeta, ws, N, HW, C, groups, n_labels, relu, stream);
 }

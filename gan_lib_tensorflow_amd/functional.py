@@ -472,6 +472,9 @@ def spectral_norm_batch(Ws, us, snapshot=False, inplace=False):
     return outs, batch
 
 
+CBN_REMASK = _os.environ.get("GANK_CBN_REMASK", "1") == "1"   # relu mask of the backward pass recomputed from x instead of read from y
+
+
 class _CondBatchNorm(Function):
     @staticmethod
     def forward(ctx, x, labels, gamma, beta, groups, relu):
@@ -490,7 +493,7 @@ class _CondBatchNorm(Function):
         groups, relu = ctx.cfg
         tg, accg = _target(gamma)
         tb, accb = _target(beta)
-        dx = K.cbn_bwd(_c(dy), x, y, labels, gamma.detach(), stats, tg, tb, groups, relu)
+        dx = K.cbn_bwd(_c(dy), x, y, labels, gamma.detach(), stats, tg, tb, groups, relu, beta=beta.detach() if CBN_REMASK else None)
         return dx, None, (None if accg else tg), (None if accb else tb), None, None
 
 

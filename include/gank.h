@@ -282,6 +282,11 @@ int gank_cbn_fwd_from_sums(const void* x, const int32_t* labels, const float* ga
 int gank_cbn_bwd(const void* dy, const void* x, const void* y, const int32_t* labels, const float* gamma,
                  const float* stats, void* dx, float* dgamma, float* dbeta, float* ws, int N, int HW, int C,
                  int groups, int n_labels, int relu, void* stream);
+/* backward with the relu mask RECOMPUTED from x ((x - mean) * invstd * gamma + beta > 0: the forward pass's expression, bit for
+ * bit) instead of read from y: one tensor read less in each of its two passes */
+int gank_cbn_bwd_remask(const void* dy, const void* x, const float* beta, const int32_t* labels, const float* gamma,
+                        const float* stats, void* dx, float* dgamma, float* dbeta, float* ws, int N, int HW, int C,
+                        int groups, int n_labels, int relu, void* stream);
 
 /* ---- resampling / elementwise glue of the block library ------------------------------------------
  * pool2x2: y = scale * (sum of the 2x2 window) (+ residual)   -- tf.add_n(...)/4. at

@@ -282,6 +282,13 @@ def test_cond_batchnorm_fwd_bwd(K, n, hw, c, groups, relu):
     assert relerr(dx, rdx) < BF_TOL
     assert relerr(dg, rdg) < F32_FROM_BF_TOL
     assert relerr(db, rdb) < F32_FROM_BF_TOL
+    # the mask recomputed from x (the forward pass's expression in the forward pass's order) instead of read from y:
+    # the same input gradient and table gradients up to fp32 summation order
+    dg2, db2 = torch.zeros_like(gt), torch.zeros_like(bt)
+    dx2 = K.cbn_bwd(dyt, xt, None, lt, gt, stats, dg2, db2, groups, relu, beta=bt)
+    torch.cuda.synchronize()
+    assert relerr(dx2, dx.double().cpu().numpy()) < 4e-3            # (the per-sample sums meet through fp32 atomics: last-bit differences between two launches)
+    assert relerr(dg2, dg.double().cpu().numpy()) < 1e-5 and relerr(db2, db.double().cpu().numpy()) < 1e-5
 
 
 def test_pool_unpool_add_relu_tanh(K):
