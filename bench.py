@@ -276,7 +276,7 @@ def main():
             "metric": "images/sec (G+D step) SNGAN-ResNet CIFAR-10 bs=64", "value": round(value, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": warm, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "median_ms_per_step_hip_events": round(median_ms, 3), "min_ms_per_step_hip_events": round(step_ms[0], 3),
-            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": os.environ.get("GANK_DTYPE", "bf16").lower(), "data": "synthetic",
             "config": {"workload": "SNGAN ResNet CIFAR-10 32x32 bs=64 hinge: 1 G update (2x64 fakes) + 5 D updates (64 real + 64 fake) per step",
                        "global_batch": per_gpu * world, "per_gpu_batch": per_gpu, "parallelism": f"dp{world}",
                        "images_per_step": "5 critic batches x 64 real images per GPU",

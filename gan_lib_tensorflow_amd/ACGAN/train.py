@@ -47,7 +47,7 @@ class ACGANTrainer:
         # build once (variables are created by name on first use)
         with torch.no_grad():
             labels = torch.zeros(batch_size, dtype=torch.int32, device=self.device)
-            z = torch.zeros((batch_size, z_dim), dtype=torch.bfloat16, device=self.device)
+            z = torch.zeros((batch_size, z_dim), dtype=K.BF16, device=self.device)
             x = self.model.get_generator(z, labels)
             self.model.get_discriminator(x, labels)
         if state is not None:

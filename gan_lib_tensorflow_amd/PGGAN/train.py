@@ -44,7 +44,7 @@ class PGGANTrainer:
         self.model = PGGAN(args)
         self.step = 0
         with torch.no_grad():            # build once: variables are created by name on first use
-            z = torch.zeros((args.batch_size, args.z_dim), dtype=torch.bfloat16, device=self.device)
+            z = torch.zeros((args.batch_size, args.z_dim), dtype=K.BF16, device=self.device)
             x = self.model.get_generator(z, 0.0)
             self.model.get_discriminator(x, 0.0, update_collection='NO_OPS')
         if state is not None:

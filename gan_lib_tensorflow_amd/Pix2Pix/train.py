@@ -53,7 +53,7 @@ class Pix2PixTrainer:
         self.global_step = 0
         with torch.no_grad():            # build once: variables are created by name on first use
             s = args.crop_size
-            a = torch.zeros((args.batch_size, s, s, in_channels), dtype=torch.bfloat16, device=self.device)
+            a = torch.zeros((args.batch_size, s, s, in_channels), dtype=K.BF16, device=self.device)
             out = self._generator(a, reuse=False)
             self._critic(a, out, 'NO_OPS', reuse=False)
         if state is not None:
@@ -67,8 +67,8 @@ class Pix2PixTrainer:
         self.losses = {}
         # the two updates as captured hipGraphs: static input / target buffers, the learning rate written outside the capture
         self.graphs = GraphRunner(use_graphs)
-        self.inputs = torch.zeros((args.batch_size, args.crop_size, args.crop_size, in_channels), dtype=torch.bfloat16, device=self.device)
-        self.targets = torch.zeros((args.batch_size, args.crop_size, args.crop_size, out_channels), dtype=torch.bfloat16, device=self.device)
+        self.inputs = torch.zeros((args.batch_size, args.crop_size, args.crop_size, in_channels), dtype=K.BF16, device=self.device)
+        self.targets = torch.zeros((args.batch_size, args.crop_size, args.crop_size, out_channels), dtype=K.BF16, device=self.device)
 
     def _generator(self, inputs, reuse=True):
         a = self.args

@@ -257,7 +257,7 @@ class SNGANTrainer:
         b = self.batch
         with torch.no_grad():
             labels = torch.zeros(b, dtype=torch.int32, device=self.device)
-            z = torch.zeros((b, 128), dtype=torch.bfloat16, device=self.device)
+            z = torch.zeros((b, 128), dtype=K.BF16, device=self.device)
             fake = Generator(b, labels, noise=z, groups=N_TOWERS)
             Discriminator(fake, labels, update_collection=NO_OPS)
         if state is not None:
@@ -279,9 +279,9 @@ class SNGANTrainer:
         # one iteration's worth of critic feeds and generator outputs (train_iteration)
         self.real_all = torch.zeros((N_CRITIC, b, OUTPUT_DIM), dtype=torch.uint8, device=self.device)
         self.labels_all = torch.zeros((N_CRITIC, b), dtype=torch.int32, device=self.device)
-        self.fake_all = torch.zeros((N_CRITIC, b, OUTPUT_DIM), dtype=torch.bfloat16, device=self.device)
+        self.fake_all = torch.zeros((N_CRITIC, b, OUTPUT_DIM), dtype=K.BF16, device=self.device)
         # the critic's input of one update, laid out by ONE launch from slot `feed_slot` of the ring above
-        self.both = torch.zeros((2 * b, OUTPUT_DIM), dtype=torch.bfloat16, device=self.device)
+        self.both = torch.zeros((2 * b, OUTPUT_DIM), dtype=K.BF16, device=self.device)
         self.both_labels = torch.zeros(2 * b, dtype=torch.int32, device=self.device)
         self.feed_slot = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.feed_done = torch.zeros(1, dtype=torch.int32, device=self.device)

@@ -5,7 +5,14 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, os.environ.get("GANK_LIB_NAME", "libgank.so"))   # GANK_LIB_NAME: experiment builds
+# GANK_DTYPE = bf16 (default) | fp16: the element type of activations / MFMA operands for this PROCESS.  The two are separate
+# builds of the same kernels (libgank.so, libgank_f16.so: gank_act_dtype()); everything above the C ABI takes the matching
+# torch dtype from ACT_DTYPE_NAME (kernels.BF16).
+DTYPE = os.environ.get("GANK_DTYPE", "bf16").lower()
+if DTYPE not in ("bf16", "fp16"):
+    raise RuntimeError(f"GANK_DTYPE={DTYPE!r}: bf16 or fp16")
+ACT_DTYPE_NAME = "bfloat16" if DTYPE == "bf16" else "float16"
+LIB_PATH = os.path.join(_HERE, os.environ.get("GANK_LIB_NAME", "libgank.so" if DTYPE == "bf16" else "libgank_f16.so"))   # GANK_LIB_NAME: experiment builds
 
 P, I, L, F = C.c_void_p, C.c_int, C.c_long, C.c_float
 
@@ -34,6 +41,7 @@ class PrepDesc(C.Structure):
 # name -> argument ctypes (all return int unless listed in _RET)
 PROTOTYPES = {
     "gank_version": [],
+    "gank_act_dtype": [],
     "gank_last_error": [],
     "gank_conv2d_prep_weights": [P, P, P, I, I, I, P],
     "gank_conv2d_prep_weights_batched": [C.POINTER(PrepDesc), I, P],
@@ -157,6 +165,8 @@ def load():
             raise RuntimeError(f"libgank.so does not export {name}; rebuild it") from e
         fn.argtypes = args
         fn.restype = _RET.get(name, C.c_int)
+    if lib.gank_act_dtype() != (1 if DTYPE == "fp16" else 0):
+        raise RuntimeError(f"{LIB_PATH} was built for {'fp16' if lib.gank_act_dtype() else 'bf16'} buffers, this process runs GANK_DTYPE={DTYPE}")
     _lib = lib
     return lib
 

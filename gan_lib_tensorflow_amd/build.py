@@ -21,8 +21,24 @@ def _newer(a, b):
     return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(force=False, verbose=True):
-    objdir = "_obj" + ("_" + os.environ["GANK_LIB_NAME"] if "GANK_LIB_NAME" in os.environ else "")
+def build(force=False, verbose=True, variants=("bf16", "fp16")):
+    """libgank.so (bfloat16 buffers) and libgank_f16.so (IEEE half: the same sources with -DGANK_ACT_F16); returns the first path"""
+    paths = [_build_one(force, verbose, v) for v in variants]
+    return paths[0]
+
+
+def _build_one(force, verbose, variant):
+    global LIB, FLAGS
+    base_flags = [f for f in FLAGS if f != "-DGANK_ACT_F16"]
+    if variant == "fp16":
+        lib, flags, objdir = os.path.join(HERE, "libgank_f16.so"), base_flags + ["-DGANK_ACT_F16"], "_obj_f16"
+    else:
+        lib, flags = os.path.join(HERE, os.environ.get("GANK_LIB_NAME", "libgank.so")), base_flags
+        objdir = "_obj" + ("_" + os.environ["GANK_LIB_NAME"] if "GANK_LIB_NAME" in os.environ else "")
+    return _compile(force, verbose, lib, flags, objdir)
+
+
+def _compile(force, verbose, LIB, FLAGS, objdir):
     os.makedirs(os.path.join(HERE, objdir), exist_ok=True)
     hdrs = [os.path.join(CSRC, "gank_common.h"), os.path.join(INC, "gank.h")]
     objs, procs = [], []

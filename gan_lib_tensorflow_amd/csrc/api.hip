@@ -18,6 +18,7 @@ int gank_set_error(const char* fmt, ...) {
 
 extern "C" const char* gank_last_error(void) { return g_err; }
 extern "C" int gank_version(void) { return GANK_VERSION; }
+extern "C" int gank_act_dtype(void) { return GANK_ACT_DTYPE; }
 
 // ---- profiler: one (start, stop) event pair per launch of a kernel family, recorded on the launch
 // stream.  Off by default; never active during graph capture (bench.py enables it for one eager pass).

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
       for (int i = 0; i < TN; i++)
 #pragma unroll
         for (int j = 0; j < TM; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = GANK_MFMA32(fa[i], fb[j], acc[i][j]);
     }
     if constexpr (PF == 1) {
       if (s + 1 < a.nsteps) {
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
         for (int i = 0; i < TN; i++)
 #pragma unroll
           for (int j = 0; j < TM; j++)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = GANK_MFMA32(fa[i], fb[j], acc[i][j]);
       }
       if (s < last) store_w(buf ^ 1);
       __syncthreads();
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(256) void conv_igemm_patch2_kernel(IgemmArgs a) {
       for (int i = 0; i < 2; i++) {
         const bf16x8 fa = __builtin_bit_cast(bf16x8, rW[tap % PFW][i][kk]);
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[t & 1][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; j++) acc[i][j] = GANK_MFMA32(fa, fb[t & 1][j], acc[i][j]);
       }
       if (kk == 3) {
         load_w(rW[tap % PFW], c * 9 + tap + PFW);        // this slot is consumed: refill it PFW steps ahead
@@ -920,7 +920,7 @@ __global__ __launch_bounds__(256) void conv_narrow_in_kernel(IgemmArgs a) {
 #pragma unroll
     for (int kk = 0; kk < 2; kk++) {
       const bf16x8 fa = *reinterpret_cast<const bf16x8*>(wr + kk * 16);
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[kk], acc[i], 0, 0, 0);
+      acc[i] = GANK_MFMA32(fa, fb[kk], acc[i]);
     }
   }
   // Epilogue.  The accumulator layout (lane = pixel, registers = channels) would store 8 bytes per lane into 64
@@ -1197,7 +1197,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
         for (int i = 0; i < 2; i++)
 #pragma unroll
           for (int j = 0; j < 4; j++)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+            acc[i][j] = GANK_MFMA32(fa[i][kk], fb[j][kk], acc[i][j]);
       __builtin_amdgcn_sched_barrier(0);
       rslot += PP_WSLOT_BYTES; if (rslot == PP_NSLOT * PP_WSLOT_BYTES) rslot = 0;
       wslot += PP_WSLOT_BYTES; if (wslot == PP_NSLOT * PP_WSLOT_BYTES) wslot = 0;

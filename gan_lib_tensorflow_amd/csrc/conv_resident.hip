@@ -88,7 +88,7 @@ __device__ __forceinline__ void res_conv3x3(f32x16 (&acc)[TPW], u32x4 (&ring)[PF
     for (int t = 0; t < TPW; t++) {
       u32x4 bv = bq[s % (PB + 1)][t];
       if constexpr (RELU) bv = relu_bf16x8(bv);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, bv), acc[t], 0, 0, 0);
+      acc[t] = GANK_MFMA32(fa, __builtin_bit_cast(bf16x8, bv), acc[t]);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (s + PF < RB_STEPS) ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, wbase + (s + PF) * 1024, 0);
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(512) void cpool_res_fprop_kernel(CpFwdArgs a) {
       const bf16x8 fa = __builtin_bit_cast(bf16x8, ring[s % PF]);
       __builtin_amdgcn_sched_barrier(0);                                    // see res_conv3x3: keeps reads early and the ring deep
 #pragma unroll
-      for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, bq[s % (PB + 1)][t], acc[t], 0, 0, 0);
+      for (int t = 0; t < TPW; t++) acc[t] = GANK_MFMA32(fa, bq[s % (PB + 1)][t], acc[t]);
       __builtin_amdgcn_sched_barrier(0);
       {
         const int nx = step + PF;
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(512) void cpool_res_dgrad_kernel(CpBwdArgs a) {
       const bf16x8 fa = __builtin_bit_cast(bf16x8, ring[s % PF]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, bq[s % (PB + 1)][t], acc[t], 0, 0, 0);
+      for (int t = 0; t < TPW; t++) acc[t] = GANK_MFMA32(fa, bq[s % (PB + 1)][t], acc[t]);
       __builtin_amdgcn_sched_barrier(0);
       {
         const int nx = s + PF;

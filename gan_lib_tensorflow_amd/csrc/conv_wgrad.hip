@@ -232,7 +232,7 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_kernel(WgradArgs a) {
         for (int i = 0; i < TA; i++)
 #pragma unroll
           for (int j = 0; j < TB; j++)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = GANK_MFMA32(fa[i], fb[j], acc[i][j]);
       }
       if (s + 1 < nsteps) {
         if constexpr (PF == 1) load_step(s + 1, rA[0], rB[0], okA[0], okB[0]);
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_lean_kernel(WgradArgs 
       for (int i = 0; i < TA; i++)
 #pragma unroll
         for (int j = 0; j < TB; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = GANK_MFMA32(fa[i], fb[j], acc[i][j]);
     }
     if (s + 1 < nsteps) {
       if constexpr (PF == 1) load_next(rA[0], rB[0]);
@@ -684,8 +684,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_packed_kernel(WgradArgs a) {
       const s16x8 tw8 = {wl[0], wl[1], wl[2], wl[3], wh[0], wh[1], wh[2], wh[3]};
       const bf16x8 fn = __builtin_bit_cast(bf16x8, tn), fw = __builtin_bit_cast(bf16x8, tw8);
       // rows (MFMA A) = ci side, cols (MFMA B, lanes) = co side
-      if constexpr (PACK_X) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fn, fw, acc, 0, 0, 0);
-      else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw, fn, acc, 0, 0, 0);
+      if constexpr (PACK_X) acc = GANK_MFMA32(fn, fw, acc);
+      else acc = GANK_MFMA32(fw, fn, acc);
     }
     if (s + 1 < nsteps) store_step(buf ^ 1);
     __syncthreads();
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_taps_kernel(WgradArgs a) {
         const int o = ((2 * kk + 1 + dh) * 10 + 1 + dw) * 32;
         const s16x4 al = lds_tr_read(pX + o), ah = lds_tr_read(pX + o + 4 * 32);
         const s16x8 ta = {al[0], al[1], al[2], al[3], ah[0], ah[1], ah[2], ah[3]};
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ta), fb, acc[t], 0, 0, 0);
+        acc[t] = GANK_MFMA32(__builtin_bit_cast(bf16x8, ta), fb, acc[t]);
       }
     }
     if (s + 1 < nsteps) store_step(buf ^ 1, rX[(D + 1) % PF], rD[(D + 1) % PF]);
@@ -1183,7 +1183,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs a) {
         const int o = S2 ? (2 * kk * COLS + (t & 1) * (COLS / 2) + (t >> 1)) * 32 : (2 * kk * COLS + t) * 32;
         const s16x4 al = lds_tr_read(pX + o), ah = lds_tr_read(pX + o + 4 * 32);
         const s16x8 ta = {al[0], al[1], al[2], al[3], ah[0], ah[1], ah[2], ah[3]};
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ta), fb, acc[t], 0, 0, 0);
+        acc[t] = GANK_MFMA32(__builtin_bit_cast(bf16x8, ta), fb, acc[t]);
       }
     }
     if (s + 1 < nsteps) store_step(buf ^ 1, rX[(D + 1) % PF], rD[(D + 1) % PF]);

@@ -9,10 +9,26 @@
 
 #include "../../include/gank.h"
 
+// The 16-bit element type of activations, activation gradients and MFMA operands.  The library is built twice from the
+// same sources: libgank.so with bfloat16 (default) and libgank_f16.so with IEEE half (-DGANK_ACT_F16: the same kernels on
+// v_mfma_f32_32x32x16_f16, fp32 accumulation either way).  The type keeps the name `bf16` in the sources: every conversion
+// goes through bf2f / f2bf, every matrix instruction through GANK_MFMA32, and nothing else depends on the encoding (the
+// packed relu is a signed 16-bit max: the sign bit sits in the same place; LDS transposes and DMA move raw 16-bit lanes).
+#ifdef GANK_ACT_F16
+typedef _Float16 bf16;
+typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 bf16x2 __attribute__((ext_vector_type(2)));
+#define GANK_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define GANK_ACT_DTYPE 1
+#else
 typedef __bf16 bf16;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#define GANK_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define GANK_ACT_DTYPE 0
+#endif
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

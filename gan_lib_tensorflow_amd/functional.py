@@ -13,7 +13,7 @@ from torch.autograd import Function
 
 from . import kernels as K
 
-BF16 = torch.bfloat16
+BF16 = K.BF16
 # register-weight patch kernel (prep kind 3, GANK_W_FRAG) for the plain 3x3 convs at 16x16 / 32x32: measured equal to
 # the LDS-weight patch kernel within 2 % either way (both sit at ~75 % of what a bare MFMA loop reaches on this
 # chip under DVFS), so the simpler operand layout stays the default

@@ -20,7 +20,7 @@ from torch.autograd import Function
 
 from . import kernels as K
 
-BF16 = torch.bfloat16
+BF16 = K.BF16
 
 
 def _c(t):

@@ -8,7 +8,8 @@ import torch
 from . import _lib
 from ._lib import IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, W_FRAG, RES_UPSAMPLE2X, STATS_PREZEROED, SnDesc, PrepDesc, WgradItem  # noqa: F401
 
-BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
+# BF16 = the 16-bit activation dtype of this process: torch.bfloat16, or torch.float16 under GANK_DTYPE=fp16 (libgank_f16.so)
+BF16, F32, I32 = getattr(torch, _lib.ACT_DTYPE_NAME), torch.float32, torch.int32
 
 
 def _stream():

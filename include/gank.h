@@ -42,6 +42,9 @@ extern "C" {
                                   materialising the upsampled tensor */
 
 int gank_version(void);
+/* element type of every `bf16` buffer of THIS library: 0 = bfloat16 (libgank.so), 1 = IEEE half (libgank_f16.so: the same sources
+ * built with -DGANK_ACT_F16 -- identical entry points, v_mfma_f32_32x32x16_f16 instead of ..._bf16, fp32 accumulation either way) */
+int gank_act_dtype(void);
 const char* gank_last_error(void);
 
 /* ---- weight preparation: fp32 HWIO master/normalised filter -> bf16 MFMA operand layouts --------

@@ -1,0 +1,132 @@
+"""Runs in its own process with GANK_DTYPE=fp16 (libgank_f16.so: the same kernels built for IEEE-half buffers and
+v_mfma_f32_32x32x16_f16): convolution kernels of every family, conditional batch norm, and the SNGAN networks with both
+losses and their gradients against the float64 oracle on fp16-rounded inputs.  Prints one `ok ...` line per check; exits
+non-zero on the first failure.  Started by tests/test_fp16_gpu.py."""
+import os
+import sys
+
+assert os.environ.get("GANK_DTYPE") == "fp16"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from gan_lib_tensorflow_amd import _lib, kernels as K  # noqa: E402
+from gan_lib_tensorflow_amd import functional as Fn  # noqa: E402
+from oracle import ref_ops as R  # noqa: E402
+from oracle import ref_torch as T  # noqa: E402
+
+assert K.BF16 is torch.float16 and _lib.load().gank_act_dtype() == 1 and _lib.LIB_PATH.endswith("libgank_f16.so")
+HALF_TOL, F32_TOL = 2e-3, 5e-4          # half: 11-bit significand (bf16: 8): tighter than the bf16 tests' 1e-2 / 2e-3
+
+
+def h(a):
+    t = torch.tensor(np.asarray(a, np.float32)).to(torch.float16)
+    return t.to(torch.float64).numpy(), t.cuda().contiguous()
+
+
+def relerr(got, ref):
+    got = got.detach().to(torch.float64).cpu().numpy()
+    assert np.isfinite(got).all()
+    return np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-300)
+
+
+rng = np.random.default_rng(0)
+# ---- convolution engines: two-group LDS-DMA kernel, LDS-patch kernel, generic, narrow input, phase form, all-taps / filter-row wgrad
+for name, (n, hw, cin, cout, k) in {"two-group": (64, 32, 256, 256, 3), "patch": (8, 16, 256, 128, 3), "generic 8x8": (4, 8, 128, 128, 3),
+                                    "1x1": (4, 8, 256, 128, 1), "narrow input": (4, 32, 3, 128, 3)}.items():
+    x, xt = h(rng.normal(size=(n, hw, hw, cin)))
+    w, _ = h(rng.normal(size=(k, k, cin, cout)) / np.sqrt(k * k * cin))
+    b = rng.normal(size=cout).astype(np.float32)
+    wt = torch.tensor(w, dtype=torch.float32).cuda()
+    wf, wd = K.prep_weights(wt, True, True)
+    K.prof_enable(True); K.prof_reset()
+    y = K.conv2d_fprop(xt, wf, torch.tensor(b).cuda(), (hw, hw), cout, k)
+    torch.cuda.synchronize()
+    ran = [r[0] for r in K.prof_kernels(0)]
+    K.prof_enable(False)
+    if n * hw * hw <= 4096:
+        ref = R.conv2d_same(x, w, b.astype(np.float64))
+        assert relerr(y, ref) < HALF_TOL, (name, relerr(y, ref))
+        dy, dyt = h(rng.normal(size=ref.shape))
+        rdx, rdw, _ = R.conv2d_same_grads(x, w, dy)
+        assert relerr(K.conv2d_dgrad(dyt, wd, (hw, hw), cin, k), rdx) < HALF_TOL, name
+        dw = K.conv2d_wgrad(xt, dyt, torch.zeros_like(wt), (hw, hw), k)
+        assert relerr(dw, rdw) < F32_TOL, (name, relerr(dw, rdw))
+    else:       # the large shape: against torch-CPU float64 conv on a slice of the batch
+        ref = T.conv2d_same(torch.tensor(x[:2]), torch.tensor(w), torch.tensor(b.astype(np.float64))).numpy()
+        assert relerr(y[:2], ref) < HALF_TOL, (name, relerr(y[:2], ref))
+    print("ok conv", name, ran[:1], flush=True)
+x, xt = h(rng.normal(size=(4, 8, 8, 128)))
+w, _ = h(rng.normal(size=(3, 3, 128, 256)) / 34.)
+wph, _ = K.upconv3x3_prep(torch.tensor(w, dtype=torch.float32).cuda())
+assert relerr(K.upconv3x3_fprop(xt, wph, None, 256), R.conv2d_same(R.upsample_nn2x(x), w)) < 2 * HALF_TOL     # the summed taps are rounded once more
+print("ok upconv phase form", flush=True)
+x, xt = h(rng.normal(size=(64, 16, 16, 256)))
+dy, dyt = h(rng.normal(size=(64, 16, 16, 256)))
+dw = K.conv2d_wgrad(xt, dyt, torch.zeros((3, 3, 256, 256), dtype=torch.float32, device="cuda"), (16, 16), 3)
+xr, dyr = torch.tensor(x), torch.tensor(dy)
+wr = torch.zeros(3, 3, 256, 256, dtype=torch.float64, requires_grad=True)
+(T.conv2d_same(xr, wr) * dyr).sum().backward()
+assert relerr(dw, wr.grad.numpy()) < F32_TOL
+print("ok wgrad all-taps", flush=True)
+# ---- conditional batch norm (statistics in fp32)
+x, xt = h(rng.normal(size=(8, 8, 8, 256)) * 2 + 0.5)
+labels = rng.integers(0, 10, 8)
+gamma = (1 + 0.2 * rng.normal(size=(10, 256))).astype(np.float32)
+beta = (0.1 * rng.normal(size=(10, 256))).astype(np.float32)
+y, stats = K.cbn_fwd(xt, torch.tensor(labels, dtype=torch.int32).cuda(), torch.tensor(gamma).cuda(), torch.tensor(beta).cuda(), 2, True)
+ry, _ = R.cond_batchnorm_forward(x, labels, gamma.astype(np.float64), beta.astype(np.float64), 2)
+assert relerr(y, R.relu(ry)) < HALF_TOL
+print("ok cond_batchnorm", flush=True)
+# ---- the SNGAN networks, both losses, every gradient (batch 8: two towers of 4), and training iterations
+from gan_lib_tensorflow_amd.SNGAN import gan_cifar_resnet as S  # noqa: E402
+tr = S.SNGANTrainer(batch_size=4, seed=11, use_graphs=False)
+state = tr.store.state_dict()
+P = T.to_torch(state)
+b = 4
+z, zt = h(rng.normal(size=(b, 128)))
+labels = torch.tensor(rng.integers(0, 10, b), dtype=torch.int32)
+real_u8 = torch.tensor(rng.integers(0, 256, (b, 3072)), dtype=torch.uint8)
+real_pre = T.preprocess_real(real_u8, torch.zeros(b, 3072, dtype=torch.float64), torch.float64)
+real_pre = real_pre.to(torch.float16).to(torch.float64)
+loss_ref, _, _ = T.d_loss_fn(P, None, labels.long(), torch.tensor(z), None, towers=2, real_pre=real_pre)
+dn = T.trainable_names(P, 'Discriminator')
+gref = dict(zip(dn, torch.autograd.grad(loss_ref, [P[k] for k in dn])))
+tr.real_labels.copy_(labels)
+tr._d_forward_backward(real_pre=real_pre.to(torch.float16).cuda(), z=zt)
+torch.cuda.synchronize()
+assert abs(float(tr.d_loss) - float(loss_ref)) < 0.02, (float(tr.d_loss), float(loss_ref))
+worst = 1.0
+for k in dn:
+    g, r = tr.store.vars[k].main_grad.double().cpu().flatten(), gref[k].flatten()
+    if float(r.norm()) > 0:
+        worst = min(worst, float((g @ r) / (g.norm() * r.norm())))
+assert worst > 0.99, worst
+print(f"ok SNGAN critic loss + gradients (worst cosine {worst:.4f})", flush=True)
+P = T.to_torch(tr.store.state_dict())
+z2, z2t = h(rng.normal(size=(2 * b, 128)))
+fl = torch.tensor(rng.integers(0, 10, 2 * b), dtype=torch.int32)
+loss_ref, _ = T.g_loss_fn(P, torch.tensor(z2), fl.long())
+gn = T.trainable_names(P, 'Generator')
+gref = dict(zip(gn, torch.autograd.grad(loss_ref, [P[k] for k in gn])))
+tr._g_forward_backward(z=z2t, fake_labels=fl.cuda())
+torch.cuda.synchronize()
+assert abs(float(tr.g_loss) - float(loss_ref)) < 0.02
+worst = 1.0
+for k in gn:
+    if k.endswith('Biases') and 'G.Output' not in k:
+        continue                                     # exactly-zero true gradient (feeds a batch norm)
+    g, r = tr.store.vars[k].main_grad.double().cpu().flatten(), gref[k].flatten()
+    worst = min(worst, float((g @ r) / (g.norm() * r.norm())))
+assert worst > 0.98, worst
+print(f"ok SNGAN generator loss + gradients (worst cosine {worst:.4f})", flush=True)
+tr2 = S.SNGANTrainer(batch_size=16, seed=3, use_graphs=True)
+feed = S.synthetic_batches(16, "cuda", seed=1)
+for _ in range(4):
+    tr2.train_iteration(feed)
+torch.cuda.synchronize()
+assert tr2.use_graphs and all(bool(torch.isfinite(tr2.store.flat[n]["params"]).all()) for n in ("Generator", "Discriminator"))
+assert np.isfinite(float(tr2.d_loss)) and np.isfinite(float(tr2.g_loss))
+print(f"ok SNGAN training iterations under hipGraph replay (d_loss {float(tr2.d_loss):.3f}, g_loss {float(tr2.g_loss):.3f})", flush=True)
+print("FP16 PATH OK", flush=True)
