@@ -10,9 +10,10 @@
  *   - every pointer is a DEVICE pointer owned by the caller (torch); the caller allocates outputs
  *     and workspaces; nothing here allocates, frees or synchronises (hipGraph-capturable);
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it asynchronously;
- *   - activations are bf16, NHWC; master weights, gradients of weights, statistics, losses and
- *     optimiser state are fp32; conv filters are HWIO ([k,k,Cin,Cout]); linear weights [in,out];
- *     labels are int32;
+ *   - activations (and every buffer documented as "bf16") are 16-bit floats, NHWC: bfloat16 in libgank.so, IEEE half in
+ *     libgank_f16.so -- the same sources and the same entry points built twice (gank_act_dtype()), MFMA bf16 / f16 tiles with
+ *     fp32 accumulation; master weights, gradients of weights, statistics, losses and optimiser state are fp32; conv filters
+ *     are HWIO ([k,k,Cin,Cout]); linear weights [in,out]; labels are int32;
  *   - return value 0 = launched, non-zero = argument/launch error, message in gank_last_error();
  *   - thread-compatible: no global mutable state besides the per-thread error string and the
  *     opt-in profiling event pool (gank_prof_*).
