@@ -22,51 +22,47 @@ def _newer(a, b):
 
 
 def build(force=False, verbose=True, variants=("bf16", "fp16")):
-    """libgank.so (bfloat16 buffers) and libgank_f16.so (IEEE half: the same sources with -DGANK_ACT_F16); returns the first path"""
-    paths = [_build_one(force, verbose, v) for v in variants]
-    return paths[0]
-
-
-def _build_one(force, verbose, variant):
-    global LIB, FLAGS
+    """libgank.so (bfloat16 buffers) and libgank_f16.so (IEEE half: the same sources with -DGANK_ACT_F16); returns the first
+    path.  Every out-of-date object of BOTH variants compiles concurrently (one hipcc process per source file)."""
     base_flags = [f for f in FLAGS if f != "-DGANK_ACT_F16"]
-    if variant == "fp16":
-        lib, flags, objdir = os.path.join(HERE, "libgank_f16.so"), base_flags + ["-DGANK_ACT_F16"], "_obj_f16"
-    else:
-        lib, flags = os.path.join(HERE, os.environ.get("GANK_LIB_NAME", "libgank.so")), base_flags
-        objdir = "_obj" + ("_" + os.environ["GANK_LIB_NAME"] if "GANK_LIB_NAME" in os.environ else "")
-    return _compile(force, verbose, lib, flags, objdir)
-
-
-def _compile(force, verbose, LIB, FLAGS, objdir):
-    os.makedirs(os.path.join(HERE, objdir), exist_ok=True)
     hdrs = [os.path.join(CSRC, "gank_common.h"), os.path.join(INC, "gank.h")]
-    objs, procs = [], []
-    for src in SOURCES:
-        sp = os.path.join(CSRC, src)
-        op = os.path.join(HERE, objdir, src.replace(".hip", ".o"))
-        objs.append(op)
-        if force or _newer(sp, op) or any(_newer(h, op) for h in hdrs):
-            cmd = ["hipcc", *FLAGS, "-I", INC, "-c", sp, "-o", op]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    plans = []
+    for variant in variants:
+        if variant == "fp16":
+            lib, flags, objdir = os.path.join(HERE, "libgank_f16.so"), base_flags + ["-DGANK_ACT_F16"], "_obj_f16"
+        else:
+            lib, flags = os.path.join(HERE, os.environ.get("GANK_LIB_NAME", "libgank.so")), base_flags
+            objdir = "_obj" + ("_" + os.environ["GANK_LIB_NAME"] if "GANK_LIB_NAME" in os.environ else "")
+        os.makedirs(os.path.join(HERE, objdir), exist_ok=True)
+        objs, procs = [], []
+        for src in SOURCES:
+            sp = os.path.join(CSRC, src)
+            op = os.path.join(HERE, objdir, src.replace(".hip", ".o"))
+            objs.append(op)
+            if force or _newer(sp, op) or any(_newer(h, op) for h in hdrs):
+                cmd = ["hipcc", *flags, "-I", INC, "-c", sp, "-o", op]
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        plans.append((lib, objs, procs))
     failed = False
-    for src, p in procs:
-        out = p.communicate()[0].decode()
-        if out.strip() and verbose:
-            print(out)
-        if p.returncode != 0:
-            print(out, file=sys.stderr)
-            failed = True
+    for _, _, procs in plans:
+        for src, p in procs:
+            out = p.communicate()[0].decode()
+            if out.strip() and verbose:
+                print(out)
+            if p.returncode != 0:
+                print(out, file=sys.stderr)
+                failed = True
     if failed:
         raise RuntimeError("hipcc failed")
-    if force or procs or not os.path.exists(LIB):
-        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-    return LIB
+    for lib, objs, procs in plans:
+        if force or procs or not os.path.exists(lib):
+            cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    return plans[0][0]
 
 
 if __name__ == "__main__":

@@ -290,6 +290,11 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_kernel(WgradArgs a) {
 // bit2 dy stored at half size), PF-slot register ring with no exits inside the unrolled body.
 // Sub-tiles are 64 B apart mod 256 B so the ds_write_b128 of one pixel's 128 channels is conflict-free.
 // ------------------------------------------------------------------------------------------------------
+static int wgrad_round_down_env() {
+  static int v = -1;   // experiment knob: GANK_WGRAD_ROUND_DOWN=0 restores ceil(target / tiles) pixel splits
+  if (v < 0) { const char* e = getenv("GANK_WGRAD_ROUND_DOWN"); v = e ? atoi(e) : 1; }
+  return v;
+}
 constexpr int SUBS = 2048 + 32;   // sub-tile stride in bf16 elements
 
 template <int WA, int WB, int TA, int TB, int PF, int MODE>
@@ -1250,7 +1255,8 @@ static int launch_wgrad_rows(WgradArgs a, hipStream_t s) {
   const int tiles = a.tiles_ci * a.tiles_co * 3 * nb;
   static int target = -1;   // experiment knob
   if (target < 0) { const char* e = getenv("GANK_WGRAD_ROWS_TARGET"); target = e ? atoi(e) : 256; }
-  int splits = (target + tiles - 1) / tiles;
+  // at most `target` workgroups: 6 splits x 48 tiles = 288 blocks ran as two rounds on 256 CUs (31 us), 5 x 48 = 240 as one
+  int splits = wgrad_round_down_env() ? target / tiles : (target + tiles - 1) / tiles;
   if (splits > total_steps / 4) splits = total_steps / 4;
   if (splits < 1) splits = 1;
   a.steps_per_split = cdiv(total_steps, splits);
@@ -1450,7 +1456,7 @@ static void wgrad_cpool_rows_geometry(WgradArgs& a) {
   const int tiles = a.tiles_ci * a.tiles_co * 4;
   static int target = -1;   // experiment knob
   if (target < 0) { const char* e = getenv("GANK_CPOOL_ROWS_TARGET"); target = e ? atoi(e) : 256; }
-  int splits = (target + tiles - 1) / tiles;
+  int splits = wgrad_round_down_env() ? target / tiles : (target + tiles - 1) / tiles;
   if (splits > total_steps / 4) splits = total_steps / 4;
   if (splits < 1) splits = 1;
   a.steps_per_split = cdiv(total_steps, splits);
