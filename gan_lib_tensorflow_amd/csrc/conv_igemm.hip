@@ -194,14 +194,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
       for (int j = 0; j < CP; j++) {
         const int cc = (tid + NT * j) & 7;
         const int kb = cur * 64 + cc * 8;
+        // (tap, channel) of the chunk's first k by ONE division, then counted up: three run-time divisions per ELEMENT made
+        // this gather 290 us for a 1.2-GFLOP layer (PGGAN's 513-channel conv behind minibatch-std)
+        int tap = kb / a.Cin, ci = kb - tap * a.Cin;
+        int th = tap / a.ks;
+        int dh = th - a.pad, dw = tap - th * a.ks - a.pad;
         bf16x8 v;
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-          const int k = kb + e;
           float val = 0.f;
-          if (k < ktot) {
-            const int tap = k / a.Cin, ci = k - tap * a.Cin;
-            const int dh = tap / a.ks - a.pad, dw = tap % a.ks - a.pad;
+          if (kb + e < ktot) {
             int ih = p_oh[j] + dh, iw = p_ow[j] + dw;
             bool ok = (unsigned)ih < (unsigned)LH && (unsigned)iw < (unsigned)LW;
             if (zins) ok = ok && (((ih | iw) & 1) == 0);
@@ -212,6 +214,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
             }
           }
           v[e] = f2bf(val);
+          if (++ci == a.Cin) {            // next tap
+            ci = 0;
+            if (++dw > a.ks - 1 - a.pad) { dw = -a.pad; dh++; }
+          }
         }
         rP[j] = __builtin_bit_cast(u32x4, v);
       }
