@@ -154,6 +154,27 @@ def test_pggan_model_losses_gradients_vs_oracle(gpu, bc, trans):
     assert all(float(tr.store.vars[k].main_grad.abs().max()) == 0.0 for k in dn)     # gen_cost moves g_vars only (train.py:132)
 
 
+def test_pggan_full_resolution_forward_vs_oracle(gpu):
+    """BASELINE.json config 4 at its last stage: block_count 6 = 256 x 256 (channels 512,512,512,256,128,64), generator images
+    and critic logits against the float64 restatement (forward only: the float64 backward pass of this size takes minutes)."""
+    bc, trans, batch, alpha = 6, True, 2, 0.6
+    tr, state = make(bc, trans, batch, seed=9)
+    P = T.to_torch(state, requires_grad=False)
+    rng = np.random.default_rng(6)
+    z, zt = bf(rng.normal(size=(batch, 512)))
+    with torch.no_grad():
+        img = tr.model.get_generator(zt, alpha, reuse=True)
+        img_ref = G.generator(P, z, alpha, bc, trans)
+        lg = tr.model.get_discriminator(img, alpha, update_collection='NO_OPS', reuse=True)
+        lg_ref, _ = G.discriminator(P, img.double().cpu(), alpha, bc, trans)
+    assert img.shape == (batch, 256, 256, 3)
+    scale = max(1.0, float(img_ref.abs().max()))
+    d = (img.double().cpu() - img_ref).abs()
+    print("pggan 256x256 image max |delta|", float(d.max()), "mean", float(d.mean()), "range", scale)
+    assert float(d.max()) < 3e-2 * scale and float(d.mean()) < 3e-3 * scale
+    assert float((lg.double().cpu() - lg_ref).abs().max()) < 3e-2 * max(1.0, float(lg_ref.abs().max()))
+
+
 def test_pggan_training_steps(gpu):
     """train.py:185-193 at the 16x16 stage with a block fading in: 1 generator + 5 critic updates per step, alpha = step /
     max_iter, real rows resized 32 -> 8 -> 16; parameters move by at most ~lr per update and stay finite."""
