@@ -19,6 +19,7 @@ MI355X-first structure
 import contextlib
 import gc
 import math
+import os as _os
 
 import numpy as np
 import torch
@@ -30,6 +31,7 @@ from ..common import resnet_block as blocks
 from ..common.ops import embedding as _embedding
 from ..common.ops import linear as _linear
 from ..common.ops import conv2d as _conv2d
+from ..common.ops import normalization as _normalization
 from ..common.ops import sn as _sn
 from ..common.ops.sn import NO_OPS
 from ..store import ParamStore, get_default_store, set_default_store
@@ -81,6 +83,17 @@ def Generator(n_samples_, labels, noise=None, reuse=False, groups=1, rng_state=N
         output = Fn.boundary(output, 'G.Block.2')
         output = ResidualBlock(output, DIM_G * 2, DIM_G * 2, 3, 'G.Block.3', resample='up', labels=labels, biases=True, groups=groups, out_stats=groups)
         output = Fn.boundary(output, 'G.Block.3')
+        if (FUSE_OUTPUT_NORM and not torch.is_grad_enabled() and NORMALIZATION_G and blocks.CONDITIONAL and labels is not None
+                and output.is_cuda):
+            # a pass that keeps nothing for a backward pass (the critic's fakes, sampling): G.OutputNorm + relu ride on
+            # G.Output's operand staging -- the normalised 32x32x256 tensor (168 MB at 320 samples) is never written or read
+            with store.variable_scope('G.OutputNorm'):
+                gamma, beta = _normalization.cond_batchnorm_variables(DIM_G * 2, 10)
+            stats = K.cbn_stats(output, groups, getattr(output, '_cbn_stats', None))
+            filters, biases = _conv2d.conv2d_variables(DIM_G * 2, 3, 3, 1, 'G.Output', he_init=False)
+            wf, _ = Fn._prepared(filters, 3, DIM_G * 2, 3, True, False)
+            output = K.cbn_relu_conv3x3_fprop(output, labels, gamma.detach(), beta.detach(), stats, wf, biases.detach(), 3, K.OUT_TANH)
+            return output.reshape(-1, OUTPUT_DIM)
         output = Normalize('G.OutputNorm', output, labels, groups=groups, relu=True)    # + nonlinearity (:257-258)
         output = _conv2d.Conv2D(output, DIM_G * 2, 3, 3, 1, 'G.Output', he_init=False, out_tanh=True)  # + tanh (:260-261)
         return output.reshape(-1, OUTPUT_DIM)
@@ -93,6 +106,7 @@ def Generator(n_samples_, labels, noise=None, reuse=False, groups=1, rng_state=N
 # against 7.67 without -- the generator's one-workgroup-per-CU kernels push the critic's kernels off the CUs instead of
 # filling their gaps, and the split pass (64 + 256 samples) is less efficient than one pass over 320.  Kept as a knob
 # (GANK_OVERLAP_GEN=1), off by default.
+FUSE_OUTPUT_NORM = _os.environ.get("GANK_FUSE_OUTNORM", "1") == "1"    # no-grad passes: G.OutputNorm + relu inside G.Output's operand staging
 OVERLAP_GEN_WITH_CRITIC = False
 # Data parallel: the generator's gradient buffer (31.5 MB fp32) leaves in these buckets, last layers first, each as soon
 # as the backward pass has passed the block boundary below it (parallel.GradBuckets).  Forward / creation order.
@@ -128,7 +142,6 @@ def _g_prep_kind(name, W):
     return 0
 
 
-import os as _os
 FUSED_HEAD = _os.environ.get("GANK_FUSED_HEAD", "1") == "1"      # D.Output + hinge loss (+ the layer's three gradients) as one launch where the train step asks for it
 
 

@@ -83,6 +83,9 @@ PROTOTYPES = {
     "gank_pixel_norm_fwd": [P, P, L, I, F, P],
     "gank_pixel_norm_bwd": [P, P, P, L, I, F, P],
     "gank_cbn_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "gank_cbn_stats": [P, P, P, I, I, I, I, F, P],
+    "gank_cbn_stats_from_sums": [P, P, P, I, I, L, F, P],
+    "gank_cbn_relu_conv3x3_fprop": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P],
     "gank_cbn_bwd_remask": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     "gank_pool2x2": [P, P, P, I, I, I, I, F, P],
     "gank_unpool2x2_add": [P, P, P, I, I, I, I, F, P],

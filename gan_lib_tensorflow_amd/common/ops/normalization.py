@@ -6,6 +6,16 @@ from ... import functional as Fn
 from ...store import get_default_store
 
 
+def cond_batchnorm_variables(c, n_labels):
+    """The variable half of cond_batchnorm (normalization.py:43,49-51): `CondBatchNorm/{offset,scale}` [n_labels, c] under
+    the current scope; returns (scale, offset).  Shared with kernels that normalise inside a consumer."""
+    store = get_default_store()
+    with store.variable_scope('CondBatchNorm'):
+        offset_m = store.get_variable('offset', [n_labels, c], np.zeros((n_labels, c), 'float32'))
+        scale_m = store.get_variable('scale', [n_labels, c], np.ones((n_labels, c), 'float32'))
+    return scale_m, offset_m
+
+
 def cond_batchnorm(name, axes, inputs, is_training=None, stats_iter=None, update_moving_stats=True, fused=True,
                    labels=None, n_labels=None, groups=1, relu=False):
     """Conditional Batchnorm (dumoulin et al 2016) for BHWC conv filtermaps (normalization.py:27-59).

@@ -467,3 +467,40 @@ extern "C" int gank_cbn_bwd_remask(const void* dy, const void* x, const float* b
   GANK_REQUIRE(!relu || beta, "cbn_bwd_remask: relu backward needs beta");
   return cbn_bwd_impl(dy, x, nullptr, beta, labels, gamma, stats, dx, dgamma, dbeta, ws, N, HW, C, groups, n_labels, relu, stream);
 }
+
+// (mean, invstd) per tower and channel from the sums a conv epilogue accumulated (gank_conv2d_fprop_stats): what
+// cbn_apply_sums_kernel computes in its prologue, as a launch of its own for consumers that normalise inside another kernel
+__global__ void cbn_stats_from_sums_kernel(const float* __restrict__ sums, const float* __restrict__ shift, float* __restrict__ stats,
+                                           int C, int groups, float M, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, grp = blockIdx.y;
+  if (c >= C) return;
+  float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+  for (int sl = 0; sl < GANK_STAT_SLOTS; sl++) {
+    t1 += sums[(((long)grp * GANK_STAT_SLOTS + sl) * 2) * C + c];
+    t2 += sums[(((long)grp * GANK_STAT_SLOTS + sl) * 2 + 1) * C + c];
+  }
+  const float m1 = t1 / M, m2 = t2 / M;
+  stats[((long)grp * 2) * C + c] = m1 + (shift ? shift[c] : 0.f);
+  stats[((long)grp * 2 + 1) * C + c] = 1.f / sqrtf(fmaxf(m2 - m1 * m1, 0.f) + eps);
+}
+extern "C" int gank_cbn_stats_from_sums(const float* sums, const float* shift, float* stats, int C, int groups, long rows_per_group,
+                                        float eps, void* stream) {
+  GANK_REQUIRE(sums && stats && C > 0 && groups > 0 && rows_per_group > 0 && eps > 0.f, "cbn_stats_from_sums: bad arguments");
+  hipLaunchKernelGGL(cbn_stats_from_sums_kernel, dim3(cdiv(C, 256), groups), dim3(256), 0, (hipStream_t)stream, sums, shift, stats, C, groups,
+                     (float)rows_per_group, eps);
+  GANK_LAUNCH_OK("cbn_stats_from_sums");
+  return 0;
+}
+// the statistics pass alone (stats [groups][2][C]; ws as gank_cbn_fwd)
+extern "C" int gank_cbn_stats(const void* x, float* stats, float* ws, int N, int HW, int C, int groups, float eps, void* stream) {
+  GANK_REQUIRE(x && stats && ws, "cbn_stats: null pointer");
+  CbnGeom q;
+  if (cbn_geom(q, N, HW, C, groups, 1, 0)) return 1;
+  q.eps = eps;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(cbn_stats_kernel, dim3(groups * q.parts), dim3(CBN_NT), 0, s, (const bf16*)x, ws, q);
+  hipLaunchKernelGGL(cbn_finalize_kernel, dim3(cdiv(C, 16), groups), dim3(256), 0, s, ws, stats, q);
+  GANK_LAUNCH_OK("cbn_stats");
+  return 0;
+}

@@ -50,6 +50,13 @@ struct IgemmArgs {
   float* stat_sums;
   int stat_n_per_group, stat_groups, stat_prezeroed;
   int phase_inner;  // phase mode: block -> (tile, phase) with the phase fastest (default) or slowest
+  // patch kernel, MODE bit 3: the input is normalised on its way into LDS -- conditional batch norm + relu of the layer in
+  // front (normalization.py:47-57, gan_cifar_resnet.py:257-258) fused into this conv's operand staging
+  const float* cbn_stats;    // [groups][2][Cin] (mean, invstd)
+  const float* cbn_gamma;    // [n_labels][Cin]
+  const float* cbn_beta;
+  const int* cbn_labels;     // [N]
+  int cbn_n_per_group, cbn_n_labels;
 };
 
 static int phase_inner_env() {
@@ -523,17 +530,54 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
       *reinterpret_cast<u32x4*>(sW + (buf * BN + (q >> 3)) * LROW + (q & 7) * 8) = rW[j];
     }
   };
+  // MODE bit 3: y = relu((x - mean) * invstd * gamma[label] + beta[label]) applied to every in-image element while it is
+  // staged (the conditional batch norm + relu in front of this conv, in the forward kernel's own expression and order, so the
+  // operand is bit-identical to the tensor the unfused path would have stored); padding stays zero.  A thread's chunks all
+  // carry the same 8 channels of a 64-channel chunk (cc = tid & 7): 4 x 8 parameters per chunk, reloaded per chunk.
+  constexpr bool NORM = (MODE & 8) != 0;
+  f32x4 nm[NORM ? 8 : 1];
+  const float* np_mu = nullptr;
+  const float* np_ga = nullptr;
+  const float* np_be = nullptr;
+  if constexpr (NORM) {
+    int lb = a.cbn_labels[n];
+    lb = lb < 0 ? 0 : (lb >= a.cbn_n_labels ? a.cbn_n_labels - 1 : lb);
+    np_mu = a.cbn_stats + (long)(n / a.cbn_n_per_group) * 2 * a.Cin + (tid & 7) * 8;
+    np_ga = a.cbn_gamma + (long)lb * a.Cin + (tid & 7) * 8;
+    np_be = a.cbn_beta + (long)lb * a.Cin + (tid & 7) * 8;
+  }
   auto load_halo = [&](int c) {
 #pragma unroll
     for (int j = 0; j < 6; j++)
       rH[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, h_off[j] == OOB ? OOB : h_off[j] + c * 128, 0, 0);
+    if constexpr (NORM) {
+      nm[0] = *reinterpret_cast<const f32x4*>(np_mu + c * 64); nm[1] = *reinterpret_cast<const f32x4*>(np_mu + c * 64 + 4);
+      nm[2] = *reinterpret_cast<const f32x4*>(np_mu + a.Cin + c * 64); nm[3] = *reinterpret_cast<const f32x4*>(np_mu + a.Cin + c * 64 + 4);
+      nm[4] = *reinterpret_cast<const f32x4*>(np_ga + c * 64); nm[5] = *reinterpret_cast<const f32x4*>(np_ga + c * 64 + 4);
+      nm[6] = *reinterpret_cast<const f32x4*>(np_be + c * 64); nm[7] = *reinterpret_cast<const f32x4*>(np_be + c * 64 + 4);
+    }
   };
   auto store_halo = [&]() {
 #pragma unroll
     for (int j = 0; j < 6; j++) {
       if (h_lds[j] >= 0) {
         u32x4 v = rH[j];
-        if constexpr ((MODE & 1) != 0) v = relu_bf16x8(v);
+        if constexpr (NORM) {
+          if (h_off[j] != OOB) {
+            const bf16x8 xv = __builtin_bit_cast(bf16x8, v);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+              const float mu = e < 4 ? nm[0][e] : nm[1][e - 4], iv = e < 4 ? nm[2][e] : nm[3][e - 4];
+              const float ga = e < 4 ? nm[4][e] : nm[5][e - 4], be = e < 4 ? nm[6][e] : nm[7][e - 4];
+              const float t = (bf2f(xv[e]) - mu) * iv * ga + be;
+              o[e] = f2bf(fmaxf(t, 0.f));
+            }
+            v = __builtin_bit_cast(u32x4, o);
+          }
+        } else if constexpr ((MODE & 1) != 0) {
+          v = relu_bf16x8(v);
+        }
         *reinterpret_cast<u32x4*>(sP + h_lds[j]) = v;
       }
     }
@@ -1578,6 +1622,33 @@ extern "C" int gank_conv2d_fprop_stats(const void* x, const void* wf, const floa
   GANK_REQUIRE(stat_sums && produced, "conv2d_fprop_stats: null statistics pointers");
   const int rc = conv2d_fprop_impl(x, wf, bias, residual, relu_ref, y, N, H, W, Cin, Cout, ksize, flags, scale, stat_sums, groups, stream);
   *produced = tl_stats_done;
+  return rc;
+}
+
+// y = conv3x3_SAME(relu(cond_batchnorm(x))) + bias [tanh]: the normalisation rides on the conv's operand staging (patch
+// kernel, MODE bit 3) -- for passes that keep nothing for a backward pass (the fakes of the critic updates, sampling): the
+// normalised tensor is never written or read (G.OutputNorm + G.Output: 168 MB each way at 320 samples).
+extern "C" int gank_cbn_relu_conv3x3_fprop(const void* x, const int32_t* labels, const float* gamma, const float* beta, const float* stats,
+                                           const void* wf, const float* bias, void* y, int N, int H, int W, int Cin, int Cout,
+                                           int groups, int n_labels, int flags, void* stream) {
+  GANK_REQUIRE(x && labels && gamma && beta && stats && wf && y, "cbn_relu_conv3x3_fprop: null pointer");
+  GANK_REQUIRE(groups > 0 && N % groups == 0 && n_labels > 0, "cbn_relu_conv3x3_fprop: batch %d / %d towers", N, groups);
+  GANK_REQUIRE(Cin % 64 == 0 && W % 16 == 0 && H % 8 == 0, "cbn_relu_conv3x3_fprop: needs Cin %% 64 == 0, W %% 16 == 0, H %% 8 == 0");
+  IgemmArgs a{};
+  a.x = (const bf16*)x; a.w = (const bf16*)wf; a.bias = bias; a.y = (bf16*)y;
+  a.N = N; a.H = H; a.W = W; a.Hin = H; a.Win = W; a.Cin = Cin; a.Cout = Cout; a.ks = 3; a.pad = 1;
+  a.flags = flags & GANK_OUT_TANH;
+  a.scale = 1.f;
+  a.taps = 9; a.CoutPad = roundup(Cout, 32); a.Kpad = roundup(9 * Cin, 64); a.nsteps = a.Kpad / 64;
+  a.M = N * H * W; a.sw = log2_or_neg(W); a.shw = log2_or_neg(H * W);
+  GANK_REQUIRE(a.CoutPad == 32 || a.CoutPad % 128 == 0, "cbn_relu_conv3x3_fprop: Cout must pad to 32 or a multiple of 128 (got %d)", Cout);
+  GANK_REQUIRE((long)N * H * W * Cin < (1L << 30), "cbn_relu_conv3x3_fprop: tensor too large (32-bit byte offsets)");
+  a.cbn_stats = stats; a.cbn_gamma = gamma; a.cbn_beta = beta; a.cbn_labels = labels;
+  a.cbn_n_per_group = N / groups; a.cbn_n_labels = n_labels;
+  hipStream_t s = (hipStream_t)stream;
+  gank_prof_begin(0, 2.0 * a.M * (double)Cout * 9 * Cin, s, 2.0 * ((double)a.M * Cin + 9.0 * Cin * Cout + (double)a.M * Cout));
+  const int rc = a.CoutPad == 32 ? launch_patch<8, 32>(a, s) : launch_patch<8, 128>(a, s);
+  gank_prof_end(0, s);
   return rc;
 }
 

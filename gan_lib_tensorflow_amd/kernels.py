@@ -543,6 +543,32 @@ def cbn_fwd_from_sums(x, labels, gamma, beta, cs, relu=False, eps=1e-5):
     return y, stats
 
 
+def cbn_stats(x, groups=1, cs=None, eps=1e-5):
+    """(mean, invstd) [groups, 2, C] of x per tower: from a conv epilogue's sums (cs: ConvStats) or by the statistics pass"""
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    stats = torch.empty((groups, 2, c), dtype=F32, device=x.device)
+    if cs is not None and cs.groups == groups and cs.sums.shape[-1] == c:
+        _lib.check(lib().gank_cbn_stats_from_sums(_p(cs.sums, F32, "sums"), _p(cs.shift, F32, "shift"), _p(stats), c, groups, (n // groups) * hw,
+                                                  float(eps), _stream()), "cbn_stats_from_sums")
+        return stats
+    parts = lib().gank_cbn_parts((n // groups) * hw)
+    ws = torch.empty(groups * parts * 3 * c, dtype=F32, device=x.device)
+    _lib.check(lib().gank_cbn_stats(_p(x, BF16, "x"), _p(stats), _p(ws), n, hw, c, groups, float(eps), _stream()), "cbn_stats")
+    return stats
+
+
+def cbn_relu_conv3x3_fprop(x, labels, gamma, beta, stats, wf, bias, cout, flags=0):
+    """conv3x3_SAME(relu(cond_batchnorm(x))) + bias [tanh], the normalisation fused into the conv's operand staging (no grad)"""
+    n, h, w, cin = x.shape
+    groups = stats.shape[0]
+    y = torch.empty((n, h, w, cout), dtype=BF16, device=x.device)
+    _lib.check(lib().gank_cbn_relu_conv3x3_fprop(_p(x, BF16, "x"), _p(labels, I32, "labels"), _p(gamma, F32, "gamma"), _p(beta, F32, "beta"),
+                                                 _p(stats, F32, "stats"), _p(wf, BF16, "wf"), _p(bias, F32, "bias"), _p(y), n, h, w, cin, cout,
+                                                 groups, gamma.shape[0], flags, _stream()), "cbn_relu_conv3x3_fprop")
+    return y
+
+
 def layer_norm_fwd(x, gamma, beta, eps=1e-12):
     n, c = x.shape[0], x.shape[-1]
     hw = x.numel() // (n * c)

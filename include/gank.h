@@ -283,6 +283,16 @@ int gank_cbn_fwd_eps(const void* x, const int32_t* labels, const float* gamma, c
 int gank_cbn_fwd_from_sums(const void* x, const int32_t* labels, const float* gamma, const float* beta, void* y, float* stats,
                            const float* sums, const float* shift, int N, int HW, int C, int groups, int n_labels, int relu,
                            float eps, void* stream);
+/* statistics alone (mean, invstd per tower and channel), and the same from a conv epilogue's sums -- for a consumer that
+ * normalises inside its own kernel: gank_cbn_relu_conv3x3_fprop = conv3x3_SAME(relu(cond_batchnorm(x))) + bias [tanh] with the
+ * normalisation applied while the conv stages its operand (the normalised tensor is never stored; for passes that keep nothing
+ * for a backward pass: gan_cifar_resnet.py:257-261 in the critic-feed and sampling passes) */
+int gank_cbn_stats(const void* x, float* stats, float* ws, int N, int HW, int C, int groups, float eps, void* stream);
+int gank_cbn_stats_from_sums(const float* sums, const float* shift, float* stats, int C, int groups, long rows_per_group,
+                             float eps, void* stream);
+int gank_cbn_relu_conv3x3_fprop(const void* x, const int32_t* labels, const float* gamma, const float* beta, const float* stats,
+                                const void* wf, const float* bias, void* y, int N, int H, int W, int Cin, int Cout,
+                                int groups, int n_labels, int flags, void* stream);
 int gank_cbn_bwd(const void* dy, const void* x, const void* y, const int32_t* labels, const float* gamma,
                  const float* stats, void* dx, float* dgamma, float* dbeta, float* ws, int N, int HW, int C,
                  int groups, int n_labels, int relu, void* stream);

@@ -424,6 +424,33 @@ def test_fused_critic_head_equals_linear_plus_hinge(K, mode):
         (0.5 * (Fn.hinge_g_head(xg, wg, bg))).backward()                      # a weighted loss goes through the unfused operators
 
 
+@pytest.mark.parametrize("n,h,cout,groups", [(8, 32, 3, 2), (6, 16, 128, 3)])
+def test_cbn_relu_fused_into_conv_operand_staging(K, n, h, cout, groups):
+    """gank_cbn_relu_conv3x3_fprop: conv3x3(relu(cond_batchnorm(x))) with the normalisation applied while the conv stages its
+    operand == the two launches one after the other, bit for bit (same expression, same order, same bf16 rounding of the
+    normalised value), with statistics from the statistics pass or from a conv epilogue's sums."""
+    rng = np.random.default_rng(n + h + cout)
+    c = 256
+    x, xt = bf(rng.normal(size=(n, h, h, c)) * 1.7 + 0.3)
+    labels = torch.tensor(rng.integers(0, 10, n), dtype=torch.int32).cuda()
+    gamma = torch.tensor(rng.normal(size=(10, c)) * 0.2 + 1, dtype=torch.float32).cuda()
+    beta = torch.tensor(rng.normal(size=(10, c)) * 0.2, dtype=torch.float32).cuda()
+    w, _ = bf(rng.normal(size=(3, 3, c, cout)) / np.sqrt(9 * c))
+    b, bt = f32(rng.normal(size=cout))
+    wf, _ = K.prep_weights(torch.tensor(w, dtype=torch.float32).cuda(), True, False)
+    flags = K.OUT_TANH if cout == 3 else 0
+    yn, stats0 = K.cbn_fwd(xt, labels, gamma, beta, groups, True)
+    ref = K.conv2d_fprop(yn, wf, bt, (h, h), cout, 3, flags)
+    stats = K.cbn_stats(xt, groups)
+    y = K.cbn_relu_conv3x3_fprop(xt, labels, gamma, beta, stats, wf, bt, cout, flags)
+    torch.cuda.synchronize()
+    assert torch.equal(stats, stats0) and torch.equal(y, ref)
+    # against the oracle too
+    ry, _ = R.cond_batchnorm_forward(x, labels.cpu().numpy(), gamma.double().cpu().numpy(), beta.double().cpu().numpy(), groups)
+    rr = R.conv2d_same(R.relu(ry), w, b)
+    assert relerr(y, np.tanh(rr) if cout == 3 else rr) < 2 * BF_TOL
+
+
 def test_adam_tf_and_lr_decay(K):
     rng = np.random.default_rng(14)
     n = 1003
