@@ -117,7 +117,7 @@ extern "C" int gank_softmax_xent(const void* logits, const int32_t* labels, floa
 __global__ __launch_bounds__(1024) void critic_head_hinge_kernel(const bf16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                                 bf16* __restrict__ logits, float* __restrict__ loss, bf16* __restrict__ dx,
                                                                 float* __restrict__ w_grad, float* __restrict__ b_grad, int M, int K, int n_real, int mode) {
-  extern __shared__ float sm[];          // dl[M] | w[K] | red[32]
+  extern __shared__ float sm[];          // dl[M] | w[K] | red[32] | part[8][K]
   float* s_dl = sm;
   float* s_w = sm + M;
   float* red = s_w + K;
@@ -127,11 +127,23 @@ __global__ __launch_bounds__(1024) void critic_head_hinge_kernel(const bf16* __r
   const float bias = b ? b[0] : 0.f;
   const int n_fake = M - n_real;
   float acc = 0.f;
-  for (int m = wv; m < M; m += nw) {                 // one wave per row
-    float t = 0.f;
-    for (int k = lane; k < K; k += 64) t += bf2f(x[(long)m * K + k]) * s_w[k];
-    t = wave_sum(t);
-    if (lane == 0) {
+  for (int mb = wv; mb < M; mb += 8 * nw) {          // one wave per row, 8 rows in flight (a row at a time was 8 dependent
+    float tt[8];                                      // load -> reduce -> store chains in a row: most of this kernel's time)
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int m = mb + u * nw;
+      float t = 0.f;
+      if (m < M)
+        for (int k = lane; k < K; k += 64) t += bf2f(x[(long)m * K + k]) * s_w[k];
+      tt[u] = t;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) tt[u] = wave_sum(tt[u]);
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+    const int m = mb + u * nw;
+    const float t = tt[u];
+    if (lane == 0 && m < M) {
       const bf16 lg = f2bf(t + bias);
       logits[m] = lg;
       const float v = bf2f(lg);
@@ -141,6 +153,7 @@ __global__ __launch_bounds__(1024) void critic_head_hinge_kernel(const bf16* __r
       else { const float u = 1.f + v; l = fmaxf(u, 0.f) / (float)n_fake; d = u > 0.f ? 1.f / (float)n_fake : 0.f; }
       s_dl[m] = bf2f(f2bf(d));
       acc += l;
+    }
     }
   }
   if (lane != 0) acc = 0.f;
@@ -160,25 +173,40 @@ __global__ __launch_bounds__(1024) void critic_head_hinge_kernel(const bf16* __r
       const int m = (int)(i / K), k = (int)(i - (long)m * K);
       dx[i] = f2bf(s_dl[m] * s_w[k]);
     }
-  // w_grad[k] += sum_m x[m][k] dl[m]  (thread per k, rows in order: deterministic);  b_grad += sum_m dl[m]
-  if (w_grad)
+  // w_grad[k] += sum_m x[m][k] dl[m]: the rows in 8 slices per column (a thread per (slice, k): 128 dependent loads in one
+  // thread were 10 of this kernel's 16 us), partial sums meet in LDS in slice order: deterministic;  b_grad += sum_m dl[m]
+  if (w_grad) {
+    __syncthreads();                         // red[] is reused below (K <= 128 * ... guarded by the host: 8 * K floats of LDS)
+    float* part = red + 32;                  // [8][K]
+    const int nsl = 8, per = (M + nsl - 1) / nsl;
+    for (int i = tid; i < nsl * K; i += blockDim.x) {
+      const int sl = i / K, k = i - sl * K;
+      const int m0 = sl * per, m1 = min(M, m0 + per);
+      float t = 0.f;
+      for (int m = m0; m < m1; m++) t += bf2f(x[(long)m * K + k]) * s_dl[m];
+      part[i] = t;
+    }
+    __syncthreads();
     for (int k = tid; k < K; k += blockDim.x) {
       float t = 0.f;
-      for (int m = 0; m < M; m++) t += bf2f(x[(long)m * K + k]) * s_dl[m];
+#pragma unroll
+      for (int sl = 0; sl < 8; sl++) t += part[sl * K + k];
       w_grad[k] += t;
     }
-  if (b_grad && tid == 0) {
+  }
+  if (b_grad && tid < 64) {
     float t = 0.f;
-    for (int m = 0; m < M; m++) t += s_dl[m];
-    b_grad[0] += t;
+    for (int m = tid; m < M; m += 64) t += s_dl[m];
+    t = wave_sum(t);
+    if (tid == 0) b_grad[0] += t;
   }
 }
 extern "C" int gank_critic_head_hinge(const void* x, const float* w, const float* b, void* logits, float* loss, void* dx, float* w_grad,
                                       float* b_grad, int M, int K, int n_real, int mode, void* stream) {
   GANK_REQUIRE(x && w && logits && loss && M > 0 && K > 0 && (mode == 0 || mode == 1), "critic_head_hinge: bad arguments");
   GANK_REQUIRE(mode == 1 || (n_real > 0 && n_real < M), "critic_head_hinge: n_real must split the batch");
-  GANK_REQUIRE((size_t)(M + K + 32) * sizeof(float) <= 60000, "critic_head_hinge: M + K too large for one block");
-  hipLaunchKernelGGL(critic_head_hinge_kernel, dim3(1), dim3(1024), (size_t)(M + K + 32) * sizeof(float), (hipStream_t)stream, (const bf16*)x, w, b,
+  GANK_REQUIRE((size_t)(M + 9 * K + 32) * sizeof(float) <= 60000, "critic_head_hinge: M + 9 K too large for one block");
+  hipLaunchKernelGGL(critic_head_hinge_kernel, dim3(1), dim3(1024), (size_t)(M + 9 * K + 32) * sizeof(float), (hipStream_t)stream, (const bf16*)x, w, b,
                      (bf16*)logits, loss, (bf16*)dx, w_grad, b_grad, M, K, n_real, mode);
   GANK_LAUNCH_OK("critic_head_hinge");
   return 0;

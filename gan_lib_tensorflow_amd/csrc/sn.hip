@@ -19,17 +19,20 @@ struct SnTable {
   int count;
 };
 
+// The table sits in the kernel arguments: a counted loop over it is one dependent scalar load per entry (12 of them in front
+// of every wave's first vector load).  Unrolled over SN_MAX with the offsets increasing, the index is a count of entries at or
+// below `row`, and the scalar loads issue back to back.
 __device__ __forceinline__ int sn_find_row(const SnTable& t, int row, int& local) {
   int w = 0;
-  for (int i = 1; i < t.count; i++)
-    if (row >= t.d[i].row_offset) w = i;
+#pragma unroll
+  for (int i = 1; i < SN_MAX; i++) w += (i < t.count && row >= t.d[i].row_offset) ? 1 : 0;
   local = row - t.d[w].row_offset;
   return w;
 }
 __device__ __forceinline__ int sn_find_chunk(const SnTable& t, int chunk, int& local) {
   int w = 0;
-  for (int i = 1; i < t.count; i++)
-    if (chunk >= t.d[i].chunk_offset) w = i;
+#pragma unroll
+  for (int i = 1; i < SN_MAX; i++) w += (i < t.count && chunk >= t.d[i].chunk_offset) ? 1 : 0;
   local = chunk - t.d[w].chunk_offset;
   return w;
 }
