@@ -112,6 +112,7 @@ OVERLAP_GEN_WITH_CRITIC = False
 # as the backward pass has passed the block boundary below it (parallel.GradBuckets).  Forward / creation order.
 G_BUCKETS = (('G.Input/', 'G.Block.1.'), ('G.Block.2.',), ('G.Block.3.',), ('G.OutputNorm/', 'G.Output/'))
 BUCKETED_G_ALLREDUCE = True
+ONE_GRAPH_PER_ITERATION = _os.environ.get("GANK_ONE_GRAPH", "0") == "1"    # single replica: the whole iteration as one captured graph (measured 0.5 % SLOWER than 7 replays: five unrolled critic updates touch five sets of activation addresses instead of one warm set)
 BATCH_SMALL_WGRADS = True    # same-shape small filter gradients of an update are issued in one launch
 SIDE_STREAM_WGRAD = False    # filter gradients on a second HIP stream: measured 6 % SLOWER per iteration (the branches contend for L2 and CUs), kept for experiments
 
@@ -684,8 +685,6 @@ class SNGANTrainer:
     def train_iteration(self, batches):
         """One reference iteration (:599-620): G update (skipped at iteration 0), then N_CRITIC critic
         updates, each on the next (uint8 images, labels) pair from `batches`."""
-        if self.iteration > 0:
-            self.g_step()
         feed = [next(batches) for _ in range(N_CRITIC)]
         if all(d.is_cuda and l.is_cuda for d, l in feed):
             # device-resident batches: the ten slot copies are two multi-tensor launches
@@ -695,6 +694,20 @@ class SNGANTrainer:
             for i, (data, labels) in enumerate(feed):
                 self.real_all[i].copy_(data, non_blocking=True)
                 self.labels_all[i].copy_(labels, non_blocking=True)
+        if ONE_GRAPH_PER_ITERATION and self.world == 1 and self.use_graphs and not self.overlap_gen and not self.bucketed:
+            # a single replica exchanges nothing between the updates: the generator update, the generator pass for the critic's
+            # fakes, the N_CRITIC critic updates and the iteration counter are ONE captured graph (7 graph launches of ~8.5 us
+            # launch gap each become 1); iteration 0 has no generator update and gets a graph of its own
+            self._ensure_clean(self.g_flat)
+            self._ensure_clean(self.d_flat)
+            if self.iteration > 0:
+                self._run_plain('iter', self._whole_iteration)
+            else:
+                self._run_plain('iter0', self._iteration_tail)
+            self.iteration += 1
+            return
+        if self.iteration > 0:
+            self.g_step()
         if self.overlap_gen and N_CRITIC > 1:
             self._run_plain('gen1', lambda: self._generate_slots(0, 1, self.rng_state_gen))
             self._run('d_first', self._d_first_with_generator_beside, self.d_opt, self.d_flat)
@@ -706,6 +719,19 @@ class SNGANTrainer:
                 self._run('d_pre', self._d_forward_backward_prefetched, self.d_opt, self.d_flat)
         self.iteration += 1
         K.counter_add(self.iteration_dev, 1)
+
+    def _iteration_tail(self):
+        """generator pass for the critic's fakes + N_CRITIC critic updates + the iteration counter (one replica: no exchange)"""
+        self._generate_for_critic()
+        for _ in range(N_CRITIC):
+            self._d_forward_backward_prefetched()
+            self.d_opt.apply()
+        K.counter_add(self.iteration_dev, 1)
+
+    def _whole_iteration(self):
+        self._g_forward_backward()
+        self._g_apply()
+        self._iteration_tail()
 
     @torch.no_grad()
     def sample(self, n=100, labels=None, noise=None):
