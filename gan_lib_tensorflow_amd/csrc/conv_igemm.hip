@@ -1094,9 +1094,6 @@ __device__ __forceinline__ void pp_wait_vmcnt() {
   if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
 }
 
-#ifndef PP_STATS_J_OUTER
-#define PP_STATS_J_OUTER 1
-#endif
 template <int MODE, int PW, bool STATS = false>   // MODE bit0: relu on the input operand; bit2: one output phase of a stride-2 transposed conv
 __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
   constexpr bool PHASE = (MODE & 4) != 0;
@@ -1268,31 +1265,28 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
   // trades quad 2q+1 of the h = 0 half-wave for quad 2q of the h = 1 half-wave, after which every lane owns 8
   // CONSECUTIVE channels (16q + 8h ..) and writes, and reads mask / residual, 16 bytes at a time.
   const bool otanh = (a.flags & GANK_OUT_TANH) != 0;
-  // Loop order (i, q) outside, the 4 pixels of the lane inside: with STATS the epilogue also accumulates the batch-norm
-  // statistics of what it writes (normalization.py:47: tf.nn.moments of the NEXT layer's input) and needs only 16 live
-  // sums at a time (all 64 at once pushed the kernel past its register budget).  Sums are of (y - bias): the mean of a
-  // conv output is mostly its bias, and E[x^2] - E[x]^2 in fp32 wants a small mean.  A wave reduces its 32 pixels by
-  // shuffles; lanes r = 0 add to one of GANK_STAT_SLOTS copies of the tower's sums (blocks of a tower spread over the
-  // copies: same-address float atomics serialise at the memory side).
+  // Pixel-outer loop order.  A wave owns 64 channels = ONE 128-byte line of each of its pixels, in four 32-byte pieces (i, q).
+  // With (i, q) outside the pieces of a line were a whole pixel loop apart; the L2 -- turned over completely by the 33 MB
+  // that the resident blocks write at the same time -- evicted the line in between and every piece went to the fabric as its
+  // own request: WRITE_SIZE 165 MB for a 67-MB output.  Computed and stored back to back they merge (67.1 MB; 69.2 MB with
+  // the statistics atomics) and the kernel is 5-9 % faster.
+  // With STATS the epilogue also accumulates the batch-norm statistics of what it writes (normalization.py:47: tf.nn.moments
+  // of the NEXT layer's input).  Sums are of (y - bias): the mean of a conv output is mostly its bias, and E[x^2] - E[x]^2
+  // in fp32 wants a small mean.  A wave reduces its 32 pixels by shuffles; lanes r = 0 add to one of GANK_STAT_SLOTS copies
+  // of the tower's sums (blocks of a tower spread over the copies: same-address float atomics serialise at the memory side).
   float keep1 = 0.f, keep2 = 0.f;
-  // The packed results wait in registers (they take the place of the accumulators they came from) and are stored in a
-  // second pass, pixel by pixel: a wave owns 64 channels = ONE 128-byte line of each of its pixels, in four 32-byte
-  // pieces (i, q).  Stored in (i, q)-outer order the pieces of a line were a whole pixel loop apart, the L2 -- turned over
-  // completely by the 33 MB that the resident blocks write at the same time -- evicted the line in between, and every
-  // piece went to the fabric as its own request: WRITE_SIZE 165 MB for a 67-MB output.  Back to back they merge.
-  // With STATS the 64 result registers beside the 16 running sums spill (22-25 VGPRs): that variant stores half lines,
-  // 64 contiguous bytes = one full-size write request, after each i.
-  constexpr int IH = 2;                              // i-values per store pass
-  if constexpr (STATS && PP_STATS_J_OUTER) {
-    // statistics variant: pixel-outer order with all 64 running sums live (they, not the packed results, share the
-    // registers with the accumulators); the four pieces of a line are computed and stored one after the other
-    float st1[2][2][8], st2[2][2][8];
+  {
+    // all 64 running sums are live beside the accumulators (200 VGPRs; holding the packed results for a separate store pass
+    // instead spilled 22-25 of them)
+    float st1[STATS ? 2 : 1][2][8], st2[STATS ? 2 : 1][2][8];
+    if constexpr (STATS) {
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+      for (int i = 0; i < 2; i++)
 #pragma unroll
-      for (int q = 0; q < 2; q++)
+        for (int q = 0; q < 2; q++)
 #pragma unroll
-        for (int e = 0; e < 8; e++) { st1[i][q][e] = 0.f; st2[i][q][e] = 0.f; }
+          for (int e = 0; e < 8; e++) { st1[i][q][e] = 0.f; st2[i][q][e] = 0.f; }
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int py = py0 + wm * (PHH / 2) + j * RS + prow, px = px0 + pcol;
@@ -1333,8 +1327,10 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; e++) { const float t = bf2f(rs[e]); v[e] += t; d[e] += t; }
           }
+          if constexpr (STATS) {
 #pragma unroll
-          for (int e = 0; e < 8; e++) { st1[i][q][e] += d[e]; st2[i][q][e] += d[e] * d[e]; }
+            for (int e = 0; e < 8; e++) { st1[i][q][e] += d[e]; st2[i][q][e] += d[e] * d[e]; }
+          }
 #pragma unroll
           for (int e = 0; e < 8; e++) outl[i][q][e] = f2bf(otanh ? tanhf(v[e]) : v[e]);
         }
@@ -1345,6 +1341,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
 #pragma unroll
         for (int q = 0; q < 2; q++) *reinterpret_cast<bf16x8*>(line + i * 32 + 16 * q) = outl[i][q];
     }
+    if constexpr (STATS) {
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -1358,87 +1355,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
           keep1 = mine ? s1 : keep1;
           keep2 = mine ? s2 : keep2;
         }
-  } else
-#pragma unroll
-  for (int i0 = 0; i0 < 2; i0 += IH) {
-  bf16x8 outp[IH][2][4];
-#pragma unroll
-  for (int i = i0; i < i0 + IH; i++) {
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-      const int co = tile_n * 256 + (wn * 2 + i) * 32 + 16 * q + 8 * h;
-      float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (a.bias) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + co), b1 = *reinterpret_cast<const f32x4*>(a.bias + co + 4);
-#pragma unroll
-        for (int e = 0; e < 4; e++) { bb[e] = b0[e]; bb[4 + e] = b1[e]; }
-      }
-      float st1[8], st2[8];
-#pragma unroll
-      for (int e = 0; e < 8; e++) { st1[e] = 0.f; st2[e] = 0.f; }
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int py = py0 + wm * (PHH / 2) + j * RS + prow, px = px0 + pcol;
-        const long m = PHASE ? ((long)(n * 2 * a.H + 2 * py + (phase >> 1))) * (2 * a.W) + 2 * px + (phase & 1) : ((long)(n * a.H + py)) * a.W + px;
-        const long mr = (!PHASE && (a.flags & IG_RES_UP2X)) ? ((long)(n * (a.H >> 1) + (py >> 1))) * (a.W >> 1) + (px >> 1) : m;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          // inline asm, not __builtin_amdgcn_permlane32_swap: hipcc (ROCm 7.2) dropped the builtin's second result here
-          // (the +4 half came out as a copy of the first).  s_nop 1 = the 2 wait states a VALU write needs before the swap reads it.
-          float lo = acc[i][j][8 * q + e] * a.scale, hi = acc[i][j][8 * q + 4 + e] * a.scale;
-          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
-          v[e] = lo;
-          v[4 + e] = hi;
-        }
-        const long o = m * a.Cout + co;
-#pragma unroll
-        for (int e = 0; e < 8; e++) v[e] += bb[e];
-        if (a.mask) {
-          const bf16x8 mk = *reinterpret_cast<const bf16x8*>(a.mask + o);
-#pragma unroll
-          for (int e = 0; e < 8; e++) v[e] = (bf2f(mk[e]) > 0.f) ? v[e] : 0.f;
-        }
-        if (a.res) {
-          const bf16x8 rs = *reinterpret_cast<const bf16x8*>(a.res + mr * a.Cout + co);
-#pragma unroll
-          for (int e = 0; e < 8; e++) v[e] += bf2f(rs[e]);
-        }
-        if constexpr (STATS) {
-#pragma unroll
-          for (int e = 0; e < 8; e++) { const float d = v[e] - bb[e]; st1[e] += d; st2[e] += d * d; }
-        }
-        bf16x8 out;
-#pragma unroll
-        for (int e = 0; e < 8; e++) out[e] = f2bf(otanh ? tanhf(v[e]) : v[e]);
-        outp[i - i0][q][j] = out;
-      }
-      if constexpr (STATS) {
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-          // sum over the 32 lanes of a half-wave: 16-lane rows by DPP (VALU operand swizzles: lane^1, lane^2, half-row
-          // mirror, row mirror), the two rows by one LDS-crossbar shuffle (5 shuffles per value made this epilogue LDS-bound)
-          float s1 = pp_row_sum(st1[e]), s2 = pp_row_sum(st2[e]);
-          s1 += __shfl_xor(s1, 16, 64);
-          s2 += __shfl_xor(s2, 16, 64);
-          // every lane of the half-wave now holds the sums of channel (i, q, e): lane r = (2i + q) * 8 + e keeps them
-          const bool mine = r == (2 * i + q) * 8 + e;
-          keep1 = mine ? s1 : keep1;
-          keep2 = mine ? s2 : keep2;
-        }
-      }
     }
-  }
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int py = py0 + wm * (PHH / 2) + j * RS + prow, px = px0 + pcol;
-    const long m = PHASE ? ((long)(n * 2 * a.H + 2 * py + (phase >> 1))) * (2 * a.W) + 2 * px + (phase & 1) : ((long)(n * a.H + py)) * a.W + px;
-    bf16* line = a.y + m * a.Cout + tile_n * 256 + wn * 64 + 8 * h;
-#pragma unroll
-    for (int i = i0; i < i0 + IH; i++)
-#pragma unroll
-      for (int q = 0; q < 2; q++) *reinterpret_cast<bf16x8*>(line + i * 32 + 16 * q) = outp[i - i0][q][j];
-  }
   }
   if constexpr (STATS) {
     // ONE full-width atomic per statistic and wave (an atomic instruction costs the memory pipe the same with 2 lanes as
