@@ -80,6 +80,63 @@ __device__ __forceinline__ float pp_row_sum(float v) {
   return v;
 }
 
+// Epilogue of ONE 32x32 accumulator tile with 16-byte pieces.  An accumulator quad g of lane (r, h) is channels 8g+4h..+3 of
+// pixel r; v_permlane32_swap trades quad 2q+1 of the h = 0 half-wave for quad 2q of the h = 1 half-wave, after which the lane
+// owns 8 CONSECUTIVE channels 16q + 8h .. +7: half as many store (and mask / residual load) instructions and L2 requests as
+// the 8-byte form, and the four pieces of a pixel's 64-byte run leave back to back.  y_px / mask_px / res_px: the pixel's row
+// (+ the tile's first channel); bias likewise.  Needs 8 | Cout.  d (optional): the values before the bias, for statistics.
+template <bool WANT_D>
+__device__ __forceinline__ void epi_tile_wide(const f32x16& acc, float scale, const float* __restrict__ bias, const bf16* __restrict__ mask_px,
+                                              const bf16* __restrict__ res_px, bf16* __restrict__ y_px, int h, bool otanh, float (*d)[8]) {
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int c = 16 * q + 8 * h;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      // inline asm, not __builtin_amdgcn_permlane32_swap: hipcc (ROCm 7.2) dropped the builtin's second result
+      // (the +4 half came out as a copy of the first).  s_nop 1 = the 2 wait states a VALU write needs before the swap reads it.
+      float lo = acc[8 * q + e] * scale, hi = acc[8 * q + 4 + e] * scale;
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+      v[e] = lo;
+      v[4 + e] = hi;
+    }
+    float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + c), b1 = *reinterpret_cast<const f32x4*>(bias + c + 4);
+#pragma unroll
+      for (int e = 0; e < 4; e++) { bb[e] = b0[e]; bb[4 + e] = b1[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      if constexpr (WANT_D) d[q][e] = v[e];
+      v[e] += bb[e];
+    }
+    if (mask_px) {
+      const bf16x8 mk = *reinterpret_cast<const bf16x8*>(mask_px + c);
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const bool on = bf2f(mk[e]) > 0.f;
+        v[e] = on ? v[e] : 0.f;
+        if constexpr (WANT_D) d[q][e] = on ? d[q][e] : -bb[e];
+      }
+    }
+    if (res_px) {
+      const bf16x8 rs = *reinterpret_cast<const bf16x8*>(res_px + c);
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const float t = bf2f(rs[e]);
+        v[e] += t;
+        if constexpr (WANT_D) d[q][e] += t;
+      }
+    }
+    bf16x8 out;
+#pragma unroll
+    for (int e = 0; e < 8; e++) out[e] = f2bf(otanh ? tanhf(v[e]) : v[e]);
+    store_out(reinterpret_cast<bf16x8*>(y_px + c), out);
+  }
+}
+
 // PF   = register prefetch slots: global loads for K-step s+PF-1 are in flight while step s is computed
 //        (plain loads survive the per-step barrier; hipcc emits counted vmcnt waits for the oldest slot).
 // MODE = compile-time gather mode (bit0: relu on the input operand, bit1: shifted index = NN-upsample or
@@ -333,6 +390,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
 
   // epilogue: lane holds, per accumulator quad g, channels co0+8g+4h .. +3 of pixel m
   const bool vec = (a.Cout & 3) == 0;
+  const bool wide = (a.Cout & 31) == 0;         // whole 32-channel tiles: 16-byte pieces (epi_tile_wide); always with STATS
   const bool otanh = (a.flags & GANK_OUT_TANH) != 0;
   // STATS (host guarantees: full tiles, every tile inside one tower, Cout % BN == 0): per-lane sums of (y - bias) and
   // its square per channel, reduced over the wave's pixels after the stores -- the batch-norm statistics of the layer
@@ -356,6 +414,22 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
       int n_, y_, x_;
       pix_decomp(m, a.H, a.W, a.shw, a.sw, n_, y_, x_);
       mr = ((long)(n_ * (a.H >> 1) + (y_ >> 1))) * (a.W >> 1) + (x_ >> 1);
+    }
+    if (wide) {
+#pragma unroll
+      for (int i = 0; i < TN; i++) {
+        const int ct = tile_n * BN + (wave_n * TN + i) * 32;
+        float d[2][8];
+        epi_tile_wide<STATS>(acc[i][j], a.scale, a.bias ? a.bias + ct : nullptr, a.mask ? a.mask + (long)m * a.Cout + ct : nullptr,
+                             a.res ? a.res + mr * a.Cout + ct : nullptr, a.y + (long)m * a.Cout + ct, h, otanh, d);
+        if constexpr (STATS) {
+#pragma unroll
+          for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) { st1[i * 16 + q * 8 + e] += d[q][e]; st2[i * 16 + q * 8 + e] += d[q][e] * d[q][e]; }
+        }
+      }
+      continue;
     }
 #pragma unroll
     for (int i = 0; i < TN; i++) {
@@ -385,14 +459,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; e++) v[e] += bf2f(rs[e]);
           }
-          if constexpr (STATS) {
-#pragma unroll
-            for (int e = 0; e < 4; e++) { const float d = v[e] - b[e]; st1[i * 16 + g * 4 + e] += d; st2[i * 16 + g * 4 + e] += d * d; }
-          }
           bf16x4 out;
 #pragma unroll
           for (int e = 0; e < 4; e++) out[e] = f2bf(otanh ? tanhf(v[e]) : v[e]);
-          *reinterpret_cast<bf16x4*>(a.y + o) = out;
+          store_out(reinterpret_cast<bf16x4*>(a.y + o), out);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; e++) {
@@ -418,11 +488,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
       keep1 = r == q ? s1 : keep1;
       keep2 = r == q ? s2 : keep2;
     }
-    if (r < TN * 16) {          // lane (r, h) holds channel (i, g, e) = (r >> 4, (r >> 2) & 3, r & 3) of its half
+    if (r < TN * 16) {          // lane (r, h) holds channel (i, q, e) = (r >> 4, (r >> 3) & 1, r & 7) of its half (epi_tile_wide)
       const int m0 = tile_m * BM;                      // the tile's first pixel (phase mode: low-resolution pixel index)
       const int n0 = a.shw >= 0 ? (m0 >> a.shw) : m0 / (a.H * a.W);
       float* dst = a.stat_sums + ((long)(n0 / a.stat_n_per_group) * GANK_STAT_SLOTS + (blockIdx.x % GANK_STAT_SLOTS)) * 2 * a.Cout;
-      const int co = tile_n * BN + (wave_n * TN + (r >> 4)) * 32 + 8 * ((r >> 2) & 3) + 4 * h + (r & 3);
+      const int co = tile_n * BN + (wave_n * TN + (r >> 4)) * 32 + 16 * ((r >> 3) & 1) + 8 * h + (r & 7);
       atomicAdd(dst + co, keep1);
       atomicAdd(dst + a.Cout + co, keep2);
     }
@@ -639,12 +709,22 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
   // epilogue (same order as the generic kernel): lane holds channels co0+8g+4h..+3 of one pixel per quad
   const bool otanh = (a.flags & GANK_OUT_TANH) != 0;
   const bool vec = (a.Cout & 3) == 0;
+  const bool wide = (a.Cout & 31) == 0;         // whole 32-channel tiles: 16-byte pieces (epi_tile_wide)
 #pragma unroll
   for (int j = 0; j < TM; j++) {
     const int py = wave_m * 2 * TM + 2 * j + (r >> 4), px = r & 15;
     const long m = PHASE ? ((long)(n * 2 * a.H + 2 * (py0 + py) + (phase >> 1))) * (2 * a.W) + 2 * (px0 + px) + (phase & 1)
                          : ((long)(n * a.H + py0 + py)) * a.W + px0 + px;
     const long mr = (!PHASE && (a.flags & IG_RES_UP2X)) ? ((long)(n * (a.H >> 1) + ((py0 + py) >> 1))) * (a.W >> 1) + ((px0 + px) >> 1) : m;
+    if (wide) {
+#pragma unroll
+      for (int i = 0; i < TN; i++) {
+        const int ct = tile_n * BN + (wave_n * TN + i) * 32;
+        epi_tile_wide<false>(acc[i][j], a.scale, a.bias ? a.bias + ct : nullptr, a.mask ? a.mask + m * a.Cout + ct : nullptr,
+                             a.res ? a.res + mr * a.Cout + ct : nullptr, a.y + m * a.Cout + ct, h, otanh, nullptr);
+      }
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < TN; i++) {
       const int co0 = tile_n * BN + (wave_n * TN + i) * 32 + 4 * h;
@@ -691,7 +771,7 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; e++) out[e] = f2bf(v[e]);
         }
-        *reinterpret_cast<bf16x4*>(a.y + o) = out;
+        store_out(reinterpret_cast<bf16x4*>(a.y + o), out);
       }
     }
   }
@@ -836,7 +916,7 @@ __global__ __launch_bounds__(256) void conv_igemm_patch2_kernel(IgemmArgs a) {
     __syncthreads();     // next slab complete, everyone is done reading this one
   }
 
-  // epilogue (same order as the other kernels): lane holds channels co0+8g+4h..+3 of one pixel per quad
+  // epilogue: 16-byte pieces (Cout % 128 == 0 here)
   const bool otanh = (a.flags & GANK_OUT_TANH) != 0;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
@@ -844,40 +924,9 @@ __global__ __launch_bounds__(256) void conv_igemm_patch2_kernel(IgemmArgs a) {
     const long m = ((long)(n * a.H + py0 + py)) * a.W + px0 + px;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      const int co0 = tile_n * BN + (wave_n * 2 + i) * 32 + 4 * h;
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const int co = co0 + 8 * g;
-        if (co >= a.Cout) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * g + e] * a.scale;
-        const long o = m * a.Cout + co;
-        if (a.bias) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + co);
-#pragma unroll
-          for (int e = 0; e < 4; e++) v[e] += b[e];
-        }
-        if (a.mask) {
-          const bf16x4 mk = *reinterpret_cast<const bf16x4*>(a.mask + o);
-#pragma unroll
-          for (int e = 0; e < 4; e++) v[e] = (bf2f(mk[e]) > 0.f) ? v[e] : 0.f;
-        }
-        if (a.res) {
-          const bf16x4 rs = *reinterpret_cast<const bf16x4*>(a.res + o);
-#pragma unroll
-          for (int e = 0; e < 4; e++) v[e] += bf2f(rs[e]);
-        }
-        bf16x4 out;
-        if (otanh) {
-#pragma unroll
-          for (int e = 0; e < 4; e++) out[e] = f2bf(tanhf(v[e]));
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; e++) out[e] = f2bf(v[e]);
-        }
-        *reinterpret_cast<bf16x4*>(a.y + o) = out;
-      }
+      const int ct = tile_n * BN + (wave_n * 2 + i) * 32;
+      epi_tile_wide<false>(acc[i][j], a.scale, a.bias ? a.bias + ct : nullptr, a.mask ? a.mask + m * a.Cout + ct : nullptr,
+                           a.res ? a.res + m * a.Cout + ct : nullptr, a.y + m * a.Cout + ct, h, otanh, nullptr);
     }
   }
 }
@@ -1018,7 +1067,7 @@ __global__ __launch_bounds__(256) void conv_narrow_in_kernel(IgemmArgs a) {
         bf16x4 out;
 #pragma unroll
         for (int e = 0; e < 4; e++) out[e] = f2bf(otanh ? tanhf(v[e]) : v[e]);
-        *reinterpret_cast<bf16x4*>(a.y + o) = out;
+        store_out(reinterpret_cast<bf16x4*>(a.y + o), out);
       }
     }
   }
@@ -1339,7 +1388,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
 #pragma unroll
       for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int q = 0; q < 2; q++) *reinterpret_cast<bf16x8*>(line + i * 32 + 16 * q) = outl[i][q];
+        for (int q = 0; q < 2; q++) store_out(reinterpret_cast<bf16x8*>(line + i * 32 + 16 * q), outl[i][q]);
     }
     if constexpr (STATS) {
 #pragma unroll

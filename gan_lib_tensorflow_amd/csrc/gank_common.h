@@ -138,4 +138,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + (bid >> 3);
 }
+// Result tiles are written once and read by the NEXT kernel: a streaming (nt) store keeps them from displacing the weight and
+// activation lines the running kernel still re-reads from its L2 (experiment knob: -DGANK_NT_STORE=0|1).
+#ifndef GANK_NT_STORE
+#define GANK_NT_STORE 0
+#endif
+template <class V>
+__device__ __forceinline__ void store_out(V* p, V v) {
+#if GANK_NT_STORE
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 #endif
