@@ -92,15 +92,7 @@ __device__ __forceinline__ void epi_tile_wide(const f32x16& acc, float scale, co
   for (int q = 0; q < 2; q++) {
     const int c = 16 * q + 8 * h;
     float v[8];
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      // inline asm, not __builtin_amdgcn_permlane32_swap: hipcc (ROCm 7.2) dropped the builtin's second result
-      // (the +4 half came out as a copy of the first).  s_nop 1 = the 2 wait states a VALU write needs before the swap reads it.
-      float lo = acc[8 * q + e] * scale, hi = acc[8 * q + 4 + e] * scale;
-      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
-      v[e] = lo;
-      v[4 + e] = hi;
-    }
+    acc_widen(acc, q, scale, v);
     float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (bias) {
       const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + c), b1 = *reinterpret_cast<const f32x4*>(bias + c + 4);

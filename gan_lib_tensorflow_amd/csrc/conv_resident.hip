@@ -511,31 +511,30 @@ __global__ __launch_bounds__(512) void cpool_res_fprop_kernel(CpFwdArgs a) {
     }
   }
 
-  // epilogue: lane holds channels co0 + 8g + 4h .. +3 of one pooled pixel per quad g
+  // epilogue: after acc_widen the lane holds channels 16q + 8h .. +7 of one pooled pixel: 16-byte pieces
 #pragma unroll
   for (int t = 0; t < TPW; t++) {
     const int py = py0 + (pg * TPW + t) * G::TROWS + trow, px = px0 + tcol;
     const long m = ((long)n * a.Hp + py) * a.Wp + px;
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-      const int co = cg * 128 + ct * 32 + 8 * g + 4 * h;
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; e++) v[e] = acc[t][4 * g + e];
+    for (int q = 0; q < 2; q++) {
+      const int co = cg * 128 + ct * 32 + 16 * q + 8 * h;
+      float v[8];
+      acc_widen(acc[t], q, 1.0f, v);
       if (a.bias) {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + co);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + co), b1 = *reinterpret_cast<const f32x4*>(a.bias + co + 4);
 #pragma unroll
-        for (int e = 0; e < 4; e++) v[e] += bb[e];
+        for (int e = 0; e < 4; e++) { v[e] += b0[e]; v[4 + e] += b1[e]; }
       }
       if (a.res) {
-        const bf16x4 rs = *reinterpret_cast<const bf16x4*>(a.res + m * a.Cout + co);
+        const bf16x8 rs = *reinterpret_cast<const bf16x8*>(a.res + m * a.Cout + co);
 #pragma unroll
-        for (int e = 0; e < 4; e++) v[e] += bf2f(rs[e]);
+        for (int e = 0; e < 8; e++) v[e] += bf2f(rs[e]);
       }
-      bf16x4 o;
+      bf16x8 o;
 #pragma unroll
-      for (int e = 0; e < 4; e++) o[e] = f2bf(v[e]);
-      *reinterpret_cast<bf16x4*>(a.y + m * a.Cout + co) = o;
+      for (int e = 0; e < 8; e++) o[e] = f2bf(v[e]);
+      *reinterpret_cast<bf16x8*>(a.y + m * a.Cout + co) = o;
     }
   }
 }
@@ -609,14 +608,14 @@ __global__ __launch_bounds__(512) void cpool_res_dgrad_kernel(CpBwdArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
     // relu masks of this phase's outputs: requested now, consumed after the K loop
-    bf16x4 mk[TPW][4];
+    bf16x8 mk[TPW][2];
     if (a.mask) {
 #pragma unroll
       for (int t = 0; t < TPW; t++) {
         const int y = py0 + (pg * TPW + t) * G::TROWS + trow, x = px0 + tcol;
         const long m = ((long)n * H2 + 2 * y + pa) * W2 + 2 * x + pb;
 #pragma unroll
-        for (int g = 0; g < 4; g++) mk[t][g] = *reinterpret_cast<const bf16x4*>(a.mask + m * a.Cin + cg * 128 + ct * 32 + 8 * g + 4 * h);
+        for (int q = 0; q < 2; q++) mk[t][q] = *reinterpret_cast<const bf16x8*>(a.mask + m * a.Cin + cg * 128 + ct * 32 + 16 * q + 8 * h);
       }
     }
     constexpr int PB = 2;
@@ -649,19 +648,18 @@ __global__ __launch_bounds__(512) void cpool_res_dgrad_kernel(CpBwdArgs a) {
       const int y = py0 + (pg * TPW + t) * G::TROWS + trow, x = px0 + tcol;
       const long m = ((long)n * H2 + 2 * y + pa) * W2 + 2 * x + pb;
 #pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const int ci = cg * 128 + ct * 32 + 8 * g + 4 * h;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = acc[t][4 * g + e];
+      for (int q = 0; q < 2; q++) {
+        const int ci = cg * 128 + ct * 32 + 16 * q + 8 * h;
+        float v[8];
+        acc_widen(acc[t], q, 1.0f, v);
         if (a.mask) {
 #pragma unroll
-          for (int e = 0; e < 4; e++) v[e] = bf2f(mk[t][g][e]) > 0.f ? v[e] : 0.f;
+          for (int e = 0; e < 8; e++) v[e] = bf2f(mk[t][q][e]) > 0.f ? v[e] : 0.f;
         }
-        bf16x4 o;
+        bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 4; e++) o[e] = f2bf(v[e]);
-        *reinterpret_cast<bf16x4*>(a.dx + m * a.Cin + ci) = o;
+        for (int e = 0; e < 8; e++) o[e] = f2bf(v[e]);
+        *reinterpret_cast<bf16x8*>(a.dx + m * a.Cin + ci) = o;
       }
     }
   }

@@ -138,6 +138,22 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + (bid >> 3);
 }
+// Widening of a 32x32 accumulator tile's pieces.  An accumulator quad g of lane (r, h) is channels 8g+4h..+3 of pixel r;
+// v_permlane32_swap trades quad 2q+1 of the h = 0 half-wave for quad 2q of the h = 1 half-wave, after which the lane owns 8
+// CONSECUTIVE channels 16q + 8h .. +7 (v[0..7]): 16-byte instead of 8-byte stores / mask / residual loads.  All 64 lanes (or
+// both lanes r and r + 32 of every pixel) must be active.
+__device__ __forceinline__ void acc_widen(const f32x16& acc, int q, float scale, float (&v)[8]) {
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    // inline asm, not __builtin_amdgcn_permlane32_swap: hipcc (ROCm 7.2) dropped the builtin's second result
+    // (the +4 half came out as a copy of the first).  s_nop 1 = the 2 wait states a VALU write needs before the swap reads it.
+    float lo = acc[8 * q + e] * scale, hi = acc[8 * q + 4 + e] * scale;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+    v[e] = lo;
+    v[4 + e] = hi;
+  }
+}
+
 // Result tiles are written once and read by the NEXT kernel: a streaming (nt) store keeps them from displacing the weight and
 // activation lines the running kernel still re-reads from its L2 (experiment knob: -DGANK_NT_STORE=0|1).
 #ifndef GANK_NT_STORE
