@@ -1113,8 +1113,7 @@ static int launch_narrow_in(const IgemmArgs& a0, hipStream_t s) {
 //     the weight pieces": vmcnt retires in issue order);
 //   * LDS images are lane-linear per DMA (1 KB = 16 pixels or couts x 64 B); the 16-byte chunk inside a 64-B row is
 //     XOR-swizzled with (row >> 2) & 3 on the SOURCE address and on the read: conflict-free ds_read_b128 groups for
-//     the weights and for one-row pixel tiles (PW = 32; SQ_LDS_BANK_CONFLICT = 0), a residual 2-way conflict on 2 of
-//     16 lanes for the two-row tiles of PW = 16;
+//     the weights and for the pixel tiles (SQ_LDS_BANK_CONFLICT = 0; the two-row tiles of PW = 16 swizzle with hx >> 1);
 //   * the epilogue widens its stores with v_permlane32_swap (8 consecutive channels = 16 B per lane): with one block
 //     per CU nothing else overlaps them.
 // Measured (256 -> 256, 32 x 32, n = 128, random data): 1.10-1.14 PFLOP/s against 0.81-0.86 for conv_igemm_patch_kernel.
@@ -1143,6 +1142,11 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
   constexpr int HW_ = PW + 2, HROW = HW_ * 64;       // halo width (pixels), halo row pitch (bytes)
   constexpr int HPX = (PHH + 2) * HW_;               // halo pixels
   constexpr int RS = 32 / PW;                        // patch rows per 32-pixel MFMA tile
+  // halo swizzle: 16-byte chunk c of halo pixel (hy, hx) sits in slot c ^ ((hx >> HSW) & 3).  ds_read_b128 is served in four
+  // fixed 16-lane groups ({0-3,12-15,20-27}, ...); with the 18-pixel rows of PW = 16 (pitch = 8 slots mod 16) a group mixes
+  // two patch rows and (hx >> 2) left two lanes of most groups on one slot: 6.7 LDS cycles per read instead of 4 by the bank
+  // rule, SQ_LDS_BANK_CONFLICT = 30 % of SQ_LDS_IDX_ACTIVE.  (hx >> 1) is conflict-free there, (hx >> 2) for one-row tiles.
+  constexpr int HSW = PW == 16 ? 1 : 2;
   static_assert(PW == 32 || PW == 16, "patch width");
   static_assert(HPX * 64 <= PP_HALO_BYTES, "halo image");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1176,7 +1180,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
                                                                         a.CoutPad * a.Kpad * 2, 0x00020000);
 
   // DMA source offsets.  Halo (group 1 only, 6 pieces per wave): 16-byte unit q of the image = pixel q>>2 (row-major
-  // (PHH+2) x (PW+2), origin (py0-1, px0-1)), slot q&3 holding channel chunk (q&3) ^ ((hx>>2)&3).  Weights: unit q of a
+  // (PHH+2) x (PW+2), origin (py0-1, px0-1)), slot q&3 holding channel chunk (q&3) ^ ((hx>>HSW)&3).  Weights: unit q of a
   // slot = cout q>>2, slot q&3 holding k chunk (q&3) ^ ((co>>2)&3).
   unsigned h_off[6];
 #pragma unroll
@@ -1185,7 +1189,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
     const int hp = q >> 2, hy = hp / HW_, hx = hp - hy * HW_;
     const int iy = py0 - 1 + hy, ix = px0 - 1 + hx;
     const bool ok = hp < HPX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-    h_off[j] = ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin + (((q & 3) ^ ((hx >> 2) & 3)) << 3)) * 2) : OOB;
+    h_off[j] = ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin + (((q & 3) ^ ((hx >> HSW) & 3)) << 3)) * 2) : OOB;
   }
   int w_off[2];
 #pragma unroll
@@ -1205,7 +1209,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
     for (int d = 0; d < ND; d++) {
       const int hx = pcol + d + (PHASE ? 1 - pad_w : 0);
       const int hy = wm * (PHH / 2) + prow + (PHASE ? 1 - pad_h : 0);
-      b_lane[d][kk] = hy * HROW + hx * 64 + (((kk * 2 + h) ^ ((hx >> 2) & 3)) << 4);
+      b_lane[d][kk] = hy * HROW + hx * 64 + (((kk * 2 + h) ^ ((hx >> HSW) & 3)) << 4);
     }
   }
 
