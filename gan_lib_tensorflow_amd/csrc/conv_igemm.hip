@@ -1014,12 +1014,22 @@ __global__ __launch_bounds__(256) void conv_narrow_in_kernel(IgemmArgs a) {
       acc[i] = GANK_MFMA32(fa, fb[kk], acc[i]);
     }
   }
-  // Epilogue.  The accumulator layout (lane = pixel, registers = channels) would store 8 bytes per lane into 64
-  // different rows per instruction; this kernel is bound by its output write, so the wave's 32 x 128 tile is turned
-  // through LDS and leaves as whole 256-byte channel rows (64 lanes x 16 B = 4 pixels per store instruction).
-  __shared__ __attribute__((aligned(16))) bf16 sO[4][32][136];      // 272-B rows: conflict-free 8-B writes / 16-B reads
+  // Epilogue.  Whole 32-channel tiles leave in 16-byte pieces, a pixel's 256-byte run in eight back-to-back stores that
+  // merge in the L2 (epi_tile_wide); an earlier LDS transpose of the wave's tile cost two barriers and 2-way bank conflicts
+  // on both sides (SQ_LDS_BANK_CONFLICT = 50 % of the LDS cycles) in a kernel that is one latency chain per block.
   const bool otanh = (a.flags & GANK_OUT_TANH) != 0;
-  const bool fast = (a.Cout - tile_n * 128) >= 128 && !a.mask && !a.res;   // full 128-channel tile, bias/tanh only
+  if ((a.Cout & 31) == 0) {
+    if (m < a.M) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int ct = tile_n * 128 + i * 32;
+        if (ct < a.Cout)
+          epi_tile_wide<false>(acc[i], a.scale, a.bias ? a.bias + ct : nullptr, a.mask ? a.mask + (long)m * a.Cout + ct : nullptr,
+                               a.res ? a.res + (long)m * a.Cout + ct : nullptr, a.y + (long)m * a.Cout + ct, h, otanh, nullptr);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int co0 = tile_n * 128 + i * 32 + 4 * h;
@@ -1029,17 +1039,7 @@ __global__ __launch_bounds__(256) void conv_narrow_in_kernel(IgemmArgs a) {
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; e++) v[e] = acc[i][4 * g + e] * a.scale;
-      if (fast) {
-        if (a.bias) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + co);
-#pragma unroll
-          for (int e = 0; e < 4; e++) v[e] += b[e];
-        }
-        bf16x4 out;
-#pragma unroll
-        for (int e = 0; e < 4; e++) out[e] = f2bf(otanh ? tanhf(v[e]) : v[e]);
-        *reinterpret_cast<bf16x4*>(&sO[wave][r][i * 32 + 8 * g + 4 * h]) = out;
-      } else if (m < a.M && co < a.Cout) {
+      if (m < a.M && co < a.Cout) {
         const long o = (long)m * a.Cout + co;
         if (a.bias) {
           const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + co);
@@ -1061,17 +1061,6 @@ __global__ __launch_bounds__(256) void conv_narrow_in_kernel(IgemmArgs a) {
         for (int e = 0; e < 4; e++) out[e] = f2bf(otanh ? tanhf(v[e]) : v[e]);
         store_out(reinterpret_cast<bf16x4*>(a.y + o), out);
       }
-    }
-  }
-  if (fast) {                       // block-uniform
-    __syncthreads();
-    const int m0 = tile_m * 128 + wave * 32;
-#pragma unroll
-    for (int it = 0; it < 8; it++) {
-      const int idx = it * 64 + lane, row = idx >> 4, c16 = idx & 15;
-      if (m0 + row < a.M)
-        *reinterpret_cast<u32x4*>(a.y + (long)(m0 + row) * a.Cout + tile_n * 128 + c16 * 8) =
-            *reinterpret_cast<const u32x4*>(&sO[wave][row][c16 * 8]);
     }
   }
 }

@@ -632,35 +632,42 @@ __global__ __launch_bounds__(256) void conv_wgrad_packed_kernel(WgradArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; e++) bw[j][e] = 0.f;
 
-  u32x4 rN, rW[4];
-  auto load_step = [&](int s) {
-    const int mbase = (step0 + s) * 64;
+  // Register ring PFD steps deep.  The grid is one block per CU (4 waves) and a step is only 16 KB of the wide operand: one
+  // step of lookahead kept 16 KB per CU in flight = 2 TB/s at the latency under load, and the kernel ran at exactly that
+  // (24 us for the critic's 33.5-MB dy; MFMA pipe 1 % busy).  Loads are unconditional -- steps past the end re-load the last
+  // one, out-of-image taps read element 0 and are zeroed by a select -- so the compiler's vmcnt counting sees straight-line code.
+  constexpr int PFD = 3;
+  u32x4 rN[PFD], rW[PFD][4];
+  const int last = nsteps - 1;
+  auto load_step = [&](int s, u32x4& rn, u32x4 (&rw)[4]) {
+    const int mbase = (step0 + (s < last ? s : last)) * 64;
     {
       const int m = mbase + np;
       int n, oh, ow;
-      pix_decomp(m, a.H, a.W, a.shw, a.sw, n, oh, ow);
+      pix_decomp(m < a.M ? m : 0, a.H, a.W, a.shw, a.sw, n, oh, ow);
       bf16x8 v;
 #pragma unroll
       for (int e = 0; e < 8; e++) {
         const int ih = oh + k_dh[e], iw = ow + k_dw[e];
         const bool ok = m < a.M && k_c[e] >= 0 && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-        v[e] = ok ? pn[((long)(n * a.H + ih) * a.W + iw) * Cn + k_c[e]] : f2bf(0.f);
+        const bf16 t = pn[ok ? ((long)(n * a.H + ih) * a.W + iw) * Cn + k_c[e] : 0L];
+        v[e] = ok ? t : f2bf(0.f);
       }
-      rN = __builtin_bit_cast(u32x4, v);
+      rn = __builtin_bit_cast(u32x4, v);
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int m = mbase + w_p[j];
-      rW[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, m < a.M ? m * Cw * 2 + w_c[j] : OOB, 0, 0);
+      rw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, m < a.M ? m * Cw * 2 + w_c[j] : OOB, 0, 0);
     }
   };
-  auto store_step = [&](int buf) {
-    *reinterpret_cast<u32x4*>(sN + buf * SUBS + np * 32 + ncc * 8) = rN;
+  auto store_step = [&](int buf, const u32x4& rn, const u32x4 (&rw)[4]) {
+    *reinterpret_cast<u32x4*>(sN + buf * SUBS + np * 32 + ncc * 8) = rn;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      *reinterpret_cast<u32x4*>(sWd + buf * 4 * SUBS + w_lds[j]) = rW[j];
+      *reinterpret_cast<u32x4*>(sWd + buf * 4 * SUBS + w_lds[j]) = rw[j];
       if (PACK_X && do_bias) {      // bias gradient of the wide dy
-        const bf16x8 t = __builtin_bit_cast(bf16x8, rW[j]);
+        const bf16x8 t = __builtin_bit_cast(bf16x8, rw[j]);
 #pragma unroll
         for (int e = 0; e < 8; e++) bw[j][e] += bf2f(t[e]);
       }
@@ -673,12 +680,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_packed_kernel(WgradArgs a) {
   const int g = lane >> 4, li = lane & 15;
   const int tr_off = ((8 * (g >> 1) + (li >> 2)) * 32) + 16 * (g & 1) + 4 * (li & 3);
 
-  load_step(0);
-  store_step(0);
+#pragma unroll
+  for (int d = 0; d < PFD; d++) load_step(d, rN[d], rW[d]);     // steps 0 .. PFD-1 (clamped)
+  store_step(0, rN[0], rW[0]);
   __syncthreads();
-  for (int s = 0; s < nsteps; s++) {
+  // one step on ring slot D (compile-time): slot D held step s (already in LDS) and is refilled with step s + PFD
+  auto step = [&](int s, auto slot) {
+    constexpr int D = decltype(slot)::value;
     const int buf = s & 1;
-    if (s + 1 < nsteps) load_step(s + 1);
+    load_step(s + PFD, rN[D], rW[D]);
     const bf16* pN = sN + buf * SUBS + tr_off;
     const bf16* pW = sWd + (buf * 4 + wave) * SUBS + tr_off;
 #pragma unroll
@@ -692,9 +702,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_packed_kernel(WgradArgs a) {
       if constexpr (PACK_X) acc = GANK_MFMA32(fn, fw, acc);
       else acc = GANK_MFMA32(fw, fn, acc);
     }
-    if (s + 1 < nsteps) store_step(buf ^ 1);
+    if (s + 1 < nsteps) store_step(buf ^ 1, rN[(D + 1) % PFD], rW[(D + 1) % PFD]);
     __syncthreads();
+  };
+  int s0 = 0;
+  for (; s0 + PFD <= nsteps; s0 += PFD) {
+    step(s0 + 0, std::integral_constant<int, 0>{});
+    step(s0 + 1, std::integral_constant<int, 1>{});
+    step(s0 + 2, std::integral_constant<int, 2>{});
   }
+  if (s0 + 0 < nsteps) step(s0 + 0, std::integral_constant<int, 0>{});
+  if (s0 + 1 < nsteps) step(s0 + 1, std::integral_constant<int, 1>{});
 
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -737,8 +755,12 @@ static int launch_wgrad_packed(WgradArgs a, hipStream_t s) {
   const int Cw = PACK_X ? a.Cout : a.Cin;
   const int tiles = cdiv(Cw, 128);
   const int total_steps = cdiv(a.M, 64);
-  int splits = 256 / tiles;
-  if (splits > total_steps / 8) splits = total_steps / 8;
+  static int target = -1;     // experiment knob: GANK_WGRAD_PACKED_BLOCKS (blocks per launch; every block ends in 32 x 128 float atomics)
+  if (target < 0) { const char* e = getenv("GANK_WGRAD_PACKED_BLOCKS"); target = e ? atoi(e) : 256; }
+  int splits = target / tiles;
+  static int minsteps = -1;   // experiment knob: GANK_WGRAD_PACKED_MINSTEPS (64-pixel steps per block, at least)
+  if (minsteps < 0) { const char* e = getenv("GANK_WGRAD_PACKED_MINSTEPS"); minsteps = e ? atoi(e) : 8; }
+  if (splits > total_steps / minsteps) splits = total_steps / minsteps;
   if (splits < 1) splits = 1;
   a.steps_per_split = cdiv(total_steps, splits);
   a.splits = cdiv(total_steps, a.steps_per_split);
