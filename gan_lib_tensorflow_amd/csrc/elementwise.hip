@@ -74,6 +74,17 @@ __device__ __forceinline__ void up_range_S(int u, int& lo, int& hi) {
   lo = u == 0 ? 2 : (u == 1 ? 1 : 0);
   hi = u == 0 ? 2 : (u == 1 ? 2 : (u == 2 ? 1 : 0));
 }
+// Sum of the 3x3 taps [h0..h1] x [w0..w1] (one or two per axis) of one (ci, co) element; p = &w[0][0][ci][co], plane = Cin*Cout.
+// FOUR UNCONDITIONAL loads (a repeated address where a range holds one tap) and 0/1 factors, in the loop's order of addition
+// (bit-identical): run-time loop bounds made each tap its own load -> wait -> add round trip, up to 4 in a row per element and
+// 32 per thread of the one-chunk-per-thread layouts -- the critic's 1.7 M weights took 17 us, all of it latency.
+__device__ __forceinline__ float sum_taps(const float* __restrict__ p, long plane, bool flip, int h0, int h1, int w0, int w1) {
+  const float mh = h1 > h0 ? 1.f : 0.f, mw = w1 > w0 ? 1.f : 0.f;
+  const int t00 = flip ? (2 - h0) * 3 + (2 - w0) : h0 * 3 + w0, t01 = flip ? (2 - h0) * 3 + (2 - w1) : h0 * 3 + w1;
+  const int t10 = flip ? (2 - h1) * 3 + (2 - w0) : h1 * 3 + w0, t11 = flip ? (2 - h1) * 3 + (2 - w1) : h1 * 3 + w1;
+  const float a = p[t00 * plane], b = p[t01 * plane], c = p[t10 * plane], d = p[t11 * plane];
+  return ((a + mw * b) + mh * c) + (mh * mw) * d;
+}
 
 // One kernel builds both operands.  `ph` = phase matrix [4][CrP pad][4*CkP], `d4` = combined 4x4 matrix
 // [CrD pad][roundup(16*CkD,64)]; (sr, sk) are the strides of the row / inner channel in w's [ci][co] plane, so the
@@ -101,11 +112,7 @@ __device__ __forceinline__ void prep_up_element(const PrepUpArgs& q, long idx) {
       int h0, h1, w0, w1;
       up_range_R(p >> 1, tap >> 1, h0, h1);
       up_range_R(p & 1, tap & 1, w0, w1);
-      for (int dh = h0; dh <= h1; dh++)
-        for (int dw = w0; dw <= w1; dw++) {
-          const int t3 = q.flip ? (2 - dh) * 3 + (2 - dw) : dh * 3 + dw;
-          v += q.w[(long)t3 * q.plane + (long)r * q.srP + (long)c * q.skP];
-        }
+      v = sum_taps(q.w + (long)r * q.srP + (long)c * q.skP, q.plane, q.flip != 0, h0, h1, w0, w1);
     }
     q.ph[idx] = f2bf(v * q.scale);
   } else {
@@ -117,11 +124,7 @@ __device__ __forceinline__ void prep_up_element(const PrepUpArgs& q, long idx) {
       int h0, h1, w0, w1;
       up_range_S(tap >> 2, h0, h1);
       up_range_S(tap & 3, w0, w1);
-      for (int dh = h0; dh <= h1; dh++)
-        for (int dw = w0; dw <= w1; dw++) {
-          const int t3 = q.flip ? (2 - dh) * 3 + (2 - dw) : dh * 3 + dw;
-          v += q.w[(long)t3 * q.plane + (long)r * q.srD + (long)c * q.skD];
-        }
+      v = sum_taps(q.w + (long)r * q.srD + (long)c * q.skD, q.plane, q.flip != 0, h0, h1, w0, w1);
     }
     q.d4[i2] = f2bf(v * q.scale);
   }
@@ -146,12 +149,7 @@ __device__ __forceinline__ void prep_up_tile(const PrepUpArgs& q, bool ph, int t
   for (int i = ty; i < 32; i += 8) {
     const int c = c0 + i, r = r0 + tx;
     float v = 0.f;
-    if (r < Cr)
-      for (int dh = h0; dh <= h1; dh++)
-        for (int dw = w0; dw <= w1; dw++) {
-          const int t3 = q.flip ? (2 - dh) * 3 + (2 - dw) : dh * 3 + dw;
-          v += q.w[(long)t3 * q.plane + r + (long)c * sk];
-        }
+    if (r < Cr) v = sum_taps(q.w + r + (long)c * sk, q.plane, q.flip != 0, h0, h1, w0, w1);
     tl[i][tx] = v * q.scale;
   }
   __syncthreads();
@@ -351,10 +349,7 @@ __global__ void prep_batch_kernel(PrepTable t) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
           const int ci = chunk * 64 + kk * 16 + hh * 8 + j;
-          float v = 0.f;
-          for (int dh = h0; dh <= h1; dh++)
-            for (int dw = w0; dw <= w1; dw++) v += d.w[((long)((2 - dh) * 3 + (2 - dw)) * d.Cin + ci) * d.Cout + co];
-          o[j] = f2bf(0.25f * v);
+          o[j] = f2bf(0.25f * sum_taps(d.w + (long)ci * d.Cout + co, (long)d.Cin * d.Cout, true, h0, h1, w0, w1));
         }
         *reinterpret_cast<bf16x8*>((bf16*)d.wf + q * 8) = o;
       } else {
@@ -369,10 +364,7 @@ __global__ void prep_batch_kernel(PrepTable t) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
           const int co = kk * 16 + hh * 8 + j;
-          float v = 0.f;
-          for (int dh = h0; dh <= h1; dh++)
-            for (int dw = w0; dw <= w1; dw++) v += d.w[((long)((2 - dh) * 3 + (2 - dw)) * d.Cin + ci) * d.Cout + co];
-          o[j] = f2bf(0.25f * v);
+          o[j] = f2bf(0.25f * sum_taps(d.w + (long)ci * d.Cout + co, (long)d.Cin * d.Cout, true, h0, h1, w0, w1));
         }
         *reinterpret_cast<bf16x8*>((bf16*)d.wd + q * 8) = o;
       }
