@@ -687,6 +687,37 @@ extern "C" int gank_copy_bytes(void* dst, const void* src, long nbytes, void* st
   return 0;
 }
 
+// `count` equal-sized device buffers -> consecutive slots of one buffer, ONE launch (grid.y = the source); the pointer list
+// travels by value in the kernel arguments, so the call is hipGraph-capturable and needs no device-side table
+#define COPY_GATHER_MAX 16
+struct CopyGatherArgs { const unsigned char* src[COPY_GATHER_MAX]; };
+__global__ void copy_gather_kernel(CopyGatherArgs a, unsigned char* __restrict__ dst, long n16, long nbytes) {
+  // static selection of the by-value pointer (a dynamic index would spill the struct to scratch)
+  const unsigned char* src = a.src[0];
+#pragma unroll
+  for (int i = 1; i < COPY_GATHER_MAX; i++) src = (int)blockIdx.y == i ? a.src[i] : src;
+  unsigned char* d = dst + (long)blockIdx.y * nbytes;
+  const long t = blockIdx.x * (long)blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+  for (long i = t; i < n16; i += stride) reinterpret_cast<u32x4*>(d)[i] = reinterpret_cast<const u32x4*>(src)[i];
+  for (long i = n16 * 16 + t; i < nbytes; i += stride) d[i] = src[i];
+}
+extern "C" int gank_copy_bytes_gather(void* dst, const void* const* srcs, int count, long nbytes_each, void* stream) {
+  GANK_REQUIRE(dst && srcs && count > 0 && count <= COPY_GATHER_MAX && nbytes_each > 0, "copy_bytes_gather: bad arguments (1..%d sources)", COPY_GATHER_MAX);
+  CopyGatherArgs a{};
+  bool al = (((uintptr_t)dst | (uintptr_t)nbytes_each) & 15) == 0;
+  for (int i = 0; i < count; i++) {
+    GANK_REQUIRE(srcs[i], "copy_bytes_gather: source %d is null", i);
+    a.src[i] = (const unsigned char*)srcs[i];
+    al = al && (((uintptr_t)srcs[i]) & 15) == 0;
+  }
+  const long n16 = al ? nbytes_each / 16 : 0;
+  long blocks = ((al ? n16 : nbytes_each) + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(copy_gather_kernel, dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, (hipStream_t)stream, a, (unsigned char*)dst, n16, nbytes_each);
+  GANK_LAUNCH_OK("copy_bytes_gather");
+  return 0;
+}
+
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, long n) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = f2bf(x[i]);
 }

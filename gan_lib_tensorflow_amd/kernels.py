@@ -669,6 +669,16 @@ def copy_(dst, src):
     return dst
 
 
+def copy_gather_(dst, srcs):
+    """dst[i] <- srcs[i] (equal-sized contiguous tensors of dst's dtype, at most 16) in one kernel launch"""
+    n = len(srcs)
+    assert dst.is_contiguous() and dst.shape[0] == n and all(s.dtype == dst.dtype and s.is_contiguous() and s.numel() == dst[0].numel() for s in srcs), \
+        (tuple(dst.shape), [tuple(s.shape) for s in srcs])
+    ptrs = (C.c_void_p * n)(*[_p(s, None, "src").value for s in srcs])
+    _lib.check(lib().gank_copy_bytes_gather(_p(dst, None, "dst"), ptrs, n, dst[0].numel() * dst.element_size(), _stream()), "copy_bytes_gather")
+    return dst
+
+
 def clone(src):
     return copy_(torch.empty_like(src), src)
 

@@ -327,6 +327,10 @@ int gank_scale_f32(const float* x, const float* s, float* y, long n, void* strea
 /* dst[0:nbytes] = src[0:nbytes], device to device, as a kernel launch (the tf.assign / feed copies of the captured
  * step: sn.py:55-56 u.assign, gan_cifar_resnet.py:616-620 feeds); 16-byte vectorised when both are 16-B aligned */
 int gank_copy_bytes(void* dst, const void* src, long nbytes, void* stream);
+/* dst[i*nbytes_each : (i+1)*nbytes_each] = srcs[i][0:nbytes_each] for i < count (<= 16): the N_CRITIC feed batches of an
+ * iteration (gan_cifar_resnet.py:616-620: five session.run feeds) into the feed ring in ONE launch.  `srcs` is a HOST array
+ * of device pointers, copied into the kernel arguments */
+int gank_copy_bytes_gather(void* dst, const void* const* srcs, int count, long nbytes_each, void* stream);
 int gank_cast_f32_bf16(const float* x, void* y, long n, void* stream);
 int gank_cast_bf16_f32(const void* x, float* y, long n, void* stream);
 

@@ -80,4 +80,5 @@ def test_entry_points_reject_bad_arguments_with_a_message():
     assert "multiple of 64" in err()
     assert lib.gank_linear_bwd(fake, None, None, fake, None, None, 4, 8, 8, None) != 0 and "dx needs w" in err()
     assert lib.gank_copy_bytes(fake, fake, 0, None) != 0 and "bad arguments" in err()
+    assert lib.gank_copy_bytes_gather(fake, fake, 17, 16, None) != 0 and "1..16 sources" in err()
     assert lib.gank_conv2d_wgrad_batched(None, 0, 1, 8, 8, 128, 128, 3, 0, C.c_float(1.0), None) != 0 and "empty list" in err()

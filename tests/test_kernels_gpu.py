@@ -1132,3 +1132,13 @@ def test_conv_epilogue_statistics_feed_cond_batchnorm(K, form, n, h, groups):
     torch.cuda.synchronize()
     assert relerr(s1[:, 0], s0[:, 0].double().cpu().numpy()) < 1e-3 and relerr(s1[:, 1], s0[:, 1].double().cpu().numpy()) < (2e-3 if M >= 16384 else 4e-3)
     assert relerr(z1, z0.double().cpu().numpy()) < BF_TOL
+
+
+def test_copy_gather(K):
+    """gank_copy_bytes_gather: equal-sized device buffers into consecutive slots of one buffer, one launch (aligned and odd sizes)"""
+    for shape, dt in (((64, 3072), torch.uint8), ((64,), torch.int32), ((7, 3), torch.uint8)):
+        srcs = [(torch.arange(int(np.prod(shape)), device="cuda") * (i + 3) % 251).to(dt).reshape(shape) for i in range(5)]
+        dst = torch.zeros((5,) + shape, dtype=dt, device="cuda")
+        K.copy_gather_(dst, srcs)
+        torch.cuda.synchronize()
+        assert all(torch.equal(dst[i], srcs[i]) for i in range(5))
