@@ -155,10 +155,12 @@ def Discriminator(inputs, labels, update_collection=None, reuse=False, loss_head
         prefix = store.full_name('')[:-1]
         with _sn.precomputed(store, prefix, update_collection, prep_kind=_d_prep_kind):   # one batched SN for all 12 weights
             output = inputs.reshape(-1, 32, 32, 3)
+            with Fn.beside(inputs.device) as br:      # label embedding -> dense layer (:279-281) beside the first block
+                embedding_y = _embedding.embed_y(labels, VOCAB_SIZE, EMBEDDING_DIM)
+                embedding_y = _linear.Linear(embedding_y, EMBEDDING_DIM, DIM_D, 'D.Embedding_y', spectral_normed=True,
+                                             update_collection=update_collection, biases=True)
             output = OptimizedResBlockDisc1(output, spectral_normed=True, update_collection=update_collection, biases=True)
-            embedding_y = _embedding.embed_y(labels, VOCAB_SIZE, EMBEDDING_DIM)
-            embedding_y = _linear.Linear(embedding_y, EMBEDDING_DIM, DIM_D, 'D.Embedding_y', spectral_normed=True,
-                                         update_collection=update_collection, biases=True)
+            Fn.join_beside(br, embedding_y)
             output = Fn.concat_tile(output, embedding_y)               # expand_dims x2 + tile + concat (:282-284)
             output = ResidualBlock(output, DIM_D * 2, DIM_D, 3, 'D.Block.2', spectral_normed=True,
                                    update_collection=update_collection, resample='down', labels=labels, biases=True)
@@ -478,6 +480,7 @@ class SNGANTrainer:
             # the gradient seed is a persistent tensor: loss.backward() alone launches a ones_like fill per update
             loss.backward(gradient=Fn.unit_seed(loss))
             Fn.join_wgrad()
+            Fn.join_beside_backward()
         finally:
             Fn.reset_deferred()      # empty after a clean join; after an exception: nothing stale survives
             Fn.BATCH_SMALL_WGRADS = False

@@ -12,6 +12,8 @@ import torch
 from torch.autograd import Function
 
 from . import kernels as K
+import os as _os0
+_os_environ_get = _os0.environ.get
 
 BF16 = K.BF16
 # register-weight patch kernel (prep kind 3, GANK_W_FRAG) for the plain 3x3 convs at 16x16 / 32x32: measured equal to
@@ -71,6 +73,68 @@ def _on_side(fn, *operands):
     with torch.cuda.stream(st):
         fn()
     _Side.keep.append(operands)
+
+
+class _Beside:
+    """A short chain of latency-bound launches that does not depend on its neighbours (the critic's label embedding ->
+    dense layer, :279-281) on a second HIP stream: under hipGraph capture the fork and the join become parallel branches,
+    and the chain's 5-9-us kernels hide behind the first residual block instead of standing in the critical path.  The
+    backward pass needs no code: autograd runs a node's backward on the stream its forward ran on and orders the streams
+    at the hand-offs; only gradients written straight into the flat buffer (bias, embedding table) need the explicit join
+    before the optimiser (join_beside_backward).
+    MEASURED (interleaved A/B, 100 iterations each): 7.27-7.29 ms per iteration with the branch against 7.03 without -- each
+    fork / join inside a captured graph costs more in cross-queue signalling than the 30 us of kernels it hides.  Third
+    multi-stream experiment with this outcome (filter gradients, the generator pass beside the critic): off by default."""
+    enabled = _os_environ_get("GANK_SIDE_BRANCH", "0") == "1"
+    streams = {}
+    used = set()
+
+
+class beside:
+    """with beside(device) as br: ...ops...   then   join_beside(br, *results)  before the results are read"""
+    def __init__(self, device):
+        self.st = None
+        if _Beside.enabled and device.type == "cuda":
+            key = device.index if device.index is not None else torch.cuda.current_device()
+            if key not in _Beside.streams:
+                _Beside.streams[key] = torch.cuda.Stream(device=device)
+            self.st = _Beside.streams[key]
+
+    def __enter__(self):
+        if self.st is None:
+            return None
+        self.st.wait_stream(torch.cuda.current_stream())
+        self.ctx = torch.cuda.stream(self.st)
+        self.ctx.__enter__()
+        return self.st
+
+    def __exit__(self, *exc):
+        if self.st is not None:
+            self.ctx.__exit__(*exc)
+            _Beside.used.add(self.st)
+        return False
+
+
+def join_beside(st, *tensors):
+    if st is None:
+        return
+    main = torch.cuda.current_stream()
+    main.wait_stream(st)
+    for t in tensors:
+        t.record_stream(main)          # allocated on the branch stream, read on this one
+
+
+def join_beside_backward():
+    """after loss.backward(): the branch's gradient kernels are in stream order before the optimiser"""
+    capturing = torch.cuda.is_current_stream_capturing()
+    for st in _Beside.used:
+        if capturing:
+            with torch.cuda.stream(st):
+                forked = torch.cuda.is_current_stream_capturing()
+            if not forked:         # a forward pass outside this capture used the branch: none of its work belongs here
+                continue
+        torch.cuda.current_stream().wait_stream(st)
+    _Beside.used.clear()
 
 
 # Small same-shape filter gradients are not launched where autograd reaches them but collected and issued together
