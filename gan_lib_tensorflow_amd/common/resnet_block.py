@@ -30,6 +30,8 @@ DIM_D = 128
 COMMUTE_1X1 = True
 # the commuted 'up' shortcut stays at half resolution and is added, upsampled on the fly, in conv_2's epilogue
 FUSE_SHORTCUT_UPSAMPLE = True
+import os as _os
+FUSE_FORK_POOL = _os.environ.get("GANK_FORK_POOL", "1") == "1"   # down blocks: fan-out and shortcut pool as one op (one unpool-add launch backward)
 FUSE_IDENTITY_SHORTCUT_GRAD = True   # identity shortcut: its gradient is added by conv_1's input-gradient kernel
 
 
@@ -131,13 +133,20 @@ def ResidualBlock(inputs, input_dim, output_dim, filter_size, name,
     else:
         raise Exception('invalid resample value')
 
-    x_short, x_main = Fn.fork(inputs)
+    pooled_short = resample == 'down' and COMMUTE_1X1 and FUSE_FORK_POOL
+    if pooled_short:
+        x_main, x_short = Fn.fork_pool(inputs)     # the 1x1 shortcut conv commutes with the pool: it runs on the pooled alias
+    else:
+        x_short, x_main = Fn.fork(inputs)
     if output_dim == input_dim and resample is None:
         shortcut = x_short  # Identity skip-connection
         if FUSE_IDENTITY_SHORTCUT_GRAD and _normalize_kind(name + '.N1', labels) is None and x_short is not x_main:
             link = Fn.ShortcutLink()          # dy of the block rides on conv_1's input-gradient epilogue
             x_short._grad_link = link
             x_main._add_link = link
+    elif pooled_short:
+        shortcut = _conv2d.Conv2D(x_short, input_dim, output_dim, 1, 1, name + '.Shortcut', spectral_normed=spectral_normed,
+                                  update_collection=update_collection, he_init=False, biases=biases)
     else:
         shortcut = conv_shortcut(inputs=x_short, output_dim=output_dim, filter_size=1, name=name + '.Shortcut',
                                  spectral_normed=spectral_normed, update_collection=update_collection,
@@ -187,10 +196,15 @@ def OptimizedResBlockDisc1(inputs, spectral_normed=False, update_collection=None
     conv_1 = functools.partial(_conv2d.Conv2D, input_dim=inputs.shape[-1], output_dim=DIM_D)
     conv_2 = functools.partial(ConvMeanPool, output_dim=DIM_D)
     conv_shortcut = MeanPoolConv
-    x_short, x_main = Fn.fork(inputs)
-    shortcut = conv_shortcut(inputs=x_short, output_dim=DIM_D, filter_size=1, name='D.Block.1.Shortcut',
-                             spectral_normed=spectral_normed, update_collection=update_collection,
-                             he_init=False, biases=biases)
+    if FUSE_FORK_POOL:
+        x_main, pooled = Fn.fork_pool(inputs)
+        shortcut = _conv2d.Conv2D(pooled, pooled.shape[-1], DIM_D, 1, 1, 'D.Block.1.Shortcut', spectral_normed=spectral_normed,
+                                  update_collection=update_collection, he_init=False, biases=biases)
+    else:
+        x_short, x_main = Fn.fork(inputs)
+        shortcut = conv_shortcut(inputs=x_short, output_dim=DIM_D, filter_size=1, name='D.Block.1.Shortcut',
+                                 spectral_normed=spectral_normed, update_collection=update_collection,
+                                 he_init=False, biases=biases)
     output = conv_1(inputs=x_main, filter_size=3, name='D.Block.1.Conv1',
                     spectral_normed=spectral_normed, update_collection=update_collection,
                     he_init=True, biases=biases)

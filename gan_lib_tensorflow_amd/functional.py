@@ -654,6 +654,30 @@ def fork(x):
     return a, b
 
 
+class _ForkPool(Function):
+    """Fan-out into (x, mean_pool2x2(x)) -- the main path and the pooled shortcut of a down-sampling block.  Backward: the
+    pooled branch's gradient is unpooled INTO the main branch's (gank_unpool2x2_add with a base): one launch and three tensor
+    passes where the separate fork + pool spent an unpool and an add (two launches, six passes)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), K.pool2x2(x, 0.25)
+
+    @staticmethod
+    def backward(ctx, ga, gp):
+        if gp is None:
+            return ga
+        return K.unpool2x2_add(_c(gp), None if ga is None else _c(ga), 0.25)
+
+
+def fork_pool(x):
+    """-> (x for the main path, mean_pool2x2(x) for the shortcut)"""
+    if not x.requires_grad:
+        return x, K.pool2x2(x, 0.25)
+    return _ForkPool.apply(x)
+
+
 class _Relu(Function):
     @staticmethod
     def forward(ctx, x, leak):
