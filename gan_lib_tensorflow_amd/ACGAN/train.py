@@ -139,17 +139,19 @@ class ACGANTrainer:
 
     # ---- updates --------------------------------------------------------------------------------------------------
     def _d_fwd_bwd(self):
-        real = K.preprocess_real(self.real_u8, self.rng_state)         # [B, 32, 32, 3] bf16   (train.py:80-83)
-        self.d_flat['grads'].zero_()
-        loss = self.d_loss(real, self.real_labels)
-        loss.backward()
-        self.losses['d_loss'] = loss.detach()
+        with F2.one_update():            # every pass over the critic in this update shares one preparation of its weights
+            real = K.preprocess_real(self.real_u8, self.rng_state)         # [B, 32, 32, 3] bf16   (train.py:80-83)
+            self.d_flat['grads'].zero_()
+            loss = self.d_loss(real, self.real_labels)
+            loss.backward()
+            self.losses['d_loss'] = loss.detach()
 
     def _g_fwd_bwd(self):
-        self.store.zero_grads('g_net')
-        loss = self.g_loss()
-        loss.backward()
-        self.losses['g_loss'] = loss.detach()
+        with F2.one_update():
+            self.store.zero_grads('g_net')
+            loss = self.g_loss()
+            loss.backward()
+            self.losses['g_loss'] = loss.detach()
 
     def d_step(self, real_u8, labels):
         """one critic update on a uint8 [B, 3072] CHW-planar batch + int labels (train.py:199-204)"""

@@ -33,14 +33,60 @@ def _geom(W):
     return W.shape[0], W.shape[2], W.shape[3]
 
 
-def _wf(W):
+# MFMA operand layouts of a weight, prepared once per update and reused by every pass over the critic in it (real, fake,
+# interpolates, and the second-order terms) inside a `with one_update():` block,
+# so a captured update holds exactly one preparation launch per weight and layout.  Keyed by the parameter tensor (leaves
+# only: a weight that is itself a graph node -- the `g` of a second-order term -- is prepared where it is used).
+_prep_cache = {}
+_prep_cache_on = [False]
+
+
+class one_update:
+    """with one_update(): ...one update's passes...  -- weights do not change inside (the optimiser runs after it); outside
+    such a block every call prepares its own operands (direct model calls, tests that rewrite the weights in between)"""
+
+    def __enter__(self):
+        _prep_cache.clear()
+        self.prev, _prep_cache_on[0] = _prep_cache_on[0], True
+        return self
+
+    def __exit__(self, *exc):
+        _prep_cache_on[0] = self.prev
+        _prep_cache.clear()
+        return False
+
+
+def _prepared(W, want_f):
     k, cin, cout = _geom(W)
-    return K.prep_weights(_c(W.detach().to(torch.float32)).view(k, k, cin, cout), True, False)[0]
+    if not W.is_leaf or not _prep_cache_on[0]:
+        return K.prep_weights(_c(W.detach().to(torch.float32)).view(k, k, cin, cout), want_f, not want_f)[0 if want_f else 1]
+    key = (id(W), want_f)
+    hit = _prep_cache.get(key)
+    if hit is None or hit[0] is not W:
+        op = K.prep_weights(_c(W.detach().to(torch.float32)).view(k, k, cin, cout), want_f, not want_f)[0 if want_f else 1]
+        _prep_cache[key] = hit = (W, op)
+    return hit[1]
+
+
+def _wf(W):
+    return _prepared(W, True)
 
 
 def _wd(W):
-    k, cin, cout = _geom(W)
-    return K.prep_weights(_c(W.detach().to(torch.float32)).view(k, k, cin, cout), False, True)[1]
+    return _prepared(W, False)
+
+
+def _direct(p):
+    """In a backward pass that is not itself differentiated, a parameter whose `.grad` already exists receives its gradient by
+    in-place addition (AccumulateGrad).  The filter / bias gradient kernels ACCUMULATE into their target, so they can write
+    there themselves: no zero fill of a temporary, no add launch -- 2 of the ~6 launches a small layer's backward costs.
+    -> the buffer to accumulate into, or None (differentiated pass, non-leaf weight, no gradient buffer yet)."""
+    if torch.is_grad_enabled() or p is None or not p.is_leaf:
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape:
+        return None
+    return g
 
 
 class ConvF(Function):
@@ -51,6 +97,7 @@ class ConvF(Function):
         k, cin, cout = _geom(W)
         ctx.save_for_backward(x, W)
         ctx.has_bias = bias is not None
+        ctx.bias = bias                      # the parameter itself (for its .grad buffer), not a saved value
         n, h, w, _ = x.shape
         return K.conv2d_fprop(_c(x), _wf(W), bias.detach() if bias is not None else None, (h, w), cout, k)
 
@@ -59,8 +106,8 @@ class ConvF(Function):
         x, W = ctx.saved_tensors
         dy = _c(dy)
         dx = ConvD.apply(dy, W) if ctx.needs_input_grad[0] else None
-        dW = ConvW.apply(x, dy, W.shape) if ctx.needs_input_grad[1] else None
-        db = ColSum.apply(dy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dW = _conv_wgrad(x, dy, W) if ctx.needs_input_grad[1] else None
+        db = _colsum(dy, ctx.bias) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dW, db
 
 
@@ -79,8 +126,26 @@ class ConvD(Function):
         dy, W = ctx.saved_tensors
         g = _c(g)
         d_dy = ConvF.apply(g, W, None) if ctx.needs_input_grad[0] else None
-        dW = ConvW.apply(g, dy, W.shape) if ctx.needs_input_grad[1] else None
+        dW = _conv_wgrad(g, dy, W) if ctx.needs_input_grad[1] else None
         return d_dy, dW
+
+
+def _conv_wgrad(x, dy, W):
+    tgt = _direct(W)
+    if tgt is None:
+        return ConvW.apply(x, dy, W.shape)
+    k, cin, cout = _geom(W)
+    n, h, w, _ = x.shape
+    K.conv2d_wgrad(_c(x), _c(dy), tgt.view(k, k, cin, cout), (h, w), k)
+    return None
+
+
+def _colsum(dy, bias):
+    tgt = _direct(bias)
+    if tgt is None:
+        return ColSum.apply(dy)
+    K.colsum(_c(dy), tgt, 1.0)
+    return None
 
 
 class ConvW(Function):
@@ -126,6 +191,7 @@ class LinF(Function):
     def forward(ctx, x, W, bias):
         ctx.save_for_backward(x, W)
         ctx.has_bias = bias is not None
+        ctx.bias = bias
         return K.linear_fwd(_c(x), _c(W.detach().to(torch.float32)), bias.detach() if bias is not None else None)
 
     @staticmethod
@@ -133,8 +199,8 @@ class LinF(Function):
         x, W = ctx.saved_tensors
         dy = _c(dy)
         dx = LinD.apply(dy, W) if ctx.needs_input_grad[0] else None
-        dW = LinW.apply(x, dy) if ctx.needs_input_grad[1] else None
-        db = ColSum.apply(dy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dW = _lin_wgrad(x, dy, W) if ctx.needs_input_grad[1] else None
+        db = _colsum(dy, ctx.bias) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dW, db
 
 
@@ -151,8 +217,16 @@ class LinD(Function):
         dy, W = ctx.saved_tensors
         g = _c(g)
         d_dy = LinF.apply(g, W, None) if ctx.needs_input_grad[0] else None
-        dW = LinW.apply(g, dy) if ctx.needs_input_grad[1] else None
+        dW = _lin_wgrad(g, dy, W) if ctx.needs_input_grad[1] else None
         return d_dy, dW
+
+
+def _lin_wgrad(x, dy, W):
+    tgt = _direct(W)
+    if tgt is None or tgt.dim() != 2:
+        return LinW.apply(x, dy)
+    K.linear_bwd(_c(dy), _c(x), None, False, tgt, None)
+    return None
 
 
 class LinW(Function):
