@@ -345,12 +345,18 @@ class BNF(Function):
         y, stats = K.cbn_fwd(x, _zl(x), gamma.detach().view(1, -1), beta.detach().view(1, -1), 1, False)
         stats = stats.view(2, -1)
         ctx.save_for_backward(x, gamma, stats)
+        ctx.beta = beta                      # the parameter itself (for its .grad buffer)
         ctx.mark_non_differentiable(stats)
         return y, stats
 
     @staticmethod
     def backward(ctx, dy, _ds):
         x, gamma, stats = ctx.saved_tensors
+        tg, tb = _direct(gamma), _direct(ctx.beta)
+        if tg is not None and tb is not None:        # not differentiated again: the table-gradient kernel adds into .grad itself
+            c = x.shape[-1]
+            dx = K.cbn_bwd(_c(dy), x, x, _zl(x), gamma.detach().view(1, -1), stats.view(1, 2, c), tg.view(1, c), tb.view(1, c), 1, False)
+            return dx, None, None
         dx, dgamma, dbeta = BNB.apply(dy, x, gamma, stats)
         return dx, dgamma, dbeta
 
