@@ -1123,6 +1123,18 @@ __device__ __forceinline__ void pp_wait_vmcnt() {
   if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
 }
 
+// Matrix instruction of the two-group kernel.  1 (default): v_mfma_f32_16x16x32 -- the same multiply-adds in twice as many
+// instructions of half the size, the same 12 fragment reads per K-step.  On this power-bound kernel it runs 6-10 % faster than
+// the 32x32x16 form (timing experiment at equal memory traffic: 145 -> 130 us at n = 128, 312 -> 288 us at n = 320; the guide
+// reports 1.12-1.15x for bare loops).  0: the 32x32x16 form (kept for A/B runs: -DGANK_PP_M16=0).
+#ifndef GANK_PP_M16
+#define GANK_PP_M16 1
+#endif
+#ifdef GANK_ACT_F16
+#define GANK_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#else
+#define GANK_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#endif
 template <int MODE, int PW, bool STATS = false>   // MODE bit0: relu on the input operand; bit2: one output phase of a stride-2 transposed conv
 __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
   constexpr bool PHASE = (MODE & 4) != 0;
@@ -1136,6 +1148,16 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
   // two patch rows and (hx >> 2) left two lanes of most groups on one slot: 6.7 LDS cycles per read instead of 4 by the bank
   // rule, SQ_LDS_BANK_CONFLICT = 30 % of SQ_LDS_IDX_ACTIVE.  (hx >> 1) is conflict-free there, (hx >> 2) for one-row tiles.
   constexpr int HSW = PW == 16 ? 1 : 2;
+#if GANK_PP_M16
+  // 16x16x32 fragments: lane l reads 16-byte chunk l >> 4 of row l & 15 (a cout, or a pixel of one 16-pixel run of a patch
+  // row: no two-row tiles here).  chunk ^ ((row >> 1) & 2) puts the 16 lanes of every ds_read_b128 lane group on 16 different
+  // slots for every start column of the run (brute force over the four groups and all shifts 0..18), weights included.
+  auto pp_hswz = [](int hx) { return (hx >> 1) & 2; };
+  auto pp_wswz = [](int co) { return (co >> 1) & 2; };
+#else
+  auto pp_hswz = [](int hx) { return (hx >> HSW) & 3; };
+  auto pp_wswz = [](int co) { return (co >> 2) & 3; };
+#endif
   static_assert(PW == 32 || PW == 16, "patch width");
   static_assert(HPX * 64 <= PP_HALO_BYTES, "halo image");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1178,29 +1200,42 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
     const int hp = q >> 2, hy = hp / HW_, hx = hp - hy * HW_;
     const int iy = py0 - 1 + hy, ix = px0 - 1 + hx;
     const bool ok = hp < HPX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-    h_off[j] = ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin + (((q & 3) ^ ((hx >> HSW) & 3)) << 3)) * 2) : OOB;
+    h_off[j] = ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin + (((q & 3) ^ pp_hswz(hx)) << 3)) * 2) : OOB;
   }
   int w_off[2];
 #pragma unroll
   for (int j = 0; j < 2; j++) {
     const int q = (j * 8 + wave) * 64 + lane;
     const int co = q >> 2;
-    w_off[j] = ((tile_n * 256 + co) * a.Kpad + (((q & 3) ^ ((co >> 2) & 3)) << 3)) * 2;
+    w_off[j] = ((tile_n * 256 + co) * a.Kpad + (((q & 3) ^ pp_wswz(co)) << 3)) * 2;
   }
   // fragment read offsets of this lane (bytes): weights row r of the wave's cout range; pixels: halo column pcol + d of
   // the wave's first patch row (+ the tap's row offset as an immediate), d = the tap's column offset 0..2
   constexpr int ND = PHASE ? 2 : 3;
+#if GANK_PP_M16
+  const int p16 = lane & 15, kc = lane >> 4;         // row / pixel inside a 16-wide tile, 16-byte K chunk
+  constexpr int RPT = PW / 16;                       // 16-pixel tiles per patch row
+  int a_lane, b_lane[ND];
+  a_lane = PP_WRING + (wn * 64 + p16) * 64 + ((kc ^ pp_wswz(p16)) << 4);          // + i * 1024 for cout tile i (16 rows)
+#pragma unroll
+  for (int d = 0; d < ND; d++) {
+    const int hx = p16 + d + (PHASE ? 1 - pad_w : 0);
+    const int hy = wm * (PHH / 2) + (PHASE ? 1 - pad_h : 0);
+    b_lane[d] = hy * HROW + hx * 64 + ((kc ^ pp_hswz(hx)) << 4);                   // + (j / RPT) * HROW + (j % RPT) * 1024 for pixel tile j
+  }
+#else
   int a_lane[2], b_lane[ND][2];
 #pragma unroll
   for (int kk = 0; kk < 2; kk++) {
-    a_lane[kk] = PP_WRING + (wn * 64 + r) * 64 + (((kk * 2 + h) ^ ((r >> 2) & 3)) << 4);
+    a_lane[kk] = PP_WRING + (wn * 64 + r) * 64 + (((kk * 2 + h) ^ pp_wswz(r)) << 4);
 #pragma unroll
     for (int d = 0; d < ND; d++) {
       const int hx = pcol + d + (PHASE ? 1 - pad_w : 0);
       const int hy = wm * (PHH / 2) + prow + (PHASE ? 1 - pad_h : 0);
-      b_lane[d][kk] = hy * HROW + hx * 64 + (((kk * 2 + h) ^ ((hx >> HSW) & 3)) << 4);
+      b_lane[d][kk] = hy * HROW + hx * 64 + (((kk * 2 + h) ^ pp_hswz(hx)) << 4);
     }
   }
+#endif
 
   const int nch = a.Cin >> 5;
   auto issue_w = [&](int slot_bytes, int c, int tap) {      // K-step (chunk c, tap) -> ring slot
@@ -1215,6 +1250,13 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_t)(smem + buf * PP_HALO_BYTES + (j * 4 + wn) * 1024), 16, (int)(h_off[j] + (unsigned)c * 64u), 0, 0, 0);
   };
 
+#if GANK_PP_M16
+  f32x4 acc[4][8];                                   // [cout tile of 16][pixel tile of 16]
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#else
   f32x16 acc[2][4];
 #pragma unroll
   for (int i = 0; i < 2; i++)
@@ -1222,6 +1264,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
     for (int j = 0; j < 4; j++)
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+#endif
 
   // prologue: halo of chunk 0, weights of K-steps 0..3 (issue order matters: the counted waits rely on it)
   if (wm == 1) { issue_h(0, 0, 0); issue_h(0, 0, 3); }
@@ -1248,6 +1291,13 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
       constexpr int t = decltype(tc)::value;
       constexpr int dh1 = PHASE ? t / 2 : t / 3, dw1 = PHASE ? t % 2 : t % 3;
       if (wm == 1) __builtin_amdgcn_s_barrier();
+#if GANK_PP_M16
+      bf16x8 fa[4], fb[8];
+#pragma unroll
+      for (int i = 0; i < 4; i++) fa[i] = *reinterpret_cast<const bf16x8*>(smem + rslot + i * 1024 + a_lane);
+#pragma unroll
+      for (int j = 0; j < 8; j++) fb[j] = *reinterpret_cast<const bf16x8*>(smem + hb + (j / RPT + dh1) * HROW + (j % RPT) * 1024 + b_lane[dw1]);
+#else
       bf16x8 fa[2][2], fb[4][2];
 #pragma unroll
       for (int kk = 0; kk < 2; kk++) {
@@ -1256,6 +1306,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; j++) fb[j][kk] = *reinterpret_cast<const bf16x8*>(smem + hb + (j * RS + dh1) * HROW + b_lane[dw1][kk]);
       }
+#endif
       // group 1: half of the next chunk's halo, ahead of the weight pieces (clamped past the end: a spare image)
       if constexpr (t < 2) { if (wm == 1) issue_h((c + 1) & 1, cn, 3 * t); }
       {                                                // K-step p + 4 (clamped to the last one: a spare write into a dead slot)
@@ -1268,6 +1319,18 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
       else pp_wait_vmcnt<4>();
       if (wm == 0) __builtin_amdgcn_s_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if GANK_PP_M16
+      if constexpr ((MODE & 1) != 0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) fb[j] = __builtin_bit_cast(bf16x8, relu_bf16x8(__builtin_bit_cast(u32x4, fb[j])));
+      }
+      __builtin_amdgcn_sched_barrier(0);               // keeps the MFMA cluster behind the barrier (hipcc hoists it otherwise)
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+          acc[i][j] = GANK_MFMA16(fa[i], fb[j], acc[i][j]);
+#else
       if constexpr ((MODE & 1) != 0) {
 #pragma unroll
         for (int j = 0; j < 4; j++)
@@ -1282,6 +1345,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
 #pragma unroll
           for (int j = 0; j < 4; j++)
             acc[i][j] = GANK_MFMA32(fa[i][kk], fb[j][kk], acc[i][j]);
+#endif
       __builtin_amdgcn_sched_barrier(0);
       rslot += PP_WSLOT_BYTES; if (rslot == PP_NSLOT * PP_WSLOT_BYTES) rslot = 0;
       wslot += PP_WSLOT_BYTES; if (wslot == PP_NSLOT * PP_WSLOT_BYTES) wslot = 0;
@@ -1309,6 +1373,90 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
   // in fp32 wants a small mean.  A wave reduces its 32 pixels by shuffles; lanes r = 0 add to one of GANK_STAT_SLOTS copies
   // of the tower's sums (blocks of a tower spread over the copies: same-address float atomics serialise at the memory side).
   float keep1 = 0.f, keep2 = 0.f;
+#if GANK_PP_M16
+  // 16x16x32 accumulators: lane (p16, kc) of tile (i, j) holds couts 4 kc .. 4 kc + 3 of pixel p16 (8 bytes).  For a PAIR of
+  // cout tiles (2P, 2P+1), v_permlane16_swap with vdst = tile 2P's register and src = tile 2P+1's trades the odd 16-lane rows
+  // of the one for the even rows of the other: afterwards row kc owns 8 CONSECUTIVE couts 8 (kc >> 1) .. + 7 of tile
+  // 2P + (kc & 1) -- 16 bytes -- and the two stores of a pixel (P = 0, 1: 64 bytes each) leave back to back.
+  {
+    float st1[STATS ? 2 : 1][8], st2[STATS ? 2 : 1][8];
+    if constexpr (STATS) {
+#pragma unroll
+      for (int P = 0; P < 2; P++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) { st1[P][e] = 0.f; st2[P][e] = 0.f; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int py = py0 + wm * (PHH / 2) + j / RPT, px = px0 + (j % RPT) * 16 + p16;
+      const long m = PHASE ? ((long)(n * 2 * a.H + 2 * py + (phase >> 1))) * (2 * a.W) + 2 * px + (phase & 1) : ((long)(n * a.H + py)) * a.W + px;
+      const long mr = (!PHASE && (a.flags & IG_RES_UP2X)) ? ((long)(n * (a.H >> 1) + (py >> 1))) * (a.W >> 1) + (px >> 1) : m;
+      bf16x8 outl[2];
+#pragma unroll
+      for (int P = 0; P < 2; P++) {
+        const int co = tile_n * 256 + wn * 64 + (2 * P + (kc & 1)) * 16 + 8 * (kc >> 1);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          // inline asm as for v_permlane32_swap (the builtin's second result was dropped by hipcc 7.2); s_nop 1 = the 2 wait
+          // states a VALU write needs before the swap reads it
+          float lo = acc[2 * P][j][e] * a.scale, hi = acc[2 * P + 1][j][e] * a.scale;
+          asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+          v[e] = lo;
+          v[4 + e] = hi;
+        }
+        const long o = m * a.Cout + co;
+        // the statistics are of d = y - bias, carried beside y without ever adding the bias
+        float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, d[8];
+        if (a.bias) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + co), b1 = *reinterpret_cast<const f32x4*>(a.bias + co + 4);
+#pragma unroll
+          for (int e = 0; e < 4; e++) { bb[e] = b0[e]; bb[4 + e] = b1[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) { d[e] = v[e]; v[e] += bb[e]; }
+        if (a.mask) {
+          const bf16x8 mk = *reinterpret_cast<const bf16x8*>(a.mask + o);
+#pragma unroll
+          for (int e = 0; e < 8; e++) { const bool on = bf2f(mk[e]) > 0.f; v[e] = on ? v[e] : 0.f; d[e] = on ? d[e] : -bb[e]; }
+        }
+        if (a.res) {
+          const bf16x8 rs = *reinterpret_cast<const bf16x8*>(a.res + mr * a.Cout + co);
+#pragma unroll
+          for (int e = 0; e < 8; e++) { const float t = bf2f(rs[e]); v[e] += t; d[e] += t; }
+        }
+        if constexpr (STATS) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) { st1[P][e] += d[e]; st2[P][e] += d[e] * d[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) outl[P][e] = f2bf(otanh ? tanhf(v[e]) : v[e]);
+      }
+      bf16* line = a.y + m * a.Cout + tile_n * 256 + wn * 64 + (kc & 1) * 16 + 8 * (kc >> 1);
+#pragma unroll
+      for (int P = 0; P < 2; P++) store_out(reinterpret_cast<bf16x8*>(line + 32 * P), outl[P]);
+    }
+    if constexpr (STATS) {
+      // a 16-lane row holds 16 pixels of the same 16 channels (2 pairs x 8): DPP row sums, lane p16 keeps channel p16
+#pragma unroll
+      for (int P = 0; P < 2; P++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const float s1 = pp_row_sum(st1[P][e]), s2 = pp_row_sum(st2[P][e]);
+          const bool mine = p16 == P * 8 + e;
+          keep1 = mine ? s1 : keep1;
+          keep2 = mine ? s2 : keep2;
+        }
+    }
+  }
+  if constexpr (STATS) {
+    // ONE full-width atomic per statistic and wave: lane (p16, kc) carries channel (P, e) = (p16 >> 3, p16 & 7) of its row
+    float* dst = a.stat_sums + ((long)(n / a.stat_n_per_group) * GANK_STAT_SLOTS + (blockIdx.x % GANK_STAT_SLOTS)) * 2 * a.Cout;
+    const int co = tile_n * 256 + wn * 64 + (2 * (p16 >> 3) + (kc & 1)) * 16 + 8 * (kc >> 1) + (p16 & 7);
+    atomicAdd(dst + co, keep1);
+    atomicAdd(dst + a.Cout + co, keep2);
+  }
+#else
   {
     // all 64 running sums are live beside the accumulators (200 VGPRs; holding the packed results for a separate store pass
     // instead spilled 22-25 of them)
@@ -1400,6 +1548,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
     atomicAdd(dst + co, keep1);
     atomicAdd(dst + a.Cout + co, keep2);
   }
+#endif
 }
 
 static thread_local int tl_stats_done = 0;     // did the kernel chosen by the last dispatch accumulate a.stat_sums?
