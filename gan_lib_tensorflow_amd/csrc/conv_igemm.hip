@@ -1083,9 +1083,10 @@ static int launch_narrow_in(const IgemmArgs& a0, hipStream_t s) {
 // Cout % 256 == 0, on 8 x 32 (PW = 32) or 16 x 16 (PW = 16) pixel patches.
 // Every kernel above sits at ~0.9 PFLOP/s: a 128-wide tile, 2-3 blocks per CU, one __syncthreads (with its vmcnt(0)
 // drain) per K-step.  This one has the structure that gets past that on a GEMM:
-//   * one 512-thread block per CU owns 256 pixels x 256 couts; wave (wm, wn) = 128 pixels x 64 couts = 4 x 2 MFMA
-//     tiles, 128 accumulator registers, 12 fragment reads (ds_read_b128) per 16 MFMAs;
-//   * a phase is one K-step of 32 channels of one tap: {12 fragment reads R, LDS-DMA issues, counted vmcnt, 16 MFMAs M}
+//   * one 512-thread block per CU owns 256 pixels x 256 couts; wave (wm, wn) = 128 pixels x 64 couts = 8 x 4 tiles of
+//     v_mfma_f32_16x16x32 (GANK_PP_M16, default; 4 x 2 of 32x32x16 otherwise), 128 accumulator registers, 12 fragment reads
+//     (ds_read_b128) per K-step;
+//   * a phase is one K-step of 32 channels of one tap: {12 fragment reads R, LDS-DMA issues, counted vmcnt, 32 (16) MFMAs M}
 //     with ONE s_barrier, which group 0 (waves 0-3) takes between R and M and group 1 (waves 4-7: the other wave of
 //     each SIMD) at the top of the phase.  After barrier p group 0 therefore runs {M_p, R_p+1} while group 1 runs
 //     {R_p, M_p}: each SIMD's matrix pipe has one group's MFMAs beside the other group's reads and staging;
