@@ -108,6 +108,47 @@ __global__ __launch_bounds__(256) void cbn_finalize_kernel(const float* __restri
   }
 }
 
+// The apply loop of both forward kernels.  Rows of one sample share the label's gamma / beta rows: they are loaded once per
+// sample (not per row, behind a dependent label load), and four rows are in flight per thread -- the loop was 5 loads, a
+// 64-bit division and one 16-byte row per trip.  The expression and its order are the forward pass's own (the backward pass
+// recomputes the relu mask from it, bit for bit).
+__device__ __forceinline__ void cbn_apply_rows(const bf16* __restrict__ x, const int* __restrict__ labels, const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, bf16* __restrict__ y, const float (&mu)[8], const float (&iv)[8],
+                                               const CbnGeom& q, long r0, long r1, int rl, int RL, int g) {
+  if (r1 <= r0) return;
+  const int n0 = (int)(r0 / q.HW), n1 = (int)((r1 - 1) / q.HW);
+  for (int n = n0; n <= n1; n++) {
+    const long lo = r0 > (long)n * q.HW ? r0 : (long)n * q.HW;
+    const long hi = r1 < (long)(n + 1) * q.HW ? r1 : (long)(n + 1) * q.HW;
+    int lb = labels[n];
+    lb = lb < 0 ? 0 : (lb >= q.n_labels ? q.n_labels - 1 : lb);
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + (long)lb * q.C + g * 8);
+    const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + (long)lb * q.C + g * 8 + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + (long)lb * q.C + g * 8);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(beta + (long)lb * q.C + g * 8 + 4);
+    auto one = [&](const bf16x8& v, long r) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const float ga = e < 4 ? g0[e] : g1[e - 4], be = e < 4 ? b0[e] : b1[e - 4];
+        float t = (bf2f(v[e]) - mu[e]) * iv[e] * ga + be;
+        if (q.relu) t = fmaxf(t, 0.f);
+        o[e] = f2bf(t);
+      }
+      *reinterpret_cast<bf16x8*>(y + r * q.C + g * 8) = o;
+    };
+    long r = lo + rl;
+    for (; r + 3L * RL < hi; r += 4L * RL) {
+      bf16x8 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const bf16x8*>(x + (r + (long)u * RL) * q.C + g * 8);
+#pragma unroll
+      for (int u = 0; u < 4; u++) one(v[u], r + (long)u * RL);
+    }
+    for (; r < hi; r += RL) one(*reinterpret_cast<const bf16x8*>(x + r * q.C + g * 8), r);
+  }
+}
+
 // pass 3: normalise + gamma/beta gather (+relu)
 __global__ __launch_bounds__(CBN_NT) void cbn_apply_kernel(const bf16* __restrict__ x, const int* __restrict__ labels,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -126,25 +167,7 @@ __global__ __launch_bounds__(CBN_NT) void cbn_apply_kernel(const bf16* __restric
     mu[e] = stats[((long)grp * 2) * q.C + g * 8 + e];
     iv[e] = stats[((long)grp * 2 + 1) * q.C + g * 8 + e];
   }
-  for (long r = r0 + rl; r < r1; r += RL) {
-    const int n = (int)(r / q.HW);
-    int lb = labels[n];
-    lb = lb < 0 ? 0 : (lb >= q.n_labels ? q.n_labels - 1 : lb);
-    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + (long)lb * q.C + g * 8);
-    const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + (long)lb * q.C + g * 8 + 4);
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + (long)lb * q.C + g * 8);
-    const f32x4 b1 = *reinterpret_cast<const f32x4*>(beta + (long)lb * q.C + g * 8 + 4);
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + r * q.C + g * 8);
-    bf16x8 o;
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-      const float ga = e < 4 ? g0[e] : g1[e - 4], be = e < 4 ? b0[e] : b1[e - 4];
-      float t = (bf2f(v[e]) - mu[e]) * iv[e] * ga + be;
-      if (q.relu) t = fmaxf(t, 0.f);
-      o[e] = f2bf(t);
-    }
-    *reinterpret_cast<bf16x8*>(y + r * q.C + g * 8) = o;
-  }
+  cbn_apply_rows(x, labels, gamma, beta, y, mu, iv, q, r0, r1, rl, RL, g);
 }
 
 // apply pass fed by statistics the PRODUCING conv accumulated in its epilogue (gank_conv2d_fprop_stats): every block
@@ -185,25 +208,7 @@ __global__ __launch_bounds__(CBN_NT) void cbn_apply_sums_kernel(const bf16* __re
   float mu[8], iv[8];
 #pragma unroll
   for (int e = 0; e < 8; e++) { mu[e] = s_mu[g * 8 + e]; iv[e] = s_iv[g * 8 + e]; }
-  for (long r = r0 + rl; r < r1; r += RL) {
-    const int n = (int)(r / q.HW);
-    int lb = labels[n];
-    lb = lb < 0 ? 0 : (lb >= q.n_labels ? q.n_labels - 1 : lb);
-    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + (long)lb * q.C + g * 8);
-    const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + (long)lb * q.C + g * 8 + 4);
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + (long)lb * q.C + g * 8);
-    const f32x4 b1 = *reinterpret_cast<const f32x4*>(beta + (long)lb * q.C + g * 8 + 4);
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + r * q.C + g * 8);
-    bf16x8 o;
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-      const float ga = e < 4 ? g0[e] : g1[e - 4], be = e < 4 ? b0[e] : b1[e - 4];
-      float t = (bf2f(v[e]) - mu[e]) * iv[e] * ga + be;
-      if (q.relu) t = fmaxf(t, 0.f);
-      o[e] = f2bf(t);
-    }
-    *reinterpret_cast<bf16x8*>(y + r * q.C + g * 8) = o;
-  }
+  cbn_apply_rows(x, labels, gamma, beta, y, mu, iv, q, r0, r1, rl, RL, g);
 }
 
 static int cbn_geom(CbnGeom& q, int N, int HW, int C, int groups, int n_labels, int relu) {
@@ -383,34 +388,38 @@ __global__ __launch_bounds__(256) void cbn_bwd_tables_kernel(const float* __rest
 __global__ void cbn_bwd_apply_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, const bf16* __restrict__ y,
                                      const int* __restrict__ labels, const float* __restrict__ gamma, const float* __restrict__ stats,
                                      const float* __restrict__ M, bf16* __restrict__ dx, CbnGeom q, long total8, const float* __restrict__ beta) {
+  // A thread keeps ONE channel group g (blockDim is a multiple of C/8) and walks rows; the 40 parameter values
+  // of a row depend on its sample only and are reloaded when the sample changes, not per 16 bytes of data behind a label load
+  // (the loop was 5 tensor-independent 16-byte loads, two 64-bit divisions and a modulo per trip); two rows are in flight.
   const int cg = q.C >> 3;
   const int gs = q.N / q.groups;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
-    const int g = (int)(i % cg);
-    const long row = i / cg;
-    const int n = (int)(row / q.HW);
+  // block b owns the rows [b * per, (b + 1) * per): consecutive rows of a thread are blockDim / cg apart, in the same sample
+  const long rows_all = total8 / cg;
+  const long per = (rows_all + gridDim.x - 1) / gridDim.x;
+  const int g = threadIdx.x % cg;
+  const long rstride = blockDim.x / cg;
+  const long rbeg = blockIdx.x * per + threadIdx.x / cg;
+  const long rows = (blockIdx.x + 1) * per < rows_all ? (blockIdx.x + 1) * per : rows_all;
+  int n_cur = -1;
+  f32x4 mu0, mu1, iv0, iv1, ma0, ma1, mb0, mb1, ga0, ga1, be0 = {0.f, 0.f, 0.f, 0.f}, be1 = be0;
+  auto params = [&](int n) {
     const int grp = n / gs;
     int lb = labels[n];
     lb = lb < 0 ? 0 : (lb >= q.n_labels ? q.n_labels - 1 : lb);
-    const bf16x8 d = reinterpret_cast<const bf16x8*>(dy)[i];
-    const bf16x8 xv = reinterpret_cast<const bf16x8*>(x)[i];
-    bf16x8 yv;
-    if (q.relu && !beta) yv = reinterpret_cast<const bf16x8*>(y)[i];
-    // the 8 channels' parameters as 16-byte loads (40 scalar loads per 16 bytes of data made this pass instruction-bound:
-    // its tensors mostly sit in the Infinity Cache when it runs)
     const float* sp = stats + ((long)grp * 2) * q.C + g * 8;
     const float* mp = M + ((long)grp * 2) * q.C + g * 8;
     const float* gp = gamma + (long)lb * q.C + g * 8;
-    const f32x4 mu0 = *reinterpret_cast<const f32x4*>(sp), mu1 = *reinterpret_cast<const f32x4*>(sp + 4);
-    const f32x4 iv0 = *reinterpret_cast<const f32x4*>(sp + q.C), iv1 = *reinterpret_cast<const f32x4*>(sp + q.C + 4);
-    const f32x4 ma0 = *reinterpret_cast<const f32x4*>(mp), ma1 = *reinterpret_cast<const f32x4*>(mp + 4);
-    const f32x4 mb0 = *reinterpret_cast<const f32x4*>(mp + q.C), mb1 = *reinterpret_cast<const f32x4*>(mp + q.C + 4);
-    const f32x4 ga0 = *reinterpret_cast<const f32x4*>(gp), ga1 = *reinterpret_cast<const f32x4*>(gp + 4);
-    f32x4 be0 = {0.f, 0.f, 0.f, 0.f}, be1 = be0;
+    mu0 = *reinterpret_cast<const f32x4*>(sp); mu1 = *reinterpret_cast<const f32x4*>(sp + 4);
+    iv0 = *reinterpret_cast<const f32x4*>(sp + q.C); iv1 = *reinterpret_cast<const f32x4*>(sp + q.C + 4);
+    ma0 = *reinterpret_cast<const f32x4*>(mp); ma1 = *reinterpret_cast<const f32x4*>(mp + 4);
+    mb0 = *reinterpret_cast<const f32x4*>(mp + q.C); mb1 = *reinterpret_cast<const f32x4*>(mp + q.C + 4);
+    ga0 = *reinterpret_cast<const f32x4*>(gp); ga1 = *reinterpret_cast<const f32x4*>(gp + 4);
     if (q.relu && beta) {
       be0 = *reinterpret_cast<const f32x4*>(beta + (long)lb * q.C + g * 8);
       be1 = *reinterpret_cast<const f32x4*>(beta + (long)lb * q.C + g * 8 + 4);
     }
+  };
+  auto one = [&](long i, const bf16x8& d, const bf16x8& xv, const bf16x8& yv) {
     bf16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
@@ -426,6 +435,30 @@ __global__ void cbn_bwd_apply_kernel(const bf16* __restrict__ dy, const bf16* __
       o[e] = f2bf(iv * (gg - (e < 4 ? ma0[e] : ma1[e - 4]) - xh * (e < 4 ? mb0[e] : mb1[e - 4])));
     }
     reinterpret_cast<bf16x8*>(dx)[i] = o;
+  };
+  const bool ry = q.relu && !beta;
+  long row = rbeg;
+  for (; row + rstride < rows; row += 2 * rstride) {
+    const long ia = row * cg + g, ib = (row + rstride) * cg + g;
+    const bf16x8 da = reinterpret_cast<const bf16x8*>(dy)[ia], xa = reinterpret_cast<const bf16x8*>(x)[ia];
+    const bf16x8 db = reinterpret_cast<const bf16x8*>(dy)[ib], xb = reinterpret_cast<const bf16x8*>(x)[ib];
+    bf16x8 ya = da, yb = db;
+    if (ry) { ya = reinterpret_cast<const bf16x8*>(y)[ia]; yb = reinterpret_cast<const bf16x8*>(y)[ib]; }
+    int n = (int)(row / q.HW);
+    if (n != n_cur) { params(n); n_cur = n; }
+    one(ia, da, xa, ya);
+    n = (int)((row + rstride) / q.HW);
+    if (n != n_cur) { params(n); n_cur = n; }
+    one(ib, db, xb, yb);
+  }
+  for (; row < rows; row += rstride) {
+    const long ia = row * cg + g;
+    const bf16x8 da = reinterpret_cast<const bf16x8*>(dy)[ia], xa = reinterpret_cast<const bf16x8*>(x)[ia];
+    bf16x8 ya = da;
+    if (ry) ya = reinterpret_cast<const bf16x8*>(y)[ia];
+    const int n = (int)(row / q.HW);
+    if (n != n_cur) { params(n); n_cur = n; }
+    one(ia, da, xa, ya);
   }
 }
 
