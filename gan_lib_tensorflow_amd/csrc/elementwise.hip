@@ -414,30 +414,52 @@ __global__ void prep_batch_kernel(PrepTable t) {
       }
     }
   } else if (b < t.nwf[e]) {
+    // wf [CoutPad][Kpad] = w^T: a 64 (k) x 32 (cout) tile through LDS -- rows of w read along cout (128-byte runs), rows of wf
+    // written along k in 16-byte pieces (one per thread; 2-byte stores before)
     const int K = taps * d.Cin, Kpad = (K + 63) / 64 * 64, CoutPad = (d.Cout + 31) / 32 * 32;
-    __shared__ float tl[32][33];
-    const int ntk = Kpad / 32;
-    const int k0 = (b % ntk) * 32, c0 = (b / ntk) * 32;
+    __shared__ float tl[64][33];
+    const int ntk = Kpad / 64;
+    const int k0 = (b % ntk) * 64, c0 = (b / ntk) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int i = ty; i < 32; i += 8) {
+#pragma unroll
+    for (int i = ty; i < 64; i += 8) {
       const int k = k0 + i, c = c0 + tx;
       tl[i][tx] = (k < K && c < d.Cout) ? d.w[(long)k * d.Cout + c] : 0.f;
     }
     __syncthreads();
     bf16* wf = (bf16*)d.wf;
-    for (int i = ty; i < 32; i += 8) {
-      const int c = c0 + i, k = k0 + tx;
-      if (c < CoutPad && k < Kpad) {
-        const bf16 v = f2bf(tl[tx][i]);
-        wf[(long)c * Kpad + k] = v;
-        if (d.kind == 3) wf[(long)CoutPad * Kpad + frag_index(c, k, d.Cin, taps, Kpad / 64)] = v;   // fragment-major copy
-      }
-    }
+    const int c = c0 + (threadIdx.x >> 3), kp = (threadIdx.x & 7) * 8;       // CoutPad % 32 == 0, Kpad % 64 == 0: always inside
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = f2bf(tl[kp + j][threadIdx.x >> 3]);
+    *reinterpret_cast<bf16x8*>(wf + (long)c * Kpad + k0 + kp) = o;
+    // fragment-major copy: 8 consecutive k of one 8-aligned group are consecutive there too (Cin % 64 == 0)
+    if (d.kind == 3) *reinterpret_cast<bf16x8*>(wf + (long)CoutPad * Kpad + frag_index(c, k0 + kp, d.Cin, taps, Kpad / 64)) = o;
   } else {
     const int Kpad2 = (taps * d.Cout + 63) / 64 * 64, CinPad = (d.Cin + 31) / 32 * 32;
     const long total = (long)CinPad * Kpad2;
     bf16* wd = (bf16*)d.wd;
     const long base = (long)(b - t.nwf[e]) * 2048;
+    if ((d.Cout & 7) == 0 && d.kind != 3) {
+      // 8 consecutive k = 8 consecutive couts of one tap (or 8 pad columns): two 16-byte loads, one 16-byte store
+      const long i = base + 8 * threadIdx.x;
+      if (i < total) {
+        const int ci = (int)(i / Kpad2), k = (int)(i - (long)ci * Kpad2);
+        bf16x8 o;
+        if (ci < d.Cin && k < taps * d.Cout) {
+          const int tp = k / d.Cout, co = k - tp * d.Cout;
+          const float* p = d.w + ((long)(taps - 1 - tp) * d.Cin + ci) * d.Cout + co;
+          const f32x4 a = *reinterpret_cast<const f32x4*>(p), bb = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+          for (int u = 0; u < 4; u++) { o[u] = f2bf(a[u]); o[4 + u] = f2bf(bb[u]); }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; u++) o[u] = f2bf(0.f);
+        }
+        *reinterpret_cast<bf16x8*>(wd + i) = o;
+      }
+      return;
+    }
     for (int j = 0; j < 8; j++) {
       const long i = base + j * 256 + threadIdx.x;
       if (i >= total) break;
@@ -468,7 +490,7 @@ extern "C" int gank_conv2d_prep_weights_batched(const gank_prep_desc* table, int
                    "prep_weights_batched: entry %d: kind %d needs ksize 3 and both outputs (1, 2, 5) / channels %% 64 == 0 (3) / %% 32 == 0 (4) / Cin %% 64 == 0 (5)", base + i, d.kind);
       t.d[i] = d;
       const int taps = d.ksize * d.ksize;
-      int nwf = d.wf ? (roundup(taps * d.Cin, 64) / 32) * (roundup(d.Cout, 32) / 32) : 0;
+      int nwf = d.wf ? (roundup(taps * d.Cin, 64) / 64) * (roundup(d.Cout, 32) / 32) : 0;
       int nwd = d.wd ? cdiv((long)roundup(d.Cin, 32) * roundup(taps * d.Cout, 64), 2048) : 0;
       if (d.kind == 1 || d.kind == 2) {
         t.up[i] = d.kind == 1 ? prep_up_args(1, d.w, d.wf, d.wd, d.Cin, d.Cout) : prep_up_args(2, d.w, d.wd, d.wf, d.Cin, d.Cout);
