@@ -167,35 +167,39 @@ __host__ __device__ inline long prep_up_total(const PrepUpArgs& q) { return 4L *
 // The operand whose inner index runs along w's SLOW channel axis (sr == 1: the phase matrix of UpsampleConv, the
 // 4x4 matrix of ConvMeanPool) read element-wise is a stride-Cout gather (the 16.8 M-element generator preparation took
 // 91 us).  Here one block turns a 32 x 32 (row, inner) tile of one (phase, tap) / tap slice through LDS: coalesced reads
-// along the rows, coalesced writes along the inner index.  Needs Ck % 32 == 0 and no K padding.
+// along the rows, coalesced writes along the inner index.  Needs Ck % 64 == 0 and no K padding.
 __host__ __device__ inline int prep_up_tiles(const PrepUpArgs& q, bool ph) {
-  return ph ? 16 * (q.CrPpad / 32) * (q.CkP / 32) : 16 * (q.CrDpad / 32) * (q.CkD / 32);
+  return ph ? 16 * (q.CrPpad / 32) * (q.CkP / 64) : 16 * (q.CrDpad / 32) * (q.CkD / 64);
 }
-__device__ __forceinline__ void prep_up_tile(const PrepUpArgs& q, bool ph, int tile, float (*tl)[33]) {
+__device__ __forceinline__ void prep_up_tile(const PrepUpArgs& q, bool ph, int tile, float (*tl)[33]) {     // tl: [64][33]
+  // a 64 (inner index c) x 32 (row r) tile: reads along r (128-byte runs of w's fast axis), writes along c in 16-byte pieces
   const int Cr = ph ? q.CrP : q.CrD, Ck = ph ? q.CkP : q.CkD, CrPad = ph ? q.CrPpad : q.CrDpad, sk = ph ? q.skP : q.skD;
-  const int tk = Ck / 32, tr = CrPad / 32;
-  const int c0 = (tile % tk) * 32, r0 = ((tile / tk) % tr) * 32, slice = tile / (tk * tr);      // slice 0..15
+  const int tk = Ck / 64, tr = CrPad / 32;
+  const int c0 = (tile % tk) * 64, r0 = ((tile / tk) % tr) * 32, slice = tile / (tk * tr);      // slice 0..15
   int h0, h1, w0, w1;
   if (ph) { up_range_R((slice >> 2) >> 1, (slice & 3) >> 1, h0, h1); up_range_R((slice >> 2) & 1, slice & 1, w0, w1); }
   else { up_range_S(slice >> 2, h0, h1); up_range_S(slice & 3, w0, w1); }
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int i = ty; i < 32; i += 8) {
+#pragma unroll
+  for (int i = ty; i < 64; i += 8) {
     const int c = c0 + i, r = r0 + tx;
     float v = 0.f;
     if (r < Cr) v = sum_taps(q.w + r + (long)c * sk, q.plane, q.flip != 0, h0, h1, w0, w1);
     tl[i][tx] = v * q.scale;
   }
   __syncthreads();
-  for (int i = ty; i < 32; i += 8) {
-    const int r = r0 + i, c = c0 + tx;
-    if (ph) q.ph[((long)((slice >> 2) * CrPad + r) * 4 + (slice & 3)) * Ck + c] = f2bf(tl[tx][i]);
-    else q.d4[(long)r * q.Kpad4 + (long)slice * Ck + c] = f2bf(tl[tx][i]);
-  }
+  const int ri = threadIdx.x >> 3, cp = (threadIdx.x & 7) * 8;
+  const int r = r0 + ri, c = c0 + cp;
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; j++) o[j] = f2bf(tl[cp + j][ri]);
+  if (ph) *reinterpret_cast<bf16x8*>(q.ph + ((long)((slice >> 2) * CrPad + r) * 4 + (slice & 3)) * Ck + c) = o;
+  else *reinterpret_cast<bf16x8*>(q.d4 + (long)r * q.Kpad4 + (long)slice * Ck + c) = o;
 }
 
 // standalone form: `ntiles` leading blocks take the transposed tiles of matrix `ph_tiled`, the rest go element-wise over [lo, hi)
 __global__ __launch_bounds__(256) void prep_upconv_kernel(PrepUpArgs q, int ntiles, int ph_tiled, long lo, long hi) {
-  __shared__ float tt[32][33];
+  __shared__ float tt[64][33];
   if ((int)blockIdx.x < ntiles) { prep_up_tile(q, ph_tiled != 0, blockIdx.x, tt); return; }
   const long base = lo + (long)(blockIdx.x - ntiles) * 2048;
   const long nph = 4L * q.CrPpad * 4 * q.CkP;
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256) void prep_upconv_kernel(PrepUpArgs q, int ntil
 struct PrepUpSplit { int ntiles, nelem; long lo, hi; };
 static inline PrepUpSplit prep_up_split(const PrepUpArgs& q, int kind) {
   const bool ph = kind == 1;          // which matrix has the strided source: kind 1 the phase matrix, kind 2 the 4x4 one
-  const bool tiled = ph ? (q.srP == 1 && q.CkP % 32 == 0) : (q.srD == 1 && q.CkD % 32 == 0 && q.Kpad4 == 16 * q.CkD);
+  const bool tiled = ph ? (q.srP == 1 && q.CkP % 64 == 0) : (q.srD == 1 && q.CkD % 64 == 0 && q.Kpad4 == 16 * q.CkD);
   const long nph = 4L * q.CrPpad * 4 * q.CkP, total = prep_up_total(q);
   PrepUpSplit s;
   s.ntiles = tiled ? prep_up_tiles(q, ph) : 0;
@@ -328,7 +332,7 @@ __global__ void prep_batch_kernel(PrepTable t) {
   const int taps = d.ksize * d.ksize;
   if (d.kind == 1 || d.kind == 2) {       // UpsampleConv / ConvMeanPool 3x3 operands
     const PrepUpArgs& q = t.up[e];
-    __shared__ float tt[32][33];
+    __shared__ float tt[64][33];
     const long nph = 4L * q.CrPpad * 4 * q.CkP, total = prep_up_total(q);
     if (b < t.nwf[e]) {                   // transposed tiles of the strided-source matrix (nwf = their count, or 0)
       prep_up_tile(q, d.kind == 1, b, tt);
