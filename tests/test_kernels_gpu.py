@@ -1142,3 +1142,30 @@ def test_copy_gather(K):
         K.copy_gather_(dst, srcs)
         torch.cuda.synchronize()
         assert all(torch.equal(dst[i], srcs[i]) for i in range(5))
+
+
+def test_fork_pool_equals_fork_then_meanpool(K):
+    """functional.fork_pool: (x, mean_pool2x2(x)) with ONE unpool-add launch backward == the separate fork + meanpool2x2
+    (forward bit-identical; the backward sum has one rounding to bf16 instead of two: compared against float64)"""
+    from gan_lib_tensorflow_amd import functional as Fn
+    rng = np.random.default_rng(5)
+    x, xt = bf(rng.normal(size=(4, 8, 8, 16)))
+    ga, gat = bf(rng.normal(size=(4, 8, 8, 16)))
+    gp, gpt = bf(rng.normal(size=(4, 4, 4, 16)))
+    x1 = xt.clone().requires_grad_(True)
+    a1, p1 = Fn.fork_pool(x1)
+    torch.autograd.backward([a1, p1], [gat, gpt])
+    x2 = xt.clone().requires_grad_(True)
+    a2, b2 = Fn.fork(x2)
+    p2 = Fn.meanpool2x2(b2)
+    torch.autograd.backward([a2, p2], [gat, gpt])
+    torch.cuda.synchronize()
+    assert torch.equal(a1, a2) and torch.equal(p1, p2)
+    ref = ga + 0.25 * np.repeat(np.repeat(gp, 2, axis=1), 2, axis=2)
+    assert relerr(x1.grad, ref) < BF_TOL and relerr(x2.grad, ref) < BF_TOL
+    # only one branch carries a gradient
+    x3 = xt.clone().requires_grad_(True)
+    a3, p3 = Fn.fork_pool(x3)
+    p3.backward(gpt)
+    torch.cuda.synchronize()
+    assert relerr(x3.grad, 0.25 * np.repeat(np.repeat(gp, 2, axis=1), 2, axis=2)) < BF_TOL
