@@ -163,7 +163,10 @@ def main():
 
     per_gpu = S.BATCH_SIZE // world if args.strong else S.BATCH_SIZE
     assert per_gpu >= 2 and per_gpu * world == (S.BATCH_SIZE if args.strong else S.BATCH_SIZE * world), "batch 64 must split evenly"
-    tr = S.SNGANTrainer(batch_size=per_gpu, device=device, seed=0, use_graphs=not args.no_graphs, process_group=pg)
+    # allow_eager_fallback: a capture failure on SOME ranks must not leave the others waiting in a collective -- every rank
+    # finishes its warm-up, then all of them agree (MIN over ranks) whether to go on
+    tr = S.SNGANTrainer(batch_size=per_gpu, device=device, seed=0, use_graphs=not args.no_graphs, process_group=pg,
+                        allow_eager_fallback=True)
     feed = S.synthetic_batches(per_gpu, device, seed=rank)
 
     def barrier():
@@ -175,8 +178,15 @@ def main():
     warm = max(args.warmup, 2)    # iterations 0 and 1 run eagerly and capture the D and G graphs
     for _ in range(warm):
         tr.train_iteration(feed)
-    if not args.no_graphs and not tr.use_graphs:
-        # capture fell back to eager execution during warm-up: a line that says "graphs" must not describe eager runs
+    graphs_ok = torch.tensor([1 if (args.no_graphs or tr.use_graphs) else 0], dtype=torch.int32, device=device)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(graphs_ok, op=dist.ReduceOp.MIN, group=pg)
+    if not int(graphs_ok.item()):
+        # capture fell back to eager execution during warm-up (on at least one rank): a line that says "graphs" must not
+        # describe eager runs.  Every rank takes this branch together and tears its process group down.
+        if world > 1:
+            dist.destroy_process_group()
         print("[bench] hipGraph capture failed during warm-up; refusing to report an eager run as a graph run "
               "(use --no-graphs to measure eager execution)", file=sys.stderr, flush=True)
         sys.exit(3)
@@ -237,9 +247,10 @@ def main():
         traffic, traffic_src, tj = None, None, None
         import glob
         for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):   # latest round first
-            tj = json.load(open(tpath))
-            traffic = traffic_per_launch(tj, dom)
+            cand = json.load(open(tpath))
+            traffic = traffic_per_launch(cand, dom)
             if traffic is not None:
+                tj = cand                      # only a file that covers the dominant kernel feeds the ratios below
                 traffic_src = f"profiles/{os.path.basename(tpath)} (" + tj["method"] + ")"
                 break
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,

@@ -238,8 +238,12 @@ class SNGANTrainer:
     and averaged inside the Adam kernel (grad_scale = 1/world_size; the reference averages its tower
     losses, :436,:498)."""
 
-    def __init__(self, batch_size=BATCH_SIZE, device="cuda", seed=0, use_graphs=True, process_group=None, state=None):
+    def __init__(self, batch_size=BATCH_SIZE, device="cuda", seed=0, use_graphs=True, process_group=None, state=None,
+                 allow_eager_fallback=False):
+        """allow_eager_fallback: a failed hipGraph capture degrades to eager execution (with a message on stderr) instead of
+        raising -- a run that asked for graphs never silently becomes a 10x slower eager run otherwise."""
         self.device = torch.device(device)
+        self.allow_eager_fallback = allow_eager_fallback
         self.batch = batch_size
         self.store = set_default_store(ParamStore(self.device, seed=seed))
         self.pg = process_group
@@ -585,16 +589,24 @@ class SNGANTrainer:
                     graphs.append(g)
                 self._graphs['g_seg'] = graphs
             except Exception as e:  # noqa: BLE001
-                import sys
-                print(f"[gank] hipGraph capture of the bucketed generator update failed ({e}); running eagerly", file=sys.stderr)
-                self.use_graphs = False
-                torch.cuda.synchronize()
+                self._capture_failed('bucketed generator update', e)
             return
         self._ensure_clean(self.g_flat)
         for i, g in enumerate(self._graphs['g_seg']):
             g.replay()
             between(i)
         self.g_flat["clean"] = True
+
+    def _capture_failed(self, what, e):
+        """The eager first execution already WAS this update, so nothing is lost either way: raise (default), or fall back
+        to eager execution for the rest of the run when the caller allowed it."""
+        import sys
+        torch.cuda.synchronize()
+        if not self.allow_eager_fallback:
+            raise RuntimeError(f"hipGraph capture of the {what} failed ({e}); pass allow_eager_fallback=True (or "
+                               f"use_graphs=False) to run eagerly") from e
+        print(f"[gank] hipGraph capture of the {what} failed ({e}); running eagerly", file=sys.stderr)
+        self.use_graphs = False
 
     def _allreduce(self, flat):
         if self.world > 1:
@@ -631,11 +643,8 @@ class SNGANTrainer:
                     with _capture(g2):
                         opt.apply()
                 self._graphs[key] = (g1, g2)
-            except Exception as e:  # noqa: BLE001 -- capture is an optimisation, never a correctness need
-                import sys
-                print(f"[gank] hipGraph capture of the {key!r} update failed ({e}); running eagerly", file=sys.stderr)
-                self.use_graphs = False
-                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                self._capture_failed(f'{key!r} update', e)
             return
         g1, g2 = self._graphs[key]
         self._ensure_clean(flat)
@@ -662,10 +671,7 @@ class SNGANTrainer:
                     fn()
                 self._graphs[key] = (g, None)
             except Exception as e:  # noqa: BLE001
-                import sys
-                print(f"[gank] hipGraph capture of {key!r} failed ({e}); running eagerly", file=sys.stderr)
-                self.use_graphs = False
-                torch.cuda.synchronize()
+                self._capture_failed(repr(key), e)
             return
         self._graphs[key][0].replay()
 

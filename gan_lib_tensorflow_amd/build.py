@@ -29,17 +29,25 @@ def build(force=False, verbose=True, variants=("bf16", "fp16")):
     plans = []
     for variant in variants:
         if variant == "fp16":
+            if "GANK_LIB_NAME" in os.environ or os.environ.get("GANK_EXTRA_FLAGS"):
+                continue        # an experiment build (scratch/README.md) is the bf16 library under its own name: the production
+                                # fp16 objects must not be rebuilt with the experiment's flags
             lib, flags, objdir = os.path.join(HERE, "libgank_f16.so"), base_flags + ["-DGANK_ACT_F16"], "_obj_f16"
         else:
             lib, flags = os.path.join(HERE, os.environ.get("GANK_LIB_NAME", "libgank.so")), base_flags
             objdir = "_obj" + ("_" + os.environ["GANK_LIB_NAME"] if "GANK_LIB_NAME" in os.environ else "")
         os.makedirs(os.path.join(HERE, objdir), exist_ok=True)
+        # a change of flags rebuilds every object of the directory (mtimes alone would keep objects of the old flags)
+        stamp, flag_str = os.path.join(HERE, objdir, "flags.txt"), " ".join(flags)
+        stale = not os.path.exists(stamp) or open(stamp).read() != flag_str
+        if stale:
+            open(stamp, "w").write(flag_str)
         objs, procs = [], []
         for src in SOURCES:
             sp = os.path.join(CSRC, src)
             op = os.path.join(HERE, objdir, src.replace(".hip", ".o"))
             objs.append(op)
-            if force or _newer(sp, op) or any(_newer(h, op) for h in hdrs):
+            if force or stale or _newer(sp, op) or any(_newer(h, op) for h in hdrs):
                 cmd = ["hipcc", *flags, "-I", INC, "-c", sp, "-o", op]
                 if verbose:
                     print(" ".join(cmd), flush=True)

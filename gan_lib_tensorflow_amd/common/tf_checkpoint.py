@@ -371,10 +371,26 @@ def trainer_state_from_checkpoint(ckpt, g_prefix='Generator', d_prefix='Discrimi
             continue
         out[k] = v
     for key, net in (('beta2_power', g_prefix), ('beta2_power_1', d_prefix)):
-        if key in ckpt:
-            p = float(np.asarray(ckpt[key]).reshape(-1)[0])
-            out[net + '/adam_t'] = np.asarray(int(round(np.log(p) / np.log(beta2))) if 0.0 < p < 1.0 else 0, dtype=np.int64)
+        if net + '/adam_t' in ckpt:          # written by checkpoint_from_trainer_state: the exact count
+            out[net + '/adam_t'] = np.asarray(int(np.asarray(ckpt[net + '/adam_t']).reshape(-1)[0]), dtype=np.int64)
+        elif key in ckpt:
+            out[net + '/adam_t'] = np.asarray(adam_t_from_beta2_power(np.asarray(ckpt[key]).reshape(-1)[0], beta2), dtype=np.int64)
     return out
+
+
+def adam_t_from_beta2_power(p, beta2=0.9):
+    """Step count from TF's float32 `beta2_power` = beta2 ** t.  The power underflows to exactly 0.0 after ~980 steps at
+    beta2 = 0.9 (under 200 iterations of the critic), and is a denormal with few significant bits before that: there the
+    count cannot be recovered, and need not be -- the bias correction sqrt(1 - beta2^t) is 1.0f from t ~ 160 on, which is
+    what TF itself computes from the stored 0.0.  Such a power maps to the SATURATED count (the smallest t whose power is
+    below the smallest float32 denormal); only p == 1 (a fresh optimiser) maps to 0."""
+    p = float(p)
+    t_sat = int(np.ceil(np.log(1e-45) / np.log(beta2)))
+    if p >= 1.0:
+        return 0
+    if p <= 1.2e-38:                  # zero, negative (corrupt) or denormal
+        return t_sat
+    return min(int(round(np.log(p) / np.log(beta2))), t_sat)
 
 
 def checkpoint_from_trainer_state(state, g_prefix='Generator', d_prefix='Discriminator', beta1=0.0, beta2=0.9):
@@ -390,7 +406,8 @@ def checkpoint_from_trainer_state(state, g_prefix='Generator', d_prefix='Discrim
         if net + '/adam_t' in state:
             t = int(np.asarray(state[net + '/adam_t']))
             out['beta1_power' + suffix] = np.asarray(beta1 ** t if t > 0 else 1.0, dtype=np.float32)
-            out['beta2_power' + suffix] = np.asarray(beta2 ** t, dtype=np.float32)
+            out['beta2_power' + suffix] = np.asarray(beta2 ** t, dtype=np.float32)       # 0.0f from t ~ 980 on, as in TF
+            out[net + '/adam_t'] = np.asarray(t, dtype=np.int64)      # the exact count beside it (read back in preference)
     return out
 
 

@@ -851,6 +851,12 @@ class _HingeHead(Function):
         if need_b:
             bt, bacc = _target(bias)
             ctx.ret[1] = None if bacc else bt
+        for prm, tgt in ((W, wt), (bias, bt)):
+            # this launch accumulates into the flat gradient buffer DURING THE FORWARD pass: a forward-only call (a loss
+            # evaluation, a capture that aborts before its backward pass) must not leave the buffer marked clean
+            fl = getattr(prm, "_flat", None) if tgt is not None else None
+            if fl is not None:
+                fl["clean"] = False
         buf = out.t if out is not None else None
         loss, logits, dx = K.critic_head_hinge(_c(x), W.detach().reshape(-1), bias.detach() if bias is not None else None, n_real, mode,
                                                ctx.needs_input_grad[0], wt.view(-1) if wt is not None else None, bt, buf)

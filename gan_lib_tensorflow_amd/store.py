@@ -121,6 +121,8 @@ class ParamStore:
         self.flat[prefix] = dict(params=params, grads=grads, names=names, offsets=offsets, grads_all=grads_all,
                                  scratch=grads_all[total:] if scratch_tail else None,
                                  m=torch.zeros_like(params), v=torch.zeros_like(params))
+        for k in names:
+            self.vars[k]._flat = self.flat[prefix]      # a kernel that accumulates OUTSIDE a backward pass marks the buffer dirty through this
         return self.flat[prefix]
 
     def flatten_state(self, prefix):

@@ -96,3 +96,28 @@ def test_name_map_and_optimistic_restore_into_a_store(tmp_path):
     assert sorted(restored) == ["Generator/G.Input/W", "Generator/G.Input/b"]                    # name AND shape must match (misc.py:290-296)
     assert np.array_equal(w.detach().numpy(), saved["Generator/G.Input/W"]) and np.array_equal(b.detach().numpy(), saved["Generator/G.Input/b"])
     assert float(d.detach().sum()) == 128.0
+
+
+def test_adam_step_count_survives_the_float32_underflow_of_beta2_power(tmp_path):
+    """TF keeps beta2 ** t as float32: exactly 0.0 after ~980 steps (under 200 critic iterations).  A checkpoint of the
+    reference then carries no count; the importer must treat it as SATURATED (bias correction = 1, what TF computes),
+    never as a fresh optimiser, and our own writer/reader round trip must keep the exact count."""
+    assert np.float32(0.9) ** np.float32(5000) == 0.0
+    t_sat = C.adam_t_from_beta2_power(0.0)
+    assert t_sat >= 900 and 1.0 - 0.9 ** t_sat == 1.0                       # sqrt(1 - beta2^t) is exactly 1
+    assert C.adam_t_from_beta2_power(1.0) == 0                              # a fresh optimiser
+    assert C.adam_t_from_beta2_power(np.float32(0.9 ** 55)) == 55
+    assert C.adam_t_from_beta2_power(np.float32(1e-42)) == t_sat            # denormal: few bits left, count not recoverable
+    # a reference-written checkpoint late in training: powers are 0.0f
+    st = C.trainer_state_from_checkpoint({"beta2_power": np.asarray(0.0, np.float32), "beta2_power_1": np.asarray(0.0, np.float32)})
+    assert int(st["Generator/adam_t"]) == t_sat and int(st["Discriminator/adam_t"]) == t_sat
+    # our own state at t = 5000 / 25000: through write_checkpoint / read_checkpoint and back, exactly
+    state = {"Generator/adam_t": np.asarray(5000, np.int64), "Discriminator/adam_t": np.asarray(25000, np.int64),
+             "Generator/G.Input/b": np.zeros(3, np.float32)}
+    tensors = C.checkpoint_from_trainer_state(state)
+    assert float(tensors["beta2_power"]) == 0.0 and float(tensors["beta2_power_1"]) == 0.0      # what TF itself would hold
+    prefix = str(tmp_path / "late.ckpt")
+    C.write_checkpoint(prefix, tensors)
+    back = C.trainer_state_from_checkpoint(C.read_checkpoint(prefix))
+    assert int(back["Generator/adam_t"]) == 5000 and int(back["Discriminator/adam_t"]) == 25000
+    assert back["Generator/adam_t"].dtype == np.int64
