@@ -143,6 +143,7 @@ def _g_prep_kind(name, W):
     return 0
 
 
+LABEL_TABLE = _os.environ.get("GANK_LABEL_TABLE", "1") == "1"    # the critic's label branch through a per-label table (0: per-sample embedding + dense layer + tile)
 FUSED_HEAD = _os.environ.get("GANK_FUSED_HEAD", "1") == "1"      # D.Output + hinge loss (+ the layer's three gradients) as one launch where the train step asks for it
 
 
@@ -153,15 +154,30 @@ def Discriminator(inputs, labels, update_collection=None, reuse=False, loss_head
     store = get_default_store()
     with store.variable_scope("Discriminator", reuse=reuse):
         prefix = store.full_name('')[:-1]
-        with _sn.precomputed(store, prefix, update_collection, prep_kind=_d_prep_kind):   # one batched SN for all 12 weights
+        # the label branch as a per-label table out of the spectral norm's second launch (functional.concat_label)
+        label_dense = None
+        if LABEL_TABLE:
+            names = [prefix + '/Embedding.Label/embedding_map', prefix + '/D.Embedding_y/W', prefix + '/D.Embedding_y/b']
+            if all(nm in store.vars for nm in names):
+                label_dense = (store.vars[names[0]], names[1], store.vars[names[2]])
+        with _sn.precomputed(store, prefix, update_collection, prep_kind=_d_prep_kind, label_dense=label_dense):   # one batched SN for all 12 weights
             output = inputs.reshape(-1, 32, 32, 3)
-            with Fn.beside(inputs.device) as br:      # label embedding -> dense layer (:279-281) beside the first block
-                embedding_y = _embedding.embed_y(labels, VOCAB_SIZE, EMBEDDING_DIM)
-                embedding_y = _linear.Linear(embedding_y, EMBEDDING_DIM, DIM_D, 'D.Embedding_y', spectral_normed=True,
-                                             update_collection=update_collection, biases=True)
-            output = OptimizedResBlockDisc1(output, spectral_normed=True, update_collection=update_collection, biases=True)
-            Fn.join_beside(br, embedding_y)
-            output = Fn.concat_tile(output, embedding_y)               # expand_dims x2 + tile + concat (:282-284)
+            if LABEL_TABLE:
+                # embed_y -> Linear -> expand_dims x2 -> tile -> concat (:276-284) depends on a sample only through its label:
+                # the dense layer runs on the 10 table rows and the concat gathers (same variables, same creation order)
+                emb_table = _embedding.embedding_variable(VOCAB_SIZE, EMBEDDING_DIM)
+                w_emb, b_emb = _linear.linear_variables(EMBEDDING_DIM, DIM_D, 'D.Embedding_y', spectral_normed=True,
+                                                        update_collection=update_collection, biases=True)
+                output = OptimizedResBlockDisc1(output, spectral_normed=True, update_collection=update_collection, biases=True)
+                output = Fn.concat_label(output, labels, emb_table, w_emb, b_emb)
+            else:
+                with Fn.beside(inputs.device) as br:      # label embedding -> dense layer (:279-281) beside the first block
+                    embedding_y = _embedding.embed_y(labels, VOCAB_SIZE, EMBEDDING_DIM)
+                    embedding_y = _linear.Linear(embedding_y, EMBEDDING_DIM, DIM_D, 'D.Embedding_y', spectral_normed=True,
+                                                 update_collection=update_collection, biases=True)
+                output = OptimizedResBlockDisc1(output, spectral_normed=True, update_collection=update_collection, biases=True)
+                Fn.join_beside(br, embedding_y)
+                output = Fn.concat_tile(output, embedding_y)               # expand_dims x2 + tile + concat (:282-284)
             output = ResidualBlock(output, DIM_D * 2, DIM_D, 3, 'D.Block.2', spectral_normed=True,
                                    update_collection=update_collection, resample='down', labels=labels, biases=True)
             if blocks.res_chain8_eligible(output, DIM_D, ['D.Block.3', 'D.Block.4'], labels):

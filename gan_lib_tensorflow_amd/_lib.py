@@ -38,6 +38,11 @@ class PrepDesc(C.Structure):
     _fields_ = [("w", P), ("wf", P), ("wd", P), ("ksize", I), ("Cin", I), ("Cout", I), ("kind", I)]
 
 
+class LabelDenseDesc(C.Structure):
+    """gank_label_dense_desc"""
+    _fields_ = [("table", P), ("bias", P), ("out", P), ("V", I), ("D", I), ("weight", I)]
+
+
 # name -> argument ctypes (all return int unless listed in _RET)
 PROTOTYPES = {
     "gank_version": [],
@@ -48,6 +53,7 @@ PROTOTYPES = {
     "gank_conv2d_fprop": [P, P, P, P, P, P, I, I, I, I, I, I, I, F, P],
     "gank_conv2d_fprop_stats": [P, P, P, P, P, P, I, I, I, I, I, I, I, F, P, I, P, P],
     "gank_conv2d_dgrad": [P, P, P, P, P, I, I, I, I, I, I, I, F, P],
+    "gank_meanpool_conv1x1_fprop": [P, P, P, P, P, I, I, I, I, I, P],
     "gank_conv2d_wgrad_batched": [C.POINTER(WgradItem), I, I, I, I, I, I, I, I, F, P],
     "gank_conv2d_wgrad_ws_elems": [I, I, I, I, I, I, I],
     "gank_conv2d_wgrad": [P, P, P, P, P, L, I, I, I, I, I, I, I, F, P],
@@ -72,8 +78,14 @@ PROTOTYPES = {
     "gank_deconv2d_dgrad": [P, P, P, I, I, I, I, I, I, P],
     "gank_deconv2d_wgrad": [P, P, P, I, I, I, I, I, I, P],
     "gank_colsum_bf16": [P, P, L, I, F, P],
+    "gank_sn_ws_floats": [I, I],
     "gank_sn_power_iter_fwd": [C.POINTER(SnDesc), I, P],
     "gank_sn_power_iter_bwd": [C.POINTER(SnDesc), I, P],
+    "gank_sn_power_iter_fwd_prep": [C.POINTER(SnDesc), I, C.POINTER(PrepDesc), C.POINTER(C.c_int), I, C.POINTER(LabelDenseDesc), P],
+    "gank_label_dense_table": [P, P, P, P, P, I, I, I, P],
+    "gank_concat_label_fwd": [P, P, P, P, I, I, I, I, I, P],
+    "gank_concat_label_bwd": [P, P, P, I, I, I, I, P],
+    "gank_label_dense_bwd": [P, P, P, P, P, P, P, I, I, I, I, P],
     "gank_cbn_parts": [L],
     "gank_cbn_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     "gank_cbn_fwd_from_sums": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P],
@@ -143,7 +155,7 @@ PROTOTYPES = {
     "gank_critic_feed": [P, P, P, P, P, P, P, P, I, I, P],
     "gank_debug_tr_probe": [P, P],
 }
-_RET = {"gank_last_error": C.c_char_p, "gank_conv2d_wgrad_ws_elems": C.c_long, "gank_convpool3x3_wgrad_ws_elems": C.c_long, "gank_prof_calibrate": C.c_double, "gank_prof_bytes": C.c_double}
+_RET = {"gank_last_error": C.c_char_p, "gank_sn_ws_floats": C.c_long, "gank_conv2d_wgrad_ws_elems": C.c_long, "gank_convpool3x3_wgrad_ws_elems": C.c_long, "gank_prof_calibrate": C.c_double, "gank_prof_bytes": C.c_double}
 
 _lib = None
 

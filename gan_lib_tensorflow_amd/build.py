@@ -65,7 +65,7 @@ def build(force=False, verbose=True, variants=("bf16", "fp16")):
     if failed:
         raise RuntimeError("hipcc failed")
     for lib, objs, procs in plans:
-        if force or procs or not os.path.exists(lib):
+        if force or procs or not os.path.exists(lib) or any(_newer(o, lib) for o in objs):     # (a link that failed after its objects compiled)
             cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs]
             if verbose:
                 print(" ".join(cmd), flush=True)

@@ -114,12 +114,15 @@ def _flat_base(store, prefix, us):
 
 
 @contextlib.contextmanager
-def precomputed(store, prefix, update_collection=None, prepare=True, prep_kind=None):
+def precomputed(store, prefix, update_collection=None, prepare=True, prep_kind=None, label_dense=None):
     """Normalise every SN weight under `prefix` in ONE batched launch group; inside the block
     `spectral_normed_weight(W, ...)` returns the precomputed W_bar for those W.  Also (prepare=True)
     builds the bf16 MFMA operand layouts of all W_bar in one launch and hands every W_bar a pre-zeroed
     slice of one flat gradient buffer, so the backward pass needs no per-weight memsets.
-    `prep_kind(variable_name, W)` -> 0 | 1 | 2 | None chooses the operand layout per weight (kernels.prep_weights_batched)."""
+    `prep_kind(variable_name, W)` -> 0 | 1 | 2 | None chooses the operand layout per weight (kernels.prep_weights_batched).
+    label_dense = (embedding table, name of a dense weight under `prefix`, bias | None): the per-label rows of that dense
+    layer on the table come out of the same launches (`W_bar._label_T`, functional.concat_label).
+    Round 3: normalisation, operand copies and label table are ONE launch pair (gank_sn_power_iter_fwd_prep)."""
     pairs = sn_pairs(store, prefix, with_names=True)
     if not pairs:
         yield None
@@ -127,10 +130,18 @@ def precomputed(store, prefix, update_collection=None, prepare=True, prep_kind=N
     Ws = [w for w, _, _ in pairs]
     us = [u for _, u, _ in pairs]
     flat = _flat_base(store, prefix, us)
+    kinds = None
+    if prepare:
+        kinds = [prep_kind(nm, w) for w, _, nm in pairs] if prep_kind is not None else [0] * len(pairs)
+    prep = (kinds, True) if prepare and len(pairs) <= 16 else None
+    label = None
+    if label_dense is not None and len(pairs) <= 16:
+        tab, wname, bias = label_dense
+        label = (tab, [nm for _, _, nm in pairs].index(wname), bias)
     if update_collection is None:
         # u <- u_final on every execution (sn.py:55-56): the kernels keep the u they read for the backward pass and
         # write u_final over u themselves -- no snapshot copy, no copy-back
-        W_bars, batch = Fn.spectral_norm_batch(Ws, [u.detach() for u in us], snapshot=True, inplace=True)
+        W_bars, batch = Fn.spectral_norm_batch(Ws, [u.detach() for u in us], snapshot=True, inplace=True, prep=prep, label=label)
     else:
         if update_collection != NO_OPS:
             if flat is not None:                      # one snapshot copy instead of one per weight
@@ -142,11 +153,11 @@ def precomputed(store, prefix, update_collection=None, prepare=True, prep_kind=N
                 u_read = [K.clone(u.detach()) for u in us]
         else:
             u_read = [u.detach() for u in us]
-        W_bars, batch = Fn.spectral_norm_batch(Ws, u_read)
+        W_bars, batch = Fn.spectral_norm_batch(Ws, u_read, prep=prep, label=label)
         _apply_update(us, batch, update_collection)
     if prepare:
-        kinds = [prep_kind(nm, w) for w, _, nm in pairs] if prep_kind is not None else None
-        K.prep_weights_batched(list(W_bars), want_d=True, kinds=kinds)
+        if prep is None:           # more weights than one launch pair takes: the separate preparation launch
+            K.prep_weights_batched(list(W_bars), want_d=True, kinds=kinds)
         if any(w.requires_grad for w in Ws):
             need = sum(w.numel() for w in W_bars)
             gflat = _grad_scratch[0]

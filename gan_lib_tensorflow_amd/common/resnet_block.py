@@ -32,6 +32,7 @@ COMMUTE_1X1 = True
 FUSE_SHORTCUT_UPSAMPLE = True
 import os as _os
 FUSE_FORK_POOL = _os.environ.get("GANK_FORK_POOL", "1") == "1"   # down blocks: fan-out and shortcut pool as one op (one unpool-add launch backward)
+FUSE_POOL_GATHER = _os.environ.get("GANK_POOL_GATHER", "1") == "1"   # first critic block: the shortcut's 2x2 mean inside its 1x1 conv's gather
 FUSE_IDENTITY_SHORTCUT_GRAD = True   # identity shortcut: its gradient is added by conv_1's input-gradient kernel
 
 
@@ -196,7 +197,12 @@ def OptimizedResBlockDisc1(inputs, spectral_normed=False, update_collection=None
     conv_1 = functools.partial(_conv2d.Conv2D, input_dim=inputs.shape[-1], output_dim=DIM_D)
     conv_2 = functools.partial(ConvMeanPool, output_dim=DIM_D)
     conv_shortcut = MeanPoolConv
-    if FUSE_FORK_POOL:
+    if FUSE_FORK_POOL and FUSE_POOL_GATHER and Fn.fork_pool_conv1x1_ok(inputs, DIM_D):
+        # the 2x2 mean inside the 1x1 conv's gather: fork + pool + conv as one launch
+        w_s, b_s = _conv2d.conv2d_variables(inputs.shape[-1], DIM_D, 1, 1, 'D.Block.1.Shortcut', spectral_normed=spectral_normed,
+                                            update_collection=update_collection, he_init=False, biases=biases)
+        x_main, shortcut = Fn.fork_pool_conv1x1(inputs, w_s, b_s)
+    elif FUSE_FORK_POOL:
         x_main, pooled = Fn.fork_pool(inputs)
         shortcut = _conv2d.Conv2D(pooled, pooled.shape[-1], DIM_D, 1, 1, 'D.Block.1.Shortcut', spectral_normed=spectral_normed,
                                   update_collection=update_collection, he_init=False, biases=biases)

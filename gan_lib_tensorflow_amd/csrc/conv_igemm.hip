@@ -57,6 +57,7 @@ struct IgemmArgs {
   const float* cbn_beta;
   const int* cbn_labels;     // [N]
   int cbn_n_per_group, cbn_n_labels;
+  bf16* aux_out;             // narrow-input kernel, POOL: the 2x2 mean-pooled input it gathered, [N,H,W,CIN] (or null)
 };
 
 static int phase_inner_env() {
@@ -969,10 +970,15 @@ static int launch_patch2(const IgemmArgs& a0, hipStream_t s) {
 // The kernel is bound by writing the output (33.5 MB for D.Block.1.Conv1 at N=128); the K-packed generic path spent
 // 45-55 us per call in per-element index arithmetic for it, this one a few microseconds above the write time.
 // ------------------------------------------------------------------------------------------------------
-template <int KS, int CIN>
+// POOL (KS = 1): the input is stored at twice the resolution, [N,2H,2W,CIN], and each gathered value is the 2x2 mean of
+// gan_cifar_resnet.py:129-130 (MeanPoolConv: pool, THEN the 1x1 conv) rounded to the element type -- the arithmetic of
+// pool2x2_kernel<1> + this kernel, without the launch in between; the pooled tensor (which the filter gradient needs) is a
+// side output of the lanes that gathered it.
+template <int KS, int CIN, bool POOL = false>
 __global__ __launch_bounds__(256) void conv_narrow_in_kernel(IgemmArgs a) {
   constexpr int TAPS = KS * KS, KTOT = TAPS * CIN, PAD = (KS - 1) / 2;
   static_assert(KTOT <= 32, "one 32-deep K-step");
+  static_assert(!POOL || KS == 1, "pooled gather: 1x1 only");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int tile_n = blockIdx.x % a.tiles_n, tile_m = blockIdx.x / a.tiles_n;
@@ -993,11 +999,24 @@ __global__ __launch_bounds__(256) void conv_narrow_in_kernel(IgemmArgs a) {
       const bool ok = m < a.M && k < KTOT && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
       // UNCONDITIONAL load from a clamped address, then select: a branch around each load serialises the 16 gathers
       // (one L2 round trip each: this was 20 of the kernel's 23 us)
-      const int idx = ok ? ((n * a.H + ih) * a.W + iw) * CIN + c : 0;
-      float val = bf2f(a.x[idx]);
+      float val;
+      if constexpr (POOL) {
+        const int rs = 2 * a.W * CIN;
+        const int idx = ok ? ((n * 2 * a.H + 2 * ih) * 2 * a.W + 2 * iw) * CIN + c : 0;
+        val = bf2f(f2bf((bf2f(a.x[idx]) + bf2f(a.x[idx + rs]) + bf2f(a.x[idx + CIN]) + bf2f(a.x[idx + rs + CIN])) * 0.25f));   // tf.add_n order (:129-130)
+      } else {
+        const int idx = ok ? ((n * a.H + ih) * a.W + iw) * CIN + c : 0;
+        val = bf2f(a.x[idx]);
+      }
       val = ok ? val : 0.f;
       if (inrelu) val = fmaxf(val, 0.f);
       fb[kk][j] = f2bf(val);
+    }
+  }
+  if constexpr (POOL) {
+    if (a.aux_out && tile_n == 0 && h == 0 && m < a.M) {
+#pragma unroll
+      for (int j = 0; j < CIN; j++) a.aux_out[(long)m * CIN + j] = fb[0][j];
     }
   }
   f32x16 acc[4];
@@ -1065,14 +1084,14 @@ __global__ __launch_bounds__(256) void conv_narrow_in_kernel(IgemmArgs a) {
   }
 }
 
-template <int KS, int CIN>
+template <int KS, int CIN, bool POOL = false>
 static int launch_narrow_in(const IgemmArgs& a0, hipStream_t s) {
   IgemmArgs a = a0;
   a.tiles_m = cdiv(a.M, 128);
   a.tiles_n = a.CoutPad / 128;
-  static const std::string tag = gank_format("conv_narrow_in_kernel<%d, %d>", KS, CIN);     // magic static: built once, thread-safe
+  static const std::string tag = gank_format("conv_narrow_in_kernel<%d, %d%s>", KS, CIN, POOL ? ", pool" : "");     // magic static: built once, thread-safe
   gank_prof_tag(0, tag.c_str());
-  hipLaunchKernelGGL((conv_narrow_in_kernel<KS, CIN>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((conv_narrow_in_kernel<KS, CIN, POOL>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
   GANK_LAUNCH_OK("conv_narrow_in");
   return 0;
 }
@@ -1850,6 +1869,27 @@ extern "C" int gank_cbn_relu_conv3x3_fprop(const void* x, const int32_t* labels,
   hipStream_t s = (hipStream_t)stream;
   gank_prof_begin(0, 2.0 * a.M * (double)Cout * 9 * Cin, s, 2.0 * ((double)a.M * Cin + 9.0 * Cin * Cout + (double)a.M * Cout));
   const int rc = a.CoutPad == 32 ? launch_patch<8, 32>(a, s) : launch_patch<8, 128>(a, s);
+  gank_prof_end(0, s);
+  return rc;
+}
+
+// MeanPoolConv with a 1x1 filter on a 3-channel image (D.Block.1.Shortcut, gan_cifar_resnet.py:125-137,218-221): the 2x2
+// mean is taken inside the conv's gather; `pooled` (optional) receives the pooled image for the filter gradient.
+extern "C" int gank_meanpool_conv1x1_fprop(const void* x, const void* wf, const float* bias, void* y, void* pooled,
+                                           int N, int H, int W, int Cin, int Cout, void* stream) {
+  GANK_REQUIRE(x && wf && y && N > 0 && H > 0 && W > 0, "meanpool_conv1x1_fprop: bad arguments");
+  GANK_REQUIRE(Cin == 3, "meanpool_conv1x1_fprop: built for 3-channel images (Cin = %d)", Cin);
+  IgemmArgs a{};
+  a.x = (const bf16*)x; a.w = (const bf16*)wf; a.bias = bias; a.y = (bf16*)y; a.aux_out = (bf16*)pooled;
+  a.N = N; a.H = H; a.W = W; a.Hin = 2 * H; a.Win = 2 * W; a.Cin = Cin; a.Cout = Cout; a.ks = 1; a.pad = 0;
+  a.scale = 1.f;
+  a.taps = 1; a.CoutPad = roundup(Cout, 32); a.Kpad = roundup(Cin, 64); a.nsteps = a.Kpad / 64;
+  a.M = N * H * W; a.sw = log2_or_neg(W); a.shw = log2_or_neg(H * W);
+  GANK_REQUIRE(a.CoutPad % 128 == 0 && Cout % 4 == 0, "meanpool_conv1x1_fprop: Cout must be a multiple of 4 that pads to a multiple of 128 (got %d)", Cout);
+  GANK_REQUIRE((long)N * 4 * H * W * Cin < (1L << 30), "meanpool_conv1x1_fprop: tensor too large (32-bit offsets)");
+  hipStream_t s = (hipStream_t)stream;
+  gank_prof_begin(0, 2.0 * a.M * (double)Cout * Cin, s, 2.0 * (4.0 * a.M * Cin + (double)Cin * Cout + (double)a.M * Cout));
+  const int rc = launch_narrow_in<1, 3, true>(a, s);
   gank_prof_end(0, s);
   return rc;
 }

@@ -10,9 +10,8 @@ static inline dim3 grid1d(long n, int block = 256, int cap = 4096) {
   return dim3((unsigned)g);
 }
 
-// ------------------------------------------------------------------------------------------------
-// weight preparation (see gank.h)
-// ------------------------------------------------------------------------------------------------
+#include "prep_weights.h"
+
 // wf[co][k] = w[k][co]  (k = tap*Cin+ci), zero padded to [CoutPad][Kpad]: 32x32 LDS-tiled transpose
 __global__ void prep_wf_kernel(const float* __restrict__ w, bf16* __restrict__ wf, int K, int Cout, int CoutPad, int Kpad) {
   __shared__ float t[32][33];
@@ -61,142 +60,6 @@ extern "C" int gank_conv2d_prep_weights(const float* w, void* wf, void* wd, int 
   return 0;
 }
 
-// ---- NN-upsample + 3x3 conv as a 4x4 stride-2 transposed conv: phase operand matrices and the
-// combined 4x4 kernel for the input gradient (see gank_upconv3x3_fprop / _dgrad).
-//   wph[p=(a,b)][co][(i*2+j)*Cin+ci] = sum_{dh in R(a,i)} sum_{dw in R(b,j)} w[dh][dw][ci][co]
-//       R(0,0)={0}  R(0,1)={1,2}  R(1,0)={0,1}  R(1,1)={2}
-//   wd4[ci][(u*4+v)*Cout+co]         = sum_{dh in S(u)} sum_{dw in S(v)} w[dh][dw][ci][co]
-//       S(0)={2}  S(1)={1,2}  S(2)={0,1}  S(3)={0}
-__device__ __forceinline__ void up_range_R(int a, int i, int& lo, int& hi) {
-  if (a == 0) { lo = i == 0 ? 0 : 1; hi = i == 0 ? 0 : 2; } else { lo = i == 0 ? 0 : 2; hi = i == 0 ? 1 : 2; }
-}
-__device__ __forceinline__ void up_range_S(int u, int& lo, int& hi) {
-  lo = u == 0 ? 2 : (u == 1 ? 1 : 0);
-  hi = u == 0 ? 2 : (u == 1 ? 2 : (u == 2 ? 1 : 0));
-}
-// Sum of the 3x3 taps [h0..h1] x [w0..w1] (one or two per axis) of one (ci, co) element; p = &w[0][0][ci][co], plane = Cin*Cout.
-// FOUR UNCONDITIONAL loads (a repeated address where a range holds one tap) and 0/1 factors, in the loop's order of addition
-// (bit-identical): run-time loop bounds made each tap its own load -> wait -> add round trip, up to 4 in a row per element and
-// 32 per thread of the one-chunk-per-thread layouts -- the critic's 1.7 M weights took 17 us, all of it latency.
-__device__ __forceinline__ float sum_taps(const float* __restrict__ p, long plane, bool flip, int h0, int h1, int w0, int w1) {
-  const float mh = h1 > h0 ? 1.f : 0.f, mw = w1 > w0 ? 1.f : 0.f;
-  const int t00 = flip ? (2 - h0) * 3 + (2 - w0) : h0 * 3 + w0, t01 = flip ? (2 - h0) * 3 + (2 - w1) : h0 * 3 + w1;
-  const int t10 = flip ? (2 - h1) * 3 + (2 - w0) : h1 * 3 + w0, t11 = flip ? (2 - h1) * 3 + (2 - w1) : h1 * 3 + w1;
-  const float a = p[t00 * plane], b = p[t01 * plane], c = p[t10 * plane], d = p[t11 * plane];
-  return ((a + mw * b) + mh * c) + (mh * mw) * d;
-}
-
-// One kernel builds both operands.  `ph` = phase matrix [4][CrP pad][4*CkP], `d4` = combined 4x4 matrix
-// [CrD pad][roundup(16*CkD,64)]; (sr, sk) are the strides of the row / inner channel in w's [ci][co] plane, so the
-// same code serves UpsampleConv (ph rows = co, d4 rows = ci) and ConvMeanPool (ph rows = ci, d4 rows = co, the
-// 3x3 taps flipped, everything scaled by 1/4 -- see gank_convpool3x3_prep_weights).
-struct PrepUpArgs {
-  const float* w;
-  bf16* ph;
-  bf16* d4;
-  int CrP, CkP, srP, skP, CrPpad;
-  int CrD, CkD, srD, skD, CrDpad, Kpad4;
-  int flip, plane;     // plane = Cin*Cout (stride of one 3x3 tap)
-  float scale;
-};
-
-__device__ __forceinline__ void prep_up_element(const PrepUpArgs& q, long idx) {
-  const long nph = 4L * q.CrPpad * 4 * q.CkP;
-  if (idx < nph) {
-    const int k = (int)(idx % (4 * q.CkP));
-    long t = idx / (4 * q.CkP);
-    const int r = (int)(t % q.CrPpad), p = (int)(t / q.CrPpad);
-    const int tap = k / q.CkP, c = k - tap * q.CkP;
-    float v = 0.f;
-    if (r < q.CrP) {
-      int h0, h1, w0, w1;
-      up_range_R(p >> 1, tap >> 1, h0, h1);
-      up_range_R(p & 1, tap & 1, w0, w1);
-      v = sum_taps(q.w + (long)r * q.srP + (long)c * q.skP, q.plane, q.flip != 0, h0, h1, w0, w1);
-    }
-    q.ph[idx] = f2bf(v * q.scale);
-  } else {
-    const long i2 = idx - nph;
-    const int r = (int)(i2 / q.Kpad4), k = (int)(i2 - (long)r * q.Kpad4);
-    float v = 0.f;
-    if (r < q.CrD && k < 16 * q.CkD) {
-      const int tap = k / q.CkD, c = k - tap * q.CkD;
-      int h0, h1, w0, w1;
-      up_range_S(tap >> 2, h0, h1);
-      up_range_S(tap & 3, w0, w1);
-      v = sum_taps(q.w + (long)r * q.srD + (long)c * q.skD, q.plane, q.flip != 0, h0, h1, w0, w1);
-    }
-    q.d4[i2] = f2bf(v * q.scale);
-  }
-}
-// Eight consecutive elements of the 4x4 matrix d4 per thread where its inner index runs along w's fast axis (skD == 1:
-// UpsampleConv) and a tap's row is a whole number of 8-element pieces: 16-byte loads and one 16-byte store instead of
-// eight 4-byte loads and 2-byte stores per tap (the generator's 8.4 M-element preparation was 43 of its 54 us).
-__device__ __forceinline__ bool prep_up_vec8_ok(const PrepUpArgs& q) { return q.skD == 1 && (q.CkD & 7) == 0 && q.Kpad4 == 16 * q.CkD; }
-__device__ __forceinline__ void prep_up_d4_vec8(const PrepUpArgs& q, long i2) {       // i2 % 8 == 0, inside d4
-  const int r = (int)(i2 / q.Kpad4), k = (int)(i2 - (long)r * q.Kpad4);
-  bf16x8 o;
-  if (r < q.CrD) {
-    const int tap = k / q.CkD, c = k - tap * q.CkD;
-    int h0, h1, w0, w1;
-    up_range_S(tap >> 2, h0, h1);
-    up_range_S(tap & 3, w0, w1);
-    const float mh = h1 > h0 ? 1.f : 0.f, mw = w1 > w0 ? 1.f : 0.f;
-    const bool flip = q.flip != 0;
-    const int t00 = flip ? (2 - h0) * 3 + (2 - w0) : h0 * 3 + w0, t01 = flip ? (2 - h0) * 3 + (2 - w1) : h0 * 3 + w1;
-    const int t10 = flip ? (2 - h1) * 3 + (2 - w0) : h1 * 3 + w0, t11 = flip ? (2 - h1) * 3 + (2 - w1) : h1 * 3 + w1;
-    const float* p = q.w + (long)r * q.srD + c;
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(p + (long)t00 * q.plane + 4 * half);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(p + (long)t01 * q.plane + 4 * half);
-      const f32x4 cc = *reinterpret_cast<const f32x4*>(p + (long)t10 * q.plane + 4 * half);
-      const f32x4 d = *reinterpret_cast<const f32x4*>(p + (long)t11 * q.plane + 4 * half);
-#pragma unroll
-      for (int e = 0; e < 4; e++) o[4 * half + e] = f2bf((((a[e] + mw * b[e]) + mh * cc[e]) + (mh * mw) * d[e]) * q.scale);   // sum_taps' order
-    }
-  } else {
-#pragma unroll
-    for (int e = 0; e < 8; e++) o[e] = f2bf(0.f);
-  }
-  *reinterpret_cast<bf16x8*>(q.d4 + i2) = o;
-}
-
-__host__ __device__ inline long prep_up_total(const PrepUpArgs& q) { return 4L * q.CrPpad * 4 * q.CkP + (long)q.CrDpad * q.Kpad4; }
-
-// The operand whose inner index runs along w's SLOW channel axis (sr == 1: the phase matrix of UpsampleConv, the
-// 4x4 matrix of ConvMeanPool) read element-wise is a stride-Cout gather (the 16.8 M-element generator preparation took
-// 91 us).  Here one block turns a 32 x 32 (row, inner) tile of one (phase, tap) / tap slice through LDS: coalesced reads
-// along the rows, coalesced writes along the inner index.  Needs Ck % 64 == 0 and no K padding.
-__host__ __device__ inline int prep_up_tiles(const PrepUpArgs& q, bool ph) {
-  return ph ? 16 * (q.CrPpad / 32) * (q.CkP / 64) : 16 * (q.CrDpad / 32) * (q.CkD / 64);
-}
-__device__ __forceinline__ void prep_up_tile(const PrepUpArgs& q, bool ph, int tile, float (*tl)[33]) {     // tl: [64][33]
-  // a 64 (inner index c) x 32 (row r) tile: reads along r (128-byte runs of w's fast axis), writes along c in 16-byte pieces
-  const int Cr = ph ? q.CrP : q.CrD, Ck = ph ? q.CkP : q.CkD, CrPad = ph ? q.CrPpad : q.CrDpad, sk = ph ? q.skP : q.skD;
-  const int tk = Ck / 64, tr = CrPad / 32;
-  const int c0 = (tile % tk) * 64, r0 = ((tile / tk) % tr) * 32, slice = tile / (tk * tr);      // slice 0..15
-  int h0, h1, w0, w1;
-  if (ph) { up_range_R((slice >> 2) >> 1, (slice & 3) >> 1, h0, h1); up_range_R((slice >> 2) & 1, slice & 1, w0, w1); }
-  else { up_range_S(slice >> 2, h0, h1); up_range_S(slice & 3, w0, w1); }
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-#pragma unroll
-  for (int i = ty; i < 64; i += 8) {
-    const int c = c0 + i, r = r0 + tx;
-    float v = 0.f;
-    if (r < Cr) v = sum_taps(q.w + r + (long)c * sk, q.plane, q.flip != 0, h0, h1, w0, w1);
-    tl[i][tx] = v * q.scale;
-  }
-  __syncthreads();
-  const int ri = threadIdx.x >> 3, cp = (threadIdx.x & 7) * 8;
-  const int r = r0 + ri, c = c0 + cp;
-  bf16x8 o;
-#pragma unroll
-  for (int j = 0; j < 8; j++) o[j] = f2bf(tl[cp + j][ri]);
-  if (ph) *reinterpret_cast<bf16x8*>(q.ph + ((long)((slice >> 2) * CrPad + r) * 4 + (slice & 3)) * Ck + c) = o;
-  else *reinterpret_cast<bf16x8*>(q.d4 + (long)r * q.Kpad4 + (long)slice * Ck + c) = o;
-}
-
 // standalone form: `ntiles` leading blocks take the transposed tiles of matrix `ph_tiled`, the rest go element-wise over [lo, hi)
 __global__ __launch_bounds__(256) void prep_upconv_kernel(PrepUpArgs q, int ntiles, int ph_tiled, long lo, long hi) {
   __shared__ float tt[64][33];
@@ -213,39 +76,6 @@ __global__ __launch_bounds__(256) void prep_upconv_kernel(PrepUpArgs q, int ntil
     if (i < hi) prep_up_element(q, i);
   }
 }
-// block split shared by the standalone and the batched launchers
-struct PrepUpSplit { int ntiles, nelem; long lo, hi; };
-static inline PrepUpSplit prep_up_split(const PrepUpArgs& q, int kind) {
-  const bool ph = kind == 1;          // which matrix has the strided source: kind 1 the phase matrix, kind 2 the 4x4 one
-  const bool tiled = ph ? (q.srP == 1 && q.CkP % 64 == 0) : (q.srD == 1 && q.CkD % 64 == 0 && q.Kpad4 == 16 * q.CkD);
-  const long nph = 4L * q.CrPpad * 4 * q.CkP, total = prep_up_total(q);
-  PrepUpSplit s;
-  s.ntiles = tiled ? prep_up_tiles(q, ph) : 0;
-  s.lo = tiled && ph ? nph : 0;
-  s.hi = tiled && !ph ? nph : total;
-  s.nelem = (int)cdiv(s.hi - s.lo, 2048);
-  return s;
-}
-
-// kind 1 = UpsampleConv 3x3 (ph rows = co, d4 rows = ci); kind 2 = ConvMeanPool 3x3 (ph rows = ci, d4 rows = co, flipped, x 1/4)
-__host__ __device__ inline PrepUpArgs prep_up_args(int kind, const float* w, void* ph, void* d4, int Cin, int Cout) {
-  PrepUpArgs q{};
-  q.w = w; q.ph = (bf16*)ph; q.d4 = (bf16*)d4; q.plane = Cin * Cout;
-  if (kind == 1) {
-    q.CrP = Cout; q.CkP = Cin; q.srP = 1; q.skP = Cout;
-    q.CrD = Cin; q.CkD = Cout; q.srD = Cout; q.skD = 1;
-    q.flip = 0; q.scale = 1.f;
-  } else {
-    q.CrP = Cin; q.CkP = Cout; q.srP = Cout; q.skP = 1;
-    q.CrD = Cout; q.CkD = Cin; q.srD = 1; q.skD = Cout;
-    q.flip = 1; q.scale = 0.25f;
-  }
-  q.CrPpad = (q.CrP + 31) / 32 * 32;
-  q.CrDpad = (q.CrD + 31) / 32 * 32;
-  q.Kpad4 = (16 * q.CkD + 63) / 64 * 64;
-  return q;
-}
-
 extern "C" int gank_upconv3x3_prep_weights(const float* w, void* wph, void* wd4, int Cin, int Cout, void* stream) {
   GANK_REQUIRE(w && wph && wd4 && Cin > 0 && Cout > 0, "upconv3x3_prep_weights: bad arguments");
   const PrepUpArgs q = prep_up_args(1, w, wph, wd4, Cin, Cout);
@@ -300,223 +130,25 @@ extern "C" int gank_deconv2d_prep_phases(const float* f, void* wph, int ksize, i
   return 0;
 }
 
-// ---- batched: every conv/linear weight of a network in ONE launch (the per-layer form costs 2 tiny
-// launches x ~5 us per layer per forward; a network has 11-12 weights).  Table by value in kernargs.
-#define PREP_MAX 16
-struct PrepTable {
-  gank_prep_desc d[PREP_MAX];
-  PrepUpArgs up[PREP_MAX];         // kinds 1/2: operand geometry, filled on the host
-  int first_block[PREP_MAX + 1];   // prefix sum of blocks per entry
-  int nwf[PREP_MAX];               // wf tiles of entry i (the rest of its blocks are wd work)
-  int count;
-};
 
-// Fragment-major operand copy (kind 3): the 16 bytes lane l of a wave feeds to v_mfma_f32_32x32x16_bf16 as its A
-// operand are contiguous, fragments ordered [32-row tile][K-step = 64-channel chunk outer, tap inner][kk][lane], so a
-// wave loads one fragment as ONE coalesced 1 KB request straight into registers (conv_igemm_patch2_kernel).
-// row: output row of the operand matrix, k = tap*C + c its column (C = channels per tap, C % 64 == 0).
-__device__ __forceinline__ long frag_index(int row, int k, int C, int taps, int nsteps) {
-  const int tap = k / C, ch = k - tap * C;
-  const int chunk = ch >> 6, w64 = ch & 63;
-  const int kk = w64 >> 4, hh = (w64 >> 3) & 1, j = w64 & 7;
-  const int kstep = chunk * taps + tap;
-  return ((((long)(row >> 5) * nsteps + kstep) * 4 + kk) * 64 + hh * 32 + (row & 31)) * 8 + j;
-}
-
+// ---- batched: every conv/linear weight of a network in ONE launch (table by value in the kernel arguments)
 __global__ void prep_batch_kernel(PrepTable t) {
-  int e = 0;
-  for (int i = 1; i < t.count; i++)
-    if ((int)blockIdx.x >= t.first_block[i]) e = i;
-  const gank_prep_desc& d = t.d[e];
-  const int b = blockIdx.x - t.first_block[e];
-  const int taps = d.ksize * d.ksize;
-  if (d.kind == 1 || d.kind == 2) {       // UpsampleConv / ConvMeanPool 3x3 operands
-    const PrepUpArgs& q = t.up[e];
-    __shared__ float tt[64][33];
-    const long nph = 4L * q.CrPpad * 4 * q.CkP, total = prep_up_total(q);
-    if (b < t.nwf[e]) {                   // transposed tiles of the strided-source matrix (nwf = their count, or 0)
-      prep_up_tile(q, d.kind == 1, b, tt);
-    } else {                              // the other matrix (or both when the tile path does not apply), element-wise
-      long lo = 0, hi = total;
-      if (t.nwf[e] > 0) { if (d.kind == 1) lo = nph; else hi = nph; }
-      const long base = lo + (long)(b - t.nwf[e]) * 2048;
-      if (lo >= nph && prep_up_vec8_ok(q)) {          // the block's 2048 elements all lie in d4 (lo = nph there, both multiples of 8)
-        const long i = base + 8 * threadIdx.x;
-        if (i < hi) prep_up_d4_vec8(q, i - nph);
-      } else {
-        for (int j = 0; j < 8; j++) {
-          const long i = base + j * 256 + threadIdx.x;
-          if (i < hi) prep_up_element(q, i);
-        }
-      }
-    }
-  } else if (d.kind == 4) {
-    // "rfrag" operands of the resident kernels (conv_resident.hip): [32-row tile][tap][k/16][lane = h*32 + r][8], one
-    // 16-byte chunk (8 consecutive k of one row) per thread.  wf rows = co, k = ci; wd rows = ci, k = co, taps flipped.
-    const bool isf = b < t.nwf[e];
-    const int rows = isf ? d.Cout : d.Cin, kc = isf ? d.Cin : d.Cout;
-    const long nchunk = (long)(rows / 32) * taps * (kc / 16) * 64;
-    bf16* dst = (bf16*)(isf ? d.wf : d.wd);
-    const long base = (long)(isf ? b : b - t.nwf[e]) * 256;
-    const long q = base + threadIdx.x;
-    if (q < nchunk) {
-      const int lane = (int)(q & 63);
-      long u = q >> 6;
-      const int kk = (int)(u % (kc / 16)); u /= (kc / 16);
-      const int tap = (int)(u % taps);
-      const int rt = (int)(u / taps);
-      const int row = rt * 32 + (lane & 31), k0 = kk * 16 + (lane >> 5) * 8;
-      bf16x8 o;
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int k = k0 + j;
-        o[j] = f2bf(isf ? d.w[((long)tap * d.Cin + k) * d.Cout + row] : d.w[((long)(taps - 1 - tap) * d.Cin + row) * d.Cout + k]);
-      }
-      *reinterpret_cast<bf16x8*>(dst + q * 8) = o;
-    }
-  } else if (d.kind == 5) {
-    // ConvMeanPool 3x3 operands of the resident kernels (conv_resident.hip), one 16-byte chunk per thread:
-    //   wf [Cout/32][Cin/64][16 taps][4 kk][64 lanes][8]   = W4[tap][ci][co]        (the 4x4 stride-2 kernel, x 1/4)
-    //   wd [4 phases][Cin/32][4 taps][Cout/16 kk][64][8]   = Wph[phase][ci][tap,co]  (its transposed conv by output phase)
-    // same tap algebra as kind 2 (gank_convpool3x3_prep_weights).
-    const bool isf = b < t.nwf[e];
-    const long q = (long)(isf ? b : b - t.nwf[e]) * 256 + threadIdx.x;
-    const long nchunk = 2L * d.Cin * d.Cout;                 // 16 * Cin * Cout / 8 sixteen-byte chunks, both operands
-    if (q < nchunk) {
-      const int lane = (int)(q & 63), r = lane & 31, hh = lane >> 5;
-      long u = q >> 6;
-      bf16x8 o;
-      if (isf) {
-        const int kk = (int)(u & 3); u >>= 2;
-        const int tap = (int)(u & 15); u >>= 4;
-        const int nch = d.Cin >> 6;
-        const int chunk = (int)(u % nch), co = (int)(u / nch) * 32 + r;
-        int h0, h1, w0, w1;
-        up_range_S(tap >> 2, h0, h1);
-        up_range_S(tap & 3, w0, w1);
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const int ci = chunk * 64 + kk * 16 + hh * 8 + j;
-          o[j] = f2bf(0.25f * sum_taps(d.w + (long)ci * d.Cout + co, (long)d.Cin * d.Cout, true, h0, h1, w0, w1));
-        }
-        *reinterpret_cast<bf16x8*>((bf16*)d.wf + q * 8) = o;
-      } else {
-        const int nkk = d.Cout >> 4;
-        const int kk = (int)(u % nkk); u /= nkk;
-        const int tap = (int)(u & 3); u >>= 2;
-        const int tiles = d.Cin >> 5;
-        const int ci = (int)(u % tiles) * 32 + r, phase = (int)(u / tiles);
-        int h0, h1, w0, w1;
-        up_range_R(phase >> 1, tap >> 1, h0, h1);
-        up_range_R(phase & 1, tap & 1, w0, w1);
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const int co = kk * 16 + hh * 8 + j;
-          o[j] = f2bf(0.25f * sum_taps(d.w + (long)ci * d.Cout + co, (long)d.Cin * d.Cout, true, h0, h1, w0, w1));
-        }
-        *reinterpret_cast<bf16x8*>((bf16*)d.wd + q * 8) = o;
-      }
-    }
-  } else if (b < t.nwf[e]) {
-    // wf [CoutPad][Kpad] = w^T: a 64 (k) x 32 (cout) tile through LDS -- rows of w read along cout (128-byte runs), rows of wf
-    // written along k in 16-byte pieces (one per thread; 2-byte stores before)
-    const int K = taps * d.Cin, Kpad = (K + 63) / 64 * 64, CoutPad = (d.Cout + 31) / 32 * 32;
-    __shared__ float tl[64][33];
-    const int ntk = Kpad / 64;
-    const int k0 = (b % ntk) * 64, c0 = (b / ntk) * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-#pragma unroll
-    for (int i = ty; i < 64; i += 8) {
-      const int k = k0 + i, c = c0 + tx;
-      tl[i][tx] = (k < K && c < d.Cout) ? d.w[(long)k * d.Cout + c] : 0.f;
-    }
-    __syncthreads();
-    bf16* wf = (bf16*)d.wf;
-    const int c = c0 + (threadIdx.x >> 3), kp = (threadIdx.x & 7) * 8;       // CoutPad % 32 == 0, Kpad % 64 == 0: always inside
-    bf16x8 o;
-#pragma unroll
-    for (int j = 0; j < 8; j++) o[j] = f2bf(tl[kp + j][threadIdx.x >> 3]);
-    *reinterpret_cast<bf16x8*>(wf + (long)c * Kpad + k0 + kp) = o;
-    // fragment-major copy: 8 consecutive k of one 8-aligned group are consecutive there too (Cin % 64 == 0)
-    if (d.kind == 3) *reinterpret_cast<bf16x8*>(wf + (long)CoutPad * Kpad + frag_index(c, k0 + kp, d.Cin, taps, Kpad / 64)) = o;
-  } else {
-    const int Kpad2 = (taps * d.Cout + 63) / 64 * 64, CinPad = (d.Cin + 31) / 32 * 32;
-    const long total = (long)CinPad * Kpad2;
-    bf16* wd = (bf16*)d.wd;
-    const long base = (long)(b - t.nwf[e]) * 2048;
-    if ((d.Cout & 7) == 0 && d.kind != 3) {
-      // 8 consecutive k = 8 consecutive couts of one tap (or 8 pad columns): two 16-byte loads, one 16-byte store
-      const long i = base + 8 * threadIdx.x;
-      if (i < total) {
-        const int ci = (int)(i / Kpad2), k = (int)(i - (long)ci * Kpad2);
-        bf16x8 o;
-        if (ci < d.Cin && k < taps * d.Cout) {
-          const int tp = k / d.Cout, co = k - tp * d.Cout;
-          const float* p = d.w + ((long)(taps - 1 - tp) * d.Cin + ci) * d.Cout + co;
-          const f32x4 a = *reinterpret_cast<const f32x4*>(p), bb = *reinterpret_cast<const f32x4*>(p + 4);
-#pragma unroll
-          for (int u = 0; u < 4; u++) { o[u] = f2bf(a[u]); o[4 + u] = f2bf(bb[u]); }
-        } else {
-#pragma unroll
-          for (int u = 0; u < 8; u++) o[u] = f2bf(0.f);
-        }
-        *reinterpret_cast<bf16x8*>(wd + i) = o;
-      }
-      return;
-    }
-    for (int j = 0; j < 8; j++) {
-      const long i = base + j * 256 + threadIdx.x;
-      if (i >= total) break;
-      const int ci = (int)(i / Kpad2), k = (int)(i - (long)ci * Kpad2);
-      float v = 0.f;
-      if (ci < d.Cin && k < taps * d.Cout) {
-        const int tp = k / d.Cout, co = k - tp * d.Cout;
-        v = d.w[((long)(taps - 1 - tp) * d.Cin + ci) * d.Cout + co];
-      }
-      wd[i] = f2bf(v);
-      if (d.kind == 3) wd[total + frag_index(ci, k, d.Cout, taps, Kpad2 / 64)] = f2bf(v);
-    }
-  }
+  const int e = prep_batch_entry(t, blockIdx.x);
+  prep_batch_block<false>(t, e, blockIdx.x, 1.f);
 }
 
 extern "C" int gank_conv2d_prep_weights_batched(const gank_prep_desc* table, int count, void* stream) {
   GANK_REQUIRE(table && count > 0, "prep_weights_batched: empty table");
   for (int base = 0; base < count; base += PREP_MAX) {
-    PrepTable t{};
-    t.count = count - base < PREP_MAX ? count - base : PREP_MAX;
-    int blocks = 0;
-    for (int i = 0; i < t.count; i++) {
-      const gank_prep_desc& d = table[base + i];
-      GANK_REQUIRE(d.w && (d.wf || d.wd) && d.ksize >= 1 && d.Cin > 0 && d.Cout > 0, "prep_weights_batched: bad entry %d", base + i);
-      GANK_REQUIRE(d.kind == 0 || ((d.kind == 1 || d.kind == 2) && d.ksize == 3 && d.wf && d.wd) ||
-                   (d.kind == 3 && d.Cin % 64 == 0 && d.Cout % 64 == 0) || (d.kind == 4 && d.Cin % 32 == 0 && d.Cout % 32 == 0) ||
-                   (d.kind == 5 && d.ksize == 3 && d.wf && d.wd && d.Cin % 64 == 0 && d.Cout % 32 == 0),
-                   "prep_weights_batched: entry %d: kind %d needs ksize 3 and both outputs (1, 2, 5) / channels %% 64 == 0 (3) / %% 32 == 0 (4) / Cin %% 64 == 0 (5)", base + i, d.kind);
-      t.d[i] = d;
-      const int taps = d.ksize * d.ksize;
-      int nwf = d.wf ? (roundup(taps * d.Cin, 64) / 64) * (roundup(d.Cout, 32) / 32) : 0;
-      int nwd = d.wd ? cdiv((long)roundup(d.Cin, 32) * roundup(taps * d.Cout, 64), 2048) : 0;
-      if (d.kind == 1 || d.kind == 2) {
-        t.up[i] = d.kind == 1 ? prep_up_args(1, d.w, d.wf, d.wd, d.Cin, d.Cout) : prep_up_args(2, d.w, d.wd, d.wf, d.Cin, d.Cout);
-        const PrepUpSplit sp = prep_up_split(t.up[i], d.kind);
-        nwf = sp.ntiles;
-        nwd = sp.nelem;
-      }
-      if (d.kind == 5) nwf = nwd = cdiv(2L * d.Cin * d.Cout, 256);
-      if (d.kind == 4) {          // one 16-byte chunk per thread
-        nwf = d.wf ? cdiv((long)d.Cout * taps * d.Cin / 8, 256) : 0;
-        nwd = d.wd ? cdiv((long)d.Cin * taps * d.Cout / 8, 256) : 0;
-      }
-      t.first_block[i] = blocks;
-      t.nwf[i] = nwf;
-      blocks += nwf + nwd;
-    }
-    t.first_block[t.count] = blocks;
+    PrepTable t;
+    const int blocks = prep_table_fill(t, table + base, count - base < PREP_MAX ? count - base : PREP_MAX, base);
+    if (blocks < 0) return 1;
     hipLaunchKernelGGL(prep_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t);
     GANK_LAUNCH_OK("prep_weights_batched");
   }
   return 0;
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // column sum  out[c] += scale * sum_r x[r][c]
@@ -921,6 +553,175 @@ extern "C" int gank_concat_tile_bwd(const void* dy, void* da, void* de, int N, i
   GANK_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && 1024 % (C2 / 8) == 0, "concat_tile_bwd: unsupported channel counts %d,%d", C1, C2);
   hipLaunchKernelGGL(concat_tile_bwd_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, (const bf16*)dy, (bf16*)da, (bf16*)de, HW, C1, C2);
   GANK_LAUNCH_OK("concat_tile_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The critic's label branch through a per-label table (gank.h: gank_concat_label_*, gank_label_dense_bwd):
+// embed_y -> Linear -> tile -> concat (gan_cifar_resnet.py:276-284) depends on the sample only through its label, so the
+// dense layer runs on the V = 10 table rows (sn.hip: second launch of the batched spectral norm) and the concat gathers.
+// ------------------------------------------------------------------------------------------------
+__global__ void concat_label_fwd_kernel(const bf16* __restrict__ a, const bf16* __restrict__ T, const int* __restrict__ labels,
+                                        bf16* __restrict__ y, long total8, int HW, int C1, int C2, int V) {
+  const int cg = (C1 + C2) >> 3, cg1 = C1 >> 3;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % cg);
+    const long p = i / cg;  // n*HW + hw
+    bf16x8 v;
+    if (g < cg1) {
+      v = *reinterpret_cast<const bf16x8*>(a + p * C1 + g * 8);
+    } else {
+      const int l = labels[p / HW];
+      const bool ok = l >= 0 && l < V;
+      v = *reinterpret_cast<const bf16x8*>(T + (long)(ok ? l : 0) * C2 + (g - cg1) * 8);
+      if (!ok) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = f2bf(0.f);
+      }
+    }
+    reinterpret_cast<bf16x8*>(y)[i] = v;
+  }
+}
+
+// da = dy[..., :C1] ; de32[n, c] = sum_hw dy[n, hw, C1 + c]   (block of 1024 threads per sample; fp32 sums)
+__global__ __launch_bounds__(1024) void concat_label_bwd_kernel(const bf16* __restrict__ dy, bf16* __restrict__ da, float* __restrict__ de,
+                                                               int HW, int C1, int C2) {
+  constexpr int NT = 1024;
+  const int n = blockIdx.x, C = C1 + C2;
+  const int cg1 = C1 >> 3;
+  for (int i = threadIdx.x; i < HW * cg1; i += NT) {
+    const int g = i % cg1, r = i / cg1;
+    *reinterpret_cast<bf16x8*>(da + ((long)n * HW + r) * C1 + g * 8) = *reinterpret_cast<const bf16x8*>(dy + ((long)n * HW + r) * C + g * 8);
+  }
+  const int cg2 = C2 >> 3, RL = NT / cg2;
+  const int g = threadIdx.x % cg2, rl = threadIdx.x / cg2;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rl < RL)
+    for (int r = rl; r < HW; r += RL) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(dy + ((long)n * HW + r) * C + C1 + g * 8);
+#pragma unroll
+      for (int e = 0; e < 8; e++) acc[e] += bf2f(v[e]);
+    }
+  __shared__ float red[NT * 8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) red[threadIdx.x * 8 + e] = acc[e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C2; c += NT) {
+    float t = 0.f;
+    for (int l = 0; l < RL; l++) t += red[(l * cg2 + (c >> 3)) * 8 + (c & 7)];
+    de[(long)n * C2 + c] = t;
+  }
+}
+
+// dT[l] = sum_{n: labels[n] = l} de32[n], then this block's 8 rows k of dW [D,C2] += bf16(emb)^T dT and of
+// demb [V,D] += dT W^T; block 0 also owns dbias.  Every block builds dT itself, 1024 threads = (column j, sample group g):
+// a thread requests its group's samples of column j in one burst, adds each into its group's table row of that sample's
+// label (an LDS read-modify-write chain of N / groups steps), and the group tables are summed in group order -- no atomics,
+// the same bits every run.  (Measured forms this replaced: a thread per (label, column) pair scanning all N samples with a
+// compare per pair, 57 k cycles of one-wave-per-SIMD latency; a wave walking 20 dependent L2 round trips for the table rows.)
+// Dynamic LDS: dTg [1024*V] | dT [V*C2] | labels [N] | Ws [8*C2] | Es [8*V] | dt_out [8*V].
+__global__ __launch_bounds__(1024) void label_dense_bwd_kernel(const float* __restrict__ de, const int* __restrict__ labels,
+                                                               const float* __restrict__ table, const float* __restrict__ W,
+                                                               float* __restrict__ dW, float* __restrict__ dbias, float* __restrict__ dtable,
+                                                               int N, int V, int D, int C2) {
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  float* dTg = lds_f;
+  float* dT = dTg + 1024 * V;
+  int* lbs = reinterpret_cast<int*>(dT + ((V * C2 + 3) & ~3));
+  float* Ws = reinterpret_cast<float*>(lbs + ((N + 3) & ~3));
+  float* Es = Ws + 8 * C2;
+  float* dto = Es + 8 * V;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NG = 1024 / C2, j = tid % C2, g = tid / C2;
+  const int k0 = blockIdx.x * 8;
+  for (int l = 0; l < V; l++) dTg[(g * V + l) * C2 + j] = 0.f;
+  for (int i = tid; i < N; i += 1024) lbs[i] = labels[i];
+  if (W)
+    for (int i = tid; i < 8 * C2; i += 1024) { const int k = k0 + i / C2; Ws[i] = k < D ? W[(long)k * C2 + i % C2] : 0.f; }
+  if (table)
+    for (int i = tid; i < 8 * V; i += 1024) { const int k = k0 + (i & 7), l = i >> 3; Es[i] = k < D ? bf2f(f2bf(table[(long)l * D + k])) : 0.f; }
+  __syncthreads();
+  for (int nb = g; nb < N; nb += 16 * NG) {
+    float x[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int n = nb + u * NG;
+      x[u] = n < N ? de[(long)n * C2 + j] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int n = nb + u * NG;
+      const int l = n < N ? lbs[n] : -1;
+      if (l >= 0 && l < V) dTg[(g * V + l) * C2 + j] += x[u];
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < V * C2; idx += 1024) {
+    const int l = idx / C2, jj = idx % C2;
+    float t = 0.f;
+    for (int gg = 0; gg < NG; gg++) t += dTg[(gg * V + l) * C2 + jj];
+    dT[idx] = t;
+  }
+  __syncthreads();
+  if (dW)
+    for (int i = tid; i < 8 * C2; i += 1024) {
+      const int kk = i / C2, jj = i % C2;
+      if (k0 + kk < D) {
+        float t = 0.f;
+        for (int l = 0; l < V; l++) t += Es[l * 8 + kk] * dT[l * C2 + jj];
+        dW[(long)(k0 + kk) * C2 + jj] += t;
+      }
+    }
+  if (dtable) {
+    for (int p = wave; p < 8 * V; p += 16) {        // pair p = (label l, row kk): a wave per pair, lanes over the columns
+      const int kk = p & 7, l = p >> 3;
+      float t = 0.f;
+      for (int jj = lane; jj < C2; jj += 64) t += dT[l * C2 + jj] * Ws[kk * C2 + jj];
+      t = wave_sum(t);
+      if (lane == 0) dto[p] = t;
+    }
+    __syncthreads();
+    for (int p = tid; p < 8 * V; p += 1024) {
+      const int kk = p & 7, l = p >> 3;
+      if (k0 + kk < D) dtable[(long)l * D + k0 + kk] += dto[p];
+    }
+  }
+  if (dbias && blockIdx.x == 0)
+    for (int jj = tid; jj < C2; jj += 1024) {
+      float t = 0.f;
+      for (int l = 0; l < V; l++) t += dT[l * C2 + jj];
+      dbias[jj] += t;
+    }
+}
+
+extern "C" int gank_concat_label_fwd(const void* a, const void* T, const int32_t* labels, void* y, int N, int HW, int C1, int C2, int V,
+                                     void* stream) {
+  GANK_REQUIRE(a && T && labels && y && N > 0 && HW > 0 && V > 0, "concat_label_fwd: bad arguments");
+  GANK_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0, "concat_label_fwd: channel counts must be multiples of 8");
+  const long total8 = (long)N * HW * ((C1 + C2) / 8);
+  hipLaunchKernelGGL(concat_label_fwd_kernel, grid1d(total8), dim3(256), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)T, labels, (bf16*)y,
+                     total8, HW, C1, C2, V);
+  GANK_LAUNCH_OK("concat_label_fwd");
+  return 0;
+}
+extern "C" int gank_concat_label_bwd(const void* dy, void* da, float* de32, int N, int HW, int C1, int C2, void* stream) {
+  GANK_REQUIRE(dy && da && de32 && N > 0 && HW > 0, "concat_label_bwd: bad arguments");
+  GANK_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && 1024 % (C2 / 8) == 0, "concat_label_bwd: unsupported channel counts %d,%d", C1, C2);
+  hipLaunchKernelGGL(concat_label_bwd_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, (const bf16*)dy, (bf16*)da, de32, HW, C1, C2);
+  GANK_LAUNCH_OK("concat_label_bwd");
+  return 0;
+}
+extern "C" int gank_label_dense_bwd(const float* de32, const int32_t* labels, const float* table, const float* W, float* dW, float* dbias,
+                                    float* dtable, int N, int V, int D, int C2, void* stream) {
+  GANK_REQUIRE(de32 && labels && N > 0 && V > 0 && D > 0 && C2 > 0, "label_dense_bwd: bad arguments");
+  GANK_REQUIRE((!dW || table) && (!dtable || W), "label_dense_bwd: dW needs the table, dtable needs W");
+  GANK_REQUIRE(C2 <= 1024 && 1024 % C2 == 0, "label_dense_bwd: C2 = %d must divide 1024", C2);
+  const size_t lds = (1024 * (size_t)V + (((size_t)V * C2 + 3) & ~(size_t)3) + (((size_t)N + 3) & ~(size_t)3) + 8 * (size_t)C2 + 16 * (size_t)V) * 4;
+  GANK_REQUIRE(lds <= 160 * 1024, "label_dense_bwd: V = %d labels, N = %d samples do not fit the LDS", V, N);
+  GANK_MAX_DYNAMIC_LDS(label_dense_bwd_kernel, 160 * 1024, "label_dense_bwd");
+  hipLaunchKernelGGL(label_dense_bwd_kernel, dim3(cdiv(D, 8)), dim3(1024), lds, (hipStream_t)stream, de32, labels, table, W, dW, dbias, dtable,
+                     N, V, D, C2);
+  GANK_LAUNCH_OK("label_dense_bwd");
   return 0;
 }
 

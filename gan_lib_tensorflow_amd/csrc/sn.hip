@@ -7,28 +7,50 @@
 //   W_bar = W / sigma
 //   dL/dW = G/sigma - (<G,W>/sigma^2) (s v b^T + g_a u^T),  s=(m+2eps)/(m+eps)^2, g_v = s W b,
 //   g_a = g_v/(n+eps) - a (a.g_v)/(n (n+eps)^2)
-// These are latency-bound wavefront reductions (1.7 M weights in total): one wave per weight row
-// for the row dots, 64-row chunks for the column sums, one block per weight for the norms.
+//
+// Round 3: TWO launches each way instead of 4 + 3 (+ 1 for the MFMA operand copies).  These are latency-bound
+// reductions over 1.7 M weights: every launch is a dependent 5-9-us step of the critic update, which runs 5x per
+// iteration, so the structure is chosen for the fewest dependent passes, not for bandwidth.
+//   forward A: a block owns a 64-row chunk of one weight and keeps it IN REGISTERS: the row dots a = W u, then the
+//              chunk's share of the UN-normalised column sums W^T a (b = W^T a / (n+eps): n is not known yet) and of
+//              |a|^2 -- one pass over W instead of two.  The chunk blocks of a weight draw tickets; the block that
+//              draws the last one reduces the partial sums (n, b, m, u', sigma, s): no finalize launch.
+//   forward B: W_bar = W / sigma, the backward pass's per-row terms (v, and g_a in closed form: a.g_v = s (n+eps) m^2
+//              because W^T a = (n+eps) b), AND the bf16 MFMA operand copies of W / sigma (prep_weights.h: the blocks of
+//              gank_conv2d_prep_weights_batched with the division folded into their loads), AND optionally the
+//              per-label table of a small dense layer on an embedding (the critic's label branch) -- what took a
+//              scale launch, a preparation launch, an embedding launch and a dense-layer launch.
+//   backward 1: per-chunk partial sums of <G, W>.
+//   backward 2: every block sums the (<= a few dozen) partials of its weight itself, then applies the gradient.
 #include "gank_common.h"
+#include "prep_weights.h"
 
 #define SN_MAX 16
 #define SN_EPS 1e-12f
+// rows per block: forward A keeps a chunk of SN_ROWS rows in registers and leaves one set of partial sums per chunk;
+// forward B and the backward launches are element-wise over the weight (plus a row dot) and run on finer pieces of SN_FINE
+// rows -- 4x the blocks in flight for the same bytes (175 blocks of 64 rows left most CUs with one latency chain each)
+#ifndef SN_ROWS
+#define SN_ROWS 32
+#endif
+#ifndef SN_FINE
+#define SN_FINE 16
+#endif
 
 struct SnTable {
   gank_sn_desc d[SN_MAX];
   int count;
 };
 
-// The table sits in the kernel arguments: a counted loop over it is one dependent scalar load per entry (12 of them in front
-// of every wave's first vector load).  Unrolled over SN_MAX with the offsets increasing, the index is a count of entries at or
-// below `row`, and the scalar loads issue back to back.
-__device__ __forceinline__ int sn_find_row(const SnTable& t, int row, int& local) {
-  int w = 0;
-#pragma unroll
-  for (int i = 1; i < SN_MAX; i++) w += (i < t.count && row >= t.d[i].row_offset) ? 1 : 0;
-  local = row - t.d[w].row_offset;
-  return w;
-}
+// Tickets of forward A: one word per table entry, zero between launches (the last arriver of a weight resets its word).
+// The slots rotate per host call, so launches that overlap on different streams do not share words unless more than
+// SN_TICKET_GROUPS of them are in flight.
+#define SN_TICKET_GROUPS 32
+__device__ unsigned sn_tickets[SN_TICKET_GROUPS * SN_MAX];
+static std::atomic<unsigned> sn_ticket_group{0};
+
+// The table sits in the kernel arguments: a counted loop over it is one dependent scalar load per entry.  Unrolled over
+// SN_MAX with the offsets increasing, the index is a count of entries at or below `chunk`, and the loads issue back to back.
 __device__ __forceinline__ int sn_find_chunk(const SnTable& t, int chunk, int& local) {
   int w = 0;
 #pragma unroll
@@ -37,184 +59,556 @@ __device__ __forceinline__ int sn_find_chunk(const SnTable& t, int chunk, int& l
   return w;
 }
 
-// k1: a[k] = sum_c W[k,c] u[c]           (one wave per row)
-__global__ void sn_rowdot_u_kernel(SnTable t, int total_rows) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= total_rows) return;
-  int k;
-  const int wi = sn_find_row(t, row, k);
-  const gank_sn_desc& d = t.d[wi];
-  const int lane = threadIdx.x & 63;
-  float s = 0.f;
-  for (int c = lane; c < d.C; c += 64) s += d.W[(long)k * d.C + c] * d.u_in[c];
-  s = wave_sum(s);
-  if (lane == 0) d.a[k] = s;
-  if (k == 0 && d.u_snap)       // the weight's first row also keeps u_in for the backward pass
-    for (int c = lane; c < d.C; c += 64) d.u_snap[c] = d.u_in[c];
+__device__ __forceinline__ int sn_find_fine(const SnTable& t, int piece, int& local) {
+  int w = 0;
+#pragma unroll
+  for (int i = 1; i < SN_MAX; i++) w += (i < t.count && piece >= t.d[i].row_offset) ? 1 : 0;      // row_offset: first fine piece of the weight
+  local = piece - t.d[w].row_offset;
+  return w;
 }
 
-// k2: n = |a|; v = a/(n+eps) for this chunk's rows; bpart[chunk][c] = sum_{k in chunk} W[k,c] v[k]
-__global__ void sn_colpart_kernel(SnTable t) {
+// Register-tile form: C a power of two in [4, 256] -- a chunk is 64*C contiguous floats, thread t takes the f32x4 pieces
+// (i*256 + t) of it, so its 4 columns are the same for every piece ((4t) mod C) and a row is C/4 consecutive lanes.
+__device__ __forceinline__ bool sn_pow2_c(int C) { return C >= 4 && C <= 256 && (C & (C - 1)) == 0; }
+__device__ __forceinline__ bool sn_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// write-through (sc1) store: the value is in memory, visible to every XCD, once the storing wave's vmcnt has drained
+__device__ __forceinline__ void sn_store_wt(float* p, float x) {
+  __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// sum over the G = C/4 lanes that hold one row (all of them get the result)
+__device__ __forceinline__ float sn_row_sum(float p, int G) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    if (o < G) p += __shfl_xor(p, o, 64);
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------------- forward A
+__global__ __launch_bounds__(256) void sn_fwd_a_kernel(SnTable t, unsigned* __restrict__ tickets) {
+  __shared__ float sm[1024 + SN_ROWS + 16 + 4];
+  float* part = sm;
+  float* as = sm + 1024;
+  float* red = sm + 1024 + SN_ROWS;
+  int* flag = reinterpret_cast<int*>(sm + 1024 + SN_ROWS + 16);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int ch;
   const int wi = sn_find_chunk(t, blockIdx.x, ch);
   const gank_sn_desc& d = t.d[wi];
-  __shared__ float red[16];
-  __shared__ float vs[64];
-  float ss = 0.f;
-  for (int k = threadIdx.x; k < d.K; k += blockDim.x) { const float x = d.a[k]; ss += x * x; }
-  const float n = sqrtf(block_sum(ss, red));
-  const int k0 = ch * 64;
-  const int kn = min(64, d.K - k0);
-  if (threadIdx.x < 64) {
-    float v = 0.f;
-    if ((int)threadIdx.x < kn) { v = d.a[k0 + threadIdx.x] / (n + SN_EPS); d.v[k0 + threadIdx.x] = v; }
-    vs[threadIdx.x] = v;
-  }
-  if (ch == 0 && threadIdx.x == 0) d.scal[1] = n;
-  __syncthreads();
-  for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
-    float s = 0.f;
-    // 64 rows in batches of 16 independent loads (rows past kn re-read the last row against vs = 0): a plain loop with
-    // a run-time bound issued one load per L2 round trip
+  const int K = d.K, C = d.C, k0 = ch * SN_ROWS, kn = min(SN_ROWS, K - k0), nch = (K + SN_ROWS - 1) / SN_ROWS;
+  const float* __restrict__ W = d.W;
+  float* bp = d.bpart + (long)ch * C;
+  if (ch == 0 && d.u_snap)       // the weight's first chunk also keeps u_in for the backward pass (u_out may alias u_in)
+    for (int c = tid; c < C; c += 256) d.u_snap[c] = d.u_in[c];
+  float n2 = 0.f;
+  if (sn_pow2_c(C) && sn_al16(W)) {
+    const int lc = __builtin_ctz(C), G = C >> 2;
+    const int L = max(1, (SN_ROWS * C) >> 10);
+    const int col = (tid * 4) & (C - 1);
+    float u4[4];
 #pragma unroll
-    for (int kb = 0; kb < 64; kb += 16) {
-      float w[16];
+    for (int e = 0; e < 4; e++) u4[e] = d.u_in[col + e];
+    f32x4 w[16];
 #pragma unroll
-      for (int u = 0; u < 16; u++) w[u] = d.W[(long)(k0 + min(kb + u, kn - 1)) * d.C + c];
-#pragma unroll
-      for (int u = 0; u < 16; u++) s += w[u] * vs[kb + u];
+    for (int i = 0; i < 16; i++) {
+      if (i < L) {
+        const int flat = (i * 256 + tid) * 4, row = flat >> lc;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        w[i] = row < kn ? *reinterpret_cast<const f32x4*>(W + (long)k0 * C + flat) : z;
+      }
     }
-    d.bpart[(long)ch * d.C + c] = s;
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      if (i < L) {
+        const int row = ((i * 256 + tid) * 4) >> lc;
+        float p = ((w[i][0] * u4[0] + w[i][1] * u4[1]) + w[i][2] * u4[2]) + w[i][3] * u4[3];
+        p = sn_row_sum(p, G);
+        if (col == 0 && row < kn) { d.a[k0 + row] = p; n2 += p * p; }
+#pragma unroll
+        for (int e = 0; e < 4; e++) s4[e] += p * w[i][e];      // rows past kn hold zeros
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) part[tid * 4 + e] = s4[e];
+    __syncthreads();
+    if (tid < C) {
+      const int g = tid >> 2, e = tid & 3, reps = 1024 >> lc;       // threads per column group
+      float s = 0.f;
+      for (int j = 0; j < reps; j++) s += part[(j * G + g) * 4 + e];
+      sn_store_wt(bp + tid, s);
+    }
+  } else {
+    for (int r = wave; r < kn; r += 4) {
+      float s = 0.f;
+      for (int c = lane; c < C; c += 64) s += W[(long)(k0 + r) * C + c] * d.u_in[c];
+      s = wave_sum(s);
+      if (lane == 0) { as[r] = s; d.a[k0 + r] = s; n2 += s * s; }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+      float s = 0.f;
+      for (int r = 0; r < kn; r++) s += as[r] * W[(long)(k0 + r) * C + c];
+      sn_store_wt(bp + c, s);
+    }
   }
-}
+  n2 = block_sum(n2, red);
+  if (tid == 0) sn_store_wt(d.bpart + (long)nch * C + ch, n2);
 
-// k3: b = sum_chunks bpart; m=|b|; u' = b/(m+eps); sigma = b.u'; s   (one block per weight)
-__global__ void sn_finalize_kernel(SnTable t) {
-  const gank_sn_desc& d = t.d[blockIdx.x];
-  __shared__ float red[16];
-  const int nch = (d.K + 63) / 64;
-  float ss = 0.f;
-  for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
-    float s = 0.f;
-    for (int jb = 0; jb < nch; jb += 8) {            // batches of 8 independent loads
-      float t[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) t[u] = d.bpart[(long)min(jb + u, nch - 1) * d.C + c];
-#pragma unroll
-      for (int u = 0; u < 8; u++) s += (jb + u < nch) ? t[u] : 0.f;
+  // ---- publish this chunk's partial sums, draw a ticket; the last chunk of the weight finishes the iteration ----
+  // The partial sums another block reads were stored WRITE-THROUGH (sc1: sn_store_wt), so no release fence (an L2 write-back,
+  // 1.7-6.5 us on the critical path of every block) is needed: every storing wave drains its stores, the workgroup meets,
+  // one lane draws the ticket; the last arriver takes ONE agent-scope acquire and reads with plain loads.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave
+  __syncthreads();
+  if (tid == 0) {
+    int last = 1;
+    if (nch > 1) {
+      const unsigned tk = __hip_atomic_fetch_add(tickets + wi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = tk == (unsigned)(nch - 1);
+      if (last) {
+        __hip_atomic_store(tickets + wi, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // zero again for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     }
-    d.b[c] = s;
-    ss += s * s;
+    *flag = last;
   }
-  const float m = sqrtf(block_sum(ss, red));
+  __syncthreads();
+  if (!*flag) return;
+
+  const float* n2p = d.bpart + (long)nch * C;
+  float s = 0.f;
+  for (int j = tid; j < nch; j += 256) s += n2p[j];
+  const float n = sqrtf(block_sum(s, red));
+  float ss = 0.f;
+  if (sn_pow2_c(C) && sn_al16(d.bpart)) {
+    // all 256 threads: thread t sums the f32x4 piece (t mod C/4) of the chunks j = t / (C/4), + 1024/C, ... -- every load of
+    // the block in flight at once (up to 36 chunks x 1 KB: one L2 round trip instead of five); then the column-group
+    // reduction of the main body
+    const int G = C >> 2, lc = __builtin_ctz(C), reps = 1024 >> lc;
+    const int g = tid & (G - 1), j0 = tid >> (lc - 2);
+    f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+    for (int jb = j0; jb < nch; jb += 16 * reps) {
+      f32x4 tt[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const int j = jb + u * reps;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        tt[u] = j < nch ? *reinterpret_cast<const f32x4*>(d.bpart + (long)j * C + 4 * g) : z;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; u++) acc4 += tt[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; e++) part[tid * 4 + e] = acc4[e];
+    __syncthreads();
+    if (tid < C) {
+      const int gg = tid >> 2, e = tid & 3;
+      float su = 0.f;
+      for (int j = 0; j < reps; j++) su += part[(j * G + gg) * 4 + e];
+      const float bb = su / (n + SN_EPS);
+      d.b[tid] = bb;
+      ss = bb * bb;
+    }
+  } else {
+    for (int c = tid; c < C; c += 256) {
+      float su = 0.f;
+      for (int jb = 0; jb < nch; jb += 8) {            // batches of 8 independent loads
+        float tt[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) tt[u] = d.bpart[(long)min(jb + u, nch - 1) * C + c];
+#pragma unroll
+        for (int u = 0; u < 8; u++) su += (jb + u < nch) ? tt[u] : 0.f;
+      }
+      const float bb = su / (n + SN_EPS);
+      d.b[c] = bb;
+      ss += bb * bb;
+    }
+  }
+  const float m2 = block_sum(ss, red);
+  const float m = sqrtf(m2);
   float dot = 0.f;
-  for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
-    const float bb = d.b[c];
+  for (int c = tid; c < C; c += 256) {
+    const float bb = d.b[c];                  // this thread's own store
     const float un = bb / (m + SN_EPS);
     d.u_out[c] = un;
     dot += bb * un;
   }
   const float sigma = block_sum(dot, red);
-  if (threadIdx.x == 0) {
+  if (tid == 0) {
+    const float sc = (m + 2.f * SN_EPS) / ((m + SN_EPS) * (m + SN_EPS));
     d.scal[0] = sigma;
+    d.scal[1] = n;
     d.scal[2] = m;
-    d.scal[3] = (m + 2.f * SN_EPS) / ((m + SN_EPS) * (m + SN_EPS));
+    d.scal[3] = sc;
+    d.scal[5] = sc * (n + SN_EPS) * m2;       // a . g_v = s a^T W b = s (W^T a) . b = s (n+eps) |b|^2
   }
 }
 
-// k4: W_bar = W / sigma                 (one wave per row)
-__global__ void sn_scale_kernel(SnTable t, int total_rows) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= total_rows) return;
-  int k;
-  const int wi = sn_find_row(t, row, k);
-  const gank_sn_desc& d = t.d[wi];
-  const float sigma = d.scal[0];
-  for (int c = threadIdx.x & 63; c < d.C; c += 64) d.W_bar[(long)k * d.C + c] = d.W[(long)k * d.C + c] / sigma;
+// ---------------------------------------------------------------------------------------------- forward B
+struct SnScaleEntry {
+  const float* W;
+  float* W_bar;
+  const float* scal;
+  const float* a;
+  const float* b;
+  float* v;
+  float* ga;
+  int K, C, chunk_offset, pad_;
+};
+struct SnScaleTable {
+  SnScaleEntry d[SN_MAX];
+  int count, nchunks;
+};
+struct SnPrepExtra {
+  const float* sigma[PREP_MAX];     // divisor of prep entry i (the scal word of its weight)
+  int prep_blocks;
+};
+// the per-label rows of a small dense layer on an embedding table: out[l] = bf16( bf16(table[l]) (W / sigma) + bias )
+struct SnLabelDense {
+  const float* table;   // [V, D] fp32
+  const float* W;       // [D, Cout] fp32 master weight
+  const float* sigma;   // its spectral norm (scal word), or NULL
+  const float* bias;    // [Cout] or NULL
+  bf16* out;            // [V, Cout]
+  int V, D, Cout;
+};
+
+__device__ __forceinline__ int sn_find_chunk_b(const SnScaleTable& t, int chunk, int& local) {
+  int w = 0;
+#pragma unroll
+  for (int i = 1; i < SN_MAX; i++) w += (i < t.count && chunk >= t.d[i].chunk_offset) ? 1 : 0;
+  local = chunk - t.d[w].chunk_offset;
+  return w;
 }
 
-// b1: rowdot[k] = sum_c G[k,c] W[k,c];  gv[k] = s * sum_c W[k,c] b[c]   (gv stored in ga)
-__global__ void sn_bwd_rows_kernel(SnTable t, int total_rows) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= total_rows) return;
-  int k;
-  const int wi = sn_find_row(t, row, k);
-  const gank_sn_desc& d = t.d[wi];
-  const int lane = threadIdx.x & 63;
-  float gw = 0.f, wb = 0.f;
-  for (int c = lane; c < d.C; c += 64) {
-    const float w = d.W[(long)k * d.C + c];
-    gw += d.dW_bar[(long)k * d.C + c] * w;
-    wb += w * d.b[c];
+// One (label row, 64-column group) of the dense layer.  The arithmetic is linear_fwd_wide_kernel's (linear.hip), order of
+// additions included: the reduction axis in 4 contiguous quarters, one per wave, each summed in ascending k, the quarters
+// added 0..3, then the bias -- with sigma = NULL (W already normalised) the row a sample's embedding used to get from
+// embedding_fwd + linear_fwd is reproduced bit for bit; with a sigma the sum over the MASTER weight is divided once (one
+// division per output instead of one per weight: 96 divisions per lane were 2-4 us of this block's chain).  Loads as there: the wave's x values by ONE lane-indexed load per 64 k (broadcast with v_readlane), the weights in
+// batches of 16 independent loads (a plain k loop is one L2 round trip per step: 150 of them took 50 us).
+__device__ __forceinline__ float sn_lane_bcast(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ void sn_label_row(const SnLabelDense& q, int l, int cg, float* red /* [4][64] */) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float sg = q.sigma ? q.sigma[0] : 1.f;
+  const int K = q.D, C = q.Cout;
+  const int kq = (K + 3) / 4, k0 = wv * kq, k1 = min(K, k0 + kq);
+  const int c = cg * 64 + lane, cc = c < C ? c : C - 1;
+  float acc = 0.f;
+  if (kq <= 96) {
+    // the wave's whole quarter requested at once (<= 96 weights per lane in flight), then the additions in ascending k
+    const float xa = (k0 + lane < k1) ? bf2f(f2bf(q.table[(long)l * K + k0 + lane])) : 0.f;
+    const float xb = (k0 + 64 + lane < k1) ? bf2f(f2bf(q.table[(long)l * K + k0 + 64 + lane])) : 0.f;
+    float wt[96];
+#pragma unroll
+    for (int u = 0; u < 96; u++) wt[u] = q.W[(long)min(k0 + u, K - 1) * C + cc];
+#pragma unroll
+    for (int u = 0; u < 96; u++) {
+      // linear_fwd_wide_kernel adds a (zero) term for every step of a started batch of 16: k0 + u < ceil16(k1 - k0 - 64 [u >= 64]) ...
+      const int kc = u < 64 ? k0 : k0 + 64, jb = (u & 63) & ~15;
+      if (kc < k1 && kc + jb < k1) acc += sn_lane_bcast(u < 64 ? xa : xb, u & 63) * wt[u];
+    }
+  } else {
+    for (int kc = k0; kc < k1; kc += 64) {
+      const float xv = (kc + lane < k1) ? bf2f(f2bf(q.table[(long)l * K + kc + lane])) : 0.f;
+#pragma unroll
+      for (int jb = 0; jb < 64; jb += 16) {
+        if (kc + jb >= k1) break;
+        float wt[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) wt[u] = q.W[(long)min(kc + jb + u, K - 1) * C + cc];
+#pragma unroll
+        for (int u = 0; u < 16; u++) acc += sn_lane_bcast(xv, jb + u) * wt[u];
+      }
+    }
   }
-  gw = wave_sum(gw);
-  wb = wave_sum(wb);
-  if (lane == 0) { d.rowdot[k] = gw; d.ga[k] = d.scal[3] * wb; }
+  red[wv * 64 + lane] = acc;
+  __syncthreads();
+  if (wv == 0 && c < C)
+    q.out[(long)l * C + c] = f2bf((red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane]) / sg + (q.bias ? q.bias[c] : 0.f));
 }
 
-// b2: GW = sum rowdot; agv = a.gv; ga = gv/(n+eps) - a agv/(n (n+eps)^2)   (one block per weight)
-__global__ void sn_bwd_scalars_kernel(SnTable t) {
-  const gank_sn_desc& d = t.d[blockIdx.x];
-  __shared__ float red[16];
-  float s1 = 0.f, s2 = 0.f;
-  for (int k = threadIdx.x; k < d.K; k += blockDim.x) { s1 += d.rowdot[k]; s2 += d.a[k] * d.ga[k]; }
-  const float GW = block_sum(s1, red);
-  const float agv = block_sum(s2, red);
-  const float n = d.scal[1];
+__global__ __launch_bounds__(256) void sn_fwd_b_kernel(SnScaleTable st, PrepTable pt, SnPrepExtra px, SnLabelDense ld) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if ((int)blockIdx.x >= st.nchunks) {
+    const int pb = blockIdx.x - st.nchunks;
+    if (pb < px.prep_blocks) {            // bf16 MFMA operand copies of W / sigma
+      const int e = prep_batch_entry(pt, pb);
+      const float* sp = px.sigma[0];
+#pragma unroll
+      for (int i = 1; i < PREP_MAX; i++) sp = e == i ? px.sigma[i] : sp;
+      prep_batch_block<true>(pt, e, pb, sp[0]);
+    } else {
+      __shared__ float lred[256];
+      const int lb = pb - px.prep_blocks, ncg = (ld.Cout + 63) >> 6;
+      sn_label_row(ld, lb / ncg, lb % ncg, lred);
+    }
+    return;
+  }
+  int ch;
+  const int wi = sn_find_chunk_b(st, blockIdx.x, ch);
+  const SnScaleEntry& d = st.d[wi];
+  const int K = d.K, C = d.C, k0 = ch * SN_FINE, kn = min(SN_FINE, K - k0);
+  const float sigma = d.scal[0], n = d.scal[1], sc = d.scal[3], agv = d.scal[5];
   const float c1 = 1.f / (n + SN_EPS), c2 = agv / (n * (n + SN_EPS) * (n + SN_EPS));
-  for (int k = threadIdx.x; k < d.K; k += blockDim.x) d.ga[k] = d.ga[k] * c1 - d.a[k] * c2;
-  if (threadIdx.x == 0) { d.scal[4] = GW; d.scal[5] = agv; }
-}
-
-// b3: dW += G/sigma - (GW/sigma^2) (s v[k] b[c] + ga[k] u[c])   (one wave per row)
-__global__ void sn_bwd_apply_kernel(SnTable t, int total_rows) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= total_rows) return;
-  int k;
-  const int wi = sn_find_row(t, row, k);
-  const gank_sn_desc& d = t.d[wi];
-  const float sigma = d.scal[0], s = d.scal[3];
-  const float coef = d.scal[4] / (sigma * sigma);
-  const float sv = s * d.v[k], gak = d.ga[k];
-  const float* uin = d.u_snap ? d.u_snap : d.u_in;
-  for (int c = threadIdx.x & 63; c < d.C; c += 64) {
-    const long i = (long)k * d.C + c;
-    d.dW[i] += d.dW_bar[i] / sigma - coef * (sv * d.b[c] + gak * uin[c]);
+  const float* __restrict__ W = d.W;
+  if (sn_pow2_c(C) && sn_al16(W) && sn_al16(d.W_bar)) {
+    const int lc = __builtin_ctz(C), G = C >> 2;
+    const int L = max(1, (SN_FINE * C) >> 10);
+    const int col = (tid * 4) & (C - 1);
+    float b4[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) b4[e] = d.b[col + e];
+    constexpr int LMAX = (SN_FINE * 256) >> 10 > 0 ? (SN_FINE * 256) >> 10 : 1;
+    f32x4 w[LMAX];
+    float ak[LMAX];
+#pragma unroll
+    for (int i = 0; i < LMAX; i++) {
+      if (i < L) {
+        const int flat = (i * 256 + tid) * 4, row = flat >> lc;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        w[i] = row < kn ? *reinterpret_cast<const f32x4*>(W + (long)k0 * C + flat) : z;
+        ak[i] = row < kn ? d.a[k0 + row] : 0.f;       // every lane of the row, up front: inside the loop below it was 16 dependent round trips
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < LMAX; i++) {
+      if (i < L) {
+        const int flat = (i * 256 + tid) * 4, row = flat >> lc;
+        if (row < kn) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; e++) o[e] = w[i][e] / sigma;
+          *reinterpret_cast<f32x4*>(d.W_bar + (long)k0 * C + flat) = o;
+        }
+        float p = ((w[i][0] * b4[0] + w[i][1] * b4[1]) + w[i][2] * b4[2]) + w[i][3] * b4[3];
+        p = sn_row_sum(p, G);
+        if (col == 0 && row < kn) {
+          d.v[k0 + row] = ak[i] / (n + SN_EPS);
+          d.ga[k0 + row] = (sc * p) * c1 - ak[i] * c2;
+        }
+      }
+    }
+  } else {
+    for (int r = wave; r < kn; r += 4) {
+      const long ro = (long)(k0 + r) * C;
+      float p = 0.f;
+      for (int c = lane; c < C; c += 64) {
+        const float x = W[ro + c];
+        d.W_bar[ro + c] = x / sigma;
+        p += x * d.b[c];
+      }
+      p = wave_sum(p);
+      if (lane == 0) {
+        const float ak = d.a[k0 + r];
+        d.v[k0 + r] = ak / (n + SN_EPS);
+        d.ga[k0 + r] = (sc * p) * c1 - ak * c2;
+      }
+    }
   }
 }
 
-static int sn_fill(SnTable& t, const gank_sn_desc* table, int count, int& rows, int& chunks, bool bwd) {
-  rows = 0; chunks = 0;
+// ---------------------------------------------------------------------------------------------- backward
+// b1: gwpart[piece] = sum over the piece (SN_FINE rows) of G * W            (kept behind the forward's partials in bpart)
+__global__ __launch_bounds__(256) void sn_bwd_gw_kernel(SnTable t) {
+  __shared__ float red[16];
+  const int tid = threadIdx.x;
+  int ch;
+  const int wi = sn_find_fine(t, blockIdx.x, ch);
+  const gank_sn_desc& d = t.d[wi];
+  const int K = d.K, C = d.C, k0 = ch * SN_FINE, kn = min(SN_FINE, K - k0), nch = (K + SN_ROWS - 1) / SN_ROWS;
+  const float* __restrict__ W = d.W + (long)k0 * C;
+  const float* __restrict__ G = d.dW_bar + (long)k0 * C;
+  const int total = kn * C;
+  float s = 0.f;
+  if ((C & 3) == 0 && sn_al16(d.W) && sn_al16(d.dW_bar)) {
+    constexpr int NB = 4;
+    f32x4 w[NB], g[NB];
+    const int n4 = total >> 2;
+    for (int base = 0; base < n4; base += NB * 256) {
+#pragma unroll
+      for (int i = 0; i < NB; i++) {
+        const int q = base + i * 256 + tid;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        w[i] = q < n4 ? reinterpret_cast<const f32x4*>(W)[q] : z;
+        g[i] = q < n4 ? reinterpret_cast<const f32x4*>(G)[q] : z;
+      }
+#pragma unroll
+      for (int i = 0; i < NB; i++) s += ((w[i][0] * g[i][0] + w[i][1] * g[i][1]) + w[i][2] * g[i][2]) + w[i][3] * g[i][3];
+    }
+  } else {
+    for (int q = tid; q < total; q += 256) s += W[q] * G[q];
+  }
+  s = block_sum(s, red);
+  if (tid == 0) d.bpart[(long)nch * C + nch + ch] = s;
+}
+
+// b2: <G,W> = sum of the weight's partials (every block for itself: a few dozen floats);
+//     dW += G/sigma - (<G,W>/sigma^2) (s v[k] b[c] + ga[k] u[c])
+__global__ __launch_bounds__(256) void sn_bwd_apply_kernel(SnTable t) {
+  __shared__ float red[16];
+  const int tid = threadIdx.x;
+  int ch;
+  const int wi = sn_find_fine(t, blockIdx.x, ch);
+  const gank_sn_desc& d = t.d[wi];
+  const int K = d.K, C = d.C, k0 = ch * SN_FINE, kn = min(SN_FINE, K - k0), nch = (K + SN_ROWS - 1) / SN_ROWS;
+  const int nfine = (K + SN_FINE - 1) / SN_FINE;
+  const float* gwp = d.bpart + (long)nch * C + nch;
+  const float* uin = d.u_snap ? d.u_snap : d.u_in;
+  const float* __restrict__ G = d.dW_bar + (long)k0 * C;
+  float* __restrict__ dW = d.dW + (long)k0 * C;
+  const bool fast = sn_pow2_c(C) && sn_al16(d.dW_bar) && sn_al16(d.dW);
+  constexpr int LMAX = (SN_FINE * 256) >> 10 > 0 ? (SN_FINE * 256) >> 10 : 1;
+  const int lc = fast ? __builtin_ctz(C) : 0;
+  const int L = max(1, (SN_FINE * C) >> 10);
+  const int col = fast ? (tid * 4) & (C - 1) : 0;
+  // every load of the block is requested before the first wait: the piece of G and dW, the row terms, b and u, and the
+  // <G,W> partials of the weight (each block sums them itself: a few dozen to a few hundred floats)
+  f32x4 g[LMAX], o[LMAX];
+  float sv[LMAX], gak[LMAX];
+  float b4[4] = {0.f, 0.f, 0.f, 0.f}, u4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (fast) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) { b4[e] = d.b[col + e]; u4[e] = uin[col + e]; }
+#pragma unroll
+    for (int i = 0; i < LMAX; i++) {
+      if (i < L) {
+        const int flat = (i * 256 + tid) * 4, row = flat >> lc;
+        const bool ok = row < kn;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        g[i] = ok ? *reinterpret_cast<const f32x4*>(G + flat) : z;
+        o[i] = ok ? *reinterpret_cast<const f32x4*>(dW + flat) : z;
+        sv[i] = ok ? d.v[k0 + row] : 0.f;
+        gak[i] = ok ? d.ga[k0 + row] : 0.f;
+      }
+    }
+  }
+  float s = 0.f;
+  for (int j = tid; j < nfine; j += 256) s += gwp[j];
+  const float GW = block_sum(s, red);
+  const float sigma = d.scal[0], sc = d.scal[3];
+  const float coef = GW / (sigma * sigma);
+  if (ch == 0 && tid == 0) d.scal[4] = GW;
+  if (fast) {
+#pragma unroll
+    for (int i = 0; i < LMAX; i++) {
+      if (i < L) {
+        const int flat = (i * 256 + tid) * 4, row = flat >> lc;
+        if (row < kn) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) o[i][e] += g[i][e] / sigma - coef * ((sc * sv[i]) * b4[e] + gak[i] * u4[e]);
+          *reinterpret_cast<f32x4*>(dW + flat) = o[i];
+        }
+      }
+    }
+  } else {
+    const int total = kn * C;
+    for (int q = tid; q < total; q += 256) {
+      const int r = q / C, c = q - r * C;
+      dW[q] += G[q] / sigma - coef * (sc * d.v[k0 + r] * d.b[c] + d.ga[k0 + r] * uin[c]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- host
+static int sn_fill(SnTable& t, const gank_sn_desc* table, int count, int& chunks, int& fine, bool bwd) {
+  chunks = 0;
+  fine = 0;
   t.count = count;
   for (int i = 0; i < count; i++) {
     t.d[i] = table[i];
     GANK_REQUIRE(t.d[i].K > 0 && t.d[i].C > 0, "sn: weight %d has bad shape", i);
-    GANK_REQUIRE(t.d[i].W && t.d[i].u_in && t.d[i].a && t.d[i].b && t.d[i].v && t.d[i].scal, "sn: weight %d has null pointers", i);
-    if (bwd) GANK_REQUIRE(t.d[i].dW_bar && t.d[i].dW && t.d[i].rowdot && t.d[i].ga, "sn bwd: weight %d has null pointers", i);
-    else GANK_REQUIRE(t.d[i].u_out && t.d[i].W_bar && t.d[i].bpart, "sn fwd: weight %d has null pointers", i);
-    t.d[i].row_offset = rows;
-    t.d[i].chunk_offset = chunks;
-    rows += t.d[i].K;
-    chunks += (t.d[i].K + 63) / 64;
+    GANK_REQUIRE(t.d[i].W && t.d[i].u_in && t.d[i].a && t.d[i].b && t.d[i].v && t.d[i].scal && t.d[i].bpart && t.d[i].ga, "sn: weight %d has null pointers", i);
+    if (bwd) GANK_REQUIRE(t.d[i].dW_bar && t.d[i].dW, "sn bwd: weight %d has null pointers", i);
+    else GANK_REQUIRE(t.d[i].u_out && t.d[i].W_bar, "sn fwd: weight %d has null pointers", i);
+    t.d[i].row_offset = fine;          // first fine piece (SN_FINE rows) of the weight
+    t.d[i].chunk_offset = chunks;      // first chunk (SN_ROWS rows)
+    fine += (t.d[i].K + SN_FINE - 1) / SN_FINE;
+    chunks += (t.d[i].K + SN_ROWS - 1) / SN_ROWS;
+  }
+  return 0;
+}
+
+// floats of gank_sn_desc.bpart for a [K, C] weight: per chunk the partial column sums and one |a|^2 partial, per fine piece
+// one <G,W> partial; a multiple of 4 (the regions of consecutive weights stay 16-byte aligned)
+extern "C" long gank_sn_ws_floats(int K, int C) {
+  const long nch = (K + SN_ROWS - 1) / SN_ROWS, nfine = (K + SN_FINE - 1) / SN_FINE;
+  return (nch * (C + 1) + nfine + 3) / 4 * 4;
+}
+
+static int sn_forward(const gank_sn_desc* table, int count, const gank_prep_desc* prep, const int* prep_weight, int prep_count,
+                      const gank_label_dense_desc* label, hipStream_t s) {
+  GANK_REQUIRE(table && count > 0, "sn fwd: empty table");
+  GANK_REQUIRE(prep_count == 0 || (prep && prep_weight), "sn fwd: preparation entries without their weight indices");
+  GANK_REQUIRE(count <= SN_MAX || (prep_count == 0 && !label), "sn fwd: the fused preparation takes at most %d weights per call", SN_MAX);
+  GANK_REQUIRE(prep_count <= PREP_MAX, "sn fwd: at most %d preparation entries per call", PREP_MAX);
+  // address of the ticket words on the current device, looked up once per device (the first call of a process is an eager
+  // one; a lookup inside a stream capture is avoided)
+  static std::atomic<unsigned*> ticket_addr[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  unsigned* tickets_base = ticket_addr[dev & 63].load(std::memory_order_relaxed);
+  if (!tickets_base) {
+    if (hipGetSymbolAddress(reinterpret_cast<void**>(&tickets_base), HIP_SYMBOL(sn_tickets)) != hipSuccess || !tickets_base)
+      return gank_set_error("sn fwd: ticket words not found");
+    ticket_addr[dev & 63].store(tickets_base, std::memory_order_relaxed);
+  }
+  for (int base = 0; base < count; base += SN_MAX) {
+    SnTable t;
+    int chunks, fine;
+    const int n = count - base < SN_MAX ? count - base : SN_MAX;
+    if (sn_fill(t, table + base, n, chunks, fine, false)) return 1;
+    unsigned* tickets = tickets_base + (sn_ticket_group.fetch_add(1, std::memory_order_relaxed) % SN_TICKET_GROUPS) * SN_MAX;
+    hipLaunchKernelGGL(sn_fwd_a_kernel, dim3(chunks), dim3(256), 0, s, t, tickets);
+    SnScaleTable st{};
+    st.count = n;
+    st.nchunks = fine;
+    for (int i = 0; i < n; i++) {
+      const gank_sn_desc& d = t.d[i];
+      st.d[i] = SnScaleEntry{d.W, d.W_bar, d.scal, d.a, d.b, d.v, d.ga, d.K, d.C, d.row_offset, 0};
+    }
+    PrepTable pt{};
+    SnPrepExtra px{};
+    SnLabelDense ld{};
+    int label_blocks = 0;
+    if (base == 0 && prep_count > 0) {
+      const int blocks = prep_table_fill(pt, prep, prep_count, 0);
+      if (blocks < 0) return 1;
+      px.prep_blocks = blocks;
+      for (int i = 0; i < prep_count; i++) {
+        GANK_REQUIRE(prep_weight[i] >= 0 && prep_weight[i] < n, "sn fwd: preparation entry %d names weight %d of %d", i, prep_weight[i], n);
+        GANK_REQUIRE(prep[i].w == (const float*)table[prep_weight[i]].W, "sn fwd: preparation entry %d must read the MASTER weight of its table entry (the division by sigma happens in the launch)", i);
+        px.sigma[i] = t.d[prep_weight[i]].scal;
+      }
+      for (int i = prep_count; i < PREP_MAX; i++) px.sigma[i] = t.d[0].scal;
+    }
+    if (base == 0 && label) {
+      GANK_REQUIRE(label->table && label->out && label->V > 0 && label->D > 0 && label->weight >= 0 && label->weight < n,
+                   "sn fwd: bad label-dense descriptor");
+      const gank_sn_desc& d = t.d[label->weight];
+      GANK_REQUIRE(d.K == label->D, "sn fwd: label-dense weight %d has %d rows, the table %d columns", label->weight, d.K, label->D);
+      ld = SnLabelDense{label->table, d.W, d.scal, label->bias, (bf16*)label->out, label->V, label->D, d.C};
+      label_blocks = label->V * ((d.C + 63) / 64);
+    }
+    hipLaunchKernelGGL(sn_fwd_b_kernel, dim3(fine + px.prep_blocks + label_blocks), dim3(256), 0, s, st, pt, px, ld);
+    GANK_LAUNCH_OK("sn_power_iter_fwd");
   }
   return 0;
 }
 
 extern "C" int gank_sn_power_iter_fwd(const gank_sn_desc* table, int count, void* stream) {
-  GANK_REQUIRE(table && count > 0, "sn fwd: empty table");
-  hipStream_t s = (hipStream_t)stream;
-  for (int base = 0; base < count; base += SN_MAX) {
-    SnTable t;
-    int rows, chunks;
-    const int n = count - base < SN_MAX ? count - base : SN_MAX;
-    if (sn_fill(t, table + base, n, rows, chunks, false)) return 1;
-    hipLaunchKernelGGL(sn_rowdot_u_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, t, rows);
-    hipLaunchKernelGGL(sn_colpart_kernel, dim3(chunks), dim3(256), 0, s, t);
-    hipLaunchKernelGGL(sn_finalize_kernel, dim3(n), dim3(256), 0, s, t);
-    hipLaunchKernelGGL(sn_scale_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, t, rows);
-    GANK_LAUNCH_OK("sn_power_iter_fwd");
-  }
-  return 0;
+  return sn_forward(table, count, nullptr, nullptr, 0, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int gank_sn_power_iter_fwd_prep(const gank_sn_desc* table, int count, const gank_prep_desc* prep, const int* prep_weight,
+                                           int prep_count, const gank_label_dense_desc* label, void* stream) {
+  return sn_forward(table, count, prep, prep_weight, prep_count, label, (hipStream_t)stream);
 }
 
 extern "C" int gank_sn_power_iter_bwd(const gank_sn_desc* table, int count, void* stream) {
@@ -222,13 +616,27 @@ extern "C" int gank_sn_power_iter_bwd(const gank_sn_desc* table, int count, void
   hipStream_t s = (hipStream_t)stream;
   for (int base = 0; base < count; base += SN_MAX) {
     SnTable t;
-    int rows, chunks;
+    int chunks, fine;
     const int n = count - base < SN_MAX ? count - base : SN_MAX;
-    if (sn_fill(t, table + base, n, rows, chunks, true)) return 1;
-    hipLaunchKernelGGL(sn_bwd_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, t, rows);
-    hipLaunchKernelGGL(sn_bwd_scalars_kernel, dim3(n), dim3(256), 0, s, t);
-    hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, t, rows);
+    if (sn_fill(t, table + base, n, chunks, fine, true)) return 1;
+    hipLaunchKernelGGL(sn_bwd_gw_kernel, dim3(fine), dim3(256), 0, s, t);
+    hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(fine), dim3(256), 0, s, t);
     GANK_LAUNCH_OK("sn_power_iter_bwd");
   }
+  return 0;
+}
+
+// The label table on its own (a caller without a batched spectral norm around it): out[l] = bf16(bf16(table[l]) (W / sigma) + bias)
+__global__ __launch_bounds__(256) void label_dense_table_kernel(SnLabelDense q) {
+  __shared__ float lred[256];
+  const int ncg = (q.Cout + 63) >> 6;
+  sn_label_row(q, blockIdx.x / ncg, blockIdx.x % ncg, lred);
+}
+extern "C" int gank_label_dense_table(const float* table, const float* W, const float* sigma, const float* bias, void* out,
+                                      int V, int D, int Cout, void* stream) {
+  GANK_REQUIRE(table && W && out && V > 0 && D > 0 && Cout > 0, "label_dense_table: bad arguments");
+  SnLabelDense q{table, W, sigma, bias, (bf16*)out, V, D, Cout};
+  hipLaunchKernelGGL(label_dense_table_kernel, dim3(V * ((Cout + 63) / 64)), dim3(256), 0, (hipStream_t)stream, q);
+  GANK_LAUNCH_OK("label_dense_table");
   return 0;
 }

@@ -527,12 +527,21 @@ class _SpectralNorm(Function):
         return (None, *rets)
 
 
-def spectral_norm_batch(Ws, us, snapshot=False, inplace=False):
+def spectral_norm_batch(Ws, us, snapshot=False, inplace=False, prep=None, label=None):
     """Ws: fp32 weights (Cout last); us: fp32 [.., C] vectors READ by this call (pass snapshots if the
     stored u is overwritten before backward, or let the kernels keep one: snapshot=True; inplace=True writes
-    u_final straight over `us`).  Returns (W_bars tuple, SnBatch)."""
+    u_final straight over `us`).  prep = (kinds, want_d): the bf16 MFMA operand copies of the normalised weights come
+    out of the same launch pair (kernels.prep_weights_batched's kinds; they land on the W_bar tensors).  label = (embedding
+    table, index of the dense weight in Ws, bias | None): the per-label rows of that dense layer too (`W_bar._label_T`).
+    Returns (W_bars tuple, SnBatch)."""
     batch = K.SnBatch(list(Ws), [u.detach() for u in us], snapshot, inplace)
+    batch.prep, batch.label = prep, label
     outs = _SpectralNorm.apply(batch, *Ws)
+    for o, wb in zip(outs, batch.W_bar):      # autograd hands out fresh tensor objects: carry the operand copies over
+        for attr in ("_prep", "_prep_up", "_prep_pool", "_prep_res", "_prep_cpres", "_label_T"):
+            val = getattr(wb, attr, None)
+            if val is not None and o is not wb:
+                setattr(o, attr, val)
     return outs, batch
 
 
@@ -678,6 +687,65 @@ def fork_pool(x):
     return _ForkPool.apply(x)
 
 
+class _ForkPoolConv1x1(Function):
+    """Fan-out of a 3-channel image into (x for the main path, conv1x1(mean_pool2x2(x)) + bias): the first critic block's
+    shortcut (MeanPoolConv 1x1, gan_cifar_resnet.py:218-221) with the pool inside the conv's gather -- one launch for
+    fork_pool + conv.  Backward = the same launches as the separate ops: filter gradient on the pooled image (a side
+    output of the forward kernel), and, when the image itself needs a gradient (the generator update), the 1x1 input
+    gradient unpooled into the main branch's."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias):
+        ctx.set_materialize_grads(False)
+        cin, cout = W.shape[-2], W.shape[-1]
+        wf, _ = _prepared(W, 1, cin, cout, True, False)
+        keep = ctx.needs_input_grad[1]
+        y, pooled = K.meanpool_conv1x1_fprop(x, wf, bias.detach() if bias is not None else None, cout, keep_pooled=keep)
+        ctx.save_for_backward(W, pooled)
+        ctx.cfg = (cin, cout, bias)
+        xv = x.view_as(x)
+        if not ctx.needs_input_grad[0]:
+            # autograd marks EVERY output of a node differentiable when any input is (here: the weight); the alias of an image
+            # that needs no gradient (the critic update) must not make the next conv compute an input gradient
+            ctx.mark_non_differentiable(xv)
+        return xv, y
+
+    @staticmethod
+    def backward(ctx, ga, gs):
+        W, pooled = ctx.saved_tensors
+        cin, cout, bias = ctx.cfg
+        dW = db = None
+        if gs is None:
+            return ga, None, None
+        g = _c(gs)
+        h, w = g.shape[1], g.shape[2]
+        btgt = None
+        if bias is not None and ctx.needs_input_grad[2]:
+            btgt, bacc = _target(bias)
+            db = None if bacc else btgt
+        if ctx.needs_input_grad[1]:
+            tgt, acc = _target(W)
+            _on_side(lambda: K.conv2d_wgrad(pooled, g, tgt, (h, w), 1, 0, 1.0, dbias=btgt), pooled, g)
+            dW = None if acc else tgt
+        elif btgt is not None:
+            K.colsum(g, btgt, 1.0)
+        dx = ga
+        if ctx.needs_input_grad[0]:
+            _, wd = _prepared(W, 1, cin, cout, False, True)
+            dp = K.conv2d_dgrad(g, wd, (h, w), cin, 1)
+            dx = K.unpool2x2_add(dp, None if ga is None else _c(ga), 0.25)
+        return dx, dW, db
+
+
+def fork_pool_conv1x1(x, W, bias=None):
+    """-> (x for the main path, conv1x1(mean_pool2x2(x)) + bias); x [N,H,W,3], W fp32 [1,1,3,Cout] (or [3,Cout])"""
+    return _ForkPoolConv1x1.apply(x, W, bias)
+
+
+def fork_pool_conv1x1_ok(x, cout):
+    return x.dim() == 4 and x.shape[3] == 3 and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 and cout % 128 == 0 and x.is_cuda
+
+
 class _Relu(Function):
     @staticmethod
     def forward(ctx, x, leak):
@@ -767,6 +835,50 @@ class _ConcatTile(Function):
 
 def concat_tile(a, e):
     return _ConcatTile.apply(a, e)
+
+
+class _ConcatLabel(Function):
+    """tf.concat([a, tile(Linear(embed_y(labels)))], 3) (gan_cifar_resnet.py:276-284) through the per-label table
+    T [V, C2] = bf16(bf16(table) W + bias): the dense layer runs on the V table rows instead of the N samples (T rides on W
+    as `W._label_T` when the batched spectral norm made it, else one launch builds it here), the concat gathers T by label.
+    Backward: da = dy[..., :C1]; the tiled half summed over pixels per sample in fp32, then per label, then the dense
+    layer's and the table's gradients from the V-row sums -- 2 launches for what was 4 (concat, dense dx, dense dw, embedding)."""
+
+    @staticmethod
+    def forward(ctx, a, labels, table, W, bias):
+        T = getattr(W, "_label_T", None)
+        if T is None:
+            T = K.label_dense_table(table.detach(), W.detach(), bias.detach() if bias is not None else None)
+        ctx.save_for_backward(labels, table, W)
+        ctx.bias = bias
+        ctx.c1 = a.shape[3]
+        return K.concat_label_fwd(a, T, labels)
+
+    @staticmethod
+    def backward(ctx, dy):
+        labels, table, W = ctx.saved_tensors
+        bias = ctx.bias
+        da, de32 = K.concat_label_bwd(_c(dy), ctx.c1)
+        need_t, need_w = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        need_b = bias is not None and ctx.needs_input_grad[4]
+        dt = dw = db = None
+        tt = wt = bt = None
+        if need_t:
+            tt, acc = _target(table)
+            dt = None if acc else tt
+        if need_w:
+            wt, acc = _target(W)
+            dw = None if acc else wt
+        if need_b:
+            bt, acc = _target(bias)
+            db = None if acc else bt
+        if need_t or need_w or need_b:
+            K.label_dense_bwd(de32, labels, table.detach(), W.detach(), wt, bt, tt)
+        return (da if ctx.needs_input_grad[0] else None), None, dt, dw, db
+
+
+def concat_label(a, labels, table, W, bias=None):
+    return _ConcatLabel.apply(a, labels, table, W, bias)
 
 
 class _Embedding(Function):

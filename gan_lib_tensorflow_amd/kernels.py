@@ -6,7 +6,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, W_FRAG, RES_UPSAMPLE2X, STATS_PREZEROED, SnDesc, PrepDesc, WgradItem  # noqa: F401
+from ._lib import IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, W_FRAG, RES_UPSAMPLE2X, STATS_PREZEROED, SnDesc, PrepDesc, WgradItem, LabelDenseDesc  # noqa: F401
 
 # BF16 = the 16-bit activation dtype of this process: torch.bfloat16, or torch.float16 under GANK_DTYPE=fp16 (libgank_f16.so)
 BF16, F32, I32 = getattr(torch, _lib.ACT_DTYPE_NAME), torch.float32, torch.int32
@@ -47,20 +47,19 @@ def prep_weights(w, want_f=True, want_d=False):
     return wf, wd
 
 
-def prep_weights_batched(ws, want_d=True, kinds=None):
-    """One launch for a list of fp32 weights ([k,k,Cin,Cout] or [Cin,Cout]).  kinds[i]: 0 = plain conv/linear ->
-    `w._prep = (wf, wd)`; 1 = UpsampleConv 3x3 -> `w._prep_up = (wph, wd4)`; 2 = ConvMeanPool 3x3 ->
-    `w._prep_pool = (wp4, wphd)`; 3 = plain + fragment-major copies for the register-weight patch kernel (the conv
-    wrappers pass GANK_W_FRAG when they see them); 4 = "rfrag" operands of the resident kernels -> `w._prep_res = (rf, rd)`;
-    5 = ConvMeanPool 3x3 operands of the resident kernels -> `w._prep_cpres = (rf, rd)`;
-    None = skip (the layer prepares nothing).  The conv wrappers pick the attributes up
-    and skip their own per-layer preparation.  Buffers persist on the tensor and are rewritten IN PLACE on later
-    calls: captured graphs keep reading the same addresses."""
+_PREP_ATTR = ("_prep", "_prep_up", "_prep_pool", "_prep", "_prep_res", "_prep_cpres")
+
+
+def _prep_plan(ws, want_d=True, kinds=None, sources=None):
+    """Descriptor table for the batched operand preparation of `ws` (see prep_weights_batched).  sources[i]: the tensor
+    whose VALUES entry i reads (default: ws[i] itself) -- the fused spectral-norm launch reads the master weight and divides
+    by sigma on the fly, while the operands belong to the normalised tensor.  -> (table, todo indices, outs)"""
     kinds = list(kinds) if kinds is not None else [0] * len(ws)
-    todo = [(w, kd) for w, kd in zip(ws, kinds) if kd is not None]
-    table = (PrepDesc * len(todo))()
+    todo = [i for i, kd in enumerate(kinds) if kd is not None]
+    table = (PrepDesc * max(len(todo), 1))()
     outs = []
-    for i, (w, kind) in enumerate(todo):
+    for slot, i in enumerate(todo):
+        w, kind = ws[i], kinds[i]
         if w.dim() == 2:
             k, cin, cout = 1, w.shape[0], w.shape[1]
         else:
@@ -98,14 +97,33 @@ def prep_weights_batched(ws, want_d=True, kinds=None):
                                                         torch.empty(16 * cin * cout, dtype=BF16, device=dev))
         else:
             raise ValueError(f"unknown preparation kind {kind}")
-        d = table[i]
-        d.w, d.wf, d.wd = _p(w.detach(), F32, "w").value, wf.data_ptr(), (wd.data_ptr() if wd is not None else None)
+        src = w if sources is None else sources[i]
+        d = table[slot]
+        d.w, d.wf, d.wd = _p(src.detach(), F32, "w").value, wf.data_ptr(), (wd.data_ptr() if wd is not None else None)
         d.ksize, d.Cin, d.Cout, d.kind = k, cin, cout, kind
         outs.append((wf, wd))
+    return table, todo, outs
+
+
+def _prep_attach(ws, kinds, todo, outs):
+    for i, o in zip(todo, outs):
+        setattr(ws[i], _PREP_ATTR[kinds[i]], o)
+
+
+def prep_weights_batched(ws, want_d=True, kinds=None):
+    """One launch for a list of fp32 weights ([k,k,Cin,Cout] or [Cin,Cout]).  kinds[i]: 0 = plain conv/linear ->
+    `w._prep = (wf, wd)`; 1 = UpsampleConv 3x3 -> `w._prep_up = (wph, wd4)`; 2 = ConvMeanPool 3x3 ->
+    `w._prep_pool = (wp4, wphd)`; 3 = plain + fragment-major copies for the register-weight patch kernel (the conv
+    wrappers pass GANK_W_FRAG when they see them); 4 = "rfrag" operands of the resident kernels -> `w._prep_res = (rf, rd)`;
+    5 = ConvMeanPool 3x3 operands of the resident kernels -> `w._prep_cpres = (rf, rd)`;
+    None = skip (the layer prepares nothing).  The conv wrappers pick the attributes up
+    and skip their own per-layer preparation.  Buffers persist on the tensor and are rewritten IN PLACE on later
+    calls: captured graphs keep reading the same addresses."""
+    kinds = list(kinds) if kinds is not None else [0] * len(ws)
+    table, todo, outs = _prep_plan(ws, want_d, kinds)
     if todo:
         _lib.check(lib().gank_conv2d_prep_weights_batched(table, len(todo), _stream()), "prep_weights_batched")
-    for (w, kind), o in zip(todo, outs):
-        setattr(w, ("_prep", "_prep_up", "_prep_pool", "_prep", "_prep_res", "_prep_cpres")[kind], o)
+    _prep_attach(ws, kinds, todo, outs)
     return outs
 
 
@@ -169,6 +187,17 @@ def conv2d_fprop(x, wf, bias, out_hw, cout, ksize, flags=0, scale=1.0, residual=
                                        _p(residual, BF16, "residual"), _p(relu_ref, BF16, "relu_ref"), _p(y),
                                        n, h, w, cin, cout, ksize, flags, scale, _stream()), "conv2d_fprop")
     return y
+
+
+def meanpool_conv1x1_fprop(x, wf, bias, cout, keep_pooled=True):
+    """conv1x1(mean_pool2x2(x)) + bias on a 3-channel image, the pool inside the gather -> (y [N,H/2,W/2,Cout], pooled [N,H/2,W/2,3] | None)"""
+    n, h2, w2, cin = x.shape
+    h, w = h2 // 2, w2 // 2
+    y = torch.empty((n, h, w, cout), dtype=BF16, device=x.device)
+    pooled = torch.empty((n, h, w, cin), dtype=BF16, device=x.device) if keep_pooled else None
+    _lib.check(lib().gank_meanpool_conv1x1_fprop(_p(x, BF16, "x"), _p(wf, BF16, "wf"), _p(bias, F32, "bias"), _p(y), _p(pooled),
+                                                 n, h, w, cin, cout, _stream()), "meanpool_conv1x1_fprop")
+    return y, pooled
 
 
 def conv2d_dgrad(dy, wd, out_hw, cin, ksize, flags=0, scale=1.0, residual=None, relu_ref=None):
@@ -470,11 +499,15 @@ class SnBatch:
         self.a = torch.empty_like(self.v)
         self.b = torch.empty_like(self.u_out)
         self.scal = torch.empty(self.n * 8, dtype=F32, device=dev)     # every entry is plainly written before it is read
-        self.bpart = torch.empty(tot(lambda k, c: ((k + 63) // 64) * c), dtype=F32, device=dev)
-        self.rowdot = torch.empty_like(self.v)
+        # partial column sums / |a|^2 / <G,W> per row chunk (the library says how many floats: 16-byte aligned regions)
+        ws = [int(lib().gank_sn_ws_floats(k, c)) for k, c in self.KC]
+        self.bpart = torch.empty(sum(ws), dtype=F32, device=dev)
         self.ga = torch.empty_like(self.v)
         self.u_snap = torch.empty_like(self.u_out) if snapshot else None
         self.inplace = inplace
+        self.prep = None          # (kinds, want_d): MFMA operand copies of the normalised weights from the same launch pair
+        self.label = None         # (table fp32 [V,D], weight index, bias | None): per-label rows of a small dense layer
+        self.label_out = None
         self.table = (SnDesc * self.n)()
         ko = co = bo = 0
         for i, (w, u, (k, c)) in enumerate(zip(self.weights, self.us, self.KC)):
@@ -489,14 +522,34 @@ class SnBatch:
             d.a = self.a.data_ptr() + 4 * ko
             d.b = self.b.data_ptr() + 4 * co
             d.bpart = self.bpart.data_ptr() + 4 * bo
-            d.rowdot = self.rowdot.data_ptr() + 4 * ko
+            d.rowdot = None
             d.ga = self.ga.data_ptr() + 4 * ko
             d.K, d.C = k, c
-            ko, co, bo = ko + k, co + c, bo + ((k + 63) // 64) * c
+            ko, co, bo = ko + k, co + c, bo + ws[i]
         self._co = co
 
     def forward(self):
-        _lib.check(lib().gank_sn_power_iter_fwd(self.table, self.n, _stream()), "sn_power_iter_fwd")
+        if self.prep is None and self.label is None:
+            _lib.check(lib().gank_sn_power_iter_fwd(self.table, self.n, _stream()), "sn_power_iter_fwd")
+            return self.W_bar
+        # W / sigma, its bf16 MFMA operand copies and the label table in one launch pair: the operand entries read the
+        # MASTER weights (the kernel divides by sigma); the copies belong to the normalised tensors
+        kinds, want_d = self.prep if self.prep is not None else ([None] * self.n, True)
+        ptable, todo, outs = _prep_plan(self.W_bar, want_d, kinds, sources=self.weights)
+        pw = (C.c_int * max(len(todo), 1))(*todo)
+        ldesc = None
+        if self.label is not None:
+            tab, wi, bias = self.label
+            v, dd = tab.shape
+            assert self.KC[wi][0] == dd, (self.KC[wi], tab.shape)
+            self.label_out = torch.empty((v, self.KC[wi][1]), dtype=BF16, device=tab.device)
+            ldesc = LabelDenseDesc(_p(tab.detach(), F32, "table").value, _p(bias.detach(), F32, "bias").value if bias is not None else None,
+                                   self.label_out.data_ptr(), v, dd, wi)
+        _lib.check(lib().gank_sn_power_iter_fwd_prep(self.table, self.n, ptable, pw, len(todo), C.byref(ldesc) if ldesc is not None else None,
+                                                     _stream()), "sn_power_iter_fwd_prep")
+        _prep_attach(self.W_bar, kinds, todo, outs)
+        if self.label is not None:
+            self.W_bar[self.label[1]]._label_T = self.label_out
         return self.W_bar
 
     def u_out_views(self):
@@ -744,6 +797,44 @@ def embedding_bwd(dy, idx, dtable):
     n, (vocab, d) = idx.numel(), dtable.shape
     _lib.check(lib().gank_embedding_bwd(_p(dy, BF16, "dy"), _p(idx, I32, "idx"), _p(dtable, F32, "dtable"), n, d, vocab, _stream()), "embedding_bwd")
     return dtable
+
+
+def label_dense_table(table, w, bias=None, sigma=None):
+    """T [V, Cout] bf16 = bf16(bf16(table) (w / sigma) + bias): the per-label rows of embed_y -> Linear (gan_cifar_resnet.py:276-281)"""
+    v, d = table.shape
+    cout = w.shape[1]
+    assert w.shape[0] == d, (table.shape, w.shape)
+    out = torch.empty((v, cout), dtype=BF16, device=table.device)
+    _lib.check(lib().gank_label_dense_table(_p(table, F32, "table"), _p(w, F32, "w"), _p(sigma, F32, "sigma"), _p(bias, F32, "bias"), _p(out),
+                                            v, d, cout, _stream()), "label_dense_table")
+    return out
+
+
+def concat_label_fwd(a, t, labels):
+    n, h, w, c1 = a.shape
+    v, c2 = t.shape
+    y = torch.empty((n, h, w, c1 + c2), dtype=BF16, device=a.device)
+    _lib.check(lib().gank_concat_label_fwd(_p(a, BF16, "a"), _p(t, BF16, "T"), _p(labels, I32, "labels"), _p(y), n, h * w, c1, c2, v, _stream()),
+               "concat_label_fwd")
+    return y
+
+
+def concat_label_bwd(dy, c1):
+    """-> (da bf16 [N,H,W,C1], de32 fp32 [N, C2])"""
+    n, h, w, c = dy.shape
+    da = torch.empty((n, h, w, c1), dtype=BF16, device=dy.device)
+    de = torch.empty((n, c - c1), dtype=F32, device=dy.device)
+    _lib.check(lib().gank_concat_label_bwd(_p(dy, BF16, "dy"), _p(da), _p(de), n, h * w, c1, c - c1, _stream()), "concat_label_bwd")
+    return da, de
+
+
+def label_dense_bwd(de32, labels, table, w, dw=None, dbias=None, dtable=None):
+    """ACCUMULATES dw [D,C2] += bf16(table)^T dT, dbias [C2] += sum_l dT[l], dtable [V,D] += dT w^T with dT[l] = sum of de32 rows of label l"""
+    n, c2 = de32.shape
+    v, d = table.shape
+    _lib.check(lib().gank_label_dense_bwd(_p(de32, F32, "de32"), _p(labels, I32, "labels"), _p(table, F32, "table"), _p(w, F32, "w"),
+                                          _p(dw, F32, "dw"), _p(dbias, F32, "dbias"), _p(dtable, F32, "dtable"), n, v, d, c2, _stream()),
+               "label_dense_bwd")
 
 
 # ------------------------------------------------------------------ losses / optimiser / input

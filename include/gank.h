@@ -210,6 +210,13 @@ int gank_conv2d_general_dgrad(const void* dy, const void* wd, const void* relu_r
 int gank_conv2d_general_wgrad(const void* x, const void* dy, float* dw, float* dbias, int N, int Hx, int Wx, int Hdy, int Wdy,
                               int Cin, int Cout, int ksize, int stride, int pad, int flags, void* stream);
 
+/* MeanPoolConv with a 1x1 filter on a 3-channel image (D.Block.1.Shortcut: gan_cifar_resnet.py:125-137, 218-221):
+ * y [N,H,W,Cout] = conv1x1(mean_pool2x2(x [N,2H,2W,3])) + bias with the pool inside the conv's gather (the pooled value is
+ * rounded to the element type exactly as gank_pool2x2 + gank_conv2d_fprop round it); `pooled` [N,H,W,3] (optional) receives
+ * the pooled image, which the filter gradient (gank_conv2d_wgrad on it) needs.  wf from gank_conv2d_prep_weights. */
+int gank_meanpool_conv1x1_fprop(const void* x, const void* wf, const float* bias, void* y, void* pooled,
+                                int N, int H, int W, int Cin, int Cout, void* stream);
+
 /* ---- Deconv2D (common/ops/deconv2d.py:99-114): tf.nn.conv2d_transpose stride 2 SAME --------------
  * x [N,H,W,Cin] -> y [N,2H,2W,Cout]; master filter F fp32 [k,k,Cout,Cin].  The op has no caller in
  * the reference; it is provided at op level on the same two MFMA engines:
@@ -235,10 +242,13 @@ int gank_colsum_bf16(const void* x, float* out, long rows, int C, float scale, v
  * Batched over `count` weights described by a HOST array of gank_sn_desc (copied into the kernel
  * arguments, 16 per launch group: no device table, capturable).  One power
  * iteration from u_in: a=W u, v=a/(|a|+eps); b=W^T v, u'=b/(|b|+eps); sigma=v W u'^T; W_bar=W/sigma.
- * fwd writes W_bar (fp32, same shape), v, u_out, and {sigma, |a|, |b|} to `scal`.  The caller copies
+ * fwd writes W_bar (fp32, same shape), v, u_out, and {sigma, |a|, |b|, ...} to `scal`.  The caller copies
  * u_out over u only under update_collection=None (sn.py:55-56); NO_OPS never writes u (sn.py:62-65).
  * bwd is the FULL gradient through the iteration (no stop_gradient in sn.py:34-61) and ACCUMULATES
- * into dW.  Workspaces: `a` [K], `bpart` [ceil(K/64)*C], `rowdot` [K], `ga` [K] per weight. */
+ * into dW.  Two launches each way: fwd = {row dots + partial column sums + norms by the last chunk of each weight
+ * (ticket), W/sigma + the backward pass's per-row terms}; bwd = {partial <G,W>, apply}.
+ * Workspaces per weight: `a` [K], `v` [K], `ga` [K], `b` [C], `bpart` [gank_sn_ws_floats(K, C)] (partial column sums and
+ * |a|^2 partials per row chunk, <G,W> partials per finer piece).  `rowdot` is no longer used (may be NULL). */
 typedef struct gank_sn_desc {
   const float* W;      /* [K,C] master weight                                   */
   const float* u_in;   /* [C]                                                    */
@@ -248,19 +258,36 @@ typedef struct gank_sn_desc {
   float* scal;         /* [8]: sigma, n=|a|, m=|b|, s, <G,W>, a.g_v, -, -        */
   float* a;            /* [K]   workspace, kept for backward                     */
   float* b;            /* [C]   kept for backward                                */
-  float* bpart;        /* [ceil(K/64)*C] workspace                               */
+  float* bpart;        /* [gank_sn_ws_floats(K,C)] workspace, kept for backward   */
   const float* dW_bar; /* [K,C] backward input                                   */
   float* dW;           /* [K,C] backward output (accumulated)                    */
-  float* rowdot;       /* [K]   workspace                                        */
-  float* ga;           /* [K]   workspace                                        */
+  float* rowdot;       /* unused (earlier revisions: [K] workspace)              */
+  float* ga;           /* [K]   written by fwd, read by bwd                      */
   float* u_snap;       /* [C] or NULL: fwd also copies u_in here and bwd reads it instead of u_in, so that
                           u_out may alias u_in (u.assign(u_final) of sn.py:55-56 without a snapshot/copy-back pair) */
   int K, C;
   int row_offset;      /* filled by the library                                  */
   int chunk_offset;    /* filled by the library                                  */
 } gank_sn_desc;
+long gank_sn_ws_floats(int K, int C);
 int gank_sn_power_iter_fwd(const gank_sn_desc* table, int count, void* stream);
 int gank_sn_power_iter_bwd(const gank_sn_desc* table, int count, void* stream);
+/* The forward pass with what always follows it in a spectrally normalised network folded into its second launch
+ * (count <= 16): the bf16 MFMA operand copies of W / sigma -- `prep[i]` as for gank_conv2d_prep_weights_batched, except
+ * that prep[i].w is the MASTER weight table[prep_weight[i]].W (the division by sigma happens inside the launch: same
+ * arithmetic as preparing W_bar, without reading it back) -- and, optionally (`label` != NULL), the per-label rows of a
+ * small dense layer on an embedding table, out[l] = bf16(bf16(emb[l]) W_bar + bias) with W_bar = entry `weight` of the
+ * table: the critic's label branch embed_y -> Linear('D.Embedding_y') (gan_cifar_resnet.py:276-281) computed once per
+ * label instead of once per sample (same arithmetic as gank_embedding_fwd + gank_linear_fwd on the 10 labels). */
+typedef struct gank_label_dense_desc {
+  const float* table;  /* [V, D] fp32 embedding table (common/ops/embedding.py:28-40)   */
+  const float* bias;   /* [Cout] fp32 or NULL                                             */
+  void* out;           /* [V, Cout] bf16                                                  */
+  int V, D;
+  int weight;          /* index into the gank_sn_desc table: its W is [D, Cout]           */
+} gank_label_dense_desc;
+int gank_sn_power_iter_fwd_prep(const gank_sn_desc* table, int count, const gank_prep_desc* prep, const int* prep_weight,
+                                int prep_count, const gank_label_dense_desc* label, void* stream);
 
 /* ---- conditional batch norm (common/ops/normalization.py:27-59) ----------------------------------
  * Batch moments over (N/groups, H, W) per tower (biased variance, eps 1e-5), per-sample gamma/beta
@@ -351,6 +378,21 @@ int gank_relu_meanpool_hw_bwd(const void* dy, const void* x, void* dx, int N, in
  * y[n,hw,:C1]=a[n,hw,:], y[n,hw,C1:]=e[n,:].  bwd: da = dy[..,:C1], de[n,:] = sum_hw dy[n,hw,C1:]. */
 int gank_concat_tile_fwd(const void* a, const void* e, void* y, int N, int HW, int C1, int C2, void* stream);
 int gank_concat_tile_bwd(const void* dy, void* da, void* de, int N, int HW, int C1, int C2, void* stream);
+
+/* The label branch of the SNGAN critic (gan_cifar_resnet.py:276-284: embed_y -> Linear -> expand_dims x2 -> tile ->
+ * concat) through a per-label table T [V, C2] bf16 = bf16(bf16(emb) W + bias) (gank_label_dense_table, or the
+ * `label` option of gank_sn_power_iter_fwd_prep; sigma: a device word W is divided by, or NULL):
+ *   fwd: y[n,hw,:C1] = a[n,hw,:], y[n,hw,C1:] = T[labels[n]]   (a label outside [0,V): zeros)
+ *   bwd: da = dy[..,:C1]; de32[n,:] = sum_hw dy[n,hw,C1:] (fp32, not rounded per sample);
+ *        gank_label_dense_bwd: dT[l] = sum_{n: labels[n]=l} de32[n] (in sample order: deterministic), then
+ *        dW [D,C2] += bf16(emb)^T dT, dbias [C2] += sum_l dT[l], demb [V,D] += dT W^T  (each optional).  C2 must divide 1024; (1024 + C2) * V + N floats must fit the LDS. */
+int gank_label_dense_table(const float* table, const float* W, const float* sigma, const float* bias, void* out,
+                           int V, int D, int Cout, void* stream);
+int gank_concat_label_fwd(const void* a, const void* T, const int32_t* labels, void* y, int N, int HW, int C1, int C2, int V,
+                          void* stream);
+int gank_concat_label_bwd(const void* dy, void* da, float* de32, int N, int HW, int C1, int C2, void* stream);
+int gank_label_dense_bwd(const float* de32, const int32_t* labels, const float* table, const float* W, float* dW, float* dbias,
+                         float* dtable, int N, int V, int D, int C2, void* stream);
 
 /* tf.nn.embedding_lookup (common/ops/embedding.py:51) and its IndexedSlices gradient (dense, accumulated) */
 int gank_embedding_fwd(const float* table, const int32_t* idx, void* y, int N, int D, int vocab, void* stream);

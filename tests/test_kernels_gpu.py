@@ -1169,3 +1169,138 @@ def test_fork_pool_equals_fork_then_meanpool(K):
     p3.backward(gpt)
     torch.cuda.synchronize()
     assert relerr(x3.grad, 0.25 * np.repeat(np.repeat(gp, 2, axis=1), 2, axis=2)) < BF_TOL
+
+
+# ---------------------------------------------------------------------------------------------- round 3
+def test_spectral_norm_two_launch_form_shapes_and_replays(K):
+    """The two-launch forward (row dots + partial column sums in one pass, norms by the last chunk block of each weight) and
+    the two-launch backward on every shape class: register-tile form (C a power of two in [4, 256], ragged last chunk),
+    generic form (C = 1, 33, 512), one-chunk weights (no ticket), K = 9216 (144 chunks).  Replayed with the weights changed
+    in place between calls: a finalizer that read a stale partial sum of the previous call (a missing acquire, a ticket left
+    non-zero) shows up as an error against the oracle of the NEW weights."""
+    rng = np.random.default_rng(50)
+    shapes = [(3, 128), (27, 128), (1152, 128), (300, 128), (2304, 256), (128, 1), (70, 33), (100, 64), (65, 4), (9216, 256), (130, 512), (64, 8), (200, 16)]
+    Ws, us, Gs = [], [], []
+    for kk, c in shapes:
+        Ws.append(f32(rng.normal(size=(kk, c)) * 0.05))
+        us.append(f32(rng.normal(size=(1, c))))
+        Gs.append(f32(rng.normal(size=(kk, c))))
+    batch = K.SnBatch([w[1] for w in Ws], [u[1] for u in us])
+    for rep in range(4):
+        if rep:
+            for w, wt in Ws:
+                wt.mul_(1.0 + 0.37 * rep)
+                w *= np.float32(1.0 + 0.37 * rep)
+            wnow = [(wt.double().cpu().numpy(), wt) for _, wt in Ws]
+        else:
+            wnow = Ws
+        Wbars = batch.forward()
+        dWs = [torch.zeros_like(w[1]) for w in Ws]
+        batch.backward([g[1] for g in Gs], dWs)
+        torch.cuda.synchronize()
+        for i, (w, u, g) in enumerate(zip(wnow, us, Gs)):
+            Wb, u1, sigma, v = R.sn_forward(w[0], u[0])
+            assert relerr(Wbars[i], Wb) < 1e-5, (rep, shapes[i])
+            assert relerr(batch.u_out_views()[i], u1.ravel()) < 1e-5, (rep, shapes[i])
+            assert abs(float(batch.sigma(i)) - sigma) / sigma < 1e-5, (rep, shapes[i])
+            assert relerr(dWs[i], R.sn_backward(w[0], u[0], g[0])) < 2e-4, (rep, shapes[i])
+
+
+def test_spectral_norm_fused_operand_copies_and_label_table_are_bit_identical(K):
+    """gank_sn_power_iter_fwd_prep: the MFMA operand copies built from W / sigma inside the second spectral-norm launch are
+    the bytes gank_conv2d_prep_weights_batched builds from the stored W_bar (every operand kind the critic uses), and the
+    per-label table is embedding_fwd + linear_fwd on the ten labels (bit for bit from W_bar; one rounding apart from W, sigma)."""
+    rng = np.random.default_rng(51)
+    specs = [((1, 1, 3, 128), 0), ((3, 3, 3, 128), 0), ((3, 3, 128, 128), 5), ((300, 128), None), ((1, 1, 256, 128), 0), ((3, 3, 256, 256), 0),
+             ((3, 3, 256, 128), 5), ((3, 3, 128, 128), 4), ((3, 3, 128, 128), 4), ((128, 1), None), ((3, 3, 64, 64), 2), ((3, 3, 64, 128), 1)]
+    Ws = [f32(rng.normal(size=s) * 0.05)[1] for s, _ in specs]
+    us = [f32(rng.normal(size=(1, s[-1])))[1] for s, _ in specs]
+    kinds = [k for _, k in specs]
+    table = f32(rng.uniform(-0.08, 0.08, size=(10, 300)))[1]
+    bias = f32(rng.normal(size=128) * 0.1)[1]
+    ref = K.SnBatch(Ws, us)
+    Wb_ref = ref.forward()
+    K.prep_weights_batched(Wb_ref, want_d=True, kinds=kinds)
+    emb = K.embedding_fwd(table, torch.arange(10, dtype=torch.int32, device="cuda"))
+    T_ref = K.linear_fwd(emb, Wb_ref[3], bias)
+    fused = K.SnBatch(Ws, us)
+    fused.prep, fused.label = (kinds, True), (table, 3, bias)
+    Wb = fused.forward()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(Wb, Wb_ref)):
+        assert torch.equal(a, b), i
+        for attr in ("_prep", "_prep_up", "_prep_pool", "_prep_res", "_prep_cpres"):
+            pa, pb = getattr(a, attr, None), getattr(b, attr, None)
+            assert (pa is None) == (pb is None), (i, attr)
+            if pa is not None:
+                for x, y in zip(pa, pb):
+                    assert (x is None) == (y is None) and (x is None or torch.equal(x.view(torch.int16), y.view(torch.int16))), (i, attr)
+    # the table on its own, from the normalised weight: embedding_fwd + linear_fwd bit for bit
+    assert torch.equal(K.label_dense_table(table, Wb_ref[3], bias).view(torch.int16), T_ref.view(torch.int16))
+    # from the master weight and sigma (what the fused launch does): the sum is divided ONCE instead of every weight -- the same
+    # value up to one rounding of the bf16 result
+    sg = fused.scal[8 * 3:8 * 3 + 1]
+    t64 = (table.to(torch.bfloat16).double() @ (Ws[3].double() / sg.double()) + bias.double()).cpu().numpy()
+    for T in (Wb[3]._label_T, K.label_dense_table(table, Ws[3], bias, sigma=sg)):
+        assert relerr(T, t64) < 2.0 ** -8
+        assert float((T.float() - T_ref.float()).abs().max()) <= 2.0 ** -8 * float(T_ref.float().abs().max())
+
+
+def test_concat_label_fwd_bwd(K):
+    """The critic's label branch through the per-label table: forward = concat_tile(x, linear(embedding(labels))) bit for
+    bit (table built from the normalised weight); backward against float64 (the fp32 per-label sums are more accurate than the per-sample bf16 chain they replace)."""
+    rng = np.random.default_rng(52)
+    n, hw, c1, c2, v, d = 24, 16, 128, 128, 10, 300
+    a, at = bf(rng.normal(size=(n, 4, 4, c1)))
+    labels = rng.integers(0, v, n)
+    lt = torch.tensor(labels, dtype=torch.int32).cuda()
+    tab, tabt = f32(rng.uniform(-0.08, 0.08, size=(v, d)))
+    w, wt = f32(rng.normal(size=(d, c2)) * 0.05)
+    b, bt = f32(rng.normal(size=c2) * 0.1)
+    T = K.label_dense_table(tabt, wt, bt)
+    y = K.concat_label_fwd(at, T, lt)
+    y_ref = K.concat_tile_fwd(at, K.linear_fwd(K.embedding_fwd(tabt, lt), wt, bt))
+    assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16))
+    dy, dyt = bf(rng.normal(size=(n, 4, 4, c1 + c2)))
+    da, de32 = K.concat_label_bwd(dyt, c1)
+    assert torch.equal(da.view(torch.int16), dyt[..., :c1].contiguous().view(torch.int16))
+    de = dy[..., c1:].reshape(n, hw, c2).sum(1)
+    assert relerr(de32, de) < 1e-6
+    dw, db, dtab = torch.zeros_like(wt), torch.zeros_like(bt), torch.zeros_like(tabt)
+    K.label_dense_bwd(de32, lt, tabt, wt, dw, db, dtab)
+    K.label_dense_bwd(de32, lt, tabt, wt, dw, db, dtab)          # accumulates
+    torch.cuda.synchronize()
+    dT = np.zeros((v, c2))
+    for i in range(n):
+        dT[labels[i]] += de[i]
+    E = torch.tensor(tab, dtype=torch.float32).to(torch.bfloat16).to(torch.float64).numpy()
+    assert relerr(dw, 2 * E.T @ dT) < 1e-5
+    assert relerr(db, 2 * dT.sum(0)) < 1e-5
+    assert relerr(dtab, 2 * dT @ w.T) < 1e-5
+    # deterministic: a second pair of launches from zero gives the same bits
+    dw2, db2, dtab2 = torch.zeros_like(wt), torch.zeros_like(bt), torch.zeros_like(tabt)
+    K.label_dense_bwd(de32, lt, tabt, wt, dw2, db2, dtab2)
+    K.label_dense_bwd(de32, lt, tabt, wt, dw2, db2, dtab2)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2) and torch.equal(dtab, dtab2)
+    # a label outside the table: a zero row forward, no contribution backward
+    lt2 = lt.clone(); lt2[0] = 99
+    y2 = K.concat_label_fwd(at, T, lt2)
+    assert float(y2[0, :, :, c1:].abs().max()) == 0.0 and torch.equal(y2[1:].view(torch.int16), y[1:].view(torch.int16))
+
+
+def test_meanpool_conv1x1_gather_is_pool_then_conv(K):
+    """D.Block.1.Shortcut with the 2x2 mean inside the conv's gather: the bytes of pool2x2 + conv2d_fprop, and the pooled image
+    as a side output."""
+    rng = np.random.default_rng(53)
+    for n in (3, 128):
+        x, xt = bf(rng.normal(size=(n, 32, 32, 3)))
+        w, wt = f32(rng.normal(size=(1, 1, 3, 128)) * 0.3)
+        b, bt = f32(rng.normal(size=128) * 0.1)
+        wf, _ = K.prep_weights(wt, True, False)
+        pooled_ref = K.pool2x2(xt, 0.25)
+        y_ref = K.conv2d_fprop(pooled_ref, wf, bt, (16, 16), 128, 1)
+        y, pooled = K.meanpool_conv1x1_fprop(xt, wf, bt, 128)
+        torch.cuda.synchronize()
+        assert torch.equal(pooled.view(torch.int16), pooled_ref.view(torch.int16))
+        assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16))
+        assert relerr(y, R.conv2d_same(R.meanpool2x2(x), w) + b) < BF_TOL
