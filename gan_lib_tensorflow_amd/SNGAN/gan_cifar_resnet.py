@@ -162,6 +162,7 @@ def Discriminator(inputs, labels, update_collection=None, reuse=False, loss_head
                 label_dense = (store.vars[names[0]], names[1], store.vars[names[2]])
         with _sn.precomputed(store, prefix, update_collection, prep_kind=_d_prep_kind, label_dense=label_dense):   # one batched SN for all 12 weights
             output = inputs.reshape(-1, 32, 32, 3)
+            prefork = None
             if LABEL_TABLE:
                 # embed_y -> Linear -> expand_dims x2 -> tile -> concat (:276-284) depends on a sample only through its label:
                 # the dense layer runs on the 10 table rows and the concat gathers (same variables, same creation order)
@@ -169,7 +170,12 @@ def Discriminator(inputs, labels, update_collection=None, reuse=False, loss_head
                 w_emb, b_emb = _linear.linear_variables(EMBEDDING_DIM, DIM_D, 'D.Embedding_y', spectral_normed=True,
                                                         update_collection=update_collection, biases=True)
                 output = OptimizedResBlockDisc1(output, spectral_normed=True, update_collection=update_collection, biases=True)
-                output = Fn.concat_label(output, labels, emb_table, w_emb, b_emb)
+                if (blocks.FUSE_LABEL_FORK and blocks.COMMUTE_1X1 and blocks.FUSE_FORK_POOL and output.requires_grad
+                        and output.shape[1] % 2 == 0 and output.shape[2] % 2 == 0 and 1024 % ((output.shape[3] + DIM_D) // 8) == 0):
+                    prefork = Fn.concat_label_fork_pool(output, labels, emb_table, w_emb, b_emb)     # concat + D.Block.2's fan-out
+                    output = None
+                else:
+                    output = Fn.concat_label(output, labels, emb_table, w_emb, b_emb)
             else:
                 with Fn.beside(inputs.device) as br:      # label embedding -> dense layer (:279-281) beside the first block
                     embedding_y = _embedding.embed_y(labels, VOCAB_SIZE, EMBEDDING_DIM)
@@ -179,7 +185,7 @@ def Discriminator(inputs, labels, update_collection=None, reuse=False, loss_head
                 Fn.join_beside(br, embedding_y)
                 output = Fn.concat_tile(output, embedding_y)               # expand_dims x2 + tile + concat (:282-284)
             output = ResidualBlock(output, DIM_D * 2, DIM_D, 3, 'D.Block.2', spectral_normed=True,
-                                   update_collection=update_collection, resample='down', labels=labels, biases=True)
+                                   update_collection=update_collection, resample='down', labels=labels, biases=True, prefork=prefork)
             if blocks.res_chain8_eligible(output, DIM_D, ['D.Block.3', 'D.Block.4'], labels):
                 # D.Block.3, D.Block.4 and nonlinearity + reduce_mean (:291-301) as ONE launch: an 8x8x128 sample stays in LDS
                 output = blocks.ResidualBlockChain8(output, DIM_D, ['D.Block.3', 'D.Block.4'], spectral_normed=True,

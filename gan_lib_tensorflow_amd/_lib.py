@@ -55,6 +55,7 @@ PROTOTYPES = {
     "gank_conv2d_dgrad": [P, P, P, P, P, I, I, I, I, I, I, I, F, P],
     "gank_meanpool_conv1x1_fprop": [P, P, P, P, P, I, I, I, I, I, P],
     "gank_conv2d_wgrad_batched": [C.POINTER(WgradItem), I, I, I, I, I, I, I, I, F, P],
+    "gank_conv2d_wgrad_narrow_pair": [P, P, P, P, I, I, I, I, I, P, P, P, P, I, I, I, I, I, F, P],
     "gank_conv2d_wgrad_ws_elems": [I, I, I, I, I, I, I],
     "gank_conv2d_wgrad": [P, P, P, P, P, L, I, I, I, I, I, I, I, F, P],
     "gank_upconv3x3_prep_weights": [P, P, P, I, I, P],
@@ -86,6 +87,8 @@ PROTOTYPES = {
     "gank_concat_label_fwd": [P, P, P, P, I, I, I, I, I, P],
     "gank_concat_label_bwd": [P, P, P, I, I, I, I, P],
     "gank_label_dense_bwd": [P, P, P, P, P, P, P, I, I, I, I, P],
+    "gank_concat_label_pool_fwd": [P, P, P, P, P, I, I, I, I, I, I, P],
+    "gank_concat_label_unpool_bwd": [P, P, P, P, I, I, I, I, I, P],
     "gank_cbn_parts": [L],
     "gank_cbn_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     "gank_cbn_fwd_from_sums": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P],

@@ -32,6 +32,7 @@ COMMUTE_1X1 = True
 FUSE_SHORTCUT_UPSAMPLE = True
 import os as _os
 FUSE_FORK_POOL = _os.environ.get("GANK_FORK_POOL", "1") == "1"   # down blocks: fan-out and shortcut pool as one op (one unpool-add launch backward)
+FUSE_LABEL_FORK = _os.environ.get("GANK_LABEL_FORK", "1") == "1"   # critic: label concat + the next block's fan-out (fork_pool) as one op each way
 FUSE_POOL_GATHER = _os.environ.get("GANK_POOL_GATHER", "1") == "1"   # first critic block: the shortcut's 2x2 mean inside its 1x1 conv's gather
 FUSE_IDENTITY_SHORTCUT_GRAD = True   # identity shortcut: its gradient is added by conv_1's input-gradient kernel
 
@@ -116,9 +117,11 @@ def UpsampleConv(inputs, output_dim, filter_size=3, stride=1, name=None,
 
 def ResidualBlock(inputs, input_dim, output_dim, filter_size, name,
                   spectral_normed=False, update_collection=None, inputs_norm=False,
-                  resample=None, labels=None, biases=True, groups=1, out_stats=0):
+                  resample=None, labels=None, biases=True, groups=1, out_stats=0, prefork=None):
     """resample: None, 'down', or 'up'  (gan_cifar_resnet.py:156-209).  out_stats: the block's output feeds a batch norm
-    over that many towers (its statistics then come out of conv_2's epilogue where the kernel can produce them)."""
+    over that many towers (its statistics then come out of conv_2's epilogue where the kernel can produce them).
+    prefork = (inputs, mean_pool2x2(inputs)): the producer of a 'down' block's input already made the block's fan-out
+    (functional.concat_label_fork_pool); `inputs` is then ignored."""
     if resample == 'down':
         conv_1 = functools.partial(_conv2d.Conv2D, input_dim=input_dim, output_dim=input_dim)
         conv_2 = functools.partial(ConvMeanPool, output_dim=output_dim)
@@ -135,7 +138,10 @@ def ResidualBlock(inputs, input_dim, output_dim, filter_size, name,
         raise Exception('invalid resample value')
 
     pooled_short = resample == 'down' and COMMUTE_1X1 and FUSE_FORK_POOL
-    if pooled_short:
+    if prefork is not None:
+        assert pooled_short, "prefork is the (x, mean_pool2x2(x)) pair of a down-sampling block"
+        x_main, x_short = prefork
+    elif pooled_short:
         x_main, x_short = Fn.fork_pool(inputs)     # the 1x1 shortcut conv commutes with the pool: it runs on the pooled alias
     else:
         x_short, x_main = Fn.fork(inputs)

@@ -773,6 +773,222 @@ static int launch_wgrad_packed(WgradArgs a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Streaming form of the narrow-input filter gradient (round 3): dW [k*k*CIN (<= 31)][Cout] = Xcol^T dY over ALL pixels,
+// i.e. a [32 x M] x [M x 128] product whose whole cost is reading dy once (33.5 MB for D.Block.1.Conv1 at 128 samples).
+// The packed kernel above walks it in 64-pixel steps behind a 3-deep register ring with a barrier per step and ran at
+// 1.25 TB/s (27 us).  Here a block owns 512 consecutive pixels x 128 couts and requests its ENTIRE dy slice (128 KB) by
+// LDS-DMA before doing anything else -- every CU has 128 KB in flight at once -- and builds the im2col operand (32 KB) from
+// the L2-resident image while the slice streams in.  Wave w issues, waits for and consumes the 32-channel sub-tile w, so
+// the dy side needs no barrier at all; one barrier publishes the im2col tile.  Row k*k*CIN of the operand is all ones: its
+// output row is the bias gradient.  LDS: the full 160 KB (dy [4 subs][512 px][32 ch] | Xcol [512 px][32 k]).
+// Two layers of different geometry can share a launch (the critic's D.Block.1.Conv1 3x3 and D.Block.1.Shortcut 1x1).
+// ------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* wg_lds_t;
+constexpr int NARROW_STREAM_LDS = (4 * 512 * 32 + 512 * 32) * 2;     // 160 KB
+constexpr int NARROW_STAGE_OFF = NARROW_STREAM_LDS - 4096;           // the last 4 KB double as the image stage (read out before the operand tile is written)
+
+struct NarrowWgArgs {
+  const bf16* x;       // [N,H,W,CIN]
+  const bf16* dy;      // [N,H,W,Cout]
+  float* dw;           // [ks*ks*CIN][Cout]
+  float* dbias;        // [Cout] or null
+  int N, H, W, Cout, M, shw, sw;
+  float scale;
+  int blocks;          // ceil(M / 512) * (Cout / 128)
+};
+
+template <int N>
+__device__ __forceinline__ void wg_wait_vmcnt() {
+  if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// NPX = pixels per block: 512 (the whole LDS) or 128 (the second, smaller layer of a folded pair: see the kernel below)
+template <int KS, int CIN, int NPX>
+__device__ __forceinline__ void wgrad_narrow_stream_body(const NarrowWgArgs& a, int blk, char* smem, f32x16& out) {
+  constexpr int KTOT = KS * KS * CIN, PAD = (KS - 1) / 2;
+  static_assert(KTOT <= 31, "one 32-row operand tile with a row left for the bias gradient");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cgroups = a.Cout >> 7;
+  const int cg = blk % cgroups, pb = blk / cgroups;
+  constexpr int NPC = NPX / 16;                              // DMA pieces (= MFMA K-steps) per wave
+  constexpr int NCH = NPX * 4 / 256;                         // operand chunks per thread
+  const int m0 = pb * NPX, co0 = cg * 128;
+  bf16* sG = reinterpret_cast<bf16*>(smem);                  // [4][NPX][32]
+  bf16* sX = sG + 4 * 512 * 32;                              // [NPX][32]  (at its NPX = 512 place either way)
+  char* stage = smem + NARROW_STAGE_OFF;                     // 4 KB at the end of sX: the image bytes this block's pixels touch
+
+  // ---- (1) the image region of the block's pixels and their halo, ONE coalesced 16-byte load per thread, BEFORE any LDS-DMA is
+  // in flight (beside a pending DMA hipcc drains vmcnt(0) at the first use of an ordinary load: the whole slice would land first).
+  // x is [N,H,W,CIN] with CIN innermost: flat pixels m0 - W - 1 .. m0 + 512 + W are one contiguous byte range.
+  const int sb = max(0, (m0 - PAD * (a.W + 1)) * CIN * 2) & ~15;        // first staged byte of x  (NPX + 2 W + 2 pixels <= 4 KB: checked by the host)
+  {
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, a.M * CIN * 2, 0x00020000);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, sb + 16 * tid, 0, 0);      // past the end: zeros
+    *reinterpret_cast<u32x4*>(stage + 16 * tid) = v;
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+  // ---- (2) the dy slice: wave w requests sub-tile w (couts co0 + 32 w ..), 32 pieces of 16 pixels x 64 B
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.dy), 0, a.M * a.Cout * 2, 0x00020000);
+  {
+    const int voff = ((lane >> 2) * a.Cout + (lane & 3) * 8) * 2;        // pixel l/4 of the piece, 16-byte chunk l%4 of its 64 B
+#pragma unroll
+    for (int pc = 0; pc < NPC; pc++) {
+      const int soff = ((m0 + pc * 16) * a.Cout + co0 + wave * 32) * 2;   // pixels past M fall outside the buffer: zeros
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (wg_lds_t)(smem + (wave * NPX + pc * 16) * 64), 16, voff, soff, 0, 0);
+    }
+  }
+  __builtin_amdgcn_s_barrier();          // raw barriers from here on: __syncthreads() would drain the DMA
+
+  // ---- (3) im2col operand from the staged bytes, while the slice streams in: chunk q = (pixel q>>2, columns 8 (q&3) .. +7),
+  // 8 chunks per thread; q & 3 is the same for all of a thread's chunks, so the tap geometry of its 8 columns is computed once
+  const int cc = tid & 3;
+  int k_d[8], k_dh[8], k_dw[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const int k = cc * 8 + e, tap = k / CIN, c = k - tap * CIN;
+    k_dh[e] = k < KTOT ? tap / KS - PAD : 1 << 20;                      // out-of-range column: never inside the image
+    k_dw[e] = tap % KS - PAD;
+    k_d[e] = ((tap / KS - PAD) * a.W + tap % KS - PAD) * CIN + c;       // element offset from the pixel's first channel
+  }
+  const int ones_e = KTOT - cc * 8;                                     // column of the all-ones row, if it is one of this thread's
+  bf16x8 ch[NCH];
+#pragma unroll
+  for (int j = 0; j < NCH; j++) {
+    const int p = (tid >> 2) + 64 * j, m = m0 + p;
+    int n, oh, ow;
+    pix_decomp(m < a.M ? m : 0, a.H, a.W, a.shw, a.sw, n, oh, ow);
+    const int base = m * CIN * 2 - sb;                                  // byte offset of the pixel in the stage
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const bool ok = m < a.M && (unsigned)(oh + k_dh[e]) < (unsigned)a.H && (unsigned)(ow + k_dw[e]) < (unsigned)a.W;
+      const bf16 t = *reinterpret_cast<const bf16*>(stage + (ok ? base + 2 * k_d[e] : 0));
+      ch[j][e] = ok ? t : f2bf((e == ones_e && m < a.M) ? 1.f : 0.f);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();          // every thread has read the stage: the operand tile may overwrite it
+#pragma unroll
+  for (int j = 0; j < NCH; j++) *reinterpret_cast<bf16x8*>(sX + ((tid >> 2) + 64 * j) * 32 + cc * 8) = ch[j];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; e++) acc[e] = 0.f;
+  const int g = lane >> 4, li = lane & 15;
+  const int tr_off = ((8 * (g >> 1) + (li >> 2)) * 32) + 16 * (g & 1) + 4 * (li & 3);
+  const bf16* pX = sX + tr_off;
+  const bf16* pG = sG + wave * NPX * 32 + tr_off;
+  auto stage8 = [&](int s0) {
+#pragma unroll
+    for (int s = s0; s < s0 + 8; s++) {             // K-step s = pixels 16 s .. 16 s + 15 = DMA piece s of this wave
+      const s16x4 xl = lds_tr_read(pX + s * 16 * 32), xh = lds_tr_read(pX + s * 16 * 32 + 4 * 32);
+      const s16x4 gl = lds_tr_read(pG + s * 16 * 32), gh = lds_tr_read(pG + s * 16 * 32 + 4 * 32);
+      const s16x8 tx = {xl[0], xl[1], xl[2], xl[3], xh[0], xh[1], xh[2], xh[3]};
+      const s16x8 tg = {gl[0], gl[1], gl[2], gl[3], gh[0], gh[1], gh[2], gh[3]};
+      acc = GANK_MFMA32(__builtin_bit_cast(bf16x8, tx), __builtin_bit_cast(bf16x8, tg), acc);
+    }
+  };
+  // the wave's own pieces retire in issue order: 8 at a time
+  if constexpr (NPC == 32) {
+    wg_wait_vmcnt<24>(); __builtin_amdgcn_sched_barrier(0); stage8(0);
+    wg_wait_vmcnt<16>(); __builtin_amdgcn_sched_barrier(0); stage8(8);
+    wg_wait_vmcnt<8>();  __builtin_amdgcn_sched_barrier(0); stage8(16);
+    wg_wait_vmcnt<0>();  __builtin_amdgcn_sched_barrier(0); stage8(24);
+  } else {
+    static_assert(NPC == 8, "512 or 128 pixels per block");
+    wg_wait_vmcnt<0>();  __builtin_amdgcn_sched_barrier(0); stage8(0);
+  }
+
+  out = acc;
+}
+
+// D rows = k (tap, channel; row KTOT = column sums of dy), cols = couts co0 + 32 wave + r
+template <int KS, int CIN>
+__device__ __forceinline__ void wgrad_narrow_stream_epilogue(const NarrowWgArgs& a, int blk, const f32x16& acc) {
+  constexpr int KTOT = KS * KS * CIN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int co0 = (blk % (a.Cout >> 7)) * 128;
+  const int r = lane & 31, h = lane >> 5;
+  const int co = co0 + wave * 32 + r;
+#pragma unroll
+  for (int e = 0; e < 16; e++) {
+    const int k = (e & 3) + 8 * (e >> 2) + 4 * h;
+    if (k < KTOT) atomicAdd(a.dw + (long)k * a.Cout + co, acc[e] * a.scale);
+    else if (k == KTOT && a.dbias) atomicAdd(a.dbias + co, acc[e] * a.scale);
+  }
+}
+
+template <int KS0, int KS1, int CIN>
+__global__ __launch_bounds__(256) void conv_wgrad_narrow_stream_kernel(NarrowWgArgs a0, NarrowWgArgs a1, int folded) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x16 acc0, acc1;
+  if (folded) {
+    // a pair whose second layer has a quarter of the first one's pixels (the critic's Conv1 on 32x32, Shortcut on the pooled
+    // 16x16): every block takes 512 pixels of the first AND then 128 of the second -- one round of blocks on the chip, where
+    // 256 + 64 blocks of 160 KB LDS ran as two.  Both layers' atomics leave at the very end: issued between the layers they
+    // would sit in front of the second layer's first vmcnt wait.
+    wgrad_narrow_stream_body<KS0, CIN, 512>(a0, blockIdx.x, smem, acc0);
+    __builtin_amdgcn_s_barrier();        // every wave is past its last LDS read of the first layer
+    wgrad_narrow_stream_body<KS1, CIN, 128>(a1, blockIdx.x, smem, acc1);
+    wgrad_narrow_stream_epilogue<KS0, CIN>(a0, blockIdx.x, acc0);
+    wgrad_narrow_stream_epilogue<KS1, CIN>(a1, blockIdx.x, acc1);
+    return;
+  }
+  if ((int)blockIdx.x < a0.blocks) {
+    wgrad_narrow_stream_body<KS0, CIN, 512>(a0, blockIdx.x, smem, acc0);
+    wgrad_narrow_stream_epilogue<KS0, CIN>(a0, blockIdx.x, acc0);
+  } else {
+    wgrad_narrow_stream_body<KS1, CIN, 512>(a1, blockIdx.x - a0.blocks, smem, acc1);
+    wgrad_narrow_stream_epilogue<KS1, CIN>(a1, blockIdx.x - a0.blocks, acc1);
+  }
+}
+
+static bool wgrad_narrow_stream_ok(int N, int H, int W, int Cin, int Cout, int ks) {
+  static int env = -1;   // experiment knob: GANK_WGRAD_STREAM=0 keeps the packed kernel
+  if (env < 0) { const char* e = getenv("GANK_WGRAD_STREAM"); env = e ? atoi(e) : 1; }
+  return env && Cin == 3 && (ks == 1 || ks == 3) && Cout % 128 == 0 && (512 + 2 * W + 2) * 6 + 16 <= 4096 && (long)N * H * W * Cout * 2 < (1L << 31) && (long)N * H * W < (1L << 30);
+}
+static NarrowWgArgs narrow_args(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int Cout, float scale) {
+  NarrowWgArgs q{};
+  q.x = (const bf16*)x; q.dy = (const bf16*)dy; q.dw = dw; q.dbias = dbias;
+  q.N = N; q.H = H; q.W = W; q.Cout = Cout; q.M = N * H * W; q.sw = log2_or_neg(W); q.shw = log2_or_neg(H * W); q.scale = scale;
+  q.blocks = cdiv(q.M, 512) * (Cout / 128);
+  return q;
+}
+// one or two layers (ks1 == 0: one) with Cin == 3
+static int launch_wgrad_narrow_stream(const NarrowWgArgs& a0, int ks0, const NarrowWgArgs& a1, int ks1, hipStream_t s) {
+  NarrowWgArgs b1 = a1;
+  if (!ks1) b1.blocks = 0;
+  // fold the second layer into the first one's blocks when it has exactly a quarter of the pixels (and the same couts)
+  // GANK_NARROW_FOLD=1: every block takes 512 pixels of the first layer and then 128 of the second (one round of blocks instead of
+  // 256 + 64).  Isolated it is faster (scratch/micro/narrow.hip: 16.8 vs 18.6 us warm, 24.2 vs 28.3 us from cold caches); inside the
+  // critic update it measured 0.5 % SLOWER per iteration (interleaved A/B on one box), so separate block ranges stay the default.
+  static int fold_env = -1;
+  if (fold_env < 0) { const char* e = getenv("GANK_NARROW_FOLD"); fold_env = e ? atoi(e) : 0; }
+  const int folded = fold_env && ks1 && a0.Cout == a1.Cout && a0.M == 4 * a1.M && a0.M % 512 == 0 ? 1 : 0;
+  const int grid = folded ? a0.blocks : a0.blocks + b1.blocks;
+#define NARROW_LAUNCH(K0, K1)                                                                                      \
+  do {                                                                                                             \
+    auto kern = conv_wgrad_narrow_stream_kernel<K0, K1, 3>;                                                        \
+    GANK_MAX_DYNAMIC_LDS(kern, NARROW_STREAM_LDS, "conv_wgrad_narrow_stream");                                     \
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), NARROW_STREAM_LDS, s, a0, b1, folded);               \
+  } while (0)
+  if (ks0 == 3 && (ks1 == 1 || ks1 == 0)) NARROW_LAUNCH(3, 1);
+  else if (ks0 == 1 && (ks1 == 3)) NARROW_LAUNCH(1, 3);
+  else if (ks0 == 3 && ks1 == 3) NARROW_LAUNCH(3, 3);
+  else NARROW_LAUNCH(1, 1);
+#undef NARROW_LAUNCH
+  GANK_LAUNCH_OK("conv_wgrad_narrow_stream");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // All-taps variant for 3x3 / stride 1 / power-of-two images / Cin%64==0 / Cout%64==0 -- the layers that
 // carry the wgrad FLOPs.  One block owns a 64(ci) x 64(co) tile for ALL 9 taps: per step it stages ONE
 // 8x8 patch of dy and the 10x10 halo of x, then every tap's A fragments are transposed reads of the same
@@ -1354,6 +1570,11 @@ int gank_wgrad_dispatch(WgradArgs a, hipStream_t s) {
   // narrow operands: pack (tap, channel) into <= 32 MFMA columns so the wide operand streams once
   const bool plain = (a.flags == 0) && a.Hx == a.H && a.Wx == a.W && a.Hdy == a.H && a.Wdy == a.W &&      // the packed kernels walk x and dy on one grid
                      (long)a.M * (a.Cin > a.Cout ? a.Cin : a.Cout) < (1L << 30);
+  if (rc < 0 && plain && wgrad_narrow_stream_ok(a.N, a.H, a.W, a.Cin, a.Cout, a.ks)) {
+    gank_prof_tag(1, a.ks == 3 ? "conv_wgrad_narrow_stream_kernel<3>" : "conv_wgrad_narrow_stream_kernel<1>");
+    const NarrowWgArgs q = narrow_args(a.x, a.dy, a.dw, a.dbias, a.N, a.H, a.W, a.Cout, a.scale);
+    rc = launch_wgrad_narrow_stream(q, a.ks, q, 0, s);
+  }
   if (rc < 0 && plain && a.Cin <= 4 && a.taps * a.Cin <= 32 && a.Cout % 8 == 0) rc = launch_wgrad_packed<true>(a, s);
   if (rc < 0 && plain && a.Cout <= 4 && a.taps * a.Cout <= 32 && a.Cin % 8 == 0) {
     rc = launch_wgrad_packed<false>(a, s);
@@ -1538,6 +1759,28 @@ extern "C" int gank_convpool3x3_wgrad(const void* x, const void* dy, float* dw, 
   hipLaunchKernelGGL(wgrad_fold4x4_kernel, dim3((unsigned)cdiv(plane4, 256)), dim3(256), 0, s, ws16, dw, plane4);
   GANK_LAUNCH_OK("convpool3x3_wgrad");
   return 0;
+}
+
+// Two 3-channel-input layers of different geometry in one launch (the streaming kernel above): the critic's D.Block.1.Conv1
+// (3x3 on the 32x32 image) and D.Block.1.Shortcut (1x1 on the pooled 16x16 image).  Falls back to two gank_conv2d_wgrad calls
+// when a layer is outside the kernel's shapes.
+extern "C" int gank_conv2d_wgrad_narrow_pair(const void* x0, const void* dy0, float* dw0, float* db0, int N0, int H0, int W0, int Cout0, int ks0,
+                                             const void* x1, const void* dy1, float* dw1, float* db1, int N1, int H1, int W1, int Cout1, int ks1,
+                                             float scale, void* stream) {
+  GANK_REQUIRE(x0 && dy0 && dw0 && x1 && dy1 && dw1, "conv2d_wgrad_narrow_pair: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (wgrad_narrow_stream_ok(N0, H0, W0, 3, Cout0, ks0) && wgrad_narrow_stream_ok(N1, H1, W1, 3, Cout1, ks1)) {
+    const NarrowWgArgs a0 = narrow_args(x0, dy0, dw0, db0, N0, H0, W0, Cout0, scale), a1 = narrow_args(x1, dy1, dw1, db1, N1, H1, W1, Cout1, scale);
+    const double m0 = (double)a0.M, m1 = (double)a1.M;
+    gank_prof_begin(1, 2.0 * (m0 * Cout0 * ks0 * ks0 * 3 + m1 * Cout1 * ks1 * ks1 * 3), s,
+                    2.0 * (m0 * (3 + Cout0) + m1 * (3 + Cout1)) + 4.0 * 3 * (ks0 * ks0 * Cout0 + ks1 * ks1 * Cout1));
+    gank_prof_tag(1, "conv_wgrad_narrow_stream_kernel (pair)");
+    const int rc = launch_wgrad_narrow_stream(a0, ks0, a1, ks1, s);
+    gank_prof_end(1, s);
+    return rc;
+  }
+  if (gank_conv2d_wgrad(x0, dy0, dw0, db0, nullptr, 0, N0, H0, W0, 3, Cout0, ks0, 0, scale, stream)) return 1;
+  return gank_conv2d_wgrad(x1, dy1, dw1, db1, nullptr, 0, N1, H1, W1, 3, Cout1, ks1, 0, scale, stream);
 }
 
 // Same-shape layers in one launch.  The critic's 8x8x128 residual blocks (D.Block.3/4, four 3x3 128->128 convs) have

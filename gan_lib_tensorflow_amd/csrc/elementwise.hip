@@ -613,6 +613,88 @@ __global__ __launch_bounds__(1024) void concat_label_bwd_kernel(const bf16* __re
   }
 }
 
+// concat + the fan-out of the down-sampling block that follows (its main path reads y, its pooled shortcut mean_pool2x2(y)):
+// one pass writes both.  The tiled half is constant over the pixels, so its 2x2 mean is the table row itself (exact); the
+// other half is pool2x2_kernel's arithmetic.  Thread = (pooled pixel, 8 channels).
+__global__ void concat_label_pool_fwd_kernel(const bf16* __restrict__ a, const bf16* __restrict__ T, const int* __restrict__ labels,
+                                             bf16* __restrict__ y, bf16* __restrict__ yp, long total8, int Hp, int Wp, int C1, int C2, int V) {
+  const int C = C1 + C2, cg = C >> 3, cg1 = C1 >> 3;
+  const int W = 2 * Wp;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % cg);
+    long p = i / cg;
+    const int pw = (int)(p % Wp); p /= Wp;
+    const int ph = (int)(p % Hp);
+    const int n = (int)(p / Hp);
+    const long hi = ((long)n * 2 * Hp + 2 * ph) * W + 2 * pw;          // top-left high-resolution pixel
+    bf16x8 v[4], m;
+    if (g < cg1) {
+      v[0] = *reinterpret_cast<const bf16x8*>(a + hi * C1 + g * 8);
+      v[1] = *reinterpret_cast<const bf16x8*>(a + (hi + 1) * C1 + g * 8);
+      v[2] = *reinterpret_cast<const bf16x8*>(a + (hi + W) * C1 + g * 8);
+      v[3] = *reinterpret_cast<const bf16x8*>(a + (hi + W + 1) * C1 + g * 8);
+#pragma unroll
+      for (int e = 0; e < 8; e++) m[e] = f2bf((bf2f(v[0][e]) + bf2f(v[2][e]) + bf2f(v[1][e]) + bf2f(v[3][e])) * 0.25f);   // order of tf.add_n at :120-121
+    } else {
+      const int l = labels[n];
+      const bool ok = l >= 0 && l < V;
+      m = *reinterpret_cast<const bf16x8*>(T + (long)(ok ? l : 0) * C2 + (g - cg1) * 8);
+      if (!ok) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) m[e] = f2bf(0.f);
+      }
+      v[0] = v[1] = v[2] = v[3] = m;
+    }
+    *reinterpret_cast<bf16x8*>(y + hi * C + g * 8) = v[0];
+    *reinterpret_cast<bf16x8*>(y + (hi + 1) * C + g * 8) = v[1];
+    *reinterpret_cast<bf16x8*>(y + (hi + W) * C + g * 8) = v[2];
+    *reinterpret_cast<bf16x8*>(y + (hi + W + 1) * C + g * 8) = v[3];
+    *reinterpret_cast<bf16x8*>(yp + (((long)n * Hp + ph) * Wp + pw) * C + g * 8) = m;
+  }
+}
+
+// backward of the pair: dy = g_main + 0.25 * unpool(g_pool) (unpool2x2_add's arithmetic) is never written -- its first C1
+// channels go straight to da, the tiled half is summed over the sample's pixels into de32 (block of 1024 threads per sample)
+__global__ __launch_bounds__(1024) void concat_label_unpool_bwd_kernel(const bf16* __restrict__ gm, const bf16* __restrict__ gp, bf16* __restrict__ da,
+                                                                      float* __restrict__ de, int H, int W, int C1, int C2) {
+  constexpr int NT = 1024;
+  const int n = blockIdx.x, C = C1 + C2, HW = H * W, Wp = W >> 1;
+  const int cg = C >> 3, cg1 = C1 >> 3, cg2 = C2 >> 3;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // thread -> a fixed 8-channel group (NT % cg == 0), pixels strided: the tiled half's partial sums stay in registers
+  const int g = threadIdx.x % cg, rl = threadIdx.x / cg, RL = NT / cg;
+  for (int r = rl; r < HW; r += RL) {
+    const int oh = r / W, ow = r - oh * W;
+    const long pi = ((long)n * (H >> 1) + (oh >> 1)) * Wp + (ow >> 1);
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(gp + pi * C + g * 8);
+    bf16x8 b;
+    if (gm) b = *reinterpret_cast<const bf16x8*>(gm + ((long)n * HW + r) * C + g * 8);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = bf2f(a[e]) * 0.25f + (gm ? bf2f(b[e]) : 0.f);
+    if (g < cg1) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = f2bf(v[e]);
+      *reinterpret_cast<bf16x8*>(da + ((long)n * HW + r) * C1 + g * 8) = o;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; e++) acc[e] += bf2f(f2bf(v[e]));       // the rounded value the separate launches summed
+    }
+  }
+  __shared__ float red[NT * 8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) red[threadIdx.x * 8 + e] = acc[e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C2; c += NT) {
+    const int gg = cg1 + (c >> 3);
+    float t = 0.f;
+    for (int l = 0; l < RL; l++) t += red[(l * cg + gg) * 8 + (c & 7)];
+    de[(long)n * C2 + c] = t;
+  }
+  (void)cg2;
+}
+
 // dT[l] = sum_{n: labels[n] = l} de32[n], then this block's 8 rows k of dW [D,C2] += bf16(emb)^T dT and of
 // demb [V,D] += dT W^T; block 0 also owns dbias.  Every block builds dT itself, 1024 threads = (column j, sample group g):
 // a thread requests its group's samples of column j in one burst, adds each into its group's table row of that sample's
@@ -709,6 +791,26 @@ extern "C" int gank_concat_label_bwd(const void* dy, void* da, float* de32, int 
   GANK_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && 1024 % (C2 / 8) == 0, "concat_label_bwd: unsupported channel counts %d,%d", C1, C2);
   hipLaunchKernelGGL(concat_label_bwd_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, (const bf16*)dy, (bf16*)da, de32, HW, C1, C2);
   GANK_LAUNCH_OK("concat_label_bwd");
+  return 0;
+}
+extern "C" int gank_concat_label_pool_fwd(const void* a, const void* T, const int32_t* labels, void* y, void* y_pooled, int N, int H, int W,
+                                          int C1, int C2, int V, void* stream) {
+  GANK_REQUIRE(a && T && labels && y && y_pooled && N > 0 && H > 0 && W > 0 && V > 0, "concat_label_pool_fwd: bad arguments");
+  GANK_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && H % 2 == 0 && W % 2 == 0, "concat_label_pool_fwd: channel counts must be multiples of 8, the size even");
+  const long total8 = (long)N * (H / 2) * (W / 2) * ((C1 + C2) / 8);
+  hipLaunchKernelGGL(concat_label_pool_fwd_kernel, grid1d(total8), dim3(256), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)T, labels,
+                     (bf16*)y, (bf16*)y_pooled, total8, H / 2, W / 2, C1, C2, V);
+  GANK_LAUNCH_OK("concat_label_pool_fwd");
+  return 0;
+}
+extern "C" int gank_concat_label_unpool_bwd(const void* g_main, const void* g_pooled, void* da, float* de32, int N, int H, int W, int C1, int C2,
+                                            void* stream) {
+  GANK_REQUIRE(g_pooled && da && de32 && N > 0 && H > 0 && W > 0, "concat_label_unpool_bwd: bad arguments");
+  GANK_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && H % 2 == 0 && W % 2 == 0 && 1024 % ((C1 + C2) / 8) == 0,
+               "concat_label_unpool_bwd: unsupported shape (%d + %d channels, %d x %d)", C1, C2, H, W);
+  hipLaunchKernelGGL(concat_label_unpool_bwd_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, (const bf16*)g_main, (const bf16*)g_pooled,
+                     (bf16*)da, de32, H, W, C1, C2);
+  GANK_LAUNCH_OK("concat_label_unpool_bwd");
   return 0;
 }
 extern "C" int gank_label_dense_bwd(const float* de32, const int32_t* labels, const float* table, const float* W, float* dW, float* dbias,

@@ -148,23 +148,42 @@ def _defer_wgrad(x, g, tgt, btgt, hw, k, flags):
     _deferred.setdefault((tuple(x.shape), tuple(g.shape), hw, k, flags), []).append((x, g, tgt, btgt))
 
 
+_deferred_narrow = []      # filter gradients of 3-channel-input layers (the image side of a critic): issued in pairs
+
+
+def _defer_narrow(x, g, tgt, btgt, hw, k):
+    _deferred_narrow.append((x, g, tgt, btgt, hw, k))
+
+
+def narrow_wgrad_ok(cin, cout, k, flags_free):
+    """a filter gradient the streaming 3-channel-input kernel takes (gank_conv2d_wgrad_narrow_pair)"""
+    return BATCH_SMALL_WGRADS and _Side.stream is None and flags_free and cin == 3 and k in (1, 3) and cout % 128 == 0
+
+
 def flush_wgrads():
     for (_, _, hw, k, flags), items in _deferred.items():
         K.conv2d_wgrad_batched(items, hw, k, flags, 1.0)
     _deferred.clear()
+    while len(_deferred_narrow) >= 2:
+        a, b = _deferred_narrow.pop(0), _deferred_narrow.pop(0)
+        K.conv2d_wgrad_narrow_pair(a, b)
+    for x, g, tgt, btgt, hw, k in _deferred_narrow:
+        K.conv2d_wgrad(x, g, tgt, hw, k, 0, 1.0, dbias=btgt)
+    _deferred_narrow.clear()
 
 
 def reset_deferred():
     """Drop every deferred / side-stream filter gradient (start of a backward pass, and after one that raised or whose
     capture aborted): stale (x, dy) pairs must never be flushed into another pass's gradient buffers."""
     _deferred.clear()
+    _deferred_narrow.clear()
     _Side.keep.clear()
 
 
 def join_wgrad():
     """Every filter gradient issued or deferred so far is complete / in stream order (before the optimiser and the
     SN backward)."""
-    if _deferred:
+    if _deferred or _deferred_narrow:
         flush_wgrads()
     if _Side.stream is not None and _Side.keep:
         torch.cuda.current_stream().wait_stream(_Side.stream)
@@ -297,6 +316,8 @@ class _Conv2d(Function):
                      and x.shape[0] * H * Wd <= 8192 and _Side.stream is None)
             if small:
                 _defer_wgrad(x, g, tgt, btgt, (H, Wd), k, wflags)
+            elif narrow_wgrad_ok(cin, cout, k, wflags == 0):
+                _defer_narrow(x, g, tgt, btgt, (H, Wd), k)       # paired with the block's other image-side layer (one launch)
             else:
                 # bias gradient rides on the dy stream
                 _on_side(lambda: K.conv2d_wgrad(x, g, tgt, (H, Wd), k, wflags, scale, dbias=btgt), x, g)
@@ -725,7 +746,10 @@ class _ForkPoolConv1x1(Function):
             db = None if bacc else btgt
         if ctx.needs_input_grad[1]:
             tgt, acc = _target(W)
-            _on_side(lambda: K.conv2d_wgrad(pooled, g, tgt, (h, w), 1, 0, 1.0, dbias=btgt), pooled, g)
+            if narrow_wgrad_ok(cin, cout, 1, True):
+                _defer_narrow(pooled, g, tgt, btgt, (h, w), 1)
+            else:
+                _on_side(lambda: K.conv2d_wgrad(pooled, g, tgt, (h, w), 1, 0, 1.0, dbias=btgt), pooled, g)
             dW = None if acc else tgt
         elif btgt is not None:
             K.colsum(g, btgt, 1.0)
@@ -859,26 +883,64 @@ class _ConcatLabel(Function):
         labels, table, W = ctx.saved_tensors
         bias = ctx.bias
         da, de32 = K.concat_label_bwd(_c(dy), ctx.c1)
-        need_t, need_w = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
-        need_b = bias is not None and ctx.needs_input_grad[4]
-        dt = dw = db = None
-        tt = wt = bt = None
-        if need_t:
-            tt, acc = _target(table)
-            dt = None if acc else tt
-        if need_w:
-            wt, acc = _target(W)
-            dw = None if acc else wt
-        if need_b:
-            bt, acc = _target(bias)
-            db = None if acc else bt
-        if need_t or need_w or need_b:
-            K.label_dense_bwd(de32, labels, table.detach(), W.detach(), wt, bt, tt)
+        dt, dw, db = _label_dense_grads(ctx, de32, labels, table, W, bias)
         return (da if ctx.needs_input_grad[0] else None), None, dt, dw, db
 
 
 def concat_label(a, labels, table, W, bias=None):
     return _ConcatLabel.apply(a, labels, table, W, bias)
+
+
+def _label_dense_grads(ctx, de32, labels, table, W, bias):
+    """the dense layer's / table's gradients from the per-sample sums of the tiled half (shared by both concat forms)"""
+    need_t, need_w = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+    need_b = bias is not None and ctx.needs_input_grad[4]
+    dt = dw = db = None
+    tt = wt = bt = None
+    if need_t:
+        tt, acc = _target(table)
+        dt = None if acc else tt
+    if need_w:
+        wt, acc = _target(W)
+        dw = None if acc else wt
+    if need_b:
+        bt, acc = _target(bias)
+        db = None if acc else bt
+    if need_t or need_w or need_b:
+        K.label_dense_bwd(de32, labels, table.detach(), W.detach(), wt, bt, tt)
+    return dt, dw, db
+
+
+class _ConcatLabelForkPool(Function):
+    """_ConcatLabel followed by the fan-out of a down-sampling residual block (fork_pool): -> (y, mean_pool2x2(y)) from one
+    forward launch (the tiled half's pool is the table row itself); backward: the two branch gradients meet in ONE launch that
+    writes da and the per-sample sums of the tiled half -- the unpool-add and the concat split never materialise dy."""
+
+    @staticmethod
+    def forward(ctx, a, labels, table, W, bias):
+        ctx.set_materialize_grads(False)
+        T = getattr(W, "_label_T", None)
+        if T is None:
+            T = K.label_dense_table(table.detach(), W.detach(), bias.detach() if bias is not None else None)
+        ctx.save_for_backward(labels, table, W)
+        ctx.bias = bias
+        ctx.c1 = a.shape[3]
+        return K.concat_label_pool_fwd(a, T, labels)
+
+    @staticmethod
+    def backward(ctx, gy, gp):
+        labels, table, W = ctx.saved_tensors
+        if gp is None:
+            da, de32 = K.concat_label_bwd(_c(gy), ctx.c1)
+        else:
+            da, de32 = K.concat_label_unpool_bwd(None if gy is None else _c(gy), _c(gp), ctx.c1)
+        dt, dw, db = _label_dense_grads(ctx, de32, labels, table, W, ctx.bias)
+        return (da if ctx.needs_input_grad[0] else None), None, dt, dw, db
+
+
+def concat_label_fork_pool(a, labels, table, W, bias=None):
+    """-> (concat(a, tile(T[labels])), its 2x2 mean): input pair of a down-sampling ResidualBlock(prefork=...)"""
+    return _ConcatLabelForkPool.apply(a, labels, table, W, bias)
 
 
 class _Embedding(Function):

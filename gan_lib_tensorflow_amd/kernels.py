@@ -238,6 +238,15 @@ def conv2d_wgrad_batched(items, hw, ksize, flags=0, scale=1.0):
                "conv2d_wgrad_batched")
 
 
+def conv2d_wgrad_narrow_pair(a, b):
+    """a, b = (x, dy, dw, dbias | None, (H, W), ksize): two filter gradients of 3-channel-input layers, ACCUMULATED, one launch"""
+    args = []
+    for x, dy, dw, db, hw, k in (a, b):
+        assert x.shape[3] == 3 and dw.numel() == k * k * 3 * dy.shape[3], (x.shape, dy.shape, dw.shape)
+        args += [_p(x, BF16, "x"), _p(dy, BF16, "dy"), _p(dw, F32, "dw"), _p(db, F32, "dbias"), x.shape[0], hw[0], hw[1], dy.shape[3], k]
+    _lib.check(lib().gank_conv2d_wgrad_narrow_pair(*args, 1.0, _stream()), "conv2d_wgrad_narrow_pair")
+
+
 def conv2d_general_fprop(x, wf, bias, out_hw, cout, ksize, stride, pad, flags=0):
     """any filter size / stride 1|2 / leading pad (gank_conv2d_general_fprop); x as stored [N,Hin,Win,Cin]"""
     n, hin, win, cin = x.shape
@@ -825,6 +834,27 @@ def concat_label_bwd(dy, c1):
     da = torch.empty((n, h, w, c1), dtype=BF16, device=dy.device)
     de = torch.empty((n, c - c1), dtype=F32, device=dy.device)
     _lib.check(lib().gank_concat_label_bwd(_p(dy, BF16, "dy"), _p(da), _p(de), n, h * w, c1, c - c1, _stream()), "concat_label_bwd")
+    return da, de
+
+
+def concat_label_pool_fwd(a, t, labels):
+    """-> (y [N,H,W,C1+C2], mean_pool2x2(y)) in one pass"""
+    n, h, w, c1 = a.shape
+    v, c2 = t.shape
+    y = torch.empty((n, h, w, c1 + c2), dtype=BF16, device=a.device)
+    yp = torch.empty((n, h // 2, w // 2, c1 + c2), dtype=BF16, device=a.device)
+    _lib.check(lib().gank_concat_label_pool_fwd(_p(a, BF16, "a"), _p(t, BF16, "T"), _p(labels, I32, "labels"), _p(y), _p(yp), n, h, w, c1, c2, v, _stream()),
+               "concat_label_pool_fwd")
+    return y, yp
+
+
+def concat_label_unpool_bwd(g_main, g_pooled, c1):
+    """gradients of concat_label_pool_fwd's two outputs -> (da bf16 [N,H,W,C1], de32 fp32 [N,C2])"""
+    n, hp, wp, c = g_pooled.shape
+    da = torch.empty((n, 2 * hp, 2 * wp, c1), dtype=BF16, device=g_pooled.device)
+    de = torch.empty((n, c - c1), dtype=F32, device=g_pooled.device)
+    _lib.check(lib().gank_concat_label_unpool_bwd(_p(g_main, BF16, "g_main"), _p(g_pooled, BF16, "g_pooled"), _p(da), _p(de), n, 2 * hp, 2 * wp, c1, c - c1,
+                                                  _stream()), "concat_label_unpool_bwd")
     return da, de
 
 

@@ -125,6 +125,12 @@ typedef struct gank_wgrad_item {
 } gank_wgrad_item;
 int gank_conv2d_wgrad_batched(const gank_wgrad_item* items, int count, int N, int H, int W, int Cin, int Cout,
                               int ksize, int flags, float scale, void* stream);
+/* Two filter gradients of 3-channel-input layers (ksize 1 or 3, SAME, stride 1; Cout % 128 == 0) with DIFFERENT geometry in
+ * one launch: the first critic block's Conv1 (3x3, 32x32) and Shortcut (1x1 on the pooled 16x16 image),
+ * gan_cifar_resnet.py:212-234.  Same arithmetic as two gank_conv2d_wgrad calls (which it falls back to). */
+int gank_conv2d_wgrad_narrow_pair(const void* x0, const void* dy0, float* dw0, float* db0, int N0, int H0, int W0, int Cout0, int ks0,
+                                  const void* x1, const void* dy1, float* dw1, float* db1, int N1, int H1, int W1, int Cout1, int ks1,
+                                  float scale, void* stream);
 
 /* ---- identity-shortcut residual blocks on 8x8 images, fused (SNGAN/gan_cifar_resnet.py:156-209, resample=None,
  * no normalisation: the critic's D.Block.3 / D.Block.4, :291-297) ---------------------------------------------------
@@ -391,6 +397,15 @@ int gank_label_dense_table(const float* table, const float* W, const float* sigm
 int gank_concat_label_fwd(const void* a, const void* T, const int32_t* labels, void* y, int N, int HW, int C1, int C2, int V,
                           void* stream);
 int gank_concat_label_bwd(const void* dy, void* da, float* de32, int N, int HW, int C1, int C2, void* stream);
+/* ... and the same with the fan-out of the down-sampling block behind the concat (gan_cifar_resnet.py:286-289: its main path
+ * reads y, its shortcut mean_pool2x2(y), resnet_block.py:53-64) folded in: fwd writes y [N,H,W,C1+C2] and y_pooled [N,H/2,W/2,.]
+ * in one pass (pool2x2's arithmetic on the first C1 channels, the table row itself on the tiled half); bwd takes the two
+ * branch gradients g_main [N,H,W,C] (or NULL) and g_pooled [N,H/2,W/2,C] and produces da / de32 of
+ * dy = g_main + 0.25 unpool(g_pooled) without writing dy. */
+int gank_concat_label_pool_fwd(const void* a, const void* T, const int32_t* labels, void* y, void* y_pooled, int N, int H, int W,
+                               int C1, int C2, int V, void* stream);
+int gank_concat_label_unpool_bwd(const void* g_main, const void* g_pooled, void* da, float* de32, int N, int H, int W, int C1, int C2,
+                                 void* stream);
 int gank_label_dense_bwd(const float* de32, const int32_t* labels, const float* table, const float* W, float* dW, float* dbias,
                          float* dtable, int N, int V, int D, int C2, void* stream);
 

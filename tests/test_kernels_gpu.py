@@ -1304,3 +1304,63 @@ def test_meanpool_conv1x1_gather_is_pool_then_conv(K):
         assert torch.equal(pooled.view(torch.int16), pooled_ref.view(torch.int16))
         assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16))
         assert relerr(y, R.conv2d_same(R.meanpool2x2(x), w) + b) < BF_TOL
+
+
+def test_narrow_input_filter_gradient_streaming_kernel(K):
+    """Filter gradients of 3-channel-input layers on the streaming kernel (the whole dy slice by LDS-DMA, the bias gradient as an
+    all-ones operand row): single layers through gank_conv2d_wgrad, the critic's pair (3x3 at 32x32 + 1x1 at 16x16) in one
+    launch, ragged pixel counts (M not a multiple of 512), accumulation into non-zero buffers."""
+    rng = np.random.default_rng(54)
+    cases = [(128, 32, 3, 128), (128, 16, 1, 128), (5, 32, 3, 256), (3, 16, 1, 128), (7, 8, 3, 128), (2, 4, 3, 128)]
+    data = []
+    for n, hw, k, cout in cases:
+        x, xt = bf(rng.normal(size=(n, hw, hw, 3)))
+        dy, dyt = bf(rng.normal(size=(n, hw, hw, cout)))
+        w0 = rng.normal(size=(k, k, 3, cout)).astype(np.float32)
+        b0 = rng.normal(size=cout).astype(np.float32)
+        if k == 3:
+            _, rdw, rdb = R.conv2d_same_grads(x, np.zeros((3, 3, 3, cout)), dy)
+        else:
+            rdw = np.einsum('nhwc,nhwo->co', x, dy).reshape(1, 1, 3, cout)
+            rdb = dy.sum((0, 1, 2))
+        dw, db = torch.tensor(w0).cuda(), torch.tensor(b0).cuda()
+        K.conv2d_wgrad(xt, dyt, dw, (hw, hw), k, 0, 1.0, dbias=db)
+        torch.cuda.synchronize()
+        assert relerr(dw - torch.tensor(w0).cuda(), rdw) < F32_FROM_BF_TOL, (n, hw, k, cout)
+        assert relerr(db - torch.tensor(b0).cuda(), rdb) < F32_FROM_BF_TOL, (n, hw, k, cout)
+        data.append((xt, dyt, hw, k, cout, rdw, rdb))
+    for i, j in ((0, 1), (1, 0), (2, 3), (4, 5)):
+        outs = []
+        items = []
+        for xt, dyt, hw, k, cout, rdw, rdb in (data[i], data[j]):
+            dw, db = torch.zeros((k, k, 3, cout), device="cuda"), torch.zeros(cout, device="cuda")
+            outs.append((dw, db, rdw, rdb))
+            items.append((xt, dyt, dw, db, (hw, hw), k))
+        K.conv2d_wgrad_narrow_pair(items[0], items[1])
+        torch.cuda.synchronize()
+        for dw, db, rdw, rdb in outs:
+            assert relerr(dw, rdw) < F32_FROM_BF_TOL and relerr(db, rdb) < F32_FROM_BF_TOL, (i, j)
+
+
+def test_concat_label_with_the_next_blocks_fan_out(K):
+    """concat + fork_pool of the down-sampling block behind it as one launch each way: the bytes of the separate launches
+    (concat_label_fwd, pool2x2; unpool2x2_add, concat_label_bwd), the per-sample sums up to fp32 summation order."""
+    rng = np.random.default_rng(55)
+    n, c1, c2, v = 6, 128, 128, 10
+    a, at = bf(rng.normal(size=(n, 16, 16, c1)))
+    T, Tt = bf(rng.normal(size=(v, c2)))
+    lt = torch.tensor(rng.integers(0, v, n), dtype=torch.int32).cuda()
+    y, yp = K.concat_label_pool_fwd(at, Tt, lt)
+    y_ref = K.concat_label_fwd(at, Tt, lt)
+    assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16))
+    assert torch.equal(yp.view(torch.int16), K.pool2x2(y_ref, 0.25).view(torch.int16))
+    gm, gmt = bf(rng.normal(size=(n, 16, 16, c1 + c2)))
+    gp, gpt = bf(rng.normal(size=(n, 8, 8, c1 + c2)))
+    da, de = K.concat_label_unpool_bwd(gmt, gpt, c1)
+    da_ref, de_ref = K.concat_label_bwd(K.unpool2x2_add(gpt, gmt, 0.25), c1)
+    torch.cuda.synchronize()
+    assert torch.equal(da.view(torch.int16), da_ref.view(torch.int16))
+    assert relerr(de, de_ref.double().cpu().numpy()) < 1e-6
+    da2, de2 = K.concat_label_unpool_bwd(None, gpt, c1)
+    da2_ref, de2_ref = K.concat_label_bwd(K.unpool2x2_add(gpt, None, 0.25), c1)
+    assert torch.equal(da2.view(torch.int16), da2_ref.view(torch.int16)) and relerr(de2, de2_ref.double().cpu().numpy()) < 1e-6
