@@ -134,6 +134,11 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling (the reference's semantics, gan_cifar_resnet.py:324,330): the global batch of 64 is split over the ranks")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="one GPU, but through the data-parallel path: a world-size-1 RCCL group, bucketed generator gradients on the "
+                         "communication stream, the all-reduces captured inside the update graphs -- what N > 1 ranks run, minus the wire")
+    ap.add_argument("--grad-wire", default=None, choices=[None, "bf16"], help="16-bit gradient buckets on the wire (data parallel)")
+    ap.add_argument("--no-capture-collectives", action="store_true", help="data parallel: collectives eagerly between graph replays (the round-2 form)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -159,14 +164,14 @@ def main():
     from gan_lib_tensorflow_amd import kernels as K
     from gan_lib_tensorflow_amd import parallel
     from gan_lib_tensorflow_amd.SNGAN import gan_cifar_resnet as S
-    pg, rank, world = parallel.init_from_env(backend=args.backend, device=device)   # nccl = RCCL over xGMI; None for 1 rank
+    pg, rank, world = parallel.init_from_env(backend=args.backend, device=device, force=args.force_dp)   # nccl = RCCL over xGMI; None for 1 rank
 
     per_gpu = S.BATCH_SIZE // world if args.strong else S.BATCH_SIZE
     assert per_gpu >= 2 and per_gpu * world == (S.BATCH_SIZE if args.strong else S.BATCH_SIZE * world), "batch 64 must split evenly"
     # allow_eager_fallback: a capture failure on SOME ranks must not leave the others waiting in a collective -- every rank
     # finishes its warm-up, then all of them agree (MIN over ranks) whether to go on
     tr = S.SNGANTrainer(batch_size=per_gpu, device=device, seed=0, use_graphs=not args.no_graphs, process_group=pg,
-                        allow_eager_fallback=True)
+                        allow_eager_fallback=True, capture_collectives=not args.no_capture_collectives, grad_wire_dtype=args.grad_wire)
     feed = S.synthetic_batches(per_gpu, device, seed=rank)
 
     def barrier():
@@ -291,7 +296,9 @@ def main():
             "config": {"workload": "SNGAN ResNet CIFAR-10 32x32 bs=64 hinge: 1 G update (2x64 fakes) + 5 D updates (64 real + 64 fake) per step",
                        "global_batch": per_gpu * world, "per_gpu_batch": per_gpu, "parallelism": f"dp{world}",
                        "images_per_step": "5 critic batches x 64 real images per GPU",
-                       "graphs": graphs_used, "finite": finite},
+                       "graphs": graphs_used, "finite": finite,
+                       "data_parallel_path": bool(pg is not None), "collectives_in_graphs": bool(pg is not None and tr.capture_collectives),
+                       "grad_wire": args.grad_wire or "fp32"},
             # reference algorithm (9-tap upsample convs, SURVEY 8d: 13.77 GFLOP per real image) and the algorithm as run
             # (UpsampleConv 3x3 as a 4-tap-per-output transposed conv; conv FLOPs counted by the kernels themselves)
             "whole_step_mfma_frac": round(value / world * GFLOP_PER_REAL_IMAGE * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
@@ -316,7 +323,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if pg is not None:
         import torch.distributed as dist
         dist.barrier(group=pg)
         dist.destroy_process_group()

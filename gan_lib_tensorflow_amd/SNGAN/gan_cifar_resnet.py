@@ -261,9 +261,13 @@ class SNGANTrainer:
     losses, :436,:498)."""
 
     def __init__(self, batch_size=BATCH_SIZE, device="cuda", seed=0, use_graphs=True, process_group=None, state=None,
-                 allow_eager_fallback=False):
+                 allow_eager_fallback=False, capture_collectives=True, grad_wire_dtype=None):
         """allow_eager_fallback: a failed hipGraph capture degrades to eager execution (with a message on stderr) instead of
-        raising -- a run that asked for graphs never silently becomes a 10x slower eager run otherwise."""
+        raising -- a run that asked for graphs never silently becomes a 10x slower eager run otherwise.
+        capture_collectives: under data parallel the RCCL all-reduces are captured INSIDE the update graphs (one graph per
+        critic update, one for the whole bucketed generator update) instead of being issued eagerly between graph replays;
+        a capture that fails falls back to the split form (graph / eager collective / graph) with a message.
+        grad_wire_dtype: 'bf16' sends the gradient buckets over xGMI in the 16-bit activation dtype (half the bytes)."""
         self.device = torch.device(device)
         self.allow_eager_fallback = allow_eager_fallback
         self.batch = batch_size
@@ -275,6 +279,9 @@ class SNGANTrainer:
             import torch.distributed as dist
             self.world, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
         self.use_graphs = use_graphs
+        self.dp = process_group is not None          # the data-parallel path (also for a world-size-1 group: rehearsal / --force-dp)
+        self.capture_collectives = capture_collectives
+        self.grad_wire_dtype = K.BF16 if grad_wire_dtype in ('bf16', 'fp16', '16') else None
         self._g_buckets = None
         # world > 1: the generator's gradients leave in buckets beside the backward pass; `bucketed` forces that path for a
         # single rank too (tests: same arithmetic as the one-piece update)
@@ -570,7 +577,7 @@ class SNGANTrainer:
 
     def _g_step_bucketed(self):
         if self._g_buckets is None:
-            self._g_buckets = parallel.GradBuckets(self.g_flat['grads'], parallel.bucket_ranges(self.g_flat, G_BUCKETS), self.pg)
+            self._g_buckets = parallel.GradBuckets(self.g_flat['grads'], parallel.bucket_ranges(self.g_flat, G_BUCKETS), self.pg, self.grad_wire_dtype)
         gb = self._g_buckets
         phases, after = self._g_phases()
         last = len(phases) - 1
@@ -595,6 +602,21 @@ class SNGANTrainer:
                     between(i)
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
+            if self.capture_collectives:
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with _capture(g):           # every phase AND the bucket all-reduces (forked onto the communication stream): ONE graph
+                        for i, ph in enumerate(phases):
+                            ph()
+                            between(i)
+                    self._graphs['g_seg'] = g
+                    return
+                except Exception as e:  # noqa: BLE001
+                    import sys
+                    torch.cuda.synchronize()
+                    print(f"[gank] capturing the bucketed generator update with its collectives failed ({e}); one graph per phase, "
+                          f"collectives between them", file=sys.stderr)
+                    self.capture_collectives = False
             try:
                 pool = torch.cuda.graph_pool_handle()
                 graphs = []
@@ -614,9 +636,12 @@ class SNGANTrainer:
                 self._capture_failed('bucketed generator update', e)
             return
         self._ensure_clean(self.g_flat)
-        for i, g in enumerate(self._graphs['g_seg']):
-            g.replay()
-            between(i)
+        if isinstance(self._graphs['g_seg'], torch.cuda.CUDAGraph):
+            self._graphs['g_seg'].replay()
+        else:
+            for i, g in enumerate(self._graphs['g_seg']):
+                g.replay()
+                between(i)
         self.g_flat["clean"] = True
 
     def _capture_failed(self, what, e):
@@ -631,8 +656,8 @@ class SNGANTrainer:
         self.use_graphs = False
 
     def _allreduce(self, flat):
-        if self.world > 1:
-            parallel.allreduce_sum_(flat["grads"], self.pg)
+        if self.dp:
+            parallel.allreduce_sum_(flat["grads"], self.pg, self.grad_wire_dtype, single_rank_too=True)
 
     def _run(self, key, fwd_bwd, opt, flat):
         """fwd+bwd (graph) -> [RCCL all-reduce] -> Adam (graph)."""
@@ -653,17 +678,31 @@ class SNGANTrainer:
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             try:
-                # thread_local: the RCCL watchdog thread polls events concurrently when world > 1
+                # thread_local: the RCCL watchdog thread polls events concurrently under data parallel
+                whole = not self.dp or self.capture_collectives
+                if whole:
+                    try:
+                        g1 = torch.cuda.CUDAGraph()
+                        with _capture(g1):       # forward + backward [+ RCCL all-reduce] + optimiser: ONE graph
+                            fwd_bwd()
+                            self._allreduce(flat)
+                            opt.apply()
+                        self._graphs[key] = (g1, None)
+                        return
+                    except Exception as e:  # noqa: BLE001
+                        if not self.dp:
+                            raise
+                        import sys
+                        torch.cuda.synchronize()
+                        print(f"[gank] capturing the all-reduce inside the {key!r} update graph failed ({e}); "
+                              f"the collective stays between two graphs", file=sys.stderr)
+                        self.capture_collectives = False
                 g1 = torch.cuda.CUDAGraph()
                 with _capture(g1):
                     fwd_bwd()
-                    if self.world == 1:
-                        opt.apply()
-                g2 = None
-                if self.world > 1:
-                    g2 = torch.cuda.CUDAGraph()
-                    with _capture(g2):
-                        opt.apply()
+                g2 = torch.cuda.CUDAGraph()
+                with _capture(g2):
+                    opt.apply()
                 self._graphs[key] = (g1, g2)
             except Exception as e:  # noqa: BLE001
                 self._capture_failed(f'{key!r} update', e)

@@ -757,8 +757,9 @@ def to_bf16(x):
     return y
 
 
-def to_f32(x):
-    y = torch.empty(x.shape, dtype=F32, device=x.device)
+def to_f32(x, out=None):
+    y = torch.empty(x.shape, dtype=F32, device=x.device) if out is None else out
+    assert y.numel() == x.numel() and y.dtype == F32
     _lib.check(lib().gank_cast_bf16_f32(_p(x, BF16, "x"), _p(y), x.numel(), _stream()), "cast_bf16_f32")
     return y
 

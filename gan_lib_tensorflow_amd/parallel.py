@@ -14,13 +14,24 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None, device=None):
+def init_from_env(backend=None, device=None, force=False):
     """Rendezvous from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run).  Returns
-    (process_group | None, rank, world)."""
+    (process_group | None, rank, world).  force: a single process still gets a (world-size-1) group, so the data-parallel
+    code path -- bucketed gradients, collectives inside the captured updates -- can be run and timed on one GPU."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world == 1:
+    if world == 1 and not force:
         return None, 0, 1
+    if world == 1:
+        import socket
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+            s.close()
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -30,9 +41,18 @@ def init_from_env(backend=None, device=None):
     return dist.group.WORLD, rank, world
 
 
-def allreduce_sum_(flat_grads, group=None):
-    """In-place SUM of a flat gradient buffer over the ranks of `group` (no-op for a single rank)."""
-    if group is None or dist.get_world_size(group) == 1:
+def allreduce_sum_(flat_grads, group=None, wire_dtype=None, single_rank_too=False):
+    """In-place SUM of a flat gradient buffer over the ranks of `group` (no-op for a single rank unless single_rank_too:
+    the world-size-1 rehearsal of the data-parallel path issues the collective all the same).
+    wire_dtype = the 16-bit activation dtype: the buffer travels (and is summed by RCCL) in 16 bits -- half the bytes on the
+    xGMI links for two cast launches; the fp32 buffer is rewritten from the summed copy."""
+    if group is None or (dist.get_world_size(group) == 1 and not single_rank_too):
+        return flat_grads
+    if wire_dtype is not None and flat_grads.is_cuda:
+        from . import kernels as K
+        wire = K.to_bf16(flat_grads)
+        dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=group)
+        K.to_f32(wire, out=flat_grads)
         return flat_grads
     dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
     return flat_grads
@@ -75,20 +95,23 @@ class GradBuckets:
     The reference sums its tower gradients in one tf.add_n at the end of the graph (SNGAN/gan_cifar_resnet.py:523-526);
     bucketing changes the schedule, not the arithmetic: every element is summed over the same ranks exactly once."""
 
-    def __init__(self, flat_grads, ranges, group):
+    def __init__(self, flat_grads, ranges, group, wire_dtype=None):
         self.group = group
         self.buckets = [flat_grads[a:b] for a, b in ranges]
         self.cuda = flat_grads.is_cuda
         self.comm = torch.cuda.Stream(device=flat_grads.device) if self.cuda else None
+        self.wire_dtype = wire_dtype if self.cuda else None      # 16-bit buckets on the wire (allreduce_sum_)
 
     def launch(self, k):
-        """all-reduce bucket k; call right after the last kernel that writes it was enqueued on the current stream"""
+        """all-reduce bucket k; call right after the last kernel that writes it was enqueued on the current stream.
+        Under hipGraph capture the fork onto the communication stream and the join become edges of the captured graph: the
+        collective is a node beside the next segment's kernels."""
         if self.group is None:
             return
         if self.cuda:
             self.comm.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm):
-                dist.all_reduce(self.buckets[k], op=dist.ReduceOp.SUM, group=self.group)
+                allreduce_sum_(self.buckets[k], self.group, self.wire_dtype, single_rank_too=True)
         else:
             dist.all_reduce(self.buckets[k], op=dist.ReduceOp.SUM, group=self.group)
 

@@ -562,23 +562,51 @@ def test_bucketed_generator_update_through_rccl_matches_the_one_piece_update(gpu
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         results = {}
-        for name, pg, graphs in (("plain", None, True), ("bucketed", dist.group.WORLD, True), ("bucketed_eager", dist.group.WORLD, False)):
-            tr = S.SNGANTrainer(batch_size=8, seed=17, use_graphs=graphs, process_group=pg)
+        # the exchange itself under capture: a replayed all-reduce node returns what the eager collective returns, bit for bit
+        buf = torch.randn(4099, device="cuda")
+        want = buf.clone()
+        dist.all_reduce(want)
+        cap = buf.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            dist.all_reduce(cap.clone())                       # warm-up outside the capture (communicator setup)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            dist.all_reduce(cap)
+        cap.copy_(buf)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(cap, want)
+        for name, pg, graphs, kw in (("plain", None, True, {}), ("bucketed", dist.group.WORLD, True, {}),
+                                     ("bucketed_split", dist.group.WORLD, True, {"capture_collectives": False}),
+                                     ("bucketed_wire16", dist.group.WORLD, True, {"grad_wire_dtype": "bf16"}),
+                                     ("bucketed_eager", dist.group.WORLD, False, {})):
+            tr = S.SNGANTrainer(batch_size=8, seed=17, use_graphs=graphs, process_group=pg, **kw)
             assert tr.bucketed == (pg is not None)
             feed = S.synthetic_batches(8, "cuda", seed=5)
             for _ in range(4):             # iterations 1.. run the generator update: eager, capture, two replays
                 tr.train_iteration(feed)
             torch.cuda.synchronize()
             assert tr.use_graphs == graphs
-            if name == "bucketed":
+            if name in ("bucketed", "bucketed_wire16"):
+                # the collectives are nodes of the captured updates: ONE graph for the critic update (no optimiser graph behind
+                # an eager all-reduce), ONE for the generator update with its four bucket all-reduces on the communication stream
+                assert tr.capture_collectives and isinstance(tr._graphs['g_seg'], torch.cuda.CUDAGraph) and 'g' not in tr._graphs
+                assert tr._graphs['d_pre'][1] is None
+            if name == "bucketed_split":
                 assert len(tr._graphs['g_seg']) == 6 and 'g' not in tr._graphs        # forward, 4 segments, optimiser
+                assert tr._graphs['d_pre'][1] is not None                             # graph / eager all-reduce / graph
+            if name.startswith("bucketed"):
                 assert [b.numel() for b in tr._g_buckets.buckets] == [b - a for a, b in
                                                                       __import__('gan_lib_tensorflow_amd').parallel.bucket_ranges(tr.g_flat, S.G_BUCKETS)]
             results[name] = (tr.g_flat["params"].clone(), tr.d_flat["params"].clone(), float(tr.g_loss), tr.rng_state.clone(), int(tr.g_opt.t))
             del tr, feed
             gc.collect()
         ref = results["plain"]
-        for name in ("bucketed", "bucketed_eager"):
+        for name in ("bucketed", "bucketed_split", "bucketed_wire16", "bucketed_eager"):
             got = results[name]
             assert torch.equal(got[3], ref[3]) and got[4] == ref[4] == 3
             # four iterations of TF-Adam (beta1 = 0) on trajectories that differ only by atomics ordering: see
