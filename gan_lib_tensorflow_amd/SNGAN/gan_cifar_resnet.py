@@ -221,7 +221,7 @@ def lr_decay(iteration):
 class AdamTF:
     """tf.train.AdamOptimizer(beta1=0., beta2=0.9) over one flat buffer (:521-526)."""
 
-    def __init__(self, flat, iteration, lr=LR, beta1=0., beta2=0.9, eps=1e-8, grad_scale=1.0, decay=DECAY):
+    def __init__(self, flat, iteration, lr=LR, beta1=0., beta2=0.9, eps=1e-8, grad_scale=1.0, decay=DECAY, health=False):
         """All step state is device resident (hyper-parameters, step count t, the shared `iteration`
         counter that drives the LR decay), so a captured update replays with no host traffic."""
         self.flat, self.iteration = flat, iteration
@@ -229,12 +229,14 @@ class AdamTF:
         self.hp = torch.tensor([lr, beta1, beta2, eps, grad_scale, 1.0 if decay else 0.0, 0.0, 0.0],
                                dtype=torch.float32, device=dev)
         self.t = torch.zeros(1, dtype=torch.int64, device=dev)
+        # {non-finite gradients, zero gradients} seen so far (loss-scaled runs: overflow / underflow watch); None = not counted
+        self.health = torch.zeros(2, dtype=torch.int64, device=dev) if health else None
 
     def apply(self):
         """One launch: the update, the step count, and the gradient buffer (with its scratch half) cleared for the next
         backward pass -- `flat['clean']` tells the trainer that no fill is needed."""
         f = self.flat
-        K.adam_tf(f["params"], f["grads_all"], f["m"], f["v"], self.hp, self.t, self.iteration, zero_grads=True)
+        K.adam_tf(f["params"], f["grads_all"], f["m"], f["v"], self.hp, self.t, self.iteration, zero_grads=True, health=self.health)
         f["clean"] = True
 
 
@@ -261,13 +263,16 @@ class SNGANTrainer:
     losses, :436,:498)."""
 
     def __init__(self, batch_size=BATCH_SIZE, device="cuda", seed=0, use_graphs=True, process_group=None, state=None,
-                 allow_eager_fallback=False, capture_collectives=True, grad_wire_dtype=None):
+                 allow_eager_fallback=False, capture_collectives=True, grad_wire_dtype=None, loss_scale=None):
         """allow_eager_fallback: a failed hipGraph capture degrades to eager execution (with a message on stderr) instead of
         raising -- a run that asked for graphs never silently becomes a 10x slower eager run otherwise.
         capture_collectives: under data parallel the RCCL all-reduces are captured INSIDE the update graphs (one graph per
         critic update, one for the whole bucketed generator update) instead of being issued eagerly between graph replays;
         a capture that fails falls back to the split form (graph / eager collective / graph) with a message.
-        grad_wire_dtype: 'bf16' sends the gradient buckets over xGMI in the 16-bit activation dtype (half the bytes)."""
+        grad_wire_dtype: 'bf16' sends the gradient buckets over xGMI in the 16-bit activation dtype (half the bytes).
+        loss_scale: static loss scale, a power of two (default: 1 for bfloat16 buffers, 1024 for the fp16 build, whose activation
+        gradients would otherwise underflow: hinge d loss / d logit is +-1/n and shrinks from there).  The loss nodes multiply
+        d loss / d logits by it, the optimisers divide it out (grad_scale) and count non-finite / zero gradients (`health()`)."""
         self.device = torch.device(device)
         self.allow_eager_fallback = allow_eager_fallback
         self.batch = batch_size
@@ -279,6 +284,10 @@ class SNGANTrainer:
             import torch.distributed as dist
             self.world, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
         self.use_graphs = use_graphs
+        if loss_scale is None:
+            loss_scale = 1024.0 if K.BF16 is torch.float16 else 1.0
+        self.loss_scale = float(loss_scale)
+        assert self.loss_scale > 0 and math.log2(self.loss_scale) == int(math.log2(self.loss_scale)), "loss_scale must be a power of two"
         self.dp = process_group is not None          # the data-parallel path (also for a world-size-1 group: rehearsal / --force-dp)
         self.capture_collectives = capture_collectives
         self.grad_wire_dtype = K.BF16 if grad_wire_dtype in ('bf16', 'fp16', '16') else None
@@ -320,8 +329,9 @@ class SNGANTrainer:
                          if k.startswith('Generator/') and (k.endswith('/Filters') or k.endswith('/W'))]
         self._refresh_g_prep()
         self.iteration_dev = torch.zeros(1, dtype=torch.int64, device=self.device)   # `_iteration` feed (:320)
-        self.g_opt = AdamTF(self.g_flat, self.iteration_dev, grad_scale=1.0 / self.world)
-        self.d_opt = AdamTF(self.d_flat, self.iteration_dev, grad_scale=1.0 / self.world)
+        scaled = self.loss_scale != 1.0
+        self.g_opt = AdamTF(self.g_flat, self.iteration_dev, grad_scale=1.0 / (self.world * self.loss_scale), health=scaled)
+        self.d_opt = AdamTF(self.d_flat, self.iteration_dev, grad_scale=1.0 / (self.world * self.loss_scale), health=scaled)
         # static input buffers (graph replays read these addresses)
         self.real_u8 = torch.zeros((b, OUTPUT_DIM), dtype=torch.uint8, device=self.device)
         self.real_labels = torch.zeros(b, dtype=torch.int32, device=self.device)
@@ -389,6 +399,12 @@ class SNGANTrainer:
         self._refresh_g_prep()
         self._graphs.clear()
 
+    def health(self):
+        """{'G': (non-finite, zero), 'D': (...)} gradient counts since the trainer was built (loss-scaled runs only; else None)"""
+        if self.g_opt.health is None:
+            return None
+        return {'G': tuple(int(v) for v in self.g_opt.health.tolist()), 'D': tuple(int(v) for v in self.d_opt.health.tolist())}
+
     def _g_apply(self):
         self.g_opt.apply()
         self._refresh_g_prep()
@@ -424,7 +440,7 @@ class SNGANTrainer:
         with _sn.grad_scratch(self.d_flat["scratch"]):        # zeroed by zero_grads above
             if FUSED_HEAD:
                 loss, _ = Discriminator(both, both_labels, update_collection=None,
-                                        loss_head=lambda f, w, bb: Fn.hinge_d_head(f, w, bb, b, out=self.d_loss))
+                                        loss_head=lambda f, w, bb: Fn.hinge_d_head(f, w, bb, b, out=self.d_loss, loss_scale=self.loss_scale))
                 logits = loss.logits
             else:
                 logits, _ = Discriminator(both, both_labels, update_collection=None)
@@ -441,7 +457,7 @@ class SNGANTrainer:
         with _sn.grad_scratch(self.d_flat["scratch"]):        # zeroed by zero_grads above
             if FUSED_HEAD:
                 loss, _ = Discriminator(self.both, self.both_labels, update_collection=None,
-                                        loss_head=lambda f, w, b: Fn.hinge_d_head(f, w, b, self.batch, out=self.d_loss))
+                                        loss_head=lambda f, w, b: Fn.hinge_d_head(f, w, b, self.batch, out=self.d_loss, loss_scale=self.loss_scale))
                 logits = loss.logits
             else:
                 logits, _ = Discriminator(self.both, self.both_labels, update_collection=None)
@@ -493,7 +509,7 @@ class SNGANTrainer:
         try:
             if FUSED_HEAD:
                 loss, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS,
-                                        loss_head=lambda f, w, b: Fn.hinge_g_head(f, w, b, out=self.g_loss))
+                                        loss_head=lambda f, w, b: Fn.hinge_g_head(f, w, b, out=self.g_loss, loss_scale=self.loss_scale))
                 logits = loss.logits
             else:
                 logits, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS)
@@ -511,7 +527,7 @@ class SNGANTrainer:
         Fn.BATCH_SMALL_WGRADS = BATCH_SMALL_WGRADS
         try:
             # the gradient seed is a persistent tensor: loss.backward() alone launches a ones_like fill per update
-            loss.backward(gradient=Fn.unit_seed(loss))
+            loss.backward(gradient=Fn.grad_seed(loss, self.loss_scale))
             Fn.join_wgrad()
             Fn.join_beside_backward()
         finally:
@@ -540,7 +556,7 @@ class SNGANTrainer:
             try:
                 if FUSED_HEAD:
                     loss, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS,
-                                            loss_head=lambda f, w, b: Fn.hinge_g_head(f, w, b, out=self.g_loss))
+                                            loss_head=lambda f, w, b: Fn.hinge_g_head(f, w, b, out=self.g_loss, loss_scale=self.loss_scale))
                 else:
                     logits, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS)
                     loss = Fn.hinge_g_loss(logits, out=self.g_loss)
@@ -549,7 +565,7 @@ class SNGANTrainer:
                     p.requires_grad_(True)
             cuts = [t for tag, t in marks if tag in ('G.Block.1', 'G.Block.2', 'G.Block.3')]
             assert len(cuts) == nb - 1, [tag for tag, _ in marks]
-            st['top'], st['gtop'], st['cuts'] = loss, Fn.unit_seed(loss), cuts
+            st['top'], st['gtop'], st['cuts'] = loss, Fn.grad_seed(loss, self.loss_scale), cuts
 
         def segment(k):          # k = nb-1 (next to the loss) .. 0 (the network input side)
             def run():

@@ -122,6 +122,7 @@ PROTOTYPES = {
     "gank_embedding_fwd": [P, P, P, I, I, I, P],
     "gank_embedding_bwd": [P, P, P, I, I, I, P],
     "gank_critic_head_hinge": [P, P, P, P, P, P, P, P, I, I, I, I, P],
+    "gank_critic_head_hinge_scaled": [P, P, P, P, P, P, P, P, I, I, I, I, F, P],
     "gank_hinge_d_loss": [P, P, P, P, I, I, P],
     "gank_hinge_g_loss": [P, P, P, P, I, P],
     "gank_wgan_d_loss": [P, P, P, P, I, I, P],
@@ -145,6 +146,7 @@ PROTOTYPES = {
     "gank_dropout_fwd": [P, P, P, L, F, P, P],
     "gank_dropout_bwd": [P, P, P, L, F, P],
     "gank_adam_tf": [P, P, P, P, P, P, P, L, L, P],
+    "gank_adam_tf_health": [P, P, P, P, P, P, P, L, L, P, P],
     "gank_counter_add": [P, C.c_int64, P],
     "gank_preprocess_real": [P, P, P, I, P],
     "gank_rng_normal_bf16": [P, L, P, P],

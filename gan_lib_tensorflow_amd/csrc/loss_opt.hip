@@ -116,7 +116,7 @@ extern "C" int gank_softmax_xent(const void* logits, const int32_t* labels, floa
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void critic_head_hinge_kernel(const bf16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                                 bf16* __restrict__ logits, float* __restrict__ loss, bf16* __restrict__ dx,
-                                                                float* __restrict__ w_grad, float* __restrict__ b_grad, int M, int K, int n_real, int mode) {
+                                                                float* __restrict__ w_grad, float* __restrict__ b_grad, int M, int K, int n_real, int mode, float loss_scale) {
   extern __shared__ float sm[];          // dl[M] | w[K] | red[32] | part[8][K]
   float* s_dl = sm;
   float* s_w = sm + M;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(1024) void critic_head_hinge_kernel(const bf16* __r
       if (mode == 1) { l = -v / (float)M; d = -1.f / (float)M; }
       else if (m < n_real) { const float u = 1.f - v; l = fmaxf(u, 0.f) / (float)n_real; d = u > 0.f ? -1.f / (float)n_real : 0.f; }
       else { const float u = 1.f + v; l = fmaxf(u, 0.f) / (float)n_fake; d = u > 0.f ? 1.f / (float)n_fake : 0.f; }
-      s_dl[m] = bf2f(f2bf(d));
+      s_dl[m] = bf2f(f2bf(d * loss_scale));      // loss_scale: a power of two (static loss scaling of the fp16 build), undone by the optimiser's grad_scale
       acc += l;
     }
     }
@@ -201,15 +201,20 @@ __global__ __launch_bounds__(1024) void critic_head_hinge_kernel(const bf16* __r
     if (tid == 0) b_grad[0] += t;
   }
 }
-extern "C" int gank_critic_head_hinge(const void* x, const float* w, const float* b, void* logits, float* loss, void* dx, float* w_grad,
-                                      float* b_grad, int M, int K, int n_real, int mode, void* stream) {
+extern "C" int gank_critic_head_hinge_scaled(const void* x, const float* w, const float* b, void* logits, float* loss, void* dx, float* w_grad,
+                                             float* b_grad, int M, int K, int n_real, int mode, float loss_scale, void* stream) {
   GANK_REQUIRE(x && w && logits && loss && M > 0 && K > 0 && (mode == 0 || mode == 1), "critic_head_hinge: bad arguments");
   GANK_REQUIRE(mode == 1 || (n_real > 0 && n_real < M), "critic_head_hinge: n_real must split the batch");
+  GANK_REQUIRE(loss_scale > 0.f, "critic_head_hinge: loss_scale must be positive");
   GANK_REQUIRE((size_t)(M + 9 * K + 32) * sizeof(float) <= 60000, "critic_head_hinge: M + 9 K too large for one block");
   hipLaunchKernelGGL(critic_head_hinge_kernel, dim3(1), dim3(1024), (size_t)(M + 9 * K + 32) * sizeof(float), (hipStream_t)stream, (const bf16*)x, w, b,
-                     (bf16*)logits, loss, (bf16*)dx, w_grad, b_grad, M, K, n_real, mode);
+                     (bf16*)logits, loss, (bf16*)dx, w_grad, b_grad, M, K, n_real, mode, loss_scale);
   GANK_LAUNCH_OK("critic_head_hinge");
   return 0;
+}
+extern "C" int gank_critic_head_hinge(const void* x, const float* w, const float* b, void* logits, float* loss, void* dx, float* w_grad,
+                                      float* b_grad, int M, int K, int n_real, int mode, void* stream) {
+  return gank_critic_head_hinge_scaled(x, w, b, logits, loss, dx, w_grad, b_grad, M, K, n_real, mode, 1.f, stream);
 }
 
 // d(total)/d(logits) = g[0] * d(loss)/d(logits) for a loss that enters a weighted sum (gen_cost + ACGAN_SCALE_G * xent,
@@ -250,7 +255,7 @@ __device__ __forceinline__ float adam_lr_t(const float* hp, const long long* t_s
 // they have been consumed, so the next backward pass accumulates into zeros without a fill launch of its own.
 __global__ void adam_tf_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                float* __restrict__ hp, long long* __restrict__ t_state,
-                               const long long* __restrict__ iteration, long n, long zero_n) {
+                               const long long* __restrict__ iteration, long n, long zero_n, unsigned long long* __restrict__ health) {
   __shared__ float s_lr;
   if (threadIdx.x == 0) s_lr = adam_lr_t(hp, t_state, iteration);
   __syncthreads();
@@ -264,9 +269,14 @@ __global__ void adam_tf_kernel(float* __restrict__ p, float* __restrict__ g, flo
   }
   const long n4 = n >> 2;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  unsigned bad = 0u, zero = 0u;        // health (optional): gradients that are not finite (loss-scale overflow) / exactly zero
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
     const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+    if (health) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) { bad += (gg[e] - gg[e] != 0.f) ? 1u : 0u; zero += gg[e] == 0.f ? 1u : 0u; }
+    }
     f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
 #pragma unroll
     for (int e = 0; e < 4; e++) {
@@ -292,12 +302,20 @@ __global__ void adam_tf_kernel(float* __restrict__ p, float* __restrict__ g, flo
   // the tail behind the gradients (n is a multiple of 4 whenever zero_n > n: checked by the host)
   for (long i = n4 + blockIdx.x * (long)blockDim.x + threadIdx.x; i < (zero_n >> 2); i += (long)gridDim.x * blockDim.x)
     reinterpret_cast<f32x4*>(g)[i] = z4;
+  if (health) {           // one pair of atomics per wave that saw anything
+    const unsigned long long b64 = (unsigned long long)wave_sum((float)bad);
+    const unsigned long long z64 = (unsigned long long)wave_sum((float)zero);
+    if ((threadIdx.x & 63) == 0) {
+      if (b64) atomicAdd(health, b64);
+      if (z64) atomicAdd(health + 1, z64);
+    }
+  }
 }
 
 __global__ void counter_add_kernel(long long* c, long long inc) { c[0] += inc; }
 
-extern "C" int gank_adam_tf(float* p, float* g, float* m, float* v, float* hp, int64_t* t_state,
-                            const int64_t* iteration, long n, long zero_n, void* stream) {
+extern "C" int gank_adam_tf_health(float* p, float* g, float* m, float* v, float* hp, int64_t* t_state,
+                                   const int64_t* iteration, long n, long zero_n, uint64_t* health, void* stream) {
   GANK_REQUIRE(p && g && m && v && hp && t_state && n > 0, "adam_tf: bad arguments");
   GANK_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_tf: buffers must be 16-byte aligned");
   GANK_REQUIRE(zero_n == 0 || zero_n == n || (zero_n > n && n % 4 == 0 && zero_n % 4 == 0), "adam_tf: zero_n must be 0, n, or a multiple of 4 beyond an n that is one");
@@ -306,9 +324,14 @@ extern "C" int gank_adam_tf(float* p, float* g, float* m, float* v, float* hp, i
   if (blocks < 1) blocks = 1;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(adam_tf_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, hp, (long long*)t_state,
-                     (const long long*)iteration, n, zero_n);
+                     (const long long*)iteration, n, zero_n, (unsigned long long*)health);
   GANK_LAUNCH_OK("adam_tf");
   return 0;
+}
+
+extern "C" int gank_adam_tf(float* p, float* g, float* m, float* v, float* hp, int64_t* t_state,
+                            const int64_t* iteration, long n, long zero_n, void* stream) {
+  return gank_adam_tf_health(p, g, m, v, hp, t_state, iteration, n, zero_n, nullptr, stream);
 }
 
 extern "C" int gank_counter_add(int64_t* counter, int64_t inc, void* stream) {

@@ -995,17 +995,27 @@ class _Loss(Function):
 
 _unit_seeds = {}
 _unit_seed_ptrs = set()
+_seed_scale = {}          # data_ptr of a registered seed tensor -> its value (1.0, or the static loss scale)
+
+
+def grad_seed(loss, scale=1.0):
+    """Persistent gradient seed for `loss.backward(gradient=...)`: no ones_like fill per update.  scale = 1: _Loss / the fused
+    head recognise it (by identity) and hand out the 16-bit gradient of the forward launch as is.  scale = a power of two
+    (static loss scaling, the fp16 build): the loss nodes multiply d loss / d logits by it before rounding to 16 bits -- every
+    gradient behind them is `scale` times larger and the optimiser's grad_scale divides it out."""
+    key = (loss.device, tuple(loss.shape), float(scale))
+    s = _unit_seeds.get(key)
+    if s is None:
+        s = _unit_seeds[key] = torch.full_like(loss, float(scale))      # never freed, never written: its address identifies it
+        _seed_scale[s.data_ptr()] = float(scale)
+        if float(scale) == 1.0:
+            _unit_seed_ptrs.add(s.data_ptr())
+    return s
 
 
 def unit_seed(loss):
-    """Persistent all-ones gradient seed for `loss.backward(gradient=...)`: no ones_like fill per update, and _Loss
-    recognises it (by identity) and skips the scale launch."""
-    key = (loss.device, tuple(loss.shape))
-    s = _unit_seeds.get(key)
-    if s is None:
-        s = _unit_seeds[key] = torch.ones_like(loss)      # never freed, never written: its address identifies it
-        _unit_seed_ptrs.add(s.data_ptr())
-    return s
+    """Persistent all-ones gradient seed (grad_seed with scale 1)."""
+    return grad_seed(loss, 1.0)
 
 
 class _HingeHead(Function):
@@ -1014,7 +1024,8 @@ class _HingeHead(Function):
     the loss must be differentiated directly (unit upstream gradient) -- a weighted sum goes through linear + hinge_*_loss."""
 
     @staticmethod
-    def forward(ctx, x, W, bias, n_real, mode, out):
+    def forward(ctx, x, W, bias, n_real, mode, out, loss_scale=1.0):
+        ctx.loss_scale = float(loss_scale)
         need_w = ctx.needs_input_grad[1]
         need_b = bias is not None and ctx.needs_input_grad[2]
         wt = bt = None
@@ -1033,28 +1044,29 @@ class _HingeHead(Function):
                 fl["clean"] = False
         buf = out.t if out is not None else None
         loss, logits, dx = K.critic_head_hinge(_c(x), W.detach().reshape(-1), bias.detach() if bias is not None else None, n_real, mode,
-                                               ctx.needs_input_grad[0], wt.view(-1) if wt is not None else None, bt, buf)
+                                               ctx.needs_input_grad[0], wt.view(-1) if wt is not None else None, bt, buf, loss_scale=ctx.loss_scale)
         ctx.dx = dx
         _HingeHead.last_logits = logits
         return loss.detach() if buf is not None else loss
 
     @staticmethod
     def backward(ctx, g):
-        if g.data_ptr() not in _unit_seed_ptrs:
-            raise NotImplementedError("the fused critic head differentiates the loss itself (loss.backward(gradient=unit_seed(loss))); "
-                                      "use linear + hinge_*_loss for a weighted sum of losses")
-        return ctx.dx, ctx.ret[0], ctx.ret[1], None, None, None
+        if _seed_scale.get(g.data_ptr()) != ctx.loss_scale:
+            raise NotImplementedError("the fused critic head differentiates the loss itself (loss.backward(gradient=grad_seed(loss, loss_scale)) "
+                                      "with the loss scale its forward launch was given); use linear + hinge_*_loss for a weighted sum of losses")
+        return ctx.dx, ctx.ret[0], ctx.ret[1], None, None, None, None
 
 
-def hinge_d_head(x, W, bias, n_real, out=None):
-    """hinge_d_loss(linear(x, W, bias), n_real) in one launch; the logits ride along as `loss.logits` (bf16 [M], detached)"""
-    loss = _HingeHead.apply(x, W, bias, int(n_real), 0, _Box(out) if out is not None else None)
+def hinge_d_head(x, W, bias, n_real, out=None, loss_scale=1.0):
+    """hinge_d_loss(linear(x, W, bias), n_real) in one launch; the logits ride along as `loss.logits` (bf16 [M], detached).
+    loss_scale: see grad_seed (the backward seed must carry the same scale)"""
+    loss = _HingeHead.apply(x, W, bias, int(n_real), 0, _Box(out) if out is not None else None, float(loss_scale))
     loss.logits, _HingeHead.last_logits = _HingeHead.last_logits, None
     return loss
 
 
-def hinge_g_head(x, W, bias, out=None):
-    loss = _HingeHead.apply(x, W, bias, 0, 1, _Box(out) if out is not None else None)
+def hinge_g_head(x, W, bias, out=None, loss_scale=1.0):
+    loss = _HingeHead.apply(x, W, bias, 0, 1, _Box(out) if out is not None else None, float(loss_scale))
     loss.logits, _HingeHead.last_logits = _HingeHead.last_logits, None
     return loss
 

@@ -895,16 +895,16 @@ def hinge_g_loss(logits, loss=None):
     return loss, dl, dl32
 
 
-def critic_head_hinge(x, w, b, n_real, mode, want_dx=True, w_grad=None, b_grad=None, loss=None):
+def critic_head_hinge(x, w, b, n_real, mode, want_dx=True, w_grad=None, b_grad=None, loss=None, loss_scale=1.0):
     """fused D.Output + hinge loss (gank_critic_head_hinge) -> (loss fp32[1], logits bf16 [M], dx bf16 [M,K] | None);
-    w_grad / b_grad are ACCUMULATED when given"""
+    w_grad / b_grad are ACCUMULATED when given; loss_scale (a power of two) multiplies the three gradients, not the loss"""
     m, k = x.shape
     assert w.numel() == k and (b is None or b.numel() == 1)
     loss = torch.empty(1, dtype=F32, device=x.device) if loss is None else loss
     logits = torch.empty(m, dtype=BF16, device=x.device)
     dx = torch.empty((m, k), dtype=BF16, device=x.device) if want_dx else None
-    _lib.check(lib().gank_critic_head_hinge(_p(x, BF16, "x"), _p(w, F32, "w"), _p(b, F32, "b"), _p(logits), _p(loss), _p(dx), _p(w_grad, F32, "w_grad"),
-                                            _p(b_grad, F32, "b_grad"), m, k, int(n_real), int(mode), _stream()), "critic_head_hinge")
+    _lib.check(lib().gank_critic_head_hinge_scaled(_p(x, BF16, "x"), _p(w, F32, "w"), _p(b, F32, "b"), _p(logits), _p(loss), _p(dx), _p(w_grad, F32, "w_grad"),
+                                                   _p(b_grad, F32, "b_grad"), m, k, int(n_real), int(mode), float(loss_scale), _stream()), "critic_head_hinge")
     return loss, logits, dx
 
 
@@ -924,13 +924,14 @@ def loss_grad_scale(dl32, g):
     return out
 
 
-def adam_tf(p, g, m, v, hp, t_state, iteration=None, zero_grads=False):
+def adam_tf(p, g, m, v, hp, t_state, iteration=None, zero_grads=False, health=None):
     """hp fp32[8] = {lr, beta1, beta2, eps, grad_scale, decay_on, 0, 0}; t_state int64[1]; iteration int64[1] | None.
-    zero_grads: clear g (ALL of it: it may be longer than p, e.g. a scratch half behind the gradients) in the same launch."""
+    zero_grads: clear g (ALL of it: it may be longer than p, e.g. a scratch half behind the gradients) in the same launch.
+    health: int64[2] counters (non-finite gradients, zero gradients), accumulated."""
     assert g.numel() >= p.numel() and hp.numel() >= 8
-    _lib.check(lib().gank_adam_tf(_p(p, F32, "p"), _p(g, F32, "g"), _p(m, F32, "m"), _p(v, F32, "v"), _p(hp, F32, "hp"),
-                                  _p(t_state, torch.int64, "t_state"), _p(iteration, torch.int64, "iteration"),
-                                  p.numel(), g.numel() if zero_grads else 0, _stream()), "adam_tf")
+    _lib.check(lib().gank_adam_tf_health(_p(p, F32, "p"), _p(g, F32, "g"), _p(m, F32, "m"), _p(v, F32, "v"), _p(hp, F32, "hp"),
+                                         _p(t_state, torch.int64, "t_state"), _p(iteration, torch.int64, "iteration"),
+                                         p.numel(), g.numel() if zero_grads else 0, _p(health, torch.int64, "health"), _stream()), "adam_tf")
 
 
 def counter_add(counter, inc=1):

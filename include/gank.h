@@ -426,6 +426,11 @@ int gank_embedding_bwd(const void* dy, const int32_t* idx, float* dtable, int N,
  * gank_linear_fwd + gank_hinge_*_loss + gank_linear_bwd (bf16 logits, bf16 d loss / d logits). */
 int gank_critic_head_hinge(const void* x, const float* w, const float* b, void* logits, float* loss, void* dx, float* w_grad,
                            float* b_grad, int M, int K, int n_real, int mode, void* stream);
+/* ... with a static loss scale (a power of two): d loss / d logit is multiplied by loss_scale before it is rounded to 16 bits, so
+ * dx, w_grad and b_grad are loss_scale x the true gradients -- the fp16 build's protection against underflow of the
+ * activation gradients behind this layer; the optimiser divides it out again (hp.grad_scale of gank_adam_tf).  `loss` is unscaled. */
+int gank_critic_head_hinge_scaled(const void* x, const float* w, const float* b, void* logits, float* loss, void* dx, float* w_grad,
+                                  float* b_grad, int M, int K, int n_real, int mode, float loss_scale, void* stream);
 int gank_hinge_d_loss(const void* logits, float* loss, void* dlogits, float* dlogits_f32, int n, int n_real, void* stream);
 int gank_hinge_g_loss(const void* logits, float* loss, void* dlogits, float* dlogits_f32, int n, void* stream);
 /* wgan_d: -mean(l[:n_real]) + mean(l[n_real:])  (common/misc.py:328-331 'WGAN', :337-352 'WGAN-GP' before its penalty) */
@@ -487,6 +492,11 @@ int gank_dropout_bwd(const void* dy, const uint8_t* mask, void* dx, long n, floa
  * cleared once consumed, so the next backward pass needs no fill launch.  gank_counter_add advances a device counter. */
 int gank_adam_tf(float* p, float* g, float* m, float* v, float* hp, int64_t* t_state,
                  const int64_t* iteration, long n, long zero_n, void* stream);
+/* ... and counters for a loss-scaled run: health[0] += gradients that are not finite (the scale overflowed the 16-bit range
+ * somewhere behind them), health[1] += gradients that are exactly zero (compare with an unscaled bf16 run: the excess is
+ * underflow).  Cumulative; the caller clears them. */
+int gank_adam_tf_health(float* p, float* g, float* m, float* v, float* hp, int64_t* t_state, const int64_t* iteration, long n,
+                        long zero_n, uint64_t* health, void* stream);
 int gank_counter_add(int64_t* counter, int64_t inc, void* stream);
 
 /* ---- input pipeline (gan_cifar_resnet.py:334-337) and graph-safe RNG -----------------------------

@@ -183,12 +183,53 @@ class _RoundBoth(torch.autograd.Function):
         return g.to(torch.bfloat16).to(g.dtype)
 
 
+class _RoundFwd(torch.autograd.Function):
+    """value rounded, gradient exact"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundBwd(torch.autograd.Function):
+    """value exact, gradient rounded"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
 def bf16_storage(x):
     return _RoundBoth.apply(x)
 
 
-def _st(x):
-    return x if STORE is None else STORE(x)
+def bf16_storage_fwd(x):
+    return _RoundFwd.apply(x)
+
+
+def bf16_storage_bwd(x):
+    return _RoundBwd.apply(x)
+
+
+# Attribution instrument: every stored tensor carries a class tag -- 'lin' (G.Input output), 'short' (shortcut conv outputs),
+# 'cbn' (normalised + activated tensors), 'conv1' (conv_1 outputs = the next norm's input), 'block' (block outputs = shortcut +
+# conv_2), 'image' (tanh output), 'd' (everything the critic stores).  Classes listed in STORE_EXACT are left unrounded, so a test
+# or script can un-round ONE class at a time and see which stored tensor carries the gradient error (DESIGN.md section 2).
+STORE_EXACT = frozenset()
+
+
+def _st(x, cls=None):
+    if STORE is None or (cls is not None and cls in STORE_EXACT):
+        return x
+    return STORE(x)
 
 
 # ------------------------------------------------------------------ model
@@ -223,17 +264,17 @@ class _Ctx:
 def generator(P, noise, labels, groups=1):
     """gan_cifar_resnet.py:237-263.  noise [n,128] -> [n,3072] (HWC order, tanh range)."""
     c = _Ctx(P, 'Generator', False)
-    out = _st(c.linear(noise, 'G.Input')).reshape(-1, 4, 4, DIM_G * 8)
+    out = _st(c.linear(noise, 'G.Input'), 'lin').reshape(-1, 4, 4, DIM_G * 8)
     for i in (1, 2, 3):
         name = f'G.Block.{i}'
-        shortcut = _st(c.conv(upsample_nn2x(out), name + '.Shortcut'))     # :179-182 -> :140-151
-        h = _st(torch.relu(c.cbn(out, name + '.N1', labels, groups)))
-        h = _st(c.conv(upsample_nn2x(h), name + '.Conv1'))                 # :192-195
-        h = _st(torch.relu(c.cbn(h, name + '.N2', labels, groups)))
+        shortcut = _st(c.conv(upsample_nn2x(out), name + '.Shortcut'), 'short')     # :179-182 -> :140-151
+        h = _st(torch.relu(c.cbn(out, name + '.N1', labels, groups)), 'cbn')
+        h = _st(c.conv(upsample_nn2x(h), name + '.Conv1'), 'conv1')                 # :192-195
+        h = _st(torch.relu(c.cbn(h, name + '.N2', labels, groups)), 'cbn')
         h = c.conv(h, name + '.Conv2')
-        out = _st(shortcut + h)
-    out = _st(torch.relu(c.cbn(out, 'G.OutputNorm', labels, groups)))
-    out = _st(torch.tanh(c.conv(out, 'G.Output')))
+        out = _st(shortcut + h, 'block')
+    out = _st(torch.relu(c.cbn(out, 'G.OutputNorm', labels, groups)), 'cbn')
+    out = _st(torch.tanh(c.conv(out, 'G.Output')), 'image')
     return out.reshape(-1, 3072)
 
 
@@ -241,24 +282,24 @@ def discriminator(P, x, labels):
     """gan_cifar_resnet.py:266-313 (ACGAN=False).  Returns logits [n] and {u name: new u}."""
     c = _Ctx(P, 'Discriminator', True)
     x = x.reshape(-1, 32, 32, 3)
-    shortcut = _st(c.conv(meanpool2x2(x), 'D.Block.1.Shortcut', sn=True))  # :218-221 -> :125-135
-    h = _st(c.conv(x, 'D.Block.1.Conv1', sn=True))
+    shortcut = _st(c.conv(meanpool2x2(x), 'D.Block.1.Shortcut', sn=True), 'd')  # :218-221 -> :125-135
+    h = _st(c.conv(x, 'D.Block.1.Conv1', sn=True), 'd')
     h = meanpool2x2(c.conv(torch.relu(h), 'D.Block.1.Conv2', sn=True))
-    out = _st(shortcut + h)
-    emb = _st(c.linear(P['Discriminator/Embedding.Label/embedding_map'][labels], 'D.Embedding_y', sn=True))
+    out = _st(shortcut + h, 'd')
+    emb = _st(c.linear(P['Discriminator/Embedding.Label/embedding_map'][labels], 'D.Embedding_y', sn=True), 'd')
     emb = emb[:, None, None, :].expand(-1, out.shape[1], out.shape[2], -1)
     out = torch.cat([out, emb], dim=3)                                      # :282-284
     # D.Block.2, resample='down'
-    shortcut = _st(meanpool2x2(c.conv(out, 'D.Block.2.Shortcut', sn=True)))    # ConvMeanPool :112-122
-    h = _st(c.conv(torch.relu(out), 'D.Block.2.Conv1', sn=True))
+    shortcut = _st(meanpool2x2(c.conv(out, 'D.Block.2.Shortcut', sn=True)), 'd')    # ConvMeanPool :112-122
+    h = _st(c.conv(torch.relu(out), 'D.Block.2.Conv1', sn=True), 'd')
     h = meanpool2x2(c.conv(torch.relu(h), 'D.Block.2.Conv2', sn=True))
-    out = _st(shortcut + h)
+    out = _st(shortcut + h, 'd')
     for i in (3, 4):                                                        # identity shortcut :176-177
-        h = _st(c.conv(torch.relu(out), f'D.Block.{i}.Conv1', sn=True))
+        h = _st(c.conv(torch.relu(out), f'D.Block.{i}.Conv1', sn=True), 'd')
         h = c.conv(torch.relu(h), f'D.Block.{i}.Conv2', sn=True)
-        out = _st(out + h)
-    out = _st(torch.relu(out).mean(dim=(1, 2)))                             # :299-301
-    logits = _st(c.linear(out, 'D.Output', sn=True)).reshape(-1)
+        out = _st(out + h, 'd')
+    out = _st(torch.relu(out).mean(dim=(1, 2)), 'd')                             # :299-301
+    logits = _st(c.linear(out, 'D.Output', sn=True), 'd').reshape(-1)
     return logits, c.new_u
 
 
