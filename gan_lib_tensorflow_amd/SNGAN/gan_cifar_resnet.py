@@ -826,6 +826,29 @@ class SNGANTrainer:
         self._iteration_tail()
 
     @torch.no_grad()
+    def dev_disc_cost(self, real_u8, labels, z=None, real_pre=None):
+        """`disc_cost` of one held-out batch, forward only -- the dev-loss evaluation of the loop (:639-647: every 100
+        iterations, session.run([disc_cost]) over dev_gen()).  It is the graph of the critic update (:326-381: fakes from the
+        generator towers on the REAL labels, critic on concat(real, fake), hinge loss) without the optimiser, and the critic
+        runs with update_collection=None as there: EVERY evaluation advances the spectral-norm `u` vectors (sn.py:48-56) --
+        the reference's behaviour, reproduced, not a side effect to be avoided.  Nothing else changes: no gradient is
+        accumulated, no Adam state moves.  Returns the loss as a float (one device synchronisation)."""
+        set_default_store(self.store)
+        b = real_u8.shape[0] if real_pre is None else real_pre.shape[0]
+        lab = labels.to(self.device, torch.int32)
+        fake = Generator(b, lab, noise=z, groups=N_TOWERS, rng_state=self.rng_state)
+        real = K.preprocess_real(real_u8.to(self.device), self.rng_state).reshape(b, OUTPUT_DIM) if real_pre is None else real_pre
+        both = torch.cat([real, fake], 0)
+        both_labels = torch.cat([lab, lab], 0)
+        logits, _ = Discriminator(both, both_labels, update_collection=None)
+        return float(Fn.hinge_d_loss(logits, b))
+
+    def dev_loss(self, dev_batches):
+        """np.mean of disc_cost over an epoch of the dev set (:641-647); dev_batches yields (uint8 [B,3072], labels)"""
+        costs = [self.dev_disc_cost(torch.as_tensor(x), torch.as_tensor(np.asarray(y))) for x, y in dev_batches]
+        return float(np.mean(costs)) if costs else float('nan')
+
+    @torch.no_grad()
     def sample(self, n=100, labels=None, noise=None):
         """Fixed-noise / IS sampling path (:530-555): one Generator call of n samples, batch statistics."""
         set_default_store(self.store)

@@ -124,6 +124,7 @@ PROTOTYPES = {
     "gank_critic_head_hinge": [P, P, P, P, P, P, P, P, I, I, I, I, P],
     "gank_critic_head_hinge_scaled": [P, P, P, P, P, P, P, P, I, I, I, I, F, P],
     "gank_hinge_d_loss": [P, P, P, P, I, I, P],
+    "gank_gan_pointwise_loss": [P, P, P, P, I, I, I, P],
     "gank_hinge_g_loss": [P, P, P, P, I, P],
     "gank_wgan_d_loss": [P, P, P, P, I, I, P],
     "gank_softmax_xent": [P, P, P, P, P, I, I, P],

@@ -10,18 +10,25 @@ def get_loss(disc_real, disc_fake, loss_type='HINGE'):
       'WGAN'    (:328-336): -mean(real) + mean(fake); -mean(fake)
       'WGAN-GP' (:337-352): the same pair -- the reference leaves the penalty to the call site (ACGAN/train.py:99-107);
                 use `gradient_penalty` below for it.
-    One launch per loss computes the value and d loss / d logits.  The sigmoid-based branches (LSGAN, CGAN, MiniMax) are
-    not used by any configuration of BASELINE.json."""
+      'LSGAN'   (:353-360): (mean((1 - real)^2) + mean(fake^2)) / 2; mean((1 - fake)^2) / 2
+      'CGAN'    (:361-372): sigmoid cross-entropy against ones / zeros; generator: against ones on the fakes
+      'Modified_MiniMax' (:373-381): -mean(log sigmoid(real)) - mean(log(1 - sigmoid(fake))); -mean(log sigmoid(fake))
+      'MiniMax' (:382-390): the same critic loss; generator mean(log(1 - sigmoid(fake)))
+    One launch per loss computes the value and d loss / d logits (the sigmoid family through the stable softplus form)."""
     n_real = disc_real.reshape(-1).shape[0]
-    both = torch.cat([disc_real.reshape(-1), disc_fake.reshape(-1)], 0)
+    fake = disc_fake.reshape(-1)
+    both = torch.cat([disc_real.reshape(-1), fake], 0)
     if loss_type == 'HINGE':
-        d_loss = Fn.hinge_d_loss(both, n_real)
-    elif loss_type in ('WGAN', 'WGAN-GP'):
-        d_loss = Fn.wgan_d_loss(both, n_real)
-    else:
-        raise NotImplementedError('loss_type %r: only HINGE / WGAN / WGAN-GP are on the configured paths' % (loss_type,))
-    g_loss = Fn.hinge_g_loss(disc_fake.reshape(-1))        # -mean(disc_fake) in all three branches
-    return d_loss, g_loss
+        return Fn.hinge_d_loss(both, n_real), Fn.hinge_g_loss(fake)
+    if loss_type in ('WGAN', 'WGAN-GP'):
+        return Fn.wgan_d_loss(both, n_real), Fn.hinge_g_loss(fake)        # -mean(disc_fake) in all three branches
+    if loss_type == 'LSGAN':
+        return Fn.gan_pointwise_loss(both, n_real, 0), Fn.gan_pointwise_loss(fake, 0, 1)
+    if loss_type in ('CGAN', 'Modified_MiniMax'):
+        return Fn.gan_pointwise_loss(both, n_real, 2), Fn.gan_pointwise_loss(fake, 0, 3)
+    if loss_type == 'MiniMax':
+        return Fn.gan_pointwise_loss(both, n_real, 2), Fn.gan_pointwise_loss(fake, 0, 4)
+    raise NotImplementedError('loss_type %r (misc.py:310-394 knows HINGE, WGAN, WGAN-GP, LSGAN, CGAN, Modified_MiniMax, MiniMax)' % (loss_type,))
 
 
 def gradient_penalty(gradients, weight=10.0):

@@ -81,6 +81,50 @@ __global__ void wgan_d_kernel(const bf16* __restrict__ l, float* __restrict__ lo
   const float tot = block_sum(acc, red);
   if (threadIdx.x == 0) loss[0] = tot;
 }
+// The remaining branches of get_loss (common/misc.py:353-394): least squares and the sigmoid cross-entropy / minimax family.
+//   kind 0 LSGAN critic     (mean((1 - real)^2) + mean(fake^2)) / 2                           :355-357
+//   kind 1 LSGAN generator  mean((1 - fake)^2) / 2                                            :360
+//   kind 2 critic of CGAN / Modified_MiniMax / MiniMax:  mean(-log sigmoid(real)) + mean(-log(1 - sigmoid(fake)))
+//          = mean(softplus(-real)) + mean(softplus(fake))  (sigmoid_cross_entropy_with_logits, labels 1 / 0)   :362-368, :376-378, :385-387
+//   kind 3 generator of CGAN / Modified_MiniMax:  mean(-log sigmoid(fake)) = mean(softplus(-fake))     :370-372, :381
+//   kind 4 generator of MiniMax:  mean(log(1 - sigmoid(fake))) = -mean(softplus(fake))                 :390
+// softplus(x) = max(x, 0) + log1p(exp(-|x|)) (TensorFlow's stable form); d softplus / dx = sigmoid(x).
+__device__ __forceinline__ float gank_softplus(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+__device__ __forceinline__ float gank_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+__global__ void gan_pointwise_loss_kernel(const bf16* __restrict__ l, float* __restrict__ loss, bf16* __restrict__ dl, float* __restrict__ dl32, int n, int n_real, int kind) {
+  __shared__ float red[16];
+  const int n_fake = n - n_real;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float v = bf2f(l[i]);
+    float t, d;
+    if (kind == 0) {
+      if (i < n_real) { t = 0.5f * (1.f - v) * (1.f - v) / (float)n_real; d = -(1.f - v) / (float)n_real; }
+      else { t = 0.5f * v * v / (float)n_fake; d = v / (float)n_fake; }
+    } else if (kind == 1) {
+      t = 0.5f * (1.f - v) * (1.f - v) / (float)n; d = -(1.f - v) / (float)n;
+    } else if (kind == 2) {
+      if (i < n_real) { t = gank_softplus(-v) / (float)n_real; d = -gank_sigmoid(-v) / (float)n_real; }
+      else { t = gank_softplus(v) / (float)n_fake; d = gank_sigmoid(v) / (float)n_fake; }
+    } else if (kind == 3) {
+      t = gank_softplus(-v) / (float)n; d = -gank_sigmoid(-v) / (float)n;
+    } else {
+      t = -gank_softplus(v) / (float)n; d = -gank_sigmoid(v) / (float)n;
+    }
+    acc += t;
+    dl[i] = f2bf(d);
+    if (dl32) dl32[i] = d;
+  }
+  const float tot = block_sum(acc, red);
+  if (threadIdx.x == 0) loss[0] = tot;
+}
+extern "C" int gank_gan_pointwise_loss(const void* logits, float* loss, void* dlogits, float* dlogits_f32, int n, int n_real, int kind, void* stream) {
+  GANK_REQUIRE(logits && loss && dlogits && n > 0 && kind >= 0 && kind <= 4, "gan_pointwise_loss: bad arguments");
+  GANK_REQUIRE((kind != 0 && kind != 2) || (n_real > 0 && n_real < n), "gan_pointwise_loss: a critic loss needs 0 < n_real < n");
+  hipLaunchKernelGGL(gan_pointwise_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, loss, (bf16*)dlogits, dlogits_f32, n, n_real, kind);
+  GANK_LAUNCH_OK("gan_pointwise_loss");
+  return 0;
+}
 extern "C" int gank_wgan_d_loss(const void* logits, float* loss, void* dlogits, float* dlogits_f32, int n, int n_real, void* stream) {
   GANK_REQUIRE(logits && loss && dlogits && n > 0 && n_real > 0 && n_real < n, "wgan_d_loss: bad arguments");
   hipLaunchKernelGGL(wgan_d_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, loss, (bf16*)dlogits, dlogits_f32, n, n_real);

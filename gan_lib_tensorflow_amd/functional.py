@@ -977,6 +977,8 @@ class _Loss(Function):
             loss, dl, dl32 = K.hinge_g_loss(logits, buf)
         elif kind == "xent":
             loss, dl, dl32 = K.softmax_xent(logits, arg)
+        elif kind.startswith("pointwise"):
+            loss, dl, dl32 = K.gan_pointwise_loss(logits, arg[0], arg[1], buf)
         else:
             raise NotImplementedError(kind)
         ctx.save_for_backward(dl, dl32)
@@ -1093,6 +1095,11 @@ def wgan_d_loss(logits, n_real, out=None):
 
 def softmax_xent(logits, labels):
     return _Loss.apply(logits, "xent", labels)
+
+
+def gan_pointwise_loss(logits, n_real, kind, out=None):
+    """the least-squares / sigmoid-cross-entropy / minimax branches of get_loss (kernels.gan_pointwise_loss)"""
+    return _Loss.apply(logits, "pointwise", (int(n_real), int(kind)), _Box(out) if out is not None else None)
 
 
 class _Cast(Function):

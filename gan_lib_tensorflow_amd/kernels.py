@@ -887,6 +887,17 @@ def wgan_d_loss(logits, n_real, loss=None):
     return loss, dl, dl32
 
 
+def gan_pointwise_loss(logits, n_real, kind, loss=None):
+    """kind 0 LSGAN critic | 1 LSGAN generator | 2 sigmoid-xent critic | 3 -log sigmoid generator | 4 MiniMax generator
+    (gank_gan_pointwise_loss) -> (loss fp32[1], dlogits bf16, dlogits fp32)"""
+    loss = torch.empty(1, dtype=F32, device=logits.device) if loss is None else loss
+    dl = torch.empty_like(logits)
+    dl32 = torch.empty(logits.shape, dtype=F32, device=logits.device)
+    _lib.check(lib().gank_gan_pointwise_loss(_p(logits, BF16, "logits"), _p(loss), _p(dl), _p(dl32), logits.numel(), int(n_real), int(kind), _stream()),
+               "gan_pointwise_loss")
+    return loss, dl, dl32
+
+
 def hinge_g_loss(logits, loss=None):
     loss = torch.empty(1, dtype=F32, device=logits.device) if loss is None else loss
     dl = torch.empty_like(logits)

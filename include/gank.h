@@ -431,6 +431,10 @@ int gank_critic_head_hinge(const void* x, const float* w, const float* b, void* 
  * activation gradients behind this layer; the optimiser divides it out again (hp.grad_scale of gank_adam_tf).  `loss` is unscaled. */
 int gank_critic_head_hinge_scaled(const void* x, const float* w, const float* b, void* logits, float* loss, void* dx, float* w_grad,
                                   float* b_grad, int M, int K, int n_real, int mode, float loss_scale, void* stream);
+/* the other branches of get_loss (common/misc.py:353-394), same conventions (critic kinds: the first n_real logits are real):
+ * kind 0 LSGAN critic, 1 LSGAN generator, 2 sigmoid-cross-entropy critic (CGAN / Modified_MiniMax / MiniMax), 3 its
+ * non-saturating generator (-log sigmoid(fake): CGAN, Modified_MiniMax), 4 the MiniMax generator (log(1 - sigmoid(fake))). */
+int gank_gan_pointwise_loss(const void* logits, float* loss, void* dlogits, float* dlogits_f32, int n, int n_real, int kind, void* stream);
 int gank_hinge_d_loss(const void* logits, float* loss, void* dlogits, float* dlogits_f32, int n, int n_real, void* stream);
 int gank_hinge_g_loss(const void* logits, float* loss, void* dlogits, float* dlogits_f32, int n, void* stream);
 /* wgan_d: -mean(l[:n_real]) + mean(l[n_real:])  (common/misc.py:328-331 'WGAN', :337-352 'WGAN-GP' before its penalty) */

@@ -735,3 +735,72 @@ def test_training_on_a_synthetic_class_conditional_dataset_learns_the_classes(gp
     # measured: 9 / 10 classes recovered, mean RMS 0.28 (the data's classes are 0.30 .. 0.72 apart; 10 / 10 and 0.23 after 5 000 iterations)
     assert (d.argmin(1) == np.arange(10)).sum() >= 8, d.argmin(1)
     assert float(np.diag(d).mean()) < 0.35, np.diag(d).mean()
+
+
+def test_dev_loss_is_forward_only_and_advances_u(gpu):
+    """The dev-loss evaluation (gan_cifar_resnet.py:639-647): disc_cost forward only, critic with update_collection=None -- the
+    spectral-norm u vectors advance on every evaluation (sn.py:48-56), weights / Adam state / gradient buffers do not move, and
+    the value is the oracle's disc_cost for the same inputs."""
+    b = 8
+    S, tr, state = make_trainer(61, b)
+    rng = np.random.default_rng(5)
+    z = bf16r(rng.normal(size=(b, 128)))
+    labels = torch.tensor(rng.integers(0, 10, b), dtype=torch.int32)
+    real_u8 = torch.tensor(rng.integers(0, 256, (b, 3072)), dtype=torch.uint8)
+    real_pre = bf16r(T.preprocess_real(real_u8, torch.zeros(b, 3072, dtype=torch.float64), torch.float64).numpy())
+    P = T.to_torch(state)
+    ref, new_u, _ = T.d_loss_fn(P, None, labels.long(), z.to(torch.float64), None, real_pre=real_pre.to(torch.float64))
+    u_name = 'Discriminator/D.Block.2.Conv1/filters/spectral_norm/u'
+    u0 = tr.store.vars[u_name].clone()
+    p0, m0 = tr.d_flat["params"].clone(), tr.d_flat["m"].clone()
+    tr.d_flat["grads_all"].zero_()
+    tr.d_flat["clean"] = True
+    got = tr.dev_disc_cost(None, labels, z=z.cuda(), real_pre=real_pre.cuda())
+    assert abs(got - float(ref)) < 0.02, (got, float(ref))
+    u1 = tr.store.vars[u_name].clone()
+    assert float((u1 - u0).abs().max()) > 1e-3                                           # u <- u_final
+    assert float((u1.double().cpu().reshape(-1) - new_u[u_name].reshape(-1)).abs().max()) < 1e-4
+    assert torch.equal(tr.d_flat["params"], p0) and torch.equal(tr.d_flat["m"], m0) and int(tr.d_opt.t) == 0
+    assert float(tr.d_flat["grads_all"].abs().max()) == 0.0 and tr.d_flat["clean"] is True
+    tr.dev_disc_cost(None, labels, z=z.cuda(), real_pre=real_pre.cuda())
+    assert float((tr.store.vars[u_name] - u1).abs().max()) > 0                           # ... and again on the next evaluation
+    # through the uint8 feed and an epoch of batches
+    feed = [(real_u8.numpy(), labels.numpy()), (real_u8.numpy(), labels.numpy())]
+    assert np.isfinite(tr.dev_loss(feed))
+    # the training step still replays after an evaluation
+    batches = S.synthetic_batches(b, "cuda", seed=2)
+    for _ in range(3):
+        tr.train_iteration(batches)
+    assert bool(torch.isfinite(tr.d_flat["params"]).all())
+
+
+def test_get_loss_least_squares_and_sigmoid_branches(gpu):
+    """common/misc.py:353-394: LSGAN, CGAN, Modified_MiniMax, MiniMax -- values and d loss / d logits against float64."""
+    from gan_lib_tensorflow_amd.common.misc import get_loss
+    rng = np.random.default_rng(9)
+    real = bf16r(rng.normal(size=24) * 3)
+    fake = bf16r(rng.normal(size=40) * 3)
+
+    def ref(kind, r, f):
+        sp = torch.nn.functional.softplus
+        if kind == 'LSGAN':
+            return (((1 - r) ** 2).mean() + (f ** 2).mean()) / 2, ((1 - f) ** 2).mean() / 2
+        d = sp(-r).mean() + sp(f).mean()
+        return d, (sp(-f).mean() if kind in ('CGAN', 'Modified_MiniMax') else -sp(f).mean())
+    for kind in ('LSGAN', 'CGAN', 'Modified_MiniMax', 'MiniMax'):
+        r = real.cuda().requires_grad_(True)
+        f = fake.cuda().requires_grad_(True)
+        d_loss, g_loss = get_loss(r, f, kind)
+        rr = real.double().requires_grad_(True)
+        ff = fake.double().requires_grad_(True)
+        d_ref, g_ref = ref(kind, rr, ff)
+        assert abs(float(d_loss) - float(d_ref)) < 1e-5 and abs(float(g_loss) - float(g_ref)) < 1e-5, kind
+        d_loss.backward()
+        gr, gf = torch.autograd.grad(d_ref, [rr, ff])
+        assert float((r.grad.double().cpu() - gr).abs().max()) < 1e-2 * float(gr.abs().max()) + 1e-6, kind      # the gradient leaves the loss launch in bf16
+        assert float((f.grad.double().cpu() - gf).abs().max()) < 1e-2 * float(gf.abs().max()) + 1e-6, kind
+        f2 = fake.cuda().requires_grad_(True)
+        _, g_loss = get_loss(real.cuda(), f2, kind)
+        g_loss.backward()
+        (gg,) = torch.autograd.grad(g_ref, [ff])
+        assert float((f2.grad.double().cpu() - gg).abs().max()) < 1e-2 * float(gg.abs().max()) + 1e-6, kind
