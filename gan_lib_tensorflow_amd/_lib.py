@@ -142,6 +142,8 @@ PROTOTYPES = {
     "gank_minibatch_std_bwd": [P, P, P, P, I, I, I, P],
     "gank_resize_bilinear": [P, P, I, I, I, I, I, I, P],
     "gank_concat_channels": [P, P, P, L, I, I, P],
+    "gank_pool2d": [P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
+    "gank_relu_to_channels": [P, P, L, I, I, I, P],
     "gank_split_channels": [P, P, P, L, I, I, P],
     "gank_l1_loss": [P, P, P, P, P, L, P],
     "gank_dropout_fwd": [P, P, P, L, F, P, P],

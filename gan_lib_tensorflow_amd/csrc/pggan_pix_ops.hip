@@ -245,3 +245,73 @@ extern "C" int gank_dropout_bwd(const void* dy, const uint8_t* mask, void* dx, l
   GANK_LAUNCH_OK("dropout_bwd");
   return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Inception-v3 classifier of the Inception-score harness (common/inception/inception_score.py:29-47 runs tfgan's frozen
+// 2015 Inception graph): the two operators it needs beside convolutions -- general 2-D pooling and the branch concat.
+//   pool2d: max or average over a k x k window, stride 1 or 2, `pad` leading rows / columns (TF SAME for odd k: (k-1)/2;
+//           VALID: 0); the average divides by the number of IN-IMAGE elements (tf.nn.avg_pool with SAME excludes the padding).
+//   Both write into a channel slice [c_off, c_off + C) of a wider output [.., Cy] (tf.concat(axis=3) of a block's branches
+//   without a concat pass); relu_to_channels is the conv's ReLU placed there.
+// ------------------------------------------------------------------------------------------------
+__global__ void pool2d_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, long total8, int H, int W, int C, int Ho, int Wo, int k, int stride,
+                              int pad, int mode, int Cy, int c_off) {
+  const int cg = C >> 3;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % cg);
+    long p = i / cg;
+    const int ow = (int)(p % Wo); p /= Wo;
+    const int oh = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) acc[e] = mode == 0 ? -3.0e38f : 0.f;
+    int cnt = 0;
+    for (int dh = 0; dh < k; dh++) {
+      const int ih = oh * stride + dh - pad;
+      if ((unsigned)ih >= (unsigned)H) continue;
+      for (int dw = 0; dw < k; dw++) {
+        const int iw = ow * stride + dw - pad;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (((long)n * H + ih) * W + iw) * C + g * 8);
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] = mode == 0 ? fmaxf(acc[e], bf2f(v[e])) : acc[e] + bf2f(v[e]);
+        cnt++;
+      }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = f2bf(mode == 0 ? acc[e] : acc[e] / (float)max(cnt, 1));
+    *reinterpret_cast<bf16x8*>(y + (((long)n * Ho + oh) * Wo + ow) * Cy + c_off + g * 8) = o;
+  }
+}
+extern "C" int gank_pool2d(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int k, int stride, int pad, int mode, int Cy, int c_off,
+                           void* stream) {
+  GANK_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && k >= 1 && (stride == 1 || stride == 2) && pad >= 0 && pad < k && (mode == 0 || mode == 1),
+               "pool2d: bad arguments");
+  GANK_REQUIRE(C % 8 == 0 && Cy % 8 == 0 && c_off % 8 == 0 && c_off + C <= Cy, "pool2d: channels %d into [%d, %d) of %d: multiples of 8 inside the output", C, c_off, c_off + C, Cy);
+  GANK_REQUIRE((Ho - 1) * stride - pad < H && (Wo - 1) * stride - pad < W, "pool2d: output %dx%d reaches past the %dx%d input", Ho, Wo, H, W);
+  const long total8 = (long)N * Ho * Wo * (C / 8);
+  hipLaunchKernelGGL(pool2d_kernel, g1(total8), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, total8, H, W, C, Ho, Wo, k, stride, pad, mode, Cy, c_off);
+  GANK_LAUNCH_OK("pool2d");
+  return 0;
+}
+
+__global__ void relu_to_channels_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, long total8, int C, int Cy, int c_off) {
+  const int cg = C >> 3;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % cg);
+    const long p = i / cg;
+    const u32x4 v = relu_bf16x8(*reinterpret_cast<const u32x4*>(x + p * C + g * 8));
+    *reinterpret_cast<u32x4*>(y + p * Cy + c_off + g * 8) = v;
+  }
+}
+extern "C" int gank_relu_to_channels(const void* x, void* y, long pixels, int C, int Cy, int c_off, void* stream) {
+  GANK_REQUIRE(x && y && pixels > 0 && C > 0, "relu_to_channels: bad arguments");
+  GANK_REQUIRE(C % 8 == 0 && Cy % 8 == 0 && c_off % 8 == 0 && c_off + C <= Cy, "relu_to_channels: channels %d into [%d, %d) of %d: multiples of 8 inside the output", C, c_off, c_off + C, Cy);
+  const long total8 = pixels * (C / 8);
+  hipLaunchKernelGGL(relu_to_channels_kernel, g1(total8), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, total8, C, Cy, c_off);
+  GANK_LAUNCH_OK("relu_to_channels");
+  return 0;
+}

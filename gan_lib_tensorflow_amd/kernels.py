@@ -1071,6 +1071,26 @@ def resize_bilinear(x, out_hw):
     return y
 
 
+def pool2d(x, k, stride, pad, out_hw, mode, out=None, c_off=0):
+    """mode 'max' | 'avg' (average over the in-image elements); writes channels [c_off, c_off + C) of `out` when given"""
+    n, h, w, c = x.shape
+    if out is None:
+        out = torch.empty((n, out_hw[0], out_hw[1], c), dtype=BF16, device=x.device)
+    assert tuple(out.shape[:3]) == (n, out_hw[0], out_hw[1])
+    _lib.check(lib().gank_pool2d(_p(x, BF16, "x"), _p(out, BF16, "out"), n, h, w, c, out_hw[0], out_hw[1], k, stride, pad, 0 if mode == 'max' else 1,
+                                 out.shape[3], c_off, _stream()), "pool2d")
+    return out
+
+
+def relu_to_channels(x, out=None, c_off=0):
+    """out[..., c_off : c_off + C] = relu(x); a fresh tensor of x's shape when out is None"""
+    c = x.shape[-1]
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib().gank_relu_to_channels(_p(x, BF16, "x"), _p(out, BF16, "out"), x.numel() // c, c, out.shape[-1], c_off, _stream()), "relu_to_channels")
+    return out
+
+
 def concat_channels(a, b):
     ca, cb = a.shape[-1], b.shape[-1]
     assert a.shape[:-1] == b.shape[:-1], (a.shape, b.shape)

@@ -482,6 +482,13 @@ int gank_minibatch_std_fwd(const void* x, void* y, float* ws, int B, int HW, int
 int gank_minibatch_std_bwd(const void* dy, const void* x, float* ws, void* dx, int B, int HW, int C, void* stream);
 int gank_resize_bilinear(const void* x, void* y, int N, int Hi, int Wi, int Ho, int Wo, int C, void* stream);
 int gank_concat_channels(const void* a, const void* b, void* y, long pixels, int Ca, int Cb, void* stream);
+/* ---- Inception-v3 classifier of the Inception-score harness (common/inception/inception_score.py:29-47): its pooling layers
+ * and the branch concat.  pool2d: x [N,H,W,C] -> y[..., c_off : c_off + C] of [N,Ho,Wo,Cy]; mode 0 max, 1 average over the
+ * in-image elements of a k x k window (tf.nn.avg_pool SAME excludes the padding), stride 1 | 2, `pad` leading rows / columns.
+ * relu_to_channels: y[p, c_off : c_off + C] = relu(x[p, :]) -- a branch's last ReLU written into the block's concat output. */
+int gank_pool2d(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int k, int stride, int pad, int mode, int Cy, int c_off,
+                void* stream);
+int gank_relu_to_channels(const void* x, void* y, long pixels, int C, int Cy, int c_off, void* stream);
 int gank_split_channels(const void* y, void* a, void* b, long pixels, int Ca, int Cb, void* stream);
 int gank_l1_loss(const void* a, const void* b, float* loss, float* dl32, float* ws, long n, void* stream);
 int gank_dropout_fwd(const void* x, void* y, uint8_t* mask, long n, float keep, uint64_t* rng_state, void* stream);
