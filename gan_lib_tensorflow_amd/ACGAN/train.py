@@ -109,7 +109,8 @@ class ACGANTrainer:
         interp = K.lerp_rows(real, x_fake, alpha).requires_grad_(True)
         d_int, _ = m.get_discriminator(interp, real_labels, 'NO_OPS', reuse=True)
         ones = torch.ones_like(d_int)                       # tf.gradients(D(x_hat), [x_hat]): d(sum of logits)/d(x_hat)
-        (grads,) = torch.autograd.grad([d_int], [interp], [ones], create_graph=True)
+        with F2.input_gradient_only():       # the filter / bias / table gradients of this pass are not part of the penalty
+            (grads,) = torch.autograd.grad([d_int], [interp], [ones], create_graph=True)
         gp = F2.gradient_penalty(grads, 10.0)
         d_ac = Fn.softmax_xent(ac_real, real_labels)
         self.losses.update(d_loss_gan=d_gan.detach() + gp.detach(), d_loss_acgan=d_ac.detach(), gradient_penalty=gp.detach())

@@ -89,6 +89,25 @@ def _direct(p):
     return g
 
 
+# A backward pass that is wanted for its INPUT gradient only -- tf.gradients(D(x_hat), [x_hat]) inside the WGAN-GP term
+# (ACGAN/train.py:101-103).  autograd calls every node's backward with needs_input_grad as recorded at forward time (the
+# weights DO require gradients), so without this hint every layer of that pass also computes -- differentiably -- a filter
+# and bias gradient that nothing reads: 10 filter-gradient launches, 10 column sums and 20 zero fills per critic update.
+_dx_only = [False]
+
+
+class input_gradient_only:
+    """with input_gradient_only(): torch.autograd.grad(outputs, [activation], create_graph=True)"""
+
+    def __enter__(self):
+        self.prev, _dx_only[0] = _dx_only[0], True
+        return self
+
+    def __exit__(self, *exc):
+        _dx_only[0] = self.prev
+        return False
+
+
 class ConvF(Function):
     """y = conv2d_SAME(x, W) + b   (conv2d.py:180-187,212-216)"""
 
@@ -106,8 +125,8 @@ class ConvF(Function):
         x, W = ctx.saved_tensors
         dy = _c(dy)
         dx = ConvD.apply(dy, W) if ctx.needs_input_grad[0] else None
-        dW = _conv_wgrad(x, dy, W) if ctx.needs_input_grad[1] else None
-        db = _colsum(dy, ctx.bias) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dW = _conv_wgrad(x, dy, W) if (ctx.needs_input_grad[1] and not _dx_only[0]) else None
+        db = _colsum(dy, ctx.bias) if (ctx.has_bias and ctx.needs_input_grad[2] and not _dx_only[0]) else None
         return dx, dW, db
 
 
@@ -199,8 +218,8 @@ class LinF(Function):
         x, W = ctx.saved_tensors
         dy = _c(dy)
         dx = LinD.apply(dy, W) if ctx.needs_input_grad[0] else None
-        dW = _lin_wgrad(x, dy, W) if ctx.needs_input_grad[1] else None
-        db = _colsum(dy, ctx.bias) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dW = _lin_wgrad(x, dy, W) if (ctx.needs_input_grad[1] and not _dx_only[0]) else None
+        db = _colsum(dy, ctx.bias) if (ctx.has_bias and ctx.needs_input_grad[2] and not _dx_only[0]) else None
         return dx, dW, db
 
 
@@ -326,6 +345,7 @@ class BcastHW(Function):
 
 
 _zero_labels = {}
+_bnb_scratch = {}      # (device, C) -> fp32 [2, 1, C] rows the batch-norm backward may accumulate into when nobody wants the table gradients
 
 
 def _zl(x):
@@ -357,22 +377,34 @@ class BNF(Function):
             c = x.shape[-1]
             dx = K.cbn_bwd(_c(dy), x, x, _zl(x), gamma.detach().view(1, -1), stats.view(1, 2, c), tg.view(1, c), tb.view(1, c), 1, False)
             return dx, None, None
-        dx, dgamma, dbeta = BNB.apply(dy, x, gamma, stats)
-        return dx, dgamma, dbeta
+        # differentiated again (the gradient-penalty term): when this pass wants the input gradient only -- autograd.grad of the
+        # critic output w.r.t. the interpolates, ACGAN/train.py:101-103 -- the table gradients are neither zero-filled nor kept
+        want = (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not _dx_only[0]
+        dx, dgamma, dbeta = BNB.apply(dy, x, gamma, stats, want)
+        return dx, (dgamma if want else None), (dbeta if want else None)
 
 
 class BNB(Function):
     """first backward of BNF: (dx, dgamma, dbeta)"""
 
     @staticmethod
-    def forward(ctx, dy, x, gamma, stats):
+    def forward(ctx, dy, x, gamma, stats, want_tables=True):
         dy = _c(dy)
         c = x.shape[-1]
-        dgamma = torch.zeros((1, c), dtype=torch.float32, device=x.device)
-        dbeta = torch.zeros((1, c), dtype=torch.float32, device=x.device)
+        if want_tables:
+            dgamma = torch.zeros((1, c), dtype=torch.float32, device=x.device)
+            dbeta = torch.zeros((1, c), dtype=torch.float32, device=x.device)
+        else:
+            # the kernel accumulates its table gradients somewhere: a persistent scratch row that nobody reads (no fill launches)
+            key = (str(x.device), c)
+            if key not in _bnb_scratch:
+                _bnb_scratch[key] = torch.zeros((2, 1, c), dtype=torch.float32, device=x.device)
+            dgamma, dbeta = _bnb_scratch[key][0], _bnb_scratch[key][1]
         dx = K.cbn_bwd(dy, x, x, _zl(x), gamma.detach().view(1, -1), stats.view(1, 2, c), dgamma, dbeta, 1, False)
         ctx.save_for_backward(dy, x, gamma, stats)
         ctx.set_materialize_grads(False)
+        if not want_tables:
+            return dx, None, None
         return dx, dgamma.view(gamma.shape), dbeta.view(gamma.shape)
 
     @staticmethod
@@ -381,10 +413,14 @@ class BNB(Function):
         if g_dgamma is not None or g_dbeta is not None:
             raise NotImplementedError("second derivative through dgamma / dbeta: the gradient penalty only uses the input gradient")
         if g_dx is None:
-            return None, None, None, None
+            return None, None, None, None, None
+        tg = _direct(gamma)
+        if tg is not None:                       # the last pass: the kernel adds gamma's second-order term into .grad itself
+            gI, ggO = K.bn_bwd_bwd(_c(g_dx), dy, x, _c(gamma.detach().view(-1)), _c(stats.view(-1)), tg.view(-1))
+            return ggO, gI, None, None, None
         gG = torch.zeros(gamma.numel(), dtype=torch.float32, device=x.device)
         gI, ggO = K.bn_bwd_bwd(_c(g_dx), dy, x, _c(gamma.detach().view(-1)), _c(stats.view(-1)), gG)
-        return ggO, gI, gG.view(gamma.shape), None
+        return ggO, gI, gG.view(gamma.shape), None, None
 
 
 class GPLoss(Function):
