@@ -19,10 +19,10 @@ MI355X-first structure
 import contextlib
 import gc
 import math
-import os as _os
 
 import numpy as np
 import torch
+import torch.distributed as _dist
 
 from .. import functional as Fn
 from .. import kernels as K
@@ -99,22 +99,12 @@ def Generator(n_samples_, labels, noise=None, reuse=False, groups=1, rng_state=N
         return output.reshape(-1, OUTPUT_DIM)
 
 
-# The critic's kernels are small (128 samples: a few hundred workgroups, bound by latency and per-CU L2 bandwidth) and
-# leave most of the chip idle; the generator pass that produces the fakes of critic updates 2..N_CRITIC is independent
-# of critic update 1, so it CAN run beside it on a second HIP stream (one fork and one join inside the captured graph).
-# Measured (round 2, interleaved A/B in one gpurun call, 100 iterations each): 7.93-7.99 ms per iteration with the overlap
-# against 7.67 without -- the generator's one-workgroup-per-CU kernels push the critic's kernels off the CUs instead of
-# filling their gaps, and the split pass (64 + 256 samples) is less efficient than one pass over 320.  Kept as a knob
-# (GANK_OVERLAP_GEN=1), off by default.
-FUSE_OUTPUT_NORM = _os.environ.get("GANK_FUSE_OUTNORM", "1") == "1"    # no-grad passes: G.OutputNorm + relu inside G.Output's operand staging
-OVERLAP_GEN_WITH_CRITIC = False
+FUSE_OUTPUT_NORM = True    # no-grad passes: G.OutputNorm + relu inside G.Output's operand staging
 # Data parallel: the generator's gradient buffer (31.5 MB fp32) leaves in these buckets, last layers first, each as soon
 # as the backward pass has passed the block boundary below it (parallel.GradBuckets).  Forward / creation order.
 G_BUCKETS = (('G.Input/', 'G.Block.1.'), ('G.Block.2.',), ('G.Block.3.',), ('G.OutputNorm/', 'G.Output/'))
 BUCKETED_G_ALLREDUCE = True
-ONE_GRAPH_PER_ITERATION = _os.environ.get("GANK_ONE_GRAPH", "0") == "1"    # single replica: the whole iteration as one captured graph (measured 0.5 % SLOWER than 7 replays: five unrolled critic updates touch five sets of activation addresses instead of one warm set)
 BATCH_SMALL_WGRADS = True    # same-shape small filter gradients of an update are issued in one launch
-SIDE_STREAM_WGRAD = False    # filter gradients on a second HIP stream: measured 6 % SLOWER per iteration (the branches contend for L2 and CUs), kept for experiments
 
 
 def _d_prep_kind(name, W):
@@ -126,25 +116,24 @@ def _d_prep_kind(name, W):
         if Fn.CPOOL_RESIDENT and W.dim() == 4 and W.shape[3] == 128 and W.shape[2] % 128 == 0:
             return 5           # resident ConvMeanPool kernels (geometry of both critic layers: pooled 16x16 and 8x8)
         return 2
-    if Fn.FRAG_PATCH and name.endswith('D.Block.2.Conv1/Filters'):      # plain 3x3 256->256 at 16x16
-        return 3
     if blocks.FUSE_RES8 and W.dim() == 4 and tuple(W.shape) == (3, 3, 128, 128) and ('D.Block.3.' in name or 'D.Block.4.' in name):
         return 4                                                          # fused 8x8 residual blocks: "rfrag" operands
     return 0
 
 
 def _g_prep_kind(name, W):
-    """the three UpsampleConv 3x3 layers run phase-decomposed; the plain 3x3 convs at 16x16 / 32x32 get the
-    fragment-major operand copy of the register-weight patch kernel"""
+    """the UpsampleConv 3x3 layers run phase-decomposed; the first block's two convs (4x4 -> 8x8 and 8x8) take the
+    LDS-resident kernel and its fragment-major operands"""
+    if Fn.RES8_CONV and name.endswith(('G.Block.1.Conv1/Filters', 'G.Block.1.Conv2/Filters')) and W.dim() == 4 and W.shape[0] == 3 \
+            and W.shape[2] in (128, 256) and W.shape[3] % 128 == 0:
+        return 4
     if Fn.PHASE_UPCONV and name.endswith('.Conv1/Filters') and W.dim() == 4 and W.shape[0] == 3:
         return 1
-    if Fn.FRAG_PATCH and name.endswith(('G.Block.2.Conv2/Filters', 'G.Block.3.Conv2/Filters')):
-        return 3
     return 0
 
 
-LABEL_TABLE = _os.environ.get("GANK_LABEL_TABLE", "1") == "1"    # the critic's label branch through a per-label table (0: per-sample embedding + dense layer + tile)
-FUSED_HEAD = _os.environ.get("GANK_FUSED_HEAD", "1") == "1"      # D.Output + hinge loss (+ the layer's three gradients) as one launch where the train step asks for it
+LABEL_TABLE = True    # the critic's label branch through a per-label table (0: per-sample embedding + dense layer + tile)
+FUSED_HEAD = True      # D.Output + hinge loss (+ the layer's three gradients) as one launch where the train step asks for it
 
 
 def Discriminator(inputs, labels, update_collection=None, reuse=False, loss_head=None):
@@ -177,12 +166,10 @@ def Discriminator(inputs, labels, update_collection=None, reuse=False, loss_head
                 else:
                     output = Fn.concat_label(output, labels, emb_table, w_emb, b_emb)
             else:
-                with Fn.beside(inputs.device) as br:      # label embedding -> dense layer (:279-281) beside the first block
-                    embedding_y = _embedding.embed_y(labels, VOCAB_SIZE, EMBEDDING_DIM)
-                    embedding_y = _linear.Linear(embedding_y, EMBEDDING_DIM, DIM_D, 'D.Embedding_y', spectral_normed=True,
-                                                 update_collection=update_collection, biases=True)
+                embedding_y = _embedding.embed_y(labels, VOCAB_SIZE, EMBEDDING_DIM)       # label embedding -> dense layer (:279-281)
+                embedding_y = _linear.Linear(embedding_y, EMBEDDING_DIM, DIM_D, 'D.Embedding_y', spectral_normed=True,
+                                             update_collection=update_collection, biases=True)
                 output = OptimizedResBlockDisc1(output, spectral_normed=True, update_collection=update_collection, biases=True)
-                Fn.join_beside(br, embedding_y)
                 output = Fn.concat_tile(output, embedding_y)               # expand_dims x2 + tile + concat (:282-284)
             output = ResidualBlock(output, DIM_D * 2, DIM_D, 3, 'D.Block.2', spectral_normed=True,
                                    update_collection=update_collection, resample='down', labels=labels, biases=True, prefork=prefork)
@@ -289,22 +276,17 @@ class SNGANTrainer:
         self.loss_scale = float(loss_scale)
         assert self.loss_scale > 0 and math.log2(self.loss_scale) == int(math.log2(self.loss_scale)), "loss_scale must be a power of two"
         self.dp = process_group is not None          # the data-parallel path (also for a world-size-1 group: rehearsal / --force-dp)
-        self.capture_collectives = capture_collectives
+        # only RCCL collectives are stream-ordered device work that a hipGraph can hold; gloo (the CPU rehearsal backend)
+        # synchronises the stream from the host, which a capture must never see
+        self.capture_collectives = bool(capture_collectives and process_group is not None
+                                        and _dist.get_backend(process_group) == "nccl")
         self.grad_wire_dtype = K.BF16 if grad_wire_dtype in ('bf16', 'fp16', '16') else None
         self._g_buckets = None
         # world > 1: the generator's gradients leave in buckets beside the backward pass; `bucketed` forces that path for a
         # single rank too (tests: same arithmetic as the one-piece update)
         self.bucketed = BUCKETED_G_ALLREDUCE and process_group is not None
-        self.side_stream = SIDE_STREAM_WGRAD
-        self._side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         # data-side RNG differs per rank; parameter init (store seed) is identical on all ranks
         self.rng_state = K.new_rng_state(parallel.data_seed(seed, self.rank), self.device)
-        # the generator pass that runs BESIDE a critic update draws from its own stream of random numbers (two kernels
-        # advancing one {seed, offset} pair concurrently would race)
-        self.rng_state_gen = K.new_rng_state(parallel.data_seed(seed, self.rank) + 104729, self.device)
-        import os
-        self.overlap_gen = (OVERLAP_GEN_WITH_CRITIC if os.environ.get("GANK_OVERLAP_GEN") is None else os.environ["GANK_OVERLAP_GEN"] == "1") \
-            and self.device.type == "cuda"
         self.iteration = 0
         self._build(state)
         self._graphs = {}
@@ -368,7 +350,6 @@ class SNGANTrainer:
             sd[net + '/adam_t'] = np.asarray(int(opt.t.item()), dtype=np.int64)
         sd['_iteration'] = np.asarray(int(self.iteration), dtype=np.int64)
         sd['_rng_state'] = self.rng_state.detach().cpu().numpy().copy()
-        sd['_rng_state_gen'] = self.rng_state_gen.detach().cpu().numpy().copy()
         return sd
 
     def load_state_dict(self, state, strict=True):
@@ -393,8 +374,6 @@ class SNGANTrainer:
             self.iteration_dev.fill_(self.iteration)
             if '_rng_state' in extra:
                 self.rng_state.copy_(torch.from_numpy(np.asarray(extra['_rng_state'], np.int64)).to(self.device))
-            if '_rng_state_gen' in extra:
-                self.rng_state_gen.copy_(torch.from_numpy(np.asarray(extra['_rng_state_gen'], np.int64)).to(self.device))
             self.feed_slot.zero_()
         self._refresh_g_prep()
         self._graphs.clear()
@@ -466,24 +445,6 @@ class SNGANTrainer:
         return logits
 
     @torch.no_grad()
-    def _generate_slots(self, lo, hi, rng_state):
-        """fakes of critic updates lo..hi-1 of this iteration (one generator pass, towers of B/N_TOWERS samples)"""
-        set_default_store(self.store)
-        n = (hi - lo) * self.batch
-        fake = Generator(n, self.labels_all[lo:hi].reshape(-1), groups=(hi - lo) * N_TOWERS, rng_state=rng_state)
-        K.copy_(self.fake_all[lo:hi], fake)
-
-    def _d_first_with_generator_beside(self):
-        """Critic update 1 of the iteration with the generator pass for updates 2..N_CRITIC on the side stream."""
-        main = torch.cuda.current_stream()
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
-            self._generate_slots(1, N_CRITIC, self.rng_state_gen)
-        out = self._d_forward_backward_prefetched()
-        main.wait_stream(self._side)
-        return out
-
-    @torch.no_grad()
     def _generate_for_critic(self):
         """The generator is frozen during the N_CRITIC critic updates of an iteration (:599-620), so their
         fakes are ONE generator pass over N_CRITIC*B samples: each update's N_TOWERS towers keep their own
@@ -521,19 +482,16 @@ class SNGANTrainer:
         return logits
 
     def _backward(self, loss):
-        """loss.backward() with the filter gradients on the side stream, joined before anything reads them."""
+        """loss.backward() with the small filter gradients deferred and issued in batches, before anything reads them."""
         Fn.reset_deferred()
-        Fn.set_wgrad_stream(self._side if self.side_stream else None)
         Fn.BATCH_SMALL_WGRADS = BATCH_SMALL_WGRADS
         try:
             # the gradient seed is a persistent tensor: loss.backward() alone launches a ones_like fill per update
             loss.backward(gradient=Fn.grad_seed(loss, self.loss_scale))
             Fn.join_wgrad()
-            Fn.join_beside_backward()
         finally:
             Fn.reset_deferred()      # empty after a clean join; after an exception: nothing stale survives
             Fn.BATCH_SMALL_WGRADS = False
-            Fn.set_wgrad_stream(None)
 
     # ---- data parallel generator update: segmented backward, bucketed all-reduce beside it ---------------------------
     def _g_phases(self):
@@ -786,44 +744,13 @@ class SNGANTrainer:
             for i, (data, labels) in enumerate(feed):
                 self.real_all[i].copy_(data, non_blocking=True)
                 self.labels_all[i].copy_(labels, non_blocking=True)
-        if ONE_GRAPH_PER_ITERATION and self.world == 1 and self.use_graphs and not self.overlap_gen and not self.bucketed:
-            # a single replica exchanges nothing between the updates: the generator update, the generator pass for the critic's
-            # fakes, the N_CRITIC critic updates and the iteration counter are ONE captured graph (7 graph launches of ~8.5 us
-            # launch gap each become 1); iteration 0 has no generator update and gets a graph of its own
-            self._ensure_clean(self.g_flat)
-            self._ensure_clean(self.d_flat)
-            if self.iteration > 0:
-                self._run_plain('iter', self._whole_iteration)
-            else:
-                self._run_plain('iter0', self._iteration_tail)
-            self.iteration += 1
-            return
         if self.iteration > 0:
             self.g_step()
-        if self.overlap_gen and N_CRITIC > 1:
-            self._run_plain('gen1', lambda: self._generate_slots(0, 1, self.rng_state_gen))
-            self._run('d_first', self._d_first_with_generator_beside, self.d_opt, self.d_flat)
-            for i in range(1, N_CRITIC):
-                self._run('d_pre', self._d_forward_backward_prefetched, self.d_opt, self.d_flat)
-        else:
-            self._run_plain('gen5', self._generate_for_critic)
-            for i in range(N_CRITIC):      # slot i of the feed ring: the device-side slot counter walks 0..N_CRITIC-1
-                self._run('d_pre', self._d_forward_backward_prefetched, self.d_opt, self.d_flat)
+        self._run_plain('gen5', self._generate_for_critic)
+        for i in range(N_CRITIC):      # slot i of the feed ring: the device-side slot counter walks 0..N_CRITIC-1
+            self._run('d_pre', self._d_forward_backward_prefetched, self.d_opt, self.d_flat)
         self.iteration += 1
         K.counter_add(self.iteration_dev, 1)
-
-    def _iteration_tail(self):
-        """generator pass for the critic's fakes + N_CRITIC critic updates + the iteration counter (one replica: no exchange)"""
-        self._generate_for_critic()
-        for _ in range(N_CRITIC):
-            self._d_forward_backward_prefetched()
-            self.d_opt.apply()
-        K.counter_add(self.iteration_dev, 1)
-
-    def _whole_iteration(self):
-        self._g_forward_backward()
-        self._g_apply()
-        self._iteration_tail()
 
     @torch.no_grad()
     def dev_disc_cost(self, real_u8, labels, z=None, real_pre=None):

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, os.environ.get("GANK_LIB_NAME", "libgank.so" if D
 P, I, L, F = C.c_void_p, C.c_int, C.c_long, C.c_float
 
 # flags (include/gank.h)
-IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, W_FRAG, RES_UPSAMPLE2X, STATS_PREZEROED = 1, 2, 4, 8, 32, 64, 256
+IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, RES_UPSAMPLE2X, STATS_PREZEROED, OUT_POOLSUM2X = 1, 2, 4, 8, 64, 256, 512
 STAT_SLOTS = 16   # GANK_STAT_SLOTS
 
 
@@ -72,6 +72,7 @@ PROTOTYPES = {
     "gank_conv2d_general_wgrad": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     "gank_res8_chain_fwd": [P, P, P, P, P, P, I, I, I, P],
     "gank_res8_chain_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "gank_res8_conv3x3": [P, P, P, P, P, I, I, I, I, P, I, P],
     "gank_cpool_res_fprop": [P, P, P, P, P, I, I, I, I, I, I, P],
     "gank_cpool_res_dgrad": [P, P, P, P, I, I, I, I, I, P],
     "gank_deconv2d_prep_phases": [P, P, I, I, I, P],

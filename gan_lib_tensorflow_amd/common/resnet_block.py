@@ -30,10 +30,9 @@ DIM_D = 128
 COMMUTE_1X1 = True
 # the commuted 'up' shortcut stays at half resolution and is added, upsampled on the fly, in conv_2's epilogue
 FUSE_SHORTCUT_UPSAMPLE = True
-import os as _os
-FUSE_FORK_POOL = _os.environ.get("GANK_FORK_POOL", "1") == "1"   # down blocks: fan-out and shortcut pool as one op (one unpool-add launch backward)
-FUSE_LABEL_FORK = _os.environ.get("GANK_LABEL_FORK", "1") == "1"   # critic: label concat + the next block's fan-out (fork_pool) as one op each way
-FUSE_POOL_GATHER = _os.environ.get("GANK_POOL_GATHER", "1") == "1"   # first critic block: the shortcut's 2x2 mean inside its 1x1 conv's gather
+FUSE_FORK_POOL = True   # down blocks: fan-out and shortcut pool as one op (one unpool-add launch backward)
+FUSE_LABEL_FORK = True   # critic: label concat + the next block's fan-out (fork_pool) as one op each way
+FUSE_POOL_GATHER = True   # first critic block: the shortcut's 2x2 mean inside its 1x1 conv's gather
 FUSE_IDENTITY_SHORTCUT_GRAD = True   # identity shortcut: its gradient is added by conv_1's input-gradient kernel
 
 

@@ -23,7 +23,6 @@
 #endif
 #define IG_IN_ZEROINS2X 16
 #define IG_IN_STRIDE2 32
-#define IG_W_FRAG 64          // the operand buffer carries the fragment-major copy (public GANK_W_FRAG)
 #define IG_RES_UP2X 128       // residual is [N,H/2,W/2,Cout]: read at (oh>>1, ow>>1) (public GANK_RES_UPSAMPLE2X)
 
 struct IgemmArgs {
@@ -61,8 +60,7 @@ struct IgemmArgs {
 };
 
 static int phase_inner_env() {
-  static int v = -1;   // experiment knob: GANK_PHASE_INNER=0 restores the phase-slowest block order
-  if (v < 0) { const char* e = getenv("GANK_PHASE_INNER"); v = e ? atoi(e) : 1; }
+  static const int v = gank_tune("GANK_PHASE_INNER", 1);   // experiment knob: GANK_PHASE_INNER=0 restores the phase-slowest block order
   return v;
 }
 
@@ -126,7 +124,7 @@ __device__ __forceinline__ void epi_tile_wide(const f32x16& acc, float scale, co
     bf16x8 out;
 #pragma unroll
     for (int e = 0; e < 8; e++) out[e] = f2bf(otanh ? tanhf(v[e]) : v[e]);
-    store_out(reinterpret_cast<bf16x8*>(y_px + c), out);
+    *reinterpret_cast<bf16x8*>(y_px + c) = out;
   }
 }
 
@@ -455,7 +453,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
           bf16x4 out;
 #pragma unroll
           for (int e = 0; e < 4; e++) out[e] = f2bf(otanh ? tanhf(v[e]) : v[e]);
-          store_out(reinterpret_cast<bf16x4*>(a.y + o), out);
+          *reinterpret_cast<bf16x4*>(a.y + o) = out;
         } else {
 #pragma unroll
           for (int e = 0; e < 4; e++) {
@@ -764,162 +762,8 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; e++) out[e] = f2bf(v[e]);
         }
-        store_out(reinterpret_cast<bf16x4*>(a.y + o), out);
+        *reinterpret_cast<bf16x4*>(a.y + o) = out;
       }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Second-generation patch kernel for plain 3x3 / stride 1 / SAME convolutions with H % 16 == 0, W % 16 == 0,
-// Cin % 64 == 0, Cout % 128 == 0 and a fragment-major weight copy (prep kind 3).
-// The PMC picture of conv_igemm_patch_kernel (profiles/, round 1): MFMA pipe 32 % busy, LDS 34 % busy -- neither
-// saturated; the waves sit at the per-tap barrier (one every 16 MFMAs per wave) and in LDS latency behind it.
-// Here one block owns a 16x16 output patch x 128 couts and each wave a 128-pixel x 64-cout tile (4 x 2 MFMA tiles):
-//   * weights never touch LDS: every wave loads its A fragments straight from L2 into a 3-step register ring (one
-//     coalesced 1 KB request per fragment); no weight ds_writes, no weight ds_reads, and no barrier per tap;
-//   * the 18x18 halo of the next 64-channel chunk is staged piecewise (1/9 per tap-step) into the OTHER LDS buffer,
-//     so there is ONE barrier per 9 tap-steps = 288 MFMAs per wave;
-//   * LDS traffic is the B operand only: 4 fragment reads per 8 MFMAs (0.5 KB per MFMA, was 1 KB + weight writes).
-// One block per CU (93 KB LDS), one wave per SIMD: latency is hidden inside the wave by the register ring and by
-// hipcc hoisting the next kk's ds_reads above the current MFMAs (8 independent accumulator tiles).
-// ------------------------------------------------------------------------------------------------------
-constexpr int P2HALO = 18 * 18;   // halo pixels of a 16x16 patch
-
-template <int MODE>   // bit0: relu on the input operand
-__global__ __launch_bounds__(256) void conv_igemm_patch2_kernel(IgemmArgs a) {
-  constexpr int NT = 256, BN = 128, PFW = 3;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16* sP = reinterpret_cast<bf16*>(smem);             // [2][18][HROWP]  (pixel stride LROW inside a halo row)
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wave_m = wave & 1, wave_n = wave >> 1;      // 2 x 2 waves, each 128 pixels (8 patch rows) x 64 couts
-  const int r = lane & 31, h = lane >> 5;
-
-  const int nwg = a.tiles_m * a.tiles_n;
-  const int lid = xcd_remap(blockIdx.x, nwg);
-  const int tile_n = lid % a.tiles_n, tile_m = lid / a.tiles_n;
-  const int pw = a.W >> 4, ph = a.H >> 4;
-  const int n = tile_m / (pw * ph), pr = tile_m - n * pw * ph;
-  const int py0 = (pr / pw) << 4, px0 = (pr % pw) << 4;
-
-  constexpr int OOB = 0x7FFFFFF0;
-  const int nsteps = a.nsteps;                          // 9 * Cin / 64
-  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, a.N * a.H * a.W * a.Cin * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w) + (long)a.CoutPad * a.Kpad, 0,
-                                                                        a.CoutPad * a.Kpad * 2, 0x00020000);
-
-  // ---- halo pieces: 2592 16-byte chunks per 64-channel slab, 288 per tap-step (thread: chunk tid, and 256+tid < 288)
-  auto halo_off = [&](int q, int& lds) -> int {         // q in [0, 2592): byte offset in x of chunk q (or OOB), LDS element offset
-    const int hp = q >> 3, cc = q & 7;
-    const int hy = hp / 18, hx = hp - hy * 18;
-    const int iy = py0 - 1 + hy, ix = px0 - 1 + hx;
-    lds = hy * HROWP + hx * LROW + cc * 8;
-    const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-    return ok ? (((n * a.H + iy) * a.W + ix) * a.Cin + cc * 8) * 2 : OOB;
-  };
-  u32x4 rH[2];
-  int hl[2];
-  auto load_piece = [&](int piece, int c) {              // piece 0..8 of the slab of chunk c
-    const int q0 = piece * 288 + tid;
-    int off = halo_off(q0, hl[0]);
-    rH[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off == OOB ? OOB : off + c * 128, 0, 0);
-    if (tid < 32) {
-      off = halo_off(q0 + 256, hl[1]);
-      rH[1] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off == OOB ? OOB : off + c * 128, 0, 0);
-    }
-  };
-  auto store_piece = [&](int buf) {
-    u32x4 v = rH[0];
-    if constexpr ((MODE & 1) != 0) v = relu_bf16x8(v);
-    *reinterpret_cast<u32x4*>(sP + buf * 18 * HROWP + hl[0]) = v;
-    if (tid < 32) {
-      u32x4 v1 = rH[1];
-      if constexpr ((MODE & 1) != 0) v1 = relu_bf16x8(v1);
-      *reinterpret_cast<u32x4*>(sP + buf * 18 * HROWP + hl[1]) = v1;
-    }
-  };
-
-  // ---- weight fragments: [32-cout tile][K-step][kk][lane][8] (prep kind 3); this wave's two tiles, 4 kk each
-  const int T0 = tile_n * (BN / 32) + wave_n * 2;
-  const int wv0 = lane * 16;                              // + kk * 1024 (folded into the instruction offset)
-  const int wv1 = wv0 + nsteps * 4096;                    // second cout tile
-  u32x4 rW[PFW][2][4];
-  auto load_w = [&](u32x4 (&dst)[2][4], int step) {
-    // wave-uniform by construction (wave index, tile index): tell the compiler, or every load becomes a waterfall loop
-    const int so = __builtin_amdgcn_readfirstlane((T0 * nsteps + (step < nsteps ? step : nsteps - 1)) * 4096);
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-      dst[0][kk] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wv0 + kk * 1024, so, 0);
-      dst[1][kk] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wv1 + kk * 1024, so, 0);
-    }
-  };
-
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
-
-  // B-fragment base of this lane in the halo image: pixel (wave_m*8 + 2j + (r>>4), r&15), centre tap
-  int pb[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) pb[j] = (wave_m * 8 + 2 * j + (r >> 4) + 1) * HROWP + ((r & 15) + 1) * LROW + h * 8;
-
-  // prologue: slab 0 into buffer 0, the first PFW weight steps into the ring
-#pragma unroll 1
-  for (int p = 0; p < 9; p++) { load_piece(p, 0); store_piece(0); }
-#pragma unroll
-  for (int d = 0; d < PFW; d++) load_w(rW[d], d);
-  __syncthreads();
-
-  const int nchunks = a.Cin >> 6;
-#pragma unroll 1
-  for (int c = 0; c < nchunks; c++) {
-    const int cur = c & 1;
-    const bool more = c + 1 < nchunks;
-    const bf16* sH = sP + cur * 18 * HROWP;
-    // 36 stages (tap, kk) per slab; the B fragments of stage t+1 are requested before the MFMAs of stage t
-    bf16x8 fb[2][4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) fb[0][j] = *reinterpret_cast<const bf16x8*>(sH + pb[j] - HROWP - LROW);
-#pragma unroll
-    for (int t = 0; t < 36; t++) {
-      const int tap = t >> 2, kk = t & 3;
-      if (kk == 0 && more) load_piece(tap, c + 1);       // lands while this tap's MFMAs run
-      if (t + 1 < 36) {
-        const int tn = (t + 1) >> 2, kn = (t + 1) & 3;
-        const int toff = (tn / 3 - 1) * HROWP + (tn % 3 - 1) * LROW + kn * 16;
-#pragma unroll
-        for (int j = 0; j < 4; j++) fb[(t + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(sH + pb[j] + toff);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; i++) {
-        const bf16x8 fa = __builtin_bit_cast(bf16x8, rW[tap % PFW][i][kk]);
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = GANK_MFMA32(fa, fb[t & 1][j], acc[i][j]);
-      }
-      if (kk == 3) {
-        load_w(rW[tap % PFW], c * 9 + tap + PFW);        // this slot is consumed: refill it PFW steps ahead
-        if (more) store_piece(cur ^ 1);
-      }
-    }
-    __syncthreads();     // next slab complete, everyone is done reading this one
-  }
-
-  // epilogue: 16-byte pieces (Cout % 128 == 0 here)
-  const bool otanh = (a.flags & GANK_OUT_TANH) != 0;
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int py = wave_m * 8 + 2 * j + (r >> 4), px = r & 15;
-    const long m = ((long)(n * a.H + py0 + py)) * a.W + px0 + px;
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      const int ct = tile_n * BN + (wave_n * 2 + i) * 32;
-      epi_tile_wide<false>(acc[i][j], a.scale, a.bias ? a.bias + ct : nullptr, a.mask ? a.mask + m * a.Cout + ct : nullptr,
-                           a.res ? a.res + m * a.Cout + ct : nullptr, a.y + m * a.Cout + ct, h, otanh, nullptr);
     }
   }
 }
@@ -941,24 +785,8 @@ static int launch_patch_phase(const IgemmArgs& a0, hipStream_t s) {
   return 0;
 }
 static bool patch_phase_ok(const IgemmArgs& a) {   // a.H, a.W = low-res grid; a.Cin % 64 == 0 is checked by the callers
-  static int env = -1;   // GANK_IGEMM_PATCH_PHASE=0 keeps the per-tap phase kernel
-  if (env < 0) { const char* e = getenv("GANK_IGEMM_PATCH_PHASE"); env = e ? atoi(e) : 1; }
+  static const int env = gank_tune("GANK_IGEMM_PATCH_PHASE", 1);   // GANK_IGEMM_PATCH_PHASE=0 keeps the per-tap phase kernel
   return env && a.W % 16 == 0 && a.H % 8 == 0 && a.CoutPad % 128 == 0 && a.Cout % 4 == 0 && a.Cin % 64 == 0;
-}
-
-template <int MODE>
-static int launch_patch2(const IgemmArgs& a0, hipStream_t s) {
-  IgemmArgs a = a0;
-  a.tiles_m = a.N * (a.H / 16) * (a.W / 16);
-  a.tiles_n = a.CoutPad / 128;
-  const size_t lds = (size_t)2 * 18 * HROWP * sizeof(bf16);
-  auto kern = conv_igemm_patch2_kernel<MODE>;
-  GANK_MAX_DYNAMIC_LDS(kern, (int)lds, "conv_igemm_patch2");
-  static const std::string tag = gank_format("conv_igemm_patch2_kernel<%d>", MODE);     // magic static: built once, thread-safe
-  gank_prof_tag(0, tag.c_str());
-  hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
-  GANK_LAUNCH_OK("conv_igemm_patch2");
-  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1078,7 +906,7 @@ __global__ __launch_bounds__(256) void conv_narrow_in_kernel(IgemmArgs a) {
         bf16x4 out;
 #pragma unroll
         for (int e = 0; e < 4; e++) out[e] = f2bf(otanh ? tanhf(v[e]) : v[e]);
-        store_out(reinterpret_cast<bf16x4*>(a.y + o), out);
+        *reinterpret_cast<bf16x4*>(a.y + o) = out;
       }
     }
   }
@@ -1454,7 +1282,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
       }
       bf16* line = a.y + m * a.Cout + tile_n * 256 + wn * 64 + (kc & 1) * 16 + 8 * (kc >> 1);
 #pragma unroll
-      for (int P = 0; P < 2; P++) store_out(reinterpret_cast<bf16x8*>(line + 32 * P), outl[P]);
+      for (int P = 0; P < 2; P++) *reinterpret_cast<bf16x8*>(line + 32 * P) = outl[P];
     }
     if constexpr (STATS) {
       // a 16-lane row holds 16 pixels of the same 16 channels (2 pairs x 8): DPP row sums, lane p16 keeps channel p16
@@ -1541,7 +1369,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
 #pragma unroll
       for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int q = 0; q < 2; q++) store_out(reinterpret_cast<bf16x8*>(line + i * 32 + 16 * q), outl[i][q]);
+        for (int q = 0; q < 2; q++) *reinterpret_cast<bf16x8*>(line + i * 32 + 16 * q) = outl[i][q];
     }
     if constexpr (STATS) {
 #pragma unroll
@@ -1580,15 +1408,13 @@ __global__ void ig_zero_kernel(float* __restrict__ p, int n) {
 static void stats_zero(const IgemmArgs& a, hipStream_t s);
 // 128x128 tiles from this many tiles on; fewer run as 64x64 (4x the workgroups: the grid rounds better on 256 CUs)
 static int t128_min() {
-  static int v = -1;   // experiment knob
-  if (v < 0) { const char* e = getenv("GANK_IGEMM_T128_MIN"); v = e ? atoi(e) : 192; }
+  static const int v = gank_tune("GANK_IGEMM_T128_MIN", 192);   // experiment knob
   return v;
 }
 // generic kernel with the statistics epilogue: every pixel tile full and inside one tower, every channel tile full
 // (a.M, a.H, a.W: the grid the tiles walk -- the low-resolution grid in phase mode)
 static bool igemm_stats_ok(const IgemmArgs& a, int BM, int BN) {
-  static int env = -1;   // experiment knob: GANK_IGEMM_STATS=0 leaves the statistics to the batch-norm kernels
-  if (env < 0) { const char* e = getenv("GANK_IGEMM_STATS"); env = e ? atoi(e) : 1; }
+  static const int env = gank_tune("GANK_IGEMM_STATS", 1);   // experiment knob: GANK_IGEMM_STATS=0 leaves the statistics to the batch-norm kernels
   return env && a.stat_sums != nullptr && !(a.flags & GANK_OUT_TANH) && a.M % BM == 0 && a.Cout % BN == 0 &&
          ((long)a.stat_n_per_group * a.H * a.W) % BM == 0;
 }
@@ -1616,8 +1442,7 @@ static int launch_pp(const IgemmArgs& a0, hipStream_t s) {
 // geometry both PP forms need (H, W = the grid the patches tile: the output for a plain conv, the low-res grid in phase mode)
 static int pp_patch_width(int H, int W) { return (W % 32 == 0 && H % 8 == 0) ? 32 : (W % 16 == 0 && H % 16 == 0) ? 16 : 0; }
 static int pp_env() {          // GANK_IGEMM_PP: 0 off, 1 32-wide patches of plain convs only, 2 (default) every form
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("GANK_IGEMM_PP"); v = e ? atoi(e) : 2; }
+  static const int v = gank_tune("GANK_IGEMM_PP", 2);
   return v;
 }
 // One 512-thread block per CU: below ~a full round of blocks the 128-wide kernels (2-3 blocks per CU) fill the chip better
@@ -1738,22 +1563,15 @@ int gank_igemm_dispatch(IgemmArgs a, hipStream_t s) {
                                       (a.res ? (double)a.M * a.Cout / ((a.flags & IG_RES_UP2X) ? 4.0 : 1.0) : 0.0) + (a.mask ? (double)a.M * a.Cout : 0.0)));
   int rc;
   const long tiles128 = (long)cdiv(a.M, 128) * (a.CoutPad / 128);
-  static int ko_env = -1;
-  if (ko_env < 0) { const char* e = getenv("GANK_IGEMM_KORDER"); ko_env = e ? atoi(e) : 0; }
+  static const int ko_env = gank_tune("GANK_IGEMM_KORDER", 0);
   a.korder = ko_env;
-  static int pf_env = -1;   // experiment knob: GANK_IGEMM_PF=1|2|3 overrides the prefetch depth
-  if (pf_env < 0) { const char* e = getenv("GANK_IGEMM_PF"); pf_env = e ? atoi(e) : 0; }
-  static int patch_env = -1;   // experiment knob: GANK_IGEMM_PATCH=0 disables the LDS-patch kernel
-  if (patch_env < 0) { const char* e = getenv("GANK_IGEMM_PATCH"); patch_env = e ? atoi(e) : 1; }
+  static const int pf_env = gank_tune("GANK_IGEMM_PF", 0);   // experiment knob: GANK_IGEMM_PF=1|2|3 overrides the prefetch depth
+  static const int patch_env = gank_tune("GANK_IGEMM_PATCH", 1);   // experiment knob: GANK_IGEMM_PATCH=0 disables the LDS-patch kernel
   const bool patch_geom = patch_env && !packed && a.ks == 3 && a.pad == 1 &&
                           !(a.flags & (GANK_IN_UPSAMPLE2X | IG_IN_ZEROINS2X | IG_IN_STRIDE2)) &&
                           a.W % 16 == 0 && a.H % 8 == 0 && a.Hin == a.H && a.Win == a.W;
   const bool patch_ok = patch_geom && (a.Cout % 4) == 0 && a.CoutPad % 128 == 0;
   const bool patch32_ok = patch_geom && a.CoutPad == 32;
-  static int patch2_env = -1;  // experiment knob: GANK_IGEMM_PATCH2=0 disables the register-weight patch kernel
-  if (patch2_env < 0) { const char* e = getenv("GANK_IGEMM_PATCH2"); patch2_env = e ? atoi(e) : 1; }
-  const bool patch2_ok = patch_ok && patch2_env && !(a.flags & IG_RES_UP2X) && (a.flags & IG_W_FRAG) && a.W % 16 == 0 && a.H % 16 == 0 && a.Cout % 128 == 0 &&
-                         a.Kpad == a.taps * a.Cin && (long)a.CoutPad * a.Kpad * 2 < (1L << 30);
   const bool narrow_ok = !(a.flags & IG_RES_UP2X) && a.Cin == 3 && (a.ks == 1 || a.ks == 3) && a.pad == (a.ks - 1) / 2 && a.CoutPad % 128 == 0 && a.Cout % 4 == 0 &&
                          !(a.flags & (GANK_IN_UPSAMPLE2X | IG_IN_ZEROINS2X | IG_IN_STRIDE2)) && a.Hin == a.H && a.Win == a.W;
   const bool pp_ok = pp_env() && patch_geom && a.Cout % 256 == 0 && a.Kpad == a.taps * a.Cin && pp_enough_blocks(a, 1) &&
@@ -1764,8 +1582,6 @@ int gank_igemm_dispatch(IgemmArgs a, hipStream_t s) {
     const bool relu = (a.flags & GANK_IN_RELU) != 0;
     if (pp_patch_width(a.H, a.W) == 32) rc = relu ? launch_pp<1, 32>(a, s) : launch_pp<0, 32>(a, s);
     else rc = relu ? launch_pp<1, 16>(a, s) : launch_pp<0, 16>(a, s);
-  } else if (patch2_ok) {
-    rc = (a.flags & GANK_IN_RELU) ? launch_patch2<1>(a, s) : launch_patch2<0>(a, s);
   } else if (patch_ok) {
     rc = (a.flags & GANK_IN_RELU) ? launch_patch<1, 128>(a, s) : launch_patch<0, 128>(a, s);
   } else if (patch32_ok) {
@@ -1824,7 +1640,7 @@ static int conv2d_fprop_impl(const void* x, const void* wf, const float* bias, c
   const bool up = flags & GANK_IN_UPSAMPLE2X;
   a.Hin = up ? H / 2 : H; a.Win = up ? W / 2 : W;
   a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.pad = (ksize - 1) / 2;
-  a.flags = (flags & (GANK_IN_UPSAMPLE2X | GANK_IN_RELU | GANK_OUT_TANH)) | ((flags & GANK_W_FRAG) ? IG_W_FRAG : 0) |
+  a.flags = (flags & (GANK_IN_UPSAMPLE2X | GANK_IN_RELU | GANK_OUT_TANH)) |
             ((flags & GANK_RES_UPSAMPLE2X) ? IG_RES_UP2X : 0);
   GANK_REQUIRE(!(flags & GANK_RES_UPSAMPLE2X) || (residual && H % 2 == 0 && W % 2 == 0), "conv2d_fprop: RES_UPSAMPLE2X needs a residual and even output size");
   a.scale = scale;
@@ -1905,7 +1721,7 @@ extern "C" int gank_conv2d_dgrad(const void* dy, const void* wd, const void* res
   const bool up = flags & GANK_IN_UPSAMPLE2X;
   a.Hin = up ? H / 2 : H; a.Win = up ? W / 2 : W;
   a.Cin = Cout; a.Cout = Cin; a.ks = ksize; a.pad = (ksize - 1) / 2;
-  a.flags = (flags & (GANK_IN_UPSAMPLE2X | GANK_IN_RELU)) | ((flags & GANK_W_FRAG) ? IG_W_FRAG : 0);
+  a.flags = (flags & (GANK_IN_UPSAMPLE2X | GANK_IN_RELU));
   a.scale = scale;
   return gank_igemm_dispatch(a, (hipStream_t)stream);
 }

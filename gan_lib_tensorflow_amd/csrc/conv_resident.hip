@@ -297,8 +297,7 @@ __global__ __launch_bounds__(512 / TPW) void res8_chain_bwd_kernel(ResBwdArgs a)
 
 // ---- host side ---------------------------------------------------------------------------------------------------
 static int res8_cfg() {          // experiment knob GANK_RES8_CFG = 10*TPW + {1: 8, 2: 12, 3: 24 fragments in flight}: 12 = 8 waves, 12 in flight (default)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("GANK_RES8_CFG"); v = e ? atoi(e) : 12; }
+  static const int v = gank_tune("GANK_RES8_CFG", 12);
   return v;
 }
 template <int TPW, int PF>
@@ -720,5 +719,253 @@ extern "C" int gank_cpool_res_dgrad(const void* dy, const void* w_rfrag, const v
   }
   gank_prof_end(0, s);
   GANK_LAUNCH_OK("cpool_res_dgrad");
+  return 0;
+}
+
+// ==================================================================================================================
+// 3x3 SAME convolution on 8x8 images with C = 256 (or 128) input channels, one image per workgroup: the generator's first
+// block (gan_cifar_resnet.py:179-207 with resample='up' at 4x4 -> 8x8: Conv1 = NN-upsample + 3x3, Conv2 = 3x3) and their
+// input gradients.  These layers are 2048-8192 pixels against 2.4 MB of weights: on the generic gather they ran at
+// 0.12-0.4 PFLOP/s (one dependent global -> LDS round trip and a barrier per 64-deep K-step, 16-36 K-steps per block).
+// Here, as in the critic's chain above: the image (+ zero halo) is staged ONCE -- the NN-upsample is done by the loader, so
+// UpsampleConv needs no phase operands --, the weights stream from L2 in MFMA-fragment order ("rfrag", prep kind 4), a ring
+// of 12 one-KB requests in flight per wave, no barrier inside the conv.  A workgroup = 1 image x 128 output channels
+// (4 waves x 32 channels x two 32-pixel tiles); grid = N x Cout/128.
+// Epilogues: y = acc + residual (full size or half size added NN-upsampled) + bias, with the batch-norm statistics of
+// (y - bias) for the layer that consumes y (normalization.py:47); or, for the input gradient of UpsampleConv, the 2x2 sums
+// of the 8x8 result (the gradient of the NN-upsample) -> [N,4,4,Cout].
+// ==================================================================================================================
+namespace {
+template <int C> struct G8Geom {
+  static constexpr int PPB = C * 2 + 16;                                   // pixel pitch (bytes): odd number of 16-byte units
+  static constexpr int RPB = ((10 * (PPB / 16) + 7) / 16 * 16 + 8) * 16;   // halo row pitch: = 8 units mod 16 (two image rows cover 16 distinct bank slots)
+  static constexpr int IMG = 10 * RPB;
+  static constexpr int KK = C / 16;                                        // MFMA K-steps per tap
+  static constexpr int STEPS = 9 * KK;
+};
+static_assert(G8Geom<128>::RPB == RB_RPB && G8Geom<128>::PPB == RB_PPB, "same image layout as the chain kernels at 128 channels");
+
+constexpr int G8_RED_BYTES = 4 * 2048 * 4;     // statistics epilogue: 2048 floats per wave (reuses the image region)
+
+struct G8Args {
+  const bf16* x;       // [N,8,8,C], or [N,4,4,C] with up_in
+  const bf16* w;       // rfrag [Cout/32][9][C/16][64][8]
+  const float* bias;   // [Cout] or null
+  const bf16* res;     // [N,8,8,Cout], [N,4,4,Cout] with res_up, or null
+  bf16* y;             // [N,8,8,Cout], or [N,4,4,Cout] with pool_out
+  float* stat_sums;    // [groups][GANK_STAT_SLOTS][2][Cout] or null
+  int N, Cout, up_in, res_up, pool_out, stat_n_per_group;
+};
+
+template <int C, int PF>
+__global__ __launch_bounds__(256) void res8_conv3x3_kernel(G8Args a) {
+  using G = G8Geom<C>;
+  static_assert(G::STEPS % PF == 0, "ring position");
+  constexpr int NT = 256, U = C / 8;                 // U = 16-byte units per pixel
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int ct = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int ntc = a.Cout >> 7;
+  const int n = blockIdx.x / ntc, half = blockIdx.x - n * ntc;
+  const int co0 = half * 128 + ct * 32;
+  const int b_base = (r >> 3) * G::RPB + (r & 7) * G::PPB + h * 16;
+  const int wbase = (half * 4 + ct) * G::STEPS * 1024;
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w), 0, (a.Cout >> 5) * G::STEPS * 1024, 0x00020000);
+
+  u32x4 ring[PF];
+#pragma unroll
+  for (int s = 0; s < PF; s++) ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, wbase + s * 1024, 0);
+
+  // zero halo: rows 0 and 9 whole, columns 0 and 9 of rows 1..8
+  constexpr int RU = G::RPB / 16, PU = G::PPB / 16;
+  for (int i = tid; i < 2 * RU + 16 * PU; i += NT) {
+    int off;
+    if (i < 2 * RU) off = (i < RU ? 0 : 9 * G::RPB - RU * 16) + i * 16;
+    else {
+      const int j = i - 2 * RU, rr = 1 + j / (2 * PU), k = j % (2 * PU);
+      off = rr * G::RPB + (k < PU ? 0 : 9 * G::PPB - PU * 16) + k * 16;
+    }
+    *reinterpret_cast<u32x4*>(smem + off) = u32x4{0u, 0u, 0u, 0u};
+  }
+  if (a.up_in) {                                     // NN-upsample in the loader: source pixel (y, x) -> (2y..2y+1, 2x..2x+1)
+    const bf16* src = a.x + (long)n * 16 * C;
+#pragma unroll
+    for (int it = 0; it < 16 * U / NT; it++) {
+      const int q = tid + it * NT, px = q / U, u = q % U;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(src + px * C + u * 8);
+      char* d = smem + (2 * (px >> 2) + 1) * G::RPB + (2 * (px & 3) + 1) * G::PPB + u * 16;
+      *reinterpret_cast<u32x4*>(d) = v;
+      *reinterpret_cast<u32x4*>(d + G::PPB) = v;
+      *reinterpret_cast<u32x4*>(d + G::RPB) = v;
+      *reinterpret_cast<u32x4*>(d + G::RPB + G::PPB) = v;
+    }
+  } else {
+    const bf16* src = a.x + (long)n * 64 * C;
+#pragma unroll
+    for (int it = 0; it < 64 * U / NT; it++) {
+      const int q = tid + it * NT, px = q / U, u = q % U;
+      *reinterpret_cast<u32x4*>(smem + ((px >> 3) + 1) * G::RPB + ((px & 7) + 1) * G::PPB + u * 16) =
+          *reinterpret_cast<const u32x4*>(src + px * C + u * 8);
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; t++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+  {
+    constexpr int PB = 2;                            // pixel fragments are read PB steps ahead of their MFMAs
+    u32x4 bq[PB + 1][2];
+    auto read_b = [&](int s, u32x4 (&dst)[2]) {
+      const int tap = s / G::KK, kk = s % G::KK;
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+        dst[t] = *reinterpret_cast<const u32x4*>(smem + b_base + (4 * t + tap / 3) * G::RPB + (tap % 3) * G::PPB + kk * 32);
+    };
+#pragma unroll
+    for (int s = 0; s < PB; s++) read_b(s, bq[s]);
+#pragma unroll
+    for (int s = 0; s < G::STEPS; s++) {
+      if (s + PB < G::STEPS) read_b(s + PB, bq[(s + PB) % (PB + 1)]);
+      const bf16x8 fa = __builtin_bit_cast(bf16x8, ring[s % PF]);
+      __builtin_amdgcn_sched_barrier(0);             // keeps the LDS reads ahead of their MFMAs and the weight ring full (see res_conv3x3)
+#pragma unroll
+      for (int t = 0; t < 2; t++) acc[t] = GANK_MFMA32(fa, __builtin_bit_cast(bf16x8, bq[s % (PB + 1)][t]), acc[t]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + PF < G::STEPS) ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, wbase + (s + PF) * 1024, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // epilogue: after acc_widen the lane holds channels co0 + 16q + 8h .. +7 of pixel 32t + r
+  if (a.pool_out) {
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        float v[8];
+        acc_widen(acc[t], q, 1.0f, v);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          v[e] += __shfl_xor(v[e], 1);
+          v[e] += __shfl_xor(v[e], 8);
+        }
+        if ((r & 9) == 0) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; e++) o[e] = f2bf(v[e]);
+          const int py = 2 * t + (r >> 4), px = (r & 7) >> 1;
+          *reinterpret_cast<bf16x8*>(a.y + ((long)n * 16 + py * 4 + px) * a.Cout + co0 + 16 * q + 8 * h) = o;
+        }
+      }
+    return;
+  }
+  const bool stats = a.stat_sums != nullptr;
+  float s1[2][8], s2[2][8];
+#pragma unroll
+  for (int q = 0; q < 2; q++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) { s1[q][e] = 0.f; s2[q][e] = 0.f; }
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    const int p = 32 * t + r;
+    const long rpix = a.res_up ? (long)n * 16 + (p >> 4) * 4 + ((p & 7) >> 1) : (long)n * 64 + p;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int c = co0 + 16 * q + 8 * h;
+      float v[8];
+      acc_widen(acc[t], q, 1.0f, v);
+      if (a.res) {
+        const bf16x8 rv = *reinterpret_cast<const bf16x8*>(a.res + rpix * a.Cout + c);
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] += bf2f(rv[e]);
+      }
+      f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias) { b0 = *reinterpret_cast<const f32x4*>(a.bias + c); b1 = *reinterpret_cast<const f32x4*>(a.bias + c + 4); }
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        s1[q][e] += v[e];
+        s2[q][e] += v[e] * v[e];
+        o[e] = f2bf(v[e] + (e < 4 ? b0[e] : b1[e - 4]));
+      }
+      *reinterpret_cast<bf16x8*>(a.y + ((long)n * 64 + p) * a.Cout + c) = o;
+    }
+  }
+  if (stats) {
+    // per wave: 32 channels x 2 statistics, each the sum over the 32 lanes r of one half-wave h (channel 16q + 8h + e).
+    // Through LDS: [stat][q][h][e][r] floats per wave, then lane (stat, channel) adds its 32 values -> ONE full-width atomic.
+    __syncthreads();                                 // every wave is done reading the image
+    float* red = reinterpret_cast<float*>(smem) + ct * 2048;
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        red[((0 * 2 + q) * 2 + h) * 256 + e * 32 + r] = s1[q][e];
+        red[((1 * 2 + q) * 2 + h) * 256 + e * 32 + r] = s2[q][e];
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // lane = stat * 32 + channel-in-wave; channel-in-wave = 16 q + 8 h + e
+    const int st = lane >> 5, cw = lane & 31, qq = cw >> 4, hh = (cw >> 3) & 1, ee = cw & 7;
+    const float* src = red + ((st * 2 + qq) * 2 + hh) * 256 + ee * 32;
+    float tsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const f32x4 t4 = *reinterpret_cast<const f32x4*>(src + 4 * i);
+      tsum += (t4[0] + t4[1]) + (t4[2] + t4[3]);
+    }
+    float* dst = a.stat_sums + ((long)(n / a.stat_n_per_group) * GANK_STAT_SLOTS + (blockIdx.x % GANK_STAT_SLOTS)) * 2 * a.Cout;
+    atomicAdd(dst + st * a.Cout + co0 + cw, tsum);
+  }
+}
+
+__global__ void g8_zero_kernel(float* __restrict__ p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+}  // namespace
+
+extern "C" int gank_res8_conv3x3(const void* x, const void* w_rfrag, const float* bias, const void* residual, void* y, int N, int Cin,
+                                 int Cout, int flags, float* stat_sums, int stat_groups, void* stream) {
+  GANK_REQUIRE(x && w_rfrag && y && N > 0, "res8_conv3x3: null pointer");
+  GANK_REQUIRE((Cin == 256 || Cin == 128) && Cout % 128 == 0, "res8_conv3x3: built for Cin 128 | 256 and Cout %% 128 == 0 (got %d, %d)", Cin, Cout);
+  const int known = GANK_IN_UPSAMPLE2X | GANK_RES_UPSAMPLE2X | GANK_STATS_PREZEROED | GANK_OUT_POOLSUM2X;
+  GANK_REQUIRE((flags & ~known) == 0, "res8_conv3x3: unsupported flags 0x%x", flags & ~known);
+  const bool pool_out = (flags & GANK_OUT_POOLSUM2X) != 0;
+  GANK_REQUIRE(!pool_out || (!bias && !residual && !stat_sums), "res8_conv3x3: the pooled-sum output takes no bias / residual / statistics");
+  GANK_REQUIRE(!(flags & GANK_RES_UPSAMPLE2X) || residual, "res8_conv3x3: GANK_RES_UPSAMPLE2X without a residual");
+  GANK_REQUIRE(!stat_sums || (stat_groups > 0 && N % stat_groups == 0), "res8_conv3x3: batch %d not divisible by %d towers", N, stat_groups);
+  GANK_REQUIRE((long)N * 64 * (Cin > Cout ? Cin : Cout) < (1L << 30), "res8_conv3x3: tensor too large");
+  G8Args a{};
+  a.x = (const bf16*)x; a.w = (const bf16*)w_rfrag; a.bias = bias; a.res = (const bf16*)residual; a.y = (bf16*)y;
+  a.stat_sums = stat_sums; a.N = N; a.Cout = Cout;
+  a.up_in = (flags & GANK_IN_UPSAMPLE2X) ? 1 : 0; a.res_up = (flags & GANK_RES_UPSAMPLE2X) ? 1 : 0; a.pool_out = pool_out ? 1 : 0;
+  a.stat_n_per_group = stat_sums ? N / stat_groups : 1;
+  hipStream_t s = (hipStream_t)stream;
+  const double px_in = a.up_in ? 16.0 : 64.0, px_out = pool_out ? 16.0 : 64.0;
+  gank_prof_begin(0, 2.0 * N * 64.0 * 9.0 * Cin * Cout, s,
+                  2.0 * (N * px_in * Cin + 9.0 * Cin * Cout + N * px_out * Cout + (residual ? N * (a.res_up ? 16.0 : 64.0) * Cout : 0.0)));
+  gank_prof_tag(0, Cin == 256 ? "res8_conv3x3_kernel<256, 12>" : "res8_conv3x3_kernel<128, 12>");
+  if (stat_sums && !(flags & GANK_STATS_PREZEROED)) {
+    const int nz = stat_groups * GANK_STAT_SLOTS * 2 * Cout;
+    hipLaunchKernelGGL(g8_zero_kernel, dim3((nz + 255) / 256), dim3(256), 0, s, stat_sums, nz);
+  }
+  const int grid = N * (Cout / 128);
+  if (Cin == 256) {
+    constexpr int LDS = G8Geom<256>::IMG > G8_RED_BYTES ? G8Geom<256>::IMG : G8_RED_BYTES;
+    GANK_MAX_DYNAMIC_LDS((res8_conv3x3_kernel<256, 12>), LDS, "res8_conv3x3");
+    hipLaunchKernelGGL((res8_conv3x3_kernel<256, 12>), dim3(grid), dim3(256), LDS, s, a);
+  } else {
+    constexpr int LDS = G8Geom<128>::IMG > G8_RED_BYTES ? G8Geom<128>::IMG : G8_RED_BYTES;
+    GANK_MAX_DYNAMIC_LDS((res8_conv3x3_kernel<128, 12>), LDS, "res8_conv3x3");
+    hipLaunchKernelGGL((res8_conv3x3_kernel<128, 12>), dim3(grid), dim3(256), LDS, s, a);
+  }
+  gank_prof_end(0, s);
+  GANK_LAUNCH_OK("res8_conv3x3");
   return 0;
 }

@@ -291,8 +291,7 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_kernel(WgradArgs a) {
 // Sub-tiles are 64 B apart mod 256 B so the ds_write_b128 of one pixel's 128 channels is conflict-free.
 // ------------------------------------------------------------------------------------------------------
 static int wgrad_round_down_env() {
-  static int v = -1;   // experiment knob: GANK_WGRAD_ROUND_DOWN=0 restores ceil(target / tiles) pixel splits
-  if (v < 0) { const char* e = getenv("GANK_WGRAD_ROUND_DOWN"); v = e ? atoi(e) : 1; }
+  static const int v = gank_tune("GANK_WGRAD_ROUND_DOWN", 1);   // experiment knob: GANK_WGRAD_ROUND_DOWN=0 restores ceil(target / tiles) pixel splits
   return v;
 }
 constexpr int SUBS = 2048 + 32;   // sub-tile stride in bf16 elements
@@ -537,9 +536,7 @@ static int launch_wgrad_lean_mode(WgradArgs a, hipStream_t s) {
   a.tiles_co = cdiv(a.Cout, CoT);
   const int total_steps = a.M / 64;
   const long tiles = (long)a.taps * a.tiles_ci * a.tiles_co * (a.nbatch > 0 ? a.nbatch : 1);   // grid.y layers fill the chip too
-  static int target_env = -1, minsteps_env = -1;   // experiment knobs
-  if (target_env < 0) { const char* e = getenv("GANK_WGRAD_SPLIT_TARGET"); target_env = e ? atoi(e) : 256; }
-  if (minsteps_env < 0) { const char* e = getenv("GANK_WGRAD_MIN_STEPS"); minsteps_env = e ? atoi(e) : 8; }
+  static const int target_env = gank_tune("GANK_WGRAD_SPLIT_TARGET", 256), minsteps_env = gank_tune("GANK_WGRAD_MIN_STEPS", 8);
   int splits = (int)((target_env + tiles - 1) / tiles);
   if (splits > total_steps / minsteps_env) splits = total_steps / minsteps_env;
   if (splits < 1) splits = 1;
@@ -755,11 +752,9 @@ static int launch_wgrad_packed(WgradArgs a, hipStream_t s) {
   const int Cw = PACK_X ? a.Cout : a.Cin;
   const int tiles = cdiv(Cw, 128);
   const int total_steps = cdiv(a.M, 64);
-  static int target = -1;     // experiment knob: GANK_WGRAD_PACKED_BLOCKS (blocks per launch; every block ends in 32 x 128 float atomics)
-  if (target < 0) { const char* e = getenv("GANK_WGRAD_PACKED_BLOCKS"); target = e ? atoi(e) : 256; }
+  static const int target = gank_tune("GANK_WGRAD_PACKED_BLOCKS", 256);   // experiment knob: GANK_WGRAD_PACKED_BLOCKS (blocks per launch; every block ends in 32 x 128 float atomics)
   int splits = target / tiles;
-  static int minsteps = -1;   // experiment knob: GANK_WGRAD_PACKED_MINSTEPS (64-pixel steps per block, at least)
-  if (minsteps < 0) { const char* e = getenv("GANK_WGRAD_PACKED_MINSTEPS"); minsteps = e ? atoi(e) : 8; }
+  static const int minsteps = gank_tune("GANK_WGRAD_PACKED_MINSTEPS", 8);   // experiment knob: GANK_WGRAD_PACKED_MINSTEPS (64-pixel steps per block, at least)
   if (splits > total_steps / minsteps) splits = total_steps / minsteps;
   if (splits < 1) splits = 1;
   a.steps_per_split = cdiv(total_steps, splits);
@@ -950,8 +945,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_narrow_stream_kernel(NarrowWgA
 }
 
 static bool wgrad_narrow_stream_ok(int N, int H, int W, int Cin, int Cout, int ks) {
-  static int env = -1;   // experiment knob: GANK_WGRAD_STREAM=0 keeps the packed kernel
-  if (env < 0) { const char* e = getenv("GANK_WGRAD_STREAM"); env = e ? atoi(e) : 1; }
+  static const int env = gank_tune("GANK_WGRAD_STREAM", 1);   // experiment knob: GANK_WGRAD_STREAM=0 keeps the packed kernel
   return env && Cin == 3 && (ks == 1 || ks == 3) && Cout % 128 == 0 && (512 + 2 * W + 2) * 6 + 16 <= 4096 && (long)N * H * W * Cout * 2 < (1L << 31) && (long)N * H * W < (1L << 30);
 }
 static NarrowWgArgs narrow_args(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int Cout, float scale) {
@@ -969,8 +963,7 @@ static int launch_wgrad_narrow_stream(const NarrowWgArgs& a0, int ks0, const Nar
   // GANK_NARROW_FOLD=1: every block takes 512 pixels of the first layer and then 128 of the second (one round of blocks instead of
   // 256 + 64).  Isolated it is faster (scratch/micro/narrow.hip: 16.8 vs 18.6 us warm, 24.2 vs 28.3 us from cold caches); inside the
   // critic update it measured 0.5 % SLOWER per iteration (interleaved A/B on one box), so separate block ranges stay the default.
-  static int fold_env = -1;
-  if (fold_env < 0) { const char* e = getenv("GANK_NARROW_FOLD"); fold_env = e ? atoi(e) : 0; }
+  static const int fold_env = gank_tune("GANK_NARROW_FOLD", 0);
   const int folded = fold_env && ks1 && a0.Cout == a1.Cout && a0.M == 4 * a1.M && a0.M % 512 == 0 ? 1 : 0;
   const int grid = folded ? a0.blocks : a0.blocks + b1.blocks;
 #define NARROW_LAUNCH(K0, K1)                                                                                      \
@@ -1198,8 +1191,7 @@ __global__ void wgrad_reduce_slabs_kernel(const float* __restrict__ ws, float* _
 }
 
 static int wgrad_taps_min_m() {
-  static int v = -1;   // experiment knob
-  if (v < 0) { const char* e = getenv("GANK_WGRAD_TAPS_MINM"); v = e ? atoi(e) : 16384; }
+  static const int v = gank_tune("GANK_WGRAD_TAPS_MINM", 16384);   // experiment knob
   return v;
 }
 static bool wgrad_taps_ok(const WgradArgs& a) {
@@ -1214,8 +1206,7 @@ static void wgrad_taps_geometry(WgradArgs& a) {
   a.tiles_co = a.Cout / 64;
   const int total_steps = a.M / 64;
   const int tiles = a.tiles_ci * a.tiles_co;
-  static int target = -1;   // experiment knob
-  if (target < 0) { const char* e = getenv("GANK_WGRAD_TAPS_TARGET"); target = e ? atoi(e) : 256; }   // one workgroup per CU: 384 leaves a half-empty second round, 512 doubles the slab traffic
+  static const int target = gank_tune("GANK_WGRAD_TAPS_TARGET", 256);   // experiment knob // one workgroup per CU: 384 leaves a half-empty second round, 512 doubles the slab traffic
   int splits = (target + tiles - 1) / tiles;
   if (splits > total_steps / 4) splits = total_steps / 4;
   if (splits < 1) splits = 1;
@@ -1233,8 +1224,7 @@ static int launch_wgrad_taps_mode(WgradArgs a, hipStream_t s) {
     a.ws = nullptr;   // atomics
   }
   const size_t lds = (size_t)2 * 2 * (XSUB + SUBS) * sizeof(bf16);
-  static int tpf = -1;
-  if (tpf < 0) { const char* e = getenv("GANK_WGRAD_TAPS_PF"); tpf = e ? atoi(e) : 2; }
+  static const int tpf = gank_tune("GANK_WGRAD_TAPS_PF", 2);
   auto kern = tpf == 1 ? conv_wgrad_taps_kernel<MODE, 1> : conv_wgrad_taps_kernel<MODE, 2>;
   static const std::string tag = gank_format("conv_wgrad_taps_kernel<%d, 2> + wgrad_reduce_slabs_kernel", MODE);     // magic static: built once, thread-safe
   gank_prof_tag(1, tag.c_str());
@@ -1479,8 +1469,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs a) {
 
 // filter-row kernel for plain 3x3 stride-1 layers below the all-taps kernel's size (single layer or a same-shape batch)
 static bool wgrad_rows_ok(const WgradArgs& a) {
-  static int env = -1;   // experiment knob: GANK_WGRAD_ROWS=0 keeps these layers on the per-tap kernel
-  if (env < 0) { const char* e = getenv("GANK_WGRAD_ROWS"); env = e ? atoi(e) : 1; }
+  static const int env = gank_tune("GANK_WGRAD_ROWS", 1);   // experiment knob: GANK_WGRAD_ROWS=0 keeps these layers on the per-tap kernel
   return env && a.ks == 3 && a.pad == 1 && (a.flags & ~GANK_IN_RELU) == 0 && a.sw >= 3 && a.shw >= 6 && a.H >= 8 && a.W >= 8 &&
          a.Hx == a.H && a.Wx == a.W && a.Hdy == a.H && a.Wdy == a.W && a.Cin % 64 == 0 && a.Cout % 64 == 0 && a.M % 64 == 0 &&
          (long)a.N * a.H * a.W * a.Cin < (1L << 30) && (long)a.N * a.H * a.W * a.Cout < (1L << 30);
@@ -1491,8 +1480,7 @@ static int launch_wgrad_rows(WgradArgs a, hipStream_t s) {
   a.tiles_co = a.Cout / 64;
   const int total_steps = a.M / 64;
   const int tiles = a.tiles_ci * a.tiles_co * 3 * nb;
-  static int target = -1;   // experiment knob
-  if (target < 0) { const char* e = getenv("GANK_WGRAD_ROWS_TARGET"); target = e ? atoi(e) : 256; }
+  static const int target = gank_tune("GANK_WGRAD_ROWS_TARGET", 256);   // experiment knob
   // at most `target` workgroups: 6 splits x 48 tiles = 288 blocks ran as two rounds on 256 CUs (31 us), 5 x 48 = 240 as one
   int splits = wgrad_round_down_env() ? target / tiles : (target + tiles - 1) / tiles;
   if (splits > total_steps / 4) splits = total_steps / 4;
@@ -1502,8 +1490,7 @@ static int launch_wgrad_rows(WgradArgs a, hipStream_t s) {
   a.ws = nullptr;          // partial tiles by fp32 atomics
   const size_t lds = (size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16);
   const bool relu = (a.flags & GANK_IN_RELU) != 0;
-  static int pf = -1;       // experiment knob: register prefetch depth
-  if (pf < 0) { const char* e = getenv("GANK_WGRAD_ROWS_PF"); pf = e ? atoi(e) : 2; }
+  static const int pf = gank_tune("GANK_WGRAD_ROWS_PF", 2);   // experiment knob: register prefetch depth
   auto kern = relu ? (pf == 4 ? conv_wgrad_rows_kernel<1, 4, false> : pf == 3 ? conv_wgrad_rows_kernel<1, 3, false> : conv_wgrad_rows_kernel<1, 2, false>)
                    : (pf == 4 ? conv_wgrad_rows_kernel<0, 4, false> : pf == 3 ? conv_wgrad_rows_kernel<0, 3, false> : conv_wgrad_rows_kernel<0, 2, false>);
   static_assert((size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16) <= 65536, "below the default dynamic-LDS limit: no attribute call");
@@ -1555,12 +1542,10 @@ int gank_wgrad_dispatch(WgradArgs a, hipStream_t s) {
   const bool dy_grid = (a.flags & GANK_DY_UPSAMPLE2X) || (a.Hdy == a.H && a.Wdy == a.W);
   const bool lean = fast && same_grid && dy_grid && a.sw >= 0 && a.shw >= 0 && (a.M % 64 == 0) &&
                     (long)a.N * a.Hx * a.Wx * a.Cin < (1L << 30) && (long)a.N * a.Hdy * a.Wdy * a.Cout < (1L << 30);
-  static int taps_env = -1;   // experiment knob: GANK_WGRAD_TAPS=0 disables the all-taps kernel
-  if (taps_env < 0) { const char* e = getenv("GANK_WGRAD_TAPS"); taps_env = e ? atoi(e) : 1; }
+  static const int taps_env = gank_tune("GANK_WGRAD_TAPS", 1);   // experiment knob: GANK_WGRAD_TAPS=0 disables the all-taps kernel
   if (taps_env && wgrad_taps_ok(a)) rc = launch_wgrad_taps(a, s);
   if (rc < 0 && wgrad_rows_ok(a)) rc = launch_wgrad_rows(a, s);
-  static int lpf_env = -1;   // experiment knob: prefetch depth of the lean kernel
-  if (lpf_env < 0) { const char* e = getenv("GANK_WGRAD_LEAN_PF"); lpf_env = e ? atoi(e) : 2; }
+  static const int lpf_env = gank_tune("GANK_WGRAD_LEAN_PF", 2);   // experiment knob: prefetch depth of the lean kernel
   if (rc < 0 && lean) {
     if (a.Cin >= 128 && a.Cout >= 128 && lpf_env == 4) rc = launch_wgrad_lean<2, 2, 2, 2, 4>(a, s);
     else if (a.Cin >= 128 && a.Cout >= 128 && lpf_env == 3) rc = launch_wgrad_lean<2, 2, 2, 2, 3>(a, s);
@@ -1687,8 +1672,7 @@ __global__ void wgrad_cpool_fold_slabs_kernel(const float* __restrict__ ws, floa
 }
 
 static bool wgrad_cpool_rows_ok(int N, int Hp, int Wp, int Cin, int Cout) {
-  static int env = -1;   // experiment knob: GANK_CPOOL_ROWS=0 falls back to the 16-tap per-tap kernel
-  if (env < 0) { const char* e = getenv("GANK_CPOOL_ROWS"); env = e ? atoi(e) : 1; }
+  static const int env = gank_tune("GANK_CPOOL_ROWS", 1);   // experiment knob: GANK_CPOOL_ROWS=0 falls back to the 16-tap per-tap kernel
   return env && Hp >= 8 && Wp >= 8 && log2_or_neg(Hp) >= 0 && log2_or_neg(Wp) >= 0 && Cin % 64 == 0 && Cout % 64 == 0 &&
          (long)N * 4 * Hp * Wp * Cin < (1L << 30) && (long)N * Hp * Wp * Cout < (1L << 30);
 }
@@ -1697,8 +1681,7 @@ static void wgrad_cpool_rows_geometry(WgradArgs& a) {
   a.tiles_co = a.Cout / 64;
   const int total_steps = a.M / 64;
   const int tiles = a.tiles_ci * a.tiles_co * 4;
-  static int target = -1;   // experiment knob
-  if (target < 0) { const char* e = getenv("GANK_CPOOL_ROWS_TARGET"); target = e ? atoi(e) : 256; }
+  static const int target = gank_tune("GANK_CPOOL_ROWS_TARGET", 256);   // experiment knob
   int splits = wgrad_round_down_env() ? target / tiles : (target + tiles - 1) / tiles;
   if (splits > total_steps / 4) splits = total_steps / 4;
   if (splits < 1) splits = 1;
@@ -1732,8 +1715,7 @@ extern "C" int gank_convpool3x3_wgrad(const void* x, const void* dy, float* dw, 
     gank_prof_tag(1, "conv_wgrad_rows_kernel<1, 2, true> + wgrad_cpool_fold_slabs_kernel");
     const size_t lds = (size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16);
     a.scale = 1.f;
-    static int pf = -1;       // experiment knob: register prefetch depth
-    if (pf < 0) { const char* e = getenv("GANK_CPOOL_ROWS_PF"); pf = e ? atoi(e) : 2; }
+    static const int pf = gank_tune("GANK_CPOOL_ROWS_PF", 2);   // experiment knob: register prefetch depth
     auto kern = (flags & GANK_IN_RELU) ? (pf == 3 ? conv_wgrad_rows_kernel<1, 3, true> : conv_wgrad_rows_kernel<1, 2, true>)
                                        : (pf == 3 ? conv_wgrad_rows_kernel<0, 3, true> : conv_wgrad_rows_kernel<0, 2, true>);
     static_assert((size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16) <= 65536, "below the default dynamic-LDS limit: no attribute call");

@@ -77,6 +77,19 @@ static inline std::string gank_format(const char* fmt, ...) {
   return std::string(buf);
 }
 
+// Tuning constants of the launch dispatchers (split targets, prefetch depths, kernel on/off switches).  A production build
+// bakes the defaults in: no environment lookups on the product path.  An experiment build (GANK_EXTRA_FLAGS=-DGANK_TUNING
+// GANK_LIB_NAME=libgank_tune.so python -m gan_lib_tensorflow_amd.build) reads each one from the environment once, for the A/B
+// sweeps under scratch/.
+static inline int gank_tune(const char* name, int dflt) {
+#ifdef GANK_TUNING
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+#else
+  (void)name;
+  return dflt;
+#endif
+}
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline int roundup(int a, int b) { return (a + b - 1) / b * b; }
 static inline int log2_or_neg(int v) { int s = 0; while ((1 << s) < v) s++; return ((1 << s) == v) ? s : -1; }
@@ -152,20 +165,6 @@ __device__ __forceinline__ void acc_widen(const f32x16& acc, int q, float scale,
     v[e] = lo;
     v[4 + e] = hi;
   }
-}
-
-// Result tiles are written once and read by the NEXT kernel: a streaming (nt) store keeps them from displacing the weight and
-// activation lines the running kernel still re-reads from its L2 (experiment knob: -DGANK_NT_STORE=0|1).
-#ifndef GANK_NT_STORE
-#define GANK_NT_STORE 0
-#endif
-template <class V>
-__device__ __forceinline__ void store_out(V* p, V v) {
-#if GANK_NT_STORE
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
 }
 
 #endif

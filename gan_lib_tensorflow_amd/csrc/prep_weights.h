@@ -198,18 +198,6 @@ struct PrepTable {
   int count;
 };
 
-// Fragment-major operand copy (kind 3): the 16 bytes lane l of a wave feeds to v_mfma_f32_32x32x16_bf16 as its A
-// operand are contiguous, fragments ordered [32-row tile][K-step = 64-channel chunk outer, tap inner][kk][lane], so a
-// wave loads one fragment as ONE coalesced 1 KB request straight into registers (conv_igemm_patch2_kernel).
-// row: output row of the operand matrix, k = tap*C + c its column (C = channels per tap, C % 64 == 0).
-__device__ __forceinline__ long frag_index(int row, int k, int C, int taps, int nsteps) {
-  const int tap = k / C, ch = k - tap * C;
-  const int chunk = ch >> 6, w64 = ch & 63;
-  const int kk = w64 >> 4, hh = (w64 >> 3) & 1, j = w64 & 7;
-  const int kstep = chunk * taps + tap;
-  return ((((long)(row >> 5) * nsteps + kstep) * 4 + kk) * 64 + hh * 32 + (row & 31)) * 8 + j;
-}
-
 // One block of the batched preparation: `bid` = block index inside the table's block range; sg = divisor of entry e's
 // weight (SC) -- read by the caller from wherever its sigma lives.
 __device__ __forceinline__ int prep_batch_entry(const PrepTable& t, int bid) {
@@ -330,14 +318,12 @@ __device__ __forceinline__ void prep_batch_block(const PrepTable& t, int e, int 
 #pragma unroll
     for (int j = 0; j < 8; j++) o[j] = f2bf(tl[kp + j][threadIdx.x >> 3]);
     *reinterpret_cast<bf16x8*>(wf + (long)c * Kpad + k0 + kp) = o;
-    // fragment-major copy: 8 consecutive k of one 8-aligned group are consecutive there too (Cin % 64 == 0)
-    if (d.kind == 3) *reinterpret_cast<bf16x8*>(wf + (long)CoutPad * Kpad + frag_index(c, k0 + kp, d.Cin, taps, Kpad / 64)) = o;
   } else {
     const int Kpad2 = (taps * d.Cout + 63) / 64 * 64, CinPad = (d.Cin + 31) / 32 * 32;
     const long total = (long)CinPad * Kpad2;
     bf16* wd = (bf16*)d.wd;
     const long base = (long)(b - t.nwf[e]) * 2048;
-    if ((d.Cout & 7) == 0 && d.kind != 3) {
+    if ((d.Cout & 7) == 0) {
       // 8 consecutive k = 8 consecutive couts of one tap (or 8 pad columns): two 16-byte loads, one 16-byte store
       const long i = base + 8 * threadIdx.x;
       if (i < total) {
@@ -367,7 +353,6 @@ __device__ __forceinline__ void prep_batch_block(const PrepTable& t, int e, int 
         v = prep_ld<SC>(d.w[((long)(taps - 1 - tp) * d.Cin + ci) * d.Cout + co], sg);
       }
       wd[i] = f2bf(v);
-      if (d.kind == 3) wd[total + frag_index(ci, k, d.Cout, taps, Kpad2 / 64)] = f2bf(v);
     }
   }
 }
@@ -383,10 +368,10 @@ static inline int prep_table_fill(PrepTable& t, const gank_prep_desc* table, int
     const bool ok = d.w && (d.wf || d.wd) && d.ksize >= 1 && d.Cin > 0 && d.Cout > 0;
     if (!ok) { gank_set_error("prep_weights_batched: bad entry %d", base_index + i); return -1; }
     const bool kind_ok = d.kind == 0 || ((d.kind == 1 || d.kind == 2) && d.ksize == 3 && d.wf && d.wd) ||
-                         (d.kind == 3 && d.Cin % 64 == 0 && d.Cout % 64 == 0) || (d.kind == 4 && d.Cin % 32 == 0 && d.Cout % 32 == 0) ||
+                         (d.kind == 4 && d.Cin % 32 == 0 && d.Cout % 32 == 0) ||
                          (d.kind == 5 && d.ksize == 3 && d.wf && d.wd && d.Cin % 64 == 0 && d.Cout % 32 == 0);
     if (!kind_ok) {
-      gank_set_error("prep_weights_batched: entry %d: kind %d needs ksize 3 and both outputs (1, 2, 5) / channels %% 64 == 0 (3) / %% 32 == 0 (4) / Cin %% 64 == 0 (5)", base_index + i, d.kind);
+      gank_set_error("prep_weights_batched: entry %d: kind %d needs ksize 3 and both outputs (1, 2, 5) / channels %% 32 == 0 (4) / Cin %% 64 == 0 (5)", base_index + i, d.kind);
       return -1;
     }
     t.d[i] = d;

@@ -12,17 +12,12 @@ import torch
 from torch.autograd import Function
 
 from . import kernels as K
-import os as _os0
-_os_environ_get = _os0.environ.get
 
 BF16 = K.BF16
-# register-weight patch kernel (prep kind 3, GANK_W_FRAG) for the plain 3x3 convs at 16x16 / 32x32: measured equal to
-# the LDS-weight patch kernel within 2 % either way (both sit at ~75 % of what a bare MFMA loop reaches on this
-# chip under DVFS), so the simpler operand layout stays the default
-FRAG_PATCH = False
 POOL_CONV4 = True     # 3x3 conv + 2x2 mean pool as one 4x4 stride-2 conv (4 instead of 9 taps per conv output)
 CPOOL_RESIDENT = True   # ... on the LDS-resident kernels where they apply (prep kind 5; kernels.cpool_res_ok)
 PHASE_UPCONV = True   # NN-upsample+3x3 conv as a phase-decomposed transposed conv (4 instead of 9 taps)
+RES8_CONV = True      # 3x3 convs on 8x8 images with "rfrag" operands attached: the LDS-resident kernel (gank_res8_conv3x3)
 
 
 # Boundaries of the backward pass (data parallel: the gradient buckets of parallel.GradBuckets end here).  A network
@@ -50,93 +45,6 @@ class record_boundaries:
         return False
 
 
-class _Side:
-    """Filter gradients on a second HIP stream.  A filter gradient only feeds the optimiser (or the batched spectral
-    norm backward), never the next layer's backward, so it can overlap the input-gradient chain: small layers
-    leave most CUs idle (one workgroup per CU at best) and their wgrad kernels fill them.  Under hipGraph capture
-    the fork/join becomes parallel branches of the graph.  Operands are kept alive until the join: the caching
-    allocator could otherwise hand their memory to a later main-stream kernel while the side stream still reads it."""
-    stream = None
-    keep = []
-
-
-def set_wgrad_stream(stream):
-    _Side.stream = stream
-
-
-def _on_side(fn, *operands):
-    st = _Side.stream
-    if st is None:
-        fn()
-        return
-    st.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(st):
-        fn()
-    _Side.keep.append(operands)
-
-
-class _Beside:
-    """A short chain of latency-bound launches that does not depend on its neighbours (the critic's label embedding ->
-    dense layer, :279-281) on a second HIP stream: under hipGraph capture the fork and the join become parallel branches,
-    and the chain's 5-9-us kernels hide behind the first residual block instead of standing in the critical path.  The
-    backward pass needs no code: autograd runs a node's backward on the stream its forward ran on and orders the streams
-    at the hand-offs; only gradients written straight into the flat buffer (bias, embedding table) need the explicit join
-    before the optimiser (join_beside_backward).
-    MEASURED (interleaved A/B, 100 iterations each): 7.27-7.29 ms per iteration with the branch against 7.03 without -- each
-    fork / join inside a captured graph costs more in cross-queue signalling than the 30 us of kernels it hides.  Third
-    multi-stream experiment with this outcome (filter gradients, the generator pass beside the critic): off by default."""
-    enabled = _os_environ_get("GANK_SIDE_BRANCH", "0") == "1"
-    streams = {}
-    used = set()
-
-
-class beside:
-    """with beside(device) as br: ...ops...   then   join_beside(br, *results)  before the results are read"""
-    def __init__(self, device):
-        self.st = None
-        if _Beside.enabled and device.type == "cuda":
-            key = device.index if device.index is not None else torch.cuda.current_device()
-            if key not in _Beside.streams:
-                _Beside.streams[key] = torch.cuda.Stream(device=device)
-            self.st = _Beside.streams[key]
-
-    def __enter__(self):
-        if self.st is None:
-            return None
-        self.st.wait_stream(torch.cuda.current_stream())
-        self.ctx = torch.cuda.stream(self.st)
-        self.ctx.__enter__()
-        return self.st
-
-    def __exit__(self, *exc):
-        if self.st is not None:
-            self.ctx.__exit__(*exc)
-            _Beside.used.add(self.st)
-        return False
-
-
-def join_beside(st, *tensors):
-    if st is None:
-        return
-    main = torch.cuda.current_stream()
-    main.wait_stream(st)
-    for t in tensors:
-        t.record_stream(main)          # allocated on the branch stream, read on this one
-
-
-def join_beside_backward():
-    """after loss.backward(): the branch's gradient kernels are in stream order before the optimiser"""
-    capturing = torch.cuda.is_current_stream_capturing()
-    for st in _Beside.used:
-        if capturing:
-            with torch.cuda.stream(st):
-                forked = torch.cuda.is_current_stream_capturing()
-            if not forked:         # a forward pass outside this capture used the branch: none of its work belongs here
-                continue
-        torch.cuda.current_stream().wait_stream(st)
-    _Beside.used.clear()
-
-
 # Small same-shape filter gradients are not launched where autograd reaches them but collected and issued together
 # (gank_conv2d_wgrad_batched): the critic's four 8x8x128 convs fill 144 workgroups each for a few microseconds; one
 # launch of all four overlaps their latencies.  Flushed before anything reads the gradients (join_wgrad).
@@ -157,7 +65,7 @@ def _defer_narrow(x, g, tgt, btgt, hw, k):
 
 def narrow_wgrad_ok(cin, cout, k, flags_free):
     """a filter gradient the streaming 3-channel-input kernel takes (gank_conv2d_wgrad_narrow_pair)"""
-    return BATCH_SMALL_WGRADS and _Side.stream is None and flags_free and cin == 3 and k in (1, 3) and cout % 128 == 0
+    return BATCH_SMALL_WGRADS and flags_free and cin == 3 and k in (1, 3) and cout % 128 == 0
 
 
 def flush_wgrads():
@@ -173,11 +81,10 @@ def flush_wgrads():
 
 
 def reset_deferred():
-    """Drop every deferred / side-stream filter gradient (start of a backward pass, and after one that raised or whose
+    """Drop every deferred filter gradient (start of a backward pass, and after one that raised or whose
     capture aborted): stale (x, dy) pairs must never be flushed into another pass's gradient buffers."""
     _deferred.clear()
     _deferred_narrow.clear()
-    _Side.keep.clear()
 
 
 def join_wgrad():
@@ -185,9 +92,6 @@ def join_wgrad():
     SN backward)."""
     if _deferred or _deferred_narrow:
         flush_wgrads()
-    if _Side.stream is not None and _Side.keep:
-        torch.cuda.current_stream().wait_stream(_Side.stream)
-        _Side.keep.clear()
 
 
 def _target(p):
@@ -248,14 +152,24 @@ class _Conv2d(Function):
         # nearest-neighbour upsampled; paths without that epilogue get it materialised
         res_up = residual is not None and getattr(residual, "_up2x", False)
         ctx.res_up_orig = res_up
+        # 8x8 images with the "rfrag" operands attached: one LDS-resident image per workgroup (conv_resident.hip), the
+        # NN-upsample of a 4x4 input done by its loader
+        res8 = (RES8_CONV and k == 3 and not in_relu and not pool_out and not out_tanh and getattr(W, "_prep_res", None) is not None
+                and K.res8_conv3x3_ok(n, (H, Wd), cin, cout))
         # NN-upsample + 3x3: run as the 4 output phases of the equivalent 4x4 stride-2 transposed conv
-        phase = upsample and k == 3 and cin % 64 == 0 and not in_relu and PHASE_UPCONV
+        phase = upsample and k == 3 and cin % 64 == 0 and not in_relu and PHASE_UPCONV and not res8
         # 3x3 conv + 2x2 mean pool: run as ONE 4x4 stride-2 conv (16 taps per pooled pixel = 4 per conv output)
         pool4 = pool_out and k == 3 and cin % 64 == 0 and cout % 64 == 0 and POOL_CONV4
         if res_up and (phase or pool_out):
             residual = K.unpool2x2_add(residual, None, 1.0)
             res_up = False
-        if phase:
+        if res8:
+            rflags = (K.IN_UPSAMPLE2X if upsample else 0) | (K.RES_UPSAMPLE2X if res_up else 0)
+            if stats_groups:
+                y, _Conv2d.last_stats = K.res8_conv3x3(x, W._prep_res[0], b, cout, rflags, residual, stats_groups)
+            else:
+                y = K.res8_conv3x3(x, W._prep_res[0], b, cout, rflags, residual)
+        elif phase:
             wph, _ = getattr(W, "_prep_up", None) or K.upconv3x3_prep(W.detach().view(3, 3, cin, cout))
             if stats_groups and not out_tanh:
                 y, _Conv2d.last_stats = K.upconv3x3_fprop(x, wph, b, cout, 0, residual, stats_groups)
@@ -282,7 +196,7 @@ class _Conv2d(Function):
         # conv_2 (called after it) then parks dy for it instead of returning it along the shortcut
         ctx.add_link = ctx.res_link = None
         link = getattr(x, "_add_link", None)
-        if link is not None and ctx.needs_input_grad[0] and not (upsample or pool_out or phase or pool4):
+        if link is not None and ctx.needs_input_grad[0] and not (upsample or pool_out or phase or pool4 or res8):
             link.armed = True
             ctx.add_link = link
         rlink = getattr(residual, "_grad_link", None) if residual is not None else None
@@ -290,6 +204,7 @@ class _Conv2d(Function):
             ctx.res_link = rlink
         ctx.save_for_backward(x, W, y if out_tanh else None)
         ctx.cfg = (k, cin, cout, H, Wd, upsample, in_relu, pool_out, out_tanh, bias, phase, pool4)
+        ctx.res8 = res8 and W._prep_res[1] is not None
         return y
 
     @staticmethod
@@ -307,24 +222,27 @@ class _Conv2d(Function):
             db = None if bacc else btgt
         if ctx.needs_input_grad[1] and pool4:
             tgt, acc = _target(W)
-            _on_side(lambda: K.convpool3x3_wgrad(x, g, tgt.view(3, 3, cin, cout), K.IN_RELU if in_relu else 0, dbias=btgt), x, g)
+            K.convpool3x3_wgrad(x, g, tgt.view(3, 3, cin, cout), K.IN_RELU if in_relu else 0, dbias=btgt)
             dW = None if acc else tgt
         elif ctx.needs_input_grad[1]:
             tgt, acc = _target(W)
             wflags = (K.IN_UPSAMPLE2X if upsample else 0) | (K.IN_RELU if in_relu else 0) | (K.DY_UPSAMPLE2X if pool_out else 0)
             small = (BATCH_SMALL_WGRADS and not upsample and not pool_out and k == 3 and cin % 128 == 0 and cout % 128 == 0
-                     and x.shape[0] * H * Wd <= 8192 and _Side.stream is None)
+                     and x.shape[0] * H * Wd <= 8192)
             if small:
                 _defer_wgrad(x, g, tgt, btgt, (H, Wd), k, wflags)
             elif narrow_wgrad_ok(cin, cout, k, wflags == 0):
                 _defer_narrow(x, g, tgt, btgt, (H, Wd), k)       # paired with the block's other image-side layer (one launch)
             else:
                 # bias gradient rides on the dy stream
-                _on_side(lambda: K.conv2d_wgrad(x, g, tgt, (H, Wd), k, wflags, scale, dbias=btgt), x, g)
+                K.conv2d_wgrad(x, g, tgt, (H, Wd), k, wflags, scale, dbias=btgt)
             dW = None if acc else tgt
         elif btgt is not None:
             K.colsum(g, btgt, 1.0)
-        if ctx.needs_input_grad[0] and phase:
+        if ctx.needs_input_grad[0] and ctx.res8:
+            # the conv with the dgrad operand (taps flipped, channels swapped); behind an upsample its 2x2 sums
+            dx = K.res8_conv3x3(g, W._prep_res[1], None, cin, K.OUT_POOLSUM2X if upsample else 0)
+        elif ctx.needs_input_grad[0] and phase:
             prep = getattr(W, "_prep_up", None) or K.upconv3x3_prep(W.detach().view(3, 3, cin, cout))
             dx = K.upconv3x3_dgrad(g, prep[1], cin)       # 4x4 stride-2 conv of dy: no hi-res dgrad, no 2x2 sum
         elif ctx.needs_input_grad[0] and pool4 and getattr(W, "_prep_cpres", None) is not None:
@@ -469,10 +387,10 @@ class _ResChain8(Function):
                     if need_w[i]:
                         tgt, acc = _target(W)
                         grads[4 * b + 2 * j] = None if acc else tgt
-                        if BATCH_SMALL_WGRADS and _Side.stream is None:
+                        if BATCH_SMALL_WGRADS:
                             _defer_wgrad(xop, gop, tgt, btgt, (8, 8), 3, K.IN_RELU)
                         else:
-                            _on_side(lambda xop=xop, gop=gop, tgt=tgt, btgt=btgt: K.conv2d_wgrad(xop, gop, tgt, (8, 8), 3, K.IN_RELU, 1.0, dbias=btgt), xop, gop)
+                            K.conv2d_wgrad(xop, gop, tgt, (8, 8), 3, K.IN_RELU, 1.0, dbias=btgt)
                     elif btgt is not None:
                         K.colsum(gop, btgt, 1.0)
         return (dx if ctx.needs_input_grad[0] else None, None, *grads)
@@ -566,7 +484,7 @@ def spectral_norm_batch(Ws, us, snapshot=False, inplace=False, prep=None, label=
     return outs, batch
 
 
-CBN_REMASK = _os.environ.get("GANK_CBN_REMASK", "1") == "1"   # relu mask of the backward pass recomputed from x instead of read from y
+CBN_REMASK = True   # relu mask of the backward pass recomputed from x instead of read from y
 
 
 class _CondBatchNorm(Function):
@@ -749,7 +667,7 @@ class _ForkPoolConv1x1(Function):
             if narrow_wgrad_ok(cin, cout, 1, True):
                 _defer_narrow(pooled, g, tgt, btgt, (h, w), 1)
             else:
-                _on_side(lambda: K.conv2d_wgrad(pooled, g, tgt, (h, w), 1, 0, 1.0, dbias=btgt), pooled, g)
+                K.conv2d_wgrad(pooled, g, tgt, (h, w), 1, 0, 1.0, dbias=btgt)
             dW = None if acc else tgt
         elif btgt is not None:
             K.colsum(g, btgt, 1.0)

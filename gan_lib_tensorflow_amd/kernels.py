@@ -6,7 +6,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, W_FRAG, RES_UPSAMPLE2X, STATS_PREZEROED, SnDesc, PrepDesc, WgradItem, LabelDenseDesc  # noqa: F401
+from ._lib import IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, RES_UPSAMPLE2X, STATS_PREZEROED, OUT_POOLSUM2X, SnDesc, PrepDesc, WgradItem, LabelDenseDesc  # noqa: F401
 
 # BF16 = the 16-bit activation dtype of this process: torch.bfloat16, or torch.float16 under GANK_DTYPE=fp16 (libgank_f16.so)
 BF16, F32, I32 = getattr(torch, _lib.ACT_DTYPE_NAME), torch.float32, torch.int32
@@ -47,7 +47,7 @@ def prep_weights(w, want_f=True, want_d=False):
     return wf, wd
 
 
-_PREP_ATTR = ("_prep", "_prep_up", "_prep_pool", "_prep", "_prep_res", "_prep_cpres")
+_PREP_ATTR = ("_prep", "_prep_up", "_prep_pool", None, "_prep_res", "_prep_cpres")     # kind 3 is retired
 
 
 def _prep_plan(ws, want_d=True, kinds=None, sources=None):
@@ -66,19 +66,13 @@ def _prep_plan(ws, want_d=True, kinds=None, sources=None):
             k, cin, cout = w.shape[0], w.shape[2], w.shape[3]
         taps = k * k
         dev = w.device
-        if kind == 0 or kind == 3:
-            # kind 3: every operand is followed by its MFMA-fragment-major copy (buffers of twice the size, `_frag`)
+        if kind == 0:
             old = getattr(w, "_prep", None)
-            if (old is not None and old[0] is not None and (old[1] is not None or not want_d)
-                    and bool(getattr(old[0], "_frag", False)) == (kind == 3)):
+            if old is not None and old[0] is not None and (old[1] is not None or not want_d):
                 wf, wd = old
             else:
-                lead = (2,) if kind == 3 else ()
-                wf = torch.empty(lead + (_roundup(cout, 32), _roundup(taps * cin, 64)), dtype=BF16, device=dev)
-                wd = torch.empty(lead + (_roundup(cin, 32), _roundup(taps * cout, 64)), dtype=BF16, device=dev) if want_d else None
-                wf._frag = kind == 3
-                if wd is not None:
-                    wd._frag = kind == 3
+                wf = torch.empty((_roundup(cout, 32), _roundup(taps * cin, 64)), dtype=BF16, device=dev)
+                wd = torch.empty((_roundup(cin, 32), _roundup(taps * cout, 64)), dtype=BF16, device=dev) if want_d else None
         elif kind == 1:
             assert k == 3
             wf, wd = getattr(w, "_prep_up", None) or (torch.empty((4, _roundup(cout, 32), 4 * cin), dtype=BF16, device=dev),
@@ -113,8 +107,7 @@ def _prep_attach(ws, kinds, todo, outs):
 def prep_weights_batched(ws, want_d=True, kinds=None):
     """One launch for a list of fp32 weights ([k,k,Cin,Cout] or [Cin,Cout]).  kinds[i]: 0 = plain conv/linear ->
     `w._prep = (wf, wd)`; 1 = UpsampleConv 3x3 -> `w._prep_up = (wph, wd4)`; 2 = ConvMeanPool 3x3 ->
-    `w._prep_pool = (wp4, wphd)`; 3 = plain + fragment-major copies for the register-weight patch kernel (the conv
-    wrappers pass GANK_W_FRAG when they see them); 4 = "rfrag" operands of the resident kernels -> `w._prep_res = (rf, rd)`;
+    `w._prep_pool = (wp4, wphd)`; 4 = "rfrag" operands of the resident kernels -> `w._prep_res = (rf, rd)`;
     5 = ConvMeanPool 3x3 operands of the resident kernels -> `w._prep_cpres = (rf, rd)`;
     None = skip (the layer prepares nothing).  The conv wrappers pick the attributes up
     and skip their own per-layer preparation.  Buffers persist on the tensor and are rewritten IN PLACE on later
@@ -173,8 +166,6 @@ def conv2d_fprop(x, wf, bias, out_hw, cout, ksize, flags=0, scale=1.0, residual=
     n, cin = x.shape[0], x.shape[3]
     h, w = out_hw
     y = torch.empty((n, h, w, cout), dtype=BF16, device=x.device)
-    if getattr(wf, "_frag", False):
-        flags |= W_FRAG
     if stats_groups:
         sums, pre = stats_arena.take((stats_groups, _lib.STAT_SLOTS, 2, cout), x.device)
         produced = C.c_int(0)
@@ -204,8 +195,6 @@ def conv2d_dgrad(dy, wd, out_hw, cin, ksize, flags=0, scale=1.0, residual=None, 
     n, cout = dy.shape[0], dy.shape[3]
     h, w = out_hw
     dx = torch.empty((n, h, w, cin), dtype=BF16, device=dy.device)
-    if getattr(wd, "_frag", False):
-        flags |= W_FRAG
     _lib.check(lib().gank_conv2d_dgrad(_p(dy, BF16, "dy"), _p(wd, BF16, "wd"), _p(residual, BF16, "residual"),
                                        _p(relu_ref, BF16, "relu_ref"), _p(dx), n, h, w, cin, cout, ksize, flags,
                                        scale, _stream()), "conv2d_dgrad")
@@ -347,6 +336,28 @@ def convpool3x3_dgrad(dy, wphd, cin, relu_ref=None):
 def cpool_res_ok(n, hp, wp, cin, cout):
     """shapes the resident ConvMeanPool kernels cover (fprop and dgrad)"""
     return cout == 128 and cin % 128 == 0 and hp % 8 == 0 and (wp % 16 == 0 or wp == 8) and n * 4 * hp * wp * cin < (1 << 30)
+
+
+def res8_conv3x3_ok(n, hw, cin, cout):
+    """geometry of gank_res8_conv3x3: 8x8 images (after the upsample, if any), Cin 128 | 256, Cout % 128 == 0"""
+    return tuple(hw) == (8, 8) and cin in (128, 256) and cout % 128 == 0 and n * 64 * max(cin, cout) < (1 << 30)
+
+
+def res8_conv3x3(x, rf, bias, cout, flags=0, residual=None, stats_groups=0):
+    """3x3 SAME conv on LDS-resident 8x8 images (rf: prep kind 4 operand, rows = output channels).  flags: IN_UPSAMPLE2X
+    (x is [N,4,4,Cin]), RES_UPSAMPLE2X (residual is [N,4,4,Cout]), OUT_POOLSUM2X (result as 2x2 sums [N,4,4,Cout]).
+    stats_groups > 0 -> (y, ConvStats)"""
+    n, cin = x.shape[0], x.shape[3]
+    hw = 4 if flags & OUT_POOLSUM2X else 8
+    y = torch.empty((n, hw, hw, cout), dtype=BF16, device=x.device)
+    if stats_groups:
+        sums, pre = stats_arena.take((stats_groups, _lib.STAT_SLOTS, 2, cout), x.device)
+        _lib.check(lib().gank_res8_conv3x3(_p(x, BF16, "x"), _p(rf, BF16, "rf"), _p(bias, F32, "bias"), _p(residual, BF16, "residual"), _p(y),
+                                           n, cin, cout, flags | (STATS_PREZEROED if pre else 0), _p(sums), stats_groups, _stream()), "res8_conv3x3")
+        return y, ConvStats(sums, bias, stats_groups)
+    _lib.check(lib().gank_res8_conv3x3(_p(x, BF16, "x"), _p(rf, BF16, "rf"), _p(bias, F32, "bias"), _p(residual, BF16, "residual"), _p(y),
+                                       n, cin, cout, flags, None, 0, _stream()), "res8_conv3x3")
+    return y
 
 
 def cpool_res_fprop(x, rf, bias, cout, flags=0, residual=None):

@@ -35,12 +35,13 @@ extern "C" {
 #define GANK_IN_RELU 2         /* relu applied to the input operand while staging                     */
 #define GANK_OUT_TANH 4        /* tanh applied last in the epilogue                                   */
 #define GANK_DY_UPSAMPLE2X 8   /* wgrad only: dy is [N,H/2,W/2,Cout] (gradient of a 2x2 mean pool)    */
-#define GANK_W_FRAG 32         /* fprop/dgrad: the operand buffer carries the fragment-major copy (prep kind 3) */
 #define GANK_STAT_SLOTS 16     /* copies of each tower's statistics sums the conv epilogues spread their atomics over */
 #define GANK_STATS_PREZEROED 256 /* *_fprop_stats: stat_sums was cleared by the caller (one fill for all layers of a pass) */
 #define GANK_RES_UPSAMPLE2X 64 /* fprop: residual is [N,H/2,W/2,Cout] and is added nearest-neighbour upsampled: the
                                   shortcut of an 'up' residual block (gan_cifar_resnet.py:179-182,209) without
                                   materialising the upsampled tensor */
+#define GANK_OUT_POOLSUM2X 512 /* gank_res8_conv3x3: the result leaves as its 2x2 sums [N,H/2,W/2,Cout] (the gradient of an
+                                  NN-upsample in front of the conv whose input gradient this launch computes) */
 
 int gank_version(void);
 /* element type of every `bf16` buffer of THIS library: 0 = bfloat16 (libgank.so), 1 = IEEE half (libgank_f16.so: the same sources
@@ -63,8 +64,7 @@ typedef struct gank_prep_desc {
   int ksize, Cin, Cout;
   int kind;       /* 0 plain conv/linear; 1 UpsampleConv 3x3 (gank_upconv3x3_prep_weights layouts);
                      2 ConvMeanPool 3x3 (gank_convpool3x3_prep_weights layouts);
-                     3 plain + a second, MFMA-fragment-major copy right after each row-major operand (buffers of
-                       twice the size; Cin % 64 == 0 and Cout % 64 == 0): pass GANK_W_FRAG to fprop / dgrad;
+                     (3 is retired: the register-weight patch kernel it fed measured equal to the LDS-weight one and was removed);
                      4 "rfrag" operands of the resident kernels (gank_res8_chain_*): bf16 [rows/32][taps][k/16][64 lanes][8],
                        lane = 32*h + r holding k = 16*kk + 8*h .. +7 of row 32*tile + r; wf: rows = co, k = ci;
                        wd: rows = ci, k = co, taps flipped.  Cin % 32 == 0 and Cout % 32 == 0; taps*Cin*Cout elements each;
@@ -150,6 +150,16 @@ int gank_res8_chain_fwd(const void* x, const void* const* w_rfrag, const float* 
 int gank_res8_chain_bwd(const void* dy, const void* dpool, const void* ylast, void* dy_out, const void* const* wd_rfrag,
                         const void* const* h1, const void* const* xin, void* const* g1, void* const* dx, int N, int C,
                         int nblocks, void* stream);
+
+/* ---- 3x3 SAME conv on 8x8 images, one LDS-resident image per workgroup (operand: prep kind 4, rows = output channels):
+ * the generator's first residual block (gan_cifar_resnet.py:179-207, resample='up' at 4x4 -> 8x8) -- tf.nn.conv2d of
+ * conv2d.py:180-187 behind the depth_to_space upsample of :139-146 -- and, with the dgrad operand, the input gradients.
+ *   x [N,8,8,Cin] (GANK_IN_UPSAMPLE2X: [N,4,4,Cin], NN-upsampled by the loader); Cin 128 | 256; Cout % 128 == 0;
+ *   y [N,8,8,Cout] = conv + residual ([N,8,8,Cout], or [N,4,4,Cout] added upsampled with GANK_RES_UPSAMPLE2X) + bias;
+ *   stat_sums (optional) as in gank_conv2d_fprop_stats (GANK_STATS_PREZEROED honoured);
+ *   GANK_OUT_POOLSUM2X: y [N,4,4,Cout] = 2x2 sums of the conv (no bias / residual / statistics). */
+int gank_res8_conv3x3(const void* x, const void* w_rfrag, const float* bias, const void* residual, void* y, int N, int Cin,
+                      int Cout, int flags, float* stat_sums, int stat_groups, void* stream);
 
 /* ---- ConvMeanPool 3x3 on LDS-resident images (same arithmetic as gank_convpool3x3_fprop / _dgrad; operands: prep kind 5)
  * A workgroup owns an 8x16 (or 8x8) patch of POOLED pixels and 128 output channels, stages its input region once per
