@@ -139,7 +139,18 @@ def main():
                          "communication stream, the all-reduces captured inside the update graphs -- what N > 1 ranks run, minus the wire")
     ap.add_argument("--grad-wire", default=None, choices=[None, "bf16"], help="16-bit gradient buckets on the wire (data parallel)")
     ap.add_argument("--no-capture-collectives", action="store_true", help="data parallel: collectives eagerly between graph replays (the round-2 form)")
+    ap.add_argument("--set", action="append", default=[], metavar="module.NAME=value",
+                    help="A/B runs: set a module constant of the package before the trainer is built, e.g. functional.RES8_CONV=False")
     args = ap.parse_args()
+    for kv in args.set:
+        import ast
+        import importlib
+        target, value = kv.split("=", 1)
+        modname, attr = target.rsplit(".", 1)
+        mod = importlib.import_module("gan_lib_tensorflow_amd." + modname)
+        if not hasattr(mod, attr):
+            raise SystemExit(f"--set {kv}: gan_lib_tensorflow_amd.{modname} has no {attr}")
+        setattr(mod, attr, ast.literal_eval(value))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -1100,6 +1100,68 @@ def test_conv_epilogue_statistics_feed_cond_batchnorm(K, form, n, h, groups):
     assert relerr(z1, z0.double().cpu().numpy()) < BF_TOL
 
 
+@pytest.mark.parametrize("n,cin,cout,up,resmode,groups", [(3, 256, 256, False, "full", 0), (8, 256, 256, True, "half", 2), (4, 128, 128, False, None, 2),
+                                                          (6, 128, 256, True, None, 0), (128, 256, 256, False, "half", 2), (320, 256, 256, True, None, 10)])
+def test_res8_conv3x3_resident_generator_layers(K, n, cin, cout, up, resmode, groups):
+    """gank_res8_conv3x3 (one LDS-resident 8x8 image per workgroup, fragment-major weights): fprop with the loader's NN-upsample,
+    bias, full- and half-resolution residual against the oracle and against the implicit-GEMM kernels on the same operands;
+    the epilogue's batch-norm statistics against the moments of the stored tensor; the input gradient through the dgrad operand,
+    with the 2x2 sums of the upsample's gradient."""
+    rng = np.random.default_rng(n + cin + cout + up)
+    hin = 4 if up else 8
+    x, xt = bf(rng.normal(size=(n, hin, hin, cin)))
+    w, _ = bf(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin))
+    b, bt = f32(rng.normal(size=cout) * 2.0)
+    wt = torch.tensor(w, dtype=torch.float32).cuda()
+    (rf, rd), = K.prep_weights_batched([wt], want_d=True, kinds=[4])
+    res = rest = None
+    if resmode is not None:
+        rh = 8 if resmode == "full" else 4
+        res, rest = bf(rng.normal(size=(n, rh, rh, cout)))
+    flags = (K.IN_UPSAMPLE2X if up else 0) | (K.RES_UPSAMPLE2X if resmode == "half" else 0)
+    if groups:
+        y, cs = K.res8_conv3x3(xt, rf, bt, cout, flags, rest, stats_groups=groups)
+    else:
+        y = K.res8_conv3x3(xt, rf, bt, cout, flags, rest)
+    torch.cuda.synchronize()
+    small = n <= 8
+    if small:
+        xin = R.upsample_nn2x(x) if up else x
+        ref = R.conv2d_same(xin, w, b)
+        if res is not None:
+            ref = ref + (R.upsample_nn2x(res) if resmode == "half" else res)
+        assert relerr(y, ref) < BF_TOL
+    # the implicit-GEMM kernels on the same operands
+    wf, wd = K.prep_weights(wt, True, True)
+    y_ig = K.conv2d_fprop(xt, wf, bt, (8, 8), cout, 3, flags, 1.0, rest)
+    torch.cuda.synchronize()
+    assert relerr(y, y_ig.double().cpu().numpy()) < 5e-3
+    if groups:
+        yd = y.double().cpu().numpy().reshape(groups, -1, cout)
+        M = yd.shape[1]
+        tot = cs.sums.double().sum(dim=1).cpu().numpy()
+        mean = tot[:, 0] / M + b
+        var = tot[:, 1] / M - (tot[:, 0] / M) ** 2
+        assert np.abs(mean - yd.mean(1)).max() < 1e-3 * np.abs(yd).max() and np.abs(var / yd.var(1) - 1).max() < 8e-3
+        y2, _ = K.res8_conv3x3(xt, rf, bt, cout, flags, rest, stats_groups=groups)      # the statistics do not touch the output
+        assert torch.equal(y, y2)
+    # input gradient
+    dy, dyt = bf(rng.normal(size=(n, 8, 8, cout)))
+    dx = K.res8_conv3x3(dyt, rd, None, cin, K.OUT_POOLSUM2X if up else 0)
+    torch.cuda.synchronize()
+    assert tuple(dx.shape) == (n, hin, hin, cin)
+    dx_ig = K.conv2d_dgrad(dyt, wd, (8, 8), cin, 3, 0, 1.0)
+    if up:
+        dx_ig = K.pool2x2(dx_ig, 1.0)
+    torch.cuda.synchronize()
+    assert relerr(dx, dx_ig.double().cpu().numpy()) < (BF_TOL if up else 5e-3)     # (pooled: the reference side rounds twice)
+    if small:
+        dref, _, _ = R.conv2d_same_grads(R.upsample_nn2x(x) if up else x, w, dy)
+        if up:
+            dref = R.upsample_nn2x_grad(dref)
+        assert relerr(dx, dref) < BF_TOL
+
+
 def test_copy_gather(K):
     """gank_copy_bytes_gather: equal-sized device buffers into consecutive slots of one buffer, one launch (aligned and odd sizes)"""
     for shape, dt in (((64, 3072), torch.uint8), ((64,), torch.int32), ((7, 3), torch.uint8)):
