@@ -10,8 +10,8 @@ done
 python3 - "$out" <<'PY'
 import csv, glob, sys, json, collections, re
 def sym(n):      # rocprofv3 prints "void name<...>(ArgTypes)": keep name<...> as libgank's launchers record it
-    n = re.sub(r"^void ", "", n)
-    n = re.sub(r"\((\(anonymous namespace\)::)?(IgemmArgs|WgradArgs|ResFwdArgs|ResBwdArgs|CpFwdArgs|CpBwdArgs)\)$", "", n)
+    n = re.sub(r"^void ", "", n).replace("(anonymous namespace)::", "")
+    n = re.sub(r"\((\(anonymous namespace\)::)?(IgemmArgs|WgradArgs|ResFwdArgs|ResBwdArgs|CpFwdArgs|CpBwdArgs|G8Args)\)$", "", n)
     return re.sub(r"\(.*\)$", "", n)            # plain kernels: drop the argument list
 per = collections.defaultdict(lambda: {"FETCH_SIZE": [], "WRITE_SIZE": []})
 for c in ("FETCH_SIZE", "WRITE_SIZE"):

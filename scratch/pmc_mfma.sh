@@ -10,7 +10,7 @@ f = glob.glob('/tmp/pmc_mf/**/*counter_collection.csv', recursive=True)[0]
 per = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
 for r in csv.DictReader(open(f)):
-    k = re.sub(r"\(.*\)$", "", re.sub(r"^void ", "", r["Kernel_Name"]))[:64]
+    k = re.sub(r"\(.*\)$", "", re.sub(r"^void ", "", r["Kernel_Name"]).replace("(anonymous namespace)::", ""))[:64]
     per[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "GRBM_GUI_ACTIVE": cnt[k] += 1
 tot = sum(d["GRBM_GUI_ACTIVE"] for d in per.values())
