@@ -336,9 +336,46 @@ import os as _os
 CONV_EPILOGUE_STATS = _os.environ.get("GANK_EPILOGUE_STATS", "1") == "1"     # batch-norm statistics of a conv's output from its own epilogue (two-group kernel), where asked for
 
 
+class _PadChannels(Function):
+    """x [N,H,W,C] -> [N,H,W,Cp] with zero channels behind (one concat launch; backward: the first C channels of the gradient)"""
+
+    @staticmethod
+    def forward(ctx, x, cp):
+        ctx.c = x.shape[3]
+        return K.concat_channels(_c(x), torch.zeros(tuple(x.shape[:3]) + (cp - x.shape[3],), dtype=x.dtype, device=x.device))
+
+    @staticmethod
+    def backward(ctx, g):
+        return K.split_channels(_c(g), ctx.c)[0], None
+
+
+class _PadCin(Function):
+    """filter [k,k,Cin,Cout] -> [k,k,Cp,Cout] with zero input channels behind; backward: the gradient of the real channels, added
+    to wherever the filter's gradient lives (`_target`)"""
+
+    @staticmethod
+    def forward(ctx, W, cp):
+        ctx.W = W
+        return torch.nn.functional.pad(W.detach(), (0, 0, 0, cp - W.shape[2]))
+
+    @staticmethod
+    def backward(ctx, g):
+        W = ctx.W
+        tgt, acc = _target(W)
+        tgt.add_(g[:, :, :W.shape[2], :])
+        return (None if acc else tgt), None
+
+
+PAD_ODD_CIN = True    # a plain conv whose Cin > 64 is not a multiple of 64 (PGGAN: 513 channels behind minibatch-std, model_nvidia.py:128-129)
+#                       runs on zero-padded operands (576 channels): the MFMA kernels instead of the K-packed scalar gather
+
+
 def conv2d(x, W, bias=None, residual=None, upsample=False, in_relu=False, pool_out=False, out_tanh=False, stats_groups=0):
     """stats_groups > 0: the output feeds a (conditional) batch norm over that many towers; when the kernel that runs can
     accumulate its statistics, they ride along on the result (`y._cbn_stats`) and cond_batchnorm skips its statistics pass."""
+    if PAD_ODD_CIN and W.dim() == 4 and x.shape[3] > 64 and x.shape[3] % 64 and not upsample and not pool_out and x.is_cuda:
+        cp = (x.shape[3] + 63) // 64 * 64
+        x, W = _PadChannels.apply(x, cp), _PadCin.apply(W, cp)
     y = _Conv2d.apply(x, W, bias, residual, upsample, in_relu, pool_out, out_tanh, stats_groups if CONV_EPILOGUE_STATS else 0)
     if stats_groups and _Conv2d.last_stats is not None:
         y._cbn_stats = _Conv2d.last_stats

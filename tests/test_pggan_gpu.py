@@ -195,3 +195,27 @@ def test_pggan_training_steps(gpu):
     assert all(np.isfinite(float(v)) for v in tr.losses.values())
     img = tr.sample(10)
     assert img.shape == (10, 16, 16, 3) and bool(torch.isfinite(img.float()).all())
+
+
+@pytest.mark.parametrize("bc,trans,res", [(4, True, 64), (6, False, 256)])
+def test_pggan_training_steps_at_64_fading_and_256(gpu, bc, trans, res):
+    """BASELINE.json config 4 at its later stages (batch 16): 64 x 64 with the newest block fading in and the final 256 x 256
+    stage -- two captured train steps each; parameters move by at most ~lr per update, stay finite, gradients are cleared by the
+    optimiser launch, samples have the stage's resolution."""
+    from gan_lib_tensorflow_amd.SNGAN.gan_cifar_resnet import synthetic_batches
+    tr, _ = make(bc, trans, 16, seed=5)
+    feed = synthetic_batches(16, "cuda", seed=2)
+    x = tr.real_images(next(feed)[0])
+    assert x.shape == (16, res, res, 3) and float(x.abs().max()) <= 1.01
+    p0d, p0g = tr.d_flat['params'].clone(), tr.g_flat['params'].clone()
+    for _ in range(2):
+        tr.train_iteration(feed)
+    torch.cuda.synchronize()
+    assert tr.step == 2 and int(tr.d_opt['t']) == 10 and int(tr.g_opt['t']) == 2
+    for flat, p0, n in ((tr.d_flat, p0d, 10), (tr.g_flat, p0g, 2)):
+        assert bool(torch.isfinite(flat['params']).all()) and float(flat['grads'].abs().max()) == 0.0
+        moved = (flat['params'] - p0).abs()
+        assert 1e-5 < float(moved.max()) < n * 1e-4 * 3      # beta1 = 0: a step is lr * g / rms(g history), above lr when a gradient outgrows its history
+    assert all(np.isfinite(float(v)) for v in tr.losses.values())
+    img = tr.sample(4)
+    assert img.shape == (4, res, res, 3) and bool(torch.isfinite(img.float()).all())

@@ -282,3 +282,32 @@ def test_pix2pix_training_steps(gpu):
         moved = (flat['params'] - p0).abs()
         assert 1e-5 < float(moved.max()) < n * 2e-4 * 1.5
     assert all(np.isfinite(float(v)) for v in tr.losses.values())
+
+
+def test_pix2pix_batch16_critic_pass_is_the_mean_of_its_sub_batches(gpu):
+    """BASELINE.json config 5 at its full size (batch 16, 512 x 512): every layer of the PatchGAN critic is per sample (instance
+    norm), so the logits of a batch are the logits of its samples and the gradient of a mean loss over 16 pairs is the mean of the
+    gradients over four sub-batches of 4 -- a size-independent check of the general conv kernels' forward pass and all three
+    gradients at shapes the float64 restatement cannot reach in a test."""
+    from gan_lib_tensorflow_amd import functional as Fn
+    tr, _ = make(batch=16, seed=11)
+    g = torch.Generator().manual_seed(8)
+    a = (torch.rand(16, 512, 512, 3, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+    b = (torch.rand(16, 512, 512, 3, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+    logits = tr._critic(a, b, 'NO_OPS')
+    assert logits.shape == (16, 30, 30, 1)
+    tr._backward(Fn.hinge_g_loss(logits.reshape(-1)))
+    torch.cuda.synchronize()
+    g16 = tr.d_flat['grads'].clone()
+    assert bool(torch.isfinite(g16).all()) and float(g16.abs().max()) > 0
+    tr.d_flat['grads'].zero_()
+    parts = []
+    for i in range(4):
+        lg = tr._critic(a[4 * i:4 * i + 4].contiguous(), b[4 * i:4 * i + 4].contiguous(), 'NO_OPS')
+        parts.append(lg.detach())
+        tr._backward(Fn.hinge_g_loss(lg.reshape(-1)))
+    torch.cuda.synchronize()
+    assert rel(logits, torch.cat(parts, 0).double().cpu()) < 1e-2
+    g4 = tr.d_flat['grads'] / 4
+    assert l2(g16, g4.double().cpu()) < 1e-2, l2(g16, g4.double().cpu())
+    tr.d_flat['grads'].zero_()
