@@ -13,7 +13,6 @@ Tensors are bf16 NHWC; images are [N, 32, 32, 3] as in the reference (train.py:8
 """
 import numpy as np
 
-from .. import functional as Fn
 from .. import functional2 as F2
 from .. import kernels as K
 from ..common import resnet_block as blocks
@@ -56,10 +55,11 @@ def _batch_norm(x, name, decay=0.9):
 
 def _residual_block(x, dim, name, resample):
     """ResidualBlock(..., spectral_normed=False, activation_fn='lrelu') of common/resnet_block.py:100-156, resample 'down' | None"""
+    xs, x = F2.fork(x)                       # the block input feeds the shortcut and the main path
     if resample == 'down':
-        shortcut = F2.meanpool2x2(_conv(x, name + '.Shortcut', dim, dim, 1, he_init=False))       # ConvMeanPool, filter_size 1
+        shortcut = F2.meanpool2x2(_conv(xs, name + '.Shortcut', dim, dim, 1, he_init=False))      # ConvMeanPool, filter_size 1
     elif resample is None:
-        shortcut = x                                                                            # identity skip-connection
+        shortcut = xs                                                                           # identity skip-connection
     else:
         raise Exception('invalid resample value')
     h = F2.lrelu(_batch_norm(x, name + '.N1'))
@@ -68,7 +68,7 @@ def _residual_block(x, dim, name, resample):
     h = _conv(h, name + '.Conv2', dim, dim, 3)
     if resample == 'down':
         h = F2.meanpool2x2(h)
-    return Fn.add(shortcut, h)
+    return F2.add(shortcut, h)
 
 
 class ACGAN(object):
@@ -94,18 +94,20 @@ class ACGAN(object):
         store = get_default_store()
         with store.variable_scope('d_net', reuse=reuse):
             # OptimizedResBlockDisc1(x, activation_fn='lrelu')   (resnet_block.py:159-184)
-            shortcut = _conv(F2.meanpool2x2(x_var), 'D.DownBlock.1.Shortcut', 3, 128, 1, he_init=False)      # MeanPoolConv
+            x_short, x_var = F2.fork(x_var)     # (only when the input carries a gradient: the interpolates of the penalty term)
+            shortcut = _conv(F2.meanpool2x2(x_short), 'D.DownBlock.1.Shortcut', 3, 128, 1, he_init=False)    # MeanPoolConv
             h = _conv(x_var, 'D.DownBlock.1.Conv1', 3, 128, 3)
             h = F2.lrelu(h)
             h = F2.meanpool2x2(_conv(h, 'D.DownBlock.1.Conv2', 128, 128, 3))                                 # ConvMeanPool
-            output = Fn.add(shortcut, h)
+            output = F2.add(shortcut, h)
             output = _residual_block(output, 128, 'D.DownBlock.2', 'down')
             output = _residual_block(output, 128, 'D.NoneBlock.3', None)
             output = _residual_block(output, 128, 'D.NoneBlock.4', None)
             output = F2.lrelu(output)
             output = F2.mean_hw(output)                                                                      # reduce_mean(axis=[1, 2])
+            out_w, out_c = F2.fork(output)      # the pooled features feed both heads
             w, b = _linear_vars('D.Output', 128, 1)
-            output_wgan = F2.linear(output, w, b).reshape(-1)
+            output_wgan = F2.linear(out_w, w, b).reshape(-1)
             w, b = _linear_vars('D.ACGANOutput', 128, 10)
-            output_acgan = F2.linear(output, w, b)
+            output_acgan = F2.linear(out_c, w, b)
             return output_wgan, output_acgan

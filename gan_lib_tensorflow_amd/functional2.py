@@ -367,10 +367,13 @@ class BNF(Function):
         ctx.save_for_backward(x, gamma, stats)
         ctx.beta = beta                      # the parameter itself (for its .grad buffer)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)     # the statistics output has no gradient: it must not arrive as a zero-filled tensor
         return y, stats
 
     @staticmethod
     def backward(ctx, dy, _ds):
+        if dy is None:
+            return None, None, None
         x, gamma, stats = ctx.saved_tensors
         tg, tb = _direct(gamma), _direct(ctx.beta)
         if tg is not None and tb is not None:        # not differentiated again: the table-gradient kernel adds into .grad itself
@@ -439,6 +442,47 @@ class GPLoss(Function):
 
 
 # ---- functional forms -------------------------------------------------------------------------------------------
+class AddF(Function):
+    """a + b (one launch); linear, so its backward is differentiable as it stands"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return K.add(_c(a), _c(b))
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+class Fork(Function):
+    """Explicit activation fan-out (an activation read by a block's shortcut and by its main path, the pooled features read by
+    both heads): two aliases forward; backward ONE add launch of this library instead of autograd's own accumulation (an
+    at::native add), again through a Function so that the gradient-penalty pass can be differentiated through it."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None:
+            return gb
+        if gb is None:
+            return ga
+        return AddF.apply(ga, gb)
+
+
+def fork(x):
+    if not x.requires_grad:
+        return x, x
+    return Fork.apply(x)
+
+
+def add(a, b):
+    return AddF.apply(a, b)
+
+
 def conv2d(x, W, bias=None):
     return ConvF.apply(x, W, bias)
 
