@@ -315,3 +315,45 @@ extern "C" int gank_relu_to_channels(const void* x, void* y, long pixels, int C,
   GANK_LAUNCH_OK("relu_to_channels");
   return 0;
 }
+
+// im2col of a narrow-channel image (Pix2Pix: the 4x4 stride-2 first layers on 3- and 6-channel inputs, networks.py:335-342, :474-486):
+// y[n, oy, ox, tap * Cin + c] = x[n, oy * stride - pad + ky, ox * stride - pad + kx, c]  (zero outside the image and for columns
+// >= k * k * Cin).  With it the filter gradient of such a layer is the filter gradient of a 1x1 conv with Kpad input channels --
+// an MFMA kernel at HBM speed instead of the scalar-gather kernel (0.8 ms for 1.6 GFLOP at 512 x 512, batch 4).
+__global__ void im2col_narrow_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, long total8, int Hin, int Win, int Cin, int Ho, int Wo,
+                                     int ks, int stride, int pad, int Kpad) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= total8) return;
+  const int g8 = Kpad >> 3;
+  const long p = i / g8;
+  const int k0 = (int)(i - p * g8) * 8;
+  const int ox = (int)(p % Wo);
+  const long t = p / Wo;
+  const int oy = (int)(t % Ho);
+  const long n = t / Ho;
+  const int ktot = ks * ks * Cin;
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const int k = k0 + e;
+    float v = 0.f;
+    if (k < ktot) {
+      const int tap = k / Cin, c = k - tap * Cin;
+      const int iy = oy * stride - pad + tap / ks, ix = ox * stride - pad + tap % ks;
+      if ((unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win) v = bf2f(x[((n * Hin + iy) * Win + ix) * Cin + c]);
+    }
+    o[e] = f2bf(v);
+  }
+  *reinterpret_cast<bf16x8*>(y + i * 8) = o;
+}
+extern "C" int gank_im2col_narrow(const void* x, void* y, int N, int Hin, int Win, int Cin, int Ho, int Wo, int ksize, int stride, int pad,
+                                  int Kpad, void* stream) {
+  GANK_REQUIRE(x && y && N > 0 && Hin > 0 && Win > 0 && Cin > 0 && Ho > 0 && Wo > 0, "im2col_narrow: bad arguments");
+  GANK_REQUIRE(ksize >= 1 && ksize <= 7 && stride >= 1 && pad >= 0 && Kpad % 8 == 0 && Kpad >= ksize * ksize * Cin,
+               "im2col_narrow: k=%d stride=%d pad=%d Kpad=%d (needs Kpad %% 8 == 0 and >= k*k*Cin = %d)", ksize, stride, pad, Kpad, ksize * ksize * Cin);
+  const long total8 = (long)N * Ho * Wo * (Kpad / 8);
+  hipLaunchKernelGGL(im2col_narrow_kernel, g1(total8), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, total8, Hin, Win, Cin, Ho, Wo,
+                     ksize, stride, pad, Kpad);
+  GANK_LAUNCH_OK("im2col_narrow");
+  return 0;
+}

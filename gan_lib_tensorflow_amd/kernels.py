@@ -254,11 +254,30 @@ def conv2d_general_dgrad(dy, wd, x_hw, cin, ksize, pad, relu_ref=None):
     return dx
 
 
+def im2col_narrow(x, out_hw, ksize, stride, pad, kpad):
+    """[N,Hin,Win,Cin] -> [N,Ho,Wo,kpad] bf16, column tap*Cin + c (gank_im2col_narrow)"""
+    n, hin, win, cin = x.shape
+    y = torch.empty((n, out_hw[0], out_hw[1], kpad), dtype=BF16, device=x.device)
+    _lib.check(lib().gank_im2col_narrow(_p(x, BF16, "x"), _p(y), n, hin, win, cin, out_hw[0], out_hw[1], ksize, stride, pad, kpad, _stream()), "im2col_narrow")
+    return y
+
+
+IM2COL_NARROW_WGRAD = True    # filter gradients of layers with k*k*Cin <= 128 and Cin < 32 (Pix2Pix's 4x4 stride-2 input layers) through im2col + the 1x1 MFMA kernels
+
+
 def conv2d_general_wgrad(x, dy, dw, ksize, stride, pad, flags=0, dbias=None):
     """ACCUMULATES into dw fp32 [k,k,Cin,Cout] (and dbias)"""
     n, hx, wx, cin = x.shape
     _, hdy, wdy, cout = dy.shape
     assert dw.numel() == ksize * ksize * cin * cout
+    ktot = ksize * ksize * cin
+    if IM2COL_NARROW_WGRAD and flags == 0 and cin < 32 and ksize > 1 and ktot <= 128 and cout % 64 == 0 and n * hdy * wdy >= 16384:
+        kpad = 64 if ktot <= 64 else 128
+        xcol = im2col_narrow(x, (hdy, wdy), ksize, stride, pad, kpad)
+        tmp = torch.zeros((1, 1, kpad, cout), dtype=F32, device=x.device)
+        conv2d_wgrad(xcol, dy, tmp, (hdy, wdy), 1, 0, 1.0, dbias=dbias)
+        dw.view(ktot, cout).add_(tmp.view(kpad, cout)[:ktot])
+        return dw
     _lib.check(lib().gank_conv2d_general_wgrad(_p(x, BF16, "x"), _p(dy, BF16, "dy"), _p(dw, F32, "dw"), _p(dbias, F32, "dbias"), n, hx, wx, hdy, wdy,
                                                cin, cout, ksize, stride, pad, flags, _stream()), "conv2d_general_wgrad")
     return dw

@@ -499,6 +499,11 @@ int gank_concat_channels(const void* a, const void* b, void* y, long pixels, int
 int gank_pool2d(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int k, int stride, int pad, int mode, int Cy, int c_off,
                 void* stream);
 int gank_relu_to_channels(const void* x, void* y, long pixels, int C, int Cy, int c_off, void* stream);
+/* im2col of a narrow-channel image: y [N,Ho,Wo,Kpad] bf16, column tap*Cin + c = x[n, oy*stride - pad + ky, ox*stride - pad + kx, c]
+ * (zeros outside the image and for columns >= k*k*Cin; Kpad % 8 == 0).  Turns the filter gradient of Pix2Pix's 4x4 stride-2 layers on
+ * 3- / 6-channel inputs (networks.py:335-342, :474-486) into the filter gradient of a 1x1 conv (gank_conv2d_wgrad, ksize 1, Cin = Kpad). */
+int gank_im2col_narrow(const void* x, void* y, int N, int Hin, int Win, int Cin, int Ho, int Wo, int ksize, int stride, int pad,
+                       int Kpad, void* stream);
 int gank_split_channels(const void* y, void* a, void* b, long pixels, int Ca, int Cb, void* stream);
 int gank_l1_loss(const void* a, const void* b, float* loss, float* dl32, float* ws, long n, void* stream);
 int gank_dropout_fwd(const void* x, void* y, uint8_t* mask, long n, float keep, uint64_t* rng_state, void* stream);
