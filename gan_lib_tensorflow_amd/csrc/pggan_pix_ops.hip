@@ -357,3 +357,95 @@ extern "C" int gank_im2col_narrow(const void* x, void* y, int N, int Hin, int Wi
   GANK_LAUNCH_OK("im2col_narrow");
   return 0;
 }
+
+// A conv with very few output channels behind a 2x nearest-neighbour upsample (Pix2Pix decoder_1: relu -> upsample -> 4x4 SAME ->
+// 3 channels -> tanh at 512 x 512, networks.py:424-452) as a 1x1 conv at LOW resolution plus a tap gather:
+//   Z[n, q, t * Cout + co] = sum_ci relu(x[n, q, ci]) W[t, ci, co]            (an MFMA 1x1 conv with k*k*Cout <= Zc outputs)
+//   y[n, p, co] = tanh(b[co] + sum_t Z[n, (p + d(t)) >> 1, t * Cout + co]),   d(t) = (ky - pad, kx - pad), taps outside the image skipped
+// instead of a k*k-tap conv whose 3 outputs are padded to a 32-row MFMA tile (1.3 ms at batch 4: 10x the padding, 4x the
+// upsampled taps).  The backward pass gathers the same way: col[n, q, t * Cout + co] = sum of g[n, p, co] over the <= 4 pixels p
+// with (p + d(t)) >> 1 == q; input and filter gradient are then the 1x1 conv's own (gank_conv2d_dgrad / _wgrad on col).
+__global__ void tap_gather_up2_kernel(const bf16* __restrict__ Z, const float* __restrict__ bias, bf16* __restrict__ y, long pixels,
+                                      int h, int w, int ks, int pad, int Cout, int Zc, int tanh_out) {
+  const long p = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (p >= pixels) return;
+  const int W2 = 2 * w, H2 = 2 * h;
+  const int px = (int)(p % W2);
+  const long t0 = p / W2;
+  const int py = (int)(t0 % H2);
+  const long n = t0 / H2;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int ky = 0; ky < ks; ky++) {
+    const int iy = py + ky - pad;
+    if ((unsigned)iy >= (unsigned)H2) continue;
+    for (int kx = 0; kx < ks; kx++) {
+      const int ix = px + kx - pad;
+      if ((unsigned)ix >= (unsigned)W2) continue;
+      const bf16* z = Z + ((n * h + (iy >> 1)) * w + (ix >> 1)) * Zc + (ky * ks + kx) * Cout;
+      for (int co = 0; co < Cout; co++) acc[co] += bf2f(z[co]);
+    }
+  }
+  for (int co = 0; co < Cout; co++) {
+    float v = acc[co] + (bias ? bias[co] : 0.f);
+    if (tanh_out) v = tanhf(v);
+    y[p * Cout + co] = f2bf(v);
+  }
+}
+
+__global__ void tap_scatter_up2_kernel(const bf16* __restrict__ g, bf16* __restrict__ col, long total8, int h, int w, int ks, int pad,
+                                       int Cout, int Zc) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= total8) return;
+  const int g8 = Zc >> 3;
+  const long q = i / g8;
+  const int j0 = (int)(i - q * g8) * 8;
+  const int qx = (int)(q % w);
+  const long t0 = q / w;
+  const int qy = (int)(t0 % h);
+  const long n = t0 / h;
+  const int W2 = 2 * w, H2 = 2 * h;
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const int j = j0 + e;
+    float v = 0.f;
+    if (j < ks * ks * Cout) {
+      const int t = j / Cout, co = j - t * Cout;
+      const int ky = t / ks, kx = t - ky * ks;
+#pragma unroll
+      for (int a = 0; a < 2; a++) {
+        const int py = 2 * qy + a - (ky - pad);
+        if ((unsigned)py >= (unsigned)H2) continue;
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+          const int px = 2 * qx + b - (kx - pad);
+          if ((unsigned)px >= (unsigned)W2) continue;
+          v += bf2f(g[((n * H2 + py) * W2 + px) * Cout + co]);
+        }
+      }
+    }
+    o[e] = f2bf(v);
+  }
+  *reinterpret_cast<bf16x8*>(col + i * 8) = o;
+}
+
+extern "C" int gank_tap_gather_up2(const void* Z, const float* bias, void* y, int N, int h, int w, int ksize, int pad, int Cout, int Zc,
+                                   int tanh_out, void* stream) {
+  GANK_REQUIRE(Z && y && N > 0 && h > 0 && w > 0, "tap_gather_up2: bad arguments");
+  GANK_REQUIRE(ksize >= 1 && ksize <= 7 && pad >= 0 && Cout >= 1 && Cout <= 4 && ksize * ksize * Cout <= Zc,
+               "tap_gather_up2: k=%d Cout=%d needs Cout <= 4 and k*k*Cout <= Zc=%d", ksize, Cout, Zc);
+  const long pixels = (long)N * 4 * h * w;
+  hipLaunchKernelGGL(tap_gather_up2_kernel, g1(pixels), dim3(256), 0, (hipStream_t)stream, (const bf16*)Z, bias, (bf16*)y, pixels, h, w, ksize, pad,
+                     Cout, Zc, tanh_out);
+  GANK_LAUNCH_OK("tap_gather_up2");
+  return 0;
+}
+extern "C" int gank_tap_scatter_up2(const void* g, void* col, int N, int h, int w, int ksize, int pad, int Cout, int Zc, void* stream) {
+  GANK_REQUIRE(g && col && N > 0 && h > 0 && w > 0, "tap_scatter_up2: bad arguments");
+  GANK_REQUIRE(ksize >= 1 && ksize <= 7 && pad >= 0 && Cout >= 1 && Cout <= 4 && ksize * ksize * Cout <= Zc && Zc % 8 == 0,
+               "tap_scatter_up2: k=%d Cout=%d needs Cout <= 4, k*k*Cout <= Zc=%d and Zc %% 8 == 0", ksize, Cout, Zc);
+  const long total8 = (long)N * h * w * (Zc / 8);
+  hipLaunchKernelGGL(tap_scatter_up2_kernel, g1(total8), dim3(256), 0, (hipStream_t)stream, (const bf16*)g, (bf16*)col, total8, h, w, ksize, pad, Cout, Zc);
+  GANK_LAUNCH_OK("tap_scatter_up2");
+  return 0;
+}

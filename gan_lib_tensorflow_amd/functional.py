@@ -272,6 +272,9 @@ class _Conv2d(Function):
         return dx, dW, db, dres, None, None, None, None, None
 
 
+FEW_OUT_UPCONV = True    # upsample + conv with <= 4 output channels (Pix2Pix decoder_1): 1x1 conv at low resolution + tap gather (gank_tap_gather_up2)
+
+
 class _ConvGeneral(Function):
     """Convolution with any filter size (even ones too), stride 1 or 2 and an explicit leading pad -- the 4x4 convs of the
     Pix2Pix U-Net and PatchGAN critic (Pix2Pix/networks.py:366-536).  `pad` rows / columns of zeros in front; the output
@@ -281,6 +284,18 @@ class _ConvGeneral(Function):
     def forward(ctx, x, W, bias, stride, pad, out_hw, upsample, in_relu, out_tanh):
         k, cin, cout = W.shape[0], W.shape[2], W.shape[3]
         assert x.dim() == 4 and x.shape[3] == cin, (tuple(x.shape), tuple(W.shape))
+        ctx.few = (FEW_OUT_UPCONV and upsample and stride == 1 and cout <= 4 and k * k * cout <= 64 and cin % 64 == 0
+                   and tuple(out_hw) == (2 * x.shape[1], 2 * x.shape[2]))
+        if ctx.few:
+            # <= 4 output channels behind the upsample: a 1x1 conv at low resolution to the k*k*Cout tap partials + a tap gather
+            wz = torch.nn.functional.pad(W.detach().permute(2, 0, 1, 3).reshape(cin, k * k * cout), (0, 64 - k * k * cout)).contiguous()
+            wf, wd = K.prep_weights(wz.view(1, 1, cin, 64), True, True)
+            Z = K.conv2d_fprop(x, wf, None, (x.shape[1], x.shape[2]), 64, 1, K.IN_RELU if in_relu else 0)
+            y = K.tap_gather_up2(Z, bias.detach() if bias is not None else None, k, pad, cout, out_tanh)
+            ctx.wd_few = wd
+            ctx.save_for_backward(x, W, y if out_tanh else None)
+            ctx.cfg = (k, cin, cout, stride, pad, upsample, in_relu, out_tanh, bias)
+            return y
         wf, _ = _prepared(W, k, cin, cout, True, False)
         flags = (K.IN_UPSAMPLE2X if upsample else 0) | (K.IN_RELU if in_relu else 0) | (K.OUT_TANH if out_tanh else 0)
         y = K.conv2d_general_fprop(x, wf, bias.detach() if bias is not None else None, out_hw, cout, k, stride, pad, flags)
@@ -300,6 +315,20 @@ class _ConvGeneral(Function):
         if bias is not None and ctx.needs_input_grad[2]:
             btgt, bacc = _target(bias)
             db = None if bacc else btgt
+        if ctx.few:
+            n, h, w, _ = x.shape
+            col = K.tap_scatter_up2(g, k, pad, 64)                  # gradient of the tap partials Z
+            if ctx.needs_input_grad[1]:
+                tgt, acc = _target(W)
+                tmp = torch.zeros((1, 1, cin, 64), dtype=torch.float32, device=x.device)
+                K.conv2d_wgrad(x, col, tmp, (h, w), 1, K.IN_RELU if in_relu else 0, 1.0)
+                tgt.view(k * k, cin, cout).add_(tmp.view(cin, 64)[:, :k * k * cout].reshape(cin, k * k, cout).permute(1, 0, 2))
+                dW = None if acc else tgt
+            if btgt is not None:
+                K.colsum(g, btgt, 1.0)
+            if ctx.needs_input_grad[0]:
+                dx = K.conv2d_dgrad(col, ctx.wd_few, (h, w), cin, 1, 0, 1.0, None, x if in_relu else None)
+            return dx, dW, db, None, None, None, None, None, None
         if ctx.needs_input_grad[1]:
             tgt, acc = _target(W)
             K.conv2d_general_wgrad(x, g, tgt, k, stride, pad, (K.IN_UPSAMPLE2X if upsample else 0) | (K.IN_RELU if in_relu else 0), dbias=btgt)

@@ -262,6 +262,23 @@ def im2col_narrow(x, out_hw, ksize, stride, pad, kpad):
     return y
 
 
+def tap_gather_up2(Z, bias, ksize, pad, cout, tanh_out=False):
+    """Z [N,h,w,Zc] (column t*cout + co) -> y [N,2h,2w,cout] = (tanh)(bias + taps gathered): gank_tap_gather_up2"""
+    n, h, w, zc = Z.shape
+    y = torch.empty((n, 2 * h, 2 * w, cout), dtype=BF16, device=Z.device)
+    _lib.check(lib().gank_tap_gather_up2(_p(Z, BF16, "Z"), _p(bias, F32, "bias"), _p(y), n, h, w, ksize, pad, cout, zc, 1 if tanh_out else 0, _stream()),
+               "tap_gather_up2")
+    return y
+
+
+def tap_scatter_up2(g, ksize, pad, zc):
+    """g [N,2h,2w,cout] -> col [N,h,w,zc]: the gradient of Z (gank_tap_scatter_up2)"""
+    n, h2, w2, cout = g.shape
+    col = torch.empty((n, h2 // 2, w2 // 2, zc), dtype=BF16, device=g.device)
+    _lib.check(lib().gank_tap_scatter_up2(_p(g, BF16, "g"), _p(col), n, h2 // 2, w2 // 2, ksize, pad, cout, zc, _stream()), "tap_scatter_up2")
+    return col
+
+
 IM2COL_NARROW_WGRAD = True    # filter gradients of layers with k*k*Cin <= 128 and Cin < 32 (Pix2Pix's 4x4 stride-2 input layers) through im2col + the 1x1 MFMA kernels
 
 

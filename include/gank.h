@@ -504,6 +504,14 @@ int gank_relu_to_channels(const void* x, void* y, long pixels, int C, int Cy, in
  * 3- / 6-channel inputs (networks.py:335-342, :474-486) into the filter gradient of a 1x1 conv (gank_conv2d_wgrad, ksize 1, Cin = Kpad). */
 int gank_im2col_narrow(const void* x, void* y, int N, int Hin, int Win, int Cin, int Ho, int Wo, int ksize, int stride, int pad,
                        int Kpad, void* stream);
+/* A conv with <= 4 output channels behind a 2x NN-upsample (Pix2Pix decoder_1: relu, upsample, 4x4 SAME, 3 channels, tanh;
+ * networks.py:424-452) = a 1x1 conv at low resolution to Z [N,h,w,Zc] (column t*Cout + co = tap t's partial output; any MFMA 1x1
+ * kernel) followed by gank_tap_gather_up2: y [N,2h,2w,Cout] = tanh(bias + the taps' partials gathered from Z).  Backward:
+ * gank_tap_scatter_up2 turns g [N,2h,2w,Cout] into col [N,h,w,Zc] (the gradient of Z); input and filter gradients are the 1x1
+ * conv's (gank_conv2d_dgrad / gank_conv2d_wgrad on col).  pad = leading zero rows / columns of the k x k window on the upsampled grid. */
+int gank_tap_gather_up2(const void* Z, const float* bias, void* y, int N, int h, int w, int ksize, int pad, int Cout, int Zc,
+                        int tanh_out, void* stream);
+int gank_tap_scatter_up2(const void* g, void* col, int N, int h, int w, int ksize, int pad, int Cout, int Zc, void* stream);
 int gank_split_channels(const void* y, void* a, void* b, long pixels, int Ca, int Cb, void* stream);
 int gank_l1_loss(const void* a, const void* b, float* loss, float* dl32, float* ws, long n, void* stream);
 int gank_dropout_fwd(const void* x, void* y, uint8_t* mask, long n, float keep, uint64_t* rng_state, void* stream);
