@@ -1589,21 +1589,21 @@ int gank_igemm_dispatch(IgemmArgs a, hipStream_t s) {
   } else if (packed) {
     if (a.CoutPad % 64 == 0) rc = launch_cfg<2, 2, 1, 1, true, 1, 0>(a, s);
     else rc = launch_cfg<4, 1, 2, 1, true, 1, 0>(a, s);
+#ifdef GANK_TUNING          // tile shapes and prefetch depths that lost their A/B runs: only an experiment build instantiates them
   } else if (a.CoutPad % 128 == 0 && tiles128 >= t128_min() && pf_env >= 20) {
     if (pf_env == 20) rc = launch_mode<4, 2, 2, 2, 1>(a, s);          // 256 x 128, 8 waves
-    else if (pf_env == 21) rc = launch_mode<4, 2, 2, 2, 2>(a, s);
     else if (pf_env == 22 && a.CoutPad % 256 == 0) rc = launch_mode<2, 4, 2, 2, 2>(a, s);   // 128 x 256
     else if (pf_env == 23 && a.CoutPad % 256 == 0) rc = launch_mode<4, 2, 2, 4, 2>(a, s);   // 256 x 256, wave 64x128
     else rc = launch_mode<4, 2, 2, 2, 2>(a, s);
-  } else if (a.CoutPad % 128 == 0 && tiles128 >= t128_min() && pf_env < 10) {
-    if (pf_env == 1) rc = launch_mode<2, 2, 2, 2, 1>(a, s);
-    else if (pf_env == 3) rc = launch_mode<2, 2, 2, 2, 3>(a, s);
-    else rc = launch_mode<2, 2, 2, 2, 2>(a, s);
+  } else if (a.CoutPad % 128 == 0 && tiles128 >= t128_min() && (pf_env == 1 || pf_env == 3)) {
+    rc = pf_env == 1 ? launch_mode<2, 2, 2, 2, 1>(a, s) : launch_mode<2, 2, 2, 2, 3>(a, s);
+  } else if (a.CoutPad % 64 == 0 && !(a.CoutPad % 128 == 0 && tiles128 >= t128_min()) && (pf_env == 1 || pf_env == 11 || pf_env == 12 || pf_env == 3)) {
+    rc = (pf_env == 1 || pf_env == 11) ? launch_mode<2, 2, 1, 1, 1>(a, s) : launch_mode<2, 2, 1, 1, 2>(a, s);
+#endif
+  } else if (a.CoutPad % 128 == 0 && tiles128 >= t128_min()) {
+    rc = launch_mode<2, 2, 2, 2, 2>(a, s);               // 128 x 128 tiles, prefetch depth 2
   } else if (a.CoutPad % 64 == 0) {
-    if (pf_env == 1 || pf_env == 11) rc = launch_mode<2, 2, 1, 1, 1>(a, s);
-    else if (pf_env == 12) rc = launch_mode<2, 2, 1, 1, 2>(a, s);
-    else if (pf_env == 3) rc = launch_mode<2, 2, 1, 1, 2>(a, s);
-    else rc = launch_mode<2, 2, 1, 1, 4>(a, s);
+    rc = launch_mode<2, 2, 1, 1, 4>(a, s);               // 64 x 64 tiles (4x the workgroups: small grids round better on 256 CUs), depth 4
   } else {
     rc = launch_mode<4, 1, 2, 1, 2>(a, s);
   }

@@ -296,10 +296,12 @@ __global__ __launch_bounds__(512 / TPW) void res8_chain_bwd_kernel(ResBwdArgs a)
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
+#ifdef GANK_TUNING
 static int res8_cfg() {          // experiment knob GANK_RES8_CFG = 10*TPW + {1: 8, 2: 12, 3: 24 fragments in flight}: 12 = 8 waves, 12 in flight (default)
   static const int v = gank_tune("GANK_RES8_CFG", 12);
   return v;
 }
+#endif
 template <int TPW, int PF>
 static int res8_launch_fwd(const ResFwdArgs& a, hipStream_t s) {
   GANK_MAX_DYNAMIC_LDS((res8_chain_fwd_kernel<TPW, PF>), RB_LDS, "res8_chain_fwd");
@@ -312,6 +314,7 @@ static int res8_launch_bwd(const ResBwdArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((res8_chain_bwd_kernel<TPW, PF>), dim3(a.N), dim3(512 / TPW), RB_LDS, s, a);
   return 0;
 }
+#ifdef GANK_TUNING
 #define RES8_DISPATCH(fn, a, s)                                      \
   switch (res8_cfg()) {                                              \
     case 11: rc = fn<1, 8>(a, s); break;                             \
@@ -321,6 +324,9 @@ static int res8_launch_bwd(const ResBwdArgs& a, hipStream_t s) {
     case 23: rc = fn<2, 24>(a, s); break;                            \
     default: rc = fn<1, 12>(a, s); break;                            \
   }
+#else          // 8 waves per sample, 12 weight fragments in flight: the configuration that won the sweep
+#define RES8_DISPATCH(fn, a, s) rc = fn<1, 12>(a, s)
+#endif
 
 extern "C" int gank_res8_chain_fwd(const void* x, const void* const* w_rfrag, const float* const* bias, void* const* h1,
                                    void* const* y, void* pooled, int N, int C, int nblocks, void* stream) {

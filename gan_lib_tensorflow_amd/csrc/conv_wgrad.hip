@@ -1225,7 +1225,12 @@ static int launch_wgrad_taps_mode(WgradArgs a, hipStream_t s) {
   }
   const size_t lds = (size_t)2 * 2 * (XSUB + SUBS) * sizeof(bf16);
   static const int tpf = gank_tune("GANK_WGRAD_TAPS_PF", 2);
+#ifdef GANK_TUNING
   auto kern = tpf == 1 ? conv_wgrad_taps_kernel<MODE, 1> : conv_wgrad_taps_kernel<MODE, 2>;
+#else
+  (void)tpf;
+  auto kern = conv_wgrad_taps_kernel<MODE, 2>;
+#endif
   static const std::string tag = gank_format("conv_wgrad_taps_kernel<%d, 2> + wgrad_reduce_slabs_kernel", MODE);     // magic static: built once, thread-safe
   gank_prof_tag(1, tag.c_str());
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_ci * a.tiles_co * a.splits)), dim3(256), lds, s, a);
@@ -1491,8 +1496,13 @@ static int launch_wgrad_rows(WgradArgs a, hipStream_t s) {
   const size_t lds = (size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16);
   const bool relu = (a.flags & GANK_IN_RELU) != 0;
   static const int pf = gank_tune("GANK_WGRAD_ROWS_PF", 2);   // experiment knob: register prefetch depth
+#ifdef GANK_TUNING
   auto kern = relu ? (pf == 4 ? conv_wgrad_rows_kernel<1, 4, false> : pf == 3 ? conv_wgrad_rows_kernel<1, 3, false> : conv_wgrad_rows_kernel<1, 2, false>)
                    : (pf == 4 ? conv_wgrad_rows_kernel<0, 4, false> : pf == 3 ? conv_wgrad_rows_kernel<0, 3, false> : conv_wgrad_rows_kernel<0, 2, false>);
+#else
+  (void)pf;
+  auto kern = relu ? conv_wgrad_rows_kernel<1, 2, false> : conv_wgrad_rows_kernel<0, 2, false>;
+#endif
   static_assert((size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16) <= 65536, "below the default dynamic-LDS limit: no attribute call");
   gank_prof_tag(1, relu ? "conv_wgrad_rows_kernel<1, 2, false>" : "conv_wgrad_rows_kernel<0, 2, false>");
   hipLaunchKernelGGL(kern, dim3((unsigned)(3 * a.tiles_ci * a.tiles_co * a.splits), nb), dim3(256), lds, s, a);
@@ -1546,10 +1556,14 @@ int gank_wgrad_dispatch(WgradArgs a, hipStream_t s) {
   if (taps_env && wgrad_taps_ok(a)) rc = launch_wgrad_taps(a, s);
   if (rc < 0 && wgrad_rows_ok(a)) rc = launch_wgrad_rows(a, s);
   static const int lpf_env = gank_tune("GANK_WGRAD_LEAN_PF", 2);   // experiment knob: prefetch depth of the lean kernel
+  (void)lpf_env;
   if (rc < 0 && lean) {
+#ifdef GANK_TUNING
     if (a.Cin >= 128 && a.Cout >= 128 && lpf_env == 4) rc = launch_wgrad_lean<2, 2, 2, 2, 4>(a, s);
     else if (a.Cin >= 128 && a.Cout >= 128 && lpf_env == 3) rc = launch_wgrad_lean<2, 2, 2, 2, 3>(a, s);
-    else if (a.Cin >= 128 && a.Cout >= 128) rc = launch_wgrad_lean<2, 2, 2, 2, 2>(a, s);
+    else
+#endif
+    if (a.Cin >= 128 && a.Cout >= 128) rc = launch_wgrad_lean<2, 2, 2, 2, 2>(a, s);
     else if (a.Cin >= 64 && a.Cout >= 64) rc = launch_wgrad_lean<2, 2, 1, 1, 2>(a, s);
   }
   // narrow operands: pack (tap, channel) into <= 32 MFMA columns so the wide operand streams once
@@ -1716,8 +1730,13 @@ extern "C" int gank_convpool3x3_wgrad(const void* x, const void* dy, float* dw, 
     const size_t lds = (size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16);
     a.scale = 1.f;
     static const int pf = gank_tune("GANK_CPOOL_ROWS_PF", 2);   // experiment knob: register prefetch depth
+#ifdef GANK_TUNING
     auto kern = (flags & GANK_IN_RELU) ? (pf == 3 ? conv_wgrad_rows_kernel<1, 3, true> : conv_wgrad_rows_kernel<1, 2, true>)
                                        : (pf == 3 ? conv_wgrad_rows_kernel<0, 3, true> : conv_wgrad_rows_kernel<0, 2, true>);
+#else
+    (void)pf;
+    auto kern = (flags & GANK_IN_RELU) ? conv_wgrad_rows_kernel<1, 2, true> : conv_wgrad_rows_kernel<0, 2, true>;
+#endif
     static_assert((size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16) <= 65536, "below the default dynamic-LDS limit: no attribute call");
     hipLaunchKernelGGL(kern, dim3((unsigned)(4 * a.tiles_ci * a.tiles_co * a.splits)), dim3(256), lds, s, a);
     const long plane4 = (long)Cin * Cout / 4;
