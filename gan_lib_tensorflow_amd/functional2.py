@@ -125,8 +125,17 @@ class ConvF(Function):
         x, W = ctx.saved_tensors
         dy = _c(dy)
         dx = ConvD.apply(dy, W) if ctx.needs_input_grad[0] else None
-        dW = _conv_wgrad(x, dy, W) if (ctx.needs_input_grad[1] and not _dx_only[0]) else None
-        db = _colsum(dy, ctx.bias) if (ctx.has_bias and ctx.needs_input_grad[2] and not _dx_only[0]) else None
+        want_w = ctx.needs_input_grad[1] and not _dx_only[0]
+        want_b = ctx.has_bias and ctx.needs_input_grad[2] and not _dx_only[0]
+        if want_w and want_b:
+            tw, tb = _direct(W), _direct(ctx.bias)
+            if tw is not None and tb is not None:        # both accumulate in place: the bias gradient rides on the filter-gradient launch
+                k, cin, cout = _geom(W)
+                n, h, w, _ = x.shape
+                K.conv2d_wgrad(_c(x), dy, tw.view(k, k, cin, cout), (h, w), k, 0, 1.0, dbias=tb)
+                return dx, None, None
+        dW = _conv_wgrad(x, dy, W) if want_w else None
+        db = _colsum(dy, ctx.bias) if want_b else None
         return dx, dW, db
 
 
