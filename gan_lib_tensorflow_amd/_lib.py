@@ -76,6 +76,8 @@ PROTOTYPES = {
     "gank_im2col_narrow": [P, P, I, I, I, I, I, I, I, I, I, I, P],
     "gank_tap_gather_up2": [P, P, P, I, I, I, I, I, I, I, I, P],
     "gank_tap_scatter_up2": [P, P, I, I, I, I, I, I, I, P],
+    "gank_depth_to_space2": [P, P, I, I, I, I, P],
+    "gank_space_to_depth2": [P, P, I, I, I, I, P],
     "gank_cpool_res_fprop": [P, P, P, P, P, I, I, I, I, I, I, P],
     "gank_cpool_res_dgrad": [P, P, P, P, I, I, I, I, I, P],
     "gank_deconv2d_prep_phases": [P, P, I, I, I, P],

@@ -449,3 +449,36 @@ extern "C" int gank_tap_scatter_up2(const void* g, void* col, int N, int h, int 
   GANK_LAUNCH_OK("tap_scatter_up2");
   return 0;
 }
+
+// depth_to_space / space_to_depth with block size 2 in the channel order (a, b, c): y[n, 2i+a, 2j+b, c] = x[n, i, j, (2a+b) C + c]
+// -- the interleave behind a phase-stacked conv (functional.conv2d_general: NN-upsample + 4x4 as ONE 3x3 conv at low resolution
+// with 4 C output channels) and its adjoint.  16 bytes per lane, C % 8 == 0.
+template <bool FWD>
+__global__ void d2s2_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, long total8, int h, int w, int C) {
+  const long i8 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i8 >= total8) return;
+  const int cg = C >> 3;
+  // index over the HIGH-resolution tensor [n, 2h, 2w, C/8]
+  const int g = (int)(i8 % cg);
+  long t = i8 / cg;
+  const int X = (int)(t % (2 * w)); t /= 2 * w;
+  const int Y = (int)(t % (2 * h));
+  const long n = t / (2 * h);
+  const long lo = (((n * h + (Y >> 1)) * w + (X >> 1)) * 4 + (Y & 1) * 2 + (X & 1)) * cg + g;
+  if (FWD) reinterpret_cast<u32x4*>(dst)[i8] = reinterpret_cast<const u32x4*>(src)[lo];
+  else reinterpret_cast<u32x4*>(dst)[lo] = reinterpret_cast<const u32x4*>(src)[i8];
+}
+extern "C" int gank_depth_to_space2(const void* x, void* y, int N, int h, int w, int C, void* stream) {
+  GANK_REQUIRE(x && y && N > 0 && h > 0 && w > 0 && C > 0 && C % 8 == 0, "depth_to_space2: bad arguments (C %% 8 == 0)");
+  const long total8 = (long)N * 4 * h * w * (C / 8);
+  hipLaunchKernelGGL(d2s2_kernel<true>, g1(total8), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, total8, h, w, C);
+  GANK_LAUNCH_OK("depth_to_space2");
+  return 0;
+}
+extern "C" int gank_space_to_depth2(const void* y, void* x, int N, int h, int w, int C, void* stream) {
+  GANK_REQUIRE(x && y && N > 0 && h > 0 && w > 0 && C > 0 && C % 8 == 0, "space_to_depth2: bad arguments (C %% 8 == 0)");
+  const long total8 = (long)N * 4 * h * w * (C / 8);
+  hipLaunchKernelGGL(d2s2_kernel<false>, g1(total8), dim3(256), 0, (hipStream_t)stream, (const bf16*)y, (bf16*)x, total8, h, w, C);
+  GANK_LAUNCH_OK("space_to_depth2");
+  return 0;
+}

@@ -357,7 +357,77 @@ class _ConvGeneral(Function):
         return dx, dW, db, None, None, None, None, None, None
 
 
+# NN-upsample + 4x4 SAME conv (Pix2Pix decoders) by output phase: output row 2i + a reads the low-resolution rows
+#   a = 0: i-1 (ky 0), i (ky 1 + ky 2), i+1 (ky 3);     a = 1: i (ky 0 + ky 1), i+1 (ky 2 + ky 3)
+# so all four phases are 3x3 convs of the low-resolution input whose filters are sums of the 4x4 filter's taps.
+_PHASE4 = torch.tensor([[[1., 0, 0, 0], [0, 1, 1, 0], [0, 0, 0, 1]], [[0., 0, 0, 0], [1, 1, 0, 0], [0, 0, 1, 1]]])      # [a][u][ky]
+_phase4_dev = {}
+
+
+def _phase4(device):
+    """the phase matrix on `device`, copied there ONCE (a host-to-device copy inside a captured graph would replay garbage)"""
+    key = str(device)
+    if key not in _phase4_dev:
+        assert not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()), "first use of the phase-stacked conv inside a graph capture"
+        _phase4_dev[key] = _PHASE4.to(device)
+    return _phase4_dev[key]
+
+PHASE_STACK_MIN_PIXELS = 16384    # low-resolution pixels; below, the stacked filter (9/4 of the 4x4 one, rebuilt and folded back every pass) costs more than the taps it saves
+PHASE_STACK_UPCONV4 = True    # ... run as ONE 3x3 conv to 4 Cout channels (phase-major) + depth_to_space: 36 instead of 64 taps per 2x2 outputs, on the patch / two-group kernels
+
+
+class _PhaseStack4(Function):
+    """[4,4,Cin,Cout] filter -> the stacked 3x3 filter [3,3,Cin,4 Cout] of the four output phases (phase-major output channels);
+    backward folds the stacked gradient back and adds it to wherever the filter's gradient lives"""
+
+    @staticmethod
+    def forward(ctx, W):
+        ctx.W = W
+        A = _phase4(W.device)
+        cin, cout = W.shape[2], W.shape[3]
+        return torch.einsum('auk,bvl,klio->uviabo', A, A, W.detach()).reshape(3, 3, cin, 4 * cout).contiguous()
+
+    @staticmethod
+    def backward(ctx, g3):
+        W = ctx.W
+        A = _phase4(W.device)
+        cin, cout = W.shape[2], W.shape[3]
+        tgt, acc = _target(W)
+        tgt.add_(torch.einsum('auk,bvl,uviabo->klio', A, A, g3.reshape(3, 3, cin, 2, 2, cout)))
+        return None if acc else tgt
+
+
+class _Tile4(Function):
+    """bias [C] -> [4 C] (one copy per output phase); backward: the four gradients summed into the bias gradient"""
+
+    @staticmethod
+    def forward(ctx, b):
+        ctx.b = b
+        return b.detach().repeat(4)
+
+    @staticmethod
+    def backward(ctx, g):
+        tgt, acc = _target(ctx.b)
+        tgt.add_(g.view(4, -1).sum(0))
+        return None if acc else tgt
+
+
+class _DepthToSpace2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return K.depth_to_space2(_c(x))
+
+    @staticmethod
+    def backward(ctx, g):
+        return K.space_to_depth2(_c(g))
+
+
 def conv2d_general(x, W, bias=None, stride=1, pad=0, out_hw=None, upsample=False, in_relu=False, out_tanh=False):
+    k, cin, cout = W.shape[0], W.shape[2], W.shape[3]
+    if (PHASE_STACK_UPCONV4 and upsample and k == 4 and stride == 1 and pad == 1 and not out_tanh and cin % 64 == 0 and cout % 32 == 0
+            and x.shape[0] * x.shape[1] * x.shape[2] >= PHASE_STACK_MIN_PIXELS and x.shape[1] % 8 == 0 and x.shape[2] % 16 == 0 and tuple(out_hw) == (2 * x.shape[1], 2 * x.shape[2])):
+        y3 = _Conv2d.apply(x, _PhaseStack4.apply(W), _Tile4.apply(bias) if bias is not None else None, None, False, in_relu, False, False, 0)
+        return _DepthToSpace2.apply(y3)
     return _ConvGeneral.apply(x, W, bias, int(stride), int(pad), (int(out_hw[0]), int(out_hw[1])), upsample, in_relu, out_tanh)
 
 

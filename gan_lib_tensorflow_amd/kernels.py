@@ -279,6 +279,22 @@ def tap_scatter_up2(g, ksize, pad, zc):
     return col
 
 
+def depth_to_space2(x):
+    """[N,h,w,4C] -> [N,2h,2w,C], channel order (a, b, c)"""
+    n, h, w, c4 = x.shape
+    y = torch.empty((n, 2 * h, 2 * w, c4 // 4), dtype=BF16, device=x.device)
+    _lib.check(lib().gank_depth_to_space2(_p(x, BF16, "x"), _p(y), n, h, w, c4 // 4, _stream()), "depth_to_space2")
+    return y
+
+
+def space_to_depth2(y):
+    """[N,2h,2w,C] -> [N,h,w,4C]: the adjoint (and inverse) of depth_to_space2"""
+    n, h2, w2, c = y.shape
+    x = torch.empty((n, h2 // 2, w2 // 2, 4 * c), dtype=BF16, device=y.device)
+    _lib.check(lib().gank_space_to_depth2(_p(y, BF16, "y"), _p(x), n, h2 // 2, w2 // 2, c, _stream()), "space_to_depth2")
+    return x
+
+
 IM2COL_NARROW_WGRAD = True    # filter gradients of layers with k*k*Cin <= 128 and Cin < 32 (Pix2Pix's 4x4 stride-2 input layers) through im2col + the 1x1 MFMA kernels
 
 

@@ -512,6 +512,11 @@ int gank_im2col_narrow(const void* x, void* y, int N, int Hin, int Win, int Cin,
 int gank_tap_gather_up2(const void* Z, const float* bias, void* y, int N, int h, int w, int ksize, int pad, int Cout, int Zc,
                         int tanh_out, void* stream);
 int gank_tap_scatter_up2(const void* g, void* col, int N, int h, int w, int ksize, int pad, int Cout, int Zc, void* stream);
+/* depth_to_space / space_to_depth, block 2, channel order (a, b, c): y [N,2h,2w,C] <-> x [N,h,w,4C], y[n,2i+a,2j+b,c] = x[n,i,j,(2a+b)C+c]
+ * (tf.depth_to_space of gan_cifar_resnet.py:145 in NHWC; C % 8 == 0).  Behind a phase-stacked conv: NN-upsample + 4x4 SAME (Pix2Pix
+ * decoders, networks.py:424-439) = one 3x3 conv at low resolution to 4 C channels (36 instead of 64 taps per 2x2 outputs) + this. */
+int gank_depth_to_space2(const void* x, void* y, int N, int h, int w, int C, void* stream);
+int gank_space_to_depth2(const void* y, void* x, int N, int h, int w, int C, void* stream);
 int gank_split_channels(const void* y, void* a, void* b, long pixels, int Ca, int Cb, void* stream);
 int gank_l1_loss(const void* a, const void* b, float* loss, float* dl32, float* ws, long n, void* stream);
 int gank_dropout_fwd(const void* x, void* y, uint8_t* mask, long n, float keep, uint64_t* rng_state, void* stream);

@@ -57,6 +57,7 @@ def cos(got, ref):
     (2, 32, 6, 64, 2, 'VALID', 1, False, False, False),       # critic layer_1: tf.pad 1 + VALID
     (2, 16, 64, 128, 1, 'VALID', 1, False, False, False),     # critic layer_5: 16 -> 15
     (2, 15, 128, 1, 1, 'VALID', 1, False, False, False),      # critic layer_6: 15 -> 14, one output channel
+    (4, 64, 64, 32, 1, 'SAME', 0, True, True, False),         # a decoder large enough for the phase-stacked form (one 3x3 conv to 4 Cout + depth_to_space)
     (1, 256, 3, 64, 2, 'SAME', 0, False, False, False),       # encoder_1 at a size whose filter gradient takes the im2col + 1x1 route
     (1, 256, 6, 64, 2, 'VALID', 1, False, False, False),      # critic layer_1 likewise (96 im2col columns)
 ])
