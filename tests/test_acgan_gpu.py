@@ -153,11 +153,12 @@ def test_acgan_names_counts_and_forward(gpu):
     assert float(mm.abs().max()) > 0 and bool(torch.isfinite(mm).all())
 
 
-@pytest.mark.parametrize("batch", [8, 32])
+@pytest.mark.parametrize("batch", [8, 32, 256])
 def test_acgan_losses_and_gradients_vs_oracle(gpu, batch):
     """Critic loss with its three terms (hinge, gradient penalty through the double backward, class cross-entropy) and the
-    generator loss (hinge + 0.1 * cross-entropy), values and gradients, at batch 8 and at config 3's per-GPU batch 32
-    (256 over 8 ranks).  Critic gradients: relative L2 <= 0.25 / 0.2, cosine >= 0.975 / 0.985 at batch 8 / 32 (two bf16 backward
+    generator loss (hinge + 0.1 * cross-entropy), values and gradients, at batch 8, at config 3's per-GPU batch 32
+    (256 over 8 ranks) and at its whole batch of 256 on one GPU (absolute limits there: the bf16-storage pass of the float64
+    restatement is skipped at that size).  Critic gradients: relative L2 <= 0.25 / 0.2, cosine >= 0.975 / 0.985 at batch 8 / 32 (two bf16 backward
     passes through 7 batch norms; measured values at the assertion); generator gradients as in the SNGAN headline test."""
     tr, state = make(4, batch)
     rng = np.random.default_rng(batch)
@@ -172,17 +173,19 @@ def test_acgan_losses_and_gradients_vs_oracle(gpu, batch):
     gref = dict(zip(dn, torch.autograd.grad(loss_ref, [P[k] for k in dn])))
     # the yardstick: the restatement ITSELF with every stored tensor rounded to bf16 (tests/test_oracle.py::
     # test_bf16_storage_sensitivity_of_acgan_gradients), on these inputs
-    T.STORE = T.bf16_storage
-    try:
-        P2 = T.to_torch(state)
-        lb, _ = T.acgan_d_loss(P2, real, rl.long(), z, fl.long(), alpha.double())
-        dfloor = dict(zip(dn, torch.autograd.grad(lb, [P2[k] for k in dn])))
-        P2 = T.to_torch(state)
-        lgb, _ = T.acgan_g_loss(P2, z, fl.long())
-        gn_ = T.trainable_names(P2, 'g_net')
-        gfloor = dict(zip(gn_, torch.autograd.grad(lgb, [P2[k] for k in gn_])))
-    finally:
-        T.STORE = None
+    dfloor = gfloor = None
+    if batch <= 32:
+        T.STORE = T.bf16_storage
+        try:
+            P2 = T.to_torch(state)
+            lb, _ = T.acgan_d_loss(P2, real, rl.long(), z, fl.long(), alpha.double())
+            dfloor = dict(zip(dn, torch.autograd.grad(lb, [P2[k] for k in dn])))
+            P2 = T.to_torch(state)
+            lgb, _ = T.acgan_g_loss(P2, z, fl.long())
+            gn_ = T.trainable_names(P2, 'g_net')
+            gfloor = dict(zip(gn_, torch.autograd.grad(lgb, [P2[k] for k in gn_])))
+        finally:
+            T.STORE = None
     tr.d_flat['grads'].zero_()
     loss = tr.d_loss(realt, rl.cuda(), z=zt, fake_labels=fl.cuda(), alpha=alpha.cuda())
     loss.backward()
@@ -203,9 +206,10 @@ def test_acgan_losses_and_gradients_vs_oracle(gpu, batch):
                 bad.append((k, 'abs', float(tr.store.vars[k].grad.abs().max())))
         elif c < lim[0] or e > lim[1]:
             bad.append((k, c, e))
-        elif e > 1.5 * l2(dfloor[k], gref[k]) + 0.05:         # per tensor: at most 1.5x as far from float64 as bf16 storage alone (+ 0.05)
+        elif batch <= 32 and e > 1.5 * l2(dfloor[k], gref[k]) + 0.05:         # per tensor: at most 1.5x as far from float64 as bf16 storage alone (+ 0.05)
             bad.append((k, 'floor', e, l2(dfloor[k], gref[k])))
-    print("acgan D grads, bf16-storage floor of the restatement:", {k.split('/', 1)[1]: round(l2(dfloor[k], gref[k]), 3) for k in dn if float(gref[k].norm()) > 1e-9})
+    if dfloor is not None:
+        print("acgan D grads, bf16-storage floor of the restatement:", {k.split('/', 1)[1]: round(l2(dfloor[k], gref[k]), 3) for k in dn if float(gref[k].norm()) > 1e-9})
     assert not bad, bad
     # generator
     loss_ref, _ = T.acgan_g_loss(P, z, fl.long())
@@ -225,8 +229,8 @@ def test_acgan_losses_and_gradients_vs_oracle(gpu, batch):
         # the generator's gradient crosses the critic's 7 batch norms and its own 7 before it reaches G.Input: the bf16
         # storage floor of tests/test_oracle.py::test_bf16_storage_sensitivity_of_generator_gradients, twice as deep
         # (measured at G.Input/W: cosine 0.967 / L2 0.256 at batch 8, 0.970 / 0.247 at batch 32)
-        f = l2(gfloor[k], gref[k])
-        if c < 0.95 or e > 0.35 or e > 1.5 * f + 0.05:
+        f = l2(gfloor[k], gref[k]) if gfloor is not None else 0.0
+        if c < 0.95 or e > 0.35 or (batch <= 32 and e > 1.5 * f + 0.05):
             bad.append((k, c, e, f))
     assert not bad, bad
 
