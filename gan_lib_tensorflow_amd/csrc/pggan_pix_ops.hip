@@ -157,14 +157,44 @@ __global__ void split_c_kernel(const bf16* __restrict__ y, bf16* __restrict__ a,
     else if (b) b[p * Cb + (c - Ca)] = y[i];
   }
 }
+// the same, 16 bytes per lane, when both channel counts are multiples of 8 (the U-Net skips: 34 us -> HBM speed)
+__global__ void concat_c8_kernel(const u32x4* __restrict__ a, const u32x4* __restrict__ b, u32x4* __restrict__ y, long total8, int Ga, int Gb) {
+  const int G = Ga + Gb;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
+    const long p = i / G;
+    const int g = (int)(i - p * G);
+    y[i] = g < Ga ? a[p * Ga + g] : b[p * Gb + (g - Ga)];
+  }
+}
+__global__ void split_c8_kernel(const u32x4* __restrict__ y, u32x4* __restrict__ a, u32x4* __restrict__ b, long total8, int Ga, int Gb) {
+  const int G = Ga + Gb;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
+    const long p = i / G;
+    const int g = (int)(i - p * G);
+    if (g < Ga) { if (a) a[p * Ga + g] = y[i]; }
+    else if (b) b[p * Gb + (g - Ga)] = y[i];
+  }
+}
 extern "C" int gank_concat_channels(const void* a, const void* b, void* y, long pixels, int Ca, int Cb, void* stream) {
   GANK_REQUIRE(a && b && y && pixels > 0 && Ca > 0 && Cb > 0, "concat_channels: bad arguments");
+  if (Ca % 8 == 0 && Cb % 8 == 0) {
+    const long total8 = pixels * ((Ca + Cb) / 8);
+    hipLaunchKernelGGL(concat_c8_kernel, g1(total8), dim3(256), 0, (hipStream_t)stream, (const u32x4*)a, (const u32x4*)b, (u32x4*)y, total8, Ca / 8, Cb / 8);
+    GANK_LAUNCH_OK("concat_channels");
+    return 0;
+  }
   hipLaunchKernelGGL(concat_c_kernel, g1(pixels * (Ca + Cb)), dim3(256), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b, (bf16*)y, pixels, Ca, Cb);
   GANK_LAUNCH_OK("concat_channels");
   return 0;
 }
 extern "C" int gank_split_channels(const void* y, void* a, void* b, long pixels, int Ca, int Cb, void* stream) {
   GANK_REQUIRE(y && (a || b) && pixels > 0 && Ca > 0 && Cb > 0, "split_channels: bad arguments");
+  if (Ca % 8 == 0 && Cb % 8 == 0) {
+    const long total8 = pixels * ((Ca + Cb) / 8);
+    hipLaunchKernelGGL(split_c8_kernel, g1(total8), dim3(256), 0, (hipStream_t)stream, (const u32x4*)y, (u32x4*)a, (u32x4*)b, total8, Ca / 8, Cb / 8);
+    GANK_LAUNCH_OK("split_channels");
+    return 0;
+  }
   hipLaunchKernelGGL(split_c_kernel, g1(pixels * (Ca + Cb)), dim3(256), 0, (hipStream_t)stream, (const bf16*)y, (bf16*)a, (bf16*)b, pixels, Ca, Cb);
   GANK_LAUNCH_OK("split_channels");
   return 0;
