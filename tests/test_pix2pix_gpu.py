@@ -314,3 +314,65 @@ def test_pix2pix_batch16_critic_pass_is_the_mean_of_its_sub_batches(gpu):
     g4 = tr.d_flat['grads'] / 4
     assert l2(g16, g4.double().cpu()) < 1e-2, l2(g16, g4.double().cpu())
     tr.d_flat['grads'].zero_()
+
+
+def test_im2col_depth_to_space_and_tap_kernels_against_numpy(gpu):
+    """The data-movement kernels behind the round-3 Pix2Pix routes, each against a NumPy restatement: gank_im2col_narrow (bit for bit:
+    a gather of bf16 values), gank_depth_to_space2 / gank_space_to_depth2 (bit for bit, and inverse of each other), gank_tap_scatter_up2
+    (sums of at most 4 bf16 values in fp32, rounded once) and gank_tap_gather_up2 (sums of k*k partials + bias, tanh)."""
+    from gan_lib_tensorflow_amd import kernels as K
+    rng = np.random.default_rng(12)
+    # im2col: 4x4 stride 2 pad 1 on a 6-channel image (critic layer_1), 96 columns padded to 128
+    x, xt = bf(rng.normal(size=(2, 10, 12, 6)))
+    col = K.im2col_narrow(xt, (5, 6), 4, 2, 1, 128)
+    ref = np.zeros((2, 5, 6, 128))
+    xn = x.numpy()
+    for oy in range(5):
+        for ox in range(6):
+            for ky in range(4):
+                for kx in range(4):
+                    iy, ix = 2 * oy - 1 + ky, 2 * ox - 1 + kx
+                    if 0 <= iy < 10 and 0 <= ix < 12:
+                        ref[:, oy, ox, (ky * 4 + kx) * 6:(ky * 4 + kx) * 6 + 6] = xn[:, iy, ix, :]
+    torch.cuda.synchronize()
+    assert np.array_equal(col.double().cpu().numpy(), ref)
+    # depth_to_space / space_to_depth
+    y3, y3t = bf(rng.normal(size=(2, 3, 5, 4 * 16)))
+    y = K.depth_to_space2(y3t)
+    refy = y3.numpy().reshape(2, 3, 5, 2, 2, 16).transpose(0, 1, 3, 2, 4, 5).reshape(2, 6, 10, 16)
+    torch.cuda.synchronize()
+    assert np.array_equal(y.double().cpu().numpy(), refy) and torch.equal(K.space_to_depth2(y), y3t)
+    # tap scatter / gather for a 4x4 window with 1 leading pad behind a 2x upsample, 3 output channels, 64 columns
+    g, gt = bf(rng.normal(size=(2, 8, 12, 3)))
+    colg = K.tap_scatter_up2(gt, 4, 1, 64)
+    refc = np.zeros((2, 4, 6, 64))
+    gn = g.numpy()
+    for qy in range(4):
+        for qx in range(6):
+            for ky in range(4):
+                for kx in range(4):
+                    for a in range(2):
+                        for b_ in range(2):
+                            py, px = 2 * qy + a - (ky - 1), 2 * qx + b_ - (kx - 1)
+                            if 0 <= py < 8 and 0 <= px < 12:
+                                refc[:, qy, qx, (ky * 4 + kx) * 3:(ky * 4 + kx) * 3 + 3] += gn[:, py, px, :]
+    torch.cuda.synchronize()
+    assert rel(colg, refc) < 5e-3
+    z, zt = bf(rng.normal(size=(2, 4, 6, 64)))
+    bias = torch.tensor(rng.normal(size=3), dtype=torch.float32).cuda()
+    out = K.tap_gather_up2(zt, bias, 4, 1, 3, True)
+    refo = np.zeros((2, 8, 12, 3))
+    zn = z.numpy()
+    for py in range(8):
+        for px in range(12):
+            for ky in range(4):
+                for kx in range(4):
+                    iy, ix = py + ky - 1, px + kx - 1
+                    if 0 <= iy < 8 and 0 <= ix < 12:
+                        refo[:, py, px, :] += zn[:, iy >> 1, ix >> 1, (ky * 4 + kx) * 3:(ky * 4 + kx) * 3 + 3]
+    refo = np.tanh(refo + bias.cpu().numpy().astype(np.float64))
+    torch.cuda.synchronize()
+    assert rel(out, refo) < 5e-3
+    # <scatter(g), z> == <g, gather-without-bias(z)>: the two kernels are adjoint
+    out_lin = K.tap_gather_up2(zt, None, 4, 1, 3, False).double().cpu().numpy()
+    assert abs(float((refc * zn).sum()) - float((gn * out_lin).sum())) < 2e-2 * float(np.abs(refc * zn).sum())
