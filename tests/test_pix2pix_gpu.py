@@ -106,6 +106,13 @@ def test_concat_dropout_l1(gpu):
     g, gt = bf(rng.normal(size=y.shape))
     y.backward(gt)
     assert torch.equal(at.grad.cpu(), gt[..., :64].cpu()) and torch.equal(bt.grad.cpu(), gt[..., 64:].cpu())
+    # odd widths take the element-wise form (PGGAN: 513 + 63 channels of zero padding)
+    c, ct = bf(rng.normal(size=(2, 4, 4, 13)))
+    d, dt = bf(rng.normal(size=(2, 4, 4, 3)))
+    yo = K.concat_channels(ct, dt)
+    assert torch.equal(yo.cpu(), torch.cat([ct.cpu(), dt.cpu()], 3))
+    ca, cb = K.split_channels(yo, 13)
+    assert torch.equal(ca, ct) and torch.equal(cb, dt)
     # dropout: Bernoulli(keep) mask from the device RNG, survivors scaled by 1/keep, a fresh mask per call, same mask backward
     rs = K.new_rng_state(11, "cuda")
     x, xt = bf(rng.normal(size=(4, 16, 16, 512)))
