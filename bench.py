@@ -139,6 +139,9 @@ def main():
                          "communication stream, the all-reduces captured inside the update graphs -- what N > 1 ranks run, minus the wire")
     ap.add_argument("--grad-wire", default=None, choices=[None, "bf16"], help="16-bit gradient buckets on the wire (data parallel)")
     ap.add_argument("--no-capture-collectives", action="store_true", help="data parallel: collectives eagerly between graph replays (the round-2 form)")
+    ap.add_argument("--capture-collectives", action="store_true",
+                    help="data parallel, world > 1: RCCL all-reduces INSIDE the update graphs (default there: between graphs, until a "
+                         "multi-GPU run has verified replayed collectives; a world-size-1 group captures by default)")
     ap.add_argument("--set", action="append", default=[], metavar="module.NAME=value",
                     help="A/B runs: set a module constant of the package before the trainer is built, e.g. functional.RES8_CONV=False")
     args = ap.parse_args()
@@ -182,7 +185,7 @@ def main():
     # allow_eager_fallback: a capture failure on SOME ranks must not leave the others waiting in a collective -- every rank
     # finishes its warm-up, then all of them agree (MIN over ranks) whether to go on
     tr = S.SNGANTrainer(batch_size=per_gpu, device=device, seed=0, use_graphs=not args.no_graphs, process_group=pg,
-                        allow_eager_fallback=True, capture_collectives=not args.no_capture_collectives, grad_wire_dtype=args.grad_wire)
+                        allow_eager_fallback=True, capture_collectives=(False if args.no_capture_collectives else True if args.capture_collectives else None), grad_wire_dtype=args.grad_wire)
     feed = S.synthetic_batches(per_gpu, device, seed=rank)
 
     def barrier():

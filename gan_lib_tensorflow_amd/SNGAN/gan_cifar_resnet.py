@@ -250,12 +250,16 @@ class SNGANTrainer:
     losses, :436,:498)."""
 
     def __init__(self, batch_size=BATCH_SIZE, device="cuda", seed=0, use_graphs=True, process_group=None, state=None,
-                 allow_eager_fallback=False, capture_collectives=True, grad_wire_dtype=None, loss_scale=None):
+                 allow_eager_fallback=False, capture_collectives=None, grad_wire_dtype=None, loss_scale=None):
         """allow_eager_fallback: a failed hipGraph capture degrades to eager execution (with a message on stderr) instead of
         raising -- a run that asked for graphs never silently becomes a 10x slower eager run otherwise.
         capture_collectives: under data parallel the RCCL all-reduces are captured INSIDE the update graphs (one graph per
         critic update, one for the whole bucketed generator update) instead of being issued eagerly between graph replays;
-        a capture that fails falls back to the split form (graph / eager collective / graph) with a message.
+        a capture that fails falls back to the split form (graph / eager collective / graph) with a message.  Default (None):
+        on for a world-size-1 group (rehearsals: the replayed graph then holds NO collective node, RCCL's single-rank
+        all-reduce is a no-op), OFF for world > 1 -- a replayed RCCL collective has never run on more than one GPU in this
+        build's history (no multi-GPU node was available), so the multi-rank default is the well-trodden split form until a
+        run has verified replay against the eager exchange; pass True to opt in.  The ranks agree on the setting (MIN).
         grad_wire_dtype: 'bf16' sends the gradient buckets over xGMI in the 16-bit activation dtype (half the bytes).
         loss_scale: static loss scale, a power of two (default: 1 for bfloat16 buffers, 1024 for the fp16 build, whose activation
         gradients would otherwise underflow: hinge d loss / d logit is +-1/n and shrinks from there).  The loss nodes multiply
@@ -278,6 +282,8 @@ class SNGANTrainer:
         self.dp = process_group is not None          # the data-parallel path (also for a world-size-1 group: rehearsal / --force-dp)
         # only RCCL collectives are stream-ordered device work that a hipGraph can hold; gloo (the CPU rehearsal backend)
         # synchronises the stream from the host, which a capture must never see
+        if capture_collectives is None:
+            capture_collectives = self.world == 1
         self.capture_collectives = bool(capture_collectives and process_group is not None
                                         and _dist.get_backend(process_group) == "nccl")
         self.grad_wire_dtype = K.BF16 if grad_wire_dtype in ('bf16', 'fp16', '16') else None
@@ -584,13 +590,17 @@ class SNGANTrainer:
                             ph()
                             between(i)
                     self._graphs['g_seg'] = g
-                    return
                 except Exception as e:  # noqa: BLE001
                     import sys
                     torch.cuda.synchronize()
                     print(f"[gank] capturing the bucketed generator update with its collectives failed ({e}); one graph per phase, "
                           f"collectives between them", file=sys.stderr)
                     self.capture_collectives = False
+                self._agree_on_capture()        # (entered with the same setting on every rank, so every rank calls this)
+                if isinstance(self._graphs.get('g_seg'), torch.cuda.CUDAGraph):
+                    if self.capture_collectives:
+                        return
+                    del self._graphs['g_seg']   # another rank could not capture its collectives: every rank takes the split form
             try:
                 pool = torch.cuda.graph_pool_handle()
                 graphs = []
@@ -629,6 +639,15 @@ class SNGANTrainer:
         print(f"[gank] hipGraph capture of the {what} failed ({e}); running eagerly", file=sys.stderr)
         self.use_graphs = False
 
+    def _agree_on_capture(self):
+        """A rank whose capture of a collective failed replays graph / eager collective / graph while the others would replay
+        one graph: the SAME collectives in the same order, so it would even work -- but one rank's host then paces everyone.
+        All ranks take the split form as soon as one of them has to (MIN over ranks, as bench.py does for `graphs_ok`)."""
+        if self.world > 1:
+            flag = torch.tensor([1 if self.capture_collectives else 0], dtype=torch.int32, device=self.device)
+            _dist.all_reduce(flag, op=_dist.ReduceOp.MIN, group=self.pg)
+            self.capture_collectives = bool(int(flag.item()))
+
     def _allreduce(self, flat):
         if self.dp:
             parallel.allreduce_sum_(flat["grads"], self.pg, self.grad_wire_dtype, single_rank_too=True)
@@ -662,7 +681,6 @@ class SNGANTrainer:
                             self._allreduce(flat)
                             opt.apply()
                         self._graphs[key] = (g1, None)
-                        return
                     except Exception as e:  # noqa: BLE001
                         if not self.dp:
                             raise
@@ -671,6 +689,12 @@ class SNGANTrainer:
                         print(f"[gank] capturing the all-reduce inside the {key!r} update graph failed ({e}); "
                               f"the collective stays between two graphs", file=sys.stderr)
                         self.capture_collectives = False
+                    if self.dp:
+                        self._agree_on_capture()    # (entered with the same setting on every rank, so every rank calls this)
+                    if key in self._graphs:
+                        if not self.dp or self.capture_collectives:
+                            return
+                        del self._graphs[key]       # another rank fell back: every rank takes the split form
                 g1 = torch.cuda.CUDAGraph()
                 with _capture(g1):
                     fwd_bwd()

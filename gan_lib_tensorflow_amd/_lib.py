@@ -116,6 +116,7 @@ PROTOTYPES = {
     "gank_tanh_bwd": [P, P, P, L, P],
     "gank_scale_f32": [P, P, P, L, P],
     "gank_linear_fwd": [P, P, P, P, I, I, I, P],
+    "gank_linear_fwd_f32out": [P, P, P, P, I, I, I, P],
     "gank_linear_bwd": [P, P, P, P, P, P, I, I, I, P],
     "gank_copy_bytes": [P, P, L, P],
     "gank_copy_bytes_gather": [P, P, I, L, P],

@@ -4,6 +4,7 @@
 
 hipcc cross-compiles without a GPU; the .so is git-ignored but travels with gpurun snapshots.
 """
+import glob
 import os
 import subprocess
 import sys
@@ -25,7 +26,7 @@ def build(force=False, verbose=True, variants=("bf16", "fp16")):
     """libgank.so (bfloat16 buffers) and libgank_f16.so (IEEE half: the same sources with -DGANK_ACT_F16); returns the first
     path.  Every out-of-date object of BOTH variants compiles concurrently (one hipcc process per source file)."""
     base_flags = [f for f in FLAGS if f != "-DGANK_ACT_F16"]
-    hdrs = [os.path.join(CSRC, "gank_common.h"), os.path.join(INC, "gank.h")]
+    hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(INC, "gank.h")]   # every header rebuilds every object
     plans = []
     for variant in variants:
         if variant == "fp16":
@@ -40,8 +41,9 @@ def build(force=False, verbose=True, variants=("bf16", "fp16")):
         # a change of flags rebuilds every object of the directory (mtimes alone would keep objects of the old flags)
         stamp, flag_str = os.path.join(HERE, objdir, "flags.txt"), " ".join(flags)
         stale = not os.path.exists(stamp) or open(stamp).read() != flag_str
-        if stale:
-            open(stamp, "w").write(flag_str)
+        if stale and os.path.exists(stamp):
+            os.remove(stamp)        # rewritten only after every compile of this directory has succeeded: an interrupted
+                                    # or failed build must not leave old-flag objects that the next build takes as current
         objs, procs = [], []
         for src in SOURCES:
             sp = os.path.join(CSRC, src)
@@ -52,19 +54,23 @@ def build(force=False, verbose=True, variants=("bf16", "fp16")):
                 if verbose:
                     print(" ".join(cmd), flush=True)
                 procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        plans.append((lib, objs, procs))
+        plans.append((lib, objs, procs, stamp, flag_str))
     failed = False
-    for _, _, procs in plans:
+    for _, _, procs, stamp, flag_str in plans:
+        plan_failed = False
         for src, p in procs:
             out = p.communicate()[0].decode()
             if out.strip() and verbose:
                 print(out)
             if p.returncode != 0:
                 print(out, file=sys.stderr)
-                failed = True
+                failed = plan_failed = True
+        if not plan_failed:
+            with open(stamp, "w") as f:
+                f.write(flag_str)
     if failed:
         raise RuntimeError("hipcc failed")
-    for lib, objs, procs in plans:
+    for lib, objs, procs, _, _ in plans:
         if force or procs or not os.path.exists(lib) or any(_newer(o, lib) for o in objs):     # (a link that failed after its objects compiled)
             cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs]
             if verbose:

@@ -222,4 +222,5 @@ class InceptionV3:
     def logits(self, images, resize=299):
         """-> float32 numpy [N, 1008] (`logits:0`): the callable get_inception_score(classifier=...) expects"""
         f = self.features(images, resize)
-        return K.linear_fwd(f, self.fc_w, self.fc_b).to(torch.float32).cpu().numpy()
+        # fp32 logits: the score exponentiates them (16-bit logits at |l| ~ 10 would be +-0.04, a few percent per probability)
+        return K.linear_fwd(f, self.fc_w, self.fc_b, out_f32=True).cpu().numpy()

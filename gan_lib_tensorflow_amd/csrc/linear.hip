@@ -15,9 +15,12 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
 }
 
 // y[m][c] = sum_k x[m][k] w[k][c] + b[c];  lanes over c (coalesced w, y), RB rows per thread reuse each w load
-template <int RB>
+__device__ __forceinline__ void store_out(bf16* p, float v) { *p = f2bf(v); }
+__device__ __forceinline__ void store_out(float* p, float v) { *p = v; }
+
+template <int RB, typename OUT>
 __global__ __launch_bounds__(256) void linear_fwd_wide_kernel(const bf16* __restrict__ x, const float* __restrict__ w,
-                                                              const float* __restrict__ b, bf16* __restrict__ y, int M, int K, int C) {
+                                                              const float* __restrict__ b, OUT* __restrict__ y, int M, int K, int C) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   const int m0 = blockIdx.y * RB;
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void linear_fwd_wide_kernel(const bf16* __rest
     const float bv = b ? b[c] : 0.f;
 #pragma unroll
     for (int r = 0; r < RB; r++)
-      if (m0 + r < M) y[(long)(m0 + r) * C + c] = f2bf(red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane] + bv);
+      if (m0 + r < M) store_out(&y[(long)(m0 + r) * C + c], red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane] + bv);
   }
 }
 
@@ -199,10 +202,17 @@ extern "C" int gank_linear_fwd(const void* x, const float* w, const float* bias,
   GANK_REQUIRE(x && w && y && M > 0 && K > 0 && C > 0, "linear_fwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   if (C >= 64)
-    hipLaunchKernelGGL(linear_fwd_wide_kernel<2>, dim3(cdiv(C, 64), cdiv(M, 2)), dim3(256), 0, s, (const bf16*)x, w, bias, (bf16*)y, M, K, C);
+    hipLaunchKernelGGL((linear_fwd_wide_kernel<2, bf16>), dim3(cdiv(C, 64), cdiv(M, 2)), dim3(256), 0, s, (const bf16*)x, w, bias, (bf16*)y, M, K, C);
   else
     hipLaunchKernelGGL(linear_fwd_narrow_kernel, dim3(cdiv(M * C, 4)), dim3(256), 0, s, (const bf16*)x, w, bias, (bf16*)y, M, K, C);
   GANK_LAUNCH_OK("linear_fwd");
+  return 0;
+}
+
+extern "C" int gank_linear_fwd_f32out(const void* x, const float* w, const float* bias, float* y, int M, int K, int C, void* stream) {
+  GANK_REQUIRE(x && w && y && M > 0 && K > 0 && C > 0, "linear_fwd_f32out: bad arguments");
+  hipLaunchKernelGGL((linear_fwd_wide_kernel<2, float>), dim3(cdiv(C, 64), cdiv(M, 2)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, w, bias, y, M, K, C);
+  GANK_LAUNCH_OK("linear_fwd_f32out");
   return 0;
 }
 

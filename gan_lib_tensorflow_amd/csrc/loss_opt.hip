@@ -325,6 +325,9 @@ __global__ void adam_tf_kernel(float* __restrict__ p, float* __restrict__ g, flo
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const float gr = gg[e] * gs;
+      // loss-scaled runs (health != nullptr): an element whose gradient overflowed keeps p, m and v -- one fp16 overflow must
+      // not write NaN into the optimiser state for good (the captured graph would keep replaying on it); it is counted above
+      if (health && (gg[e] - gg[e] != 0.f)) continue;
       mm[e] = b1 * mm[e] + (1.f - b1) * gr;
       vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
       pp[e] -= lr_t * mm[e] / (sqrtf(vv[e]) + eps);
@@ -337,11 +340,15 @@ __global__ void adam_tf_kernel(float* __restrict__ p, float* __restrict__ g, flo
   if (blockIdx.x == 0)
     for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) {
       const float gr = g[i] * gs;
+      if (zero_n > 0) g[i] = 0.f;
+      if (health) {
+        bad += (gr - gr != 0.f) ? 1u : 0u; zero += gr == 0.f ? 1u : 0u;
+        if (gr - gr != 0.f) continue;
+      }
       const float mm = b1 * m[i] + (1.f - b1) * gr;
       const float vv = b2 * v[i] + (1.f - b2) * gr * gr;
       m[i] = mm; v[i] = vv;
       p[i] -= lr_t * mm / (sqrtf(vv) + eps);
-      if (zero_n > 0) g[i] = 0.f;
     }
   // the tail behind the gradients (n is a multiple of 4 whenever zero_n > n: checked by the host)
   for (long i = n4 + blockIdx.x * (long)blockDim.x + threadIdx.x; i < (zero_n >> 2); i += (long)gridDim.x * blockDim.x)

@@ -204,7 +204,9 @@ class _Conv2d(Function):
             ctx.res_link = rlink
         ctx.save_for_backward(x, W, y if out_tanh else None)
         ctx.cfg = (k, cin, cout, H, Wd, upsample, in_relu, pool_out, out_tanh, bias, phase, pool4)
-        ctx.res8 = res8 and W._prep_res[1] is not None
+        # the backward pass runs the same kernel with the channel roles swapped: its own geometry check (Cin there = cout here),
+        # otherwise the generic input-gradient path
+        ctx.res8 = res8 and W._prep_res[1] is not None and K.res8_conv3x3_ok(n, (8, 8), cout, cin)
         return y
 
     @staticmethod

@@ -525,13 +525,14 @@ def deconv2d_wgrad(x, dy, df, ksize):
     return df
 
 
-def linear_fwd(x, w, bias=None):
-    """y = x w + bias on the fp32 master weight (small layers): x bf16 [M,K], w fp32 [K,C] -> y bf16 [M,C]"""
+def linear_fwd(x, w, bias=None, out_f32=False):
+    """y = x w + bias on the fp32 master weight (small layers): x bf16 [M,K], w fp32 [K,C] -> y bf16 [M,C] (out_f32: fp32)"""
     m, k = x.shape
     c = w.shape[1]
     assert w.shape[0] == k, (x.shape, w.shape)
-    y = torch.empty((m, c), dtype=BF16, device=x.device)
-    _lib.check(lib().gank_linear_fwd(_p(x, BF16, "x"), _p(w, F32, "w"), _p(bias, F32, "bias"), _p(y), m, k, c, _stream()), "linear_fwd")
+    y = torch.empty((m, c), dtype=F32 if out_f32 else BF16, device=x.device)
+    fn = lib().gank_linear_fwd_f32out if out_f32 else lib().gank_linear_fwd
+    _lib.check(fn(_p(x, BF16, "x"), _p(w, F32, "w"), _p(bias, F32, "bias"), _p(y), m, k, c, _stream()), "linear_fwd")
     return y
 
 

@@ -383,6 +383,10 @@ int gank_cast_bf16_f32(const void* x, float* y, long n, void* stream);
  * large layers (G.Input 128->16384) use gank_conv2d_* with ksize 1.  bwd: dx (optional) = dy w^T; dw (optional)
  * += x^T dy; dbias (optional) += column sums of dy. */
 int gank_linear_fwd(const void* x, const float* w, const float* bias, void* y, int M, int K, int C, void* stream);
+/* the same with the result left in fp32 (y fp32 [M,C]): the 2048 -> 1008 `logits:0` layer of the Inception graph
+ * (common/inception/inception_score.py:44-56), whose outputs are exponentiated by the score -- rounding them to 16 bits
+ * first would move every class probability by a few percent */
+int gank_linear_fwd_f32out(const void* x, const float* w, const float* bias, float* y, int M, int K, int C, void* stream);
 int gank_linear_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, float* dbias, int M, int K, int C,
                     void* stream);
 

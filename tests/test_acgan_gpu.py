@@ -235,7 +235,7 @@ def test_acgan_losses_and_gradients_vs_oracle(gpu, batch):
     assert not bad, bad
 
 
-def test_acgan_training_steps_and_lr_schedule(gpu):
+def test_acgan_training_steps_and_lr_schedule(gpu, deterministic_stats):
     from gan_lib_tensorflow_amd.ACGAN.train import polynomial_decay
     from gan_lib_tensorflow_amd.SNGAN.gan_cifar_resnet import synthetic_batches
     assert polynomial_decay(0) == 0.0004 and abs(polynomial_decay(25000) - 0.0003) < 1e-12 and polynomial_decay(10 ** 6) == 0.0002

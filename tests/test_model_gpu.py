@@ -400,7 +400,10 @@ def test_headline_batch_64_forward_and_gradients_vs_oracle(gpu):
     assert not bad, bad
 
 
-def test_short_training_tracks_the_fp32_restatement(gpu):
+ZERO_TABLE_TRAVEL_BOUND = 0.5
+
+
+def test_short_training_tracks_the_fp32_restatement(gpu, deterministic_stats):
     """The only available proxy for "same sample quality as the reference" (no Inception weights, no TensorFlow): 60
     full iterations (300 critic + 60 generator updates) at batch 8 from identical parameters, on IDENTICAL inputs
     (same images, labels, z, fake labels; no dequantisation noise), HIP bf16 trainer vs the fp32 CPU restatement of the
@@ -466,10 +469,12 @@ def test_short_training_tracks_the_fp32_restatement(gpu):
     print("short training: worst |norm ratio - 1|", top(norms), "worst |travel ratio - 1|", top(travels))
     # measured over repeated runs: norm ratios within 0.003, travel ratios within 0.25 (worst: the zero-initialised G.OutputNorm
     # offset table, whose 60-step random walk is the noisiest)
-    # (observed once in ~10 runs: 0.50 on that table with everything else below 0.3 -- the zero-initialised tables get their own bound)
+    # Runs on the deterministic batch-norm statistics (`deterministic_stats`): the trajectory then repeats to 0.02 % per update
+    # instead of 0.4 %, and the bounds below are set from the distribution over 20 parameter / data seeds in
+    # profiles/r04_travel_ratio_distribution.txt (scratch/travel_dist.py), not from repeated runs of one seed.
     zero_init = lambda k: k.endswith('CondBatchNorm/offset')      # noqa: E731
     assert max(norms.values()) < 0.02, top(norms)
-    assert max(v for k, v in travels.items() if not zero_init(k)) < 0.5 and max(v for k, v in travels.items() if zero_init(k)) < 1.0, top(travels)
+    assert max(v for k, v in travels.items() if not zero_init(k)) < 0.5 and max(v for k, v in travels.items() if zero_init(k)) < ZERO_TABLE_TRAVEL_BOUND, top(travels)
     # ---- parity at a TRAINED state (spectral norms, conditional-batch-norm tables and Adam-shaped weights have moved):
     # the HIP trainer takes over the restatement's parameters and both differentiate the same losses on the same inputs
     tr.store.load_state_dict({k: v.detach().numpy() for k, v in P.items()})
@@ -565,7 +570,10 @@ def test_bucketed_generator_update_through_rccl_matches_the_one_piece_update(gpu
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         results = {}
-        # the exchange itself under capture: a replayed all-reduce node returns what the eager collective returns, bit for bit
+        # the exchange call under capture.  NOTE what this does and does not show: at world size 1 RCCL's all-reduce is a no-op,
+        # so the captured graph holds NO collective node (torch warns "The CUDA Graph is empty") -- this only checks that
+        # issuing the call inside a capture neither raises nor disturbs the buffer.  Replay of a real multi-rank collective
+        # is unverified (no multi-GPU box), which is why SNGANTrainer captures collectives by default only at world size 1.
         buf = torch.randn(4099, device="cuda")
         want = buf.clone()
         dist.all_reduce(want)
@@ -595,8 +603,9 @@ def test_bucketed_generator_update_through_rccl_matches_the_one_piece_update(gpu
             torch.cuda.synchronize()
             assert tr.use_graphs == graphs
             if name in ("bucketed", "bucketed_wire16"):
-                # the collectives are nodes of the captured updates: ONE graph for the critic update (no optimiser graph behind
-                # an eager all-reduce), ONE for the generator update with its four bucket all-reduces on the communication stream
+                # the collective CALLS sit inside the captured updates (world size 1: they add no node): ONE graph for the critic
+                # update (no optimiser graph behind an eager all-reduce), ONE for the generator update with its four bucket
+                # all-reduce calls on the communication stream
                 assert tr.capture_collectives and isinstance(tr._graphs['g_seg'], torch.cuda.CUDAGraph) and 'g' not in tr._graphs
                 assert tr._graphs['d_pre'][1] is None
             if name == "bucketed_split":
@@ -704,7 +713,7 @@ def test_run_to_run_noise_of_the_generator_update_is_bounded(gpu):
     assert out[True] < 0.05 and out[False] < 0.003, out
 
 
-def test_training_on_a_synthetic_class_conditional_dataset_learns_the_classes(gpu):
+def test_training_on_a_synthetic_class_conditional_dataset_learns_the_classes(gpu, deterministic_stats):
     """Sample-quality proxy (no Inception weights, no CIFAR): 3 000 iterations of the captured train step at the headline batch
     on ten synthetic classes (tests/synthetic_classes.py), then 200 samples per class through the sampling path.  The generator
     must have learned to condition on the label -- at least 8 of 10 generated class means are nearest to THEIR data class

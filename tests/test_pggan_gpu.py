@@ -175,7 +175,7 @@ def test_pggan_full_resolution_forward_vs_oracle(gpu):
     assert float((lg.double().cpu() - lg_ref).abs().max()) < 3e-2 * max(1.0, float(lg_ref.abs().max()))
 
 
-def test_pggan_training_steps(gpu):
+def test_pggan_training_steps(gpu, deterministic_stats):
     """train.py:185-193 at the 16x16 stage with a block fading in: 1 generator + 5 critic updates per step, alpha = step /
     max_iter, real rows resized 32 -> 8 -> 16; parameters move by at most ~lr per update and stay finite."""
     from gan_lib_tensorflow_amd.SNGAN.gan_cifar_resnet import synthetic_batches
@@ -198,7 +198,7 @@ def test_pggan_training_steps(gpu):
 
 
 @pytest.mark.parametrize("bc,trans,res", [(4, True, 64), (6, False, 256)])
-def test_pggan_training_steps_at_64_fading_and_256(gpu, bc, trans, res):
+def test_pggan_training_steps_at_64_fading_and_256(gpu, bc, trans, res, deterministic_stats):
     """BASELINE.json config 4 at its later stages (batch 16): 64 x 64 with the newest block fading in and the final 256 x 256
     stage -- two captured train steps each; parameters move by at most ~lr per update, stay finite, gradients are cleared by the
     optimiser launch, samples have the stage's resolution."""

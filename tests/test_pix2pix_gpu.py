@@ -273,7 +273,7 @@ def test_pix2pix_networks_losses_gradients_vs_oracle(gpu):
     assert all(float(tr.store.vars[k].main_grad.abs().max()) == 0.0 for k in dn)      # gen_loss moves g_vars only (train.py:552)
 
 
-def test_pix2pix_training_steps(gpu):
+def test_pix2pix_training_steps(gpu, deterministic_stats):
     """train.py:704-730: n_dis critic updates then one generator update per step; learning rate 2e-4 -> 1e-4 over max_steps;
     parameters move by at most ~lr per update and stay finite."""
     from gan_lib_tensorflow_amd.Pix2Pix.train import polynomial_decay
