@@ -134,6 +134,7 @@ def _g_prep_kind(name, W):
 
 LABEL_TABLE = True    # the critic's label branch through a per-label table (0: per-sample embedding + dense layer + tile)
 FUSED_HEAD = True      # D.Output + hinge loss (+ the layer's three gradients) as one launch where the train step asks for it
+HEAD_IN_CHAIN = True   # ... and that launch folded into the fused 8x8 chain's forward / backward launches (functional.HingeHeadSpec)
 
 
 def Discriminator(inputs, labels, update_collection=None, reuse=False, loss_head=None):
@@ -175,6 +176,12 @@ def Discriminator(inputs, labels, update_collection=None, reuse=False, loss_head
                                    update_collection=update_collection, resample='down', labels=labels, biases=True, prefork=prefork)
             if blocks.res_chain8_eligible(output, DIM_D, ['D.Block.3', 'D.Block.4'], labels):
                 # D.Block.3, D.Block.4 and nonlinearity + reduce_mean (:291-301) as ONE launch: an 8x8x128 sample stays in LDS
+                if HEAD_IN_CHAIN and isinstance(loss_head, Fn.HingeHeadSpec) and not (CONDITIONAL and ACGAN):
+                    # ... and D.Output + the hinge loss (:303-304, :379-381 / :492) inside the same two launches
+                    return blocks.ResidualBlockChain8(
+                        output, DIM_D, ['D.Block.3', 'D.Block.4'], spectral_normed=True, update_collection=update_collection, biases=True, pool=True,
+                        head=(loss_head, lambda: _linear.linear_variables(DIM_D, 1, 'D.Output', spectral_normed=True,
+                                                                          update_collection=update_collection))), None
                 output = blocks.ResidualBlockChain8(output, DIM_D, ['D.Block.3', 'D.Block.4'], spectral_normed=True,
                                                     update_collection=update_collection, biases=True, pool=True)
             else:
@@ -425,7 +432,7 @@ class SNGANTrainer:
         with _sn.grad_scratch(self.d_flat["scratch"]):        # zeroed by zero_grads above
             if FUSED_HEAD:
                 loss, _ = Discriminator(both, both_labels, update_collection=None,
-                                        loss_head=lambda f, w, bb: Fn.hinge_d_head(f, w, bb, b, out=self.d_loss, loss_scale=self.loss_scale))
+                                        loss_head=Fn.HingeHeadSpec(0, b, out=self.d_loss, loss_scale=self.loss_scale))
                 logits = loss.logits
             else:
                 logits, _ = Discriminator(both, both_labels, update_collection=None)
@@ -442,7 +449,7 @@ class SNGANTrainer:
         with _sn.grad_scratch(self.d_flat["scratch"]):        # zeroed by zero_grads above
             if FUSED_HEAD:
                 loss, _ = Discriminator(self.both, self.both_labels, update_collection=None,
-                                        loss_head=lambda f, w, b: Fn.hinge_d_head(f, w, b, self.batch, out=self.d_loss, loss_scale=self.loss_scale))
+                                        loss_head=Fn.HingeHeadSpec(0, self.batch, out=self.d_loss, loss_scale=self.loss_scale))
                 logits = loss.logits
             else:
                 logits, _ = Discriminator(self.both, self.both_labels, update_collection=None)
@@ -476,7 +483,7 @@ class SNGANTrainer:
         try:
             if FUSED_HEAD:
                 loss, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS,
-                                        loss_head=lambda f, w, b: Fn.hinge_g_head(f, w, b, out=self.g_loss, loss_scale=self.loss_scale))
+                                        loss_head=Fn.HingeHeadSpec(1, 0, out=self.g_loss, loss_scale=self.loss_scale))
                 logits = loss.logits
             else:
                 logits, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS)
@@ -520,7 +527,7 @@ class SNGANTrainer:
             try:
                 if FUSED_HEAD:
                     loss, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS,
-                                            loss_head=lambda f, w, b: Fn.hinge_g_head(f, w, b, out=self.g_loss, loss_scale=self.loss_scale))
+                                            loss_head=Fn.HingeHeadSpec(1, 0, out=self.g_loss, loss_scale=self.loss_scale))
                 else:
                     logits, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS)
                     loss = Fn.hinge_g_loss(logits, out=self.g_loss)

@@ -38,6 +38,12 @@ class PrepDesc(C.Structure):
     _fields_ = [("w", P), ("wf", P), ("wd", P), ("ksize", I), ("Cin", I), ("Cout", I), ("kind", I)]
 
 
+class Res8Head(C.Structure):
+    """gank_res8_head"""
+    _fields_ = [("logits", P), ("head_w", P), ("pooled", P), ("loss", P), ("w_grad", P), ("b_grad", P), ("n_real", I), ("mode", I),
+                ("loss_scale", F)]
+
+
 class LabelDenseDesc(C.Structure):
     """gank_label_dense_desc"""
     _fields_ = [("table", P), ("bias", P), ("out", P), ("V", I), ("D", I), ("weight", I)]
@@ -72,6 +78,8 @@ PROTOTYPES = {
     "gank_conv2d_general_wgrad": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     "gank_res8_chain_fwd": [P, P, P, P, P, P, I, I, I, P],
     "gank_res8_chain_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "gank_res8_chain_fwd_head": [P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "gank_res8_chain_bwd_head": [C.POINTER(Res8Head), P, P, P, P, P, P, P, I, I, I, P],
     "gank_res8_conv3x3": [P, P, P, P, P, I, I, I, I, P, I, P],
     "gank_im2col_narrow": [P, P, I, I, I, I, I, I, I, I, I, I, P],
     "gank_tap_gather_up2": [P, P, P, I, I, I, I, I, I, I, I, P],

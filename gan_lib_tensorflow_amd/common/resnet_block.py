@@ -182,11 +182,12 @@ def res_chain8_eligible(inputs, input_dim, names, labels=None):
             and all(_normalize_kind(nm + '.N1', labels) is None and _normalize_kind(nm + '.N2', labels) is None for nm in names))
 
 
-def ResidualBlockChain8(inputs, dim, names, spectral_normed=False, update_collection=None, biases=True, pool=False):
+def ResidualBlockChain8(inputs, dim, names, spectral_normed=False, update_collection=None, biases=True, pool=False, head=None):
     """`ResidualBlock(..., resample=None)` for each name in `names`, in sequence, on 8x8 images with dim == 128 and no
     normalisation (gan_cifar_resnet.py:291-297), as one fused kernel; pool=True appends the `nonlinearity` +
     `reduce_mean(axis=[1, 2])` that follows the last critic block (:299-301).  Owns exactly the variables the
-    per-block path creates (`<name>.Conv1/Filters`, ...)."""
+    per-block path creates (`<name>.Conv1/Filters`, ...).  head: the critic's last dense layer + hinge loss inside the two
+    launches (functional.HingeHeadSpec; returns the loss)."""
     params = []
     for nm in names:
         w1, b1 = _conv2d.conv2d_variables(dim, dim, 3, 1, nm + '.Conv1', spectral_normed=spectral_normed,
@@ -194,6 +195,12 @@ def ResidualBlockChain8(inputs, dim, names, spectral_normed=False, update_collec
         w2, b2 = _conv2d.conv2d_variables(dim, dim, 3, 1, nm + '.Conv2', spectral_normed=spectral_normed,
                                           update_collection=update_collection, he_init=True, biases=biases)
         params.append((w1, b1, w2, b2))
+    if head is not None:
+        # head = (HingeHeadSpec, variables): `variables()` creates / fetches the dense layer's (W, b) AFTER the blocks' own
+        # variables, the order of the unfused graph (gan_cifar_resnet.py:291-304)
+        spec, variables = head
+        w_out, b_out = variables()
+        return Fn.res_chain8(inputs, params, pool=True, head=(spec, w_out, b_out))
     return Fn.res_chain8(inputs, params, pool=pool)
 
 

@@ -36,6 +36,10 @@ struct ResFwdArgs {
   bf16* h1[2];            // conv1 output (bias added, before the relu) per block; null = not kept
   bf16* y[2];             // block outputs; null = not kept
   bf16* pooled;           // optional [N,C]: mean over the 64 pixels of relu(y_last)   (gan_cifar_resnet.py:299-301)
+  // optional fused critic head (with pooled): logits[n] = bf16(pooled[n] . head_w + head_b[0])   (D.Output, :303-304)
+  const float* head_w;    // [C] fp32 (the spectrally normalised D.Output weight)
+  const float* head_b;    // [1] fp32 or null
+  bf16* logits;           // [N] or null (no head)
   int N, nblocks;
 };
 
@@ -49,8 +53,29 @@ struct ResBwdArgs {
   const bf16* xin[2];     // block inputs (mask of the pre-activation relu), same order
   bf16* g1[2];            // out: gradient of conv1's output (dy operand of conv1's filter gradient); null = not kept
   bf16* dx[2];            // out: gradient of the block input; null = not kept (the last one is the chain's result)
+  // optional fused critic head (instead of dpool): d loss / d pooled[n][c] = bf16(dl[n] * head_w[c]) with dl[n] the hinge
+  // derivative at logits[n] (gan_cifar_resnet.py:379-381 mode 0, :492 mode 1), exactly gank_critic_head_hinge's arithmetic;
+  // workgroup N of the grid (one more than samples) writes the loss and accumulates the layer's weight / bias gradients
+  const bf16* logits;     // [N] from the forward launch, or null
+  const float* head_w;    // [C]
+  const bf16* pooled;     // [N,C] from the forward launch (weight gradient operand)
+  float* loss;            // [1]
+  float* w_grad;          // [C] accumulated, or null
+  float* b_grad;          // [1] accumulated, or null
+  int n_real, mode;
+  float loss_scale;
   int N, nblocks;
 };
+
+// hinge derivative / loss term of one logit: the arithmetic of critic_head_hinge_kernel (loss_opt.hip)
+__device__ __forceinline__ void res_head_term(float v, int m, int M, int n_real, int mode, float loss_scale, float& dl, float& l) {
+  const int n_fake = M - n_real;
+  float d;
+  if (mode == 1) { l = -v / (float)M; d = -1.f / (float)M; }
+  else if (m < n_real) { const float u = 1.f - v; l = fmaxf(u, 0.f) / (float)n_real; d = u > 0.f ? -1.f / (float)n_real : 0.f; }
+  else { const float u = 1.f + v; l = fmaxf(u, 0.f) / (float)n_fake; d = u > 0.f ? 1.f / (float)n_fake : 0.f; }
+  dl = bf2f(f2bf(d * loss_scale));
+}
 
 // TPW = 32-pixel MFMA tiles per wave (1: 8 waves per sample, 2: 4 waves, every weight fragment feeds two MFMAs);
 // PF = weight fragments in flight per wave.  A wave consumes one 1 KB fragment per TPW x 32 MFMA cycles and an L2 hit
@@ -192,11 +217,24 @@ __global__ __launch_bounds__(512 / TPW) void res8_chain_fwd_kernel(ResFwdArgs a)
     __syncthreads();                                                              // image A = y complete
     if (y) res_store_image<NT>(smem, y + n * 64 * RB_C, tid);
   }
+  float* sp = reinterpret_cast<float*>(smem + RB_IMG);                            // image B is dead here: [C] pooled values for the head
   if (a.pooled && tid < RB_C) {                                                   // relu + mean over the 8 x 8 pixels (:299-301)
     float s = 0.f;
     for (int px = 0; px < 64; px++)
       s += fmaxf(bf2f(*reinterpret_cast<const bf16*>(smem + ((px >> 3) + 1) * RB_RPB + ((px & 7) + 1) * RB_PPB + tid * 2)), 0.f);
-    a.pooled[n * RB_C + tid] = f2bf(s * (1.f / 64.f));
+    const bf16 pv = f2bf(s * (1.f / 64.f));
+    a.pooled[n * RB_C + tid] = pv;
+    if (a.logits) sp[tid] = bf2f(pv);
+  }
+  if (a.logits) {                                                                 // D.Output on the pooled row (:303-304): one wave, the
+    __syncthreads();                                                              // summation order of critic_head_hinge_kernel
+    if (wave == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < RB_C; k += 64) t += sp[k + lane] * a.head_w[k + lane];
+      t = wave_sum(t);
+      if (lane == 0) a.logits[n] = f2bf(t + (a.head_b ? a.head_b[0] : 0.f));
+    }
   }
 }
 
@@ -209,6 +247,50 @@ __global__ __launch_bounds__(512 / TPW) void res8_chain_bwd_kernel(ResBwdArgs a)
   const int ct = wave & 3;
   const int r = lane & 31, h = lane >> 5;
   const long n = blockIdx.x;
+  if (a.logits && n == a.N) {                        // the workgroup behind the samples: loss value, D.Output's weight / bias gradient
+    float* s_dl = reinterpret_cast<float*>(smem);    // [N]
+    float* red = s_dl + a.N;                         // [16]
+    float* part = red + 16;                          // [8][C]
+    float acc = 0.f;
+    for (int m = tid; m < a.N; m += NT) {
+      float dl, l;
+      res_head_term(bf2f(a.logits[m]), m, a.N, a.n_real, a.mode, a.loss_scale, dl, l);
+      s_dl[m] = dl;
+      acc += l;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.f;
+      for (int i = 0; i < NT / 64; i++) t += red[i];
+      a.loss[0] = t;
+    }
+    if (a.w_grad) {                                  // w_grad[k] += sum_m pooled[m][k] dl[m]: 8 row slices per column, summed in slice order
+      const int nsl = 8, per = (a.N + nsl - 1) / nsl;
+      for (int i = tid; i < nsl * RB_C; i += NT) {
+        const int sl = i / RB_C, k = i - sl * RB_C;
+        const int m0 = sl * per, m1 = min(a.N, m0 + per);
+        float t = 0.f;
+        for (int m = m0; m < m1; m++) t += bf2f(a.pooled[(long)m * RB_C + k]) * s_dl[m];
+        part[i] = t;
+      }
+      __syncthreads();
+      if (tid < RB_C) {
+        float t = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 8; sl++) t += part[sl * RB_C + tid];
+        a.w_grad[tid] += t;
+      }
+    }
+    if (a.b_grad && tid < 64) {
+      float t = 0.f;
+      for (int m = tid; m < a.N; m += 64) t += s_dl[m];
+      t = wave_sum(t);
+      if (tid == 0) a.b_grad[0] += t;
+    }
+    return;
+  }
   const int row = 4 * (wave >> 2) + (r >> 3), col = r & 7;
   const int b_base = row * RB_RPB + col * RB_PPB + h * 16;
   const int own = (row + 1) * RB_RPB + (col + 1) * RB_PPB + ct * 64 + h * 8;
@@ -219,12 +301,21 @@ __global__ __launch_bounds__(512 / TPW) void res8_chain_bwd_kernel(ResBwdArgs a)
   res_ring_fill<PF>(ring, __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.wd[0]), 0, RB_WBYTES, 0x00020000), lane * 16, wbase);
   for (int i = tid; i < RB_LDS / 16; i += NT) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
   __syncthreads();
-  if (a.dpool) {                                     // gradient of relu + spatial mean: dpool / 64 where y_last > 0
+  if (a.dpool || a.logits) {                         // gradient of relu + spatial mean: dpool / 64 where y_last > 0
+    float dl = 0.f, lterm;
+    if (a.logits) res_head_term(bf2f(a.logits[n]), (int)n, a.N, a.n_real, a.mode, a.loss_scale, dl, lterm);
 #pragma unroll
     for (int it = 0; it < 1024 / NT; it++) {
       const int q = tid + it * NT, px = q >> 4, c16 = q & 15;
       const bf16x8 yv = *reinterpret_cast<const bf16x8*>(a.ylast + (n * 64 + px) * RB_C + c16 * 8);
-      const bf16x8 dp = *reinterpret_cast<const bf16x8*>(a.dpool + n * RB_C + c16 * 8);
+      bf16x8 dp;
+      if (a.logits) {                                // the head's input gradient, bf16(dl * w) as the head kernel rounds it
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(a.head_w + c16 * 8), w1 = *reinterpret_cast<const f32x4*>(a.head_w + c16 * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; e++) { dp[e] = f2bf(dl * w0[e]); dp[4 + e] = f2bf(dl * w1[e]); }
+      } else {
+        dp = *reinterpret_cast<const bf16x8*>(a.dpool + n * RB_C + c16 * 8);
+      }
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; e++) o[e] = f2bf(bf2f(yv[e]) > 0.f ? bf2f(dp[e]) * (1.f / 64.f) : 0.f);
@@ -311,7 +402,7 @@ static int res8_launch_fwd(const ResFwdArgs& a, hipStream_t s) {
 template <int TPW, int PF>
 static int res8_launch_bwd(const ResBwdArgs& a, hipStream_t s) {
   GANK_MAX_DYNAMIC_LDS((res8_chain_bwd_kernel<TPW, PF>), RB_LDS, "res8_chain_bwd");
-  hipLaunchKernelGGL((res8_chain_bwd_kernel<TPW, PF>), dim3(a.N), dim3(512 / TPW), RB_LDS, s, a);
+  hipLaunchKernelGGL((res8_chain_bwd_kernel<TPW, PF>), dim3(a.N + (a.logits ? 1 : 0)), dim3(512 / TPW), RB_LDS, s, a);
   return 0;
 }
 #ifdef GANK_TUNING
@@ -328,13 +419,16 @@ static int res8_launch_bwd(const ResBwdArgs& a, hipStream_t s) {
 #define RES8_DISPATCH(fn, a, s) rc = fn<1, 12>(a, s)
 #endif
 
-extern "C" int gank_res8_chain_fwd(const void* x, const void* const* w_rfrag, const float* const* bias, void* const* h1,
-                                   void* const* y, void* pooled, int N, int C, int nblocks, void* stream) {
+extern "C" int gank_res8_chain_fwd_head(const void* x, const void* const* w_rfrag, const float* const* bias, void* const* h1,
+                                        void* const* y, void* pooled, const float* head_w, const float* head_b, void* logits, int N, int C,
+                                        int nblocks, void* stream) {
   GANK_REQUIRE(x && w_rfrag && bias && h1 && y && N > 0, "res8_chain_fwd: null pointer");
+  GANK_REQUIRE(!logits || (pooled && head_w), "res8_chain_fwd: the fused head needs the pooled output and the head weight");
   GANK_REQUIRE(C == RB_C, "res8_chain_fwd: built for %d channels (got %d)", RB_C, C);
   GANK_REQUIRE(nblocks == 1 || nblocks == 2, "res8_chain_fwd: 1 or 2 blocks per launch (got %d)", nblocks);
   ResFwdArgs a{};
   a.x = (const bf16*)x; a.pooled = (bf16*)pooled; a.N = N; a.nblocks = nblocks;
+  a.head_w = head_w; a.head_b = head_b; a.logits = (bf16*)logits;
   for (int i = 0; i < 2 * nblocks; i++) {
     GANK_REQUIRE(w_rfrag[i], "res8_chain_fwd: null weight operand %d", i);
     a.w[i] = (const bf16*)w_rfrag[i];
@@ -354,16 +448,32 @@ extern "C" int gank_res8_chain_fwd(const void* x, const void* const* w_rfrag, co
   GANK_LAUNCH_OK("res8_chain_fwd");
   return 0;
 }
+extern "C" int gank_res8_chain_fwd(const void* x, const void* const* w_rfrag, const float* const* bias, void* const* h1,
+                                   void* const* y, void* pooled, int N, int C, int nblocks, void* stream) {
+  return gank_res8_chain_fwd_head(x, w_rfrag, bias, h1, y, pooled, nullptr, nullptr, nullptr, N, C, nblocks, stream);
+}
 
-extern "C" int gank_res8_chain_bwd(const void* dy, const void* dpool, const void* ylast, void* dy_out, const void* const* wd_rfrag,
-                                   const void* const* h1, const void* const* xin, void* const* g1, void* const* dx, int N, int C,
-                                   int nblocks, void* stream) {
-  GANK_REQUIRE((dy || (dpool && ylast)) && wd_rfrag && h1 && xin && g1 && dx && N > 0, "res8_chain_bwd: null pointer");
+static int res8_chain_bwd_impl(const void* dy, const void* dpool, const void* ylast, void* dy_out, const void* const* wd_rfrag,
+                               const void* const* h1, const void* const* xin, void* const* g1, void* const* dx, int N, int C,
+                               int nblocks, const gank_res8_head* head, void* stream) {
+  GANK_REQUIRE((dy || ((dpool || head) && ylast)) && wd_rfrag && h1 && xin && g1 && dx && N > 0, "res8_chain_bwd: null pointer");
+  if (head) {
+    GANK_REQUIRE(!dy && !dpool, "res8_chain_bwd_head: the head replaces dy / dpool");
+    GANK_REQUIRE(head->logits && head->head_w && head->pooled && head->loss, "res8_chain_bwd_head: null head tensor");
+    GANK_REQUIRE(head->mode == 0 || head->mode == 1, "res8_chain_bwd_head: mode 0 (hinge_d) or 1 (hinge_g)");
+    GANK_REQUIRE(head->mode == 1 || (head->n_real > 0 && head->n_real < N), "res8_chain_bwd_head: n_real must split the batch");
+    GANK_REQUIRE(head->loss_scale > 0.f, "res8_chain_bwd_head: loss_scale must be positive");
+    GANK_REQUIRE(N <= 8192, "res8_chain_bwd_head: at most 8192 samples (got %d)", N);
+  }
   GANK_REQUIRE(C == RB_C, "res8_chain_bwd: built for %d channels (got %d)", RB_C, C);
   GANK_REQUIRE(nblocks == 1 || nblocks == 2, "res8_chain_bwd: 1 or 2 blocks per launch (got %d)", nblocks);
   ResBwdArgs a{};
   a.dy = (const bf16*)dy; a.dpool = dy ? nullptr : (const bf16*)dpool; a.ylast = (const bf16*)ylast; a.dy_out = (bf16*)dy_out;
   a.N = N; a.nblocks = nblocks;
+  if (head) {
+    a.logits = (const bf16*)head->logits; a.head_w = head->head_w; a.pooled = (const bf16*)head->pooled; a.loss = head->loss;
+    a.w_grad = head->w_grad; a.b_grad = head->b_grad; a.n_real = head->n_real; a.mode = head->mode; a.loss_scale = head->loss_scale;
+  }
   for (int i = 0; i < 2 * nblocks; i++) {
     GANK_REQUIRE(wd_rfrag[i], "res8_chain_bwd: null weight operand %d", i);
     a.wd[i] = (const bf16*)wd_rfrag[i];
@@ -383,6 +493,17 @@ extern "C" int gank_res8_chain_bwd(const void* dy, const void* dpool, const void
   if (rc) return rc;
   GANK_LAUNCH_OK("res8_chain_bwd");
   return 0;
+}
+extern "C" int gank_res8_chain_bwd(const void* dy, const void* dpool, const void* ylast, void* dy_out, const void* const* wd_rfrag,
+                                   const void* const* h1, const void* const* xin, void* const* g1, void* const* dx, int N, int C,
+                                   int nblocks, void* stream) {
+  return res8_chain_bwd_impl(dy, dpool, ylast, dy_out, wd_rfrag, h1, xin, g1, dx, N, C, nblocks, nullptr, stream);
+}
+extern "C" int gank_res8_chain_bwd_head(const gank_res8_head* head, const void* ylast, void* dy_out, const void* const* wd_rfrag,
+                                        const void* const* h1, const void* const* xin, void* const* g1, void* const* dx, int N, int C,
+                                        int nblocks, void* stream) {
+  GANK_REQUIRE(head, "res8_chain_bwd_head: null head");
+  return res8_chain_bwd_impl(nullptr, nullptr, ylast, dy_out, wd_rfrag, h1, xin, g1, dx, N, C, nblocks, head, stream);
 }
 
 // ==================================================================================================================

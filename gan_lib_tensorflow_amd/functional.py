@@ -484,6 +484,43 @@ def conv2d(x, W, bias=None, residual=None, upsample=False, in_relu=False, pool_o
     return y
 
 
+def _res_chain8_grads(ctx, g, head=None):
+    """the backward launch of a fused chain and its filter / bias gradients -> (dx, [grads of the 4 * nb parameters])"""
+    nb, pool, Ws, bs = ctx.cfg
+    x, h1s, ys = ctx.kept
+    off = ctx.param_offset
+    need_w = [ctx.needs_input_grad[off + 4 * b + 2 * j] for b in range(nb) for j in range(2)]
+    need_b = [bs[i] is not None and ctx.needs_input_grad[off + 2 * i + 1] for i in range(2 * nb)]
+    train = any(need_w) or any(need_b)
+    xins = [x] + ys[:-1]
+    if head is not None:
+        dx, g1s, dys = K.res8_chain_bwd(None, None, ys[-1], [w._prep_res[1] for w in Ws], h1s, xins, keep=train, head=head)
+    else:
+        g = _c(g)
+        dx, g1s, dys = K.res8_chain_bwd(None if pool else g, g if pool else None, ys[-1] if pool else None,
+                                        [w._prep_res[1] for w in Ws], h1s, xins, keep=train)
+    grads = [None] * (4 * nb)
+    if train:
+        for b in range(nb):
+            for j, (xop, gop) in enumerate(((xins[b], g1s[b]), (h1s[b], dys[b]))):      # conv_1: (relu(x), g1); conv_2: (relu(h1), dy)
+                i = 2 * b + j
+                W, bias = Ws[i], bs[i]
+                btgt = None
+                if need_b[i]:
+                    btgt, bacc = _target(bias)
+                    grads[4 * b + 2 * j + 1] = None if bacc else btgt
+                if need_w[i]:
+                    tgt, acc = _target(W)
+                    grads[4 * b + 2 * j] = None if acc else tgt
+                    if BATCH_SMALL_WGRADS:
+                        _defer_wgrad(xop, gop, tgt, btgt, (8, 8), 3, K.IN_RELU)
+                    else:
+                        K.conv2d_wgrad(xop, gop, tgt, (8, 8), 3, K.IN_RELU, 1.0, dbias=btgt)
+                elif btgt is not None:
+                    K.colsum(gop, btgt, 1.0)
+    return dx, grads
+
+
 class _ResChain8(Function):
     """Up to two identity-shortcut residual blocks on 8x8x128 images in one launch each way (conv_resident.hip):
     y = x + conv_2(relu(conv_1(relu(x)) + b1)) + b2 per block (gan_cifar_resnet.py:176-209 with resample=None and no
@@ -491,56 +528,100 @@ class _ResChain8(Function):
     carries `_prep_res` (prep kind 4)."""
 
     @staticmethod
-    def forward(ctx, x, pool, *params):
+    def forward(ctx, x, pool, grad_on, *params):
         nb = len(params) // 4
         Ws = [params[4 * b + 2 * j] for b in range(nb) for j in range(2)]
         bs = [params[4 * b + 2 * j + 1] for b in range(nb) for j in range(2)]
-        keep = any(ctx.needs_input_grad)
+        keep = grad_on and any(ctx.needs_input_grad)      # (needs_input_grad ignores torch.no_grad(); grad mode is off inside forward)
         out, h1s, ys = K.res8_chain_fwd(x, [w._prep_res[0] for w in Ws], [b.detach() if b is not None else None for b in bs], keep, pool)
         ctx.cfg = (nb, pool, Ws, bs)
+        ctx.param_offset = 3
         ctx.kept = (x, h1s, ys) if keep else None
         return out
 
     @staticmethod
     def backward(ctx, g):
-        nb, pool, Ws, bs = ctx.cfg
-        x, h1s, ys = ctx.kept
-        need_w = [ctx.needs_input_grad[2 + 4 * b + 2 * j] for b in range(nb) for j in range(2)]
-        need_b = [bs[i] is not None and ctx.needs_input_grad[2 + 2 * i + 1] for i in range(2 * nb)]
-        train = any(need_w) or any(need_b)
-        xins = [x] + ys[:-1]
-        g = _c(g)
-        dx, g1s, dys = K.res8_chain_bwd(None if pool else g, g if pool else None, ys[-1] if pool else None,
-                                        [w._prep_res[1] for w in Ws], h1s, xins, keep=train)
-        grads = [None] * (4 * nb)
-        if train:
-            for b in range(nb):
-                for j, (xop, gop) in enumerate(((xins[b], g1s[b]), (h1s[b], dys[b]))):      # conv_1: (relu(x), g1); conv_2: (relu(h1), dy)
-                    i = 2 * b + j
-                    W, bias = Ws[i], bs[i]
-                    btgt = None
-                    if need_b[i]:
-                        btgt, bacc = _target(bias)
-                        grads[4 * b + 2 * j + 1] = None if bacc else btgt
-                    if need_w[i]:
-                        tgt, acc = _target(W)
-                        grads[4 * b + 2 * j] = None if acc else tgt
-                        if BATCH_SMALL_WGRADS:
-                            _defer_wgrad(xop, gop, tgt, btgt, (8, 8), 3, K.IN_RELU)
-                        else:
-                            K.conv2d_wgrad(xop, gop, tgt, (8, 8), 3, K.IN_RELU, 1.0, dbias=btgt)
-                    elif btgt is not None:
-                        K.colsum(gop, btgt, 1.0)
-        return (dx if ctx.needs_input_grad[0] else None, None, *grads)
+        dx, grads = _res_chain8_grads(ctx, g)
+        return (dx if ctx.needs_input_grad[0] else None, None, None, *grads)
 
 
-def res_chain8(x, blocks_params, pool=False):
-    """blocks_params: [(W1, b1, W2, b2), ...] (1 or 2 blocks)"""
+class HingeHeadSpec:
+    """The critic's last dense layer + hinge loss as a `loss_head` of Discriminator(): mode 0 = hinge_d with the first n_real
+    rows real (gan_cifar_resnet.py:379-381), mode 1 = hinge_g (:492); `out`: persistent fp32[1] buffer that receives the loss;
+    loss_scale: see grad_seed.  Called with (features, W, b) it is hinge_d_head / hinge_g_head (one launch of its own); a model
+    that ends in the fused 8x8 chain hands it to res_chain8 instead, which computes the logits in the chain's forward launch
+    and the loss, its derivative and the layer's gradients in the chain's backward launch (no launch of its own)."""
+
+    def __init__(self, mode, n_real=0, out=None, loss_scale=1.0):
+        self.mode, self.n_real, self.out, self.loss_scale = int(mode), int(n_real), out, float(loss_scale)
+
+    def __call__(self, x, W, bias):
+        if self.mode == 0:
+            return hinge_d_head(x, W, bias, self.n_real, out=self.out, loss_scale=self.loss_scale)
+        return hinge_g_head(x, W, bias, out=self.out, loss_scale=self.loss_scale)
+
+
+class _ResChain8Head(Function):
+    """_ResChain8 with pool=True and the head of HingeHeadSpec inside: forward launch -> pooled features AND logits; backward
+    launch -> hinge derivative from the logits, the loss value, D.Output's weight / bias gradients, then the chain's input
+    gradients as before.  The returned loss tensor holds its value once the BACKWARD launch has run (a train step always
+    runs it); a call that needs no gradient evaluates the loss with the stand-alone head kernel on the pooled features."""
+
+    @staticmethod
+    def forward(ctx, x, head_W, head_b, spec, grad_on, *params):
+        nb = len(params) // 4
+        Ws = [params[4 * b + 2 * j] for b in range(nb) for j in range(2)]
+        bs = [params[4 * b + 2 * j + 1] for b in range(nb) for j in range(2)]
+        keep = grad_on and any(ctx.needs_input_grad)      # (needs_input_grad ignores torch.no_grad(); grad mode is off inside forward)
+        hw = head_W.detach().reshape(-1)
+        hb = head_b.detach() if head_b is not None else None
+        pooled, h1s, ys, logits = K.res8_chain_fwd(x, [w._prep_res[0] for w in Ws], [b.detach() if b is not None else None for b in bs],
+                                                  keep, True, head=(hw, hb))
+        loss = spec.out if spec.out is not None else torch.empty(1, dtype=torch.float32, device=x.device)
+        _ResChain8Head.last_logits = logits
+        if not keep:             # forward only: the loss now, by the stand-alone kernel (same arithmetic)
+            K.critic_head_hinge(pooled, hw, hb, spec.n_real, spec.mode, want_dx=False, loss=loss, loss_scale=spec.loss_scale)
+            return loss.detach() if spec.out is not None else loss
+        ctx.cfg = (nb, True, Ws, bs)
+        ctx.param_offset = 5
+        ctx.kept = (x, h1s, ys)
+        ctx.head = (head_W, head_b, hw, spec, pooled, logits, loss)
+        return loss.detach() if spec.out is not None else loss
+
+    @staticmethod
+    def backward(ctx, g):
+        head_W, head_b, hw, spec, pooled, logits, loss = ctx.head
+        if _seed_scale.get(g.data_ptr()) != spec.loss_scale:
+            raise NotImplementedError("the fused critic head differentiates the loss itself (loss.backward(gradient=grad_seed(loss, loss_scale)) "
+                                      "with the loss scale its forward launch was given); use linear + hinge_*_loss for a weighted sum of losses")
+        wt = bt = None
+        ret = [None, None]
+        if ctx.needs_input_grad[1]:
+            wt, acc = _target(head_W)
+            ret[0] = None if acc else wt
+        if head_b is not None and ctx.needs_input_grad[2]:
+            bt, bacc = _target(head_b)
+            ret[1] = None if bacc else bt
+        head = dict(logits=logits, w=hw, pooled=pooled, loss=loss, w_grad=wt.view(-1) if wt is not None else None, b_grad=bt,
+                    n_real=spec.n_real, mode=spec.mode, loss_scale=spec.loss_scale)
+        dx, grads = _res_chain8_grads(ctx, None, head=head)
+        return (dx if ctx.needs_input_grad[0] else None, ret[0], ret[1], None, None, *grads)
+
+
+def res_chain8(x, blocks_params, pool=False, head=None):
+    """blocks_params: [(W1, b1, W2, b2), ...] (1 or 2 blocks).  head = (HingeHeadSpec, W [128,1], b [1] | None) with pool: the
+    critic's last dense layer and its hinge loss inside the two launches -> the loss (logits ride along as `loss.logits`)"""
     flat = [t for bp in blocks_params for t in bp]
     todo = [w for w in flat[0::2] if getattr(w, "_prep_res", None) is None]
     if todo:                                         # not prepared by a batched pass (sn.precomputed)
         K.prep_weights_batched(todo, want_d=True, kinds=[4] * len(todo))
-    return _ResChain8.apply(x, pool, *flat)
+    if head is not None:
+        assert pool
+        spec, hW, hb = head
+        loss = _ResChain8Head.apply(x, hW, hb, spec, torch.is_grad_enabled(), *flat)
+        loss.logits, _ResChain8Head.last_logits = _ResChain8Head.last_logits, None
+        return loss
+    return _ResChain8.apply(x, pool, torch.is_grad_enabled(), *flat)
 
 
 class _LinearSmall(Function):

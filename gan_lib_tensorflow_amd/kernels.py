@@ -6,7 +6,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, RES_UPSAMPLE2X, STATS_PREZEROED, OUT_POOLSUM2X, SnDesc, PrepDesc, WgradItem, LabelDenseDesc  # noqa: F401
+from ._lib import IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, RES_UPSAMPLE2X, STATS_PREZEROED, OUT_POOLSUM2X, SnDesc, PrepDesc, WgradItem, LabelDenseDesc, Res8Head  # noqa: F401
 
 # BF16 = the 16-bit activation dtype of this process: torch.bfloat16, or torch.float16 under GANK_DTYPE=fp16 (libgank_f16.so)
 BF16, F32, I32 = getattr(torch, _lib.ACT_DTYPE_NAME), torch.float32, torch.int32
@@ -447,11 +447,13 @@ def _ptr_array(ts):
     return arr
 
 
-def res8_chain_fwd(x, w_rfrag, biases, keep=True, pool=False):
+def res8_chain_fwd(x, w_rfrag, biases, keep=True, pool=False, head=None):
     """Fused identity-shortcut residual blocks on 8x8 images (gank_res8_chain_fwd).  x bf16 [N,8,8,128]; w_rfrag: the
     2*nblocks kind-4 `rf` operands (conv_1, conv_2 per block); biases: fp32 [128] or None each.
     -> (out, h1s, ys): out = pooled [N,128] when pool else the last block's output; h1s / ys = per-block tensors kept for
-    the backward pass (empty lists when keep=False and they are not the result)."""
+    the backward pass (empty lists when keep=False and they are not the result).
+    head = (w fp32 [128], b fp32 [1] | None) with pool: the critic's last dense layer inside the launch (gank_res8_chain_fwd_head);
+    -> (pooled, h1s, ys, logits bf16 [N])"""
     n, hh, ww, c = x.shape
     assert hh == 8 and ww == 8 and len(w_rfrag) in (2, 4) and len(biases) == len(w_rfrag), (x.shape, len(w_rfrag))
     nb = len(w_rfrag) // 2
@@ -462,17 +464,26 @@ def res8_chain_fwd(x, w_rfrag, biases, keep=True, pool=False):
     h1s = [torch.empty_like(x) for _ in range(nb)] if keep else [None] * nb
     ys = [torch.empty_like(x) if (keep or (b == nb - 1 and not pool)) else None for b in range(nb)]
     pooled = torch.empty((n, c), dtype=BF16, device=x.device) if pool else None
+    if head is not None:
+        assert pool and head[0].numel() == c and (head[1] is None or head[1].numel() == 1)
+        logits = torch.empty(n, dtype=BF16, device=x.device)
+        _lib.check(lib().gank_res8_chain_fwd_head(_p(x, BF16, "x"), _ptr_array(w_rfrag), _ptr_array(biases), _ptr_array(h1s), _ptr_array(ys),
+                                                  _p(pooled), _p(head[0], F32, "head_w"), _p(head[1], F32, "head_b"), _p(logits), n, c, nb,
+                                                  _stream()), "res8_chain_fwd_head")
+        return pooled, h1s, ys, logits
     _lib.check(lib().gank_res8_chain_fwd(_p(x, BF16, "x"), _ptr_array(w_rfrag), _ptr_array(biases), _ptr_array(h1s), _ptr_array(ys),
                                          _p(pooled), n, c, nb, _stream()), "res8_chain_fwd")
     return (pooled if pool else ys[-1]), h1s, ys
 
 
-def res8_chain_bwd(dy, dpool, ylast, wd_rfrag, h1s, xins, keep=True):
+def res8_chain_bwd(dy, dpool, ylast, wd_rfrag, h1s, xins, keep=True, head=None):
     """Backward chain (gank_res8_chain_bwd); lists are in FORWARD order (reversed here).  dy [N,8,8,128] or None with
     dpool [N,128] + ylast.  -> (dx, g1s, dys): dx = gradient of the chain input; g1s[b] = gradient of block b's conv_1
-    output, dys[b] = gradient of block b's output (forward order; None entries when keep=False)."""
+    output, dys[b] = gradient of block b's output (forward order; None entries when keep=False).
+    head = dict(logits, w, pooled, loss, w_grad | None, b_grad | None, n_real, mode, loss_scale) instead of dy / dpool: the
+    hinge loss on the fused head's logits differentiated inside the launch (gank_res8_chain_bwd_head)"""
     nb = len(h1s)
-    assert len(wd_rfrag) == 2 * nb and len(xins) == nb and (dy is not None or (dpool is not None and ylast is not None))
+    assert len(wd_rfrag) == 2 * nb and len(xins) == nb and (dy is not None or ((dpool is not None or head is not None) and ylast is not None))
     ref = xins[0]
     n, c = ref.shape[0], ref.shape[3]
     for w in wd_rfrag:
@@ -486,9 +497,21 @@ def res8_chain_bwd(dy, dpool, ylast, wd_rfrag, h1s, xins, keep=True):
     for b in reversed(range(nb)):
         wd_rev += [wd_rfrag[2 * b + 1], wd_rfrag[2 * b]]       # conv_2's operand first
         h1_rev.append(h1s[b]); x_rev.append(xins[b]); g1_rev.append(g1s[b]); dx_rev.append(dxs[b])
-    _lib.check(lib().gank_res8_chain_bwd(_p(dy, BF16, "dy"), _p(dpool, BF16, "dpool"), _p(ylast, BF16, "ylast"), _p(dy_out),
-                                         _ptr_array(wd_rev), _ptr_array(h1_rev), _ptr_array(x_rev), _ptr_array(g1_rev), _ptr_array(dx_rev),
-                                         n, c, nb, _stream()), "res8_chain_bwd")
+    if head is not None:
+        assert dy is None and dpool is None
+        hd = Res8Head()
+        hd.logits, hd.head_w, hd.pooled = _p(head["logits"], BF16, "logits").value, _p(head["w"], F32, "head_w").value, _p(head["pooled"], BF16, "pooled").value
+        hd.loss = _p(head["loss"], F32, "loss").value
+        hd.w_grad = _p(head.get("w_grad"), F32, "w_grad").value if head.get("w_grad") is not None else None
+        hd.b_grad = _p(head.get("b_grad"), F32, "b_grad").value if head.get("b_grad") is not None else None
+        hd.n_real, hd.mode, hd.loss_scale = int(head["n_real"]), int(head["mode"]), float(head["loss_scale"])
+        assert head["logits"].numel() == n and head["w"].numel() == c and tuple(head["pooled"].shape) == (n, c)
+        _lib.check(lib().gank_res8_chain_bwd_head(C.byref(hd), _p(ylast, BF16, "ylast"), _p(dy_out), _ptr_array(wd_rev), _ptr_array(h1_rev),
+                                                  _ptr_array(x_rev), _ptr_array(g1_rev), _ptr_array(dx_rev), n, c, nb, _stream()), "res8_chain_bwd_head")
+    else:
+        _lib.check(lib().gank_res8_chain_bwd(_p(dy, BF16, "dy"), _p(dpool, BF16, "dpool"), _p(ylast, BF16, "ylast"), _p(dy_out),
+                                             _ptr_array(wd_rev), _ptr_array(h1_rev), _ptr_array(x_rev), _ptr_array(g1_rev), _ptr_array(dx_rev),
+                                             n, c, nb, _stream()), "res8_chain_bwd")
     dys = [dxs[b + 1] if b + 1 < nb else (dy if dy is not None else dy_out) for b in range(nb)]
     return dxs[0], g1s, dys
 

@@ -150,6 +150,31 @@ int gank_res8_chain_fwd(const void* x, const void* const* w_rfrag, const float* 
 int gank_res8_chain_bwd(const void* dy, const void* dpool, const void* ylast, void* dy_out, const void* const* wd_rfrag,
                         const void* const* h1, const void* const* xin, void* const* g1, void* const* dx, int N, int C,
                         int nblocks, void* stream);
+/* The same pair with the critic's head inside: D.Output (a dense layer to ONE logit on the pooled features,
+ * gan_cifar_resnet.py:303-304) and the hinge loss on it (:379-381 mode 0 with the first n_real samples real, :492 mode 1) --
+ * what gank_critic_head_hinge does as a launch of its own between the two chains (a single latency-bound workgroup).
+ *   fwd_head: additionally logits[n] = bf16(pooled[n] . head_w + head_b[0]) (head_w fp32 [C], head_b fp32 [1] or NULL,
+ *        logits bf16 [N]); `pooled` is required.  logits == NULL: exactly gank_res8_chain_fwd.
+ *   bwd_head: instead of dy / dpool the gradient of the pooled features is built from the logits: d loss / d pooled[n][c] =
+ *        bf16(dl[n] * head_w[c]), dl[n] = bf16(loss_scale * d hinge / d logit) -- bit for bit what gank_critic_head_hinge_scaled
+ *        hands to gank_res8_chain_bwd -- and one extra workgroup writes loss[0] and ACCUMULATES w_grad [C] / b_grad [1] (either
+ *        may be NULL) = the layer's weight / bias gradients (fixed summation order: deterministic). */
+typedef struct gank_res8_head {
+  const void* logits;   /* bf16 [N], written by gank_res8_chain_fwd_head */
+  const float* head_w;  /* fp32 [C] */
+  const void* pooled;   /* bf16 [N,C], written by gank_res8_chain_fwd_head */
+  float* loss;          /* fp32 [1] <- the hinge loss */
+  float* w_grad;        /* fp32 [C] += , or NULL */
+  float* b_grad;        /* fp32 [1] += , or NULL */
+  int n_real, mode;     /* mode 0: hinge_d (n_real real samples first); mode 1: hinge_g */
+  float loss_scale;     /* power of two: multiplies the gradients, not the loss */
+} gank_res8_head;
+int gank_res8_chain_fwd_head(const void* x, const void* const* w_rfrag, const float* const* bias, void* const* h1,
+                             void* const* y, void* pooled, const float* head_w, const float* head_b, void* logits, int N, int C,
+                             int nblocks, void* stream);
+int gank_res8_chain_bwd_head(const gank_res8_head* head, const void* ylast, void* dy_out, const void* const* wd_rfrag,
+                             const void* const* h1, const void* const* xin, void* const* g1, void* const* dx, int N, int C,
+                             int nblocks, void* stream);
 
 /* ---- 3x3 SAME conv on 8x8 images, one LDS-resident image per workgroup (operand: prep kind 4, rows = output channels):
  * the generator's first residual block (gan_cifar_resnet.py:179-207, resample='up' at 4x4 -> 8x8) -- tf.nn.conv2d of

@@ -1021,6 +1021,70 @@ def test_res8_chain_fused_residual_blocks(K, n, nb, pool):
     assert torch.equal(out2, out.detach())
 
 
+@pytest.mark.parametrize("n,n_real,mode,scale", [(128, 64, 0, 1.0), (6, 2, 0, 1.0), (7, 0, 1, 1.0), (128, 0, 1, 1.0), (16, 8, 0, 1024.0)])
+def test_res8_chain_with_the_critic_head_inside(K, n, n_real, mode, scale):
+    """gank_res8_chain_fwd_head / _bwd_head: D.Output + hinge loss (gan_cifar_resnet.py:303-304, :379-381 / :492) computed inside
+    the fused chain's two launches.  Reference = the SAME chain followed by the stand-alone head launch
+    (gank_critic_head_hinge_scaled, itself tested against linear + hinge and the oracle): logits, the chain's input gradient
+    and every filter / bias gradient behind it are BIT-identical (the in-chain head repeats the head kernel's arithmetic and
+    rounding); the loss and the head's own weight / bias gradient sum the same terms in another order (fp32: <= 1e-6 relative).
+    Also: the forward-only form returns the loss at once; the loss against the float64 oracle."""
+    from oracle import ref_ops as R
+    from gan_lib_tensorflow_amd import functional as Fn
+    rng = np.random.default_rng(4100 + n + mode)
+    x, xt0 = bf(rng.normal(size=(n, 8, 8, 128)))
+    hw = (rng.normal(size=(128, 1)) * 0.6).astype(np.float32)
+    hb = np.asarray([0.13], np.float32)
+
+    def build():
+        r2 = np.random.default_rng(77)
+        params = []
+        for b in range(2):
+            blk = []
+            for j in range(2):
+                w, _ = bf(r2.normal(size=(3, 3, 128, 128)) / np.sqrt(9 * 128) * 1.4)
+                blk += [torch.tensor(w, dtype=torch.float32).cuda().requires_grad_(True), torch.tensor(r2.normal(size=128).astype(np.float32) * 0.1).cuda().requires_grad_(True)]
+            params.append(tuple(blk))
+        K.prep_weights_batched([p[i] for p in params for i in (0, 2)], want_d=True, kinds=[4] * 4)
+        return params, torch.tensor(hw).cuda().requires_grad_(True), torch.tensor(hb).cuda().requires_grad_(True), xt0.clone().requires_grad_(True)
+
+    res = {}
+    for form in ("separate", "fused"):
+        params, W, b, xt = build()
+        out = torch.zeros(1, dtype=torch.float32, device="cuda")
+        spec = Fn.HingeHeadSpec(mode, n_real, out=out, loss_scale=scale)
+        if form == "separate":
+            f = Fn.res_chain8(xt, params, pool=True)
+            loss = spec(f, W, b)
+        else:
+            loss = Fn.res_chain8(xt, params, pool=True, head=(spec, W, b))
+        logits = loss.logits
+        loss.backward(gradient=Fn.grad_seed(loss, scale))
+        torch.cuda.synchronize()
+        res[form] = dict(loss=float(out), logits=logits.clone(), dx=xt.grad.clone(), W=W.grad.clone(), b=b.grad.clone(),
+                         params=[p.grad.clone() for blk in params for p in blk])
+    a, c = res["separate"], res["fused"]
+    assert torch.equal(a["logits"], c["logits"]) and torch.equal(a["dx"], c["dx"])
+    for pa, pc in zip(a["params"], c["params"]):
+        # the filter gradients of the chain's 8x8 layers accumulate with fp32 atomics: same operands, arrival order differs
+        assert float((pa - pc).abs().max()) <= 2e-5 * float(pa.abs().max()) + 1e-12
+    assert abs(a["loss"] - c["loss"]) <= 1e-6 * max(1.0, abs(a["loss"]))
+    assert float((a["W"] - c["W"]).abs().max()) <= 1e-6 * float(a["W"].abs().max()) + 1e-12, float((a["W"] - c["W"]).abs().max())
+    assert float((a["b"] - c["b"]).abs().max()) <= 1e-6 * max(1.0, float(a["b"].abs().max()))
+    assert float(c["dx"].abs().max()) > 0
+    # the loss against the oracle on the fused logits
+    lg = c["logits"].double().cpu().numpy()
+    want = float(R.hinge_d_loss(lg, n_real)[0]) if mode == 0 else float(R.hinge_g_loss(lg)[0])
+    assert abs(c["loss"] - want) < 1e-5 * max(1.0, abs(want)), (c["loss"], want)
+    # forward only (no gradient anywhere): the loss is there without a backward launch
+    params, W, b, xt = build()
+    out = torch.full((1,), -7.0, dtype=torch.float32, device="cuda")
+    with torch.no_grad():
+        loss = Fn.res_chain8(xt, params, pool=True, head=(Fn.HingeHeadSpec(mode, n_real, out=out, loss_scale=scale), W, b))
+    torch.cuda.synchronize()
+    assert torch.equal(loss.logits, c["logits"]) and abs(float(out) - c["loss"]) <= 1e-6 * max(1.0, abs(c["loss"]))
+
+
 @pytest.mark.parametrize("n,hp,wp,cin,relu", [(3, 16, 16, 128, True), (2, 8, 8, 256, True), (2, 8, 16, 128, False), (5, 8, 8, 128, False),
                                               (2, 16, 32, 256, True)])
 def test_convpool3x3_resident_kernels(K, n, hp, wp, cin, relu):
