@@ -665,6 +665,147 @@ __global__ __launch_bounds__(512) void cpool_res_fprop_kernel(CpFwdArgs a) {
   }
 }
 
+// The same for 8-wide pooled patches (one 16x16 -> 8x8 image per workgroup: D.Block.2.Conv2 at n = 128 is 128 patches) with
+// the chip filled: a workgroup covers 64 output channels instead of 128 (twice the workgroups) and its 8 waves are
+// (ct = 2 channel tiles) x (pg = 2 pixel tiles) x (kg = 2 halves of the reduction): K group kg runs the input-channel chunks
+// 2r + kg out of its OWN image (two chunk images resident at once), the two partial sums meet in LDS at the end.  What bounded
+// the one-group form was each CU streaming the whole 16 * Cin * 128 * 2-byte operand through its L1 (1 MB at 40-70 GB/s);
+// here a CU streams half of it and a wave a quarter; the next round's input pieces are requested before the current round's
+// MFMAs (in flight behind the weight stream instead of in front of it).
+template <int PF>
+__global__ __launch_bounds__(512) void cpool_res_fprop_k2_kernel(CpFwdArgs a) {
+  using G = CpGeom<8>;
+  constexpr int PW = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];          // [2 K groups][IMG]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = wave & 1, pg = (wave >> 1) & 1, kg = wave >> 2;
+  const int r = lane & 31, h = lane >> 5;
+  const int ph_n = a.Hp / G::PHH, cgroups = a.Cout >> 6;
+  int bid = blockIdx.x;
+  const int cg = bid % cgroups; bid /= cgroups;
+  const int n = bid / ph_n, pr = bid - n * ph_n;
+  const int py0 = pr * G::PHH, px0 = 0;
+  const int nchunks = a.Cin >> 6, nrounds = nchunks >> 1;
+  const int H2 = 2 * a.Hp, W2 = 2 * a.Wp;
+  const int trow = r >> 3, tcol = r & 7;
+  const int b_base = kg * G::IMG + (pg * G::TROWS + trow) * G::RP + tcol * CP_PP + h * 16;
+
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w), 0, a.Cout * 16 * a.Cin * 2, 0x00020000);
+  const int tile = cg * 2 + ct;
+  // this wave's weight stream: chunks kg, kg + 2, ... of its channel tile, 64 steps (16 taps x 4 kk) of 1 KB each
+  auto wofs = [&](int st) {                                             // st = 64 * round + s
+    const int rd = st >> 6, s = st & 63;
+    return ((tile * nchunks + 2 * rd + kg) * 64 + s) * 1024;
+  };
+  const int nsteps = nrounds * 64;
+  u32x4 ring[PF];
+#pragma unroll
+  for (int s = 0; s < PF; s++) ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, wofs(s < nsteps ? s : nsteps - 1), 0);
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; e++) acc[e] = 0.f;
+
+  // staging of one round: the 18 x 18 input pixels of the patch for TWO 64-channel chunks, 8 sixteen-byte pieces per pixel and chunk
+  constexpr int HR = 2 * G::PHH + 2, HC = 2 * PW + 2, NPIECE = 2 * HR * HC * 8;
+  constexpr int NLD = (NPIECE + 511) / 512;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, a.N * H2 * W2 * a.Cin * 2, 0x00020000);
+  constexpr int OOB = 0x7FFFFFF0;
+  int p_off[NLD], p_lds[NLD];
+#pragma unroll
+  for (int j = 0; j < NLD; j++) {
+    const int q = tid + j * 512;
+    const bool on = q < NPIECE;
+    const int hp = q >> 4, c16 = q & 15;                                // 16 pieces per pixel: chunk (c16 >> 3), piece (c16 & 7)
+    const int hr = hp / HC, hc = hp - hr * HC;
+    const int iy = 2 * py0 - 1 + hr, ix = 2 * px0 - 1 + hc;
+    const bool ok = on && (unsigned)iy < (unsigned)H2 && (unsigned)ix < (unsigned)W2;
+    p_off[j] = ok ? (((n * H2 + iy) * W2 + ix) * a.Cin + c16 * 8) * 2 : OOB;
+    p_lds[j] = on ? (c16 >> 3) * G::IMG + ((hr & 1) * 2 + (hc & 1)) * G::PLANE + (hr >> 1) * G::RP + (hc >> 1) * CP_PP + (c16 & 7) * 16 : -1;
+  }
+  u32x4 rP[NLD];
+  auto load_round = [&](int rd) {
+#pragma unroll
+    for (int j = 0; j < NLD; j++) rP[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, p_off[j] == OOB ? OOB : p_off[j] + rd * 256, 0, 0);
+  };
+  load_round(0);
+
+  int step = 0;
+#pragma unroll 1
+  for (int rd = 0; rd < nrounds; rd++) {
+    if (rd > 0) __syncthreads();                                        // every wave is done reading the previous round's images
+#pragma unroll
+    for (int j = 0; j < NLD; j++)
+      if (p_lds[j] >= 0) {
+        u32x4 v = rP[j];
+        if (a.relu) v = relu_bf16x8(v);
+        *reinterpret_cast<u32x4*>(smem + p_lds[j]) = v;
+      }
+    __syncthreads();
+    if (rd + 1 < nrounds) load_round(rd + 1);                           // in flight behind this round's weight stream
+    static_assert(64 % PF == 0, "ring position is round-invariant");
+    constexpr int PB = 2;
+    bf16x8 bq[PB + 1];
+    auto read_b = [&](int s, bf16x8& dst) {
+      const int tap = s >> 2, kk = s & 3, ta = tap >> 2, tb = tap & 3;
+      dst = *reinterpret_cast<const bf16x8*>(smem + b_base + ((ta & 1) * 2 + (tb & 1)) * G::PLANE + (ta >> 1) * G::RP + (tb >> 1) * CP_PP + kk * 32);
+    };
+#pragma unroll
+    for (int s = 0; s < PB; s++) read_b(s, bq[s]);
+#pragma unroll
+    for (int s = 0; s < 64; s++, step++) {
+      if (s + PB < 64) read_b(s + PB, bq[(s + PB) % (PB + 1)]);
+      const bf16x8 fa = __builtin_bit_cast(bf16x8, ring[s % PF]);
+      __builtin_amdgcn_sched_barrier(0);                                // see res_conv3x3: keeps reads early and the ring deep
+      acc = GANK_MFMA32(fa, bq[s % (PB + 1)], acc);
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const int nx = step + PF;
+        ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, wofs(nx < nsteps ? nx : nsteps - 1), 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // the two K groups meet: group 1 parks its partial tile in LDS (the images are dead), group 0 adds it and finishes
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem) + ((wave & 3) * 64 + lane) * 16;
+  if (kg == 1) {
+#pragma unroll
+    for (int e = 0; e < 16; e += 4) *reinterpret_cast<f32x4*>(red + e) = f32x4{acc[e], acc[e + 1], acc[e + 2], acc[e + 3]};
+  }
+  __syncthreads();
+  if (kg == 1) return;
+#pragma unroll
+  for (int e = 0; e < 16; e += 4) {
+    const f32x4 o = *reinterpret_cast<const f32x4*>(red + e);
+    acc[e] += o[0]; acc[e + 1] += o[1]; acc[e + 2] += o[2]; acc[e + 3] += o[3];
+  }
+  const int py = py0 + pg * G::TROWS + trow, px = px0 + tcol;
+  const long m = ((long)n * a.Hp + py) * a.Wp + px;
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int co = cg * 64 + ct * 32 + 16 * q + 8 * h;
+    float v[8];
+    acc_widen(acc, q, 1.0f, v);
+    if (a.bias) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + co), b1 = *reinterpret_cast<const f32x4*>(a.bias + co + 4);
+#pragma unroll
+      for (int e = 0; e < 4; e++) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+    }
+    if (a.res) {
+      const bf16x8 rs = *reinterpret_cast<const bf16x8*>(a.res + m * a.Cout + co);
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[e] += bf2f(rs[e]);
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = f2bf(v[e]);
+    *reinterpret_cast<bf16x8*>(a.y + m * a.Cout + co) = o;
+  }
+}
+
 // dgrad: dx[n, 2y+pa, 2x+pb, ci] = sum_{i,j in {0,1}} sum_co dy[n, y+i-(1-pa), x+j-(1-pb), co] * Wph[pa,pb][ci][(i,j),co].
 // The dy patch (+1 halo) with Cout = 128 channels stays in LDS for all four phases (pixel pitch 272 B); a workgroup covers
 // 128 of the Cin "output" channels; wave (ct, pg) as above.
@@ -792,6 +933,10 @@ __global__ __launch_bounds__(512) void cpool_res_dgrad_kernel(CpBwdArgs a) {
 }
 
 static bool cpool_res_geom_ok(int Hp, int Wp) { return Hp % 8 == 0 && (Wp % 16 == 0 || Wp == 8); }
+static int cpool_k2_env() {
+  static const int v = gank_tune("GANK_CPOOL_K2", 1);   // experiment knob: GANK_CPOOL_K2=0 keeps the one-group kernel for 8-wide patches
+  return v;
+}
 
 extern "C" int gank_cpool_res_fprop(const void* x, const void* w_rfrag, const float* bias, const void* residual, void* y, int N, int Hp,
                                     int Wp, int Cin, int Cout, int flags, void* stream) {
@@ -810,6 +955,12 @@ extern "C" int gank_cpool_res_fprop(const void* x, const void* w_rfrag, const fl
     GANK_MAX_DYNAMIC_LDS((cpool_res_fprop_kernel<16, 2, 8>), CpGeom<16>::IMG, "cpool_res_fprop");
     gank_prof_tag(0, "cpool_res_fprop_kernel<16, 2, 8>");
     hipLaunchKernelGGL((cpool_res_fprop_kernel<16, 2, 8>), dim3(grid), dim3(512), CpGeom<16>::IMG, s, a);
+  } else if (Cin % 128 == 0 && cpool_k2_env() && N * (Hp / 8) * (Cout / 128) < 256) {
+    // fewer one-per-CU workgroups than CUs: 64 output channels per workgroup, the reduction split over two wave groups
+    const int grid = N * (Hp / 8) * (Cout / 64);
+    GANK_MAX_DYNAMIC_LDS((cpool_res_fprop_k2_kernel<8>), 2 * CpGeom<8>::IMG, "cpool_res_fprop");
+    gank_prof_tag(0, "cpool_res_fprop_k2_kernel<8>");
+    hipLaunchKernelGGL((cpool_res_fprop_k2_kernel<8>), dim3(grid), dim3(512), 2 * CpGeom<8>::IMG, s, a);
   } else {
     const int grid = N * (Hp / 8) * (Cout / 128);
     GANK_MAX_DYNAMIC_LDS((cpool_res_fprop_kernel<8, 1, 8>), CpGeom<8>::IMG, "cpool_res_fprop");
