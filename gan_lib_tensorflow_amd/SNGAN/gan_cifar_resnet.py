@@ -118,6 +118,9 @@ def _d_prep_kind(name, W):
         return 2
     if blocks.FUSE_RES8 and W.dim() == 4 and tuple(W.shape) == (3, 3, 128, 128) and ('D.Block.3.' in name or 'D.Block.4.' in name):
         return 4                                                          # fused 8x8 residual blocks: "rfrag" operands
+    if Fn.IMG16_CONV and name.endswith('D.Block.2.Conv1/Filters') and W.dim() == 4 and W.shape[0] == 3 and W.shape[2] % 64 == 0 and W.shape[3] % 128 == 0 \
+            and W.shape[2] % 128 == 0:
+        return 4                                                          # 16x16 image-resident conv (forward and input gradient)
     return 0
 
 

@@ -994,6 +994,151 @@ __global__ __launch_bounds__(512) void cpool_res_dgrad_kernel(CpBwdArgs a) {
   }
 }
 
+// The same with the 8 waves as (4 channel tiles) x (2 halves of each phase's reduction) instead of x (2 pixel groups): a wave
+// owns ALL pixel tiles of the patch, so every weight fragment is requested by one wave of the workgroup (and feeds TW MFMAs)
+// instead of by two -- the CU's L1 path, which bounds these kernels, carries half the bytes.  After a phase's K loop the two
+// halves swap partial tiles through LDS: group kg finishes (masks, rounds, stores) the tiles t with t / (TW/2) == kg.
+template <int PW, int PF>
+__global__ __launch_bounds__(512) void cpool_res_dgrad_ks_kernel(CpBwdArgs a) {
+  using G = CdGeom<PW>;
+  constexpr int TW = G::PHH / G::TROWS, TH = TW / 2;       // pixel tiles per wave / tiles a wave finishes
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = wave & 3, kg = wave >> 2;
+  const int r = lane & 31, h = lane >> 5;
+  const int pw_n = a.Wp / PW, ph_n = a.Hp / G::PHH, cgroups = a.Cin >> 7;
+  int bid = blockIdx.x;
+  const int cg = bid % cgroups; bid /= cgroups;
+  const int n = bid / (pw_n * ph_n), pr = bid - n * pw_n * ph_n;
+  const int py0 = (pr / pw_n) * G::PHH, px0 = (pr % pw_n) * PW;
+  const int trow = PW == 16 ? (r >> 4) : (r >> 3), tcol = PW == 16 ? (r & 15) : (r & 7);
+  const int b_base = trow * G::RP + tcol * G::PP + h * 16;
+  f32x4* part = reinterpret_cast<f32x4*>(smem + G::IMG) + (kg * 4 + ct) * (TH * 4 * 64);      // [writer kg][ct][TH tiles x 4 quads][64 lanes]
+  f32x4* part_in = reinterpret_cast<f32x4*>(smem + G::IMG) + ((kg ^ 1) * 4 + ct) * (TH * 4 * 64);
+
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w), 0, 4 * a.Cin * 4 * a.Cout * 2, 0x00020000);
+  const int tiles = a.Cin >> 5, tile = cg * 4 + ct;
+  auto wofs = [&](int phase, int s) { return ((phase * tiles + tile) * 32 + 16 * kg + s) * 1024; };      // this wave's 16 steps of a phase
+  u32x4 ring[PF];
+  static_assert(16 % PF == 0, "ring position is phase-invariant");
+#pragma unroll
+  for (int s = 0; s < PF; s++) ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, wofs(0, s), 0);
+
+  constexpr int HR = G::PHH + 2, HC = PW + 2, NPIECE = HR * HC * 16;
+  constexpr int NLD = (NPIECE + 511) / 512;
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.dy), 0, a.N * a.Hp * a.Wp * a.Cout * 2, 0x00020000);
+  constexpr int OOB = 0x7FFFFFF0;
+#pragma unroll
+  for (int j = 0; j < NLD; j++) {
+    const int q = tid + j * 512;
+    if (NPIECE % 512 == 0 || q < NPIECE) {
+      const int hp = q >> 4, c16 = q & 15;
+      const int hr = hp / HC, hc = hp - hr * HC;
+      const int iy = py0 - 1 + hr, ix = px0 - 1 + hc;
+      const bool ok = (unsigned)iy < (unsigned)a.Hp && (unsigned)ix < (unsigned)a.Wp;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ry, ok ? (((n * a.Hp + iy) * a.Wp + ix) * a.Cout + c16 * 8) * 2 : OOB, 0, 0);
+      *reinterpret_cast<u32x4*>(smem + hr * G::RP + hc * G::PP + c16 * 16) = v;
+    }
+  }
+  __syncthreads();
+
+  const int H2 = 2 * a.Hp, W2 = 2 * a.Wp;
+#pragma unroll 1
+  for (int phase = 0; phase < 4; phase++) {
+    const int pa = phase >> 1, pb = phase & 1;
+    const int poff = pa * G::RP + pb * G::PP;
+    f32x16 acc[TW];
+#pragma unroll
+    for (int t = 0; t < TW; t++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+    // relu masks of the tiles this wave finishes: requested now, consumed after the K loop
+    bf16x8 mk[TH][2];
+    if (a.mask) {
+#pragma unroll
+      for (int t = 0; t < TH; t++) {
+        const int y = py0 + (kg * TH + t) * G::TROWS + trow, x = px0 + tcol;
+        const long m = ((long)n * H2 + 2 * y + pa) * W2 + 2 * x + pb;
+#pragma unroll
+        for (int q = 0; q < 2; q++) mk[t][q] = *reinterpret_cast<const bf16x8*>(a.mask + m * a.Cin + cg * 128 + ct * 32 + 16 * q + 8 * h);
+      }
+    }
+    constexpr int PB = 2;
+    bf16x8 bq[PB + 1][TW];
+    auto body = [&](auto half) {
+      constexpr int S0 = decltype(half)::value * 16;
+      auto read_b = [&](int s, bf16x8 (&dst)[TW]) {
+        const int tap = (S0 + s) >> 3, kk = (S0 + s) & 7, ti = tap >> 1, tj = tap & 1;
+#pragma unroll
+        for (int t = 0; t < TW; t++)
+          dst[t] = *reinterpret_cast<const bf16x8*>(smem + b_base + poff + (t * G::TROWS + ti) * G::RP + tj * G::PP + kk * 32);
+      };
+#pragma unroll
+      for (int s = 0; s < PB; s++) read_b(s, bq[s]);
+#pragma unroll
+      for (int s = 0; s < 16; s++) {
+        if (s + PB < 16) read_b(s + PB, bq[(s + PB) % (PB + 1)]);
+        const bf16x8 fa = __builtin_bit_cast(bf16x8, ring[s % PF]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TW; t++) acc[t] = GANK_MFMA32(fa, bq[s % (PB + 1)][t], acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          const int nx = s + PF;
+          const int np = nx < 16 ? phase : (phase < 3 ? phase + 1 : 3), ns = nx < 16 ? nx : (phase < 3 ? nx - 16 : 15);
+          ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, wofs(np, ns), 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if (kg == 0) body(std::integral_constant<int, 0>{});
+    else body(std::integral_constant<int, 1>{});
+    // swap: park the partial sums of the tiles the OTHER group finishes (compile-time tile indices in both branches: a
+    // run-time index into the accumulator array would move it to scratch memory)
+    if (phase > 0) __syncthreads();                    // the previous phase's partials have been read
+    auto finish = [&](auto group) {
+      constexpr int KG = decltype(group)::value;
+#pragma unroll
+      for (int t = 0; t < TH; t++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const f32x16& src = acc[(KG ^ 1) * TH + t];
+          part[(t * 4 + g) * 64 + lane] = f32x4{src[4 * g], src[4 * g + 1], src[4 * g + 2], src[4 * g + 3]};
+        }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < TH; t++) {
+        f32x16& fin = acc[KG * TH + t];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const f32x4 o = part_in[(t * 4 + g) * 64 + lane];
+#pragma unroll
+          for (int e = 0; e < 4; e++) fin[4 * g + e] += o[e];
+        }
+        const int y = py0 + (KG * TH + t) * G::TROWS + trow, x = px0 + tcol;
+        const long m = ((long)n * H2 + 2 * y + pa) * W2 + 2 * x + pb;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const int ci = cg * 128 + ct * 32 + 16 * q + 8 * h;
+          float v[8];
+          acc_widen(fin, q, 1.0f, v);
+          if (a.mask) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = bf2f(mk[t][q][e]) > 0.f ? v[e] : 0.f;
+          }
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; e++) o[e] = f2bf(v[e]);
+          *reinterpret_cast<bf16x8*>(a.dx + m * a.Cin + ci) = o;
+        }
+      }
+    };
+    if (kg == 0) finish(std::integral_constant<int, 0>{});
+    else finish(std::integral_constant<int, 1>{});
+  }
+}
+
 static bool cpool_res_geom_ok(int Hp, int Wp) { return Hp % 8 == 0 && (Wp % 16 == 0 || Wp == 8); }
 static int cpool_k2_env() {
   static const int v = gank_tune("GANK_CPOOL_K2", 1);   // experiment knob: GANK_CPOOL_K2=0 keeps the one-group kernel for 8-wide patches
@@ -1046,19 +1191,236 @@ extern "C" int gank_cpool_res_dgrad(const void* dy, const void* w_rfrag, const v
   hipStream_t s = (hipStream_t)stream;
   const double M = (double)N * Hp * Wp;
   gank_prof_begin(0, 2.0 * M * 4.0 * Cin * 4.0 * Cout, s, 2.0 * (M * Cout + 16.0 * Cin * Cout + 4.0 * M * Cin + (relu_ref ? 4.0 * M * Cin : 0.0)));
+  static const int ks_env = gank_tune("GANK_CPOOL_DGRAD_KS", 1);   // experiment knob: 0 keeps the (channel tile) x (pixel group) wave layout
   if (Wp % 16 == 0) {
     const int grid = N * (Hp / 8) * (Wp / 16) * (Cin / 128);
-    GANK_MAX_DYNAMIC_LDS((cpool_res_dgrad_kernel<16, 2, 8>), CdGeom<16>::IMG, "cpool_res_dgrad");
-    gank_prof_tag(0, "cpool_res_dgrad_kernel<16, 2, 8>");
-    hipLaunchKernelGGL((cpool_res_dgrad_kernel<16, 2, 8>), dim3(grid), dim3(512), CdGeom<16>::IMG, s, a);
+    if (ks_env == 2) {
+      constexpr int LDS = CdGeom<16>::IMG + 2 * 4 * 2 * 4 * 64 * 16;
+      GANK_MAX_DYNAMIC_LDS((cpool_res_dgrad_ks_kernel<16, 16>), LDS, "cpool_res_dgrad");
+      gank_prof_tag(0, "cpool_res_dgrad_ks_kernel<16, 16>");
+      hipLaunchKernelGGL((cpool_res_dgrad_ks_kernel<16, 16>), dim3(grid), dim3(512), LDS, s, a);
+    } else if (ks_env) {
+      constexpr int LDS = CdGeom<16>::IMG + 2 * 4 * 2 * 4 * 64 * 16;      // + [2 groups][4 channel tiles][2 tiles x 4 quads][64 lanes] x 16 B
+      GANK_MAX_DYNAMIC_LDS((cpool_res_dgrad_ks_kernel<16, 8>), LDS, "cpool_res_dgrad");
+      gank_prof_tag(0, "cpool_res_dgrad_ks_kernel<16, 8>");
+      hipLaunchKernelGGL((cpool_res_dgrad_ks_kernel<16, 8>), dim3(grid), dim3(512), LDS, s, a);
+    } else {
+      GANK_MAX_DYNAMIC_LDS((cpool_res_dgrad_kernel<16, 2, 8>), CdGeom<16>::IMG, "cpool_res_dgrad");
+      gank_prof_tag(0, "cpool_res_dgrad_kernel<16, 2, 8>");
+      hipLaunchKernelGGL((cpool_res_dgrad_kernel<16, 2, 8>), dim3(grid), dim3(512), CdGeom<16>::IMG, s, a);
+    }
   } else {
     const int grid = N * (Hp / 8) * (Cin / 128);
-    GANK_MAX_DYNAMIC_LDS((cpool_res_dgrad_kernel<8, 1, 8>), CdGeom<8>::IMG, "cpool_res_dgrad");
-    gank_prof_tag(0, "cpool_res_dgrad_kernel<8, 1, 8>");
-    hipLaunchKernelGGL((cpool_res_dgrad_kernel<8, 1, 8>), dim3(grid), dim3(512), CdGeom<8>::IMG, s, a);
+    if (ks_env == 2) {
+      constexpr int LDS = CdGeom<8>::IMG + 2 * 4 * 1 * 4 * 64 * 16;
+      GANK_MAX_DYNAMIC_LDS((cpool_res_dgrad_ks_kernel<8, 16>), LDS, "cpool_res_dgrad");
+      gank_prof_tag(0, "cpool_res_dgrad_ks_kernel<8, 16>");
+      hipLaunchKernelGGL((cpool_res_dgrad_ks_kernel<8, 16>), dim3(grid), dim3(512), LDS, s, a);
+    } else if (ks_env) {
+      constexpr int LDS = CdGeom<8>::IMG + 2 * 4 * 1 * 4 * 64 * 16;
+      GANK_MAX_DYNAMIC_LDS((cpool_res_dgrad_ks_kernel<8, 8>), LDS, "cpool_res_dgrad");
+      gank_prof_tag(0, "cpool_res_dgrad_ks_kernel<8, 8>");
+      hipLaunchKernelGGL((cpool_res_dgrad_ks_kernel<8, 8>), dim3(grid), dim3(512), LDS, s, a);
+    } else {
+      GANK_MAX_DYNAMIC_LDS((cpool_res_dgrad_kernel<8, 1, 8>), CdGeom<8>::IMG, "cpool_res_dgrad");
+      gank_prof_tag(0, "cpool_res_dgrad_kernel<8, 1, 8>");
+      hipLaunchKernelGGL((cpool_res_dgrad_kernel<8, 1, 8>), dim3(grid), dim3(512), CdGeom<8>::IMG, s, a);
+    }
   }
   gank_prof_end(0, s);
   GANK_LAUNCH_OK("cpool_res_dgrad");
+  return 0;
+}
+
+// ==================================================================================================================
+// 3x3 SAME convolution on 16x16 images, one image x 128 output channels per workgroup: the critic's D.Block.2.Conv1
+// (256 -> 256 at 16x16, gan_cifar_resnet.py:186-190 with resample='down') forward and input gradient, 2 x 38.6 GFLOP per
+// update at n = 128.  On the LDS-patch kernel these ran at 0.92 PFLOP/s with the matrix pipe 34 % busy: a barrier and a
+// weight tile through LDS per (tap, 64-channel chunk) step, 36 barriers per block.  Here, as in the kernels above: the image
+// (18 x 18 halo pixels of a 64-channel chunk, 51 KB; TWO chunks resident, the next one requested before the current one's
+// MFMAs and stored behind them) stays in LDS for all 9 taps with ONE barrier per chunk, and the weights stream from L2 in
+// MFMA-fragment order ("rfrag", prep kind 4) straight into a register ring.  256 pixels per image make the weight stream
+// small against the arithmetic (1.2 MB requested per workgroup for 576 MFMAs per wave), so, unlike the 8x8 kernels, this one
+// is bound by the matrix pipe.  Waves: (ct = 4 tiles of 32 output channels) x (pg = upper / lower 8 image rows), 4 pixel
+// tiles (2 rows x 16 columns) per wave.  Pixel pitch 144 B, row pitch 2816 B (= 11 x 256: the conflict-free pair of the patch kernel).
+// ==================================================================================================================
+namespace {
+constexpr int I16_PP = 144, I16_RP = 2816, I16_IMG = 18 * I16_RP;      // 50688 bytes per chunk image
+struct I16Args {
+  const bf16* x;          // [N,16,16,Cin]
+  const bf16* w;          // rfrag kind 4: [Cout/32][9 taps][Cin/16][64 lanes][8]
+  const float* bias;      // optional [Cout]
+  const bf16* mask;       // optional [N,16,16,Cout]: result zeroed where mask <= 0 (relu backward)
+  const bf16* res;        // optional [N,16,16,Cout]: added last
+  bf16* y;                // [N,16,16,Cout]
+  int N, Cin, Cout, relu; // relu: on the input operand while it is staged
+};
+}  // namespace
+
+template <int PF>
+__global__ __launch_bounds__(512) void img16_conv3x3_kernel(I16Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][I16_IMG]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = wave & 3, pg = wave >> 2;
+  const int r = lane & 31, h = lane >> 5;
+  const int cgroups = a.Cout >> 7;
+  const int cg = blockIdx.x % cgroups, n = blockIdx.x / cgroups;
+  const int nchunks = a.Cin >> 6, kq = a.Cin >> 4;                      // 64-channel chunks; 16-channel K-steps per tap
+  const int trow = r >> 4, tcol = r & 15;
+  const int b_base = (pg * 8 + trow) * I16_RP + tcol * I16_PP + h * 16; // tile t adds 2 t rows; tap (ty, tx) adds ty rows, tx pixels
+
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w), 0, a.Cout * 9 * a.Cin * 2, 0x00020000);
+  const int tile = cg * 4 + ct;
+  // fragment stream of this wave: chunk-major, then tap, then the chunk's 4 K-steps: step (c, 4 tap + kk) sits at
+  // wbase + 4096 c + toff[tap] + 1024 kk.  toff[] is scalar state computed once (a division per step cost 18 scalar
+  // instructions per MFMA group: SQ_INSTS_SALU was 4.6 x SQ_INSTS_MFMA)
+  const int wbase = tile * 9 * kq * 1024;
+  int toff[9];
+#pragma unroll
+  for (int t = 0; t < 9; t++) toff[t] = t * kq * 1024;
+  static_assert(PF <= 36, "the ring spans at most one chunk");
+  u32x4 ring[PF];
+#pragma unroll
+  for (int s = 0; s < PF; s++) ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, wbase + toff[s >> 2] + (s & 3) * 1024, 0);
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+
+  // staging: 18 x 18 halo pixels x 8 sixteen-byte pieces of the chunk
+  constexpr int NPIECE = 18 * 18 * 8, NLD = (NPIECE + 511) / 512;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, a.N * 256 * a.Cin * 2, 0x00020000);
+  constexpr int OOB = 0x7FFFFFF0;
+  int p_off[NLD], p_lds[NLD];
+#pragma unroll
+  for (int j = 0; j < NLD; j++) {
+    const int q = tid + j * 512;
+    const bool on = q < NPIECE;
+    const int hp = q >> 3, c16 = q & 7;
+    const int hr = hp / 18, hc = hp - hr * 18;
+    const bool ok = on && (unsigned)(hr - 1) < 16u && (unsigned)(hc - 1) < 16u;
+    p_off[j] = ok ? (((n * 16 + hr - 1) * 16 + hc - 1) * a.Cin + c16 * 8) * 2 : OOB;
+    p_lds[j] = on ? hr * I16_RP + hc * I16_PP + c16 * 16 : -1;
+  }
+  u32x4 rP[NLD];
+  auto load_chunk = [&](int c) {
+#pragma unroll
+    for (int j = 0; j < NLD; j++) rP[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, p_off[j] == OOB ? OOB : p_off[j] + c * 128, 0, 0);
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NLD; j++)
+      if (p_lds[j] >= 0) {
+        u32x4 v = rP[j];
+        if (a.relu) v = relu_bf16x8(v);
+        *reinterpret_cast<u32x4*>(smem + buf * I16_IMG + p_lds[j]) = v;
+      }
+  };
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+#pragma unroll 1
+  for (int c = 0; c < nchunks; c++) {
+    const char* img = smem + (c & 1) * I16_IMG;
+    const bool more = c + 1 < nchunks;
+    const int cbase = wbase + c * 4096;
+    if (more) load_chunk(c + 1);                                       // in flight during this chunk's 36 steps
+    static_assert(36 % PF == 0, "ring position is chunk-invariant");
+    constexpr int PB = 2;                                               // pixel fragments are read PB steps ahead of their MFMAs
+    bf16x8 bq[PB + 1][4];
+    auto read_b = [&](int s, bf16x8 (&dst)[4]) {
+      const int tap = s >> 2, kk = s & 3, ty = tap / 3, tx = tap - 3 * ty;
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+        dst[t] = *reinterpret_cast<const bf16x8*>(img + b_base + (2 * t + ty) * I16_RP + tx * I16_PP + kk * 32);
+    };
+#pragma unroll
+    for (int s = 0; s < PB; s++) read_b(s, bq[s]);
+#pragma unroll
+    for (int s = 0; s < 36; s++) {
+      if (s + PB < 36) read_b(s + PB, bq[(s + PB) % (PB + 1)]);
+      const bf16x8 fa = __builtin_bit_cast(bf16x8, ring[s % PF]);
+      __builtin_amdgcn_sched_barrier(0);                                // see res_conv3x3: keeps reads early and the ring deep
+#pragma unroll
+      for (int t = 0; t < 4; t++) acc[t] = GANK_MFMA32(fa, bq[s % (PB + 1)][t], acc[t]);
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const int nx = s + PF;                                          // compile-time after unrolling
+        if (nx < 36) ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, cbase + toff[nx >> 2] + (nx & 3) * 1024, 0);
+        else if (more) ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, cbase + 4096 + toff[(nx - 36) >> 2] + ((nx - 36) & 3) * 1024, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (more) {
+      store_chunk((c + 1) & 1);          // that image was last read in chunk c - 1: every wave is past it (the barrier below, one chunk ago)
+      __syncthreads();
+    }
+  }
+
+  // epilogue: after acc_widen the lane holds channels 16q + 8h .. +7 of one pixel: 16-byte pieces
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const long m = (long)n * 256 + (pg * 8 + 2 * t + trow) * 16 + tcol;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int co = cg * 128 + ct * 32 + 16 * q + 8 * h;
+      float v[8];
+      acc_widen(acc[t], q, 1.0f, v);
+      if (a.bias) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + co), b1 = *reinterpret_cast<const f32x4*>(a.bias + co + 4);
+#pragma unroll
+        for (int e = 0; e < 4; e++) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+      }
+      if (a.mask) {
+        const bf16x8 mk = *reinterpret_cast<const bf16x8*>(a.mask + m * a.Cout + co);
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = bf2f(mk[e]) > 0.f ? v[e] : 0.f;
+      }
+      if (a.res) {
+        const bf16x8 rs = *reinterpret_cast<const bf16x8*>(a.res + m * a.Cout + co);
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] += bf2f(rs[e]);
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = f2bf(v[e]);
+      *reinterpret_cast<bf16x8*>(a.y + m * a.Cout + co) = o;
+    }
+  }
+}
+
+extern "C" int gank_img16_conv3x3(const void* x, const void* w_rfrag, const float* bias, const void* relu_ref, const void* residual, void* y,
+                                  int N, int Cin, int Cout, int flags, void* stream) {
+  GANK_REQUIRE(x && w_rfrag && y && N > 0, "img16_conv3x3: null pointer");
+  GANK_REQUIRE(Cin % 64 == 0 && Cout % 128 == 0, "img16_conv3x3: needs Cin %% 64 == 0 and Cout %% 128 == 0 (got %d, %d)", Cin, Cout);
+  GANK_REQUIRE((flags & ~GANK_IN_RELU) == 0, "img16_conv3x3: flags: GANK_IN_RELU only");
+  GANK_REQUIRE((long)N * 256 * (Cin > Cout ? Cin : Cout) < (1L << 30) && (long)Cout * 9 * Cin * 2 < (1L << 31), "img16_conv3x3: tensor too large (32-bit byte offsets)");
+  I16Args a{};
+  a.x = (const bf16*)x; a.w = (const bf16*)w_rfrag; a.bias = bias; a.mask = (const bf16*)relu_ref; a.res = (const bf16*)residual; a.y = (bf16*)y;
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.relu = (flags & GANK_IN_RELU) ? 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  const double M = (double)N * 256;
+  gank_prof_begin(0, 2.0 * M * Cout * 9.0 * Cin, s, 2.0 * (M * Cin + 9.0 * Cin * Cout + M * Cout * (1 + (relu_ref ? 1 : 0) + (residual ? 1 : 0))));
+  static const int pf_env = gank_tune("GANK_IMG16_PF", 12);   // experiment knob: weight fragments in flight per wave
+  if (pf_env == 18) {
+    gank_prof_tag(0, "img16_conv3x3_kernel<18>");
+    GANK_MAX_DYNAMIC_LDS((img16_conv3x3_kernel<18>), 2 * I16_IMG, "img16_conv3x3");
+    hipLaunchKernelGGL((img16_conv3x3_kernel<18>), dim3(N * (Cout / 128)), dim3(512), 2 * I16_IMG, s, a);
+  } else if (pf_env == 6) {
+    gank_prof_tag(0, "img16_conv3x3_kernel<6>");
+    GANK_MAX_DYNAMIC_LDS((img16_conv3x3_kernel<6>), 2 * I16_IMG, "img16_conv3x3");
+    hipLaunchKernelGGL((img16_conv3x3_kernel<6>), dim3(N * (Cout / 128)), dim3(512), 2 * I16_IMG, s, a);
+  } else {
+    gank_prof_tag(0, "img16_conv3x3_kernel<12>");
+    GANK_MAX_DYNAMIC_LDS((img16_conv3x3_kernel<12>), 2 * I16_IMG, "img16_conv3x3");
+    hipLaunchKernelGGL((img16_conv3x3_kernel<12>), dim3(N * (Cout / 128)), dim3(512), 2 * I16_IMG, s, a);
+  }
+  gank_prof_end(0, s);
+  GANK_LAUNCH_OK("img16_conv3x3");
   return 0;
 }
 

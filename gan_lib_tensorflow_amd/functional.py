@@ -18,6 +18,7 @@ POOL_CONV4 = True     # 3x3 conv + 2x2 mean pool as one 4x4 stride-2 conv (4 ins
 CPOOL_RESIDENT = True   # ... on the LDS-resident kernels where they apply (prep kind 5; kernels.cpool_res_ok)
 PHASE_UPCONV = True   # NN-upsample+3x3 conv as a phase-decomposed transposed conv (4 instead of 9 taps)
 RES8_CONV = True      # 3x3 convs on 8x8 images with "rfrag" operands attached: the LDS-resident kernel (gank_res8_conv3x3)
+IMG16_CONV = True     # plain 3x3 convs on 16x16 images with "rfrag" operands attached: the image-resident kernel (gank_img16_conv3x3)
 
 
 # Boundaries of the backward pass (data parallel: the gradient buckets of parallel.GradBuckets end here).  A network
@@ -156,6 +157,9 @@ class _Conv2d(Function):
         # NN-upsample of a 4x4 input done by its loader
         res8 = (RES8_CONV and k == 3 and not in_relu and not pool_out and not out_tanh and getattr(W, "_prep_res", None) is not None
                 and K.res8_conv3x3_ok(n, (H, Wd), cin, cout))
+        # plain 3x3 on 16x16 images with the "rfrag" operands attached: one image x 128 output channels per workgroup
+        img16 = (IMG16_CONV and k == 3 and not upsample and not pool_out and not out_tanh and not stats_groups and not res_up
+                 and getattr(W, "_prep_res", None) is not None and K.img16_conv3x3_ok(n, (H, Wd), cin, cout))
         # NN-upsample + 3x3: run as the 4 output phases of the equivalent 4x4 stride-2 transposed conv
         phase = upsample and k == 3 and cin % 64 == 0 and not in_relu and PHASE_UPCONV and not res8
         # 3x3 conv + 2x2 mean pool: run as ONE 4x4 stride-2 conv (16 taps per pooled pixel = 4 per conv output)
@@ -169,6 +173,8 @@ class _Conv2d(Function):
                 y, _Conv2d.last_stats = K.res8_conv3x3(x, W._prep_res[0], b, cout, rflags, residual, stats_groups)
             else:
                 y = K.res8_conv3x3(x, W._prep_res[0], b, cout, rflags, residual)
+        elif img16:
+            y = K.img16_conv3x3(x, W._prep_res[0], b, cout, K.IN_RELU if in_relu else 0, None, residual)
         elif phase:
             wph, _ = getattr(W, "_prep_up", None) or K.upconv3x3_prep(W.detach().view(3, 3, cin, cout))
             if stats_groups and not out_tanh:
@@ -207,6 +213,7 @@ class _Conv2d(Function):
         # the backward pass runs the same kernel with the channel roles swapped: its own geometry check (Cin there = cout here),
         # otherwise the generic input-gradient path
         ctx.res8 = res8 and W._prep_res[1] is not None and K.res8_conv3x3_ok(n, (8, 8), cout, cin)
+        ctx.img16 = img16 and W._prep_res[1] is not None and K.img16_conv3x3_ok(n, (16, 16), cout, cin)
         return y
 
     @staticmethod
@@ -253,7 +260,7 @@ class _Conv2d(Function):
             prep = getattr(W, "_prep_pool", None) or K.convpool3x3_prep(W.detach().view(3, 3, cin, cout))
             dx = K.convpool3x3_dgrad(g, prep[1], cin, x if in_relu else None)
         elif ctx.needs_input_grad[0]:
-            _, wd = _prepared(W, k, cin, cout, False, True)
+            wd = None if ctx.img16 else _prepared(W, k, cin, cout, False, True)[1]
             dflags = K.IN_UPSAMPLE2X if pool_out else 0
             if upsample:
                 dxf = K.conv2d_dgrad(g, wd, (H, Wd), cin, k, dflags, scale)
@@ -264,7 +271,10 @@ class _Conv2d(Function):
                 extra = None
                 if ctx.add_link is not None:
                     extra, ctx.add_link.g = ctx.add_link.g, None
-                dx = K.conv2d_dgrad(g, wd, (H, Wd), cin, k, dflags, scale, extra, x if in_relu else None)
+                if ctx.img16:      # the same kernel with the dgrad operand (taps flipped, channels swapped); relu mask and fan-in in its epilogue
+                    dx = K.img16_conv3x3(g, W._prep_res[1], None, cin, 0, x if in_relu else None, extra)
+                else:
+                    dx = K.conv2d_dgrad(g, wd, (H, Wd), cin, k, dflags, scale, extra, x if in_relu else None)
         dres = None
         if ctx.needs_input_grad[3] and ctx.res_link is not None:
             ctx.res_link.g = g                     # consumed by conv_1's input-gradient epilogue

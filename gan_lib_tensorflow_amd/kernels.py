@@ -395,6 +395,21 @@ def res8_conv3x3_ok(n, hw, cin, cout):
     return tuple(hw) == (8, 8) and cin in (128, 256) and cout % 128 == 0 and n * 64 * max(cin, cout) < (1 << 30)
 
 
+def img16_conv3x3_ok(n, hw, cin, cout):
+    """geometry of gank_img16_conv3x3: 16x16 images, Cin % 64 == 0, Cout % 128 == 0"""
+    return tuple(hw) == (16, 16) and cin % 64 == 0 and cout % 128 == 0 and n * 256 * max(cin, cout) < (1 << 30)
+
+
+def img16_conv3x3(x, rf, bias, cout, flags=0, relu_ref=None, residual=None):
+    """3x3 SAME conv on LDS-resident 16x16 images (rf: prep kind 4 operand, rows = output channels); flags: IN_RELU"""
+    n, cin = x.shape[0], x.shape[3]
+    assert tuple(x.shape[1:3]) == (16, 16), x.shape
+    y = torch.empty((n, 16, 16, cout), dtype=BF16, device=x.device)
+    _lib.check(lib().gank_img16_conv3x3(_p(x, BF16, "x"), _p(rf, BF16, "rf"), _p(bias, F32, "bias"), _p(relu_ref, BF16, "relu_ref"),
+                                        _p(residual, BF16, "residual"), _p(y), n, cin, cout, int(flags), _stream()), "img16_conv3x3")
+    return y
+
+
 def res8_conv3x3(x, rf, bias, cout, flags=0, residual=None, stats_groups=0):
     """3x3 SAME conv on LDS-resident 8x8 images (rf: prep kind 4 operand, rows = output channels).  flags: IN_UPSAMPLE2X
     (x is [N,4,4,Cin]), RES_UPSAMPLE2X (residual is [N,4,4,Cout]), OUT_POOLSUM2X (result as 2x2 sums [N,4,4,Cout]).

@@ -176,6 +176,15 @@ int gank_res8_chain_bwd_head(const gank_res8_head* head, const void* ylast, void
                              const void* const* h1, const void* const* xin, void* const* g1, void* const* dx, int N, int C,
                              int nblocks, void* stream);
 
+/* ---- 3x3 SAME stride-1 conv on 16x16 images, one image x 128 output channels per workgroup, the image resident in LDS per
+ * 64-channel chunk and the weights streamed in fragment order (operand: prep kind 4, rows = output channels): the critic's
+ * D.Block.2.Conv1 (tf.nn.conv2d of conv2d.py:180-187 behind the pre-activation relu of gan_cifar_resnet.py:186) and, with the
+ * kind 4 `wd` operand and Cin / Cout swapped, its input gradient (Conv2DBackpropInput).  x [N,16,16,Cin], y [N,16,16,Cout];
+ * y = conv(in(x)) + bias, zeroed where relu_ref <= 0 (optional, [N,16,16,Cout]), + residual (optional, same shape).
+ * flags: GANK_IN_RELU.  Cin % 64 == 0, Cout % 128 == 0. */
+int gank_img16_conv3x3(const void* x, const void* w_rfrag, const float* bias, const void* relu_ref, const void* residual, void* y,
+                       int N, int Cin, int Cout, int flags, void* stream);
+
 /* ---- 3x3 SAME conv on 8x8 images, one LDS-resident image per workgroup (operand: prep kind 4, rows = output channels):
  * the generator's first residual block (gan_cifar_resnet.py:179-207, resample='up' at 4x4 -> 8x8) -- tf.nn.conv2d of
  * conv2d.py:180-187 behind the depth_to_space upsample of :139-146 -- and, with the dgrad operand, the input gradients.

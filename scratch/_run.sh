@@ -1,1 +1,2 @@
-python -m pytest tests/test_kernels_gpu.py -m gpu -q -k "res8_chain" > gpurun_out/r04_t8.log 2>&1; tail -4 gpurun_out/r04_t8.log; grep -n "AssertionError: (" gpurun_out/r04_t8.log | cut -c1-300
+python -m pytest tests/test_model_gpu.py -m gpu -x -q > gpurun_out/r04_t13.log 2>&1; tail -3 gpurun_out/r04_t13.log
+bash scratch/ab_base.sh 2 100

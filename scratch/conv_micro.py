@@ -13,6 +13,7 @@ dyp = torch.randn(n, h // 2, h // 2, cout, device="cuda").to(torch.bfloat16)
 wf, wd = K.prep_weights(w, True, True)
 if os.environ.get("MICRO_FRAG", "0") == "1":
     (wf, wd), = K.prep_weights_batched([w], want_d=True, kinds=[3])
+rfrag = K.prep_weights_batched([w], want_d=True, kinds=[4])[0] if (k == 3 and cin % 32 == 0 and cout % 32 == 0) else None
 wup = K.upconv3x3_prep(w) if k == 3 and cin % 64 == 0 else None
 dw = torch.zeros_like(w)
 torch.cuda.synchronize()
@@ -24,6 +25,8 @@ def run():
         K.upconv3x3_fprop(xh, wup[0], None, cout)
     elif which == "fprop_up":
         K.conv2d_fprop(xh, wf, None, (h, h), cout, k, K.IN_UPSAMPLE2X)
+    elif which == "img16":        # 16x16 image-resident conv (gank_img16_conv3x3), h must be 16
+        K.img16_conv3x3(x, rfrag[0], None, cout, K.IN_RELU)
     elif which == "dgrad":
         K.conv2d_dgrad(dy, wd, (h, h), cin, k)
     elif which == "cpwgrad":      # ConvMeanPool 3x3 filter gradient: x [n,h,h,cin], dy pooled [n,h/2,h/2,cout]

@@ -14,7 +14,7 @@ if not f: print("no counter file"); sys.exit()
 rows = list(csv.DictReader(open(f[0])))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
-    if 'conv_' in r['Kernel_Name'] and 'prep' not in r['Kernel_Name']:
+    if ('conv_' in r['Kernel_Name'] or 'conv3x3' in r['Kernel_Name']) and 'prep' not in r['Kernel_Name']:
         agg[r['Kernel_Name'][:50]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in agg.items():
     print(k, {c: round(sum(v) / len(v)) for c, v in d.items()})

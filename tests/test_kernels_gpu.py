@@ -1173,6 +1173,47 @@ def test_conv_epilogue_statistics_feed_cond_batchnorm(K, form, n, h, groups):
     assert relerr(z1, z0.double().cpu().numpy()) < BF_TOL
 
 
+@pytest.mark.parametrize("n,cin,cout,relu,masked,res", [(2, 256, 256, True, False, False), (3, 256, 256, False, True, True), (1, 128, 128, False, False, False),
+                                                       (2, 128, 384, True, True, False), (128, 256, 256, True, False, False), (128, 256, 256, False, True, False)])
+def test_img16_conv3x3_resident_image_kernel(K, n, cin, cout, relu, masked, res):
+    """gank_img16_conv3x3 (one 16x16 image x 128 output channels per workgroup, chunk images resident in LDS, fragment-major
+    weights): forward with the pre-activation relu and bias, and -- through the dgrad operand with the channel roles swapped --
+    the input gradient with its relu mask and a gradient fan-in, against the float64 oracle (small cases) and against the
+    implicit-GEMM kernels on the same operands (every case, incl. the critic's n = 128)."""
+    rng = np.random.default_rng(1600 + n + cin + cout + relu)
+    x, xt = bf(rng.normal(size=(n, 16, 16, cin)))
+    w, _ = bf(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin))
+    b, bt = f32(rng.normal(size=cout) * 0.5)
+    wt = torch.tensor(w, dtype=torch.float32).cuda()
+    (rf, rd), = K.prep_weights_batched([wt], want_d=True, kinds=[4])
+    wf, wd = K.prep_weights(wt, True, True)
+    # forward: y = conv(relu?(x)) + b
+    y = K.img16_conv3x3(xt, rf, bt, cout, K.IN_RELU if relu else 0)
+    y_ig = K.conv2d_fprop(xt, wf, bt, (16, 16), cout, 3, K.IN_RELU if relu else 0)
+    torch.cuda.synchronize()
+    assert relerr(y, y_ig.double().cpu().numpy()) < 5e-3
+    if n <= 3:
+        assert relerr(y, R.conv2d_same(R.relu(x) if relu else x, w, b)) < BF_TOL
+    # input gradient: dx = conv(dy, flip(w)^T) [* (mask > 0)] [+ fan-in]
+    dy, dyt = bf(rng.normal(size=(n, 16, 16, cout)))
+    mk = mkt = rs = rst = None
+    if masked:
+        mk, mkt = bf(rng.normal(size=(n, 16, 16, cin)))
+    if res:
+        rs, rst = bf(rng.normal(size=(n, 16, 16, cin)))
+    dx = K.img16_conv3x3(dyt, rd, None, cin, 0, relu_ref=mkt, residual=rst)
+    dx_ig = K.conv2d_dgrad(dyt, wd, (16, 16), cin, 3, 0, 1.0, rst, mkt)
+    torch.cuda.synchronize()
+    assert relerr(dx, dx_ig.double().cpu().numpy()) < 5e-3
+    if n <= 3:
+        rdx, _, _ = R.conv2d_same_grads(x, w, dy)
+        if masked:
+            rdx = rdx * (mk > 0)
+        if res:
+            rdx = rdx + rs
+        assert relerr(dx, rdx) < BF_TOL
+
+
 @pytest.mark.parametrize("n,cin,cout,up,resmode,groups", [(3, 256, 256, False, "full", 0), (8, 256, 256, True, "half", 2), (4, 128, 128, False, None, 2),
                                                           (6, 128, 256, True, None, 0), (128, 256, 256, False, "half", 2), (320, 256, 256, True, None, 10)])
 def test_res8_conv3x3_resident_generator_layers(K, n, cin, cout, up, resmode, groups):
