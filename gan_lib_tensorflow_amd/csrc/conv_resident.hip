@@ -1241,7 +1241,10 @@ extern "C" int gank_cpool_res_dgrad(const void* dy, const void* w_rfrag, const v
 // MFMAs and stored behind them) stays in LDS for all 9 taps with ONE barrier per chunk, and the weights stream from L2 in
 // MFMA-fragment order ("rfrag", prep kind 4) straight into a register ring.  256 pixels per image make the weight stream
 // small against the arithmetic (1.2 MB requested per workgroup for 576 MFMAs per wave), so, unlike the 8x8 kernels, this one
-// is bound by the matrix pipe.  Waves: (ct = 4 tiles of 32 output channels) x (pg = upper / lower 8 image rows), 4 pixel
+// is bound by the matrix pipe: timing-only builds without the weight reloads and without the pixel-fragment reads (garbage
+// results, same MFMAs) ran 32.9 / 33.5 / 31.2 us (neither / either / both removed: 36.2 us) at n = 128 -- the MFMA loop at the
+// ~1.5 GHz the chip holds under it plus ~6 us of prologue, epilogue and launch; one wave per SIMD with 8 tiles per wave was slower
+// (39.7 us), deeper or shallower weight rings made no difference.  Waves: (ct = 4 tiles of 32 output channels) x (pg = upper / lower 8 image rows), 4 pixel
 // tiles (2 rows x 16 columns) per wave.  Pixel pitch 144 B, row pitch 2816 B (= 11 x 256: the conflict-free pair of the patch kernel).
 // ==================================================================================================================
 namespace {
@@ -1257,18 +1260,21 @@ struct I16Args {
 };
 }  // namespace
 
-template <int PF>
-__global__ __launch_bounds__(512) void img16_conv3x3_kernel(I16Args a) {
+// TW = pixel tiles per wave: 4 -> 8 waves = (4 channel tiles) x (upper / lower half of the image); 8 -> 4 waves, one per SIMD, each
+// weight fragment feeding 8 MFMAs (half the weight requests, no second wave contending for the SIMD's matrix pipe)
+template <int PF, int TW>
+__global__ __launch_bounds__(2048 / TW) void img16_conv3x3_kernel(I16Args a) {
+  constexpr int NT = 2048 / TW;
   extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][I16_IMG]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ct = wave & 3, pg = wave >> 2;
+  const int ct = wave & 3, pg = TW == 8 ? 0 : wave >> 2;
   const int r = lane & 31, h = lane >> 5;
   const int cgroups = a.Cout >> 7;
   const int cg = blockIdx.x % cgroups, n = blockIdx.x / cgroups;
   const int nchunks = a.Cin >> 6, kq = a.Cin >> 4;                      // 64-channel chunks; 16-channel K-steps per tap
   const int trow = r >> 4, tcol = r & 15;
-  const int b_base = (pg * 8 + trow) * I16_RP + tcol * I16_PP + h * 16; // tile t adds 2 t rows; tap (ty, tx) adds ty rows, tx pixels
+  const int b_base = (pg * 2 * TW + trow) * I16_RP + tcol * I16_PP + h * 16; // tile t adds 2 t rows; tap (ty, tx) adds ty rows, tx pixels
 
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w), 0, a.Cout * 9 * a.Cin * 2, 0x00020000);
   const int tile = cg * 4 + ct;
@@ -1284,20 +1290,20 @@ __global__ __launch_bounds__(512) void img16_conv3x3_kernel(I16Args a) {
 #pragma unroll
   for (int s = 0; s < PF; s++) ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, wbase + toff[s >> 2] + (s & 3) * 1024, 0);
 
-  f32x16 acc[4];
+  f32x16 acc[TW];
 #pragma unroll
-  for (int t = 0; t < 4; t++)
+  for (int t = 0; t < TW; t++)
 #pragma unroll
     for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
 
   // staging: 18 x 18 halo pixels x 8 sixteen-byte pieces of the chunk
-  constexpr int NPIECE = 18 * 18 * 8, NLD = (NPIECE + 511) / 512;
+  constexpr int NPIECE = 18 * 18 * 8, NLD = (NPIECE + NT - 1) / NT;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, a.N * 256 * a.Cin * 2, 0x00020000);
   constexpr int OOB = 0x7FFFFFF0;
   int p_off[NLD], p_lds[NLD];
 #pragma unroll
   for (int j = 0; j < NLD; j++) {
-    const int q = tid + j * 512;
+    const int q = tid + j * NT;
     const bool on = q < NPIECE;
     const int hp = q >> 3, c16 = q & 7;
     const int hr = hp / 18, hc = hp - hr * 18;
@@ -1331,11 +1337,11 @@ __global__ __launch_bounds__(512) void img16_conv3x3_kernel(I16Args a) {
     if (more) load_chunk(c + 1);                                       // in flight during this chunk's 36 steps
     static_assert(36 % PF == 0, "ring position is chunk-invariant");
     constexpr int PB = 2;                                               // pixel fragments are read PB steps ahead of their MFMAs
-    bf16x8 bq[PB + 1][4];
-    auto read_b = [&](int s, bf16x8 (&dst)[4]) {
+    bf16x8 bq[PB + 1][TW];
+    auto read_b = [&](int s, bf16x8 (&dst)[TW]) {
       const int tap = s >> 2, kk = s & 3, ty = tap / 3, tx = tap - 3 * ty;
 #pragma unroll
-      for (int t = 0; t < 4; t++)
+      for (int t = 0; t < TW; t++)
         dst[t] = *reinterpret_cast<const bf16x8*>(img + b_base + (2 * t + ty) * I16_RP + tx * I16_PP + kk * 32);
     };
 #pragma unroll
@@ -1346,7 +1352,7 @@ __global__ __launch_bounds__(512) void img16_conv3x3_kernel(I16Args a) {
       const bf16x8 fa = __builtin_bit_cast(bf16x8, ring[s % PF]);
       __builtin_amdgcn_sched_barrier(0);                                // see res_conv3x3: keeps reads early and the ring deep
 #pragma unroll
-      for (int t = 0; t < 4; t++) acc[t] = GANK_MFMA32(fa, bq[s % (PB + 1)][t], acc[t]);
+      for (int t = 0; t < TW; t++) acc[t] = GANK_MFMA32(fa, bq[s % (PB + 1)][t], acc[t]);
       __builtin_amdgcn_sched_barrier(0);
       {
         const int nx = s + PF;                                          // compile-time after unrolling
@@ -1363,8 +1369,8 @@ __global__ __launch_bounds__(512) void img16_conv3x3_kernel(I16Args a) {
 
   // epilogue: after acc_widen the lane holds channels 16q + 8h .. +7 of one pixel: 16-byte pieces
 #pragma unroll
-  for (int t = 0; t < 4; t++) {
-    const long m = (long)n * 256 + (pg * 8 + 2 * t + trow) * 16 + tcol;
+  for (int t = 0; t < TW; t++) {
+    const long m = (long)n * 256 + (pg * 2 * TW + 2 * t + trow) * 16 + tcol;
 #pragma unroll
     for (int q = 0; q < 2; q++) {
       const int co = cg * 128 + ct * 32 + 16 * q + 8 * h;
@@ -1405,20 +1411,24 @@ extern "C" int gank_img16_conv3x3(const void* x, const void* w_rfrag, const floa
   hipStream_t s = (hipStream_t)stream;
   const double M = (double)N * 256;
   gank_prof_begin(0, 2.0 * M * Cout * 9.0 * Cin, s, 2.0 * (M * Cin + 9.0 * Cin * Cout + M * Cout * (1 + (relu_ref ? 1 : 0) + (residual ? 1 : 0))));
-  static const int pf_env = gank_tune("GANK_IMG16_PF", 12);   // experiment knob: weight fragments in flight per wave
-  if (pf_env == 18) {
-    gank_prof_tag(0, "img16_conv3x3_kernel<18>");
-    GANK_MAX_DYNAMIC_LDS((img16_conv3x3_kernel<18>), 2 * I16_IMG, "img16_conv3x3");
-    hipLaunchKernelGGL((img16_conv3x3_kernel<18>), dim3(N * (Cout / 128)), dim3(512), 2 * I16_IMG, s, a);
-  } else if (pf_env == 6) {
-    gank_prof_tag(0, "img16_conv3x3_kernel<6>");
-    GANK_MAX_DYNAMIC_LDS((img16_conv3x3_kernel<6>), 2 * I16_IMG, "img16_conv3x3");
-    hipLaunchKernelGGL((img16_conv3x3_kernel<6>), dim3(N * (Cout / 128)), dim3(512), 2 * I16_IMG, s, a);
-  } else {
-    gank_prof_tag(0, "img16_conv3x3_kernel<12>");
-    GANK_MAX_DYNAMIC_LDS((img16_conv3x3_kernel<12>), 2 * I16_IMG, "img16_conv3x3");
-    hipLaunchKernelGGL((img16_conv3x3_kernel<12>), dim3(N * (Cout / 128)), dim3(512), 2 * I16_IMG, s, a);
+  static const int cfg_env = gank_tune("GANK_IMG16_CFG", 412);   // experiment knob: 100 * (pixel tiles per wave) + weight fragments in flight
+#define IMG16_LAUNCH(PF, TW)                                                                              \
+  do {                                                                                                    \
+    gank_prof_tag(0, "img16_conv3x3_kernel<" #PF ", " #TW ">");                                         \
+    GANK_MAX_DYNAMIC_LDS((img16_conv3x3_kernel<PF, TW>), 2 * I16_IMG, "img16_conv3x3");                   \
+    hipLaunchKernelGGL((img16_conv3x3_kernel<PF, TW>), dim3(N * (Cout / 128)), dim3(2048 / TW), 2 * I16_IMG, s, a); \
+  } while (0)
+  switch (cfg_env) {
+#ifdef GANK_TUNING
+    case 406: IMG16_LAUNCH(6, 4); break;
+    case 418: IMG16_LAUNCH(18, 4); break;
+    case 806: IMG16_LAUNCH(6, 8); break;
+    case 812: IMG16_LAUNCH(12, 8); break;
+    case 818: IMG16_LAUNCH(18, 8); break;
+#endif
+    default: IMG16_LAUNCH(12, 4); break;
   }
+#undef IMG16_LAUNCH
   gank_prof_end(0, s);
   GANK_LAUNCH_OK("img16_conv3x3");
   return 0;
