@@ -768,6 +768,170 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(IgemmArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / SAME convolution with at most 4 output channels: the generator's image layer G.Output (256 -> 3 + tanh,
+// gan_cifar_resnet.py:260-261).  On the 32-row instance of the patch kernel above it ran 36 tap-steps per block, each with a
+// weight tile through LDS and a barrier for FOUR MFMAs per wave (87 us for the 320-sample pass against a 35 us HBM floor:
+// latency, not arithmetic).  The whole filter is 4 rows x 9 x Cin: it is loaded into LDS ONCE per block ([4][Kpad + 8], row 3
+// zero), the 10 x 18 halo of a 64-channel chunk is staged as before (next chunk's requests in flight during the taps), and a
+// chunk's 36 MFMA steps run with no barrier in between.  MODE bits as the patch kernel: 0 relu on the input, 3 conditional batch
+// norm + relu applied while staging.
+// ------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void conv3x3_few_kernel(IgemmArgs a) {
+  constexpr int NT = 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* sP = reinterpret_cast<bf16*>(smem);             // [10][HROWP]
+  bf16* sW = sP + 10 * HROWP;                           // [4][Kpad + 8]
+  const int wrow = a.Kpad + 8;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int lid = xcd_remap(blockIdx.x, a.tiles_m);
+  const int pw = a.W >> 4, ph = a.H >> 3;
+  const int n = lid / (pw * ph), pr = lid - n * pw * ph;
+  const int py0 = (pr / pw) << 3, px0 = (pr % pw) << 4;
+
+  constexpr int OOB = 0x7FFFFFF0;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, a.N * a.H * a.W * a.Cin * 2, 0x00020000);
+
+  // the filter: rows 0 .. Cout-1 of the [CoutPad][Kpad] operand, row 3 (and any row >= Cout) zero
+  for (int q = tid; q < 4 * (a.Kpad >> 3); q += NT) {
+    const int row = q / (a.Kpad >> 3), c8 = q - row * (a.Kpad >> 3);
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row < a.Cout && row < 3) v = *reinterpret_cast<const u32x4*>(a.w + (long)row * a.Kpad + c8 * 8);
+    *reinterpret_cast<u32x4*>(sW + row * wrow + c8 * 8) = v;
+  }
+
+  int h_off[6], h_lds[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    const int q = tid + NT * j;
+    const int hp = q >> 3, cc = q & 7;
+    const int iy = py0 - 1 + hp / 18, ix = px0 - 1 + hp % 18;
+    const bool ok = q < PHALO * 8 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    h_off[j] = ok ? (((n * a.H + iy) * a.W + ix) * a.Cin + cc * 8) * 2 : OOB;
+    h_lds[j] = (q < PHALO * 8) ? (hp / 18) * HROWP + (hp % 18) * LROW + cc * 8 : -1;
+  }
+  u32x4 rH[6];
+  constexpr bool NORM = (MODE & 8) != 0;
+  f32x4 nm[NORM ? 8 : 1];
+  const float* np_mu = nullptr;
+  const float* np_ga = nullptr;
+  const float* np_be = nullptr;
+  if constexpr (NORM) {
+    int lb = a.cbn_labels[n];
+    lb = lb < 0 ? 0 : (lb >= a.cbn_n_labels ? a.cbn_n_labels - 1 : lb);
+    np_mu = a.cbn_stats + (long)(n / a.cbn_n_per_group) * 2 * a.Cin + (tid & 7) * 8;
+    np_ga = a.cbn_gamma + (long)lb * a.Cin + (tid & 7) * 8;
+    np_be = a.cbn_beta + (long)lb * a.Cin + (tid & 7) * 8;
+  }
+  auto load_halo = [&](int c) {
+#pragma unroll
+    for (int j = 0; j < 6; j++)
+      rH[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, h_off[j] == OOB ? OOB : h_off[j] + c * 128, 0, 0);
+    if constexpr (NORM) {
+      nm[0] = *reinterpret_cast<const f32x4*>(np_mu + c * 64); nm[1] = *reinterpret_cast<const f32x4*>(np_mu + c * 64 + 4);
+      nm[2] = *reinterpret_cast<const f32x4*>(np_mu + a.Cin + c * 64); nm[3] = *reinterpret_cast<const f32x4*>(np_mu + a.Cin + c * 64 + 4);
+      nm[4] = *reinterpret_cast<const f32x4*>(np_ga + c * 64); nm[5] = *reinterpret_cast<const f32x4*>(np_ga + c * 64 + 4);
+      nm[6] = *reinterpret_cast<const f32x4*>(np_be + c * 64); nm[7] = *reinterpret_cast<const f32x4*>(np_be + c * 64 + 4);
+    }
+  };
+  auto store_halo = [&]() {           // the patch kernel's staging, expression for expression (MODE bit 3: the forward CBN kernel's)
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      if (h_lds[j] >= 0) {
+        u32x4 v = rH[j];
+        if constexpr (NORM) {
+          if (h_off[j] != OOB) {
+            const bf16x8 xv = __builtin_bit_cast(bf16x8, v);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+              const float mu = e < 4 ? nm[0][e] : nm[1][e - 4], iv = e < 4 ? nm[2][e] : nm[3][e - 4];
+              const float ga = e < 4 ? nm[4][e] : nm[5][e - 4], be = e < 4 ? nm[6][e] : nm[7][e - 4];
+              const float t = (bf2f(xv[e]) - mu) * iv * ga + be;
+              o[e] = f2bf(fmaxf(t, 0.f));
+            }
+            v = __builtin_bit_cast(u32x4, o);
+          }
+        } else if constexpr ((MODE & 1) != 0) {
+          v = relu_bf16x8(v);
+        }
+        *reinterpret_cast<u32x4*>(sP + h_lds[j]) = v;
+      }
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; e++) acc[e] = 0.f;
+  // B fragment of this lane: pixel (2 * wave + (r >> 4), r & 15) of the patch, centre tap; A fragment: filter row min(r, 3)
+  const int pb = (wave * 2 + (r >> 4) + 1) * HROWP + ((r & 15) + 1) * LROW + h * 8;
+  const int ab = (r < 3 ? r : 3) * wrow + h * 8;
+
+  const int nchunks = a.Cin >> 6;
+  load_halo(0);
+  store_halo();
+  __syncthreads();
+#pragma unroll 1
+  for (int c = 0; c < nchunks; c++) {
+    if (c + 1 < nchunks) load_halo(c + 1);           // in flight during the 36 steps of this chunk
+    const bf16* pW = sW + ab + c * 64;
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) {
+      const int toff = (tap / 3 - 1) * HROWP + (tap % 3 - 1) * LROW;
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        const bf16x8 fa = *reinterpret_cast<const bf16x8*>(pW + tap * a.Cin + kk * 16);
+        const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sP + pb + toff + kk * 16);
+        acc = GANK_MFMA32(fa, fb, acc);
+      }
+    }
+    if (c + 1 < nchunks) {
+      __syncthreads();                               // every wave is past its last read of the patch
+      store_halo();
+      __syncthreads();
+    }
+  }
+
+  // epilogue: rows 0 .. Cout-1 of the tile sit in the first accumulator quad of the h = 0 lanes
+  if (h == 0) {
+    const bool otanh = (a.flags & GANK_OUT_TANH) != 0;
+    const int py = wave * 2 + (r >> 4), px = r & 15;
+    const long m = ((long)(n * a.H + py0 + py)) * a.W + px0 + px;
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+      if (e >= a.Cout) break;
+      float t = acc[e] * a.scale;
+      if (a.bias) t += a.bias[e];
+      if (a.mask) t = (bf2f(a.mask[m * a.Cout + e]) > 0.f) ? t : 0.f;
+      if (a.res) t += bf2f(a.res[m * a.Cout + e]);
+      a.y[m * a.Cout + e] = f2bf(otanh ? tanhf(t) : t);
+    }
+  }
+}
+
+template <int MODE>
+static int launch_few(const IgemmArgs& a0, hipStream_t s) {
+  IgemmArgs a = a0;
+  a.tiles_m = a.N * (a.H / 8) * (a.W / 16);
+  a.tiles_n = 1;
+  const size_t lds = ((size_t)10 * HROWP + (size_t)4 * (a.Kpad + 8)) * sizeof(bf16);
+  auto kern = conv3x3_few_kernel<MODE>;
+  GANK_MAX_DYNAMIC_LDS(kern, (int)lds, "conv3x3_few");
+  static const std::string tag = gank_format("conv3x3_few_kernel<%d>", MODE);     // magic static: built once, thread-safe
+  gank_prof_tag(0, tag.c_str());
+  hipLaunchKernelGGL(kern, dim3(a.tiles_m), dim3(256), lds, s, a);
+  GANK_LAUNCH_OK("conv3x3_few");
+  return 0;
+}
+static bool few_ok(const IgemmArgs& a) {
+  static const int env = gank_tune("GANK_IGEMM_FEW", 1);   // experiment knob: 0 keeps the 32-row patch kernel
+  return env && a.Cout <= 3 && a.CoutPad == 32 && a.Cin % 64 == 0 && a.Kpad == 9 * a.Cin && !(a.flags & IG_RES_UP2X) &&
+         (size_t)(10 * HROWP + 4 * (a.Kpad + 8)) * sizeof(bf16) <= 160 * 1024;
+}
+
 template <int MODE>    // MODE has bit 2 set
 static int launch_patch_phase(const IgemmArgs& a0, hipStream_t s) {
   IgemmArgs a = a0;
@@ -1584,6 +1748,8 @@ int gank_igemm_dispatch(IgemmArgs a, hipStream_t s) {
     else rc = relu ? launch_pp<1, 16>(a, s) : launch_pp<0, 16>(a, s);
   } else if (patch_ok) {
     rc = (a.flags & GANK_IN_RELU) ? launch_patch<1, 128>(a, s) : launch_patch<0, 128>(a, s);
+  } else if (patch32_ok && few_ok(a)) {
+    rc = (a.flags & GANK_IN_RELU) ? launch_few<1>(a, s) : launch_few<0>(a, s);
   } else if (patch32_ok) {
     rc = (a.flags & GANK_IN_RELU) ? launch_patch<1, 32>(a, s) : launch_patch<0, 32>(a, s);
   } else if (packed) {
@@ -1684,7 +1850,7 @@ extern "C" int gank_cbn_relu_conv3x3_fprop(const void* x, const int32_t* labels,
   a.cbn_n_per_group = N / groups; a.cbn_n_labels = n_labels;
   hipStream_t s = (hipStream_t)stream;
   gank_prof_begin(0, 2.0 * a.M * (double)Cout * 9 * Cin, s, 2.0 * ((double)a.M * Cin + 9.0 * Cin * Cout + (double)a.M * Cout));
-  const int rc = a.CoutPad == 32 ? launch_patch<8, 32>(a, s) : launch_patch<8, 128>(a, s);
+  const int rc = a.CoutPad == 32 ? (few_ok(a) ? launch_few<8>(a, s) : launch_patch<8, 32>(a, s)) : launch_patch<8, 128>(a, s);
   gank_prof_end(0, s);
   return rc;
 }
