@@ -32,7 +32,7 @@ def polynomial_decay(step, lr0=0.0004, decay_steps=50000, lr_end=0.0002):
 
 class ACGANTrainer:
     def __init__(self, batch_size=64, z_dim=128, acgan_scale_G=0.1, n_dis=5, max_iter=100000, device="cuda", seed=0,
-                 process_group=None, state=None, use_graphs=True):
+                 process_group=None, state=None, use_graphs=True, allow_eager_fallback=False):
         self.device = torch.device(device)
         self.batch, self.z_dim, self.scale_g, self.n_dis, self.max_iter = batch_size, z_dim, acgan_scale_G, n_dis, max_iter
         self.store = set_default_store(ParamStore(self.device, seed=seed))
@@ -64,7 +64,7 @@ class ACGANTrainer:
         self.losses = {}
         # the two updates as captured hipGraphs (gan_lib_tensorflow_amd/graphs.py): static input buffers, the learning rate
         # written into the optimiser's device-side hyper-parameters outside the captured region
-        self.graphs = GraphRunner(use_graphs)
+        self.graphs = GraphRunner(use_graphs, allow_eager_fallback)     # a failed hipGraph capture raises unless the caller allows eager execution
         self.real_u8 = torch.zeros((batch_size, 3072), dtype=torch.uint8, device=self.device)
         self.real_labels = torch.zeros(batch_size, dtype=torch.int32, device=self.device)
 

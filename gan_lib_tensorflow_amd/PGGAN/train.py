@@ -30,7 +30,7 @@ def default_args(**over):
 
 
 class PGGANTrainer:
-    def __init__(self, args, device="cuda", seed=0, process_group=None, state=None, use_graphs=True):
+    def __init__(self, args, device="cuda", seed=0, process_group=None, state=None, use_graphs=True, allow_eager_fallback=False):
         assert args.image_size == 4 * 2 ** args.block_count, "image_size must be 4 * 2**block_count (train.py:52-54)"
         self.args = args
         self.device = torch.device(device)
@@ -57,7 +57,7 @@ class PGGANTrainer:
         self.d_opt = self._adam(self.d_flat)
         self.losses = {}
         # the two updates as captured hipGraphs: static input rows, the fade-in weight in device memory (written before a replay)
-        self.graphs = GraphRunner(use_graphs)
+        self.graphs = GraphRunner(use_graphs, allow_eager_fallback)     # a failed hipGraph capture raises unless the caller allows eager execution
         self.real_u8 = torch.zeros((args.batch_size, args.image_dim), dtype=torch.uint8, device=self.device)
         self.alpha_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
 

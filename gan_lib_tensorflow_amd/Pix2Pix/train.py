@@ -36,7 +36,7 @@ def polynomial_decay(step, lr0, decay_steps, lr_end):
 
 
 class Pix2PixTrainer:
-    def __init__(self, args, device="cuda", seed=0, process_group=None, state=None, in_channels=3, out_channels=3, use_graphs=True):
+    def __init__(self, args, device="cuda", seed=0, process_group=None, state=None, in_channels=3, out_channels=3, use_graphs=True, allow_eager_fallback=False):
         if args.loss_type != 'HINGE':
             raise NotImplementedError('loss_type HINGE (the reference default, train.py:38)')
         self.args = args
@@ -66,7 +66,7 @@ class Pix2PixTrainer:
         self.d_opt = self._adam(self.d_flat)
         self.losses = {}
         # the two updates as captured hipGraphs: static input / target buffers, the learning rate written outside the capture
-        self.graphs = GraphRunner(use_graphs)
+        self.graphs = GraphRunner(use_graphs, allow_eager_fallback)     # a failed hipGraph capture raises unless the caller allows eager execution
         self.inputs = torch.zeros((args.batch_size, args.crop_size, args.crop_size, in_channels), dtype=K.BF16, device=self.device)
         self.targets = torch.zeros((args.batch_size, args.crop_size, args.crop_size, out_channels), dtype=K.BF16, device=self.device)
 

@@ -7,6 +7,14 @@
 //   abs_diff_mean   mean |a - b| and its gradient              L1 loss (Pix2Pix/train.py:510-512)
 #include "gank_common.h"
 
+// grid of a GRID-STRIDE kernel: capped.  Kernels that take ONE element per thread and return (`if (i >= n) return;`) must be
+// launched with g_all -- capped, they silently left everything behind the first 4096 x 256 elements unwritten (found by the
+// batch-16 Pix2Pix generator test: NaN garbage in every tensor of more than 8.4 M elements that passed through them)
+static inline dim3 g_all(long n) {
+  long b = (n + 255) / 256;
+  if (b < 1) b = 1;
+  return dim3((unsigned)b);
+}
 static inline dim3 g1(long n, long cap = 4096) {
   long b = (n + 255) / 256;
   if (b > cap) b = cap;
@@ -382,7 +390,7 @@ extern "C" int gank_im2col_narrow(const void* x, void* y, int N, int Hin, int Wi
   GANK_REQUIRE(ksize >= 1 && ksize <= 7 && stride >= 1 && pad >= 0 && Kpad % 8 == 0 && Kpad >= ksize * ksize * Cin,
                "im2col_narrow: k=%d stride=%d pad=%d Kpad=%d (needs Kpad %% 8 == 0 and >= k*k*Cin = %d)", ksize, stride, pad, Kpad, ksize * ksize * Cin);
   const long total8 = (long)N * Ho * Wo * (Kpad / 8);
-  hipLaunchKernelGGL(im2col_narrow_kernel, g1(total8), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, total8, Hin, Win, Cin, Ho, Wo,
+  hipLaunchKernelGGL(im2col_narrow_kernel, g_all(total8), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, total8, Hin, Win, Cin, Ho, Wo,
                      ksize, stride, pad, Kpad);
   GANK_LAUNCH_OK("im2col_narrow");
   return 0;
@@ -465,7 +473,7 @@ extern "C" int gank_tap_gather_up2(const void* Z, const float* bias, void* y, in
   GANK_REQUIRE(ksize >= 1 && ksize <= 7 && pad >= 0 && Cout >= 1 && Cout <= 4 && ksize * ksize * Cout <= Zc,
                "tap_gather_up2: k=%d Cout=%d needs Cout <= 4 and k*k*Cout <= Zc=%d", ksize, Cout, Zc);
   const long pixels = (long)N * 4 * h * w;
-  hipLaunchKernelGGL(tap_gather_up2_kernel, g1(pixels), dim3(256), 0, (hipStream_t)stream, (const bf16*)Z, bias, (bf16*)y, pixels, h, w, ksize, pad,
+  hipLaunchKernelGGL(tap_gather_up2_kernel, g_all(pixels), dim3(256), 0, (hipStream_t)stream, (const bf16*)Z, bias, (bf16*)y, pixels, h, w, ksize, pad,
                      Cout, Zc, tanh_out);
   GANK_LAUNCH_OK("tap_gather_up2");
   return 0;
@@ -475,7 +483,7 @@ extern "C" int gank_tap_scatter_up2(const void* g, void* col, int N, int h, int 
   GANK_REQUIRE(ksize >= 1 && ksize <= 7 && pad >= 0 && Cout >= 1 && Cout <= 4 && ksize * ksize * Cout <= Zc && Zc % 8 == 0,
                "tap_scatter_up2: k=%d Cout=%d needs Cout <= 4, k*k*Cout <= Zc=%d and Zc %% 8 == 0", ksize, Cout, Zc);
   const long total8 = (long)N * h * w * (Zc / 8);
-  hipLaunchKernelGGL(tap_scatter_up2_kernel, g1(total8), dim3(256), 0, (hipStream_t)stream, (const bf16*)g, (bf16*)col, total8, h, w, ksize, pad, Cout, Zc);
+  hipLaunchKernelGGL(tap_scatter_up2_kernel, g_all(total8), dim3(256), 0, (hipStream_t)stream, (const bf16*)g, (bf16*)col, total8, h, w, ksize, pad, Cout, Zc);
   GANK_LAUNCH_OK("tap_scatter_up2");
   return 0;
 }
@@ -501,14 +509,14 @@ __global__ void d2s2_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst
 extern "C" int gank_depth_to_space2(const void* x, void* y, int N, int h, int w, int C, void* stream) {
   GANK_REQUIRE(x && y && N > 0 && h > 0 && w > 0 && C > 0 && C % 8 == 0, "depth_to_space2: bad arguments (C %% 8 == 0)");
   const long total8 = (long)N * 4 * h * w * (C / 8);
-  hipLaunchKernelGGL(d2s2_kernel<true>, g1(total8), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, total8, h, w, C);
+  hipLaunchKernelGGL(d2s2_kernel<true>, g_all(total8), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, total8, h, w, C);
   GANK_LAUNCH_OK("depth_to_space2");
   return 0;
 }
 extern "C" int gank_space_to_depth2(const void* y, void* x, int N, int h, int w, int C, void* stream) {
   GANK_REQUIRE(x && y && N > 0 && h > 0 && w > 0 && C > 0 && C % 8 == 0, "space_to_depth2: bad arguments (C %% 8 == 0)");
   const long total8 = (long)N * 4 * h * w * (C / 8);
-  hipLaunchKernelGGL(d2s2_kernel<false>, g1(total8), dim3(256), 0, (hipStream_t)stream, (const bf16*)y, (bf16*)x, total8, h, w, C);
+  hipLaunchKernelGGL(d2s2_kernel<false>, g_all(total8), dim3(256), 0, (hipStream_t)stream, (const bf16*)y, (bf16*)x, total8, h, w, C);
   GANK_LAUNCH_OK("space_to_depth2");
   return 0;
 }

@@ -5,8 +5,9 @@ cost ~100 us of host time each and the GPU idles between them (ACGAN at 32 sampl
 piece runs eagerly once (allocator warm-up, lazy initialisation; this IS the step), is captured on the next use and
 replayed from then on.  What a captured piece may depend on: device memory at fixed addresses only -- inputs are copied into
 static buffers, step counters / learning rates / fade-in weights / RNG state live on the device and are updated OUTSIDE the
-captured region.  Capture failure falls back to eager execution (with a message): capture is an optimisation, never a
-correctness need.
+captured region.  A capture that fails RAISES (the eager first execution already was that step, so nothing is lost): a run
+that asked for graphs must not silently become a 10x slower eager run.  `allow_eager_fallback=True` restores the degradation
+to eager execution with a message on stderr.
 """
 import gc
 import sys
@@ -15,8 +16,9 @@ import torch
 
 
 class GraphRunner:
-    def __init__(self, enabled=True):
+    def __init__(self, enabled=True, allow_eager_fallback=False):
         self.enabled = enabled and torch.cuda.is_available()
+        self.allow_eager_fallback = allow_eager_fallback
         self.graphs = {}
         self._seen = set()
 
@@ -51,9 +53,12 @@ class GraphRunner:
             self.graphs[key] = g
             g.replay()                   # capture executed nothing: this is the step
         except Exception as e:  # noqa: BLE001
+            torch.cuda.synchronize()
+            if not self.allow_eager_fallback:
+                raise RuntimeError(f"hipGraph capture of {key!r} failed ({e}); pass allow_eager_fallback=True (or use_graphs=False) "
+                                   f"to run eagerly") from e
             print(f"[gank] hipGraph capture of {key!r} failed ({e}); running eagerly", file=sys.stderr)
             self.enabled = False
-            torch.cuda.synchronize()
             return fn()
         return None
 

@@ -323,6 +323,81 @@ def test_pix2pix_batch16_critic_pass_is_the_mean_of_its_sub_batches(gpu):
     tr.d_flat['grads'].zero_()
 
 
+def test_pix2pix_batch16_generator_pass_is_the_mean_of_its_sub_batches(gpu):
+    """BASELINE.json config 5 at its full size on the OTHER network: the U-Net generator at batch 16, 512 x 512.  Every layer is
+    per sample (instance norm; the decoder's dropout masks are recorded from the batch-16 pass and re-applied slice by slice),
+    so the images of the batch are the images of its four sub-batches of 4 and the gradient of a mean L1 loss over 16 pairs is
+    the mean of the four sub-batch gradients.  At batch 16 the dispatcher takes routes batch 1-4 never take (decoder_3 / decoder_4
+    cross the phase-stack threshold of functional.PHASE_STACK_MIN_PIXELS, other tile shapes): a size-independent check of those
+    routes' forward pass and all three gradients, at a size the float64 restatement cannot reach in a test."""
+    from gan_lib_tensorflow_amd import functional as Fn, kernels as K
+    tr, _ = make(batch=16, seed=13)
+    g = torch.Generator().manual_seed(9)
+    a = (torch.rand(16, 512, 512, 3, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+    b = (torch.rand(16, 512, 512, 3, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+    with _MaskLog(K) as log:
+        out16 = tr._generator(a)
+        tr._backward(Fn.l1_loss(out16, b))
+    torch.cuda.synchronize()
+    assert out16.shape == (16, 512, 512, 3) and len(log.masks) == 3
+    g16 = tr.g_flat['grads'].clone()
+    assert bool(torch.isfinite(g16).all()) and float(g16.abs().max()) > 0
+    tr.g_flat['grads'].zero_()
+    masks, orig, parts = log.masks, K.dropout_fwd, []
+    try:
+        for i in range(4):
+            calls = iter(range(3))
+
+            def replay(x, keep, rng_state, i=i, calls=calls):         # the recorded mask rows of this sub-batch, same kernel arithmetic
+                m = masks[next(calls)][4 * i:4 * i + 4].contiguous()
+                return K.dropout_bwd(x, m, keep), m
+            K.dropout_fwd = replay
+            o = tr._generator(a[4 * i:4 * i + 4].contiguous())
+            parts.append(o.detach())
+            tr._backward(Fn.l1_loss(o, b[4 * i:4 * i + 4].contiguous()))
+    finally:
+        K.dropout_fwd = orig
+    torch.cuda.synchronize()
+    # images in tanh range: the two batch sizes run different kernels (other tiles, the phase-stacked decoders), bf16 rounding apart
+    d = (out16.double().cpu() - torch.cat(parts, 0).double().cpu()).abs()
+    assert float(d.max()) < 0.1 and float(d.mean()) < 4e-3, (float(d.max()), float(d.mean()))
+    g4 = tr.g_flat['grads'] / 4
+    e = l2(g16, g4.double().cpu())
+    assert e < 3e-2, e
+    tr.g_flat['grads'].zero_()
+
+
+def test_one_element_per_thread_kernels_cover_tensors_beyond_the_grid_cap(gpu):
+    """gank_depth_to_space2 / _space_to_depth2, gank_im2col_narrow and the tap gather / scatter pair take one 16-byte piece (or pixel)
+    per thread; launched on the capped grid of the grid-stride kernels (4096 blocks) they left everything behind the first 8.4 M
+    elements unwritten -- every Pix2Pix pass at batch >= 4 went through such tensors.  Sizes here are 2.5x past that cap; the
+    outputs are compared in full (torch on the GPU as the checker: these are pure data movements / short sums)."""
+    from gan_lib_tensorflow_amd import kernels as K
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn((5, 128, 128, 256), generator=g, device="cuda").to(torch.bfloat16)           # 21 M elements
+    y = K.depth_to_space2(x)
+    ref = x.view(5, 128, 128, 2, 2, 64).permute(0, 1, 3, 2, 4, 5).reshape(5, 256, 256, 64)
+    assert torch.equal(y, ref) and torch.equal(K.space_to_depth2(y), x)
+    img = torch.randn((5, 512, 512, 6), generator=g, device="cuda").to(torch.bfloat16)
+    col = K.im2col_narrow(img, (256, 256), 4, 2, 1, 128)                                           # 42 M elements
+    pad = torch.nn.functional.pad(img, (0, 0, 1, 1, 1, 1))
+    for (ky, kx) in ((0, 0), (1, 2), (3, 3)):
+        want = pad[:, ky:ky + 512:2, kx:kx + 512:2, :]
+        assert torch.equal(col[..., (ky * 4 + kx) * 6:(ky * 4 + kx) * 6 + 6], want), (ky, kx)
+    assert float(col[..., 96:].abs().max()) == 0.0
+    z = torch.randn((5, 256, 256, 64), generator=g, device="cuda").to(torch.bfloat16)            # 21 M elements in, 3.9 M pixels out
+    out = K.tap_gather_up2(z, None, 4, 1, 3, False)
+    assert out.shape == (5, 512, 512, 3) and bool(torch.isfinite(out.float()).all())
+    gsm = torch.randn((5, 512, 512, 3), generator=g, device="cuda").to(torch.bfloat16)
+    colg = K.tap_scatter_up2(gsm, 4, 1, 64)
+    # adjointness over the WHOLE tensors: <scatter(g), z> == <g, gather(z)> (an unwritten tail breaks it)
+    lhs, rhs = float((colg.double() * z.double()).sum()), float((gsm.double() * out.double()).sum())
+    assert abs(lhs - rhs) < 2e-2 * float((colg.double() * z.double()).abs().sum()) and abs(lhs) > 0
+    # and the tails themselves: the last sample equals the same sample run alone
+    assert torch.equal(K.tap_gather_up2(z[4:].contiguous(), None, 4, 1, 3, False), out[4:])
+    assert torch.equal(K.tap_scatter_up2(gsm[4:].contiguous(), 4, 1, 64), colg[4:])
+
+
 def test_im2col_depth_to_space_and_tap_kernels_against_numpy(gpu):
     """The data-movement kernels behind the round-3 Pix2Pix routes, each against a NumPy restatement: gank_im2col_narrow (bit for bit:
     a gather of bf16 values), gank_depth_to_space2 / gank_space_to_depth2 (bit for bit, and inverse of each other), gank_tap_scatter_up2
