@@ -99,6 +99,7 @@ def Generator(n_samples_, labels, noise=None, reuse=False, groups=1, rng_state=N
         return output.reshape(-1, OUTPUT_DIM)
 
 
+INCEPTION_FREQUENCY = 1000   # how frequently to calculate the Inception score (:49)
 FUSE_OUTPUT_NORM = True    # no-grad passes: G.OutputNorm + relu inside G.Output's operand staging
 # Data parallel: the generator's gradient buffer (31.5 MB fp32) leaves in these buckets, last layers first, each as soon
 # as the backward pass has passed the block boundary below it (parallel.GradBuckets).  Forward / creation order.
@@ -809,6 +810,20 @@ class SNGANTrainer:
         costs = [self.dev_disc_cost(torch.as_tensor(x), torch.as_tensor(np.asarray(y))) for x, y in dev_batches]
         return float(np.mean(costs)) if costs else float('nan')
 
+    def inception_score(self, n=50000, classifier=None, splits=10, batch_size=100):
+        """get_inception_score(n) of the training script (:546-555): 50 000 samples every INCEPTION_FREQUENCY iterations
+        (:634-637, `maybe_inception_score`).  classifier: images [-1, 1] NHWC float32 -> logits [b, >= 1000], e.g.
+        `common.inception.inception_v3.InceptionV3.from_npz(path).logits` (the frozen graph's weights are a download)."""
+        return _inception_score_of(self, n, classifier, splits, batch_size)
+
+    def maybe_inception_score(self, classifier, n=50000):
+        """The loop hook (:634-637): after `train_iteration`, `self.iteration` counts finished iterations, so the reference's
+        `iteration % INCEPTION_FREQUENCY == INCEPTION_FREQUENCY - 1` reads `self.iteration % INCEPTION_FREQUENCY == 0` here.
+        -> (mean, std) when due, else None"""
+        if self.iteration > 0 and self.iteration % INCEPTION_FREQUENCY == 0:
+            return self.inception_score(n, classifier)
+        return None
+
     @torch.no_grad()
     def sample(self, n=100, labels=None, noise=None):
         """Fixed-noise / IS sampling path (:530-555): one Generator call of n samples, batch statistics."""
@@ -816,6 +831,20 @@ class SNGANTrainer:
         if labels is None:
             labels = K.rng_labels(n, 10, self.rng_state)
         return Generator(n, labels, noise=noise, groups=1, rng_state=self.rng_state)
+
+
+def _inception_score_of(trainer, n, classifier, splits, batch_size):
+    """(:543-555)  n / 100 calls of `samples_100` -- a Generator(100, ...) pass on fresh uniform labels and fresh noise, batch
+    statistics of its own 100 samples --, `((x + 1) * (255.99 / 2)).astype('int32')` on the host, reshape to [-1, 32, 32, 3],
+    then common.inception.inception_score.get_inception_score: pixel values back to [-1, 1], whole classifier batches, the first
+    1000 logits, softmax, exp(mean KL) over `splits` splits -> (mean, std)."""
+    from ..common.inception.inception_score import get_inception_score, quantize_samples
+    all_samples = []
+    for _ in range(int(n / 100)):
+        all_samples.append(trainer.sample(100).float().cpu().numpy())
+    all_samples = np.concatenate(all_samples, axis=0)
+    all_samples = quantize_samples(all_samples, for_score=True).reshape((-1, 32, 32, 3))
+    return get_inception_score(all_samples, splits=splits, classifier=classifier, batch_size=batch_size)
 
 
 def synthetic_batches(batch_size, device, seed=0):

@@ -1,5 +1,7 @@
 """The Inception-v3 classifier of the Inception-score harness (common/inception/inception_v3.py) on the HIP kernels against the
 float64 restatement (oracle/ref_inception.py), random weights in the frozen graph's layout (the real weights are a download)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -101,3 +103,53 @@ def test_inception_v3_forward_matches_the_float64_restatement():
     many = rng.uniform(-1, 1, size=(40, 32, 32, 3)).astype(np.float32)
     mean, std = get_inception_score(many, splits=2, classifier=net.logits, batch_size=20)
     assert np.isfinite(mean) and mean >= 1.0 and np.isfinite(std)
+
+
+@pytest.mark.gpu
+def test_inception_score_protocol_end_to_end_vs_the_float64_restatement():
+    """SNGAN/gan_cifar_resnet.py:543-555 wired through `SNGANTrainer.inception_score`: n / 100 generator passes of 100 samples on
+    fresh uniform labels, `(x + 1) * 255.99 / 2` -> int32 on the host, back to [-1, 1], whole classifier batches, first 1000 logits,
+    softmax, 10-split exp(KL).  The HIP Inception network (random weights in the frozen graph's layout) classifies 1000 samples;
+    the SAME quantised samples go through the float64 restatement (oracle/ref_inception.py) in the same batches, and the two scores
+    agree to 2 % (bf16 storage 47 convolutions deep moves the logits by 0.4 %; the score is a smooth function of them).  Also the
+    every-1000-iterations hook (:634-637)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from gan_lib_tensorflow_amd.SNGAN import gan_cifar_resnet as S
+    from gan_lib_tensorflow_amd.common.inception.inception_v3 import InceptionV3
+    from gan_lib_tensorflow_amd.common.inception import inception_score as IS
+    from oracle import ref_inception as RI
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    params = random_params(5)
+    net = InceptionV3(params)
+    ref = RI.Net(params)
+    tr = S.SNGANTrainer(batch_size=8, seed=4, use_graphs=False)
+    seen = []
+
+    def classifier(batch):                      # the HIP network; keeps what it was shown for the restatement
+        seen.append(np.array(batch, copy=True))
+        return net.logits(torch.tensor(batch).to(torch.bfloat16))
+    n = 1000
+    mean, std = tr.inception_score(n=n, classifier=classifier, splits=10, batch_size=100)
+    assert len(seen) == n // 100 and all(b.shape == (100, 32, 32, 3) for b in seen)
+    shown = np.concatenate(seen, 0)
+    # what the classifier saw is the quantised sample grid: k / 127.5 - 1 for integers k in [0, 255]
+    k = (shown + 1.0) * 127.5
+    assert np.abs(k - np.round(k)).max() < 1e-3 and k.min() >= -1e-3 and k.max() <= 255 + 1e-3
+    assert np.isfinite(mean) and mean >= 1.0 and np.isfinite(std)
+
+    def ref_classifier(batch):
+        x = torch.tensor(batch).to(torch.bfloat16).double()      # the HIP network receives bf16 images
+        f = ref.features(x)
+        return (f @ ref.p['softmax/weights'] + ref.p['softmax/biases']).numpy()
+    sub = 200                                   # the float64 network on 200 of the 1000 samples (a minute of CPU), same protocol, 2 splits
+    m_hip, _ = IS.get_inception_score(shown[:sub], splits=2, classifier=lambda b: net.logits(torch.tensor(b).to(torch.bfloat16)), batch_size=100)
+    m_ref, _ = IS.get_inception_score(shown[:sub], splits=2, classifier=ref_classifier, batch_size=100)
+    print("inception score (random weights): HIP", m_hip, "float64", m_ref, "| 1000 samples, 10 splits:", mean, std)
+    assert abs(m_hip - m_ref) < 0.02 * m_ref, (m_hip, m_ref)
+    # the hook: due every INCEPTION_FREQUENCY finished iterations
+    tr.iteration = S.INCEPTION_FREQUENCY - 1
+    assert tr.maybe_inception_score(classifier, n=100) is None
+    tr.iteration = S.INCEPTION_FREQUENCY
+    got = tr.maybe_inception_score(classifier, n=100)
+    assert got is not None and np.isfinite(got[0])
