@@ -261,7 +261,7 @@ class SNGANTrainer:
     losses, :436,:498)."""
 
     def __init__(self, batch_size=BATCH_SIZE, device="cuda", seed=0, use_graphs=True, process_group=None, state=None,
-                 allow_eager_fallback=False, capture_collectives=None, grad_wire_dtype=None, loss_scale=None):
+                 allow_eager_fallback=False, capture_collectives=None, grad_wire_dtype=None, loss_scale=None, loss_type=None):
         """allow_eager_fallback: a failed hipGraph capture degrades to eager execution (with a message on stderr) instead of
         raising -- a run that asked for graphs never silently becomes a 10x slower eager run otherwise.
         capture_collectives: under data parallel the RCCL all-reduces are captured INSIDE the update graphs (one graph per
@@ -277,6 +277,12 @@ class SNGANTrainer:
         d loss / d logits by it, the optimisers divide it out (grad_scale) and count non-finite / zero gradients (`health()`)."""
         self.device = torch.device(device)
         self.allow_eager_fallback = allow_eager_fallback
+        # LOSS_TYPE of the script (:62, SOFT_PLUS = False :63): 'HINGE' (:371-381, :487-492), 'Goodfellow' (-mean(log sigmoid(real)) -
+        # mean(log(1 - sigmoid(fake))); generator -mean(log sigmoid(fake)): :363-369, :483-486), 'WGAN' (mean(fake) - mean(real);
+        # generator -mean(fake): :382-387, :493-497)
+        self.loss_type = LOSS_TYPE if loss_type is None else loss_type
+        if self.loss_type not in ('HINGE', 'Goodfellow', 'WGAN'):
+            raise NotImplementedError("LOSS_TYPE %r (gan_cifar_resnet.py:62 knows 'Goodfellow', 'HINGE', 'WGAN'; 'WGAN-GP' has no branch in the script)" % (self.loss_type,))
         self.batch = batch_size
         self.store = set_default_store(ParamStore(self.device, seed=seed))
         self.pg = process_group
@@ -419,6 +425,31 @@ class SNGANTrainer:
             flat["grads_all"].zero_()
             flat["clean"] = True
 
+    # ---- the losses of the script's LOSS_TYPE switch ----------------------------------------------------------
+    def _critic_loss(self, both, both_labels, n_real):
+        """-> (loss, logits): disc_cost on concat(real, fake) with update_collection=None"""
+        if self.loss_type == 'HINGE' and FUSED_HEAD:
+            loss, _ = Discriminator(both, both_labels, update_collection=None,
+                                    loss_head=Fn.HingeHeadSpec(0, n_real, out=self.d_loss, loss_scale=self.loss_scale))
+            return loss, loss.logits
+        logits, _ = Discriminator(both, both_labels, update_collection=None)
+        if self.loss_type == 'HINGE':
+            return Fn.hinge_d_loss(logits, n_real, out=self.d_loss), logits
+        if self.loss_type == 'WGAN':
+            return Fn.wgan_d_loss(logits, n_real, out=self.d_loss), logits
+        return Fn.gan_pointwise_loss(logits, n_real, 2, out=self.d_loss), logits          # Goodfellow: sigmoid cross-entropy against ones / zeros
+
+    def _generator_loss(self, fake, fake_labels):
+        """-> (loss, logits): gen_cost, critic with update_collection=NO_OPS"""
+        if self.loss_type == 'HINGE' and FUSED_HEAD:
+            loss, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS,
+                                    loss_head=Fn.HingeHeadSpec(1, 0, out=self.g_loss, loss_scale=self.loss_scale))
+            return loss, loss.logits
+        logits, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS)
+        if self.loss_type in ('HINGE', 'WGAN'):
+            return Fn.hinge_g_loss(logits, out=self.g_loss), logits                         # -mean(disc_fake) in both branches
+        return Fn.gan_pointwise_loss(logits, 0, 3, out=self.g_loss), logits                 # Goodfellow: -mean(log sigmoid(disc_fake))
+
     # ---- the two updates, as plain eager code (captured into graphs by _run) -----------------------
     def _d_forward_backward(self, real_pre=None, z=None, fake=None):
         """disc_cost and its gradients (:326-381): fakes from N_TOWERS generator towers conditioned on
@@ -434,13 +465,7 @@ class SNGANTrainer:
             both = torch.cat([real, fake], 0)                          # plumbing: device memcpy
             both_labels = torch.cat([self.real_labels, self.real_labels], 0)
         with _sn.grad_scratch(self.d_flat["scratch"]):        # zeroed by zero_grads above
-            if FUSED_HEAD:
-                loss, _ = Discriminator(both, both_labels, update_collection=None,
-                                        loss_head=Fn.HingeHeadSpec(0, b, out=self.d_loss, loss_scale=self.loss_scale))
-                logits = loss.logits
-            else:
-                logits, _ = Discriminator(both, both_labels, update_collection=None)
-                loss = Fn.hinge_d_loss(logits, b, out=self.d_loss)
+            loss, logits = self._critic_loss(both, both_labels, b)
         self._backward(loss)
         return logits
 
@@ -451,13 +476,7 @@ class SNGANTrainer:
         K.critic_feed(self.real_all, self.labels_all, self.fake_all, self.both, self.both_labels, self.feed_slot,
                       self.rng_state, self.feed_done)
         with _sn.grad_scratch(self.d_flat["scratch"]):        # zeroed by zero_grads above
-            if FUSED_HEAD:
-                loss, _ = Discriminator(self.both, self.both_labels, update_collection=None,
-                                        loss_head=Fn.HingeHeadSpec(0, self.batch, out=self.d_loss, loss_scale=self.loss_scale))
-                logits = loss.logits
-            else:
-                logits, _ = Discriminator(self.both, self.both_labels, update_collection=None)
-                loss = Fn.hinge_d_loss(logits, self.batch, out=self.d_loss)
+            loss, logits = self._critic_loss(self.both, self.both_labels, self.batch)
         self._backward(loss)
         return logits
 
@@ -485,13 +504,7 @@ class SNGANTrainer:
         for p in d_params:      # gen_cost is differentiated w.r.t. gen_params only (:523)
             p.requires_grad_(False)
         try:
-            if FUSED_HEAD:
-                loss, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS,
-                                        loss_head=Fn.HingeHeadSpec(1, 0, out=self.g_loss, loss_scale=self.loss_scale))
-                logits = loss.logits
-            else:
-                logits, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS)
-                loss = Fn.hinge_g_loss(logits, out=self.g_loss)
+            loss, logits = self._generator_loss(fake, fake_labels)
             self._backward(loss)
         finally:
             for p in d_params:
@@ -529,12 +542,7 @@ class SNGANTrainer:
             for p in d_params:
                 p.requires_grad_(False)
             try:
-                if FUSED_HEAD:
-                    loss, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS,
-                                            loss_head=Fn.HingeHeadSpec(1, 0, out=self.g_loss, loss_scale=self.loss_scale))
-                else:
-                    logits, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS)
-                    loss = Fn.hinge_g_loss(logits, out=self.g_loss)
+                loss, _ = self._generator_loss(fake, fake_labels)
             finally:
                 for p in d_params:
                     p.requires_grad_(True)
@@ -803,6 +811,10 @@ class SNGANTrainer:
         both = torch.cat([real, fake], 0)
         both_labels = torch.cat([lab, lab], 0)
         logits, _ = Discriminator(both, both_labels, update_collection=None)
+        if self.loss_type == 'WGAN':
+            return float(Fn.wgan_d_loss(logits, b))
+        if self.loss_type == 'Goodfellow':
+            return float(Fn.gan_pointwise_loss(logits, b, 2))
         return float(Fn.hinge_d_loss(logits, b))
 
     def dev_loss(self, dev_batches):

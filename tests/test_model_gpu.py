@@ -149,6 +149,65 @@ def test_d_and_g_gradients_vs_oracle(gpu):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("loss_type", ["Goodfellow", "WGAN"])
+def test_other_loss_types_of_the_script_vs_oracle(gpu, loss_type):
+    """LOSS_TYPE of SNGAN/gan_cifar_resnet.py:62 with SOFT_PLUS = False: 'Goodfellow' (:363-369 critic, :483-486 generator) and
+    'WGAN' (:382-387, :493-497) through `SNGANTrainer(loss_type=...)`: both losses and every gradient against torch-float64
+    autograd of the same expressions on the oracle's logits (tolerances of test_d_and_g_gradients_vs_oracle); an unknown type
+    raises as a missing branch would."""
+    import torch.nn.functional as F
+    from gan_lib_tensorflow_amd.SNGAN import gan_cifar_resnet as S
+    seed, b = 6, 4
+    state = T.init_sngan_params(seed)
+    tr = S.SNGANTrainer(batch_size=b, seed=seed, use_graphs=False, state=state, loss_type=loss_type)
+    rng = np.random.default_rng(17)
+    z = bf16r(rng.normal(size=(b, 128)))
+    labels = torch.tensor(rng.integers(0, 10, b), dtype=torch.int32)
+    real_u8 = torch.tensor(rng.integers(0, 256, (b, 3072)), dtype=torch.uint8)
+    real_pre = bf16r(T.preprocess_real(real_u8, torch.zeros(b, 3072, dtype=torch.float64), torch.float64).numpy())
+    P = T.to_torch(state)
+    _, _, lg = T.d_loss_fn(P, None, labels.long(), z.to(torch.float64), None, real_pre=real_pre.to(torch.float64))
+    if loss_type == 'Goodfellow':
+        loss = -F.logsigmoid(lg[:b]).mean() - F.logsigmoid(-lg[b:]).mean()          # log(1 - sigmoid(x)) = logsigmoid(-x)
+    else:
+        loss = lg[b:].mean() - lg[:b].mean()
+    dn = T.trainable_names(P, 'Discriminator')
+    ref_g = dict(zip(dn, torch.autograd.grad(loss, [P[k] for k in dn])))
+    tr.real_labels.copy_(labels)
+    tr._d_forward_backward(real_pre=real_pre.cuda(), z=z.cuda())
+    torch.cuda.synchronize()
+    assert abs(float(tr.d_loss) - float(loss)) < 0.05, (float(tr.d_loss), float(loss))
+    for k in dn:
+        g = tr.store.vars[k].main_grad.double().cpu().flatten()
+        r = ref_g[k].flatten()
+        if r.norm() < 1e-12:
+            continue
+        cos, l2 = float((g @ r) / (g.norm() * r.norm())), float((g - r).norm() / r.norm())
+        lim = (0.98, 0.2) if 'mbedding' in k else (0.995, 0.08)
+        assert cos > lim[0] and l2 < lim[1], (k, cos, l2)
+    P = T.to_torch(tr.store.state_dict())
+    z2 = bf16r(rng.normal(size=(2 * b, 128)))
+    fl = torch.tensor(rng.integers(0, 10, 2 * b), dtype=torch.int32)
+    _, lg = T.g_loss_fn(P, z2.to(torch.float64), fl.long())
+    loss = -F.logsigmoid(lg).mean() if loss_type == 'Goodfellow' else -lg.mean()
+    gn = T.trainable_names(P, 'Generator')
+    ref_g = dict(zip(gn, torch.autograd.grad(loss, [P[k] for k in gn])))
+    tr._g_forward_backward(z=z2.cuda(), fake_labels=fl.cuda())
+    torch.cuda.synchronize()
+    assert abs(float(tr.g_loss) - float(loss)) < 0.05
+    bad = []
+    for k in gn:
+        g, r = tr.store.vars[k].main_grad.double().cpu().flatten(), ref_g[k].flatten()
+        if k.endswith('Biases') and 'G.Output' not in k:
+            continue
+        cos, l2 = float((g @ r) / (g.norm() * r.norm())), float((g - r).norm() / r.norm())
+        if cos < 0.98 or l2 > 0.2:
+            bad.append((k, cos, l2))
+    assert not bad, bad
+    with pytest.raises(NotImplementedError):
+        S.SNGANTrainer(batch_size=b, seed=seed, use_graphs=False, loss_type='WGAN-GP')
+
+
 def test_train_steps_eager_vs_graph_and_oracle_update(gpu):
     """Same seeds, same feed: hipGraph replay must reproduce the eager steps (bit-for-bit except the
     fp32 atomics of wgrad), and one D update must move the parameters like the oracle's TF-Adam."""
