@@ -133,6 +133,8 @@ def _g_prep_kind(name, W):
         return 4
     if Fn.PHASE_UPCONV and name.endswith('.Conv1/Filters') and W.dim() == 4 and W.shape[0] == 3:
         return 1
+    if Fn.IMG16_CONV and name.endswith('G.Block.2.Conv2/Filters') and W.dim() == 4 and W.shape[0] == 3 and W.shape[2] % 128 == 0 and W.shape[3] % 128 == 0:
+        return 4                                                          # 16x16 image-resident conv (forward with statistics, input gradient)
     return 0
 
 

@@ -1256,7 +1256,9 @@ struct I16Args {
   const bf16* mask;       // optional [N,16,16,Cout]: result zeroed where mask <= 0 (relu backward)
   const bf16* res;        // optional [N,16,16,Cout]: added last
   bf16* y;                // [N,16,16,Cout]
+  float* stat_sums;       // optional [groups][GANK_STAT_SLOTS][2][Cout]: batch-norm statistics of (y - bias), as gank_res8_conv3x3
   int N, Cin, Cout, relu; // relu: on the input operand while it is staged
+  int res_up, stat_n_per_group;      // res_up: res is [N,8,8,Cout], added nearest-neighbour upsampled
 };
 }  // namespace
 
@@ -1367,48 +1369,97 @@ __global__ __launch_bounds__(2048 / TW) void img16_conv3x3_kernel(I16Args a) {
     }
   }
 
-  // epilogue: after acc_widen the lane holds channels 16q + 8h .. +7 of one pixel: 16-byte pieces
+  // epilogue: after acc_widen the lane holds channels 16q + 8h .. +7 of one pixel: 16-byte pieces.  Statistics (optional): the
+  // sums of v = acc + residual (the result without its bias) and v^2 per channel, as the 8x8 kernel accumulates them
+  const bool stats = a.stat_sums != nullptr;
+  float s1[2][8], s2[2][8];
+#pragma unroll
+  for (int q = 0; q < 2; q++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) { s1[q][e] = 0.f; s2[q][e] = 0.f; }
 #pragma unroll
   for (int t = 0; t < TW; t++) {
-    const long m = (long)n * 256 + (pg * 2 * TW + 2 * t + trow) * 16 + tcol;
+    const int py = pg * 2 * TW + 2 * t + trow;
+    const long m = (long)n * 256 + py * 16 + tcol;
+    const long mr = a.res_up ? (long)n * 64 + (py >> 1) * 8 + (tcol >> 1) : m;
 #pragma unroll
     for (int q = 0; q < 2; q++) {
       const int co = cg * 128 + ct * 32 + 16 * q + 8 * h;
       float v[8];
       acc_widen(acc[t], q, 1.0f, v);
-      if (a.bias) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + co), b1 = *reinterpret_cast<const f32x4*>(a.bias + co + 4);
-#pragma unroll
-        for (int e = 0; e < 4; e++) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-      }
       if (a.mask) {
         const bf16x8 mk = *reinterpret_cast<const bf16x8*>(a.mask + m * a.Cout + co);
 #pragma unroll
         for (int e = 0; e < 8; e++) v[e] = bf2f(mk[e]) > 0.f ? v[e] : 0.f;
       }
       if (a.res) {
-        const bf16x8 rs = *reinterpret_cast<const bf16x8*>(a.res + m * a.Cout + co);
+        const bf16x8 rs = *reinterpret_cast<const bf16x8*>(a.res + mr * a.Cout + co);
 #pragma unroll
         for (int e = 0; e < 8; e++) v[e] += bf2f(rs[e]);
       }
+      f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias) { b0 = *reinterpret_cast<const f32x4*>(a.bias + co); b1 = *reinterpret_cast<const f32x4*>(a.bias + co + 4); }
       bf16x8 o;
 #pragma unroll
-      for (int e = 0; e < 8; e++) o[e] = f2bf(v[e]);
+      for (int e = 0; e < 8; e++) {
+        s1[q][e] += v[e];
+        s2[q][e] += v[e] * v[e];
+        o[e] = f2bf(v[e] + (e < 4 ? b0[e] : b1[e - 4]));
+      }
       *reinterpret_cast<bf16x8*>(a.y + m * a.Cout + co) = o;
     }
   }
+  if (stats) {
+    // per wave: 32 channels x 2 statistics, each the sum over the 32 lanes r of a half-wave (channel 16q + 8h + e); through LDS
+    // ([stat][q][h][e][r] floats per wave), then lane (stat, channel) adds its 32 values -> ONE full-width atomic per wave
+    __syncthreads();                                 // every wave is done reading the images
+    float* red = reinterpret_cast<float*>(smem) + wave * 2048;
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        red[((0 * 2 + q) * 2 + h) * 256 + e * 32 + r] = s1[q][e];
+        red[((1 * 2 + q) * 2 + h) * 256 + e * 32 + r] = s2[q][e];
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int st = lane >> 5, cw = lane & 31, qq = cw >> 4, hh = (cw >> 3) & 1, ee = cw & 7;
+    const float* src = red + ((st * 2 + qq) * 2 + hh) * 256 + ee * 32;
+    float tsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const f32x4 t4 = *reinterpret_cast<const f32x4*>(src + 4 * i);
+      tsum += (t4[0] + t4[1]) + (t4[2] + t4[3]);
+    }
+    float* dst = a.stat_sums + ((long)(n / a.stat_n_per_group) * GANK_STAT_SLOTS + (blockIdx.x % GANK_STAT_SLOTS)) * 2 * a.Cout;
+    atomicAdd(dst + st * a.Cout + cg * 128 + ct * 32 + cw, tsum);
+  }
 }
 
-extern "C" int gank_img16_conv3x3(const void* x, const void* w_rfrag, const float* bias, const void* relu_ref, const void* residual, void* y,
-                                  int N, int Cin, int Cout, int flags, void* stream) {
+__global__ void i16_zero_kernel(float* __restrict__ p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
+extern "C" int gank_img16_conv3x3_stats(const void* x, const void* w_rfrag, const float* bias, const void* relu_ref, const void* residual, void* y,
+                                        int N, int Cin, int Cout, int flags, float* stat_sums, int stat_groups, void* stream) {
   GANK_REQUIRE(x && w_rfrag && y && N > 0, "img16_conv3x3: null pointer");
   GANK_REQUIRE(Cin % 64 == 0 && Cout % 128 == 0, "img16_conv3x3: needs Cin %% 64 == 0 and Cout %% 128 == 0 (got %d, %d)", Cin, Cout);
-  GANK_REQUIRE((flags & ~GANK_IN_RELU) == 0, "img16_conv3x3: flags: GANK_IN_RELU only");
+  GANK_REQUIRE((flags & ~(GANK_IN_RELU | GANK_RES_UPSAMPLE2X | GANK_STATS_PREZEROED)) == 0, "img16_conv3x3: flags: GANK_IN_RELU, GANK_RES_UPSAMPLE2X, GANK_STATS_PREZEROED");
+  GANK_REQUIRE(!(flags & GANK_RES_UPSAMPLE2X) || residual, "img16_conv3x3: GANK_RES_UPSAMPLE2X without a residual");
+  GANK_REQUIRE(!stat_sums || (stat_groups > 0 && N % stat_groups == 0), "img16_conv3x3: batch %d not divisible by %d towers", N, stat_groups);
+  GANK_REQUIRE(!(bias && relu_ref), "img16_conv3x3: bias and relu_ref together (a forward layer has the bias, an input gradient the mask)");
   GANK_REQUIRE((long)N * 256 * (Cin > Cout ? Cin : Cout) < (1L << 30) && (long)Cout * 9 * Cin * 2 < (1L << 31), "img16_conv3x3: tensor too large (32-bit byte offsets)");
   I16Args a{};
   a.x = (const bf16*)x; a.w = (const bf16*)w_rfrag; a.bias = bias; a.mask = (const bf16*)relu_ref; a.res = (const bf16*)residual; a.y = (bf16*)y;
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.relu = (flags & GANK_IN_RELU) ? 1 : 0;
+  a.res_up = (flags & GANK_RES_UPSAMPLE2X) ? 1 : 0; a.stat_sums = stat_sums; a.stat_n_per_group = stat_sums ? N / stat_groups : 1;
   hipStream_t s = (hipStream_t)stream;
+  if (stat_sums && !(flags & GANK_STATS_PREZEROED)) {
+    const int nz = stat_groups * GANK_STAT_SLOTS * 2 * Cout;
+    hipLaunchKernelGGL(i16_zero_kernel, dim3((nz + 255) / 256), dim3(256), 0, s, stat_sums, nz);
+  }
   const double M = (double)N * 256;
   gank_prof_begin(0, 2.0 * M * Cout * 9.0 * Cin, s, 2.0 * (M * Cin + 9.0 * Cin * Cout + M * Cout * (1 + (relu_ref ? 1 : 0) + (residual ? 1 : 0))));
   static const int cfg_env = gank_tune("GANK_IMG16_CFG", 412);   // experiment knob: 100 * (pixel tiles per wave) + weight fragments in flight
@@ -1432,6 +1483,10 @@ extern "C" int gank_img16_conv3x3(const void* x, const void* w_rfrag, const floa
   gank_prof_end(0, s);
   GANK_LAUNCH_OK("img16_conv3x3");
   return 0;
+}
+extern "C" int gank_img16_conv3x3(const void* x, const void* w_rfrag, const float* bias, const void* relu_ref, const void* residual, void* y,
+                                  int N, int Cin, int Cout, int flags, void* stream) {
+  return gank_img16_conv3x3_stats(x, w_rfrag, bias, relu_ref, residual, y, N, Cin, Cout, flags, nullptr, 0, stream);
 }
 
 // ==================================================================================================================

@@ -158,7 +158,7 @@ class _Conv2d(Function):
         res8 = (RES8_CONV and k == 3 and not in_relu and not pool_out and not out_tanh and getattr(W, "_prep_res", None) is not None
                 and K.res8_conv3x3_ok(n, (H, Wd), cin, cout))
         # plain 3x3 on 16x16 images with the "rfrag" operands attached: one image x 128 output channels per workgroup
-        img16 = (IMG16_CONV and k == 3 and not upsample and not pool_out and not out_tanh and not stats_groups and not res_up
+        img16 = (IMG16_CONV and k == 3 and not upsample and not pool_out and not out_tanh
                  and getattr(W, "_prep_res", None) is not None and K.img16_conv3x3_ok(n, (H, Wd), cin, cout))
         # NN-upsample + 3x3: run as the 4 output phases of the equivalent 4x4 stride-2 transposed conv
         phase = upsample and k == 3 and cin % 64 == 0 and not in_relu and PHASE_UPCONV and not res8
@@ -174,7 +174,11 @@ class _Conv2d(Function):
             else:
                 y = K.res8_conv3x3(x, W._prep_res[0], b, cout, rflags, residual)
         elif img16:
-            y = K.img16_conv3x3(x, W._prep_res[0], b, cout, K.IN_RELU if in_relu else 0, None, residual)
+            iflags = (K.IN_RELU if in_relu else 0) | (K.RES_UPSAMPLE2X if res_up else 0)
+            if stats_groups:
+                y, _Conv2d.last_stats = K.img16_conv3x3(x, W._prep_res[0], b, cout, iflags, None, residual, stats_groups)
+            else:
+                y = K.img16_conv3x3(x, W._prep_res[0], b, cout, iflags, None, residual)
         elif phase:
             wph, _ = getattr(W, "_prep_up", None) or K.upconv3x3_prep(W.detach().view(3, 3, cin, cout))
             if stats_groups and not out_tanh:

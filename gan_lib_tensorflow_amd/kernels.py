@@ -400,11 +400,18 @@ def img16_conv3x3_ok(n, hw, cin, cout):
     return tuple(hw) == (16, 16) and cin % 64 == 0 and cout % 128 == 0 and n * 256 * max(cin, cout) < (1 << 30)
 
 
-def img16_conv3x3(x, rf, bias, cout, flags=0, relu_ref=None, residual=None):
-    """3x3 SAME conv on LDS-resident 16x16 images (rf: prep kind 4 operand, rows = output channels); flags: IN_RELU"""
+def img16_conv3x3(x, rf, bias, cout, flags=0, relu_ref=None, residual=None, stats_groups=0):
+    """3x3 SAME conv on LDS-resident 16x16 images (rf: prep kind 4 operand, rows = output channels); flags: IN_RELU, RES_UPSAMPLE2X
+    (residual is [N,8,8,Cout]).  stats_groups > 0 -> (y, ConvStats)"""
     n, cin = x.shape[0], x.shape[3]
     assert tuple(x.shape[1:3]) == (16, 16), x.shape
     y = torch.empty((n, 16, 16, cout), dtype=BF16, device=x.device)
+    if stats_groups:
+        sums, pre = stats_arena.take((stats_groups, _lib.STAT_SLOTS, 2, cout), x.device)
+        _lib.check(lib().gank_img16_conv3x3_stats(_p(x, BF16, "x"), _p(rf, BF16, "rf"), _p(bias, F32, "bias"), _p(relu_ref, BF16, "relu_ref"),
+                                                  _p(residual, BF16, "residual"), _p(y), n, cin, cout, int(flags) | (STATS_PREZEROED if pre else 0),
+                                                  _p(sums), stats_groups, _stream()), "img16_conv3x3_stats")
+        return y, ConvStats(sums, bias, stats_groups)
     _lib.check(lib().gank_img16_conv3x3(_p(x, BF16, "x"), _p(rf, BF16, "rf"), _p(bias, F32, "bias"), _p(relu_ref, BF16, "relu_ref"),
                                         _p(residual, BF16, "residual"), _p(y), n, cin, cout, int(flags), _stream()), "img16_conv3x3")
     return y

@@ -184,6 +184,12 @@ int gank_res8_chain_bwd_head(const gank_res8_head* head, const void* ylast, void
  * flags: GANK_IN_RELU.  Cin % 64 == 0, Cout % 128 == 0. */
 int gank_img16_conv3x3(const void* x, const void* w_rfrag, const float* bias, const void* relu_ref, const void* residual, void* y,
                        int N, int Cin, int Cout, int flags, void* stream);
+/* the same with the conditional-batch-norm statistics of y accumulated by the epilogue (stat_sums as gank_conv2d_fprop_stats: the
+ * generator's G.Block.2.Conv2, whose output feeds G.Block.3's first normalisation, gan_cifar_resnet.py:176-209) and, with
+ * GANK_RES_UPSAMPLE2X, a half-resolution residual [N,8,8,Cout] added nearest-neighbour upsampled (the 'up' block's shortcut, :179-182).
+ * flags: GANK_IN_RELU | GANK_RES_UPSAMPLE2X | GANK_STATS_PREZEROED; stat_sums NULL: no statistics. */
+int gank_img16_conv3x3_stats(const void* x, const void* w_rfrag, const float* bias, const void* relu_ref, const void* residual, void* y,
+                             int N, int Cin, int Cout, int flags, float* stat_sums, int stat_groups, void* stream);
 
 /* ---- 3x3 SAME conv on 8x8 images, one LDS-resident image per workgroup (operand: prep kind 4, rows = output channels):
  * the generator's first residual block (gan_cifar_resnet.py:179-207, resample='up' at 4x4 -> 8x8) -- tf.nn.conv2d of

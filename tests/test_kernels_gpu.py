@@ -1214,6 +1214,42 @@ def test_img16_conv3x3_resident_image_kernel(K, n, cin, cout, relu, masked, res)
         assert relerr(dx, rdx) < BF_TOL
 
 
+@pytest.mark.parametrize("n,groups,resmode", [(4, 2, "half"), (6, 3, None), (128, 2, "half"), (320, 10, "half")])
+def test_img16_conv3x3_statistics_and_half_resolution_residual(K, n, groups, resmode):
+    """gank_img16_conv3x3_stats as the generator's G.Block.2.Conv2 uses it: bias, the 'up' block's shortcut added from HALF
+    resolution (GANK_RES_UPSAMPLE2X), and the batch-norm statistics of the result accumulated by the epilogue -- against the oracle
+    (small cases), the implicit-GEMM kernel on the same operands, and the moments of the stored tensor."""
+    rng = np.random.default_rng(1700 + n)
+    x, xt = bf(rng.normal(size=(n, 16, 16, 256)))
+    w, _ = bf(rng.normal(size=(3, 3, 256, 256)) / np.sqrt(9 * 256))
+    b, bt = f32(rng.normal(size=256) * 2.0)
+    wt = torch.tensor(w, dtype=torch.float32).cuda()
+    (rf, rd), = K.prep_weights_batched([wt], want_d=True, kinds=[4])
+    res = rest = None
+    if resmode == "half":
+        res, rest = bf(rng.normal(size=(n, 8, 8, 256)))
+    flags = K.RES_UPSAMPLE2X if resmode == "half" else 0
+    y, cs = K.img16_conv3x3(xt, rf, bt, 256, flags, None, rest, stats_groups=groups)
+    torch.cuda.synchronize()
+    if n <= 6:
+        ref = R.conv2d_same(x, w, b)
+        if res is not None:
+            ref = ref + R.upsample_nn2x(res)
+        assert relerr(y, ref) < BF_TOL
+    wf, _ = K.prep_weights(wt, True, False)
+    y_ig = K.conv2d_fprop(xt, wf, bt, (16, 16), 256, 3, flags, 1.0, rest)
+    torch.cuda.synchronize()
+    assert relerr(y, y_ig.double().cpu().numpy()) < 5e-3
+    yd = y.double().cpu().numpy().reshape(groups, -1, 256)
+    M = yd.shape[1]
+    tot = cs.sums.double().sum(dim=1).cpu().numpy()
+    mean = tot[:, 0] / M + b
+    var = tot[:, 1] / M - (tot[:, 0] / M) ** 2
+    assert np.abs(mean - yd.mean(1)).max() < 1e-3 * np.abs(yd).max() and np.abs(var / yd.var(1) - 1).max() < 8e-3
+    y2, _ = K.img16_conv3x3(xt, rf, bt, 256, flags, None, rest, stats_groups=groups)      # the statistics do not touch the output
+    assert torch.equal(y, y2)
+
+
 @pytest.mark.parametrize("n,cin,cout,up,resmode,groups", [(3, 256, 256, False, "full", 0), (8, 256, 256, True, "half", 2), (4, 128, 128, False, None, 2),
                                                           (6, 128, 256, True, None, 0), (128, 256, 256, False, "half", 2), (320, 256, 256, True, None, 10)])
 def test_res8_conv3x3_resident_generator_layers(K, n, cin, cout, up, resmode, groups):
