@@ -1,2 +1,2 @@
-python -m pytest tests/test_model_gpu.py -m gpu -x -q > gpurun_out/r04_t22b.log 2>&1; tail -3 gpurun_out/r04_t22b.log
-bash scratch/ab_base.sh 2 100
+python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k "conv_fprop or cbn_relu_fused" > gpurun_out/r04_t23.log 2>&1; tail -2 gpurun_out/r04_t23.log
+python scratch/bench_few.py
