@@ -1557,13 +1557,18 @@ int gank_wgrad_dispatch(WgradArgs a, hipStream_t s) {
   if (rc < 0 && wgrad_rows_ok(a)) rc = launch_wgrad_rows(a, s);
   static const int lpf_env = gank_tune("GANK_WGRAD_LEAN_PF", 2);   // experiment knob: prefetch depth of the lean kernel
   (void)lpf_env;
+  // 1x1 layers on few pixels (the shortcuts: 2 K - 8 K pixels, 0.5 - 1 GFLOP): the partial tile a workgroup adds with fp32
+  // atomics is what it costs (a CU retires one 256-byte atomic instruction per ~50 ns: 64 KB of a 128 x 128 tile = 13 us);
+  // 64 x 64 tiles are 16 KB per workgroup and fill the chip four times better
+  static const int small1x1_env = gank_tune("GANK_WGRAD_1X1_SMALL_TILE", 1);
   if (rc < 0 && lean) {
 #ifdef GANK_TUNING
     if (a.Cin >= 128 && a.Cout >= 128 && lpf_env == 4) rc = launch_wgrad_lean<2, 2, 2, 2, 4>(a, s);
     else if (a.Cin >= 128 && a.Cout >= 128 && lpf_env == 3) rc = launch_wgrad_lean<2, 2, 2, 2, 3>(a, s);
     else
 #endif
-    if (a.Cin >= 128 && a.Cout >= 128) rc = launch_wgrad_lean<2, 2, 2, 2, 2>(a, s);
+    if (small1x1_env && a.ks == 1 && a.M <= 16384 && a.Cin >= 64 && a.Cout >= 64) rc = launch_wgrad_lean<2, 2, 1, 1, 2>(a, s);
+    else if (a.Cin >= 128 && a.Cout >= 128) rc = launch_wgrad_lean<2, 2, 2, 2, 2>(a, s);
     else if (a.Cin >= 64 && a.Cout >= 64) rc = launch_wgrad_lean<2, 2, 1, 1, 2>(a, s);
   }
   // narrow operands: pack (tap, channel) into <= 32 MFMA columns so the wide operand streams once
