@@ -1,1 +1,2 @@
-for st in 1 0; do for ms in 2 4 8; do for tg in 256 512; do echo "small_tile=$st MIN_STEPS=$ms TARGET=$tg"; GANK_LIB_NAME=libgank_tune.so GANK_WGRAD_1X1_SMALL_TILE=$st GANK_WGRAD_MIN_STEPS=$ms GANK_WGRAD_SPLIT_TARGET=$tg python scratch/bench_critic_wgrad.py lean; done; done; done
+python scratch/travel_dist.py hip profiles/r04_travel_cpu_summaries.json gpurun_out/r04_travel_ratio_distribution.txt > gpurun_out/r04_travel_log.txt 2>&1; tail -8 gpurun_out/r04_travel_ratio_distribution.txt
+python scratch/other_configs_bench.py > gpurun_out/r04_other_configs.txt 2>&1; cat gpurun_out/r04_other_configs.txt
