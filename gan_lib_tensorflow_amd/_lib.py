@@ -78,6 +78,11 @@ PROTOTYPES = {
     "gank_conv2d_general_wgrad": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     "gank_res8_chain_fwd": [P, P, P, P, P, P, I, I, I, P],
     "gank_res8_chain_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "gank_phase_stack4": [P, P, I, I, I, P],
+    "gank_pad_rows": [P, P, C.c_long, I, I, I, I, P],
+    "gank_tile_rows": [P, P, I, I, I, P],
+    "gank_fewout_pack": [P, P, I, I, I, I, I, P],
+    "gank_zero_f32": [P, C.c_long, P],
     "gank_img16_conv3x3": [P, P, P, P, P, P, I, I, I, I, P],
     "gank_img16_conv3x3_stats": [P, P, P, P, P, P, I, I, I, I, P, I, P],
     "gank_res8_chain_fwd_head": [P, P, P, P, P, P, P, P, P, I, I, I, P],

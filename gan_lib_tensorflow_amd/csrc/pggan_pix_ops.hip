@@ -520,3 +520,152 @@ extern "C" int gank_space_to_depth2(const void* y, void* x, int N, int h, int w,
   GANK_LAUNCH_OK("space_to_depth2");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight-side transforms of the Pix2Pix / PGGAN routes (fp32, a few MB at most) that used to run as torch.einsum / pad /
+// repeat / add_ on the product path: every FLOP of a train step is now a kernel of this library.
+// ------------------------------------------------------------------------------------------------------------------
+// phase-stacked filter of "NN-upsample + 4x4 SAME conv" (functional.conv2d_general): output row 2i + a reads the low-resolution
+// rows  a = 0: i-1 (ky 0), i (ky 1 + ky 2), i+1 (ky 3);  a = 1: i (ky 0 + ky 1), i+1 (ky 2 + ky 3)  -- likewise in x.
+//   w3[u][v][ci][(a, b, co)] = sum_{ky in T(a,u), kx in T(b,v)} w4[ky][kx][ci][co]
+// T(a,u) as a bit mask over ky:
+__device__ __forceinline__ int ps4_taps(int a, int u) {
+  return a == 0 ? (u == 0 ? 1 : (u == 1 ? 6 : 8)) : (u == 0 ? 0 : (u == 1 ? 3 : 12));
+}
+__device__ __forceinline__ int ps4_row(int a, int k) {     // the u with k in T(a,u)
+  return a == 0 ? (k == 0 ? 0 : (k == 3 ? 2 : 1)) : (k < 2 ? 1 : 2);
+}
+__global__ void phase_stack4_fwd_kernel(const float* __restrict__ w4, float* __restrict__ w3, int Cin, int Cout, long total) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Cout);
+    long t = i / Cout;
+    const int b = (int)(t & 1), a = (int)((t >> 1) & 1); t >>= 2;
+    const int ci = (int)(t % Cin); t /= Cin;
+    const int v = (int)(t % 3), u = (int)(t / 3);
+    const int my = ps4_taps(a, u), mx = ps4_taps(b, v);
+    float sacc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 4; ky++)
+#pragma unroll
+      for (int kx = 0; kx < 4; kx++)
+        if (((my >> ky) & 1) && ((mx >> kx) & 1)) sacc += w4[((long)(ky * 4 + kx) * Cin + ci) * Cout + co];
+    w3[i] = sacc;
+  }
+}
+// adjoint, ACCUMULATED: dw4[ky][kx][ci][co] += sum_{a,b} g3[u(a,ky)][u(b,kx)][ci][(a, b, co)]
+__global__ void phase_stack4_bwd_kernel(const float* __restrict__ g3, float* __restrict__ dw4, int Cin, int Cout, long total) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Cout);
+    long t = i / Cout;
+    const int ci = (int)(t % Cin); t /= Cin;
+    const int kx = (int)(t & 3), ky = (int)(t >> 2);
+    float sacc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        const int u = ps4_row(a, ky), v = ps4_row(b, kx);
+        sacc += g3[((((long)(u * 3 + v) * Cin + ci) * 2 + a) * 2 + b) * Cout + co];
+      }
+    dw4[i] += sacc;
+  }
+}
+extern "C" int gank_phase_stack4(const float* w4, float* w3, int Cin, int Cout, int adjoint, void* stream) {
+  GANK_REQUIRE(w4 && w3 && Cin > 0 && Cout > 0, "phase_stack4: bad arguments");
+  if (!adjoint) {
+    const long total = 9L * Cin * 4 * Cout;
+    hipLaunchKernelGGL(phase_stack4_fwd_kernel, g1(total), dim3(256), 0, (hipStream_t)stream, w4, w3, Cin, Cout, total);
+  } else {       // w3 holds the stacked gradient, w4 the 4x4 filter's gradient (accumulated)
+    const long total = 16L * Cin * Cout;
+    hipLaunchKernelGGL(phase_stack4_bwd_kernel, g1(total), dim3(256), 0, (hipStream_t)stream, (const float*)w3, const_cast<float*>(w4), Cin, Cout, total);
+  }
+  GANK_LAUNCH_OK("phase_stack4");
+  return 0;
+}
+
+// rows of `w_in` values -> rows of `w_out >= w_in` values, zeros behind (adjoint = 0), or the first w_in values of every wide row
+// back into the narrow one (adjoint = 1: fp32 ACCUMULATES, 16-bit overwrites).  Serves: zero input channels behind a filter
+// ([k*k][Cin*Cout] -> [k*k][Cp*Cout]) and behind an activation ([pixels][C] -> [pixels][Cp]).
+template <typename T, bool ADJ>
+__global__ void pad_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, long rows, int w_in, int w_out) {
+  const long total = ADJ ? rows * w_in : rows * (long)w_out;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    if (ADJ) {
+      const long r = i / w_in;
+      const int c = (int)(i - r * w_in);
+      if constexpr (sizeof(T) == 4) dst[i] += src[r * w_out + c];
+      else dst[i] = src[r * w_out + c];
+    } else {
+      const long r = i / w_out;
+      const int c = (int)(i - r * w_out);
+      dst[i] = c < w_in ? src[r * w_in + c] : T(0);
+    }
+  }
+}
+extern "C" int gank_pad_rows(const void* src, void* dst, long rows, int w_in, int w_out, int elem_bytes, int adjoint, void* stream) {
+  GANK_REQUIRE(src && dst && rows > 0 && w_in > 0 && w_out >= w_in && (elem_bytes == 2 || elem_bytes == 4), "pad_rows: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const long total = adjoint ? rows * w_in : rows * (long)w_out;
+  if (elem_bytes == 4) {
+    if (adjoint) hipLaunchKernelGGL((pad_rows_kernel<float, true>), g1(total), dim3(256), 0, s, (const float*)src, (float*)dst, rows, w_in, w_out);
+    else hipLaunchKernelGGL((pad_rows_kernel<float, false>), g1(total), dim3(256), 0, s, (const float*)src, (float*)dst, rows, w_in, w_out);
+  } else {
+    if (adjoint) hipLaunchKernelGGL((pad_rows_kernel<unsigned short, true>), g1(total), dim3(256), 0, s, (const unsigned short*)src, (unsigned short*)dst, rows, w_in, w_out);
+    else hipLaunchKernelGGL((pad_rows_kernel<unsigned short, false>), g1(total), dim3(256), 0, s, (const unsigned short*)src, (unsigned short*)dst, rows, w_in, w_out);
+  }
+  GANK_LAUNCH_OK("pad_rows");
+  return 0;
+}
+
+// b [n] -> [reps][n] (adjoint = 0), or b[c] += sum_j g[j][c] (adjoint = 1): the bias of a phase-stacked conv and its gradient
+__global__ void tile_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int reps, int n, int adjoint) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (adjoint ? n : reps * n); i += gridDim.x * blockDim.x) {
+    if (adjoint) {
+      float sacc = 0.f;
+      for (int j = 0; j < reps; j++) sacc += src[j * n + i];
+      dst[i] += sacc;
+    } else {
+      dst[i] = src[i % n];
+    }
+  }
+}
+extern "C" int gank_tile_rows(const float* src, float* dst, int reps, int n, int adjoint, void* stream) {
+  GANK_REQUIRE(src && dst && reps > 0 && n > 0, "tile_rows: bad arguments");
+  hipLaunchKernelGGL(tile_rows_kernel, g1(adjoint ? n : (long)reps * n), dim3(256), 0, (hipStream_t)stream, src, dst, reps, n, adjoint);
+  GANK_LAUNCH_OK("tile_rows");
+  return 0;
+}
+
+// filter [k*k][Cin][Cout] (Cout <= 4) <-> the 1x1 operand of the few-output upsample conv, wz [Cin][Zc] with column t*Cout + co
+// (zeros behind k*k*Cout); adjoint = 1: dw[t][ci][co] += gz[ci][t*Cout + co]
+__global__ void fewout_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int taps, int Cin, int Cout, int Zc, int adjoint) {
+  const int total = adjoint ? taps * Cin * Cout : Cin * Zc;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    if (adjoint) {
+      const int co = i % Cout, ci = (i / Cout) % Cin, t = i / (Cout * Cin);
+      dst[i] += src[ci * Zc + t * Cout + co];
+    } else {
+      const int col = i % Zc, ci = i / Zc;
+      const int t = col / Cout, co = col - t * Cout;
+      dst[i] = t < taps ? src[(t * Cin + ci) * Cout + co] : 0.f;
+    }
+  }
+}
+extern "C" int gank_fewout_pack(const float* src, float* dst, int ksize, int Cin, int Cout, int Zc, int adjoint, void* stream) {
+  GANK_REQUIRE(src && dst && ksize >= 1 && ksize <= 7 && Cin > 0 && Cout >= 1 && Cout <= 4 && ksize * ksize * Cout <= Zc, "fewout_pack: bad arguments");
+  const int taps = ksize * ksize;
+  hipLaunchKernelGGL(fewout_pack_kernel, g1(adjoint ? (long)taps * Cin * Cout : (long)Cin * Zc), dim3(256), 0, (hipStream_t)stream, src, dst, taps, Cin, Cout, Zc, adjoint);
+  GANK_LAUNCH_OK("fewout_pack");
+  return 0;
+}
+
+// zero fill (fp32 scratch of a backward pass: a kernel of this library instead of a framework fill)
+__global__ void zero_f32_kernel(float* __restrict__ p, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+extern "C" int gank_zero_f32(float* p, long n, void* stream) {
+  GANK_REQUIRE(p && n > 0, "zero_f32: bad arguments");
+  hipLaunchKernelGGL(zero_f32_kernel, g1(n), dim3(256), 0, (hipStream_t)stream, p, n);
+  GANK_LAUNCH_OK("zero_f32");
+  return 0;
+}

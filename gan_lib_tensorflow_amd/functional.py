@@ -304,7 +304,7 @@ class _ConvGeneral(Function):
                    and tuple(out_hw) == (2 * x.shape[1], 2 * x.shape[2]))
         if ctx.few:
             # <= 4 output channels behind the upsample: a 1x1 conv at low resolution to the k*k*Cout tap partials + a tap gather
-            wz = torch.nn.functional.pad(W.detach().permute(2, 0, 1, 3).reshape(cin, k * k * cout), (0, 64 - k * k * cout)).contiguous()
+            wz = K.fewout_pack(W.detach().view(k, k, cin, cout), 64)          # [Cin, 64]: column t * Cout + co, zeros behind
             wf, wd = K.prep_weights(wz.view(1, 1, cin, 64), True, True)
             Z = K.conv2d_fprop(x, wf, None, (x.shape[1], x.shape[2]), 64, 1, K.IN_RELU if in_relu else 0)
             y = K.tap_gather_up2(Z, bias.detach() if bias is not None else None, k, pad, cout, out_tanh)
@@ -336,9 +336,9 @@ class _ConvGeneral(Function):
             col = K.tap_scatter_up2(g, k, pad, 64)                  # gradient of the tap partials Z
             if ctx.needs_input_grad[1]:
                 tgt, acc = _target(W)
-                tmp = torch.zeros((1, 1, cin, 64), dtype=torch.float32, device=x.device)
+                tmp = K.zeros_f32((1, 1, cin, 64), x.device)
                 K.conv2d_wgrad(x, col, tmp, (h, w), 1, K.IN_RELU if in_relu else 0, 1.0)
-                tgt.view(k * k, cin, cout).add_(tmp.view(cin, 64)[:, :k * k * cout].reshape(cin, k * k, cout).permute(1, 0, 2))
+                K.fewout_pack_bwd(tmp.view(cin, 64), tgt.view(k, k, cin, cout))
                 dW = None if acc else tgt
             if btgt is not None:
                 K.colsum(g, btgt, 1.0)
@@ -376,18 +376,6 @@ class _ConvGeneral(Function):
 # NN-upsample + 4x4 SAME conv (Pix2Pix decoders) by output phase: output row 2i + a reads the low-resolution rows
 #   a = 0: i-1 (ky 0), i (ky 1 + ky 2), i+1 (ky 3);     a = 1: i (ky 0 + ky 1), i+1 (ky 2 + ky 3)
 # so all four phases are 3x3 convs of the low-resolution input whose filters are sums of the 4x4 filter's taps.
-_PHASE4 = torch.tensor([[[1., 0, 0, 0], [0, 1, 1, 0], [0, 0, 0, 1]], [[0., 0, 0, 0], [1, 1, 0, 0], [0, 0, 1, 1]]])      # [a][u][ky]
-_phase4_dev = {}
-
-
-def _phase4(device):
-    """the phase matrix on `device`, copied there ONCE (a host-to-device copy inside a captured graph would replay garbage)"""
-    key = str(device)
-    if key not in _phase4_dev:
-        assert not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()), "first use of the phase-stacked conv inside a graph capture"
-        _phase4_dev[key] = _PHASE4.to(device)
-    return _phase4_dev[key]
-
 PHASE_STACK_MIN_PIXELS = 16384    # low-resolution pixels; below, the stacked filter (9/4 of the 4x4 one, rebuilt and folded back every pass) costs more than the taps it saves
 PHASE_STACK_UPCONV4 = True    # ... run as ONE 3x3 conv to 4 Cout channels (phase-major) + depth_to_space: 36 instead of 64 taps per 2x2 outputs, on the patch / two-group kernels
 
@@ -399,17 +387,13 @@ class _PhaseStack4(Function):
     @staticmethod
     def forward(ctx, W):
         ctx.W = W
-        A = _phase4(W.device)
-        cin, cout = W.shape[2], W.shape[3]
-        return torch.einsum('auk,bvl,klio->uviabo', A, A, W.detach()).reshape(3, 3, cin, 4 * cout).contiguous()
+        return K.phase_stack4(W.detach().contiguous())
 
     @staticmethod
     def backward(ctx, g3):
         W = ctx.W
-        A = _phase4(W.device)
-        cin, cout = W.shape[2], W.shape[3]
         tgt, acc = _target(W)
-        tgt.add_(torch.einsum('auk,bvl,uviabo->klio', A, A, g3.reshape(3, 3, cin, 2, 2, cout)))
+        K.phase_stack4_bwd(_c(g3), tgt.view(W.shape))
         return None if acc else tgt
 
 
@@ -419,12 +403,12 @@ class _Tile4(Function):
     @staticmethod
     def forward(ctx, b):
         ctx.b = b
-        return b.detach().repeat(4)
+        return K.tile_rows(b.detach(), 4)
 
     @staticmethod
     def backward(ctx, g):
         tgt, acc = _target(ctx.b)
-        tgt.add_(g.view(4, -1).sum(0))
+        K.tile_rows_bwd(_c(g), tgt.view(-1), 4)
         return None if acc else tgt
 
 
@@ -457,7 +441,7 @@ class _PadChannels(Function):
     @staticmethod
     def forward(ctx, x, cp):
         ctx.c = x.shape[3]
-        return K.concat_channels(_c(x), torch.zeros(tuple(x.shape[:3]) + (cp - x.shape[3],), dtype=x.dtype, device=x.device))
+        return K.pad_rows(_c(x), cp)
 
     @staticmethod
     def backward(ctx, g):
@@ -471,13 +455,15 @@ class _PadCin(Function):
     @staticmethod
     def forward(ctx, W, cp):
         ctx.W = W
-        return torch.nn.functional.pad(W.detach(), (0, 0, 0, cp - W.shape[2]))
+        k, cin, cout = W.shape[0], W.shape[2], W.shape[3]
+        return K.pad_rows(W.detach().contiguous().view(k * k, cin * cout), cp * cout).view(k, k, cp, cout)
 
     @staticmethod
     def backward(ctx, g):
         W = ctx.W
         tgt, acc = _target(W)
-        tgt.add_(g[:, :, :W.shape[2], :])
+        k, cin, cout = W.shape[0], W.shape[2], W.shape[3]
+        K.pad_rows_bwd(_c(g).view(k * k, g.shape[2] * cout), tgt.view(k * k, cin * cout))
         return (None if acc else tgt), None
 
 

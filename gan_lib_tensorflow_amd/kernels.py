@@ -279,6 +279,68 @@ def tap_scatter_up2(g, ksize, pad, zc):
     return col
 
 
+def zeros_f32(shape, device):
+    """fp32 zeros by a kernel of the library (scratch gradients)"""
+    t = torch.empty(shape, dtype=F32, device=device)
+    _lib.check(lib().gank_zero_f32(_p(t), t.numel(), _stream()), "zero_f32")
+    return t
+
+
+def phase_stack4(w4):
+    """[4,4,Cin,Cout] fp32 -> the stacked 3x3 filter [3,3,Cin,4*Cout] (gank_phase_stack4)"""
+    cin, cout = w4.shape[2], w4.shape[3]
+    w3 = torch.empty((3, 3, cin, 4 * cout), dtype=F32, device=w4.device)
+    _lib.check(lib().gank_phase_stack4(_p(w4, F32, "w4"), _p(w3), cin, cout, 0, _stream()), "phase_stack4")
+    return w3
+
+
+def phase_stack4_bwd(g3, dw4):
+    """dw4 [4,4,Cin,Cout] += adjoint of phase_stack4 applied to g3 [3,3,Cin,4*Cout]"""
+    cin, cout = dw4.shape[2], dw4.shape[3]
+    _lib.check(lib().gank_phase_stack4(_p(dw4, F32, "dw4"), _p(g3, F32, "g3"), cin, cout, 1, _stream()), "phase_stack4_bwd")
+    return dw4
+
+
+def pad_rows(src, w_out):
+    """[..., w_in] -> [..., w_out] with zeros behind (fp32 or the 16-bit activation dtype)"""
+    w_in = src.shape[-1]
+    dst = torch.empty(tuple(src.shape[:-1]) + (w_out,), dtype=src.dtype, device=src.device)
+    _lib.check(lib().gank_pad_rows(_p(src), _p(dst), src.numel() // w_in, w_in, w_out, src.element_size(), 0, _stream()), "pad_rows")
+    return dst
+
+
+def pad_rows_bwd(g, dst):
+    """dst [..., w_in] (+)= g [..., w_out][..., :w_in]  (fp32 accumulates, 16-bit overwrites)"""
+    w_in, w_out = dst.shape[-1], g.shape[-1]
+    _lib.check(lib().gank_pad_rows(_p(g), _p(dst), dst.numel() // w_in, w_in, w_out, g.element_size(), 1, _stream()), "pad_rows_bwd")
+    return dst
+
+
+def tile_rows(b, reps):
+    out = torch.empty(reps * b.numel(), dtype=F32, device=b.device)
+    _lib.check(lib().gank_tile_rows(_p(b, F32, "b"), _p(out), reps, b.numel(), 0, _stream()), "tile_rows")
+    return out
+
+
+def tile_rows_bwd(g, db, reps):
+    _lib.check(lib().gank_tile_rows(_p(g, F32, "g"), _p(db, F32, "db"), reps, db.numel(), 1, _stream()), "tile_rows_bwd")
+    return db
+
+
+def fewout_pack(w, zc):
+    """[k,k,Cin,Cout<=4] -> [Cin, zc] with column t*Cout + co"""
+    k, cin, cout = w.shape[0], w.shape[2], w.shape[3]
+    wz = torch.empty((cin, zc), dtype=F32, device=w.device)
+    _lib.check(lib().gank_fewout_pack(_p(w, F32, "w"), _p(wz), k, cin, cout, zc, 0, _stream()), "fewout_pack")
+    return wz
+
+
+def fewout_pack_bwd(gz, dw):
+    k, cin, cout = dw.shape[0], dw.shape[2], dw.shape[3]
+    _lib.check(lib().gank_fewout_pack(_p(gz, F32, "gz"), _p(dw, F32, "dw"), k, cin, cout, gz.shape[1], 1, _stream()), "fewout_pack_bwd")
+    return dw
+
+
 def depth_to_space2(x):
     """[N,h,w,4C] -> [N,2h,2w,C], channel order (a, b, c)"""
     n, h, w, c4 = x.shape

@@ -618,6 +618,22 @@ double gank_prof_calibrate(int n, void* stream);
 /* debug: what ds_read_b64_tr_b16 delivers for a known LDS image (layout self-check) */
 int gank_debug_tr_probe(int32_t* out, void* stream);
 
+/* ---- weight-side transforms of the Pix2Pix / PGGAN routes (fp32; no framework arithmetic on the product path) ----
+ * gank_phase_stack4: the stacked 3x3 filter [3,3,Cin,4*Cout] (output channels (a, b, co)) of "NN-upsample + 4x4 SAME conv"
+ *   (Pix2Pix/networks.py:420-445 decoders) from the 4x4 filter [4,4,Cin,Cout]; adjoint != 0: the 4x4 filter's gradient
+ *   ACCUMULATED from the stacked filter's (w4 is then written, w3 read).
+ * gank_pad_rows: `rows` rows of w_in elements -> rows of w_out elements with zeros behind (2- or 4-byte elements); adjoint:
+ *   the first w_in elements of every wide row back (fp32 accumulates, 16-bit overwrites) -- zero channels behind a filter's Cin
+ *   or an activation's C (PGGAN's 513-channel conv, model_nvidia.py:128-129).
+ * gank_tile_rows: b [n] -> [reps][n]; adjoint: b[c] += sum_j g[j][c].
+ * gank_fewout_pack: filter [k,k,Cin,Cout<=4] -> [Cin][Zc] with column t*Cout+co (zeros behind); adjoint: accumulated back. */
+int gank_phase_stack4(const float* w4, float* w3, int Cin, int Cout, int adjoint, void* stream);
+int gank_pad_rows(const void* src, void* dst, long rows, int w_in, int w_out, int elem_bytes, int adjoint, void* stream);
+int gank_tile_rows(const float* src, float* dst, int reps, int n, int adjoint, void* stream);
+int gank_fewout_pack(const float* src, float* dst, int ksize, int Cin, int Cout, int Zc, int adjoint, void* stream);
+/* fp32 zero fill (scratch gradients of the routes above) */
+int gank_zero_f32(float* p, long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

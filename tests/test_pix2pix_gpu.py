@@ -367,6 +367,53 @@ def test_pix2pix_batch16_generator_pass_is_the_mean_of_its_sub_batches(gpu):
     tr.g_flat['grads'].zero_()
 
 
+def test_weight_side_transform_kernels_vs_torch(gpu):
+    """gank_phase_stack4 (+ adjoint), gank_pad_rows (+ adjoint, fp32 and 16-bit), gank_tile_rows (+ adjoint), gank_fewout_pack
+    (+ adjoint), gank_zero_f32: the library kernels that replaced torch.einsum / pad / repeat / add_ on the Pix2Pix / PGGAN routes,
+    against those torch expressions (the checker here; sums of <= 4 fp32 values, exact or to 1 ulp)."""
+    from gan_lib_tensorflow_amd import kernels as K
+    g = torch.Generator(device="cuda").manual_seed(5)
+    A = torch.tensor([[[1., 0, 0, 0], [0, 1, 1, 0], [0, 0, 0, 1]], [[0., 0, 0, 0], [1, 1, 0, 0], [0, 0, 1, 1]]], device="cuda")      # [a][u][ky]
+    for cin, cout in ((64, 32), (128, 96)):
+        w4 = torch.randn((4, 4, cin, cout), generator=g, device="cuda")
+        w3 = K.phase_stack4(w4)
+        ref = torch.einsum('auk,bvl,klio->uviabo', A, A, w4).reshape(3, 3, cin, 4 * cout)
+        assert float((w3 - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+        g3 = torch.randn((3, 3, cin, 4 * cout), generator=g, device="cuda")
+        base = torch.randn((4, 4, cin, cout), generator=g, device="cuda")
+        dw = K.phase_stack4_bwd(g3, base.clone())
+        refb = base + torch.einsum('auk,bvl,uviabo->klio', A, A, g3.reshape(3, 3, cin, 2, 2, cout))
+        assert float((dw - refb).abs().max()) <= 2e-6 * float(refb.abs().max())
+        # adjointness: <stack(w), g> == <w, fold(g)>
+        lhs, rhs = float((w3.double() * g3.double()).sum()), float((w4.double() * (dw - base).double()).sum())
+        assert abs(lhs - rhs) < 1e-4 * (abs(lhs) + 1)
+    w = torch.randn((3, 3, 513, 64), generator=g, device="cuda")
+    wp = K.pad_rows(w.view(9, 513 * 64), 576 * 64).view(3, 3, 576, 64)
+    assert torch.equal(wp, torch.nn.functional.pad(w, (0, 0, 0, 63)))
+    gw = torch.randn((3, 3, 576, 64), generator=g, device="cuda")
+    acc = torch.ones((3, 3, 513, 64), device="cuda")
+    K.pad_rows_bwd(gw.view(9, 576 * 64), acc.view(9, 513 * 64))
+    assert torch.equal(acc, 1 + gw[:, :, :513, :])
+    x = torch.randn((3, 5, 7, 513), generator=g, device="cuda").to(torch.bfloat16)
+    xp = K.pad_rows(x, 576)
+    assert torch.equal(xp[..., :513], x) and float(xp[..., 513:].float().abs().max()) == 0.0
+    b = torch.randn(96, generator=g, device="cuda")
+    assert torch.equal(K.tile_rows(b, 4), b.repeat(4))
+    gb = torch.randn(4 * 96, generator=g, device="cuda")
+    db = torch.ones(96, device="cuda")
+    K.tile_rows_bwd(gb, db, 4)
+    assert float((db - (1 + gb.view(4, 96).sum(0))).abs().max()) < 1e-5
+    wf = torch.randn((4, 4, 128, 3), generator=g, device="cuda")
+    wz = K.fewout_pack(wf, 64)
+    assert torch.equal(wz, torch.nn.functional.pad(wf.permute(2, 0, 1, 3).reshape(128, 48), (0, 16)))
+    gz = torch.randn((128, 64), generator=g, device="cuda")
+    dwf = torch.ones((4, 4, 128, 3), device="cuda")
+    K.fewout_pack_bwd(gz, dwf)
+    assert torch.equal(dwf, 1 + gz[:, :48].reshape(128, 16, 3).permute(1, 0, 2).reshape(4, 4, 128, 3))
+    z = K.zeros_f32((3, 1000), "cuda")
+    assert float(z.abs().max()) == 0.0 and z.shape == (3, 1000)
+
+
 def test_one_element_per_thread_kernels_cover_tensors_beyond_the_grid_cap(gpu):
     """gank_depth_to_space2 / _space_to_depth2, gank_im2col_narrow and the tap gather / scatter pair take one 16-byte piece (or pixel)
     per thread; launched on the capped grid of the grid-stride kernels (4096 blocks) they left everything behind the first 8.4 M
