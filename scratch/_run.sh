@@ -1,2 +1,2 @@
-python scratch/travel_dist.py hip profiles/r04_travel_cpu_summaries.json gpurun_out/r04_travel_ratio_distribution.txt > gpurun_out/r04_travel_log.txt 2>&1; tail -8 gpurun_out/r04_travel_ratio_distribution.txt
-python scratch/other_configs_bench.py > gpurun_out/r04_other_configs.txt 2>&1; cat gpurun_out/r04_other_configs.txt
+python -m pytest tests/test_model_gpu.py -m gpu -x -q > gpurun_out/r04_t28.log 2>&1; tail -3 gpurun_out/r04_t28.log
+bash scratch/ab_base.sh 2 100
