@@ -4,7 +4,9 @@ iters = float(sys.argv[2])
 rows = list(csv.DictReader(open(f)))
 cat = collections.defaultdict(float); cnt = collections.defaultdict(int)
 def classify(n):
-    for key, name in (("conv_igemm", "igemm"), ("conv_wgrad", "wgrad"), ("cbn_", "cbn"), ("sn_", "sn"), ("prep_", "prep"), ("copyBuffer", "copy"),
+    for key, name in (("conv_igemm", "igemm"), ("conv3x3_few", "igemm"), ("conv_narrow_in", "igemm"), ("img16_conv3x3", "resident"), ("res8_", "resident"),
+                      ("cpool_res", "resident"), ("conv_wgrad", "wgrad"), ("wgrad_reduce_slabs", "wgrad slab reduce / fold"), ("wgrad_cpool_fold", "wgrad slab reduce / fold"),
+                      ("cbn_", "cbn"), ("sn_", "sn"), ("prep_", "prep"), ("copyBuffer", "copy"),
                       ("at::native", "torch-native"), ("adam", "adam"), ("pool2x2", "pool"), ("ew_kernel", "elementwise"), ("colsum", "colsum"),
                       ("rng_", "rng"), ("concat", "concat"), ("relu_meanpool", "gap"), ("fillBuffer", "memset")):
         if key in n: return name

@@ -11,13 +11,13 @@ python3 - "$out" <<'PY'
 import csv, glob, sys, json, collections, re
 def sym(n):      # rocprofv3 prints "void name<...>(ArgTypes)": keep name<...> as libgank's launchers record it
     n = re.sub(r"^void ", "", n).replace("(anonymous namespace)::", "")
-    n = re.sub(r"\((\(anonymous namespace\)::)?(IgemmArgs|WgradArgs|ResFwdArgs|ResBwdArgs|CpFwdArgs|CpBwdArgs|G8Args)\)$", "", n)
+    n = re.sub(r"\((\(anonymous namespace\)::)?(IgemmArgs|WgradArgs|ResFwdArgs|ResBwdArgs|CpFwdArgs|CpBwdArgs|G8Args|I16Args|NarrowWgArgs, NarrowWgArgs, int)\)$", "", n)
     return re.sub(r"\(.*\)$", "", n)            # plain kernels: drop the argument list
 per = collections.defaultdict(lambda: {"FETCH_SIZE": [], "WRITE_SIZE": []})
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f'/tmp/pmc_b_{c}/**/*counter_collection.csv', recursive=True)[0]
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == c and any(t in r["Kernel_Name"] for t in ("conv_", "res8_", "cpool_res", "wgrad_")) and "prep" not in r["Kernel_Name"]:
+        if r["Counter_Name"] == c and any(t in r["Kernel_Name"] for t in ("conv_", "conv3x3", "res8_", "cpool_res", "wgrad_")) and "prep" not in r["Kernel_Name"]:
             per[sym(r['Kernel_Name'])][c].append(float(r['Counter_Value']))
 res = {"per_kernel": {}}
 for k, d in per.items():
