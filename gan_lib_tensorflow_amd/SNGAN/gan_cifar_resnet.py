@@ -246,6 +246,7 @@ def _capture(graph):
     destroy an older trainer's CUDAGraph / return its pool memory while the stream is capturing, which aborts the
     process (torch only collects once, on entry)."""
     was = gc.isenabled()
+    parallel.drain_collective_watchdog()
     with torch.cuda.graph(graph, capture_error_mode="thread_local"):
         gc.disable()
         try:
@@ -628,6 +629,7 @@ class SNGANTrainer:
                 for ph in phases:               # one graph per phase, one memory pool: later phases read what earlier ones made
                     g = torch.cuda.CUDAGraph()
                     was = gc.isenabled()
+                    parallel.drain_collective_watchdog()
                     with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                         gc.disable()
                         try:

@@ -1263,34 +1263,43 @@ struct I16Args {
 }  // namespace
 
 // TW = pixel tiles per wave: 4 -> 8 waves = (4 channel tiles) x (upper / lower half of the image); 8 -> 4 waves, one per SIMD, each
-// weight fragment feeding 8 MFMAs (half the weight requests, no second wave contending for the SIMD's matrix pipe)
-template <int PF, int TW>
-__global__ __launch_bounds__(2048 / TW) void img16_conv3x3_kernel(I16Args a) {
-  constexpr int NT = 2048 / TW;
-  extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][I16_IMG]
+// weight fragment feeding 8 MFMAs (half the weight requests, no second wave contending for the SIMD's matrix pipe).
+// HALF: a workgroup owns 8 of the 16 image rows (10 halo rows resident) -- for launches whose whole-image grid leaves CUs idle
+// (the critic's 128 -> 128 layer at n = 128 is 128 workgroups on 256 CUs).  Its 8 waves are (4 channel tiles) x (2 halves of
+// the reduction: K-steps 0,1 / 2,3 of every tap), 4 pixel tiles each, so every weight fragment is still requested once per
+// workgroup and feeds 4 MFMAs; the two partial sums of a tile meet through LDS after the last chunk and each wave of a pair
+// finishes two of the four tiles.
+template <int PF, int TW, bool HALF = false>
+__global__ __launch_bounds__(HALF ? 512 : 2048 / TW) void img16_conv3x3_kernel(I16Args a) {
+  static_assert(!HALF || TW == 4, "half-image form: 4 pixel tiles per wave");
+  constexpr int NT = HALF ? 512 : 2048 / TW;
+  constexpr int HROWS = HALF ? 10 : 18, IMG = HROWS * I16_RP;            // resident halo rows, bytes per chunk image
+  constexpr int STEPS = HALF ? 18 : 36, KPT = HALF ? 2 : 4;              // K-steps of a chunk this wave executes; per tap
+  extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][IMG] (HALF: at least the 64-KB exchange area)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ct = wave & 3, pg = TW == 8 ? 0 : wave >> 2;
+  const int ct = wave & 3, pg = (HALF || TW == 8) ? 0 : wave >> 2, kh = HALF ? wave >> 2 : 0;
   const int r = lane & 31, h = lane >> 5;
   const int cgroups = a.Cout >> 7;
-  const int cg = blockIdx.x % cgroups, n = blockIdx.x / cgroups;
+  const int bid = HALF ? blockIdx.x >> 1 : blockIdx.x, row0 = HALF ? (blockIdx.x & 1) * 8 : 0;
+  const int cg = bid % cgroups, n = bid / cgroups;
   const int nchunks = a.Cin >> 6, kq = a.Cin >> 4;                      // 64-channel chunks; 16-channel K-steps per tap
   const int trow = r >> 4, tcol = r & 15;
-  const int b_base = (pg * 2 * TW + trow) * I16_RP + tcol * I16_PP + h * 16; // tile t adds 2 t rows; tap (ty, tx) adds ty rows, tx pixels
+  const int b_base = (pg * 2 * TW + trow) * I16_RP + tcol * I16_PP + h * 16 + kh * 64; // tile t adds 2 t rows; tap (ty, tx) adds ty rows, tx pixels
 
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w), 0, a.Cout * 9 * a.Cin * 2, 0x00020000);
   const int tile = cg * 4 + ct;
-  // fragment stream of this wave: chunk-major, then tap, then the chunk's 4 K-steps: step (c, 4 tap + kk) sits at
-  // wbase + 4096 c + toff[tap] + 1024 kk.  toff[] is scalar state computed once (a division per step cost 18 scalar
-  // instructions per MFMA group: SQ_INSTS_SALU was 4.6 x SQ_INSTS_MFMA)
-  const int wbase = tile * 9 * kq * 1024;
+  // fragment stream of this wave: chunk-major, then tap, then the chunk's K-steps of that tap (4, or this wave's 2): step s of
+  // chunk c sits at wbase + 4096 c + toff[s / KPT] + 1024 (s % KPT).  toff[] is scalar state computed once (a division per step
+  // cost 18 scalar instructions per MFMA group: SQ_INSTS_SALU was 4.6 x SQ_INSTS_MFMA)
+  const int wbase = tile * 9 * kq * 1024 + kh * 2048;
   int toff[9];
 #pragma unroll
   for (int t = 0; t < 9; t++) toff[t] = t * kq * 1024;
-  static_assert(PF <= 36, "the ring spans at most one chunk");
+  static_assert(PF <= STEPS, "the ring spans at most one chunk");
   u32x4 ring[PF];
 #pragma unroll
-  for (int s = 0; s < PF; s++) ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, wbase + toff[s >> 2] + (s & 3) * 1024, 0);
+  for (int s = 0; s < PF; s++) ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, wbase + toff[s / KPT] + (s % KPT) * 1024, 0);
 
   f32x16 acc[TW];
 #pragma unroll
@@ -1298,8 +1307,8 @@ __global__ __launch_bounds__(2048 / TW) void img16_conv3x3_kernel(I16Args a) {
 #pragma unroll
     for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
 
-  // staging: 18 x 18 halo pixels x 8 sixteen-byte pieces of the chunk
-  constexpr int NPIECE = 18 * 18 * 8, NLD = (NPIECE + NT - 1) / NT;
+  // staging: HROWS x 18 halo pixels x 8 sixteen-byte pieces of the chunk
+  constexpr int NPIECE = HROWS * 18 * 8, NLD = (NPIECE + NT - 1) / NT;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, a.N * 256 * a.Cin * 2, 0x00020000);
   constexpr int OOB = 0x7FFFFFF0;
   int p_off[NLD], p_lds[NLD];
@@ -1309,8 +1318,8 @@ __global__ __launch_bounds__(2048 / TW) void img16_conv3x3_kernel(I16Args a) {
     const bool on = q < NPIECE;
     const int hp = q >> 3, c16 = q & 7;
     const int hr = hp / 18, hc = hp - hr * 18;
-    const bool ok = on && (unsigned)(hr - 1) < 16u && (unsigned)(hc - 1) < 16u;
-    p_off[j] = ok ? (((n * 16 + hr - 1) * 16 + hc - 1) * a.Cin + c16 * 8) * 2 : OOB;
+    const bool ok = on && (unsigned)(row0 + hr - 1) < 16u && (unsigned)(hc - 1) < 16u;
+    p_off[j] = ok ? (((n * 16 + row0 + hr - 1) * 16 + hc - 1) * a.Cin + c16 * 8) * 2 : OOB;
     p_lds[j] = on ? hr * I16_RP + hc * I16_PP + c16 * 16 : -1;
   }
   u32x4 rP[NLD];
@@ -1324,7 +1333,7 @@ __global__ __launch_bounds__(2048 / TW) void img16_conv3x3_kernel(I16Args a) {
       if (p_lds[j] >= 0) {
         u32x4 v = rP[j];
         if (a.relu) v = relu_bf16x8(v);
-        *reinterpret_cast<u32x4*>(smem + buf * I16_IMG + p_lds[j]) = v;
+        *reinterpret_cast<u32x4*>(smem + buf * IMG + p_lds[j]) = v;
       }
   };
   load_chunk(0);
@@ -1333,15 +1342,15 @@ __global__ __launch_bounds__(2048 / TW) void img16_conv3x3_kernel(I16Args a) {
 
 #pragma unroll 1
   for (int c = 0; c < nchunks; c++) {
-    const char* img = smem + (c & 1) * I16_IMG;
+    const char* img = smem + (c & 1) * IMG;
     const bool more = c + 1 < nchunks;
     const int cbase = wbase + c * 4096;
-    if (more) load_chunk(c + 1);                                       // in flight during this chunk's 36 steps
-    static_assert(36 % PF == 0, "ring position is chunk-invariant");
+    if (more) load_chunk(c + 1);                                       // in flight during this chunk's steps
+    static_assert(STEPS % PF == 0, "ring position is chunk-invariant");
     constexpr int PB = 2;                                               // pixel fragments are read PB steps ahead of their MFMAs
     bf16x8 bq[PB + 1][TW];
     auto read_b = [&](int s, bf16x8 (&dst)[TW]) {
-      const int tap = s >> 2, kk = s & 3, ty = tap / 3, tx = tap - 3 * ty;
+      const int tap = s / KPT, kk = s % KPT, ty = tap / 3, tx = tap - 3 * ty;
 #pragma unroll
       for (int t = 0; t < TW; t++)
         dst[t] = *reinterpret_cast<const bf16x8*>(img + b_base + (2 * t + ty) * I16_RP + tx * I16_PP + kk * 32);
@@ -1349,8 +1358,8 @@ __global__ __launch_bounds__(2048 / TW) void img16_conv3x3_kernel(I16Args a) {
 #pragma unroll
     for (int s = 0; s < PB; s++) read_b(s, bq[s]);
 #pragma unroll
-    for (int s = 0; s < 36; s++) {
-      if (s + PB < 36) read_b(s + PB, bq[(s + PB) % (PB + 1)]);
+    for (int s = 0; s < STEPS; s++) {
+      if (s + PB < STEPS) read_b(s + PB, bq[(s + PB) % (PB + 1)]);
       const bf16x8 fa = __builtin_bit_cast(bf16x8, ring[s % PF]);
       __builtin_amdgcn_sched_barrier(0);                                // see res_conv3x3: keeps reads early and the ring deep
 #pragma unroll
@@ -1358,8 +1367,8 @@ __global__ __launch_bounds__(2048 / TW) void img16_conv3x3_kernel(I16Args a) {
       __builtin_amdgcn_sched_barrier(0);
       {
         const int nx = s + PF;                                          // compile-time after unrolling
-        if (nx < 36) ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, cbase + toff[nx >> 2] + (nx & 3) * 1024, 0);
-        else if (more) ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, cbase + 4096 + toff[(nx - 36) >> 2] + ((nx - 36) & 3) * 1024, 0);
+        if (nx < STEPS) ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, cbase + toff[nx / KPT] + (nx % KPT) * 1024, 0);
+        else if (more) ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, cbase + 4096 + toff[(nx - STEPS) / KPT] + ((nx - STEPS) % KPT) * 1024, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1367,6 +1376,32 @@ __global__ __launch_bounds__(2048 / TW) void img16_conv3x3_kernel(I16Args a) {
       store_chunk((c + 1) & 1);          // that image was last read in chunk c - 1: every wave is past it (the barrier below, one chunk ago)
       __syncthreads();
     }
+  }
+
+  if constexpr (HALF) {
+    // the two halves of the reduction meet: wave (ct, kh) hands the partial sums of the tiles its partner finishes (2 (1 - kh), +1)
+    // to LDS [wave][2 tiles][16][64 lanes] and adds the partner's partial sums of its own tiles (2 kh, +1).  Register arrays are
+    // indexed with constants under the wave-uniform branch (a run-time index would move acc[] to scratch)
+    __syncthreads();                                 // every wave is done reading the images
+    float* xch = reinterpret_cast<float*>(smem);
+    auto send = [&](auto T0) {
+      constexpr int t0 = decltype(T0)::value;
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) xch[((wave * 2 + j) * 16 + e) * 64 + lane] = acc[t0 + j][e];
+    };
+    auto recv = [&](auto T0) {
+      constexpr int t0 = decltype(T0)::value;
+      const int partner = wave ^ 4;
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[t0 + j][e] += xch[((partner * 2 + j) * 16 + e) * 64 + lane];
+    };
+    if (kh == 0) send(std::integral_constant<int, 2>{}); else send(std::integral_constant<int, 0>{});
+    __syncthreads();
+    if (kh == 0) recv(std::integral_constant<int, 0>{}); else recv(std::integral_constant<int, 2>{});
   }
 
   // epilogue: after acc_widen the lane holds channels 16q + 8h .. +7 of one pixel: 16-byte pieces.  Statistics (optional): the
@@ -1379,7 +1414,8 @@ __global__ __launch_bounds__(2048 / TW) void img16_conv3x3_kernel(I16Args a) {
     for (int e = 0; e < 8; e++) { s1[q][e] = 0.f; s2[q][e] = 0.f; }
 #pragma unroll
   for (int t = 0; t < TW; t++) {
-    const int py = pg * 2 * TW + 2 * t + trow;
+    if (HALF && (t >> 1) != kh) continue;            // wave-uniform: this wave finishes tiles 2 kh, 2 kh + 1
+    const int py = row0 + pg * 2 * TW + 2 * t + trow;
     const long m = (long)n * 256 + py * 16 + tcol;
     const long mr = a.res_up ? (long)n * 64 + (py >> 1) * 8 + (tcol >> 1) : m;
 #pragma unroll
@@ -1463,6 +1499,28 @@ extern "C" int gank_img16_conv3x3_stats(const void* x, const void* w_rfrag, cons
   const double M = (double)N * 256;
   gank_prof_begin(0, 2.0 * M * Cout * 9.0 * Cin, s, 2.0 * (M * Cin + 9.0 * Cin * Cout + M * Cout * (1 + (relu_ref ? 1 : 0) + (residual ? 1 : 0))));
   static const int cfg_env = gank_tune("GANK_IMG16_CFG", 412);   // experiment knob: 100 * (pixel tiles per wave) + weight fragments in flight
+  static const int half_env = gank_tune("GANK_IMG16_HALF", 1);   // experiment knob: 0 = whole images only, 1 = half images when the whole-image grid leaves CUs idle, 2 = always
+  if (half_env == 2 || (half_env == 1 && N * (Cout / 128) < 256)) {
+    constexpr int HALF_LDS = 2 * 10 * I16_RP > 65536 ? 2 * 10 * I16_RP : 65536;
+    static const int hpf_env = gank_tune("GANK_IMG16_HALF_PF", 9);
+#define IMG16_LAUNCH_HALF(PF)                                                                             \
+  do {                                                                                                    \
+    gank_prof_tag(0, "img16_conv3x3_kernel<" #PF ", 4, half>");                                         \
+    GANK_MAX_DYNAMIC_LDS((img16_conv3x3_kernel<PF, 4, true>), HALF_LDS, "img16_conv3x3");                 \
+    hipLaunchKernelGGL((img16_conv3x3_kernel<PF, 4, true>), dim3(2 * N * (Cout / 128)), dim3(512), HALF_LDS, s, a); \
+  } while (0)
+    switch (hpf_env) {
+#ifdef GANK_TUNING
+      case 6: IMG16_LAUNCH_HALF(6); break;
+      case 18: IMG16_LAUNCH_HALF(18); break;
+#endif
+      default: IMG16_LAUNCH_HALF(9); break;
+    }
+#undef IMG16_LAUNCH_HALF
+    GANK_LAUNCH_OK("img16_conv3x3");
+    gank_prof_end(0, s);
+    return 0;
+  }
 #define IMG16_LAUNCH(PF, TW)                                                                              \
   do {                                                                                                    \
     gank_prof_tag(0, "img16_conv3x3_kernel<" #PF ", " #TW ">");                                         \

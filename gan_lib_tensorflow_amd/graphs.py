@@ -43,6 +43,8 @@ class GraphRunner:
         try:
             g = torch.cuda.CUDAGraph()
             was = gc.isenabled()
+            from . import parallel
+            parallel.drain_collective_watchdog()   # no eager collective left on the RCCL watchdog's list when a capture starts
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 gc.disable()             # a cyclic-GC pass that frees another graph's pool memory mid-capture aborts the process
                 try:

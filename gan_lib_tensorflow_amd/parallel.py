@@ -88,6 +88,20 @@ def bucket_ranges(flat, groups):
     return ranges
 
 
+def drain_collective_watchdog(seconds=0.25):
+    """Call before a hipGraph capture in a process that owns an RCCL process group.  ProcessGroupNCCL's watchdog thread polls
+    the end event of every EAGER collective (`hipEventQuery`, every 100 ms) until it has completed; those events are recycled
+    from a cache that also served collectives issued under capture, and HIP refuses the query
+    (`hipErrorCapturedEvent`, which terminates the process from the watchdog thread) while the stream such an event was once
+    captured on is capturing again.  Observed once in 30-odd runs of tests/rccl_worker.py, right after an eager first execution
+    was followed by a capture.  After a device synchronise every eager collective has completed, and two watchdog periods
+    later none is left on its list; captures happen a handful of times per run."""
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl" and torch.cuda.is_available():
+        import time
+        torch.cuda.synchronize()
+        time.sleep(seconds)
+
+
 class GradBuckets:
     """The flat gradient buffer of a network cut into contiguous buckets that are all-reduced one by one, each as soon as
     the backward pass has produced its last gradient, on a communication stream of their own: the collective of bucket k

@@ -24,3 +24,11 @@ for n in (128, 320):
     t3 = warm(lambda: K.img16_conv3x3(x, rd, None, 256, 0, relu_ref=x))
     t4 = warm(lambda: K.conv2d_dgrad(x, wd, (16, 16), 256, 3, 0, 1.0, None, x))
     print(f"n={n} 256->256 16x16: fprop resident {t1:6.1f} us ({fl/t1/1e6:5.0f} TF) | igemm {t2:6.1f} us ({fl/t2/1e6:5.0f} TF) || dgrad resident {t3:6.1f} us | igemm {t4:6.1f} us", flush=True)
+# the critic's layer: 128 -> 128 at n = 128 (128 whole-image workgroups; the half-image form fills the chip)
+for n in (64, 128, 256):
+    x = torch.randn(n, 16, 16, 128, device=dev).to(K.BF16)
+    w = torch.randn(3, 3, 128, 128, device=dev) / 34.
+    (rf, rd), = K.prep_weights_batched([w], want_d=True, kinds=[4])
+    t1 = warm(lambda: K.img16_conv3x3(x, rf, None, 128, K.IN_RELU))
+    t3 = warm(lambda: K.img16_conv3x3(x, rd, None, 128, 0, relu_ref=x))
+    print(f"n={n} 128->128 16x16: fprop resident {t1:6.1f} us | dgrad resident {t3:6.1f} us", flush=True)

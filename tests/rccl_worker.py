@@ -58,6 +58,8 @@ try:
         dist.all_reduce(cap.clone())                       # warm-up outside the capture (communicator setup)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
+    from gan_lib_tensorflow_amd import parallel
+    parallel.drain_collective_watchdog()               # the eager warm-up's work items leave the watchdog's list first
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, capture_error_mode="thread_local"):
         dist.all_reduce(cap)
