@@ -42,9 +42,9 @@ def timed(fn, n=5, warm=3):       # warm-up covers the eager first execution and
     return (time.perf_counter() - t0) / n
 
 
-if "acgan" in which:
+if "acgan" in which or "acgan32" in which:
     from gan_lib_tensorflow_amd.ACGAN.train import ACGANTrainer
-    for bs in (32, 256):
+    for bs in ((32,) if "acgan32" in which else (32, 256)):
         feed = synthetic_batches(bs, "cuda", seed=2)
         it = [0]
 
