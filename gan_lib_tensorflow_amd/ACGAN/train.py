@@ -105,7 +105,7 @@ class ACGANTrainer:
             x_fake = m.get_generator(z, fake_labels)
         disc_real, ac_real = m.get_discriminator(real, real_labels, update_collection=None)
         disc_fake, _ = m.get_discriminator(x_fake, fake_labels, update_collection='NO_OPS', reuse=True)
-        d_gan = Fn.hinge_d_loss(torch.cat([disc_real, disc_fake], 0), b)
+        d_gan = Fn.hinge_d_loss(Fn.concat_rows(disc_real, disc_fake), b)
         interp = K.lerp_rows(real, x_fake, alpha).requires_grad_(True)
         d_int, _ = m.get_discriminator(interp, real_labels, 'NO_OPS', reuse=True)
         ones = torch.ones_like(d_int)                       # tf.gradients(D(x_hat), [x_hat]): d(sum of logits)/d(x_hat)

@@ -104,7 +104,7 @@ class PGGANTrainer:
             x_fake = self.model.get_generator(z, alpha, reuse=True)
         disc_real = self.model.get_discriminator(real, alpha, update_collection=None, reuse=True)
         disc_fake = self.model.get_discriminator(x_fake, alpha, update_collection='NO_OPS', reuse=True)
-        return Fn.hinge_d_loss(torch.cat([disc_real, disc_fake], 0), b)
+        return Fn.hinge_d_loss(Fn.concat_rows(disc_real, disc_fake), b)
 
     def g_loss(self, z=None, alpha=None):
         set_default_store(self.store)

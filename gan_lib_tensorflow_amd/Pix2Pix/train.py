@@ -111,7 +111,7 @@ class Pix2PixTrainer:
         predict_real = self._critic(inputs, targets, None)
         predict_fake = self._critic(inputs, outputs, None)
         n = predict_real.numel()
-        return Fn.hinge_d_loss(torch.cat([predict_real.reshape(-1), predict_fake.reshape(-1)], 0), n)
+        return Fn.hinge_d_loss(Fn.concat_rows(predict_real.reshape(-1), predict_fake.reshape(-1)), n)
 
     def g_loss(self, inputs, targets):
         """gen_loss (train.py:504-512); the critic's variables are not differentiated (var_list=gen_tvars, :552).  The

@@ -17,7 +17,7 @@ def get_loss(disc_real, disc_fake, loss_type='HINGE'):
     One launch per loss computes the value and d loss / d logits (the sigmoid family through the stable softplus form)."""
     n_real = disc_real.reshape(-1).shape[0]
     fake = disc_fake.reshape(-1)
-    both = torch.cat([disc_real.reshape(-1), fake], 0)
+    both = Fn.concat_rows(disc_real.reshape(-1), fake)
     if loss_type == 'HINGE':
         return Fn.hinge_d_loss(both, n_real), Fn.hinge_g_loss(fake)
     if loss_type in ('WGAN', 'WGAN-GP'):

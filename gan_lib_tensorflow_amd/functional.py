@@ -1217,6 +1217,28 @@ class _Box:
         self.t = t
 
 
+class _ConcatRows(Function):
+    """tf.concat([a, b], axis=0) of two contiguous tensors: two device copies of the library (captured graphs hold kernel nodes
+    only); backward: the two row ranges of the gradient (views)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        ctx.na = a.shape[0]
+        out = torch.empty((a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
+        K.copy_(out[:ctx.na], a)
+        K.copy_(out[ctx.na:], b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:ctx.na], g[ctx.na:]
+
+
+def concat_rows(a, b):
+    return _ConcatRows.apply(a, b)
+
+
 def hinge_d_loss(logits, n_real, out=None):
     """out: persistent fp32[1] buffer that also receives the loss value (no copy launch for the reported loss)"""
     return _Loss.apply(logits, "hinge_d", n_real, _Box(out) if out is not None else None)
