@@ -127,7 +127,7 @@ class stats_arena:
     current = None
 
     def __init__(self, floats, device):
-        self.buf = torch.zeros(int(floats), dtype=F32, device=device)
+        self.buf = zeros_f32(int(floats), device) if torch.device(device).type == 'cuda' else torch.zeros(int(floats), dtype=F32, device=device)
         self.used = 0
 
     def __enter__(self):
