@@ -172,3 +172,13 @@ def test_bucket_ranges_rejects_bad_groupings():
     with pytest.raises(ValueError, match="belongs to 0"):
         parallel.bucket_ranges(flat, (("A/",),))
     assert parallel.bucket_ranges(flat, (("Net/",),)) == [(0, flat["params"].numel())]
+
+
+def test_watchdog_drain_is_a_noop_without_an_rccl_group():
+    """parallel.drain_collective_watchdog (called before every hipGraph capture): returns at once when there is no process group
+    or the group is not RCCL -- the gloo rehearsals and single-process runs must not pay its sleep"""
+    import time
+    from gan_lib_tensorflow_amd import parallel
+    t0 = time.perf_counter()
+    parallel.drain_collective_watchdog(seconds=5.0)
+    assert time.perf_counter() - t0 < 1.0

@@ -1424,6 +1424,19 @@ def test_spectral_norm_fused_operand_copies_and_label_table_are_bit_identical(K)
         assert float((T.float() - T_ref.float()).abs().max()) <= 2.0 ** -8 * float(T_ref.float().abs().max())
 
 
+def test_concat_rows_is_two_copies_and_its_backward_two_views(K):
+    """functional.concat_rows (tf.concat(axis=0) of the real and fake logits in front of a critic loss): the library's copy
+    kernel twice; the gradient comes back as the two row ranges"""
+    from gan_lib_tensorflow_amd import functional as Fn
+    a = torch.randn(5, 3, device="cuda").to(torch.bfloat16).requires_grad_(True)
+    b = torch.randn(7, 3, device="cuda").to(torch.bfloat16).requires_grad_(True)
+    y = Fn.concat_rows(a, b)
+    assert torch.equal(y.detach(), torch.cat([a.detach(), b.detach()], 0))
+    g = torch.randn(12, 3, device="cuda").to(torch.bfloat16)
+    y.backward(g)
+    assert torch.equal(a.grad, g[:5]) and torch.equal(b.grad, g[5:])
+
+
 def test_concat_label_fwd_bwd(K):
     """The critic's label branch through the per-label table: forward = concat_tile(x, linear(embedding(labels))) bit for
     bit (table built from the normalised weight); backward against float64 (the fp32 per-label sums are more accurate than the per-sample bf16 chain they replace)."""
