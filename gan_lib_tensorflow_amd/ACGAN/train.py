@@ -108,13 +108,13 @@ class ACGANTrainer:
         d_gan = Fn.hinge_d_loss(Fn.concat_rows(disc_real, disc_fake), b)
         interp = K.lerp_rows(real, x_fake, alpha).requires_grad_(True)
         d_int, _ = m.get_discriminator(interp, real_labels, 'NO_OPS', reuse=True)
-        ones = torch.ones_like(d_int)                       # tf.gradients(D(x_hat), [x_hat]): d(sum of logits)/d(x_hat)
+        ones = Fn.constant_like(d_int, 1.0)                 # tf.gradients(D(x_hat), [x_hat]): d(sum of logits)/d(x_hat); a persistent buffer
         with F2.input_gradient_only():       # the filter / bias / table gradients of this pass are not part of the penalty
             (grads,) = torch.autograd.grad([d_int], [interp], [ones], create_graph=True)
         gp = F2.gradient_penalty(grads, 10.0)
         d_ac = Fn.softmax_xent(ac_real, real_labels)
-        self.losses.update(d_loss_gan=d_gan.detach() + gp.detach(), d_loss_acgan=d_ac.detach(), gradient_penalty=gp.detach())
-        return d_gan + gp + d_ac
+        self.losses.update(d_loss_gan=K.weighted_sum_f32([d_gan.detach(), gp.detach()], [1.0, 1.0]), d_loss_acgan=d_ac.detach(), gradient_penalty=gp.detach())
+        return Fn.weighted_sum([d_gan, gp, d_ac])
 
     def g_loss(self, z=None, fake_labels=None):
         set_default_store(self.store)
@@ -131,7 +131,7 @@ class ACGANTrainer:
             disc_fake, ac_fake = m.get_discriminator(x_fake, fake_labels, update_collection='NO_OPS', reuse=True)
             g_gan = Fn.hinge_g_loss(disc_fake)
             g_ac = Fn.softmax_xent(ac_fake, fake_labels)
-            total = g_gan + self.scale_g * g_ac
+            total = Fn.weighted_sum([g_gan, g_ac], [1.0, self.scale_g])
         finally:
             for p in self.d_params:
                 p.requires_grad_(True)
@@ -142,16 +142,16 @@ class ACGANTrainer:
     def _d_fwd_bwd(self):
         with F2.one_update():            # every pass over the critic in this update shares one preparation of its weights
             real = K.preprocess_real(self.real_u8, self.rng_state)         # [B, 32, 32, 3] bf16   (train.py:80-83)
-            self.d_flat['grads'].zero_()
+            K.zero_(self.d_flat['grads'])
             loss = self.d_loss(real, self.real_labels)
-            loss.backward()
+            loss.backward(gradient=Fn.unit_seed(loss))
             self.losses['d_loss'] = loss.detach()
 
     def _g_fwd_bwd(self):
         with F2.one_update():
             self.store.zero_grads('g_net')
             loss = self.g_loss()
-            loss.backward()
+            loss.backward(gradient=Fn.unit_seed(loss))
             self.losses['g_loss'] = loss.detach()
 
     def d_step(self, real_u8, labels):

@@ -48,8 +48,13 @@ def unet_generator(generator_inputs, generator_outputs_channels, ngf, conv_type,
         cin = generator_inputs.shape[-1]
         output = _conv2d.Conv2D(generator_inputs, cin, ngf, 4, 2, 'Conv2D', conv_type=conv_type, padding=padding, he_init=True, biases=True)
         layers.append(output)
+    # Every encoder output but the last feeds the next encoder AND a decoder's skip concat: the fan-out is explicit (Fn.fork: two
+    # aliases forward, ONE add launch of the library backward) so that autograd's own accumulation never runs.  `skips[k]` is the
+    # alias the decoder reads, `layers[k]` the one the next encoder reads.
+    skips = {}
     for out_channels in (ngf * 2, ngf * 4, ngf * 8, ngf * 8, ngf * 8, ngf * 8, ngf * 8, ngf * 8):
         with store.variable_scope("encoder_%d" % (len(layers) + 1)):
+            layers[-1], skips[len(layers) - 1] = Fn.fork(layers[-1])
             rectified = nonlinearity(layers[-1], 'lrelu', 0.2)
             convolved = _conv2d.Conv2D(rectified, rectified.shape[-1], out_channels, 4, 2, 'Conv2D', conv_type=conv_type,
                                        padding=padding, he_init=True, biases=True)
@@ -60,7 +65,7 @@ def unet_generator(generator_inputs, generator_outputs_channels, ngf, conv_type,
         skip_layer = num_encoder_layers - decoder_layer - 1
         with store.variable_scope("decoder_%d" % (skip_layer + 1)):
             # first decoder layer doesn't have skip connections since it is directly connected to the skip_layer
-            inputs = layers[-1] if decoder_layer == 0 else Fn.concat_channels(layers[-1], layers[skip_layer])
+            inputs = layers[-1] if decoder_layer == 0 else Fn.concat_channels(layers[-1], skips[skip_layer])
             # relu, 2x nearest-neighbour upsampling and the 4x4 SAME convolution: one gather (:424-439)
             output = _conv2d.Conv2D(inputs, inputs.shape[-1], out_channels, 4, 1, 'Conv2D', conv_type=conv_type, padding=padding,
                                     he_init=True, biases=True, upsample=True, in_relu=True)
@@ -71,7 +76,7 @@ def unet_generator(generator_inputs, generator_outputs_channels, ngf, conv_type,
                 output = Fn.dropout(output, 1 - dropout, rng_state)
             layers.append(output)
     with store.variable_scope("decoder_1"):
-        inputs = Fn.concat_channels(layers[-1], layers[0])
+        inputs = Fn.concat_channels(layers[-1], skips[0])
         output = _conv2d.Conv2D(inputs, inputs.shape[-1], generator_outputs_channels, 4, 1, 'Conv2D', conv_type=conv_type, padding=padding,
                                 he_init=True, biases=True, upsample=True, in_relu=True, out_tanh=True)
         layers.append(output)

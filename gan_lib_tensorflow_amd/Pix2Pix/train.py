@@ -117,7 +117,7 @@ class Pix2PixTrainer:
         """gen_loss (train.py:504-512); the critic's variables are not differentiated (var_list=gen_tvars, :552).  The
         generator update's graph contains BOTH critic passes with update_collection=None (:452-475), so `u` advances twice."""
         set_default_store(self.store)
-        outputs = self._generator(inputs)
+        outputs, outputs_l1 = Fn.fork(self._generator(inputs))     # read by the critic and by the L1 term: one add launch backward
         for p in self.d_params:
             p.requires_grad_(False)
         try:
@@ -125,18 +125,18 @@ class Pix2PixTrainer:
                 self._critic(inputs, targets, None)            # predict_real: only its u update is observable here
             predict_fake = self._critic(inputs, outputs, None)
             gan = Fn.hinge_g_loss(predict_fake.reshape(-1))
-            l1 = Fn.l1_loss(outputs, targets)
+            l1 = Fn.l1_loss(outputs_l1, targets)
         finally:
             for p in self.d_params:
                 p.requires_grad_(True)
         self.losses.update(gen_loss_GAN=gan.detach(), gen_loss_L1=l1.detach())
-        return gan * self.args.gan_weight + l1 * self.args.l1_weight
+        return Fn.weighted_sum([gan, l1], [self.args.gan_weight, self.args.l1_weight])
 
     # ---- updates --------------------------------------------------------------------------------------------------
     def _backward(self, loss):
         Fn.reset_deferred()
         try:
-            loss.backward()
+            loss.backward(gradient=Fn.unit_seed(loss))
             Fn.join_wgrad()
         finally:
             Fn.reset_deferred()

@@ -130,6 +130,7 @@ PROTOTYPES = {
     "gank_relu_bwd": [P, P, P, L, F, P],
     "gank_tanh_bwd": [P, P, P, L, P],
     "gank_scale_f32": [P, P, P, L, P],
+    "gank_weighted_sum4_f32": [P, P, P, P, F, F, F, F, P, L, P],
     "gank_linear_fwd": [P, P, P, P, I, I, I, P],
     "gank_linear_fwd_f32out": [P, P, P, P, I, I, I, P],
     "gank_linear_bwd": [P, P, P, P, P, P, I, I, I, P],

@@ -163,7 +163,7 @@ def precomputed(store, prefix, update_collection=None, prepare=True, prep_kind=N
             gflat = _grad_scratch[0]
             _grad_scratch[0] = None                      # one use per zeroing
             if gflat is None or gflat.numel() < need:
-                gflat = torch.zeros(need, dtype=torch.float32, device=W_bars[0].device)
+                gflat = K.zeros_f32(need, W_bars[0].device) if W_bars[0].is_cuda else torch.zeros(need, dtype=torch.float32, device=W_bars[0].device)
             o = 0
             for wb in W_bars:
                 wb._grad_buf = gflat[o:o + wb.numel()].view(wb.shape)

@@ -364,6 +364,25 @@ __global__ void scale_f32_kernel(const float* __restrict__ x, const float* __res
   const float k = s[0];
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = x[i] * k;
 }
+// y = wa a + wb b + wc c + wd d over n floats (null terms skipped): the weighted sums of scalar losses in the train steps
+// (ACGAN/train.py:108-121, Pix2Pix/model.py: gen_loss = gan_weight GAN + l1_weight L1) and fp32 accumulations y = y + x
+__global__ void wsum4_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, const float* __restrict__ d,
+                                 float wa, float wb, float wc, float wd, float* __restrict__ y, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float t = wa * a[i];
+    if (b) t += wb * b[i];
+    if (c) t += wc * c[i];
+    if (d) t += wd * d[i];
+    y[i] = t;
+  }
+}
+extern "C" int gank_weighted_sum4_f32(const float* a, const float* b, const float* c, const float* d, float wa, float wb, float wc, float wd,
+                                      float* y, long n, void* stream) {
+  GANK_REQUIRE(a && y && n > 0, "weighted_sum4_f32: bad arguments");
+  hipLaunchKernelGGL(wsum4_f32_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, a, b, c, d, wa, wb, wc, wd, y, n);
+  GANK_LAUNCH_OK("weighted_sum4_f32");
+  return 0;
+}
 extern "C" int gank_scale_f32(const float* x, const float* sc, float* y, long n, void* stream) {
   GANK_REQUIRE(x && sc && y && n > 0, "scale_f32: bad arguments");
   hipLaunchKernelGGL(scale_f32_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, x, sc, y, n);

@@ -105,7 +105,7 @@ def _target(p):
     gb = getattr(p, "_grad_buf", None)
     if gb is not None:
         return gb, False
-    return torch.zeros_like(p), False
+    return (K.zeros_f32(p.shape, p.device) if p.dtype == torch.float32 and p.is_cuda else torch.zeros_like(p)), False
 
 
 def _prepared(W, k, cin, cout, want_f, want_d):
@@ -741,10 +741,13 @@ class _BatchNormStats(Function):
         ctx.save_for_backward(x, y, labels, gamma, beta, stats)
         ctx.cfg = (groups, relu)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)     # the statistics output has no gradient: autograd must not fill a zero tensor for it
         return y, stats
 
     @staticmethod
     def backward(ctx, dy, _dstats):
+        if dy is None:
+            return None, None, None, None, None, None, None
         x, y, labels, gamma, beta, stats = ctx.saved_tensors
         groups, relu = ctx.cfg
         tg, accg = _target(gamma)
@@ -1152,6 +1155,19 @@ def grad_seed(loss, scale=1.0):
     return s
 
 
+_constants = {}
+
+
+def constant_like(t, value):
+    """a persistent tensor of t's shape / dtype / device filled with `value` ONCE (grad_outputs of an autograd.grad call, ...):
+    never written again, so a captured graph may read it"""
+    key = (t.device, tuple(t.shape), t.dtype, float(value))
+    c = _constants.get(key)
+    if c is None:
+        c = _constants[key] = torch.full_like(t, float(value))
+    return c
+
+
 def unit_seed(loss):
     """Persistent all-ones gradient seed (grad_seed with scale 1)."""
     return grad_seed(loss, 1.0)
@@ -1215,6 +1231,34 @@ class _Box:
 
     def __init__(self, t):
         self.t = t
+
+
+class _WeightedSum(Function):
+    """sum_i w_i * term_i of fp32 scalar losses (one launch).  Backward: a unit seed passes through a weight of 1 untouched (the
+    loss nodes recognise it and hand out the gradient their forward launch made); any other weight turns it into the persistent
+    constant seed of that value (grad_seed: no launch either); an upstream gradient that is no seed is scaled on the device."""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        ctx.weights = tuple(float(w) for w in weights)
+        return K.weighted_sum_f32([_c(t) for t in terms], ctx.weights)
+
+    @staticmethod
+    def backward(ctx, g):
+        sc = _seed_scale.get(g.data_ptr())
+        outs = []
+        for w in ctx.weights:
+            if sc is not None:
+                outs.append(g if w == 1.0 else grad_seed(g, sc * w))
+            else:
+                outs.append(K.weighted_sum_f32([_c(g)], [w]))
+        return (None,) + tuple(outs)
+
+
+def weighted_sum(terms, weights=None):
+    """the train steps' sums of loss terms (d_loss = gan + gp + ac; gen_loss = gan_weight * GAN + l1_weight * L1) without framework arithmetic"""
+    weights = [1.0] * len(terms) if weights is None else weights
+    return _WeightedSum.apply(tuple(weights), *terms)
 
 
 class _ConcatRows(Function):

@@ -286,6 +286,12 @@ def zeros_f32(shape, device):
     return t
 
 
+def zero_(t):
+    """t <- 0 in place by a kernel of the library (fp32, contiguous: gradient buffers)"""
+    _lib.check(lib().gank_zero_f32(_p(t, F32, "t"), t.numel(), _stream()), "zero_f32")
+    return t
+
+
 def phase_stack4(w4):
     """[4,4,Cin,Cout] fp32 -> the stacked 3x3 filter [3,3,Cin,4*Cout] (gank_phase_stack4)"""
     cin, cout = w4.shape[2], w4.shape[3]
@@ -369,9 +375,10 @@ def conv2d_general_wgrad(x, dy, dw, ksize, stride, pad, flags=0, dbias=None):
     if IM2COL_NARROW_WGRAD and flags == 0 and cin < 32 and ksize > 1 and ktot <= 128 and cout % 64 == 0 and n * hdy * wdy >= 16384:
         kpad = 64 if ktot <= 64 else 128
         xcol = im2col_narrow(x, (hdy, wdy), ksize, stride, pad, kpad)
-        tmp = torch.zeros((1, 1, kpad, cout), dtype=F32, device=x.device)
+        tmp = zeros_f32((1, 1, kpad, cout), x.device)
         conv2d_wgrad(xcol, dy, tmp, (hdy, wdy), 1, 0, 1.0, dbias=dbias)
-        dw.view(ktot, cout).add_(tmp.view(kpad, cout)[:ktot])
+        dwv = dw.view(ktot, cout)
+        weighted_sum_f32([dwv, tmp.view(kpad, cout)[:ktot]], [1.0, 1.0], out=dwv)     # the rows of the real taps; dw ACCUMULATES
         return dw
     _lib.check(lib().gank_conv2d_general_wgrad(_p(x, BF16, "x"), _p(dy, BF16, "dy"), _p(dw, F32, "dw"), _p(dbias, F32, "dbias"), n, hx, wx, hdy, wdy,
                                                cin, cout, ksize, stride, pad, flags, _stream()), "conv2d_general_wgrad")
@@ -920,6 +927,17 @@ def scale_f32(x, s):
     y = torch.empty_like(x)
     _lib.check(lib().gank_scale_f32(_p(x, F32, "x"), _p(s, F32, "s"), _p(y), x.numel(), _stream()), "scale_f32")
     return y
+
+
+def weighted_sum_f32(terms, weights, out=None):
+    """out = sum_i weights[i] * terms[i] (fp32 tensors of one shape, at most 4; out may be one of them)"""
+    assert 1 <= len(terms) <= 4 and len(terms) == len(weights)
+    out = torch.empty_like(terms[0]) if out is None else out
+    ts = list(terms) + [None] * (4 - len(terms))
+    ws = [float(w) for w in weights] + [0.0] * (4 - len(weights))
+    _lib.check(lib().gank_weighted_sum4_f32(_p(ts[0], F32, "term 0"), _p(ts[1], F32, "term 1"), _p(ts[2], F32, "term 2"), _p(ts[3], F32, "term 3"),
+                                            ws[0], ws[1], ws[2], ws[3], _p(out, F32, "out"), terms[0].numel(), _stream()), "weighted_sum4_f32")
+    return out
 
 
 def to_bf16(x):

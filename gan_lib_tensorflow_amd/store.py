@@ -146,7 +146,12 @@ class ParamStore:
         return self.flat[key]
 
     def zero_grads(self, prefix):
-        self.flat[prefix]["grads_all"].zero_()
+        g = self.flat[prefix]["grads_all"]
+        if g.is_cuda and g.dtype == torch.float32:
+            from . import kernels as K
+            K.zero_(g)                      # a kernel of the library (captured graphs hold kernel nodes only)
+        else:
+            g.zero_()
 
 
 _default_store = None

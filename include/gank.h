@@ -407,6 +407,10 @@ int gank_relu_fwd(const void* x, void* y, long n, float leak, void* stream);    
 int gank_relu_bwd(const void* dy, const void* x, void* dx, long n, float leak, void* stream);
 int gank_tanh_bwd(const void* dy, const void* y, void* dx, long n, void* stream);      /* tf.tanh grad, :261 */
 int gank_scale_f32(const float* x, const float* s, float* y, long n, void* stream);    /* y = x * s[0] */
+/* y = wa a + wb b + wc c + wd d over n floats, null terms skipped, y may alias a term: the weighted sums of scalar losses in the
+ * train steps (ACGAN/train.py:108-121; Pix2Pix/model.py gen_loss = gan_weight * GAN + l1_weight * L1) and fp32 accumulation */
+int gank_weighted_sum4_f32(const float* a, const float* b, const float* c, const float* d, float wa, float wb, float wc, float wd,
+                           float* y, long n, void* stream);
 /* dst[0:nbytes] = src[0:nbytes], device to device, as a kernel launch (the tf.assign / feed copies of the captured
  * step: sn.py:55-56 u.assign, gan_cifar_resnet.py:616-620 feeds); 16-byte vectorised when both are 16-B aligned */
 int gank_copy_bytes(void* dst, const void* src, long nbytes, void* stream);

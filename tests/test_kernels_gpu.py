@@ -1437,6 +1437,27 @@ def test_concat_rows_is_two_copies_and_its_backward_two_views(K):
     assert torch.equal(a.grad, g[:5]) and torch.equal(b.grad, g[5:])
 
 
+def test_weighted_sum_of_loss_terms_and_its_seeds(K):
+    """functional.weighted_sum (gen_loss = gan_weight * GAN + l1_weight * L1; d_loss = gan + gp + ac): one launch forward; backward
+    hands a unit seed through weight 1 untouched (identity), turns it into the persistent constant seed of any other weight, and
+    scales an ordinary upstream gradient on the device -- the gradients of the terms are w_i * g in all three cases."""
+    from gan_lib_tensorflow_amd import functional as Fn
+    a = torch.tensor([1.5], device="cuda", requires_grad=True)
+    b = torch.tensor([-0.25], device="cuda", requires_grad=True)
+    c = torch.tensor([4.0], device="cuda", requires_grad=True)
+    y = Fn.weighted_sum([a, b, c], [1.0, 100.0, 0.5])
+    assert abs(float(y) - (1.5 - 25.0 + 2.0)) < 1e-6
+    seed = Fn.unit_seed(y)
+    ga, gb, gc = torch.autograd.grad([y], [a, b, c], [seed], retain_graph=True)
+    assert ga.data_ptr() == seed.data_ptr() and float(gb) == 100.0 and float(gc) == 0.5
+    assert Fn._seed_scale.get(gb.data_ptr()) == 100.0
+    ga, gb, gc = torch.autograd.grad([y], [a, b, c], [torch.tensor([3.0], device="cuda")])
+    assert (float(ga), float(gb), float(gc)) == (3.0, 300.0, 1.5)
+    acc = torch.full((7, 5), 2.0, device="cuda")
+    K.weighted_sum_f32([acc, torch.ones((7, 5), device="cuda")], [1.0, 1.0], out=acc)      # in-place accumulation
+    assert bool((acc == 3.0).all())
+
+
 def test_concat_label_fwd_bwd(K):
     """The critic's label branch through the per-label table: forward = concat_tile(x, linear(embedding(labels))) bit for
     bit (table built from the normalised weight); backward against float64 (the fp32 per-label sums are more accurate than the per-sample bf16 chain they replace)."""
