@@ -73,6 +73,8 @@ PROTOTYPES = {
     "gank_convpool3x3_dgrad": [P, P, P, P, I, I, I, I, I, P],
     "gank_convpool3x3_wgrad": [P, P, P, P, P, L, I, I, I, I, I, I, P],
     "gank_convpool3x3_wgrad_ws_elems": [I, I, I, I, I],
+    "gank_upconv3x3_wgrad_ws_elems": [I, I, I, I, I],
+    "gank_upconv3x3_wgrad": [P, P, P, P, L, I, I, I, I, I, P],
     "gank_conv2d_general_fprop": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     "gank_conv2d_general_dgrad": [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "gank_conv2d_general_wgrad": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
@@ -186,7 +188,7 @@ PROTOTYPES = {
     "gank_critic_feed": [P, P, P, P, P, P, P, P, I, I, P],
     "gank_debug_tr_probe": [P, P],
 }
-_RET = {"gank_last_error": C.c_char_p, "gank_sn_ws_floats": C.c_long, "gank_conv2d_wgrad_ws_elems": C.c_long, "gank_convpool3x3_wgrad_ws_elems": C.c_long, "gank_prof_calibrate": C.c_double, "gank_prof_bytes": C.c_double}
+_RET = {"gank_last_error": C.c_char_p, "gank_sn_ws_floats": C.c_long, "gank_conv2d_wgrad_ws_elems": C.c_long, "gank_convpool3x3_wgrad_ws_elems": C.c_long, "gank_upconv3x3_wgrad_ws_elems": C.c_long, "gank_prof_calibrate": C.c_double, "gank_prof_bytes": C.c_double}
 
 _lib = None
 

@@ -1767,6 +1767,77 @@ extern "C" int gank_convpool3x3_wgrad(const void* x, const void* dy, float* dw, 
   return 0;
 }
 
+// ---- filter gradient of UpsampleConv 3x3 (nearest-neighbour 2x upsample, then the 3x3 conv: gan_cifar_resnet.py:138-153) in its
+// phase form.  With u = the conv output position, the output phase (a, b) = (u_y & 1, u_x & 1) reads the LOW-resolution input
+// through 2 x 2 taps (gank_upconv3x3_fprop), so the gradient of those 16 (phase, tap) matrices is
+//     D4[kh][kw][co][ci] = sum_{n,y,x} dy[n, 2y + kh - 1, 2x + kw - 1, co] * x_low[n, y, x, ci],   kh = 3 - 2i - a, kw = 3 - 2j - b
+// -- exactly the 16-tap stride-2 filter gradient of ConvMeanPool with the operands swapped (its "x" := dy at 2H x 2W, its "dy"
+// := x at H x W): the rows kernel above computes it at 4/9 of the multiply-adds of the all-taps kernel on the upsampled input.
+// The 3 x 3 taps then collect the phase taps they fed: dW3[t][s] += sum_{kh in {2-t, 3-t}} sum_{kw in {2-s, 3-s}} D4[kh][kw]^T.
+// One thread block transposes a 32 x 32 (co, ci) tile through LDS so that both the slab reads and the dw updates are coalesced.
+__global__ __launch_bounds__(256) void wgrad_upconv_fold_slabs_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cin, int Cout, int splits) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int tap = blockIdx.z, t = tap / 3, sidx = tap % 3;
+  const long plane = (long)Cin * Cout;
+#pragma unroll
+  for (int rr = 0; rr < 4; rr++) {
+    const int co = co0 + ty + 8 * rr, ci = ci0 + tx;
+    float acc = 0.f;
+    for (int sp = 0; sp < splits; sp++) {               // fixed order: deterministic
+      const float* base = ws + (long)sp * 16 * plane + (long)co * Cin + ci;
+      acc += (base[((2 - t) * 4 + (2 - sidx)) * plane] + base[((2 - t) * 4 + (3 - sidx)) * plane]) +
+             (base[((3 - t) * 4 + (2 - sidx)) * plane] + base[((3 - t) * 4 + (3 - sidx)) * plane]);
+    }
+    tile[ty + 8 * rr][tx] = acc;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rr = 0; rr < 4; rr++) {
+    const int ci = ci0 + ty + 8 * rr, co = co0 + tx;
+    dw[((long)tap * Cin + ci) * Cout + co] += tile[tx][ty + 8 * rr];
+  }
+}
+
+static bool wgrad_upconv_ok(int N, int H, int W, int Cin, int Cout) {
+  static const int env = gank_tune("GANK_UPCONV_WGRAD_PHASE", 1);   // experiment knob: 0 keeps the all-taps kernel on the upsampled input
+  return env && Cin % 64 == 0 && Cout % 64 == 0 && wgrad_cpool_rows_ok(N, H, W, Cout, Cin);
+}
+
+extern "C" long gank_upconv3x3_wgrad_ws_elems(int N, int H, int W, int Cin, int Cout) {
+  if (!wgrad_upconv_ok(N, H, W, Cin, Cout)) return 0;
+  WgradArgs a{};
+  a.Cin = Cout; a.Cout = Cin; a.M = N * H * W;
+  wgrad_cpool_rows_geometry(a);
+  return 16L * Cin * Cout * a.splits;
+}
+
+extern "C" int gank_upconv3x3_wgrad(const void* x_low, const void* dy, float* dw, float* ws16, long ws_elems, int N, int H, int W, int Cin, int Cout,
+                                    void* stream) {
+  GANK_REQUIRE(x_low && dy && dw && ws16, "upconv3x3_wgrad: null pointer");
+  GANK_REQUIRE(wgrad_upconv_ok(N, H, W, Cin, Cout), "upconv3x3_wgrad: unsupported shape (N %d, %d x %d, %d -> %d channels): gank_upconv3x3_wgrad_ws_elems returns 0 for it",
+               N, H, W, Cin, Cout);
+  hipStream_t s = (hipStream_t)stream;
+  WgradArgs a{};
+  a.x = (const bf16*)dy; a.dy = (const bf16*)x_low; a.dw = dw; a.dbias = nullptr; a.ws = ws16;          // operands swapped (above)
+  a.N = N; a.H = H; a.W = W; a.Hx = 2 * H; a.Wx = 2 * W; a.Hdy = H; a.Wdy = W;
+  a.Cin = Cout; a.Cout = Cin; a.M = N * H * W;
+  a.sw = log2_or_neg(W); a.shw = log2_or_neg(H * W);
+  wgrad_cpool_rows_geometry(a);
+  GANK_REQUIRE(ws_elems >= 16L * Cin * Cout * a.splits, "upconv3x3_wgrad: workspace of %ld floats, need %ld (gank_upconv3x3_wgrad_ws_elems)", ws_elems,
+               16L * Cin * Cout * a.splits);
+  gank_prof_begin(1, 2.0 * a.M * 16.0 * Cin * Cout, s, 2.0 * ((double)a.M * Cin + 4.0 * a.M * Cout) + 36.0 * Cin * Cout);
+  gank_prof_tag(1, "conv_wgrad_rows_kernel<0, 2, true> + wgrad_upconv_fold_slabs_kernel");
+  const size_t lds = (size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16);
+  a.scale = 1.f;
+  hipLaunchKernelGGL((conv_wgrad_rows_kernel<0, 2, true>), dim3((unsigned)(4 * a.tiles_ci * a.tiles_co * a.splits)), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(wgrad_upconv_fold_slabs_kernel, dim3(Cin / 32, Cout / 32, 9), dim3(256), 0, s, ws16, dw, Cin, Cout, a.splits);
+  gank_prof_end(1, s);
+  GANK_LAUNCH_OK("upconv3x3_wgrad");
+  return 0;
+}
+
 // Two 3-channel-input layers of different geometry in one launch (the streaming kernel above): the critic's D.Block.1.Conv1
 // (3x3 on the 32x32 image) and D.Block.1.Shortcut (1x1 on the pooled 16x16 image).  Falls back to two gank_conv2d_wgrad calls
 // when a layer is outside the kernel's shapes.

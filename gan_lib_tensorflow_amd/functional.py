@@ -18,6 +18,7 @@ POOL_CONV4 = True     # 3x3 conv + 2x2 mean pool as one 4x4 stride-2 conv (4 ins
 CPOOL_RESIDENT = True   # ... on the LDS-resident kernels where they apply (prep kind 5; kernels.cpool_res_ok)
 PHASE_UPCONV = True   # NN-upsample+3x3 conv as a phase-decomposed transposed conv (4 instead of 9 taps)
 RES8_CONV = True      # 3x3 convs on 8x8 images with "rfrag" operands attached: the LDS-resident kernel (gank_res8_conv3x3)
+UPCONV_WGRAD_PHASE = True   # filter gradient of UpsampleConv 3x3 in its phase form (gank_upconv3x3_wgrad)
 IMG16_CONV = True     # plain 3x3 convs on 16x16 images with "rfrag" operands attached: the image-resident kernel (gank_img16_conv3x3)
 
 
@@ -136,6 +137,8 @@ class _Conv2d(Function):
     """conv2d SAME stride 1 with fused NN-upsample / relu on the input and bias / mean-pool /
     residual / tanh on the output (common/ops/conv2d.py:180-216; gan_cifar_resnet.py:112-153)."""
 
+    last_stats = None
+
     @staticmethod
     def forward(ctx, x, W, bias, residual, upsample, in_relu, pool_out, out_tanh, stats_groups=0):
         _Conv2d.last_stats = None
@@ -246,6 +249,11 @@ class _Conv2d(Function):
                 _defer_wgrad(x, g, tgt, btgt, (H, Wd), k, wflags)
             elif narrow_wgrad_ok(cin, cout, k, wflags == 0):
                 _defer_narrow(x, g, tgt, btgt, (H, Wd), k)       # paired with the block's other image-side layer (one launch)
+            elif UPCONV_WGRAD_PHASE and upsample and k == 3 and not in_relu and not pool_out and K.upconv3x3_wgrad_ws(x, cout) > 0:
+                # phase form: 16 (phase, tap) products at LOW resolution instead of 9 taps on the upsampled input (4/9 of the work)
+                K.upconv3x3_wgrad(x, g, tgt.view(3, 3, cin, cout))
+                if btgt is not None:
+                    K.colsum(g, btgt, 1.0)           # (the rows kernel sums its OTHER operand: the bias gradient is a launch of its own)
             else:
                 # bias gradient rides on the dy stream
                 K.conv2d_wgrad(x, g, tgt, (H, Wd), k, wflags, scale, dbias=btgt)

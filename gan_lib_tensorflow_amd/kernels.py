@@ -531,6 +531,27 @@ def convpool3x3_wgrad(x, dy, dw, flags=0, dbias=None):
     return dw
 
 
+def upconv3x3_wgrad_ws(xl, cout):
+    """workspace floats of upconv3x3_wgrad for this input; 0: the shape is not served by the phase form"""
+    n, h, w, cin = xl.shape
+    return int(lib().gank_upconv3x3_wgrad_ws_elems(n, h, w, cin, cout))
+
+
+def upconv3x3_wgrad(xl, dy, dw):
+    """ACCUMULATES the UpsampleConv 3x3 filter gradient into dw fp32 [3,3,Cin,Cout]: xl = the conv's input before the upsample
+    [N,H,W,Cin], dy [N,2H,2W,Cout] (phase form on the ConvMeanPool rows kernel: gank_upconv3x3_wgrad).  No bias gradient."""
+    n, h, w, cin = xl.shape
+    cout = dy.shape[3]
+    assert dy.shape[1] == 2 * h and dy.shape[2] == 2 * w and dw.numel() == 9 * cin * cout, (xl.shape, dy.shape, dw.shape)
+    ws_elems = upconv3x3_wgrad_ws(xl, cout)
+    if ws_elems <= 0:
+        raise RuntimeError(f"gank: upconv3x3_wgrad does not serve {tuple(xl.shape)} -> {cout} channels")
+    ws16 = torch.empty(ws_elems, dtype=F32, device=xl.device)
+    _lib.check(lib().gank_upconv3x3_wgrad(_p(xl, BF16, "x_low"), _p(dy, BF16, "dy"), _p(dw, F32, "dw"), _p(ws16), ws_elems, n, h, w, cin, cout, _stream()),
+               "upconv3x3_wgrad")
+    return dw
+
+
 def _ptr_array(ts):
     arr = (C.c_void_p * len(ts))()
     for i, t in enumerate(ts):

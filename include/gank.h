@@ -247,6 +247,14 @@ int gank_convpool3x3_fprop(const void* x, const void* wp4, const float* bias, co
                            int N, int Hp, int Wp, int Cin, int Cout, int flags, void* stream);
 int gank_convpool3x3_dgrad(const void* dy, const void* wphd, const void* relu_ref, void* dx, int N, int Hp, int Wp,
                            int Cin, int Cout, void* stream);
+/* Filter gradient of UpsampleConv 3x3 (gan_cifar_resnet.py:138-153: NN-upsample 2x, then Conv2D 3x3) in its phase form: x_low
+ * bf16 [N,H,W,Cin] (the conv's input BEFORE the upsample), dy bf16 [N,2H,2W,Cout]; ACCUMULATES into dw fp32 [3,3,Cin,Cout]
+ * (Conv2DBackpropFilter of conv2d.py:180-187 composed with the upsample); 4/9 of the multiply-adds of the all-taps form.
+ * ws16: workspace of gank_upconv3x3_wgrad_ws_elems floats -- 0 = this shape is not served (use gank_conv2d_wgrad with
+ * GANK_IN_UPSAMPLE2X).  No bias gradient (the sum of dy over pixels: gank_colsum_bf16). */
+long gank_upconv3x3_wgrad_ws_elems(int N, int H, int W, int Cin, int Cout);
+int gank_upconv3x3_wgrad(const void* x_low, const void* dy, float* dw, float* ws16, long ws_elems, int N, int H, int W, int Cin, int Cout,
+                         void* stream);
 long gank_convpool3x3_wgrad_ws_elems(int N, int Hp, int Wp, int Cin, int Cout);
 int gank_convpool3x3_wgrad(const void* x, const void* dy, float* dw, float* dbias, float* ws16, long ws_elems, int N, int Hp, int Wp,
                            int Cin, int Cout, int flags, void* stream);

@@ -518,6 +518,34 @@ def test_upconv3x3_phase_decomposition(K, n, hl, cin, cout):
     assert relerr(dx, R.upsample_nn2x_grad(dx_hi)) < BF_TOL
 
 
+@pytest.mark.parametrize("n,hl,cin,cout", [(2, 8, 64, 64), (3, 8, 128, 64), (4, 16, 256, 256), (128, 16, 256, 256), (128, 4, 1024, 256)])
+def test_upconv3x3_filter_gradient_phase_form(K, n, hl, cin, cout):
+    """gank_upconv3x3_wgrad: the filter gradient of NN-upsample + 3x3 SAME conv (gan_cifar_resnet.py:138-153) as 16 (phase, tap)
+    products at LOW resolution -- the ConvMeanPool rows kernel with its operands swapped -- folded onto the 3 x 3 taps, against
+    the float64 gradient through the explicit upsample (small cases: <= 2e-3 of the maximum, fp32 sums of bf16 products) and
+    against the all-taps kernel on the upsampled input (every case: the two sum the same products in different orders, <= 1e-3);
+    it ACCUMULATES into dw.  Shapes the rows kernel does not serve (4 x 4 inputs) report a workspace of 0."""
+    rng = np.random.default_rng(3000 + n + hl + cin)
+    x, xt = bf(rng.normal(size=(n, hl, hl, cin)))
+    dy, dyt = bf(rng.normal(size=(n, 2 * hl, 2 * hl, cout)))
+    if K.upconv3x3_wgrad_ws(xt, cout) == 0:
+        assert hl < 8                                   # the rows kernel wants >= 8 x 8 low-resolution images
+        with pytest.raises(RuntimeError):
+            K.upconv3x3_wgrad(xt, dyt, torch.zeros((3, 3, cin, cout), device="cuda"))
+        return
+    dw = torch.full((3, 3, cin, cout), 0.25, device="cuda")
+    K.upconv3x3_wgrad(xt, dyt, dw)
+    ref = torch.zeros((3, 3, cin, cout), device="cuda")
+    K.conv2d_wgrad(xt, dyt, ref, (2 * hl, 2 * hl), 3, K.IN_UPSAMPLE2X)
+    torch.cuda.synchronize()
+    got = (dw - 0.25).double().cpu().numpy()
+    assert relerr(got, ref.double().cpu().numpy()) < 1e-3
+    if n <= 4:
+        w0 = np.zeros((3, 3, cin, cout))
+        _, dw_ref, _ = R.conv2d_same_grads(R.upsample_nn2x(x), w0, dy)
+        assert relerr(got, dw_ref) < 2e-3
+
+
 def test_copy_bytes(K):
     """Kernel-based device copy (the u.assign / feed copies of the captured step): bit-exact, any size/alignment."""
     g = torch.Generator(device="cpu").manual_seed(5)
