@@ -1029,6 +1029,41 @@ __global__ __launch_bounds__(256) void conv_narrow_in_kernel(IgemmArgs a) {
   // merge in the L2 (epi_tile_wide); an earlier LDS transpose of the wave's tile cost two barriers and 2-way bank conflicts
   // on both sides (SQ_LDS_BANK_CONFLICT = 50 % of the LDS cycles) in a kernel that is one latency chain per block.
   const bool otanh = (a.flags & GANK_OUT_TANH) != 0;
+  if (a.korder == 0 && !a.mask && !a.res && !otanh && (a.Cout & 127) == 0) {
+    // Wave-private transpose: the wave's 32 pixels x 128 channels (8 KB) go through its OWN LDS region, so nothing but the
+    // wave's LDS counter orders the two sides (no s_barrier: the block-wide transpose this kernel once had cost two), and a store
+    // instruction then covers FOUR whole 256-byte pixel runs instead of a 32-byte piece of 32 different ones.  Pitch 272 B: a
+    // 16-lane pass of ds_write_b128 lands on 16 different bank quads (4 r mod 64), a pass of the reads on 256 contiguous bytes.
+    __shared__ __attribute__((aligned(16))) char s_t[4 * 32 * 272];
+    char* mine = s_t + wave * 32 * 272;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int ct = tile_n * 128 + i * 32;
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        float v[8];
+        acc_widen(acc[i], q, a.scale, v);
+        bf16x8 o;
+        if (a.bias) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + ct + 16 * q + 8 * h), b1 = *reinterpret_cast<const f32x4*>(a.bias + ct + 16 * q + 8 * h + 4);
+#pragma unroll
+          for (int e = 0; e < 4; e++) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = f2bf(v[e]);
+        *reinterpret_cast<bf16x8*>(mine + r * 272 + (i * 32 + 16 * q + 8 * h) * 2) = o;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's own writes: program order + this wait, no barrier
+    const int m_w = tile_m * 128 + wave * 32;                // first pixel of the wave
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int p = it * 4 + (lane >> 4), c16 = lane & 15;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(mine + p * 272 + c16 * 16);
+      if (m_w + p < a.M) *reinterpret_cast<u32x4*>(a.y + (long)(m_w + p) * a.Cout + tile_n * 128 + c16 * 8) = v;
+    }
+    return;
+  }
   if ((a.Cout & 31) == 0) {
     if (m < a.M) {
 #pragma unroll
