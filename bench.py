@@ -338,8 +338,15 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if pg is not None:
+        # ordered teardown: the captured graphs (they may hold collective nodes) and the bucket views go before the communicator,
+        # and nothing is in flight when it is destroyed
+        import gc
         import torch.distributed as dist
+        del tr, feed
+        gc.collect()
+        torch.cuda.synchronize()
         dist.barrier(group=pg)
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

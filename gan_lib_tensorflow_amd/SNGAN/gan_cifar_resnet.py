@@ -317,6 +317,10 @@ class SNGANTrainer:
         self._build(state)
         self._graphs = {}
         self._g_applier = type("_Apply", (), {"apply": staticmethod(self._g_apply)})()
+        # tests: callable(stage, k) invoked by train_iteration between its pieces ('g', 'gen5', 'd_pre' before / after each),
+        # so the captured path can be inspected where bench.py times it; None in production (no host work is added)
+        self.observer = None
+        self.last_logits = None      # the critic logits of the latest prefetched update (a graph-pool tensor under replay)
 
     # ---- graph construction (variables are created by name on the first call, :238,:267) ----------
     def _build(self, state):
@@ -481,6 +485,7 @@ class SNGANTrainer:
         with _sn.grad_scratch(self.d_flat["scratch"]):        # zeroed by zero_grads above
             loss, logits = self._critic_loss(self.both, self.both_labels, self.batch)
         self._backward(loss)
+        self.last_logits = logits
         return logits
 
     @torch.no_grad()
@@ -791,11 +796,22 @@ class SNGANTrainer:
             for i, (data, labels) in enumerate(feed):
                 self.real_all[i].copy_(data, non_blocking=True)
                 self.labels_all[i].copy_(labels, non_blocking=True)
+        obs = self.observer
         if self.iteration > 0:
             self.g_step()
+            if obs:
+                obs('after_g', 0)
+        if obs:
+            obs('before_gen5', 0)
         self._run_plain('gen5', self._generate_for_critic)
+        if obs:
+            obs('after_gen5', 0)
         for i in range(N_CRITIC):      # slot i of the feed ring: the device-side slot counter walks 0..N_CRITIC-1
+            if obs:
+                obs('before_d', i)
             self._run('d_pre', self._d_forward_backward_prefetched, self.d_opt, self.d_flat)
+            if obs:
+                obs('after_d', i)
         self.iteration += 1
         K.counter_add(self.iteration_dev, 1)
 

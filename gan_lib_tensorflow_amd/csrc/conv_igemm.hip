@@ -928,7 +928,9 @@ static int launch_few(const IgemmArgs& a0, hipStream_t s) {
 }
 static bool few_ok(const IgemmArgs& a) {
   static const int env = gank_tune("GANK_IGEMM_FEW", 1);   // experiment knob: 0 keeps the 32-row patch kernel
-  return env && a.Cout <= 3 && a.CoutPad == 32 && a.Cin % 64 == 0 && a.Kpad == 9 * a.Cin && !(a.flags & IG_RES_UP2X) &&
+  // (channel-inner K order only: the kernel walks [tap][channel]; it accumulates no statistics -- `tl_stats_done` stays 0 and the
+  //  caller's batch-norm pass computes them, as after the 32-row patch kernel it replaces)
+  return env && a.korder == 0 && a.Cout <= 3 && a.CoutPad == 32 && a.Cin % 64 == 0 && a.Kpad == 9 * a.Cin && !(a.flags & IG_RES_UP2X) &&
          (size_t)(10 * HROWP + 4 * (a.Kpad + 8)) * sizeof(bf16) <= 160 * 1024;
 }
 

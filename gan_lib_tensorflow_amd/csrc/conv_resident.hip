@@ -601,6 +601,7 @@ struct CpFwdArgs {
   const bf16* res;        // optional residual at pooled resolution [N,Hp,Wp,Cout]
   bf16* y;                // [N,Hp,Wp,Cout]
   int N, Hp, Wp, Cin, Cout, relu;
+  int xcd;                // XCD-aware block order (resident_xcd_env): workgroups that share an input patch share an L2
 };
 
 struct CpBwdArgs {
@@ -609,6 +610,7 @@ struct CpBwdArgs {
   const bf16* mask;       // optional relu reference [N,2Hp,2Wp,Cin]
   bf16* dx;               // [N,2Hp,2Wp,Cin]
   int N, Hp, Wp, Cin, Cout;
+  int xcd;
 };
 }  // namespace
 
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(512) void cpool_res_fprop_kernel(CpFwdArgs a) {
   const int ct = wave & 3, pg = wave >> 2;
   const int r = lane & 31, h = lane >> 5;
   const int pw_n = a.Wp / PW, ph_n = a.Hp / G::PHH, cgroups = a.Cout >> 7;
-  int bid = blockIdx.x;
+  int bid = a.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
   const int cg = bid % cgroups; bid /= cgroups;
   const int n = bid / (pw_n * ph_n), pr = bid - n * pw_n * ph_n;
   const int py0 = (pr / pw_n) * G::PHH, px0 = (pr % pw_n) * PW;          // pooled patch origin
@@ -744,7 +746,7 @@ __global__ __launch_bounds__(512) void cpool_res_fprop_k2_kernel(CpFwdArgs a) {
   const int ct = wave & 1, pg = (wave >> 1) & 1, kg = wave >> 2;
   const int r = lane & 31, h = lane >> 5;
   const int ph_n = a.Hp / G::PHH, cgroups = a.Cout >> 6;
-  int bid = blockIdx.x;
+  int bid = a.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
   const int cg = bid % cgroups; bid /= cgroups;
   const int n = bid / ph_n, pr = bid - n * ph_n;
   const int py0 = pr * G::PHH, px0 = 0;
@@ -891,7 +893,7 @@ __global__ __launch_bounds__(512) void cpool_res_dgrad_kernel(CpBwdArgs a) {
   const int ct = wave & 3, pg = wave >> 2;
   const int r = lane & 31, h = lane >> 5;
   const int pw_n = a.Wp / PW, ph_n = a.Hp / G::PHH, cgroups = a.Cin >> 7;
-  int bid = blockIdx.x;
+  int bid = a.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
   const int cg = bid % cgroups; bid /= cgroups;
   const int n = bid / (pw_n * ph_n), pr = bid - n * pw_n * ph_n;
   const int py0 = (pr / pw_n) * G::PHH, px0 = (pr % pw_n) * PW;
@@ -1008,7 +1010,7 @@ __global__ __launch_bounds__(512) void cpool_res_dgrad_ks_kernel(CpBwdArgs a) {
   const int ct = wave & 3, kg = wave >> 2;
   const int r = lane & 31, h = lane >> 5;
   const int pw_n = a.Wp / PW, ph_n = a.Hp / G::PHH, cgroups = a.Cin >> 7;
-  int bid = blockIdx.x;
+  int bid = a.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
   const int cg = bid % cgroups; bid /= cgroups;
   const int n = bid / (pw_n * ph_n), pr = bid - n * pw_n * ph_n;
   const int py0 = (pr / pw_n) * G::PHH, px0 = (pr % pw_n) * PW;
@@ -1139,6 +1141,10 @@ __global__ __launch_bounds__(512) void cpool_res_dgrad_ks_kernel(CpBwdArgs a) {
   }
 }
 
+static int resident_xcd_env() {
+  static const int v = gank_tune("GANK_RESIDENT_XCD", 1);   // experiment knob: 0 = hardware block order (neighbouring ids round-robin over the XCDs)
+  return v;
+}
 static bool cpool_res_geom_ok(int Hp, int Wp) { return Hp % 8 == 0 && (Wp % 16 == 0 || Wp == 8); }
 static int cpool_k2_env() {
   static const int v = gank_tune("GANK_CPOOL_K2", 1);   // experiment knob: GANK_CPOOL_K2=0 keeps the one-group kernel for 8-wide patches
@@ -1154,6 +1160,7 @@ extern "C" int gank_cpool_res_fprop(const void* x, const void* w_rfrag, const fl
   CpFwdArgs a{};
   a.x = (const bf16*)x; a.w = (const bf16*)w_rfrag; a.bias = bias; a.res = (const bf16*)residual; a.y = (bf16*)y;
   a.N = N; a.Hp = Hp; a.Wp = Wp; a.Cin = Cin; a.Cout = Cout; a.relu = (flags & GANK_IN_RELU) ? 1 : 0;
+  a.xcd = resident_xcd_env();
   hipStream_t s = (hipStream_t)stream;
   const double M = (double)N * Hp * Wp;
   gank_prof_begin(0, 2.0 * M * Cout * 16.0 * Cin, s, 2.0 * (4.0 * M * Cin + 16.0 * Cin * Cout + M * Cout + (residual ? M * Cout : 0.0)));
@@ -1188,6 +1195,7 @@ extern "C" int gank_cpool_res_dgrad(const void* dy, const void* w_rfrag, const v
   CpBwdArgs a{};
   a.dy = (const bf16*)dy; a.w = (const bf16*)w_rfrag; a.mask = (const bf16*)relu_ref; a.dx = (bf16*)dx;
   a.N = N; a.Hp = Hp; a.Wp = Wp; a.Cin = Cin; a.Cout = Cout;
+  a.xcd = resident_xcd_env();
   hipStream_t s = (hipStream_t)stream;
   const double M = (double)N * Hp * Wp;
   gank_prof_begin(0, 2.0 * M * 4.0 * Cin * 4.0 * Cout, s, 2.0 * (M * Cout + 16.0 * Cin * Cout + 4.0 * M * Cin + (relu_ref ? 4.0 * M * Cin : 0.0)));
@@ -1259,6 +1267,7 @@ struct I16Args {
   float* stat_sums;       // optional [groups][GANK_STAT_SLOTS][2][Cout]: batch-norm statistics of (y - bias), as gank_res8_conv3x3
   int N, Cin, Cout, relu; // relu: on the input operand while it is staged
   int res_up, stat_n_per_group;      // res_up: res is [N,8,8,Cout], added nearest-neighbour upsampled
+  int xcd;                // XCD-aware block order: the Cout/128 workgroups of an image share an L2
 };
 }  // namespace
 
@@ -1281,7 +1290,8 @@ __global__ __launch_bounds__(HALF ? 512 : 2048 / TW) void img16_conv3x3_kernel(I
   const int ct = wave & 3, pg = (HALF || TW == 8) ? 0 : wave >> 2, kh = HALF ? wave >> 2 : 0;
   const int r = lane & 31, h = lane >> 5;
   const int cgroups = a.Cout >> 7;
-  const int bid = HALF ? blockIdx.x >> 1 : blockIdx.x, row0 = HALF ? (blockIdx.x & 1) * 8 : 0;
+  const int lid = a.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int bid = HALF ? lid >> 1 : lid, row0 = HALF ? (lid & 1) * 8 : 0;
   const int cg = bid % cgroups, n = bid / cgroups;
   const int nchunks = a.Cin >> 6, kq = a.Cin >> 4;                      // 64-channel chunks; 16-channel K-steps per tap
   const int trow = r >> 4, tcol = r & 15;
@@ -1491,6 +1501,7 @@ extern "C" int gank_img16_conv3x3_stats(const void* x, const void* w_rfrag, cons
   a.x = (const bf16*)x; a.w = (const bf16*)w_rfrag; a.bias = bias; a.mask = (const bf16*)relu_ref; a.res = (const bf16*)residual; a.y = (bf16*)y;
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.relu = (flags & GANK_IN_RELU) ? 1 : 0;
   a.res_up = (flags & GANK_RES_UPSAMPLE2X) ? 1 : 0; a.stat_sums = stat_sums; a.stat_n_per_group = stat_sums ? N / stat_groups : 1;
+  a.xcd = resident_xcd_env();
   hipStream_t s = (hipStream_t)stream;
   if (stat_sums && !(flags & GANK_STATS_PREZEROED)) {
     const int nz = stat_groups * GANK_STAT_SLOTS * 2 * Cout;
@@ -1580,6 +1591,7 @@ struct G8Args {
   bf16* y;             // [N,8,8,Cout], or [N,4,4,Cout] with pool_out
   float* stat_sums;    // [groups][GANK_STAT_SLOTS][2][Cout] or null
   int N, Cout, up_in, res_up, pool_out, stat_n_per_group;
+  int xcd;
 };
 
 template <int C, int PF>
@@ -1592,7 +1604,8 @@ __global__ __launch_bounds__(256) void res8_conv3x3_kernel(G8Args a) {
   const int ct = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int ntc = a.Cout >> 7;
-  const int n = blockIdx.x / ntc, half = blockIdx.x - n * ntc;
+  const int lid = a.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int n = lid / ntc, half = lid - n * ntc;
   const int co0 = half * 128 + ct * 32;
   const int b_base = (r >> 3) * G::RPB + (r & 7) * G::PPB + h * 16;
   const int wbase = (half * 4 + ct) * G::STEPS * 1024;
@@ -1771,6 +1784,7 @@ extern "C" int gank_res8_conv3x3(const void* x, const void* w_rfrag, const float
   a.stat_sums = stat_sums; a.N = N; a.Cout = Cout;
   a.up_in = (flags & GANK_IN_UPSAMPLE2X) ? 1 : 0; a.res_up = (flags & GANK_RES_UPSAMPLE2X) ? 1 : 0; a.pool_out = pool_out ? 1 : 0;
   a.stat_n_per_group = stat_sums ? N / stat_groups : 1;
+  a.xcd = resident_xcd_env();
   hipStream_t s = (hipStream_t)stream;
   const double px_in = a.up_in ? 16.0 : 64.0, px_out = pool_out ? 16.0 : 64.0;
   gank_prof_begin(0, 2.0 * N * 64.0 * 9.0 * Cin * Cout, s,

@@ -34,7 +34,13 @@ struct WgradArgs {
   float scale;
   int tiles_ci, tiles_co, splits, steps_per_split;
   int shw, sw;
-  // batched launch of up to 4 same-shape layers (gank_conv2d_wgrad_batched): blockIdx.y picks the operand set
+  // block order (filter-row and all-taps kernels): 1 = XCD-aware -- one-dimensional grid, xcd_remap, (channel tile, filter row)
+  // fastest, so the workgroups that read the SAME pixel range of x and dy (every tile of one split of one layer) have
+  // consecutive logical ids = share an XCD's L2; 0 = the split index fastest (tiles of a split land on all eight XCDs unless
+  // the split count happens to be a multiple of 8, and every XCD then pulls the whole operand through the fabric)
+  int xcd;
+  int dbg;            // TUNING builds only (GANK_WGRAD_DBG): 1 = no output (timing of everything but the partial-tile stores / atomics), 2 = one step per block
+  // batched launch of up to 4 same-shape layers (gank_conv2d_wgrad_batched): blockIdx.y (xcd: the logical id) picks the operand set
   int nbatch;
   const bf16* xs[4];
   const bf16* dys[4];
@@ -290,6 +296,10 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_kernel(WgradArgs a) {
 // bit2 dy stored at half size), PF-slot register ring with no exits inside the unrolled body.
 // Sub-tiles are 64 B apart mod 256 B so the ds_write_b128 of one pixel's 128 channels is conflict-free.
 // ------------------------------------------------------------------------------------------------------
+static int wgrad_xcd_env() {
+  static const int v = gank_tune("GANK_WGRAD_XCD", 1);   // experiment knob: 0 = split-fastest block order without the XCD remap (WgradArgs.xcd)
+  return v;
+}
 static int wgrad_round_down_env() {
   static const int v = gank_tune("GANK_WGRAD_ROUND_DOWN", 1);   // experiment knob: GANK_WGRAD_ROUND_DOWN=0 restores ceil(target / tiles) pixel splits
   return v;
@@ -1003,8 +1013,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_taps_kernel(WgradArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_a = wave & 1, wave_b = wave >> 1;
-  int bid = blockIdx.x;
-  const int split = bid % a.splits; bid /= a.splits;
+  int bid = blockIdx.x, split;
+  if (a.xcd) {            // tiles fastest behind the XCD remap: the tiles of one pixel split share an L2 (WgradArgs.xcd)
+    const int ntile = a.tiles_co * a.tiles_ci;
+    bid = xcd_remap(blockIdx.x, gridDim.x);
+    split = bid / ntile; bid -= split * ntile;
+  } else {
+    split = bid % a.splits; bid /= a.splits;
+  }
   const int tco = bid % a.tiles_co, tci = bid / a.tiles_co;
   const int ci0 = tci * 64, co0 = tco * 64;
   const bool do_bias = a.dbias != nullptr && tci == 0;
@@ -1233,6 +1249,7 @@ static int launch_wgrad_taps_mode(WgradArgs a, hipStream_t s) {
 #endif
   static const std::string tag = gank_format("conv_wgrad_taps_kernel<%d, 2> + wgrad_reduce_slabs_kernel", MODE);     // magic static: built once, thread-safe
   gank_prof_tag(1, tag.c_str());
+  a.xcd = wgrad_xcd_env();
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_ci * a.tiles_co * a.splits)), dim3(256), lds, s, a);
   GANK_LAUNCH_OK("conv_wgrad_taps");
   if (a.ws) {
@@ -1292,18 +1309,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs a) {
   const bf16* DY = a.dy;
   float* DW = a.dw;
   float* DB = a.dbias;
+  int bid = blockIdx.x, bi = blockIdx.y;
+  int split, tco, tci, frow;
+  if (a.xcd) {
+    const int ntile = a.tiles_co * a.tiles_ci * (S2 ? 4 : 3), per_layer = ntile * a.splits;
+    bid = xcd_remap(blockIdx.x, gridDim.x);
+    bi = bid / per_layer; bid -= bi * per_layer;
+    split = bid / ntile; bid -= split * ntile;
+    tco = bid % a.tiles_co; bid /= a.tiles_co;
+    tci = bid % a.tiles_ci;
+    frow = bid / a.tiles_ci;
+  } else {
+    split = bid % a.splits; bid /= a.splits;
+    tco = bid % a.tiles_co; bid /= a.tiles_co;
+    tci = bid % a.tiles_ci;
+    frow = bid / a.tiles_ci;               // filter row
+  }
   if (a.nbatch > 0) {      // static indices only (a dynamically indexed by-value struct is spilled to scratch)
-    const int bi = blockIdx.y;
     X = bi == 0 ? a.xs[0] : (bi == 1 ? a.xs[1] : (bi == 2 ? a.xs[2] : a.xs[3]));
     DY = bi == 0 ? a.dys[0] : (bi == 1 ? a.dys[1] : (bi == 2 ? a.dys[2] : a.dys[3]));
     DW = bi == 0 ? a.dws[0] : (bi == 1 ? a.dws[1] : (bi == 2 ? a.dws[2] : a.dws[3]));
     DB = bi == 0 ? a.dbs[0] : (bi == 1 ? a.dbs[1] : (bi == 2 ? a.dbs[2] : a.dbs[3]));
   }
-  int bid = blockIdx.x;
-  const int split = bid % a.splits; bid /= a.splits;
-  const int tco = bid % a.tiles_co; bid /= a.tiles_co;
-  const int tci = bid % a.tiles_ci;
-  const int frow = bid / a.tiles_ci;               // filter row
   const int ci0 = tci * 64, co0 = tco * 64;
   const bool do_bias = DB != nullptr && tci == 0 && frow == 0;
 
@@ -1311,6 +1338,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs a) {
   int nsteps = (a.M >> 6) - step0;
   if (nsteps > a.steps_per_split) nsteps = a.steps_per_split;
   if (nsteps <= 0) return;
+#ifdef GANK_TUNING
+  if (a.dbg & 2) nsteps = 1;
+#endif
 
   constexpr int OOB = 0x7FFFFFF0;
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(X), 0, a.N * a.Hx * a.Wx * a.Cin * 2, 0x00020000);
@@ -1438,6 +1468,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs a) {
   if constexpr (PF >= 3) { if (s0 + 1 < nsteps) step(s0 + 1, std::integral_constant<int, 1 % PF>{}); }
   if constexpr (PF >= 4) { if (s0 + 2 < nsteps) step(s0 + 2, std::integral_constant<int, 2 % PF>{}); }
 
+#ifdef GANK_TUNING
+  if (a.dbg & 1) { if (acc[0][0] == 123.456f) DW[0] = 1.f; return; }
+#endif
   // partial tile -> slab [split][frow*NTAP + t][Cin][Cout], or atomics into dw
   const int r = lane & 31, h = lane >> 5;
   const int co = co0 + wave_b * 32 + r;
@@ -1505,7 +1538,11 @@ static int launch_wgrad_rows(WgradArgs a, hipStream_t s) {
 #endif
   static_assert((size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16) <= 65536, "below the default dynamic-LDS limit: no attribute call");
   gank_prof_tag(1, relu ? "conv_wgrad_rows_kernel<1, 2, false>" : "conv_wgrad_rows_kernel<0, 2, false>");
-  hipLaunchKernelGGL(kern, dim3((unsigned)(3 * a.tiles_ci * a.tiles_co * a.splits), nb), dim3(256), lds, s, a);
+  a.xcd = wgrad_xcd_env();
+  static const int dbg = gank_tune("GANK_WGRAD_DBG", 0);
+  a.dbg = dbg;
+  if (a.xcd) hipLaunchKernelGGL(kern, dim3((unsigned)(3 * a.tiles_ci * a.tiles_co * a.splits * nb)), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(kern, dim3((unsigned)(3 * a.tiles_ci * a.tiles_co * a.splits), nb), dim3(256), lds, s, a);
   GANK_LAUNCH_OK("conv_wgrad_rows");
   return 0;
 }
@@ -1743,6 +1780,7 @@ extern "C" int gank_convpool3x3_wgrad(const void* x, const void* dy, float* dw, 
     auto kern = (flags & GANK_IN_RELU) ? conv_wgrad_rows_kernel<1, 2, true> : conv_wgrad_rows_kernel<0, 2, true>;
 #endif
     static_assert((size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16) <= 65536, "below the default dynamic-LDS limit: no attribute call");
+    a.xcd = wgrad_xcd_env();
     hipLaunchKernelGGL(kern, dim3((unsigned)(4 * a.tiles_ci * a.tiles_co * a.splits)), dim3(256), lds, s, a);
     const long plane4 = (long)Cin * Cout / 4;
     hipLaunchKernelGGL(wgrad_cpool_fold_slabs_kernel, dim3((unsigned)cdiv(plane4, 256), 9), dim3(256), 0, s, ws16, dw, plane4, a.splits);
@@ -1831,6 +1869,7 @@ extern "C" int gank_upconv3x3_wgrad(const void* x_low, const void* dy, float* dw
   gank_prof_tag(1, "conv_wgrad_rows_kernel<0, 2, true> + wgrad_upconv_fold_slabs_kernel");
   const size_t lds = (size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16);
   a.scale = 1.f;
+  a.xcd = wgrad_xcd_env();
   hipLaunchKernelGGL((conv_wgrad_rows_kernel<0, 2, true>), dim3((unsigned)(4 * a.tiles_ci * a.tiles_co * a.splits)), dim3(256), lds, s, a);
   hipLaunchKernelGGL(wgrad_upconv_fold_slabs_kernel, dim3(Cin / 32, Cout / 32, 9), dim3(256), 0, s, ws16, dw, Cin, Cout, a.splits);
   gank_prof_end(1, s);

@@ -366,8 +366,9 @@ __global__ void scale_f32_kernel(const float* __restrict__ x, const float* __res
 }
 // y = wa a + wb b + wc c + wd d over n floats (null terms skipped): the weighted sums of scalar losses in the train steps
 // (ACGAN/train.py:108-121, Pix2Pix/model.py: gen_loss = gan_weight GAN + l1_weight L1) and fp32 accumulations y = y + x
-__global__ void wsum4_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, const float* __restrict__ d,
-                                 float wa, float wb, float wc, float wd, float* __restrict__ y, long n) {
+// (no __restrict__: callers accumulate in place, y aliasing one of the terms -- element i is read before it is written)
+__global__ void wsum4_f32_kernel(const float* a, const float* b, const float* c, const float* d,
+                                 float wa, float wb, float wc, float wd, float* y, long n) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float t = wa * a[i];
     if (b) t += wb * b[i];

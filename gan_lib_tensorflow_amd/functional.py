@@ -585,7 +585,9 @@ class _ResChain8Head(Function):
         hb = head_b.detach() if head_b is not None else None
         pooled, h1s, ys, logits = K.res8_chain_fwd(x, [w._prep_res[0] for w in Ws], [b.detach() if b is not None else None for b in bs],
                                                   keep, True, head=(hw, hb))
-        loss = spec.out if spec.out is not None else torch.empty(1, dtype=torch.float32, device=x.device)
+        # a fresh buffer starts as NaN: in the gradient-keeping path the value is written by the BACKWARD launch, and a caller that
+        # never runs it must not read a plausible-looking stale number (a caller-supplied `out` keeps its previous loss)
+        loss = spec.out if spec.out is not None else torch.full((1,), float('nan'), dtype=torch.float32, device=x.device)
         _ResChain8Head.last_logits = logits
         if not keep:             # forward only: the loss now, by the stand-alone kernel (same arithmetic)
             K.critic_head_hinge(pooled, hw, hb, spec.n_real, spec.mode, want_dx=False, loss=loss, loss_scale=spec.loss_scale)

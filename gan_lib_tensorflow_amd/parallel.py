@@ -35,6 +35,7 @@ def init_from_env(backend=None, device=None, force=False):
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    disable_collective_event_cache()
     kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
     if not dist.is_initialized():
         dist.init_process_group(backend, **kw)
@@ -86,6 +87,18 @@ def bucket_ranges(flat, groups):
     if sorted(ranges) != ranges or ranges[0][0] != 0 or ranges[-1][1] != total or any(a[1] != b[0] for a, b in zip(ranges, ranges[1:])):
         raise ValueError(f"buckets do not tile the buffer: {ranges} of {total}")
     return ranges
+
+
+def disable_collective_event_cache():
+    """Call before `init_process_group("nccl")` in a process that will capture hipGraphs.  ProcessGroupNCCL recycles the events
+    of its work items from a per-device cache; an event that once marked a collective issued UNDER CAPTURE can come back as the
+    end event of an eager collective, and the watchdog thread's `hipEventQuery` on it is refused with `hipErrorCapturedEvent`
+    (process-terminating, from the watchdog thread) while its old stream is capturing again.  With the cache off every work
+    item creates its own events, so an eager collective's events have never been near a capture: the hazard itself is gone,
+    not waited out.  (`drain_collective_watchdog` stays as a second line: it costs a synchronise + 0.25 s per capture, a
+    handful per run.)  Remaining failure mode: a torch build that ignores TORCH_NCCL_CUDA_EVENT_CACHE -- then only the drain
+    stands between an eager collective's pending query and the next capture, and that is a matter of timing."""
+    os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
 
 
 def drain_collective_watchdog(seconds=0.25):

@@ -1,7 +1,9 @@
 """Worker of tests/test_model_gpu.py::test_bucketed_generator_update_through_rccl_matches_the_one_piece_update: the data-parallel
 generator / critic updates through a world-size-1 RCCL group, in a process of its own -- an abort inside RCCL's teardown
 (observed once in `destroy_process_group` on a pool box, after every check had passed) must cost one test, not the pytest session.
-Prints `RCCL PATH OK` when every check has passed, BEFORE the process group is destroyed."""
+Teardown is ORDERED: every trainer, captured graph and tensor that refers to the communicator is released first, the device is
+synchronised (no collective or graph replay in flight), then the group is destroyed -- and only then `RCCL PATH OK` is printed;
+the parent test fails on any non-zero exit code, so an abort anywhere (checks, teardown, interpreter shutdown) fails the suite."""
 import gc
 import os
 import sys
@@ -41,7 +43,10 @@ seg = tr.g_flat["grads"]
 # gradient that crosses a bf16 rounding boundary is amplified on the way down -- two runs of the SAME pass differ alike)
 assert float(whole.norm()) > 0 and float((seg - whole).norm() / whole.norm()) < 5e-3, float((seg - whole).norm() / whole.norm())
 del tr
+from gan_lib_tensorflow_amd import parallel as _parallel
+_parallel.disable_collective_event_cache()
 dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+ok = False
 try:
     results = {}
     # the exchange call under capture.  NOTE what this does and does not show: at world size 1 RCCL's all-reduce is a no-op,
@@ -103,9 +108,18 @@ try:
             d = (a - b_).abs()
             assert torch.isfinite(a).all() and d.max().item() < 40 * 2e-4 and d.mean().item() < 3e-4, (name, d.max().item(), d.mean().item())      # measured 1.7e-4 .. 2.1e-4 over repeated runs
         assert abs(got[2] - ref[2]) < 0.5
-    print("RCCL PATH OK", flush=True)
+    ok = True
 finally:
     Fn.CONV_EPILOGUE_STATS = stats_were
+    # ordered teardown: graphs that hold captured collective calls and tensors registered with the communicator go first,
+    # then nothing may be in flight when the communicator is destroyed
+    results = ref = got = g = cap = buf = want = side = None
+    gc.collect()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
     dist.destroy_process_group()
+if ok:
+    print("RCCL PATH OK", flush=True)
 
 

@@ -462,14 +462,29 @@ def test_headline_batch_64_forward_and_gradients_vs_oracle(gpu):
 ZERO_TABLE_TRAVEL_BOUND = 0.5
 
 
-def test_short_training_tracks_the_fp32_restatement(gpu, deterministic_stats):
-    """The only available proxy for "same sample quality as the reference" (no Inception weights, no TensorFlow): 60
+@pytest.mark.parametrize("stats", ["deterministic", "epilogue_atomics"])
+def test_short_training_tracks_the_fp32_restatement(gpu, stats):
+    """stats: 'deterministic' = the fixed-order batch-norm statistics (bounds from the 20-seed distribution below);
+    'epilogue_atomics' = the PRODUCTION default (statistics summed by the conv epilogues' float atomics, incl. the image-resident
+    16x16 kernel's), on the wider bounds run-to-run noise of 0.4 % per update needs (0.6 / 0.8 travel, 0.35 loss windows).
+
+    The only available proxy for "same sample quality as the reference" (no Inception weights, no TensorFlow): 60
     full iterations (300 critic + 60 generator updates) at batch 8 from identical parameters, on IDENTICAL inputs
     (same images, labels, z, fake labels; no dequantisation noise), HIP bf16 trainer vs the fp32 CPU restatement of the
     reference graph.  Individual weights diverge chaotically (TF-Adam with beta1 = 0 turns a sign flip of a ~0 gradient
     into a 2*lr jump), so the comparison is statistical: loss curves averaged over windows, per-tensor parameter
     norms, and the distance travelled from the initial point."""
+    from gan_lib_tensorflow_amd import functional as Fn
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    stats_were = Fn.CONV_EPILOGUE_STATS
+    Fn.CONV_EPILOGUE_STATS = stats == "epilogue_atomics"
+    try:
+        _short_training(stats == "deterministic")
+    finally:
+        Fn.CONV_EPILOGUE_STATS = stats_were
+
+
+def _short_training(deterministic):
     iters, b = 60, 8
     S, tr, state = make_trainer(31, b)
     P = T.to_torch(state, dtype=torch.float32)
@@ -506,7 +521,7 @@ def test_short_training_tracks_the_fp32_restatement(gpu, deterministic_stats):
     wd = np.abs(hip_d.reshape(-1, 50).mean(1) - ref_d.reshape(-1, 50).mean(1))
     print("short training: d_loss windows", hip_d.reshape(-1, 50).mean(1), ref_d.reshape(-1, 50).mean(1))
     print("short training: g_loss mean/std", hip_g.mean(), hip_g.std(), ref_g.mean(), ref_g.std())
-    assert wd.max() < 0.3, wd
+    assert wd.max() < (0.3 if deterministic else 0.35), wd
     # generator loss = -mean(D(G(z))) over 16 samples swings by +-1 from update to update on either trajectory (std ~0.8):
     # only its level over the whole run is comparable
     assert abs(hip_g.mean() - ref_g.mean()) < 0.8 and 0.0 < hip_g.mean() < 5.0, (hip_g.mean(), ref_g.mean())        # measured 0.07 .. 0.34
@@ -533,7 +548,8 @@ def test_short_training_tracks_the_fp32_restatement(gpu, deterministic_stats):
     # profiles/r04_travel_ratio_distribution.txt (scratch/travel_dist.py), not from repeated runs of one seed.
     zero_init = lambda k: k.endswith('CondBatchNorm/offset')      # noqa: E731
     assert max(norms.values()) < 0.02, top(norms)
-    assert max(v for k, v in travels.items() if not zero_init(k)) < 0.5 and max(v for k, v in travels.items() if zero_init(k)) < ZERO_TABLE_TRAVEL_BOUND, top(travels)
+    lim = (0.5, ZERO_TABLE_TRAVEL_BOUND) if deterministic else (0.6, 0.8)
+    assert max(v for k, v in travels.items() if not zero_init(k)) < lim[0] and max(v for k, v in travels.items() if zero_init(k)) < lim[1], top(travels)
     # ---- parity at a TRAINED state (spectral norms, conditional-batch-norm tables and Adam-shaped weights have moved):
     # the HIP trainer takes over the restatement's parameters and both differentiate the same losses on the same inputs
     tr.store.load_state_dict({k: v.detach().numpy() for k, v in P.items()})
@@ -596,7 +612,8 @@ def test_bucketed_generator_update_through_rccl_matches_the_one_piece_update(gpu
     cut at the block boundaries, the bucket of each segment all-reduced on the communication stream while the next
     segment runs, optimiser -- every phase its own hipGraph in one memory pool.  Same seeds, same feed as a trainer that
     runs the update in one piece: same RNG consumption, same loss, parameters equal up to fp32-atomics ordering."""
-    # the body runs in tests/rccl_worker.py (a process of its own: an abort in RCCL's teardown must not take the session down)
+    # the body runs in tests/rccl_worker.py (a process of its own: an abort in RCCL's teardown must not take the session down --
+    # but it FAILS this test: the marker is printed after destroy_process_group() and any non-zero exit code is an error)
     import subprocess
     import sys
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -604,9 +621,7 @@ def test_bucketed_generator_update_through_rccl_matches_the_one_piece_update(gpu
                        capture_output=True, text=True, timeout=900)
     print(r.stdout[-2000:])
     assert "RCCL PATH OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
-    if r.returncode != 0:          # every check passed, the process died while tearing the communicator down
-        import warnings
-        warnings.warn(f"rccl_worker exited with {r.returncode} AFTER all checks had passed (teardown): {r.stderr[-500:]}")
+    assert r.returncode == 0, f"rccl_worker exited with {r.returncode} after its checks and teardown: {r.stderr[-3000:]}"
 
 
 def test_sngan_critic_acgan_head(gpu):
