@@ -97,6 +97,7 @@ PROTOTYPES = {
     "gank_space_to_depth2": [P, P, I, I, I, I, P],
     "gank_cpool_res_fprop": [P, P, P, P, P, I, I, I, I, I, I, P],
     "gank_cpool_res_dgrad": [P, P, P, P, I, I, I, I, I, P],
+    "gank_cpool_res_dgrad_image_wgrad": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
     "gank_deconv2d_prep_phases": [P, P, I, I, I, P],
     "gank_deconv2d_fprop": [P, P, P, P, I, I, I, I, I, I, P],
     "gank_deconv2d_dgrad": [P, P, P, I, I, I, I, I, I, P],

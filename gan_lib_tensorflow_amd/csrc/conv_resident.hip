@@ -1141,6 +1141,302 @@ __global__ __launch_bounds__(512) void cpool_res_dgrad_ks_kernel(CpBwdArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same input gradient with the FILTER GRADIENT OF THE 3-CHANNEL-INPUT CONV IN FRONT OF IT in its epilogue (round 5).
+// In the critic's first block (gan_cifar_resnet.py:212-234) the tensor this kernel produces -- d loss / d relu'(Conv1 output),
+// 128 x 32 x 32 x 128 = 33.5 MB -- has ONE consumer in a critic update: D.Block.1.Conv1's filter and bias gradient (the image
+// needs no gradient).  Written, it cost this kernel its store phase and the streaming filter-gradient kernel a 33.5-MB read at
+// 1.3 TB/s (25 us).  Here the finished (masked, bf16-rounded -- the values the stored tensor held) tile of a wave goes through
+// the wave's OWN 2-KB LDS region ([32 pixels][32 channels], ordered by the wave's LDS counter alone) and comes back through
+// ds_read_b64_tr_b16 as the B operand of  dW1[k][c] += sum_p Xcol[k][p] dh[p][c]:  k = (kh, kw, cin) of the 3x3x3 filter (27 rows),
+// row 27 = ones (the bias gradient), 4 MFMAs per wave and phase.  Xcol ([128 pixels of the phase][32 k], 8 KB, two buffers) is
+// built by all threads from the workgroup's image rows (18 x 32 x 3 bf16, zero-padded in LDS) one phase ahead.  The 1x1
+// shortcut conv on the pooled image (D.Block.1.Shortcut) reads the SAME dy this kernel stages: its filter and bias gradient are
+// rows 28..31 of the same accumulator tile, 4 more MFMAs per wave on the resident dy halo.  The tensor is never stored.
+// One [32][Cin] tile per workgroup leaves as fp32 atomics (the two K groups of a channel tile meet in LDS first).
+// Geometry: Wp == 16 (a patch spans the image width, so the image rows need no column halo beyond the zero padding).
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct CpBwdWgArgs {
+  const bf16* dy;         // [N,Hp,Wp,Cout]
+  const bf16* w;          // rfrag (as CpBwdArgs)
+  const bf16* mask;       // relu reference [N,2Hp,2Wp,Cin] (the front conv's output)
+  const bf16* ximg;       // [N,2Hp,2Wp,3]: input of the front 3x3 conv
+  const bf16* xpool;      // [N,Hp,Wp,3] or null: input of the 1x1 shortcut conv whose output gradient is dy
+  float* dw1;             // [3,3,3,Cin] accumulated
+  float* db1;             // [Cin] or null
+  float* dws;             // [1,1,3,Cout] or null
+  float* dbs;             // [Cout] or null
+  int N, Hp, Wp, Cin, Cout;
+  int xcd;
+  int dbg;                // TUNING builds (GANK_IMGWG_DBG): 1 = no final atomics, 2 = no filter-gradient section, 4 = no Xcol build
+};
+constexpr int WG_XI_PITCH = 112;                       // image row in LDS (bf16): 8 zeros, 96 values, 8 zeros
+constexpr int WG_XI = CdGeom<16>::IMG + 2 * 4 * 2 * 4 * 64 * 16;     // byte offsets behind the halo image and the partial-tile area
+constexpr int WG_XP = WG_XI + 4096;
+constexpr int WG_XCOL = WG_XP + 768;
+constexpr int WG_DH = WG_XCOL + 2 * 8192;
+constexpr int WG_LDS = WG_DH + 8 * 2048;
+static_assert(WG_XCOL % 16 == 0 && WG_DH % 16 == 0 && WG_LDS <= 160 * 1024, "LDS plan of the fused filter gradient");
+__device__ __forceinline__ s16x4 res_tr_read(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+}  // namespace
+
+template <int PF>
+__global__ __launch_bounds__(512) void cpool_res_dgrad_imgwg_kernel(CpBwdWgArgs a) {
+  constexpr int PW = 16;
+  using G = CdGeom<PW>;
+  constexpr int TW = G::PHH / G::TROWS, TH = TW / 2;       // 4 pixel tiles per wave, 2 finished per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = wave & 3, kg = wave >> 2;
+  const int r = lane & 31, h = lane >> 5;
+  const int ph_n = a.Hp / G::PHH, cgroups = a.Cin >> 7;
+  int bid = a.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int cg = bid % cgroups; bid /= cgroups;
+  const int n = bid / ph_n, py0 = (bid - n * ph_n) * G::PHH, px0 = 0;
+  const int trow = r >> 4, tcol = r & 15;
+  const int b_base = trow * G::RP + tcol * G::PP + h * 16;
+  f32x4* part = reinterpret_cast<f32x4*>(smem + G::IMG) + (kg * 4 + ct) * (TH * 4 * 64);
+  f32x4* part_in = reinterpret_cast<f32x4*>(smem + G::IMG) + ((kg ^ 1) * 4 + ct) * (TH * 4 * 64);
+  const bool shortcut = a.xpool != nullptr && cg == 0;
+
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w), 0, 4 * a.Cin * 4 * a.Cout * 2, 0x00020000);
+  const int tiles = a.Cin >> 5, tile = cg * 4 + ct;
+  auto wofs = [&](int phase, int s) { return ((phase * tiles + tile) * 32 + 16 * kg + s) * 1024; };
+  u32x4 ring[PF];
+  static_assert(16 % PF == 0, "ring position is phase-invariant");
+#pragma unroll
+  for (int s = 0; s < PF; s++) ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, wofs(0, s), 0);
+
+  // ---- stage: dy halo, the image rows 2 py0 - 1 .. 2 py0 + 16 (zero outside the image / in the pads), the pooled-image rows
+  constexpr int HR = G::PHH + 2, HC = PW + 2, NPIECE = HR * HC * 16;
+  constexpr int NLD = (NPIECE + 511) / 512;
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.dy), 0, a.N * a.Hp * a.Wp * a.Cout * 2, 0x00020000);
+  constexpr int OOB = 0x7FFFFFF0;
+#pragma unroll
+  for (int j = 0; j < NLD; j++) {
+    const int q = tid + j * 512;
+    if (NPIECE % 512 == 0 || q < NPIECE) {
+      const int hp = q >> 4, c16 = q & 15;
+      const int hr = hp / HC, hc = hp - hr * HC;
+      const int iy = py0 - 1 + hr, ix = px0 - 1 + hc;
+      const bool ok = (unsigned)iy < (unsigned)a.Hp && (unsigned)ix < (unsigned)a.Wp;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ry, ok ? (((n * a.Hp + iy) * a.Wp + ix) * a.Cout + c16 * 8) * 2 : OOB, 0, 0);
+      *reinterpret_cast<u32x4*>(smem + hr * G::RP + hc * G::PP + c16 * 16) = v;
+    }
+  }
+  const int H2 = 2 * a.Hp, W2 = 2 * a.Wp;      // W2 == 32
+  {
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+    if (tid < 216) {                           // 18 rows x 12 sixteen-byte pieces (a 32-pixel row of 3 channels = 192 B)
+      const int lr = tid / 12, j = tid - lr * 12, gr = 2 * py0 - 1 + lr;
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.ximg), 0, a.N * H2 * W2 * 3 * 2, 0x00020000);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)gr < (unsigned)H2 ? ((n * H2 + gr) * W2 * 3) * 2 + j * 16 : OOB, 0, 0);
+      *reinterpret_cast<u32x4*>(smem + WG_XI + lr * (WG_XI_PITCH * 2) + 16 + j * 16) = v;
+    } else if (tid < 252) {                    // the two 16-byte pads of each row
+      const int q = tid - 216, lr = q >> 1;
+      *reinterpret_cast<u32x4*>(smem + WG_XI + lr * (WG_XI_PITCH * 2) + (q & 1) * 208) = z4;
+    } else if (tid >= 256 && tid < 304 && shortcut) {      // 8 pooled rows x 16 pixels x 3 channels = 768 contiguous bytes
+      const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.xpool), 0, a.N * a.Hp * a.Wp * 3 * 2, 0x00020000);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rp, ((n * a.Hp + py0) * a.Wp * 3) * 2 + (tid - 256) * 16, 0, 0);
+      *reinterpret_cast<u32x4*>(smem + WG_XP + (tid - 256) * 16) = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- Xcol: thread (p = tid / 4, kq = tid % 4) writes rows k = 8 kq .. + 7 of phase pixel p.  k = 9 kh + (3 kw + cin) reads the
+  // image row (2 y + pa + kh) at element 5 + 3 (2 x + pb) + (3 kw + cin): nine consecutive values per filter row.
+  const unsigned short* xi = reinterpret_cast<const unsigned short*>(smem + WG_XI);
+  int xoff[8];
+  {
+    const int p = tid >> 2, kq = tid & 3, t = p >> 5, rr = p & 31, y = 2 * t + (rr >> 4), xq = rr & 15;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int k = 8 * kq + j, kh = (k * 57) >> 9, jj = k - 9 * kh;       // k / 9 for k < 32
+      xoff[j] = k < 27 ? (2 * y + kh) * WG_XI_PITCH + 5 + 6 * xq + jj : (k == 27 ? -1 : -2);
+    }
+  }
+  auto build_xcol = [&](int phase) {
+    const int sh = (phase >> 1) * WG_XI_PITCH + (phase & 1) * 3;
+    unsigned short v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = xoff[j] >= 0 ? xi[xoff[j] + sh] : (xoff[j] == -1 ? (unsigned short)0x3F80 : (unsigned short)0);
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; j++) o[j] = (unsigned)v[2 * j] | ((unsigned)v[2 * j + 1] << 16);
+    *reinterpret_cast<u32x4*>(smem + WG_XCOL + (phase & 1) * 8192 + tid * 16) = o;       // row p = tid / 4: 64 B, piece kq
+  };
+  build_xcol(0);
+  if (shortcut) {      // Xs [128 pooled pixels][32]: rows 28..30 = the pooled image's channels, row 31 = ones (in the DH area, before any wave uses it)
+    const unsigned short* xp = reinterpret_cast<const unsigned short*>(smem + WG_XP);
+    const int p = tid >> 2, kq = tid & 3;
+    u32x4 o = {0u, 0u, 0u, 0u};
+    if (kq == 3) {
+      o[2] = (unsigned)xp[3 * p] | ((unsigned)xp[3 * p + 1] << 16);
+      o[3] = (unsigned)xp[3 * p + 2] | (0x3F80u << 16);
+    }
+    *reinterpret_cast<u32x4*>(smem + WG_DH + tid * 16) = o;
+  }
+  __syncthreads();
+
+  f32x16 accw;
+#pragma unroll
+  for (int e = 0; e < 16; e++) accw[e] = 0.f;
+  const int g4 = lane >> 4, li = lane & 15;
+  const int tr_row = 8 * (g4 >> 1) + (li >> 2), tr_col = 16 * (g4 & 1) + 4 * (li & 3);      // transposed-read lane geometry (conv_wgrad.hip)
+  const int tr64 = (tr_row * 32 + tr_col) * 2;                                              // bytes, 64-byte rows
+  if (shortcut) {      // this wave: channel tile ct, pooled rows 4 kg .. + 3 (a K-step = one pooled row of 16 pixels)
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) {
+      const int j = 4 * kg + jj;
+      const char* pa_ = smem + WG_DH + j * 16 * 64 + tr64;
+      const char* pb_ = smem + (1 + j) * G::RP + (1 + tr_row) * G::PP + (ct * 32 + tr_col) * 2;
+      const s16x4 al = res_tr_read(pa_), ah = res_tr_read(pa_ + 4 * 64);
+      const s16x4 bl = res_tr_read(pb_), bh = res_tr_read(pb_ + 4 * G::PP);
+      const s16x8 ta = {al[0], al[1], al[2], al[3], ah[0], ah[1], ah[2], ah[3]};
+      const s16x8 tb = {bl[0], bl[1], bl[2], bl[3], bh[0], bh[1], bh[2], bh[3]};
+      accw = GANK_MFMA32(__builtin_bit_cast(bf16x8, ta), __builtin_bit_cast(bf16x8, tb), accw);
+    }
+  }
+
+  char* dh = smem + WG_DH + wave * 2048;
+#pragma unroll 1
+  for (int phase = 0; phase < 4; phase++) {
+    const int pa = phase >> 1, pb = phase & 1;
+    const int poff = pa * G::RP + pb * G::PP;
+    f32x16 acc[TW];
+#pragma unroll
+    for (int t = 0; t < TW; t++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+    bf16x8 mk[TH][2];
+#pragma unroll
+    for (int t = 0; t < TH; t++) {
+      const int y = py0 + (kg * TH + t) * G::TROWS + trow, x = px0 + tcol;
+      const long m = ((long)n * H2 + 2 * y + pa) * W2 + 2 * x + pb;
+#pragma unroll
+      for (int q = 0; q < 2; q++) mk[t][q] = *reinterpret_cast<const bf16x8*>(a.mask + m * a.Cin + cg * 128 + ct * 32 + 16 * q + 8 * h);
+    }
+    constexpr int PB = 2;
+    bf16x8 bq[PB + 1][TW];
+    auto body = [&](auto half) {
+      constexpr int S0 = decltype(half)::value * 16;
+      auto read_b = [&](int s, bf16x8 (&dst)[TW]) {
+        const int tap = (S0 + s) >> 3, kk = (S0 + s) & 7, ti = tap >> 1, tj = tap & 1;
+#pragma unroll
+        for (int t = 0; t < TW; t++)
+          dst[t] = *reinterpret_cast<const bf16x8*>(smem + b_base + poff + (t * G::TROWS + ti) * G::RP + tj * G::PP + kk * 32);
+      };
+#pragma unroll
+      for (int s = 0; s < PB; s++) read_b(s, bq[s]);
+#pragma unroll
+      for (int s = 0; s < 16; s++) {
+        if (s + PB < 16) read_b(s + PB, bq[(s + PB) % (PB + 1)]);
+        const bf16x8 fa = __builtin_bit_cast(bf16x8, ring[s % PF]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TW; t++) acc[t] = GANK_MFMA32(fa, bq[s % (PB + 1)][t], acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          const int nx = s + PF;
+          const int np = nx < 16 ? phase : (phase < 3 ? phase + 1 : 3), ns = nx < 16 ? nx : (phase < 3 ? nx - 16 : 15);
+          ring[s % PF] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, wofs(np, ns), 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if (kg == 0) body(std::integral_constant<int, 0>{});
+    else body(std::integral_constant<int, 1>{});
+    if (phase > 0) __syncthreads();                    // the previous phase's partials have been read; every wave has left phase - 1
+#ifdef GANK_TUNING
+    if (!(a.dbg & 4))
+#endif
+    if (phase < 3) build_xcol(phase + 1);              // (its buffer was last read in phase - 1; visible after this phase's barrier below)
+    auto finish = [&](auto group) {
+      constexpr int KG = decltype(group)::value;
+#pragma unroll
+      for (int t = 0; t < TH; t++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const f32x16& src = acc[(KG ^ 1) * TH + t];
+          part[(t * 4 + g) * 64 + lane] = f32x4{src[4 * g], src[4 * g + 1], src[4 * g + 2], src[4 * g + 3]};
+        }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < TH; t++) {
+        f32x16& fin = acc[KG * TH + t];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const f32x4 o = part_in[(t * 4 + g) * 64 + lane];
+#pragma unroll
+          for (int e = 0; e < 4; e++) fin[4 * g + e] += o[e];
+        }
+        // the finished tile (32 pixels x this wave's 32 channels), masked and rounded as the stored tensor was, through the wave's own LDS rows
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          float v[8];
+          acc_widen(fin, q, 1.0f, v);
+#pragma unroll
+          for (int e = 0; e < 8; e++) v[e] = bf2f(mk[t][q][e]) > 0.f ? v[e] : 0.f;
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; e++) o[e] = f2bf(v[e]);
+          *reinterpret_cast<bf16x8*>(dh + r * 64 + 32 * q + 16 * h) = o;
+        }
+#ifdef GANK_TUNING
+        if (a.dbg & 2) continue;
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's own writes: program order + this wait, no barrier
+        const char* xc = smem + WG_XCOL + (phase & 1) * 8192 + (KG * TH + t) * 32 * 64 + tr64;
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+          const s16x4 al = res_tr_read(xc + kk * 16 * 64), ah = res_tr_read(xc + kk * 16 * 64 + 4 * 64);
+          const s16x4 bl = res_tr_read(dh + kk * 16 * 64 + tr64), bh = res_tr_read(dh + kk * 16 * 64 + 4 * 64 + tr64);
+          const s16x8 ta = {al[0], al[1], al[2], al[3], ah[0], ah[1], ah[2], ah[3]};
+          const s16x8 tb = {bl[0], bl[1], bl[2], bl[3], bh[0], bh[1], bh[2], bh[3]};
+          accw = GANK_MFMA32(__builtin_bit_cast(bf16x8, ta), __builtin_bit_cast(bf16x8, tb), accw);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the reads above have returned before the next tile overwrites the rows
+      }
+    };
+    if (kg == 0) finish(std::integral_constant<int, 0>{});
+    else finish(std::integral_constant<int, 1>{});
+  }
+
+  // ---- the two K groups of a channel tile meet in LDS (each keeps one half of the rows), then one [32][32] tile per wave pair
+  // leaves as fp32 atomics: rows 0..26 -> dw1, 27 -> db1, 28..30 -> dws, 31 -> dbs
+#ifdef GANK_TUNING
+  if (a.dbg & 1) { if (accw[0] == 123.456f) a.dw1[0] = 1.f; return; }
+#endif
+  __syncthreads();
+  float* ex = reinterpret_cast<float*>(smem + G::IMG) + ((kg * 4 + ct) * 8) * 64;
+  const float* ex_in = reinterpret_cast<const float*>(smem + G::IMG) + (((kg ^ 1) * 4 + ct) * 8) * 64;
+#pragma unroll
+  for (int e = 0; e < 8; e++) ex[e * 64 + lane] = kg == 0 ? accw[8 + e] : accw[e];      // the half the OTHER group finishes
+  __syncthreads();
+  const int col = ct * 32 + r;
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const int ee = kg == 0 ? e : 8 + e;
+    const float v = (kg == 0 ? accw[e] : accw[8 + e]) + ex_in[e * 64 + lane];
+    const int k = (ee & 3) + 8 * (ee >> 2) + 4 * h;
+    float* dst = nullptr;
+    if (k < 27) dst = a.dw1 + (long)k * a.Cin + cg * 128 + col;
+#ifdef GANK_TUNING          // contention experiments: one copy of the tile per XCD (8) / per workgroup (16); the caller's buffer is that large
+    if (k < 27 && (a.dbg & 8)) dst += (blockIdx.x & 7) * 8192;
+    if (k < 27 && (a.dbg & 16)) dst += blockIdx.x * 8192;
+#endif
+    else if (k == 27) dst = a.db1 ? a.db1 + cg * 128 + col : nullptr;
+    else if (k < 31) dst = (shortcut && a.dws) ? a.dws + (long)(k - 28) * a.Cout + col : nullptr;
+    else dst = (shortcut && a.dbs) ? a.dbs + col : nullptr;
+    if (dst) atomicAdd(dst, v);
+  }
+}
+
 static int resident_xcd_env() {
   static const int v = gank_tune("GANK_RESIDENT_XCD", 1);   // experiment knob: 0 = hardware block order (neighbouring ids round-robin over the XCDs)
   return v;
@@ -1237,6 +1533,37 @@ extern "C" int gank_cpool_res_dgrad(const void* dy, const void* w_rfrag, const v
   }
   gank_prof_end(0, s);
   GANK_LAUNCH_OK("cpool_res_dgrad");
+  return 0;
+}
+
+// dy [N,Hp,16,128] -> NO dx: the filter / bias gradients of the 3x3 conv on the 3-channel image in front (dw1 [3,3,3,Cin], db1) and,
+// with x_pooled, of the 1x1 shortcut conv on the pooled image whose output gradient dy also is (dws [1,1,3,128], dbs), accumulated.
+extern "C" int gank_cpool_res_dgrad_image_wgrad(const void* dy, const void* w_rfrag, const void* relu_ref, const void* x_image,
+                                                float* dw1, float* db1, const void* x_pooled, float* dws, float* dbs, int N, int Hp, int Wp,
+                                                int Cin, int Cout, void* stream) {
+  GANK_REQUIRE(dy && w_rfrag && relu_ref && x_image && dw1 && N > 0, "cpool_res_dgrad_image_wgrad: null pointer");
+  GANK_REQUIRE(Cout == 128 && Cin % 128 == 0 && Hp % 8 == 0 && Wp == 16,
+               "cpool_res_dgrad_image_wgrad: needs Cout == 128, Cin %% 128 == 0, Hp %% 8 == 0 and Wp == 16 (got %d, %d, %dx%d)", Cout, Cin, Hp, Wp);
+  GANK_REQUIRE(!x_pooled || (dws != nullptr), "cpool_res_dgrad_image_wgrad: x_pooled without dws");
+  GANK_REQUIRE((long)N * 4 * Hp * Wp * Cin < (1L << 30), "cpool_res_dgrad_image_wgrad: tensor too large (32-bit byte offsets)");
+  CpBwdWgArgs a{};
+  a.dy = (const bf16*)dy; a.w = (const bf16*)w_rfrag; a.mask = (const bf16*)relu_ref; a.ximg = (const bf16*)x_image;
+  a.xpool = (const bf16*)x_pooled; a.dw1 = dw1; a.db1 = db1; a.dws = dws; a.dbs = dbs;
+  a.N = N; a.Hp = Hp; a.Wp = Wp; a.Cin = Cin; a.Cout = Cout;
+  a.xcd = resident_xcd_env();
+  static const int dbg = gank_tune("GANK_IMGWG_DBG", 0);
+  a.dbg = dbg;
+  hipStream_t s = (hipStream_t)stream;
+  const double M = (double)N * Hp * Wp;
+  // the input gradient's multiply-adds + the two filter gradients'; bytes: dy, the operand, the relu reference, the images (no dx)
+  gank_prof_begin(0, 2.0 * M * 4.0 * Cin * 4.0 * Cout + 2.0 * 4.0 * M * 28.0 * Cin + (x_pooled ? 2.0 * M * 4.0 * Cout : 0.0), s,
+                  2.0 * (M * Cout + 16.0 * Cin * Cout + 4.0 * M * Cin + 4.0 * M * 3 + (x_pooled ? M * 3 : 0.0)));
+  const int grid = N * (Hp / 8) * (Cin / 128);
+  GANK_MAX_DYNAMIC_LDS((cpool_res_dgrad_imgwg_kernel<8>), WG_LDS, "cpool_res_dgrad_image_wgrad");
+  gank_prof_tag(0, "cpool_res_dgrad_imgwg_kernel<8>");
+  hipLaunchKernelGGL((cpool_res_dgrad_imgwg_kernel<8>), dim3(grid), dim3(512), WG_LDS, s, a);
+  gank_prof_end(0, s);
+  GANK_LAUNCH_OK("cpool_res_dgrad_image_wgrad");
   return 0;
 }
 

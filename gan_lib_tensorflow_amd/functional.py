@@ -121,6 +121,31 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+FUSE_IMAGE_WGRAD = True   # D.Block.1.Conv1's and D.Block.1.Shortcut's filter gradients inside the ConvMeanPool input-gradient launch (round 5)
+
+
+class ImageWgradSink:
+    """Links a 3-channel-input conv whose input needs NO gradient (conv_1 / the 1x1 shortcut of OptimizedResBlockDisc1 in a critic
+    update, gan_cifar_resnet.py:212-234) with the resident ConvMeanPool behind it.  The ConvMeanPool's input gradient then has
+    exactly one consumer -- this conv's filter and bias gradient -- and gank_cpool_res_dgrad_image_wgrad computes both inside
+    the launch that would have produced the 33.5-MB tensor (never stored).  The producer's forward creates the sink (on its
+    output tensor: `_image_wgrad_sink` / `_shortcut_sink`), the ConvMeanPool's forward picks it up, its backward fills `tgt`
+    and sets `done`, and the producer's backward -- called with no gradient -- hands `tgt` to autograd."""
+    __slots__ = ("x", "W", "bias", "done", "tgt")
+
+    def __init__(self, x, W, bias):
+        self.x, self.W, self.bias, self.done, self.tgt = x, W, bias, False, None
+
+    def targets(self):
+        """(filter target, accumulated?, bias target | None, accumulated?) -- resolved once, by whoever runs the fused launch"""
+        tgt, acc = _target(self.W)
+        btgt, bacc = (None, True)
+        if self.bias is not None and self.bias.requires_grad:
+            btgt, bacc = _target(self.bias)
+        self.tgt = (tgt, acc, btgt, bacc)
+        return self.tgt
+
+
 class ShortcutLink:
     """Identity-shortcut residual block (`shortcut + conv_2(relu(conv_1(relu(x))))`, no normalisation): the gradient of
     the block input is mask(dgrad_1) + dy.  conv_2's backward parks dy here instead of returning it for the shortcut
@@ -138,10 +163,13 @@ class _Conv2d(Function):
     residual / tanh on the output (common/ops/conv2d.py:180-216; gan_cifar_resnet.py:112-153)."""
 
     last_stats = None
+    last_sink = None
 
     @staticmethod
     def forward(ctx, x, W, bias, residual, upsample, in_relu, pool_out, out_tanh, stats_groups=0):
         _Conv2d.last_stats = None
+        _Conv2d.last_sink = None
+        ctx.sink = ctx.isink = ctx.ssink = None
         if W.dim() == 2:
             k, cin, cout = 1, W.shape[0], W.shape[1]
         else:
@@ -217,6 +245,16 @@ class _Conv2d(Function):
             ctx.res_link = rlink
         ctx.save_for_backward(x, W, y if out_tanh else None)
         ctx.cfg = (k, cin, cout, H, Wd, upsample, in_relu, pool_out, out_tanh, bias, phase, pool4)
+        if FUSE_IMAGE_WGRAD and x.is_cuda:
+            if (k == 3 and cin == 3 and residual is None and not (upsample or in_relu or pool_out or out_tanh or stats_groups)
+                    and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]):
+                # the image-side conv of a critic update: a ConvMeanPool behind it may take over the filter gradient (ImageWgradSink)
+                ctx.sink = _Conv2d.last_sink = ImageWgradSink(x, W, bias)
+                ctx.set_materialize_grads(False)           # ... and then calls this node's backward with no gradient at all
+            elif (pool4 and in_relu and getattr(W, "_prep_cpres", None) is not None and ctx.needs_input_grad[0]
+                  and getattr(x, "_image_wgrad_sink", None) is not None and K.cpool_res_dgrad_image_wgrad_ok(y, cin)):
+                ctx.isink = x._image_wgrad_sink
+                ctx.ssink = getattr(residual, "_shortcut_sink", None) if (residual is not None and not ctx.res_up_orig) else None
         # the backward pass runs the same kernel with the channel roles swapped: its own geometry check (Cin there = cout here),
         # otherwise the generic input-gradient path
         ctx.res8 = res8 and W._prep_res[1] is not None and K.res8_conv3x3_ok(n, (8, 8), cout, cin)
@@ -227,6 +265,11 @@ class _Conv2d(Function):
     def backward(ctx, dy):
         x, W, y = ctx.saved_tensors
         k, cin, cout, H, Wd, upsample, in_relu, pool_out, out_tanh, bias, phase, pool4 = ctx.cfg
+        if ctx.sink is not None and ctx.sink.done:        # the ConvMeanPool behind this conv computed its filter / bias gradient
+            tgt, acc, btgt, bacc = ctx.sink.tgt
+            return None, (None if acc else tgt), (None if (btgt is None or bacc) else btgt), None, None, None, None, None, None
+        if dy is None:
+            return (None,) * 9
         g = _c(dy)
         if out_tanh:
             g = K.tanh_bwd(g, y)
@@ -266,6 +309,19 @@ class _Conv2d(Function):
         elif ctx.needs_input_grad[0] and phase:
             prep = getattr(W, "_prep_up", None) or K.upconv3x3_prep(W.detach().view(3, 3, cin, cout))
             dx = K.upconv3x3_dgrad(g, prep[1], cin)       # 4x4 stride-2 conv of dy: no hi-res dgrad, no 2x2 sum
+        elif ctx.needs_input_grad[0] and pool4 and getattr(W, "_prep_cpres", None) is not None and ctx.isink is not None:
+            # the input gradient's only consumer is the image-side conv's filter gradient: both in one launch, nothing stored
+            isink, ssink = ctx.isink, ctx.ssink
+            t1, _, b1, _ = isink.targets()
+            ts = bs_ = xp = None
+            if ssink is not None:
+                ts, _, bs_, _ = ssink.targets()
+                xp = ssink.x
+            K.cpool_res_dgrad_image_wgrad(g, W._prep_cpres[1], x, isink.x, t1, b1, xp, ts, bs_)
+            isink.done = True
+            if ssink is not None:
+                ssink.done = True
+            dx = None
         elif ctx.needs_input_grad[0] and pool4 and getattr(W, "_prep_cpres", None) is not None:
             dx = K.cpool_res_dgrad(g, W._prep_cpres[1], cin, x if in_relu else None)
         elif ctx.needs_input_grad[0] and pool4:
@@ -489,6 +545,8 @@ def conv2d(x, W, bias=None, residual=None, upsample=False, in_relu=False, pool_o
     if stats_groups and _Conv2d.last_stats is not None:
         y._cbn_stats = _Conv2d.last_stats
         _Conv2d.last_stats = None
+    if _Conv2d.last_sink is not None:
+        y._image_wgrad_sink, _Conv2d.last_sink = _Conv2d.last_sink, None
     return y
 
 
@@ -864,6 +922,7 @@ class _ForkPoolConv1x1(Function):
     fork_pool + conv.  Backward = the same launches as the separate ops: filter gradient on the pooled image (a side
     output of the forward kernel), and, when the image itself needs a gradient (the generator update), the 1x1 input
     gradient unpooled into the main branch's."""
+    last_sink = None
 
     @staticmethod
     def forward(ctx, x, W, bias):
@@ -874,6 +933,9 @@ class _ForkPoolConv1x1(Function):
         y, pooled = K.meanpool_conv1x1_fprop(x, wf, bias.detach() if bias is not None else None, cout, keep_pooled=keep)
         ctx.save_for_backward(W, pooled)
         ctx.cfg = (cin, cout, bias)
+        ctx.sink = _ForkPoolConv1x1.last_sink = None
+        if FUSE_IMAGE_WGRAD and keep and not ctx.needs_input_grad[0] and cin == 3 and pooled is not None:
+            ctx.sink = _ForkPoolConv1x1.last_sink = ImageWgradSink(pooled, W, bias)      # see ImageWgradSink: the ConvMeanPool this shortcut is added to may serve it
         xv = x.view_as(x)
         if not ctx.needs_input_grad[0]:
             # autograd marks EVERY output of a node differentiable when any input is (here: the weight); the alias of an image
@@ -886,6 +948,9 @@ class _ForkPoolConv1x1(Function):
         W, pooled = ctx.saved_tensors
         cin, cout, bias = ctx.cfg
         dW = db = None
+        if ctx.sink is not None and ctx.sink.done:
+            tgt, acc, btgt, bacc = ctx.sink.tgt
+            return ga, (None if acc else tgt), (None if (btgt is None or bacc) else btgt)
         if gs is None:
             return ga, None, None
         g = _c(gs)
@@ -913,7 +978,10 @@ class _ForkPoolConv1x1(Function):
 
 def fork_pool_conv1x1(x, W, bias=None):
     """-> (x for the main path, conv1x1(mean_pool2x2(x)) + bias); x [N,H,W,3], W fp32 [1,1,3,Cout] (or [3,Cout])"""
-    return _ForkPoolConv1x1.apply(x, W, bias)
+    xv, y = _ForkPoolConv1x1.apply(x, W, bias)
+    if _ForkPoolConv1x1.last_sink is not None:
+        y._shortcut_sink, _ForkPoolConv1x1.last_sink = _ForkPoolConv1x1.last_sink, None
+    return xv, y
 
 
 def fork_pool_conv1x1_ok(x, cout):

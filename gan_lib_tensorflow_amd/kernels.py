@@ -519,6 +519,26 @@ def cpool_res_dgrad(dy, rd, cin, relu_ref=None):
     return dx
 
 
+def cpool_res_dgrad_image_wgrad_ok(dy, cin):
+    """geometry of gank_cpool_res_dgrad_image_wgrad: 16-wide pooled grid (32-pixel image rows), 128 dy channels"""
+    n, hp, wp, cout = dy.shape
+    return wp == 16 and hp % 8 == 0 and cout == 128 and cin % 128 == 0 and n * 4 * hp * wp * cin < (1 << 30)
+
+
+def cpool_res_dgrad_image_wgrad(dy, rd, relu_ref, x_image, dw1, db1=None, x_pooled=None, dws=None, dbs=None):
+    """ConvMeanPool input gradient whose only consumer is the filter gradient of the 3-channel-input 3x3 conv in front: nothing is
+    stored; dw1 fp32 [3,3,3,Cin] / db1 [Cin] (and, with x_pooled, the 1x1 shortcut's dws [1,1,3,Cout] / dbs) are ACCUMULATED."""
+    n, hp, wp, cout = dy.shape
+    cin = relu_ref.shape[3]
+    assert tuple(relu_ref.shape) == (n, 2 * hp, 2 * wp, cin) and tuple(x_image.shape) == (n, 2 * hp, 2 * wp, 3), (relu_ref.shape, x_image.shape)
+    assert dw1.numel() == 27 * cin and (db1 is None or db1.numel() == cin)
+    assert x_pooled is None or (tuple(x_pooled.shape) == (n, hp, wp, 3) and dws is not None and dws.numel() == 3 * cout)
+    _lib.check(lib().gank_cpool_res_dgrad_image_wgrad(_p(dy, BF16, "dy"), _p(rd, BF16, "rd"), _p(relu_ref, BF16, "relu_ref"),
+                                                      _p(x_image, BF16, "x_image"), _p(dw1, F32, "dw1"), _p(db1, F32, "db1"),
+                                                      _p(x_pooled, BF16, "x_pooled"), _p(dws, F32, "dws"), _p(dbs, F32, "dbs"),
+                                                      n, hp, wp, cin, cout, _stream()), "cpool_res_dgrad_image_wgrad")
+
+
 def convpool3x3_wgrad(x, dy, dw, flags=0, dbias=None):
     """ACCUMULATES the ConvMeanPool 3x3 filter gradient into dw fp32 [3,3,Cin,Cout] (and dbias)."""
     n, hp, wp, cout = dy.shape

@@ -212,6 +212,16 @@ int gank_cpool_res_fprop(const void* x, const void* w_rfrag, const float* bias, 
                          int Wp, int Cin, int Cout, int flags, void* stream);
 int gank_cpool_res_dgrad(const void* dy, const void* w_rfrag, const void* relu_ref, void* dx, int N, int Hp, int Wp, int Cin,
                          int Cout, void* stream);
+/* The same input gradient when its ONLY consumer is the filter gradient of a 3x3 conv on a 3-channel image in front of it
+ * (OptimizedResBlockDisc1 in a critic update, SNGAN/gan_cifar_resnet.py:212-234; tf.gradients of disc_cost w.r.t.
+ * D.Block.1.Conv1 / D.Block.1.Shortcut, :523-526): dx is never stored -- each finished tile (masked by relu_ref > 0, rounded to the
+ * activation dtype as the stored tensor was) feeds  dw1 [3,3,3,Cin] += x_image (*) dx  and  db1 [Cin] += sum dx  inside the launch;
+ * with x_pooled [N,Hp,Wp,3] also the 1x1 shortcut conv whose output gradient dy is:  dws [1,1,3,Cout] += x_pooled^T dy,
+ * dbs [Cout] += sum dy.  x_image [N,2Hp,2Wp,3]; Wp == 16, Hp % 8 == 0, Cout == 128, Cin % 128 == 0; db1 / x_pooled / dws / dbs
+ * optional.  fp32 atomics (one [32][Cin] tile per workgroup). */
+int gank_cpool_res_dgrad_image_wgrad(const void* dy, const void* w_rfrag, const void* relu_ref, const void* x_image, float* dw1,
+                                     float* db1, const void* x_pooled, float* dws, float* dbs, int N, int Hp, int Wp, int Cin,
+                                     int Cout, void* stream);
 
 /* ---- UpsampleConv 3x3 (SNGAN/gan_cifar_resnet.py:140-153) as a stride-2 transposed conv -------------
  * nearest-neighbour 2x followed by a 3x3 SAME conv equals a 4x4 stride-2 transposed conv whose taps are sums

@@ -1604,3 +1604,63 @@ def test_concat_label_with_the_next_blocks_fan_out(K):
     da2, de2 = K.concat_label_unpool_bwd(None, gpt, c1)
     da2_ref, de2_ref = K.concat_label_bwd(K.unpool2x2_add(gpt, None, 0.25), c1)
     assert torch.equal(da2.view(torch.int16), da2_ref.view(torch.int16)) and relerr(de2, de2_ref.double().cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("n,hp,cin,shortcut,bias", [(3, 16, 128, True, True), (2, 8, 128, False, True), (5, 16, 256, True, False), (128, 16, 128, True, True)])
+def test_convpool_input_gradient_with_the_image_convs_filter_gradient_inside(K, n, hp, cin, shortcut, bias):
+    """gank_cpool_res_dgrad_image_wgrad (round 5): the ConvMeanPool input gradient of OptimizedResBlockDisc1 in a critic update
+    (gan_cifar_resnet.py:212-234) never stores its result; the launch accumulates the filter / bias gradient of the 3x3 conv on the
+    3-channel image in front (dw1, db1) and of the 1x1 shortcut conv on the pooled image (dws, dbs).  Oracle: float64 gradients of
+    the un-reduced composition, fed the tensor the UNFUSED path stores (the oracle's masked input gradient rounded to bf16 --
+    the fused kernel rounds its tiles the same way), tolerance of an fp32 sum of bf16 products; and against the two-launch path
+    (gank_cpool_res_dgrad + gank_conv2d_wgrad_narrow_pair) on the same inputs; accumulation into non-zero buffers."""
+    wp, cout = 16, 128
+    rng = np.random.default_rng(n * 7 + hp + cin)
+    img, imgt = bf(rng.normal(size=(n, 2 * hp, 2 * wp, 3)))
+    h1, h1t = bf(rng.normal(size=(n, 2 * hp, 2 * wp, cin)))                  # Conv1's output = the relu reference
+    w2, _ = bf(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin))
+    dy, dyt = bf(rng.normal(size=(n, hp, wp, cout)))
+    pooled = R.meanpool2x2(img)
+    pooled, pooledt = bf(pooled)
+    w2t = torch.tensor(w2, dtype=torch.float32).cuda()
+    (rf, rd), = K.prep_weights_batched([w2t], want_d=True, kinds=[5])
+    assert K.cpool_res_dgrad_image_wgrad_ok(dyt, cin)
+    # reference: dh = mask * dgrad(ConvMeanPool), rounded as the stored tensor; then the two filter gradients
+    dh_ref, _, _ = R.conv2d_same_grads(R.relu(h1), w2, R.meanpool2x2_grad(dy))
+    dh_ref = dh_ref * (h1 > 0)
+    dh_b = torch.tensor(dh_ref, dtype=torch.float32).to(torch.bfloat16).to(torch.float64).numpy()
+    _, rdw1, rdb1 = R.conv2d_same_grads(img, np.zeros((3, 3, 3, cin)), dh_b)
+    rdws = np.einsum('nhwc,nhwo->co', pooled, dy).reshape(1, 1, 3, cout)
+    rdbs = dy.sum((0, 1, 2))
+    w0, b0 = rng.normal(size=(3, 3, 3, cin)).astype(np.float32), rng.normal(size=cin).astype(np.float32)       # non-zero targets
+    ws0, bs0 = rng.normal(size=(1, 1, 3, cout)).astype(np.float32), rng.normal(size=cout).astype(np.float32)
+    dw1, db1 = torch.tensor(w0).cuda(), torch.tensor(b0).cuda()
+    dws, dbs = torch.tensor(ws0).cuda(), torch.tensor(bs0).cuda()
+    K.cpool_res_dgrad_image_wgrad(dyt, rd, h1t, imgt, dw1, db1 if bias else None, pooledt if shortcut else None,
+                                  dws if shortcut else None, dbs if (shortcut and bias) else None)
+    torch.cuda.synchronize()
+    # a few tiles of dh differ from the oracle's rounding by one bf16 ulp where the fp32 sum sits on a rounding boundary: the bound
+    # is the bf16-output one on the sum's scale, not the fp32-from-identical-bf16 one
+    assert relerr(dw1 - torch.tensor(w0).cuda(), rdw1) < 4e-3, relerr(dw1 - torch.tensor(w0).cuda(), rdw1)
+    if bias:
+        assert relerr(db1 - torch.tensor(b0).cuda(), rdb1) < 4e-3
+    else:
+        assert torch.equal(db1.cpu(), torch.tensor(b0))
+    if shortcut:
+        assert relerr(dws - torch.tensor(ws0).cuda(), rdws) < F32_FROM_BF_TOL
+        if bias:
+            assert relerr(dbs - torch.tensor(bs0).cuda(), rdbs) < F32_FROM_BF_TOL
+    else:
+        assert torch.equal(dws.cpu(), torch.tensor(ws0)) and torch.equal(dbs.cpu(), torch.tensor(bs0))
+    # the two-launch path on the same inputs
+    dx = K.cpool_res_dgrad(dyt, rd, cin, h1t)
+    u1, ub1 = torch.zeros((3, 3, 3, cin), device="cuda"), torch.zeros(cin, device="cuda")
+    us, ubs = torch.zeros((1, 1, 3, cout), device="cuda"), torch.zeros(cout, device="cuda")
+    K.conv2d_wgrad(imgt, dx, u1, (2 * hp, 2 * wp), 3, 0, 1.0, dbias=ub1)
+    K.conv2d_wgrad(pooledt, dyt, us, (hp, wp), 1, 0, 1.0, dbias=ubs)
+    torch.cuda.synchronize()
+    assert relerr(dw1 - torch.tensor(w0).cuda(), u1.double().cpu().numpy()) < 1e-3           # same bf16 operands, other summation order
+    if bias:
+        assert relerr(db1 - torch.tensor(b0).cuda(), ub1.double().cpu().numpy()) < 1e-3
+    if shortcut:
+        assert relerr(dws - torch.tensor(ws0).cuda(), us.double().cpu().numpy()) < 1e-3

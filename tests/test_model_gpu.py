@@ -808,3 +808,54 @@ def test_get_loss_least_squares_and_sigmoid_branches(gpu):
         g_loss.backward()
         (gg,) = torch.autograd.grad(g_ref, [ff])
         assert float((f2.grad.double().cpu() - gg).abs().max()) < 1e-2 * float(gg.abs().max()) + 1e-6, kind
+
+
+def test_image_side_filter_gradients_inside_the_convmeanpool_input_gradient(gpu, monkeypatch):
+    """functional.FUSE_IMAGE_WGRAD (round 5): in a critic update D.Block.1.Conv1's and D.Block.1.Shortcut's filter / bias gradients
+    come out of the ConvMeanPool input-gradient launch (gank_cpool_res_dgrad_image_wgrad; the 33.5-MB tensor between them is never
+    stored).  Same inputs, same state: the fused launch IS taken (once per critic pass), every critic gradient equals the
+    two-launch path's up to summation order (relative L2 <= 2e-3 per tensor; the four tensors concerned are printed), the loss is
+    identical; the generator update -- where the image needs a gradient -- does not take it."""
+    from gan_lib_tensorflow_amd import functional as Fn
+    from gan_lib_tensorflow_amd import kernels as K
+    seed, b = 33, 16
+    S, tr, state = make_trainer(seed, b)
+    rng = np.random.default_rng(12)
+    z = bf16r(rng.normal(size=(b, 128))).cuda()
+    labels = torch.tensor(rng.integers(0, 10, b), dtype=torch.int32)
+    real_u8 = torch.tensor(rng.integers(0, 256, (b, 3072)), dtype=torch.uint8)
+    real_pre = bf16r(T.preprocess_real(real_u8, torch.zeros(b, 3072, dtype=torch.float64), torch.float64).numpy()).cuda()
+    tr.real_labels.copy_(labels)
+    with torch.no_grad():       # ONE set of fakes for both passes (the generator's epilogue statistics are summed by atomics: two passes differ in the last bit)
+        fake = S.Generator(b, tr.real_labels, noise=z, groups=2)
+    calls = []
+    orig = K.cpool_res_dgrad_image_wgrad
+    monkeypatch.setattr(K, "cpool_res_dgrad_image_wgrad", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    u0 = {k: v.clone() for k, v in tr.store.vars.items() if k.endswith('spectral_norm/u')}
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setattr(Fn, "FUSE_IMAGE_WGRAD", fused)
+        for k, v in u0.items():
+            tr.store.vars[k].copy_(v)                  # update_collection=None advanced u: both passes start from the same state
+        calls.clear()
+        tr._d_forward_backward(real_pre=real_pre, fake=fake)
+        torch.cuda.synchronize()
+        assert len(calls) == (1 if fused else 0), (fused, len(calls))
+        out[fused] = (float(tr.d_loss), tr.d_flat["grads"].double().clone())
+    assert out[True][0] == out[False][0]
+    names = tr.d_flat['names']
+    worst = {}
+    for k in names:
+        o, nel = tr.d_flat['offsets'][k], tr.store.vars[k].numel()
+        a, r = out[True][1][o:o + nel], out[False][1][o:o + nel]
+        if float(r.norm()) > 1e-12:
+            worst[k] = float((a - r).norm() / r.norm())
+    print("fused vs two-launch image-side gradients:", {k.split('/', 1)[1]: f"{v:.1e}" for k, v in worst.items() if 'D.Block.1.Conv1' in k or 'D.Block.1.Shortcut' in k})
+    others = {k: v for k, v in worst.items() if 'D.Block.1.Conv1' not in k and 'D.Block.1.Shortcut' not in k}
+    assert max(others.values()) < 1e-4, sorted(others.items(), key=lambda kv: -kv[1])[:4]            # everything else: the same launches, atomics order only
+    assert max(worst.values()) < 2e-3, sorted(worst.items(), key=lambda kv: -kv[1])[:4]
+    monkeypatch.setattr(Fn, "FUSE_IMAGE_WGRAD", True)
+    calls.clear()
+    tr._g_forward_backward()
+    torch.cuda.synchronize()
+    assert len(calls) == 0 and bool(torch.isfinite(tr.g_flat["grads"]).all()) and float(tr.g_flat["grads"].abs().sum()) > 0
