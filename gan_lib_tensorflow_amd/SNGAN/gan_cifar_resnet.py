@@ -138,6 +138,7 @@ def _g_prep_kind(name, W):
     return 0
 
 
+FUSE_SN_TAIL = True    # critic update: spectral-norm backward apply + TF-Adam + the NEXT pass's power iteration as ONE launch (gank_sn_adam_fwd_a)
 LABEL_TABLE = True    # the critic's label branch through a per-label table (0: per-sample embedding + dense layer + tile)
 FUSED_HEAD = True      # D.Output + hinge loss (+ the layer's three gradients) as one launch where the train step asks for it
 HEAD_IN_CHAIN = True   # ... and that launch folded into the fused 8x8 chain's forward / backward launches (functional.HingeHeadSpec)
@@ -231,12 +232,24 @@ class AdamTF:
         self.t = torch.zeros(1, dtype=torch.int64, device=dev)
         # {non-finite gradients, zero gradients} seen so far (loss-scaled runs: overflow / underflow watch); None = not counted
         self.health = torch.zeros(2, dtype=torch.int64, device=dev) if health else None
+        self.pending_sn = None       # a batched spectral norm whose backward apply this optimiser's next launch performs (functional.defer_sn_apply)
+        self.sn_state = None         # the network's persistent spectral-norm state, if any: a plain step invalidates it
 
     def apply(self):
         """One launch: the update, the step count, and the gradient buffer (with its scratch half) cleared for the next
-        backward pass -- `flat['clean']` tells the trainer that no fill is needed."""
+        backward pass -- `flat['clean']` tells the trainer that no fill is needed.  With a deferred spectral-norm backward
+        pending, the launch is gank_sn_adam_fwd_a: that backward's apply step, this update, and the next forward pass's power
+        iteration on the updated weights."""
         f = self.flat
-        K.adam_tf(f["params"], f["grads_all"], f["m"], f["v"], self.hp, self.t, self.iteration, zero_grads=True, health=self.health)
+        batch, self.pending_sn = self.pending_sn, None
+        if batch is not None:
+            # (dw_zero: a spectrally normalised weight receives gradient through its normalised copy only, and this launch's
+            #  predecessor cleared the buffer: the weights' own gradient views are zero and are not touched)
+            batch.adam_fwd_a(f["params"], f["grads"], f["m"], f["v"], self.hp, self.t, self.iteration, health=self.health, dw_zero=True)
+        else:
+            if self.sn_state is not None:
+                self.sn_state.valid = False
+            K.adam_tf(f["params"], f["grads_all"], f["m"], f["v"], self.hp, self.t, self.iteration, zero_grads=True, health=self.health)
         f["clean"] = True
 
 
@@ -335,6 +348,13 @@ class SNGANTrainer:
         self.g_flat = self.store.flatten('Generator')
         self.d_flat = self.store.flatten('Discriminator', scratch_tail=True)
         self.store.flatten_state('Discriminator')      # the 12 SN u vectors: one buffer
+        self.sn_state = None
+        if FUSE_SN_TAIL and self.device.type == 'cuda':
+            # persistent spectral-norm workspaces: the critic's optimiser launch runs the NEXT forward pass's power iteration
+            pairs = _sn.sn_pairs(self.store, 'Discriminator')
+            u_flat = _sn._flat_base(self.store, 'Discriminator', [u for _, u in pairs])
+            if pairs and len(pairs) <= 16 and u_flat is not None and all(w.shape[-1] <= 256 for w, _ in pairs):
+                self.sn_state = self.store.sn_state['Discriminator'] = K.SnState([w for w, _ in pairs], [u for _, u in pairs], u_flat)
         # bf16 MFMA operand copies of the generator weights: rebuilt by ONE launch after each G update
         # (the generator runs 6 forwards per iteration on unchanged weights)
         self._g_convs = [(k, v) for k, v in self.store.vars.items()
@@ -344,6 +364,7 @@ class SNGANTrainer:
         scaled = self.loss_scale != 1.0
         self.g_opt = AdamTF(self.g_flat, self.iteration_dev, grad_scale=1.0 / (self.world * self.loss_scale), health=scaled)
         self.d_opt = AdamTF(self.d_flat, self.iteration_dev, grad_scale=1.0 / (self.world * self.loss_scale), health=scaled)
+        self.d_opt.sn_state = self.sn_state
         # static input buffers (graph replays read these addresses)
         self.real_u8 = torch.zeros((b, OUTPUT_DIM), dtype=torch.uint8, device=self.device)
         self.real_labels = torch.zeros(b, dtype=torch.int32, device=self.device)
@@ -407,6 +428,19 @@ class SNGANTrainer:
             self.feed_slot.zero_()
         self._refresh_g_prep()
         self._graphs.clear()
+
+    def sn_state_changed(self):
+        """Call after writing critic weights or u vectors behind the trainer's back (tests, tools): the power iteration the last
+        critic update ran ahead of time (kernels.SnState) no longer belongs to them."""
+        if self.sn_state is not None:
+            self.sn_state.valid = False
+
+    def _ensure_sn_state(self):
+        """Before replaying a captured update that contains a critic pass: a graph captured while the power iteration was already
+        done holds only the second spectral-norm launch, so the persistent state must be current -- after an eager pass that
+        assigned u without an update behind it (the dev-loss evaluation), or after sn_state_changed(), it is recomputed here."""
+        if self.sn_state is not None and not self.sn_state.valid:
+            self.sn_state.refresh()
 
     def health(self):
         """{'G': (non-finite, zero), 'D': (...)} gradient counts since the trainer was built (loss-scaled runs only; else None)"""
@@ -648,6 +682,7 @@ class SNGANTrainer:
                 self._capture_failed('bucketed generator update', e)
             return
         self._ensure_clean(self.g_flat)
+        self._ensure_sn_state()
         if isinstance(self._graphs['g_seg'], torch.cuda.CUDAGraph):
             self._graphs['g_seg'].replay()
         else:
@@ -682,6 +717,13 @@ class SNGANTrainer:
 
     def _run(self, key, fwd_bwd, opt, flat):
         """fwd+bwd (graph) -> [RCCL all-reduce] -> Adam (graph)."""
+        # critic updates outside data parallel: the spectral norm's backward apply rides on the optimiser launch (FUSE_SN_TAIL)
+        defer = opt if (FUSE_SN_TAIL and opt is self.d_opt and not self.dp and self.sn_state is not None) else None
+        fwd_bwd_plain = fwd_bwd
+
+        def fwd_bwd():
+            with Fn.defer_sn_apply(defer):
+                return fwd_bwd_plain()
         if not self.use_graphs:
             fwd_bwd()
             self._allreduce(flat)
@@ -735,6 +777,7 @@ class SNGANTrainer:
             return
         g1, g2 = self._graphs[key]
         self._ensure_clean(flat)
+        self._ensure_sn_state()
         g1.replay()
         if g2 is not None:
             self._allreduce(flat)

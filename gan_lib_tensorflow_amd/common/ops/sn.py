@@ -138,10 +138,17 @@ def precomputed(store, prefix, update_collection=None, prepare=True, prep_kind=N
     if label_dense is not None and len(pairs) <= 16:
         tab, wname, bias = label_dense
         label = (tab, [nm for _, _, nm in pairs].index(wname), bias)
+    # persistent workspaces of this network (kernels.SnState, registered by a trainer): a pass whose power iteration was already
+    # run by the previous update's optimiser launch runs its second launch only
+    state = getattr(store, "sn_state", {}).get(prefix)
+    if state is not None and (len(pairs) > 16 or not state.matches(Ws, [u.detach() for u in us])):
+        state = None
     if update_collection is None:
         # u <- u_final on every execution (sn.py:55-56): the kernels keep the u they read for the backward pass and
         # write u_final over u themselves -- no snapshot copy, no copy-back
-        W_bars, batch = Fn.spectral_norm_batch(Ws, [u.detach() for u in us], snapshot=True, inplace=True, prep=prep, label=label)
+        W_bars, batch = Fn.spectral_norm_batch(Ws, [u.detach() for u in us], snapshot=True, inplace=True, prep=prep, label=label, state=state)
+    elif update_collection == NO_OPS and state is not None:
+        W_bars, batch = Fn.spectral_norm_batch(Ws, [u.detach() for u in us], prep=prep, label=label, state=state)       # u is read, never written
     else:
         if update_collection != NO_OPS:
             if flat is not None:                      # one snapshot copy instead of one per weight

@@ -129,6 +129,19 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;
 }
 
+// tf.train.AdamOptimizer's step size (loss_opt.hip: adam_tf_kernel; sn.hip: the fused spectral-norm tail): hp = {lr, beta1,
+// beta2, eps, grad_scale, decay_on}; t_state[0] = steps taken so far; iteration[0] = the `_iteration` feed of the LR decay
+// (SNGAN/gan_cifar_resnet.py:454-459).
+__device__ __forceinline__ float adam_lr_t(const float* hp, const long long* t_state, const long long* iteration) {
+  const double t = (double)(t_state[0] + 1);
+  double lr = hp[0];
+  if (hp[5] != 0.f && iteration) {
+    const double it = (double)iteration[0];
+    lr *= (it < 50000.0) ? fmax(0.0, 1.0 - it / 100000.0) : 0.5;
+  }
+  return (float)(lr * sqrt(1.0 - pow((double)hp[2], t)) / (1.0 - pow((double)hp[1], t)));
+}
+
 // m -> (n, oh, ow) over an [N,H,W] pixel grid; shifts when H*W and W are powers of two (sw/shw >= 0)
 __device__ __forceinline__ void pix_decomp(int m, int H, int W, int shw, int sw, int& n, int& oh, int& ow) {
   if (shw >= 0 && sw >= 0) {

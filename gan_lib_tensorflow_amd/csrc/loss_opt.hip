@@ -282,15 +282,7 @@ extern "C" int gank_loss_grad_scale(const float* dlogits_f32, const float* g, vo
 //   lr_t  = lr * decay * sqrt(1 - beta2^t) / (1 - beta1^t),  t = t_state[0] + 1
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr_t m / (sqrt(v) + eps)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float adam_lr_t(const float* hp, const long long* t_state, const long long* iteration) {
-  const double t = (double)(t_state[0] + 1);
-  double lr = hp[0];
-  if (hp[5] != 0.f && iteration) {
-    const double it = (double)iteration[0];
-    lr *= (it < 50000.0) ? fmax(0.0, 1.0 - it / 100000.0) : 0.5;
-  }
-  return (float)(lr * sqrt(1.0 - pow((double)hp[2], t)) / (1.0 - pow((double)hp[1], t)));
-}
+// (adam_lr_t: gank_common.h -- shared with the fused spectral-norm / optimiser launch of sn.hip)
 
 // One launch per update: the step count advances and (zero_n > 0) the gradient buffer is cleared here too.  Every block
 // derives lr_t from t_state[0] BEFORE it takes a ticket (the value goes through LDS, so the load has completed); the block that

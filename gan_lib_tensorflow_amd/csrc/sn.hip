@@ -85,6 +85,81 @@ __device__ __forceinline__ float sn_row_sum(float p, int G) {
   return p;
 }
 
+// The last chunk block of a weight (ticket) finishes the power iteration from the published partial sums: n = |a|, b = W^T a / (n + eps),
+// m = |b|, u' -> u_out, sigma and the scalars of the backward pass.  Shared by forward A and the fused optimiser tail below, whose
+// u' goes to a staging buffer instead of over u.
+__device__ __forceinline__ void sn_fwd_a_finish(const gank_sn_desc& d, float* u_out, int nch, float* part, float* red, int tid) {
+  const int C = d.C;
+  const float* n2p = d.bpart + (long)nch * C;
+  float s = 0.f;
+  for (int j = tid; j < nch; j += 256) s += n2p[j];
+  const float n = sqrtf(block_sum(s, red));
+  float ss = 0.f;
+  if (sn_pow2_c(C) && sn_al16(d.bpart)) {
+    // all 256 threads: thread t sums the f32x4 piece (t mod C/4) of the chunks j = t / (C/4), + 1024/C, ... -- every load of
+    // the block in flight at once (up to 36 chunks x 1 KB: one L2 round trip instead of five); then the column-group
+    // reduction of the main body
+    const int G = C >> 2, lc = __builtin_ctz(C), reps = 1024 >> lc;
+    const int g = tid & (G - 1), j0 = tid >> (lc - 2);
+    f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+    for (int jb = j0; jb < nch; jb += 16 * reps) {
+      f32x4 tt[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const int j = jb + u * reps;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        tt[u] = j < nch ? *reinterpret_cast<const f32x4*>(d.bpart + (long)j * C + 4 * g) : z;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; u++) acc4 += tt[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; e++) part[tid * 4 + e] = acc4[e];
+    __syncthreads();
+    if (tid < C) {
+      const int gg = tid >> 2, e = tid & 3;
+      float su = 0.f;
+      for (int j = 0; j < reps; j++) su += part[(j * G + gg) * 4 + e];
+      const float bb = su / (n + SN_EPS);
+      d.b[tid] = bb;
+      ss = bb * bb;
+    }
+  } else {
+    for (int c = tid; c < C; c += 256) {
+      float su = 0.f;
+      for (int jb = 0; jb < nch; jb += 8) {            // batches of 8 independent loads
+        float tt[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) tt[u] = d.bpart[(long)min(jb + u, nch - 1) * C + c];
+#pragma unroll
+        for (int u = 0; u < 8; u++) su += (jb + u < nch) ? tt[u] : 0.f;
+      }
+      const float bb = su / (n + SN_EPS);
+      d.b[c] = bb;
+      ss += bb * bb;
+    }
+  }
+  const float m2 = block_sum(ss, red);
+  const float m = sqrtf(m2);
+  float dot = 0.f;
+  for (int c = tid; c < C; c += 256) {
+    const float bb = d.b[c];                  // this thread's own store
+    const float un = bb / (m + SN_EPS);
+    u_out[c] = un;
+    dot += bb * un;
+  }
+  const float sigma = block_sum(dot, red);
+  if (tid == 0) {
+    const float sc = (m + 2.f * SN_EPS) / ((m + SN_EPS) * (m + SN_EPS));
+    d.scal[0] = sigma;
+    d.scal[1] = n;
+    d.scal[2] = m;
+    d.scal[3] = sc;
+    d.scal[5] = sc * (n + SN_EPS) * m2;       // a . g_v = s a^T W b = s (W^T a) . b = s (n+eps) |b|^2
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- forward A
 __global__ __launch_bounds__(256) void sn_fwd_a_kernel(SnTable t, unsigned* __restrict__ tickets) {
   __shared__ float sm[1024 + SN_ROWS + 16 + 4];
@@ -178,74 +253,7 @@ __global__ __launch_bounds__(256) void sn_fwd_a_kernel(SnTable t, unsigned* __re
   __syncthreads();
   if (!*flag) return;
 
-  const float* n2p = d.bpart + (long)nch * C;
-  float s = 0.f;
-  for (int j = tid; j < nch; j += 256) s += n2p[j];
-  const float n = sqrtf(block_sum(s, red));
-  float ss = 0.f;
-  if (sn_pow2_c(C) && sn_al16(d.bpart)) {
-    // all 256 threads: thread t sums the f32x4 piece (t mod C/4) of the chunks j = t / (C/4), + 1024/C, ... -- every load of
-    // the block in flight at once (up to 36 chunks x 1 KB: one L2 round trip instead of five); then the column-group
-    // reduction of the main body
-    const int G = C >> 2, lc = __builtin_ctz(C), reps = 1024 >> lc;
-    const int g = tid & (G - 1), j0 = tid >> (lc - 2);
-    f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
-    for (int jb = j0; jb < nch; jb += 16 * reps) {
-      f32x4 tt[16];
-#pragma unroll
-      for (int u = 0; u < 16; u++) {
-        const int j = jb + u * reps;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        tt[u] = j < nch ? *reinterpret_cast<const f32x4*>(d.bpart + (long)j * C + 4 * g) : z;
-      }
-#pragma unroll
-      for (int u = 0; u < 16; u++) acc4 += tt[u];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 4; e++) part[tid * 4 + e] = acc4[e];
-    __syncthreads();
-    if (tid < C) {
-      const int gg = tid >> 2, e = tid & 3;
-      float su = 0.f;
-      for (int j = 0; j < reps; j++) su += part[(j * G + gg) * 4 + e];
-      const float bb = su / (n + SN_EPS);
-      d.b[tid] = bb;
-      ss = bb * bb;
-    }
-  } else {
-    for (int c = tid; c < C; c += 256) {
-      float su = 0.f;
-      for (int jb = 0; jb < nch; jb += 8) {            // batches of 8 independent loads
-        float tt[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) tt[u] = d.bpart[(long)min(jb + u, nch - 1) * C + c];
-#pragma unroll
-        for (int u = 0; u < 8; u++) su += (jb + u < nch) ? tt[u] : 0.f;
-      }
-      const float bb = su / (n + SN_EPS);
-      d.b[c] = bb;
-      ss += bb * bb;
-    }
-  }
-  const float m2 = block_sum(ss, red);
-  const float m = sqrtf(m2);
-  float dot = 0.f;
-  for (int c = tid; c < C; c += 256) {
-    const float bb = d.b[c];                  // this thread's own store
-    const float un = bb / (m + SN_EPS);
-    d.u_out[c] = un;
-    dot += bb * un;
-  }
-  const float sigma = block_sum(dot, red);
-  if (tid == 0) {
-    const float sc = (m + 2.f * SN_EPS) / ((m + SN_EPS) * (m + SN_EPS));
-    d.scal[0] = sigma;
-    d.scal[1] = n;
-    d.scal[2] = m;
-    d.scal[3] = sc;
-    d.scal[5] = sc * (n + SN_EPS) * m2;       // a . g_v = s a^T W b = s (W^T a) . b = s (n+eps) |b|^2
-  }
+  sn_fwd_a_finish(d, d.u_out, nch, part, red, tid);
 }
 
 // ---------------------------------------------------------------------------------------------- forward B
@@ -268,6 +276,15 @@ struct SnPrepExtra {
   int prep_blocks;
 };
 // the per-label rows of a small dense layer on an embedding table: out[l] = bf16( bf16(table[l]) (W / sigma) + bias )
+// Consumer side of the fused optimiser tail (below): the power iteration of this forward pass was already run when the weights
+// were updated, its u' waits in a staging buffer.  u.assign(u_final) (sn.py:55-56) then is a flat copy over the concatenated u
+// vectors of the table, with the snapshot the backward pass reads taken first: u_snap <- u, u <- u_next (total floats).
+struct SnAdopt {
+  float* u;
+  float* u_snap;
+  const float* u_next;
+  int total, blocks;
+};
 struct SnLabelDense {
   const float* table;   // [V, D] fp32
   const float* W;       // [D, Cout] fp32 master weight
@@ -334,10 +351,21 @@ __device__ __forceinline__ void sn_label_row(const SnLabelDense& q, int l, int c
     q.out[(long)l * C + c] = f2bf((red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane]) / sg + (q.bias ? q.bias[c] : 0.f));
 }
 
-__global__ __launch_bounds__(256) void sn_fwd_b_kernel(SnScaleTable st, PrepTable pt, SnPrepExtra px, SnLabelDense ld) {
+__device__ __forceinline__ int ld_blocks(const SnLabelDense& ld) { return ld.table ? ld.V * ((ld.Cout + 63) >> 6) : 0; }
+
+__global__ __launch_bounds__(256) void sn_fwd_b_kernel(SnScaleTable st, PrepTable pt, SnPrepExtra px, SnLabelDense ld, SnAdopt ad) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if ((int)blockIdx.x >= st.nchunks) {
     const int pb = blockIdx.x - st.nchunks;
+    if (pb >= px.prep_blocks + ld_blocks(ld)) {      // u_snap <- u, u <- u_next (nothing else in this launch reads u)
+      const int i = (pb - px.prep_blocks - ld_blocks(ld)) * 256 + tid;
+      if (i < ad.total) {
+        const float uo = ad.u[i];
+        if (ad.u_snap) ad.u_snap[i] = uo;
+        ad.u[i] = ad.u_next[i];
+      }
+      return;
+    }
     if (pb < px.prep_blocks) {            // bf16 MFMA operand copies of W / sigma
       const int e = prep_batch_entry(pt, pb);
       const float* sp = px.sigma[0];
@@ -542,8 +570,10 @@ extern "C" long gank_sn_ws_floats(int K, int C) {
   return (nch * (C + 1) + nfine + 3) / 4 * 4;
 }
 
+// which = 1: forward A only, 2: forward B only (the power iteration's results are in the table's workspaces already: the fused
+// optimiser tail or a forward-A-only call put them there), 3: both.  adopt (B): see SnAdopt.
 static int sn_forward(const gank_sn_desc* table, int count, const gank_prep_desc* prep, const int* prep_weight, int prep_count,
-                      const gank_label_dense_desc* label, hipStream_t s) {
+                      const gank_label_dense_desc* label, hipStream_t s, int which = 3, const SnAdopt* adopt = nullptr) {
   GANK_REQUIRE(table && count > 0, "sn fwd: empty table");
   GANK_REQUIRE(prep_count == 0 || (prep && prep_weight), "sn fwd: preparation entries without their weight indices");
   GANK_REQUIRE(count <= SN_MAX || (prep_count == 0 && !label), "sn fwd: the fused preparation takes at most %d weights per call", SN_MAX);
@@ -565,7 +595,8 @@ static int sn_forward(const gank_sn_desc* table, int count, const gank_prep_desc
     const int n = count - base < SN_MAX ? count - base : SN_MAX;
     if (sn_fill(t, table + base, n, chunks, fine, false)) return 1;
     unsigned* tickets = tickets_base + (sn_ticket_group.fetch_add(1, std::memory_order_relaxed) % SN_TICKET_GROUPS) * SN_MAX;
-    hipLaunchKernelGGL(sn_fwd_a_kernel, dim3(chunks), dim3(256), 0, s, t, tickets);
+    if (which & 1) hipLaunchKernelGGL(sn_fwd_a_kernel, dim3(chunks), dim3(256), 0, s, t, tickets);
+    if (!(which & 2)) continue;
     SnScaleTable st{};
     st.count = n;
     st.nchunks = fine;
@@ -596,7 +627,12 @@ static int sn_forward(const gank_sn_desc* table, int count, const gank_prep_desc
       ld = SnLabelDense{label->table, d.W, d.scal, label->bias, (bf16*)label->out, label->V, label->D, d.C};
       label_blocks = label->V * ((d.C + 63) / 64);
     }
-    hipLaunchKernelGGL(sn_fwd_b_kernel, dim3(fine + px.prep_blocks + label_blocks), dim3(256), 0, s, st, pt, px, ld);
+    SnAdopt ad{};
+    if (base == 0 && adopt && adopt->total > 0) {
+      ad = *adopt;
+      ad.blocks = (ad.total + 255) / 256;
+    }
+    hipLaunchKernelGGL(sn_fwd_b_kernel, dim3(fine + px.prep_blocks + label_blocks + ad.blocks), dim3(256), 0, s, st, pt, px, ld, ad);
     GANK_LAUNCH_OK("sn_power_iter_fwd");
   }
   return 0;
@@ -623,6 +659,346 @@ extern "C" int gank_sn_power_iter_bwd(const gank_sn_desc* table, int count, void
     hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(fine), dim3(256), 0, s, t);
     GANK_LAUNCH_OK("sn_power_iter_bwd");
   }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- fused optimiser tail (round 5)
+// One critic update used to END with  sn_bwd_apply (dW += G/sigma - ...), adam_tf (a pass over the flat buffer) and BEGIN the next one
+// with  sn_fwd_a (row dots of the updated weights): three back-to-back passes over the same 6.8 MB, each a dependent 6-17 us step.
+// Here a block owns a 32-row chunk of one spectrally normalised weight: it applies the spectral norm's gradient to the chunk
+// (the arithmetic of sn_bwd_apply_kernel), takes the TF-Adam step on it (adam_tf_kernel's), clears the gradient slices it has
+// consumed (dW and dW_bar), and -- the updated rows still in registers -- computes its rows of a = W_new u and its partial
+// column sums of W_new^T a for the NEXT forward pass (sn_fwd_a_kernel's body); the last chunk of a weight (ticket) finishes that
+// power iteration into the table's workspaces, u' into a staging buffer (`u_next`: u itself is only advanced when a forward pass
+// with update_collection=None consumes it, sn.py:55-56).  The parameters outside the spectrally normalised weights (biases, the
+// embedding table) take their Adam step in extra blocks of the same launch.  Bit-identical to the three launches.
+struct SnAdamArgs {
+  float* p;               // flat parameter buffer [n]; every table entry's W lies inside it
+  float* m;
+  float* v;
+  float* hp;              // {lr, beta1, beta2, eps, grad_scale, decay_on, ticket, -}
+  long long* t_state;
+  const long long* iteration;
+  unsigned long long* health;
+  float* g;               // flat gradient buffer [n] (the table's dW are views of it)
+  float* u_next[SN_MAX];
+  long gap_lo[SN_MAX + 1], gap_hi[SN_MAX + 1];     // [lo, hi) element ranges of the flat buffer outside every table entry
+  int gap_block[SN_MAX + 2];                       // first extra block of gap i (4096 elements per block)
+  int ngaps, sn_blocks;
+  int dw_zero;            // every table entry's dW is known to be zero (nothing but this backward pass contributes): neither read nor cleared
+};
+
+__device__ __forceinline__ bool sn_adam_elem(float gg, float gs, float b1, float b2, float eps, float lr_t, bool health, float& pp, float& mm, float& vv,
+                                             unsigned& bad, unsigned& zero) {
+  if (health) {
+    bad += (gg - gg != 0.f) ? 1u : 0u;
+    zero += gg == 0.f ? 1u : 0u;
+    if (gg - gg != 0.f) return false;       // an overflowed element keeps p, m and v (adam_tf_kernel)
+  }
+  const float gr = gg * gs;
+  mm = b1 * mm + (1.f - b1) * gr;
+  vv = b2 * vv + (1.f - b2) * gr * gr;
+  pp -= lr_t * mm / (sqrtf(vv) + eps);
+  return true;
+}
+
+__global__ __launch_bounds__(256) void sn_adam_fwd_a_kernel(SnTable t, SnAdamArgs ad, unsigned* __restrict__ tickets) {
+  __shared__ float sm[1024 + SN_ROWS + 16 + 4];
+  __shared__ float s_lr;
+  float* part = sm;
+  float* as = sm + 1024;
+  float* red = sm + 1024 + SN_ROWS;
+  int* flag = reinterpret_cast<int*>(sm + 1024 + SN_ROWS + 16);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // every block derives the step size from the step count BEFORE it takes the optimiser's ticket (at the very end); the block that
+  // draws the last one knows that every block has read the count, advances it and resets the ticket (adam_tf_kernel).  The
+  // double-precision pow() behind the step size is ~1 us of one lane: a weight chunk's block issues its loads first.
+  const float b1 = ad.hp[1], b2 = ad.hp[2], eps = ad.hp[3], gs = ad.hp[4];
+  const bool health = ad.health != nullptr;
+  unsigned bad = 0u, zero = 0u;
+
+  if ((int)blockIdx.x >= ad.sn_blocks) {
+    // ---- plain TF-Adam on a 4096-element piece of a range outside the spectrally normalised weights
+    if (tid == 0) s_lr = adam_lr_t(ad.hp, ad.t_state, ad.iteration);
+    __syncthreads();
+    const float lr_t = s_lr;
+    const int eb = blockIdx.x - ad.sn_blocks;
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i <= SN_MAX; i++) gi += (i < ad.ngaps && eb >= ad.gap_block[i]) ? 1 : 0;
+    const long lo = ad.gap_lo[gi] + (long)(eb - ad.gap_block[gi]) * 4096, hi = min(ad.gap_hi[gi], lo + 4096);
+    for (long i = lo + tid; i < hi; i += 256) {
+      float pp = ad.p[i], mm = ad.m[i], vv = ad.v[i];
+      const float gg = ad.g[i];
+      ad.g[i] = 0.f;
+      if (sn_adam_elem(gg, gs, b1, b2, eps, lr_t, health, pp, mm, vv, bad, zero)) { ad.p[i] = pp; ad.m[i] = mm; ad.v[i] = vv; }
+    }
+  } else {
+    int ch;
+    const int wi = sn_find_chunk(t, blockIdx.x, ch);
+    const gank_sn_desc& d = t.d[wi];
+    float* u_next = ad.u_next[0];
+#pragma unroll
+    for (int i = 1; i < SN_MAX; i++) u_next = wi == i ? ad.u_next[i] : u_next;
+    const int K = d.K, C = d.C, k0 = ch * SN_ROWS, kn = min(SN_ROWS, K - k0), nch = (K + SN_ROWS - 1) / SN_ROWS;
+    const int nfine = (K + SN_FINE - 1) / SN_FINE;
+    float* __restrict__ W = const_cast<float*>(d.W) + (long)k0 * C;
+    float* __restrict__ G = const_cast<float*>(d.dW_bar) + (long)k0 * C;
+    float* __restrict__ dW = d.dW + (long)k0 * C;
+    const long off = (d.W - ad.p) + (long)k0 * C;
+    float* __restrict__ M = ad.m + off;
+    float* __restrict__ V = ad.v + off;
+    const float* gwp = d.bpart + (long)nch * C + nch;
+    const float* uold = d.u_snap ? d.u_snap : d.u_in;       // the u the finished forward pass read
+    const float* ucur = d.u_in;                             // the u the NEXT forward pass reads
+    float* bp = d.bpart + (long)ch * C;
+    float n2 = 0.f;
+    const bool fast = sn_pow2_c(C) && sn_al16(d.W) && sn_al16(d.dW_bar) && sn_al16(d.dW) && sn_al16(M) && sn_al16(V);
+    const int lc = fast ? __builtin_ctz(C) : 0, Gq = C >> 2;
+    const int L = max(1, (SN_ROWS * C) >> 10);       // <= 8 pieces per thread (C <= 256)
+    f32x4 w[8], mm[8], vv[8];                        // the chunk, its Adam slots: loaded, updated, stored behind the ticket
+    if (fast) {
+      const int col = (tid * 4) & (C - 1);
+      f32x4 g[8], o[8];
+      float sv[8], gak[8];
+      float b4[4], u4[4], c4[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) { b4[e] = d.b[col + e]; u4[e] = uold[col + e]; c4[e] = ucur[col + e]; }
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        if (i < L) {
+          const int flat = (i * 256 + tid) * 4, row = flat >> lc;
+          const bool ok = row < kn;
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          w[i] = ok ? *reinterpret_cast<const f32x4*>(W + flat) : z;
+          g[i] = ok ? *reinterpret_cast<const f32x4*>(G + flat) : z;
+          o[i] = (ok && !ad.dw_zero) ? *reinterpret_cast<const f32x4*>(dW + flat) : z;
+          mm[i] = ok ? *reinterpret_cast<const f32x4*>(M + flat) : z;
+          vv[i] = ok ? *reinterpret_cast<const f32x4*>(V + flat) : z;
+          sv[i] = ok ? d.v[k0 + row] : 0.f;
+          gak[i] = ok ? d.ga[k0 + row] : 0.f;
+        }
+      }
+      float s = 0.f;
+      for (int j = tid; j < nfine; j += 256) s += gwp[j];
+      if (tid == 0) s_lr = adam_lr_t(ad.hp, ad.t_state, ad.iteration);       // (visible behind the barriers of the sum below)
+      const float GW = block_sum(s, red);
+      const float lr_t = s_lr;
+      const float sigma = d.scal[0], sc = d.scal[3];
+      const float coef = GW / (sigma * sigma);
+      if (ch == 0 && tid == 0) d.scal[4] = GW;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        if (i < L) {
+          const int flat = (i * 256 + tid) * 4, row = flat >> lc;
+          if (row < kn) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              o[i][e] += g[i][e] / sigma - coef * ((sc * sv[i]) * b4[e] + gak[i] * u4[e]);       // sn_bwd_apply_kernel
+              float pp = w[i][e], m1 = mm[i][e], v1 = vv[i][e];
+              sn_adam_elem(o[i][e], gs, b1, b2, eps, lr_t, health, pp, m1, v1, bad, zero);
+              w[i][e] = pp; mm[i][e] = m1; vv[i][e] = v1;
+            }
+          }
+        }
+      }
+      // (the updated chunk stays in registers: its stores are issued BEHIND the ticket below, so that the publication of the
+      //  partial sums does not wait for 80 KB of parameter / slot / cleared-gradient stores to drain)
+      // ---- forward A of the next pass on the updated rows (sn_fwd_a_kernel's register-tile body)
+      float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        if (i < L) {
+          const int row = ((i * 256 + tid) * 4) >> lc;
+          float pq = ((w[i][0] * c4[0] + w[i][1] * c4[1]) + w[i][2] * c4[2]) + w[i][3] * c4[3];
+          pq = sn_row_sum(pq, Gq);
+          if (col == 0 && row < kn) { d.a[k0 + row] = pq; n2 += pq * pq; }
+#pragma unroll
+          for (int e = 0; e < 4; e++) s4[e] += pq * w[i][e];      // rows past kn hold zeros
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 4; e++) part[tid * 4 + e] = s4[e];
+      __syncthreads();
+      if (tid < C) {
+        const int gq = tid >> 2, e = tid & 3, reps = 1024 >> lc;
+        float su = 0.f;
+        for (int j = 0; j < reps; j++) su += part[(j * Gq + gq) * 4 + e];
+        sn_store_wt(bp + tid, su);
+      }
+    } else {
+      // ---- any other shape (C = 1 of the critic's last dense layer, 256-wide layers, unaligned slices): element-wise apply + Adam,
+      // then sn_fwd_a_kernel's generic body on the values just written (the storing thread re-reads its own elements; the column
+      // pass reads rows other lanes wrote: ordered by the barrier, through L2 -- stores write through the L1)
+      float s = 0.f;
+      for (int j = tid; j < nfine; j += 256) s += gwp[j];
+      if (tid == 0) s_lr = adam_lr_t(ad.hp, ad.t_state, ad.iteration);
+      const float GW = block_sum(s, red);
+      const float lr_t = s_lr;
+      const float sigma = d.scal[0], sc = d.scal[3];
+      const float coef = GW / (sigma * sigma);
+      if (ch == 0 && tid == 0) d.scal[4] = GW;
+      const int total = kn * C;
+      for (int q = tid; q < total; q += 256) {
+        const int r = q / C, c = q - r * C;
+        const float gg = (ad.dw_zero ? 0.f : dW[q]) + (G[q] / sigma - coef * (sc * d.v[k0 + r] * d.b[c] + d.ga[k0 + r] * uold[c]));
+        float pp = W[q], m1 = M[q], v1 = V[q];
+        if (sn_adam_elem(gg, gs, b1, b2, eps, lr_t, health, pp, m1, v1, bad, zero)) {
+          __hip_atomic_store(W + q, pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          M[q] = m1; V[q] = v1;
+        }
+        if (!ad.dw_zero) dW[q] = 0.f;
+        G[q] = 0.f;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      for (int r = wave; r < kn; r += 4) {
+        float sd = 0.f;
+        for (int c = lane; c < C; c += 64) sd += __hip_atomic_load(W + (long)r * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * ucur[c];
+        sd = wave_sum(sd);
+        if (lane == 0) { as[r] = sd; d.a[k0 + r] = sd; n2 += sd * sd; }
+      }
+      __syncthreads();
+      for (int c = tid; c < C; c += 256) {
+        float su = 0.f;
+        for (int r = 0; r < kn; r++) su += as[r] * __hip_atomic_load(W + (long)r * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sn_store_wt(bp + c, su);
+      }
+    }
+    n2 = block_sum(n2, red);
+    if (tid == 0) sn_store_wt(d.bpart + (long)nch * C + ch, n2);
+    // publish, ticket, finish (as sn_fwd_a_kernel)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      int last = 1;
+      if (nch > 1) {
+        const unsigned tk = __hip_atomic_fetch_add(tickets + wi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = tk == (unsigned)(nch - 1);
+        if (last) {
+          __hip_atomic_store(tickets + wi, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+      *flag = last;
+    }
+    if (fast) {          // the updated chunk, its slots, the cleared gradient slices: beside the ticket's round trip
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        if (i < L) {
+          const int flat = (i * 256 + tid) * 4, row = flat >> lc;
+          if (row < kn) {
+            *reinterpret_cast<f32x4*>(W + flat) = w[i];
+            *reinterpret_cast<f32x4*>(M + flat) = mm[i];
+            *reinterpret_cast<f32x4*>(V + flat) = vv[i];
+            if (!ad.dw_zero) *reinterpret_cast<f32x4*>(dW + flat) = z4;
+            *reinterpret_cast<f32x4*>(G + flat) = z4;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (*flag) sn_fwd_a_finish(d, u_next, nch, part, red, tid);
+  }
+  if (health) {           // one pair of atomics per wave that saw anything (adam_tf_kernel)
+    const unsigned long long b64 = (unsigned long long)wave_sum((float)bad);
+    const unsigned long long z64 = (unsigned long long)wave_sum((float)zero);
+    if ((threadIdx.x & 63) == 0) {
+      if (b64) atomicAdd(ad.health, b64);
+      if (z64) atomicAdd(ad.health + 1, z64);
+    }
+  }
+  // the optimiser's ticket LAST (the step count was read into s_lr at the top, through LDS: the load has completed): ~360 same-address
+  // atomics whose return a block would otherwise wait for in front of its first barrier
+  if (tid == 0) {
+    unsigned* ticket = reinterpret_cast<unsigned*>(ad.hp + 6);
+    if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+      *ticket = 0u;
+      ad.t_state[0] += 1;
+    }
+  }
+}
+
+static unsigned* sn_ticket_base() {
+  static std::atomic<unsigned*> ticket_addr[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  unsigned* base = ticket_addr[dev & 63].load(std::memory_order_relaxed);
+  if (!base) {
+    if (hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(sn_tickets)) != hipSuccess || !base) return nullptr;
+    ticket_addr[dev & 63].store(base, std::memory_order_relaxed);
+  }
+  return base;
+}
+
+extern "C" int gank_sn_power_iter_fwd_a(const gank_sn_desc* table, int count, void* stream) {
+  return sn_forward(table, count, nullptr, nullptr, 0, nullptr, (hipStream_t)stream, 1);
+}
+
+extern "C" int gank_sn_power_iter_fwd_b_prep(const gank_sn_desc* table, int count, const gank_prep_desc* prep, const int* prep_weight,
+                                             int prep_count, const gank_label_dense_desc* label, float* u_flat, float* u_snap_flat,
+                                             const float* u_next_flat, int u_total, void* stream) {
+  GANK_REQUIRE(count <= SN_MAX, "sn fwd b: at most %d weights per call", SN_MAX);
+  GANK_REQUIRE(u_total == 0 || (u_flat && u_next_flat), "sn fwd b: adopting u' needs the flat u and staging buffers");
+  SnAdopt ad{};
+  ad.u = u_flat; ad.u_snap = u_snap_flat; ad.u_next = u_next_flat; ad.total = u_total;
+  return sn_forward(table, count, prep, prep_weight, prep_count, label, (hipStream_t)stream, 2, &ad);
+}
+
+extern "C" int gank_sn_power_iter_bwd_gw(const gank_sn_desc* table, int count, void* stream) {
+  GANK_REQUIRE(table && count > 0 && count <= SN_MAX, "sn bwd gw: 1..%d weights", SN_MAX);
+  SnTable t;
+  int chunks, fine;
+  if (sn_fill(t, table, count, chunks, fine, true)) return 1;
+  hipLaunchKernelGGL(sn_bwd_gw_kernel, dim3(fine), dim3(256), 0, (hipStream_t)stream, t);
+  GANK_LAUNCH_OK("sn_power_iter_bwd_gw");
+  return 0;
+}
+
+extern "C" int gank_sn_adam_fwd_a(const gank_sn_desc* table, int count, float* const* u_next, float* p, float* g, float* m, float* v, long n,
+                                  float* hp, int64_t* t_state, const int64_t* iteration, uint64_t* health, int flags, void* stream) {
+  GANK_REQUIRE(table && count > 0 && count <= SN_MAX && u_next && p && g && m && v && hp && t_state && n > 0, "sn_adam_fwd_a: bad arguments");
+  SnTable t;
+  int chunks, fine;
+  if (sn_fill(t, table, count, chunks, fine, true)) return 1;
+  SnAdamArgs ad{};
+  ad.p = p; ad.g = g; ad.m = m; ad.v = v; ad.hp = hp; ad.t_state = (long long*)t_state; ad.iteration = (const long long*)iteration;
+  ad.health = (unsigned long long*)health;
+  ad.sn_blocks = chunks;
+  ad.dw_zero = (flags & 1) ? 1 : 0;
+  // the table's weights, in buffer order, must be disjoint views of [p, p + n) whose gradient views sit at the same offsets of g
+  int order[SN_MAX];
+  for (int i = 0; i < count; i++) order[i] = i;
+  for (int i = 1; i < count; i++)
+    for (int j = i; j > 0 && t.d[order[j]].W < t.d[order[j - 1]].W; j--) { const int x = order[j]; order[j] = order[j - 1]; order[j - 1] = x; }
+  long pos = 0;
+  int blocks = 0;
+  for (int i = 0; i <= count; i++) {
+    long lo = n, len = 0;
+    if (i < count) {
+      const gank_sn_desc& d = t.d[order[i]];
+      GANK_REQUIRE(u_next[order[i]] && d.C <= 256, "sn_adam_fwd_a: weight %d: no staging buffer, or more than 256 columns", order[i]);
+      lo = d.W - p; len = (long)d.K * d.C;
+      GANK_REQUIRE(lo >= pos && lo + len <= n, "sn_adam_fwd_a: weight %d is not a disjoint view of the flat parameter buffer", order[i]);
+      GANK_REQUIRE(d.dW == g + lo, "sn_adam_fwd_a: weight %d: its gradient is not the view of the flat gradient buffer at the weight's offset", order[i]);
+      ad.u_next[order[i]] = u_next[order[i]];
+    }
+    if (lo > pos) {
+      ad.gap_lo[ad.ngaps] = pos; ad.gap_hi[ad.ngaps] = lo; ad.gap_block[ad.ngaps] = blocks;
+      blocks += (int)((lo - pos + 4095) / 4096);
+      ad.ngaps++;
+    }
+    pos = lo + len;
+  }
+  ad.gap_block[ad.ngaps] = blocks;
+  unsigned* tickets_base = sn_ticket_base();
+  if (!tickets_base) return gank_set_error("sn_adam_fwd_a: ticket words not found");
+  unsigned* tickets = tickets_base + (sn_ticket_group.fetch_add(1, std::memory_order_relaxed) % SN_TICKET_GROUPS) * SN_MAX;
+  hipLaunchKernelGGL(sn_adam_fwd_a_kernel, dim3(chunks + blocks), dim3(256), 0, (hipStream_t)stream, t, ad, tickets);
+  GANK_LAUNCH_OK("sn_adam_fwd_a");
   return 0;
 }
 

@@ -749,18 +749,49 @@ class _SpectralNorm(Function):
             tgts.append(tgt)
             rets.append(None if acc else tgt)
             gl.append(_c(g) if g is not None else torch.zeros_like(wb))
-        batch.backward(gl, tgts)
+        opt = SN_DEFER_APPLY
+        if (opt is not None and batch.state is not None and batch.inplace and batch.n <= 16 and all(r is None for r in rets)
+                and all(w.shape[-1] <= 256 for w in batch.weights)):
+            # the train step's optimiser launch applies the spectral norm's gradient itself (gank_sn_adam_fwd_a): only the
+            # <dW_bar, W> partials now.  Until that launch the weights' gradient views hold NO spectral-norm contribution.
+            batch.backward_gw(gl, tgts)
+            opt.pending_sn = batch
+        else:
+            batch.backward(gl, tgts)
         return (None, *rets)
 
 
-def spectral_norm_batch(Ws, us, snapshot=False, inplace=False, prep=None, label=None):
+SN_DEFER_APPLY = None     # an optimiser object (attribute `pending_sn`) whose next launch applies the spectral norm's backward pass itself
+
+
+class defer_sn_apply:
+    """with defer_sn_apply(optimiser): backward passes inside leave the second half of the batched spectral-norm backward to the
+    optimiser's launch (SNGANTrainer: AdamTF.apply -> gank_sn_adam_fwd_a).  None = off."""
+
+    def __init__(self, opt):
+        self.opt = opt
+
+    def __enter__(self):
+        global SN_DEFER_APPLY
+        self.prev, SN_DEFER_APPLY = SN_DEFER_APPLY, self.opt
+        if self.opt is not None:
+            self.opt.pending_sn = None
+        return self
+
+    def __exit__(self, *exc):
+        global SN_DEFER_APPLY
+        SN_DEFER_APPLY = self.prev
+        return False
+
+
+def spectral_norm_batch(Ws, us, snapshot=False, inplace=False, prep=None, label=None, state=None):
     """Ws: fp32 weights (Cout last); us: fp32 [.., C] vectors READ by this call (pass snapshots if the
     stored u is overwritten before backward, or let the kernels keep one: snapshot=True; inplace=True writes
     u_final straight over `us`).  prep = (kinds, want_d): the bf16 MFMA operand copies of the normalised weights come
     out of the same launch pair (kernels.prep_weights_batched's kinds; they land on the W_bar tensors).  label = (embedding
     table, index of the dense weight in Ws, bias | None): the per-label rows of that dense layer too (`W_bar._label_T`).
     Returns (W_bars tuple, SnBatch)."""
-    batch = K.SnBatch(list(Ws), [u.detach() for u in us], snapshot, inplace)
+    batch = K.SnBatch(list(Ws), [u.detach() for u in us], snapshot, inplace, state=state)
     batch.prep, batch.label = prep, label
     outs = _SpectralNorm.apply(batch, *Ws)
     for o, wb in zip(outs, batch.W_bar):      # autograd hands out fresh tensor objects: carry the operand copies over

@@ -710,28 +710,77 @@ def colsum(x2d, out, scale=1.0):
 
 
 # ------------------------------------------------------------------ spectral norm
+class SnState:
+    """PERSISTENT spectral-norm workspaces of one network (a, b, v, ga, scal, bpart, the u snapshot and a staging buffer for
+    u'), owned by a trainer, so that the end of one update can run the power iteration of the NEXT forward pass
+    (gank_sn_adam_fwd_a: spectral-norm backward + Adam + forward A in one launch).  `valid`: the workspaces hold the power
+    iteration of the CURRENT (W, u) and `u_next` its u'; a forward pass then runs its second launch only, and when it is one
+    that assigns u (update_collection=None) it adopts u' and clears the flag.  Only the fused tail and `refresh()` set it;
+    whoever changes the weights or u behind the trainer's back (load_state_dict, tests writing into the variables) clears it
+    (`SNGANTrainer.sn_state_changed`).  `u_flat`: the concatenated u vectors (ParamStore.flatten_state), `us` its views."""
+
+    def __init__(self, weights, us, u_flat):
+        self.weights, self.us, self.u_flat = list(weights), [u.detach() for u in us], u_flat
+        dev = self.weights[0].device
+        self.n = len(self.weights)
+        assert self.n <= 16
+        self.KC = [(w.numel() // w.shape[-1], w.shape[-1]) for w in self.weights]
+        kt, ct = sum(k for k, _ in self.KC), sum(c for _, c in self.KC)
+        assert ct == u_flat.numel() and all(u.data_ptr() == u_flat.data_ptr() + 4 * o for u, o in zip(self.us, self._coffs()))
+        self.v, self.a, self.ga = (torch.empty(kt, dtype=F32, device=dev) for _ in range(3))
+        self.b, self.u_snap, self.u_next = (torch.empty(ct, dtype=F32, device=dev) for _ in range(3))
+        self.scal = torch.zeros(self.n * 8, dtype=F32, device=dev)
+        self.ws = [int(lib().gank_sn_ws_floats(k, c)) for k, c in self.KC]
+        self.bpart = torch.empty(sum(self.ws), dtype=F32, device=dev)
+        self.valid = False
+        self._key = tuple(w.data_ptr() for w in self.weights) + tuple(u.data_ptr() for u in self.us)
+
+    def _coffs(self):
+        out, o = [], 0
+        for _, c in self.KC:
+            out.append(o)
+            o += c
+        return out
+
+    def matches(self, weights, us):
+        return len(weights) == self.n and tuple(w.data_ptr() for w in weights) + tuple(u.data_ptr() for u in us) == self._key
+
+    def refresh(self):
+        """forward A alone on the current (W, u): u' -> u_next, nothing else moves"""
+        SnBatch(self.weights, self.us, state=self).forward_a_only()
+        self.valid = True
+
+
 class SnBatch:
     """Workspaces + descriptor table for one batched spectral-norm call over several weights."""
 
-    def __init__(self, weights, us, snapshot=False, inplace=False):
+    def __init__(self, weights, us, snapshot=False, inplace=False, state=None):
         """snapshot: the kernels keep their own copy of u for the backward pass; inplace: u_final is written straight
-        over `us` (needs snapshot when a backward pass follows): u.assign(u_final) without clone/copy launches."""
+        over `us` (needs snapshot when a backward pass follows): u.assign(u_final) without clone/copy launches.
+        state: an SnState for exactly these weights and u vectors -- its persistent workspaces are used instead of fresh ones."""
         self.weights, self.us = list(weights), list(us)
         dev = self.weights[0].device
         self.n = len(self.weights)
         self.KC = [(w.numel() // w.shape[-1], w.shape[-1]) for w in self.weights]
         tot = lambda f: sum(f(k, c) for k, c in self.KC)  # noqa: E731
         self.W_bar = [torch.empty_like(w) for w in self.weights]
-        self.u_out = torch.empty(tot(lambda k, c: c), dtype=F32, device=dev)
-        self.v = torch.empty(tot(lambda k, c: k), dtype=F32, device=dev)
-        self.a = torch.empty_like(self.v)
-        self.b = torch.empty_like(self.u_out)
-        self.scal = torch.empty(self.n * 8, dtype=F32, device=dev)     # every entry is plainly written before it is read
-        # partial column sums / |a|^2 / <G,W> per row chunk (the library says how many floats: 16-byte aligned regions)
+        self.state = state if (state is not None and state.matches(self.weights, self.us)) else None
         ws = [int(lib().gank_sn_ws_floats(k, c)) for k, c in self.KC]
-        self.bpart = torch.empty(sum(ws), dtype=F32, device=dev)
-        self.ga = torch.empty_like(self.v)
-        self.u_snap = torch.empty_like(self.u_out) if snapshot else None
+        if self.state is not None:
+            st = self.state
+            # u' of a pass that does not assign it goes to the staging buffer (the workspaces then stay consistent with (W, u))
+            self.u_out, self.v, self.a, self.b, self.scal, self.bpart, self.ga = st.u_next, st.v, st.a, st.b, st.scal, st.bpart, st.ga
+            self.u_snap = st.u_snap if snapshot else None
+        else:
+            self.u_out = torch.empty(tot(lambda k, c: c), dtype=F32, device=dev)
+            self.v = torch.empty(tot(lambda k, c: k), dtype=F32, device=dev)
+            self.a = torch.empty_like(self.v)
+            self.b = torch.empty_like(self.u_out)
+            self.scal = torch.empty(self.n * 8, dtype=F32, device=dev)     # every entry is plainly written before it is read
+            # partial column sums / |a|^2 / <G,W> per row chunk (the library says how many floats: 16-byte aligned regions)
+            self.bpart = torch.empty(sum(ws), dtype=F32, device=dev)
+            self.ga = torch.empty_like(self.v)
+            self.u_snap = torch.empty_like(self.u_out) if snapshot else None
         self.inplace = inplace
         self.prep = None          # (kinds, want_d): MFMA operand copies of the normalised weights from the same launch pair
         self.label = None         # (table fp32 [V,D], weight index, bias | None): per-label rows of a small dense layer
@@ -756,8 +805,15 @@ class SnBatch:
             ko, co, bo = ko + k, co + c, bo + ws[i]
         self._co = co
 
+    def forward_a_only(self):
+        _lib.check(lib().gank_sn_power_iter_fwd_a(self.table, self.n, _stream()), "sn_power_iter_fwd_a")
+
     def forward(self):
-        if self.prep is None and self.label is None:
+        st = self.state
+        b_only = st is not None and st.valid and self.n <= 16        # the power iteration of this (W, u) has been run already
+        if st is not None:
+            st.valid = b_only and not self.inplace                   # after this pass: u moved on (assigning pass), or nothing changed
+        if self.prep is None and self.label is None and not b_only:
             _lib.check(lib().gank_sn_power_iter_fwd(self.table, self.n, _stream()), "sn_power_iter_fwd")
             return self.W_bar
         # W / sigma, its bf16 MFMA operand copies and the label table in one launch pair: the operand entries read the
@@ -773,8 +829,17 @@ class SnBatch:
             self.label_out = torch.empty((v, self.KC[wi][1]), dtype=BF16, device=tab.device)
             ldesc = LabelDenseDesc(_p(tab.detach(), F32, "table").value, _p(bias.detach(), F32, "bias").value if bias is not None else None,
                                    self.label_out.data_ptr(), v, dd, wi)
-        _lib.check(lib().gank_sn_power_iter_fwd_prep(self.table, self.n, ptable, pw, len(todo), C.byref(ldesc) if ldesc is not None else None,
-                                                     _stream()), "sn_power_iter_fwd_prep")
+        if b_only:
+            # second launch only; an assigning pass adopts the staged u' (u_snap <- u, u <- u_next: flat copies)
+            adopt = self.inplace
+            _lib.check(lib().gank_sn_power_iter_fwd_b_prep(self.table, self.n, ptable, pw, len(todo), C.byref(ldesc) if ldesc is not None else None,
+                                                           _p(st.u_flat, F32, "u_flat") if adopt else None,
+                                                           _p(self.u_snap, F32, "u_snap") if (adopt and self.u_snap is not None) else None,
+                                                           _p(st.u_next, F32, "u_next") if adopt else None, st.u_flat.numel() if adopt else 0,
+                                                           _stream()), "sn_power_iter_fwd_b_prep")
+        else:
+            _lib.check(lib().gank_sn_power_iter_fwd_prep(self.table, self.n, ptable, pw, len(todo), C.byref(ldesc) if ldesc is not None else None,
+                                                         _stream()), "sn_power_iter_fwd_prep")
         _prep_attach(self.W_bar, kinds, todo, outs)
         if self.label is not None:
             self.W_bar[self.label[1]]._label_T = self.label_out
@@ -796,6 +861,30 @@ class SnBatch:
             self.table[i].dW_bar = _p(g, F32, "dW_bar").value
             self.table[i].dW = _p(d, F32, "dW").value
         _lib.check(lib().gank_sn_power_iter_bwd(self.table, self.n, _stream()), "sn_power_iter_bwd")
+
+    def backward_gw(self, dW_bars, dWs):
+        """first backward launch only (<dW_bar, W> partials); the apply step rides on the optimiser launch (sn_adam_fwd_a)"""
+        for i, (g, d) in enumerate(zip(dW_bars, dWs)):
+            self.table[i].dW_bar = _p(g, F32, "dW_bar").value
+            self.table[i].dW = _p(d, F32, "dW").value
+        _lib.check(lib().gank_sn_power_iter_bwd_gw(self.table, self.n, _stream()), "sn_power_iter_bwd_gw")
+
+    def adam_fwd_a(self, p, g, m, v, hp, t_state, iteration=None, health=None, dw_zero=False):
+        """gank_sn_adam_fwd_a after backward_gw: the spectral norm's gradient, TF-Adam over the WHOLE flat buffer (p, g, m, v; the
+        consumed gradients and dW_bar slices cleared) and the next forward pass's power iteration on the updated weights (u' ->
+        the state's staging buffer) in one launch.  Needs the persistent state and an assigning forward pass before it.
+        dw_zero: the caller guarantees the weights' own gradient views are zero (only this backward pass contributes to them)."""
+        st = self.state
+        assert st is not None and self.inplace and self.n <= 16
+        ptrs = (C.c_void_p * self.n)()
+        o = 0
+        for i, (_, c) in enumerate(self.KC):
+            ptrs[i] = st.u_next.data_ptr() + 4 * o
+            o += c
+        _lib.check(lib().gank_sn_adam_fwd_a(self.table, self.n, ptrs, _p(p, F32, "p"), _p(g, F32, "g"), _p(m, F32, "m"), _p(v, F32, "v"), p.numel(),
+                                            _p(hp, F32, "hp"), _p(t_state, torch.int64, "t_state"), _p(iteration, torch.int64, "iteration"),
+                                            _p(health, torch.int64, "health"), 1 if dw_zero else 0, _stream()), "sn_adam_fwd_a")
+        st.valid = True
 
 
 # ------------------------------------------------------------------ conditional batch norm

@@ -28,6 +28,7 @@ class ParamStore:
         self.rng = np.random.RandomState(seed)
         self._scope = []
         self.flat = {}                  # prefix -> dict(params=, grads=, names=, offsets=)
+        self.sn_state = {}              # prefix -> kernels.SnState: persistent spectral-norm workspaces a trainer registered (common/ops/sn.py)
 
     # ---- scopes -------------------------------------------------------------------------------
     @contextlib.contextmanager
@@ -80,6 +81,8 @@ class ParamStore:
 
     def load_state_dict(self, state, strict=True):
         """Name+shape matching restore (cf. optimistic_restore, common/misc.py:275-307)."""
+        for st in self.sn_state.values():
+            st.valid = False                # weights / u change: a power iteration run ahead of time is stale
         with torch.no_grad():
             for k, v in state.items():
                 if k not in self.vars:

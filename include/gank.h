@@ -362,6 +362,28 @@ typedef struct gank_label_dense_desc {
 } gank_label_dense_desc;
 int gank_sn_power_iter_fwd_prep(const gank_sn_desc* table, int count, const gank_prep_desc* prep, const int* prep_weight,
                                 int prep_count, const gank_label_dense_desc* label, void* stream);
+/* The pieces of the two passes, for a train step that folds the end of one critic update into the start of the next (round 5):
+ *   gank_sn_power_iter_fwd_a     : the first launch of the forward pass alone (power iteration into the table's workspaces, u' -> u_out);
+ *   gank_sn_power_iter_fwd_b_prep: the second launch alone (W / sigma, operand copies, label table) on workspaces a forward-A or the
+ *                                  fused tail below already filled; with u_total > 0 it also performs u.assign(u_final) (sn.py:55-56) as a
+ *                                  flat copy over the CONCATENATED u vectors of the table: u_snap_flat <- u_flat (what the backward pass
+ *                                  reads; may be NULL), u_flat <- u_next_flat;
+ *   gank_sn_power_iter_bwd_gw    : the first backward launch alone (partial <dW_bar, W>);
+ *   gank_sn_adam_fwd_a           : ONE launch for  sn backward apply (the table's dW_bar, workspaces, u_snap as after _bwd_gw)  +
+ *                                  tf.train.AdamOptimizer over the WHOLE flat buffer p / g / m / v [n] (SNGAN/gan_cifar_resnet.py:521-526;
+ *                                  arguments as gank_adam_tf_health; the consumed gradients -- g and every dW_bar -- are cleared)  +  the
+ *                                  NEXT forward pass's first launch on the updated weights (from the table's u_in, u' -> u_next[i]).
+ *                                  Every table entry's W must be a disjoint view of p and its dW the view of g at the same offset;
+ *                                  C <= 256.  flags bit 0: the caller guarantees that every entry's dW is zero on entry (nothing but
+ *                                  this backward pass contributes to those weights): it is then neither read nor cleared.
+ *                                  Bit-identical to gank_sn_power_iter_bwd + gank_adam_tf + gank_sn_power_iter_fwd_a. */
+int gank_sn_power_iter_fwd_a(const gank_sn_desc* table, int count, void* stream);
+int gank_sn_power_iter_fwd_b_prep(const gank_sn_desc* table, int count, const gank_prep_desc* prep, const int* prep_weight,
+                                  int prep_count, const gank_label_dense_desc* label, float* u_flat, float* u_snap_flat,
+                                  const float* u_next_flat, int u_total, void* stream);
+int gank_sn_power_iter_bwd_gw(const gank_sn_desc* table, int count, void* stream);
+int gank_sn_adam_fwd_a(const gank_sn_desc* table, int count, float* const* u_next, float* p, float* g, float* m, float* v, long n,
+                       float* hp, int64_t* t_state, const int64_t* iteration, uint64_t* health, int flags, void* stream);
 
 /* ---- conditional batch norm (common/ops/normalization.py:27-59) ----------------------------------
  * Batch moments over (N/groups, H, W) per tower (biased variance, eps 1e-5), per-sample gamma/beta

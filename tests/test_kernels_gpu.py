@@ -1664,3 +1664,108 @@ def test_convpool_input_gradient_with_the_image_convs_filter_gradient_inside(K, 
         assert relerr(db1 - torch.tensor(b0).cuda(), ub1.double().cpu().numpy()) < 1e-3
     if shortcut:
         assert relerr(dws - torch.tensor(ws0).cuda(), us.double().cpu().numpy()) < 1e-3
+
+
+@pytest.mark.parametrize("health,dw_zero", [(False, False), (True, False), (False, True)])
+def test_spectral_norm_backward_adam_and_next_power_iteration_in_one_launch(K, health, dw_zero):
+    """gank_sn_adam_fwd_a (round 5): the end of a critic update -- spectral-norm backward apply, TF-Adam over the flat buffer, and
+    the NEXT forward pass's power iteration on the updated weights -- as one launch, against the launches it replaces
+    (gank_sn_power_iter_bwd, gank_adam_tf_health with the gradient clear, gank_sn_power_iter_fwd_a): BIT-IDENTICAL parameters,
+    Adam slots, cleared gradients, workspaces (a, b, scal) and staged u'; then the consumer side: a forward pass that runs its
+    second launch only (gank_sn_power_iter_fwd_b_prep) and adopts u' equals the two-launch forward pass bit for bit.  Shapes:
+    the critic's (27 x 128 image conv, 1152 x 128, 300 x 128 dense, 128 x 1 head behind an odd-sized bias: unaligned slices take
+    the generic path), biases and an embedding table in the gaps."""
+    torch.manual_seed(5)
+    shapes = [(3, 3, 3, 128), (128,), (3, 3, 128, 128), (128,), (10, 300), (300, 128), (128,), (1, 1, 256, 128), (3, 3, 32, 256), (128, 1), (1,), (3, 3, 64, 64), (7,), (5, 5, 3, 32)]
+    sn = [0, 2, 5, 7, 8, 9, 11, 13]
+    sizes = [int(np.prod(sh)) for sh in shapes]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+    n = int(offs[-1])
+    n_sn = sum(sizes[i] for i in sn)
+
+    def build():
+        g = torch.Generator().manual_seed(11)
+        p = (torch.randn(n, generator=g) * 0.05).cuda()
+        m, v = (torch.randn(n, generator=g) * 1e-3).cuda(), (torch.rand(n, generator=g) * 1e-4).cuda()
+        grads_all = torch.zeros(n + n_sn + 8, device="cuda")
+        grads = grads_all[:n]
+        Ws = [p[offs[i]:offs[i] + sizes[i]].view(shapes[i]) for i in sn]
+        dWs = [grads[offs[i]:offs[i] + sizes[i]].view(shapes[i]) for i in sn]
+        cs = [shapes[i][-1] for i in sn]
+        u_flat = torch.randn(sum(cs), generator=g).cuda()
+        us, o = [], 0
+        for c in cs:
+            us.append(u_flat[o:o + c].view(1, c))
+            o += c
+        # gradients: plain ones for the gaps, dW_bar slices (scratch half) for the normalised weights, a little of both in dW
+        for i in range(len(shapes)):
+            if i not in sn:
+                grads[offs[i]:offs[i] + sizes[i]] = torch.randn(sizes[i], generator=g).cuda() * 0.1
+        Gs, o = [], n
+        for i in sn:
+            Gs.append(grads_all[o:o + sizes[i]].view(shapes[i]))
+            Gs[-1].copy_((torch.randn(sizes[i], generator=g) * 0.1).view(shapes[i]))
+            o += sizes[i]
+        if not dw_zero:
+            dWs[2].add_(0.01)
+        if health:
+            grads[offs[1] + 3] = float("inf")              # a bias gradient that overflowed
+            Gs[1].view(-1)[17] = float("nan")             # ... and one element of a normalised weight's
+            Gs[1].view(-1)[18] = 0.0
+        hp = torch.tensor([2e-4, 0.0, 0.9, 1e-8, 0.5, 1.0, 0.0, 0.0], device="cuda")
+        t = torch.tensor([3], dtype=torch.int64, device="cuda")
+        it = torch.tensor([1234], dtype=torch.int64, device="cuda")
+        hl = torch.zeros(2, dtype=torch.int64, device="cuda") if health else None
+        st = K.SnState(Ws, us, u_flat)
+        return dict(p=p, m=m, v=v, grads_all=grads_all, grads=grads, Ws=Ws, dWs=dWs, Gs=Gs, us=us, u_flat=u_flat, hp=hp, t=t, it=it, hl=hl, st=st)
+
+    # ---- A: the launches it replaces
+    A = build()
+    bA = K.SnBatch(A["Ws"], A["us"], snapshot=True, inplace=True, state=A["st"])
+    bA.forward()
+    bA.backward(A["Gs"], A["dWs"])
+    K.adam_tf(A["p"], A["grads_all"], A["m"], A["v"], A["hp"], A["t"], A["it"], zero_grads=True, health=A["hl"])
+    A["st"].refresh()
+    # ---- B: one launch
+    B = build()
+    bB = K.SnBatch(B["Ws"], B["us"], snapshot=True, inplace=True, state=B["st"])
+    bB.forward()
+    bB.backward_gw(B["Gs"], B["dWs"])
+    bB.adam_fwd_a(B["p"], B["grads"], B["m"], B["v"], B["hp"], B["t"], B["it"], health=B["hl"], dw_zero=dw_zero)
+    torch.cuda.synchronize()
+    assert B["st"].valid
+    for key in ("p", "m", "v", "grads_all", "u_flat", "t"):
+        assert torch.equal(A[key], B[key]), key
+    if health:
+        # (the NaN in one dW_bar makes <dW_bar, W> and with it every gradient element of that weight non-finite: 3*3*128*128 + the bias's one)
+        assert torch.equal(A["hl"], B["hl"]) and int(A["hl"][0]) == 3 * 3 * 128 * 128 + 1, (A["hl"], B["hl"])
+        assert bool(torch.isfinite(B["p"]).all())               # ... and none of them touched p, m or v
+    for name in ("a", "b", "scal", "u_next"):        # bit patterns: <dW_bar, W> of the poisoned weight is NaN in both
+        assert torch.equal(getattr(A["st"], name).view(torch.int32), getattr(B["st"], name).view(torch.int32)), name
+    assert float(B["grads_all"].abs().max()) == 0.0 and int(B["t"]) == 4
+    assert float((B["p"] - build()["p"]).abs().max()) > 1e-5           # (the step did move the weights)
+    # ---- consumer: second launch only + adoption of u' == the two-launch forward pass
+    A["st"].valid = False
+    fA = K.SnBatch(A["Ws"], A["us"], snapshot=True, inplace=True, state=A["st"])
+    WA = fA.forward()
+    fB = K.SnBatch(B["Ws"], B["us"], snapshot=True, inplace=True, state=B["st"])
+    WB = fB.forward()
+    torch.cuda.synchronize()
+    assert not B["st"].valid
+    for x, y in zip(WA, WB):
+        assert torch.equal(x, y)
+    for name in ("v", "ga", "u_snap"):
+        assert torch.equal(getattr(A["st"], name), getattr(B["st"], name)), name
+    assert torch.equal(A["u_flat"], B["u_flat"]) and torch.equal(B["u_flat"], B["st"].u_next)
+    # ... and a reading pass (NO_OPS: u never written) on valid state
+    B["st"].refresh()
+    u_before = B["u_flat"].clone()
+    rB = K.SnBatch(B["Ws"], B["us"], state=B["st"])
+    WR = rB.forward()
+    A["st"].valid = False
+    rA = K.SnBatch(A["Ws"], A["us"])
+    WRA = rA.forward()
+    torch.cuda.synchronize()
+    assert B["st"].valid and torch.equal(B["u_flat"], u_before)
+    for x, y in zip(WRA, WR):
+        assert torch.equal(x, y)

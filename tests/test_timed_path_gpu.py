@@ -170,6 +170,7 @@ def _sync_trainers(dst, src):
                 flat['grads_all'].zero_()
                 flat['clean'] = True
     dst._refresh_g_prep()
+    dst.sn_state_changed()           # the critic's weights and u were written behind the trainer's back
     torch.cuda.synchronize()
 
 
