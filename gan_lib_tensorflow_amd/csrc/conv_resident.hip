@@ -1168,6 +1168,7 @@ struct CpBwdWgArgs {
   float* db1;             // [Cin] or null
   float* dws;             // [1,1,3,Cout] or null
   float* dbs;             // [Cout] or null
+  float* slabs;           // null: fp32 atomics into the four targets; else [grid][32][128] plain stores (Cin == 128), summed by the caller
   int N, Hp, Wp, Cin, Cout;
   int xcd;
   int dbg;                // TUNING builds (GANK_IMGWG_DBG): 1 = no final atomics, 2 = no filter-gradient section, 4 = no Xcol build
@@ -1419,6 +1420,16 @@ __global__ __launch_bounds__(512) void cpool_res_dgrad_imgwg_kernel(CpBwdWgArgs 
   for (int e = 0; e < 8; e++) ex[e * 64 + lane] = kg == 0 ? accw[8 + e] : accw[e];      // the half the OTHER group finishes
   __syncthreads();
   const int col = ct * 32 + r;
+  if (a.slabs) {            // this workgroup's own [32][128] tile: no atomics, no contention (gank_sum_slabs adds the tiles up)
+    float* sl = a.slabs + (long)blockIdx.x * 4096;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int ee = kg == 0 ? e : 8 + e;
+      const int k = (ee & 3) + 8 * (ee >> 2) + 4 * h;
+      sl[k * 128 + col] = (kg == 0 ? accw[e] : accw[8 + e]) + ex_in[e * 64 + lane];
+    }
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < 8; e++) {
     const int ee = kg == 0 ? e : 8 + e;
@@ -1540,7 +1551,7 @@ extern "C" int gank_cpool_res_dgrad(const void* dy, const void* w_rfrag, const v
 // with x_pooled, of the 1x1 shortcut conv on the pooled image whose output gradient dy also is (dws [1,1,3,128], dbs), accumulated.
 extern "C" int gank_cpool_res_dgrad_image_wgrad(const void* dy, const void* w_rfrag, const void* relu_ref, const void* x_image,
                                                 float* dw1, float* db1, const void* x_pooled, float* dws, float* dbs, int N, int Hp, int Wp,
-                                                int Cin, int Cout, void* stream) {
+                                                int Cin, int Cout, float* slabs, void* stream) {
   GANK_REQUIRE(dy && w_rfrag && relu_ref && x_image && dw1 && N > 0, "cpool_res_dgrad_image_wgrad: null pointer");
   GANK_REQUIRE(Cout == 128 && Cin % 128 == 0 && Hp % 8 == 0 && Wp == 16,
                "cpool_res_dgrad_image_wgrad: needs Cout == 128, Cin %% 128 == 0, Hp %% 8 == 0 and Wp == 16 (got %d, %d, %dx%d)", Cout, Cin, Hp, Wp);
@@ -1548,7 +1559,8 @@ extern "C" int gank_cpool_res_dgrad_image_wgrad(const void* dy, const void* w_rf
   GANK_REQUIRE((long)N * 4 * Hp * Wp * Cin < (1L << 30), "cpool_res_dgrad_image_wgrad: tensor too large (32-bit byte offsets)");
   CpBwdWgArgs a{};
   a.dy = (const bf16*)dy; a.w = (const bf16*)w_rfrag; a.mask = (const bf16*)relu_ref; a.ximg = (const bf16*)x_image;
-  a.xpool = (const bf16*)x_pooled; a.dw1 = dw1; a.db1 = db1; a.dws = dws; a.dbs = dbs;
+  GANK_REQUIRE(!slabs || Cin == 128, "cpool_res_dgrad_image_wgrad: the slab form takes Cin == 128 (got %d)", Cin);
+  a.xpool = (const bf16*)x_pooled; a.dw1 = dw1; a.db1 = db1; a.dws = dws; a.dbs = dbs; a.slabs = slabs;
   a.N = N; a.Hp = Hp; a.Wp = Wp; a.Cin = Cin; a.Cout = Cout;
   a.xcd = resident_xcd_env();
   static const int dbg = gank_tune("GANK_IMGWG_DBG", 0);

@@ -46,6 +46,7 @@ struct WgradArgs {
   const bf16* dys[4];
   float* dws[4];
   float* dbs[4];
+  float* wss[4];      // slab workspaces of a batched launch (filter-row kernel; all null = atomics into dws)
 };
 
 __device__ __forceinline__ s16x4 lds_tr_read(const bf16* p) {
@@ -1325,7 +1326,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs a) {
     tci = bid % a.tiles_ci;
     frow = bid / a.tiles_ci;               // filter row
   }
+  float* WS = a.ws;
   if (a.nbatch > 0) {      // static indices only (a dynamically indexed by-value struct is spilled to scratch)
+    WS = bi == 0 ? a.wss[0] : (bi == 1 ? a.wss[1] : (bi == 2 ? a.wss[2] : a.wss[3]));
     X = bi == 0 ? a.xs[0] : (bi == 1 ? a.xs[1] : (bi == 2 ? a.xs[2] : a.xs[3]));
     DY = bi == 0 ? a.dys[0] : (bi == 1 ? a.dys[1] : (bi == 2 ? a.dys[2] : a.dys[3]));
     DW = bi == 0 ? a.dws[0] : (bi == 1 ? a.dws[1] : (bi == 2 ? a.dws[2] : a.dws[3]));
@@ -1477,11 +1480,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs a) {
   const long plane = (long)a.Cin * a.Cout;
 #pragma unroll
   for (int t = 0; t < NTAP; t++) {
-    float* dst = a.ws ? a.ws + ((long)split * NTAP * NTAP + frow * NTAP + t) * plane : DW + (long)(frow * NTAP + t) * plane;
+    float* dst = WS ? WS + ((long)split * NTAP * NTAP + frow * NTAP + t) * plane : DW + (long)(frow * NTAP + t) * plane;
 #pragma unroll
     for (int e = 0; e < 16; e++) {
       const int ci = ci0 + wave_a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-      if (a.ws) dst[(long)ci * a.Cout + co] = acc[t][e];
+      if (WS) dst[(long)ci * a.Cout + co] = acc[t][e];
       else atomicAdd(dst + (long)ci * a.Cout + co, acc[t][e] * a.scale);
     }
   }
@@ -1512,6 +1515,14 @@ static bool wgrad_rows_ok(const WgradArgs& a) {
          a.Hx == a.H && a.Wx == a.W && a.Hdy == a.H && a.Wdy == a.W && a.Cin % 64 == 0 && a.Cout % 64 == 0 && a.M % 64 == 0 &&
          (long)a.N * a.H * a.W * a.Cin < (1L << 30) && (long)a.N * a.H * a.W * a.Cout < (1L << 30);
 }
+static int wgrad_rows_splits(const WgradArgs& a, int nb) {     // the pixel splits launch_wgrad_rows will use for a batch of nb layers
+  const int total_steps = a.M / 64, tiles = (a.Cin / 64) * (a.Cout / 64) * 3 * nb;
+  static const int target = gank_tune("GANK_WGRAD_ROWS_TARGET", 256);
+  int splits = wgrad_round_down_env() ? target / tiles : (target + tiles - 1) / tiles;
+  if (splits > total_steps / 4) splits = total_steps / 4;
+  if (splits < 1) splits = 1;
+  return cdiv(total_steps, cdiv(total_steps, splits));
+}
 static int launch_wgrad_rows(WgradArgs a, hipStream_t s) {
   const int nb = a.nbatch > 0 ? a.nbatch : 1;
   a.tiles_ci = a.Cin / 64;
@@ -1525,7 +1536,8 @@ static int launch_wgrad_rows(WgradArgs a, hipStream_t s) {
   if (splits < 1) splits = 1;
   a.steps_per_split = cdiv(total_steps, splits);
   a.splits = cdiv(total_steps, a.steps_per_split);
-  a.ws = nullptr;          // partial tiles by fp32 atomics
+  a.ws = nullptr;          // partial tiles by fp32 atomics, or (a batched launch with wss[] set) to per-layer slabs [split][9][Cin][Cout]
+  if (a.nbatch <= 0) for (int j = 0; j < 4; j++) a.wss[j] = nullptr;
   const size_t lds = (size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16);
   const bool relu = (a.flags & GANK_IN_RELU) != 0;
   static const int pf = gank_tune("GANK_WGRAD_ROWS_PF", 2);   // experiment knob: register prefetch depth
@@ -1902,12 +1914,13 @@ extern "C" int gank_conv2d_wgrad_narrow_pair(const void* x0, const void* dy0, fl
 // Same-shape layers in one launch.  The critic's 8x8x128 residual blocks (D.Block.3/4, four 3x3 128->128 convs) have
 // filter gradients of 2.4 GFLOP each that fill 144 workgroups for a few microseconds; issued together (grid.y = layer)
 // they overlap each other's latency instead of queueing behind one another.
+static int wgrad_batched_impl(const gank_wgrad_item* items, int count, int N, int H, int W, int Cin, int Cout, int ksize, int flags, float scale,
+                              float* ws, long ws_elems, gank_slab_job* jobs, void* stream);
 extern "C" int gank_conv2d_wgrad_batched(const gank_wgrad_item* items, int count, int N, int H, int W, int Cin, int Cout,
                                          int ksize, int flags, float scale, void* stream) {
-  GANK_REQUIRE(items && count > 0, "conv2d_wgrad_batched: empty list");
-  GANK_REQUIRE(ksize % 2 == 1, "conv2d_wgrad_batched: even filter sizes are not on this path (ksize=%d)", ksize);
-  hipStream_t s = (hipStream_t)stream;
-  WgradArgs a{};
+  return wgrad_batched_impl(items, count, N, H, W, Cin, Cout, ksize, flags, scale, nullptr, 0, nullptr, stream);
+}
+static bool wgrad_batched_geometry(WgradArgs& a, int N, int H, int W, int Cin, int Cout, int ksize, int flags, float scale, bool& rows) {
   a.N = N; a.H = H; a.W = W; a.Hx = H; a.Wx = W; a.Hdy = H; a.Wdy = W;
   a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.pad = (ksize - 1) / 2; a.taps = ksize * ksize;
   a.flags = flags & GANK_IN_RELU;
@@ -1915,15 +1928,56 @@ extern "C" int gank_conv2d_wgrad_batched(const gank_wgrad_item* items, int count
   a.M = N * H * W; a.sw = log2_or_neg(W); a.shw = log2_or_neg(H * W);
   const bool batchable = (flags & ~GANK_IN_RELU) == 0 && Cin % 8 == 0 && Cout % 8 == 0 && Cin >= 128 && Cout >= 128 && a.sw >= 0 &&
                          a.shw >= 0 && a.M % 64 == 0 && !wgrad_taps_ok(a) && (long)a.M * (Cin > Cout ? Cin : Cout) < (1L << 30);
-  const bool rows = batchable && wgrad_rows_ok(a);
+  rows = batchable && wgrad_rows_ok(a);
+  return batchable;
+}
+extern "C" long gank_conv2d_wgrad_batched_ws_elems(int count, int N, int H, int W, int Cin, int Cout, int ksize, int flags) {
+  if (count <= 0 || ksize != 3) return 0;
+  WgradArgs a{};
+  bool rows = false;
+  wgrad_batched_geometry(a, N, H, W, Cin, Cout, ksize, flags, 1.f, rows);
+  if (!rows) return 0;
+  long total = 0;
+  for (int i = 0; i < count; i += 4) {
+    const int nb = count - i < 4 ? count - i : 4;
+    total += (long)nb * wgrad_rows_splits(a, nb) * 9 * Cin * Cout;
+  }
+  return total;
+}
+extern "C" int gank_conv2d_wgrad_batched_slabs(const gank_wgrad_item* items, int count, int N, int H, int W, int Cin, int Cout, int ksize,
+                                               int flags, float scale, float* ws, long ws_elems, gank_slab_job* jobs, void* stream) {
+  GANK_REQUIRE(ws && jobs, "conv2d_wgrad_batched_slabs: null workspace / job list");
+  GANK_REQUIRE(ws_elems >= gank_conv2d_wgrad_batched_ws_elems(count, N, H, W, Cin, Cout, ksize, flags) &&
+               gank_conv2d_wgrad_batched_ws_elems(count, N, H, W, Cin, Cout, ksize, flags) > 0,
+               "conv2d_wgrad_batched_slabs: this geometry has no slab form, or the workspace is smaller than gank_conv2d_wgrad_batched_ws_elems");
+  return wgrad_batched_impl(items, count, N, H, W, Cin, Cout, ksize, flags, scale, ws, ws_elems, jobs, stream);
+}
+static int wgrad_batched_impl(const gank_wgrad_item* items, int count, int N, int H, int W, int Cin, int Cout, int ksize, int flags, float scale,
+                              float* ws, long ws_elems, gank_slab_job* jobs, void* stream) {
+  GANK_REQUIRE(items && count > 0, "conv2d_wgrad_batched: empty list");
+  GANK_REQUIRE(ksize % 2 == 1, "conv2d_wgrad_batched: even filter sizes are not on this path (ksize=%d)", ksize);
+  hipStream_t s = (hipStream_t)stream;
+  WgradArgs a{};
+  bool rows = false;
+  const bool batchable = wgrad_batched_geometry(a, N, H, W, Cin, Cout, ksize, flags, scale, rows);
+  long ws_used = 0;
   int i = 0;
   while (batchable && count - i >= (rows ? 1 : 2)) {
     const int nb = count - i < 4 ? count - i : 4;
+    const long slab = 9L * Cin * Cout;
+    const int splits = (ws && rows) ? wgrad_rows_splits(a, nb) : 0;
     for (int j = 0; j < nb; j++) {
       GANK_REQUIRE(items[i + j].x && items[i + j].dy && items[i + j].dw, "conv2d_wgrad_batched: null pointer in item %d", i + j);
       a.xs[j] = (const bf16*)items[i + j].x; a.dys[j] = (const bf16*)items[i + j].dy;
       a.dws[j] = items[i + j].dw; a.dbs[j] = items[i + j].dbias;
+      a.wss[j] = nullptr;
+      if (ws && rows) {        // partial tiles to slabs [split][9][Cin][Cout]; the caller sums them (gank_sum_slabs)
+        a.wss[j] = ws + ws_used;
+        jobs[i + j] = gank_slab_job{a.wss[j], items[i + j].dw, slab, slab, splits, scale};
+        ws_used += (long)splits * slab;
+      }
     }
+    for (int j = nb; j < 4; j++) a.wss[j] = nullptr;
     a.nbatch = nb;
     a.x = a.xs[0]; a.dy = a.dys[0]; a.dw = a.dws[0]; a.dbias = a.dbs[0];
     gank_prof_begin(1, 2.0 * nb * a.M * (double)Cout * a.taps * Cin, s, nb * (2.0 * a.M * ((double)Cin + Cout) + 4.0 * a.taps * Cin * Cout));

@@ -384,6 +384,84 @@ extern "C" int gank_weighted_sum4_f32(const float* a, const float* b, const floa
   GANK_LAUNCH_OK("weighted_sum4_f32");
   return 0;
 }
+// out[i] += scale * sum_{s < nslabs} slabs[s * stride + i]   for up to 8 jobs per launch, slabs summed in ascending order
+// (deterministic).  Split-K filter gradients whose partial tiles used to leave as fp32 atomics write plain slabs instead and
+// are summed here: in the critic update the atomics of the 3-channel-input fused gradient (256 workgroups x 4096 floats onto
+// the SAME 4096 addresses) and of the batched 8x8 layers (240 x 12288) cost 17 + 12 us of their kernels' 40 + 30 us.
+// Few slabs (<= 16): a thread owns 4 consecutive outputs and walks the slabs; many slabs (the 256 of the fused gradient): a
+// block owns 64 outputs, its four waves take every fourth slab each and meet in LDS.
+struct SlabJobTable {
+  gank_slab_job j[8];
+  int first_block[9];
+  int count;
+};
+__global__ __launch_bounds__(256) void sum_slabs_kernel(SlabJobTable t) {
+  __shared__ float part[4][64];
+  int ji = 0;
+#pragma unroll
+  for (int i = 1; i < 8; i++) ji += (i < t.count && (int)blockIdx.x >= t.first_block[i]) ? 1 : 0;
+  const gank_slab_job& jb = t.j[ji];
+  const int lb = blockIdx.x - t.first_block[ji], tid = threadIdx.x;
+  const float* __restrict__ sl = jb.slabs;
+  if (jb.nslabs <= 16) {
+    const long i0 = ((long)lb * 256 + tid) * 4;
+    if (i0 >= jb.n) return;
+    if (i0 + 4 <= jb.n && (jb.stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(sl) | reinterpret_cast<uintptr_t>(jb.out)) & 15) == 0) {
+      f32x4 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) v[u] = *reinterpret_cast<const f32x4*>(sl + (long)min(u, jb.nslabs - 1) * jb.stride + i0);
+      f32x4 acc = v[0];
+#pragma unroll
+      for (int u = 1; u < 16; u++)
+        if (u < jb.nslabs) { acc[0] += v[u][0]; acc[1] += v[u][1]; acc[2] += v[u][2]; acc[3] += v[u][3]; }
+      f32x4 o = *reinterpret_cast<const f32x4*>(jb.out + i0);
+#pragma unroll
+      for (int e = 0; e < 4; e++) o[e] += jb.scale * acc[e];
+      *reinterpret_cast<f32x4*>(jb.out + i0) = o;
+    } else {
+      for (long i = i0; i < min(i0 + 4, jb.n); i++) {
+        float acc = 0.f;
+        for (int u = 0; u < jb.nslabs; u++) acc += sl[(long)u * jb.stride + i];
+        jb.out[i] += jb.scale * acc;
+      }
+    }
+    return;
+  }
+  const int o = tid & 63, sg = tid >> 6;
+  const long i = (long)lb * 64 + o;
+  float acc = 0.f;
+  if (i < jb.n) {
+    for (int sb = sg; sb < jb.nslabs; sb += 4 * 16) {          // 16 independent loads per batch, this wave's slabs in ascending order
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) v[u] = sl[(long)min(sb + 4 * u, jb.nslabs - 1) * jb.stride + i];
+#pragma unroll
+      for (int u = 0; u < 16; u++) acc += (sb + 4 * u < jb.nslabs) ? v[u] : 0.f;
+    }
+  }
+  part[sg][o] = acc;
+  __syncthreads();
+  if (sg == 0 && i < jb.n) jb.out[i] += jb.scale * (((part[0][o] + part[1][o]) + part[2][o]) + part[3][o]);
+}
+extern "C" int gank_sum_slabs(const gank_slab_job* jobs, int count, void* stream) {
+  GANK_REQUIRE(jobs && count > 0, "sum_slabs: empty list");
+  for (int base = 0; base < count; base += 8) {
+    SlabJobTable t{};
+    t.count = count - base < 8 ? count - base : 8;
+    int blocks = 0;
+    for (int i = 0; i < t.count; i++) {
+      const gank_slab_job& j = jobs[base + i];
+      GANK_REQUIRE(j.slabs && j.out && j.n > 0 && j.nslabs > 0 && j.stride >= j.n, "sum_slabs: bad job %d", base + i);
+      t.j[i] = j;
+      t.first_block[i] = blocks;
+      blocks += j.nslabs <= 16 ? (int)((j.n + 1023) / 1024) : (int)((j.n + 63) / 64);
+    }
+    t.first_block[t.count] = blocks;
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t);
+  }
+  GANK_LAUNCH_OK("sum_slabs");
+  return 0;
+}
 extern "C" int gank_scale_f32(const float* x, const float* sc, float* y, long n, void* stream) {
   GANK_REQUIRE(x && sc && y && n > 0, "scale_f32: bad arguments");
   hipLaunchKernelGGL(scale_f32_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, x, sc, y, n);

@@ -70,10 +70,19 @@ def narrow_wgrad_ok(cin, cout, k, flags_free):
     return BATCH_SMALL_WGRADS and flags_free and cin == 3 and k in (1, 3) and cout % 128 == 0
 
 
+# Split-K partial results written as slabs instead of added with fp32 atomics (in a critic update the atomics of the fused
+# image-side gradient and of the batched 8x8 layers were 17 + 12 us of their kernels' 40 + 30): the jobs that sum them collect
+# here and leave as ONE launch in join_wgrad().  Only under BATCH_SMALL_WGRADS (the caller guarantees the join).
+SLAB_WGRADS = True
+_slab_jobs = []
+
+
 def flush_wgrads():
     for (_, _, hw, k, flags), items in _deferred.items():
-        K.conv2d_wgrad_batched(items, hw, k, flags, 1.0)
+        K.conv2d_wgrad_batched(items, hw, k, flags, 1.0, slab_jobs=_slab_jobs if SLAB_WGRADS else None)
     _deferred.clear()
+    if _slab_jobs:
+        K.sum_slabs(_slab_jobs)
     while len(_deferred_narrow) >= 2:
         a, b = _deferred_narrow.pop(0), _deferred_narrow.pop(0)
         K.conv2d_wgrad_narrow_pair(a, b)
@@ -87,12 +96,13 @@ def reset_deferred():
     capture aborted): stale (x, dy) pairs must never be flushed into another pass's gradient buffers."""
     _deferred.clear()
     _deferred_narrow.clear()
+    _slab_jobs.clear()
 
 
 def join_wgrad():
     """Every filter gradient issued or deferred so far is complete / in stream order (before the optimiser and the
     SN backward)."""
-    if _deferred or _deferred_narrow:
+    if _deferred or _deferred_narrow or _slab_jobs:
         flush_wgrads()
 
 
@@ -317,7 +327,8 @@ class _Conv2d(Function):
             if ssink is not None:
                 ts, _, bs_, _ = ssink.targets()
                 xp = ssink.x
-            K.cpool_res_dgrad_image_wgrad(g, W._prep_cpres[1], x, isink.x, t1, b1, xp, ts, bs_)
+            K.cpool_res_dgrad_image_wgrad(g, W._prep_cpres[1], x, isink.x, t1, b1, xp, ts, bs_,
+                                          slab_jobs=_slab_jobs if (SLAB_WGRADS and BATCH_SMALL_WGRADS) else None)
             isink.done = True
             if ssink is not None:
                 ssink.done = True

@@ -6,7 +6,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, RES_UPSAMPLE2X, STATS_PREZEROED, OUT_POOLSUM2X, SnDesc, PrepDesc, WgradItem, LabelDenseDesc, Res8Head  # noqa: F401
+from ._lib import IN_UPSAMPLE2X, IN_RELU, OUT_TANH, DY_UPSAMPLE2X, RES_UPSAMPLE2X, STATS_PREZEROED, OUT_POOLSUM2X, SnDesc, PrepDesc, WgradItem, LabelDenseDesc, Res8Head, SlabJob  # noqa: F401
 
 # BF16 = the 16-bit activation dtype of this process: torch.bfloat16, or torch.float16 under GANK_DTYPE=fp16 (libgank_f16.so)
 BF16, F32, I32 = getattr(torch, _lib.ACT_DTYPE_NAME), torch.float32, torch.int32
@@ -213,9 +213,10 @@ def conv2d_wgrad(x, dy, dw, hw, ksize, flags=0, scale=1.0, dbias=None):
     return dw
 
 
-def conv2d_wgrad_batched(items, hw, ksize, flags=0, scale=1.0):
+def conv2d_wgrad_batched(items, hw, ksize, flags=0, scale=1.0, slab_jobs=None):
     """items: [(x, dy, dw, dbias | None)] of identical geometry; ACCUMULATES every dw (and dbias) in as few launches
-    as possible."""
+    as possible.  slab_jobs: a list -- where the geometry has a slab form the partial tiles are written to slabs instead of
+    added with fp32 atomics and the jobs that sum them into the dw are APPENDED to the list: the caller owes a sum_slabs(list)."""
     x0, dy0 = items[0][0], items[0][1]
     n, cin, cout = x0.shape[0], x0.shape[3], dy0.shape[3]
     table = (WgradItem * len(items))()
@@ -223,8 +224,39 @@ def conv2d_wgrad_batched(items, hw, ksize, flags=0, scale=1.0):
         assert x.shape == x0.shape and dy.shape == dy0.shape and dw.numel() == ksize * ksize * cin * cout
         t.x, t.dy, t.dw = _p(x, BF16, "x").value, _p(dy, BF16, "dy").value, _p(dw, F32, "dw").value
         t.dbias = _p(db, F32, "dbias").value if db is not None else None
+    if slab_jobs is not None:
+        ws_elems = int(lib().gank_conv2d_wgrad_batched_ws_elems(len(items), n, hw[0], hw[1], cin, cout, ksize, flags))
+        if ws_elems > 0:
+            ws = torch.empty(ws_elems, dtype=F32, device=x0.device)
+            jobs = (SlabJob * len(items))()
+            _lib.check(lib().gank_conv2d_wgrad_batched_slabs(table, len(items), n, hw[0], hw[1], cin, cout, ksize, flags, scale, _p(ws), ws_elems,
+                                                             jobs, _stream()), "conv2d_wgrad_batched_slabs")
+            slab_jobs.append((jobs, len(items), ws))
+            return
     _lib.check(lib().gank_conv2d_wgrad_batched(table, len(items), n, hw[0], hw[1], cin, cout, ksize, flags, scale, _stream()),
                "conv2d_wgrad_batched")
+
+
+def slab_job(slabs, out, n, stride, nslabs, scale=1.0):
+    """one gank_slab_job as an entry of a slab-job list: out[:n] += scale * sum_s slabs.view(-1)[s * stride : s * stride + n]"""
+    jobs = (SlabJob * 1)()
+    jobs[0].slabs, jobs[0].out, jobs[0].n, jobs[0].stride, jobs[0].nslabs, jobs[0].scale = _p(slabs, F32, "slabs").value, _p(out, F32, "out").value, n, stride, nslabs, scale
+    return (jobs, 1, slabs)
+
+
+def sum_slabs(slab_jobs):
+    """ONE launch (per 8 jobs) for every job of the list (entries: (SlabJob array, count, the workspace kept alive)); clears the list"""
+    total = sum(c for _, c, _ in slab_jobs)
+    if total == 0:
+        return
+    table, i = (SlabJob * total)(), 0
+    for jobs, c, _ in slab_jobs:
+        for j in range(c):
+            for f, _t in SlabJob._fields_:
+                setattr(table[i], f, getattr(jobs[j], f))
+            i += 1
+    _lib.check(lib().gank_sum_slabs(table, total, _stream()), "sum_slabs")
+    slab_jobs.clear()
 
 
 def conv2d_wgrad_narrow_pair(a, b):
@@ -525,18 +557,28 @@ def cpool_res_dgrad_image_wgrad_ok(dy, cin):
     return wp == 16 and hp % 8 == 0 and cout == 128 and cin % 128 == 0 and n * 4 * hp * wp * cin < (1 << 30)
 
 
-def cpool_res_dgrad_image_wgrad(dy, rd, relu_ref, x_image, dw1, db1=None, x_pooled=None, dws=None, dbs=None):
+def cpool_res_dgrad_image_wgrad(dy, rd, relu_ref, x_image, dw1, db1=None, x_pooled=None, dws=None, dbs=None, slab_jobs=None):
     """ConvMeanPool input gradient whose only consumer is the filter gradient of the 3-channel-input 3x3 conv in front: nothing is
-    stored; dw1 fp32 [3,3,3,Cin] / db1 [Cin] (and, with x_pooled, the 1x1 shortcut's dws [1,1,3,Cout] / dbs) are ACCUMULATED."""
+    stored; dw1 fp32 [3,3,3,Cin] / db1 [Cin] (and, with x_pooled, the 1x1 shortcut's dws [1,1,3,Cout] / dbs) are ACCUMULATED --
+    by fp32 atomics, or (slab_jobs: a list, Cin == 128) each workgroup's tile goes to a slab of its own and the jobs that add the
+    slabs into the targets are appended to the list: the caller owes a sum_slabs(list)."""
     n, hp, wp, cout = dy.shape
     cin = relu_ref.shape[3]
     assert tuple(relu_ref.shape) == (n, 2 * hp, 2 * wp, cin) and tuple(x_image.shape) == (n, 2 * hp, 2 * wp, 3), (relu_ref.shape, x_image.shape)
     assert dw1.numel() == 27 * cin and (db1 is None or db1.numel() == cin)
     assert x_pooled is None or (tuple(x_pooled.shape) == (n, hp, wp, 3) and dws is not None and dws.numel() == 3 * cout)
+    slabs = None
+    if slab_jobs is not None and cin == 128:
+        nsl = n * (hp // 8)
+        slabs = torch.empty(nsl * 4096, dtype=F32, device=dy.device)
     _lib.check(lib().gank_cpool_res_dgrad_image_wgrad(_p(dy, BF16, "dy"), _p(rd, BF16, "rd"), _p(relu_ref, BF16, "relu_ref"),
                                                       _p(x_image, BF16, "x_image"), _p(dw1, F32, "dw1"), _p(db1, F32, "db1"),
                                                       _p(x_pooled, BF16, "x_pooled"), _p(dws, F32, "dws"), _p(dbs, F32, "dbs"),
-                                                      n, hp, wp, cin, cout, _stream()), "cpool_res_dgrad_image_wgrad")
+                                                      n, hp, wp, cin, cout, _p(slabs), _stream()), "cpool_res_dgrad_image_wgrad")
+    if slabs is not None:
+        for row0, rows, tgt in ((0, 27, dw1), (27, 1, db1), (28, 3, dws if x_pooled is not None else None), (31, 1, dbs if x_pooled is not None else None)):
+            if tgt is not None:
+                slab_jobs.append(slab_job(slabs[row0 * 128:], tgt, rows * 128, 4096, nsl))
 
 
 def convpool3x3_wgrad(x, dy, dw, flags=0, dbias=None):

@@ -125,6 +125,24 @@ typedef struct gank_wgrad_item {
 } gank_wgrad_item;
 int gank_conv2d_wgrad_batched(const gank_wgrad_item* items, int count, int N, int H, int W, int Cin, int Cout,
                               int ksize, int flags, float scale, void* stream);
+/* Split-K partial results as plain SLABS instead of fp32 atomics (round 5).  A job: out[i] += scale * sum_{s < nslabs}
+ * slabs[s * stride + i], i < n, the slabs added in ascending order (deterministic); gank_sum_slabs runs up to 8 jobs per launch.
+ * gank_conv2d_wgrad_batched_slabs = gank_conv2d_wgrad_batched whose partial tiles go to `ws` (gank_conv2d_wgrad_batched_ws_elems
+ * floats; 0 = this geometry is not on the slab-capable filter-row kernel: use gank_conv2d_wgrad_batched) and which fills
+ * jobs[count] for a LATER gank_sum_slabs call of the caller (several producers' jobs in one launch); bias gradients are
+ * accumulated directly as before. */
+typedef struct gank_slab_job {
+  const float* slabs;
+  float* out;
+  long n;          /* outputs                                  */
+  long stride;     /* floats between consecutive slabs (>= n)  */
+  int nslabs;
+  float scale;
+} gank_slab_job;
+int gank_sum_slabs(const gank_slab_job* jobs, int count, void* stream);
+long gank_conv2d_wgrad_batched_ws_elems(int count, int N, int H, int W, int Cin, int Cout, int ksize, int flags);
+int gank_conv2d_wgrad_batched_slabs(const gank_wgrad_item* items, int count, int N, int H, int W, int Cin, int Cout, int ksize,
+                                    int flags, float scale, float* ws, long ws_elems, gank_slab_job* jobs, void* stream);
 /* Two filter gradients of 3-channel-input layers (ksize 1 or 3, SAME, stride 1; Cout % 128 == 0) with DIFFERENT geometry in
  * one launch: the first critic block's Conv1 (3x3, 32x32) and Shortcut (1x1 on the pooled 16x16 image),
  * gan_cifar_resnet.py:212-234.  Same arithmetic as two gank_conv2d_wgrad calls (which it falls back to). */
@@ -218,10 +236,12 @@ int gank_cpool_res_dgrad(const void* dy, const void* w_rfrag, const void* relu_r
  * activation dtype as the stored tensor was) feeds  dw1 [3,3,3,Cin] += x_image (*) dx  and  db1 [Cin] += sum dx  inside the launch;
  * with x_pooled [N,Hp,Wp,3] also the 1x1 shortcut conv whose output gradient dy is:  dws [1,1,3,Cout] += x_pooled^T dy,
  * dbs [Cout] += sum dy.  x_image [N,2Hp,2Wp,3]; Wp == 16, Hp % 8 == 0, Cout == 128, Cin % 128 == 0; db1 / x_pooled / dws / dbs
- * optional.  fp32 atomics (one [32][Cin] tile per workgroup). */
+ * optional.  One [32][Cin] tile per workgroup: fp32 atomics into the four targets, or, with `slabs` (Cin == 128 only;
+ * N * Hp / 8 slabs of 32 x 128 floats), plain stores -- rows 0..26 of a slab belong to dw1, row 27 to db1, rows 28..30 to dws,
+ * row 31 to dbs -- that the caller sums later (gank_sum_slabs, stride 4096): the targets are then not touched by this call. */
 int gank_cpool_res_dgrad_image_wgrad(const void* dy, const void* w_rfrag, const void* relu_ref, const void* x_image, float* dw1,
                                      float* db1, const void* x_pooled, float* dws, float* dbs, int N, int Hp, int Wp, int Cin,
-                                     int Cout, void* stream);
+                                     int Cout, float* slabs, void* stream);
 
 /* ---- UpsampleConv 3x3 (SNGAN/gan_cifar_resnet.py:140-153) as a stride-2 transposed conv -------------
  * nearest-neighbour 2x followed by a 3x3 SAME conv equals a 4x4 stride-2 transposed conv whose taps are sums

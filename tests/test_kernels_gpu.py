@@ -754,10 +754,13 @@ def test_conv_fprop_upsampled_residual(K, n, h, cin, cout, k):
     assert relerr(y, ref) < BF_TOL
 
 
-def test_conv_wgrad_batched_equals_separate(K):
-    """Four same-shape 3x3 filter gradients (the critic's 8x8x128 blocks) in one launch == four separate launches."""
+@pytest.mark.parametrize("slabs,n", [(False, 16), (True, 16), (True, 128)])
+def test_conv_wgrad_batched_equals_separate(K, slabs, n):
+    """Four same-shape 3x3 filter gradients (the critic's 8x8x128 blocks) in one launch == four separate launches.  slabs: the
+    partial tiles of the pixel splits go to slabs and ONE gank_sum_slabs launch adds them into the (non-zero) targets with the
+    scale -- no fp32 atomics, the same result on every run."""
     rng = np.random.default_rng(8)
-    n, h, c = 16, 8, 128
+    h, c = 8, 128
     items, refs = [], []
     for i in range(5):                      # 4 in one launch + 1 through the single-layer path
         x, xt = bf(rng.normal(size=(n, h, h, c)))
@@ -767,12 +770,26 @@ def test_conv_wgrad_batched_equals_separate(K):
         items.append((xt, dyt, dw, db))
         _, dw_ref, db_ref = R.conv2d_same_grads(R.relu(x), np.zeros((3, 3, c, c)), dy)
         refs.append((dw_ref, db_ref))
-    K.conv2d_wgrad_batched(items, (h, h), 3, K.IN_RELU, 1.0)
+    jobs = [] if slabs else None
+    K.conv2d_wgrad_batched(items, (h, h), 3, K.IN_RELU, 1.0, slab_jobs=jobs)
+    if slabs:
+        assert len(jobs) == 1 and jobs[0][1] == 5                  # every layer has its job; nothing reached the targets yet
+        assert all(float((dw - float(i)).abs().max()) == 0.0 for i, (_, _, dw, _) in enumerate(items))
+        K.sum_slabs(jobs)
+        assert jobs == []
     torch.cuda.synchronize()
     for i, ((_, _, dw, db), (dw_ref, db_ref)) in enumerate(zip(items, refs)):
         assert relerr(dw - float(i), dw_ref) < F32_FROM_BF_TOL
         if db is not None:
             assert relerr(db, db_ref) < F32_FROM_BF_TOL
+    if slabs:                # deterministic: a second run from the same targets is bit-identical
+        first = [dw.clone() for _, _, dw, _ in items]
+        for i, (_, _, dw, _) in enumerate(items):
+            dw.fill_(float(i))
+        K.conv2d_wgrad_batched(items, (h, h), 3, K.IN_RELU, 1.0, slab_jobs=jobs)
+        K.sum_slabs(jobs)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, dw) for a, (_, _, dw, _) in zip(first, items))
 
 
 @pytest.mark.parametrize("n,h,w_,cin,cout,relu", [(3, 8, 16, 64, 128, True), (5, 16, 8, 128, 64, False), (24, 8, 8, 256, 256, True)])
@@ -1606,8 +1623,9 @@ def test_concat_label_with_the_next_blocks_fan_out(K):
     assert torch.equal(da2.view(torch.int16), da2_ref.view(torch.int16)) and relerr(de2, de2_ref.double().cpu().numpy()) < 1e-6
 
 
-@pytest.mark.parametrize("n,hp,cin,shortcut,bias", [(3, 16, 128, True, True), (2, 8, 128, False, True), (5, 16, 256, True, False), (128, 16, 128, True, True)])
-def test_convpool_input_gradient_with_the_image_convs_filter_gradient_inside(K, n, hp, cin, shortcut, bias):
+@pytest.mark.parametrize("n,hp,cin,shortcut,bias,slabs", [(3, 16, 128, True, True, False), (2, 8, 128, False, True, True), (5, 16, 256, True, False, True),
+                                                         (128, 16, 128, True, True, False), (128, 16, 128, True, True, True), (3, 16, 128, True, False, True)])
+def test_convpool_input_gradient_with_the_image_convs_filter_gradient_inside(K, n, hp, cin, shortcut, bias, slabs):
     """gank_cpool_res_dgrad_image_wgrad (round 5): the ConvMeanPool input gradient of OptimizedResBlockDisc1 in a critic update
     (gan_cifar_resnet.py:212-234) never stores its result; the launch accumulates the filter / bias gradient of the 3x3 conv on the
     3-channel image in front (dw1, db1) and of the 1x1 shortcut conv on the pooled image (dws, dbs).  Oracle: float64 gradients of
@@ -1636,8 +1654,14 @@ def test_convpool_input_gradient_with_the_image_convs_filter_gradient_inside(K, 
     ws0, bs0 = rng.normal(size=(1, 1, 3, cout)).astype(np.float32), rng.normal(size=cout).astype(np.float32)
     dw1, db1 = torch.tensor(w0).cuda(), torch.tensor(b0).cuda()
     dws, dbs = torch.tensor(ws0).cuda(), torch.tensor(bs0).cuda()
+    jobs = [] if slabs else None       # slabs: each workgroup's tile to a slab of its own (Cin == 128; else the atomics), summed by ONE later launch
     K.cpool_res_dgrad_image_wgrad(dyt, rd, h1t, imgt, dw1, db1 if bias else None, pooledt if shortcut else None,
-                                  dws if shortcut else None, dbs if (shortcut and bias) else None)
+                                  dws if shortcut else None, dbs if (shortcut and bias) else None, slab_jobs=jobs)
+    if slabs and cin == 128:
+        assert len(jobs) == 1 + int(bias) + (1 + int(bias)) * int(shortcut) and torch.equal(dw1.cpu(), torch.tensor(w0))
+        K.sum_slabs(jobs)
+    elif slabs:
+        assert jobs == []
     torch.cuda.synchronize()
     # a few tiles of dh differ from the oracle's rounding by one bf16 ulp where the fp32 sum sits on a rounding boundary: the bound
     # is the bf16-output one on the sum's scale, not the fp32-from-identical-bf16 one
