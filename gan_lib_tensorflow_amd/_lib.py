@@ -104,6 +104,8 @@ PROTOTYPES = {
     "gank_cpool_res_dgrad": [P, P, P, P, I, I, I, I, I, P],
     "gank_cpool_res_dgrad_image_wgrad": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, P],
     "gank_sum_slabs": [C.POINTER(SlabJob), I, P],
+    "gank_conv2d_wgrad_slab_elems": [I, I, I, I, I, I, I],
+    "gank_conv2d_wgrad_slabs": [P, P, P, P, I, I, I, I, I, I, I, F, P, L, C.POINTER(SlabJob), P],
     "gank_conv2d_wgrad_batched_ws_elems": [I, I, I, I, I, I, I, I],
     "gank_conv2d_wgrad_batched_slabs": [C.POINTER(WgradItem), I, I, I, I, I, I, I, I, F, P, L, C.POINTER(SlabJob), P],
     "gank_deconv2d_prep_phases": [P, P, I, I, I, P],
@@ -201,7 +203,7 @@ PROTOTYPES = {
     "gank_critic_feed": [P, P, P, P, P, P, P, P, I, I, P],
     "gank_debug_tr_probe": [P, P],
 }
-_RET = {"gank_last_error": C.c_char_p, "gank_sn_ws_floats": C.c_long, "gank_conv2d_wgrad_ws_elems": C.c_long, "gank_convpool3x3_wgrad_ws_elems": C.c_long, "gank_upconv3x3_wgrad_ws_elems": C.c_long, "gank_conv2d_wgrad_batched_ws_elems": C.c_long, "gank_prof_calibrate": C.c_double, "gank_prof_bytes": C.c_double}
+_RET = {"gank_last_error": C.c_char_p, "gank_sn_ws_floats": C.c_long, "gank_conv2d_wgrad_ws_elems": C.c_long, "gank_convpool3x3_wgrad_ws_elems": C.c_long, "gank_upconv3x3_wgrad_ws_elems": C.c_long, "gank_conv2d_wgrad_batched_ws_elems": C.c_long, "gank_conv2d_wgrad_slab_elems": C.c_long, "gank_prof_calibrate": C.c_double, "gank_prof_bytes": C.c_double}
 
 _lib = None
 

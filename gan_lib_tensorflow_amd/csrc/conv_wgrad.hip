@@ -47,6 +47,14 @@ struct WgradArgs {
   float* dws[4];
   float* dbs[4];
   float* wss[4];      // slab workspaces of a batched launch (filter-row kernel; all null = atomics into dws)
+  // split-K slabs of the per-tap / lean / packed kernels (gank_conv2d_wgrad_slabs): block `split` stores its tiles into
+  // slab[split] = slab + split * slab_stride (a private copy of dw, every element written exactly once) instead of adding them to
+  // dw with fp32 atomics; the caller sums the slabs later (gank_sum_slabs, job filled by the launcher).  Host-side request:
+  float* slab;
+  long slab_stride;
+  float* slab_ws;     // (host) workspace offered by the caller
+  long slab_elems;
+  gank_slab_job* slab_job;   // (host) out: the job that sums what the launch wrote; nslabs = 0 when the launch used atomics
 };
 
 __device__ __forceinline__ s16x4 lds_tr_read(const bf16* p) {
@@ -251,6 +259,9 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_kernel(WgradArgs a) {
 
   // D[i][j]: row i = ci (reg&3)+8*(reg>>2)+4*(lane>>5), col j = co = lane&31
   const int r = lane & 31, h = lane >> 5;
+#ifdef GANK_TUNING
+  if (a.dbg & 16) { if (acc[0][0][0] == 123.456f) a.dw[0] = 1.f; return; }
+#endif
 #pragma unroll
   for (int i = 0; i < TA; i++) {
 #pragma unroll
@@ -260,7 +271,11 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; e++) {
         const int ci = ci0 + (wave_a * TA + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (ci < a.Cin) atomicAdd(a.dw + ((long)tap * a.Cin + ci) * a.Cout + co, acc[i][j][e] * a.scale);
+        if (ci < a.Cin) {
+          const long o = ((long)tap * a.Cin + ci) * a.Cout + co;
+          if (a.slab) a.slab[(long)split * a.slab_stride + o] = acc[i][j][e];
+          else atomicAdd(a.dw + o, acc[i][j][e] * a.scale);
+        }
       }
     }
   }
@@ -297,6 +312,18 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_kernel(WgradArgs a) {
 // bit2 dy stored at half size), PF-slot register ring with no exits inside the unrolled body.
 // Sub-tiles are 64 B apart mod 256 B so the ds_write_b128 of one pixel's 128 channels is conflict-free.
 // ------------------------------------------------------------------------------------------------------
+// Launchers of the atomics-based kernels: take the caller's slab workspace when one is offered and the launch's splits fit it.
+static void wgrad_slab_setup(WgradArgs& a) {
+  a.slab = nullptr;
+  a.slab_stride = 0;
+  const long dw_elems = (long)a.taps * a.Cin * a.Cout;
+  if (a.slab_job) *a.slab_job = gank_slab_job{nullptr, a.dw, dw_elems, dw_elems, 0, a.scale};
+  if (!a.slab_ws || !a.slab_job || a.nbatch > 0 || a.splits < 2 || (long)a.splits * dw_elems > a.slab_elems) return;
+  a.slab = a.slab_ws;
+  a.slab_stride = dw_elems;
+  a.slab_job->slabs = a.slab_ws;
+  a.slab_job->nslabs = a.splits;
+}
 static int wgrad_xcd_env() {
   static const int v = gank_tune("GANK_WGRAD_XCD", 1);   // experiment knob: 0 = split-fastest block order without the XCD remap (WgradArgs.xcd)
   return v;
@@ -506,6 +533,9 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_lean_kernel(WgradArgs 
   if constexpr (PF >= 4) { if (s0 + 2 < nsteps) step(s0 + 2, std::integral_constant<int, 2 % PF>{}); }
 
   const int r = lane & 31, h = lane >> 5;
+#ifdef GANK_TUNING
+  if (a.dbg & 16) { if (acc[0][0][0] == 123.456f) DW[0] = 1.f; return; }
+#endif
 #pragma unroll
   for (int i = 0; i < TA; i++) {
 #pragma unroll
@@ -515,7 +545,11 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_lean_kernel(WgradArgs 
 #pragma unroll
       for (int e = 0; e < 16; e++) {
         const int ci = ci0 + (wave_a * TA + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (ci < a.Cin) atomicAdd(DW + ((long)tap * a.Cin + ci) * a.Cout + co, acc[i][j][e] * a.scale);
+        if (ci < a.Cin) {
+          const long o = ((long)tap * a.Cin + ci) * a.Cout + co;
+          if (a.slab) a.slab[(long)split * a.slab_stride + o] = acc[i][j][e];
+          else atomicAdd(DW + o, acc[i][j][e] * a.scale);
+        }
       }
     }
   }
@@ -562,6 +596,8 @@ static int launch_wgrad_lean_mode(WgradArgs a, hipStream_t s) {
   GANK_REQUIRE(grid < (1L << 30), "conv_wgrad: grid too large");
   static const std::string tag = gank_format("conv_wgrad_lean_kernel<%d, %d, %d, %d, %d, %d>", WA, WB, TA, TB, PF, MODE);     // magic static: built once, thread-safe
   gank_prof_tag(1, tag.c_str());
+  wgrad_slab_setup(a);
+  { static const int dbg_ = gank_tune("GANK_WGRAD_DBG", 0); a.dbg = dbg_; }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid, a.nbatch > 0 ? a.nbatch : 1), dim3(WA * WB * 64), lds, s, a);
   GANK_LAUNCH_OK("conv_wgrad_lean");
   return 0;
@@ -723,17 +759,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_packed_kernel(WgradArgs a) {
   if (s0 + 1 < nsteps) step(s0 + 1, std::integral_constant<int, 1>{});
 
   const int r = lane & 31, h = lane >> 5;
+#ifdef GANK_TUNING
+  if (a.dbg & 16) { if (acc[0] == 123.456f) a.dw[0] = 1.f; return; }
+#endif
 #pragma unroll
   for (int e = 0; e < 16; e++) {
     const int row = (e & 3) + 8 * (e >> 2) + 4 * h;      // MFMA row index 0..31, col = r
     if constexpr (PACK_X) {
       const int k = row, co = w0 + wave * 32 + r;        // dw[(tap*Cin+ci)][co] == dw[k][co]
-      if (k < kcols && co < a.Cout) atomicAdd(a.dw + (long)k * a.Cout + co, acc[e] * a.scale);
+      if (k < kcols && co < a.Cout) {
+        if (a.slab) a.slab[(long)split * a.slab_stride + (long)k * a.Cout + co] = acc[e];
+        else atomicAdd(a.dw + (long)k * a.Cout + co, acc[e] * a.scale);
+      }
     } else {
       const int ci = w0 + wave * 32 + row, k = r;        // k = tap*Cout + co
       if (k < kcols && ci < a.Cin) {
         const int tap = k / a.Cout, co = k - tap * a.Cout;
-        atomicAdd(a.dw + ((long)tap * a.Cin + ci) * a.Cout + co, acc[e] * a.scale);
+        const long o = ((long)tap * a.Cin + ci) * a.Cout + co;
+        if (a.slab) a.slab[(long)split * a.slab_stride + o] = acc[e];
+        else atomicAdd(a.dw + o, acc[e] * a.scale);
       }
     }
   }
@@ -773,6 +817,8 @@ static int launch_wgrad_packed(WgradArgs a, hipStream_t s) {
   const size_t lds = (size_t)2 * 5 * SUBS * sizeof(bf16);   // 41.6 KB (>= the 32 KB bias-reduction scratch)
   auto kern = conv_wgrad_packed_kernel<PACK_X>;
   gank_prof_tag(1, PACK_X ? "conv_wgrad_packed_kernel<true>" : "conv_wgrad_packed_kernel<false>");
+  wgrad_slab_setup(a);
+  { static const int dbg_ = gank_tune("GANK_WGRAD_DBG", 0); a.dbg = dbg_; }
   hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * a.splits)), dim3(256), lds, s, a);
   GANK_LAUNCH_OK("conv_wgrad_packed");
   return 0;
@@ -1579,6 +1625,8 @@ static int launch_wgrad(WgradArgs a, hipStream_t s) {
   GANK_REQUIRE(grid < (1L << 30), "conv_wgrad: grid too large");
   static const std::string tag = gank_format("conv_wgrad_kernel<%d, %d, %d, %d, %s, %d>", WA, WB, TA, TB, FAST ? "true" : "false", PF);     // magic static: built once, thread-safe
   gank_prof_tag(1, tag.c_str());
+  wgrad_slab_setup(a);
+  { static const int dbg_ = gank_tune("GANK_WGRAD_DBG", 0); a.dbg = dbg_; }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WA * WB * 64), lds, s, a);
   GANK_LAUNCH_OK("conv_wgrad");
   return 0;
@@ -1661,10 +1709,35 @@ extern "C" long gank_conv2d_wgrad_ws_elems(int N, int H, int W, int Cin, int Cou
   return a.splits > 1 ? 9L * Cin * Cout * a.splits : 0;
 }
 
+static int conv2d_wgrad_impl(const void* x, const void* dy, float* dw, float* dbias, float* ws, long ws_elems, int N, int H, int W, int Cin, int Cout,
+                             int ksize, int flags, float scale, float* slab_ws, long slab_elems, gank_slab_job* job, void* stream);
 extern "C" int gank_conv2d_wgrad(const void* x, const void* dy, float* dw, float* dbias, float* ws, long ws_elems, int N,
                                  int H, int W, int Cin, int Cout, int ksize, int flags, float scale, void* stream) {
+  return conv2d_wgrad_impl(x, dy, dw, dbias, ws, ws_elems, N, H, W, Cin, Cout, ksize, flags, scale, nullptr, 0, nullptr, stream);
+}
+// floats of slab workspace worth offering to gank_conv2d_wgrad_slabs (0: the filter is too large for per-split copies, or the
+// layer runs on a kernel with its own slab reduction): up to 256 pixel splits of filters of <= 65536 elements
+extern "C" long gank_conv2d_wgrad_slab_elems(int N, int H, int W, int Cin, int Cout, int ksize, int flags) {
+  const long dw_elems = (long)ksize * ksize * Cin * Cout;
+  if (dw_elems > 65536 || (long)N * H * W < 4096) return 0;
+  if (gank_conv2d_wgrad_ws_elems(N, H, W, Cin, Cout, ksize, flags) > 0) return 0;       // all-taps kernel: its own slabs
+  // Measured in the step (round 5): the narrow-channel layers (G.Output's 256 -> 3 filter gradient: 256 blocks x 6912 atomics onto the
+  // same addresses) lose 21 of 41 us to their atomics and 18 of them come back with slabs; the 1x1 shortcuts' small tiles lose 3 of
+  // 8.6 us and a slab store + their share of the summing launch costs as much; the 256 -> 256 shortcut's 64 slabs are 16.8 MB.
+  if (!(Cin <= 4 || Cout <= 4) || ksize * ksize * (Cin <= 4 ? Cin : Cout) > 32) return 0;
+  return 256 * dw_elems;
+}
+extern "C" int gank_conv2d_wgrad_slabs(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int Cin, int Cout, int ksize,
+                                       int flags, float scale, float* slab_ws, long slab_elems, gank_slab_job* job, void* stream) {
+  GANK_REQUIRE(slab_ws && job && slab_elems > 0, "conv2d_wgrad_slabs: null slab workspace / job");
+  *job = gank_slab_job{nullptr, dw, (long)ksize * ksize * Cin * Cout, (long)ksize * ksize * Cin * Cout, 0, scale};
+  return conv2d_wgrad_impl(x, dy, dw, dbias, nullptr, 0, N, H, W, Cin, Cout, ksize, flags, scale, slab_ws, slab_elems, job, stream);
+}
+static int conv2d_wgrad_impl(const void* x, const void* dy, float* dw, float* dbias, float* ws, long ws_elems, int N, int H, int W, int Cin, int Cout,
+                             int ksize, int flags, float scale, float* slab_ws, long slab_elems, gank_slab_job* job, void* stream) {
   GANK_REQUIRE(ksize % 2 == 1, "conv2d_wgrad: even filter sizes are not on this path (ksize=%d)", ksize);
   WgradArgs a{};
+  a.slab_ws = slab_ws; a.slab_elems = slab_elems; a.slab_job = job;
   a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.dw = dw; a.dbias = dbias; a.ws = ws; a.ws_elems = ws_elems;
   a.N = N; a.H = H; a.W = W;
   const bool xup = flags & GANK_IN_UPSAMPLE2X, dyup = flags & GANK_DY_UPSAMPLE2X;

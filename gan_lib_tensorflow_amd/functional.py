@@ -309,7 +309,8 @@ class _Conv2d(Function):
                     K.colsum(g, btgt, 1.0)           # (the rows kernel sums its OTHER operand: the bias gradient is a launch of its own)
             else:
                 # bias gradient rides on the dy stream
-                K.conv2d_wgrad(x, g, tgt, (H, Wd), k, wflags, scale, dbias=btgt)
+                K.conv2d_wgrad(x, g, tgt, (H, Wd), k, wflags, scale, dbias=btgt,
+                               slab_jobs=_slab_jobs if (SLAB_WGRADS and BATCH_SMALL_WGRADS) else None)
             dW = None if acc else tgt
         elif btgt is not None:
             K.colsum(g, btgt, 1.0)

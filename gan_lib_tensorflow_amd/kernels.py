@@ -201,10 +201,23 @@ def conv2d_dgrad(dy, wd, out_hw, cin, ksize, flags=0, scale=1.0, residual=None, 
     return dx
 
 
-def conv2d_wgrad(x, dy, dw, hw, ksize, flags=0, scale=1.0, dbias=None):
-    """ACCUMULATES into dw fp32 [k,k,Cin,Cout] (and the bias gradient into dbias fp32 [Cout] when given)."""
+def conv2d_wgrad(x, dy, dw, hw, ksize, flags=0, scale=1.0, dbias=None, slab_jobs=None):
+    """ACCUMULATES into dw fp32 [k,k,Cin,Cout] (and the bias gradient into dbias fp32 [Cout] when given).
+    slab_jobs: a list -- small filters on the split-K kernels that add their partial tiles with fp32 atomics write per-split
+    slabs instead, and the job that sums them into dw is appended: the caller owes a sum_slabs(list) (dbias: as before)."""
     n, cin, cout = x.shape[0], x.shape[3], dy.shape[3]
     assert dw.shape[-2] == cin and dw.shape[-1] == cout, (dw.shape, cin, cout)
+    if slab_jobs is not None:
+        slab_elems = int(lib().gank_conv2d_wgrad_slab_elems(n, hw[0], hw[1], cin, cout, ksize, flags))
+        if slab_elems > 0:
+            ws = torch.empty(slab_elems, dtype=F32, device=x.device)
+            job = (SlabJob * 1)()
+            _lib.check(lib().gank_conv2d_wgrad_slabs(_p(x, BF16, "x"), _p(dy, BF16, "dy"), _p(dw, F32, "dw"), _p(dbias, F32, "dbias"),
+                                                     n, hw[0], hw[1], cin, cout, ksize, flags, scale, _p(ws), slab_elems, job, _stream()),
+                       "conv2d_wgrad_slabs")
+            if job[0].nslabs > 0:
+                slab_jobs.append((job, 1, ws))
+            return dw
     ws_elems = lib().gank_conv2d_wgrad_ws_elems(n, hw[0], hw[1], cin, cout, ksize, flags)
     ws = torch.empty(ws_elems, dtype=F32, device=x.device) if ws_elems > 0 else None
     _lib.check(lib().gank_conv2d_wgrad(_p(x, BF16, "x"), _p(dy, BF16, "dy"), _p(dw, F32, "dw"), _p(dbias, F32, "dbias"),

@@ -140,6 +140,12 @@ typedef struct gank_slab_job {
   float scale;
 } gank_slab_job;
 int gank_sum_slabs(const gank_slab_job* jobs, int count, void* stream);
+/* gank_conv2d_wgrad whose split-K kernels (per-tap, 1x1 / narrow-channel forms) store their partial tiles into per-split copies
+ * of the filter inside `slab_ws` (gank_conv2d_wgrad_slab_elems floats; 0 = not worth it / not applicable) instead of adding
+ * them to dw with fp32 atomics; *job then describes the sum (nslabs = 0: the launch accumulated into dw directly, nothing to do). */
+long gank_conv2d_wgrad_slab_elems(int N, int H, int W, int Cin, int Cout, int ksize, int flags);
+int gank_conv2d_wgrad_slabs(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int Cin, int Cout, int ksize,
+                            int flags, float scale, float* slab_ws, long slab_elems, gank_slab_job* job, void* stream);
 long gank_conv2d_wgrad_batched_ws_elems(int count, int N, int H, int W, int Cin, int Cout, int ksize, int flags);
 int gank_conv2d_wgrad_batched_slabs(const gank_wgrad_item* items, int count, int N, int H, int W, int Cin, int Cout, int ksize,
                                     int flags, float scale, float* ws, long ws_elems, gank_slab_job* jobs, void* stream);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scratch/ab_base.sh [reps] [steps] ["ENV=.. ENV=.." ...]   -- the round-3 tree (_baseline_r03, a git worktree of a14a361 with its own
+# usage: scratch/ab_base.sh [reps] [steps] ["ENV=.. ENV=.." ...]   -- the round-4 tree (_baseline_r04, a git worktree of 282d0e9 with its own
 # libgank.so, not tracked) against the current tree, bench.py interleaved on ONE box; extra arguments: environment settings of further
 # arms of the current tree
 reps=${1:-2}; steps=${2:-100}; shift 2 2>/dev/null
@@ -10,7 +10,7 @@ one() {   # dir, label, env...
     python -c "import json; d=json.load(open('/tmp/ab.json')); print('$label', d['value'], 'img/s', d['ms_per_step'], 'ms', 'median', d['median_ms_per_step_hip_events'])" )
 }
 for rep in $(seq $reps); do
-  [ -d $root/_baseline_r03 ] && one $root/_baseline_r03 "r03-baseline" X=1
+  [ -d $root/_baseline_r04 ] && one $root/_baseline_r04 "r04-baseline" X=1
   one $root "current" X=1
   for kv in "$@"; do one $root "current[$kv]" $kv; done
 done

@@ -1793,3 +1793,39 @@ def test_spectral_norm_backward_adam_and_next_power_iteration_in_one_launch(K, h
     assert B["st"].valid and torch.equal(B["u_flat"], u_before)
     for x, y in zip(WRA, WR):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("n,h,cin,cout,k,relu", [(128, 16, 256, 256, 1, False), (128, 8, 256, 128, 1, False), (16, 32, 256, 3, 3, False), (8, 16, 64, 64, 1, True),
+                                                 (4, 8, 128, 128, 3, False), (128, 16, 256, 256, 3, False)])
+def test_conv_wgrad_split_slabs_instead_of_atomics(K, n, h, cin, cout, k, relu):
+    """gank_conv2d_wgrad_slabs + gank_sum_slabs (round 5): the split-K kernels that add their partial tiles with fp32 atomics
+    (1x1 shortcuts, the 256 -> 3 output layer's filter gradient, small per-tap layers) write per-split copies of the filter
+    and ONE later launch sums them, scaled, into the non-zero target -- same result as the atomics form (oracle tolerance),
+    bit-identical from run to run; layers on kernels with their own slab reduction (last case: all-taps) report no job."""
+    rng = np.random.default_rng(n + h + cin + cout + k)
+    x, xt = bf(rng.normal(size=(n, h, h, cin)))
+    dy, dyt = bf(rng.normal(size=(n, h, h, cout)))
+    xin = R.relu(x) if relu else x
+    if k == 3:
+        _, rdw, rdb = R.conv2d_same_grads(xin, np.zeros((3, 3, cin, cout)), dy)
+    else:
+        rdw, rdb = np.einsum('nhwc,nhwo->co', xin, dy).reshape(1, 1, cin, cout), dy.sum((0, 1, 2))
+    w0 = rng.normal(size=(k, k, cin, cout)).astype(np.float32)
+    flags = K.IN_RELU if relu else 0
+    outs = []
+    for rep in range(2):
+        dw, db = torch.tensor(w0).cuda(), torch.zeros(cout, device="cuda")
+        jobs = []
+        K.conv2d_wgrad(xt, dyt, dw, (h, h), k, flags, 0.5, dbias=db, slab_jobs=jobs)
+        expect_job = K.lib().gank_conv2d_wgrad_slab_elems(n, h, h, cin, cout, k, flags) > 0
+        if not expect_job:
+            assert jobs == []
+        else:
+            assert len(jobs) == 1 and torch.equal(dw.cpu(), torch.tensor(w0))          # nothing reached the target before the sum
+            K.sum_slabs(jobs)
+        torch.cuda.synchronize()
+        assert relerr(dw - torch.tensor(w0).cuda(), 0.5 * rdw) < F32_FROM_BF_TOL
+        assert relerr(db, 0.5 * rdb) < F32_FROM_BF_TOL
+        outs.append((dw.clone(), expect_job))
+    if (n, h, cin, cout, k) == (16, 32, 256, 3, 3):
+        assert outs[0][1] and torch.equal(outs[0][0], outs[1][0])    # the output layer's geometry takes the slab form: deterministic
