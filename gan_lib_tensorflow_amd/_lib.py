@@ -35,7 +35,7 @@ class WgradItem(C.Structure):
 
 class SlabJob(C.Structure):
     """gank_slab_job"""
-    _fields_ = [("slabs", P), ("out", P), ("n", L), ("stride", L), ("nslabs", I), ("scale", F)]
+    _fields_ = [("slabs", P), ("out", P), ("n", L), ("stride", L), ("nslabs", I), ("scale", F), ("fold", I)]
 
 
 class PrepDesc(C.Structure):
@@ -104,6 +104,7 @@ PROTOTYPES = {
     "gank_cpool_res_dgrad": [P, P, P, P, I, I, I, I, I, P],
     "gank_cpool_res_dgrad_image_wgrad": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, P],
     "gank_sum_slabs": [C.POINTER(SlabJob), I, P],
+    "gank_convpool3x3_wgrad_job": [P, P, P, P, P, L, I, I, I, I, I, I, C.POINTER(SlabJob), P],
     "gank_conv2d_wgrad_slab_elems": [I, I, I, I, I, I, I],
     "gank_conv2d_wgrad_slabs": [P, P, P, P, I, I, I, I, I, I, I, F, P, L, C.POINTER(SlabJob), P],
     "gank_conv2d_wgrad_batched_ws_elems": [I, I, I, I, I, I, I, I],

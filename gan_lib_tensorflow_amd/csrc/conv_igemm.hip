@@ -15,6 +15,17 @@
 // Replaces tf.nn.conv2d / Conv2DBackpropInput at common/ops/conv2d.py:180-187 and the
 // surrounding block-library glue (SNGAN/gan_cifar_resnet.py:112-153,186,198,209,261).
 #include "gank_common.h"
+#ifdef GANK_TUNING
+// timing-only experiment (GANK_STATS_DBG=1): the statistics epilogues skip their atomics (set once per process, before the first launch)
+static __device__ int gank_stats_dbg = 0;
+static void gank_stats_dbg_init() {
+  static const int v = gank_tune("GANK_STATS_DBG", 0);
+  static bool done = false;
+  if (!done) { done = true; if (v) (void)hipMemcpyToSymbol(HIP_SYMBOL(gank_stats_dbg), &v, sizeof(int)); }
+}
+#else
+static inline void gank_stats_dbg_init() {}
+#endif
 #include <stdlib.h>
 #include <type_traits>
 
@@ -484,6 +495,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(IgemmArgs a) {
       const int n0 = a.shw >= 0 ? (m0 >> a.shw) : m0 / (a.H * a.W);
       float* dst = a.stat_sums + ((long)(n0 / a.stat_n_per_group) * GANK_STAT_SLOTS + (blockIdx.x % GANK_STAT_SLOTS)) * 2 * a.Cout;
       const int co = tile_n * BN + (wave_n * TN + (r >> 4)) * 32 + 16 * ((r >> 3) & 1) + 8 * h + (r & 7);
+#ifdef GANK_TUNING
+      if (gank_stats_dbg) return;
+#endif
       atomicAdd(dst + co, keep1);
       atomicAdd(dst + a.Cout + co, keep2);
     }
@@ -1502,6 +1516,9 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
     // ONE full-width atomic per statistic and wave: lane (p16, kc) carries channel (P, e) = (p16 >> 3, p16 & 7) of its row
     float* dst = a.stat_sums + ((long)(n / a.stat_n_per_group) * GANK_STAT_SLOTS + (blockIdx.x % GANK_STAT_SLOTS)) * 2 * a.Cout;
     const int co = tile_n * 256 + wn * 64 + (2 * (p16 >> 3) + (kc & 1)) * 16 + 8 * (kc >> 1) + (p16 & 7);
+#ifdef GANK_TUNING
+    if (gank_stats_dbg) return;
+#endif
     atomicAdd(dst + co, keep1);
     atomicAdd(dst + a.Cout + co, keep2);
   }
@@ -1594,6 +1611,9 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(IgemmArgs a) {
     float* dst = a.stat_sums + ((long)(n / a.stat_n_per_group) * GANK_STAT_SLOTS + (blockIdx.x % GANK_STAT_SLOTS)) * 2 * a.Cout;
     const int ci = r >> 4, cq = (r >> 3) & 1, ce = r & 7;
     const int co = tile_n * 256 + (wn * 2 + ci) * 32 + 16 * cq + 8 * h + ce;
+#ifdef GANK_TUNING
+    if (gank_stats_dbg) return;
+#endif
     atomicAdd(dst + co, keep1);
     atomicAdd(dst + a.Cout + co, keep2);
   }
@@ -1817,6 +1837,7 @@ int gank_igemm_dispatch(IgemmArgs a, hipStream_t s) {
 static int stats_setup(IgemmArgs& a, float* stat_sums, int groups, int N, int Cout, hipStream_t s, int flags) {
   tl_stats_done = 0;
   if (!stat_sums) return 0;
+  gank_stats_dbg_init();
   a.stat_prezeroed = (flags & GANK_STATS_PREZEROED) != 0;
   GANK_REQUIRE(groups > 0 && N % groups == 0, "conv statistics: batch %d not divisible by %d towers", N, groups);
   a.stat_sums = stat_sums;

@@ -18,6 +18,17 @@
 // bf16, one coalesced 1 KB request per MFMA A-fragment, a register ring of 8 requests in flight per wave.
 // Wave ct of the 4: output channels 32*ct .. +31 of all 64 pixels (two MFMA tiles: image rows 0-3, 4-7).
 #include "gank_common.h"
+#ifdef GANK_TUNING
+// timing-only experiment (GANK_STATS_DBG=1): the statistics epilogues skip their atomics (set once per process, before the first launch)
+static __device__ int gank_stats_dbg = 0;
+static void gank_stats_dbg_init() {
+  static const int v = gank_tune("GANK_STATS_DBG", 0);
+  static bool done = false;
+  if (!done) { done = true; if (v) (void)hipMemcpyToSymbol(HIP_SYMBOL(gank_stats_dbg), &v, sizeof(int)); }
+}
+#else
+static inline void gank_stats_dbg_init() {}
+#endif
 #include <stdlib.h>
 
 namespace {
@@ -1818,6 +1829,9 @@ __global__ __launch_bounds__(HALF ? 512 : 2048 / TW) void img16_conv3x3_kernel(I
       tsum += (t4[0] + t4[1]) + (t4[2] + t4[3]);
     }
     float* dst = a.stat_sums + ((long)(n / a.stat_n_per_group) * GANK_STAT_SLOTS + (blockIdx.x % GANK_STAT_SLOTS)) * 2 * a.Cout;
+#ifdef GANK_TUNING
+    if (gank_stats_dbg) return;
+#endif
     atomicAdd(dst + st * a.Cout + cg * 128 + ct * 32 + cw, tsum);
   }
 }
@@ -1842,6 +1856,7 @@ extern "C" int gank_img16_conv3x3_stats(const void* x, const void* w_rfrag, cons
   a.res_up = (flags & GANK_RES_UPSAMPLE2X) ? 1 : 0; a.stat_sums = stat_sums; a.stat_n_per_group = stat_sums ? N / stat_groups : 1;
   a.xcd = resident_xcd_env();
   hipStream_t s = (hipStream_t)stream;
+  if (stat_sums) gank_stats_dbg_init();
   if (stat_sums && !(flags & GANK_STATS_PREZEROED)) {
     const int nz = stat_groups * GANK_STAT_SLOTS * 2 * Cout;
     hipLaunchKernelGGL(i16_zero_kernel, dim3((nz + 255) / 256), dim3(256), 0, s, stat_sums, nz);
@@ -2097,6 +2112,9 @@ __global__ __launch_bounds__(256) void res8_conv3x3_kernel(G8Args a) {
       tsum += (t4[0] + t4[1]) + (t4[2] + t4[3]);
     }
     float* dst = a.stat_sums + ((long)(n / a.stat_n_per_group) * GANK_STAT_SLOTS + (blockIdx.x % GANK_STAT_SLOTS)) * 2 * a.Cout;
+#ifdef GANK_TUNING
+    if (gank_stats_dbg) return;
+#endif
     atomicAdd(dst + st * a.Cout + co0 + cw, tsum);
   }
 }
@@ -2129,6 +2147,7 @@ extern "C" int gank_res8_conv3x3(const void* x, const void* w_rfrag, const float
   gank_prof_begin(0, 2.0 * N * 64.0 * 9.0 * Cin * Cout, s,
                   2.0 * (N * px_in * Cin + 9.0 * Cin * Cout + N * px_out * Cout + (residual ? N * (a.res_up ? 16.0 : 64.0) * Cout : 0.0)));
   gank_prof_tag(0, Cin == 256 ? "res8_conv3x3_kernel<256, 12>" : "res8_conv3x3_kernel<128, 12>");
+  if (stat_sums) gank_stats_dbg_init();
   if (stat_sums && !(flags & GANK_STATS_PREZEROED)) {
     const int nz = stat_groups * GANK_STAT_SLOTS * 2 * Cout;
     hipLaunchKernelGGL(g8_zero_kernel, dim3((nz + 255) / 256), dim3(256), 0, s, stat_sums, nz);

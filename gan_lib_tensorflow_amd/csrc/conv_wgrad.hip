@@ -317,7 +317,7 @@ static void wgrad_slab_setup(WgradArgs& a) {
   a.slab = nullptr;
   a.slab_stride = 0;
   const long dw_elems = (long)a.taps * a.Cin * a.Cout;
-  if (a.slab_job) *a.slab_job = gank_slab_job{nullptr, a.dw, dw_elems, dw_elems, 0, a.scale};
+  if (a.slab_job) *a.slab_job = gank_slab_job{nullptr, a.dw, dw_elems, dw_elems, 0, a.scale, 0};
   if (!a.slab_ws || !a.slab_job || a.nbatch > 0 || a.splits < 2 || (long)a.splits * dw_elems > a.slab_elems) return;
   a.slab = a.slab_ws;
   a.slab_stride = dw_elems;
@@ -1299,7 +1299,9 @@ static int launch_wgrad_taps_mode(WgradArgs a, hipStream_t s) {
   a.xcd = wgrad_xcd_env();
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_ci * a.tiles_co * a.splits)), dim3(256), lds, s, a);
   GANK_LAUNCH_OK("conv_wgrad_taps");
-  if (a.ws) {
+  if (a.ws && a.slab_job && a.splits <= 16) {       // the caller sums the slabs later, with other producers' (gank_sum_slabs)
+    *a.slab_job = gank_slab_job{a.ws, a.dw, slab, slab, a.splits, 1.0f, 0};
+  } else if (a.ws) {
     const long n4 = slab / 4;
     long blocks = (n4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
@@ -1719,8 +1721,9 @@ extern "C" int gank_conv2d_wgrad(const void* x, const void* dy, float* dw, float
 // layer runs on a kernel with its own slab reduction): up to 256 pixel splits of filters of <= 65536 elements
 extern "C" long gank_conv2d_wgrad_slab_elems(int N, int H, int W, int Cin, int Cout, int ksize, int flags) {
   const long dw_elems = (long)ksize * ksize * Cin * Cout;
+  const long taps_ws = gank_conv2d_wgrad_ws_elems(N, H, W, Cin, Cout, ksize, flags);
+  if (taps_ws > 0) return taps_ws;              // all-taps kernel: its slabs, the reduction left to the caller's summing launch
   if (dw_elems > 65536 || (long)N * H * W < 4096) return 0;
-  if (gank_conv2d_wgrad_ws_elems(N, H, W, Cin, Cout, ksize, flags) > 0) return 0;       // all-taps kernel: its own slabs
   // Measured in the step (round 5): the narrow-channel layers (G.Output's 256 -> 3 filter gradient: 256 blocks x 6912 atomics onto the
   // same addresses) lose 21 of 41 us to their atomics and 18 of them come back with slabs; the 1x1 shortcuts' small tiles lose 3 of
   // 8.6 us and a slab store + their share of the summing launch costs as much; the 256 -> 256 shortcut's 64 slabs are 16.8 MB.
@@ -1730,7 +1733,7 @@ extern "C" long gank_conv2d_wgrad_slab_elems(int N, int H, int W, int Cin, int C
 extern "C" int gank_conv2d_wgrad_slabs(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int Cin, int Cout, int ksize,
                                        int flags, float scale, float* slab_ws, long slab_elems, gank_slab_job* job, void* stream) {
   GANK_REQUIRE(slab_ws && job && slab_elems > 0, "conv2d_wgrad_slabs: null slab workspace / job");
-  *job = gank_slab_job{nullptr, dw, (long)ksize * ksize * Cin * Cout, (long)ksize * ksize * Cin * Cout, 0, scale};
+  *job = gank_slab_job{nullptr, dw, (long)ksize * ksize * Cin * Cout, (long)ksize * ksize * Cin * Cout, 0, scale, 0};
   return conv2d_wgrad_impl(x, dy, dw, dbias, nullptr, 0, N, H, W, Cin, Cout, ksize, flags, scale, slab_ws, slab_elems, job, stream);
 }
 static int conv2d_wgrad_impl(const void* x, const void* dy, float* dw, float* dbias, float* ws, long ws_elems, int N, int H, int W, int Cin, int Cout,
@@ -1738,6 +1741,7 @@ static int conv2d_wgrad_impl(const void* x, const void* dy, float* dw, float* db
   GANK_REQUIRE(ksize % 2 == 1, "conv2d_wgrad: even filter sizes are not on this path (ksize=%d)", ksize);
   WgradArgs a{};
   a.slab_ws = slab_ws; a.slab_elems = slab_elems; a.slab_job = job;
+  if (slab_ws && !ws) { ws = slab_ws; ws_elems = slab_elems; }        // (a layer on the all-taps kernel takes the offered space as its slab workspace)
   a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.dw = dw; a.dbias = dbias; a.ws = ws; a.ws_elems = ws_elems;
   a.N = N; a.H = H; a.W = W;
   const bool xup = flags & GANK_IN_UPSAMPLE2X, dyup = flags & GANK_DY_UPSAMPLE2X;
@@ -1838,8 +1842,20 @@ extern "C" long gank_convpool3x3_wgrad_ws_elems(int N, int Hp, int Wp, int Cin, 
   return 16L * Cin * Cout * a.splits;
 }
 
+static int convpool3x3_wgrad_impl(const void* x, const void* dy, float* dw, float* dbias, float* ws16, long ws_elems, int N, int Hp, int Wp,
+                                  int Cin, int Cout, int flags, gank_slab_job* job, void* stream);
 extern "C" int gank_convpool3x3_wgrad(const void* x, const void* dy, float* dw, float* dbias, float* ws16, long ws_elems, int N, int Hp, int Wp,
                                       int Cin, int Cout, int flags, void* stream) {
+  return convpool3x3_wgrad_impl(x, dy, dw, dbias, ws16, ws_elems, N, Hp, Wp, Cin, Cout, flags, nullptr, stream);
+}
+extern "C" int gank_convpool3x3_wgrad_job(const void* x, const void* dy, float* dw, float* dbias, float* ws16, long ws_elems, int N, int Hp, int Wp,
+                                          int Cin, int Cout, int flags, gank_slab_job* job, void* stream) {
+  GANK_REQUIRE(job, "convpool3x3_wgrad_job: null job");
+  *job = gank_slab_job{nullptr, dw, 9L * Cin * Cout, 16L * Cin * Cout, 0, 0.25f, 1};
+  return convpool3x3_wgrad_impl(x, dy, dw, dbias, ws16, ws_elems, N, Hp, Wp, Cin, Cout, flags, job, stream);
+}
+static int convpool3x3_wgrad_impl(const void* x, const void* dy, float* dw, float* dbias, float* ws16, long ws_elems, int N, int Hp, int Wp,
+                                  int Cin, int Cout, int flags, gank_slab_job* job, void* stream) {
   GANK_REQUIRE(x && dy && dw && ws16, "convpool3x3_wgrad: null pointer");
   GANK_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "convpool3x3_wgrad: channels must be multiples of 4");
   hipStream_t s = (hipStream_t)stream;
@@ -1868,7 +1884,12 @@ extern "C" int gank_convpool3x3_wgrad(const void* x, const void* dy, float* dw, 
     a.xcd = wgrad_xcd_env();
     hipLaunchKernelGGL(kern, dim3((unsigned)(4 * a.tiles_ci * a.tiles_co * a.splits)), dim3(256), lds, s, a);
     const long plane4 = (long)Cin * Cout / 4;
-    hipLaunchKernelGGL(wgrad_cpool_fold_slabs_kernel, dim3((unsigned)cdiv(plane4, 256), 9), dim3(256), 0, s, ws16, dw, plane4, a.splits);
+    if (job && a.splits <= 16 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0) {        // the fold is left to the caller's summing launch
+      job->slabs = ws16;
+      job->nslabs = a.splits;
+    } else {
+      hipLaunchKernelGGL(wgrad_cpool_fold_slabs_kernel, dim3((unsigned)cdiv(plane4, 256), 9), dim3(256), 0, s, ws16, dw, plane4, a.splits);
+    }
     gank_prof_end(1, s);
     GANK_LAUNCH_OK("convpool3x3_wgrad");
     return 0;
@@ -2046,7 +2067,7 @@ static int wgrad_batched_impl(const gank_wgrad_item* items, int count, int N, in
       a.wss[j] = nullptr;
       if (ws && rows) {        // partial tiles to slabs [split][9][Cin][Cout]; the caller sums them (gank_sum_slabs)
         a.wss[j] = ws + ws_used;
-        jobs[i + j] = gank_slab_job{a.wss[j], items[i + j].dw, slab, slab, splits, scale};
+        jobs[i + j] = gank_slab_job{a.wss[j], items[i + j].dw, slab, slab, splits, scale, 0};
         ws_used += (long)splits * slab;
       }
     }

@@ -390,19 +390,47 @@ extern "C" int gank_weighted_sum4_f32(const float* a, const float* b, const floa
 // the SAME 4096 addresses) and of the batched 8x8 layers (240 x 12288) cost 17 + 12 us of their kernels' 40 + 30 us.
 // Few slabs (<= 16): a thread owns 4 consecutive outputs and walks the slabs; many slabs (the 256 of the fused gradient): a
 // block owns 64 outputs, its four waves take every fourth slab each and meet in LDS.
+constexpr int SLAB_JOBS = 12;
 struct SlabJobTable {
-  gank_slab_job j[8];
-  int first_block[9];
+  gank_slab_job j[SLAB_JOBS];
+  int first_block[SLAB_JOBS + 1];
   int count;
 };
 __global__ __launch_bounds__(256) void sum_slabs_kernel(SlabJobTable t) {
   __shared__ float part[4][64];
   int ji = 0;
 #pragma unroll
-  for (int i = 1; i < 8; i++) ji += (i < t.count && (int)blockIdx.x >= t.first_block[i]) ? 1 : 0;
+  for (int i = 1; i < SLAB_JOBS; i++) ji += (i < t.count && (int)blockIdx.x >= t.first_block[i]) ? 1 : 0;
   const gank_slab_job& jb = t.j[ji];
   const int lb = blockIdx.x - t.first_block[ji], tid = threadIdx.x;
   const float* __restrict__ sl = jb.slabs;
+  if (jb.fold) {
+    // 4x4 -> 3x3 fold of the ConvMeanPool filter gradient (wgrad_cpool_fold_slabs_kernel's arithmetic and order): one thread per
+    // (3x3 tap, float4 of the plane); host checked plane % 4 == 0 and 16-byte alignment
+    const long plane4 = jb.n / 36, i = (long)lb * 256 + tid;
+    if (i >= 9 * plane4) return;
+    const int tap = (int)(i / plane4), ti = tap / 3, tj = tap - 3 * ti;
+    const long e = i - (long)tap * plane4;
+    const long stride4 = jb.stride >> 2;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < jb.nslabs; sp += 2) {          // 8 independent loads per batch (2 splits x 4 source taps), fixed order
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int s2 = min(sp + (u >> 2), jb.nslabs - 1);
+        const int src = (ti + ((u >> 1) & 1)) * 4 + tj + (u & 1);
+        v[u] = reinterpret_cast<const f32x4*>(sl)[(long)s2 * stride4 + (long)src * plane4 + e];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (sp + (u >> 2) < jb.nslabs) { acc[0] += v[u][0]; acc[1] += v[u][1]; acc[2] += v[u][2]; acc[3] += v[u][3]; }
+    }
+    f32x4 o = reinterpret_cast<f32x4*>(jb.out)[(long)tap * plane4 + e];
+#pragma unroll
+    for (int q = 0; q < 4; q++) o[q] += jb.scale * acc[q];
+    reinterpret_cast<f32x4*>(jb.out)[(long)tap * plane4 + e] = o;
+    return;
+  }
   if (jb.nslabs <= 16) {
     const long i0 = ((long)lb * 256 + tid) * 4;
     if (i0 >= jb.n) return;
@@ -445,16 +473,18 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(SlabJobTable t) {
 }
 extern "C" int gank_sum_slabs(const gank_slab_job* jobs, int count, void* stream) {
   GANK_REQUIRE(jobs && count > 0, "sum_slabs: empty list");
-  for (int base = 0; base < count; base += 8) {
+  for (int base = 0; base < count; base += SLAB_JOBS) {
     SlabJobTable t{};
-    t.count = count - base < 8 ? count - base : 8;
+    t.count = count - base < SLAB_JOBS ? count - base : SLAB_JOBS;
     int blocks = 0;
     for (int i = 0; i < t.count; i++) {
       const gank_slab_job& j = jobs[base + i];
-      GANK_REQUIRE(j.slabs && j.out && j.n > 0 && j.nslabs > 0 && j.stride >= j.n, "sum_slabs: bad job %d", base + i);
+      GANK_REQUIRE(j.slabs && j.out && j.n > 0 && j.nslabs > 0 && (j.fold ? j.stride >= j.n / 9 * 16 : j.stride >= j.n), "sum_slabs: bad job %d", base + i);
+      GANK_REQUIRE(!j.fold || (j.n % 36 == 0 && (j.stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(j.slabs) | reinterpret_cast<uintptr_t>(j.out)) & 15) == 0),
+                   "sum_slabs: fold job %d needs n %% 36 == 0 and 16-byte aligned buffers", base + i);
       t.j[i] = j;
       t.first_block[i] = blocks;
-      blocks += j.nslabs <= 16 ? (int)((j.n + 1023) / 1024) : (int)((j.n + 63) / 64);
+      blocks += j.fold ? (int)((j.n / 4 + 255) / 256) : (j.nslabs <= 16 ? (int)((j.n + 1023) / 1024) : (int)((j.n + 63) / 64));
     }
     t.first_block[t.count] = blocks;
     hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t);

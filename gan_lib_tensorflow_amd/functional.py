@@ -291,7 +291,8 @@ class _Conv2d(Function):
             db = None if bacc else btgt
         if ctx.needs_input_grad[1] and pool4:
             tgt, acc = _target(W)
-            K.convpool3x3_wgrad(x, g, tgt.view(3, 3, cin, cout), K.IN_RELU if in_relu else 0, dbias=btgt)
+            K.convpool3x3_wgrad(x, g, tgt.view(3, 3, cin, cout), K.IN_RELU if in_relu else 0, dbias=btgt,
+                                slab_jobs=_slab_jobs if (SLAB_WGRADS and BATCH_SMALL_WGRADS) else None)
             dW = None if acc else tgt
         elif ctx.needs_input_grad[1]:
             tgt, acc = _target(W)

@@ -594,13 +594,21 @@ def cpool_res_dgrad_image_wgrad(dy, rd, relu_ref, x_image, dw1, db1=None, x_pool
                 slab_jobs.append(slab_job(slabs[row0 * 128:], tgt, rows * 128, 4096, nsl))
 
 
-def convpool3x3_wgrad(x, dy, dw, flags=0, dbias=None):
-    """ACCUMULATES the ConvMeanPool 3x3 filter gradient into dw fp32 [3,3,Cin,Cout] (and dbias)."""
+def convpool3x3_wgrad(x, dy, dw, flags=0, dbias=None, slab_jobs=None):
+    """ACCUMULATES the ConvMeanPool 3x3 filter gradient into dw fp32 [3,3,Cin,Cout] (and dbias).  slab_jobs: a list -- the
+    sum-and-fold of the filter-row kernel's slabs is left to the caller's sum_slabs(list) (job appended; dbias as before)."""
     n, hp, wp, cout = dy.shape
     cin = x.shape[3]
     assert x.shape[1] == 2 * hp and x.shape[2] == 2 * wp and dw.numel() == 9 * cin * cout, (x.shape, dy.shape, dw.shape)
     ws_elems = lib().gank_convpool3x3_wgrad_ws_elems(n, hp, wp, cin, cout)
     ws16 = torch.empty(ws_elems, dtype=F32, device=x.device)
+    if slab_jobs is not None:
+        job = (SlabJob * 1)()
+        _lib.check(lib().gank_convpool3x3_wgrad_job(_p(x, BF16, "x"), _p(dy, BF16, "dy"), _p(dw, F32, "dw"), _p(dbias, F32, "dbias"),
+                                                    _p(ws16), ws_elems, n, hp, wp, cin, cout, flags, job, _stream()), "convpool3x3_wgrad_job")
+        if job[0].nslabs > 0:
+            slab_jobs.append((job, 1, ws16))
+        return
     _lib.check(lib().gank_convpool3x3_wgrad(_p(x, BF16, "x"), _p(dy, BF16, "dy"), _p(dw, F32, "dw"), _p(dbias, F32, "dbias"),
                                             _p(ws16), ws_elems, n, hp, wp, cin, cout, flags, _stream()), "convpool3x3_wgrad")
     return dw

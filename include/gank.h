@@ -138,14 +138,21 @@ typedef struct gank_slab_job {
   long stride;     /* floats between consecutive slabs (>= n)  */
   int nslabs;
   float scale;
+  int fold;        /* 0: plain sum.  1: each slab holds the SIXTEEN taps of a 4x4 stride-2 filter gradient [16][n / 9] (ConvMeanPool as one
+                      conv, gank_convpool3x3_wgrad) and out the nine of the 3x3 filter: out[3i+j] += scale * sum_{s,t in {0,1}} slab[4(i+s)+j+t] */
 } gank_slab_job;
-int gank_sum_slabs(const gank_slab_job* jobs, int count, void* stream);
+int gank_sum_slabs(const gank_slab_job* jobs, int count, void* stream);    /* up to 12 jobs per launch */
 /* gank_conv2d_wgrad whose split-K kernels (per-tap, 1x1 / narrow-channel forms) store their partial tiles into per-split copies
  * of the filter inside `slab_ws` (gank_conv2d_wgrad_slab_elems floats; 0 = not worth it / not applicable) instead of adding
  * them to dw with fp32 atomics; *job then describes the sum (nslabs = 0: the launch accumulated into dw directly, nothing to do). */
 long gank_conv2d_wgrad_slab_elems(int N, int H, int W, int Cin, int Cout, int ksize, int flags);
 int gank_conv2d_wgrad_slabs(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int Cin, int Cout, int ksize,
                             int flags, float scale, float* slab_ws, long slab_elems, gank_slab_job* job, void* stream);
+/* (layers on the all-taps kernel: gank_conv2d_wgrad_slab_elems = gank_conv2d_wgrad_ws_elems, and the slab reduction that
+ *  gank_conv2d_wgrad launches itself becomes the job.)  The same for the ConvMeanPool filter gradient: the filter-row kernel's
+ *  slabs (ws16) are left for the caller's gank_sum_slabs (job->fold = 1); job->nslabs = 0 when the call did everything itself. */
+int gank_convpool3x3_wgrad_job(const void* x, const void* dy, float* dw, float* dbias, float* ws16, long ws_elems, int N, int Hp, int Wp,
+                               int Cin, int Cout, int flags, gank_slab_job* job, void* stream);
 long gank_conv2d_wgrad_batched_ws_elems(int count, int N, int H, int W, int Cin, int Cout, int ksize, int flags);
 int gank_conv2d_wgrad_batched_slabs(const gank_wgrad_item* items, int count, int N, int H, int W, int Cin, int Cout, int ksize,
                                     int flags, float scale, float* ws, long ws_elems, gank_slab_job* jobs, void* stream);

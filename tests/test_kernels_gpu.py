@@ -1801,7 +1801,7 @@ def test_conv_wgrad_split_slabs_instead_of_atomics(K, n, h, cin, cout, k, relu):
     """gank_conv2d_wgrad_slabs + gank_sum_slabs (round 5): the split-K kernels that add their partial tiles with fp32 atomics
     (1x1 shortcuts, the 256 -> 3 output layer's filter gradient, small per-tap layers) write per-split copies of the filter
     and ONE later launch sums them, scaled, into the non-zero target -- same result as the atomics form (oracle tolerance),
-    bit-identical from run to run; layers on kernels with their own slab reduction (last case: all-taps) report no job."""
+    bit-identical from run to run; a layer on the all-taps kernel (last case) leaves ITS slab reduction to the same launch."""
     rng = np.random.default_rng(n + h + cin + cout + k)
     x, xt = bf(rng.normal(size=(n, h, h, cin)))
     dy, dyt = bf(rng.normal(size=(n, h, h, cout)))
@@ -1829,3 +1829,27 @@ def test_conv_wgrad_split_slabs_instead_of_atomics(K, n, h, cin, cout, k, relu):
         outs.append((dw.clone(), expect_job))
     if (n, h, cin, cout, k) == (16, 32, 256, 3, 3):
         assert outs[0][1] and torch.equal(outs[0][0], outs[1][0])    # the output layer's geometry takes the slab form: deterministic
+
+
+@pytest.mark.parametrize("n,hp,cin,cout", [(128, 8, 256, 128), (16, 16, 128, 128), (3, 8, 64, 64)])
+def test_convpool_filter_gradient_fold_left_to_the_summing_launch(K, n, hp, cin, cout):
+    """gank_convpool3x3_wgrad_job + gank_sum_slabs(fold = 1): the ConvMeanPool filter gradient's sum-and-fold (16 taps of the
+    4x4 stride-2 form -> 9) as a job of the caller's ONE summing launch instead of a launch of its own: bit-identical to
+    gank_convpool3x3_wgrad (the same additions in the same order), together with a plain job in the same launch."""
+    rng = np.random.default_rng(n + hp + cin)
+    _, xt = bf(rng.normal(size=(n, 2 * hp, 2 * hp, cin)))
+    _, dyt = bf(rng.normal(size=(n, hp, hp, cout)))
+    w0 = torch.tensor(rng.normal(size=(3, 3, cin, cout)).astype(np.float32)).cuda()
+    a, da = w0.clone(), torch.zeros(cout, device="cuda")
+    K.convpool3x3_wgrad(xt, dyt, a, K.IN_RELU, dbias=da)
+    b, db = w0.clone(), torch.zeros(cout, device="cuda")
+    jobs = []
+    K.convpool3x3_wgrad(xt, dyt, b, K.IN_RELU, dbias=db, slab_jobs=jobs)
+    extra_slabs, extra_out = torch.randn(3, 1000, device="cuda"), torch.zeros(1000, device="cuda")
+    jobs.append(K.slab_job(extra_slabs, extra_out, 1000, 1000, 3, 2.0))
+    assert len(jobs) == 2 and torch.equal(b, w0)
+    K.sum_slabs(jobs)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert float((da - db).abs().max()) <= 1e-5 * float(da.abs().max())        # (the bias gradient is added with atomics in both forms: order noise)
+    assert float((extra_out - 2.0 * extra_slabs.sum(0)).abs().max()) < 1e-5
