@@ -406,7 +406,32 @@ __device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0
 
 __global__ void rng_advance_kernel(unsigned long long* state, unsigned long long inc) { state[1] += inc; }
 
-__global__ void rng_normal_kernel(bf16* __restrict__ y, long n, const unsigned long long* __restrict__ state) {
+// The generators advance the stream offset THEMSELVES: every workgroup has read {seed, offset} (their use feeds the address-free
+// arithmetic below, and the barrier in front of the ticket orders the loads) before it draws a ticket; the last one to arrive
+// rewrites the offset and resets the word -- no one-thread rng_advance launch behind every draw (3 per iteration).  The ticket words
+// rotate per host call, so draws in flight on different streams do not share one.
+__device__ unsigned rng_tickets[32];
+static std::atomic<unsigned> rng_ticket_next{0};
+static unsigned* rng_ticket_word() {
+  static std::atomic<unsigned*> base_of[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  unsigned* base = base_of[dev & 63].load(std::memory_order_relaxed);
+  if (!base) {
+    if (hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(rng_tickets)) != hipSuccess || !base) return nullptr;
+    base_of[dev & 63].store(base, std::memory_order_relaxed);
+  }
+  return base + (rng_ticket_next.fetch_add(1, std::memory_order_relaxed) & 31);
+}
+__device__ __forceinline__ void rng_finish(unsigned long long* state, unsigned long long off, unsigned* done) {
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(done, 1u) == gridDim.x - 1) {
+    *done = 0u;
+    state[1] = off + 1;
+  }
+}
+
+__global__ void rng_normal_kernel(bf16* __restrict__ y, long n, unsigned long long* __restrict__ state, unsigned* __restrict__ done) {
   const unsigned long long seed = state[0], off = state[1];
   const long n4 = (n + 3) >> 2;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -417,9 +442,10 @@ __global__ void rng_normal_kernel(bf16* __restrict__ y, long n, const unsigned l
     for (int e = 0; e < 4; e++)
       if (i * 4 + e < n) y[i * 4 + e] = f2bf(z[e]);
   }
+  rng_finish(state, off, done);
 }
 
-__global__ void rng_labels_kernel(int* __restrict__ y, long n, int n_labels, const unsigned long long* __restrict__ state) {
+__global__ void rng_labels_kernel(int* __restrict__ y, long n, int n_labels, unsigned long long* __restrict__ state, unsigned* __restrict__ done) {
   const unsigned long long seed = state[0], off = state[1];
   const long n4 = (n + 3) >> 2;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -431,6 +457,7 @@ __global__ void rng_labels_kernel(int* __restrict__ y, long n, int n_labels, con
         y[i * 4 + e] = lb >= n_labels ? n_labels - 1 : lb;
       }
   }
+  rng_finish(state, off, done);
 }
 
 // uint8 CHW-planar [B,3072] -> bf16 HWC [B,32,32,3]:  2*(x/256 - .5) + U[0,1/128)   (gan_cifar_resnet.py:334-337)
@@ -466,9 +493,11 @@ static inline dim3 rgrid(long n4) {
 extern "C" int gank_rng_normal_bf16(void* y, long n, uint64_t* rng_state, void* stream) {
   GANK_REQUIRE(y && rng_state && n > 0, "rng_normal: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(rng_normal_kernel, rgrid((n + 3) / 4), dim3(256), 0, s, (bf16*)y, n, (const unsigned long long*)rng_state);
+  unsigned* done = rng_ticket_word();
+  if (!done) return gank_set_error("rng_normal: ticket words not found");
+  hipLaunchKernelGGL(rng_normal_kernel, rgrid((n + 3) / 4), dim3(256), 0, s, (bf16*)y, n, (unsigned long long*)rng_state, done);
   GANK_LAUNCH_OK("rng_normal");
-  return rng_advance((unsigned long long*)rng_state, 1, s);
+  return 0;
 }
 __global__ void rng_uniform_kernel(float* __restrict__ y, long n, const unsigned long long* __restrict__ state) {
   const unsigned long long seed = state[0], off = state[1];
@@ -490,9 +519,11 @@ extern "C" int gank_rng_uniform_f32(float* y, long n, uint64_t* rng_state, void*
 extern "C" int gank_rng_labels(int32_t* y, long n, int n_labels, uint64_t* rng_state, void* stream) {
   GANK_REQUIRE(y && rng_state && n > 0 && n_labels > 0, "rng_labels: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(rng_labels_kernel, rgrid((n + 3) / 4), dim3(256), 0, s, y, n, n_labels, (const unsigned long long*)rng_state);
+  unsigned* done = rng_ticket_word();
+  if (!done) return gank_set_error("rng_labels: ticket words not found");
+  hipLaunchKernelGGL(rng_labels_kernel, rgrid((n + 3) / 4), dim3(256), 0, s, y, n, n_labels, (unsigned long long*)rng_state, done);
   GANK_LAUNCH_OK("rng_labels");
-  return rng_advance((unsigned long long*)rng_state, 1, s);
+  return 0;
 }
 extern "C" int gank_preprocess_real(const uint8_t* data, void* y, uint64_t* rng_state, int B, void* stream) {
   GANK_REQUIRE(data && y && rng_state && B > 0, "preprocess_real: bad arguments");

@@ -683,8 +683,9 @@ struct SnAdamArgs {
   float* g;               // flat gradient buffer [n] (the table's dW are views of it)
   float* u_next[SN_MAX];
   long gap_lo[SN_MAX + 1], gap_hi[SN_MAX + 1];     // [lo, hi) element ranges of the flat buffer outside every table entry
-  int gap_block[SN_MAX + 2];                       // first extra block of gap i (4096 elements per block)
+  int gap_block[SN_MAX + 2];                       // first extra block of gap i (1024 elements per block)
   int ngaps, sn_blocks;
+  int dbg;                // TUNING builds (GANK_SNTAIL_DBG): 1 = no finalize, 2 = return before the publication, 4 = no parameter / slot stores
   int dw_zero;            // every table entry's dW is known to be zero (nothing but this backward pass contributes): neither read nor cleared
 };
 
@@ -719,19 +720,30 @@ __global__ __launch_bounds__(256) void sn_adam_fwd_a_kernel(SnTable t, SnAdamArg
 
   if ((int)blockIdx.x >= ad.sn_blocks) {
     // ---- plain TF-Adam on a 4096-element piece of a range outside the spectrally normalised weights
-    if (tid == 0) s_lr = adam_lr_t(ad.hp, ad.t_state, ad.iteration);
-    __syncthreads();
-    const float lr_t = s_lr;
     const int eb = blockIdx.x - ad.sn_blocks;
     int gi = 0;
 #pragma unroll
     for (int i = 1; i <= SN_MAX; i++) gi += (i < ad.ngaps && eb >= ad.gap_block[i]) ? 1 : 0;
-    const long lo = ad.gap_lo[gi] + (long)(eb - ad.gap_block[gi]) * 4096, hi = min(ad.gap_hi[gi], lo + 4096);
-    for (long i = lo + tid; i < hi; i += 256) {
-      float pp = ad.p[i], mm = ad.m[i], vv = ad.v[i];
-      const float gg = ad.g[i];
-      ad.g[i] = 0.f;
-      if (sn_adam_elem(gg, gs, b1, b2, eps, lr_t, health, pp, mm, vv, bad, zero)) { ad.p[i] = pp; ad.m[i] = mm; ad.v[i] = vv; }
+    // (1024 elements per block, every load of a thread requested before the first is used: a 16-iteration load -> store loop was
+    //  the launch's longest latency chain)
+    const long lo = ad.gap_lo[gi] + (long)(eb - ad.gap_block[gi]) * 1024, hi = min(ad.gap_hi[gi], lo + 1024);
+    float pp[4], mm[4], vv[4], gg[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const long i = lo + tid + 256 * u;
+      const bool ok = i < hi;
+      pp[u] = ok ? ad.p[i] : 0.f; mm[u] = ok ? ad.m[i] : 0.f; vv[u] = ok ? ad.v[i] : 0.f; gg[u] = ok ? ad.g[i] : 0.f;
+    }
+    if (tid == 0) s_lr = adam_lr_t(ad.hp, ad.t_state, ad.iteration);
+    __syncthreads();
+    const float lr_t = s_lr;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const long i = lo + tid + 256 * u;
+      if (i < hi) {
+        ad.g[i] = 0.f;
+        if (sn_adam_elem(gg[u], gs, b1, b2, eps, lr_t, health, pp[u], mm[u], vv[u], bad, zero)) { ad.p[i] = pp[u]; ad.m[i] = mm[u]; ad.v[i] = vv[u]; }
+      }
     }
   } else {
     int ch;
@@ -802,6 +814,9 @@ __global__ __launch_bounds__(256) void sn_adam_fwd_a_kernel(SnTable t, SnAdamArg
           }
         }
       }
+#ifdef GANK_TUNING
+      if (ad.dbg & 2) { if (w[0][0] == 123.456f) W[0] = 1.f; return; }
+#endif
       // (the updated chunk stays in registers: its stores are issued BEHIND the ticket below, so that the publication of the
       //  partial sums does not wait for 80 KB of parameter / slot / cleared-gradient stores to drain)
       // ---- forward A of the next pass on the updated rows (sn_fwd_a_kernel's register-tile body)
@@ -884,6 +899,9 @@ __global__ __launch_bounds__(256) void sn_adam_fwd_a_kernel(SnTable t, SnAdamArg
       }
       *flag = last;
     }
+#ifdef GANK_TUNING
+    if (!(ad.dbg & 4))
+#endif
     if (fast) {          // the updated chunk, its slots, the cleared gradient slices: beside the ticket's round trip
       const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -901,6 +919,9 @@ __global__ __launch_bounds__(256) void sn_adam_fwd_a_kernel(SnTable t, SnAdamArg
       }
     }
     __syncthreads();
+#ifdef GANK_TUNING
+    if (!(ad.dbg & 1))
+#endif
     if (*flag) sn_fwd_a_finish(d, u_next, nch, part, red, tid);
   }
   if (health) {           // one pair of atomics per wave that saw anything (adam_tf_kernel)
@@ -969,6 +990,7 @@ extern "C" int gank_sn_adam_fwd_a(const gank_sn_desc* table, int count, float* c
   ad.health = (unsigned long long*)health;
   ad.sn_blocks = chunks;
   ad.dw_zero = (flags & 1) ? 1 : 0;
+  { static const int dbg_ = gank_tune("GANK_SNTAIL_DBG", 0); ad.dbg = dbg_; }
   // the table's weights, in buffer order, must be disjoint views of [p, p + n) whose gradient views sit at the same offsets of g
   int order[SN_MAX];
   for (int i = 0; i < count; i++) order[i] = i;
@@ -988,7 +1010,7 @@ extern "C" int gank_sn_adam_fwd_a(const gank_sn_desc* table, int count, float* c
     }
     if (lo > pos) {
       ad.gap_lo[ad.ngaps] = pos; ad.gap_hi[ad.ngaps] = lo; ad.gap_block[ad.ngaps] = blocks;
-      blocks += (int)((lo - pos + 4095) / 4096);
+      blocks += (int)((lo - pos + 1023) / 1024);
       ad.ngaps++;
     }
     pos = lo + len;
