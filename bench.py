@@ -124,6 +124,88 @@ def cpu_baseline(budget_s=40.0):
                       f"{t_iter:.2f}s (D {sum(tds) / 5:.2f}s each, G {tg:.2f}s)"}
 
 
+def other_configs(steps=5):
+    """BASELINE.json configs 3-5 at their per-GPU sizes, in this process AFTER the headline measurement (outside its timed region):
+    a few captured steps each -> {ms_per_step, gflop_as_run, mfma_frac}.  ACGAN at 32 samples (config 3's share of 256 over 8
+    GPUs; ACGAN/train.py:89-121), PGGAN model_nvidia at 64x64 while the block fades in (PGGAN/train.py:83-136), Pix2Pix U-Net at
+    512x512, batch 16 (Pix2Pix/train.py:704-729; the reference graph does not run at 256x256).  The conv
+    FLOPs are the ones the kernels executed (counted by the launchers over one eager step of the same configuration)."""
+    from gan_lib_tensorflow_amd import kernels as K
+    from gan_lib_tensorflow_amd.SNGAN.gan_cifar_resnet import synthetic_batches
+    out = {}
+
+    def measure(name, make, step, workload):
+        try:
+            tr = make(False)                      # eager: FLOPs as run
+            step(tr)
+            torch.cuda.synchronize()
+            K.prof_reset()
+            K.prof_enable(True)
+            step(tr)
+            torch.cuda.synchronize()
+            K.prof_enable(False)
+            fl = sum(K.prof_collect(f)[2] for f in (0, 1))
+            K.prof_reset()
+            del tr
+            tr = make(True)                       # captured
+            for _ in range(3):                    # eager first execution, capture, one replay
+                step(tr)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step(tr)
+            torch.cuda.synchronize()
+            t = (time.perf_counter() - t0) / steps
+            out[name] = {"workload": workload, "ms_per_step": round(1e3 * t, 3), "steps": steps, "gflop_as_run": round(fl / 1e9, 1),
+                         "mfma_frac": round(fl / t / (PEAK_BF16_TFLOPS * 1e12), 4)}
+            del tr
+        except Exception as e:  # noqa: BLE001 -- the headline line must not depend on the other configurations
+            out[name] = {"workload": workload, "error": f"{type(e).__name__}: {e}"[:300]}
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+
+    from gan_lib_tensorflow_amd.ACGAN.train import ACGANTrainer
+    feed = synthetic_batches(32, "cuda", seed=2)
+    it = [0]
+
+    def acgan_step(trn):
+        it[0] += 1
+        trn.train_iteration(feed, it[0])
+    measure("acgan_bs32", lambda g: ACGANTrainer(batch_size=32, seed=1, use_graphs=g), acgan_step,
+            "ACGAN ResNet CIFAR-10, 32 samples per GPU (bs=256 over 8 GPUs): 1 G + 5 D updates, WGAN-GP double backward")
+    from gan_lib_tensorflow_amd.PGGAN.train import PGGANTrainer, default_args as pg_args
+    feed16 = synthetic_batches(16, "cuda", seed=2)
+    measure("pggan_64_fading", lambda g: PGGANTrainer(pg_args(batch_size=16, block_count=4, image_size=64, trans=True), seed=1, use_graphs=g),
+            lambda trn: trn.train_iteration(feed16), "PGGAN model_nvidia 64x64, block fading in, batch 16: 1 G + 5 D updates")
+    from gan_lib_tensorflow_amd.Pix2Pix.train import Pix2PixTrainer, default_args as px_args
+    g = torch.Generator().manual_seed(3)
+    a = (torch.rand(16, 512, 512, 3, generator=g) * 2 - 1).to(K.BF16).cuda()
+    b = (torch.rand(16, 512, 512, 3, generator=g) * 2 - 1).to(K.BF16).cuda()
+    measure("pix2pix_512_bs16", lambda gr: Pix2PixTrainer(px_args(batch_size=16, crop_size=512), seed=1, use_graphs=gr),
+            lambda trn: trn.train_step(a, b), "Pix2Pix U-Net + PatchGAN 512x512, batch 16: 5 D + 1 G updates")
+    return out
+
+
+def fp16_child(steps, warmup):
+    """The same headline measurement with IEEE-half activations (libgank_f16.so, static loss scale 1024), in a process of its own --
+    the element type is a per-process choice -- started BEFORE this process touches the GPU and finished before it does."""
+    import subprocess
+    env = dict(os.environ, GANK_DTYPE="fp16", GANK_BENCH_CHILD="1")
+    env.pop("GANK_LIB_NAME", None)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup),
+                            "--no-cpu-baseline", "--no-other-configs", "--no-fp16"], env=env, capture_output=True, text=True, timeout=300)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": f"exit {r.returncode}: {r.stderr[-300:]}"}
+        d = json.loads(line[-1])
+        return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "median_ms_per_step_hip_events": d["median_ms_per_step_hip_events"],
+                "steps": d["steps"], "dtype": d["dtype"], "loss_scale": 1024, "finite": d["config"]["finite"]}
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,6 +224,8 @@ def main():
     ap.add_argument("--capture-collectives", action="store_true",
                     help="data parallel, world > 1: RCCL all-reduces INSIDE the update graphs (default there: between graphs, until a "
                          "multi-GPU run has verified replayed collectives; a world-size-1 group captures by default)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the ACGAN / PGGAN / Pix2Pix step times behind the headline line (key other_configs)")
+    ap.add_argument("--no-fp16", action="store_true", help="skip the fp16 child process (key fp16)")
     ap.add_argument("--set", action="append", default=[], metavar="module.NAME=value",
                     help="A/B runs: set a module constant of the package before the trainer is built, e.g. functional.RES8_CONV=False")
     args = ap.parse_args()
@@ -158,6 +242,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    extras = world == 1 and not args.set and not args.no_graphs and not args.force_dp and os.environ.get("GANK_DTYPE", "bf16").lower() == "bf16" \
+        and "GANK_LIB_NAME" not in os.environ and os.environ.get("GANK_BENCH_EXTRAS", "1") != "0"      # (measurement scripts: headline only)
+    fp16 = None
+    if extras and not args.no_fp16:
+        fp16 = fp16_child(min(args.steps, 100), min(max(args.warmup, 2), 10))       # before this process touches the GPU
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
                          " (one rank per GPU)")
@@ -336,6 +425,15 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         else:
             out["cpu_baseline"] = None
+        if fp16 is not None:
+            out["fp16"] = fp16
+        if extras and not args.no_other_configs:
+            del tr, feed
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
+            out["other_configs"] = other_configs()
+            tr = feed = None
         print(json.dumps(out), flush=True)
     if pg is not None:
         # ordered teardown: the captured graphs (they may hold collective nodes) and the bucket views go before the communicator,

@@ -91,6 +91,7 @@ PROTOTYPES = {
     "gank_fewout_pack": [P, P, I, I, I, I, I, P],
     "gank_zero_f32": [P, C.c_long, P],
     "gank_img16_conv3x3": [P, P, P, P, P, P, I, I, I, I, P],
+    "gank_cbn_relu_img16_conv3x3": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P, I, P],
     "gank_img16_conv3x3_stats": [P, P, P, P, P, P, I, I, I, I, P, I, P],
     "gank_res8_chain_fwd_head": [P, P, P, P, P, P, P, P, P, I, I, I, P],
     "gank_res8_chain_bwd_head": [C.POINTER(Res8Head), P, P, P, P, P, P, P, I, I, I, P],

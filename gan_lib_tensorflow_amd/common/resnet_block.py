@@ -12,7 +12,10 @@ epilogue instead of being a TensorFlow op that materialises a tensor:
 """
 import functools
 
+import torch
+
 from .. import functional as Fn
+from .. import kernels as K
 from ..store import get_default_store
 from .ops import conv2d as _conv2d
 from .ops import normalization as _normalization
@@ -166,11 +169,50 @@ def ResidualBlock(inputs, input_dim, output_dim, filter_size, name,
                     spectral_normed=spectral_normed, update_collection=update_collection,
                     he_init=True, biases=biases, in_relu=not norm1, stats_groups=groups if norm2 else 0)
 
+    fused = _norm2_inside_conv2(name, output, labels, groups, output_dim, resample, shortcut, biases, spectral_normed, out_stats) \
+        if norm2 else None
+    if fused is not None:
+        return fused
     output = Normalize(name + '.N2', output, labels=labels, groups=groups, relu=True)
     # shortcut + output (:209) rides on conv_2's epilogue
     return conv_2(inputs=output, filter_size=filter_size, name=name + '.Conv2',
                   spectral_normed=spectral_normed, update_collection=update_collection,
                   he_init=True, biases=biases, in_relu=not norm2, residual=shortcut, stats_groups=out_stats)
+
+
+FUSE_NORM_INTO_CONV2 = True   # no-grad passes: N2 + relu of an 'up' block applied while conv_2's image-resident kernel stages its operand
+
+
+def _norm2_inside_conv2(name, x, labels, groups, output_dim, resample, shortcut, biases, spectral_normed, out_stats):
+    """`Normalize(N2) -> nonlinearity -> conv_2 (+ shortcut)` of an 'up' block (gan_cifar_resnet.py:197-209) as ONE launch where
+    nothing is kept for a backward pass and conv_2 runs on the image-resident 16x16 kernel: the 320-sample generator pass behind
+    the critic updates and the sampling path (G.Block.2).  The normalised tensor (42 MB at 320 samples) is never written or read;
+    same variables, same creation order (N2's tables, then Conv2's filter) as the unfused graph; bit-identical to it.  None = not
+    applicable (the caller runs the unfused ops)."""
+    if not (FUSE_NORM_INTO_CONV2 and resample == 'up' and not torch.is_grad_enabled() and not spectral_normed and x.is_cuda
+            and _normalize_kind(name + '.N2', labels) == 'cbn' and x.dim() == 4 and tuple(x.shape[1:3]) == (16, 16)):
+        return None
+    n, c = x.shape[0], x.shape[3]
+    if not (Fn.IMG16_CONV and K.img16_conv3x3_ok(n, (16, 16), c, output_dim) and n * (output_dim // 128) >= 256 and c == output_dim):
+        return None
+    store = get_default_store()
+    with store.variable_scope(name + '.N2'):
+        gamma, beta = _normalization.cond_batchnorm_variables(c, 10)
+    filters, b = _conv2d.conv2d_variables(output_dim, output_dim, 3, 1, name + '.Conv2', he_init=True, biases=biases)
+    prep = getattr(filters, '_prep_res', None)
+    if prep is None or prep[0] is None:
+        return None
+    stats = K.cbn_stats(x, groups, getattr(x, '_cbn_stats', None))
+    res_up = shortcut is not None and getattr(shortcut, '_up2x', False)
+    flags = K.RES_UPSAMPLE2X if res_up else 0
+    bias = b.detach() if b is not None else None
+    want = out_stats if Fn.CONV_EPILOGUE_STATS else 0
+    out = K.cbn_relu_img16_conv3x3(x, labels, gamma.detach(), beta.detach(), stats, prep[0], bias, output_dim, flags, shortcut, stats_groups=want)
+    if want:
+        y, cs = out
+        y._cbn_stats = cs
+        return y
+    return out
 
 
 FUSE_RES8 = True     # consecutive identity-shortcut 8x8x128 blocks without normalisation: one fused launch each way

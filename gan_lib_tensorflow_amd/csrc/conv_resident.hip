@@ -1618,6 +1618,12 @@ struct I16Args {
   int N, Cin, Cout, relu; // relu: on the input operand while it is staged
   int res_up, stat_n_per_group;      // res_up: res is [N,8,8,Cout], added nearest-neighbour upsampled
   int xcd;                // XCD-aware block order: the Cout/128 workgroups of an image share an L2
+  // NORM: relu(cond_batchnorm(x)) applied while a chunk is staged (the workgroup owns ONE sample: one (scale, shift) row pair)
+  const float* cbn_stats; // [groups][2][Cin] (mean, invstd)
+  const float* cbn_gamma; // [n_labels][Cin]
+  const float* cbn_beta;
+  const int* cbn_labels;  // [N]
+  int cbn_n_per_group, cbn_n_labels;
 };
 }  // namespace
 
@@ -1628,7 +1634,7 @@ struct I16Args {
 // the reduction: K-steps 0,1 / 2,3 of every tap), 4 pixel tiles each, so every weight fragment is still requested once per
 // workgroup and feeds 4 MFMAs; the two partial sums of a tile meet through LDS after the last chunk and each wave of a pair
 // finishes two of the four tiles.
-template <int PF, int TW, bool HALF = false>
+template <int PF, int TW, bool HALF = false, bool NORM = false>
 __global__ __launch_bounds__(HALF ? 512 : 2048 / TW) void img16_conv3x3_kernel(I16Args a) {
   static_assert(!HALF || TW == 4, "half-image form: 4 pixel tiles per wave");
   constexpr int NT = HALF ? 512 : 2048 / TW;
@@ -1683,16 +1689,53 @@ __global__ __launch_bounds__(HALF ? 512 : 2048 / TW) void img16_conv3x3_kernel(I
     p_lds[j] = on ? hr * I16_RP + hc * I16_PP + c16 * 16 : -1;
   }
   u32x4 rP[NLD];
+  // NORM: this thread's pieces are channels 8 (tid & 7) .. + 7 of every chunk (NT is a multiple of 8): the sample's mean / invstd /
+  // gamma / beta for them ride along with the chunk's loads; the arithmetic and its order are the forward CBN kernel's
+  // ((x - mean) * invstd * gamma + beta, relu, ONE rounding -- gank_cbn_relu_conv3x3_fprop's staging, expression for expression),
+  // so the result equals cbn_apply + this conv bit for bit and the normalised tensor is never stored.  Padding stays zero.
+  static_assert(!NORM || NT % 8 == 0, "a thread's pieces must share their channel group");
+  f32x4 nm[NORM ? 8 : 1];
+  const float* np_mu = nullptr;
+  const float* np_ga = nullptr;
+  const float* np_be = nullptr;
+  if constexpr (NORM) {
+    int lb = a.cbn_labels[n];
+    lb = lb < 0 ? 0 : (lb >= a.cbn_n_labels ? a.cbn_n_labels - 1 : lb);
+    np_mu = a.cbn_stats + (long)(n / a.cbn_n_per_group) * 2 * a.Cin + (tid & 7) * 8;
+    np_ga = a.cbn_gamma + (long)lb * a.Cin + (tid & 7) * 8;
+    np_be = a.cbn_beta + (long)lb * a.Cin + (tid & 7) * 8;
+  }
   auto load_chunk = [&](int c) {
 #pragma unroll
     for (int j = 0; j < NLD; j++) rP[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, p_off[j] == OOB ? OOB : p_off[j] + c * 128, 0, 0);
+    if constexpr (NORM) {
+      nm[0] = *reinterpret_cast<const f32x4*>(np_mu + c * 64); nm[1] = *reinterpret_cast<const f32x4*>(np_mu + c * 64 + 4);
+      nm[2] = *reinterpret_cast<const f32x4*>(np_mu + a.Cin + c * 64); nm[3] = *reinterpret_cast<const f32x4*>(np_mu + a.Cin + c * 64 + 4);
+      nm[4] = *reinterpret_cast<const f32x4*>(np_ga + c * 64); nm[5] = *reinterpret_cast<const f32x4*>(np_ga + c * 64 + 4);
+      nm[6] = *reinterpret_cast<const f32x4*>(np_be + c * 64); nm[7] = *reinterpret_cast<const f32x4*>(np_be + c * 64 + 4);
+    }
   };
   auto store_chunk = [&](int buf) {
 #pragma unroll
     for (int j = 0; j < NLD; j++)
       if (p_lds[j] >= 0) {
         u32x4 v = rP[j];
-        if (a.relu) v = relu_bf16x8(v);
+        if constexpr (NORM) {
+          if (p_off[j] != OOB) {
+            const bf16x8 xv = __builtin_bit_cast(bf16x8, v);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+              const float mu = e < 4 ? nm[0][e] : nm[1][e - 4], iv = e < 4 ? nm[2][e] : nm[3][e - 4];
+              const float ga = e < 4 ? nm[4][e] : nm[5][e - 4], be = e < 4 ? nm[6][e] : nm[7][e - 4];
+              const float t = (bf2f(xv[e]) - mu) * iv * ga + be;
+              o[e] = f2bf(fmaxf(t, 0.f));
+            }
+            v = __builtin_bit_cast(u32x4, o);
+          }
+        } else {
+          if (a.relu) v = relu_bf16x8(v);
+        }
         *reinterpret_cast<u32x4*>(smem + buf * IMG + p_lds[j]) = v;
       }
   };
@@ -1841,8 +1884,31 @@ __global__ void i16_zero_kernel(float* __restrict__ p, int n) {
   if (i < n) p[i] = 0.f;
 }
 
+namespace {
+struct I16Cbn { const int* labels; const float* gamma; const float* beta; const float* stats; int groups, n_labels; };
+}
+static int img16_conv3x3_impl(const void* x, const void* w_rfrag, const float* bias, const void* relu_ref, const void* residual, void* y,
+                              int N, int Cin, int Cout, int flags, float* stat_sums, int stat_groups, const I16Cbn* cbn, void* stream);
 extern "C" int gank_img16_conv3x3_stats(const void* x, const void* w_rfrag, const float* bias, const void* relu_ref, const void* residual, void* y,
                                         int N, int Cin, int Cout, int flags, float* stat_sums, int stat_groups, void* stream) {
+  return img16_conv3x3_impl(x, w_rfrag, bias, relu_ref, residual, y, N, Cin, Cout, flags, stat_sums, stat_groups, nullptr, stream);
+}
+// conv3x3_SAME(relu(cond_batchnorm(x))) + bias (+ residual) on 16x16 images: the normalisation of common/ops/normalization.py:47-57 and
+// the nonlinearity (gan_cifar_resnet.py:186) applied while the image-resident kernel stages its operand -- for passes that keep
+// nothing for a backward pass (the 320-sample generator pass for the critic's fakes, sampling): the normalised tensor is never
+// stored.  stats [groups][2][Cin] = (mean, invstd) per tower (gank_cbn_stats / _from_sums); bit-identical to gank_cbn_fwd* +
+// gank_img16_conv3x3_stats.
+extern "C" int gank_cbn_relu_img16_conv3x3(const void* x, const int32_t* labels, const float* gamma, const float* beta, const float* stats,
+                                           const void* w_rfrag, const float* bias, const void* residual, void* y, int N, int Cin, int Cout,
+                                           int groups, int n_labels, int flags, float* stat_sums, int stat_groups, void* stream) {
+  GANK_REQUIRE(labels && gamma && beta && stats, "cbn_relu_img16_conv3x3: null normalisation pointers");
+  GANK_REQUIRE(groups > 0 && N % groups == 0 && n_labels > 0, "cbn_relu_img16_conv3x3: batch %d / %d towers", N, groups);
+  GANK_REQUIRE(!(flags & GANK_IN_RELU), "cbn_relu_img16_conv3x3: the relu is part of the fused normalisation");
+  const I16Cbn cbn{labels, gamma, beta, stats, groups, n_labels};
+  return img16_conv3x3_impl(x, w_rfrag, bias, nullptr, residual, y, N, Cin, Cout, flags, stat_sums, stat_groups, &cbn, stream);
+}
+static int img16_conv3x3_impl(const void* x, const void* w_rfrag, const float* bias, const void* relu_ref, const void* residual, void* y,
+                              int N, int Cin, int Cout, int flags, float* stat_sums, int stat_groups, const I16Cbn* cbn, void* stream) {
   GANK_REQUIRE(x && w_rfrag && y && N > 0, "img16_conv3x3: null pointer");
   GANK_REQUIRE(Cin % 64 == 0 && Cout % 128 == 0, "img16_conv3x3: needs Cin %% 64 == 0 and Cout %% 128 == 0 (got %d, %d)", Cin, Cout);
   GANK_REQUIRE((flags & ~(GANK_IN_RELU | GANK_RES_UPSAMPLE2X | GANK_STATS_PREZEROED)) == 0, "img16_conv3x3: flags: GANK_IN_RELU, GANK_RES_UPSAMPLE2X, GANK_STATS_PREZEROED");
@@ -1855,6 +1921,10 @@ extern "C" int gank_img16_conv3x3_stats(const void* x, const void* w_rfrag, cons
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.relu = (flags & GANK_IN_RELU) ? 1 : 0;
   a.res_up = (flags & GANK_RES_UPSAMPLE2X) ? 1 : 0; a.stat_sums = stat_sums; a.stat_n_per_group = stat_sums ? N / stat_groups : 1;
   a.xcd = resident_xcd_env();
+  if (cbn) {
+    a.cbn_labels = cbn->labels; a.cbn_gamma = cbn->gamma; a.cbn_beta = cbn->beta; a.cbn_stats = cbn->stats;
+    a.cbn_n_per_group = N / cbn->groups; a.cbn_n_labels = cbn->n_labels;
+  }
   hipStream_t s = (hipStream_t)stream;
   if (stat_sums) gank_stats_dbg_init();
   if (stat_sums && !(flags & GANK_STATS_PREZEROED)) {
@@ -1865,6 +1935,14 @@ extern "C" int gank_img16_conv3x3_stats(const void* x, const void* w_rfrag, cons
   gank_prof_begin(0, 2.0 * M * Cout * 9.0 * Cin, s, 2.0 * (M * Cin + 9.0 * Cin * Cout + M * Cout * (1 + (relu_ref ? 1 : 0) + (residual ? 1 : 0))));
   static const int cfg_env = gank_tune("GANK_IMG16_CFG", 412);   // experiment knob: 100 * (pixel tiles per wave) + weight fragments in flight
   static const int half_env = gank_tune("GANK_IMG16_HALF", 1);   // experiment knob: 0 = whole images only, 1 = half images when the whole-image grid leaves CUs idle, 2 = always
+  if (cbn) {          // whole-image form only (the passes this serves have N * Cout / 128 >= 256 workgroups)
+    gank_prof_tag(0, "img16_conv3x3_kernel<12, 4, false, norm>");
+    GANK_MAX_DYNAMIC_LDS((img16_conv3x3_kernel<12, 4, false, true>), 2 * I16_IMG, "cbn_relu_img16_conv3x3");
+    hipLaunchKernelGGL((img16_conv3x3_kernel<12, 4, false, true>), dim3(N * (Cout / 128)), dim3(512), 2 * I16_IMG, s, a);
+    gank_prof_end(0, s);
+    GANK_LAUNCH_OK("cbn_relu_img16_conv3x3");
+    return 0;
+  }
   if (half_env == 2 || (half_env == 1 && N * (Cout / 128) < 256)) {
     constexpr int HALF_LDS = 2 * 10 * I16_RP > 65536 ? 2 * 10 * I16_RP : 65536;
     static const int hpf_env = gank_tune("GANK_IMG16_HALF_PF", 9);

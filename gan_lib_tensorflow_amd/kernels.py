@@ -531,6 +531,23 @@ def img16_conv3x3(x, rf, bias, cout, flags=0, relu_ref=None, residual=None, stat
     return y
 
 
+def cbn_relu_img16_conv3x3(x, labels, gamma, beta, stats, rf, bias, cout, flags=0, residual=None, stats_groups=0):
+    """conv3x3_SAME(relu(cond_batchnorm(x))) + bias (+ residual) on 16x16 images, the normalisation inside the image-resident
+    kernel's operand staging (no grad; stats [groups,2,Cin] from cbn_stats).  flags: RES_UPSAMPLE2X.  stats_groups > 0 -> (y, ConvStats)"""
+    n, cin = x.shape[0], x.shape[3]
+    assert tuple(x.shape[1:3]) == (16, 16), x.shape
+    groups = stats.shape[0]
+    y = torch.empty((n, 16, 16, cout), dtype=BF16, device=x.device)
+    sums, pre = (stats_arena.take((stats_groups, _lib.STAT_SLOTS, 2, cout), x.device) if stats_groups else (None, False))
+    _lib.check(lib().gank_cbn_relu_img16_conv3x3(_p(x, BF16, "x"), _p(labels, I32, "labels"), _p(gamma, F32, "gamma"), _p(beta, F32, "beta"),
+                                                 _p(stats, F32, "stats"), _p(rf, BF16, "rf"), _p(bias, F32, "bias"), _p(residual, BF16, "residual"),
+                                                 _p(y), n, cin, cout, groups, gamma.shape[0], int(flags) | (STATS_PREZEROED if pre else 0),
+                                                 _p(sums), stats_groups, _stream()), "cbn_relu_img16_conv3x3")
+    if stats_groups:
+        return y, ConvStats(sums, bias, stats_groups)
+    return y
+
+
 def res8_conv3x3(x, rf, bias, cout, flags=0, residual=None, stats_groups=0):
     """3x3 SAME conv on LDS-resident 8x8 images (rf: prep kind 4 operand, rows = output channels).  flags: IN_UPSAMPLE2X
     (x is [N,4,4,Cin]), RES_UPSAMPLE2X (residual is [N,4,4,Cout]), OUT_POOLSUM2X (result as 2x2 sums [N,4,4,Cout]).

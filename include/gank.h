@@ -215,6 +215,14 @@ int gank_res8_chain_bwd_head(const gank_res8_head* head, const void* ylast, void
  * flags: GANK_IN_RELU.  Cin % 64 == 0, Cout % 128 == 0. */
 int gank_img16_conv3x3(const void* x, const void* w_rfrag, const float* bias, const void* relu_ref, const void* residual, void* y,
                        int N, int Cin, int Cout, int flags, void* stream);
+/* conv3x3_SAME(relu(cond_batchnorm(x))) + bias (+ residual) on 16x16 images with the normalisation (common/ops/normalization.py:47-57)
+ * and the nonlinearity (SNGAN/gan_cifar_resnet.py:186) applied while the image-resident kernel stages its operand: for passes
+ * that keep nothing for a backward pass (the 320-sample generator pass behind the critic updates, :326-332; sampling, :530-555) the
+ * normalised tensor is never written or read.  stats [groups][2][Cin] = (mean, invstd) per tower; flags: GANK_RES_UPSAMPLE2X,
+ * GANK_STATS_PREZEROED; stat_sums as gank_img16_conv3x3_stats.  Bit-identical to gank_cbn_fwd* followed by gank_img16_conv3x3_stats. */
+int gank_cbn_relu_img16_conv3x3(const void* x, const int32_t* labels, const float* gamma, const float* beta, const float* stats,
+                                const void* w_rfrag, const float* bias, const void* residual, void* y, int N, int Cin, int Cout,
+                                int groups, int n_labels, int flags, float* stat_sums, int stat_groups, void* stream);
 /* the same with the conditional-batch-norm statistics of y accumulated by the epilogue (stat_sums as gank_conv2d_fprop_stats: the
  * generator's G.Block.2.Conv2, whose output feeds G.Block.3's first normalisation, gan_cifar_resnet.py:176-209) and, with
  * GANK_RES_UPSAMPLE2X, a half-resolution residual [N,8,8,Cout] added nearest-neighbour upsampled (the 'up' block's shortcut, :179-182).

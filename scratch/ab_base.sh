@@ -2,6 +2,7 @@
 # usage: scratch/ab_base.sh [reps] [steps] ["ENV=.. ENV=.." ...]   -- the round-4 tree (_baseline_r04, a git worktree of 282d0e9 with its own
 # libgank.so, not tracked) against the current tree, bench.py interleaved on ONE box; extra arguments: environment settings of further
 # arms of the current tree
+export GANK_BENCH_EXTRAS=0     # bench.py: the headline measurement only (no fp16 child, no other configurations)
 reps=${1:-2}; steps=${2:-100}; shift 2 2>/dev/null
 root=$(pwd)
 one() {   # dir, label, env...

@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage: bash scratch/ab_env.sh reps steps "ENV=.. ENV=.." "ENV=.." ...   -- bench.py on the TUNING library (libgank_tune.so), one arm per
 # environment setting ("X=1" = defaults), interleaved on ONE box
+export GANK_BENCH_EXTRAS=0     # bench.py: the headline measurement only (no fp16 child, no other configurations)
 reps=${1:-2}; steps=${2:-100}; shift 2
 export GANK_LIB_NAME=libgank_tune.so
 for rep in $(seq $reps); do

@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage: bash scratch/ab_set.sh reps steps "args of arm 1" "args of arm 2" ...   -- bench.py arms interleaved on ONE box
 # (an arm = extra bench.py arguments, e.g. "--set functional.RES8_CONV=False"; "" = defaults)
+export GANK_BENCH_EXTRAS=0     # bench.py: the headline measurement only (no fp16 child, no other configurations)
 reps=${1:-2}; steps=${2:-100}; shift 2
 for rep in $(seq $reps); do
   for arm in "$@"; do

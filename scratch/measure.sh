@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage: scratch/measure.sh <tag>   -- bench under rocprofv3 kernel trace, category summary per iteration, kernel sequence of one iteration
+export GANK_BENCH_EXTRAS=0     # bench.py: the headline measurement only (no fp16 child, no other configurations)
 tag=${1:-m}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/prof_$tag

@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage: r5_knob.sh "pat1|pat2" "ENV=.." ...  -- in-step kernel durations per setting of the TUNING library (regex on kernel names)
+export GANK_BENCH_EXTRAS=0     # bench.py: the headline measurement only (no fp16 child, no other configurations)
 pat=$1; shift
 cd /tmp && export TMPDIR=/tmp
 export GANK_LIB_NAME=libgank_tune.so

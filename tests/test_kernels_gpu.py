@@ -1853,3 +1853,45 @@ def test_convpool_filter_gradient_fold_left_to_the_summing_launch(K, n, hp, cin,
     assert torch.equal(a, b)
     assert float((da - db).abs().max()) <= 1e-5 * float(da.abs().max())        # (the bias gradient is added with atomics in both forms: order noise)
     assert float((extra_out - 2.0 * extra_slabs.sum(0)).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("n,groups,res,stat_groups", [(6, 3, "half", 3), (4, 2, None, 0), (320, 10, "half", 10)])
+def test_cbn_relu_fused_into_the_image_resident_16x16_conv(K, n, groups, res, stat_groups):
+    """gank_cbn_relu_img16_conv3x3 (round 5): G.Block.2's  N2 -> relu -> Conv2 (+ half-resolution shortcut, + the statistics of the
+    NEXT batch norm in the epilogue) as one launch for passes that keep nothing for a backward pass (gan_cifar_resnet.py:197-209;
+    the 320-sample pass behind the critic updates) == cond-batch-norm launch + image-resident conv launch, BIT FOR BIT (the staged
+    value is the forward CBN kernel's expression, rounded once), and against the float64 oracle."""
+    rng = np.random.default_rng(n + groups)
+    c = 256
+    x, xt = bf(rng.normal(size=(n, 16, 16, c)) * 1.3 - 0.2)
+    labels = torch.tensor(rng.integers(0, 10, n), dtype=torch.int32).cuda()
+    gamma = torch.tensor(rng.normal(size=(10, c)) * 0.2 + 1, dtype=torch.float32).cuda()
+    beta = torch.tensor(rng.normal(size=(10, c)) * 0.2, dtype=torch.float32).cuda()
+    w, _ = bf(rng.normal(size=(3, 3, c, c)) / np.sqrt(9 * c))
+    b, bt = f32(rng.normal(size=c))
+    wt = torch.tensor(w, dtype=torch.float32).cuda()
+    (rf, _), = K.prep_weights_batched([wt], want_d=True, kinds=[4])
+    r8, r8t = bf(rng.normal(size=(n, 8, 8, c))) if res else (None, None)
+    flags = K.RES_UPSAMPLE2X if res else 0
+    yn, _ = K.cbn_fwd(xt, labels, gamma, beta, groups, True)
+    stats = K.cbn_stats(xt, groups)
+    if stat_groups:
+        ref, cs_ref = K.img16_conv3x3(yn, rf, bt, c, flags, None, r8t, stat_groups)
+        y, cs = K.cbn_relu_img16_conv3x3(xt, labels, gamma, beta, stats, rf, bt, c, flags, r8t, stat_groups)
+    else:
+        ref = K.img16_conv3x3(yn, rf, bt, c, flags, None, r8t)
+        y = K.cbn_relu_img16_conv3x3(xt, labels, gamma, beta, stats, rf, bt, c, flags, r8t)
+    torch.cuda.synchronize()
+    if n * (c // 128) >= 256:
+        assert torch.equal(y, ref)
+    else:       # (small batches: the unfused conv takes the half-image form, whose two reduction halves add in another order)
+        assert relerr(y, ref.double().cpu().numpy()) < 1e-2
+    if stat_groups:         # the epilogue sums (atomics: order noise only)
+        a, r_ = cs.sums.sum(1), cs_ref.sums.sum(1)
+        assert float((a - r_).abs().max()) <= 1e-4 * float(r_.abs().max())
+    if n <= 8:
+        ry, _ = R.cond_batchnorm_forward(x, labels.cpu().numpy(), gamma.double().cpu().numpy(), beta.double().cpu().numpy(), groups)
+        rr = R.conv2d_same(R.relu(ry), w, b)
+        if res:
+            rr = rr + np.repeat(np.repeat(r8, 2, axis=1), 2, axis=2)
+        assert relerr(y, rr) < 2 * BF_TOL
