@@ -234,6 +234,8 @@ class AdamTF:
         self.health = torch.zeros(2, dtype=torch.int64, device=dev) if health else None
         self.pending_sn = None       # a batched spectral norm whose backward apply this optimiser's next launch performs (functional.defer_sn_apply)
         self.sn_state = None         # the network's persistent spectral-norm state, if any: a plain step invalidates it
+        self.bump = None             # (counter int64[1], condition int32[1]): the fused launch advances the counter when the condition word is 0
+        self.bumped = False          # ... and says so here (train_iteration then skips its own counter launch)
 
     def apply(self):
         """One launch: the update, the step count, and the gradient buffer (with its scratch half) cleared for the next
@@ -245,8 +247,12 @@ class AdamTF:
         if batch is not None:
             # (dw_zero: a spectrally normalised weight receives gradient through its normalised copy only, and this launch's
             #  predecessor cleared the buffer: the weights' own gradient views are zero and are not touched)
-            batch.adam_fwd_a(f["params"], f["grads"], f["m"], f["v"], self.hp, self.t, self.iteration, health=self.health, dw_zero=True)
+            bump = self.bump if self.bump is not None else (None, None)
+            batch.adam_fwd_a(f["params"], f["grads"], f["m"], f["v"], self.hp, self.t, self.iteration, health=self.health, dw_zero=True,
+                             bump=bump[0], bump_when_zero=bump[1])
+            self.bumped = self.bump is not None
         else:
+            self.bumped = False
             if self.sn_state is not None:
                 self.sn_state.valid = False
             K.adam_tf(f["params"], f["grads_all"], f["m"], f["v"], self.hp, self.t, self.iteration, zero_grads=True, health=self.health)
@@ -849,14 +855,21 @@ class SNGANTrainer:
         self._run_plain('gen5', self._generate_for_critic)
         if obs:
             obs('after_gen5', 0)
-        for i in range(N_CRITIC):      # slot i of the feed ring: the device-side slot counter walks 0..N_CRITIC-1
-            if obs:
-                obs('before_d', i)
-            self._run('d_pre', self._d_forward_backward_prefetched, self.d_opt, self.d_flat)
-            if obs:
-                obs('after_d', i)
+        # the iteration counter advances inside the LAST critic update's optimiser launch (the feed-ring slot has wrapped to 0 by then)
+        # where that launch is the fused one; `d_opt.bumped` says whether the update path, as last executed or captured, carries it
+        self.d_opt.bump = (self.iteration_dev, self.feed_slot) if (FUSE_SN_TAIL and not self.dp and self.sn_state is not None) else None
+        try:
+            for i in range(N_CRITIC):      # slot i of the feed ring: the device-side slot counter walks 0..N_CRITIC-1
+                if obs:
+                    obs('before_d', i)
+                self._run('d_pre', self._d_forward_backward_prefetched, self.d_opt, self.d_flat)
+                if obs:
+                    obs('after_d', i)
+        finally:
+            self.d_opt.bump = None
         self.iteration += 1
-        K.counter_add(self.iteration_dev, 1)
+        if not self.d_opt.bumped:
+            K.counter_add(self.iteration_dev, 1)
 
     @torch.no_grad()
     def dev_disc_cost(self, real_u8, labels, z=None, real_pre=None):

@@ -122,7 +122,7 @@ PROTOTYPES = {
     "gank_sn_power_iter_fwd_a": [C.POINTER(SnDesc), I, P],
     "gank_sn_power_iter_fwd_b_prep": [C.POINTER(SnDesc), I, C.POINTER(PrepDesc), C.POINTER(C.c_int), I, C.POINTER(LabelDenseDesc), P, P, P, I, P],
     "gank_sn_power_iter_bwd_gw": [C.POINTER(SnDesc), I, P],
-    "gank_sn_adam_fwd_a": [C.POINTER(SnDesc), I, C.POINTER(C.c_void_p), P, P, P, P, L, P, P, P, P, I, P],
+    "gank_sn_adam_fwd_a": [C.POINTER(SnDesc), I, C.POINTER(C.c_void_p), P, P, P, P, L, P, P, P, P, I, P, P, P],
     "gank_label_dense_table": [P, P, P, P, P, I, I, I, P],
     "gank_concat_label_fwd": [P, P, P, P, I, I, I, I, I, P],
     "gank_concat_label_bwd": [P, P, P, I, I, I, I, P],

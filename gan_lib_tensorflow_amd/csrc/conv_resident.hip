@@ -1936,7 +1936,7 @@ static int img16_conv3x3_impl(const void* x, const void* w_rfrag, const float* b
   static const int cfg_env = gank_tune("GANK_IMG16_CFG", 412);   // experiment knob: 100 * (pixel tiles per wave) + weight fragments in flight
   static const int half_env = gank_tune("GANK_IMG16_HALF", 1);   // experiment knob: 0 = whole images only, 1 = half images when the whole-image grid leaves CUs idle, 2 = always
   if (cbn) {          // whole-image form only (the passes this serves have N * Cout / 128 >= 256 workgroups)
-    gank_prof_tag(0, "img16_conv3x3_kernel<12, 4, false, norm>");
+    gank_prof_tag(0, "img16_conv3x3_kernel<12, 4, false, true>");
     GANK_MAX_DYNAMIC_LDS((img16_conv3x3_kernel<12, 4, false, true>), 2 * I16_IMG, "cbn_relu_img16_conv3x3");
     hipLaunchKernelGGL((img16_conv3x3_kernel<12, 4, false, true>), dim3(N * (Cout / 128)), dim3(512), 2 * I16_IMG, s, a);
     gank_prof_end(0, s);
@@ -1948,7 +1948,7 @@ static int img16_conv3x3_impl(const void* x, const void* w_rfrag, const float* b
     static const int hpf_env = gank_tune("GANK_IMG16_HALF_PF", 9);
 #define IMG16_LAUNCH_HALF(PF)                                                                             \
   do {                                                                                                    \
-    gank_prof_tag(0, "img16_conv3x3_kernel<" #PF ", 4, half>");                                         \
+    gank_prof_tag(0, "img16_conv3x3_kernel<" #PF ", 4, true, false>");                                         \
     GANK_MAX_DYNAMIC_LDS((img16_conv3x3_kernel<PF, 4, true>), HALF_LDS, "img16_conv3x3");                 \
     hipLaunchKernelGGL((img16_conv3x3_kernel<PF, 4, true>), dim3(2 * N * (Cout / 128)), dim3(512), HALF_LDS, s, a); \
   } while (0)
@@ -1966,7 +1966,7 @@ static int img16_conv3x3_impl(const void* x, const void* w_rfrag, const float* b
   }
 #define IMG16_LAUNCH(PF, TW)                                                                              \
   do {                                                                                                    \
-    gank_prof_tag(0, "img16_conv3x3_kernel<" #PF ", " #TW ">");                                         \
+    gank_prof_tag(0, "img16_conv3x3_kernel<" #PF ", " #TW ", false, false>");                                         \
     GANK_MAX_DYNAMIC_LDS((img16_conv3x3_kernel<PF, TW>), 2 * I16_IMG, "img16_conv3x3");                   \
     hipLaunchKernelGGL((img16_conv3x3_kernel<PF, TW>), dim3(N * (Cout / 128)), dim3(2048 / TW), 2 * I16_IMG, s, a); \
   } while (0)

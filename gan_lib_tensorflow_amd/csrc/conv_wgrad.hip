@@ -1295,7 +1295,8 @@ static int launch_wgrad_taps_mode(WgradArgs a, hipStream_t s) {
   auto kern = conv_wgrad_taps_kernel<MODE, 2>;
 #endif
   static const std::string tag = gank_format("conv_wgrad_taps_kernel<%d, 2> + wgrad_reduce_slabs_kernel", MODE);     // magic static: built once, thread-safe
-  gank_prof_tag(1, tag.c_str());
+  static const std::string tag_deferred = gank_format("conv_wgrad_taps_kernel<%d, 2>", MODE);      // (the slab reduction is a job of the caller's summing launch)
+  gank_prof_tag(1, (a.ws && a.slab_job && a.splits <= 16) ? tag_deferred.c_str() : tag.c_str());
   a.xcd = wgrad_xcd_env();
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_ci * a.tiles_co * a.splits)), dim3(256), lds, s, a);
   GANK_LAUNCH_OK("conv_wgrad_taps");
@@ -1869,7 +1870,8 @@ static int convpool3x3_wgrad_impl(const void* x, const void* dy, float* dw, floa
     GANK_REQUIRE(ws_elems >= 16L * Cin * Cout * a.splits, "convpool3x3_wgrad: workspace of %ld floats, need %ld (gank_convpool3x3_wgrad_ws_elems)",
                  ws_elems, 16L * Cin * Cout * a.splits);
     gank_prof_begin(1, 2.0 * a.M * 16.0 * Cin * Cout, s, 2.0 * ((double)N * 4 * Hp * Wp * Cin + (double)a.M * Cout) + 36.0 * Cin * Cout);
-    gank_prof_tag(1, "conv_wgrad_rows_kernel<1, 2, true> + wgrad_cpool_fold_slabs_kernel");
+    gank_prof_tag(1, (job && a.splits <= 16 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0) ? "conv_wgrad_rows_kernel<1, 2, true>"
+                                                                                           : "conv_wgrad_rows_kernel<1, 2, true> + wgrad_cpool_fold_slabs_kernel");
     const size_t lds = (size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16);
     a.scale = 1.f;
     static const int pf = gank_tune("GANK_CPOOL_ROWS_PF", 2);   // experiment knob: register prefetch depth

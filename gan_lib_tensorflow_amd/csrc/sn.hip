@@ -685,6 +685,8 @@ struct SnAdamArgs {
   long gap_lo[SN_MAX + 1], gap_hi[SN_MAX + 1];     // [lo, hi) element ranges of the flat buffer outside every table entry
   int gap_block[SN_MAX + 2];                       // first extra block of gap i (1024 elements per block)
   int ngaps, sn_blocks;
+  long long* bump;        // optional: a step counter that advances by one when bump_when[0] == 0 (below)
+  const int* bump_when;
   int dbg;                // TUNING builds (GANK_SNTAIL_DBG): 1 = no finalize, 2 = return before the publication, 4 = no parameter / slot stores
   int dw_zero;            // every table entry's dW is known to be zero (nothing but this backward pass contributes): neither read nor cleared
 };
@@ -939,6 +941,9 @@ __global__ __launch_bounds__(256) void sn_adam_fwd_a_kernel(SnTable t, SnAdamArg
     if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
       *ticket = 0u;
       ad.t_state[0] += 1;
+      // the train loop's iteration counter (the `_iteration` feed of the LR decay, gan_cifar_resnet.py:320,454-459) advances behind
+      // the LAST critic update of an iteration: every block of this launch has derived its step size from the old value by now
+      if (ad.bump && ad.bump_when[0] == 0) ad.bump[0] += 1;
     }
   }
 }
@@ -980,7 +985,8 @@ extern "C" int gank_sn_power_iter_bwd_gw(const gank_sn_desc* table, int count, v
 }
 
 extern "C" int gank_sn_adam_fwd_a(const gank_sn_desc* table, int count, float* const* u_next, float* p, float* g, float* m, float* v, long n,
-                                  float* hp, int64_t* t_state, const int64_t* iteration, uint64_t* health, int flags, void* stream) {
+                                  float* hp, int64_t* t_state, const int64_t* iteration, uint64_t* health, int flags, int64_t* bump,
+                                  const int32_t* bump_when_zero, void* stream) {
   GANK_REQUIRE(table && count > 0 && count <= SN_MAX && u_next && p && g && m && v && hp && t_state && n > 0, "sn_adam_fwd_a: bad arguments");
   SnTable t;
   int chunks, fine;
@@ -990,6 +996,8 @@ extern "C" int gank_sn_adam_fwd_a(const gank_sn_desc* table, int count, float* c
   ad.health = (unsigned long long*)health;
   ad.sn_blocks = chunks;
   ad.dw_zero = (flags & 1) ? 1 : 0;
+  GANK_REQUIRE(!bump || bump_when_zero, "sn_adam_fwd_a: a counter to advance needs its condition word");
+  ad.bump = (long long*)bump; ad.bump_when = bump_when_zero;
   { static const int dbg_ = gank_tune("GANK_SNTAIL_DBG", 0); ad.dbg = dbg_; }
   // the table's weights, in buffer order, must be disjoint views of [p, p + n) whose gradient views sit at the same offsets of g
   int order[SN_MAX];

@@ -949,11 +949,12 @@ class SnBatch:
             self.table[i].dW = _p(d, F32, "dW").value
         _lib.check(lib().gank_sn_power_iter_bwd_gw(self.table, self.n, _stream()), "sn_power_iter_bwd_gw")
 
-    def adam_fwd_a(self, p, g, m, v, hp, t_state, iteration=None, health=None, dw_zero=False):
+    def adam_fwd_a(self, p, g, m, v, hp, t_state, iteration=None, health=None, dw_zero=False, bump=None, bump_when_zero=None):
         """gank_sn_adam_fwd_a after backward_gw: the spectral norm's gradient, TF-Adam over the WHOLE flat buffer (p, g, m, v; the
         consumed gradients and dW_bar slices cleared) and the next forward pass's power iteration on the updated weights (u' ->
         the state's staging buffer) in one launch.  Needs the persistent state and an assigning forward pass before it.
-        dw_zero: the caller guarantees the weights' own gradient views are zero (only this backward pass contributes to them)."""
+        dw_zero: the caller guarantees the weights' own gradient views are zero (only this backward pass contributes to them).
+        bump / bump_when_zero: an int64 counter advanced by one when the int32 word is 0 (the iteration count behind an iteration's last update)."""
         st = self.state
         assert st is not None and self.inplace and self.n <= 16
         ptrs = (C.c_void_p * self.n)()
@@ -963,7 +964,8 @@ class SnBatch:
             o += c
         _lib.check(lib().gank_sn_adam_fwd_a(self.table, self.n, ptrs, _p(p, F32, "p"), _p(g, F32, "g"), _p(m, F32, "m"), _p(v, F32, "v"), p.numel(),
                                             _p(hp, F32, "hp"), _p(t_state, torch.int64, "t_state"), _p(iteration, torch.int64, "iteration"),
-                                            _p(health, torch.int64, "health"), 1 if dw_zero else 0, _stream()), "sn_adam_fwd_a")
+                                            _p(health, torch.int64, "health"), 1 if dw_zero else 0, _p(bump, torch.int64, "bump"),
+                                            _p(bump_when_zero, I32, "bump_when_zero"), _stream()), "sn_adam_fwd_a")
         st.valid = True
 
 

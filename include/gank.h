@@ -417,6 +417,9 @@ int gank_sn_power_iter_fwd_prep(const gank_sn_desc* table, int count, const gank
  *                                  Every table entry's W must be a disjoint view of p and its dW the view of g at the same offset;
  *                                  C <= 256.  flags bit 0: the caller guarantees that every entry's dW is zero on entry (nothing but
  *                                  this backward pass contributes to those weights): it is then neither read nor cleared.
+ *                                  bump (optional): an int64 counter that advances by one, after every block has read `iteration`,
+ *                                  when bump_when_zero[0] == 0 -- the train loop's iteration count behind the last critic update
+ *                                  of an iteration (the feed-ring slot has wrapped to 0 by then) without a launch of its own.
  *                                  Bit-identical to gank_sn_power_iter_bwd + gank_adam_tf + gank_sn_power_iter_fwd_a. */
 int gank_sn_power_iter_fwd_a(const gank_sn_desc* table, int count, void* stream);
 int gank_sn_power_iter_fwd_b_prep(const gank_sn_desc* table, int count, const gank_prep_desc* prep, const int* prep_weight,
@@ -424,7 +427,8 @@ int gank_sn_power_iter_fwd_b_prep(const gank_sn_desc* table, int count, const ga
                                   const float* u_next_flat, int u_total, void* stream);
 int gank_sn_power_iter_bwd_gw(const gank_sn_desc* table, int count, void* stream);
 int gank_sn_adam_fwd_a(const gank_sn_desc* table, int count, float* const* u_next, float* p, float* g, float* m, float* v, long n,
-                       float* hp, int64_t* t_state, const int64_t* iteration, uint64_t* health, int flags, void* stream);
+                       float* hp, int64_t* t_state, const int64_t* iteration, uint64_t* health, int flags, int64_t* bump,
+                       const int32_t* bump_when_zero, void* stream);
 
 /* ---- conditional batch norm (common/ops/normalization.py:27-59) ----------------------------------
  * Batch moments over (N/groups, H, W) per tower (biased variance, eps 1e-5), per-sample gamma/beta

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: scratch/final_measure.sh <tag>   -- the round's measurement set on ONE box: plain bench, interleaved A/B against the previous
 # round's tree, bench under rocprofv3 (kernel stats, category summary, kernel sequence), matrix-pipe busy share per kernel, HBM traffic per kernel
-tag=${1:-r04_v1}
+tag=${1:-r05_v1}
 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 echo "bench: $(cut -c1-220 gpurun_out/${tag}_bench.json)"
 bash scratch/ab_base.sh 3 100 > gpurun_out/${tag}_ab_vs_previous_round.txt 2>&1

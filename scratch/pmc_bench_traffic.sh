@@ -1,6 +1,7 @@
 #!/bin/bash
 # HBM traffic of the dominant kernel family over bench.py's workload: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc
 # passes (MI355X_MICROARCH.md: TCC has 4 slots, the two need 3 + 2), units KB, FETCH_SIZE doubled on gfx950.
+export GANK_BENCH_EXTRAS=0     # bench.py: the headline measurement only
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/traffic.json
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -11,13 +12,13 @@ python3 - "$out" <<'PY'
 import csv, glob, sys, json, collections, re
 def sym(n):      # rocprofv3 prints "void name<...>(ArgTypes)": keep name<...> as libgank's launchers record it
     n = re.sub(r"^void ", "", n).replace("(anonymous namespace)::", "")
-    n = re.sub(r"\((\(anonymous namespace\)::)?(IgemmArgs|WgradArgs|ResFwdArgs|ResBwdArgs|CpFwdArgs|CpBwdArgs|G8Args|I16Args|NarrowWgArgs, NarrowWgArgs, int)\)$", "", n)
+    n = re.sub(r"\((\(anonymous namespace\)::)?(IgemmArgs|WgradArgs|ResFwdArgs|ResBwdArgs|CpFwdArgs|CpBwdArgs|CpBwdWgArgs|G8Args|I16Args|NarrowWgArgs, NarrowWgArgs, int)\)$", "", n)
     return re.sub(r"\(.*\)$", "", n)            # plain kernels: drop the argument list
 per = collections.defaultdict(lambda: {"FETCH_SIZE": [], "WRITE_SIZE": []})
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f'/tmp/pmc_b_{c}/**/*counter_collection.csv', recursive=True)[0]
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == c and any(t in r["Kernel_Name"] for t in ("conv_", "conv3x3", "res8_", "cpool_res", "wgrad_")) and "prep" not in r["Kernel_Name"]:
+        if r["Counter_Name"] == c and any(t in r["Kernel_Name"] for t in ("conv_", "conv3x3", "res8_", "cpool_res", "wgrad_", "sum_slabs")) and "prep" not in r["Kernel_Name"]:
             per[sym(r['Kernel_Name'])][c].append(float(r['Counter_Value']))
 res = {"per_kernel": {}}
 for k, d in per.items():

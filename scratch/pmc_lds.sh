@@ -1,6 +1,7 @@
 #!/bin/bash
 # LDS bank-conflict share per kernel over bench.py's workload: SQ_LDS_BANK_CONFLICT (extra cycles) / SQ_LDS_IDX_ACTIVE (all LDS-array
 # cycles), one --pmc pass; plus SQ_LDS_UNALIGNED_STALL
+export GANK_BENCH_EXTRAS=0     # bench.py: the headline measurement only
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_lds
 timeout -k 10 280 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL --output-format csv -d /tmp/pmc_lds -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 2 > /dev/null 2>&1 < /dev/null || { echo "pass failed"; exit 1; }

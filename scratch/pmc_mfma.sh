@@ -1,6 +1,7 @@
 #!/bin/bash
 # matrix-pipe share per kernel over bench.py's workload: SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the SIMDs) against
 # GRBM_GUI_ACTIVE (sum over the 8 XCDs) -> busy / (active / 8 * 1024 SIMDs); effective clock = active / 8 / duration needs the trace
+export GANK_BENCH_EXTRAS=0     # bench.py: the headline measurement only
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_mf
 timeout -k 10 280 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --output-format csv -d /tmp/pmc_mf -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 2 > /dev/null 2>&1 < /dev/null || { echo "pass failed"; exit 1; }
