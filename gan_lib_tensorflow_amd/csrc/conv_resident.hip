@@ -1447,12 +1447,13 @@ __global__ __launch_bounds__(512) void cpool_res_dgrad_imgwg_kernel(CpBwdWgArgs 
     const float v = (kg == 0 ? accw[e] : accw[8 + e]) + ex_in[e * 64 + lane];
     const int k = (ee & 3) + 8 * (ee >> 2) + 4 * h;
     float* dst = nullptr;
-    if (k < 27) dst = a.dw1 + (long)k * a.Cin + cg * 128 + col;
+    if (k < 27) {
+      dst = a.dw1 + (long)k * a.Cin + cg * 128 + col;
 #ifdef GANK_TUNING          // contention experiments: one copy of the tile per XCD (8) / per workgroup (16); the caller's buffer is that large
-    if (k < 27 && (a.dbg & 8)) dst += (blockIdx.x & 7) * 8192;
-    if (k < 27 && (a.dbg & 16)) dst += blockIdx.x * 8192;
+      if (a.dbg & 8) dst += (blockIdx.x & 7) * 8192;
+      if (a.dbg & 16) dst += blockIdx.x * 8192;
 #endif
-    else if (k == 27) dst = a.db1 ? a.db1 + cg * 128 + col : nullptr;
+    } else if (k == 27) dst = a.db1 ? a.db1 + cg * 128 + col : nullptr;
     else if (k < 31) dst = (shortcut && a.dws) ? a.dws + (long)(k - 28) * a.Cout + col : nullptr;
     else dst = (shortcut && a.dbs) ? a.dbs + col : nullptr;
     if (dst) atomicAdd(dst, v);

@@ -39,7 +39,7 @@ struct WgradArgs {
   // consecutive logical ids = share an XCD's L2; 0 = the split index fastest (tiles of a split land on all eight XCDs unless
   // the split count happens to be a multiple of 8, and every XCD then pulls the whole operand through the fabric)
   int xcd;
-  int dbg;            // TUNING builds only (GANK_WGRAD_DBG): 1 = no output (timing of everything but the partial-tile stores / atomics), 2 = one step per block
+  int dbg;            // TUNING builds only (GANK_WGRAD_DBG): 1 = no output (timing of everything but the partial-tile stores / atomics), 2 = one step per block; rows kernel: 4 = no MFMA section, 8 = no global loads in the loop, 16 = no LDS stores, 32 = no barrier
   // batched launch of up to 4 same-shape layers (gank_conv2d_wgrad_batched): blockIdx.y (xcd: the logical id) picks the operand set
   int nbatch;
   const bf16* xs[4];
@@ -1343,9 +1343,17 @@ constexpr int CPR_XSUB = 8 * 18 * 32 + 32;   // sub-tile stride (bf16) of the wi
 // patch) -- for layers too small for the all-taps kernel (its 9-tap partial tiles, one per pixel split, cost more slab
 // traffic than the layer has FLOPs); partial tiles are added to dw with fp32 atomics (a third of the all-taps volume per
 // block) or written to slabs when a workspace is given.  grid.y = layer of a same-shape batch (nbatch > 0).
-template <int MODE, int PF, bool S2>
-__global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs a) {
-  constexpr int NT = 256;
+// KG = 2: 512 threads, the two wave groups take the first / second pixel-row pairs of every patch (two waves per SIMD: one
+// group's transposed reads run under the other's MFMAs; with one wave per SIMD a step took ~1300 cycles against 512 of LDS
+// reads and 384 of MFMA) and the second group's partial tile is added through LDS at the end -- same slab volume.
+// KG = 3: 512 threads in two ROLES: waves 0-3 only read LDS and issue MFMAs, waves 4-7 only load the next patches and store them
+// to the other LDS buffer (one barrier per step as before).  In the one-role form a step was the SUM of its MFMA section (0.25 us),
+// its 20 buffer loads (0.2 us, the same with out-of-range addresses: issue through the CU's one address unit, not memory) and
+// its 20 16-byte LDS stores (0.2 us): every wave stalled on the load issue in the middle of its MFMA stream.
+template <int MODE, int PF, bool S2, int KG = 1>
+__global__ __launch_bounds__(KG == 3 ? 512 : 256 * KG) void conv_wgrad_rows_kernel(WgradArgs a) {
+  constexpr bool SPEC = KG == 3;
+  constexpr int NT = SPEC ? 256 : 256 * KG, NDC = 512 / NT, KPG = SPEC ? 4 : 4 / KG;      // NT = staging threads
   constexpr bool XRELU = (MODE & 1) != 0;
   constexpr int COLS = S2 ? 18 : 10, NTAP = S2 ? 4 : 3, ST = S2 ? 2 : 1;
   constexpr int XCHUNKS = 8 * COLS * 8, NXC = (XCHUNKS + NT - 1) / NT;
@@ -1353,8 +1361,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs a) {
   bf16* sX = reinterpret_cast<bf16*>(smem);        // [2][2 subs][8 * COLS pix][32 ch]
   bf16* sD = sX + 2 * 2 * CPR_XSUB;                // [2][2 subs][64 pix][32 ch]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wave_a = wave & 1, wave_b = wave >> 1;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave_a = wave & 1, wave_b = (wave >> 1) & 1, kgrp = SPEC ? 0 : wave >> 2;
+  const bool feeds = !SPEC || wave >= 4, computes = !SPEC || wave < 4;      // wave-uniform roles
+  const int tid = SPEC ? (threadIdx.x & 255) : threadIdx.x;                   // index among the staging (and among the computing) threads
   const bf16* X = a.x;
   const bf16* DY = a.dy;
   float* DW = a.dw;
@@ -1413,25 +1423,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs a) {
     const int slot = S2 ? hyi * COLS + (hx & 1) * (COLS / 2) + (hx >> 1) : hyi * COLS + hx;
     x_lds[j] = (cc >> 2) * CPR_XSUB + slot * 32 + (cc & 3) * 8;
   }
-  int d_y[2], d_x[2], d_c[2], d_lds[2];
+  int d_y[NDC], d_x[NDC], d_c[NDC], d_lds[NDC];
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
+  for (int j = 0; j < NDC; j++) {
     const int q = tid + NT * j, p = q >> 3, cc = q & 7;
     d_y[j] = p >> 3; d_x[j] = p & 7;
     d_c[j] = (co0 + cc * 8) * 2;
     d_lds[j] = (cc >> 2) * SUBS + p * 32 + (cc & 3) * 8;
   }
 
-  u32x4 rX[PF][NXC], rD[PF][2];
-  float bsum[2][8];
+  u32x4 rX[PF][NXC], rD[PF][NDC];
+  float bsum[NDC][8];
 #pragma unroll
-  for (int j = 0; j < 2; j++)
+  for (int j = 0; j < NDC; j++)
 #pragma unroll
     for (int e = 0; e < 8; e++) bsum[j][e] = 0.f;
 
   const int last = nsteps - 1;
   int cur = 0;
-  auto load_next = [&](u32x4 (&rX)[NXC], u32x4 (&rD)[2]) {
+  auto load_next = [&](u32x4 (&rX)[NXC], u32x4 (&rD)[NDC]) {
     const int patch = step0 + cur;                       // wave-uniform
     const int n = patch >> pi_shift;
     const int pin = patch & ((1 << pi_shift) - 1);
@@ -1439,18 +1449,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < NXC; j++) {
       const int iy = ST * py0 + x_hy[j], ix = ST * px0 + x_hx[j];
-      const bool ok = (unsigned)iy < (unsigned)a.Hx && (unsigned)ix < (unsigned)a.Wx;
+      bool ok = (unsigned)iy < (unsigned)a.Hx && (unsigned)ix < (unsigned)a.Wx;
+#ifdef GANK_TUNING
+      if (a.dbg & 64) ok = false;            // timing only: x reads out of range (zero fill, no memory traffic)
+#endif
       const int off = ((n * a.Hx + iy) * a.Wx + ix) * a.Cin * 2 + x_c[j];
       rX[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? off : OOB, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int off = ((n * a.H + py0 + d_y[j]) * a.W + px0 + d_x[j]) * a.Cout * 2 + d_c[j];
+    for (int j = 0; j < NDC; j++) {
+      int off = ((n * a.H + py0 + d_y[j]) * a.W + px0 + d_x[j]) * a.Cout * 2 + d_c[j];
+#ifdef GANK_TUNING
+      if (a.dbg & 128) off = OOB;            // timing only: dy reads out of range
+#endif
       rD[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, off, 0, 0);
     }
     if (cur < last) cur++;
   };
-  auto store_step = [&](int buf, u32x4 (&rX)[NXC], u32x4 (&rD)[2]) {
+  auto store_step = [&](int buf, u32x4 (&rX)[NXC], u32x4 (&rD)[NDC]) {
 #pragma unroll
     for (int j = 0; j < NXC; j++) {
       if (x_on[j]) {
@@ -1460,7 +1476,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs a) {
       }
     }
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
+    for (int j = 0; j < NDC; j++) {
       *reinterpret_cast<u32x4*>(sD + buf * 2 * SUBS + d_lds[j]) = rD[j];
       if (do_bias) {
         const bf16x8 t = __builtin_bit_cast(bf16x8, rD[j]);
@@ -1478,23 +1494,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs a) {
 
   const int g = lane >> 4, li = lane & 15;
   // lane part of the transposed-read addresses: k half (g>>1) = dy row within the pair, (li>>2) = dy column
-  const int xl = ((g >> 1) * COLS + (li >> 2)) * 32 + 16 * (g & 1) + 4 * (li & 3);
-  const int dl = (8 * (g >> 1) + (li >> 2)) * 32 + 16 * (g & 1) + 4 * (li & 3);
+  const int xl = ((g >> 1) * COLS + (li >> 2)) * 32 + 16 * (g & 1) + 4 * (li & 3) + kgrp * KPG * 2 * COLS * 32;     // (+ the wave group's first row pair)
+  const int dl = (8 * (g >> 1) + (li >> 2)) * 32 + 16 * (g & 1) + 4 * (li & 3) + kgrp * KPG * 16 * 32;
 
+  if (feeds) {
 #pragma unroll
-  for (int d = 0; d < PF; d++) load_next(rX[d], rD[d]);
-  store_step(0, rX[0], rD[0]);
+    for (int d = 0; d < PF; d++) load_next(rX[d], rD[d]);
+    store_step(0, rX[0], rD[0]);
+  }
   __syncthreads();
 
   auto step = [&](int s, auto slot) {
     constexpr int D = decltype(slot)::value;
     const int buf = s & 1;
-    if constexpr (PF > 1) load_next(rX[D], rD[D]);
-    else if (s + 1 < nsteps) load_next(rX[0], rD[0]);
+#ifdef GANK_TUNING
+    if (!(a.dbg & 8))
+#endif
+    if (feeds) {
+      if constexpr (PF > 1) load_next(rX[D], rD[D]);
+      else if (s + 1 < nsteps) load_next(rX[0], rD[0]);
+    }
     const bf16* pX = sX + (buf * 2 + wave_a) * CPR_XSUB + xl;
     const bf16* pD = sD + (buf * 2 + wave_b) * SUBS + dl;
+#ifdef GANK_TUNING
+    if (!(a.dbg & 4))
+#endif
+    if (computes)
 #pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
+    for (int kk = 0; kk < KPG; kk++) {
       const s16x4 bl = lds_tr_read(pD + kk * 16 * 32), bh = lds_tr_read(pD + kk * 16 * 32 + 4 * 32);
       const s16x8 tb = {bl[0], bl[1], bl[2], bl[3], bh[0], bh[1], bh[2], bh[3]};
       const bf16x8 fb = __builtin_bit_cast(bf16x8, tb);
@@ -1506,7 +1533,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs a) {
         acc[t] = GANK_MFMA32(__builtin_bit_cast(bf16x8, ta), fb, acc[t]);
       }
     }
-    if (s + 1 < nsteps) store_step(buf ^ 1, rX[(D + 1) % PF], rD[(D + 1) % PF]);
+#ifdef GANK_TUNING
+    if (!(a.dbg & 16))
+#endif
+    if (feeds && s + 1 < nsteps) store_step(buf ^ 1, rX[(D + 1) % PF], rD[(D + 1) % PF]);
+#ifdef GANK_TUNING
+    if (!(a.dbg & 32))
+#endif
     __syncthreads();
   };
   int s0 = 0;
@@ -1523,40 +1556,69 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs a) {
 #ifdef GANK_TUNING
   if (a.dbg & 1) { if (acc[0][0] == 123.456f) DW[0] = 1.f; return; }
 #endif
+  if constexpr (KG == 2) {        // second wave group's partial tile -> first group's registers (the loop's last barrier has passed)
+    float* xr = reinterpret_cast<float*>(smem);             // [NTAP * 16][256]
+    if (kgrp == 1) {
+#pragma unroll
+      for (int t = 0; t < NTAP; t++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) xr[(t * 16 + e) * 256 + (tid & 255)] = acc[t][e];
+    }
+    __syncthreads();
+    if (kgrp == 0) {
+#pragma unroll
+      for (int t = 0; t < NTAP; t++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[t][e] += xr[(t * 16 + e) * 256 + tid];
+    }
+  }
   // partial tile -> slab [split][frow*NTAP + t][Cin][Cout], or atomics into dw
   const int r = lane & 31, h = lane >> 5;
   const int co = co0 + wave_b * 32 + r;
   const long plane = (long)a.Cin * a.Cout;
+  if (kgrp == 0 && computes) {
 #pragma unroll
-  for (int t = 0; t < NTAP; t++) {
-    float* dst = WS ? WS + ((long)split * NTAP * NTAP + frow * NTAP + t) * plane : DW + (long)(frow * NTAP + t) * plane;
+    for (int t = 0; t < NTAP; t++) {
+      float* dst = WS ? WS + ((long)split * NTAP * NTAP + frow * NTAP + t) * plane : DW + (long)(frow * NTAP + t) * plane;
 #pragma unroll
-    for (int e = 0; e < 16; e++) {
-      const int ci = ci0 + wave_a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-      if (WS) dst[(long)ci * a.Cout + co] = acc[t][e];
-      else atomicAdd(dst + (long)ci * a.Cout + co, acc[t][e] * a.scale);
+      for (int e = 0; e < 16; e++) {
+        const int ci = ci0 + wave_a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (WS) dst[(long)ci * a.Cout + co] = acc[t][e];
+        else atomicAdd(dst + (long)ci * a.Cout + co, acc[t][e] * a.scale);
+      }
     }
   }
   if (do_bias) {
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);            // [256][16]
+    float* red = reinterpret_cast<float*>(smem);            // [512 chunks][8]
+    if (feeds) {
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+      for (int j = 0; j < NDC; j++)
 #pragma unroll
-      for (int e = 0; e < 8; e++) red[(tid * 2 + j) * 8 + e] = bsum[j][e];
+        for (int e = 0; e < 8; e++) red[(tid * NDC + j) * 8 + e] = bsum[j][e];
+    }
     __syncthreads();
-    if (tid < 64) {
+    if (threadIdx.x < 64) {
       const int cc = tid >> 3, e = tid & 7;
       float tsum = 0.f;
       for (int p = 0; p < 64; p++) {
         const int q = p * 8 + cc;
-        tsum += red[((q % NT) * 2 + q / NT) * 8 + e];
+        tsum += red[((q % NT) * NDC + q / NT) * 8 + e];
       }
       atomicAdd(DB + co0 + tid, tsum * a.scale);
     }
   }
 }
 
+static int wgrad_rows_kg() {
+  static const int v = gank_tune("GANK_WGRAD_ROWS_KG", 3);   // experiment knob: 1 = 256 threads, every wave feeds and computes; 2 = two K groups (512 threads); 3 = feeding + computing waves (512 threads)
+  return (v == 2 || v == 3) ? v : 1;
+}
+template <bool S2>
+static size_t wgrad_rows_lds(int kg) {
+  const size_t stage = (size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16), xr = kg == 2 ? (size_t)(S2 ? 4 : 3) * 16 * 256 * sizeof(float) : 0;
+  return stage > xr ? stage : xr;
+}
 // filter-row kernel for plain 3x3 stride-1 layers below the all-taps kernel's size (single layer or a same-shape batch)
 static bool wgrad_rows_ok(const WgradArgs& a) {
   static const int env = gank_tune("GANK_WGRAD_ROWS", 1);   // experiment knob: GANK_WGRAD_ROWS=0 keeps these layers on the per-tap kernel
@@ -1587,7 +1649,8 @@ static int launch_wgrad_rows(WgradArgs a, hipStream_t s) {
   a.splits = cdiv(total_steps, a.steps_per_split);
   a.ws = nullptr;          // partial tiles by fp32 atomics, or (a batched launch with wss[] set) to per-layer slabs [split][9][Cin][Cout]
   if (a.nbatch <= 0) for (int j = 0; j < 4; j++) a.wss[j] = nullptr;
-  const size_t lds = (size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16);
+  const int kg = wgrad_rows_kg();
+  const size_t lds = wgrad_rows_lds<false>(kg);
   const bool relu = (a.flags & GANK_IN_RELU) != 0;
   static const int pf = gank_tune("GANK_WGRAD_ROWS_PF", 2);   // experiment knob: register prefetch depth
 #ifdef GANK_TUNING
@@ -1597,13 +1660,15 @@ static int launch_wgrad_rows(WgradArgs a, hipStream_t s) {
   (void)pf;
   auto kern = relu ? conv_wgrad_rows_kernel<1, 2, false> : conv_wgrad_rows_kernel<0, 2, false>;
 #endif
+  if (kg == 2) kern = relu ? conv_wgrad_rows_kernel<1, 2, false, 2> : conv_wgrad_rows_kernel<0, 2, false, 2>;
+  if (kg == 3) kern = relu ? conv_wgrad_rows_kernel<1, 2, false, 3> : conv_wgrad_rows_kernel<0, 2, false, 3>;
   static_assert((size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16) <= 65536, "below the default dynamic-LDS limit: no attribute call");
   gank_prof_tag(1, relu ? "conv_wgrad_rows_kernel<1, 2, false>" : "conv_wgrad_rows_kernel<0, 2, false>");
   a.xcd = wgrad_xcd_env();
   static const int dbg = gank_tune("GANK_WGRAD_DBG", 0);
   a.dbg = dbg;
-  if (a.xcd) hipLaunchKernelGGL(kern, dim3((unsigned)(3 * a.tiles_ci * a.tiles_co * a.splits * nb)), dim3(256), lds, s, a);
-  else hipLaunchKernelGGL(kern, dim3((unsigned)(3 * a.tiles_ci * a.tiles_co * a.splits), nb), dim3(256), lds, s, a);
+  if (a.xcd) hipLaunchKernelGGL(kern, dim3((unsigned)(3 * a.tiles_ci * a.tiles_co * a.splits * nb)), dim3(kg == 1 ? 256 : 512), lds, s, a);
+  else hipLaunchKernelGGL(kern, dim3((unsigned)(3 * a.tiles_ci * a.tiles_co * a.splits), nb), dim3(kg == 1 ? 256 : 512), lds, s, a);
   GANK_LAUNCH_OK("conv_wgrad_rows");
   return 0;
 }
@@ -1872,7 +1937,8 @@ static int convpool3x3_wgrad_impl(const void* x, const void* dy, float* dw, floa
     gank_prof_begin(1, 2.0 * a.M * 16.0 * Cin * Cout, s, 2.0 * ((double)N * 4 * Hp * Wp * Cin + (double)a.M * Cout) + 36.0 * Cin * Cout);
     gank_prof_tag(1, (job && a.splits <= 16 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0) ? "conv_wgrad_rows_kernel<1, 2, true>"
                                                                                            : "conv_wgrad_rows_kernel<1, 2, true> + wgrad_cpool_fold_slabs_kernel");
-    const size_t lds = (size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16);
+    const int kg = wgrad_rows_kg();
+    const size_t lds = wgrad_rows_lds<true>(kg);
     a.scale = 1.f;
     static const int pf = gank_tune("GANK_CPOOL_ROWS_PF", 2);   // experiment knob: register prefetch depth
 #ifdef GANK_TUNING
@@ -1883,8 +1949,10 @@ static int convpool3x3_wgrad_impl(const void* x, const void* dy, float* dw, floa
     auto kern = (flags & GANK_IN_RELU) ? conv_wgrad_rows_kernel<1, 2, true> : conv_wgrad_rows_kernel<0, 2, true>;
 #endif
     static_assert((size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16) <= 65536, "below the default dynamic-LDS limit: no attribute call");
+    if (kg == 2) kern = (flags & GANK_IN_RELU) ? conv_wgrad_rows_kernel<1, 2, true, 2> : conv_wgrad_rows_kernel<0, 2, true, 2>;
+    if (kg == 3) kern = (flags & GANK_IN_RELU) ? conv_wgrad_rows_kernel<1, 2, true, 3> : conv_wgrad_rows_kernel<0, 2, true, 3>;
     a.xcd = wgrad_xcd_env();
-    hipLaunchKernelGGL(kern, dim3((unsigned)(4 * a.tiles_ci * a.tiles_co * a.splits)), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(4 * a.tiles_ci * a.tiles_co * a.splits)), dim3(kg == 1 ? 256 : 512), lds, s, a);
     const long plane4 = (long)Cin * Cout / 4;
     if (job && a.splits <= 16 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0) {        // the fold is left to the caller's summing launch
       job->slabs = ws16;
@@ -1975,10 +2043,14 @@ extern "C" int gank_upconv3x3_wgrad(const void* x_low, const void* dy, float* dw
                16L * Cin * Cout * a.splits);
   gank_prof_begin(1, 2.0 * a.M * 16.0 * Cin * Cout, s, 2.0 * ((double)a.M * Cin + 4.0 * a.M * Cout) + 36.0 * Cin * Cout);
   gank_prof_tag(1, "conv_wgrad_rows_kernel<0, 2, true> + wgrad_upconv_fold_slabs_kernel");
-  const size_t lds = (size_t)2 * 2 * (CPR_XSUB + SUBS) * sizeof(bf16);
+  const int kg = wgrad_rows_kg();
+  const size_t lds = wgrad_rows_lds<true>(kg);
   a.scale = 1.f;
   a.xcd = wgrad_xcd_env();
-  hipLaunchKernelGGL((conv_wgrad_rows_kernel<0, 2, true>), dim3((unsigned)(4 * a.tiles_ci * a.tiles_co * a.splits)), dim3(256), lds, s, a);
+  auto kern = conv_wgrad_rows_kernel<0, 2, true>;
+  if (kg == 2) kern = conv_wgrad_rows_kernel<0, 2, true, 2>;
+  if (kg == 3) kern = conv_wgrad_rows_kernel<0, 2, true, 3>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(4 * a.tiles_ci * a.tiles_co * a.splits)), dim3(kg == 1 ? 256 : 512), lds, s, a);
   hipLaunchKernelGGL(wgrad_upconv_fold_slabs_kernel, dim3(Cin / 32, Cout / 32, 9), dim3(256), 0, s, ws16, dw, Cin, Cout, a.splits);
   gank_prof_end(1, s);
   GANK_LAUNCH_OK("upconv3x3_wgrad");
