@@ -139,6 +139,7 @@ def _g_prep_kind(name, W):
 
 
 FUSE_SN_TAIL = True    # critic update: spectral-norm backward apply + TF-Adam + the NEXT pass's power iteration as ONE launch (gank_sn_adam_fwd_a)
+FUSE_FEED = True        # the critic's input feed rides on the second spectral-norm launch of its forward pass (gank_sn_power_iter_fwd_b_prep_feed)
 LABEL_TABLE = True    # the critic's label branch through a per-label table (0: per-sample embedding + dense layer + tile)
 FUSED_HEAD = True      # D.Output + hinge loss (+ the layer's three gradients) as one launch where the train step asks for it
 HEAD_IN_CHAIN = True   # ... and that launch folded into the fused 8x8 chain's forward / backward launches (functional.HingeHeadSpec)
@@ -520,10 +521,15 @@ class SNGANTrainer:
         """Critic update number `feed_slot` of the iteration: inputs come from the feed ring by one launch."""
         set_default_store(self.store)
         self._begin_grads(self.d_flat)
-        K.critic_feed(self.real_all, self.labels_all, self.fake_all, self.both, self.both_labels, self.feed_slot,
-                      self.rng_state, self.feed_done)
+        feed = (self.real_all, self.labels_all, self.fake_all, self.both, self.both_labels, self.feed_slot, self.rng_state, self.feed_done)
+        if FUSE_FEED:
+            K.defer_critic_feed(*feed)        # launched by the spectral-norm forward pass in front of the first layer
+        else:
+            K.critic_feed(*feed)
         with _sn.grad_scratch(self.d_flat["scratch"]):        # zeroed by zero_grads above
             loss, logits = self._critic_loss(self.both, self.both_labels, self.batch)
+        if K.deferred_critic_feed_pending():
+            raise RuntimeError("the critic's forward pass launched no spectral-norm batch: its deferred feed never ran")
         self._backward(loss)
         self.last_logits = logits
         return logits

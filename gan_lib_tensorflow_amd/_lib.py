@@ -54,6 +54,12 @@ class LabelDenseDesc(C.Structure):
     _fields_ = [("table", P), ("bias", P), ("out", P), ("V", I), ("D", I), ("weight", I)]
 
 
+class CriticFeedDesc(C.Structure):
+    """gank_critic_feed_desc"""
+    _fields_ = [("real_all", P), ("labels_all", P), ("fake_all", P), ("both", P), ("labels2", P), ("slot", P), ("rng_state", P),
+                ("done_counter", P), ("B", I), ("n_slots", I)]
+
+
 # name -> argument ctypes (all return int unless listed in _RET)
 PROTOTYPES = {
     "gank_version": [],
@@ -121,6 +127,8 @@ PROTOTYPES = {
     "gank_sn_power_iter_fwd_prep": [C.POINTER(SnDesc), I, C.POINTER(PrepDesc), C.POINTER(C.c_int), I, C.POINTER(LabelDenseDesc), P],
     "gank_sn_power_iter_fwd_a": [C.POINTER(SnDesc), I, P],
     "gank_sn_power_iter_fwd_b_prep": [C.POINTER(SnDesc), I, C.POINTER(PrepDesc), C.POINTER(C.c_int), I, C.POINTER(LabelDenseDesc), P, P, P, I, P],
+    "gank_sn_power_iter_fwd_b_prep_feed": [C.POINTER(SnDesc), I, C.POINTER(PrepDesc), C.POINTER(C.c_int), I, C.POINTER(LabelDenseDesc), P, P, P, I,
+                                           C.POINTER(CriticFeedDesc), P],
     "gank_sn_power_iter_bwd_gw": [C.POINTER(SnDesc), I, P],
     "gank_sn_adam_fwd_a": [C.POINTER(SnDesc), I, C.POINTER(C.c_void_p), P, P, P, P, L, P, P, P, P, I, P, P, P],
     "gank_label_dense_table": [P, P, P, P, P, I, I, I, P],

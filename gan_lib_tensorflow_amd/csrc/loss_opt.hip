@@ -1,5 +1,6 @@
 // Losses, TF-style Adam, the input pipeline and the graph-safe counter-based RNG.
 #include "gank_common.h"
+#include "feed.h"
 
 // ------------------------------------------------------------------------------------------------
 // hinge / softmax-xent losses: loss value + d loss / d logits in one single-block launch
@@ -387,23 +388,6 @@ extern "C" int gank_counter_add(int64_t* counter, int64_t inc, void* stream) {
 // ------------------------------------------------------------------------------------------------
 // Philox4x32-10 counter-based RNG; state = {seed, offset} in device memory, advanced on the device
 // ------------------------------------------------------------------------------------------------
-struct u4 { unsigned x, y, z, w; };
-
-__device__ __forceinline__ u4 philox4x32_10(unsigned long long ctr, unsigned long long stream_off, unsigned long long seed) {
-  unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = (unsigned)stream_off, c3 = (unsigned)(stream_off >> 32);
-  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
-#pragma unroll
-  for (int r = 0; r < 10; r++) {
-    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
-    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
-    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  return {c0, c1, c2, c3};
-}
-__device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }  // [0,1)
-
 __global__ void rng_advance_kernel(unsigned long long* state, unsigned long long inc) { state[1] += inc; }
 
 // The generators advance the stream offset THEMSELVES: every workgroup has read {seed, offset} (their use feeds the address-free
@@ -538,54 +522,16 @@ extern "C" int gank_preprocess_real(const uint8_t* data, void* y, uint64_t* rng_
 // both[B:2B] = the generator output kept for that slot, labels2 = the slot's labels twice; then the slot counter
 // and the RNG offset advance.  Replaces 3 staging copies, the preprocess launch, its RNG advance and two concats.
 // The counters are advanced by the LAST workgroup to finish (every workgroup has read them by then).
-__global__ void critic_feed_kernel(const unsigned char* __restrict__ real_all, const int* __restrict__ labels_all,
-                                   const bf16* __restrict__ fake_all, bf16* __restrict__ both, int* __restrict__ labels2,
-                                   int* __restrict__ slot, unsigned long long* __restrict__ state, unsigned* __restrict__ done,
-                                   int B, int n_slots) {
-  const unsigned long long seed = state[0], off = state[1];
-  const int sl = slot[0];
-  const unsigned char* data = real_all + (long)sl * B * 3072;
-  const long n = (long)B * 3072, n4 = n >> 2;
-  const long stride = (long)gridDim.x * blockDim.x, t = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  for (long i = t; i < n4; i += stride) {                       // identical arithmetic to preprocess_kernel
-    const u4 r = philox4x32_10((unsigned long long)i, off, seed);
-    const unsigned v[4] = {r.x, r.y, r.z, r.w};
-    for (int e = 0; e < 4; e++) {
-      const long o = i * 4 + e;
-      const int b = (int)(o / 3072), rem = (int)(o - (long)b * 3072);
-      const int c = rem % 3, hw = rem / 3;
-      const float px = (float)data[(long)b * 3072 + c * 1024 + hw];
-      both[o] = f2bf(2.f * (px / 256.f - .5f) + u01(v[e]) * (1.f / 128.f));
-    }
-  }
-  const u32x4* fs = reinterpret_cast<const u32x4*>(fake_all + (long)sl * n);
-  u32x4* fd = reinterpret_cast<u32x4*>(both + n);
-  for (long i = t; i < n / 8; i += stride) fd[i] = fs[i];
-  for (long i = t; i < B; i += stride) {
-    const int lb = labels_all[(long)sl * B + i];
-    labels2[i] = lb;
-    labels2[B + i] = lb;
-  }
-  // no fence: the counters only have to be READ by every workgroup before the last one rewrites them, and each
-  // workgroup's loads of them are consumed (addresses of everything above) before it reaches its atomic
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned prev = atomicAdd(done, 1u);
-    if (prev == gridDim.x - 1) {
-      done[0] = 0u;
-      slot[0] = sl + 1 < n_slots ? sl + 1 : 0;
-      state[1] = off + 1;
-    }
-  }
-}
+__global__ __launch_bounds__(256) void critic_feed_kernel(CriticFeedArgs a) { critic_feed_block(a, blockIdx.x); }
 
 extern "C" int gank_critic_feed(const uint8_t* real_all, const int32_t* labels_all, const void* fake_all, void* both,
                                 int32_t* labels2, int32_t* slot, uint64_t* rng_state, uint32_t* done_counter, int B, int n_slots,
                                 void* stream) {
   GANK_REQUIRE(real_all && labels_all && fake_all && both && labels2 && slot && rng_state && done_counter && B > 0 && n_slots > 0,
                "critic_feed: bad arguments");
-  hipLaunchKernelGGL(critic_feed_kernel, rgrid((long)B * 768), dim3(256), 0, (hipStream_t)stream, real_all, labels_all,
-                     (const bf16*)fake_all, (bf16*)both, labels2, slot, (unsigned long long*)rng_state, done_counter, B, n_slots);
+  CriticFeedArgs a{real_all, labels_all, (const bf16*)fake_all, (bf16*)both, labels2, slot, (unsigned long long*)rng_state, done_counter, B, n_slots,
+                   critic_feed_blocks(B)};
+  hipLaunchKernelGGL(critic_feed_kernel, dim3(a.blocks), dim3(256), 0, (hipStream_t)stream, a);
   GANK_LAUNCH_OK("critic_feed");
   return 0;
 }

@@ -24,6 +24,7 @@
 //   backward 2: every block sums the (<= a few dozen) partials of its weight itself, then applies the gradient.
 #include "gank_common.h"
 #include "prep_weights.h"
+#include "feed.h"
 
 #define SN_MAX 16
 #define SN_EPS 1e-12f
@@ -274,6 +275,7 @@ struct SnScaleTable {
 struct SnPrepExtra {
   const float* sigma[PREP_MAX];     // divisor of prep entry i (the scal word of its weight)
   int prep_blocks;
+  int dbg;                          // TUNING builds (GANK_SNB_DBG), timing only: 1 = scale blocks return, 2 = operand blocks return, 4 = label rows return
 };
 // the per-label rows of a small dense layer on an embedding table: out[l] = bf16( bf16(table[l]) (W / sigma) + bias )
 // Consumer side of the fused optimiser tail (below): the power iteration of this forward pass was already run when the weights
@@ -353,10 +355,21 @@ __device__ __forceinline__ void sn_label_row(const SnLabelDense& q, int l, int c
 
 __device__ __forceinline__ int ld_blocks(const SnLabelDense& ld) { return ld.table ? ld.V * ((ld.Cout + 63) >> 6) : 0; }
 
-__global__ __launch_bounds__(256) void sn_fwd_b_kernel(SnScaleTable st, PrepTable pt, SnPrepExtra px, SnLabelDense ld, SnAdopt ad) {
+// fd (blocks > 0): the critic's input feed of this update (feed.h) as the last block range of the launch -- it reads and writes
+// nothing the other ranges touch, and every consumer of either comes after the launch.
+__global__ __launch_bounds__(256) void sn_fwd_b_kernel(SnScaleTable st, PrepTable pt, SnPrepExtra px, SnLabelDense ld, SnAdopt ad, CriticFeedArgs fd) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef GANK_TUNING
+  if ((px.dbg & 1) && (int)blockIdx.x < st.nchunks) return;
+  if ((px.dbg & 2) && (int)blockIdx.x >= st.nchunks && (int)blockIdx.x - st.nchunks < px.prep_blocks) return;
+  if ((px.dbg & 4) && (int)blockIdx.x - st.nchunks >= px.prep_blocks && (int)blockIdx.x - st.nchunks < px.prep_blocks + ld_blocks(ld)) return;
+#endif
   if ((int)blockIdx.x >= st.nchunks) {
     const int pb = blockIdx.x - st.nchunks;
+    if (pb >= px.prep_blocks + ld_blocks(ld) + ad.blocks) {
+      critic_feed_block(fd, pb - (px.prep_blocks + ld_blocks(ld) + ad.blocks));
+      return;
+    }
     if (pb >= px.prep_blocks + ld_blocks(ld)) {      // u_snap <- u, u <- u_next (nothing else in this launch reads u)
       const int i = (pb - px.prep_blocks - ld_blocks(ld)) * 256 + tid;
       if (i < ad.total) {
@@ -573,7 +586,8 @@ extern "C" long gank_sn_ws_floats(int K, int C) {
 // which = 1: forward A only, 2: forward B only (the power iteration's results are in the table's workspaces already: the fused
 // optimiser tail or a forward-A-only call put them there), 3: both.  adopt (B): see SnAdopt.
 static int sn_forward(const gank_sn_desc* table, int count, const gank_prep_desc* prep, const int* prep_weight, int prep_count,
-                      const gank_label_dense_desc* label, hipStream_t s, int which = 3, const SnAdopt* adopt = nullptr) {
+                      const gank_label_dense_desc* label, hipStream_t s, int which = 3, const SnAdopt* adopt = nullptr,
+                      const CriticFeedArgs* feed = nullptr) {
   GANK_REQUIRE(table && count > 0, "sn fwd: empty table");
   GANK_REQUIRE(prep_count == 0 || (prep && prep_weight), "sn fwd: preparation entries without their weight indices");
   GANK_REQUIRE(count <= SN_MAX || (prep_count == 0 && !label), "sn fwd: the fused preparation takes at most %d weights per call", SN_MAX);
@@ -632,7 +646,10 @@ static int sn_forward(const gank_sn_desc* table, int count, const gank_prep_desc
       ad = *adopt;
       ad.blocks = (ad.total + 255) / 256;
     }
-    hipLaunchKernelGGL(sn_fwd_b_kernel, dim3(fine + px.prep_blocks + label_blocks + ad.blocks), dim3(256), 0, s, st, pt, px, ld, ad);
+    { static const int dbg_ = gank_tune("GANK_SNB_DBG", 0); px.dbg = dbg_; }
+    CriticFeedArgs fd{};
+    if (base == 0 && feed) fd = *feed;
+    hipLaunchKernelGGL(sn_fwd_b_kernel, dim3(fine + px.prep_blocks + label_blocks + ad.blocks + fd.blocks), dim3(256), 0, s, st, pt, px, ld, ad, fd);
     GANK_LAUNCH_OK("sn_power_iter_fwd");
   }
   return 0;
@@ -972,6 +989,20 @@ extern "C" int gank_sn_power_iter_fwd_b_prep(const gank_sn_desc* table, int coun
   SnAdopt ad{};
   ad.u = u_flat; ad.u_snap = u_snap_flat; ad.u_next = u_next_flat; ad.total = u_total;
   return sn_forward(table, count, prep, prep_weight, prep_count, label, (hipStream_t)stream, 2, &ad);
+}
+
+extern "C" int gank_sn_power_iter_fwd_b_prep_feed(const gank_sn_desc* table, int count, const gank_prep_desc* prep, const int* prep_weight,
+                                                  int prep_count, const gank_label_dense_desc* label, float* u_flat, float* u_snap_flat,
+                                                  const float* u_next_flat, int u_total, const gank_critic_feed_desc* feed, void* stream) {
+  GANK_REQUIRE(count <= SN_MAX, "sn fwd b: at most %d weights per call", SN_MAX);
+  GANK_REQUIRE(u_total == 0 || (u_flat && u_next_flat), "sn fwd b: adopting u' needs the flat u and staging buffers");
+  GANK_REQUIRE(feed && feed->real_all && feed->labels_all && feed->fake_all && feed->both && feed->labels2 && feed->slot && feed->rng_state &&
+               feed->done_counter && feed->B > 0 && feed->n_slots > 0, "sn fwd b: bad feed descriptor");
+  SnAdopt ad{};
+  ad.u = u_flat; ad.u_snap = u_snap_flat; ad.u_next = u_next_flat; ad.total = u_total;
+  const CriticFeedArgs fd{feed->real_all, feed->labels_all, (const bf16*)feed->fake_all, (bf16*)feed->both, feed->labels2, feed->slot,
+                          (unsigned long long*)feed->rng_state, feed->done_counter, feed->B, feed->n_slots, critic_feed_blocks(feed->B)};
+  return sn_forward(table, count, prep, prep_weight, prep_count, label, (hipStream_t)stream, 2, &ad, &fd);
 }
 
 extern "C" int gank_sn_power_iter_bwd_gw(const gank_sn_desc* table, int count, void* stream) {

@@ -894,6 +894,9 @@ class SnBatch:
         if st is not None:
             st.valid = b_only and not self.inplace                   # after this pass: u moved on (assigning pass), or nothing changed
         if self.prep is None and self.label is None and not b_only:
+            feed = take_deferred_critic_feed()
+            if feed is not None:
+                critic_feed(*feed)
             _lib.check(lib().gank_sn_power_iter_fwd(self.table, self.n, _stream()), "sn_power_iter_fwd")
             return self.W_bar
         # W / sigma, its bf16 MFMA operand copies and the label table in one launch pair: the operand entries read the
@@ -909,15 +912,22 @@ class SnBatch:
             self.label_out = torch.empty((v, self.KC[wi][1]), dtype=BF16, device=tab.device)
             ldesc = LabelDenseDesc(_p(tab.detach(), F32, "table").value, _p(bias.detach(), F32, "bias").value if bias is not None else None,
                                    self.label_out.data_ptr(), v, dd, wi)
+        feed = take_deferred_critic_feed()
         if b_only:
-            # second launch only; an assigning pass adopts the staged u' (u_snap <- u, u <- u_next: flat copies)
+            # second launch only; an assigning pass adopts the staged u' (u_snap <- u, u <- u_next: flat copies); a deferred
+            # critic feed (defer_critic_feed) rides on the launch as a block range of its own
             adopt = self.inplace
-            _lib.check(lib().gank_sn_power_iter_fwd_b_prep(self.table, self.n, ptable, pw, len(todo), C.byref(ldesc) if ldesc is not None else None,
-                                                           _p(st.u_flat, F32, "u_flat") if adopt else None,
-                                                           _p(self.u_snap, F32, "u_snap") if (adopt and self.u_snap is not None) else None,
-                                                           _p(st.u_next, F32, "u_next") if adopt else None, st.u_flat.numel() if adopt else 0,
-                                                           _stream()), "sn_power_iter_fwd_b_prep")
+            args = (self.table, self.n, ptable, pw, len(todo), C.byref(ldesc) if ldesc is not None else None,
+                    _p(st.u_flat, F32, "u_flat") if adopt else None,
+                    _p(self.u_snap, F32, "u_snap") if (adopt and self.u_snap is not None) else None,
+                    _p(st.u_next, F32, "u_next") if adopt else None, st.u_flat.numel() if adopt else 0)
+            if feed is not None:
+                _lib.check(lib().gank_sn_power_iter_fwd_b_prep_feed(*args, C.byref(_critic_feed_desc(*feed)), _stream()), "sn_power_iter_fwd_b_prep_feed")
+            else:
+                _lib.check(lib().gank_sn_power_iter_fwd_b_prep(*args, _stream()), "sn_power_iter_fwd_b_prep")
         else:
+            if feed is not None:
+                critic_feed(*feed)        # no launch to ride on: the feed's own
             _lib.check(lib().gank_sn_power_iter_fwd_prep(self.table, self.n, ptable, pw, len(todo), C.byref(ldesc) if ldesc is not None else None,
                                                          _stream()), "sn_power_iter_fwd_prep")
         _prep_attach(self.W_bar, kinds, todo, outs)
@@ -1528,6 +1538,37 @@ def dropout_bwd(dy, mask, keep):
     dx = torch.empty_like(dy)
     _lib.check(lib().gank_dropout_bwd(_p(dy, BF16, "dy"), _p(mask, torch.uint8, "mask"), _p(dx), dy.numel(), float(keep), _stream()), "dropout_bwd")
     return dx
+
+
+_deferred_feed = None
+
+
+def defer_critic_feed(*args):
+    """The critic's feed of the update that is about to start (arguments of critic_feed), to be launched by the FIRST spectral-norm
+    forward pass that follows: as a block range of its second launch when that launch runs alone (the power iteration came with
+    the previous optimiser step), else as the feed's own launch in front of it.  The caller checks deferred_critic_feed_pending()
+    after building the forward pass: a pass without a spectral-norm batch would leave the feed unlaunched."""
+    global _deferred_feed
+    assert _deferred_feed is None, "a deferred critic feed is still pending"
+    _deferred_feed = args
+
+
+def take_deferred_critic_feed():
+    global _deferred_feed
+    f, _deferred_feed = _deferred_feed, None
+    return f
+
+
+def deferred_critic_feed_pending():
+    return _deferred_feed is not None
+
+
+def _critic_feed_desc(real_all, labels_all, fake_all, both, labels2, slot, rng_state, done):
+    n_slots, b = labels_all.shape
+    assert both.shape[0] == 2 * b and labels2.numel() == 2 * b and real_all.shape[0] == n_slots and fake_all.shape[0] == n_slots
+    return _lib.CriticFeedDesc(_p(real_all, torch.uint8, "real_all").value, _p(labels_all, I32, "labels_all").value, _p(fake_all, BF16, "fake_all").value,
+                               _p(both, BF16, "both").value, _p(labels2, I32, "labels2").value, _p(slot, I32, "slot").value,
+                               _p(rng_state, torch.int64, "rng_state").value, _p(done, I32, "done").value, b, n_slots)
 
 
 def critic_feed(real_all, labels_all, fake_all, both, labels2, slot, rng_state, done):

@@ -425,6 +425,23 @@ int gank_sn_power_iter_fwd_a(const gank_sn_desc* table, int count, void* stream)
 int gank_sn_power_iter_fwd_b_prep(const gank_sn_desc* table, int count, const gank_prep_desc* prep, const int* prep_weight,
                                   int prep_count, const gank_label_dense_desc* label, float* u_flat, float* u_snap_flat,
                                   const float* u_next_flat, int u_total, void* stream);
+/* gank_sn_power_iter_fwd_b_prep with the critic's input feed of the update (gank_critic_feed below: same arguments, same arithmetic,
+ * same counters) as one more block range of the launch: the feed of a critic update and the second spectral-norm launch of its
+ * forward pass are independent and both precede every layer, so the update starts with one launch instead of two. */
+typedef struct gank_critic_feed_desc {
+  const uint8_t* real_all;     /* as gank_critic_feed */
+  const int32_t* labels_all;
+  const void* fake_all;
+  void* both;
+  int32_t* labels2;
+  int32_t* slot;
+  uint64_t* rng_state;
+  uint32_t* done_counter;
+  int B, n_slots;
+} gank_critic_feed_desc;
+int gank_sn_power_iter_fwd_b_prep_feed(const gank_sn_desc* table, int count, const gank_prep_desc* prep, const int* prep_weight,
+                                       int prep_count, const gank_label_dense_desc* label, float* u_flat, float* u_snap_flat,
+                                       const float* u_next_flat, int u_total, const gank_critic_feed_desc* feed, void* stream);
 int gank_sn_power_iter_bwd_gw(const gank_sn_desc* table, int count, void* stream);
 int gank_sn_adam_fwd_a(const gank_sn_desc* table, int count, float* const* u_next, float* p, float* g, float* m, float* v, long n,
                        float* hp, int64_t* t_state, const int64_t* iteration, uint64_t* health, int flags, int64_t* bump,

@@ -666,6 +666,65 @@ def test_critic_feed_matches_separate_launches(K):
         assert int(slot) == (i + 1) % slots and int(done) == 0 and torch.equal(rng_a, rng_b)
 
 
+def test_critic_feed_as_a_block_range_of_the_second_spectral_norm_launch(K):
+    """gank_sn_power_iter_fwd_b_prep_feed: a deferred critic feed (K.defer_critic_feed) is launched by the next spectral-norm forward
+    pass -- inside its second launch when the power iteration has been run already (valid persistent state), as the feed's own
+    launch otherwise.  Either way the feed's outputs and counters and the pass's normalised weights, operand copies and u equal
+    the two separate launches bit for bit, and the ring walks on."""
+    g = torch.Generator(device="cpu").manual_seed(4)
+    b, slots = 64, 3
+    real_all = torch.randint(0, 256, (slots, b, 3072), generator=g, dtype=torch.uint8).cuda()
+    labels_all = torch.randint(0, 10, (slots, b), generator=g, dtype=torch.int32).cuda()
+    fake_all = torch.randn((slots, b, 3072), generator=g).to(torch.bfloat16).cuda()
+    shapes = [(3, 3, 3, 128), (3, 3, 128, 128), (300, 128), (1, 1, 256, 128), (128, 1)]
+    kinds = [0, 4, None, 0, None]
+
+    def build():
+        gg = torch.Generator(device="cpu").manual_seed(8)
+        Ws = [(torch.randn(sh, generator=gg) * 0.05).cuda() for sh in shapes]
+        u_flat = torch.randn(sum(sh[-1] for sh in shapes), generator=gg).cuda()
+        us, o = [], 0
+        for sh in shapes:
+            us.append(u_flat[o:o + sh[-1]].view(1, sh[-1]))
+            o += sh[-1]
+        return dict(Ws=Ws, us=us, u_flat=u_flat, st=K.SnState(Ws, us, u_flat), both=torch.zeros((2 * b, 3072), dtype=torch.bfloat16, device="cuda"),
+                    labels2=torch.zeros(2 * b, dtype=torch.int32, device="cuda"), slot=torch.zeros(1, dtype=torch.int32, device="cuda"),
+                    done=torch.zeros(1, dtype=torch.int32, device="cuda"), rng=K.new_rng_state(7, "cuda"))
+
+    A, B = build(), build()
+    for step in range(slots + 1):
+        valid = step != 1                     # step 1: no power iteration in hand -> the feed's own launch in front of the two-launch pass
+        outs = []
+        for d, fused in ((A, False), (B, True)):
+            if valid:
+                d["st"].refresh()
+            else:
+                d["st"].valid = False
+            feed = (real_all, labels_all, fake_all, d["both"], d["labels2"], d["slot"], d["rng"], d["done"])
+            batch = K.SnBatch(d["Ws"], d["us"], snapshot=True, inplace=True, state=d["st"])
+            batch.prep = (kinds, True)
+            if fused:
+                K.defer_critic_feed(*feed)
+                assert K.deferred_critic_feed_pending()
+            else:
+                K.critic_feed(*feed)
+            outs.append(batch.forward())
+            assert not K.deferred_critic_feed_pending()
+        torch.cuda.synchronize()
+        i = step % slots
+        for key in ("both", "labels2", "slot", "done", "rng", "u_flat"):
+            assert torch.equal(A[key], B[key]), (step, key)
+        assert torch.equal(B["both"][b:].view(torch.int16), fake_all[i].reshape(b, 3072).view(torch.int16)) and int(B["slot"]) == (i + 1) % slots and int(B["done"]) == 0
+        for x, y in zip(*outs):
+            assert torch.equal(x, y)
+            for attr in ("_prep", "_prep_res"):
+                pa, pb = getattr(x, attr, None), getattr(y, attr, None)
+                assert (pa is None) == (pb is None)
+                if pa is not None:
+                    for u, v in zip(pa, pb):
+                        assert (u is None) == (v is None) and (u is None or torch.equal(u.view(torch.int16), v.view(torch.int16)))
+
+
 def test_batch_norm_op_and_get_loss(K):
     """a4' / a15 of the scope table: tf.contrib batch_norm in train mode (normalization.py:8-24) with its moving
     statistics, and common/misc.py get_loss('HINGE'), through the reference-shaped ops."""
