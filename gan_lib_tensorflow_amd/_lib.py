@@ -150,6 +150,8 @@ PROTOTYPES = {
     "gank_cbn_stats_from_sums": [P, P, P, I, I, L, F, P],
     "gank_cbn_relu_conv3x3_fprop": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P],
     "gank_cbn_bwd_remask": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "gank_cbn_bwd_ws_floats": [I, I, I, I],
+    "gank_cbn_bwd_ws": [P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, P],
     "gank_pool2x2": [P, P, P, I, I, I, I, F, P],
     "gank_unpool2x2_add": [P, P, P, I, I, I, I, F, P],
     "gank_add_bf16": [P, P, P, L, P],
@@ -213,7 +215,7 @@ PROTOTYPES = {
     "gank_critic_feed": [P, P, P, P, P, P, P, P, I, I, P],
     "gank_debug_tr_probe": [P, P],
 }
-_RET = {"gank_last_error": C.c_char_p, "gank_sn_ws_floats": C.c_long, "gank_conv2d_wgrad_ws_elems": C.c_long, "gank_convpool3x3_wgrad_ws_elems": C.c_long, "gank_upconv3x3_wgrad_ws_elems": C.c_long, "gank_conv2d_wgrad_batched_ws_elems": C.c_long, "gank_conv2d_wgrad_slab_elems": C.c_long, "gank_prof_calibrate": C.c_double, "gank_prof_bytes": C.c_double}
+_RET = {"gank_last_error": C.c_char_p, "gank_sn_ws_floats": C.c_long, "gank_cbn_bwd_ws_floats": C.c_long, "gank_conv2d_wgrad_ws_elems": C.c_long, "gank_convpool3x3_wgrad_ws_elems": C.c_long, "gank_upconv3x3_wgrad_ws_elems": C.c_long, "gank_conv2d_wgrad_batched_ws_elems": C.c_long, "gank_conv2d_wgrad_slab_elems": C.c_long, "gank_prof_calibrate": C.c_double, "gank_prof_bytes": C.c_double}
 
 _lib = None
 

@@ -2,6 +2,7 @@
 //   moments over (N/groups, H, W) per tower, biased (tf.nn.moments): ONE pass of shifted sums per part
 //   + a deterministic Chan merge of the parts, eps = 1e-5; y = (x-mean)*invstd*gamma[label] + beta[label]; optional fused relu.
 // x is [N, HW, C] bf16 with C % 8 == 0: every lane moves 16 B; thread = (8-channel group, row lane).
+#include <atomic>
 #include "gank_common.h"
 
 #define BN_EPS 1e-5f
@@ -265,7 +266,8 @@ extern "C" int gank_cbn_fwd(const void* x, const int32_t* labels, const float* g
 // four accesses of the apply pass) less.
 __global__ void cbn_bwd_sums_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, const bf16* __restrict__ y,
                                     const float* __restrict__ stats, float* __restrict__ S, CbnGeom q, int hw_parts,
-                                    const int* __restrict__ labels, const float* __restrict__ gamma, const float* __restrict__ beta) {
+                                    const int* __restrict__ labels, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    float* __restrict__ Sp, unsigned* __restrict__ tickets) {
   const int cg = q.C >> 3, RL = 256 / cg;
   const int g = threadIdx.x % cg, rl = threadIdx.x / cg;
   const int n = blockIdx.x / hw_parts, hp = blockIdx.x % hw_parts;
@@ -318,9 +320,40 @@ __global__ void cbn_bwd_sums_kernel(const bf16* __restrict__ dy, const bf16* __r
     if (hw_parts == 1) {
       S[((long)n * 2) * q.C + c] = t1;
       S[((long)n * 2 + 1) * q.C + c] = t2;
+    } else if (Sp) {            // rows of this part's own, written through to memory (visible to every XCD once vmcnt has drained)
+      __hip_atomic_store(Sp + (((long)hp * q.N + n) * 2) * q.C + c, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(Sp + (((long)hp * q.N + n) * 2 + 1) * q.C + c, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       atomicAdd(S + ((long)n * 2) * q.C + c, t1);
       atomicAdd(S + ((long)n * 2 + 1) * q.C + c, t2);
+    }
+  }
+  if (hw_parts > 1 && Sp) {
+    // the last part of sample n to arrive adds the parts' rows in ascending order (the same bits every run): no fill launch, no
+    // atomics on the sums (idiom of sn.hip: write-through stores, drained; one ticket per block; one acquire by the last arriver)
+    __shared__ int last_flag;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned tk = __hip_atomic_fetch_add(tickets + n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = tk == (unsigned)(hw_parts - 1);
+      if (last) {
+        __hip_atomic_store(tickets + n, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // zero again for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      last_flag = last;
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    for (int i = threadIdx.x; i < 2 * q.C; i += 256) {
+      float v[8];
+#pragma unroll
+      for (int p = 0; p < 8; p++) v[p] = p < hw_parts ? Sp[((long)p * q.N + n) * 2 * q.C + i] : 0.f;
+      float t = v[0];
+#pragma unroll
+      for (int p = 1; p < 8; p++) t += p < hw_parts ? v[p] : 0.f;
+      S[(long)n * 2 * q.C + i] = t;
     }
   }
 }
@@ -462,23 +495,49 @@ __global__ void cbn_bwd_apply_kernel(const bf16* __restrict__ dy, const bf16* __
   }
 }
 
+static int cbn_bwd_parts(int HW) {
+  int hw_parts = HW / 64;
+  return hw_parts < 1 ? 1 : (hw_parts > 8 ? 8 : hw_parts);
+}
+// ws_floats: what the caller's workspace holds.  N*2*C + groups*2*C (the contract of gank_cbn_bwd / _remask): the pixel parts of a
+// sample meet by fp32 atomics in a zero-filled buffer; gank_cbn_bwd_ws_floats(): every part writes rows of its own and the last
+// part of a sample to finish adds them in a fixed order -- no fill launch, no atomics on the sums (in a train step they cost ~3x
+// their micro-benchmark price), the same bits every run.  (Adding the parts inside the table launch instead -- 8x its loads on a
+// 44-block grid -- cost 20 us per call.)  Ticket words: self-resetting, a group per call in rotation (calls on one stream follow
+// each other; N <= CBN_TICKETS).
+constexpr int CBN_TICKETS = 4096, CBN_TICKET_GROUPS = 8;
+__device__ unsigned cbn_tickets[CBN_TICKETS * CBN_TICKET_GROUPS];
 static int cbn_bwd_impl(const void* dy, const void* x, const void* y, const float* beta, const int32_t* labels, const float* gamma,
                         const float* stats, void* dx, float* dgamma, float* dbeta, float* ws, int N, int HW, int C,
-                        int groups, int n_labels, int relu, void* stream) {
+                        int groups, int n_labels, int relu, void* stream, long ws_floats = 0) {
   GANK_REQUIRE(dy && x && labels && gamma && stats && dx && dgamma && dbeta && ws, "cbn_bwd: null pointer");
   GANK_REQUIRE(!relu || y || beta, "cbn_bwd: relu backward needs y or beta");
   CbnGeom q;
   if (cbn_geom(q, N, HW, C, groups, n_labels, relu)) return 1;
   hipStream_t s = (hipStream_t)stream;
-  float* S = ws;                       // [N][2][C]
-  float* M = ws + (long)N * 2 * C;     // [groups][2][C]
-  int hw_parts = HW / 64;
-  if (hw_parts < 1) hw_parts = 1;
-  if (hw_parts > 8) hw_parts = 8;
+  const int hw_parts = cbn_bwd_parts(HW);
+  const bool slab = hw_parts > 1 && N <= CBN_TICKETS && ws_floats >= (long)(hw_parts + 1) * N * 2 * C + (long)groups * 2 * C;
+  float* S = ws;                                       // [N][2][C]
+  float* M = ws + (long)N * 2 * C;                     // [groups][2][C]
+  float* Sp = slab ? M + (long)groups * 2 * C : nullptr;      // [hw_parts][N][2][C]
+  unsigned* tickets = nullptr;
+  if (slab) {
+    static std::atomic<unsigned*> ticket_addr[64];     // per device, looked up once (the first call of a process is an eager one)
+    static std::atomic<unsigned> ticket_group{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    unsigned* base = ticket_addr[dev & 63].load(std::memory_order_relaxed);
+    if (!base) {
+      if (hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(cbn_tickets)) != hipSuccess || !base) return gank_set_error("cbn_bwd: ticket words not found");
+      ticket_addr[dev & 63].store(base, std::memory_order_relaxed);
+    }
+    tickets = base + (ticket_group.fetch_add(1, std::memory_order_relaxed) % CBN_TICKET_GROUPS) * CBN_TICKETS;
+  }
   // zeroed by a kernel, not hipMemsetAsync: inside a captured hipGraph the memset node was observed to race with
   // its kernel neighbours (intermittent NaN generator gradients under graph replay, never in eager mode)
-  if (hw_parts > 1) hipLaunchKernelGGL(cbn_zero_kernel, dim3(cdiv(N * 2 * C / 4, 256)), dim3(256), 0, s, S, N * 2 * C / 4);
-  hipLaunchKernelGGL(cbn_bwd_sums_kernel, dim3(N * hw_parts), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (const bf16*)y, stats, S, q, hw_parts, labels, gamma, beta);
+  if (hw_parts > 1 && !slab) hipLaunchKernelGGL(cbn_zero_kernel, dim3(cdiv(N * 2 * C / 4, 256)), dim3(256), 0, s, S, N * 2 * C / 4);
+  hipLaunchKernelGGL(cbn_bwd_sums_kernel, dim3(N * hw_parts), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (const bf16*)y, stats, S, q, hw_parts, labels, gamma, beta,
+                     Sp, tickets);
   hipLaunchKernelGGL(cbn_bwd_tables_kernel, dim3(cdiv(C, 64), n_labels + 1), dim3(256), 0, s, S, labels, gamma, dgamma, dbeta, M, q);
   const long total8 = (long)N * HW * (C / 8);
   long blocks = (total8 + 255) / 256;
@@ -499,6 +558,19 @@ extern "C" int gank_cbn_bwd_remask(const void* dy, const void* x, const float* b
                                    int groups, int n_labels, int relu, void* stream) {
   GANK_REQUIRE(!relu || beta, "cbn_bwd_remask: relu backward needs beta");
   return cbn_bwd_impl(dy, x, nullptr, beta, labels, gamma, stats, dx, dgamma, dbeta, ws, N, HW, C, groups, n_labels, relu, stream);
+}
+
+extern "C" long gank_cbn_bwd_ws_floats(int N, int HW, int C, int groups) {
+  const int parts = cbn_bwd_parts(HW);
+  return (long)(parts > 1 ? parts + 1 : 1) * N * 2 * C + (long)groups * 2 * C;
+}
+// either mask form (y, or beta with y = NULL) on a workspace of ws_floats floats
+extern "C" int gank_cbn_bwd_ws(const void* dy, const void* x, const void* y, const float* beta, const int32_t* labels, const float* gamma,
+                               const float* stats, void* dx, float* dgamma, float* dbeta, float* ws, long ws_floats, int N, int HW, int C,
+                               int groups, int n_labels, int relu, void* stream) {
+  GANK_REQUIRE(ws_floats >= (long)N * 2 * C + (long)groups * 2 * C, "cbn_bwd_ws: workspace of %ld floats, need at least %ld", ws_floats,
+               (long)N * 2 * C + (long)groups * 2 * C);
+  return cbn_bwd_impl(dy, x, beta ? nullptr : y, beta, labels, gamma, stats, dx, dgamma, dbeta, ws, N, HW, C, groups, n_labels, relu, stream, ws_floats);
 }
 
 // (mean, invstd) per tower and channel from the sums a conv epilogue accumulated (gank_conv2d_fprop_stats): what

@@ -1065,11 +1065,23 @@ def pixel_norm_bwd(dy, x, eps=1e-8):
     return dx
 
 
+CBN_BWD_PART_ROWS = True
+
+
 def cbn_bwd(dy, x, y, labels, gamma, stats, dgamma, dbeta, groups=1, relu=False, beta=None):
     """beta given (and relu): the mask is recomputed from x, gamma, beta and the statistics instead of read from y"""
     n, c = x.shape[0], x.shape[-1]
     hw = x.numel() // (n * c)
     dx = torch.empty_like(x)
+    # the larger workspace: per-part rows instead of a fill launch + fp32 atomics (CBN_BWD_PART_ROWS = False: the two older entries)
+    if CBN_BWD_PART_ROWS:
+        nws = int(lib().gank_cbn_bwd_ws_floats(n, hw, c, groups))
+        ws = torch.empty(nws, dtype=F32, device=x.device)
+        remask = beta is not None and relu
+        _lib.check(lib().gank_cbn_bwd_ws(_p(dy, BF16, "dy"), _p(x, BF16, "x"), None if remask else _p(y, BF16, "y"), _p(beta, F32, "beta") if remask else None,
+                                         _p(labels, I32, "labels"), _p(gamma, F32, "gamma"), _p(stats, F32), _p(dx), _p(dgamma, F32, "dgamma"),
+                                         _p(dbeta, F32, "dbeta"), _p(ws), nws, n, hw, c, groups, gamma.shape[0], int(relu), _stream()), "cbn_bwd_ws")
+        return dx
     ws = torch.empty(n * 2 * c + groups * 2 * c, dtype=F32, device=x.device)
     if beta is not None and relu:
         _lib.check(lib().gank_cbn_bwd_remask(_p(dy, BF16, "dy"), _p(x, BF16, "x"), _p(beta, F32, "beta"), _p(labels, I32, "labels"),

@@ -486,6 +486,14 @@ int gank_cbn_bwd(const void* dy, const void* x, const void* y, const int32_t* la
 int gank_cbn_bwd_remask(const void* dy, const void* x, const float* beta, const int32_t* labels, const float* gamma,
                         const float* stats, void* dx, float* dgamma, float* dbeta, float* ws, int N, int HW, int C,
                         int groups, int n_labels, int relu, void* stream);
+/* Both forms on a workspace whose size the caller states (y, or beta with the mask recomputed and y ignored).  With
+ * gank_cbn_bwd_ws_floats(N, HW, C, groups) floats the partial sums of a sample's pixel parts go to rows of their own and the last
+ * part of the sample to finish adds them in a fixed order: no fill launch, no fp32 atomics on the sums, the same bits every run.  With the smaller workspace of
+ * the two entries above (N*2*C + groups*2*C floats) it behaves as they do. */
+long gank_cbn_bwd_ws_floats(int N, int HW, int C, int groups);
+int gank_cbn_bwd_ws(const void* dy, const void* x, const void* y, const float* beta, const int32_t* labels, const float* gamma,
+                    const float* stats, void* dx, float* dgamma, float* dbeta, float* ws, long ws_floats, int N, int HW, int C,
+                    int groups, int n_labels, int relu, void* stream);
 
 /* ---- resampling / elementwise glue of the block library ------------------------------------------
  * pool2x2: y = scale * (sum of the 2x2 window) (+ residual)   -- tf.add_n(...)/4. at
