@@ -30,6 +30,25 @@ def polynomial_decay(step, lr0=0.0004, decay_steps=50000, lr_end=0.0002):
     return (lr0 - lr_end) * (1.0 - s / float(decay_steps)) + lr_end
 
 
+BATCHED_PREP = True     # operand copies of the weights: one launch per network and update (False: per conv and layout on first use)
+
+
+def _g_prep_kind(name, W):
+    """operand layout per generator weight (kernels.prep_weights_batched), by the kernel its conv wrapper picks: the UpsampleConv
+    3x3 layers run phase-decomposed, the 16x16 conv of G.2 on the image-resident kernel where its shape allows; a wrapper that
+    wants another layout than the one attached prepares its own."""
+    if W.dim() != 4:
+        return None
+    # (the same choices as the SNGAN generator's, whose blocks these are: SNGAN/gan_cifar_resnet.py _g_prep_kind)
+    if Fn.RES8_CONV and name.endswith(('G.1.Conv1/Filters', 'G.1.Conv2/Filters')) and W.shape[0] == 3 and W.shape[2] in (128, 256) and W.shape[3] % 128 == 0:
+        return 4                      # 8x8 images: LDS-resident kernel, fragment-major operands
+    if Fn.PHASE_UPCONV and name.endswith('.Conv1/Filters') and W.shape[0] == 3:
+        return 1
+    if Fn.IMG16_CONV and name.endswith('G.2.Conv2/Filters') and W.shape[0] == 3 and W.shape[2] % 128 == 0 and W.shape[3] % 128 == 0:
+        return 4                      # 16x16 image-resident conv
+    return 0
+
+
 class ACGANTrainer:
     def __init__(self, batch_size=64, z_dim=128, acgan_scale_G=0.1, n_dis=5, max_iter=100000, device="cuda", seed=0,
                  process_group=None, state=None, use_graphs=True, allow_eager_fallback=False):
@@ -61,6 +80,8 @@ class ACGANTrainer:
             del p.main_grad
         self.g_opt = self._adam(self.g_flat)
         self.d_opt = self._adam(self.d_flat)
+        self._g_convs = [(k, v) for k, v in self.store.vars.items() if k.startswith('g_net/') and k.endswith('/Filters') and v.dim() == 4]
+        self._refresh_g_prep()
         self.losses = {}
         # the two updates as captured hipGraphs (gan_lib_tensorflow_amd/graphs.py): static input buffers, the learning rate
         # written into the optimiser's device-side hyper-parameters outside the captured region
@@ -79,6 +100,15 @@ class ACGANTrainer:
     def _apply(self, opt):
         f = opt['flat']
         K.adam_tf(f['params'], f['grads'], f['m'], f['v'], opt['hp'], opt['t'], None)
+        if opt is self.g_opt:
+            self._refresh_g_prep()
+
+    def _refresh_g_prep(self):
+        """The generator's MFMA operand copies, once per generator update in ONE launch (every pass until the next update -- the
+        fakes of the critic updates, the generator's own forward / backward -- picks them up from the variables) instead of one
+        or two launches per conv and pass."""
+        if BATCHED_PREP and self._g_convs:
+            K.prep_weights_batched([v for _, v in self._g_convs], want_d=True, kinds=[_g_prep_kind(k, v) for k, v in self._g_convs])
 
     def _update(self, key, fwd_bwd, opt):
         """fwd_bwd (graph) -> [RCCL all-reduce] -> Adam (graph): one graph when there is nothing to exchange"""
@@ -141,6 +171,8 @@ class ACGANTrainer:
     # ---- updates --------------------------------------------------------------------------------------------------
     def _d_fwd_bwd(self):
         with F2.one_update():            # every pass over the critic in this update shares one preparation of its weights
+            if BATCHED_PREP:
+                F2.prepare_batched(self.d_params)
             real = K.preprocess_real(self.real_u8, self.rng_state)         # [B, 32, 32, 3] bf16   (train.py:80-83)
             K.zero_(self.d_flat['grads'])
             loss = self.d_loss(real, self.real_labels)
@@ -149,6 +181,8 @@ class ACGANTrainer:
 
     def _g_fwd_bwd(self):
         with F2.one_update():
+            if BATCHED_PREP:
+                F2.prepare_batched(self.d_params)
             self.store.zero_grads('g_net')
             loss = self.g_loss()
             loss.backward(gradient=Fn.unit_seed(loss))

@@ -68,6 +68,23 @@ def _prepared(W, want_f):
     return hit[1]
 
 
+def prepare_batched(ws):
+    """Inside `with one_update():` -- both operand layouts of every 4-D leaf weight of `ws` in ONE launch
+    (kernels.prep_weights_batched, the layouts of K.prep_weights bit for bit) instead of one launch per weight and layout on
+    first use: a critic update held 22 such launches.  The buffers persist on the tensors (`w._prep`, rewritten in place by
+    later calls: captured graphs keep reading the same addresses); the cache entries live until the block ends."""
+    if not _prep_cache_on[0]:
+        return
+    ws = [w for w in ws if w.is_leaf and w.dim() == 4 and w.is_cuda and w.dtype == torch.float32]
+    if not ws:
+        return
+    K.prep_weights_batched(ws, want_d=True)
+    for w in ws:
+        wf, wd = w._prep
+        _prep_cache[(id(w), True)] = (w, wf)
+        _prep_cache[(id(w), False)] = (w, wd)
+
+
 def _wf(W):
     return _prepared(W, True)
 
