@@ -52,6 +52,7 @@ ACGAN = False
 VOCAB_SIZE = 10
 EMBEDDING_DIM = 300
 LOSS_TYPE = 'HINGE'
+SOFT_PLUS = False        # (:63) the softplus-wrapped variants of the three losses (:364-386, :483-497)
 N_TOWERS = 2  # len(DEVICES) after the single-GPU hack (:73-75)
 
 nonlinearity = blocks.nonlinearity
@@ -284,7 +285,7 @@ class SNGANTrainer:
     losses, :436,:498)."""
 
     def __init__(self, batch_size=BATCH_SIZE, device="cuda", seed=0, use_graphs=True, process_group=None, state=None,
-                 allow_eager_fallback=False, capture_collectives=None, grad_wire_dtype=None, loss_scale=None, loss_type=None):
+                 allow_eager_fallback=False, capture_collectives=None, grad_wire_dtype=None, loss_scale=None, loss_type=None, soft_plus=None):
         """allow_eager_fallback: a failed hipGraph capture degrades to eager execution (with a message on stderr) instead of
         raising -- a run that asked for graphs never silently becomes a 10x slower eager run otherwise.
         capture_collectives: under data parallel the RCCL all-reduces are captured INSIDE the update graphs (one graph per
@@ -304,6 +305,9 @@ class SNGANTrainer:
         # mean(log(1 - sigmoid(fake))); generator -mean(log sigmoid(fake)): :363-369, :483-486), 'WGAN' (mean(fake) - mean(real);
         # generator -mean(fake): :382-387, :493-497)
         self.loss_type = LOSS_TYPE if loss_type is None else loss_type
+        # SOFT_PLUS (:63): critic -softplus(log sigmoid(real)) - softplus(log(1 - sigmoid(fake))) | softplus(-min(0, -1 + real)) +
+        # softplus(-min(0, -1 - fake)) | softplus(fake) + softplus(-real); generator softplus(-log sigmoid(fake)) | softplus(-fake) (both)
+        self.soft_plus = SOFT_PLUS if soft_plus is None else bool(soft_plus)
         if self.loss_type not in ('HINGE', 'Goodfellow', 'WGAN'):
             raise NotImplementedError("LOSS_TYPE %r (gan_cifar_resnet.py:62 knows 'Goodfellow', 'HINGE', 'WGAN'; 'WGAN-GP' has no branch in the script)" % (self.loss_type,))
         self.batch = batch_size
@@ -476,11 +480,14 @@ class SNGANTrainer:
     # ---- the losses of the script's LOSS_TYPE switch ----------------------------------------------------------
     def _critic_loss(self, both, both_labels, n_real):
         """-> (loss, logits): disc_cost on concat(real, fake) with update_collection=None"""
-        if self.loss_type == 'HINGE' and FUSED_HEAD:
+        if self.loss_type == 'HINGE' and FUSED_HEAD and not self.soft_plus:
             loss, _ = Discriminator(both, both_labels, update_collection=None,
                                     loss_head=Fn.HingeHeadSpec(0, n_real, out=self.d_loss, loss_scale=self.loss_scale))
             return loss, loss.logits
         logits, _ = Discriminator(both, both_labels, update_collection=None)
+        if self.soft_plus:               # (:366-367, :372-373, :383-385; softplus(fake) + softplus(-real) IS the sigmoid cross-entropy)
+            kind = {'Goodfellow': 5, 'HINGE': 7, 'WGAN': 2}[self.loss_type]
+            return Fn.gan_pointwise_loss(logits, n_real, kind, out=self.d_loss), logits
         if self.loss_type == 'HINGE':
             return Fn.hinge_d_loss(logits, n_real, out=self.d_loss), logits
         if self.loss_type == 'WGAN':
@@ -489,11 +496,13 @@ class SNGANTrainer:
 
     def _generator_loss(self, fake, fake_labels):
         """-> (loss, logits): gen_cost, critic with update_collection=NO_OPS"""
-        if self.loss_type == 'HINGE' and FUSED_HEAD:
+        if self.loss_type == 'HINGE' and FUSED_HEAD and not self.soft_plus:
             loss, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS,
                                     loss_head=Fn.HingeHeadSpec(1, 0, out=self.g_loss, loss_scale=self.loss_scale))
             return loss, loss.logits
         logits, _ = Discriminator(fake, fake_labels, update_collection=NO_OPS)
+        if self.soft_plus:               # (:484, :489-490, :494-495)
+            return Fn.gan_pointwise_loss(logits, 0, 6 if self.loss_type == 'Goodfellow' else 3, out=self.g_loss), logits
         if self.loss_type in ('HINGE', 'WGAN'):
             return Fn.hinge_g_loss(logits, out=self.g_loss), logits                         # -mean(disc_fake) in both branches
         return Fn.gan_pointwise_loss(logits, 0, 3, out=self.g_loss), logits                 # Goodfellow: -mean(log sigmoid(disc_fake))

@@ -109,8 +109,17 @@ __global__ void gan_pointwise_loss_kernel(const bf16* __restrict__ l, float* __r
       else { t = gank_softplus(v) / (float)n_fake; d = gank_sigmoid(v) / (float)n_fake; }
     } else if (kind == 3) {
       t = gank_softplus(-v) / (float)n; d = -gank_sigmoid(-v) / (float)n;
-    } else {
+    } else if (kind == 4) {
       t = -gank_softplus(v) / (float)n; d = -gank_sigmoid(v) / (float)n;
+    } else if (kind == 5) {            // SOFT_PLUS 'Goodfellow' critic: -softplus(log sigmoid(real)), -softplus(log(1 - sigmoid(fake)))
+      if (i < n_real) { const float u = -gank_softplus(-v); t = -gank_softplus(u) / (float)n_real; d = -gank_sigmoid(u) * gank_sigmoid(-v) / (float)n_real; }
+      else { const float u = -gank_softplus(v); t = -gank_softplus(u) / (float)n_fake; d = gank_sigmoid(u) * gank_sigmoid(v) / (float)n_fake; }
+    } else if (kind == 6) {            // SOFT_PLUS 'Goodfellow' generator: softplus(-log sigmoid(fake))
+      const float u = gank_softplus(-v);
+      t = gank_softplus(u) / (float)n; d = -gank_sigmoid(u) * gank_sigmoid(-v) / (float)n;
+    } else {                           // kind 7, SOFT_PLUS 'HINGE' critic: softplus(-min(0, -1 + real)), softplus(-min(0, -1 - fake))
+      if (i < n_real) { const float m = fminf(0.f, v - 1.f); t = gank_softplus(-m) / (float)n_real; d = v < 1.f ? -gank_sigmoid(-m) / (float)n_real : 0.f; }
+      else { const float m = fminf(0.f, -1.f - v); t = gank_softplus(-m) / (float)n_fake; d = v > -1.f ? gank_sigmoid(-m) / (float)n_fake : 0.f; }
     }
     acc += t;
     dl[i] = f2bf(d);
@@ -120,8 +129,8 @@ __global__ void gan_pointwise_loss_kernel(const bf16* __restrict__ l, float* __r
   if (threadIdx.x == 0) loss[0] = tot;
 }
 extern "C" int gank_gan_pointwise_loss(const void* logits, float* loss, void* dlogits, float* dlogits_f32, int n, int n_real, int kind, void* stream) {
-  GANK_REQUIRE(logits && loss && dlogits && n > 0 && kind >= 0 && kind <= 4, "gan_pointwise_loss: bad arguments");
-  GANK_REQUIRE((kind != 0 && kind != 2) || (n_real > 0 && n_real < n), "gan_pointwise_loss: a critic loss needs 0 < n_real < n");
+  GANK_REQUIRE(logits && loss && dlogits && n > 0 && kind >= 0 && kind <= 7, "gan_pointwise_loss: bad arguments");
+  GANK_REQUIRE((kind != 0 && kind != 2 && kind != 5 && kind != 7) || (n_real > 0 && n_real < n), "gan_pointwise_loss: a critic loss needs 0 < n_real < n");
   hipLaunchKernelGGL(gan_pointwise_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, loss, (bf16*)dlogits, dlogits_f32, n, n_real, kind);
   GANK_LAUNCH_OK("gan_pointwise_loss");
   return 0;

@@ -1311,7 +1311,8 @@ def wgan_d_loss(logits, n_real, loss=None):
 
 
 def gan_pointwise_loss(logits, n_real, kind, loss=None):
-    """kind 0 LSGAN critic | 1 LSGAN generator | 2 sigmoid-xent critic | 3 -log sigmoid generator | 4 MiniMax generator
+    """kind 0 LSGAN critic | 1 LSGAN generator | 2 sigmoid-xent critic | 3 -log sigmoid generator | 4 MiniMax generator |
+    5 / 6 / 7 the SOFT_PLUS 'Goodfellow' critic / generator and 'HINGE' critic of SNGAN/gan_cifar_resnet.py:364-386
     (gank_gan_pointwise_loss) -> (loss fp32[1], dlogits bf16, dlogits fp32)"""
     loss = torch.empty(1, dtype=F32, device=logits.device) if loss is None else loss
     dl = torch.empty_like(logits)

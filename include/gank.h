@@ -601,7 +601,11 @@ int gank_critic_head_hinge_scaled(const void* x, const float* w, const float* b,
                                   float* b_grad, int M, int K, int n_real, int mode, float loss_scale, void* stream);
 /* the other branches of get_loss (common/misc.py:353-394), same conventions (critic kinds: the first n_real logits are real):
  * kind 0 LSGAN critic, 1 LSGAN generator, 2 sigmoid-cross-entropy critic (CGAN / Modified_MiniMax / MiniMax), 3 its
- * non-saturating generator (-log sigmoid(fake): CGAN, Modified_MiniMax), 4 the MiniMax generator (log(1 - sigmoid(fake))). */
+ * non-saturating generator (-log sigmoid(fake): CGAN, Modified_MiniMax), 4 the MiniMax generator (log(1 - sigmoid(fake))).
+ * The SOFT_PLUS = True branches of SNGAN/gan_cifar_resnet.py:364-386,483-497: kind 5 'Goodfellow' critic (-softplus(log sigmoid(real)) -
+ * softplus(log(1 - sigmoid(fake)))), 6 its generator (softplus(-log sigmoid(fake))), 7 'HINGE' critic (softplus(-min(0, -1 + real)) +
+ * softplus(-min(0, -1 - fake)); tf.minimum passes the gradient where the second argument is strictly smaller); the 'WGAN' critic
+ * with SOFT_PLUS is kind 2 and both remaining generators (softplus(-fake)) are kind 3. */
 int gank_gan_pointwise_loss(const void* logits, float* loss, void* dlogits, float* dlogits_f32, int n, int n_real, int kind, void* stream);
 int gank_hinge_d_loss(const void* logits, float* loss, void* dlogits, float* dlogits_f32, int n, int n_real, void* stream);
 int gank_hinge_g_loss(const void* logits, float* loss, void* dlogits, float* dlogits_f32, int n, void* stream);

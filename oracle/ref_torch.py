@@ -331,6 +331,37 @@ def g_loss_fn(P, z, fake_labels, towers=2):
     return -logits.mean(), logits
 
 
+def sngan_losses(logits_d, b, logits_g=None, loss_type='HINGE', soft_plus=False):
+    """The LOSS_TYPE / SOFT_PLUS switch of gan_cifar_resnet.py:364-386 (critic: logits_d = concat(real [b], fake)) and :483-497
+    (generator: logits_g), expression for expression.  -> (disc_cost | None, gen_cost | None)"""
+    import torch.nn.functional as F
+    sp = F.softplus
+    d = g = None
+    if logits_d is not None:
+        real, fake = logits_d[:b], logits_d[b:]
+        if loss_type == 'Goodfellow':
+            if soft_plus:
+                d = -sp(torch.log(torch.sigmoid(real))).mean() - sp(torch.log(1 - torch.sigmoid(fake))).mean()
+            else:
+                d = -torch.log(torch.sigmoid(real)).mean() - torch.log(1 - torch.sigmoid(fake)).mean()
+        elif loss_type == 'HINGE':
+            if soft_plus:
+                zero = torch.zeros((), dtype=real.dtype)
+                d = sp(-torch.minimum(zero, -1 + real)).mean() + sp(-torch.minimum(zero, -1 - fake)).mean()
+            else:
+                d = torch.relu(1. - real).mean() + torch.relu(1. + fake).mean()
+        elif loss_type == 'WGAN':
+            d = (sp(fake).mean() + sp(-real).mean()) if soft_plus else (fake.mean() - real.mean())
+        else:
+            raise ValueError(loss_type)
+    if logits_g is not None:
+        if loss_type == 'Goodfellow':
+            g = sp(-torch.log(torch.sigmoid(logits_g))).mean() if soft_plus else -torch.log(torch.sigmoid(logits_g)).mean()
+        else:
+            g = sp(-logits_g).mean() if soft_plus else -logits_g.mean()
+    return d, g
+
+
 def lr_decay(iteration):
     return max(0., 1. - iteration / 100000.) if iteration < 50000 else 0.5
 

@@ -1544,6 +1544,29 @@ def test_spectral_norm_fused_operand_copies_and_label_table_are_bit_identical(K)
         assert float((T.float() - T_ref.float()).abs().max()) <= 2.0 ** -8 * float(T_ref.float().abs().max())
 
 
+@pytest.mark.parametrize("kind,loss_type,critic", [(5, "Goodfellow", True), (6, "Goodfellow", False), (7, "HINGE", True), (2, "WGAN", True),
+                                                   (3, "HINGE", False), (3, "WGAN", False)])
+def test_soft_plus_variants_of_the_sngan_losses(K, kind, loss_type, critic):
+    """SOFT_PLUS = True (SNGAN/gan_cifar_resnet.py:63) wraps the three loss types in softplus (:364-386 critic, :483-497 generator):
+    gank_gan_pointwise_loss kinds 5 / 6 / 7, and kinds 2 / 3 for the branches that coincide with the sigmoid cross-entropy and its
+    non-saturating generator.  Loss and d loss / d logits against torch-float64 autograd of the script's expressions
+    (oracle.ref_torch.sngan_losses) on the same bf16 logits, incl. logits far outside (-1, 1) on both sides."""
+    from oracle import ref_torch as T
+    rng = np.random.default_rng(kind * 7 + len(loss_type))
+    n, b = 96, 40
+    lg = np.concatenate([rng.normal(size=n - 8) * 2.0, [-9.0, -3.5, -1.25, -0.75, 0.75, 1.25, 3.5, 9.0]])
+    rng.shuffle(lg)
+    lt = torch.tensor(lg, dtype=torch.float32).to(torch.bfloat16).cuda()
+    x = lt.double().cpu().requires_grad_(True)
+    d, g = T.sngan_losses(x if critic else None, b, None if critic else x, loss_type, True)
+    ref = d if critic else g
+    (rg,) = torch.autograd.grad(ref, [x])
+    loss, dl, dl32 = K.gan_pointwise_loss(lt, b if critic else 0, kind)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(ref)) < 2e-5 * max(1.0, abs(float(ref)))
+    assert relerr(dl32, rg.numpy()) < 1e-5 and relerr(dl, rg.numpy()) < BF_TOL
+
+
 def test_concat_rows_is_two_copies_and_its_backward_two_views(K):
     """functional.concat_rows (tf.concat(axis=0) of the real and fake logits in front of a critic loss): the library's copy
     kernel twice; the gradient comes back as the two row ranges"""

@@ -149,17 +149,16 @@ def test_d_and_g_gradients_vs_oracle(gpu):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("loss_type", ["Goodfellow", "WGAN"])
-def test_other_loss_types_of_the_script_vs_oracle(gpu, loss_type):
-    """LOSS_TYPE of SNGAN/gan_cifar_resnet.py:62 with SOFT_PLUS = False: 'Goodfellow' (:363-369 critic, :483-486 generator) and
-    'WGAN' (:382-387, :493-497) through `SNGANTrainer(loss_type=...)`: both losses and every gradient against torch-float64
-    autograd of the same expressions on the oracle's logits (tolerances of test_d_and_g_gradients_vs_oracle); an unknown type
-    raises as a missing branch would."""
-    import torch.nn.functional as F
+@pytest.mark.parametrize("loss_type,soft_plus", [("Goodfellow", False), ("WGAN", False), ("Goodfellow", True), ("HINGE", True), ("WGAN", True)])
+def test_other_loss_types_of_the_script_vs_oracle(gpu, loss_type, soft_plus):
+    """LOSS_TYPE of SNGAN/gan_cifar_resnet.py:62: 'Goodfellow' (:363-369 critic, :483-486 generator) and 'WGAN' (:382-387, :493-497),
+    and the SOFT_PLUS = True (:63) variants of all three types, through `SNGANTrainer(loss_type=..., soft_plus=...)`: both losses and
+    every gradient against torch-float64 autograd of the script's expressions (oracle.ref_torch.sngan_losses) on the oracle's
+    logits (tolerances of test_d_and_g_gradients_vs_oracle); an unknown type raises as a missing branch would."""
     from gan_lib_tensorflow_amd.SNGAN import gan_cifar_resnet as S
     seed, b = 6, 4
     state = T.init_sngan_params(seed)
-    tr = S.SNGANTrainer(batch_size=b, seed=seed, use_graphs=False, state=state, loss_type=loss_type)
+    tr = S.SNGANTrainer(batch_size=b, seed=seed, use_graphs=False, state=state, loss_type=loss_type, soft_plus=soft_plus)
     rng = np.random.default_rng(17)
     z = bf16r(rng.normal(size=(b, 128)))
     labels = torch.tensor(rng.integers(0, 10, b), dtype=torch.int32)
@@ -167,10 +166,7 @@ def test_other_loss_types_of_the_script_vs_oracle(gpu, loss_type):
     real_pre = bf16r(T.preprocess_real(real_u8, torch.zeros(b, 3072, dtype=torch.float64), torch.float64).numpy())
     P = T.to_torch(state)
     _, _, lg = T.d_loss_fn(P, None, labels.long(), z.to(torch.float64), None, real_pre=real_pre.to(torch.float64))
-    if loss_type == 'Goodfellow':
-        loss = -F.logsigmoid(lg[:b]).mean() - F.logsigmoid(-lg[b:]).mean()          # log(1 - sigmoid(x)) = logsigmoid(-x)
-    else:
-        loss = lg[b:].mean() - lg[:b].mean()
+    loss, _ = T.sngan_losses(lg, b, None, loss_type, soft_plus)
     dn = T.trainable_names(P, 'Discriminator')
     ref_g = dict(zip(dn, torch.autograd.grad(loss, [P[k] for k in dn])))
     tr.real_labels.copy_(labels)
@@ -189,7 +185,7 @@ def test_other_loss_types_of_the_script_vs_oracle(gpu, loss_type):
     z2 = bf16r(rng.normal(size=(2 * b, 128)))
     fl = torch.tensor(rng.integers(0, 10, 2 * b), dtype=torch.int32)
     _, lg = T.g_loss_fn(P, z2.to(torch.float64), fl.long())
-    loss = -F.logsigmoid(lg).mean() if loss_type == 'Goodfellow' else -lg.mean()
+    _, loss = T.sngan_losses(None, 0, lg, loss_type, soft_plus)
     gn = T.trainable_names(P, 'Generator')
     ref_g = dict(zip(gn, torch.autograd.grad(loss, [P[k] for k in gn])))
     tr._g_forward_backward(z=z2.cuda(), fake_labels=fl.cuda())
