@@ -40,7 +40,7 @@ class SlabJob(C.Structure):
 
 class PrepDesc(C.Structure):
     """gank_prep_desc"""
-    _fields_ = [("w", P), ("wf", P), ("wd", P), ("ksize", I), ("Cin", I), ("Cout", I), ("kind", I)]
+    _fields_ = [("w", P), ("wf", P), ("wd", P), ("ksize", I), ("Cin", I), ("Cout", I), ("kind", I), ("cin_pitch", I)]
 
 
 class Res8Head(C.Structure):
@@ -137,6 +137,11 @@ PROTOTYPES = {
     "gank_label_dense_bwd": [P, P, P, P, P, P, P, I, I, I, I, P],
     "gank_concat_label_pool_fwd": [P, P, P, P, P, I, I, I, I, I, I, P],
     "gank_concat_label_unpool_bwd": [P, P, P, P, I, I, I, I, I, P],
+    "gank_concat_label_unpool_bwd_factored": [P, P, P, P, P, I, I, I, I, I, I, P],
+    "gank_label_conv3x3_table": [P, I, I, I, I, P, I, P, P, P],
+    "gank_img16_conv3x3_label_bias": [P, P, P, P, I, P, I, I, I, I, P],
+    "gank_label_conv3x3_bwd_ws_floats": [I, I],
+    "gank_label_conv3x3_bwd": [P, P, P, I, P, I, I, I, I, I, I, I, P, P, P, P, P],
     "gank_cbn_parts": [L],
     "gank_cbn_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     "gank_cbn_fwd_from_sums": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P],
@@ -215,7 +220,7 @@ PROTOTYPES = {
     "gank_critic_feed": [P, P, P, P, P, P, P, P, I, I, P],
     "gank_debug_tr_probe": [P, P],
 }
-_RET = {"gank_last_error": C.c_char_p, "gank_sn_ws_floats": C.c_long, "gank_cbn_bwd_ws_floats": C.c_long, "gank_conv2d_wgrad_ws_elems": C.c_long, "gank_convpool3x3_wgrad_ws_elems": C.c_long, "gank_upconv3x3_wgrad_ws_elems": C.c_long, "gank_conv2d_wgrad_batched_ws_elems": C.c_long, "gank_conv2d_wgrad_slab_elems": C.c_long, "gank_prof_calibrate": C.c_double, "gank_prof_bytes": C.c_double}
+_RET = {"gank_last_error": C.c_char_p, "gank_sn_ws_floats": C.c_long, "gank_cbn_bwd_ws_floats": C.c_long, "gank_label_conv3x3_bwd_ws_floats": C.c_long, "gank_conv2d_wgrad_ws_elems": C.c_long, "gank_convpool3x3_wgrad_ws_elems": C.c_long, "gank_upconv3x3_wgrad_ws_elems": C.c_long, "gank_conv2d_wgrad_batched_ws_elems": C.c_long, "gank_conv2d_wgrad_slab_elems": C.c_long, "gank_prof_calibrate": C.c_double, "gank_prof_bytes": C.c_double}
 
 _lib = None
 

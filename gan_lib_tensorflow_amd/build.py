@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, os.environ.get("GANK_LIB_NAME", "libgank.so"))   # experiment builds: GANK_LIB_NAME + GANK_EXTRA_FLAGS
-SOURCES = ["api.hip", "conv_igemm.hip", "conv_wgrad.hip", "conv_resident.hip", "acgan_ops.hip", "pggan_pix_ops.hip", "elementwise.hip", "sn.hip", "cbn.hip", "loss_opt.hip", "linear.hip", "norms.hip"]
+SOURCES = ["api.hip", "conv_igemm.hip", "conv_wgrad.hip", "conv_resident.hip", "label_conv.hip", "acgan_ops.hip", "pggan_pix_ops.hip", "elementwise.hip", "sn.hip", "cbn.hip", "loss_opt.hip", "linear.hip", "norms.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"] + \
     os.environ.get("GANK_EXTRA_FLAGS", "").split()
 

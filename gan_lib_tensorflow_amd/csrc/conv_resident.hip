@@ -1611,7 +1611,9 @@ constexpr int I16_PP = 144, I16_RP = 2816, I16_IMG = 18 * I16_RP;      // 50688 
 struct I16Args {
   const bf16* x;          // [N,16,16,Cin]
   const bf16* w;          // rfrag kind 4: [Cout/32][9 taps][Cin/16][64 lanes][8]
-  const float* bias;      // optional [Cout]
+  const float* bias;      // optional [Cout]; with bias_labels: [V][9][Cout], row (label of the sample, border class of the pixel)
+  const int* bias_labels; // optional [N] (label_conv.hip: the spatially constant input channels of the layer, factored out)
+  int bias_V;
   const bf16* mask;       // optional [N,16,16,Cout]: result zeroed where mask <= 0 (relu backward)
   const bf16* res;        // optional [N,16,16,Cout]: added last
   bf16* y;                // [N,16,16,Cout]
@@ -1838,7 +1840,16 @@ __global__ __launch_bounds__(HALF ? 512 : 2048 / TW) void img16_conv3x3_kernel(I
         for (int e = 0; e < 8; e++) v[e] += bf2f(rs[e]);
       }
       f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-      if (a.bias) { b0 = *reinterpret_cast<const f32x4*>(a.bias + co); b1 = *reinterpret_cast<const f32x4*>(a.bias + co + 4); }
+      if (a.bias) {
+        const float* bp = a.bias + co;
+        if (a.bias_labels) {
+          int lb = a.bias_labels[n];
+          lb = lb < 0 ? 0 : (lb >= a.bias_V ? a.bias_V - 1 : lb);
+          const int cls = (py == 0 ? 0 : (py == 15 ? 2 : 1)) * 3 + (tcol == 0 ? 0 : (tcol == 15 ? 2 : 1));
+          bp += ((long)lb * 9 + cls) * a.Cout;
+        }
+        b0 = *reinterpret_cast<const f32x4*>(bp); b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+      }
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; e++) {
@@ -1889,7 +1900,16 @@ namespace {
 struct I16Cbn { const int* labels; const float* gamma; const float* beta; const float* stats; int groups, n_labels; };
 }
 static int img16_conv3x3_impl(const void* x, const void* w_rfrag, const float* bias, const void* relu_ref, const void* residual, void* y,
-                              int N, int Cin, int Cout, int flags, float* stat_sums, int stat_groups, const I16Cbn* cbn, void* stream);
+                              int N, int Cin, int Cout, int flags, float* stat_sums, int stat_groups, const I16Cbn* cbn, void* stream,
+                              const int32_t* bias_labels = nullptr, int bias_V = 0);
+// the layer's spatially constant input channels factored out (label_conv.hip): bias_table [V][9][Cout] from gank_label_conv3x3_table
+// holds, per label and border class of a pixel, the layer's bias plus what those channels contribute; x and w_rfrag are the
+// remaining (feature) channels only
+extern "C" int gank_img16_conv3x3_label_bias(const void* x, const void* w_rfrag, const float* bias_table, const int32_t* labels, int V, void* y,
+                                             int N, int Cin, int Cout, int flags, void* stream) {
+  GANK_REQUIRE(bias_table && labels && V > 0, "img16_conv3x3_label_bias: null table / labels");
+  return img16_conv3x3_impl(x, w_rfrag, bias_table, nullptr, nullptr, y, N, Cin, Cout, flags, nullptr, 0, nullptr, stream, labels, V);
+}
 extern "C" int gank_img16_conv3x3_stats(const void* x, const void* w_rfrag, const float* bias, const void* relu_ref, const void* residual, void* y,
                                         int N, int Cin, int Cout, int flags, float* stat_sums, int stat_groups, void* stream) {
   return img16_conv3x3_impl(x, w_rfrag, bias, relu_ref, residual, y, N, Cin, Cout, flags, stat_sums, stat_groups, nullptr, stream);
@@ -1909,7 +1929,8 @@ extern "C" int gank_cbn_relu_img16_conv3x3(const void* x, const int32_t* labels,
   return img16_conv3x3_impl(x, w_rfrag, bias, nullptr, residual, y, N, Cin, Cout, flags, stat_sums, stat_groups, &cbn, stream);
 }
 static int img16_conv3x3_impl(const void* x, const void* w_rfrag, const float* bias, const void* relu_ref, const void* residual, void* y,
-                              int N, int Cin, int Cout, int flags, float* stat_sums, int stat_groups, const I16Cbn* cbn, void* stream) {
+                              int N, int Cin, int Cout, int flags, float* stat_sums, int stat_groups, const I16Cbn* cbn, void* stream,
+                              const int32_t* bias_labels, int bias_V) {
   GANK_REQUIRE(x && w_rfrag && y && N > 0, "img16_conv3x3: null pointer");
   GANK_REQUIRE(Cin % 64 == 0 && Cout % 128 == 0, "img16_conv3x3: needs Cin %% 64 == 0 and Cout %% 128 == 0 (got %d, %d)", Cin, Cout);
   GANK_REQUIRE((flags & ~(GANK_IN_RELU | GANK_RES_UPSAMPLE2X | GANK_STATS_PREZEROED)) == 0, "img16_conv3x3: flags: GANK_IN_RELU, GANK_RES_UPSAMPLE2X, GANK_STATS_PREZEROED");
@@ -1922,6 +1943,7 @@ static int img16_conv3x3_impl(const void* x, const void* w_rfrag, const float* b
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.relu = (flags & GANK_IN_RELU) ? 1 : 0;
   a.res_up = (flags & GANK_RES_UPSAMPLE2X) ? 1 : 0; a.stat_sums = stat_sums; a.stat_n_per_group = stat_sums ? N / stat_groups : 1;
   a.xcd = resident_xcd_env();
+  a.bias_labels = bias_labels; a.bias_V = bias_V;
   if (cbn) {
     a.cbn_labels = cbn->labels; a.cbn_gamma = cbn->gamma; a.cbn_beta = cbn->beta; a.cbn_stats = cbn->stats;
     a.cbn_n_per_group = N / cbn->groups; a.cbn_n_labels = cbn->n_labels;

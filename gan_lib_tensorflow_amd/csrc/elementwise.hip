@@ -784,18 +784,23 @@ __global__ void concat_label_pool_fwd_kernel(const bf16* __restrict__ a, const b
       }
       v[0] = v[1] = v[2] = v[3] = m;
     }
-    *reinterpret_cast<bf16x8*>(y + hi * C + g * 8) = v[0];
-    *reinterpret_cast<bf16x8*>(y + (hi + 1) * C + g * 8) = v[1];
-    *reinterpret_cast<bf16x8*>(y + (hi + W) * C + g * 8) = v[2];
-    *reinterpret_cast<bf16x8*>(y + (hi + W + 1) * C + g * 8) = v[3];
+    if (y) {           // (null: the consumer of the full-resolution tensor reads `a` and the table itself -- label_conv.hip)
+      *reinterpret_cast<bf16x8*>(y + hi * C + g * 8) = v[0];
+      *reinterpret_cast<bf16x8*>(y + (hi + 1) * C + g * 8) = v[1];
+      *reinterpret_cast<bf16x8*>(y + (hi + W) * C + g * 8) = v[2];
+      *reinterpret_cast<bf16x8*>(y + (hi + W + 1) * C + g * 8) = v[3];
+    }
     *reinterpret_cast<bf16x8*>(yp + (((long)n * Hp + ph) * Wp + pw) * C + g * 8) = m;
   }
 }
 
 // backward of the pair: dy = g_main + 0.25 * unpool(g_pool) (unpool2x2_add's arithmetic) is never written -- its first C1
 // channels go straight to da, the tiled half is summed over the sample's pixels into de32 (block of 1024 threads per sample)
+// gm_c1: g_main holds the first C1 channels only (the consumer of the tiled half was factored out: label_conv.hip) and that
+// consumer's gradient of the tiled vector arrives as de_parts partial sums [de_parts][N][C2], added in ascending order.
 __global__ __launch_bounds__(1024) void concat_label_unpool_bwd_kernel(const bf16* __restrict__ gm, const bf16* __restrict__ gp, bf16* __restrict__ da,
-                                                                      float* __restrict__ de, int H, int W, int C1, int C2) {
+                                                                      float* __restrict__ de, int H, int W, int C1, int C2,
+                                                                      int gm_c1, const float* __restrict__ de_add, int de_parts, int N) {
   constexpr int NT = 1024;
   const int n = blockIdx.x, C = C1 + C2, HW = H * W, Wp = W >> 1;
   const int cg = C >> 3, cg1 = C1 >> 3, cg2 = C2 >> 3;
@@ -807,10 +812,11 @@ __global__ __launch_bounds__(1024) void concat_label_unpool_bwd_kernel(const bf1
     const long pi = ((long)n * (H >> 1) + (oh >> 1)) * Wp + (ow >> 1);
     const bf16x8 a = *reinterpret_cast<const bf16x8*>(gp + pi * C + g * 8);
     bf16x8 b;
-    if (gm) b = *reinterpret_cast<const bf16x8*>(gm + ((long)n * HW + r) * C + g * 8);
+    const bool has_main = gm != nullptr && (!gm_c1 || g < cg1);
+    if (has_main) b = *reinterpret_cast<const bf16x8*>(gm + ((long)n * HW + r) * (gm_c1 ? C1 : C) + g * 8);
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) v[e] = bf2f(a[e]) * 0.25f + (gm ? bf2f(b[e]) : 0.f);
+    for (int e = 0; e < 8; e++) v[e] = bf2f(a[e]) * 0.25f + (has_main ? bf2f(b[e]) : 0.f);
     if (g < cg1) {
       bf16x8 o;
 #pragma unroll
@@ -829,6 +835,7 @@ __global__ __launch_bounds__(1024) void concat_label_unpool_bwd_kernel(const bf1
     const int gg = cg1 + (c >> 3);
     float t = 0.f;
     for (int l = 0; l < RL; l++) t += red[(l * cg + gg) * 8 + (c & 7)];
+    for (int p = 0; p < de_parts; p++) t += de_add[((long)p * N + n) * C2 + c];
     de[(long)n * C2 + c] = t;
   }
   (void)cg2;
@@ -934,7 +941,7 @@ extern "C" int gank_concat_label_bwd(const void* dy, void* da, float* de32, int 
 }
 extern "C" int gank_concat_label_pool_fwd(const void* a, const void* T, const int32_t* labels, void* y, void* y_pooled, int N, int H, int W,
                                           int C1, int C2, int V, void* stream) {
-  GANK_REQUIRE(a && T && labels && y && y_pooled && N > 0 && H > 0 && W > 0 && V > 0, "concat_label_pool_fwd: bad arguments");
+  GANK_REQUIRE(a && T && labels && y_pooled && N > 0 && H > 0 && W > 0 && V > 0, "concat_label_pool_fwd: bad arguments");      // y may be NULL: pooled output only
   GANK_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && H % 2 == 0 && W % 2 == 0, "concat_label_pool_fwd: channel counts must be multiples of 8, the size even");
   const long total8 = (long)N * (H / 2) * (W / 2) * ((C1 + C2) / 8);
   hipLaunchKernelGGL(concat_label_pool_fwd_kernel, grid1d(total8), dim3(256), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)T, labels,
@@ -948,8 +955,20 @@ extern "C" int gank_concat_label_unpool_bwd(const void* g_main, const void* g_po
   GANK_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && H % 2 == 0 && W % 2 == 0 && 1024 % ((C1 + C2) / 8) == 0,
                "concat_label_unpool_bwd: unsupported shape (%d + %d channels, %d x %d)", C1, C2, H, W);
   hipLaunchKernelGGL(concat_label_unpool_bwd_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, (const bf16*)g_main, (const bf16*)g_pooled,
-                     (bf16*)da, de32, H, W, C1, C2);
+                     (bf16*)da, de32, H, W, C1, C2, 0, (const float*)nullptr, 0, N);
   GANK_LAUNCH_OK("concat_label_unpool_bwd");
+  return 0;
+}
+// the same where the consumer of the tiled half was factored out (gank_label_conv3x3_*): g_main_c1 [N,H,W,C1] is the gradient of the
+// first C1 channels only, de_add [de_parts][N][C2] that consumer's gradient of the tiled vector (partial sums, added in order)
+extern "C" int gank_concat_label_unpool_bwd_factored(const void* g_main_c1, const void* g_pooled, void* da, float* de32, const float* de_add, int de_parts,
+                                                     int N, int H, int W, int C1, int C2, void* stream) {
+  GANK_REQUIRE(g_main_c1 && g_pooled && da && de32 && N > 0 && H > 0 && W > 0 && (de_parts == 0 || de_add), "concat_label_unpool_bwd_factored: bad arguments");
+  GANK_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && H % 2 == 0 && W % 2 == 0 && 1024 % ((C1 + C2) / 8) == 0,
+               "concat_label_unpool_bwd_factored: unsupported shape (%d + %d channels, %d x %d)", C1, C2, H, W);
+  hipLaunchKernelGGL(concat_label_unpool_bwd_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, (const bf16*)g_main_c1, (const bf16*)g_pooled,
+                     (bf16*)da, de32, H, W, C1, C2, 1, de_add, de_parts, N);
+  GANK_LAUNCH_OK("concat_label_unpool_bwd_factored");
   return 0;
 }
 extern "C" int gank_label_dense_bwd(const float* de32, const int32_t* labels, const float* table, const float* W, float* dW, float* dbias,

@@ -251,7 +251,8 @@ __device__ __forceinline__ void prep_batch_block(const PrepTable& t, int e, int 
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         const int k = k0 + j;
-        o[j] = f2bf(prep_ld<SC>(isf ? d.w[((long)tap * d.Cin + k) * d.Cout + row] : d.w[((long)(taps - 1 - tap) * d.Cin + row) * d.Cout + k], sg));
+        const long cp = d.cin_pitch > 0 ? d.cin_pitch : d.Cin;       // the first Cin of cin_pitch input channels (a channel slice of a wider filter)
+        o[j] = f2bf(prep_ld<SC>(isf ? d.w[((long)tap * cp + k) * d.Cout + row] : d.w[((long)(taps - 1 - tap) * cp + row) * d.Cout + k], sg));
       }
       *reinterpret_cast<bf16x8*>(dst + q * 8) = o;
     }
@@ -368,7 +369,7 @@ static inline int prep_table_fill(PrepTable& t, const gank_prep_desc* table, int
     const bool ok = d.w && (d.wf || d.wd) && d.ksize >= 1 && d.Cin > 0 && d.Cout > 0;
     if (!ok) { gank_set_error("prep_weights_batched: bad entry %d", base_index + i); return -1; }
     const bool kind_ok = d.kind == 0 || ((d.kind == 1 || d.kind == 2) && d.ksize == 3 && d.wf && d.wd) ||
-                         (d.kind == 4 && d.Cin % 32 == 0 && d.Cout % 32 == 0) ||
+                         (d.kind == 4 && d.Cin % 32 == 0 && d.Cout % 32 == 0 && (d.cin_pitch == 0 || d.cin_pitch >= d.Cin)) ||
                          (d.kind == 5 && d.ksize == 3 && d.wf && d.wd && d.Cin % 64 == 0 && d.Cout % 32 == 0);
     if (!kind_ok) {
       gank_set_error("prep_weights_batched: entry %d: kind %d needs ksize 3 and both outputs (1, 2, 5) / channels %% 32 == 0 (4) / Cin %% 64 == 0 (5)", base_index + i, d.kind);

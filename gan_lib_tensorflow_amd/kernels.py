@@ -47,7 +47,7 @@ def prep_weights(w, want_f=True, want_d=False):
     return wf, wd
 
 
-_PREP_ATTR = ("_prep", "_prep_up", "_prep_pool", None, "_prep_res", "_prep_cpres")     # kind 3 is retired
+_PREP_ATTR = ("_prep", "_prep_up", "_prep_pool", None, "_prep_res", "_prep_cpres", "_prep_feat")     # kind 3 is retired; 6: below
 
 
 def _prep_plan(ws, want_d=True, kinds=None, sources=None):
@@ -89,12 +89,21 @@ def _prep_plan(ws, want_d=True, kinds=None, sources=None):
             assert k == 3 and cin % 64 == 0 and cout % 32 == 0
             wf, wd = getattr(w, "_prep_cpres", None) or (torch.empty(16 * cin * cout, dtype=BF16, device=dev),
                                                         torch.empty(16 * cin * cout, dtype=BF16, device=dev))
+        elif kind == 6:
+            # "rfrag" operands (kind 4) of the FIRST HALF of the input channels: the feature half of a conv whose other input
+            # channels are spatially constant and factored out (label_conv3x3_table) -> `w._prep_feat`
+            assert k == 3 and cin % 64 == 0 and cout % 32 == 0
+            half = cin // 2
+            wf, wd = getattr(w, "_prep_feat", None) or (torch.empty(taps * half * cout, dtype=BF16, device=dev),
+                                                       torch.empty(taps * half * cout, dtype=BF16, device=dev) if want_d else None)
         else:
             raise ValueError(f"unknown preparation kind {kind}")
         src = w if sources is None else sources[i]
         d = table[slot]
         d.w, d.wf, d.wd = _p(src.detach(), F32, "w").value, wf.data_ptr(), (wd.data_ptr() if wd is not None else None)
         d.ksize, d.Cin, d.Cout, d.kind = k, cin, cout, kind
+        if kind == 6:
+            d.Cin, d.kind, d.cin_pitch = cin // 2, 4, cin
         outs.append((wf, wd))
     return table, todo, outs
 
@@ -1261,15 +1270,66 @@ def concat_label_bwd(dy, c1):
     return da, de
 
 
-def concat_label_pool_fwd(a, t, labels):
-    """-> (y [N,H,W,C1+C2], mean_pool2x2(y)) in one pass"""
+def concat_label_pool_fwd(a, t, labels, want_full=True):
+    """-> (y [N,H,W,C1+C2], mean_pool2x2(y)) in one pass; want_full=False: (None, mean_pool2x2(y)) -- the full tensor is not written"""
     n, h, w, c1 = a.shape
     v, c2 = t.shape
-    y = torch.empty((n, h, w, c1 + c2), dtype=BF16, device=a.device)
+    y = torch.empty((n, h, w, c1 + c2), dtype=BF16, device=a.device) if want_full else None
     yp = torch.empty((n, h // 2, w // 2, c1 + c2), dtype=BF16, device=a.device)
     _lib.check(lib().gank_concat_label_pool_fwd(_p(a, BF16, "a"), _p(t, BF16, "T"), _p(labels, I32, "labels"), _p(y), _p(yp), n, h, w, c1, c2, v, _stream()),
                "concat_label_pool_fwd")
     return y, yp
+
+
+def concat_label_unpool_bwd_factored(g_main_c1, g_pooled, de_add=None):
+    """concat_label_unpool_bwd where the consumer of the tiled half was factored out: g_main_c1 [N,H,W,C1] (the first C1 channels'
+    gradient), de_add fp32 [parts,N,C2] that consumer's gradient of the tiled vector -> (da bf16 [N,H,W,C1], de32 fp32 [N,C2])"""
+    n, hp, wp, c = g_pooled.shape
+    c1 = g_main_c1.shape[3]
+    da = torch.empty((n, 2 * hp, 2 * wp, c1), dtype=BF16, device=g_pooled.device)
+    de = torch.empty((n, c - c1), dtype=F32, device=g_pooled.device)
+    parts = 0 if de_add is None else de_add.shape[0]
+    _lib.check(lib().gank_concat_label_unpool_bwd_factored(_p(g_main_c1, BF16, "g_main_c1"), _p(g_pooled, BF16, "g_pooled"), _p(da), _p(de),
+                                                           _p(de_add, F32, "de_add"), parts, n, 2 * hp, 2 * wp, c1, c - c1, _stream()),
+               "concat_label_unpool_bwd_factored")
+    return da, de
+
+
+# ---- the spatially constant input channels of a 3x3 conv, factored out (csrc/label_conv.hip)
+def label_conv3x3_table(w, c0, t, bias=None):
+    """bias_table fp32 [V,9,Cout] = bias + what the constant channels c0.. of the fp32 filter w [3,3,Cin,Cout] contribute per (label,
+    border class) with the per-label vectors relu(t[v]) (t bf16 [V,C2])"""
+    v, c2 = t.shape
+    cin, cout = w.shape[2], w.shape[3]
+    out = torch.empty((v, 9, cout), dtype=F32, device=w.device)
+    _lib.check(lib().gank_label_conv3x3_table(_p(w, F32, "w"), cin, c0, c2, cout, _p(t, BF16, "T"), v, _p(bias, F32, "bias"), _p(out), _stream()),
+               "label_conv3x3_table")
+    return out
+
+
+def img16_conv3x3_label_bias(x, rf, bias_table, labels, cout, flags=0):
+    """gank_img16_conv3x3_label_bias: the image-resident conv on the feature channels x [N,16,16,Cin] (rf: kind-6 operand) plus row
+    (label, border class) of the table"""
+    n, cin = x.shape[0], x.shape[3]
+    assert tuple(x.shape[1:3]) == (16, 16) and bias_table.shape[1:] == (9, cout), (x.shape, bias_table.shape)
+    y = torch.empty((n, 16, 16, cout), dtype=BF16, device=x.device)
+    _lib.check(lib().gank_img16_conv3x3_label_bias(_p(x, BF16, "x"), _p(rf, BF16, "rf"), _p(bias_table, F32, "bias_table"), _p(labels, I32, "labels"),
+                                                   bias_table.shape[0], _p(y), n, cin, cout, flags, _stream()), "img16_conv3x3_label_bias")
+    return y
+
+
+def label_conv3x3_bwd(dy, labels, t, w, c0, dw, dw_feat_tmp=None):
+    """gank_label_conv3x3_bwd: ACCUMULATES the constant channels' filter gradient into rows c0.. of dw [3,3,Cin,Cout] (and adds +
+    clears dw_feat_tmp [3,3,c0,Cout] into rows 0..c0-1) -> de_parts fp32 [9,N,C2]"""
+    n, h, wd_, cout = dy.shape
+    v, c2 = t.shape
+    cin = w.shape[2]
+    assert dw.shape == w.shape and (dw_feat_tmp is None or tuple(dw_feat_tmp.shape) == (3, 3, c0, cout))
+    ws = torch.empty(int(lib().gank_label_conv3x3_bwd_ws_floats(n, cout)), dtype=F32, device=dy.device)
+    parts = torch.empty((9, n, c2), dtype=F32, device=dy.device)
+    _lib.check(lib().gank_label_conv3x3_bwd(_p(dy, BF16, "dy"), _p(labels, I32, "labels"), _p(t, BF16, "T"), v, _p(w, F32, "w"), cin, c0, c2, cout, n, h, wd_,
+                                            _p(dw, F32, "dw"), _p(dw_feat_tmp, F32, "dw_feat_tmp"), _p(parts), _p(ws), _stream()), "label_conv3x3_bwd")
+    return parts
 
 
 def concat_label_unpool_bwd(g_main, g_pooled, c1):

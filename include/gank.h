@@ -71,6 +71,9 @@ typedef struct gank_prep_desc {
                      5 ConvMeanPool 3x3 operands of the resident kernels (gank_cpool_res_*), 16*Cin*Cout elements each, same
                        tap algebra as kind 2: wf bf16 [Cout/32][Cin/64][16 taps][4][64 lanes][8] (the 4x4 stride-2 kernel),
                        wd bf16 [4 phases][Cin/32][4 taps][Cout/16][64][8] (its transposed conv).  Cin % 64 == 0, Cout % 32 == 0 */
+  int cin_pitch;  /* kind 4 only: w is [k,k,cin_pitch,Cout] and the operands are built from its FIRST Cin input channels
+                     (0 = Cin: the whole filter) -- the feature half of a conv whose other input channels are factored out
+                     (gank_label_conv3x3_table) */
 } gank_prep_desc;
 int gank_conv2d_prep_weights_batched(const gank_prep_desc* table, int count, void* stream);
 
@@ -574,6 +577,31 @@ int gank_concat_label_pool_fwd(const void* a, const void* T, const int32_t* labe
                                int C1, int C2, int V, void* stream);
 int gank_concat_label_unpool_bwd(const void* g_main, const void* g_pooled, void* da, float* de32, int N, int H, int W, int C1, int C2,
                                  void* stream);
+int gank_concat_label_unpool_bwd_factored(const void* g_main_c1, const void* g_pooled, void* da, float* de32, const float* de_add, int de_parts,
+                                          int N, int H, int W, int C1, int C2, void* stream);
+
+/* ---- the spatially constant input channels of a 3x3 conv, factored out (round 5) ------------------------------------------
+ * The critic tiles the label embedding over the 16x16 grid and concatenates it to its features in front of D.Block.2
+ * (SNGAN/gan_cifar_resnet.py:276-284), so C2 = 128 of the 256 input channels of D.Block.2.Conv1 (:186-190; 35 % of the critic's
+ * multiply-adds) hold one vector per sample, relu(T[label]) after the pre-activation.  Their contribution to the conv depends on a
+ * sample only through its label and on a pixel only through its border class (3 row x 3 column classes: first / inner / last), so a
+ * table [V][9][Cout] replaces half of the layer in all three passes -- exact algebra:
+ *   gank_label_conv3x3_table    : bias_table[v][cls][co] = bias[co] + sum_{taps valid in cls} sum_c bf16(w[t][c0+c][co]) relu(T[v][c]);
+ *                                 w is the WHOLE fp32 filter [3,3,Cin_total,Cout], the constant channels are c0 .. c0+C2-1;
+ *   gank_img16_conv3x3_label_bias: the image-resident 16x16 conv on the OTHER channels (x [N,16,16,Cin], operands prepared with
+ *                                 gank_prep_desc.cin_pitch = Cin_total) adding row (label of the sample, class of the pixel);
+ *   gank_label_conv3x3_bwd      : from dy [N,H,W,Cout]: dw[t][c0+c][co] += sum_n relu(T[l_n][c]) S[n][t][co] and
+ *                                 de_parts[t][n][c] = [T[l_n][c] > 0] sum_co bf16(w[t][c0+c][co]) S[n][t][co], S = the sums of dy over
+ *                                 the pixels where tap t is valid (ws: gank_label_conv3x3_bwd_ws_floats).  dw_feat_tmp (optional,
+ *                                 contiguous [9][c0][Cout]): the other channels' filter gradient, accumulated there by an ordinary
+ *                                 filter-gradient launch, is added into rows [0, c0) of dw and the buffer cleared. */
+int gank_label_conv3x3_table(const float* w, int Cin_total, int c0, int C2, int Cout, const void* T, int V, const float* bias,
+                             float* bias_table, void* stream);
+int gank_img16_conv3x3_label_bias(const void* x, const void* w_rfrag, const float* bias_table, const int32_t* labels, int V, void* y,
+                                  int N, int Cin, int Cout, int flags, void* stream);
+long gank_label_conv3x3_bwd_ws_floats(int N, int Cout);
+int gank_label_conv3x3_bwd(const void* dy, const int32_t* labels, const void* T, int V, const float* w, int Cin_total, int c0, int C2,
+                           int Cout, int N, int H, int W, float* dw, float* dw_feat_tmp, float* de_parts, float* ws, void* stream);
 int gank_label_dense_bwd(const float* de32, const int32_t* labels, const float* table, const float* W, float* dW, float* dbias,
                          float* dtable, int N, int V, int D, int C2, void* stream);
 

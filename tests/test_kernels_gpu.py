@@ -1567,6 +1567,61 @@ def test_soft_plus_variants_of_the_sngan_losses(K, kind, loss_type, critic):
     assert relerr(dl32, rg.numpy()) < 1e-5 and relerr(dl, rg.numpy()) < BF_TOL
 
 
+@pytest.mark.parametrize("n", [6, 128])
+def test_conv3x3_with_its_spatially_constant_input_channels_factored_out(K, n):
+    """csrc/label_conv.hip (round 5): D.Block.2.Conv1 (SNGAN/gan_cifar_resnet.py:186-190) reads concat(features, tile(label vector))
+    (:282-284), so half of its input channels hold one vector per sample.  gank_label_conv3x3_table + gank_img16_conv3x3_label_bias
+    (forward), the image-resident input gradient on the feature half, gank_conv2d_wgrad on the feature half + gank_label_conv3x3_bwd
+    (filter gradient of both halves, gradient of the tiled vector) against float64 of the UNFACTORED layer on the concatenated
+    tensor: y, dW (all 256 input channels), the feature gradient and the per-sample gradient of the tiled vector."""
+    rng = np.random.default_rng(91 + n)
+    c1 = c2 = 128
+    cout, v = 256, 10
+    a, at = bf(rng.normal(size=(n, 16, 16, c1)))
+    tab, tt = bf(rng.normal(size=(v, c2)) * 0.7)
+    labels = rng.integers(0, v, n)
+    lt = torch.tensor(labels, dtype=torch.int32).cuda()
+    w, _ = bf(rng.normal(size=(3, 3, c1 + c2, cout)) / np.sqrt(9 * (c1 + c2)))       # bf16-representable: the operands round nothing away
+    bias, bt = f32(rng.normal(size=cout) * 0.1)
+    wt = torch.tensor(w, dtype=torch.float32).cuda()
+    xcat = np.concatenate([a, np.broadcast_to(tab[labels][:, None, None, :], (n, 16, 16, c2))], axis=3)
+    y_ref = R.conv2d_same(R.relu(xcat), w) + bias
+    (rf, rd), = K.prep_weights_batched([wt], want_d=True, kinds=[6])
+    table = K.label_conv3x3_table(wt, c1, tt, bt)
+    y = K.img16_conv3x3_label_bias(at, rf, table, lt, cout, K.IN_RELU)
+    torch.cuda.synchronize()
+    assert relerr(y, y_ref) < BF_TOL, relerr(y, y_ref)
+    # backward
+    dy, dyt = bf(rng.normal(size=(n, 16, 16, cout)))
+    dx_ref, dw_ref, _ = R.conv2d_same_grads(R.relu(xcat), w, dy)
+    dx_ref = dx_ref * (xcat > 0)
+    da_ref, de_ref = dx_ref[..., :c1], dx_ref[..., c1:].sum((1, 2))
+    dw0 = rng.normal(size=w.shape).astype(np.float32)              # accumulation into a non-zero gradient buffer
+    dw = torch.tensor(dw0).cuda()
+    dwf = torch.zeros((3, 3, c1, cout), device="cuda")
+    jobs = []
+    K.conv2d_wgrad(at, dyt, dwf, (16, 16), 3, K.IN_RELU, slab_jobs=jobs)
+    if jobs:
+        K.sum_slabs(jobs)
+    parts = K.label_conv3x3_bwd(dyt, lt, tt, wt, c1, dw, dwf)
+    da = K.img16_conv3x3(dyt, rd, None, c1, 0, relu_ref=at)
+    torch.cuda.synchronize()
+    assert float(dwf.abs().max()) == 0.0                           # (left clean for the next pass)
+    assert relerr(dw - torch.tensor(dw0).cuda(), dw_ref) < F32_FROM_BF_TOL, relerr(dw - torch.tensor(dw0).cuda(), dw_ref)
+    assert relerr(parts.sum(0), de_ref) < F32_FROM_BF_TOL, relerr(parts.sum(0), de_ref)
+    assert relerr(da, da_ref) < BF_TOL
+    # the pooled / unpooled ends of the pair: the pooled concat alone, and the gradient join with the factored consumer's partial sums
+    _, yp = K.concat_label_pool_fwd(at, tt, lt, want_full=False)
+    y_full, yp_full = K.concat_label_pool_fwd(at, tt, lt)
+    gp, gpt = bf(rng.normal(size=(n, 8, 8, c1 + c2)))
+    da2, de2 = K.concat_label_unpool_bwd_factored(da, gpt, parts)
+    gm_full = torch.cat([da, torch.zeros((n, 16, 16, c2), dtype=da.dtype, device="cuda")], 3).contiguous()
+    da3, de3 = K.concat_label_unpool_bwd(gm_full, gpt, c1)
+    torch.cuda.synchronize()
+    assert torch.equal(yp.view(torch.int16), yp_full.view(torch.int16)) and torch.equal(da2.view(torch.int16), da3.view(torch.int16))
+    assert relerr(de2, (de3 + parts.sum(0)).double().cpu().numpy()) < 1e-6
+
+
 def test_concat_rows_is_two_copies_and_its_backward_two_views(K):
     """functional.concat_rows (tf.concat(axis=0) of the real and fake logits in front of a critic loss): the library's copy
     kernel twice; the gradient comes back as the two row ranges"""
