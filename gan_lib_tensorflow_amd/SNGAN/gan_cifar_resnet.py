@@ -122,6 +122,8 @@ def _d_prep_kind(name, W):
         return 4                                                          # fused 8x8 residual blocks: "rfrag" operands
     if Fn.IMG16_CONV and name.endswith('D.Block.2.Conv1/Filters') and W.dim() == 4 and W.shape[0] == 3 and W.shape[2] % 64 == 0 and W.shape[3] % 128 == 0 \
             and W.shape[2] % 128 == 0:
+        if Fn.FACTOR_LABEL_CONV and LABEL_TABLE and CONDITIONAL and W.shape[2] == 2 * DIM_D:
+            return 6                                                      # ... on the feature half; the tiled label half is a bias table
         return 4                                                          # 16x16 image-resident conv (forward and input gradient)
     return 0
 
@@ -171,8 +173,25 @@ def Discriminator(inputs, labels, update_collection=None, reuse=False, loss_head
                 output = OptimizedResBlockDisc1(output, spectral_normed=True, update_collection=update_collection, biases=True)
                 if (blocks.FUSE_LABEL_FORK and blocks.COMMUTE_1X1 and blocks.FUSE_FORK_POOL and output.requires_grad
                         and output.shape[1] % 2 == 0 and output.shape[2] % 2 == 0 and 1024 % ((output.shape[3] + DIM_D) // 8) == 0):
-                    prefork = Fn.concat_label_fork_pool(output, labels, emb_table, w_emb, b_emb)     # concat + D.Block.2's fan-out
-                    output = None
+                    w1 = None
+                    if Fn.FACTOR_LABEL_CONV:
+                        # D.Block.2's variables in ResidualBlock's order (shortcut, conv_1; conv_2 below), then the block itself with conv_1
+                        # computed on the feature half alone (the tiled half of its input is one vector per sample)
+                        _conv2d.conv2d_variables(DIM_D * 2, DIM_D, 1, 1, 'D.Block.2.Shortcut', spectral_normed=True,
+                                                 update_collection=update_collection, he_init=False, biases=True)
+                        w1, b1 = _conv2d.conv2d_variables(DIM_D * 2, DIM_D * 2, 3, 1, 'D.Block.2.Conv1', spectral_normed=True,
+                                                          update_collection=update_collection, he_init=True, biases=True)
+                    if w1 is not None and Fn.concat_label_conv1_ok(output, w1):
+                        h1, pooled = Fn.concat_label_conv1(output, labels, emb_table, w_emb, b_emb, w1, b1)
+                        shortcut = _conv2d.Conv2D(pooled, DIM_D * 2, DIM_D, 1, 1, 'D.Block.2.Shortcut', spectral_normed=True,
+                                                  update_collection=update_collection, he_init=False, biases=True)
+                        output = blocks.ConvMeanPool(h1, output_dim=DIM_D, filter_size=3, name='D.Block.2.Conv2', spectral_normed=True,
+                                                     update_collection=update_collection, he_init=True, biases=True, in_relu=True,
+                                                     residual=shortcut)
+                        prefork = 'done'
+                    else:
+                        prefork = Fn.concat_label_fork_pool(output, labels, emb_table, w_emb, b_emb)     # concat + D.Block.2's fan-out
+                        output = None
                 else:
                     output = Fn.concat_label(output, labels, emb_table, w_emb, b_emb)
             else:
@@ -181,8 +200,9 @@ def Discriminator(inputs, labels, update_collection=None, reuse=False, loss_head
                                              update_collection=update_collection, biases=True)
                 output = OptimizedResBlockDisc1(output, spectral_normed=True, update_collection=update_collection, biases=True)
                 output = Fn.concat_tile(output, embedding_y)               # expand_dims x2 + tile + concat (:282-284)
-            output = ResidualBlock(output, DIM_D * 2, DIM_D, 3, 'D.Block.2', spectral_normed=True,
-                                   update_collection=update_collection, resample='down', labels=labels, biases=True, prefork=prefork)
+            if prefork != 'done':
+                output = ResidualBlock(output, DIM_D * 2, DIM_D, 3, 'D.Block.2', spectral_normed=True,
+                                       update_collection=update_collection, resample='down', labels=labels, biases=True, prefork=prefork)
             if blocks.res_chain8_eligible(output, DIM_D, ['D.Block.3', 'D.Block.4'], labels):
                 # D.Block.3, D.Block.4 and nonlinearity + reduce_mean (:291-301) as ONE launch: an 8x8x128 sample stays in LDS
                 if HEAD_IN_CHAIN and isinstance(loss_head, Fn.HingeHeadSpec) and not (CONDITIONAL and ACGAN):

@@ -35,7 +35,7 @@ class WgradItem(C.Structure):
 
 class SlabJob(C.Structure):
     """gank_slab_job"""
-    _fields_ = [("slabs", P), ("out", P), ("n", L), ("stride", L), ("nslabs", I), ("scale", F), ("fold", I)]
+    _fields_ = [("slabs", P), ("out", P), ("n", L), ("stride", L), ("nslabs", I), ("scale", F), ("fold", I), ("out_run", L), ("out_pitch", L)]
 
 
 class PrepDesc(C.Structure):
@@ -114,6 +114,8 @@ PROTOTYPES = {
     "gank_convpool3x3_wgrad_job": [P, P, P, P, P, L, I, I, I, I, I, I, C.POINTER(SlabJob), P],
     "gank_conv2d_wgrad_slab_elems": [I, I, I, I, I, I, I],
     "gank_conv2d_wgrad_slabs": [P, P, P, P, I, I, I, I, I, I, I, F, P, L, C.POINTER(SlabJob), P],
+    "gank_conv2d_wgrad_slab_splits": [I, I, I, I, I, I, I],
+    "gank_conv2d_wgrad_slabs_rows": [P, P, P, P, I, I, I, I, I, I, I, I, F, P, L, C.POINTER(SlabJob), P],
     "gank_conv2d_wgrad_batched_ws_elems": [I, I, I, I, I, I, I, I],
     "gank_conv2d_wgrad_batched_slabs": [C.POINTER(WgradItem), I, I, I, I, I, I, I, I, F, P, L, C.POINTER(SlabJob), P],
     "gank_deconv2d_prep_phases": [P, P, I, I, I, P],
@@ -137,8 +139,8 @@ PROTOTYPES = {
     "gank_label_dense_bwd": [P, P, P, P, P, P, P, I, I, I, I, P],
     "gank_concat_label_pool_fwd": [P, P, P, P, P, I, I, I, I, I, I, P],
     "gank_concat_label_unpool_bwd": [P, P, P, P, I, I, I, I, I, P],
-    "gank_concat_label_unpool_bwd_factored": [P, P, P, P, P, I, I, I, I, I, I, P],
-    "gank_label_conv3x3_table": [P, I, I, I, I, P, I, P, P, P],
+    "gank_concat_label_unpool_bwd_factored": [P, P, P, P, P, I, P, P, I, I, I, I, I, I, P],
+    "gank_label_conv3x3_table": [P, I, I, I, I, P, I, P, P, P, I, P, P],
     "gank_img16_conv3x3_label_bias": [P, P, P, P, I, P, I, I, I, I, P],
     "gank_label_conv3x3_bwd_ws_floats": [I, I],
     "gank_label_conv3x3_bwd": [P, P, P, I, P, I, I, I, I, I, I, I, P, P, P, P, P],

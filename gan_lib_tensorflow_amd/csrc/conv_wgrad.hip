@@ -1296,11 +1296,11 @@ static int launch_wgrad_taps_mode(WgradArgs a, hipStream_t s) {
 #endif
   static const std::string tag = gank_format("conv_wgrad_taps_kernel<%d, 2> + wgrad_reduce_slabs_kernel", MODE);     // magic static: built once, thread-safe
   static const std::string tag_deferred = gank_format("conv_wgrad_taps_kernel<%d, 2>", MODE);      // (the slab reduction is a job of the caller's summing launch)
-  gank_prof_tag(1, (a.ws && a.slab_job && a.splits <= 16) ? tag_deferred.c_str() : tag.c_str());
+  gank_prof_tag(1, (a.ws && a.slab_job && a.splits <= 32) ? tag_deferred.c_str() : tag.c_str());
   a.xcd = wgrad_xcd_env();
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_ci * a.tiles_co * a.splits)), dim3(256), lds, s, a);
   GANK_LAUNCH_OK("conv_wgrad_taps");
-  if (a.ws && a.slab_job && a.splits <= 16) {       // the caller sums the slabs later, with other producers' (gank_sum_slabs)
+  if (a.ws && a.slab_job && a.splits <= 32) {       // the caller sums the slabs later, with other producers' (gank_sum_slabs)
     *a.slab_job = gank_slab_job{a.ws, a.dw, slab, slab, a.splits, 1.0f, 0};
   } else if (a.ws) {
     const long n4 = slab / 4;
@@ -1795,6 +1795,31 @@ extern "C" long gank_conv2d_wgrad_slab_elems(int N, int H, int W, int Cin, int C
   // 8.6 us and a slab store + their share of the summing launch costs as much; the 256 -> 256 shortcut's 64 slabs are 16.8 MB.
   if (!(Cin <= 4 || Cout <= 4) || ksize * ksize * (Cin <= 4 ? Cin : Cout) > 32) return 0;
   return 256 * dw_elems;
+}
+// pixel splits of the all-taps kernel's deferred slab form for this layer (0: another kernel, or more than gank_sum_slabs' wide path takes)
+extern "C" int gank_conv2d_wgrad_slab_splits(int N, int H, int W, int Cin, int Cout, int ksize, int flags) {
+  WgradArgs a{};
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.pad = (ksize - 1) / 2; a.flags = flags;
+  const bool xup = flags & GANK_IN_UPSAMPLE2X, dyup = flags & GANK_DY_UPSAMPLE2X;
+  a.Hx = xup ? H / 2 : H; a.Wx = xup ? W / 2 : W; a.Hdy = dyup ? H / 2 : H; a.Wdy = dyup ? W / 2 : W;
+  a.M = N * H * W; a.sw = log2_or_neg(W); a.shw = log2_or_neg(H * W);
+  static const int taps_env = gank_tune("GANK_WGRAD_TAPS", 1);
+  if (!taps_env || !wgrad_taps_ok(a)) return 0;
+  wgrad_taps_geometry(a);
+  return (a.splits > 1 && a.splits <= 32) ? a.splits : 0;
+}
+extern "C" int gank_conv2d_wgrad_slabs_rows(const void* x, const void* dy, float* dw_full, float* dbias, int N, int H, int W, int Cin, int Cin_total,
+                                            int Cout, int ksize, int flags, float scale, float* slab_ws, long slab_elems, gank_slab_job* job, void* stream) {
+  GANK_REQUIRE(slab_ws && job && slab_elems > 0 && dw_full && Cin_total >= Cin, "conv2d_wgrad_slabs_rows: bad arguments");
+  const int splits = gank_conv2d_wgrad_slab_splits(N, H, W, Cin, Cout, ksize, flags);
+  GANK_REQUIRE(splits > 0 && slab_elems >= (long)ksize * ksize * Cin * Cout * splits && (Cin * Cout) % 4 == 0 && ((long)Cin_total * Cout) % 4 == 0 && scale == 1.0f,
+               "conv2d_wgrad_slabs_rows: this layer has no deferred slab form (gank_conv2d_wgrad_slab_splits = %d)", splits);
+  *job = gank_slab_job{nullptr, dw_full, (long)ksize * ksize * Cin * Cout, (long)ksize * ksize * Cin * Cout, 0, scale, 0, 0, 0};
+  if (conv2d_wgrad_impl(x, dy, dw_full, dbias, nullptr, 0, N, H, W, Cin, Cout, ksize, flags, scale, slab_ws, slab_elems, job, stream)) return 1;
+  GANK_REQUIRE(job->nslabs > 0, "conv2d_wgrad_slabs_rows: the launch did not leave its reduction to the job");
+  job->out_run = (long)Cin * Cout;
+  job->out_pitch = (long)Cin_total * Cout;
+  return 0;
 }
 extern "C" int gank_conv2d_wgrad_slabs(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int Cin, int Cout, int ksize,
                                        int flags, float scale, float* slab_ws, long slab_elems, gank_slab_job* job, void* stream) {

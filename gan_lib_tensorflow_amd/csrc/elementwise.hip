@@ -442,26 +442,31 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(SlabJobTable t) {
     reinterpret_cast<f32x4*>(jb.out)[(long)tap * plane4 + e] = o;
     return;
   }
-  if (jb.nslabs <= 16) {
+  if (jb.nslabs <= 32) {
     const long i0 = ((long)lb * 256 + tid) * 4;
     if (i0 >= jb.n) return;
+    // (out_run: runs of out_run outputs, out_pitch apart -- both multiples of 4, so a thread's four outputs share a run)
+    float* op = jb.out + (jb.out_run > 0 ? (i0 / jb.out_run) * jb.out_pitch + i0 % jb.out_run : i0);
     if (i0 + 4 <= jb.n && (jb.stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(sl) | reinterpret_cast<uintptr_t>(jb.out)) & 15) == 0) {
-      f32x4 v[16];
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int b0 = 0; b0 < jb.nslabs; b0 += 16) {          // batches of 16 independent loads, slabs in ascending order
+        f32x4 v[16];
 #pragma unroll
-      for (int u = 0; u < 16; u++) v[u] = *reinterpret_cast<const f32x4*>(sl + (long)min(u, jb.nslabs - 1) * jb.stride + i0);
-      f32x4 acc = v[0];
+        for (int u = 0; u < 16; u++) v[u] = *reinterpret_cast<const f32x4*>(sl + (long)min(b0 + u, jb.nslabs - 1) * jb.stride + i0);
+        if (b0 == 0) acc = v[0];
 #pragma unroll
-      for (int u = 1; u < 16; u++)
-        if (u < jb.nslabs) { acc[0] += v[u][0]; acc[1] += v[u][1]; acc[2] += v[u][2]; acc[3] += v[u][3]; }
-      f32x4 o = *reinterpret_cast<const f32x4*>(jb.out + i0);
+        for (int u = 0; u < 16; u++)
+          if ((b0 > 0 || u > 0) && b0 + u < jb.nslabs) { acc[0] += v[u][0]; acc[1] += v[u][1]; acc[2] += v[u][2]; acc[3] += v[u][3]; }
+      }
+      f32x4 o = *reinterpret_cast<const f32x4*>(op);
 #pragma unroll
       for (int e = 0; e < 4; e++) o[e] += jb.scale * acc[e];
-      *reinterpret_cast<f32x4*>(jb.out + i0) = o;
+      *reinterpret_cast<f32x4*>(op) = o;
     } else {
       for (long i = i0; i < min(i0 + 4, jb.n); i++) {
         float acc = 0.f;
         for (int u = 0; u < jb.nslabs; u++) acc += sl[(long)u * jb.stride + i];
-        jb.out[i] += jb.scale * acc;
+        op[i - i0] += jb.scale * acc;
       }
     }
     return;
@@ -495,7 +500,9 @@ extern "C" int gank_sum_slabs(const gank_slab_job* jobs, int count, void* stream
                    "sum_slabs: fold job %d needs n %% 36 == 0 and 16-byte aligned buffers", base + i);
       t.j[i] = j;
       t.first_block[i] = blocks;
-      blocks += j.fold ? (int)((j.n / 4 + 255) / 256) : (j.nslabs <= 16 ? (int)((j.n + 1023) / 1024) : (int)((j.n + 63) / 64));
+      GANK_REQUIRE(j.out_run == 0 || (!j.fold && j.nslabs <= 32 && j.out_run % 4 == 0 && j.out_pitch % 4 == 0 && j.out_pitch >= j.out_run && j.n % j.out_run == 0),
+                   "sum_slabs: job %d: strided outputs need a plain sum of <= 32 slabs and runs / pitches that are multiples of 4", base + i);
+      blocks += j.fold ? (int)((j.n / 4 + 255) / 256) : (j.nslabs <= 32 ? (int)((j.n + 1023) / 1024) : (int)((j.n + 63) / 64));
     }
     t.first_block[t.count] = blocks;
     hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t);
@@ -797,10 +804,13 @@ __global__ void concat_label_pool_fwd_kernel(const bf16* __restrict__ a, const b
 // backward of the pair: dy = g_main + 0.25 * unpool(g_pool) (unpool2x2_add's arithmetic) is never written -- its first C1
 // channels go straight to da, the tiled half is summed over the sample's pixels into de32 (block of 1024 threads per sample)
 // gm_c1: g_main holds the first C1 channels only (the consumer of the tiled half was factored out: label_conv.hip) and that
-// consumer's gradient of the tiled vector arrives as de_parts partial sums [de_parts][N][C2], added in ascending order.
+// consumer's gradient of the tiled vector arrives SUMMED PER LABEL as de_parts partial sums [de_parts][V][C2]: added, in ascending
+// order, to the row of the label's first sample (lists: row v = {count, samples of label v ascending}; de's consumers add the
+// samples of a label anyway).
 __global__ __launch_bounds__(1024) void concat_label_unpool_bwd_kernel(const bf16* __restrict__ gm, const bf16* __restrict__ gp, bf16* __restrict__ da,
                                                                       float* __restrict__ de, int H, int W, int C1, int C2,
-                                                                      int gm_c1, const float* __restrict__ de_add, int de_parts, int N) {
+                                                                      int gm_c1, const float* __restrict__ de_add, int de_parts, int N,
+                                                                      const int* __restrict__ labels, const int* __restrict__ lists, int V) {
   constexpr int NT = 1024;
   const int n = blockIdx.x, C = C1 + C2, HW = H * W, Wp = W >> 1;
   const int cg = C >> 3, cg1 = C1 >> 3, cg2 = C2 >> 3;
@@ -835,7 +845,12 @@ __global__ __launch_bounds__(1024) void concat_label_unpool_bwd_kernel(const bf1
     const int gg = cg1 + (c >> 3);
     float t = 0.f;
     for (int l = 0; l < RL; l++) t += red[(l * cg + gg) * 8 + (c & 7)];
-    for (int p = 0; p < de_parts; p++) t += de_add[((long)p * N + n) * C2 + c];
+    if (de_parts > 0) {
+      int lb = labels[n];
+      lb = lb < 0 ? 0 : (lb >= V ? V - 1 : lb);
+      if (lists[(long)lb * (N + 1) + 1] == n)
+        for (int p = 0; p < de_parts; p++) t += de_add[((long)p * V + lb) * C2 + c];
+    }
     de[(long)n * C2 + c] = t;
   }
   (void)cg2;
@@ -955,19 +970,21 @@ extern "C" int gank_concat_label_unpool_bwd(const void* g_main, const void* g_po
   GANK_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && H % 2 == 0 && W % 2 == 0 && 1024 % ((C1 + C2) / 8) == 0,
                "concat_label_unpool_bwd: unsupported shape (%d + %d channels, %d x %d)", C1, C2, H, W);
   hipLaunchKernelGGL(concat_label_unpool_bwd_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, (const bf16*)g_main, (const bf16*)g_pooled,
-                     (bf16*)da, de32, H, W, C1, C2, 0, (const float*)nullptr, 0, N);
+                     (bf16*)da, de32, H, W, C1, C2, 0, (const float*)nullptr, 0, N, (const int*)nullptr, (const int*)nullptr, 0);
   GANK_LAUNCH_OK("concat_label_unpool_bwd");
   return 0;
 }
 // the same where the consumer of the tiled half was factored out (gank_label_conv3x3_*): g_main_c1 [N,H,W,C1] is the gradient of the
-// first C1 channels only, de_add [de_parts][N][C2] that consumer's gradient of the tiled vector (partial sums, added in order)
+// first C1 channels only, de_add [de_parts][V][C2] that consumer's gradient of the tiled vector per LABEL (partial sums, added in
+// order to the label's first sample: labels [N], lists from gank_label_conv3x3_table)
 extern "C" int gank_concat_label_unpool_bwd_factored(const void* g_main_c1, const void* g_pooled, void* da, float* de32, const float* de_add, int de_parts,
-                                                     int N, int H, int W, int C1, int C2, void* stream) {
-  GANK_REQUIRE(g_main_c1 && g_pooled && da && de32 && N > 0 && H > 0 && W > 0 && (de_parts == 0 || de_add), "concat_label_unpool_bwd_factored: bad arguments");
+                                                     const int32_t* labels, const int32_t* lists, int V, int N, int H, int W, int C1, int C2, void* stream) {
+  GANK_REQUIRE(g_main_c1 && g_pooled && da && de32 && N > 0 && H > 0 && W > 0 && (de_parts == 0 || (de_add && labels && lists && V > 0)),
+               "concat_label_unpool_bwd_factored: bad arguments");
   GANK_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && H % 2 == 0 && W % 2 == 0 && 1024 % ((C1 + C2) / 8) == 0,
                "concat_label_unpool_bwd_factored: unsupported shape (%d + %d channels, %d x %d)", C1, C2, H, W);
   hipLaunchKernelGGL(concat_label_unpool_bwd_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, (const bf16*)g_main_c1, (const bf16*)g_pooled,
-                     (bf16*)da, de32, H, W, C1, C2, 1, de_add, de_parts, N);
+                     (bf16*)da, de32, H, W, C1, C2, 1, de_add, de_parts, N, labels, lists, V);
   GANK_LAUNCH_OK("concat_label_unpool_bwd_factored");
   return 0;
 }

@@ -14,7 +14,9 @@
 //             (gank_img16_conv3x3_label_bias);
 //   backward: S[n][t][co] = sum of dy[n, p, co] over the pixels p where tap t is valid (one pass over dy), then
 //             dW[t][c0+c][co] += sum_n r_n[c] S[n][t][co]   and   de[n][c] = relu'(T[label_n][c]) sum_{t,co} bf16(W[t][c0+c][co]) S[n][t][co]
-//             (gank_label_conv3x3_bwd; de leaves as 9 per-tap partials the consumer adds in a fixed order).
+//             (gank_label_conv3x3_bwd; de leaves as 9 per-tap partials [9][V][C2] SUMMED OVER THE SAMPLES OF A LABEL -- r and the mask
+//             depend on the label alone, and so do de's consumers; gank_concat_label_unpool_bwd_factored adds them, in a fixed order,
+//             to the row of the label's first sample).
 #include "gank_common.h"
 
 namespace {
@@ -26,81 +28,156 @@ __device__ __forceinline__ bool tap_valid(int t, int cls) {
 }
 }  // namespace
 
-// grid = V * 9 (label, class), 256 threads over the output channels
-__global__ __launch_bounds__(256) void label_conv_table_kernel(const float* __restrict__ w, int Cin_total, int c0, int C2, int Cout,
-                                                             const bf16* __restrict__ T, const float* __restrict__ bias, float* __restrict__ out) {
+// block = (label v, 64 output channels), thread = (tap t, channel co): 128-deep dot products with 16 loads in flight (the first form --
+// a block per (label, class) walking every valid tap, 1152 dependent-ish loads per thread -- took 46 us), the nine per-tap sums meet
+// in LDS and thread (class, co) adds the taps valid in its class.
+// lists (optional, int32 [V][N + 1]): row v = {count, the samples of label v in ascending order} -- what the backward launches walk
+// (built by the first channel block of every label: a deterministic rank per sample)
+__global__ __launch_bounds__(576) void label_conv_table_kernel(const float* __restrict__ w, int Cin_total, int c0, int C2, int Cout,
+                                                             const bf16* __restrict__ T, const float* __restrict__ bias, float* __restrict__ out,
+                                                             const int* __restrict__ labels, int N, int V, int* __restrict__ lists) {
   __shared__ float r[1024];
-  const int v = blockIdx.x / 9, cls = blockIdx.x - 9 * v;
-  for (int c = threadIdx.x; c < C2; c += 256) r[c] = fmaxf(bf2f(T[(long)v * C2 + c]), 0.f);
-  __syncthreads();
-  for (int co = threadIdx.x; co < Cout; co += 256) {
-    float acc = 0.f;
-    for (int t = 0; t < 9; t++) {
-      if (!tap_valid(t, cls)) continue;          // block-uniform
-      const float* wp = w + ((long)t * Cin_total + c0) * Cout + co;
-      float a4[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int c = 0; c < C2; c += 4) {          // four independent chains (C2 % 4 == 0)
-#pragma unroll
-        for (int u = 0; u < 4; u++) a4[u] += bf2f(f2bf(wp[(long)(c + u) * Cout])) * r[c + u];
-      }
-      acc += (a4[0] + a4[1]) + (a4[2] + a4[3]);
+  __shared__ float P[9][64];
+  __shared__ int lab[1024];
+  const int nco = (Cout + 63) / 64;
+  const int v = blockIdx.x / nco, cb = (blockIdx.x - v * nco) * 64;
+  const int t = threadIdx.x >> 6, col = threadIdx.x & 63;
+  if (lists && cb == 0) {
+    for (int i = threadIdx.x; i < N; i += 576) {
+      const int lb = labels[i];
+      lab[i] = lb < 0 ? 0 : (lb >= V ? V - 1 : lb);
     }
-    out[((long)v * 9 + cls) * Cout + co] = acc + (bias ? bias[co] : 0.f);
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += 576)
+      if (lab[i] == v) {
+        int rank = 0;
+        for (int j = 0; j < i; j++) rank += lab[j] == v ? 1 : 0;
+        lists[(long)v * (N + 1) + 1 + rank] = i;
+      }
+    if (threadIdx.x == 0) {
+      int cnt = 0;
+      for (int j = 0; j < N; j++) cnt += lab[j] == v ? 1 : 0;
+      lists[(long)v * (N + 1)] = cnt;
+    }
   }
+  const int co = cb + col < Cout ? cb + col : Cout - 1;
+  for (int c = threadIdx.x; c < C2; c += 576) r[c] = fmaxf(bf2f(T[(long)v * C2 + c]), 0.f);
+  __syncthreads();
+  const float* wp = w + ((long)t * Cin_total + c0) * Cout + co;
+  float acc = 0.f;
+  for (int c = 0; c < C2; c += 16) {            // C2 % 16 == 0 (64 loads in flight measured slower: 13.8 against 9.4 us)
+    float x[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) x[u] = wp[(long)(c + u) * Cout];
+#pragma unroll
+    for (int u = 0; u < 16; u++) acc += bf2f(f2bf(x[u])) * r[c + u];
+  }
+  P[t][col] = acc;
+  __syncthreads();
+  const int cls = t;                            // the same 576 threads as (class, channel)
+  float sum = 0.f;
+#pragma unroll
+  for (int tt = 0; tt < 9; tt++) sum += tap_valid(tt, cls) ? P[tt][col] : 0.f;
+  if (cb + col < Cout) out[((long)v * 9 + cls) * Cout + cb + col] = sum + (bias ? bias[cb + col] : 0.f);
 }
 
 extern "C" int gank_label_conv3x3_table(const float* w, int Cin_total, int c0, int C2, int Cout, const void* T, int V, const float* bias,
-                                        float* bias_table, void* stream) {
-  GANK_REQUIRE(w && T && bias_table && V > 0 && C2 > 0 && C2 <= 1024 && C2 % 4 == 0 && c0 >= 0 && c0 + C2 <= Cin_total && Cout > 0,
+                                        float* bias_table, const int32_t* labels, int N, int32_t* lists, void* stream) {
+  GANK_REQUIRE(w && T && bias_table && V > 0 && C2 > 0 && C2 <= 1024 && C2 % 16 == 0 && c0 >= 0 && c0 + C2 <= Cin_total && Cout > 0,
                "label_conv3x3_table: bad arguments");
-  hipLaunchKernelGGL(label_conv_table_kernel, dim3(V * 9), dim3(256), 0, (hipStream_t)stream, w, Cin_total, c0, C2, Cout, (const bf16*)T, bias, bias_table);
+  GANK_REQUIRE(!lists || (labels && N > 0 && N <= 1024), "label_conv3x3_table: the sample lists need the labels of 1..1024 samples");
+  hipLaunchKernelGGL(label_conv_table_kernel, dim3(V * ((Cout + 63) / 64)), dim3(576), 0, (hipStream_t)stream, w, Cin_total, c0, C2, Cout, (const bf16*)T, bias,
+                     bias_table, labels, N, V, lists);
   GANK_LAUNCH_OK("label_conv3x3_table");
   return 0;
 }
 
-// S[n][t][co]: block = sample, thread = (8-channel group g, pixel lane pl); 16-byte loads, nine predicated accumulators, the pixel
-// lanes of a channel group meet in LDS in a fixed order.  H x W pixels per sample (row-major), Cout % 8 == 0, 256 % (Cout / 8) == 0.
-__global__ __launch_bounds__(256) void label_conv_tap_sums_kernel(const bf16* __restrict__ dy, float* __restrict__ S, int H, int W, int Cout) {
-  extern __shared__ __attribute__((aligned(16))) float red[];         // [PL][9][Cout]
-  const int n = blockIdx.x, cg = Cout >> 3, PL = 256 / cg;
-  const int g = threadIdx.x % cg, pl = threadIdx.x / cg;
+// Sl[half][v][t][co] = sum over the samples n of label v and the pixels p of the row half where tap t is valid of dy[n, p, co].
+// block = (label v, half of the rows, 64 output channels): it lists the label's samples in ascending order (deterministic), adds
+// their rows per PIXEL first (thread = (8-channel group, pixel lane), four samples = 16 sixteen-byte loads in flight) and applies
+// the nine tap masks once at the end; the pixel lanes meet in LDS in a fixed order.  The per-sample form of this pass (a block
+// per sample, the label sums left to the consumer) made the consumer walk 128 samples per block: 12 + 29 us; this one feeds it
+// V x 9 x Cout numbers.  H x W pixels per sample (H even, (H / 2) * W % 32 == 0), Cout % 64 == 0.
+__global__ __launch_bounds__(256) void label_conv_tap_sums_kernel(const bf16* __restrict__ dy, const int* __restrict__ lists, float* __restrict__ S,
+                                                                int N, int V, int H, int W, int Cout) {
+  // (a 512-thread form -- 64 pixel lanes, 16 samples per batch, the lanes of a wave meeting by shuffles -- measured 18.8 us against 11.4)
+  extern __shared__ __attribute__((aligned(16))) float red[];         // [32 pixel lanes][9][64]
+  const int nchunk = Cout >> 6;
+  int b = blockIdx.x;
+  const int cb = (b % nchunk) * 64; b /= nchunk;
+  const int half = b & 1, v = b >> 1;
+  const int tid = threadIdx.x, g = tid & 7, pl = tid >> 3;
+  const int* list = lists + (long)v * (N + 1) + 1;
+  const int cnt = lists[(long)v * (N + 1)];
+  const int HW = H * W, hp = HW >> 1, p0 = half * hp;
+  const int KP = hp >> 5;                                             // pixels per thread (4 at 16 x 16)
+  float dl[4][8];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) dl[k][e] = 0.f;
+  for (int sb = 0; sb < cnt; sb += 8) {
+    bf16x8 x[8][4];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int n = list[sb + u < cnt ? sb + u : cnt - 1];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int p = p0 + pl + 32 * (k < KP ? k : 0);
+        x[u][k] = *reinterpret_cast<const bf16x8*>(dy + ((long)n * HW + p) * Cout + cb + g * 8);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const float on = sb + u < cnt ? 1.f : 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) dl[k][e] += on * bf2f(x[u][k][e]);
+    }
+  }
   float acc[9][8];
 #pragma unroll
   for (int t = 0; t < 9; t++)
 #pragma unroll
     for (int e = 0; e < 8; e++) acc[t][e] = 0.f;
-  const int HW = H * W;
-  for (int p = pl; p < HW; p += PL) {
-    const int y = p / W, x = p - y * W;
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(dy + ((long)n * HW + p) * Cout + g * 8);
-    float f[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) f[e] = bf2f(v[e]);
-    // tap (kh, kw) is valid at this pixel when its input pixel (y + kh - 1, x + kw - 1) is inside
-    const bool rv[3] = {y > 0, true, y < H - 1}, cv[3] = {x > 0, true, x < W - 1};
+  for (int k = 0; k < 4; k++) {
+    if (k < KP) {
+      const int p = p0 + pl + 32 * k, y = p / W, x = p - y * W;
+      // tap (kh, kw) is valid at this pixel when its input pixel (y + kh - 1, x + kw - 1) is inside
+      const bool rv[3] = {y > 0, true, y < H - 1}, cv[3] = {x > 0, true, x < W - 1};
 #pragma unroll
-    for (int t = 0; t < 9; t++) {
-      const float m = (rv[t / 3] && cv[t % 3]) ? 1.f : 0.f;
+      for (int t = 0; t < 9; t++) {
+        const float m = (rv[t / 3] && cv[t % 3]) ? 1.f : 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; e++) acc[t][e] += m * f[e];
+        for (int e = 0; e < 8; e++) acc[t][e] += m * dl[k][e];
+      }
     }
   }
 #pragma unroll
   for (int t = 0; t < 9; t++)
 #pragma unroll
-    for (int e = 0; e < 8; e++) red[((long)pl * 9 + t) * Cout + g * 8 + e] = acc[t][e];
+    for (int e = 0; e < 8; e++) red[((long)pl * 9 + t) * 64 + g * 8 + e] = acc[t][e];
   __syncthreads();
-  for (int i = threadIdx.x; i < 9 * Cout; i += 256) {
-    float s = 0.f;
-    for (int l = 0; l < PL; l++) s += red[(long)l * 9 * Cout + i];
-    S[(long)n * 9 * Cout + i] = s;
+  for (int i = tid; i < 9 * 64; i += 256) {
+    float sum = 0.f;
+    for (int l = 0; l < 32; l++) sum += red[(long)l * 9 * 64 + i];
+    const int t = i >> 6, c = i & 63;
+    S[(((long)half * V + v) * 9 + t) * Cout + cb + c] = sum;
   }
 }
 
-// block = (tap t, tile of CT channels of the constant half): the whole S[:, t, :] (N x Cout fp32, padded rows) and the tile's
-// weights in LDS.  Threads = output channels for the filter gradient, then (sample, channel group) for the vector gradient.
-constexpr int LCB_CT = 16;
-__global__ __launch_bounds__(256) void label_conv_bwd_kernel(const float* __restrict__ S, const int* __restrict__ labels, const bf16* __restrict__ T, int V,
+// block = (tap t, tile of CT channels of the constant half), 256 threads.  The per-tap sums enter only through their sums per LABEL
+// (r and the relu mask depend on a sample through its label alone): thread co adds S[n][t][co] of the samples of each label (registers,
+// predicated; loads in batches of 16), then
+//   dw[t][c0 + c][co] += sum_v relu(T[v][c]) Sl[v][co]                                                   (this block is the only writer of its rows)
+//   de_parts[t][first sample of label v][c] = [T[v][c] > 0] sum_co bf16(w[t][c0 + c][co]) Sl[v][co]      (zero for every other sample)
+// -- the gradient of the tiled vector leaves SUMMED PER LABEL, parked at the label's first sample: its consumers (the label branch's
+// dense layer and embedding table) add the samples of a label anyway.  (The first form kept S[:, t, :] in LDS and walked it per
+// sample: 59 us, LDS-bound.)
+constexpr int LCB_CT = 16, LCB_V = 16;
+__global__ __launch_bounds__(256) void label_conv_bwd_kernel(const float* __restrict__ S, const int* __restrict__ lists, const bf16* __restrict__ T, int V,
                                                            const float* __restrict__ w, int Cin_total, int c0, int C2, int Cout, int N,
                                                            float* __restrict__ dw, float* __restrict__ de_parts,
                                                            float* __restrict__ dw_feat_tmp, int merge_blocks) {
@@ -119,73 +196,78 @@ __global__ __launch_bounds__(256) void label_conv_bwd_kernel(const float* __rest
     return;
   }
   const int t = blockIdx.x / tiles, ct = blockIdx.x - t * tiles;
-  const int SP = Cout + 1;                               // padded row: thread n walks row n without bank conflicts
-  float* Ss = sm;                                        // [N][Cout + 1]
-  float* Ws = Ss + (long)N * SP;                         // [CT][Cout]  (bf16-rounded, as the MFMA operand was)
-  float* Rs = Ws + LCB_CT * Cout;                        // [V][CT]     relu(T), and the relu mask below
-  int* Lb = reinterpret_cast<int*>(Rs + V * LCB_CT);     // [N]
-  for (int i = tid; i < N * Cout; i += 256) {
-    const int n = i / Cout, co = i - n * Cout;
-    Ss[(long)n * SP + co] = S[((long)n * 9 + t) * Cout + co];
+  const int SP = Cout + 4;                               // padded rows (16-byte aligned)
+  float* Sl = sm;                                        // [V][SP]     per-label sums of this tap
+  float* Ws = Sl + (long)V * SP;                         // [CT][SP]    (bf16-rounded, as the MFMA operand was)
+  float* Rs = Ws + (long)LCB_CT * SP;                    // [V][CT]     relu(T)
+  // Cout <= 256 (host check): one output channel per thread.  EVERY global load of the block is requested before the first wait:
+  // the tile's filter rows, the per-label sums of both row halves, the gradient rows this block adds to (three dependent round
+  // trips of 2 us each otherwise)
+  const int co = tid < Cout ? tid : Cout - 1;
+  float wreg[LCB_CT], dold[LCB_CT], sl[LCB_V];
+#pragma unroll
+  for (int j = 0; j < LCB_CT; j++) wreg[j] = w[((long)t * Cin_total + c0 + ct * LCB_CT + j) * Cout + co];
+#pragma unroll
+  for (int v = 0; v < LCB_V; v++) {
+    const int vv = v < V ? v : V - 1;
+    const float a = S[((long)vv * 9 + t) * Cout + co] + S[(((long)V + vv) * 9 + t) * Cout + co];      // the two row halves
+    sl[v] = v < V ? a : 0.f;
   }
-  for (int i = tid; i < LCB_CT * Cout; i += 256) {
-    const int j = i / Cout, co = i - j * Cout;
-    Ws[i] = bf2f(f2bf(w[((long)t * Cin_total + c0 + ct * LCB_CT + j) * Cout + co]));
-  }
+#pragma unroll
+  for (int j = 0; j < LCB_CT; j++) dold[j] = dw[((long)t * Cin_total + c0 + ct * LCB_CT + j) * Cout + co];
   for (int i = tid; i < V * LCB_CT; i += 256) Rs[i] = fmaxf(bf2f(T[(long)(i / LCB_CT) * C2 + ct * LCB_CT + (i % LCB_CT)]), 0.f);
-  for (int i = tid; i < N; i += 256) {
-    const int lb = labels[i];
-    Lb[i] = lb < 0 ? 0 : (lb >= V ? V - 1 : lb);
+  if (tid < Cout) {
+#pragma unroll
+    for (int j = 0; j < LCB_CT; j++) Ws[(long)j * SP + tid] = bf2f(f2bf(wreg[j]));
+#pragma unroll
+    for (int v = 0; v < LCB_V; v++)
+      if (v < V) Sl[(long)v * SP + tid] = sl[v];
   }
   __syncthreads();
-  // filter gradient: dw[t][c0 + c][co] += sum_n r_n[c] S[n][t][co]   (this block is the only writer of its rows)
-  for (int co = tid; co < Cout; co += 256) {
-    float acc[LCB_CT];
+  if (tid < Cout) {
+    // filter gradient of this block's CT rows: dw[t][c0 + c][co] += sum_v relu(T[v][c]) Sl[v][co]   (this block is their only writer)
 #pragma unroll
-    for (int j = 0; j < LCB_CT; j++) acc[j] = 0.f;
-    for (int n = 0; n < N; n++) {
-      const float s = Ss[(long)n * SP + co];
-      const float* rr = Rs + Lb[n] * LCB_CT;
+    for (int v = 0; v < LCB_V; v++)
+      if (v < V) {
 #pragma unroll
-      for (int j = 0; j < LCB_CT; j++) acc[j] += rr[j] * s;
-    }
+        for (int j = 0; j < LCB_CT; j++) dold[j] += Rs[v * LCB_CT + j] * sl[v];
+      }
 #pragma unroll
-    for (int j = 0; j < LCB_CT; j++) dw[((long)t * Cin_total + c0 + ct * LCB_CT + j) * Cout + co] += acc[j];
+    for (int j = 0; j < LCB_CT; j++) dw[((long)t * Cin_total + c0 + ct * LCB_CT + j) * Cout + tid] = dold[j];
   }
-  // vector gradient, this tap's share: de_parts[t][n][c] = [T[label_n][c] > 0] sum_co W[t][c0 + c][co] S[n][t][co]
-  for (int i = tid; i < N * (LCB_CT / 8); i += 256) {
-    const int n = i % N, jh = i / N;
-    float acc[8];
+  // gradient of the tiled vector, this tap's and tile's share per LABEL: thread (v, channel j of the tile)
+  if (tid < V * LCB_CT) {
+    const int v = tid / LCB_CT, j = tid - v * LCB_CT;
+    f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4* wr = reinterpret_cast<const f32x4*>(Ws + (long)j * SP);
+    const f32x4* sr = reinterpret_cast<const f32x4*>(Sl + (long)v * SP);
+#pragma unroll 8
+    for (int q = 0; q < (Cout >> 2); q++) {
+      const f32x4 a = wr[q], b2 = sr[q];
 #pragma unroll
-    for (int j = 0; j < 8; j++) acc[j] = 0.f;
-    const float* sr = Ss + (long)n * SP;
-    for (int co = 0; co < Cout; co++) {
-      const float s = sr[co];
-#pragma unroll
-      for (int j = 0; j < 8; j++) acc[j] += Ws[(jh * 8 + j) * Cout + co] * s;
+      for (int u = 0; u < 4; u++) a4[u] += a[u] * b2[u];
     }
-    const float* rr = Rs + Lb[n] * LCB_CT + jh * 8;
-#pragma unroll
-    for (int j = 0; j < 8; j++) de_parts[((long)t * N + n) * C2 + ct * LCB_CT + jh * 8 + j] = rr[j] > 0.f ? acc[j] : 0.f;
+    de_parts[((long)t * V + v) * C2 + ct * LCB_CT + j] = Rs[v * LCB_CT + j] > 0.f ? (a4[0] + a4[1]) + (a4[2] + a4[3]) : 0.f;
   }
+  (void)lists; (void)N;
 }
 
-extern "C" long gank_label_conv3x3_bwd_ws_floats(int N, int Cout) { return (long)N * 9 * Cout; }
+extern "C" long gank_label_conv3x3_bwd_ws_floats(int N, int Cout) { (void)N; return 2L * 16 * 9 * Cout; }      // [2 row halves][<= 16 labels][9][Cout]
 
-extern "C" int gank_label_conv3x3_bwd(const void* dy, const int32_t* labels, const void* T, int V, const float* w, int Cin_total, int c0, int C2,
+extern "C" int gank_label_conv3x3_bwd(const void* dy, const int32_t* lists, const void* T, int V, const float* w, int Cin_total, int c0, int C2,
                                       int Cout, int N, int H, int W, float* dw, float* dw_feat_tmp, float* de_parts, float* ws, void* stream) {
-  GANK_REQUIRE(dy && labels && T && w && dw && de_parts && ws && N > 0 && H > 1 && W > 1 && V > 0, "label_conv3x3_bwd: bad arguments");
+  GANK_REQUIRE(dy && lists && T && w && dw && de_parts && ws && N > 0 && H > 1 && W > 1 && V > 0, "label_conv3x3_bwd: bad arguments");
   GANK_REQUIRE(Cout % 8 == 0 && 256 % (Cout / 8) == 0 && C2 % LCB_CT == 0 && c0 >= 0 && c0 + C2 <= Cin_total, "label_conv3x3_bwd: unsupported channel counts");
   hipStream_t s = (hipStream_t)stream;
-  const int PL = 256 / (Cout / 8);
-  const size_t lds1 = (size_t)PL * 9 * Cout * sizeof(float);
-  const size_t lds2 = ((size_t)N * (Cout + 1) + (size_t)LCB_CT * Cout + (size_t)V * LCB_CT) * sizeof(float) + (size_t)N * sizeof(int);
-  GANK_REQUIRE(lds1 <= 160 * 1024 && lds2 <= 160 * 1024, "label_conv3x3_bwd: N = %d, Cout = %d do not fit the LDS", N, Cout);
+  GANK_REQUIRE(V <= LCB_V && H % 2 == 0 && ((H / 2) * W) % 32 == 0 && (H / 2) * W <= 128 && Cout % 64 == 0 && N <= 1024,
+               "label_conv3x3_bwd: at most %d labels, 1024 samples, (H / 2) * W a multiple of 32 up to 128, Cout %% 64 == 0", LCB_V);
+  const size_t lds1 = (size_t)32 * 9 * 64 * sizeof(float);
   GANK_MAX_DYNAMIC_LDS(label_conv_tap_sums_kernel, (int)lds1, "label_conv3x3_bwd");
-  hipLaunchKernelGGL(label_conv_tap_sums_kernel, dim3(N), dim3(256), lds1, s, (const bf16*)dy, ws, H, W, Cout);
+  const size_t lds2 = ((size_t)V * (Cout + 4) + (size_t)LCB_CT * (Cout + 4) + (size_t)V * LCB_CT) * sizeof(float);
+  GANK_REQUIRE(lds2 <= 64 * 1024, "label_conv3x3_bwd: N = %d, Cout = %d do not fit the LDS", N, Cout);
+  hipLaunchKernelGGL(label_conv_tap_sums_kernel, dim3(V * 2 * (Cout / 64)), dim3(256), lds1, s, (const bf16*)dy, lists, ws, N, V, H, W, Cout);
   const int merge_blocks = dw_feat_tmp ? 64 : 0;
-  GANK_MAX_DYNAMIC_LDS(label_conv_bwd_kernel, (int)lds2, "label_conv3x3_bwd");
-  hipLaunchKernelGGL(label_conv_bwd_kernel, dim3(9 * (C2 / LCB_CT) + merge_blocks), dim3(256), lds2, s, ws, labels, (const bf16*)T, V, w, Cin_total, c0, C2, Cout,
+  hipLaunchKernelGGL(label_conv_bwd_kernel, dim3(9 * (C2 / LCB_CT) + merge_blocks), dim3(256), lds2, s, ws, lists, (const bf16*)T, V, w, Cin_total, c0, C2, Cout,
                      N, dw, de_parts, dw_feat_tmp, merge_blocks);
   GANK_LAUNCH_OK("label_conv3x3_bwd");
   return 0;

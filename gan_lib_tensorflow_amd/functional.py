@@ -1200,6 +1200,96 @@ class _ConcatLabelForkPool(Function):
         return (da if ctx.needs_input_grad[0] else None), None, dt, dw, db
 
 
+FACTOR_LABEL_CONV = True    # D.Block.2.Conv1 with the tiled (spatially constant) half of its input factored out (csrc/label_conv.hip, round 5)
+
+
+class _ConcatLabelConv1(Function):
+    """concat(a, tile(T[labels])) (gan_cifar_resnet.py:282-284) -> the fan-out of D.Block.2 with conv_1 of the main path
+    (relu -> 3x3 conv, :186-190) computed WITHOUT the concatenated tensor: -> (h1 = conv_1(relu(concat)) [N,16,16,Cout],
+    mean_pool2x2(concat) [N,8,8,C1+C2] for the pooled shortcut).  The tiled half of the input is one vector per sample, so its
+    contribution to conv_1 is a per-(label, border class) bias row (kernels.label_conv3x3_table) and the conv itself runs on the
+    C1 feature channels: half the multiply-adds in the forward pass, the input gradient and the filter gradient.  Backward: the
+    feature half's filter gradient (a slab job into its rows of the gradient), the tiled half's filter gradient and the gradient of
+    the tiled vector from nine per-tap sums of dh1 (kernels.label_conv3x3_bwd), the feature input gradient; both branch gradients
+    then meet as in _ConcatLabelForkPool."""
+
+    @staticmethod
+    def forward(ctx, a, labels, table, W_emb, b_emb, W1, b1):
+        ctx.set_materialize_grads(False)
+        T = getattr(W_emb, "_label_T", None)
+        if T is None:
+            T = K.label_dense_table(table.detach(), W_emb.detach(), b_emb.detach() if b_emb is not None else None)
+        c1, cout = a.shape[3], W1.shape[3]
+        rf, rd = W1._prep_feat
+        bt, lists = K.label_conv3x3_table(W1.detach(), c1, T, b1.detach() if b1 is not None else None, labels)
+        h1 = K.img16_conv3x3_label_bias(a, rf, bt, labels, cout, K.IN_RELU)
+        _, yp = K.concat_label_pool_fwd(a, T, labels, want_full=False)
+        ctx.save_for_backward(a, labels, table, W_emb, W1, T, lists)
+        ctx.b_emb, ctx.b1, ctx.rd = b_emb, b1, rd
+        return h1, yp
+
+    @staticmethod
+    def backward(ctx, dh1, gp):
+        a, labels, table, W_emb, W1, T, lists = ctx.saved_tensors
+        n, c1, cout = a.shape[0], a.shape[3], W1.shape[3]
+        dW = db = None
+        parts = da = None
+        need_label = ctx.needs_input_grad[2] or ctx.needs_input_grad[3] or (ctx.b_emb is not None and ctx.needs_input_grad[4])
+        if dh1 is not None:
+            g = _c(dh1)
+            btgt = None
+            if ctx.b1 is not None and ctx.needs_input_grad[6]:
+                btgt, bacc = _target(ctx.b1)
+                db = None if bacc else btgt
+            if ctx.needs_input_grad[5]:
+                tgt, acc = _target(W1)
+                tgt4 = tgt.view(3, 3, W1.shape[2], cout)
+                if SLAB_WGRADS and BATCH_SMALL_WGRADS and K.conv2d_wgrad_rows_ok(n, (16, 16), c1, cout, 3, K.IN_RELU):
+                    K.conv2d_wgrad_rows(a, g, tgt4, (16, 16), 3, K.IN_RELU, _slab_jobs, dbias=btgt)     # summed with the pass's other slabs
+                    parts = K.label_conv3x3_bwd(g, lists, T, W1.detach(), c1, tgt4)
+                else:                          # small batches: through a zero-filled staging buffer, merged by the same launch
+                    tmp = K.zeros_f32((3, 3, c1, cout), a.device)
+                    K.conv2d_wgrad(a, g, tmp, (16, 16), 3, K.IN_RELU, 1.0, dbias=btgt)
+                    parts = K.label_conv3x3_bwd(g, lists, T, W1.detach(), c1, tgt4, tmp)
+                dW = None if acc else tgt
+            else:
+                if btgt is not None:
+                    K.colsum(g, btgt, 1.0)
+                if need_label:                 # (a frozen filter with a trainable label branch: no such graph in the train steps)
+                    scratch = K.zeros_f32(tuple(W1.shape), a.device)
+                    parts = K.label_conv3x3_bwd(g, lists, T, W1.detach(), c1, scratch)
+            if ctx.needs_input_grad[0]:
+                da = K.img16_conv3x3(g, ctx.rd, None, c1, 0, a)          # relu mask of the feature half in the epilogue
+        if gp is not None:
+            if da is None:
+                da = K.zeros_bf16(tuple(a.shape), a.device) if hasattr(K, "zeros_bf16") else torch.zeros_like(a)
+            da, de32 = K.concat_label_unpool_bwd_factored(da, _c(gp), parts if need_label else None, labels, lists)
+        else:                                  # (no pooled branch: not a graph of this library; the per-label sums at each label's first sample)
+            de32 = torch.zeros((n, T.shape[1]), dtype=torch.float32, device=a.device)
+            if parts is not None:
+                pl = parts.sum(0)
+                for v in range(T.shape[0]):
+                    if int(lists[v, 0]) > 0:
+                        de32[int(lists[v, 1])] = pl[v]
+        dt = dw = dbe = None
+        if need_label:
+            dt, dw, dbe = _label_dense_grads(ctx, de32, labels, table, W_emb, ctx.b_emb)
+        return (da if ctx.needs_input_grad[0] else None), None, dt, dw, dbe, dW, db
+
+
+def concat_label_conv1(a, labels, table, W_emb, b_emb, W1, b1):
+    """-> (conv3x3(relu(concat(a, tile(T[labels]))), W1) + b1, mean_pool2x2(concat)): see _ConcatLabelConv1"""
+    return _ConcatLabelConv1.apply(a, labels, table, W_emb, b_emb, W1, b1)
+
+
+def concat_label_conv1_ok(a, W1):
+    """16x16 feature maps, a filter whose first half of input channels is `a`, and the sliced operands attached by the batched preparation"""
+    return (FACTOR_LABEL_CONV and a.is_cuda and a.dim() == 4 and tuple(a.shape[1:3]) == (16, 16) and W1.dim() == 4 and W1.shape[0] == 3
+            and W1.shape[2] == 2 * a.shape[3] and getattr(W1, "_prep_feat", None) is not None and W1._prep_feat[1] is not None
+            and K.img16_conv3x3_ok(a.shape[0], (16, 16), a.shape[3], W1.shape[3]) and W1.shape[3] % 8 == 0 and 256 % (W1.shape[3] // 8) == 0
+            and a.shape[3] % 16 == 0)
+
+
 def concat_label_fork_pool(a, labels, table, W, bias=None):
     """-> (concat(a, tile(T[labels])), its 2x2 mean): input pair of a down-sampling ResidualBlock(prefork=...)"""
     return _ConcatLabelForkPool.apply(a, labels, table, W, bias)

@@ -235,6 +235,26 @@ def conv2d_wgrad(x, dy, dw, hw, ksize, flags=0, scale=1.0, dbias=None, slab_jobs
     return dw
 
 
+def conv2d_wgrad_rows_ok(n, hw, cin, cout, ksize=3, flags=0):
+    """the layer has the deferred slab form conv2d_wgrad_rows needs"""
+    return int(lib().gank_conv2d_wgrad_slab_splits(n, hw[0], hw[1], cin, cout, ksize, flags)) > 0
+
+
+def conv2d_wgrad_rows(x, dy, dw_full, hw, ksize, flags, slab_jobs, dbias=None):
+    """filter gradient of the FIRST x.shape[3] input channels of the wider filter dw_full [k,k,Cin_total,Cout], accumulated into those
+    rows by a slab job appended to slab_jobs (gank_conv2d_wgrad_slabs_rows; the caller owes a sum_slabs(list))"""
+    n, cin, cout = x.shape[0], x.shape[3], dy.shape[3]
+    assert dw_full.dim() == 4 and dw_full.shape[3] == cout and dw_full.shape[2] >= cin and slab_jobs is not None
+    slab_elems = int(lib().gank_conv2d_wgrad_slab_elems(n, hw[0], hw[1], cin, cout, ksize, flags))
+    ws = torch.empty(max(slab_elems, 1), dtype=F32, device=x.device)
+    job = (SlabJob * 1)()
+    _lib.check(lib().gank_conv2d_wgrad_slabs_rows(_p(x, BF16, "x"), _p(dy, BF16, "dy"), _p(dw_full, F32, "dw_full"), _p(dbias, F32, "dbias"),
+                                                  n, hw[0], hw[1], cin, dw_full.shape[2], cout, ksize, flags, 1.0, _p(ws), slab_elems, job, _stream()),
+               "conv2d_wgrad_slabs_rows")
+    slab_jobs.append((job, 1, ws))
+    return dw_full
+
+
 def conv2d_wgrad_batched(items, hw, ksize, flags=0, scale=1.0, slab_jobs=None):
     """items: [(x, dy, dw, dbias | None)] of identical geometry; ACCUMULATES every dw (and dbias) in as few launches
     as possible.  slab_jobs: a list -- where the geometry has a slab form the partial tiles are written to slabs instead of
@@ -1281,30 +1301,36 @@ def concat_label_pool_fwd(a, t, labels, want_full=True):
     return y, yp
 
 
-def concat_label_unpool_bwd_factored(g_main_c1, g_pooled, de_add=None):
+def concat_label_unpool_bwd_factored(g_main_c1, g_pooled, de_add=None, labels=None, lists=None):
     """concat_label_unpool_bwd where the consumer of the tiled half was factored out: g_main_c1 [N,H,W,C1] (the first C1 channels'
-    gradient), de_add fp32 [parts,N,C2] that consumer's gradient of the tiled vector -> (da bf16 [N,H,W,C1], de32 fp32 [N,C2])"""
+    gradient), de_add fp32 [parts,V,C2] that consumer's gradient of the tiled vector per LABEL (added to the row of the label's first
+    sample: labels, lists from label_conv3x3_table) -> (da bf16 [N,H,W,C1], de32 fp32 [N,C2])"""
     n, hp, wp, c = g_pooled.shape
     c1 = g_main_c1.shape[3]
     da = torch.empty((n, 2 * hp, 2 * wp, c1), dtype=BF16, device=g_pooled.device)
     de = torch.empty((n, c - c1), dtype=F32, device=g_pooled.device)
     parts = 0 if de_add is None else de_add.shape[0]
+    v = 0 if de_add is None else de_add.shape[1]
     _lib.check(lib().gank_concat_label_unpool_bwd_factored(_p(g_main_c1, BF16, "g_main_c1"), _p(g_pooled, BF16, "g_pooled"), _p(da), _p(de),
-                                                           _p(de_add, F32, "de_add"), parts, n, 2 * hp, 2 * wp, c1, c - c1, _stream()),
+                                                           _p(de_add, F32, "de_add"), parts, _p(labels, I32, "labels"), _p(lists, I32, "lists"), v,
+                                                           n, 2 * hp, 2 * wp, c1, c - c1, _stream()),
                "concat_label_unpool_bwd_factored")
     return da, de
 
 
 # ---- the spatially constant input channels of a 3x3 conv, factored out (csrc/label_conv.hip)
-def label_conv3x3_table(w, c0, t, bias=None):
+def label_conv3x3_table(w, c0, t, bias=None, labels=None):
     """bias_table fp32 [V,9,Cout] = bias + what the constant channels c0.. of the fp32 filter w [3,3,Cin,Cout] contribute per (label,
-    border class) with the per-label vectors relu(t[v]) (t bf16 [V,C2])"""
+    border class) with the per-label vectors relu(t[v]) (t bf16 [V,C2]).  labels given: -> (bias_table, lists int32 [V,N+1]: row v =
+    {count, the samples of label v in ascending order} for the backward entries)"""
     v, c2 = t.shape
     cin, cout = w.shape[2], w.shape[3]
     out = torch.empty((v, 9, cout), dtype=F32, device=w.device)
-    _lib.check(lib().gank_label_conv3x3_table(_p(w, F32, "w"), cin, c0, c2, cout, _p(t, BF16, "T"), v, _p(bias, F32, "bias"), _p(out), _stream()),
-               "label_conv3x3_table")
-    return out
+    n = 0 if labels is None else labels.numel()
+    lists = torch.empty((v, n + 1), dtype=I32, device=w.device) if labels is not None else None
+    _lib.check(lib().gank_label_conv3x3_table(_p(w, F32, "w"), cin, c0, c2, cout, _p(t, BF16, "T"), v, _p(bias, F32, "bias"), _p(out),
+                                              _p(labels, I32, "labels"), n, _p(lists), _stream()), "label_conv3x3_table")
+    return out if labels is None else (out, lists)
 
 
 def img16_conv3x3_label_bias(x, rf, bias_table, labels, cout, flags=0):
@@ -1318,16 +1344,17 @@ def img16_conv3x3_label_bias(x, rf, bias_table, labels, cout, flags=0):
     return y
 
 
-def label_conv3x3_bwd(dy, labels, t, w, c0, dw, dw_feat_tmp=None):
+def label_conv3x3_bwd(dy, lists, t, w, c0, dw, dw_feat_tmp=None):
     """gank_label_conv3x3_bwd: ACCUMULATES the constant channels' filter gradient into rows c0.. of dw [3,3,Cin,Cout] (and adds +
-    clears dw_feat_tmp [3,3,c0,Cout] into rows 0..c0-1) -> de_parts fp32 [9,N,C2]"""
+    clears dw_feat_tmp [3,3,c0,Cout] into rows 0..c0-1) -> de_parts fp32 [9,V,C2]: the gradient of the tiled vector per tap and LABEL
+    (summed over the label's samples); lists from label_conv3x3_table(labels=...)"""
     n, h, wd_, cout = dy.shape
     v, c2 = t.shape
     cin = w.shape[2]
     assert dw.shape == w.shape and (dw_feat_tmp is None or tuple(dw_feat_tmp.shape) == (3, 3, c0, cout))
     ws = torch.empty(int(lib().gank_label_conv3x3_bwd_ws_floats(n, cout)), dtype=F32, device=dy.device)
-    parts = torch.empty((9, n, c2), dtype=F32, device=dy.device)
-    _lib.check(lib().gank_label_conv3x3_bwd(_p(dy, BF16, "dy"), _p(labels, I32, "labels"), _p(t, BF16, "T"), v, _p(w, F32, "w"), cin, c0, c2, cout, n, h, wd_,
+    parts = torch.empty((9, v, c2), dtype=F32, device=dy.device)
+    _lib.check(lib().gank_label_conv3x3_bwd(_p(dy, BF16, "dy"), _p(lists, I32, "lists"), _p(t, BF16, "T"), v, _p(w, F32, "w"), cin, c0, c2, cout, n, h, wd_,
                                             _p(dw, F32, "dw"), _p(dw_feat_tmp, F32, "dw_feat_tmp"), _p(parts), _p(ws), _stream()), "label_conv3x3_bwd")
     return parts
 

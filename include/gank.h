@@ -143,12 +143,20 @@ typedef struct gank_slab_job {
   float scale;
   int fold;        /* 0: plain sum.  1: each slab holds the SIXTEEN taps of a 4x4 stride-2 filter gradient [16][n / 9] (ConvMeanPool as one
                       conv, gank_convpool3x3_wgrad) and out the nine of the 3x3 filter: out[3i+j] += scale * sum_{s,t in {0,1}} slab[4(i+s)+j+t] */
+  long out_run;    /* 0: out is linear.  > 0 (plain sums of <= 32 slabs): output i goes to out[(i / out_run) * out_pitch + i % out_run] -- runs  */
+  long out_pitch;  /* of out_run elements out_pitch apart: the first Cin input channels of every tap of a wider filter (both % 4 == 0)   */
 } gank_slab_job;
 int gank_sum_slabs(const gank_slab_job* jobs, int count, void* stream);    /* up to 12 jobs per launch */
 /* gank_conv2d_wgrad whose split-K kernels (per-tap, 1x1 / narrow-channel forms) store their partial tiles into per-split copies
  * of the filter inside `slab_ws` (gank_conv2d_wgrad_slab_elems floats; 0 = not worth it / not applicable) instead of adding
  * them to dw with fp32 atomics; *job then describes the sum (nslabs = 0: the launch accumulated into dw directly, nothing to do). */
 long gank_conv2d_wgrad_slab_elems(int N, int H, int W, int Cin, int Cout, int ksize, int flags);
+/* ... of the FIRST Cin input channels of a [k,k,Cin_total,Cout] filter (x holds those channels only), accumulated into their rows
+ * of dw_full by the job (out_run / out_pitch); needs the all-taps kernel with at most 32 pixel splits -- gank_conv2d_wgrad_slab_splits
+ * says how many (0: this entry fails and launches nothing). */
+int gank_conv2d_wgrad_slab_splits(int N, int H, int W, int Cin, int Cout, int ksize, int flags);
+int gank_conv2d_wgrad_slabs_rows(const void* x, const void* dy, float* dw_full, float* dbias, int N, int H, int W, int Cin, int Cin_total, int Cout,
+                                 int ksize, int flags, float scale, float* slab_ws, long slab_elems, gank_slab_job* job, void* stream);
 int gank_conv2d_wgrad_slabs(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int Cin, int Cout, int ksize,
                             int flags, float scale, float* slab_ws, long slab_elems, gank_slab_job* job, void* stream);
 /* (layers on the all-taps kernel: gank_conv2d_wgrad_slab_elems = gank_conv2d_wgrad_ws_elems, and the slab reduction that
@@ -578,7 +586,7 @@ int gank_concat_label_pool_fwd(const void* a, const void* T, const int32_t* labe
 int gank_concat_label_unpool_bwd(const void* g_main, const void* g_pooled, void* da, float* de32, int N, int H, int W, int C1, int C2,
                                  void* stream);
 int gank_concat_label_unpool_bwd_factored(const void* g_main_c1, const void* g_pooled, void* da, float* de32, const float* de_add, int de_parts,
-                                          int N, int H, int W, int C1, int C2, void* stream);
+                                          const int32_t* labels, const int32_t* lists, int V, int N, int H, int W, int C1, int C2, void* stream);
 
 /* ---- the spatially constant input channels of a 3x3 conv, factored out (round 5) ------------------------------------------
  * The critic tiles the label embedding over the 16x16 grid and concatenates it to its features in front of D.Block.2
@@ -588,19 +596,23 @@ int gank_concat_label_unpool_bwd_factored(const void* g_main_c1, const void* g_p
  * table [V][9][Cout] replaces half of the layer in all three passes -- exact algebra:
  *   gank_label_conv3x3_table    : bias_table[v][cls][co] = bias[co] + sum_{taps valid in cls} sum_c bf16(w[t][c0+c][co]) relu(T[v][c]);
  *                                 w is the WHOLE fp32 filter [3,3,Cin_total,Cout], the constant channels are c0 .. c0+C2-1;
+ *                                 lists (optional, int32 [V][N+1], with labels [N]): row v = {count, the samples of label v ascending}
+ *                                 -- what the backward entries walk;
  *   gank_img16_conv3x3_label_bias: the image-resident 16x16 conv on the OTHER channels (x [N,16,16,Cin], operands prepared with
  *                                 gank_prep_desc.cin_pitch = Cin_total) adding row (label of the sample, class of the pixel);
- *   gank_label_conv3x3_bwd      : from dy [N,H,W,Cout]: dw[t][c0+c][co] += sum_n relu(T[l_n][c]) S[n][t][co] and
- *                                 de_parts[t][n][c] = [T[l_n][c] > 0] sum_co bf16(w[t][c0+c][co]) S[n][t][co], S = the sums of dy over
- *                                 the pixels where tap t is valid (ws: gank_label_conv3x3_bwd_ws_floats).  dw_feat_tmp (optional,
+ *   gank_label_conv3x3_bwd      : from dy [N,H,W,Cout] and the lists: dw[t][c0+c][co] += sum_v relu(T[v][c]) Sl[v][t][co] and
+ *                                 de_parts[t][v][c] = [T[v][c] > 0] sum_co bf16(w[t][c0+c][co]) Sl[v][t][co] -- the gradient of the tiled
+ *                                 vector summed per LABEL (what gank_label_dense_bwd adds up anyway; gank_concat_label_unpool_bwd_factored
+ *                                 adds it to the row of the label's first sample) --, Sl[v][t] = the sum of dy over the samples of label v
+ *                                 and the pixels where tap t is valid (ws: gank_label_conv3x3_bwd_ws_floats); at most 16 labels.  dw_feat_tmp (optional,
  *                                 contiguous [9][c0][Cout]): the other channels' filter gradient, accumulated there by an ordinary
  *                                 filter-gradient launch, is added into rows [0, c0) of dw and the buffer cleared. */
 int gank_label_conv3x3_table(const float* w, int Cin_total, int c0, int C2, int Cout, const void* T, int V, const float* bias,
-                             float* bias_table, void* stream);
+                             float* bias_table, const int32_t* labels, int N, int32_t* lists, void* stream);
 int gank_img16_conv3x3_label_bias(const void* x, const void* w_rfrag, const float* bias_table, const int32_t* labels, int V, void* y,
                                   int N, int Cin, int Cout, int flags, void* stream);
 long gank_label_conv3x3_bwd_ws_floats(int N, int Cout);
-int gank_label_conv3x3_bwd(const void* dy, const int32_t* labels, const void* T, int V, const float* w, int Cin_total, int c0, int C2,
+int gank_label_conv3x3_bwd(const void* dy, const int32_t* lists, const void* T, int V, const float* w, int Cin_total, int c0, int C2,
                            int Cout, int N, int H, int W, float* dw, float* dw_feat_tmp, float* de_parts, float* ws, void* stream);
 int gank_label_dense_bwd(const float* de32, const int32_t* labels, const float* table, const float* W, float* dW, float* dbias,
                          float* dtable, int N, int V, int D, int C2, void* stream);

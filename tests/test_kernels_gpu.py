@@ -1587,7 +1587,12 @@ def test_conv3x3_with_its_spatially_constant_input_channels_factored_out(K, n):
     xcat = np.concatenate([a, np.broadcast_to(tab[labels][:, None, None, :], (n, 16, 16, c2))], axis=3)
     y_ref = R.conv2d_same(R.relu(xcat), w) + bias
     (rf, rd), = K.prep_weights_batched([wt], want_d=True, kinds=[6])
-    table = K.label_conv3x3_table(wt, c1, tt, bt)
+    table, lists = K.label_conv3x3_table(wt, c1, tt, bt, lt)
+    assert torch.equal(K.label_conv3x3_table(wt, c1, tt, bt), table)
+    for lab in range(v):             # row v of the lists: {count, the samples of the label in ascending order}
+        idx = np.nonzero(labels == lab)[0]
+        row = lists[lab].cpu().numpy()
+        assert row[0] == len(idx) and np.array_equal(row[1:1 + len(idx)], idx)
     y = K.img16_conv3x3_label_bias(at, rf, table, lt, cout, K.IN_RELU)
     torch.cuda.synchronize()
     assert relerr(y, y_ref) < BF_TOL, relerr(y, y_ref)
@@ -1603,23 +1608,47 @@ def test_conv3x3_with_its_spatially_constant_input_channels_factored_out(K, n):
     K.conv2d_wgrad(at, dyt, dwf, (16, 16), 3, K.IN_RELU, slab_jobs=jobs)
     if jobs:
         K.sum_slabs(jobs)
-    parts = K.label_conv3x3_bwd(dyt, lt, tt, wt, c1, dw, dwf)
+    parts = K.label_conv3x3_bwd(dyt, lists, tt, wt, c1, dw, dwf)
     da = K.img16_conv3x3(dyt, rd, None, c1, 0, relu_ref=at)
     torch.cuda.synchronize()
     assert float(dwf.abs().max()) == 0.0                           # (left clean for the next pass)
     assert relerr(dw - torch.tensor(dw0).cuda(), dw_ref) < F32_FROM_BF_TOL, relerr(dw - torch.tensor(dw0).cuda(), dw_ref)
-    assert relerr(parts.sum(0), de_ref) < F32_FROM_BF_TOL, relerr(parts.sum(0), de_ref)
+    # (the vector gradient leaves summed per label: [9 taps][V][C2])
+    de = parts.sum(0).double().cpu().numpy()
+    for lab in range(v):
+        idx = np.nonzero(labels == lab)[0]
+        if len(idx):
+            assert relerr(de[lab], de_ref[idx].sum(0)) < F32_FROM_BF_TOL, (lab, relerr(de[lab], de_ref[idx].sum(0)))
+        else:
+            assert float(np.abs(de[lab]).max()) == 0.0
     assert relerr(da, da_ref) < BF_TOL
+    # the feature half's filter gradient straight into its rows of the full gradient (a strided slab job: no staging buffer)
+    if K.conv2d_wgrad_rows_ok(n, (16, 16), c1, cout):
+        dw2 = torch.tensor(dw0).cuda()
+        jobs = []
+        K.conv2d_wgrad_rows(at, dyt, dw2, (16, 16), 3, K.IN_RELU, jobs)
+        assert len(jobs) == 1 and torch.equal(dw2.cpu(), torch.tensor(dw0))
+        K.sum_slabs(jobs)
+        K.label_conv3x3_bwd(dyt, lists, tt, wt, c1, dw2)
+        torch.cuda.synchronize()
+        assert relerr(dw2 - torch.tensor(dw0).cuda(), dw_ref) < F32_FROM_BF_TOL
+    else:
+        assert n < 64
     # the pooled / unpooled ends of the pair: the pooled concat alone, and the gradient join with the factored consumer's partial sums
     _, yp = K.concat_label_pool_fwd(at, tt, lt, want_full=False)
     y_full, yp_full = K.concat_label_pool_fwd(at, tt, lt)
     gp, gpt = bf(rng.normal(size=(n, 8, 8, c1 + c2)))
-    da2, de2 = K.concat_label_unpool_bwd_factored(da, gpt, parts)
+    da2, de2 = K.concat_label_unpool_bwd_factored(da, gpt, parts, lt, lists)
     gm_full = torch.cat([da, torch.zeros((n, 16, 16, c2), dtype=da.dtype, device="cuda")], 3).contiguous()
     da3, de3 = K.concat_label_unpool_bwd(gm_full, gpt, c1)
     torch.cuda.synchronize()
     assert torch.equal(yp.view(torch.int16), yp_full.view(torch.int16)) and torch.equal(da2.view(torch.int16), da3.view(torch.int16))
-    assert relerr(de2, (de3 + parts.sum(0)).double().cpu().numpy()) < 1e-6
+    want = de3.double().cpu().numpy().copy()            # the per-label sums join the row of the label's first sample
+    for lab in range(v):
+        idx = np.nonzero(labels == lab)[0]
+        if len(idx):
+            want[idx[0]] += de[lab]
+    assert relerr(de2, want) < 1e-6
 
 
 def test_concat_rows_is_two_copies_and_its_backward_two_views(K):
