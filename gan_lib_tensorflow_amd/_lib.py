@@ -116,6 +116,7 @@ PROTOTYPES = {
     "gank_conv2d_wgrad_slabs": [P, P, P, P, I, I, I, I, I, I, I, F, P, L, C.POINTER(SlabJob), P],
     "gank_conv2d_wgrad_slab_splits": [I, I, I, I, I, I, I],
     "gank_conv2d_wgrad_slabs_rows": [P, P, P, P, I, I, I, I, I, I, I, I, F, P, L, C.POINTER(SlabJob), P],
+    "gank_conv2d_wgrad_slabs_rows_tap_sums": [P, P, P, P, I, I, I, I, I, I, I, I, F, P, L, C.POINTER(SlabJob), P, I, P, P],
     "gank_conv2d_wgrad_batched_ws_elems": [I, I, I, I, I, I, I, I],
     "gank_conv2d_wgrad_batched_slabs": [C.POINTER(WgradItem), I, I, I, I, I, I, I, I, F, P, L, C.POINTER(SlabJob), P],
     "gank_deconv2d_prep_phases": [P, P, I, I, I, P],

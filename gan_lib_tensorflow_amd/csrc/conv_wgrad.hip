@@ -11,6 +11,7 @@
 // Replaces Conv2DBackpropFilter for common/ops/conv2d.py:180-187; the gather fuses NN-upsample,
 // relu, the mean-pool gradient (dy stored at half size) and the stride-2 form used by Deconv2D.
 #include "gank_common.h"
+#include "label_conv_dev.h"
 #include <type_traits>
 #include <stdlib.h>
 
@@ -55,6 +56,11 @@ struct WgradArgs {
   float* slab_ws;     // (host) workspace offered by the caller
   long slab_elems;
   gank_slab_job* slab_job;   // (host) out: the job that sums what the launch wrote; nslabs = 0 when the launch used atomics
+  // rider of the all-taps launch (gank_conv2d_wgrad_slabs_rows_tap_sums): rider_blocks extra workgroups behind the main_blocks of
+  // the filter gradient compute the per-label tap sums of the same dy (label_conv_dev.h) -- no launch of their own
+  const int* rider_lists;
+  float* rider_S;
+  int rider_blocks, rider_V, main_blocks;
 };
 
 __device__ __forceinline__ s16x4 lds_tr_read(const bf16* p) {
@@ -1058,12 +1064,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_taps_kernel(WgradArgs a) {
   bf16* sX = reinterpret_cast<bf16*>(smem);        // [2][2 subs][100 pix][32 ch]
   bf16* sD = sX + 2 * 2 * XSUB;                    // [2][2 subs][64 pix][32 ch]
 
+  if (a.rider_blocks > 0 && (int)blockIdx.x >= a.main_blocks) {
+    label_conv_tap_sums_block(a.dy, a.rider_lists, a.rider_S, a.N, a.rider_V, a.H, a.W, a.Cout, blockIdx.x - a.main_blocks, reinterpret_cast<float*>(smem));
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_a = wave & 1, wave_b = wave >> 1;
   int bid = blockIdx.x, split;
+  const int nmain = a.rider_blocks > 0 ? a.main_blocks : (int)gridDim.x;
   if (a.xcd) {            // tiles fastest behind the XCD remap: the tiles of one pixel split share an L2 (WgradArgs.xcd)
     const int ntile = a.tiles_co * a.tiles_ci;
-    bid = xcd_remap(blockIdx.x, gridDim.x);
+    bid = xcd_remap(blockIdx.x, nmain);
     split = bid / ntile; bid -= split * ntile;
   } else {
     split = bid % a.splits; bid /= a.splits;
@@ -1286,7 +1297,7 @@ static int launch_wgrad_taps_mode(WgradArgs a, hipStream_t s) {
   } else {
     a.ws = nullptr;   // atomics
   }
-  const size_t lds = (size_t)2 * 2 * (XSUB + SUBS) * sizeof(bf16);
+  size_t lds = (size_t)2 * 2 * (XSUB + SUBS) * sizeof(bf16);
   static const int tpf = gank_tune("GANK_WGRAD_TAPS_PF", 2);
 #ifdef GANK_TUNING
   auto kern = tpf == 1 ? conv_wgrad_taps_kernel<MODE, 1> : conv_wgrad_taps_kernel<MODE, 2>;
@@ -1298,7 +1309,13 @@ static int launch_wgrad_taps_mode(WgradArgs a, hipStream_t s) {
   static const std::string tag_deferred = gank_format("conv_wgrad_taps_kernel<%d, 2>", MODE);      // (the slab reduction is a job of the caller's summing launch)
   gank_prof_tag(1, (a.ws && a.slab_job && a.splits <= 32) ? tag_deferred.c_str() : tag.c_str());
   a.xcd = wgrad_xcd_env();
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_ci * a.tiles_co * a.splits)), dim3(256), lds, s, a);
+  a.main_blocks = a.tiles_ci * a.tiles_co * a.splits;
+  if (a.rider_blocks > 0) {
+    GANK_REQUIRE(a.ws && a.slab_job && a.splits <= 32 && a.Hdy == a.H && a.Wdy == a.W, "conv_wgrad_taps: the tap-sums rider needs the deferred slab form");
+    if (lds < (size_t)LABEL_TAP_SUMS_LDS) lds = LABEL_TAP_SUMS_LDS;
+    GANK_MAX_DYNAMIC_LDS(kern, (int)lds, "conv_wgrad_taps");
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.main_blocks + (a.rider_blocks > 0 ? a.rider_blocks : 0))), dim3(256), lds, s, a);
   GANK_LAUNCH_OK("conv_wgrad_taps");
   if (a.ws && a.slab_job && a.splits <= 32) {       // the caller sums the slabs later, with other producers' (gank_sum_slabs)
     *a.slab_job = gank_slab_job{a.ws, a.dw, slab, slab, a.splits, 1.0f, 0};
@@ -1777,8 +1794,10 @@ extern "C" long gank_conv2d_wgrad_ws_elems(int N, int H, int W, int Cin, int Cou
   return a.splits > 1 ? 9L * Cin * Cout * a.splits : 0;
 }
 
+namespace { struct TapSumsRider { const int32_t* lists; float* S; int V; }; }
 static int conv2d_wgrad_impl(const void* x, const void* dy, float* dw, float* dbias, float* ws, long ws_elems, int N, int H, int W, int Cin, int Cout,
-                             int ksize, int flags, float scale, float* slab_ws, long slab_elems, gank_slab_job* job, void* stream);
+                             int ksize, int flags, float scale, float* slab_ws, long slab_elems, gank_slab_job* job, void* stream,
+                             const TapSumsRider* rider = nullptr);
 extern "C" int gank_conv2d_wgrad(const void* x, const void* dy, float* dw, float* dbias, float* ws, long ws_elems, int N,
                                  int H, int W, int Cin, int Cout, int ksize, int flags, float scale, void* stream) {
   return conv2d_wgrad_impl(x, dy, dw, dbias, ws, ws_elems, N, H, W, Cin, Cout, ksize, flags, scale, nullptr, 0, nullptr, stream);
@@ -1808,14 +1827,33 @@ extern "C" int gank_conv2d_wgrad_slab_splits(int N, int H, int W, int Cin, int C
   wgrad_taps_geometry(a);
   return (a.splits > 1 && a.splits <= 32) ? a.splits : 0;
 }
+static int wgrad_slabs_rows_impl(const void* x, const void* dy, float* dw_full, float* dbias, int N, int H, int W, int Cin, int Cin_total,
+                                 int Cout, int ksize, int flags, float scale, float* slab_ws, long slab_elems, gank_slab_job* job, void* stream,
+                                 const TapSumsRider* rider);
 extern "C" int gank_conv2d_wgrad_slabs_rows(const void* x, const void* dy, float* dw_full, float* dbias, int N, int H, int W, int Cin, int Cin_total,
                                             int Cout, int ksize, int flags, float scale, float* slab_ws, long slab_elems, gank_slab_job* job, void* stream) {
+  return wgrad_slabs_rows_impl(x, dy, dw_full, dbias, N, H, W, Cin, Cin_total, Cout, ksize, flags, scale, slab_ws, slab_elems, job, stream, nullptr);
+}
+// ... with the per-label tap sums of the SAME dy (gank_label_conv3x3_bwd's first launch: lists from gank_label_conv3x3_table, V labels,
+// tap_sums_ws of gank_label_conv3x3_bwd_ws_floats floats) computed by extra workgroups of the filter-gradient launch; pass dy = NULL to
+// gank_label_conv3x3_bwd afterwards
+extern "C" int gank_conv2d_wgrad_slabs_rows_tap_sums(const void* x, const void* dy, float* dw_full, float* dbias, int N, int H, int W, int Cin, int Cin_total,
+                                                     int Cout, int ksize, int flags, float scale, float* slab_ws, long slab_elems, gank_slab_job* job,
+                                                     const int32_t* lists, int V, float* tap_sums_ws, void* stream) {
+  GANK_REQUIRE(lists && tap_sums_ws && V > 0 && V <= 16 && Cout % 64 == 0 && H % 2 == 0 && ((H / 2) * W) % 32 == 0 && (H / 2) * W <= 128 && N <= 1024,
+               "conv2d_wgrad_slabs_rows_tap_sums: unsupported geometry for the tap-sums rider");
+  const TapSumsRider rider{lists, tap_sums_ws, V};
+  return wgrad_slabs_rows_impl(x, dy, dw_full, dbias, N, H, W, Cin, Cin_total, Cout, ksize, flags, scale, slab_ws, slab_elems, job, stream, &rider);
+}
+static int wgrad_slabs_rows_impl(const void* x, const void* dy, float* dw_full, float* dbias, int N, int H, int W, int Cin, int Cin_total,
+                                 int Cout, int ksize, int flags, float scale, float* slab_ws, long slab_elems, gank_slab_job* job, void* stream,
+                                 const TapSumsRider* rider) {
   GANK_REQUIRE(slab_ws && job && slab_elems > 0 && dw_full && Cin_total >= Cin, "conv2d_wgrad_slabs_rows: bad arguments");
   const int splits = gank_conv2d_wgrad_slab_splits(N, H, W, Cin, Cout, ksize, flags);
   GANK_REQUIRE(splits > 0 && slab_elems >= (long)ksize * ksize * Cin * Cout * splits && (Cin * Cout) % 4 == 0 && ((long)Cin_total * Cout) % 4 == 0 && scale == 1.0f,
                "conv2d_wgrad_slabs_rows: this layer has no deferred slab form (gank_conv2d_wgrad_slab_splits = %d)", splits);
   *job = gank_slab_job{nullptr, dw_full, (long)ksize * ksize * Cin * Cout, (long)ksize * ksize * Cin * Cout, 0, scale, 0, 0, 0};
-  if (conv2d_wgrad_impl(x, dy, dw_full, dbias, nullptr, 0, N, H, W, Cin, Cout, ksize, flags, scale, slab_ws, slab_elems, job, stream)) return 1;
+  if (conv2d_wgrad_impl(x, dy, dw_full, dbias, nullptr, 0, N, H, W, Cin, Cout, ksize, flags, scale, slab_ws, slab_elems, job, stream, rider)) return 1;
   GANK_REQUIRE(job->nslabs > 0, "conv2d_wgrad_slabs_rows: the launch did not leave its reduction to the job");
   job->out_run = (long)Cin * Cout;
   job->out_pitch = (long)Cin_total * Cout;
@@ -1828,9 +1866,11 @@ extern "C" int gank_conv2d_wgrad_slabs(const void* x, const void* dy, float* dw,
   return conv2d_wgrad_impl(x, dy, dw, dbias, nullptr, 0, N, H, W, Cin, Cout, ksize, flags, scale, slab_ws, slab_elems, job, stream);
 }
 static int conv2d_wgrad_impl(const void* x, const void* dy, float* dw, float* dbias, float* ws, long ws_elems, int N, int H, int W, int Cin, int Cout,
-                             int ksize, int flags, float scale, float* slab_ws, long slab_elems, gank_slab_job* job, void* stream) {
+                             int ksize, int flags, float scale, float* slab_ws, long slab_elems, gank_slab_job* job, void* stream,
+                             const TapSumsRider* rider) {
   GANK_REQUIRE(ksize % 2 == 1, "conv2d_wgrad: even filter sizes are not on this path (ksize=%d)", ksize);
   WgradArgs a{};
+  if (rider) { a.rider_lists = rider->lists; a.rider_S = rider->S; a.rider_V = rider->V; a.rider_blocks = rider->V * 2 * (Cout / 64); }
   a.slab_ws = slab_ws; a.slab_elems = slab_elems; a.slab_job = job;
   if (slab_ws && !ws) { ws = slab_ws; ws_elems = slab_elems; }        // (a layer on the all-taps kernel takes the offered space as its slab workspace)
   a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.dw = dw; a.dbias = dbias; a.ws = ws; a.ws_elems = ws_elems;

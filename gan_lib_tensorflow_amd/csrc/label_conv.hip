@@ -18,6 +18,7 @@
 //             depend on the label alone, and so do de's consumers; gank_concat_label_unpool_bwd_factored adds them, in a fixed order,
 //             to the row of the label's first sample).
 #include "gank_common.h"
+#include "label_conv_dev.h"
 
 namespace {
 // tap t = (kh, kw) reads input pixel (y + kh - 1, x + kw - 1): invalid in the first row / column class for kh / kw == 0 and in the
@@ -100,72 +101,8 @@ extern "C" int gank_label_conv3x3_table(const float* w, int Cin_total, int c0, i
 // V x 9 x Cout numbers.  H x W pixels per sample (H even, (H / 2) * W % 32 == 0), Cout % 64 == 0.
 __global__ __launch_bounds__(256) void label_conv_tap_sums_kernel(const bf16* __restrict__ dy, const int* __restrict__ lists, float* __restrict__ S,
                                                                 int N, int V, int H, int W, int Cout) {
-  // (a 512-thread form -- 64 pixel lanes, 16 samples per batch, the lanes of a wave meeting by shuffles -- measured 18.8 us against 11.4)
-  extern __shared__ __attribute__((aligned(16))) float red[];         // [32 pixel lanes][9][64]
-  const int nchunk = Cout >> 6;
-  int b = blockIdx.x;
-  const int cb = (b % nchunk) * 64; b /= nchunk;
-  const int half = b & 1, v = b >> 1;
-  const int tid = threadIdx.x, g = tid & 7, pl = tid >> 3;
-  const int* list = lists + (long)v * (N + 1) + 1;
-  const int cnt = lists[(long)v * (N + 1)];
-  const int HW = H * W, hp = HW >> 1, p0 = half * hp;
-  const int KP = hp >> 5;                                             // pixels per thread (4 at 16 x 16)
-  float dl[4][8];
-#pragma unroll
-  for (int k = 0; k < 4; k++)
-#pragma unroll
-    for (int e = 0; e < 8; e++) dl[k][e] = 0.f;
-  for (int sb = 0; sb < cnt; sb += 8) {
-    bf16x8 x[8][4];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int n = list[sb + u < cnt ? sb + u : cnt - 1];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int p = p0 + pl + 32 * (k < KP ? k : 0);
-        x[u][k] = *reinterpret_cast<const bf16x8*>(dy + ((long)n * HW + p) * Cout + cb + g * 8);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const float on = sb + u < cnt ? 1.f : 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) dl[k][e] += on * bf2f(x[u][k][e]);
-    }
-  }
-  float acc[9][8];
-#pragma unroll
-  for (int t = 0; t < 9; t++)
-#pragma unroll
-    for (int e = 0; e < 8; e++) acc[t][e] = 0.f;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    if (k < KP) {
-      const int p = p0 + pl + 32 * k, y = p / W, x = p - y * W;
-      // tap (kh, kw) is valid at this pixel when its input pixel (y + kh - 1, x + kw - 1) is inside
-      const bool rv[3] = {y > 0, true, y < H - 1}, cv[3] = {x > 0, true, x < W - 1};
-#pragma unroll
-      for (int t = 0; t < 9; t++) {
-        const float m = (rv[t / 3] && cv[t % 3]) ? 1.f : 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; e++) acc[t][e] += m * dl[k][e];
-      }
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < 9; t++)
-#pragma unroll
-    for (int e = 0; e < 8; e++) red[((long)pl * 9 + t) * 64 + g * 8 + e] = acc[t][e];
-  __syncthreads();
-  for (int i = tid; i < 9 * 64; i += 256) {
-    float sum = 0.f;
-    for (int l = 0; l < 32; l++) sum += red[(long)l * 9 * 64 + i];
-    const int t = i >> 6, c = i & 63;
-    S[(((long)half * V + v) * 9 + t) * Cout + cb + c] = sum;
-  }
+  extern __shared__ __attribute__((aligned(16))) float red_[];
+  label_conv_tap_sums_block(dy, lists, S, N, V, H, W, Cout, blockIdx.x, red_);
 }
 
 // block = (tap t, tile of CT channels of the constant half), 256 threads.  The per-tap sums enter only through their sums per LABEL
@@ -256,7 +193,7 @@ extern "C" long gank_label_conv3x3_bwd_ws_floats(int N, int Cout) { (void)N; ret
 
 extern "C" int gank_label_conv3x3_bwd(const void* dy, const int32_t* lists, const void* T, int V, const float* w, int Cin_total, int c0, int C2,
                                       int Cout, int N, int H, int W, float* dw, float* dw_feat_tmp, float* de_parts, float* ws, void* stream) {
-  GANK_REQUIRE(dy && lists && T && w && dw && de_parts && ws && N > 0 && H > 1 && W > 1 && V > 0, "label_conv3x3_bwd: bad arguments");
+  GANK_REQUIRE(lists && T && w && dw && de_parts && ws && N > 0 && H > 1 && W > 1 && V > 0, "label_conv3x3_bwd: bad arguments");      // dy NULL: the sums are in ws already
   GANK_REQUIRE(Cout % 8 == 0 && 256 % (Cout / 8) == 0 && C2 % LCB_CT == 0 && c0 >= 0 && c0 + C2 <= Cin_total, "label_conv3x3_bwd: unsupported channel counts");
   hipStream_t s = (hipStream_t)stream;
   GANK_REQUIRE(V <= LCB_V && H % 2 == 0 && ((H / 2) * W) % 32 == 0 && (H / 2) * W <= 128 && Cout % 64 == 0 && N <= 1024,
@@ -265,7 +202,7 @@ extern "C" int gank_label_conv3x3_bwd(const void* dy, const int32_t* lists, cons
   GANK_MAX_DYNAMIC_LDS(label_conv_tap_sums_kernel, (int)lds1, "label_conv3x3_bwd");
   const size_t lds2 = ((size_t)V * (Cout + 4) + (size_t)LCB_CT * (Cout + 4) + (size_t)V * LCB_CT) * sizeof(float);
   GANK_REQUIRE(lds2 <= 64 * 1024, "label_conv3x3_bwd: N = %d, Cout = %d do not fit the LDS", N, Cout);
-  hipLaunchKernelGGL(label_conv_tap_sums_kernel, dim3(V * 2 * (Cout / 64)), dim3(256), lds1, s, (const bf16*)dy, lists, ws, N, V, H, W, Cout);
+  if (dy) hipLaunchKernelGGL(label_conv_tap_sums_kernel, dim3(V * 2 * (Cout / 64)), dim3(256), lds1, s, (const bf16*)dy, lists, ws, N, V, H, W, Cout);
   const int merge_blocks = dw_feat_tmp ? 64 : 0;
   hipLaunchKernelGGL(label_conv_bwd_kernel, dim3(9 * (C2 / LCB_CT) + merge_blocks), dim3(256), lds2, s, ws, lists, (const bf16*)T, V, w, Cin_total, c0, C2, Cout,
                      N, dw, de_parts, dw_feat_tmp, merge_blocks);

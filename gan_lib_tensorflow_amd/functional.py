@@ -1200,6 +1200,7 @@ class _ConcatLabelForkPool(Function):
         return (da if ctx.needs_input_grad[0] else None), None, dt, dw, db
 
 
+TAP_SUMS_RIDER = True       # ... its per-label tap sums as extra workgroups of the feature half's filter-gradient launch
 FACTOR_LABEL_CONV = True    # D.Block.2.Conv1 with the tiled (spatially constant) half of its input factored out (csrc/label_conv.hip, round 5)
 
 
@@ -1245,8 +1246,10 @@ class _ConcatLabelConv1(Function):
                 tgt, acc = _target(W1)
                 tgt4 = tgt.view(3, 3, W1.shape[2], cout)
                 if SLAB_WGRADS and BATCH_SMALL_WGRADS and K.conv2d_wgrad_rows_ok(n, (16, 16), c1, cout, 3, K.IN_RELU):
-                    K.conv2d_wgrad_rows(a, g, tgt4, (16, 16), 3, K.IN_RELU, _slab_jobs, dbias=btgt)     # summed with the pass's other slabs
-                    parts = K.label_conv3x3_bwd(g, lists, T, W1.detach(), c1, tgt4)
+                    # (summed with the pass's other slabs; the per-label tap sums of dh1 ride on the same launch)
+                    sums = K.conv2d_wgrad_rows(a, g, tgt4, (16, 16), 3, K.IN_RELU, _slab_jobs, dbias=btgt,
+                                               tap_sums=(lists, T.shape[0]) if TAP_SUMS_RIDER else None)
+                    parts = K.label_conv3x3_bwd(g, lists, T, W1.detach(), c1, tgt4, sums=sums)
                 else:                          # small batches: through a zero-filled staging buffer, merged by the same launch
                     tmp = K.zeros_f32((3, 3, c1, cout), a.device)
                     K.conv2d_wgrad(a, g, tmp, (16, 16), 3, K.IN_RELU, 1.0, dbias=btgt)

@@ -240,19 +240,29 @@ def conv2d_wgrad_rows_ok(n, hw, cin, cout, ksize=3, flags=0):
     return int(lib().gank_conv2d_wgrad_slab_splits(n, hw[0], hw[1], cin, cout, ksize, flags)) > 0
 
 
-def conv2d_wgrad_rows(x, dy, dw_full, hw, ksize, flags, slab_jobs, dbias=None):
+def conv2d_wgrad_rows(x, dy, dw_full, hw, ksize, flags, slab_jobs, dbias=None, tap_sums=None):
     """filter gradient of the FIRST x.shape[3] input channels of the wider filter dw_full [k,k,Cin_total,Cout], accumulated into those
-    rows by a slab job appended to slab_jobs (gank_conv2d_wgrad_slabs_rows; the caller owes a sum_slabs(list))"""
+    rows by a slab job appended to slab_jobs (gank_conv2d_wgrad_slabs_rows; the caller owes a sum_slabs(list)).  tap_sums = (lists,
+    n_labels): the launch also computes the per-label tap sums of dy (extra workgroups) -> their workspace, for
+    label_conv3x3_bwd(sums=...)"""
     n, cin, cout = x.shape[0], x.shape[3], dy.shape[3]
     assert dw_full.dim() == 4 and dw_full.shape[3] == cout and dw_full.shape[2] >= cin and slab_jobs is not None
     slab_elems = int(lib().gank_conv2d_wgrad_slab_elems(n, hw[0], hw[1], cin, cout, ksize, flags))
     ws = torch.empty(max(slab_elems, 1), dtype=F32, device=x.device)
     job = (SlabJob * 1)()
-    _lib.check(lib().gank_conv2d_wgrad_slabs_rows(_p(x, BF16, "x"), _p(dy, BF16, "dy"), _p(dw_full, F32, "dw_full"), _p(dbias, F32, "dbias"),
-                                                  n, hw[0], hw[1], cin, dw_full.shape[2], cout, ksize, flags, 1.0, _p(ws), slab_elems, job, _stream()),
-               "conv2d_wgrad_slabs_rows")
+    sums = None
+    if tap_sums is not None:
+        lists, v = tap_sums
+        sums = torch.empty(int(lib().gank_label_conv3x3_bwd_ws_floats(n, cout)), dtype=F32, device=x.device)
+        _lib.check(lib().gank_conv2d_wgrad_slabs_rows_tap_sums(_p(x, BF16, "x"), _p(dy, BF16, "dy"), _p(dw_full, F32, "dw_full"), _p(dbias, F32, "dbias"),
+                                                               n, hw[0], hw[1], cin, dw_full.shape[2], cout, ksize, flags, 1.0, _p(ws), slab_elems, job,
+                                                               _p(lists, I32, "lists"), int(v), _p(sums), _stream()), "conv2d_wgrad_slabs_rows_tap_sums")
+    else:
+        _lib.check(lib().gank_conv2d_wgrad_slabs_rows(_p(x, BF16, "x"), _p(dy, BF16, "dy"), _p(dw_full, F32, "dw_full"), _p(dbias, F32, "dbias"),
+                                                      n, hw[0], hw[1], cin, dw_full.shape[2], cout, ksize, flags, 1.0, _p(ws), slab_elems, job, _stream()),
+                   "conv2d_wgrad_slabs_rows")
     slab_jobs.append((job, 1, ws))
-    return dw_full
+    return sums
 
 
 def conv2d_wgrad_batched(items, hw, ksize, flags=0, scale=1.0, slab_jobs=None):
@@ -1344,17 +1354,18 @@ def img16_conv3x3_label_bias(x, rf, bias_table, labels, cout, flags=0):
     return y
 
 
-def label_conv3x3_bwd(dy, lists, t, w, c0, dw, dw_feat_tmp=None):
+def label_conv3x3_bwd(dy, lists, t, w, c0, dw, dw_feat_tmp=None, sums=None):
     """gank_label_conv3x3_bwd: ACCUMULATES the constant channels' filter gradient into rows c0.. of dw [3,3,Cin,Cout] (and adds +
     clears dw_feat_tmp [3,3,c0,Cout] into rows 0..c0-1) -> de_parts fp32 [9,V,C2]: the gradient of the tiled vector per tap and LABEL
-    (summed over the label's samples); lists from label_conv3x3_table(labels=...)"""
+    (summed over the label's samples); lists from label_conv3x3_table(labels=...).  sums: the tap sums of dy are in this workspace
+    already (conv2d_wgrad_rows(tap_sums=...)): the launch that computes them is skipped"""
     n, h, wd_, cout = dy.shape
     v, c2 = t.shape
     cin = w.shape[2]
     assert dw.shape == w.shape and (dw_feat_tmp is None or tuple(dw_feat_tmp.shape) == (3, 3, c0, cout))
-    ws = torch.empty(int(lib().gank_label_conv3x3_bwd_ws_floats(n, cout)), dtype=F32, device=dy.device)
+    ws = sums if sums is not None else torch.empty(int(lib().gank_label_conv3x3_bwd_ws_floats(n, cout)), dtype=F32, device=dy.device)
     parts = torch.empty((9, v, c2), dtype=F32, device=dy.device)
-    _lib.check(lib().gank_label_conv3x3_bwd(_p(dy, BF16, "dy"), _p(lists, I32, "lists"), _p(t, BF16, "T"), v, _p(w, F32, "w"), cin, c0, c2, cout, n, h, wd_,
+    _lib.check(lib().gank_label_conv3x3_bwd(None if sums is not None else _p(dy, BF16, "dy"), _p(lists, I32, "lists"), _p(t, BF16, "T"), v, _p(w, F32, "w"), cin, c0, c2, cout, n, h, wd_,
                                             _p(dw, F32, "dw"), _p(dw_feat_tmp, F32, "dw_feat_tmp"), _p(parts), _p(ws), _stream()), "label_conv3x3_bwd")
     return parts
 

@@ -157,6 +157,12 @@ long gank_conv2d_wgrad_slab_elems(int N, int H, int W, int Cin, int Cout, int ks
 int gank_conv2d_wgrad_slab_splits(int N, int H, int W, int Cin, int Cout, int ksize, int flags);
 int gank_conv2d_wgrad_slabs_rows(const void* x, const void* dy, float* dw_full, float* dbias, int N, int H, int W, int Cin, int Cin_total, int Cout,
                                  int ksize, int flags, float scale, float* slab_ws, long slab_elems, gank_slab_job* job, void* stream);
+/* ... and, as extra workgroups of the same launch, the per-label tap sums of dy that gank_label_conv3x3_bwd (below) needs: lists from
+ * gank_label_conv3x3_table, V labels, tap_sums_ws of gank_label_conv3x3_bwd_ws_floats floats; call gank_label_conv3x3_bwd with
+ * dy = NULL and that workspace afterwards (its own first launch is then skipped). */
+int gank_conv2d_wgrad_slabs_rows_tap_sums(const void* x, const void* dy, float* dw_full, float* dbias, int N, int H, int W, int Cin, int Cin_total,
+                                          int Cout, int ksize, int flags, float scale, float* slab_ws, long slab_elems, gank_slab_job* job,
+                                          const int32_t* lists, int V, float* tap_sums_ws, void* stream);
 int gank_conv2d_wgrad_slabs(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int Cin, int Cout, int ksize,
                             int flags, float scale, float* slab_ws, long slab_elems, gank_slab_job* job, void* stream);
 /* (layers on the all-taps kernel: gank_conv2d_wgrad_slab_elems = gank_conv2d_wgrad_ws_elems, and the slab reduction that
@@ -604,7 +610,8 @@ int gank_concat_label_unpool_bwd_factored(const void* g_main_c1, const void* g_p
  *                                 de_parts[t][v][c] = [T[v][c] > 0] sum_co bf16(w[t][c0+c][co]) Sl[v][t][co] -- the gradient of the tiled
  *                                 vector summed per LABEL (what gank_label_dense_bwd adds up anyway; gank_concat_label_unpool_bwd_factored
  *                                 adds it to the row of the label's first sample) --, Sl[v][t] = the sum of dy over the samples of label v
- *                                 and the pixels where tap t is valid (ws: gank_label_conv3x3_bwd_ws_floats); at most 16 labels.  dw_feat_tmp (optional,
+ *                                 and the pixels where tap t is valid (ws: gank_label_conv3x3_bwd_ws_floats; dy = NULL: ws already holds
+ *                                 them -- gank_conv2d_wgrad_slabs_rows_tap_sums); at most 16 labels.  dw_feat_tmp (optional,
  *                                 contiguous [9][c0][Cout]): the other channels' filter gradient, accumulated there by an ordinary
  *                                 filter-gradient launch, is added into rows [0, c0) of dw and the buffer cleared. */
 int gank_label_conv3x3_table(const float* w, int Cin_total, int c0, int C2, int Cout, const void* T, int V, const float* bias,

@@ -1632,6 +1632,13 @@ def test_conv3x3_with_its_spatially_constant_input_channels_factored_out(K, n):
         K.label_conv3x3_bwd(dyt, lists, tt, wt, c1, dw2)
         torch.cuda.synchronize()
         assert relerr(dw2 - torch.tensor(dw0).cuda(), dw_ref) < F32_FROM_BF_TOL
+        # ... and with the per-label tap sums computed by extra workgroups of that launch: bit-identical results
+        dw3 = torch.tensor(dw0).cuda()
+        sums = K.conv2d_wgrad_rows(at, dyt, dw3, (16, 16), 3, K.IN_RELU, jobs, tap_sums=(lists, v))
+        K.sum_slabs(jobs)
+        parts3 = K.label_conv3x3_bwd(dyt, lists, tt, wt, c1, dw3, sums=sums)
+        torch.cuda.synchronize()
+        assert torch.equal(dw3, dw2) and torch.equal(parts3, parts)
     else:
         assert n < 64
     # the pooled / unpooled ends of the pair: the pooled concat alone, and the gradient join with the factored consumer's partial sums
