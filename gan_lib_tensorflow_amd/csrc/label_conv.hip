@@ -32,15 +32,60 @@ __device__ __forceinline__ bool tap_valid(int t, int cls) {
 // block = (label v, 64 output channels), thread = (tap t, channel co): 128-deep dot products with 16 loads in flight (the first form --
 // a block per (label, class) walking every valid tap, 1152 dependent-ish loads per thread -- took 46 us), the nine per-tap sums meet
 // in LDS and thread (class, co) adds the taps valid in its class.
+// The pooled half of functional.concat_label_fork_pool as a rider of the table launch (the block's shortcut reads
+// mean_pool2x2(concat(a, tile(T[labels]))); the full-resolution concatenation is not built): concat_label_pool_fwd_kernel's
+// arithmetic for its pooled output, expression for expression (elementwise.hip), grid-stride over `nblocks` blocks of `nthreads`.
+struct LabelPoolRider {
+  const bf16* a;          // [N, 2Hp, 2Wp, C1]
+  bf16* yp;               // [N, Hp, Wp, C1 + C2]
+  long total8;
+  int Hp, Wp, C1, blocks;
+};
+__device__ __forceinline__ void label_pool_rider_block(const LabelPoolRider& q, const bf16* __restrict__ T, const int* __restrict__ labels, int C2, int V,
+                                                      int bid, int nthreads) {
+  const int C = q.C1 + C2, cg = C >> 3, cg1 = q.C1 >> 3;
+  const int W = 2 * q.Wp;
+  for (long i = bid * (long)nthreads + threadIdx.x; i < q.total8; i += (long)q.blocks * nthreads) {
+    const int g = (int)(i % cg);
+    long p = i / cg;
+    const int pw = (int)(p % q.Wp); p /= q.Wp;
+    const int ph = (int)(p % q.Hp);
+    const int n = (int)(p / q.Hp);
+    const long hi = ((long)n * 2 * q.Hp + 2 * ph) * W + 2 * pw;          // top-left high-resolution pixel
+    bf16x8 m;
+    if (g < cg1) {
+      const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(q.a + hi * q.C1 + g * 8);
+      const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(q.a + (hi + 1) * q.C1 + g * 8);
+      const bf16x8 v2 = *reinterpret_cast<const bf16x8*>(q.a + (hi + W) * q.C1 + g * 8);
+      const bf16x8 v3 = *reinterpret_cast<const bf16x8*>(q.a + (hi + W + 1) * q.C1 + g * 8);
+#pragma unroll
+      for (int e = 0; e < 8; e++) m[e] = f2bf((bf2f(v0[e]) + bf2f(v2[e]) + bf2f(v1[e]) + bf2f(v3[e])) * 0.25f);   // order of tf.add_n at :120-121
+    } else {
+      const int l = labels[n];
+      const bool ok = l >= 0 && l < V;
+      m = *reinterpret_cast<const bf16x8*>(T + (long)(ok ? l : 0) * C2 + (g - cg1) * 8);
+      if (!ok) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) m[e] = f2bf(0.f);
+      }
+    }
+    *reinterpret_cast<bf16x8*>(q.yp + (((long)n * q.Hp + ph) * q.Wp + pw) * C + g * 8) = m;
+  }
+}
+
 // lists (optional, int32 [V][N + 1]): row v = {count, the samples of label v in ascending order} -- what the backward launches walk
 // (built by the first channel block of every label: a deterministic rank per sample)
 __global__ __launch_bounds__(576) void label_conv_table_kernel(const float* __restrict__ w, int Cin_total, int c0, int C2, int Cout,
                                                              const bf16* __restrict__ T, const float* __restrict__ bias, float* __restrict__ out,
-                                                             const int* __restrict__ labels, int N, int V, int* __restrict__ lists) {
+                                                             const int* __restrict__ labels, int N, int V, int* __restrict__ lists, LabelPoolRider pr) {
   __shared__ float r[1024];
   __shared__ float P[9][64];
   __shared__ int lab[1024];
   const int nco = (Cout + 63) / 64;
+  if ((int)blockIdx.x >= V * nco) {
+    label_pool_rider_block(pr, T, labels, C2, V, blockIdx.x - V * nco, 576);
+    return;
+  }
   const int v = blockIdx.x / nco, cb = (blockIdx.x - v * nco) * 64;
   const int t = threadIdx.x >> 6, col = threadIdx.x & 63;
   if (lists && cb == 0) {
@@ -88,8 +133,24 @@ extern "C" int gank_label_conv3x3_table(const float* w, int Cin_total, int c0, i
                "label_conv3x3_table: bad arguments");
   GANK_REQUIRE(!lists || (labels && N > 0 && N <= 1024), "label_conv3x3_table: the sample lists need the labels of 1..1024 samples");
   hipLaunchKernelGGL(label_conv_table_kernel, dim3(V * ((Cout + 63) / 64)), dim3(576), 0, (hipStream_t)stream, w, Cin_total, c0, C2, Cout, (const bf16*)T, bias,
-                     bias_table, labels, N, V, lists);
+                     bias_table, labels, N, V, lists, LabelPoolRider{});
   GANK_LAUNCH_OK("label_conv3x3_table");
+  return 0;
+}
+// ... with mean_pool2x2(concat(a, tile(T[labels]))) -> y_pooled [N, H/2, W/2, C1 + C2] (gank_concat_label_pool_fwd with y = NULL, bit for
+// bit) computed by extra workgroups of the same launch: the two launches in front of D.Block.2 become one
+extern "C" int gank_label_conv3x3_table_pooled(const float* w, int Cin_total, int c0, int C2, int Cout, const void* T, int V, const float* bias,
+                                               float* bias_table, const int32_t* labels, int N, int32_t* lists, const void* a, void* y_pooled,
+                                               int H, int W, int C1, void* stream) {
+  GANK_REQUIRE(w && T && bias_table && labels && a && y_pooled && V > 0 && C2 > 0 && C2 <= 1024 && C2 % 16 == 0 && c0 >= 0 && c0 + C2 <= Cin_total && Cout > 0,
+               "label_conv3x3_table_pooled: bad arguments");
+  GANK_REQUIRE(N > 0 && N <= 1024 && C1 % 8 == 0 && H % 2 == 0 && W % 2 == 0, "label_conv3x3_table_pooled: 1..1024 samples, C1 %% 8 == 0, even sizes");
+  LabelPoolRider pr{(const bf16*)a, (bf16*)y_pooled, (long)N * (H / 2) * (W / 2) * ((C1 + C2) / 8), H / 2, W / 2, C1, 0};
+  long blocks = (pr.total8 + 575) / 576;
+  pr.blocks = (int)(blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(label_conv_table_kernel, dim3(V * ((Cout + 63) / 64) + pr.blocks), dim3(576), 0, (hipStream_t)stream, w, Cin_total, c0, C2, Cout,
+                     (const bf16*)T, bias, bias_table, labels, N, V, lists, pr);
+  GANK_LAUNCH_OK("label_conv3x3_table_pooled");
   return 0;
 }
 

@@ -1222,9 +1222,8 @@ class _ConcatLabelConv1(Function):
             T = K.label_dense_table(table.detach(), W_emb.detach(), b_emb.detach() if b_emb is not None else None)
         c1, cout = a.shape[3], W1.shape[3]
         rf, rd = W1._prep_feat
-        bt, lists = K.label_conv3x3_table(W1.detach(), c1, T, b1.detach() if b1 is not None else None, labels)
+        bt, lists, yp = K.label_conv3x3_table_pooled(W1.detach(), c1, T, b1.detach() if b1 is not None else None, labels, a)     # one launch
         h1 = K.img16_conv3x3_label_bias(a, rf, bt, labels, cout, K.IN_RELU)
-        _, yp = K.concat_label_pool_fwd(a, T, labels, want_full=False)
         ctx.save_for_backward(a, labels, table, W_emb, W1, T, lists)
         ctx.b_emb, ctx.b1, ctx.rd = b_emb, b1, rd
         return h1, yp

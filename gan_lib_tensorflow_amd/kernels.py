@@ -1343,6 +1343,21 @@ def label_conv3x3_table(w, c0, t, bias=None, labels=None):
     return out if labels is None else (out, lists)
 
 
+def label_conv3x3_table_pooled(w, c0, t, bias, labels, a):
+    """label_conv3x3_table(labels=...) and concat_label_pool_fwd(a, t, labels, want_full=False) in ONE launch
+    -> (bias_table, lists, mean_pool2x2(concat(a, tile(t[labels]))))"""
+    v, c2 = t.shape
+    cin, cout = w.shape[2], w.shape[3]
+    n, h, wd_, c1 = a.shape
+    out = torch.empty((v, 9, cout), dtype=F32, device=w.device)
+    lists = torch.empty((v, n + 1), dtype=I32, device=w.device)
+    yp = torch.empty((n, h // 2, wd_ // 2, c1 + c2), dtype=BF16, device=a.device)
+    _lib.check(lib().gank_label_conv3x3_table_pooled(_p(w, F32, "w"), cin, c0, c2, cout, _p(t, BF16, "T"), v, _p(bias, F32, "bias"), _p(out),
+                                                     _p(labels, I32, "labels"), n, _p(lists), _p(a, BF16, "a"), _p(yp), h, wd_, c1, _stream()),
+               "label_conv3x3_table_pooled")
+    return out, lists, yp
+
+
 def img16_conv3x3_label_bias(x, rf, bias_table, labels, cout, flags=0):
     """gank_img16_conv3x3_label_bias: the image-resident conv on the feature channels x [N,16,16,Cin] (rf: kind-6 operand) plus row
     (label, border class) of the table"""

@@ -616,6 +616,10 @@ int gank_concat_label_unpool_bwd_factored(const void* g_main_c1, const void* g_p
  *                                 filter-gradient launch, is added into rows [0, c0) of dw and the buffer cleared. */
 int gank_label_conv3x3_table(const float* w, int Cin_total, int c0, int C2, int Cout, const void* T, int V, const float* bias,
                              float* bias_table, const int32_t* labels, int N, int32_t* lists, void* stream);
+/* gank_label_conv3x3_table + gank_concat_label_pool_fwd(y = NULL) in one launch (the pooled concatenation for the block's shortcut) */
+int gank_label_conv3x3_table_pooled(const float* w, int Cin_total, int c0, int C2, int Cout, const void* T, int V, const float* bias,
+                                    float* bias_table, const int32_t* labels, int N, int32_t* lists, const void* a, void* y_pooled,
+                                    int H, int W, int C1, void* stream);
 int gank_img16_conv3x3_label_bias(const void* x, const void* w_rfrag, const float* bias_table, const int32_t* labels, int V, void* y,
                                   int N, int Cin, int Cout, int flags, void* stream);
 long gank_label_conv3x3_bwd_ws_floats(int N, int Cout);

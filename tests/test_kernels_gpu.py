@@ -1644,6 +1644,12 @@ def test_conv3x3_with_its_spatially_constant_input_channels_factored_out(K, n):
     # the pooled / unpooled ends of the pair: the pooled concat alone, and the gradient join with the factored consumer's partial sums
     _, yp = K.concat_label_pool_fwd(at, tt, lt, want_full=False)
     y_full, yp_full = K.concat_label_pool_fwd(at, tt, lt)
+    table2, lists2, yp2 = K.label_conv3x3_table_pooled(wt, c1, tt, bt, lt, at)          # the table and the pooled concatenation in one launch
+    torch.cuda.synchronize()
+    assert torch.equal(table2, table) and torch.equal(yp2.view(torch.int16), yp_full.view(torch.int16))
+    for lab in range(v):
+        cnt = int(lists[lab, 0])
+        assert torch.equal(lists2[lab, :1 + cnt], lists[lab, :1 + cnt])
     gp, gpt = bf(rng.normal(size=(n, 8, 8, c1 + c2)))
     da2, de2 = K.concat_label_unpool_bwd_factored(da, gpt, parts, lt, lists)
     gm_full = torch.cat([da, torch.zeros((n, 16, 16, c2), dtype=da.dtype, device="cuda")], 3).contiguous()
