@@ -18,6 +18,7 @@
 // bf16, one coalesced 1 KB request per MFMA A-fragment, a register ring of 8 requests in flight per wave.
 // Wave ct of the 4: output channels 32*ct .. +31 of all 64 pixels (two MFMA tiles: image rows 0-3, 4-7).
 #include "gank_common.h"
+#include "label_conv_dev.h"
 #ifdef GANK_TUNING
 // timing-only experiment (GANK_STATS_DBG=1): the statistics epilogues skip their atomics (set once per process, before the first launch)
 static __device__ int gank_stats_dbg = 0;
@@ -1614,6 +1615,10 @@ struct I16Args {
   const float* bias;      // optional [Cout]; with bias_labels: [V][9][Cout], row (label of the sample, border class of the pixel)
   const int* bias_labels; // optional [N] (label_conv.hip: the spatially constant input channels of the layer, factored out)
   int bias_V;
+  // rider (gank_img16_conv3x3_label_bwd): lb.blocks extra workgroups behind the main_blocks of the conv compute the label gradients of
+  // the factored layer (label_conv_dev.h) -- independent of this launch's own work, no launch of their own
+  LabelBwdArgs lb;
+  int main_blocks;
   const bf16* mask;       // optional [N,16,16,Cout]: result zeroed where mask <= 0 (relu backward)
   const bf16* res;        // optional [N,16,16,Cout]: added last
   bf16* y;                // [N,16,16,Cout]
@@ -1644,12 +1649,16 @@ __global__ __launch_bounds__(HALF ? 512 : 2048 / TW) void img16_conv3x3_kernel(I
   constexpr int HROWS = HALF ? 10 : 18, IMG = HROWS * I16_RP;            // resident halo rows, bytes per chunk image
   constexpr int STEPS = HALF ? 18 : 36, KPT = HALF ? 2 : 4;              // K-steps of a chunk this wave executes; per tap
   extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][IMG] (HALF: at least the 64-KB exchange area)
+  if (a.lb.blocks > 0 && (int)blockIdx.x >= a.main_blocks) {
+    label_conv_bwd_block(a.lb, blockIdx.x - a.main_blocks, reinterpret_cast<float*>(smem));
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ct = wave & 3, pg = (HALF || TW == 8) ? 0 : wave >> 2, kh = HALF ? wave >> 2 : 0;
   const int r = lane & 31, h = lane >> 5;
   const int cgroups = a.Cout >> 7;
-  const int lid = a.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int lid = a.xcd ? xcd_remap(blockIdx.x, a.lb.blocks > 0 ? a.main_blocks : (int)gridDim.x) : blockIdx.x;
   const int bid = HALF ? lid >> 1 : lid, row0 = HALF ? (lid & 1) * 8 : 0;
   const int cg = bid % cgroups, n = bid / cgroups;
   const int nchunks = a.Cin >> 6, kq = a.Cin >> 4;                      // 64-channel chunks; 16-channel K-steps per tap
@@ -1901,7 +1910,7 @@ struct I16Cbn { const int* labels; const float* gamma; const float* beta; const 
 }
 static int img16_conv3x3_impl(const void* x, const void* w_rfrag, const float* bias, const void* relu_ref, const void* residual, void* y,
                               int N, int Cin, int Cout, int flags, float* stat_sums, int stat_groups, const I16Cbn* cbn, void* stream,
-                              const int32_t* bias_labels = nullptr, int bias_V = 0);
+                              const int32_t* bias_labels = nullptr, int bias_V = 0, const LabelBwdArgs* lb = nullptr);
 // the layer's spatially constant input channels factored out (label_conv.hip): bias_table [V][9][Cout] from gank_label_conv3x3_table
 // holds, per label and border class of a pixel, the layer's bias plus what those channels contribute; x and w_rfrag are the
 // remaining (feature) channels only
@@ -1909,6 +1918,17 @@ extern "C" int gank_img16_conv3x3_label_bias(const void* x, const void* w_rfrag,
                                              int N, int Cin, int Cout, int flags, void* stream) {
   GANK_REQUIRE(bias_table && labels && V > 0, "img16_conv3x3_label_bias: null table / labels");
   return img16_conv3x3_impl(x, w_rfrag, bias_table, nullptr, nullptr, y, N, Cin, Cout, flags, nullptr, 0, nullptr, stream, labels, V);
+}
+// the input gradient of the factored layer (x = dy, w_rfrag = the feature half's dgrad operand, relu_ref = the features) with the label
+// gradients -- gank_label_conv3x3_bwd's second launch on tap sums that are already in `tap_sums` (gank_conv2d_wgrad_slabs_rows_tap_sums) --
+// computed by extra workgroups of the same launch
+extern "C" int gank_img16_conv3x3_label_bwd(const void* x, const void* w_rfrag, const void* relu_ref, void* y, int N, int Cin, int Cout, int flags,
+                                            const float* tap_sums, const void* T, int V, const float* w, int Cin_total, int c0, int C2, int CoutW,
+                                            float* dw, float* de_parts, void* stream) {
+  GANK_REQUIRE(tap_sums && T && w && dw && de_parts && V > 0 && V <= LCB_V && C2 % LCB_CT == 0 && CoutW <= 256 && CoutW % 4 == 0 && c0 >= 0 && c0 + C2 <= Cin_total,
+               "img16_conv3x3_label_bwd: bad label-gradient arguments");
+  const LabelBwdArgs lb{tap_sums, (const bf16*)T, w, dw, de_parts, nullptr, V, Cin_total, c0, C2, CoutW, 0, 9 * (C2 / LCB_CT)};
+  return img16_conv3x3_impl(x, w_rfrag, nullptr, relu_ref, nullptr, y, N, Cin, Cout, flags, nullptr, 0, nullptr, stream, nullptr, 0, &lb);
 }
 extern "C" int gank_img16_conv3x3_stats(const void* x, const void* w_rfrag, const float* bias, const void* relu_ref, const void* residual, void* y,
                                         int N, int Cin, int Cout, int flags, float* stat_sums, int stat_groups, void* stream) {
@@ -1930,7 +1950,7 @@ extern "C" int gank_cbn_relu_img16_conv3x3(const void* x, const int32_t* labels,
 }
 static int img16_conv3x3_impl(const void* x, const void* w_rfrag, const float* bias, const void* relu_ref, const void* residual, void* y,
                               int N, int Cin, int Cout, int flags, float* stat_sums, int stat_groups, const I16Cbn* cbn, void* stream,
-                              const int32_t* bias_labels, int bias_V) {
+                              const int32_t* bias_labels, int bias_V, const LabelBwdArgs* lb) {
   GANK_REQUIRE(x && w_rfrag && y && N > 0, "img16_conv3x3: null pointer");
   GANK_REQUIRE(Cin % 64 == 0 && Cout % 128 == 0, "img16_conv3x3: needs Cin %% 64 == 0 and Cout %% 128 == 0 (got %d, %d)", Cin, Cout);
   GANK_REQUIRE((flags & ~(GANK_IN_RELU | GANK_RES_UPSAMPLE2X | GANK_STATS_PREZEROED)) == 0, "img16_conv3x3: flags: GANK_IN_RELU, GANK_RES_UPSAMPLE2X, GANK_STATS_PREZEROED");
@@ -1944,6 +1964,9 @@ static int img16_conv3x3_impl(const void* x, const void* w_rfrag, const float* b
   a.res_up = (flags & GANK_RES_UPSAMPLE2X) ? 1 : 0; a.stat_sums = stat_sums; a.stat_n_per_group = stat_sums ? N / stat_groups : 1;
   a.xcd = resident_xcd_env();
   a.bias_labels = bias_labels; a.bias_V = bias_V;
+  if (lb) a.lb = *lb;
+  const bool half_form = !cbn && (gank_tune("GANK_IMG16_HALF", 1) == 2 || (gank_tune("GANK_IMG16_HALF", 1) == 1 && N * (Cout / 128) < 256));
+  a.main_blocks = (half_form ? 2 : 1) * N * (Cout / 128);
   if (cbn) {
     a.cbn_labels = cbn->labels; a.cbn_gamma = cbn->gamma; a.cbn_beta = cbn->beta; a.cbn_stats = cbn->stats;
     a.cbn_n_per_group = N / cbn->groups; a.cbn_n_labels = cbn->n_labels;
@@ -1961,7 +1984,7 @@ static int img16_conv3x3_impl(const void* x, const void* w_rfrag, const float* b
   if (cbn) {          // whole-image form only (the passes this serves have N * Cout / 128 >= 256 workgroups)
     gank_prof_tag(0, "img16_conv3x3_kernel<12, 4, false, true>");
     GANK_MAX_DYNAMIC_LDS((img16_conv3x3_kernel<12, 4, false, true>), 2 * I16_IMG, "cbn_relu_img16_conv3x3");
-    hipLaunchKernelGGL((img16_conv3x3_kernel<12, 4, false, true>), dim3(N * (Cout / 128)), dim3(512), 2 * I16_IMG, s, a);
+    hipLaunchKernelGGL((img16_conv3x3_kernel<12, 4, false, true>), dim3(a.main_blocks + a.lb.blocks), dim3(512), 2 * I16_IMG, s, a);
     gank_prof_end(0, s);
     GANK_LAUNCH_OK("cbn_relu_img16_conv3x3");
     return 0;
@@ -1973,7 +1996,7 @@ static int img16_conv3x3_impl(const void* x, const void* w_rfrag, const float* b
   do {                                                                                                    \
     gank_prof_tag(0, "img16_conv3x3_kernel<" #PF ", 4, true, false>");                                         \
     GANK_MAX_DYNAMIC_LDS((img16_conv3x3_kernel<PF, 4, true>), HALF_LDS, "img16_conv3x3");                 \
-    hipLaunchKernelGGL((img16_conv3x3_kernel<PF, 4, true>), dim3(2 * N * (Cout / 128)), dim3(512), HALF_LDS, s, a); \
+    hipLaunchKernelGGL((img16_conv3x3_kernel<PF, 4, true>), dim3(a.main_blocks + a.lb.blocks), dim3(512), HALF_LDS, s, a); \
   } while (0)
     switch (hpf_env) {
 #ifdef GANK_TUNING
@@ -1991,7 +2014,7 @@ static int img16_conv3x3_impl(const void* x, const void* w_rfrag, const float* b
   do {                                                                                                    \
     gank_prof_tag(0, "img16_conv3x3_kernel<" #PF ", " #TW ", false, false>");                                         \
     GANK_MAX_DYNAMIC_LDS((img16_conv3x3_kernel<PF, TW>), 2 * I16_IMG, "img16_conv3x3");                   \
-    hipLaunchKernelGGL((img16_conv3x3_kernel<PF, TW>), dim3(N * (Cout / 128)), dim3(2048 / TW), 2 * I16_IMG, s, a); \
+    hipLaunchKernelGGL((img16_conv3x3_kernel<PF, TW>), dim3(a.main_blocks + a.lb.blocks), dim3(2048 / TW), 2 * I16_IMG, s, a); \
   } while (0)
   switch (cfg_env) {
 #ifdef GANK_TUNING

@@ -174,80 +174,9 @@ __global__ __launch_bounds__(256) void label_conv_tap_sums_kernel(const bf16* __
 // -- the gradient of the tiled vector leaves SUMMED PER LABEL, parked at the label's first sample: its consumers (the label branch's
 // dense layer and embedding table) add the samples of a label anyway.  (The first form kept S[:, t, :] in LDS and walked it per
 // sample: 59 us, LDS-bound.)
-constexpr int LCB_CT = 16, LCB_V = 16;
-__global__ __launch_bounds__(256) void label_conv_bwd_kernel(const float* __restrict__ S, const int* __restrict__ lists, const bf16* __restrict__ T, int V,
-                                                           const float* __restrict__ w, int Cin_total, int c0, int C2, int Cout, int N,
-                                                           float* __restrict__ dw, float* __restrict__ de_parts,
-                                                           float* __restrict__ dw_feat_tmp, int merge_blocks) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int tid = threadIdx.x;
-  const int tiles = C2 / LCB_CT;
-  if ((int)blockIdx.x >= 9 * tiles) {
-    // the feature half's filter gradient, accumulated by the ordinary filter-gradient launch into a contiguous [9][c0][Cout] buffer:
-    // added into rows [0, c0) of every tap of dw, the buffer cleared for the next pass (no fill launch)
-    const long total = 9L * c0 * Cout;
-    for (long i = ((long)blockIdx.x - 9 * tiles) * 256 + tid; i < total; i += (long)merge_blocks * 256) {
-      const long t = i / ((long)c0 * Cout), rem = i - t * (long)c0 * Cout;
-      dw[t * (long)Cin_total * Cout + rem] += dw_feat_tmp[i];
-      dw_feat_tmp[i] = 0.f;
-    }
-    return;
-  }
-  const int t = blockIdx.x / tiles, ct = blockIdx.x - t * tiles;
-  const int SP = Cout + 4;                               // padded rows (16-byte aligned)
-  float* Sl = sm;                                        // [V][SP]     per-label sums of this tap
-  float* Ws = Sl + (long)V * SP;                         // [CT][SP]    (bf16-rounded, as the MFMA operand was)
-  float* Rs = Ws + (long)LCB_CT * SP;                    // [V][CT]     relu(T)
-  // Cout <= 256 (host check): one output channel per thread.  EVERY global load of the block is requested before the first wait:
-  // the tile's filter rows, the per-label sums of both row halves, the gradient rows this block adds to (three dependent round
-  // trips of 2 us each otherwise)
-  const int co = tid < Cout ? tid : Cout - 1;
-  float wreg[LCB_CT], dold[LCB_CT], sl[LCB_V];
-#pragma unroll
-  for (int j = 0; j < LCB_CT; j++) wreg[j] = w[((long)t * Cin_total + c0 + ct * LCB_CT + j) * Cout + co];
-#pragma unroll
-  for (int v = 0; v < LCB_V; v++) {
-    const int vv = v < V ? v : V - 1;
-    const float a = S[((long)vv * 9 + t) * Cout + co] + S[(((long)V + vv) * 9 + t) * Cout + co];      // the two row halves
-    sl[v] = v < V ? a : 0.f;
-  }
-#pragma unroll
-  for (int j = 0; j < LCB_CT; j++) dold[j] = dw[((long)t * Cin_total + c0 + ct * LCB_CT + j) * Cout + co];
-  for (int i = tid; i < V * LCB_CT; i += 256) Rs[i] = fmaxf(bf2f(T[(long)(i / LCB_CT) * C2 + ct * LCB_CT + (i % LCB_CT)]), 0.f);
-  if (tid < Cout) {
-#pragma unroll
-    for (int j = 0; j < LCB_CT; j++) Ws[(long)j * SP + tid] = bf2f(f2bf(wreg[j]));
-#pragma unroll
-    for (int v = 0; v < LCB_V; v++)
-      if (v < V) Sl[(long)v * SP + tid] = sl[v];
-  }
-  __syncthreads();
-  if (tid < Cout) {
-    // filter gradient of this block's CT rows: dw[t][c0 + c][co] += sum_v relu(T[v][c]) Sl[v][co]   (this block is their only writer)
-#pragma unroll
-    for (int v = 0; v < LCB_V; v++)
-      if (v < V) {
-#pragma unroll
-        for (int j = 0; j < LCB_CT; j++) dold[j] += Rs[v * LCB_CT + j] * sl[v];
-      }
-#pragma unroll
-    for (int j = 0; j < LCB_CT; j++) dw[((long)t * Cin_total + c0 + ct * LCB_CT + j) * Cout + tid] = dold[j];
-  }
-  // gradient of the tiled vector, this tap's and tile's share per LABEL: thread (v, channel j of the tile)
-  if (tid < V * LCB_CT) {
-    const int v = tid / LCB_CT, j = tid - v * LCB_CT;
-    f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
-    const f32x4* wr = reinterpret_cast<const f32x4*>(Ws + (long)j * SP);
-    const f32x4* sr = reinterpret_cast<const f32x4*>(Sl + (long)v * SP);
-#pragma unroll 8
-    for (int q = 0; q < (Cout >> 2); q++) {
-      const f32x4 a = wr[q], b2 = sr[q];
-#pragma unroll
-      for (int u = 0; u < 4; u++) a4[u] += a[u] * b2[u];
-    }
-    de_parts[((long)t * V + v) * C2 + ct * LCB_CT + j] = Rs[v * LCB_CT + j] > 0.f ? (a4[0] + a4[1]) + (a4[2] + a4[3]) : 0.f;
-  }
-  (void)lists; (void)N;
+__global__ __launch_bounds__(256) void label_conv_bwd_kernel(LabelBwdArgs q) {
+  extern __shared__ __attribute__((aligned(16))) float sm_[];
+  label_conv_bwd_block(q, blockIdx.x, sm_);
 }
 
 extern "C" long gank_label_conv3x3_bwd_ws_floats(int N, int Cout) { (void)N; return 2L * 16 * 9 * Cout; }      // [2 row halves][<= 16 labels][9][Cout]
@@ -265,8 +194,8 @@ extern "C" int gank_label_conv3x3_bwd(const void* dy, const int32_t* lists, cons
   GANK_REQUIRE(lds2 <= 64 * 1024, "label_conv3x3_bwd: N = %d, Cout = %d do not fit the LDS", N, Cout);
   if (dy) hipLaunchKernelGGL(label_conv_tap_sums_kernel, dim3(V * 2 * (Cout / 64)), dim3(256), lds1, s, (const bf16*)dy, lists, ws, N, V, H, W, Cout);
   const int merge_blocks = dw_feat_tmp ? 64 : 0;
-  hipLaunchKernelGGL(label_conv_bwd_kernel, dim3(9 * (C2 / LCB_CT) + merge_blocks), dim3(256), lds2, s, ws, lists, (const bf16*)T, V, w, Cin_total, c0, C2, Cout,
-                     N, dw, de_parts, dw_feat_tmp, merge_blocks);
+  const LabelBwdArgs q{ws, (const bf16*)T, w, dw, de_parts, dw_feat_tmp, V, Cin_total, c0, C2, Cout, merge_blocks, 9 * (C2 / LCB_CT) + merge_blocks};
+  hipLaunchKernelGGL(label_conv_bwd_kernel, dim3(q.blocks), dim3(256), lds2, s, q);
   GANK_LAUNCH_OK("label_conv3x3_bwd");
   return 0;
 }

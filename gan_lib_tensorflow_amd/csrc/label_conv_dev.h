@@ -75,3 +75,95 @@ __device__ __forceinline__ void label_conv_tap_sums_block(const bf16* __restrict
   }
 }
 
+
+// ---- the label gradients (gank_label_conv3x3_bwd's second launch), also carried by the image-resident input-gradient launch ----
+constexpr int LCB_CT = 16, LCB_V = 16;
+struct LabelBwdArgs {
+  const float* S;          // [2 row halves][V][9][Cout] per-label tap sums
+  const bf16* T;           // [V][C2]
+  const float* w;          // the whole fp32 filter [3,3,Cin_total,Cout]
+  float* dw;               // its gradient (rows c0 .. c0 + C2 - 1 of every tap accumulated here)
+  float* de_parts;         // [9][V][C2]
+  float* dw_feat_tmp;      // optional staging buffer of the other rows (see gank_label_conv3x3_bwd)
+  int V, Cin_total, c0, C2, Cout, merge_blocks;
+  int blocks;              // 9 * (C2 / LCB_CT) + merge_blocks
+};
+// one block of the label gradients; NT = threads of the calling launch (>= 256: the first 256 work, all of them meet at the barriers)
+__device__ __forceinline__ void label_conv_bwd_block(const LabelBwdArgs& q, int block, float* sm) {
+  const float* __restrict__ S = q.S;
+  const bf16* __restrict__ T = q.T;
+  const float* __restrict__ w = q.w;
+  float* __restrict__ dw = q.dw;
+  float* __restrict__ de_parts = q.de_parts;
+  float* __restrict__ dw_feat_tmp = q.dw_feat_tmp;
+  const int V = q.V, Cin_total = q.Cin_total, c0 = q.c0, C2 = q.C2, Cout = q.Cout, merge_blocks = q.merge_blocks;
+  const int tid = threadIdx.x < 256 ? threadIdx.x : 256 + (threadIdx.x & 255);      // threads past 256 fall outside every loop bound below
+  const bool worker = threadIdx.x < 256;
+  const int tiles = C2 / LCB_CT;
+  if (block >= 9 * tiles) {
+    // the feature half's filter gradient, accumulated by the ordinary filter-gradient launch into a contiguous [9][c0][Cout] buffer:
+    // added into rows [0, c0) of every tap of dw, the buffer cleared for the next pass (no fill launch)
+    const long total = 9L * c0 * Cout;
+    for (long i = ((long)block - 9 * tiles) * 256 + threadIdx.x; worker && i < total; i += (long)merge_blocks * 256) {
+      const long t = i / ((long)c0 * Cout), rem = i - t * (long)c0 * Cout;
+      dw[t * (long)Cin_total * Cout + rem] += dw_feat_tmp[i];
+      dw_feat_tmp[i] = 0.f;
+    }
+    return;
+  }
+  const int t = block / tiles, ct = block - t * tiles;
+  const int SP = Cout + 4;                               // padded rows (16-byte aligned)
+  float* Sl = sm;                                        // [V][SP]     per-label sums of this tap
+  float* Ws = Sl + (long)V * SP;                         // [CT][SP]    (bf16-rounded, as the MFMA operand was)
+  float* Rs = Ws + (long)LCB_CT * SP;                    // [V][CT]     relu(T)
+  // Cout <= 256 (host check): one output channel per thread.  EVERY global load of the block is requested before the first wait:
+  // the tile's filter rows, the per-label sums of both row halves, the gradient rows this block adds to (three dependent round
+  // trips of 2 us each otherwise)
+  const int co = tid < Cout ? tid : Cout - 1;
+  float wreg[LCB_CT], dold[LCB_CT], sl[LCB_V];
+#pragma unroll
+  for (int j = 0; j < LCB_CT; j++) wreg[j] = w[((long)t * Cin_total + c0 + ct * LCB_CT + j) * Cout + co];
+#pragma unroll
+  for (int v = 0; v < LCB_V; v++) {
+    const int vv = v < V ? v : V - 1;
+    const float a = S[((long)vv * 9 + t) * Cout + co] + S[(((long)V + vv) * 9 + t) * Cout + co];      // the two row halves
+    sl[v] = v < V ? a : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < LCB_CT; j++) dold[j] = dw[((long)t * Cin_total + c0 + ct * LCB_CT + j) * Cout + co];
+  for (int i = tid; i < V * LCB_CT; i += 256) Rs[i] = fmaxf(bf2f(T[(long)(i / LCB_CT) * C2 + ct * LCB_CT + (i % LCB_CT)]), 0.f);
+  if (tid < Cout) {
+#pragma unroll
+    for (int j = 0; j < LCB_CT; j++) Ws[(long)j * SP + tid] = bf2f(f2bf(wreg[j]));
+#pragma unroll
+    for (int v = 0; v < LCB_V; v++)
+      if (v < V) Sl[(long)v * SP + tid] = sl[v];
+  }
+  __syncthreads();
+  if (tid < Cout) {
+    // filter gradient of this block's CT rows: dw[t][c0 + c][co] += sum_v relu(T[v][c]) Sl[v][co]   (this block is their only writer)
+#pragma unroll
+    for (int v = 0; v < LCB_V; v++)
+      if (v < V) {
+#pragma unroll
+        for (int j = 0; j < LCB_CT; j++) dold[j] += Rs[v * LCB_CT + j] * sl[v];
+      }
+#pragma unroll
+    for (int j = 0; j < LCB_CT; j++) dw[((long)t * Cin_total + c0 + ct * LCB_CT + j) * Cout + tid] = dold[j];
+  }
+  // gradient of the tiled vector, this tap's and tile's share per LABEL: thread (v, channel j of the tile)
+  if (tid < V * LCB_CT) {
+    const int v = tid / LCB_CT, j = tid - v * LCB_CT;
+    f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4* wr = reinterpret_cast<const f32x4*>(Ws + (long)j * SP);
+    const f32x4* sr = reinterpret_cast<const f32x4*>(Sl + (long)v * SP);
+#pragma unroll 8
+    for (int q = 0; q < (Cout >> 2); q++) {
+      const f32x4 a = wr[q], b2 = sr[q];
+#pragma unroll
+      for (int u = 0; u < 4; u++) a4[u] += a[u] * b2[u];
+    }
+    de_parts[((long)t * V + v) * C2 + ct * LCB_CT + j] = Rs[v * LCB_CT + j] > 0.f ? (a4[0] + a4[1]) + (a4[2] + a4[3]) : 0.f;
+  }
+}
+

@@ -1200,6 +1200,7 @@ class _ConcatLabelForkPool(Function):
         return (da if ctx.needs_input_grad[0] else None), None, dt, dw, db
 
 
+LABEL_BWD_RIDER = False     # ... and its label gradients as extra workgroups of the input-gradient launch (measured: 20.7 + 6.8 us -> 26.6 us, no gain)
 TAP_SUMS_RIDER = True       # ... its per-label tap sums as extra workgroups of the feature half's filter-gradient launch
 FACTOR_LABEL_CONV = True    # D.Block.2.Conv1 with the tiled (spatially constant) half of its input factored out (csrc/label_conv.hip, round 5)
 
@@ -1248,7 +1249,11 @@ class _ConcatLabelConv1(Function):
                     # (summed with the pass's other slabs; the per-label tap sums of dh1 ride on the same launch)
                     sums = K.conv2d_wgrad_rows(a, g, tgt4, (16, 16), 3, K.IN_RELU, _slab_jobs, dbias=btgt,
                                                tap_sums=(lists, T.shape[0]) if TAP_SUMS_RIDER else None)
-                    parts = K.label_conv3x3_bwd(g, lists, T, W1.detach(), c1, tgt4, sums=sums)
+                    if sums is not None and LABEL_BWD_RIDER and ctx.needs_input_grad[0]:
+                        # ... and the label gradients on the input-gradient launch
+                        da, parts = K.img16_conv3x3_label_bwd(g, ctx.rd, a, c1, sums, T, W1.detach(), c1, tgt4)
+                    else:
+                        parts = K.label_conv3x3_bwd(g, lists, T, W1.detach(), c1, tgt4, sums=sums)
                 else:                          # small batches: through a zero-filled staging buffer, merged by the same launch
                     tmp = K.zeros_f32((3, 3, c1, cout), a.device)
                     K.conv2d_wgrad(a, g, tmp, (16, 16), 3, K.IN_RELU, 1.0, dbias=btgt)
@@ -1260,7 +1265,7 @@ class _ConcatLabelConv1(Function):
                 if need_label:                 # (a frozen filter with a trainable label branch: no such graph in the train steps)
                     scratch = K.zeros_f32(tuple(W1.shape), a.device)
                     parts = K.label_conv3x3_bwd(g, lists, T, W1.detach(), c1, scratch)
-            if ctx.needs_input_grad[0]:
+            if ctx.needs_input_grad[0] and da is None:
                 da = K.img16_conv3x3(g, ctx.rd, None, c1, 0, a)          # relu mask of the feature half in the epilogue
         if gp is not None:
             if da is None:

@@ -1369,6 +1369,19 @@ def img16_conv3x3_label_bias(x, rf, bias_table, labels, cout, flags=0):
     return y
 
 
+def img16_conv3x3_label_bwd(dy, rd, relu_ref, cin_out, sums, t, w, c0, dw):
+    """gank_img16_conv3x3_label_bwd: the factored layer's input gradient (dy [N,16,16,Cout] -> [N,16,16,cin_out], masked by relu_ref) and,
+    as extra workgroups of the same launch, label_conv3x3_bwd's label gradients on the tap sums `sums` -> (dx, de_parts fp32 [9,V,C2])"""
+    n, cout = dy.shape[0], dy.shape[3]
+    v, c2 = t.shape
+    dx = torch.empty((n, 16, 16, cin_out), dtype=BF16, device=dy.device)
+    parts = torch.empty((9, v, c2), dtype=F32, device=dy.device)
+    _lib.check(lib().gank_img16_conv3x3_label_bwd(_p(dy, BF16, "dy"), _p(rd, BF16, "rd"), _p(relu_ref, BF16, "relu_ref"), _p(dx), n, cout, cin_out, 0,
+                                                  _p(sums, F32, "sums"), _p(t, BF16, "T"), v, _p(w, F32, "w"), w.shape[2], c0, c2, w.shape[3],
+                                                  _p(dw, F32, "dw"), _p(parts), _stream()), "img16_conv3x3_label_bwd")
+    return dx, parts
+
+
 def label_conv3x3_bwd(dy, lists, t, w, c0, dw, dw_feat_tmp=None, sums=None):
     """gank_label_conv3x3_bwd: ACCUMULATES the constant channels' filter gradient into rows c0.. of dw [3,3,Cin,Cout] (and adds +
     clears dw_feat_tmp [3,3,c0,Cout] into rows 0..c0-1) -> de_parts fp32 [9,V,C2]: the gradient of the tiled vector per tap and LABEL

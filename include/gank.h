@@ -622,6 +622,12 @@ int gank_label_conv3x3_table_pooled(const float* w, int Cin_total, int c0, int C
                                     int H, int W, int C1, void* stream);
 int gank_img16_conv3x3_label_bias(const void* x, const void* w_rfrag, const float* bias_table, const int32_t* labels, int V, void* y,
                                   int N, int Cin, int Cout, int flags, void* stream);
+/* the image-resident conv (here: the factored layer's input gradient, x = dy [N,16,16,Cin], w_rfrag = the feature half's dgrad operand,
+ * relu_ref = the features) with gank_label_conv3x3_bwd's label-gradient launch as extra workgroups (tap_sums as left by
+ * gank_conv2d_wgrad_slabs_rows_tap_sums; w [3,3,Cin_total,CoutW] and dw the whole filter and its gradient) */
+int gank_img16_conv3x3_label_bwd(const void* x, const void* w_rfrag, const void* relu_ref, void* y, int N, int Cin, int Cout, int flags,
+                                 const float* tap_sums, const void* T, int V, const float* w, int Cin_total, int c0, int C2, int CoutW,
+                                 float* dw, float* de_parts, void* stream);
 long gank_label_conv3x3_bwd_ws_floats(int N, int Cout);
 int gank_label_conv3x3_bwd(const void* dy, const int32_t* lists, const void* T, int V, const float* w, int Cin_total, int c0, int C2,
                            int Cout, int N, int H, int W, float* dw, float* dw_feat_tmp, float* de_parts, float* ws, void* stream);

@@ -1639,6 +1639,13 @@ def test_conv3x3_with_its_spatially_constant_input_channels_factored_out(K, n):
         parts3 = K.label_conv3x3_bwd(dyt, lists, tt, wt, c1, dw3, sums=sums)
         torch.cuda.synchronize()
         assert torch.equal(dw3, dw2) and torch.equal(parts3, parts)
+        # ... and with the label gradients as extra workgroups of the input-gradient launch
+        dw4 = torch.tensor(dw0).cuda()
+        sums = K.conv2d_wgrad_rows(at, dyt, dw4, (16, 16), 3, K.IN_RELU, jobs, tap_sums=(lists, v))
+        K.sum_slabs(jobs)
+        da4, parts4 = K.img16_conv3x3_label_bwd(dyt, rd, at, c1, sums, tt, wt, c1, dw4)
+        torch.cuda.synchronize()
+        assert torch.equal(dw4, dw2) and torch.equal(parts4, parts) and torch.equal(da4.view(torch.int16), da.view(torch.int16))
     else:
         assert n < 64
     # the pooled / unpooled ends of the pair: the pooled concat alone, and the gradient join with the factored consumer's partial sums
