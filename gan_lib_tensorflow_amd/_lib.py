@@ -144,6 +144,7 @@ PROTOTYPES = {
     "gank_label_conv3x3_table": [P, I, I, I, I, P, I, P, P, P, I, P, P],
     "gank_label_conv3x3_table_pooled": [P, I, I, I, I, P, I, P, P, P, I, P, P, P, I, I, I, P],
     "gank_img16_conv3x3_label_bias": [P, P, P, P, I, P, I, I, I, I, P],
+    "gank_img16_conv3x3_dgrad_unpool": [P, P, P, P, I, F, P, I, I, I, P],
     "gank_img16_conv3x3_label_bwd": [P, P, P, P, I, I, I, I, P, P, I, P, I, I, I, I, P, P, P],
     "gank_label_conv3x3_bwd_ws_floats": [I, I],
     "gank_label_conv3x3_bwd": [P, P, P, I, P, I, I, I, I, I, I, I, P, P, P, P, P],

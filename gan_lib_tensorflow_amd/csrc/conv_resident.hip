@@ -1620,7 +1620,9 @@ struct I16Args {
   LabelBwdArgs lb;
   int main_blocks;
   const bf16* mask;       // optional [N,16,16,Cout]: result zeroed where mask <= 0 (relu backward)
-  const bf16* res;        // optional [N,16,16,Cout]: added last
+  const bf16* res;        // optional [N,16,16,Cout]: added last (res_pitch > 0: rows of res_pitch channels, the first Cout of them; scaled by res_scale)
+  int res_pitch;
+  float res_scale;
   bf16* y;                // [N,16,16,Cout]
   float* stat_sums;       // optional [groups][GANK_STAT_SLOTS][2][Cout]: batch-norm statistics of (y - bias), as gank_res8_conv3x3
   int N, Cin, Cout, relu; // relu: on the input operand while it is staged
@@ -1844,9 +1846,14 @@ __global__ __launch_bounds__(HALF ? 512 : 2048 / TW) void img16_conv3x3_kernel(I
         for (int e = 0; e < 8; e++) v[e] = bf2f(mk[e]) > 0.f ? v[e] : 0.f;
       }
       if (a.res) {
-        const bf16x8 rs = *reinterpret_cast<const bf16x8*>(a.res + mr * a.Cout + co);
+        const bf16x8 rs = *reinterpret_cast<const bf16x8*>(a.res + mr * (a.res_pitch > 0 ? a.res_pitch : a.Cout) + co);
+        if (a.res_pitch > 0) {
 #pragma unroll
-        for (int e = 0; e < 8; e++) v[e] += bf2f(rs[e]);
+          for (int e = 0; e < 8; e++) v[e] += a.res_scale * bf2f(rs[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; e++) v[e] += bf2f(rs[e]);
+        }
       }
       f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
       if (a.bias) {
@@ -1910,7 +1917,7 @@ struct I16Cbn { const int* labels; const float* gamma; const float* beta; const 
 }
 static int img16_conv3x3_impl(const void* x, const void* w_rfrag, const float* bias, const void* relu_ref, const void* residual, void* y,
                               int N, int Cin, int Cout, int flags, float* stat_sums, int stat_groups, const I16Cbn* cbn, void* stream,
-                              const int32_t* bias_labels = nullptr, int bias_V = 0, const LabelBwdArgs* lb = nullptr);
+                              const int32_t* bias_labels = nullptr, int bias_V = 0, const LabelBwdArgs* lb = nullptr, int res_pitch = 0, float res_scale = 1.f);
 // the layer's spatially constant input channels factored out (label_conv.hip): bias_table [V][9][Cout] from gank_label_conv3x3_table
 // holds, per label and border class of a pixel, the layer's bias plus what those channels contribute; x and w_rfrag are the
 // remaining (feature) channels only
@@ -1929,6 +1936,15 @@ extern "C" int gank_img16_conv3x3_label_bwd(const void* x, const void* w_rfrag, 
                "img16_conv3x3_label_bwd: bad label-gradient arguments");
   const LabelBwdArgs lb{tap_sums, (const bf16*)T, w, dw, de_parts, nullptr, V, Cin_total, c0, C2, CoutW, 0, 9 * (C2 / LCB_CT)};
   return img16_conv3x3_impl(x, w_rfrag, nullptr, relu_ref, nullptr, y, N, Cin, Cout, flags, nullptr, 0, nullptr, stream, nullptr, 0, &lb);
+}
+// the input gradient behind a fork whose other branch is a 2x2 mean pool (D.Block.2's fan-out: gan_cifar_resnet.py:166-184 with the pooled
+// shortcut): dx = relu_mask(conv(dy)) + res_scale * unpool2x(g_pooled[..., :Cout]) in the conv's epilogue -- g_pooled [N,8,8,res_pitch]
+// holds the pooled branch's gradient (its first Cout channels belong to this tensor), so the join of the two branch gradients costs no pass
+extern "C" int gank_img16_conv3x3_dgrad_unpool(const void* x, const void* w_rfrag, const void* relu_ref, const void* g_pooled, int res_pitch,
+                                               float res_scale, void* y, int N, int Cin, int Cout, void* stream) {
+  GANK_REQUIRE(g_pooled && res_pitch >= Cout && res_pitch % 8 == 0, "img16_conv3x3_dgrad_unpool: the pooled gradient needs at least Cout channels per pixel");
+  return img16_conv3x3_impl(x, w_rfrag, nullptr, relu_ref, g_pooled, y, N, Cin, Cout, GANK_RES_UPSAMPLE2X, nullptr, 0, nullptr, stream, nullptr, 0, nullptr,
+                            res_pitch, res_scale);
 }
 extern "C" int gank_img16_conv3x3_stats(const void* x, const void* w_rfrag, const float* bias, const void* relu_ref, const void* residual, void* y,
                                         int N, int Cin, int Cout, int flags, float* stat_sums, int stat_groups, void* stream) {
@@ -1950,7 +1966,7 @@ extern "C" int gank_cbn_relu_img16_conv3x3(const void* x, const int32_t* labels,
 }
 static int img16_conv3x3_impl(const void* x, const void* w_rfrag, const float* bias, const void* relu_ref, const void* residual, void* y,
                               int N, int Cin, int Cout, int flags, float* stat_sums, int stat_groups, const I16Cbn* cbn, void* stream,
-                              const int32_t* bias_labels, int bias_V, const LabelBwdArgs* lb) {
+                              const int32_t* bias_labels, int bias_V, const LabelBwdArgs* lb, int res_pitch, float res_scale) {
   GANK_REQUIRE(x && w_rfrag && y && N > 0, "img16_conv3x3: null pointer");
   GANK_REQUIRE(Cin % 64 == 0 && Cout % 128 == 0, "img16_conv3x3: needs Cin %% 64 == 0 and Cout %% 128 == 0 (got %d, %d)", Cin, Cout);
   GANK_REQUIRE((flags & ~(GANK_IN_RELU | GANK_RES_UPSAMPLE2X | GANK_STATS_PREZEROED)) == 0, "img16_conv3x3: flags: GANK_IN_RELU, GANK_RES_UPSAMPLE2X, GANK_STATS_PREZEROED");
@@ -1965,6 +1981,7 @@ static int img16_conv3x3_impl(const void* x, const void* w_rfrag, const float* b
   a.xcd = resident_xcd_env();
   a.bias_labels = bias_labels; a.bias_V = bias_V;
   if (lb) a.lb = *lb;
+  a.res_pitch = res_pitch; a.res_scale = res_scale;
   const bool half_form = !cbn && (gank_tune("GANK_IMG16_HALF", 1) == 2 || (gank_tune("GANK_IMG16_HALF", 1) == 1 && N * (Cout / 128) < 256));
   a.main_blocks = (half_form ? 2 : 1) * N * (Cout / 128);
   if (cbn) {

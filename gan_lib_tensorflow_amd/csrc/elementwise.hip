@@ -814,6 +814,35 @@ __global__ __launch_bounds__(1024) void concat_label_unpool_bwd_kernel(const bf1
   constexpr int NT = 1024;
   const int n = blockIdx.x, C = C1 + C2, HW = H * W, Wp = W >> 1;
   const int cg = C >> 3, cg1 = C1 >> 3, cg2 = C2 >> 3;
+  __shared__ float red[NT * 8];
+  if (!da) {
+    // only the tiled vector's gradient (the first C1 channels' join happens in gank_img16_conv3x3_dgrad_unpool): each of the four
+    // full-resolution pixels under a pooled pixel contributes bf16(0.25 g) = 0.25 g exactly, so the sum over the sample is the sum of
+    // the pooled gradient's tiled half -- thread = (8-channel group, pooled pixel lane), ONE batch of loads, lanes meet in LDS
+    const int PL = NT / cg2, g2 = threadIdx.x % cg2, pl = threadIdx.x / cg2;
+    const int HWp = (H >> 1) * Wp;
+    float a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int p = pl; p < HWp; p += PL) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(gp + ((long)n * HWp + p) * C + C1 + g2 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; e++) a8[e] += bf2f(v[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) red[threadIdx.x * 8 + e] = a8[e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C2; c += NT) {
+      float t = 0.f;
+      for (int l = 0; l < PL; l++) t += red[(l * cg2 + (c >> 3)) * 8 + (c & 7)];
+      if (de_parts > 0) {
+        int lb = labels[n];
+        lb = lb < 0 ? 0 : (lb >= V ? V - 1 : lb);
+        if (lists[(long)lb * (N + 1) + 1] == n)
+          for (int p = 0; p < de_parts; p++) t += de_add[((long)p * V + lb) * C2 + c];
+      }
+      de[(long)n * C2 + c] = t;
+    }
+    return;
+  }
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // thread -> a fixed 8-channel group (NT % cg == 0), pixels strided: the tiled half's partial sums stay in registers
   const int g = threadIdx.x % cg, rl = threadIdx.x / cg, RL = NT / cg;
@@ -837,7 +866,6 @@ __global__ __launch_bounds__(1024) void concat_label_unpool_bwd_kernel(const bf1
       for (int e = 0; e < 8; e++) acc[e] += bf2f(f2bf(v[e]));       // the rounded value the separate launches summed
     }
   }
-  __shared__ float red[NT * 8];
 #pragma unroll
   for (int e = 0; e < 8; e++) red[threadIdx.x * 8 + e] = acc[e];
   __syncthreads();
@@ -979,9 +1007,9 @@ extern "C" int gank_concat_label_unpool_bwd(const void* g_main, const void* g_po
 // order to the label's first sample: labels [N], lists from gank_label_conv3x3_table)
 extern "C" int gank_concat_label_unpool_bwd_factored(const void* g_main_c1, const void* g_pooled, void* da, float* de32, const float* de_add, int de_parts,
                                                      const int32_t* labels, const int32_t* lists, int V, int N, int H, int W, int C1, int C2, void* stream) {
-  GANK_REQUIRE(g_main_c1 && g_pooled && da && de32 && N > 0 && H > 0 && W > 0 && (de_parts == 0 || (de_add && labels && lists && V > 0)),
-               "concat_label_unpool_bwd_factored: bad arguments");
-  GANK_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && H % 2 == 0 && W % 2 == 0 && 1024 % ((C1 + C2) / 8) == 0,
+  GANK_REQUIRE(g_pooled && de32 && N > 0 && H > 0 && W > 0 && (de_parts == 0 || (de_add && labels && lists && V > 0)) && (da == nullptr || g_main_c1),
+               "concat_label_unpool_bwd_factored: bad arguments");      // da NULL (then g_main_c1 is ignored): only the tiled vector's gradient
+  GANK_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && H % 2 == 0 && W % 2 == 0 && 1024 % ((C1 + C2) / 8) == 0 && 1024 % (C2 / 8) == 0,
                "concat_label_unpool_bwd_factored: unsupported shape (%d + %d channels, %d x %d)", C1, C2, H, W);
   hipLaunchKernelGGL(concat_label_unpool_bwd_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, (const bf16*)g_main_c1, (const bf16*)g_pooled,
                      (bf16*)da, de32, H, W, C1, C2, 1, de_add, de_parts, N, labels, lists, V);

@@ -1200,6 +1200,7 @@ class _ConcatLabelForkPool(Function):
         return (da if ctx.needs_input_grad[0] else None), None, dt, dw, db
 
 
+JOIN_IN_DGRAD = True        # ... the pooled shortcut's gradient joins the feature gradient in the input-gradient launch's epilogue
 LABEL_BWD_RIDER = False     # ... and its label gradients as extra workgroups of the input-gradient launch (measured: 20.7 + 6.8 us -> 26.6 us, no gain)
 TAP_SUMS_RIDER = True       # ... its per-label tap sums as extra workgroups of the feature half's filter-gradient launch
 FACTOR_LABEL_CONV = True    # D.Block.2.Conv1 with the tiled (spatially constant) half of its input factored out (csrc/label_conv.hip, round 5)
@@ -1235,6 +1236,7 @@ class _ConcatLabelConv1(Function):
         n, c1, cout = a.shape[0], a.shape[3], W1.shape[3]
         dW = db = None
         parts = da = None
+        joined = False
         need_label = ctx.needs_input_grad[2] or ctx.needs_input_grad[3] or (ctx.b_emb is not None and ctx.needs_input_grad[4])
         if dh1 is not None:
             g = _c(dh1)
@@ -1266,11 +1268,19 @@ class _ConcatLabelConv1(Function):
                     scratch = K.zeros_f32(tuple(W1.shape), a.device)
                     parts = K.label_conv3x3_bwd(g, lists, T, W1.detach(), c1, scratch)
             if ctx.needs_input_grad[0] and da is None:
-                da = K.img16_conv3x3(g, ctx.rd, None, c1, 0, a)          # relu mask of the feature half in the epilogue
+                if gp is not None and JOIN_IN_DGRAD:
+                    # ... and the pooled branch's gradient joins in the same epilogue: 0.25 * unpool(gp[..., :C1]) (no join pass over da)
+                    da = K.img16_conv3x3_dgrad_unpool(g, ctx.rd, a, _c(gp), c1, 0.25)
+                    joined = True
+                else:
+                    da = K.img16_conv3x3(g, ctx.rd, None, c1, 0, a)      # relu mask of the feature half in the epilogue
         if gp is not None:
             if da is None:
                 da = K.zeros_bf16(tuple(a.shape), a.device) if hasattr(K, "zeros_bf16") else torch.zeros_like(a)
-            da, de32 = K.concat_label_unpool_bwd_factored(da, _c(gp), parts if need_label else None, labels, lists)
+            if joined:
+                _, de32 = K.concat_label_unpool_bwd_factored(c1, _c(gp), parts if need_label else None, labels, lists)
+            else:
+                da, de32 = K.concat_label_unpool_bwd_factored(da, _c(gp), parts if need_label else None, labels, lists)
         else:                                  # (no pooled branch: not a graph of this library; the per-label sums at each label's first sample)
             de32 = torch.zeros((n, T.shape[1]), dtype=torch.float32, device=a.device)
             if parts is not None:

@@ -1316,8 +1316,11 @@ def concat_label_unpool_bwd_factored(g_main_c1, g_pooled, de_add=None, labels=No
     gradient), de_add fp32 [parts,V,C2] that consumer's gradient of the tiled vector per LABEL (added to the row of the label's first
     sample: labels, lists from label_conv3x3_table) -> (da bf16 [N,H,W,C1], de32 fp32 [N,C2])"""
     n, hp, wp, c = g_pooled.shape
-    c1 = g_main_c1.shape[3]
-    da = torch.empty((n, 2 * hp, 2 * wp, c1), dtype=BF16, device=g_pooled.device)
+    want_da = not isinstance(g_main_c1, int)          # an int = C1: only the tiled vector's gradient (the feature join happened elsewhere)
+    c1 = g_main_c1.shape[3] if want_da else int(g_main_c1)
+    da = torch.empty((n, 2 * hp, 2 * wp, c1), dtype=BF16, device=g_pooled.device) if want_da else None
+    if not want_da:
+        g_main_c1 = None
     de = torch.empty((n, c - c1), dtype=F32, device=g_pooled.device)
     parts = 0 if de_add is None else de_add.shape[0]
     v = 0 if de_add is None else de_add.shape[1]
@@ -1366,6 +1369,16 @@ def img16_conv3x3_label_bias(x, rf, bias_table, labels, cout, flags=0):
     y = torch.empty((n, 16, 16, cout), dtype=BF16, device=x.device)
     _lib.check(lib().gank_img16_conv3x3_label_bias(_p(x, BF16, "x"), _p(rf, BF16, "rf"), _p(bias_table, F32, "bias_table"), _p(labels, I32, "labels"),
                                                    bias_table.shape[0], _p(y), n, cin, cout, flags, _stream()), "img16_conv3x3_label_bias")
+    return y
+
+
+def img16_conv3x3_dgrad_unpool(dy, rd, relu_ref, g_pooled, cout, scale=0.25):
+    """gank_img16_conv3x3_dgrad_unpool: relu_mask(conv(dy)) + scale * unpool2x(g_pooled[..., :cout]) -> [N,16,16,cout]"""
+    n, cin = dy.shape[0], dy.shape[3]
+    assert tuple(dy.shape[1:3]) == (16, 16) and tuple(g_pooled.shape[:3]) == (n, 8, 8) and g_pooled.shape[3] >= cout
+    y = torch.empty((n, 16, 16, cout), dtype=BF16, device=dy.device)
+    _lib.check(lib().gank_img16_conv3x3_dgrad_unpool(_p(dy, BF16, "dy"), _p(rd, BF16, "rd"), _p(relu_ref, BF16, "relu_ref"), _p(g_pooled, BF16, "g_pooled"),
+                                                     g_pooled.shape[3], float(scale), _p(y), n, cin, cout, _stream()), "img16_conv3x3_dgrad_unpool")
     return y
 
 

@@ -622,6 +622,11 @@ int gank_label_conv3x3_table_pooled(const float* w, int Cin_total, int c0, int C
                                     int H, int W, int C1, void* stream);
 int gank_img16_conv3x3_label_bias(const void* x, const void* w_rfrag, const float* bias_table, const int32_t* labels, int V, void* y,
                                   int N, int Cin, int Cout, int flags, void* stream);
+/* the image-resident conv as the input gradient behind a fork whose other branch is a 2x2 mean pool: dx = relu_mask(conv(dy)) +
+ * res_scale * unpool2x(g_pooled[..., :Cout]), g_pooled [N,8,8,res_pitch] the pooled branch's gradient -- the join of the two branch gradients
+ * in the conv's epilogue (gank_concat_label_unpool_bwd_factored with da = NULL then computes the tiled vector's gradient alone) */
+int gank_img16_conv3x3_dgrad_unpool(const void* x, const void* w_rfrag, const void* relu_ref, const void* g_pooled, int res_pitch,
+                                    float res_scale, void* y, int N, int Cin, int Cout, void* stream);
 /* the image-resident conv (here: the factored layer's input gradient, x = dy [N,16,16,Cin], w_rfrag = the feature half's dgrad operand,
  * relu_ref = the features) with gank_label_conv3x3_bwd's label-gradient launch as extra workgroups (tap_sums as left by
  * gank_conv2d_wgrad_slabs_rows_tap_sums; w [3,3,Cin_total,CoutW] and dw the whole filter and its gradient) */

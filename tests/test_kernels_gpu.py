@@ -1663,6 +1663,13 @@ def test_conv3x3_with_its_spatially_constant_input_channels_factored_out(K, n):
     da3, de3 = K.concat_label_unpool_bwd(gm_full, gpt, c1)
     torch.cuda.synchronize()
     assert torch.equal(yp.view(torch.int16), yp_full.view(torch.int16)) and torch.equal(da2.view(torch.int16), da3.view(torch.int16))
+    # the feature half's join inside the input-gradient launch: relu_mask(conv(dy)) + 0.25 * unpool(gp[..., :C1]) with ONE rounding
+    da5 = K.img16_conv3x3_dgrad_unpool(dyt, rd, at, gpt, c1, 0.25)
+    _, de5 = K.concat_label_unpool_bwd_factored(c1, gpt, parts, lt, lists)
+    torch.cuda.synchronize()
+    assert relerr(da5, da_ref + 0.25 * np.repeat(np.repeat(gp[..., :c1], 2, axis=1), 2, axis=2)) < BF_TOL
+    assert float((da5.float() - da3.float()).abs().max()) <= 2.0 ** -7 * float(da3.float().abs().max())        # (the two-pass form rounds twice)
+    assert relerr(de5, de2.double().cpu().numpy()) < 1e-6           # (the sum of the pooled gradient itself: another order of the same additions)
     want = de3.double().cpu().numpy().copy()            # the per-label sums join the row of the label's first sample
     for lab in range(v):
         idx = np.nonzero(labels == lab)[0]
