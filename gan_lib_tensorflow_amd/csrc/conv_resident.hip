@@ -627,9 +627,10 @@ struct CpBwdArgs {
 }  // namespace
 
 // fprop: 8 waves = (Cout tile ct = wave & 3) x (pixel group pg = wave >> 2); a workgroup covers 128 output channels
-template <int PW, int TPW, int PF>
+template <int PW, int TPW, int PF, int NTAP = 16>      // NTAP != 16: timing experiments only (GANK_CPOOL_TAPS, tuning builds)
 __global__ __launch_bounds__(512) void cpool_res_fprop_kernel(CpFwdArgs a) {
   using G = CpGeom<PW>;
+  constexpr int NSTEP = NTAP * 4;
   static_assert(2 * TPW * G::TROWS == G::PHH, "8 waves = 4 channel tiles x 2 pixel groups must tile the patch");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -650,7 +651,7 @@ __global__ __launch_bounds__(512) void cpool_res_fprop_kernel(CpFwdArgs a) {
 
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w), 0, a.Cout * 16 * a.Cin * 2, 0x00020000);
   const int wbase = (cg * 4 + ct) * nchunks * 64 * 1024;                  // 64 steps (16 taps x 4 kk) of 1 KB per chunk
-  const int nsteps = nchunks * 64;
+  const int nsteps = nchunks * NSTEP;
   u32x4 ring[PF];
 #pragma unroll
   for (int s = 0; s < PF; s++) ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, wbase + (s < nsteps ? s : nsteps - 1) * 1024, 0);
@@ -685,7 +686,7 @@ __global__ __launch_bounds__(512) void cpool_res_fprop_kernel(CpFwdArgs a) {
       }
     }
     __syncthreads();
-    static_assert(64 % PF == 0, "ring position is chunk-invariant");
+    static_assert(NSTEP % PF == 0, "ring position is chunk-invariant");
     constexpr int PB = 2;                                                   // pixel fragments are read PB steps ahead of their MFMAs
     bf16x8 bq[PB + 1][TPW];
     auto read_b = [&](int s, bf16x8 (&dst)[TPW]) {
@@ -698,8 +699,8 @@ __global__ __launch_bounds__(512) void cpool_res_fprop_kernel(CpFwdArgs a) {
 #pragma unroll
     for (int s = 0; s < PB; s++) read_b(s, bq[s]);
 #pragma unroll
-    for (int s = 0; s < 64; s++, step++) {
-      if (s + PB < 64) read_b(s + PB, bq[(s + PB) % (PB + 1)]);
+    for (int s = 0; s < NSTEP; s++, step++) {
+      if (s + PB < NSTEP) read_b(s + PB, bq[(s + PB) % (PB + 1)]);
       const bf16x8 fa = __builtin_bit_cast(bf16x8, ring[s % PF]);
       __builtin_amdgcn_sched_barrier(0);                                    // see res_conv3x3: keeps reads early and the ring deep
 #pragma unroll
@@ -748,10 +749,10 @@ __global__ __launch_bounds__(512) void cpool_res_fprop_kernel(CpFwdArgs a) {
 // the one-group form was each CU streaming the whole 16 * Cin * 128 * 2-byte operand through its L1 (1 MB at 40-70 GB/s);
 // here a CU streams half of it and a wave a quarter; the next round's input pieces are requested before the current round's
 // MFMAs (in flight behind the weight stream instead of in front of it).
-template <int PF>
+template <int PF, int NTAP = 16>                       // NTAP != 16: timing experiments only
 __global__ __launch_bounds__(512) void cpool_res_fprop_k2_kernel(CpFwdArgs a) {
   using G = CpGeom<8>;
-  constexpr int PW = 8;
+  constexpr int PW = 8, NSTEP = NTAP * 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];          // [2 K groups][IMG]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -771,10 +772,10 @@ __global__ __launch_bounds__(512) void cpool_res_fprop_k2_kernel(CpFwdArgs a) {
   const int tile = cg * 2 + ct;
   // this wave's weight stream: chunks kg, kg + 2, ... of its channel tile, 64 steps (16 taps x 4 kk) of 1 KB each
   auto wofs = [&](int st) {                                             // st = 64 * round + s
-    const int rd = st >> 6, s = st & 63;
+    const int rd = st / NSTEP, s = st - rd * NSTEP;
     return ((tile * nchunks + 2 * rd + kg) * 64 + s) * 1024;
   };
-  const int nsteps = nrounds * 64;
+  const int nsteps = nrounds * NSTEP;
   u32x4 ring[PF];
 #pragma unroll
   for (int s = 0; s < PF; s++) ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, wofs(s < nsteps ? s : nsteps - 1), 0);
@@ -820,7 +821,7 @@ __global__ __launch_bounds__(512) void cpool_res_fprop_k2_kernel(CpFwdArgs a) {
       }
     __syncthreads();
     if (rd + 1 < nrounds) load_round(rd + 1);                           // in flight behind this round's weight stream
-    static_assert(64 % PF == 0, "ring position is round-invariant");
+    static_assert(NSTEP % PF == 0, "ring position is round-invariant");
     constexpr int PB = 2;
     bf16x8 bq[PB + 1];
     auto read_b = [&](int s, bf16x8& dst) {
@@ -830,8 +831,8 @@ __global__ __launch_bounds__(512) void cpool_res_fprop_k2_kernel(CpFwdArgs a) {
 #pragma unroll
     for (int s = 0; s < PB; s++) read_b(s, bq[s]);
 #pragma unroll
-    for (int s = 0; s < 64; s++, step++) {
-      if (s + PB < 64) read_b(s + PB, bq[(s + PB) % (PB + 1)]);
+    for (int s = 0; s < NSTEP; s++, step++) {
+      if (s + PB < NSTEP) read_b(s + PB, bq[(s + PB) % (PB + 1)]);
       const bf16x8 fa = __builtin_bit_cast(bf16x8, ring[s % PF]);
       __builtin_amdgcn_sched_barrier(0);                                // see res_conv3x3: keeps reads early and the ring deep
       acc = GANK_MFMA32(fa, bq[s % (PB + 1)], acc);
@@ -1484,6 +1485,18 @@ extern "C" int gank_cpool_res_fprop(const void* x, const void* w_rfrag, const fl
   hipStream_t s = (hipStream_t)stream;
   const double M = (double)N * Hp * Wp;
   gank_prof_begin(0, 2.0 * M * Cout * 16.0 * Cin, s, 2.0 * (4.0 * M * Cin + 16.0 * Cin * Cout + M * Cout + (residual ? M * Cout : 0.0)));
+#ifdef GANK_TUNING
+  static const int taps_env = gank_tune("GANK_CPOOL_TAPS", 16);   // timing only: 9 = the step count of a box-filter + 3x3 stride-2 form (results are wrong)
+  if (taps_env == 9 && Wp % 16 == 0) {
+    const int grid = N * (Hp / 8) * (Wp / 16) * (Cout / 128);
+    GANK_MAX_DYNAMIC_LDS((cpool_res_fprop_kernel<16, 2, 12, 9>), CpGeom<16>::IMG, "cpool_res_fprop");
+    hipLaunchKernelGGL((cpool_res_fprop_kernel<16, 2, 12, 9>), dim3(grid), dim3(512), CpGeom<16>::IMG, s, a);
+  } else if (taps_env == 9 && Cin % 128 == 0 && N * (Hp / 8) * (Cout / 128) < 256) {
+    const int grid = N * (Hp / 8) * (Cout / 64);
+    GANK_MAX_DYNAMIC_LDS((cpool_res_fprop_k2_kernel<12, 9>), 2 * CpGeom<8>::IMG, "cpool_res_fprop");
+    hipLaunchKernelGGL((cpool_res_fprop_k2_kernel<12, 9>), dim3(grid), dim3(512), 2 * CpGeom<8>::IMG, s, a);
+  } else
+#endif
   if (Wp % 16 == 0) {
     const int grid = N * (Hp / 8) * (Wp / 16) * (Cout / 128);
     GANK_MAX_DYNAMIC_LDS((cpool_res_fprop_kernel<16, 2, 8>), CpGeom<16>::IMG, "cpool_res_fprop");
