@@ -614,6 +614,7 @@ struct CpFwdArgs {
   bf16* y;                // [N,Hp,Wp,Cout]
   int N, Hp, Wp, Cin, Cout, relu;
   int xcd;                // XCD-aware block order (resident_xcd_env): workgroups that share an input patch share an L2
+  int dbg;                // TUNING builds (GANK_CPOOL_DBG, timing only): 1 = input loads out of range (zero fill, no traffic), 2 = no output
 };
 
 struct CpBwdArgs {
@@ -668,24 +669,44 @@ __global__ __launch_bounds__(512) void cpool_res_fprop_kernel(CpFwdArgs a) {
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, a.N * H2 * W2 * a.Cin * 2, 0x00020000);
   constexpr int OOB = 0x7FFFFFF0;
 
+  // the next chunk's pieces are requested before the current chunk's MFMA loop (in flight behind the weight stream, as in the
+  // two-group kernel below): with the loads in front of each loop the workgroup spent 16.8 of its 24.6 us outside the loops
+  // (profiles/r05_cpool_9tap_bound.txt: 64 -> 36 steps per chunk took 3.4 us off)
+  int p_off[NLD], p_lds[NLD];
+#pragma unroll
+  for (int j = 0; j < NLD; j++) {
+    const int q = tid + j * 512;
+    const bool on = NPIECE % 512 == 0 || q < NPIECE;
+    const int hp = q >> 3, c16 = q & 7;
+    const int hr = hp / HC, hc = hp - hr * HC;                            // halo row / column: input pixel (2*py0 - 1 + hr, 2*px0 - 1 + hc)
+    const int iy = 2 * py0 - 1 + hr, ix = 2 * px0 - 1 + hc;
+    const bool ok = on && (unsigned)iy < (unsigned)H2 && (unsigned)ix < (unsigned)W2;
+    p_off[j] = ok ? (((n * H2 + iy) * W2 + ix) * a.Cin + c16 * 8) * 2 : OOB;
+#ifdef GANK_TUNING
+    if (a.dbg & 1) p_off[j] = OOB;
+#endif
+    p_lds[j] = on ? ((hr & 1) * 2 + (hc & 1)) * G::PLANE + (hr >> 1) * G::RP + (hc >> 1) * CP_PP + c16 * 16 : -1;
+  }
+  u32x4 rP[NLD];
+  auto load_chunk = [&](int c) {
+#pragma unroll
+    for (int j = 0; j < NLD; j++) rP[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, p_off[j] == OOB ? OOB : p_off[j] + c * 128, 0, 0);
+  };
+  load_chunk(0);
+
   int step = 0;
 #pragma unroll 1
   for (int c = 0; c < nchunks; c++) {
     if (c > 0) __syncthreads();                                           // every wave is done reading the previous chunk's image
 #pragma unroll
-    for (int j = 0; j < NLD; j++) {
-      const int q = tid + j * 512;
-      if (NPIECE % 512 == 0 || q < NPIECE) {
-        const int hp = q >> 3, c16 = q & 7;
-        const int hr = hp / HC, hc = hp - hr * HC;                        // halo row / column: input pixel (2*py0 - 1 + hr, 2*px0 - 1 + hc)
-        const int iy = 2 * py0 - 1 + hr, ix = 2 * px0 - 1 + hc;
-        const bool ok = (unsigned)iy < (unsigned)H2 && (unsigned)ix < (unsigned)W2;
-        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (((n * H2 + iy) * W2 + ix) * a.Cin + c * 64 + c16 * 8) * 2 : OOB, 0, 0);
+    for (int j = 0; j < NLD; j++)
+      if (p_lds[j] >= 0) {
+        u32x4 v = rP[j];
         if (a.relu) v = relu_bf16x8(v);
-        *reinterpret_cast<u32x4*>(smem + ((hr & 1) * 2 + (hc & 1)) * G::PLANE + (hr >> 1) * G::RP + (hc >> 1) * CP_PP + c16 * 16) = v;
+        *reinterpret_cast<u32x4*>(smem + p_lds[j]) = v;
       }
-    }
     __syncthreads();
+    if (c + 1 < nchunks) load_chunk(c + 1);
     static_assert(NSTEP % PF == 0, "ring position is chunk-invariant");
     constexpr int PB = 2;                                                   // pixel fragments are read PB steps ahead of their MFMAs
     bf16x8 bq[PB + 1][TPW];
@@ -715,6 +736,9 @@ __global__ __launch_bounds__(512) void cpool_res_fprop_kernel(CpFwdArgs a) {
   }
 
   // epilogue: after acc_widen the lane holds channels 16q + 8h .. +7 of one pooled pixel: 16-byte pieces
+#ifdef GANK_TUNING
+  if (a.dbg & 2) return;
+#endif
 #pragma unroll
   for (int t = 0; t < TPW; t++) {
     const int py = py0 + (pg * TPW + t) * G::TROWS + trow, px = px0 + tcol;
@@ -1482,6 +1506,9 @@ extern "C" int gank_cpool_res_fprop(const void* x, const void* w_rfrag, const fl
   a.x = (const bf16*)x; a.w = (const bf16*)w_rfrag; a.bias = bias; a.res = (const bf16*)residual; a.y = (bf16*)y;
   a.N = N; a.Hp = Hp; a.Wp = Wp; a.Cin = Cin; a.Cout = Cout; a.relu = (flags & GANK_IN_RELU) ? 1 : 0;
   a.xcd = resident_xcd_env();
+#ifdef GANK_TUNING
+  a.dbg = gank_tune("GANK_CPOOL_DBG", 0);
+#endif
   hipStream_t s = (hipStream_t)stream;
   const double M = (double)N * Hp * Wp;
   gank_prof_begin(0, 2.0 * M * Cout * 16.0 * Cin, s, 2.0 * (4.0 * M * Cin + 16.0 * Cin * Cout + M * Cout + (residual ? M * Cout : 0.0)));

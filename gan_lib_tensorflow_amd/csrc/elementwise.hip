@@ -894,7 +894,9 @@ __global__ __launch_bounds__(1024) void concat_label_unpool_bwd_kernel(const bf1
 __global__ __launch_bounds__(1024) void label_dense_bwd_kernel(const float* __restrict__ de, const int* __restrict__ labels,
                                                                const float* __restrict__ table, const float* __restrict__ W,
                                                                float* __restrict__ dW, float* __restrict__ dbias, float* __restrict__ dtable,
-                                                               int N, int V, int D, int C2) {
+                                                               int N, int V, int D, int C2, const float* __restrict__ de_add, int de_parts) {
+  // de_add [de_parts][V][C2]: gradient rows that arrive summed per label already (label_conv.hip), added in part order behind the
+  // per-sample rows; de may be null then (no per-sample rows at all: N = 0)
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
   float* dTg = lds_f;
   float* dT = dTg + 1024 * V;
@@ -905,7 +907,8 @@ __global__ __launch_bounds__(1024) void label_dense_bwd_kernel(const float* __re
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NG = 1024 / C2, j = tid % C2, g = tid / C2;
   const int k0 = blockIdx.x * 8;
-  for (int l = 0; l < V; l++) dTg[(g * V + l) * C2 + j] = 0.f;
+  if (N > 0)
+    for (int l = 0; l < V; l++) dTg[(g * V + l) * C2 + j] = 0.f;
   for (int i = tid; i < N; i += 1024) lbs[i] = labels[i];
   if (W)
     for (int i = tid; i < 8 * C2; i += 1024) { const int k = k0 + i / C2; Ws[i] = k < D ? W[(long)k * C2 + i % C2] : 0.f; }
@@ -930,7 +933,9 @@ __global__ __launch_bounds__(1024) void label_dense_bwd_kernel(const float* __re
   for (int idx = tid; idx < V * C2; idx += 1024) {
     const int l = idx / C2, jj = idx % C2;
     float t = 0.f;
-    for (int gg = 0; gg < NG; gg++) t += dTg[(gg * V + l) * C2 + jj];
+    if (N > 0)
+      for (int gg = 0; gg < NG; gg++) t += dTg[(gg * V + l) * C2 + jj];
+    for (int p = 0; p < de_parts; p++) t += de_add[((long)p * V + l) * C2 + jj];
     dT[idx] = t;
   }
   __syncthreads();
@@ -1025,8 +1030,23 @@ extern "C" int gank_label_dense_bwd(const float* de32, const int32_t* labels, co
   GANK_REQUIRE(lds <= 160 * 1024, "label_dense_bwd: V = %d labels, N = %d samples do not fit the LDS", V, N);
   GANK_MAX_DYNAMIC_LDS(label_dense_bwd_kernel, 160 * 1024, "label_dense_bwd");
   hipLaunchKernelGGL(label_dense_bwd_kernel, dim3(cdiv(D, 8)), dim3(1024), lds, (hipStream_t)stream, de32, labels, table, W, dW, dbias, dtable,
-                     N, V, D, C2);
+                     N, V, D, C2, (const float*)nullptr, 0);
   GANK_LAUNCH_OK("label_dense_bwd");
+  return 0;
+}
+// the same from gradient rows that are summed per label already: dT[l] = sum_p de_parts_rows[p][l] (fp32 [parts][V][C2], added in part
+// order: gank_label_conv3x3_bwd_pooled's ten parts) -- no per-sample rows, no labels
+extern "C" int gank_label_dense_bwd_parts(const float* de_parts_rows, int parts, const float* table, const float* W, float* dW, float* dbias,
+                                          float* dtable, int V, int D, int C2, void* stream) {
+  GANK_REQUIRE(de_parts_rows && parts > 0 && V > 0 && D > 0 && C2 > 0, "label_dense_bwd_parts: bad arguments");
+  GANK_REQUIRE((!dW || table) && (!dtable || W), "label_dense_bwd_parts: dW needs the table, dtable needs W");
+  GANK_REQUIRE(C2 <= 1024 && 1024 % C2 == 0, "label_dense_bwd_parts: C2 = %d must divide 1024", C2);
+  const size_t lds = (1024 * (size_t)V + (((size_t)V * C2 + 3) & ~(size_t)3) + 8 * (size_t)C2 + 16 * (size_t)V) * 4;
+  GANK_REQUIRE(lds <= 160 * 1024, "label_dense_bwd_parts: V = %d labels do not fit the LDS", V);
+  GANK_MAX_DYNAMIC_LDS(label_dense_bwd_kernel, 160 * 1024, "label_dense_bwd_parts");
+  hipLaunchKernelGGL(label_dense_bwd_kernel, dim3(cdiv(D, 8)), dim3(1024), lds, (hipStream_t)stream, (const float*)nullptr, (const int*)nullptr, table, W,
+                     dW, dbias, dtable, 0, V, D, C2, de_parts_rows, parts);
+  GANK_LAUNCH_OK("label_dense_bwd_parts");
   return 0;
 }
 

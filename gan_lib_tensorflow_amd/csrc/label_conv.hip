@@ -194,8 +194,33 @@ extern "C" int gank_label_conv3x3_bwd(const void* dy, const int32_t* lists, cons
   GANK_REQUIRE(lds2 <= 64 * 1024, "label_conv3x3_bwd: N = %d, Cout = %d do not fit the LDS", N, Cout);
   if (dy) hipLaunchKernelGGL(label_conv_tap_sums_kernel, dim3(V * 2 * (Cout / 64)), dim3(256), lds1, s, (const bf16*)dy, lists, ws, N, V, H, W, Cout);
   const int merge_blocks = dw_feat_tmp ? 64 : 0;
-  const LabelBwdArgs q{ws, (const bf16*)T, w, dw, de_parts, dw_feat_tmp, V, Cin_total, c0, C2, Cout, merge_blocks, 9 * (C2 / LCB_CT) + merge_blocks};
+  const LabelBwdArgs q{ws, (const bf16*)T, w, dw, de_parts, dw_feat_tmp, V, Cin_total, c0, C2, Cout, merge_blocks, 9 * (C2 / LCB_CT) + merge_blocks,
+                       nullptr, nullptr, 0, 0, 0, 0, 0};
   hipLaunchKernelGGL(label_conv_bwd_kernel, dim3(q.blocks), dim3(256), lds2, s, q);
   GANK_LAUNCH_OK("label_conv3x3_bwd");
+  return 0;
+}
+
+// the second launch alone (the tap sums are in `tap_sums` already: gank_conv2d_wgrad_slabs_rows_tap_sums) with a TENTH part computed by
+// extra blocks: de_parts [10][V][C2], part 9 = the gradient the tiled vector receives through the POOLED shortcut branch, summed per
+// label -- sum over the samples of label v and the Hp x Wp pooled pixels of g_pooled[n][p][c0g + c] (g_pooled [N,Hp,Wp,pitch]: each of
+// the four pixels under a pooled pixel receives 0.25 g, so the sum over the sample is the sum of the pooled gradient).  With it the
+// join launch of the two branches (gank_concat_label_unpool_bwd_factored) has nothing left to do when the feature channels join in
+// gank_img16_conv3x3_dgrad_unpool; the consumer is gank_label_dense_bwd_parts.
+extern "C" int gank_label_conv3x3_bwd_pooled(const float* tap_sums, const int32_t* lists, const void* T, int V, const float* w, int Cin_total, int c0,
+                                             int C2, int Cout, int N, float* dw, float* dw_feat_tmp, float* de_parts, const void* g_pooled, int HWp,
+                                             int pitch, int c0g, void* stream) {
+  GANK_REQUIRE(tap_sums && lists && T && w && dw && de_parts && g_pooled && N > 0 && N <= 1024 && V > 0 && V <= LCB_V && HWp > 0,
+               "label_conv3x3_bwd_pooled: bad arguments");
+  GANK_REQUIRE(Cout % 4 == 0 && Cout <= 256 && C2 % 32 == 0 && c0 >= 0 && c0 + C2 <= Cin_total && pitch % 8 == 0 && c0g % 8 == 0 && c0g + C2 <= pitch,
+               "label_conv3x3_bwd_pooled: unsupported channel counts");
+  size_t lds2 = ((size_t)V * (Cout + 4) + (size_t)LCB_CT * (Cout + 4) + (size_t)V * LCB_CT) * sizeof(float);
+  if (lds2 < 64 * 4 * 8 * sizeof(float)) lds2 = 64 * 4 * 8 * sizeof(float);
+  GANK_REQUIRE(lds2 <= 64 * 1024, "label_conv3x3_bwd_pooled: Cout = %d does not fit the LDS", Cout);
+  const int merge_blocks = dw_feat_tmp ? 64 : 0, pool_blocks = V * (C2 / 32);
+  const LabelBwdArgs q{tap_sums, (const bf16*)T, w, dw, de_parts, dw_feat_tmp, V, Cin_total, c0, C2, Cout, merge_blocks,
+                       9 * (C2 / LCB_CT) + merge_blocks + pool_blocks, (const bf16*)g_pooled, lists, N, HWp, pitch, c0g, pool_blocks};
+  hipLaunchKernelGGL(label_conv_bwd_kernel, dim3(q.blocks), dim3(256), lds2, (hipStream_t)stream, q);
+  GANK_LAUNCH_OK("label_conv3x3_bwd_pooled");
   return 0;
 }

@@ -86,7 +86,12 @@ struct LabelBwdArgs {
   float* de_parts;         // [9][V][C2]
   float* dw_feat_tmp;      // optional staging buffer of the other rows (see gank_label_conv3x3_bwd)
   int V, Cin_total, c0, C2, Cout, merge_blocks;
-  int blocks;              // 9 * (C2 / LCB_CT) + merge_blocks
+  int blocks;              // 9 * (C2 / LCB_CT) + merge_blocks + pool_blocks
+  // optional tenth part: the pooled shortcut branch's gradient of the tiled vector, summed per label -- de_parts[9][v][c] = sum over
+  // the samples n of label v and the pooled pixels p of gp[n][p][gp_c0 + c] (pool_blocks = V * (C2 / 32) extra blocks)
+  const bf16* gp;          // [N][HWp][gp_pitch]
+  const int* lists;        // [V][N + 1]
+  int N, HWp, gp_pitch, gp_c0, pool_blocks;
 };
 // one block of the label gradients; NT = threads of the calling launch (>= 256: the first 256 work, all of them meet at the barriers)
 __device__ __forceinline__ void label_conv_bwd_block(const LabelBwdArgs& q, int block, float* sm) {
@@ -100,6 +105,43 @@ __device__ __forceinline__ void label_conv_bwd_block(const LabelBwdArgs& q, int 
   const int tid = threadIdx.x < 256 ? threadIdx.x : 256 + (threadIdx.x & 255);      // threads past 256 fall outside every loop bound below
   const bool worker = threadIdx.x < 256;
   const int tiles = C2 / LCB_CT;
+  if (block >= 9 * tiles + merge_blocks) {
+    // block = (label v, 32 channels): thread = (8-channel group, pooled pixel lane); the label's samples in list order, 16 loads in flight
+    const int pb = block - 9 * tiles - merge_blocks, nch = C2 >> 5;
+    const int v = pb / nch, ch = pb - v * nch;
+    const int g = threadIdx.x & 3, pl = (threadIdx.x >> 2) & 63;
+    const int* list = q.lists + (long)v * (q.N + 1) + 1;
+    const int cnt = q.lists[(long)v * (q.N + 1)];
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (worker)
+      for (int p = pl; p < q.HWp; p += 64)
+        for (int sb = 0; sb < cnt; sb += 16) {
+          bf16x8 x[16];
+#pragma unroll
+          for (int u = 0; u < 16; u++) {
+            const int n = list[sb + u < cnt ? sb + u : cnt - 1];
+            x[u] = *reinterpret_cast<const bf16x8*>(q.gp + ((long)n * q.HWp + p) * q.gp_pitch + q.gp_c0 + ch * 32 + g * 8);
+          }
+#pragma unroll
+          for (int u = 0; u < 16; u++) {
+            const float on = sb + u < cnt ? 1.f : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) a8[e] += on * bf2f(x[u][e]);
+          }
+        }
+    if (worker) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) sm[(pl * 4 + g) * 8 + e] = a8[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      const int c = threadIdx.x;
+      float t = 0.f;
+      for (int l = 0; l < 64; l++) t += sm[(l * 4 + (c >> 3)) * 8 + (c & 7)];
+      de_parts[(9L * V + v) * C2 + ch * 32 + c] = t;
+    }
+    return;
+  }
   if (block >= 9 * tiles) {
     // the feature half's filter gradient, accumulated by the ordinary filter-gradient launch into a contiguous [9][c0][Cout] buffer:
     // added into rows [0, c0) of every tap of dw, the buffer cleared for the next pass (no fill launch)

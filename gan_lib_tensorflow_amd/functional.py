@@ -1169,7 +1169,10 @@ def _label_dense_grads(ctx, de32, labels, table, W, bias):
         bt, acc = _target(bias)
         db = None if acc else bt
     if need_t or need_w or need_b:
-        K.label_dense_bwd(de32, labels, table.detach(), W.detach(), wt, bt, tt)
+        if labels is None:                     # de32 = rows summed per label already, fp32 [parts, V, C2]
+            K.label_dense_bwd_parts(de32, table.detach(), W.detach(), wt, bt, tt)
+        else:
+            K.label_dense_bwd(de32, labels, table.detach(), W.detach(), wt, bt, tt)
     return dt, dw, db
 
 
@@ -1200,6 +1203,7 @@ class _ConcatLabelForkPool(Function):
         return (da if ctx.needs_input_grad[0] else None), None, dt, dw, db
 
 
+POOLED_LABEL_PART = True    # ... what is left of the join launch (the tiled vector's gradient through the pooled branch) as a tenth part of the label-gradient launch
 JOIN_IN_DGRAD = True        # ... the pooled shortcut's gradient joins the feature gradient in the input-gradient launch's epilogue
 LABEL_BWD_RIDER = False     # ... and its label gradients as extra workgroups of the input-gradient launch (measured: 20.7 + 6.8 us -> 26.6 us, no gain)
 TAP_SUMS_RIDER = True       # ... its per-label tap sums as extra workgroups of the feature half's filter-gradient launch
@@ -1254,6 +1258,10 @@ class _ConcatLabelConv1(Function):
                     if sums is not None and LABEL_BWD_RIDER and ctx.needs_input_grad[0]:
                         # ... and the label gradients on the input-gradient launch
                         da, parts = K.img16_conv3x3_label_bwd(g, ctx.rd, a, c1, sums, T, W1.detach(), c1, tgt4)
+                    elif sums is not None and POOLED_LABEL_PART and JOIN_IN_DGRAD and gp is not None and need_label and ctx.needs_input_grad[0]:
+                        # ... with the pooled branch's share of the tiled vector's gradient as a tenth part (extra workgroups): the join
+                        # launch below has nothing left to do
+                        parts = K.label_conv3x3_bwd_pooled(sums, lists, T, W1.detach(), c1, tgt4, _c(gp), c1, n)
                     else:
                         parts = K.label_conv3x3_bwd(g, lists, T, W1.detach(), c1, tgt4, sums=sums)
                 else:                          # small batches: through a zero-filled staging buffer, merged by the same launch
@@ -1274,6 +1282,9 @@ class _ConcatLabelConv1(Function):
                     joined = True
                 else:
                     da = K.img16_conv3x3(g, ctx.rd, None, c1, 0, a)      # relu mask of the feature half in the epilogue
+        if gp is not None and joined and parts is not None and parts.shape[0] == 10:
+            dt, dw, dbe = _label_dense_grads(ctx, parts, None, table, W_emb, ctx.b_emb)
+            return da, None, dt, dw, dbe, dW, db
         if gp is not None:
             if da is None:
                 da = K.zeros_bf16(tuple(a.shape), a.device) if hasattr(K, "zeros_bf16") else torch.zeros_like(a)

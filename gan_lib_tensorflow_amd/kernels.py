@@ -1411,6 +1411,28 @@ def label_conv3x3_bwd(dy, lists, t, w, c0, dw, dw_feat_tmp=None, sums=None):
     return parts
 
 
+def label_conv3x3_bwd_pooled(sums, lists, t, w, c0, dw, g_pooled, c0g, n, dw_feat_tmp=None):
+    """gank_label_conv3x3_bwd_pooled: label_conv3x3_bwd(sums=...) -> de_parts fp32 [10,V,C2] whose tenth part is the per-label sum of
+    g_pooled[..., c0g:c0g+C2] (the pooled shortcut branch's gradient of the tiled vector) from extra workgroups of the same launch"""
+    v, c2 = t.shape
+    cin, cout = w.shape[2], w.shape[3]
+    assert dw.shape == w.shape and g_pooled.shape[0] == n
+    hwp, pitch = g_pooled.shape[1] * g_pooled.shape[2], g_pooled.shape[3]
+    parts = torch.empty((10, v, c2), dtype=F32, device=g_pooled.device)
+    _lib.check(lib().gank_label_conv3x3_bwd_pooled(_p(sums, F32, "sums"), _p(lists, I32, "lists"), _p(t, BF16, "T"), v, _p(w, F32, "w"), cin, c0, c2, cout, n,
+                                                   _p(dw, F32, "dw"), _p(dw_feat_tmp, F32, "dw_feat_tmp"), _p(parts), _p(g_pooled, BF16, "g_pooled"), hwp, pitch, c0g,
+                                                   _stream()), "label_conv3x3_bwd_pooled")
+    return parts
+
+
+def label_dense_bwd_parts(parts, table, w, dw=None, dbias=None, dtable=None):
+    """label_dense_bwd from rows summed per label already: parts fp32 [P,V,C2], dT[l] = sum_p parts[p][l]"""
+    npart, v, c2 = parts.shape
+    assert table.shape[0] == v
+    _lib.check(lib().gank_label_dense_bwd_parts(_p(parts, F32, "parts"), npart, _p(table, F32, "table"), _p(w, F32, "w"), _p(dw, F32, "dw"),
+                                                _p(dbias, F32, "dbias"), _p(dtable, F32, "dtable"), v, table.shape[1], c2, _stream()), "label_dense_bwd_parts")
+
+
 def concat_label_unpool_bwd(g_main, g_pooled, c1):
     """gradients of concat_label_pool_fwd's two outputs -> (da bf16 [N,H,W,C1], de32 fp32 [N,C2])"""
     n, hp, wp, c = g_pooled.shape

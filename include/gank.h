@@ -638,6 +638,17 @@ int gank_label_conv3x3_bwd(const void* dy, const int32_t* lists, const void* T, 
                            int Cout, int N, int H, int W, float* dw, float* dw_feat_tmp, float* de_parts, float* ws, void* stream);
 int gank_label_dense_bwd(const float* de32, const int32_t* labels, const float* table, const float* W, float* dW, float* dbias,
                          float* dtable, int N, int V, int D, int C2, void* stream);
+/* gank_label_conv3x3_bwd's label-gradient launch (tap sums as left by gank_conv2d_wgrad_slabs_rows_tap_sums) with a TENTH part from extra
+ * workgroups: de_parts [10][V][C2], part 9 = the gradient the tiled vector receives through the block's POOLED shortcut branch, summed per
+ * label: sum over the samples of label v and the HWp pooled pixels of g_pooled[n][p][c0g + c] (g_pooled [N][HWp][pitch] bf16; each of the
+ * four pixels under a pooled pixel receives 0.25 g, so a sample's sum is the sum of the pooled gradient).  With the feature channels joined
+ * in gank_img16_conv3x3_dgrad_unpool, gank_concat_label_unpool_bwd_factored has nothing left to do: its launch is gone.
+ * gank_label_dense_bwd_parts: gank_label_dense_bwd from rows that are summed per label already, dT[l] = sum_p rows[p][l] in part order. */
+int gank_label_conv3x3_bwd_pooled(const float* tap_sums, const int32_t* lists, const void* T, int V, const float* w, int Cin_total, int c0,
+                                  int C2, int Cout, int N, float* dw, float* dw_feat_tmp, float* de_parts, const void* g_pooled, int HWp,
+                                  int pitch, int c0g, void* stream);
+int gank_label_dense_bwd_parts(const float* de_parts_rows, int parts, const float* table, const float* W, float* dW, float* dbias,
+                               float* dtable, int V, int D, int C2, void* stream);
 
 /* tf.nn.embedding_lookup (common/ops/embedding.py:51) and its IndexedSlices gradient (dense, accumulated) */
 int gank_embedding_fwd(const float* table, const int32_t* idx, void* y, int N, int D, int vocab, void* stream);

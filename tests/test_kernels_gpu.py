@@ -1646,6 +1646,18 @@ def test_conv3x3_with_its_spatially_constant_input_channels_factored_out(K, n):
         da4, parts4 = K.img16_conv3x3_label_bwd(dyt, rd, at, c1, sums, tt, wt, c1, dw4)
         torch.cuda.synchronize()
         assert torch.equal(dw4, dw2) and torch.equal(parts4, parts) and torch.equal(da4.view(torch.int16), da.view(torch.int16))
+        # ... and with the pooled shortcut branch's share of the tiled vector's gradient as a tenth part, summed per label
+        gq, gqt = bf(np.random.default_rng(7).normal(size=(n, 8, 8, c1 + c2)))
+        dw5 = torch.tensor(dw0).cuda()
+        sums = K.conv2d_wgrad_rows(at, dyt, dw5, (16, 16), 3, K.IN_RELU, jobs, tap_sums=(lists, v))
+        K.sum_slabs(jobs)
+        parts10 = K.label_conv3x3_bwd_pooled(sums, lists, tt, wt, c1, dw5, gqt, c1, n)
+        torch.cuda.synchronize()
+        assert torch.equal(dw5, dw2) and torch.equal(parts10[:9], parts)
+        want9 = np.zeros((v, c2))
+        for i in range(n):
+            want9[labels[i]] += gq[i, :, :, c1:].reshape(64, c2).sum(0)
+        assert relerr(parts10[9], want9) < 1e-6
     else:
         assert n < 64
     # the pooled / unpooled ends of the pair: the pooled concat alone, and the gradient join with the factored consumer's partial sums
@@ -1748,6 +1760,14 @@ def test_concat_label_fwd_bwd(K):
     K.label_dense_bwd(de32, lt, tabt, wt, dw2, db2, dtab2)
     K.label_dense_bwd(de32, lt, tabt, wt, dw2, db2, dtab2)
     assert torch.equal(dw, dw2) and torch.equal(db, db2) and torch.equal(dtab, dtab2)
+    # the same from rows that are summed per label already (gank_label_dense_bwd_parts: dT[l] = sum_p parts[p][l])
+    pr, prt = f32(rng.normal(size=(10, v, c2)))
+    dw3, db3, dtab3 = torch.zeros_like(wt), torch.zeros_like(bt), torch.zeros_like(tabt)
+    K.label_dense_bwd_parts(prt, tabt, wt, dw3, db3, dtab3)
+    K.label_dense_bwd_parts(prt, tabt, wt, dw3, db3, dtab3)
+    torch.cuda.synchronize()
+    dT3 = pr.astype(np.float64).sum(0)
+    assert relerr(dw3, 2 * E.T @ dT3) < 1e-5 and relerr(db3, 2 * dT3.sum(0)) < 1e-5 and relerr(dtab3, 2 * dT3 @ w.T) < 1e-5
     # a label outside the table: a zero row forward, no contribution backward
     lt2 = lt.clone(); lt2[0] = 99
     y2 = K.concat_label_fwd(at, T, lt2)
