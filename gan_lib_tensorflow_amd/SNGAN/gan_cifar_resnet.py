@@ -177,12 +177,12 @@ def Discriminator(inputs, labels, update_collection=None, reuse=False, loss_head
                     if Fn.FACTOR_LABEL_CONV:
                         # D.Block.2's variables in ResidualBlock's order (shortcut, conv_1; conv_2 below), then the block itself with conv_1
                         # computed on the feature half alone (the tiled half of its input is one vector per sample)
-                        _conv2d.conv2d_variables(DIM_D * 2, DIM_D, 1, 1, 'D.Block.2.Shortcut', spectral_normed=True,
-                                                 update_collection=update_collection, he_init=False, biases=True)
+                        ws, bs = _conv2d.conv2d_variables(DIM_D * 2, DIM_D, 1, 1, 'D.Block.2.Shortcut', spectral_normed=True,
+                                                          update_collection=update_collection, he_init=False, biases=True)
                         w1, b1 = _conv2d.conv2d_variables(DIM_D * 2, DIM_D * 2, 3, 1, 'D.Block.2.Conv1', spectral_normed=True,
                                                           update_collection=update_collection, he_init=True, biases=True)
                     if w1 is not None and Fn.concat_label_conv1_ok(output, w1):
-                        h1, pooled = Fn.concat_label_conv1(output, labels, emb_table, w_emb, b_emb, w1, b1)
+                        h1, pooled = Fn.concat_label_conv1(output, labels, emb_table, w_emb, b_emb, w1, b1, ws, bs)
                         shortcut = _conv2d.Conv2D(pooled, DIM_D * 2, DIM_D, 1, 1, 'D.Block.2.Shortcut', spectral_normed=True,
                                                   update_collection=update_collection, he_init=False, biases=True)
                         output = blocks.ConvMeanPool(h1, output_dim=DIM_D, filter_size=3, name='D.Block.2.Conv2', spectral_normed=True,

@@ -145,6 +145,7 @@ PROTOTYPES = {
     "gank_concat_label_unpool_bwd_factored": [P, P, P, P, P, I, P, P, I, I, I, I, I, I, P],
     "gank_label_conv3x3_table": [P, I, I, I, I, P, I, P, P, P, I, P, P],
     "gank_label_conv3x3_table_pooled": [P, I, I, I, I, P, I, P, P, P, I, P, P, P, I, I, I, P],
+    "gank_label_conv3x3_table_pooled_shortcut": [P, I, I, I, I, P, I, P, P, P, I, P, P, P, I, I, I, P, I, P, I, P, P],
     "gank_img16_conv3x3_label_bias": [P, P, P, P, I, P, I, I, I, I, P],
     "gank_img16_conv3x3_dgrad_unpool": [P, P, P, P, I, F, P, I, I, I, P],
     "gank_img16_conv3x3_label_bwd": [P, P, P, P, I, I, I, I, P, P, I, P, I, I, I, I, P, P, P],

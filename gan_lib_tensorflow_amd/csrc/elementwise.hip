@@ -907,6 +907,19 @@ __global__ __launch_bounds__(1024) void label_dense_bwd_kernel(const float* __re
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NG = 1024 / C2, j = tid % C2, g = tid / C2;
   const int k0 = blockIdx.x * 8;
+  // the values this block adds to (first element of each thread's strided loops) are requested with the block's first loads: the
+  // read-modify-write round trips at the end were a third of the kernel
+  float dw_old = 0.f, dt_old = 0.f, db_old = 0.f;
+  if (dW && tid < 8 * C2 && k0 + tid / C2 < D) dw_old = dW[(long)(k0 + tid / C2) * C2 + tid % C2];
+  if (dtable && tid < 8 * V && k0 + (tid & 7) < D) dt_old = dtable[(long)(tid >> 3) * D + k0 + (tid & 7)];
+  if (dbias && blockIdx.x == 0 && tid < C2) db_old = dbias[tid];
+  if (N == 0) {                                  // rows summed per label already: dT needs nothing but them
+    for (int idx = tid; idx < V * C2; idx += 1024) {
+      float t = 0.f;
+      for (int p = 0; p < de_parts; p++) t += de_add[(long)p * V * C2 + idx];
+      dT[idx] = t;
+    }
+  }
   if (N > 0)
     for (int l = 0; l < V; l++) dTg[(g * V + l) * C2 + j] = 0.f;
   for (int i = tid; i < N; i += 1024) lbs[i] = labels[i];
@@ -930,22 +943,23 @@ __global__ __launch_bounds__(1024) void label_dense_bwd_kernel(const float* __re
     }
   }
   __syncthreads();
-  for (int idx = tid; idx < V * C2; idx += 1024) {
-    const int l = idx / C2, jj = idx % C2;
-    float t = 0.f;
-    if (N > 0)
+  if (N > 0) {
+    for (int idx = tid; idx < V * C2; idx += 1024) {
+      const int l = idx / C2, jj = idx % C2;
+      float t = 0.f;
       for (int gg = 0; gg < NG; gg++) t += dTg[(gg * V + l) * C2 + jj];
-    for (int p = 0; p < de_parts; p++) t += de_add[((long)p * V + l) * C2 + jj];
-    dT[idx] = t;
+      for (int p = 0; p < de_parts; p++) t += de_add[((long)p * V + l) * C2 + jj];
+      dT[idx] = t;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   if (dW)
     for (int i = tid; i < 8 * C2; i += 1024) {
       const int kk = i / C2, jj = i % C2;
       if (k0 + kk < D) {
         float t = 0.f;
         for (int l = 0; l < V; l++) t += Es[l * 8 + kk] * dT[l * C2 + jj];
-        dW[(long)(k0 + kk) * C2 + jj] += t;
+        dW[(long)(k0 + kk) * C2 + jj] = (i == tid ? dw_old : dW[(long)(k0 + kk) * C2 + jj]) + t;
       }
     }
   if (dtable) {
@@ -959,14 +973,14 @@ __global__ __launch_bounds__(1024) void label_dense_bwd_kernel(const float* __re
     __syncthreads();
     for (int p = tid; p < 8 * V; p += 1024) {
       const int kk = p & 7, l = p >> 3;
-      if (k0 + kk < D) dtable[(long)l * D + k0 + kk] += dto[p];
+      if (k0 + kk < D) dtable[(long)l * D + k0 + kk] = (p == tid ? dt_old : dtable[(long)l * D + k0 + kk]) + dto[p];
     }
   }
   if (dbias && blockIdx.x == 0)
     for (int jj = tid; jj < C2; jj += 1024) {
       float t = 0.f;
       for (int l = 0; l < V; l++) t += dT[l * C2 + jj];
-      dbias[jj] += t;
+      dbias[jj] = (jj == tid ? db_old : dbias[jj]) + t;
     }
 }
 

@@ -73,17 +73,117 @@ __device__ __forceinline__ void label_pool_rider_block(const LabelPoolRider& q, 
   }
 }
 
+// The pooled concatenation of ONE sample per block, kept in LDS, and the block's 1x1 shortcut conv on it (gan_cifar_resnet.py:172-184:
+// Shortcut = Conv2D 1x1 on the mean-pooled input): sc[n] = yp[n] W_s + b_s by 8 waves = (4 tiles of 32 output channels) x (2 tiles of
+// 32 pooled pixels), A fragments straight from the plain-conv operand (bf16 [Cs][wpitch], rows = output channels: lane (r, h) reads 16
+// bytes of row r), B fragments from the LDS image.  The launch of the 1x1 conv (6.4 us at the launch floor) is gone.
+struct LabelShortcut {
+  const bf16* wf;          // [Cs][wpitch]
+  const float* bias;       // [Cs] or null
+  bf16* out;               // [N, Hp, Wp, Cs]; null = no shortcut (the element-wise rider runs instead)
+  int Cs, wpitch;
+};
+constexpr int LSC_MAXC = 256, LSC_PITCH = 2 * LSC_MAXC + 16;      // bytes per pooled pixel in LDS (33 sixteen-byte units: odd)
+__device__ __forceinline__ void label_pool_shortcut_block(const LabelPoolRider& q, const LabelShortcut& sc, const bf16* __restrict__ T,
+                                                          const int* __restrict__ labels, int C2, int V, int n, char* img) {
+  const int C = q.C1 + C2, cg = C >> 3, cg1 = q.C1 >> 3;
+  const int W = 2 * q.Wp, HWp = q.Hp * q.Wp;                        // HWp == 64 (host check)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ct = wave & 3, pt = (wave >> 2) & 1, r = lane & 31, h = lane >> 5;
+  // the A fragments of this wave's 32 output channels: requested before the pooling pass
+  bf16x8 fa[LSC_MAXC / 16];
+  if (wave < 8) {
+    const bf16* wrow = sc.wf + (long)(ct * 32 + r) * sc.wpitch + h * 8;
+#pragma unroll
+    for (int kk = 0; kk < LSC_MAXC / 16; kk++)
+      if (kk * 16 < C) fa[kk] = *reinterpret_cast<const bf16x8*>(wrow + kk * 16);
+  }
+  // every load of the block is requested before the first wait: the sample's C1 feature channels (two 8-channel groups of one pooled
+  // pixel per thread of waves 0-7 at C1 = 128: 8 sixteen-byte loads) and the label's table row (one piece per thread)
+  const int l = labels[n];
+  const bool ok = l >= 0 && l < V;
+  constexpr int FI = 2;                                             // feature items per thread (64 pixels x C1 / 8 groups <= 2 x 512: host check)
+  bf16x8 fv[FI][4];
+  const int nfeat = HWp * cg1;
+#pragma unroll
+  for (int u = 0; u < FI; u++) {
+    const int i = tid + u * 512;
+    if (tid < 512 && i < nfeat) {
+      const int g = i % cg1, p = i / cg1;
+      const int pw = p % q.Wp, ph = p / q.Wp;
+      const long hi = ((long)n * 2 * q.Hp + 2 * ph) * W + 2 * pw;
+      fv[u][0] = *reinterpret_cast<const bf16x8*>(q.a + hi * q.C1 + g * 8);
+      fv[u][1] = *reinterpret_cast<const bf16x8*>(q.a + (hi + 1) * q.C1 + g * 8);
+      fv[u][2] = *reinterpret_cast<const bf16x8*>(q.a + (hi + W) * q.C1 + g * 8);
+      fv[u][3] = *reinterpret_cast<const bf16x8*>(q.a + (hi + W + 1) * q.C1 + g * 8);
+    }
+  }
+  const int cg2 = cg - cg1;
+  bf16x8 tv;
+#pragma unroll
+  for (int e = 0; e < 8; e++) tv[e] = f2bf(0.f);
+  const int tg = tid % cg2;
+  if (ok) tv = *reinterpret_cast<const bf16x8*>(T + (long)l * C2 + tg * 8);
+#pragma unroll
+  for (int u = 0; u < FI; u++) {
+    const int i = tid + u * 512;
+    if (tid < 512 && i < nfeat) {
+      const int g = i % cg1, p = i / cg1;
+      bf16x8 m;
+#pragma unroll
+      for (int e = 0; e < 8; e++) m[e] = f2bf((bf2f(fv[u][0][e]) + bf2f(fv[u][2][e]) + bf2f(fv[u][1][e]) + bf2f(fv[u][3][e])) * 0.25f);   // label_pool_rider_block's arithmetic
+      *reinterpret_cast<bf16x8*>(q.yp + ((long)n * HWp + p) * C + g * 8) = m;
+      *reinterpret_cast<bf16x8*>(img + p * LSC_PITCH + g * 16) = m;
+    }
+  }
+  for (int i = tid; i < HWp * cg2; i += 576) {                      // 576 % cg2 == 0 (host check): a thread keeps its group
+    const int p = i / cg2;
+    *reinterpret_cast<bf16x8*>(q.yp + ((long)n * HWp + p) * C + (cg1 + tg) * 8) = tv;
+    *reinterpret_cast<bf16x8*>(img + p * LSC_PITCH + (cg1 + tg) * 16) = tv;
+  }
+  __syncthreads();
+  if (wave >= 8) return;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; e++) acc[e] = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < LSC_MAXC / 16; kk++)
+    if (kk * 16 < C) {
+      const bf16x8 fb = *reinterpret_cast<const bf16x8*>(img + (pt * 32 + r) * LSC_PITCH + kk * 32 + h * 16);
+      acc = GANK_MFMA32(fa[kk], fb, acc);
+    }
+#pragma unroll
+  for (int qq = 0; qq < 2; qq++) {
+    const int co = ct * 32 + 16 * qq + 8 * h;
+    float v[8];
+    acc_widen(acc, qq, 1.0f, v);
+    if (sc.bias) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(sc.bias + co), b1 = *reinterpret_cast<const f32x4*>(sc.bias + co + 4);
+#pragma unroll
+      for (int e = 0; e < 4; e++) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = f2bf(v[e]);
+    *reinterpret_cast<bf16x8*>(sc.out + ((long)n * HWp + pt * 32 + r) * sc.Cs + co) = o;
+  }
+}
+
 // lists (optional, int32 [V][N + 1]): row v = {count, the samples of label v in ascending order} -- what the backward launches walk
 // (built by the first channel block of every label: a deterministic rank per sample)
 __global__ __launch_bounds__(576) void label_conv_table_kernel(const float* __restrict__ w, int Cin_total, int c0, int C2, int Cout,
                                                              const bf16* __restrict__ T, const float* __restrict__ bias, float* __restrict__ out,
-                                                             const int* __restrict__ labels, int N, int V, int* __restrict__ lists, LabelPoolRider pr) {
-  __shared__ float r[1024];
-  __shared__ float P[9][64];
-  __shared__ int lab[1024];
+                                                             const int* __restrict__ labels, int N, int V, int* __restrict__ lists, LabelPoolRider pr,
+                                                             LabelShortcut sc) {
+  __shared__ __attribute__((aligned(16))) char lds_[64 * LSC_PITCH];      // the table blocks' arrays / one pooled sample of a shortcut block
+  float* r = reinterpret_cast<float*>(lds_);                               // [1024]
+  float (*P)[64] = reinterpret_cast<float (*)[64]>(lds_ + 4096);            // [9][64]
+  int* lab = reinterpret_cast<int*>(lds_ + 4096 + 9 * 64 * 4);              // [1024]
+  static_assert(4096 + 9 * 64 * 4 + 4096 <= 64 * LSC_PITCH, "LDS plan");
   const int nco = (Cout + 63) / 64;
   if ((int)blockIdx.x >= V * nco) {
-    label_pool_rider_block(pr, T, labels, C2, V, blockIdx.x - V * nco, 576);
+    if (sc.out) label_pool_shortcut_block(pr, sc, T, labels, C2, V, blockIdx.x - V * nco, lds_);
+    else label_pool_rider_block(pr, T, labels, C2, V, blockIdx.x - V * nco, 576);
     return;
   }
   const int v = blockIdx.x / nco, cb = (blockIdx.x - v * nco) * 64;
@@ -133,7 +233,7 @@ extern "C" int gank_label_conv3x3_table(const float* w, int Cin_total, int c0, i
                "label_conv3x3_table: bad arguments");
   GANK_REQUIRE(!lists || (labels && N > 0 && N <= 1024), "label_conv3x3_table: the sample lists need the labels of 1..1024 samples");
   hipLaunchKernelGGL(label_conv_table_kernel, dim3(V * ((Cout + 63) / 64)), dim3(576), 0, (hipStream_t)stream, w, Cin_total, c0, C2, Cout, (const bf16*)T, bias,
-                     bias_table, labels, N, V, lists, LabelPoolRider{});
+                     bias_table, labels, N, V, lists, LabelPoolRider{}, LabelShortcut{});
   GANK_LAUNCH_OK("label_conv3x3_table");
   return 0;
 }
@@ -149,8 +249,28 @@ extern "C" int gank_label_conv3x3_table_pooled(const float* w, int Cin_total, in
   long blocks = (pr.total8 + 575) / 576;
   pr.blocks = (int)(blocks > 2048 ? 2048 : blocks);
   hipLaunchKernelGGL(label_conv_table_kernel, dim3(V * ((Cout + 63) / 64) + pr.blocks), dim3(576), 0, (hipStream_t)stream, w, Cin_total, c0, C2, Cout,
-                     (const bf16*)T, bias, bias_table, labels, N, V, lists, pr);
+                     (const bf16*)T, bias, bias_table, labels, N, V, lists, pr, LabelShortcut{});
   GANK_LAUNCH_OK("label_conv3x3_table_pooled");
+  return 0;
+}
+// ... and the block's 1x1 shortcut conv on the pooled concatenation in the same launch (one workgroup per sample pools into LDS and
+// multiplies from there): shortcut [N, H/2, W/2, Cs] = y_pooled x ws_f + bias_s with ws_f the plain-conv operand of the 1x1 filter
+// (bf16 [Cs][ws_pitch], rows = output channels: gank_conv2d_prep_weights' wf).  (H/2) * (W/2) == 64, Cs == 128, C1 + C2 <= 256 and a
+// multiple of 16.
+extern "C" int gank_label_conv3x3_table_pooled_shortcut(const float* w, int Cin_total, int c0, int C2, int Cout, const void* T, int V, const float* bias,
+                                                        float* bias_table, const int32_t* labels, int N, int32_t* lists, const void* a, void* y_pooled,
+                                                        int H, int W, int C1, const void* ws_f, int ws_pitch, const float* bias_s, int Cs,
+                                                        void* shortcut, void* stream) {
+  GANK_REQUIRE(w && T && bias_table && labels && a && y_pooled && ws_f && shortcut && V > 0 && C2 > 0 && C2 <= 1024 && C2 % 16 == 0 && c0 >= 0 &&
+               c0 + C2 <= Cin_total && Cout > 0, "label_conv3x3_table_pooled_shortcut: bad arguments");
+  GANK_REQUIRE(N > 0 && N <= 1024 && C1 % 8 == 0 && H % 2 == 0 && W % 2 == 0 && (H / 2) * (W / 2) == 64 && Cs == 128 && (C1 + C2) % 16 == 0 &&
+               C1 + C2 <= LSC_MAXC && ws_pitch >= C1 + C2 && ws_pitch % 8 == 0 && 64 * (C1 / 8) <= 1024 && 576 % (C2 / 8) == 0,
+               "label_conv3x3_table_pooled_shortcut: 64 pooled pixels, 128 shortcut channels, at most %d input channels (multiple of 16)", LSC_MAXC);
+  LabelPoolRider pr{(const bf16*)a, (bf16*)y_pooled, (long)N * (H / 2) * (W / 2) * ((C1 + C2) / 8), H / 2, W / 2, C1, N};
+  const LabelShortcut sc{(const bf16*)ws_f, bias_s, (bf16*)shortcut, Cs, ws_pitch};
+  hipLaunchKernelGGL(label_conv_table_kernel, dim3(V * ((Cout + 63) / 64) + N), dim3(576), 0, (hipStream_t)stream, w, Cin_total, c0, C2, Cout,
+                     (const bf16*)T, bias, bias_table, labels, N, V, lists, pr, sc);
+  GANK_LAUNCH_OK("label_conv3x3_table_pooled_shortcut");
   return 0;
 }
 

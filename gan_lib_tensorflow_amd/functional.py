@@ -236,12 +236,17 @@ class _Conv2d(Function):
             yfull = K.conv2d_fprop(x, wf, b, (H, Wd), cout, k, flags)
             y = K.pool2x2(yfull, 0.25, residual)
         else:
-            wf, _ = _prepared(W, k, cin, cout, True, False)
-            if stats_groups and not out_tanh:
-                y, _Conv2d.last_stats = K.conv2d_fprop(x, wf, b, (H, Wd), cout, k, flags | (K.RES_UPSAMPLE2X if res_up else 0), 1.0, residual,
-                                                       stats_groups=stats_groups)
+            pre = getattr(x, "_conv_result", None)
+            if (pre is not None and pre[0] is W and pre[1] is bias and flags == 0 and residual is None and not stats_groups
+                    and tuple(pre[2].shape) == (n, H, Wd, cout)):
+                y = pre[2]          # computed by the launch that produced x (concat_label_conv1: the 1x1 shortcut on the pooled concatenation)
             else:
-                y = K.conv2d_fprop(x, wf, b, (H, Wd), cout, k, flags | (K.RES_UPSAMPLE2X if res_up else 0), 1.0, residual)
+                wf, _ = _prepared(W, k, cin, cout, True, False)
+                if stats_groups and not out_tanh:
+                    y, _Conv2d.last_stats = K.conv2d_fprop(x, wf, b, (H, Wd), cout, k, flags | (K.RES_UPSAMPLE2X if res_up else 0), 1.0, residual,
+                                                           stats_groups=stats_groups)
+                else:
+                    y = K.conv2d_fprop(x, wf, b, (H, Wd), cout, k, flags | (K.RES_UPSAMPLE2X if res_up else 0), 1.0, residual)
         ctx.res_up = res_up
         # identity-shortcut fusion (ShortcutLink): conv_1 arms the link when it will produce a plain input gradient;
         # conv_2 (called after it) then parks dy for it instead of returning it along the shortcut
@@ -1221,21 +1226,33 @@ class _ConcatLabelConv1(Function):
     then meet as in _ConcatLabelForkPool."""
 
     @staticmethod
-    def forward(ctx, a, labels, table, W_emb, b_emb, W1, b1):
+    def forward(ctx, a, labels, table, W_emb, b_emb, W1, b1, shortcut):
         ctx.set_materialize_grads(False)
         T = getattr(W_emb, "_label_T", None)
         if T is None:
             T = K.label_dense_table(table.detach(), W_emb.detach(), b_emb.detach() if b_emb is not None else None)
         c1, cout = a.shape[3], W1.shape[3]
         rf, rd = W1._prep_feat
-        bt, lists, yp = K.label_conv3x3_table_pooled(W1.detach(), c1, T, b1.detach() if b1 is not None else None, labels, a)     # one launch
+        sc = None
+        if shortcut is not None:       # (ws_f, bias_s | None, Cs): the block's 1x1 shortcut conv on the pooled concatenation rides on the same launch
+            bt, lists, yp, sc = K.label_conv3x3_table_pooled(W1.detach(), c1, T, b1.detach() if b1 is not None else None, labels, a, shortcut)
+        else:
+            bt, lists, yp = K.label_conv3x3_table_pooled(W1.detach(), c1, T, b1.detach() if b1 is not None else None, labels, a)     # one launch
         h1 = K.img16_conv3x3_label_bias(a, rf, bt, labels, cout, K.IN_RELU)
         ctx.save_for_backward(a, labels, table, W_emb, W1, T, lists)
         ctx.b_emb, ctx.b1, ctx.rd = b_emb, b1, rd
-        return h1, yp
+        if sc is None:
+            return h1, yp
+        ctx.mark_non_differentiable(sc)        # the value of a conv node of its own (whose backward is unchanged): see concat_label_conv1
+        return h1, yp, sc
 
     @staticmethod
-    def backward(ctx, dh1, gp):
+    def backward(ctx, dh1, gp, *_unused):
+        out = _ConcatLabelConv1._backward(ctx, dh1, gp)
+        return out + (None,)
+
+    @staticmethod
+    def _backward(ctx, dh1, gp):
         a, labels, table, W_emb, W1, T, lists = ctx.saved_tensors
         n, c1, cout = a.shape[0], a.shape[3], W1.shape[3]
         dW = db = None
@@ -1305,9 +1322,25 @@ class _ConcatLabelConv1(Function):
         return (da if ctx.needs_input_grad[0] else None), None, dt, dw, dbe, dW, db
 
 
-def concat_label_conv1(a, labels, table, W_emb, b_emb, W1, b1):
-    """-> (conv3x3(relu(concat(a, tile(T[labels]))), W1) + b1, mean_pool2x2(concat)): see _ConcatLabelConv1"""
-    return _ConcatLabelConv1.apply(a, labels, table, W_emb, b_emb, W1, b1)
+SHORTCUT_IN_TABLE_LAUNCH = True     # ... the block's 1x1 shortcut conv on the pooled concatenation computed by the table / pooling launch
+
+
+def concat_label_conv1(a, labels, table, W_emb, b_emb, W1, b1, Ws=None, bs=None):
+    """-> (conv3x3(relu(concat(a, tile(T[labels]))), W1) + b1, mean_pool2x2(concat)): see _ConcatLabelConv1.
+    Ws [1,1,C1+C2,Cs], bs: the filter / bias of the 1x1 conv the caller applies to the pooled result next (the down-sampling block's
+    shortcut): its VALUE is computed by the same launch and parked on the pooled tensor (`_conv_result`), where conv2d() with exactly
+    these tensors picks it up instead of launching -- the conv stays a node of its own, its backward is unchanged."""
+    sc_arg = None
+    if SHORTCUT_IN_TABLE_LAUNCH and Ws is not None and Ws.dim() == 4 and Ws.shape[0] == 1:
+        prep = getattr(Ws, "_prep", None)
+        c2 = W1.shape[2] - a.shape[3]
+        if prep is not None and prep[0] is not None and K.label_conv3x3_table_pooled_shortcut_ok(a, c2, prep[0], Ws.shape[3]) and Ws.shape[2] == W1.shape[2]:
+            sc_arg = (prep[0], bs.detach() if bs is not None else None, Ws.shape[3])
+    if sc_arg is None:
+        return _ConcatLabelConv1.apply(a, labels, table, W_emb, b_emb, W1, b1, None)
+    h1, yp, sc = _ConcatLabelConv1.apply(a, labels, table, W_emb, b_emb, W1, b1, sc_arg)
+    yp._conv_result = (Ws, bs, sc)
+    return h1, yp
 
 
 def concat_label_conv1_ok(a, W1):

@@ -1346,15 +1346,33 @@ def label_conv3x3_table(w, c0, t, bias=None, labels=None):
     return out if labels is None else (out, lists)
 
 
-def label_conv3x3_table_pooled(w, c0, t, bias, labels, a):
+def label_conv3x3_table_pooled_shortcut_ok(a, c2, ws_f, cs):
+    """the one-workgroup-per-sample form: 64 pooled pixels, 128 shortcut channels, at most 256 input channels"""
+    n, h, wd_, c1 = a.shape
+    return ((h // 2) * (wd_ // 2) == 64 and h % 2 == 0 and wd_ % 2 == 0 and cs == 128 and (c1 + c2) % 16 == 0 and c1 + c2 <= 256
+            and c1 % 8 == 0 and c1 <= 128 and c2 % 8 == 0 and 576 % (c2 // 8) == 0
+            and ws_f is not None and ws_f.dim() == 2 and ws_f.shape[0] >= cs and ws_f.shape[1] >= c1 + c2 and ws_f.shape[1] % 8 == 0)
+
+
+def label_conv3x3_table_pooled(w, c0, t, bias, labels, a, shortcut=None):
     """label_conv3x3_table(labels=...) and concat_label_pool_fwd(a, t, labels, want_full=False) in ONE launch
-    -> (bias_table, lists, mean_pool2x2(concat(a, tile(t[labels]))))"""
+    -> (bias_table, lists, mean_pool2x2(concat(a, tile(t[labels]))))
+    shortcut = (ws_f bf16 [Cs, >= C1 + C2] (the plain-conv operand of a 1x1 filter), bias_s | None, Cs): the launch also computes
+    conv1x1(pooled) + bias_s -> a fourth result [N, H/2, W/2, Cs] (gank_label_conv3x3_table_pooled_shortcut)"""
     v, c2 = t.shape
     cin, cout = w.shape[2], w.shape[3]
     n, h, wd_, c1 = a.shape
     out = torch.empty((v, 9, cout), dtype=F32, device=w.device)
     lists = torch.empty((v, n + 1), dtype=I32, device=w.device)
     yp = torch.empty((n, h // 2, wd_ // 2, c1 + c2), dtype=BF16, device=a.device)
+    if shortcut is not None:
+        ws_f, bias_s, cs = shortcut
+        sc = torch.empty((n, h // 2, wd_ // 2, cs), dtype=BF16, device=a.device)
+        _lib.check(lib().gank_label_conv3x3_table_pooled_shortcut(_p(w, F32, "w"), cin, c0, c2, cout, _p(t, BF16, "T"), v, _p(bias, F32, "bias"), _p(out),
+                                                                  _p(labels, I32, "labels"), n, _p(lists), _p(a, BF16, "a"), _p(yp), h, wd_, c1,
+                                                                  _p(ws_f, BF16, "ws_f"), ws_f.shape[1], _p(bias_s, F32, "bias_s"), cs, _p(sc), _stream()),
+                   "label_conv3x3_table_pooled_shortcut")
+        return out, lists, yp, sc
     _lib.check(lib().gank_label_conv3x3_table_pooled(_p(w, F32, "w"), cin, c0, c2, cout, _p(t, BF16, "T"), v, _p(bias, F32, "bias"), _p(out),
                                                      _p(labels, I32, "labels"), n, _p(lists), _p(a, BF16, "a"), _p(yp), h, wd_, c1, _stream()),
                "label_conv3x3_table_pooled")

@@ -620,6 +620,14 @@ int gank_label_conv3x3_table(const float* w, int Cin_total, int c0, int C2, int 
 int gank_label_conv3x3_table_pooled(const float* w, int Cin_total, int c0, int C2, int Cout, const void* T, int V, const float* bias,
                                     float* bias_table, const int32_t* labels, int N, int32_t* lists, const void* a, void* y_pooled,
                                     int H, int W, int C1, void* stream);
+/* ... and the block's 1x1 shortcut conv on that pooled concatenation (gan_cifar_resnet.py:172-184 with resample='down': Conv2D 1x1 on the
+ * mean-pooled input) in the same launch: one workgroup per sample pools into LDS and multiplies from there.  ws_f = the plain-conv
+ * operand of the 1x1 filter (bf16 [Cs][ws_pitch], rows = output channels); shortcut [N, H/2, W/2, Cs] bf16.  (H/2) * (W/2) == 64,
+ * Cs == 128, C1 + C2 <= 256 and a multiple of 16. */
+int gank_label_conv3x3_table_pooled_shortcut(const float* w, int Cin_total, int c0, int C2, int Cout, const void* T, int V, const float* bias,
+                                             float* bias_table, const int32_t* labels, int N, int32_t* lists, const void* a, void* y_pooled,
+                                             int H, int W, int C1, const void* ws_f, int ws_pitch, const float* bias_s, int Cs,
+                                             void* shortcut, void* stream);
 int gank_img16_conv3x3_label_bias(const void* x, const void* w_rfrag, const float* bias_table, const int32_t* labels, int V, void* y,
                                   int N, int Cin, int Cout, int flags, void* stream);
 /* the image-resident conv as the input gradient behind a fork whose other branch is a 2x2 mean pool: dx = relu_mask(conv(dy)) +

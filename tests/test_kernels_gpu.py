@@ -1669,6 +1669,18 @@ def test_conv3x3_with_its_spatially_constant_input_channels_factored_out(K, n):
     for lab in range(v):
         cnt = int(lists[lab, 0])
         assert torch.equal(lists2[lab, :1 + cnt], lists[lab, :1 + cnt])
+    # ... and with the block's 1x1 shortcut conv on the pooled concatenation computed by that launch (one workgroup per sample)
+    wsn, wst = f32(np.random.default_rng(11).normal(size=(1, 1, c1 + c2, 128)) * 0.1)
+    bsn, bst = f32(np.random.default_rng(12).normal(size=128) * 0.1)
+    wsf, _ = K.prep_weights(wst, True, False)
+    assert K.label_conv3x3_table_pooled_shortcut_ok(at, c2, wsf, 128)
+    table3, lists3, yp3, sc3 = K.label_conv3x3_table_pooled(wt, c1, tt, bt, lt, at, (wsf, bst, 128))
+    sc_launch = K.conv2d_fprop(yp_full, wsf, bst, (8, 8), 128, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(table3, table) and torch.equal(yp3.view(torch.int16), yp_full.view(torch.int16))
+    sc_ref = yp_full.double().cpu().numpy().reshape(-1, c1 + c2) @ torch.tensor(wsn).to(torch.bfloat16).double().numpy().reshape(c1 + c2, 128) + bsn
+    assert relerr(sc3, sc_ref.reshape(n, 8, 8, 128)) < BF_TOL
+    assert float((sc3.float() - sc_launch.float()).abs().max()) <= 2.0 ** -7 * float(sc_launch.float().abs().max())     # (another summation order)
     gp, gpt = bf(rng.normal(size=(n, 8, 8, c1 + c2)))
     da2, de2 = K.concat_label_unpool_bwd_factored(da, gpt, parts, lt, lists)
     gm_full = torch.cat([da, torch.zeros((n, 16, 16, c2), dtype=da.dtype, device="cuda")], 3).contiguous()
