@@ -74,6 +74,7 @@ PROTOTYPES = {
     "gank_conv2d_wgrad_batched": [C.POINTER(WgradItem), I, I, I, I, I, I, I, I, F, P],
     "gank_conv2d_wgrad_narrow_pair": [P, P, P, P, I, I, I, I, I, P, P, P, P, I, I, I, I, I, F, P],
     "gank_conv2d_wgrad_ws_elems": [I, I, I, I, I, I, I],
+    "gank_conv1x1_wgrad_dgrad": [P, P, P, P, P, I, P, I, I, I, I, I, P],
     "gank_conv2d_wgrad": [P, P, P, P, P, L, I, I, I, I, I, I, I, F, P],
     "gank_upconv3x3_prep_weights": [P, P, P, I, I, P],
     "gank_upconv3x3_fprop": [P, P, P, P, P, I, I, I, I, I, I, P],

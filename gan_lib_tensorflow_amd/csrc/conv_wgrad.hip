@@ -61,7 +61,52 @@ struct WgradArgs {
   const int* rider_lists;
   float* rider_S;
   int rider_blocks, rider_V, main_blocks;
+  // rider of the lean launch on a 1x1 layer (gank_conv1x1_wgrad_dgrad): d1_blocks extra workgroups compute the layer's INPUT gradient
+  // dx[p][ci] = sum_co dy[p][co] wd[ci][co] (32 pixels x all input channels each) -- the two launches of a 1x1 conv's backward become one
+  const bf16* d1_wd;  // bf16 [Cin][d1_pitch], rows = input channels (the plain-conv dgrad operand)
+  bf16* d1_dx;        // [M][Cin]
+  int d1_pitch, d1_blocks;
 };
+
+// one rider block of the 1x1 input gradient: 4 waves, wave w takes the 64-channel groups w, w + 4, ... (two 32-row A tiles each) of the
+// block's 32 pixels; A fragments straight from wd (lane (r, h): 16 bytes of row r), B fragments straight from dy (lane (r, h): 16 bytes of
+// pixel r) -- every load of a group is requested before its first MFMA; Cout <= 128 (8 K-steps), Cin % 64 == 0, M % 32 == 0
+__device__ __forceinline__ void dgrad1x1_rider_block(const WgradArgs& a, int block) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const long px = (long)block * 32 + r;
+  bf16x8 fb[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; kk++)
+    if (kk * 16 < a.Cout) fb[kk] = *reinterpret_cast<const bf16x8*>(a.dy + px * a.Cout + kk * 16 + h * 8);
+  for (int cgp = wave; cgp < (a.Cin >> 6); cgp += 4) {
+    bf16x8 fa[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int kk = 0; kk < 8; kk++)
+        if (kk * 16 < a.Cout) fa[t][kk] = *reinterpret_cast<const bf16x8*>(a.d1_wd + (long)(cgp * 64 + t * 32 + r) * a.d1_pitch + kk * 16 + h * 8);
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[e] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 8; kk++)
+        if (kk * 16 < a.Cout) acc = GANK_MFMA32(fa[t][kk], fb[kk], acc);
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        float v[8];
+        acc_widen(acc, q, 1.0f, v);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = f2bf(v[e]);
+        *reinterpret_cast<bf16x8*>(a.d1_dx + px * a.Cin + cgp * 64 + t * 32 + 16 * q + 8 * h) = o;
+      }
+    }
+  }
+}
+static thread_local bool g_d1_carried = false;       // (host) set by the lean launcher when it carried the rider
 
 __device__ __forceinline__ s16x4 lds_tr_read(const bf16* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
@@ -358,6 +403,12 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_lean_kernel(WgradArgs 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_a = wave % WA, wave_b = wave / WA;
+  if constexpr (NT == 256 && TA == 1 && TB == 1 && MODE == 0) {      // (the instantiation the 1x1 shortcuts run on: the rider's registers stay out of the others)
+    if (a.d1_blocks > 0 && (int)blockIdx.x >= a.main_blocks) {      // rider: the 1x1 layer's input gradient (no barrier on this path)
+      dgrad1x1_rider_block(a, blockIdx.x - a.main_blocks);
+      return;
+    }
+  }
   // operand set of this block: the single layer, or layer blockIdx.y of a same-shape batch.  Static indices only: a
   // dynamically indexed (or modified) by-value argument struct is spilled to scratch and every field read pays for it
   // (measured: every instantiation of this kernel ran 2x slower).
@@ -604,7 +655,15 @@ static int launch_wgrad_lean_mode(WgradArgs a, hipStream_t s) {
   gank_prof_tag(1, tag.c_str());
   wgrad_slab_setup(a);
   { static const int dbg_ = gank_tune("GANK_WGRAD_DBG", 0); a.dbg = dbg_; }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid, a.nbatch > 0 ? a.nbatch : 1), dim3(WA * WB * 64), lds, s, a);
+  long gx = grid;
+  a.d1_blocks = 0;
+  if (a.d1_dx && a.nbatch <= 0 && WA * WB * 64 == 256 && TA == 1 && TB == 1 && MODE == 0 && a.ks == 1) {
+    a.main_blocks = (int)grid;
+    a.d1_blocks = a.M / 32;
+    gx += a.d1_blocks;
+    g_d1_carried = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, a.nbatch > 0 ? a.nbatch : 1), dim3(WA * WB * 64), lds, s, a);
   GANK_LAUNCH_OK("conv_wgrad_lean");
   return 0;
 }
@@ -1794,10 +1853,10 @@ extern "C" long gank_conv2d_wgrad_ws_elems(int N, int H, int W, int Cin, int Cou
   return a.splits > 1 ? 9L * Cin * Cout * a.splits : 0;
 }
 
-namespace { struct TapSumsRider { const int32_t* lists; float* S; int V; }; }
+namespace { struct TapSumsRider { const int32_t* lists; float* S; int V; }; struct Dgrad1x1Rider { const void* wd; int pitch; void* dx; }; }
 static int conv2d_wgrad_impl(const void* x, const void* dy, float* dw, float* dbias, float* ws, long ws_elems, int N, int H, int W, int Cin, int Cout,
                              int ksize, int flags, float scale, float* slab_ws, long slab_elems, gank_slab_job* job, void* stream,
-                             const TapSumsRider* rider = nullptr);
+                             const TapSumsRider* rider = nullptr, const Dgrad1x1Rider* d1 = nullptr);
 extern "C" int gank_conv2d_wgrad(const void* x, const void* dy, float* dw, float* dbias, float* ws, long ws_elems, int N,
                                  int H, int W, int Cin, int Cout, int ksize, int flags, float scale, void* stream) {
   return conv2d_wgrad_impl(x, dy, dw, dbias, ws, ws_elems, N, H, W, Cin, Cout, ksize, flags, scale, nullptr, 0, nullptr, stream);
@@ -1867,9 +1926,10 @@ extern "C" int gank_conv2d_wgrad_slabs(const void* x, const void* dy, float* dw,
 }
 static int conv2d_wgrad_impl(const void* x, const void* dy, float* dw, float* dbias, float* ws, long ws_elems, int N, int H, int W, int Cin, int Cout,
                              int ksize, int flags, float scale, float* slab_ws, long slab_elems, gank_slab_job* job, void* stream,
-                             const TapSumsRider* rider) {
+                             const TapSumsRider* rider, const Dgrad1x1Rider* d1) {
   GANK_REQUIRE(ksize % 2 == 1, "conv2d_wgrad: even filter sizes are not on this path (ksize=%d)", ksize);
   WgradArgs a{};
+  if (d1) { a.d1_wd = (const bf16*)d1->wd; a.d1_pitch = d1->pitch; a.d1_dx = (bf16*)d1->dx; }
   if (rider) { a.rider_lists = rider->lists; a.rider_S = rider->S; a.rider_V = rider->V; a.rider_blocks = rider->V * 2 * (Cout / 64); }
   a.slab_ws = slab_ws; a.slab_elems = slab_elems; a.slab_job = job;
   if (slab_ws && !ws) { ws = slab_ws; ws_elems = slab_elems; }        // (a layer on the all-taps kernel takes the offered space as its slab workspace)
@@ -1883,6 +1943,26 @@ static int conv2d_wgrad_impl(const void* x, const void* dy, float* dw, float* db
   a.flags = flags & (GANK_IN_UPSAMPLE2X | GANK_IN_RELU | GANK_DY_UPSAMPLE2X);
   a.scale = scale;
   return gank_wgrad_dispatch(a, (hipStream_t)stream);
+}
+
+// both gradients of a 1x1 conv (stride 1) in ONE launch: the filter / bias gradient as gank_conv2d_wgrad (ACCUMULATED into dw [Cin][Cout],
+// dbias) and the input gradient dx [N,H,W,Cin] = dy wd^T (bf16, the bytes' meaning of gank_conv2d_dgrad with ksize 1, no flags) computed
+// by extra workgroups of the filter-gradient launch.  wd: the plain-conv dgrad operand (bf16 [Cin][wd_pitch], rows = input channels).
+// Cin % 64 == 0, Cout % 16 == 0, Cout <= 128, N * H * W % 32 == 0.  A layer whose filter gradient runs on a kernel without the rider
+// gets its input gradient from a launch of its own (gank_conv2d_dgrad) -- the results are the same either way.
+extern "C" int gank_conv2d_dgrad(const void* dy, const void* wd, const void* residual, const void* relu_ref, void* dx, int N, int H, int W, int Cin, int Cout,
+                                 int ksize, int flags, float scale, void* stream);
+extern "C" int gank_conv1x1_wgrad_dgrad(const void* x, const void* dy, float* dw, float* dbias, const void* wd, int wd_pitch, void* dx, int N, int H, int W,
+                                        int Cin, int Cout, void* stream) {
+  GANK_REQUIRE(x && dy && dw && wd && dx && N > 0 && H > 0 && W > 0, "conv1x1_wgrad_dgrad: null pointer");
+  GANK_REQUIRE(Cin % 64 == 0 && Cout % 16 == 0 && Cout <= 128 && ((long)N * H * W) % 32 == 0 && wd_pitch >= Cout && wd_pitch % 8 == 0 &&
+               (long)N * H * W * Cin < (1L << 31), "conv1x1_wgrad_dgrad: needs Cin %% 64 == 0, Cout %% 16 == 0, Cout <= 128, pixels %% 32 == 0 (got %d, %d, %ld)",
+               Cin, Cout, (long)N * H * W);
+  const Dgrad1x1Rider d1{wd, wd_pitch, dx};
+  g_d1_carried = false;
+  if (conv2d_wgrad_impl(x, dy, dw, dbias, nullptr, 0, N, H, W, Cin, Cout, 1, 0, 1.0f, nullptr, 0, nullptr, stream, nullptr, &d1)) return 1;
+  if (g_d1_carried) return 0;
+  return gank_conv2d_dgrad(dy, wd, nullptr, nullptr, dx, N, H, W, Cin, Cout, 1, 0, 1.0f, stream);
 }
 
 // filter gradient of the general convolution (gank_conv2d_general_fprop): x [N,Hx,Wx,Cin] as stored, dy [N,Hdy,Wdy,Cout];

@@ -131,6 +131,7 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+CONV1X1_BWD_ONE_LAUNCH = True   # a 1x1 conv's input gradient as extra workgroups of its filter-gradient launch (gank_conv1x1_wgrad_dgrad)
 FUSE_IMAGE_WGRAD = True   # D.Block.1.Conv1's and D.Block.1.Shortcut's filter gradients inside the ConvMeanPool input-gradient launch (round 5)
 
 
@@ -290,6 +291,7 @@ class _Conv2d(Function):
             g = K.tanh_bwd(g, y)
         scale = 0.25 if pool_out else 1.0
         dW = db = dx = None
+        dx_fused = None
         btgt = None
         if bias is not None and ctx.needs_input_grad[2]:
             btgt, bacc = _target(bias)
@@ -313,6 +315,12 @@ class _Conv2d(Function):
                 K.upconv3x3_wgrad(x, g, tgt.view(3, 3, cin, cout))
                 if btgt is not None:
                     K.colsum(g, btgt, 1.0)           # (the rows kernel sums its OTHER operand: the bias gradient is a launch of its own)
+            elif (CONV1X1_BWD_ONE_LAUNCH and k == 1 and wflags == 0 and scale == 1.0 and ctx.needs_input_grad[0] and ctx.add_link is None
+                  and not ctx.img16 and not ctx.res8 and not phase
+                  and int(K.lib().gank_conv2d_wgrad_slab_elems(x.shape[0], H, Wd, cin, cout, 1, 0)) == 0
+                  and K.conv1x1_wgrad_dgrad_ok(x.shape[0], (H, Wd), cin, cout, _prepared(W, k, cin, cout, False, True)[1])):
+                # a 1x1 layer's two gradients in one launch: the input gradient from extra workgroups of the filter-gradient launch
+                dx_fused = K.conv1x1_wgrad_dgrad(x, g, tgt, _prepared(W, k, cin, cout, False, True)[1], dbias=btgt)
             else:
                 # bias gradient rides on the dy stream
                 K.conv2d_wgrad(x, g, tgt, (H, Wd), k, wflags, scale, dbias=btgt,
@@ -320,7 +328,9 @@ class _Conv2d(Function):
             dW = None if acc else tgt
         elif btgt is not None:
             K.colsum(g, btgt, 1.0)
-        if ctx.needs_input_grad[0] and ctx.res8:
+        if dx_fused is not None:
+            dx = dx_fused
+        elif ctx.needs_input_grad[0] and ctx.res8:
             # the conv with the dgrad operand (taps flipped, channels swapped); behind an upsample its 2x2 sums
             dx = K.res8_conv3x3(g, W._prep_res[1], None, cin, K.OUT_POOLSUM2X if upsample else 0)
         elif ctx.needs_input_grad[0] and phase:

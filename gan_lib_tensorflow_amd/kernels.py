@@ -235,6 +235,23 @@ def conv2d_wgrad(x, dy, dw, hw, ksize, flags=0, scale=1.0, dbias=None, slab_jobs
     return dw
 
 
+def conv1x1_wgrad_dgrad_ok(n, hw, cin, cout, wd):
+    return (cin % 64 == 0 and cout % 16 == 0 and cout <= 128 and (n * hw[0] * hw[1]) % 32 == 0 and wd is not None and wd.dim() == 2
+            and wd.shape[0] >= cin and wd.shape[1] >= cout and wd.shape[1] % 8 == 0)
+
+
+def conv1x1_wgrad_dgrad(x, dy, dw, wd, dbias=None):
+    """gank_conv1x1_wgrad_dgrad: ACCUMULATES the 1x1 filter gradient into dw [.., Cin, Cout] (and dbias) and returns the input gradient
+    dx [N,H,W,Cin] = dy wd^T from extra workgroups of the same launch"""
+    n, h, w, cin = x.shape
+    cout = dy.shape[3]
+    assert dw.shape[-2] == cin and dw.shape[-1] == cout and tuple(dy.shape[:3]) == (n, h, w)
+    dx = torch.empty((n, h, w, cin), dtype=BF16, device=dy.device)
+    _lib.check(lib().gank_conv1x1_wgrad_dgrad(_p(x, BF16, "x"), _p(dy, BF16, "dy"), _p(dw, F32, "dw"), _p(dbias, F32, "dbias"), _p(wd, BF16, "wd"),
+                                              wd.shape[1], _p(dx), n, h, w, cin, cout, _stream()), "conv1x1_wgrad_dgrad")
+    return dx
+
+
 def conv2d_wgrad_rows_ok(n, hw, cin, cout, ksize=3, flags=0):
     """the layer has the deferred slab form conv2d_wgrad_rows needs"""
     return int(lib().gank_conv2d_wgrad_slab_splits(n, hw[0], hw[1], cin, cout, ksize, flags)) > 0

@@ -106,6 +106,14 @@ int gank_conv2d_fprop_stats(const void* x, const void* wf, const float* bias, co
 int gank_conv2d_dgrad(const void* dy, const void* wd, const void* residual, const void* relu_ref, void* dx,
                       int N, int H, int W, int Cin, int Cout, int ksize, int flags, float scale, void* stream);
 
+/* Both gradients of a 1x1 conv (stride 1, no flags) in ONE launch: the filter / bias gradient exactly as gank_conv2d_wgrad (ACCUMULATED
+ * into dw [Cin][Cout] and dbias) and the input gradient dx [N,H,W,Cin] = dy wd^T (gank_conv2d_dgrad with ksize 1) computed by extra
+ * workgroups of the filter-gradient launch (32 pixels x all input channels each, operands straight from memory).  wd: the plain-conv
+ * dgrad operand, bf16 [Cin][wd_pitch] (rows = input channels).  Cin % 64 == 0, Cout % 16 == 0, Cout <= 128, N*H*W % 32 == 0.  A layer
+ * whose filter gradient runs on a kernel without the rider gets its input gradient from gank_conv2d_dgrad inside this call. */
+int gank_conv1x1_wgrad_dgrad(const void* x, const void* dy, float* dw, float* dbias, const void* wd, int wd_pitch, void* dx, int N, int H, int W,
+                             int Cin, int Cout, void* stream);
+
 /* ---- conv2d filter gradient: dw[tap][ci][co] += scale * sum_pixels in(x)[p+tap][ci] * dy[p][co] --
  * Replaces Conv2DBackpropFilter for conv2d.py:180-187.  ACCUMULATES (fp32 atomics, split over pixel
  * ranges) into dw [k,k,Cin,Cout] -- zero it first for a plain gradient.  (H,W) is the conv OUTPUT

@@ -1786,6 +1786,31 @@ def test_concat_label_fwd_bwd(K):
     assert float(y2[0, :, :, c1:].abs().max()) == 0.0 and torch.equal(y2[1:].view(torch.int16), y[1:].view(torch.int16))
 
 
+@pytest.mark.parametrize("n,hw,cin,cout", [(128, 8, 256, 128), (8, 8, 64, 64), (64, 4, 128, 128)])
+def test_conv1x1_both_gradients_in_one_launch(K, n, hw, cin, cout):
+    """gank_conv1x1_wgrad_dgrad (the backward of D.Block.2.Shortcut in a critic update, common/ops/conv2d.py:180-187 with a 1x1 filter):
+    the filter / bias gradient of gank_conv2d_wgrad and the input gradient of gank_conv2d_dgrad, the latter from extra workgroups of the
+    former's launch -- against float64 and against the two launches."""
+    rng = np.random.default_rng(61)
+    x, xt = bf(rng.normal(size=(n, hw, hw, cin)))
+    dy, dyt = bf(rng.normal(size=(n, hw, hw, cout)))
+    w, wt = f32(rng.normal(size=(1, 1, cin, cout)) * 0.1)
+    _, wd = K.prep_weights(wt, False, True)
+    assert K.conv1x1_wgrad_dgrad_ok(n, (hw, hw), cin, cout, wd)
+    dw, db = torch.zeros_like(wt), torch.zeros(cout, dtype=torch.float32, device="cuda")
+    dx = K.conv1x1_wgrad_dgrad(xt, dyt, dw, wd, dbias=db)
+    dw2, db2 = torch.zeros_like(wt), torch.zeros(cout, dtype=torch.float32, device="cuda")
+    K.conv2d_wgrad(xt, dyt, dw2, (hw, hw), 1, 0, 1.0, dbias=db2)
+    dx2 = K.conv2d_dgrad(dyt, wd, (hw, hw), cin, 1)
+    torch.cuda.synchronize()
+    X, DY = x.reshape(-1, cin).astype(np.float64), dy.reshape(-1, cout).astype(np.float64)
+    wb = torch.tensor(w).to(torch.bfloat16).double().numpy().reshape(cin, cout)
+    assert relerr(dw, (X.T @ DY).reshape(1, 1, cin, cout)) < F32_FROM_BF_TOL and relerr(db, DY.sum(0)) < F32_FROM_BF_TOL
+    assert relerr(dx, (DY @ wb.T).reshape(n, hw, hw, cin)) < BF_TOL
+    assert relerr(dw, dw2.double().cpu().numpy()) < 1e-5 and relerr(db, db2.double().cpu().numpy()) < 1e-5      # (fp32 atomics: the order is free)
+    assert float((dx.float() - dx2.float()).abs().max()) <= 2.0 ** -7 * float(dx2.float().abs().max())          # (another summation order)
+
+
 def test_meanpool_conv1x1_gather_is_pool_then_conv(K):
     """D.Block.1.Shortcut with the 2x2 mean inside the conv's gather: the bytes of pool2x2 + conv2d_fprop, and the pooled image
     as a side output."""
