@@ -71,6 +71,7 @@ PROTOTYPES = {
     "gank_conv2d_fprop_stats": [P, P, P, P, P, P, I, I, I, I, I, I, I, F, P, I, P, P],
     "gank_conv2d_dgrad": [P, P, P, P, P, I, I, I, I, I, I, I, F, P],
     "gank_meanpool_conv1x1_fprop": [P, P, P, P, P, I, I, I, I, I, P],
+    "gank_image_conv_pair_fprop": [P, P, P, P, P, P, P, P, I, I, I, I, I, P],
     "gank_conv2d_wgrad_batched": [C.POINTER(WgradItem), I, I, I, I, I, I, I, I, F, P],
     "gank_conv2d_wgrad_narrow_pair": [P, P, P, P, I, I, I, I, I, P, P, P, P, I, I, I, I, I, F, P],
     "gank_conv2d_wgrad_ws_elems": [I, I, I, I, I, I, I],

@@ -255,7 +255,9 @@ def OptimizedResBlockDisc1(inputs, spectral_normed=False, update_collection=None
         # the 2x2 mean inside the 1x1 conv's gather: fork + pool + conv as one launch
         w_s, b_s = _conv2d.conv2d_variables(inputs.shape[-1], DIM_D, 1, 1, 'D.Block.1.Shortcut', spectral_normed=spectral_normed,
                                             update_collection=update_collection, he_init=False, biases=biases)
-        x_main, shortcut = Fn.fork_pool_conv1x1(inputs, w_s, b_s)
+        w_1, b_1 = _conv2d.conv2d_variables(inputs.shape[-1], DIM_D, 3, 1, 'D.Block.1.Conv1', spectral_normed=spectral_normed,
+                                            update_collection=update_collection, he_init=True, biases=biases)
+        x_main, shortcut = Fn.fork_pool_conv1x1(inputs, w_s, b_s, w_1, b_1)      # ... and conv_1 below on the same launch
     elif FUSE_FORK_POOL:
         x_main, pooled = Fn.fork_pool(inputs)
         shortcut = _conv2d.Conv2D(pooled, pooled.shape[-1], DIM_D, 1, 1, 'D.Block.1.Shortcut', spectral_normed=spectral_normed,

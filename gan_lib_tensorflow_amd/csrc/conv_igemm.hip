@@ -982,14 +982,15 @@ static bool patch_phase_ok(const IgemmArgs& a) {   // a.H, a.W = low-res grid; a
 // gan_cifar_resnet.py:129-130 (MeanPoolConv: pool, THEN the 1x1 conv) rounded to the element type -- the arithmetic of
 // pool2x2_kernel<1> + this kernel, without the launch in between; the pooled tensor (which the filter gradient needs) is a
 // side output of the lanes that gathered it.
-template <int KS, int CIN, bool POOL = false>
-__global__ __launch_bounds__(256) void conv_narrow_in_kernel(IgemmArgs a) {
+constexpr int NARROW_LDS = 4 * 32 * 272;      // the four waves' private transpose regions
+template <int KS, int CIN, bool POOL>
+__device__ __forceinline__ void narrow_in_body(const IgemmArgs& a, const int block, char* s_t) {
   constexpr int TAPS = KS * KS, KTOT = TAPS * CIN, PAD = (KS - 1) / 2;
   static_assert(KTOT <= 32, "one 32-deep K-step");
   static_assert(!POOL || KS == 1, "pooled gather: 1x1 only");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int tile_n = blockIdx.x % a.tiles_n, tile_m = blockIdx.x / a.tiles_n;
+  const int tile_n = block % a.tiles_n, tile_m = block / a.tiles_n;
   const int m = tile_m * 128 + wave * 32 + r;
   const bool inrelu = (a.flags & GANK_IN_RELU) != 0;
 
@@ -1050,7 +1051,6 @@ __global__ __launch_bounds__(256) void conv_narrow_in_kernel(IgemmArgs a) {
     // wave's LDS counter orders the two sides (no s_barrier: the block-wide transpose this kernel once had cost two), and a store
     // instruction then covers FOUR whole 256-byte pixel runs instead of a 32-byte piece of 32 different ones.  Pitch 272 B (16 B off
     // a multiple of 256 B; measured SQ_LDS_BANK_CONFLICT: 25 % of this kernel's LDS cycles, which are few).
-    __shared__ __attribute__((aligned(16))) char s_t[4 * 32 * 272];
     char* mine = s_t + wave * 32 * 272;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -1125,6 +1125,19 @@ __global__ __launch_bounds__(256) void conv_narrow_in_kernel(IgemmArgs a) {
       }
     }
   }
+}
+
+template <int KS, int CIN, bool POOL = false>
+__global__ __launch_bounds__(256) void conv_narrow_in_kernel(IgemmArgs a) {
+  __shared__ __attribute__((aligned(16))) char s_t[NARROW_LDS];
+  narrow_in_body<KS, CIN, POOL>(a, blockIdx.x, s_t);
+}
+// the two image-side layers of the critic's first block (gan_cifar_resnet.py:212-234: conv_1 3x3 on the image, Shortcut = 1x1 on its 2x2
+// mean) read the same 3-channel image: one launch, the shortcut's workgroups behind conv_1's (no wave takes both paths)
+__global__ __launch_bounds__(256) void conv_narrow_in_pair_kernel(IgemmArgs a, IgemmArgs b, int blocks_a) {
+  __shared__ __attribute__((aligned(16))) char s_t[NARROW_LDS];
+  if ((int)blockIdx.x < blocks_a) narrow_in_body<3, 3, false>(a, blockIdx.x, s_t);
+  else narrow_in_body<1, 3, true>(b, blockIdx.x - blocks_a, s_t);
 }
 
 template <int KS, int CIN, bool POOL = false>
@@ -1932,6 +1945,39 @@ extern "C" int gank_meanpool_conv1x1_fprop(const void* x, const void* wf, const 
   const int rc = launch_narrow_in<1, 3, true>(a, s);
   gank_prof_end(0, s);
   return rc;
+}
+
+// gank_conv2d_fprop(x [N,H,W,3], wf1: 3x3 -> Cout1, no flags) and gank_meanpool_conv1x1_fprop(x, wfs: -> Couts at H/2 x W/2, pooled side
+// output) in ONE launch -- the two image-side layers of OptimizedResBlockDisc1 (gan_cifar_resnet.py:212-234); results bit for bit those
+// of the two entries.
+extern "C" int gank_image_conv_pair_fprop(const void* x, const void* wf1, const float* bias1, void* y1, const void* wfs, const float* biass, void* ys,
+                                          void* pooled, int N, int H, int W, int Cout1, int Couts, void* stream) {
+  GANK_REQUIRE(x && wf1 && y1 && wfs && ys && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "image_conv_pair_fprop: bad arguments");
+  GANK_REQUIRE(Cout1 % 128 == 0 && Couts % 128 == 0, "image_conv_pair_fprop: channel counts must be multiples of 128 (got %d, %d)", Cout1, Couts);
+  GANK_REQUIRE((long)N * H * W * 3 < (1L << 30) && (long)N * H * W * Cout1 < (1L << 31), "image_conv_pair_fprop: tensor too large (32-bit offsets)");
+  IgemmArgs a{}, b{};
+  a.x = (const bf16*)x; a.w = (const bf16*)wf1; a.bias = bias1; a.y = (bf16*)y1;
+  a.N = N; a.H = H; a.W = W; a.Hin = H; a.Win = W; a.Cin = 3; a.Cout = Cout1; a.ks = 3; a.pad = 1; a.scale = 1.f;
+  a.taps = 9; a.CoutPad = Cout1; a.Kpad = roundup(27, 64); a.nsteps = 1;
+  a.M = N * H * W; a.sw = log2_or_neg(W); a.shw = log2_or_neg(H * W);
+  a.tiles_m = cdiv(a.M, 128); a.tiles_n = a.CoutPad / 128;
+  { static const int ko_env = gank_tune("GANK_IGEMM_KORDER", 0); a.korder = ko_env; }
+  const int Hp = H / 2, Wp = W / 2;
+  b.x = (const bf16*)x; b.w = (const bf16*)wfs; b.bias = biass; b.y = (bf16*)ys; b.aux_out = (bf16*)pooled;
+  b.N = N; b.H = Hp; b.W = Wp; b.Hin = H; b.Win = W; b.Cin = 3; b.Cout = Couts; b.ks = 1; b.pad = 0; b.scale = 1.f;
+  b.taps = 1; b.CoutPad = Couts; b.Kpad = roundup(3, 64); b.nsteps = 1;
+  b.M = N * Hp * Wp; b.sw = log2_or_neg(Wp); b.shw = log2_or_neg(Hp * Wp);
+  b.tiles_m = cdiv(b.M, 128); b.tiles_n = b.CoutPad / 128;
+  b.korder = 0;                       // (as gank_meanpool_conv1x1_fprop)
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks_a = a.tiles_m * a.tiles_n, blocks_b = b.tiles_m * b.tiles_n;
+  gank_prof_begin(0, 2.0 * a.M * (double)Cout1 * 27 + 2.0 * b.M * (double)Couts * 3, s,
+                  2.0 * ((double)a.M * 3 + 27.0 * Cout1 + (double)a.M * Cout1 + 3.0 * Couts + (double)b.M * Couts));
+  gank_prof_tag(0, "conv_narrow_in_pair_kernel");
+  hipLaunchKernelGGL(conv_narrow_in_pair_kernel, dim3(blocks_a + blocks_b), dim3(256), 0, s, a, b, blocks_a);
+  gank_prof_end(0, s);
+  GANK_LAUNCH_OK("image_conv_pair_fprop");
+  return 0;
 }
 
 // dgrad of the stride-1 SAME conv = the same engine on dy with the flipped/transposed operand (wd)

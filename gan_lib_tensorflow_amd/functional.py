@@ -984,26 +984,38 @@ class _ForkPoolConv1x1(Function):
     last_sink = None
 
     @staticmethod
-    def forward(ctx, x, W, bias):
+    def forward(ctx, x, W, bias, conv1=None):
         ctx.set_materialize_grads(False)
         cin, cout = W.shape[-2], W.shape[-1]
         wf, _ = _prepared(W, 1, cin, cout, True, False)
         keep = ctx.needs_input_grad[1]
-        y, pooled = K.meanpool_conv1x1_fprop(x, wf, bias.detach() if bias is not None else None, cout, keep_pooled=keep)
+        y1 = None
+        if conv1 is not None:      # (wf1, bias1 | None, cout1): the 3x3 conv the caller applies to x next rides on the same launch
+            y1, y, pooled = K.image_conv_pair_fprop(x, conv1[0], conv1[1], conv1[2], wf, bias.detach() if bias is not None else None, cout, keep_pooled=keep)
+        else:
+            y, pooled = K.meanpool_conv1x1_fprop(x, wf, bias.detach() if bias is not None else None, cout, keep_pooled=keep)
         ctx.save_for_backward(W, pooled)
         ctx.cfg = (cin, cout, bias)
         ctx.sink = _ForkPoolConv1x1.last_sink = None
         if FUSE_IMAGE_WGRAD and keep and not ctx.needs_input_grad[0] and cin == 3 and pooled is not None:
             ctx.sink = _ForkPoolConv1x1.last_sink = ImageWgradSink(pooled, W, bias)      # see ImageWgradSink: the ConvMeanPool this shortcut is added to may serve it
         xv = x.view_as(x)
-        if not ctx.needs_input_grad[0]:
-            # autograd marks EVERY output of a node differentiable when any input is (here: the weight); the alias of an image
-            # that needs no gradient (the critic update) must not make the next conv compute an input gradient
-            ctx.mark_non_differentiable(xv)
-        return xv, y
+        nd = [] if ctx.needs_input_grad[0] else [xv]
+        # autograd marks EVERY output of a node differentiable when any input is (here: the weight); the alias of an image
+        # that needs no gradient (the critic update) must not make the next conv compute an input gradient
+        if y1 is not None:
+            nd.append(y1)          # the VALUE of the caller's conv node (fork_pool_conv1x1 parks it on xv)
+        if nd:
+            ctx.mark_non_differentiable(*nd)
+        return (xv, y) if y1 is None else (xv, y, y1)
 
     @staticmethod
-    def backward(ctx, ga, gs):
+    def backward(ctx, ga, gs, *_unused):
+        out = _ForkPoolConv1x1._backward(ctx, ga, gs)
+        return out + (None,)
+
+    @staticmethod
+    def _backward(ctx, ga, gs):
         W, pooled = ctx.saved_tensors
         cin, cout, bias = ctx.cfg
         dW = db = None
@@ -1035,9 +1047,24 @@ class _ForkPoolConv1x1(Function):
         return dx, dW, db
 
 
-def fork_pool_conv1x1(x, W, bias=None):
-    """-> (x for the main path, conv1x1(mean_pool2x2(x)) + bias); x [N,H,W,3], W fp32 [1,1,3,Cout] (or [3,Cout])"""
-    xv, y = _ForkPoolConv1x1.apply(x, W, bias)
+IMAGE_CONV_PAIR = True      # the critic's two image-side convs (conv_1 3x3 and the pooled 1x1 shortcut) in one launch
+
+
+def fork_pool_conv1x1(x, W, bias=None, W1=None, b1=None):
+    """-> (x for the main path, conv1x1(mean_pool2x2(x)) + bias); x [N,H,W,3], W fp32 [1,1,3,Cout] (or [3,Cout]).
+    W1 [3,3,3,Cout1], b1: the filter / bias of the 3x3 conv the caller applies to the returned x next: its VALUE comes from the same
+    launch and is parked on that tensor (`_conv_result`), where conv2d() with exactly these tensors picks it up (the conv stays a
+    node of its own with its own backward)."""
+    conv1 = None
+    if (IMAGE_CONV_PAIR and W1 is not None and W1.dim() == 4 and W1.shape[0] == 3 and W1.shape[2] == 3 and W1.shape[3] % 128 == 0
+            and W.shape[-1] % 128 == 0 and x.is_cuda):
+        wf1, _ = _prepared(W1, 3, 3, W1.shape[3], True, False)
+        conv1 = (wf1, b1.detach() if b1 is not None else None, W1.shape[3])
+    if conv1 is not None:
+        xv, y, y1 = _ForkPoolConv1x1.apply(x, W, bias, conv1)
+        xv._conv_result = (W1, b1, y1)
+    else:
+        xv, y = _ForkPoolConv1x1.apply(x, W, bias)
     if _ForkPoolConv1x1.last_sink is not None:
         y._shortcut_sink, _ForkPoolConv1x1.last_sink = _ForkPoolConv1x1.last_sink, None
     return xv, y

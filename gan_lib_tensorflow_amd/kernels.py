@@ -200,6 +200,19 @@ def meanpool_conv1x1_fprop(x, wf, bias, cout, keep_pooled=True):
     return y, pooled
 
 
+def image_conv_pair_fprop(x, wf1, bias1, cout1, wfs, biass, couts, keep_pooled=True):
+    """conv2d_fprop(x, wf1, bias1, 3x3) and meanpool_conv1x1_fprop(x, wfs, biass) in one launch (gank_image_conv_pair_fprop)
+    -> (y1 [N,H,W,cout1], ys [N,H/2,W/2,couts], pooled image | None)"""
+    n, h, w, cin = x.shape
+    assert cin == 3 and h % 2 == 0 and w % 2 == 0
+    y1 = torch.empty((n, h, w, cout1), dtype=BF16, device=x.device)
+    ys = torch.empty((n, h // 2, w // 2, couts), dtype=BF16, device=x.device)
+    pooled = torch.empty((n, h // 2, w // 2, cin), dtype=BF16, device=x.device) if keep_pooled else None
+    _lib.check(lib().gank_image_conv_pair_fprop(_p(x, BF16, "x"), _p(wf1, BF16, "wf1"), _p(bias1, F32, "bias1"), _p(y1), _p(wfs, BF16, "wfs"),
+                                                _p(biass, F32, "biass"), _p(ys), _p(pooled), n, h, w, cout1, couts, _stream()), "image_conv_pair_fprop")
+    return y1, ys, pooled
+
+
 def conv2d_dgrad(dy, wd, out_hw, cin, ksize, flags=0, scale=1.0, residual=None, relu_ref=None):
     n, cout = dy.shape[0], dy.shape[3]
     h, w = out_hw

@@ -356,6 +356,11 @@ int gank_conv2d_general_wgrad(const void* x, const void* dy, float* dw, float* d
  * the pooled image, which the filter gradient (gank_conv2d_wgrad on it) needs.  wf from gank_conv2d_prep_weights. */
 int gank_meanpool_conv1x1_fprop(const void* x, const void* wf, const float* bias, void* y, void* pooled,
                                 int N, int H, int W, int Cin, int Cout, void* stream);
+/* gank_conv2d_fprop(x [N,H,W,3], wf1: 3x3 -> Cout1, bias1, no flags) AND gank_meanpool_conv1x1_fprop(x, wfs: 1x1 -> Couts at H/2 x W/2,
+ * pooled side output) in ONE launch: the two image-side layers of OptimizedResBlockDisc1 (gan_cifar_resnet.py:212-234) read the same
+ * image; the shortcut's workgroups run behind conv_1's.  Results bit for bit those of the two entries.  Cout1, Couts % 128 == 0. */
+int gank_image_conv_pair_fprop(const void* x, const void* wf1, const float* bias1, void* y1, const void* wfs, const float* biass, void* ys,
+                               void* pooled, int N, int H, int W, int Cout1, int Couts, void* stream);
 
 /* ---- Deconv2D (common/ops/deconv2d.py:99-114): tf.nn.conv2d_transpose stride 2 SAME --------------
  * x [N,H,W,Cin] -> y [N,2H,2W,Cout]; master filter F fp32 [k,k,Cout,Cin].  The op has no caller in

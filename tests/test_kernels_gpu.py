@@ -1827,6 +1827,16 @@ def test_meanpool_conv1x1_gather_is_pool_then_conv(K):
         assert torch.equal(pooled.view(torch.int16), pooled_ref.view(torch.int16))
         assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16))
         assert relerr(y, R.conv2d_same(R.meanpool2x2(x), w) + b) < BF_TOL
+        # ... and with the block's 3x3 conv on the same image in the same launch (gank_image_conv_pair_fprop): the bytes of the two entries
+        w1, w1t = f32(rng.normal(size=(3, 3, 3, 128)) * 0.2)
+        b1, b1t = f32(rng.normal(size=128) * 0.1)
+        wf1, _ = K.prep_weights(w1t, True, False)
+        y1_ref = K.conv2d_fprop(xt, wf1, b1t, (32, 32), 128, 3)
+        y1, ys, pooled2 = K.image_conv_pair_fprop(xt, wf1, b1t, 128, wf, bt, 128)
+        torch.cuda.synchronize()
+        assert torch.equal(y1.view(torch.int16), y1_ref.view(torch.int16)) and torch.equal(ys.view(torch.int16), y.view(torch.int16))
+        assert torch.equal(pooled2.view(torch.int16), pooled.view(torch.int16))
+        assert relerr(y1, R.conv2d_same(x, w1) + b1) < BF_TOL
 
 
 def test_narrow_input_filter_gradient_streaming_kernel(K):
