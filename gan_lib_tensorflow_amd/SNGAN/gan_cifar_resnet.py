@@ -64,12 +64,21 @@ ResidualBlock = blocks.ResidualBlock
 OptimizedResBlockDisc1 = blocks.OptimizedResBlockDisc1
 
 
-def Generator(n_samples_, labels, noise=None, reuse=False, groups=1, rng_state=None):
+GEN_FEED_ONE_LAUNCH = True      # the label draw, the noise draw and the statistics arena's fill in front of a generator pass as one launch
+
+
+def generator_arena_floats(groups):
+    """floats of the statistics arena of one generator pass (0: the pass takes none)"""
+    return 6 * groups * 16 * 2 * DIM_G * 2 + 512 if (NORMALIZATION_G and Fn.CONV_EPILOGUE_STATS) else 0
+
+
+def Generator(n_samples_, labels, noise=None, reuse=False, groups=1, rng_state=None, arena_buf=None):
     """(:237-263)  noise [n,128] bf16 (drawn from the device RNG when None) -> [n, 3072] bf16, HWC order,
-    tanh range.  `groups` towers of n/groups samples have independent CBN statistics."""
+    tanh range.  `groups` towers of n/groups samples have independent CBN statistics.  arena_buf: the pass's statistics arena,
+    cleared by the caller (kernels.generator_feed)."""
     store = get_default_store()
     # the statistics sums of the six convs that feed a conditional batch norm: one fill for the whole pass
-    arena = K.stats_arena(6 * groups * 16 * 2 * DIM_G * 2 + 512, labels.device) if (NORMALIZATION_G and Fn.CONV_EPILOGUE_STATS and labels.is_cuda) \
+    arena = K.stats_arena(generator_arena_floats(groups), labels.device, arena_buf) if (generator_arena_floats(groups) and labels.is_cuda) \
         else contextlib.nullcontext()
     with store.variable_scope("Generator", reuse=reuse), arena:
         if noise is None:
@@ -571,7 +580,10 @@ class SNGANTrainer:
         N_CRITIC separate passes, in 5x fewer, 5x larger launches."""
         set_default_store(self.store)
         n = N_CRITIC * self.batch
-        fake = Generator(n, self.labels_all.reshape(-1), groups=N_CRITIC * N_TOWERS, rng_state=self.rng_state)
+        z = abuf = None
+        if GEN_FEED_ONE_LAUNCH and self.labels_all.is_cuda:
+            _, z, abuf = K.generator_feed(self.rng_state, (n, 128), generator_arena_floats(N_CRITIC * N_TOWERS))
+        fake = Generator(n, self.labels_all.reshape(-1), noise=z, groups=N_CRITIC * N_TOWERS, rng_state=self.rng_state, arena_buf=abuf)
         K.copy_(self.fake_all, fake)
 
     def _g_forward_backward(self, z=None, fake_labels=None):
@@ -580,9 +592,12 @@ class SNGANTrainer:
         set_default_store(self.store)   # the store is the "default graph": several trainers may coexist
         n = GEN_BS_MULTIPLE * self.batch
         self._begin_grads(self.g_flat)
+        abuf = None
+        if fake_labels is None and z is None and GEN_FEED_ONE_LAUNCH and self.rng_state.is_cuda:
+            fake_labels, z, abuf = K.generator_feed(self.rng_state, (n, 128), generator_arena_floats(N_TOWERS), n, 10)       # :467, :240
         if fake_labels is None:
             fake_labels = K.rng_labels(n, 10, self.rng_state)           # :467
-        fake = Generator(n, fake_labels, noise=z, groups=N_TOWERS, rng_state=self.rng_state)
+        fake = Generator(n, fake_labels, noise=z, groups=N_TOWERS, rng_state=self.rng_state, arena_buf=abuf)
         d_params = self.store.params_with_name('Discriminator')
         for p in d_params:      # gen_cost is differentiated w.r.t. gen_params only (:523)
             p.requires_grad_(False)

@@ -221,6 +221,7 @@ PROTOTYPES = {
     "gank_counter_add": [P, C.c_int64, P],
     "gank_preprocess_real": [P, P, P, I, P],
     "gank_rng_normal_bf16": [P, L, P, P],
+    "gank_generator_feed": [P, L, I, P, L, P, L, P, P],
     "gank_rng_labels": [P, L, I, P, P],
     "gank_prof_enable": [I],
     "gank_prof_reset": [],

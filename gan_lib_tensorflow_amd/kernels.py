@@ -135,8 +135,13 @@ class stats_arena:
     `floats`: capacity; a request that does not fit falls back to its own buffer and fill."""
     current = None
 
-    def __init__(self, floats, device):
-        self.buf = zeros_f32(int(floats), device) if torch.device(device).type == 'cuda' else torch.zeros(int(floats), dtype=F32, device=device)
+    def __init__(self, floats, device, buf=None):
+        # buf: a cleared buffer of `floats` floats the caller already has (generator_feed)
+        if buf is not None:
+            assert buf.numel() >= int(floats) and buf.dtype == F32
+            self.buf = buf
+        else:
+            self.buf = zeros_f32(int(floats), device) if torch.device(device).type == 'cuda' else torch.zeros(int(floats), dtype=F32, device=device)
         self.used = 0
 
     def __enter__(self):
@@ -1599,6 +1604,18 @@ def rng_normal(shape, rng_state):
     y = torch.empty(shape, dtype=BF16, device=rng_state.device)
     _lib.check(lib().gank_rng_normal_bf16(_p(y), y.numel(), _p(rng_state, torch.int64), _stream()), "rng_normal")
     return y
+
+
+def generator_feed(rng_state, noise_shape, zero_floats=0, n_lab=0, n_labels=10):
+    """gank_generator_feed: (labels int32 [n_lab] | None, noise bf16 [noise_shape], zeroed fp32 [zero_floats] | None) from ONE launch --
+    rng_labels, rng_normal and a zero fill with the values and the stream offset of the separate calls"""
+    dev = rng_state.device
+    labels = torch.empty(n_lab, dtype=I32, device=dev) if n_lab else None
+    y = torch.empty(noise_shape, dtype=BF16, device=dev)
+    zb = torch.empty(int(zero_floats), dtype=F32, device=dev) if zero_floats else None
+    _lib.check(lib().gank_generator_feed(_p(labels), n_lab, n_labels, _p(y), y.numel(), _p(zb), int(zero_floats), _p(rng_state, torch.int64), _stream()),
+               "generator_feed")
+    return labels, y, zb
 
 
 def rng_labels(n, n_labels, rng_state):

@@ -811,6 +811,11 @@ int gank_critic_feed(const uint8_t* real_all, const int32_t* labels_all, const v
                      void* stream);
 int gank_rng_normal_bf16(void* y, long n, uint64_t* rng_state, void* stream);
 int gank_rng_labels(int32_t* y, long n, int n_labels, uint64_t* rng_state, void* stream);
+/* The three launches in front of a generator pass as one: labels (int32 [n_lab]; NULL with n_lab = 0: no draw) as gank_rng_labels
+ * (gan_cifar_resnet.py:467), noise (bf16 [n]) as gank_rng_normal_bf16 (:240) drawn at the next stream offset, zero_buf (fp32 [zero_n],
+ * 16-byte aligned; NULL with 0) cleared (the pass's statistics arena).  Outputs and the stream offset are those of the separate calls. */
+int gank_generator_feed(int32_t* labels, long n_lab, int n_labels, void* noise, long n, float* zero_buf, long zero_n, uint64_t* rng_state,
+                        void* stream);
 
 /* ---- opt-in per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ------- */
 int gank_prof_enable(int on);

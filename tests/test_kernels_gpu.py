@@ -495,6 +495,28 @@ def test_adam_tf_and_lr_decay(K):
     assert int(t) == 4 and float(g2.abs().max()) == 0.0 and float(p2.abs().min()) > 0.0
 
 
+def test_generator_feed_is_the_three_launches_in_front_of_a_generator_pass(K):
+    """gank_generator_feed (gan_cifar_resnet.py:240,467): label draw + noise draw + statistics-arena fill in one launch -- the values
+    and the stream offset of gank_rng_labels, gank_rng_normal_bf16 and a zero fill, with and without the label draw."""
+    for n_lab in (128, 0, 5):
+        a, b = K.new_rng_state(321, "cuda"), K.new_rng_state(321, "cuda")
+        for _ in range(2):          # two passes in a row: the offsets keep agreeing
+            lab_ref = K.rng_labels(n_lab, 10, a) if n_lab else None
+            z_ref = K.rng_normal((max(n_lab, 3), 128), a)
+            lab, z, zb = K.generator_feed(b, (max(n_lab, 3), 128), 1027 * 4, n_lab, 10)
+            torch.cuda.synchronize()
+            assert torch.equal(z.view(torch.int16), z_ref.view(torch.int16)) and torch.equal(a, b)
+            assert (lab is None) == (n_lab == 0) and (n_lab == 0 or torch.equal(lab, lab_ref))
+            assert zb.shape == (1027 * 4,) and float(zb.abs().max()) == 0.0
+    zb = torch.full((4 * 37 + 4,), 3.0, device="cuda")      # a fill that is not a multiple of four floats
+    _lib_fill = K.lib().gank_generator_feed
+    st = K.new_rng_state(1, "cuda")
+    z = torch.empty(8, dtype=torch.bfloat16, device="cuda")
+    assert _lib_fill(None, 0, 10, z.data_ptr(), 8, zb.data_ptr(), 4 * 37 + 3, st.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert float(zb[:4 * 37 + 3].abs().max()) == 0.0 and float(zb[4 * 37 + 3]) == 3.0
+
+
 def test_preprocess_and_rng(K):
     st = K.new_rng_state(42, "cuda")
     data = torch.randint(0, 256, (16, 3072), dtype=torch.uint8)
