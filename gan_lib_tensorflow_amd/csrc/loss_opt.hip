@@ -316,13 +316,15 @@ __global__ void adam_tf_kernel(float* __restrict__ p, float* __restrict__ g, flo
   const long n4 = n >> 2;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   unsigned bad = 0u, zero = 0u;        // health (optional): gradients that are not finite (loss-scale overflow) / exactly zero
-  // two elements of the grid-stride loop per trip, all eight loads requested before the first use: 45.7 us for 137 MB (3.0 TB/s) with
-  // one element per trip
-  auto upd = [&](f32x4& pp, const f32x4& gg, f32x4& mm, f32x4& vv) {
+  // (two elements per trip with all eight loads up front measured the same: 46.4 against 45.7 us for 137 MB)
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
+    const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
     if (health) {
 #pragma unroll
       for (int e = 0; e < 4; e++) { bad += (gg[e] - gg[e] != 0.f) ? 1u : 0u; zero += gg[e] == 0.f ? 1u : 0u; }
     }
+    f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const float gr = gg[e] * gs;
@@ -333,27 +335,6 @@ __global__ void adam_tf_kernel(float* __restrict__ p, float* __restrict__ g, flo
       vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
       pp[e] -= lr_t * mm[e] / (sqrtf(vv[e]) + eps);
     }
-  };
-  const long stride = (long)gridDim.x * blockDim.x;
-  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  for (; i + stride < n4; i += 2 * stride) {
-    const long j = i + stride;
-    f32x4 pp0 = reinterpret_cast<f32x4*>(p)[i], pp1 = reinterpret_cast<f32x4*>(p)[j];
-    const f32x4 gg0 = reinterpret_cast<const f32x4*>(g)[i], gg1 = reinterpret_cast<const f32x4*>(g)[j];
-    f32x4 mm0 = reinterpret_cast<f32x4*>(m)[i], mm1 = reinterpret_cast<f32x4*>(m)[j];
-    f32x4 vv0 = reinterpret_cast<f32x4*>(v)[i], vv1 = reinterpret_cast<f32x4*>(v)[j];
-    upd(pp0, gg0, mm0, vv0);
-    upd(pp1, gg1, mm1, vv1);
-    reinterpret_cast<f32x4*>(p)[i] = pp0; reinterpret_cast<f32x4*>(p)[j] = pp1;
-    reinterpret_cast<f32x4*>(m)[i] = mm0; reinterpret_cast<f32x4*>(m)[j] = mm1;
-    reinterpret_cast<f32x4*>(v)[i] = vv0; reinterpret_cast<f32x4*>(v)[j] = vv1;
-    if (zero_n > 0) { reinterpret_cast<f32x4*>(g)[i] = z4; reinterpret_cast<f32x4*>(g)[j] = z4; }
-  }
-  for (; i < n4; i += stride) {
-    f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
-    const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
-    f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
-    upd(pp, gg, mm, vv);
     reinterpret_cast<f32x4*>(p)[i] = pp;
     reinterpret_cast<f32x4*>(m)[i] = mm;
     reinterpret_cast<f32x4*>(v)[i] = vv;
