@@ -142,6 +142,7 @@ PROTOTYPES = {
     "gank_label_dense_bwd": [P, P, P, P, P, P, P, I, I, I, I, P],
     "gank_label_conv3x3_bwd_pooled": [P, P, P, I, P, I, I, I, I, I, P, P, P, P, I, I, I, P],
     "gank_label_dense_bwd_parts": [P, I, P, P, P, P, P, I, I, I, P],
+    "gank_sum_slabs_label_bwd": [P, I, P, P, P, I, P, I, I, I, I, I, P, P, P, I, I, I, P],
     "gank_concat_label_pool_fwd": [P, P, P, P, P, I, I, I, I, I, I, P],
     "gank_concat_label_unpool_bwd": [P, P, P, P, I, I, I, I, I, P],
     "gank_concat_label_unpool_bwd_factored": [P, P, P, P, P, I, P, P, I, I, I, I, I, I, P],

@@ -2,6 +2,7 @@
 // pooling, concat/tile, embedding, casts, column sums.  All bf16 traffic is 16 B per lane whenever the
 // channel count allows (C % 8 == 0); a scalar path covers the 3-channel image side and odd sizes.
 #include "gank_common.h"
+#include "label_conv_dev.h"
 
 static inline dim3 grid1d(long n, int block = 256, int cap = 4096) {
   long g = (n + block - 1) / block;
@@ -407,8 +408,7 @@ struct SlabJobTable {
   int first_block[SLAB_JOBS + 1];
   int count;
 };
-__global__ __launch_bounds__(256) void sum_slabs_kernel(SlabJobTable t) {
-  __shared__ float part[4][64];
+__device__ __forceinline__ void sum_slabs_block(const SlabJobTable& t, float (*part)[64]) {
   int ji = 0;
 #pragma unroll
   for (int i = 1; i < SLAB_JOBS; i++) ji += (i < t.count && (int)blockIdx.x >= t.first_block[i]) ? 1 : 0;
@@ -487,7 +487,42 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(SlabJobTable t) {
   __syncthreads();
   if (sg == 0 && i < jb.n) jb.out[i] += jb.scale * (((part[0][o] + part[1][o]) + part[2][o]) + part[3][o]);
 }
-extern "C" int gank_sum_slabs(const gank_slab_job* jobs, int count, void* stream) {
+__global__ __launch_bounds__(256) void sum_slabs_kernel(SlabJobTable t) {
+  __shared__ float part[4][64];
+  sum_slabs_block(t, part);
+}
+// ... with the label-gradient launch of a critic update (gank_label_conv3x3_bwd_pooled: independent of every slab, small) as extra
+// workgroups behind the summing ones: one launch less per update
+__global__ __launch_bounds__(256) void sum_slabs_label_kernel(SlabJobTable t, LabelBwdArgs q, int main_blocks) {
+  __shared__ float part[4][64];
+  extern __shared__ __attribute__((aligned(16))) float sm_[];
+  if ((int)blockIdx.x >= main_blocks) {
+    label_conv_bwd_block(q, blockIdx.x - main_blocks, sm_);
+    return;
+  }
+  sum_slabs_block(t, part);
+}
+static int sum_slabs_impl(const gank_slab_job* jobs, int count, const LabelBwdArgs* lq, size_t lds, void* stream);
+extern "C" int gank_sum_slabs(const gank_slab_job* jobs, int count, void* stream) { return sum_slabs_impl(jobs, count, nullptr, 0, stream); }
+// gank_sum_slabs(jobs, count) + gank_label_conv3x3_bwd_pooled(...) in ONE launch (the label gradients are extra workgroups; dw_feat_tmp is
+// not offered here: the feature rows arrive through a slab job).  count <= 12.
+extern "C" int gank_sum_slabs_label_bwd(const gank_slab_job* jobs, int count, const float* tap_sums, const int32_t* lists, const void* T, int V, const float* w,
+                                        int Cin_total, int c0, int C2, int Cout, int N, float* dw, float* de_parts, const void* g_pooled, int HWp, int pitch,
+                                        int c0g, void* stream) {
+  GANK_REQUIRE(jobs && count > 0 && count <= SLAB_JOBS, "sum_slabs_label_bwd: 1..%d jobs", SLAB_JOBS);
+  GANK_REQUIRE(tap_sums && lists && T && w && dw && de_parts && g_pooled && N > 0 && N <= 1024 && V > 0 && V <= LCB_V && HWp > 0,
+               "sum_slabs_label_bwd: bad arguments");
+  GANK_REQUIRE(Cout % 4 == 0 && Cout <= 256 && C2 % 32 == 0 && c0 >= 0 && c0 + C2 <= Cin_total && pitch % 8 == 0 && c0g % 8 == 0 && c0g + C2 <= pitch,
+               "sum_slabs_label_bwd: unsupported channel counts");
+  size_t lds2 = ((size_t)V * (Cout + 4) + (size_t)LCB_CT * (Cout + 4) + (size_t)V * LCB_CT) * sizeof(float);
+  if (lds2 < 64 * 4 * 8 * sizeof(float)) lds2 = 64 * 4 * 8 * sizeof(float);
+  GANK_REQUIRE(lds2 <= 48 * 1024, "sum_slabs_label_bwd: Cout = %d does not fit the LDS", Cout);
+  const int pool_blocks = V * (C2 / 32);
+  const LabelBwdArgs q{tap_sums, (const bf16*)T, w, dw, de_parts, nullptr, V, Cin_total, c0, C2, Cout, 0, 9 * (C2 / LCB_CT) + pool_blocks,
+                       (const bf16*)g_pooled, lists, N, HWp, pitch, c0g, pool_blocks};
+  return sum_slabs_impl(jobs, count, &q, lds2, stream);
+}
+static int sum_slabs_impl(const gank_slab_job* jobs, int count, const LabelBwdArgs* lq, size_t lds, void* stream) {
   GANK_REQUIRE(jobs && count > 0, "sum_slabs: empty list");
   for (int base = 0; base < count; base += SLAB_JOBS) {
     SlabJobTable t{};
@@ -505,7 +540,8 @@ extern "C" int gank_sum_slabs(const gank_slab_job* jobs, int count, void* stream
       blocks += j.fold ? (int)((j.n / 4 + 255) / 256) : (j.nslabs <= 32 ? (int)((j.n + 1023) / 1024) : (int)((j.n + 63) / 64));
     }
     t.first_block[t.count] = blocks;
-    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t);
+    if (lq) hipLaunchKernelGGL(sum_slabs_label_kernel, dim3((unsigned)(blocks + lq->blocks)), dim3(256), lds, (hipStream_t)stream, t, *lq, blocks);
+    else hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t);
   }
   GANK_LAUNCH_OK("sum_slabs");
   return 0;

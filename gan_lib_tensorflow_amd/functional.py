@@ -75,6 +75,10 @@ def narrow_wgrad_ok(cin, cout, k, flags_free):
 # here and leave as ONE launch in join_wgrad().  Only under BATCH_SMALL_WGRADS (the caller guarantees the join).
 SLAB_WGRADS = True
 _slab_jobs = []
+# ... and the label-gradient launch of a critic update (concat_label_conv1's backward) rides on that launch as extra workgroups; what
+# depends on it (the label branch's dense-layer gradients) is issued right behind: entries (label arguments of kernels.sum_slabs, finish(parts))
+LABEL_BWD_IN_SUM_SLABS = True
+_label_jobs = []
 
 
 def flush_wgrads():
@@ -82,7 +86,14 @@ def flush_wgrads():
         K.conv2d_wgrad_batched(items, hw, k, flags, 1.0, slab_jobs=_slab_jobs if SLAB_WGRADS else None)
     _deferred.clear()
     if _slab_jobs:
-        K.sum_slabs(_slab_jobs)
+        if _label_jobs and sum(c for _, c, _ in _slab_jobs) <= K.SUM_SLABS_MAX_JOBS:
+            label, finish = _label_jobs.pop(0)
+            finish(K.sum_slabs(_slab_jobs, label))
+        else:
+            K.sum_slabs(_slab_jobs)
+    for label, finish in _label_jobs:          # (no summing launch to ride on: a launch of their own)
+        finish(K.label_conv3x3_bwd_pooled(*label))
+    _label_jobs.clear()
     while len(_deferred_narrow) >= 2:
         a, b = _deferred_narrow.pop(0), _deferred_narrow.pop(0)
         K.conv2d_wgrad_narrow_pair(a, b)
@@ -97,12 +108,13 @@ def reset_deferred():
     _deferred.clear()
     _deferred_narrow.clear()
     _slab_jobs.clear()
+    _label_jobs.clear()
 
 
 def join_wgrad():
     """Every filter gradient issued or deferred so far is complete / in stream order (before the optimiser and the
     SN backward)."""
-    if _deferred or _deferred_narrow or _slab_jobs:
+    if _deferred or _deferred_narrow or _slab_jobs or _label_jobs:
         flush_wgrads()
 
 
@@ -1195,8 +1207,10 @@ def concat_label(a, labels, table, W, bias=None):
     return _ConcatLabel.apply(a, labels, table, W, bias)
 
 
-def _label_dense_grads(ctx, de32, labels, table, W, bias):
-    """the dense layer's / table's gradients from the per-sample sums of the tiled half (shared by both concat forms)"""
+def _label_dense_grads(ctx, de32, labels, table, W, bias, defer=False):
+    """the dense layer's / table's gradients from the per-sample sums of the tiled half (shared by both concat forms).
+    defer: -> (dt, dw, db, finish): the targets are handed to autograd now, finish(parts) issues the launch later (in stream order
+    before anything reads them: join_wgrad)"""
     need_t, need_w = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
     need_b = bias is not None and ctx.needs_input_grad[4]
     dt = dw = db = None
@@ -1210,11 +1224,16 @@ def _label_dense_grads(ctx, de32, labels, table, W, bias):
     if need_b:
         bt, acc = _target(bias)
         db = None if acc else bt
-    if need_t or need_w or need_b:
-        if labels is None:                     # de32 = rows summed per label already, fp32 [parts, V, C2]
-            K.label_dense_bwd_parts(de32, table.detach(), W.detach(), wt, bt, tt)
-        else:
-            K.label_dense_bwd(de32, labels, table.detach(), W.detach(), wt, bt, tt)
+
+    def finish(rows):
+        if need_t or need_w or need_b:
+            if labels is None:                     # rows summed per label already, fp32 [parts, V, C2]
+                K.label_dense_bwd_parts(rows, table.detach(), W.detach(), wt, bt, tt)
+            else:
+                K.label_dense_bwd(rows, labels, table.detach(), W.detach(), wt, bt, tt)
+    if defer:
+        return dt, dw, db, finish
+    finish(de32)
     return dt, dw, db
 
 
@@ -1315,7 +1334,15 @@ class _ConcatLabelConv1(Function):
                     elif sums is not None and POOLED_LABEL_PART and JOIN_IN_DGRAD and gp is not None and need_label and ctx.needs_input_grad[0]:
                         # ... with the pooled branch's share of the tiled vector's gradient as a tenth part (extra workgroups): the join
                         # launch below has nothing left to do
-                        parts = K.label_conv3x3_bwd_pooled(sums, lists, T, W1.detach(), c1, tgt4, _c(gp), c1, n)
+                        label = (sums, lists, T, W1.detach(), c1, tgt4, _c(gp), c1, n)
+                        if LABEL_BWD_IN_SUM_SLABS and BATCH_SMALL_WGRADS:
+                            # ... and the launch itself rides on the pass's slab-summing launch (join_wgrad), the dense layer's gradients behind it
+                            # (their targets go to autograd now, as a deferred filter gradient's do)
+                            dt_, dw_, dbe_, finish = _label_dense_grads(ctx, None, None, table, W_emb, ctx.b_emb, defer=True)
+                            _label_jobs.append((label, finish))
+                            parts = ("deferred", dt_, dw_, dbe_)
+                        else:
+                            parts = K.label_conv3x3_bwd_pooled(*label)
                     else:
                         parts = K.label_conv3x3_bwd(g, lists, T, W1.detach(), c1, tgt4, sums=sums)
                 else:                          # small batches: through a zero-filled staging buffer, merged by the same launch
@@ -1336,6 +1363,8 @@ class _ConcatLabelConv1(Function):
                     joined = True
                 else:
                     da = K.img16_conv3x3(g, ctx.rd, None, c1, 0, a)      # relu mask of the feature half in the epilogue
+        if gp is not None and joined and isinstance(parts, tuple):        # deferred (join_wgrad issues the launches)
+            return da, None, parts[1], parts[2], parts[3], dW, db
         if gp is not None and joined and parts is not None and parts.shape[0] == 10:
             dt, dw, dbe = _label_dense_grads(ctx, parts, None, table, W_emb, ctx.b_emb)
             return da, None, dt, dw, dbe, dW, db

@@ -331,19 +331,37 @@ def slab_job(slabs, out, n, stride, nslabs, scale=1.0):
     return (jobs, 1, slabs)
 
 
-def sum_slabs(slab_jobs):
-    """ONE launch (per 8 jobs) for every job of the list (entries: (SlabJob array, count, the workspace kept alive)); clears the list"""
+SUM_SLABS_MAX_JOBS = 12       # jobs of one launch (gank_sum_slabs_label_bwd takes no more)
+
+
+def sum_slabs(slab_jobs, label=None):
+    """ONE launch (per 12 jobs) for every job of the list (entries: (SlabJob array, count, the workspace kept alive)); clears the list.
+    label = (sums, lists, t, w, c0, dw, g_pooled, c0g, n): label_conv3x3_bwd_pooled's launch rides on this one as extra workgroups
+    (gank_sum_slabs_label_bwd; at most 12 jobs) -> its de_parts fp32 [10,V,C2]"""
     total = sum(c for _, c, _ in slab_jobs)
     if total == 0:
-        return
+        assert label is None
+        return None
     table, i = (SlabJob * total)(), 0
     for jobs, c, _ in slab_jobs:
         for j in range(c):
             for f, _t in SlabJob._fields_:
                 setattr(table[i], f, getattr(jobs[j], f))
             i += 1
-    _lib.check(lib().gank_sum_slabs(table, total, _stream()), "sum_slabs")
+    parts = None
+    if label is not None:
+        sums, lists, t, w, c0, dw, g_pooled, c0g, n = label
+        assert total <= SUM_SLABS_MAX_JOBS and dw.shape == w.shape and g_pooled.shape[0] == n
+        v, c2 = t.shape
+        hwp, pitch = g_pooled.shape[1] * g_pooled.shape[2], g_pooled.shape[3]
+        parts = torch.empty((10, v, c2), dtype=F32, device=g_pooled.device)
+        _lib.check(lib().gank_sum_slabs_label_bwd(table, total, _p(sums, F32, "sums"), _p(lists, I32, "lists"), _p(t, BF16, "T"), v, _p(w, F32, "w"), w.shape[2], c0,
+                                                  c2, w.shape[3], n, _p(dw, F32, "dw"), _p(parts), _p(g_pooled, BF16, "g_pooled"), hwp, pitch, c0g, _stream()),
+                   "sum_slabs_label_bwd")
+    else:
+        _lib.check(lib().gank_sum_slabs(table, total, _stream()), "sum_slabs")
     slab_jobs.clear()
+    return parts
 
 
 def conv2d_wgrad_narrow_pair(a, b):

@@ -670,6 +670,11 @@ int gank_label_conv3x3_bwd_pooled(const float* tap_sums, const int32_t* lists, c
                                   int pitch, int c0g, void* stream);
 int gank_label_dense_bwd_parts(const float* de_parts_rows, int parts, const float* table, const float* W, float* dW, float* dbias,
                                float* dtable, int V, int D, int C2, void* stream);
+/* gank_sum_slabs(jobs, count <= 12) + gank_label_conv3x3_bwd_pooled (without dw_feat_tmp) in ONE launch: the label gradients of a critic
+ * update are independent of every slab and small, so they run as extra workgroups behind the summing ones. */
+int gank_sum_slabs_label_bwd(const gank_slab_job* jobs, int count, const float* tap_sums, const int32_t* lists, const void* T, int V, const float* w,
+                             int Cin_total, int c0, int C2, int Cout, int N, float* dw, float* de_parts, const void* g_pooled, int HWp, int pitch,
+                             int c0g, void* stream);
 
 /* tf.nn.embedding_lookup (common/ops/embedding.py:51) and its IndexedSlices gradient (dense, accumulated) */
 int gank_embedding_fwd(const float* table, const int32_t* idx, void* y, int N, int D, int vocab, void* stream);

@@ -1680,6 +1680,12 @@ def test_conv3x3_with_its_spatially_constant_input_channels_factored_out(K, n):
         for i in range(n):
             want9[labels[i]] += gq[i, :, :, c1:].reshape(64, c2).sum(0)
         assert relerr(parts10[9], want9) < 1e-6
+        # ... and that launch as extra workgroups of the slab-summing launch (gank_sum_slabs_label_bwd): the same bits
+        dw6 = torch.tensor(dw0).cuda()
+        sums = K.conv2d_wgrad_rows(at, dyt, dw6, (16, 16), 3, K.IN_RELU, jobs, tap_sums=(lists, v))
+        parts11 = K.sum_slabs(jobs, (sums, lists, tt, wt, c1, dw6, gqt, c1, n))
+        torch.cuda.synchronize()
+        assert len(jobs) == 0 and torch.equal(dw6, dw2) and torch.equal(parts11, parts10)
     else:
         assert n < 64
     # the pooled / unpooled ends of the pair: the pooled concat alone, and the gradient join with the factored consumer's partial sums

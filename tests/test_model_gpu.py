@@ -858,8 +858,8 @@ def test_image_side_filter_gradients_inside_the_convmeanpool_input_gradient(gpu,
 
 
 def test_launch_folds_of_the_critic_update_match_the_separate_launches(gpu, monkeypatch):
-    """Late round 5: four launches of a critic update became extra workgroups of their neighbours (functional.POOLED_LABEL_PART,
-    SHORTCUT_IN_TABLE_LAUNCH, CONV1X1_BWD_ONE_LAUNCH, IMAGE_CONV_PAIR; gan_cifar_resnet.py:172-184,212-234,276-284 forward and backward).
+    """Late round 5: five launches of a critic update became extra workgroups of their neighbours (functional.POOLED_LABEL_PART +
+    LABEL_BWD_IN_SUM_SLABS, SHORTCUT_IN_TABLE_LAUNCH, CONV1X1_BWD_ONE_LAUNCH, IMAGE_CONV_PAIR; gan_cifar_resnet.py:172-184,212-234,276-284 forward and backward).
     Same inputs, same state, headline batch: every fold IS taken once per critic pass, the loss agrees to the last bf16 digit of the
     logits and every critic gradient with the separate launches' up to rounding (two of the folds change a summation order in front of
     a bf16 rounding: relative L2 <= 1e-3 per tensor, the worst ones are printed)."""
@@ -875,8 +875,11 @@ def test_launch_folds_of_the_critic_update_match_the_separate_launches(gpu, monk
     tr.real_labels.copy_(labels)
     with torch.no_grad():
         fake = S.Generator(b, tr.real_labels, noise=z, groups=2)
-    calls = {"conv1x1_wgrad_dgrad": 0, "image_conv_pair_fprop": 0, "label_conv3x3_bwd_pooled": 0, "table_shortcut": 0}
-    for name in ("conv1x1_wgrad_dgrad", "image_conv_pair_fprop", "label_conv3x3_bwd_pooled"):
+    calls = {"conv1x1_wgrad_dgrad": 0, "image_conv_pair_fprop": 0, "sum_slabs_with_label_gradients": 0, "table_shortcut": 0}
+    orig_s = K.sum_slabs
+    monkeypatch.setattr(K, "sum_slabs", lambda jobs, label=None: (calls.__setitem__("sum_slabs_with_label_gradients", calls["sum_slabs_with_label_gradients"] + (1 if label is not None else 0)),
+                                                                  orig_s(jobs, label))[1])
+    for name in ("conv1x1_wgrad_dgrad", "image_conv_pair_fprop"):
         orig = getattr(K, name)
         monkeypatch.setattr(K, name, (lambda o, nm: lambda *a, **k: (calls.__setitem__(nm, calls[nm] + 1), o(*a, **k))[1])(orig, name))
     orig_t = K.label_conv3x3_table_pooled
@@ -885,7 +888,7 @@ def test_launch_folds_of_the_critic_update_match_the_separate_launches(gpu, monk
     u0 = {k: v.clone() for k, v in tr.store.vars.items() if k.endswith('spectral_norm/u')}
     out = {}
     for folded in (True, False):
-        for sw in ("POOLED_LABEL_PART", "SHORTCUT_IN_TABLE_LAUNCH", "CONV1X1_BWD_ONE_LAUNCH", "IMAGE_CONV_PAIR"):
+        for sw in ("POOLED_LABEL_PART", "LABEL_BWD_IN_SUM_SLABS", "SHORTCUT_IN_TABLE_LAUNCH", "CONV1X1_BWD_ONE_LAUNCH", "IMAGE_CONV_PAIR"):
             monkeypatch.setattr(Fn, sw, folded)
         for k, v in u0.items():
             tr.store.vars[k].copy_(v)
