@@ -1371,7 +1371,9 @@ class _ConcatLabelConv1(Function):
         if gp is not None:
             if da is None:
                 da = K.zeros_bf16(tuple(a.shape), a.device) if hasattr(K, "zeros_bf16") else torch.zeros_like(a)
-            if joined:
+            if joined and not need_label:
+                de32 = None                    # (the generator update: nobody asks for the tiled vector's gradient -- no launch)
+            elif joined:
                 _, de32 = K.concat_label_unpool_bwd_factored(c1, _c(gp), parts if need_label else None, labels, lists)
             else:
                 da, de32 = K.concat_label_unpool_bwd_factored(da, _c(gp), parts if need_label else None, labels, lists)
