@@ -2144,10 +2144,18 @@ __global__ __launch_bounds__(256) void wgrad_upconv_fold_slabs_kernel(const floa
   for (int rr = 0; rr < 4; rr++) {
     const int co = co0 + ty + 8 * rr, ci = ci0 + tx;
     float acc = 0.f;
-    for (int sp = 0; sp < splits; sp++) {               // fixed order: deterministic
-      const float* base = ws + (long)sp * 16 * plane + (long)co * Cin + ci;
-      acc += (base[((2 - t) * 4 + (2 - sidx)) * plane] + base[((2 - t) * 4 + (3 - sidx)) * plane]) +
-             (base[((3 - t) * 4 + (2 - sidx)) * plane] + base[((3 - t) * 4 + (3 - sidx)) * plane]);
+    for (int sp0 = 0; sp0 < splits; sp0 += 4) {         // fixed order: deterministic; 16 loads requested per trip (one split per trip was a
+      float v[4][4];                                    // chain of dependent round trips: 10.5 us for 17 MB)
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int sp = sp0 + u < splits ? sp0 + u : splits - 1;
+        const float* base = ws + (long)sp * 16 * plane + (long)co * Cin + ci;
+        v[u][0] = base[((2 - t) * 4 + (2 - sidx)) * plane]; v[u][1] = base[((2 - t) * 4 + (3 - sidx)) * plane];
+        v[u][2] = base[((3 - t) * 4 + (2 - sidx)) * plane]; v[u][3] = base[((3 - t) * 4 + (3 - sidx)) * plane];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (sp0 + u < splits) acc += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
     }
     tile[ty + 8 * rr][tx] = acc;
   }
