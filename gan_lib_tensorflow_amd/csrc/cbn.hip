@@ -224,6 +224,117 @@ static int cbn_geom(CbnGeom& q, int N, int HW, int C, int groups, int n_labels, 
   return 0;
 }
 
+// Small towers (<= 1024 rows: the generator's first conditional batch norm, on the 4x4 map behind G.Input, whose statistics no conv
+// epilogue can deliver) in ONE launch instead of three at the launch floor: block = (tower, 64 channels = 128 bytes of every row),
+// thread = (8-channel group, row lane); the tower's rows of the block stay in REGISTERS (<= 16 sixteen-byte pieces per thread, all
+// requested before the first use) for the mean, the sum of squared deviations from that exact mean (two passes over registers: no
+// shifted sums, no part merge) and the apply -- the forward expression of cbn_apply_rows, operand for operand.  The 64 row lanes meet
+// in LDS in a fixed order (deterministic).
+constexpr int CFS_ROWS = 16, CFS_LANES = 64;        // rows per thread, row lanes (512 threads: 256 VGPRs for the 16 resident pieces)
+__global__ __launch_bounds__(512) void cbn_fwd_small_kernel(const bf16* __restrict__ x, const int* __restrict__ labels, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, bf16* __restrict__ y, float* __restrict__ stats, CbnGeom q) {
+  __shared__ float red[512 * 8];
+  __shared__ float mean_s[64], iv_s[64];
+  const int tid = threadIdx.x, g = tid & 7, rl = tid >> 3;
+  const int cgroups = q.C >> 6;
+  const int grp = blockIdx.x / cgroups, cb = blockIdx.x - grp * cgroups;
+  const long r0 = (long)grp * q.rows_per_group;
+  const int rows = (int)q.rows_per_group;
+  const int c0 = cb * 64 + g * 8;
+  float v[CFS_ROWS][8];                 // as floats: the three passes below would otherwise each convert (or the compiler keep both forms)
+  {
+    bf16x8 raw[CFS_ROWS];
+#pragma unroll
+    for (int u = 0; u < CFS_ROWS; u++) {
+      const int r = rl * CFS_ROWS + u;
+      raw[u] = *reinterpret_cast<const bf16x8*>(x + (r0 + (r < rows ? r : 0)) * q.C + c0);       // unconditional, clamped
+    }
+#pragma unroll
+    for (int u = 0; u < CFS_ROWS; u++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[u][e] = bf2f(raw[u][e]);
+  }
+  float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int u = 0; u < CFS_ROWS; u++)
+    if (rl * CFS_ROWS + u < rows) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) s1[e] += v[u][e];
+    }
+#pragma unroll
+  for (int e = 0; e < 8; e++) red[tid * 8 + e] = s1[e];
+  __syncthreads();
+  if (tid < 64) {
+    float p[CFS_LANES];                 // all loads first (a load per add in a chain was 2.7 us per reduction), the adds in lane order
+#pragma unroll
+    for (int l = 0; l < CFS_LANES; l++) p[l] = red[l * 64 + tid];
+    float t = 0.f;
+#pragma unroll
+    for (int l = 0; l < CFS_LANES; l++) t += p[l];
+    mean_s[tid] = t / (float)rows;
+  }
+  __syncthreads();
+  float mu[8], s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int e = 0; e < 8; e++) mu[e] = mean_s[g * 8 + e];
+#pragma unroll
+  for (int u = 0; u < CFS_ROWS; u++)
+    if (rl * CFS_ROWS + u < rows) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) { const float d = v[u][e] - mu[e]; s2[e] += d * d; }
+    }
+#pragma unroll
+  for (int e = 0; e < 8; e++) red[tid * 8 + e] = s2[e];
+  __syncthreads();
+  if (tid < 64) {
+    float p[CFS_LANES];
+#pragma unroll
+    for (int l = 0; l < CFS_LANES; l++) p[l] = red[l * 64 + tid];
+    float t = 0.f;
+#pragma unroll
+    for (int l = 0; l < CFS_LANES; l++) t += p[l];
+    const float iv = 1.f / sqrtf(t / (float)rows + q.eps);       // biased variance (tf.nn.moments)
+    iv_s[tid] = iv;
+    stats[((long)grp * 2 + 0) * q.C + cb * 64 + tid] = mean_s[tid];
+    stats[((long)grp * 2 + 1) * q.C + cb * 64 + tid] = iv;
+  }
+  if (!y) return;                       // statistics only (gank_cbn_stats: the same numbers as the forward pass's, bit for bit)
+  __syncthreads();
+  float iv[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) iv[e] = iv_s[g * 8 + e];
+  // a thread's rows are consecutive: the label's gamma / beta rows are reloaded only when the sample changes (once per thread at HW >= 16)
+  int n_cur = -1;
+  f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, b0 = g0, b1 = g0;
+#pragma unroll
+  for (int u = 0; u < CFS_ROWS; u++) {
+    const int r = rl * CFS_ROWS + u;
+    if (r < rows) {
+      const int n = (int)((r0 + r) / q.HW);
+      if (n != n_cur) {
+        n_cur = n;
+        int lb = labels[n];
+        lb = lb < 0 ? 0 : (lb >= q.n_labels ? q.n_labels - 1 : lb);
+        g0 = *reinterpret_cast<const f32x4*>(gamma + (long)lb * q.C + c0); g1 = *reinterpret_cast<const f32x4*>(gamma + (long)lb * q.C + c0 + 4);
+        b0 = *reinterpret_cast<const f32x4*>(beta + (long)lb * q.C + c0); b1 = *reinterpret_cast<const f32x4*>(beta + (long)lb * q.C + c0 + 4);
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const float ga = e < 4 ? g0[e] : g1[e - 4], be = e < 4 ? b0[e] : b1[e - 4];
+        float t = (v[u][e] - mu[e]) * iv[e] * ga + be;
+        if (q.relu) t = fmaxf(t, 0.f);
+        o[e] = f2bf(t);
+      }
+      *reinterpret_cast<bf16x8*>(y + (r0 + r) * q.C + c0) = o;
+    }
+  }
+}
+static bool cbn_fwd_small_ok(const CbnGeom& q) {
+  static const int env = gank_tune("GANK_CBN_SMALL", 1);   // experiment knob: 0 keeps the three-launch form for small towers
+  return env && q.rows_per_group <= CFS_LANES * CFS_ROWS && q.C % 64 == 0;
+}
+
 extern "C" int gank_cbn_fwd_eps(const void* x, const int32_t* labels, const float* gamma, const float* beta, void* y,
                             float* stats, float* ws, int N, int HW, int C, int groups, int n_labels, int relu, float eps, void* stream) {
   GANK_REQUIRE(x && labels && gamma && beta && y && stats && ws, "cbn_fwd: null pointer");
@@ -232,6 +343,11 @@ extern "C" int gank_cbn_fwd_eps(const void* x, const int32_t* labels, const floa
   GANK_REQUIRE(eps > 0.f, "cbn_fwd: eps must be positive");
   q.eps = eps;
   hipStream_t s = (hipStream_t)stream;
+  if (cbn_fwd_small_ok(q)) {
+    hipLaunchKernelGGL(cbn_fwd_small_kernel, dim3(groups * (C / 64)), dim3(512), 0, s, (const bf16*)x, labels, gamma, beta, (bf16*)y, stats, q);
+    GANK_LAUNCH_OK("cbn_fwd");
+    return 0;
+  }
   const dim3 grid(groups * q.parts);
   hipLaunchKernelGGL(cbn_stats_kernel, grid, dim3(CBN_NT), 0, s, (const bf16*)x, ws, q);
   hipLaunchKernelGGL(cbn_finalize_kernel, dim3(cdiv(C, 16), groups), dim3(256), 0, s, ws, stats, q);
@@ -604,6 +720,12 @@ extern "C" int gank_cbn_stats(const void* x, float* stats, float* ws, int N, int
   if (cbn_geom(q, N, HW, C, groups, 1, 0)) return 1;
   q.eps = eps;
   hipStream_t s = (hipStream_t)stream;
+  if (cbn_fwd_small_ok(q)) {            // small towers: the forward pass's one-launch kernel without its apply (the same statistics, bit for bit)
+    hipLaunchKernelGGL(cbn_fwd_small_kernel, dim3(groups * (C / 64)), dim3(512), 0, s, (const bf16*)x, (const int*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (bf16*)nullptr, stats, q);
+    GANK_LAUNCH_OK("cbn_stats");
+    return 0;
+  }
   hipLaunchKernelGGL(cbn_stats_kernel, dim3(groups * q.parts), dim3(CBN_NT), 0, s, (const bf16*)x, ws, q);
   hipLaunchKernelGGL(cbn_finalize_kernel, dim3(cdiv(C, 16), groups), dim3(256), 0, s, ws, stats, q);
   GANK_LAUNCH_OK("cbn_stats");
