@@ -72,10 +72,11 @@ def generator_arena_floats(groups):
     return 6 * groups * 16 * 2 * DIM_G * 2 + 512 if (NORMALIZATION_G and Fn.CONV_EPILOGUE_STATS) else 0
 
 
-def Generator(n_samples_, labels, noise=None, reuse=False, groups=1, rng_state=None, arena_buf=None):
+def Generator(n_samples_, labels, noise=None, reuse=False, groups=1, rng_state=None, arena_buf=None, out=None):
     """(:237-263)  noise [n,128] bf16 (drawn from the device RNG when None) -> [n, 3072] bf16, HWC order,
     tanh range.  `groups` towers of n/groups samples have independent CBN statistics.  arena_buf: the pass's statistics arena,
-    cleared by the caller (kernels.generator_feed)."""
+    cleared by the caller (kernels.generator_feed).  out: a bf16 buffer of n * 3072 elements a no-grad pass writes its result into
+    (the fused G.OutputNorm + G.Output launch only; other paths ignore it -- the caller compares data pointers)."""
     store = get_default_store()
     # the statistics sums of the six convs that feed a conditional batch norm: one fill for the whole pass
     arena = K.stats_arena(generator_arena_floats(groups), labels.device, arena_buf) if (generator_arena_floats(groups) and labels.is_cuda) \
@@ -102,7 +103,7 @@ def Generator(n_samples_, labels, noise=None, reuse=False, groups=1, rng_state=N
             stats = K.cbn_stats(output, groups, getattr(output, '_cbn_stats', None))
             filters, biases = _conv2d.conv2d_variables(DIM_G * 2, 3, 3, 1, 'G.Output', he_init=False)
             wf, _ = Fn._prepared(filters, 3, DIM_G * 2, 3, True, False)
-            output = K.cbn_relu_conv3x3_fprop(output, labels, gamma.detach(), beta.detach(), stats, wf, biases.detach(), 3, K.OUT_TANH)
+            output = K.cbn_relu_conv3x3_fprop(output, labels, gamma.detach(), beta.detach(), stats, wf, biases.detach(), 3, K.OUT_TANH, out=out)
             return output.reshape(-1, OUTPUT_DIM)
         output = Normalize('G.OutputNorm', output, labels, groups=groups, relu=True)    # + nonlinearity (:257-258)
         output = _conv2d.Conv2D(output, DIM_G * 2, 3, 3, 1, 'G.Output', he_init=False, out_tanh=True)  # + tanh (:260-261)
@@ -583,8 +584,10 @@ class SNGANTrainer:
         z = abuf = None
         if GEN_FEED_ONE_LAUNCH and self.labels_all.is_cuda:
             _, z, abuf = K.generator_feed(self.rng_state, (n, 128), generator_arena_floats(N_CRITIC * N_TOWERS))
-        fake = Generator(n, self.labels_all.reshape(-1), noise=z, groups=N_CRITIC * N_TOWERS, rng_state=self.rng_state, arena_buf=abuf)
-        K.copy_(self.fake_all, fake)
+        fake = Generator(n, self.labels_all.reshape(-1), noise=z, groups=N_CRITIC * N_TOWERS, rng_state=self.rng_state, arena_buf=abuf,
+                         out=self.fake_all if (self.fake_all.is_contiguous() and self.fake_all.numel() == n * OUTPUT_DIM) else None)
+        if fake.data_ptr() != self.fake_all.data_ptr():      # (the fused output launch wrote the ring itself: no copy)
+            K.copy_(self.fake_all, fake)
 
     def _g_forward_backward(self, z=None, fake_labels=None):
         """gen_cost and its gradients (:464-498): N_TOWERS towers of GEN_BS_MULTIPLE*B/N_TOWERS samples,

@@ -1112,11 +1112,16 @@ def cbn_stats(x, groups=1, cs=None, eps=1e-5):
     return stats
 
 
-def cbn_relu_conv3x3_fprop(x, labels, gamma, beta, stats, wf, bias, cout, flags=0):
-    """conv3x3_SAME(relu(cond_batchnorm(x))) + bias [tanh], the normalisation fused into the conv's operand staging (no grad)"""
+def cbn_relu_conv3x3_fprop(x, labels, gamma, beta, stats, wf, bias, cout, flags=0, out=None):
+    """conv3x3_SAME(relu(cond_batchnorm(x))) + bias [tanh], the normalisation fused into the conv's operand staging (no grad).
+    out: a contiguous bf16 buffer of n*h*w*cout elements to write into (any shape) -> returned as [n,h,w,cout]"""
     n, h, w, cin = x.shape
     groups = stats.shape[0]
-    y = torch.empty((n, h, w, cout), dtype=BF16, device=x.device)
+    if out is not None:
+        assert out.dtype == BF16 and out.is_contiguous() and out.numel() == n * h * w * cout and out.device == x.device
+        y = out.view(n, h, w, cout)
+    else:
+        y = torch.empty((n, h, w, cout), dtype=BF16, device=x.device)
     _lib.check(lib().gank_cbn_relu_conv3x3_fprop(_p(x, BF16, "x"), _p(labels, I32, "labels"), _p(gamma, F32, "gamma"), _p(beta, F32, "beta"),
                                                  _p(stats, F32, "stats"), _p(wf, BF16, "wf"), _p(bias, F32, "bias"), _p(y), n, h, w, cin, cout,
                                                  groups, gamma.shape[0], flags, _stream()), "cbn_relu_conv3x3_fprop")
