@@ -182,6 +182,7 @@ PROTOTYPES = {
     "gank_linear_bwd": [P, P, P, P, P, P, I, I, I, P],
     "gank_copy_bytes": [P, P, L, P],
     "gank_copy_bytes_gather": [P, P, I, L, P],
+    "gank_copy_bytes_gather2": [P, P, I, L, P, P, I, L, P],
     "gank_cast_f32_bf16": [P, P, L, P],
     "gank_cast_bf16_f32": [P, P, L, P],
     "gank_relu_meanpool_hw_fwd": [P, P, I, I, I, P],

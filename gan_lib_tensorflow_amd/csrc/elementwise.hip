@@ -602,6 +602,48 @@ extern "C" int gank_copy_bytes_gather(void* dst, const void* const* srcs, int co
   return 0;
 }
 
+// two gathers in one launch (the iteration's image batches and their label vectors into the two feed rings): grid.y = count_a + count_b,
+// the second group's rows behind the first's
+struct CopyGather2Args { const unsigned char* src[2 * COPY_GATHER_MAX]; };
+__global__ void copy_gather2_kernel(CopyGather2Args a, unsigned char* __restrict__ dst_a, long n16_a, long nbytes_a, int count_a,
+                                    unsigned char* __restrict__ dst_b, long n16_b, long nbytes_b) {
+  const unsigned char* src = a.src[0];
+#pragma unroll
+  for (int i = 1; i < 2 * COPY_GATHER_MAX; i++) src = (int)blockIdx.y == i ? a.src[i] : src;
+  const bool second = (int)blockIdx.y >= count_a;
+  const int row = second ? blockIdx.y - count_a : blockIdx.y;
+  const long nbytes = second ? nbytes_b : nbytes_a, n16 = second ? n16_b : n16_a;
+  unsigned char* d = (second ? dst_b : dst_a) + (long)row * nbytes;
+  const long t = blockIdx.x * (long)blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+  for (long i = t; i < n16; i += stride) reinterpret_cast<u32x4*>(d)[i] = reinterpret_cast<const u32x4*>(src)[i];
+  for (long i = n16 * 16 + t; i < nbytes; i += stride) d[i] = src[i];
+}
+extern "C" int gank_copy_bytes_gather2(void* dst_a, const void* const* srcs_a, int count_a, long nbytes_a, void* dst_b, const void* const* srcs_b, int count_b,
+                                       long nbytes_b, void* stream) {
+  GANK_REQUIRE(dst_a && srcs_a && dst_b && srcs_b && count_a > 0 && count_b > 0 && count_a <= COPY_GATHER_MAX && count_b <= COPY_GATHER_MAX && nbytes_a > 0 &&
+               nbytes_b > 0, "copy_bytes_gather2: bad arguments (1..%d sources per group)", COPY_GATHER_MAX);
+  CopyGather2Args a{};
+  bool al_a = (((uintptr_t)dst_a | (uintptr_t)nbytes_a) & 15) == 0, al_b = (((uintptr_t)dst_b | (uintptr_t)nbytes_b) & 15) == 0;
+  for (int i = 0; i < count_a; i++) {
+    GANK_REQUIRE(srcs_a[i], "copy_bytes_gather2: source %d of the first group is null", i);
+    a.src[i] = (const unsigned char*)srcs_a[i];
+    al_a = al_a && (((uintptr_t)srcs_a[i]) & 15) == 0;
+  }
+  for (int i = 0; i < count_b; i++) {
+    GANK_REQUIRE(srcs_b[i], "copy_bytes_gather2: source %d of the second group is null", i);
+    a.src[count_a + i] = (const unsigned char*)srcs_b[i];
+    al_b = al_b && (((uintptr_t)srcs_b[i]) & 15) == 0;
+  }
+  const long n16_a = al_a ? nbytes_a / 16 : 0, n16_b = al_b ? nbytes_b / 16 : 0;
+  const long work_a = al_a ? n16_a : nbytes_a, work_b = al_b ? n16_b : nbytes_b;
+  long blocks = ((work_a > work_b ? work_a : work_b) + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(copy_gather2_kernel, dim3((unsigned)blocks, (unsigned)(count_a + count_b)), dim3(256), 0, (hipStream_t)stream, a, (unsigned char*)dst_a, n16_a,
+                     nbytes_a, count_a, (unsigned char*)dst_b, n16_b, nbytes_b);
+  GANK_LAUNCH_OK("copy_bytes_gather2");
+  return 0;
+}
+
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, long n) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = f2bf(x[i]);
 }

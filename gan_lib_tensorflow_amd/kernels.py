@@ -1250,6 +1250,17 @@ def copy_gather_(dst, srcs):
     return dst
 
 
+def copy_gather2_(dst_a, srcs_a, dst_b, srcs_b):
+    """copy_gather_(dst_a, srcs_a) and copy_gather_(dst_b, srcs_b) in ONE launch (gank_copy_bytes_gather2)"""
+    for dst, srcs in ((dst_a, srcs_a), (dst_b, srcs_b)):
+        assert dst.is_contiguous() and dst.shape[0] == len(srcs) and all(s.dtype == dst.dtype and s.is_contiguous() and s.numel() == dst[0].numel() for s in srcs), \
+            (tuple(dst.shape), [tuple(s.shape) for s in srcs])
+    pa = (C.c_void_p * len(srcs_a))(*[_p(s, None, "src").value for s in srcs_a])
+    pb = (C.c_void_p * len(srcs_b))(*[_p(s, None, "src").value for s in srcs_b])
+    _lib.check(lib().gank_copy_bytes_gather2(_p(dst_a, None, "dst"), pa, len(srcs_a), dst_a[0].numel() * dst_a.element_size(),
+                                             _p(dst_b, None, "dst"), pb, len(srcs_b), dst_b[0].numel() * dst_b.element_size(), _stream()), "copy_bytes_gather2")
+
+
 def clone(src):
     return copy_(torch.empty_like(src), src)
 

@@ -558,6 +558,9 @@ int gank_copy_bytes(void* dst, const void* src, long nbytes, void* stream);
  * iteration (gan_cifar_resnet.py:616-620: five session.run feeds) into the feed ring in ONE launch.  `srcs` is a HOST array
  * of device pointers, copied into the kernel arguments */
 int gank_copy_bytes_gather(void* dst, const void* const* srcs, int count, long nbytes_each, void* stream);
+/* two gathers of that kind (different row sizes) in one launch: the iteration's image batches and label vectors into the two feed rings */
+int gank_copy_bytes_gather2(void* dst_a, const void* const* srcs_a, int count_a, long nbytes_a, void* dst_b, const void* const* srcs_b, int count_b,
+                            long nbytes_b, void* stream);
 int gank_cast_f32_bf16(const float* x, void* y, long n, void* stream);
 int gank_cast_bf16_f32(const void* x, float* y, long n, void* stream);
 

@@ -1462,6 +1462,14 @@ def test_copy_gather(K):
         K.copy_gather_(dst, srcs)
         torch.cuda.synchronize()
         assert all(torch.equal(dst[i], srcs[i]) for i in range(5))
+    # two gathers with different row sizes in one launch (gank_copy_bytes_gather2: the image batches and the label vectors of an iteration)
+    for sa, sb in (((64, 3072), (64,)), ((7, 3), (5,))):
+        a_src = [(torch.arange(int(np.prod(sa)), device="cuda") * (i + 3) % 251).to(torch.uint8).reshape(sa) for i in range(5)]
+        b_src = [(torch.arange(int(np.prod(sb)), device="cuda") * (i + 7) % 11).to(torch.int32).reshape(sb) for i in range(3)]
+        da, db = torch.zeros((5,) + sa, dtype=torch.uint8, device="cuda"), torch.full((3,) + sb, -1, dtype=torch.int32, device="cuda")
+        K.copy_gather2_(da, a_src, db, b_src)
+        torch.cuda.synchronize()
+        assert all(torch.equal(da[i], a_src[i]) for i in range(5)) and all(torch.equal(db[i], b_src[i]) for i in range(3))
 
 
 def test_fork_pool_equals_fork_then_meanpool(K):
